@@ -1,0 +1,280 @@
+/*
+ * okvis_amd_ba.h — C-ABI of the MI355X-native sliding-window bundle-adjustment backend.
+ *
+ * This is the drop-in boundary for ONE path of ethz-asl/okvis: the optimisation loop behind
+ * okvis::Estimator::optimize (reference okvis_ceres/src/Estimator.cpp:843-906 -> Map::solve,
+ * okvis_ceres/include/okvis/ceres/Map.hpp:371-373 -> ::ceres::Solve).  The reference has no FFI; the
+ * boundary a maintainer binds is the concrete C++ class okvis::Estimator
+ * (okvis_ceres/include/okvis/Estimator.hpp:77-581).  The replacement Estimator (okvis_amd/csrc/host/)
+ * keeps that class's methods and calls ONLY the functions declared here.  Plain pointers and sizes,
+ * no C++/torch types, int status codes, no exceptions across the boundary.
+ *
+ * All floating point data are IEEE double, like the reference.  Indices are int32, times are int64
+ * nanoseconds (okvis::Time is {u32 sec, u32 nsec}, okvis_time/include/okvis/Time.hpp:125-205).
+ *
+ * Block conventions (reference file:line):
+ *   pose block   double[7] = r_x r_y r_z q_x q_y q_z q_w   (PoseParameterBlock.cpp:68-79); minimal dim 6,
+ *                (+) = PoseLocalParameterization::plus (PoseLocalParameterization.cpp:60-87).  Both the
+ *                body poses T_WS and the camera extrinsics T_SC are pose blocks and live in ONE array.
+ *   speed/bias   double[9] = v_W b_g b_a                   (SpeedAndBiasParameterBlock.hpp:108-153), Euclidean.
+ *   landmark     double[4] homogeneous x y z w in W        (HomogeneousPointLocalParameterization.cpp:59-71);
+ *                minimal dim 3, w is never updated.
+ */
+#ifndef OKVIS_AMD_BA_H_
+#define OKVIS_AMD_BA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OKVIS_BA_ABI_VERSION 1
+
+/* status codes (0 ok; >0 = hipError_t passthrough + 1000; <0 = argument / state errors) */
+#define OKVIS_BA_OK 0
+#define OKVIS_BA_ERR_ARG (-1)          /* null pointer / negative size / index out of range            */
+#define OKVIS_BA_ERR_STATE (-2)        /* call order violated (e.g. optimize before upload)             */
+#define OKVIS_BA_ERR_UNSUPPORTED (-3)  /* structure exceeds a documented limit (see okvis_ba_limits)    */
+#define OKVIS_BA_ERR_NO_DEVICE (-4)    /* no HIP device: the product path has NO CPU fallback           */
+#define OKVIS_BA_ERR_NUMERIC (-5)      /* reduced system not positive definite after max damping        */
+#define OKVIS_BA_HIP_ERROR_BASE 1000
+
+/* camera distortion models (okvis_cv/include/okvis/cameras/ XxxDistortion.hpp) */
+#define OKVIS_BA_DIST_NONE 0
+#define OKVIS_BA_DIST_RADTAN 1       /* RadialTangentialDistortion  k1 k2 p1 p2            */
+#define OKVIS_BA_DIST_EQUIDISTANT 2  /* EquidistantDistortion       k1 k2 k3 k4            */
+#define OKVIS_BA_DIST_RADTAN8 3      /* RadialTangentialDistortion8 k1 k2 p1 p2 k3 k4 k5 k6 */
+
+/* block types inside the marginalisation prior */
+#define OKVIS_BA_BLOCK_POSE 0
+#define OKVIS_BA_BLOCK_SPEEDBIAS 1
+
+/* IMU noise parameters that reach the hot path (okvis_common/include/okvis/Parameters.hpp ImuParameters;
+ * used at ImuError.cpp:153-173,228-249,564) */
+typedef struct okvis_ba_imu_params {
+  double sigma_g_c;  /* gyro noise density                */
+  double sigma_a_c;  /* accelerometer noise density       */
+  double sigma_gw_c; /* gyro drift noise density          */
+  double sigma_aw_c; /* accelerometer drift noise density */
+  double g;          /* gravity magnitude                 */
+  double g_max;      /* gyro saturation                   */
+  double a_max;      /* accelerometer saturation          */
+} okvis_ba_imu_params;
+
+/*
+ * One sliding window as flat struct-of-arrays.  This replaces okvis::ceres::Map's hash maps of
+ * shared_ptr parameter blocks and residual blocks (Map.hpp:348-402, Map.cpp:292-565) and
+ * Estimator::statesMap_/landmarksMap_ (Estimator.hpp:555-563).  All pointers are HOST pointers owned by
+ * the caller; okvis_ba_upload copies them.
+ */
+typedef struct okvis_ba_window {
+  /* ---- parameter blocks ---- */
+  int32_t n_pose;             /* pose-type blocks (T_WS per frame + T_SC extrinsics)                    */
+  const double* pose;         /* [n_pose][7]                                                           */
+  const uint8_t* pose_fixed;  /* [n_pose] 1 = Map::setParameterBlockConstant (Map.cpp:568-576)         */
+  int32_t n_sb;
+  const double* sb;           /* [n_sb][9]                                                             */
+  const uint8_t* sb_fixed;    /* [n_sb]                                                                */
+  int32_t n_lm;
+  const double* lm;           /* [n_lm][4]                                                             */
+
+  /* ---- cameras (PinholeCamera<D>, okvis_cv/.../implementation/PinholeCamera.hpp:148-226) ---- */
+  int32_t n_cam;
+  const double* cam_intr;     /* [n_cam][12] = fu fv cu cv d0..d7                                      */
+  const int32_t* cam_model;   /* [n_cam] OKVIS_BA_DIST_*                                               */
+
+  /* ---- reprojection observations (ReprojectionError<G>, implementation/Estimator.hpp:43-90) ----
+   * MUST be sorted by (lm, pose, cam); every landmark referenced by <= okvis_ba_limits.max_obs_per_lm. */
+  int32_t n_obs;
+  const int32_t* obs_lm;      /* [n_obs] landmark index                                                */
+  const int32_t* obs_pose;    /* [n_obs] pose block index of T_WS                                      */
+  const int32_t* obs_ext;     /* [n_obs] pose block index of T_SC                                      */
+  const int32_t* obs_cam;     /* [n_obs] camera (intrinsics) index                                     */
+  const double* obs_uv;       /* [n_obs][2] keypoint measurement                                       */
+  const double* obs_sqrtw;    /* [n_obs] sqrt-information scalar = 8/keypoint.size
+                                 (information = 64/size^2 * I2, implementation/Estimator.hpp:62-65)     */
+  double cauchy_b;            /* CauchyLoss(b) on reprojection residuals (Estimator.cpp:60: 1.0);
+                                 <= 0 disables the loss                                                 */
+
+  /* ---- IMU factors (ImuError over pose0,sb0,pose1,sb1; Estimator.cpp:288-307) ---- */
+  int32_t n_imu;
+  const int32_t* imu_pose0;   /* [n_imu] */
+  const int32_t* imu_sb0;
+  const int32_t* imu_pose1;
+  const int32_t* imu_sb1;
+  const int64_t* imu_t0;      /* [n_imu] ns */
+  const int64_t* imu_t1;
+  const int32_t* imu_s_begin; /* [n_imu] first raw sample of this factor's measurement deque           */
+  const int32_t* imu_s_count; /* [n_imu] number of raw samples (the deque copied at ImuError.hpp:151)   */
+  int32_t n_imu_samples;
+  const int64_t* imu_s_t;     /* [n_imu_samples] ns */
+  const double* imu_s_gyr;    /* [n_imu_samples][3] */
+  const double* imu_s_acc;    /* [n_imu_samples][3] */
+  okvis_ba_imu_params imu_params;
+
+  /* ---- absolute pose priors (PoseError, PoseError.cpp:86-138; Estimator.cpp:238-262) ---- */
+  int32_t n_pprior;
+  const int32_t* pprior_pose;      /* [n_pprior] pose block index                                      */
+  const double* pprior_meas;       /* [n_pprior][7]                                                    */
+  const double* pprior_sqrtinfo;   /* [n_pprior][36] row-major upper-triangular L^T (PoseError.cpp:70-76)*/
+
+  /* ---- speed/bias priors (SpeedAndBiasError.cpp:89-118; Estimator.cpp:269-284) ---- */
+  int32_t n_sbprior;
+  const int32_t* sbprior_sb;
+  const double* sbprior_meas;      /* [n_sbprior][9]  */
+  const double* sbprior_sqrtinfo;  /* [n_sbprior][81] */
+
+  /* ---- relative pose factors (RelativePoseError.cpp:84-163; Estimator.cpp:310-336) ---- */
+  int32_t n_relpose;
+  const int32_t* rel_pose0;
+  const int32_t* rel_pose1;
+  const double* rel_sqrtinfo;      /* [n_relpose][36] */
+
+  /* ---- marginalisation prior (MarginalizationError::EvaluateWithMinimalJacobians,
+   *      MarginalizationError.cpp:893-946): e = e0 + J * DeltaChi ---- */
+  int32_t marg_dim;                /* D_m = rows = cols of J (0 = no prior)                            */
+  int32_t marg_nblocks;
+  const int32_t* marg_block_type;  /* [marg_nblocks] OKVIS_BA_BLOCK_*                                  */
+  const int32_t* marg_block_idx;   /* [marg_nblocks] index into pose[] / sb[]                          */
+  const int32_t* marg_block_off;   /* [marg_nblocks] column offset (orderingIdx) of the block in J     */
+  const double* marg_J;            /* [marg_dim][marg_dim] row-major                                   */
+  const double* marg_e0;           /* [marg_dim]                                                       */
+  const double* marg_lin;          /* [marg_nblocks][9] linearisation points (7 or 9 used)             */
+} okvis_ba_window;
+
+/*
+ * Solver policy.  The reference configures Ceres 1.9 TRUST_REGION/DOGLEG/SPARSE_SCHUR with defaults
+ * (Estimator.cpp:854-873); Ceres is not in the reference tree.  This backend runs a Schur-complement
+ * Gauss-Newton with a Levenberg-Marquardt trust-region safeguard (Ceres' LevenbergMarquardtStrategy
+ * semantics restated from its documentation; see DESIGN.md "solver policy").
+ */
+typedef struct okvis_ba_options {
+  double initial_radius;        /* 1e4   */
+  double max_radius;            /* 1e16  */
+  double min_radius;            /* 1e-32 */
+  double min_lm_diagonal;       /* 1e-6  */
+  double max_lm_diagonal;       /* 1e32  */
+  double min_relative_decrease; /* 1e-3  */
+  double function_tolerance;    /* 1e-6  (0 disables: every launched iteration does full work)          */
+  double gradient_tolerance;    /* 1e-10 */
+  double parameter_tolerance;   /* 1e-8  */
+  int32_t use_graph;            /* 1 = replay the captured hipGraph of the iteration sequence           */
+  int32_t schur_lm_per_block;   /* landmarks per Schur workgroup (0 = auto)                             */
+} okvis_ba_options;
+
+/* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */
+typedef struct okvis_ba_summary {
+  double initial_cost;
+  double final_cost;
+  int32_t iterations;            /* iterations executed (successful + unsuccessful), excluding iteration 0 */
+  int32_t successful_steps;
+  int32_t termination;           /* 0 = max iterations, 1 = function tol, 2 = gradient tol, 3 = parameter tol,
+                                    4 = radius below min, 5 = numeric failure */
+  int32_t reserved;
+  double final_radius;
+  double gradient_max_norm;
+} okvis_ba_summary;
+
+typedef struct okvis_ba_limits {
+  int32_t max_obs_per_lm;   /* observations of one landmark                          */
+  int32_t max_reduced_dim;  /* 6*free poses + 9*free speed/bias of ONE window        */
+  int32_t max_marg_dim;
+  int32_t max_imu_samples_per_factor;
+} okvis_ba_limits;
+
+typedef struct okvis_ba_solver okvis_ba_solver; /* opaque: a batch of independent windows on one GPU */
+
+/* identify array for okvis_ba_download() — intermediate results used by the parity tests */
+enum okvis_ba_array {
+  OKVIS_BA_ARR_POSE = 0,        /* [n_pose][7]  accepted state                                          */
+  OKVIS_BA_ARR_SB = 1,          /* [n_sb][9]                                                            */
+  OKVIS_BA_ARR_LM = 2,          /* [n_lm][4]                                                            */
+  OKVIS_BA_ARR_OBS_RESIDUAL = 3,/* [n_obs][2]   un-robustified weighted residual at the accepted state  */
+  OKVIS_BA_ARR_LM_V = 4,        /* [n_lm][6]    upper-tri V = sum J_l^T J_l (robustified)               */
+  OKVIS_BA_ARR_LM_B = 5,        /* [n_lm][3]    sum J_l^T r                                             */
+  OKVIS_BA_ARR_LM_HQ = 6,       /* [n_lm][6]    un-robustified J_l^T J_l (Map::getLhs, Map.cpp:101-156) */
+  OKVIS_BA_ARR_PAIR_W = 7,      /* [n_pair][18] W_(block,lm) = sum J_block^T J_l, row-major 6x3          */
+  OKVIS_BA_ARR_REDUCED_S = 8,   /* [D][D]       damped reduced-camera matrix actually factorised        */
+  OKVIS_BA_ARR_REDUCED_RHS = 9, /* [D]          reduced right-hand side (= -gradient after Schur)        */
+  OKVIS_BA_ARR_STEP = 10,       /* [D]          last reduced step delta                                  */
+  OKVIS_BA_ARR_LM_QUALITY = 11, /* [n_lm]       sqrt(lambda_min)/sqrt(lambda_max) (Estimator.cpp:880-896)*/
+  OKVIS_BA_ARR_GRADIENT = 12,   /* [D]          un-reduced gradient of the pose/speed-bias part          */
+  OKVIS_BA_ARR_IMU_RESIDUAL = 13,/* [n_imu][15] weighted IMU residual at the accepted state             */
+  OKVIS_BA_ARR_HPP = 14         /* [D][D]       un-reduced, un-damped pose/speed-bias Hessian block U   */
+};
+
+/* ---- lifecycle ----------------------------------------------------------------------------------- */
+int okvis_ba_abi_version(void);
+void okvis_ba_get_limits(okvis_ba_limits* out);
+void okvis_ba_default_options(okvis_ba_options* out);
+const char* okvis_ba_error_string(int status);
+
+/* replaces `new okvis::ceres::Map` + ::ceres::Problem construction (Map.cpp:54-62).  device = HIP ordinal.
+ * Fails with OKVIS_BA_ERR_NO_DEVICE when no GPU is visible: there is no CPU path. */
+int okvis_ba_create(okvis_ba_solver** out, int device);
+int okvis_ba_destroy(okvis_ba_solver* s);
+
+/* replaces the sequence of Map::addParameterBlock / addResidualBlock / setParameterBlockConstant calls
+ * (Map.cpp:292-434,568-576) that Estimator::addStates/addLandmark/addObservation issue: uploads the whole
+ * structure + values of n independent windows and builds the device index arrays. */
+int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows);
+/* overwrite only block VALUES of window w (Estimator::set_T_WS/setSpeedAndBias/setLandmark,
+ * Estimator.cpp:1205-1302); any pointer may be NULL to keep the device copy. */
+int okvis_ba_set_state(okvis_ba_solver* s, int w, const double* pose, const double* sb, const double* lm);
+int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt);
+
+/* ---- the hot path ---------------------------------------------------------------------------------- */
+/* replaces Estimator::optimize(numIter, numThreads, verbose) -> Map::solve() -> ::ceres::Solve
+ * (Estimator.cpp:843-877, Map.hpp:371-373) for every uploaded window at once.  summaries may be NULL or
+ * [n_windows].  Also refreshes landmark quality (Estimator.cpp:880-900). */
+int okvis_ba_optimize(okvis_ba_solver* s, int num_iter, okvis_ba_summary* summaries);
+
+/* time-limited variant (CeresIterationCallback.hpp:77-86 + Estimator::setOptimizationTimeLimit,
+ * Estimator.cpp:909-929): always runs min_iter iterations, then stops as soon as elapsed wall time
+ * exceeds time_limit_s (time_limit_s < 0: no limit). */
+int okvis_ba_optimize_timed(okvis_ba_solver* s, int max_iter, int min_iter, double time_limit_s,
+                            okvis_ba_summary* summaries);
+
+/* step-wise entry points (one kernel sequence each; what one trust-region iteration is made of).
+ *   begin:      evaluate + linearise all factors at the uploaded state, accept it (iteration 0)
+ *   iterate(n): n x [Schur reduce -> reduced solve -> back-substitute + (+)update + re-linearise]
+ *   finish:     download nothing; finalise summaries + landmark quality
+ * okvis_ba_optimize == begin + iterate(num_iter) + finish. */
+int okvis_ba_begin(okvis_ba_solver* s);
+int okvis_ba_iterate(okvis_ba_solver* s, int n);
+int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries);
+
+/* cost-only evaluation at the accepted state: 0.5*sum rho(|r|^2) (Ceres Evaluate(params,r,NULL) path,
+ * implementation/ReprojectionError.hpp:127-132, ImuError.cpp:608). costs = [n_windows]. */
+int okvis_ba_evaluate_cost(okvis_ba_solver* s, double* costs);
+
+/* ---- results -------------------------------------------------------------------------------------- */
+/* Estimator::get_T_WS / getSpeedAndBias / getLandmark (Estimator.cpp:933-1200): copy the accepted state
+ * of window w back; any pointer may be NULL. */
+int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, double* lm);
+/* size (in doubles) and contents of an intermediate array of window w (parity tests) */
+int okvis_ba_array_size(okvis_ba_solver* s, int w, int which, int64_t* n_doubles);
+int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t n_doubles);
+/* structure queries: reduced dimension and (block,landmark) pair list as built by upload */
+int okvis_ba_reduced_dim(okvis_ba_solver* s, int w, int32_t* dim);
+int okvis_ba_pair_count(okvis_ba_solver* s, int w, int32_t* n_pair);
+int okvis_ba_pairs(okvis_ba_solver* s, int w, int32_t* pair_lm, int32_t* pair_block);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------------------------------- */
+/* HIP-event timing of the NEXT okvis_ba_iterate call on the solver's own stream: after the call,
+ * total_ms = elapsed between events bracketing the n iterations. */
+int okvis_ba_last_iterate_ms(okvis_ba_solver* s, float* total_ms);
+/* per-kernel HIP-event timing (eager launches, events around every kernel): fills ms[3] with the summed
+ * time of {linearise, schur, solve} kernels over n iterations. Slower than graph replay; used only to
+ * attribute time for the roofline object. */
+int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms3);
+/* algorithmic bytes one iteration moves for the uploaded batch (formula in DESIGN.md §4) */
+int okvis_ba_algorithmic_bytes(okvis_ba_solver* s, int64_t* linearize_bytes, int64_t* schur_bytes,
+                               int64_t* solve_bytes);
+int okvis_ba_synchronize(okvis_ba_solver* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OKVIS_AMD_BA_H_ */

@@ -1,0 +1,253 @@
+"""Flat struct-of-arrays description of one sliding window (host side).
+
+Mirror of ``okvis_ba_window`` in ``include/okvis_amd_ba.h``.  It replaces the pointer graph the reference
+builds in ``okvis::ceres::Map`` (reference okvis_ceres/include/okvis/ceres/Map.hpp:348-402,
+okvis_ceres/src/Map.cpp:292-565) and ``Estimator::statesMap_/landmarksMap_``
+(okvis_ceres/include/okvis/Estimator.hpp:555-563) by index arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT, DIST_RADTAN8 = 0, 1, 2, 3
+BLOCK_POSE, BLOCK_SPEEDBIAS = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_bp = C.POINTER(C.c_uint8)
+
+
+class ImuParamsC(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("sigma_g_c", "sigma_a_c", "sigma_gw_c", "sigma_aw_c", "g", "g_max", "a_max")]
+
+
+class WindowC(C.Structure):
+    """ctypes image of ``okvis_ba_window`` (field order must match the header)."""
+    _fields_ = [
+        ("n_pose", C.c_int32), ("pose", _dp), ("pose_fixed", _bp),
+        ("n_sb", C.c_int32), ("sb", _dp), ("sb_fixed", _bp),
+        ("n_lm", C.c_int32), ("lm", _dp),
+        ("n_cam", C.c_int32), ("cam_intr", _dp), ("cam_model", _ip),
+        ("n_obs", C.c_int32), ("obs_lm", _ip), ("obs_pose", _ip), ("obs_ext", _ip), ("obs_cam", _ip),
+        ("obs_uv", _dp), ("obs_sqrtw", _dp), ("cauchy_b", C.c_double),
+        ("n_imu", C.c_int32), ("imu_pose0", _ip), ("imu_sb0", _ip), ("imu_pose1", _ip), ("imu_sb1", _ip),
+        ("imu_t0", _lp), ("imu_t1", _lp), ("imu_s_begin", _ip), ("imu_s_count", _ip),
+        ("n_imu_samples", C.c_int32), ("imu_s_t", _lp), ("imu_s_gyr", _dp), ("imu_s_acc", _dp),
+        ("imu_params", ImuParamsC),
+        ("n_pprior", C.c_int32), ("pprior_pose", _ip), ("pprior_meas", _dp), ("pprior_sqrtinfo", _dp),
+        ("n_sbprior", C.c_int32), ("sbprior_sb", _ip), ("sbprior_meas", _dp), ("sbprior_sqrtinfo", _dp),
+        ("n_relpose", C.c_int32), ("rel_pose0", _ip), ("rel_pose1", _ip), ("rel_sqrtinfo", _dp),
+        ("marg_dim", C.c_int32), ("marg_nblocks", C.c_int32), ("marg_block_type", _ip),
+        ("marg_block_idx", _ip), ("marg_block_off", _ip), ("marg_J", _dp), ("marg_e0", _dp),
+        ("marg_lin", _dp),
+    ]
+
+
+class OptionsC(C.Structure):
+    _fields_ = [
+        ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("min_relative_decrease", C.c_double), ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+        ("use_graph", C.c_int32), ("schur_lm_per_block", C.c_int32),
+    ]
+
+
+class SummaryC(C.Structure):
+    _fields_ = [
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int32),
+        ("successful_steps", C.c_int32), ("termination", C.c_int32), ("reserved", C.c_int32),
+        ("final_radius", C.c_double), ("gradient_max_norm", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+class LimitsC(C.Structure):
+    _fields_ = [("max_obs_per_lm", C.c_int32), ("max_reduced_dim", C.c_int32),
+                ("max_marg_dim", C.c_int32), ("max_imu_samples_per_factor", C.c_int32)]
+
+
+def default_options() -> OptionsC:
+    """Ceres 1.9 defaults restated from its documentation (not in the reference tree)."""
+    return OptionsC(1e4, 1e16, 1e-32, 1e-6, 1e32, 1e-3, 1e-6, 1e-10, 1e-8, 1, 0)
+
+
+def _f64(a, shape):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(shape))
+    return a
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
+
+
+def _i64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int64).reshape(-1))
+
+
+@dataclass
+class ImuParams:
+    """Subset of okvis::ImuParameters reaching the hot path (okvis_common Parameters.hpp)."""
+    sigma_g_c: float = 12.0e-4
+    sigma_a_c: float = 8.0e-3
+    sigma_gw_c: float = 4.0e-6
+    sigma_aw_c: float = 4.0e-5
+    g: float = 9.81007
+    g_max: float = 7.8
+    a_max: float = 176.0
+    sigma_bg: float = 0.03   # only used to build the first speed/bias prior (Estimator.cpp:272-277)
+    sigma_ba: float = 0.1
+
+    def as_c(self) -> ImuParamsC:
+        return ImuParamsC(self.sigma_g_c, self.sigma_a_c, self.sigma_gw_c, self.sigma_aw_c, self.g,
+                          self.g_max, self.a_max)
+
+
+@dataclass
+class Window:
+    """One sliding window.  All arrays are numpy, converted to the C layout by :meth:`as_c`."""
+    pose: np.ndarray                      # [n_pose,7]
+    pose_fixed: np.ndarray                # [n_pose] u8
+    sb: np.ndarray                        # [n_sb,9]
+    sb_fixed: np.ndarray
+    lm: np.ndarray                        # [n_lm,4]
+    cam_intr: np.ndarray                  # [n_cam,12]
+    cam_model: np.ndarray                 # [n_cam]
+    obs_lm: np.ndarray
+    obs_pose: np.ndarray
+    obs_ext: np.ndarray
+    obs_cam: np.ndarray
+    obs_uv: np.ndarray                    # [n_obs,2]
+    obs_sqrtw: np.ndarray                 # [n_obs]
+    cauchy_b: float = 1.0
+    imu_pose0: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    imu_sb0: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    imu_pose1: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    imu_sb1: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    imu_t0: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int64))
+    imu_t1: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int64))
+    imu_s_begin: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    imu_s_count: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    imu_s_t: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int64))
+    imu_s_gyr: np.ndarray = field(default_factory=lambda: np.zeros((0, 3)))
+    imu_s_acc: np.ndarray = field(default_factory=lambda: np.zeros((0, 3)))
+    imu_params: ImuParams = field(default_factory=ImuParams)
+    pprior_pose: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    pprior_meas: np.ndarray = field(default_factory=lambda: np.zeros((0, 7)))
+    pprior_sqrtinfo: np.ndarray = field(default_factory=lambda: np.zeros((0, 36)))
+    sbprior_sb: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    sbprior_meas: np.ndarray = field(default_factory=lambda: np.zeros((0, 9)))
+    sbprior_sqrtinfo: np.ndarray = field(default_factory=lambda: np.zeros((0, 81)))
+    rel_pose0: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    rel_pose1: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    rel_sqrtinfo: np.ndarray = field(default_factory=lambda: np.zeros((0, 36)))
+    marg_block_type: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    marg_block_idx: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    marg_block_off: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    marg_J: np.ndarray = field(default_factory=lambda: np.zeros((0, 0)))
+    marg_e0: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    marg_lin: np.ndarray = field(default_factory=lambda: np.zeros((0, 9)))
+    meta: dict = field(default_factory=dict)   # generator bookkeeping (truth etc.); never uploaded
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def n_pose(self): return int(np.asarray(self.pose).reshape(-1, 7).shape[0])
+    @property
+    def n_sb(self): return int(np.asarray(self.sb).reshape(-1, 9).shape[0])
+    @property
+    def n_lm(self): return int(np.asarray(self.lm).reshape(-1, 4).shape[0])
+    @property
+    def n_obs(self): return int(np.asarray(self.obs_lm).size)
+    @property
+    def n_imu(self): return int(np.asarray(self.imu_pose0).size)
+
+    def reduced_dim(self) -> int:
+        return 6 * int((np.asarray(self.pose_fixed) == 0).sum()) + 9 * int((np.asarray(self.sb_fixed) == 0).sum())
+
+    def sort_observations(self) -> None:
+        """Establish the (lm, pose, cam) order the C-ABI requires."""
+        order = np.lexsort((self.obs_cam, self.obs_pose, self.obs_lm))
+        for n in ("obs_lm", "obs_pose", "obs_ext", "obs_cam", "obs_uv", "obs_sqrtw"):
+            setattr(self, n, np.asarray(getattr(self, n))[order])
+
+    def validate(self) -> None:
+        """Host-side argument checks (what OKVIS_ASSERT_* would catch in the reference)."""
+        npz, nl = self.n_pose, self.n_lm
+        for n in ("obs_pose", "obs_ext"):
+            a = np.asarray(getattr(self, n))
+            if a.size and (a.min() < 0 or a.max() >= npz):
+                raise ValueError(f"{n} out of range")
+        a = np.asarray(self.obs_lm)
+        if a.size and (a.min() < 0 or a.max() >= nl):
+            raise ValueError("obs_lm out of range")
+        if a.size:
+            key = np.stack([self.obs_lm, self.obs_pose, self.obs_cam], 1).astype(np.int64)
+            k = (key[:, 0] * (npz + 1) + key[:, 1]) * (len(self.cam_model) + 1) + key[:, 2]
+            if np.any(np.diff(k) < 0):
+                raise ValueError("observations must be sorted by (lm, pose, cam)")
+            if np.any(np.diff(k) == 0):
+                raise ValueError("duplicate observation (implementation/Estimator.hpp:52-56)")
+        md = np.asarray(self.marg_e0).size
+        if md and np.asarray(self.marg_J).shape != (md, md):
+            raise ValueError("marg_J must be [marg_dim, marg_dim]")
+
+    def as_c(self):
+        """Return (WindowC, keepalive list). Arrays are made contiguous with the ABI dtypes."""
+        k = {}
+        k["pose"] = _f64(self.pose, (-1, 7)); k["pose_fixed"] = np.ascontiguousarray(self.pose_fixed, np.uint8)
+        k["sb"] = _f64(self.sb, (-1, 9)); k["sb_fixed"] = np.ascontiguousarray(self.sb_fixed, np.uint8)
+        k["lm"] = _f64(self.lm, (-1, 4))
+        k["cam_intr"] = _f64(self.cam_intr, (-1, 12)); k["cam_model"] = _i32(self.cam_model)
+        for n in ("obs_lm", "obs_pose", "obs_ext", "obs_cam", "imu_pose0", "imu_sb0", "imu_pose1", "imu_sb1",
+                  "imu_s_begin", "imu_s_count", "pprior_pose", "sbprior_sb", "rel_pose0", "rel_pose1",
+                  "marg_block_type", "marg_block_idx", "marg_block_off"):
+            k[n] = _i32(getattr(self, n))
+        for n in ("imu_t0", "imu_t1", "imu_s_t"):
+            k[n] = _i64(getattr(self, n))
+        k["obs_uv"] = _f64(self.obs_uv, (-1, 2)); k["obs_sqrtw"] = _f64(self.obs_sqrtw, (-1,))
+        k["imu_s_gyr"] = _f64(self.imu_s_gyr, (-1, 3)); k["imu_s_acc"] = _f64(self.imu_s_acc, (-1, 3))
+        k["pprior_meas"] = _f64(self.pprior_meas, (-1, 7)); k["pprior_sqrtinfo"] = _f64(self.pprior_sqrtinfo, (-1, 36))
+        k["sbprior_meas"] = _f64(self.sbprior_meas, (-1, 9)); k["sbprior_sqrtinfo"] = _f64(self.sbprior_sqrtinfo, (-1, 81))
+        k["rel_sqrtinfo"] = _f64(self.rel_sqrtinfo, (-1, 36))
+        md = int(np.asarray(self.marg_e0).size)
+        k["marg_J"] = _f64(self.marg_J, (md, md)); k["marg_e0"] = _f64(self.marg_e0, (-1,))
+        k["marg_lin"] = _f64(self.marg_lin, (-1, 9))
+
+        def p(name, typ):
+            a = k[name]
+            return a.ctypes.data_as(typ) if a.size else C.cast(None, typ)
+
+        w = WindowC()
+        w.n_pose = k["pose"].shape[0]; w.pose = p("pose", _dp); w.pose_fixed = p("pose_fixed", _bp)
+        w.n_sb = k["sb"].shape[0]; w.sb = p("sb", _dp); w.sb_fixed = p("sb_fixed", _bp)
+        w.n_lm = k["lm"].shape[0]; w.lm = p("lm", _dp)
+        w.n_cam = k["cam_intr"].shape[0]; w.cam_intr = p("cam_intr", _dp); w.cam_model = p("cam_model", _ip)
+        w.n_obs = k["obs_lm"].size
+        for n in ("obs_lm", "obs_pose", "obs_ext", "obs_cam"):
+            setattr(w, n, p(n, _ip))
+        w.obs_uv = p("obs_uv", _dp); w.obs_sqrtw = p("obs_sqrtw", _dp); w.cauchy_b = float(self.cauchy_b)
+        w.n_imu = k["imu_pose0"].size
+        for n in ("imu_pose0", "imu_sb0", "imu_pose1", "imu_sb1", "imu_s_begin", "imu_s_count"):
+            setattr(w, n, p(n, _ip))
+        w.imu_t0 = p("imu_t0", _lp); w.imu_t1 = p("imu_t1", _lp)
+        w.n_imu_samples = k["imu_s_t"].size; w.imu_s_t = p("imu_s_t", _lp)
+        w.imu_s_gyr = p("imu_s_gyr", _dp); w.imu_s_acc = p("imu_s_acc", _dp)
+        w.imu_params = self.imu_params.as_c()
+        w.n_pprior = k["pprior_pose"].size; w.pprior_pose = p("pprior_pose", _ip)
+        w.pprior_meas = p("pprior_meas", _dp); w.pprior_sqrtinfo = p("pprior_sqrtinfo", _dp)
+        w.n_sbprior = k["sbprior_sb"].size; w.sbprior_sb = p("sbprior_sb", _ip)
+        w.sbprior_meas = p("sbprior_meas", _dp); w.sbprior_sqrtinfo = p("sbprior_sqrtinfo", _dp)
+        w.n_relpose = k["rel_pose0"].size; w.rel_pose0 = p("rel_pose0", _ip); w.rel_pose1 = p("rel_pose1", _ip)
+        w.rel_sqrtinfo = p("rel_sqrtinfo", _dp)
+        w.marg_dim = md; w.marg_nblocks = k["marg_block_type"].size
+        w.marg_block_type = p("marg_block_type", _ip); w.marg_block_idx = p("marg_block_idx", _ip)
+        w.marg_block_off = p("marg_block_off", _ip)
+        w.marg_J = p("marg_J", _dp); w.marg_e0 = p("marg_e0", _dp); w.marg_lin = p("marg_lin", _dp)
+        return w, k
