@@ -161,6 +161,9 @@ typedef struct okvis_ba_options {
   double parameter_tolerance;   /* 1e-8  */
   int32_t use_graph;            /* 1 = replay the captured hipGraph of the iteration sequence           */
   int32_t schur_lm_per_block;   /* landmarks per Schur workgroup (0 = auto)                             */
+  int32_t debug_arrays;         /* 1 = also write the parity/debug arrays (per-observation residuals,
+                                   damped reduced matrix); off in production                            */
+  int32_t reserved;
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */
@@ -201,7 +204,8 @@ enum okvis_ba_array {
   OKVIS_BA_ARR_LM_QUALITY = 11, /* [n_lm]       sqrt(lambda_min)/sqrt(lambda_max) (Estimator.cpp:880-896)*/
   OKVIS_BA_ARR_GRADIENT = 12,   /* [D]          un-reduced gradient of the pose/speed-bias part          */
   OKVIS_BA_ARR_IMU_RESIDUAL = 13,/* [n_imu][15] weighted IMU residual at the accepted state             */
-  OKVIS_BA_ARR_HPP = 14         /* [D][D]       un-reduced, un-damped pose/speed-bias Hessian block U   */
+  OKVIS_BA_ARR_HPP = 14,        /* [D][D]       un-reduced, un-damped pose/speed-bias Hessian block U (oracle only) */
+  OKVIS_BA_ARR_DAMPING = 15     /* [D]          clamp(diag U) used for the LM damping of the last solve   */
 };
 
 /* ---- lifecycle ----------------------------------------------------------------------------------- */
@@ -219,6 +223,11 @@ int okvis_ba_destroy(okvis_ba_solver* s);
  * (Map.cpp:292-434,568-576) that Estimator::addStates/addLandmark/addObservation issue: uploads the whole
  * structure + values of n independent windows and builds the device index arrays. */
 int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows);
+/* host-only structure check: runs exactly the index building of okvis_ba_upload (validation, reduced
+ * ordering, (landmark,block) pairs, linearise groups, Schur chunks) without touching a device and without
+ * any numeric work.  stats[8] = {D, Dp, n_pair, n_group, n_chunk, n_task, gpart doubles, arena bytes}.
+ * opt may be NULL (defaults). */
+int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt, int64_t* stats);
 /* overwrite only block VALUES of window w (Estimator::set_T_WS/setSpeedAndBias/setLandmark,
  * Estimator.cpp:1205-1302); any pointer may be NULL to keep the device copy. */
 int okvis_ba_set_state(okvis_ba_solver* s, int w, const double* pose, const double* sb, const double* lm);
@@ -265,13 +274,13 @@ int okvis_ba_pairs(okvis_ba_solver* s, int w, int32_t* pair_lm, int32_t* pair_bl
 /* HIP-event timing of the NEXT okvis_ba_iterate call on the solver's own stream: after the call,
  * total_ms = elapsed between events bracketing the n iterations. */
 int okvis_ba_last_iterate_ms(okvis_ba_solver* s, float* total_ms);
-/* per-kernel HIP-event timing (eager launches, events around every kernel): fills ms[3] with the summed
- * time of {linearise, schur, solve} kernels over n iterations. Slower than graph replay; used only to
- * attribute time for the roofline object. */
-int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms3);
+/* per-kernel HIP-event timing (eager launches, events around every kernel): fills ms[4] with the summed
+ * time of the {Schur, solve, IMU/prior, linearise} kernels over n iterations. Slower than graph replay;
+ * used only to attribute time for the roofline object. */
+int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4);
 /* algorithmic bytes one iteration moves for the uploaded batch (formula in DESIGN.md §4) */
 int okvis_ba_algorithmic_bytes(okvis_ba_solver* s, int64_t* linearize_bytes, int64_t* schur_bytes,
-                               int64_t* solve_bytes);
+                               int64_t* solve_bytes, int64_t* small_bytes);
 int okvis_ba_synchronize(okvis_ba_solver* s);
 
 #ifdef __cplusplus

@@ -1,0 +1,993 @@
+// C-ABI of the MI355X sliding-window BA backend (include/okvis_amd_ba.h): host-side structure building
+// (the index arrays that replace okvis::ceres::Map's pointer graph), the HBM arena, kernel launches and
+// hipGraph capture of the iteration sequence.  There is NO CPU compute path in this file: every numeric
+// entry point ends in a kernel launch and fails with OKVIS_BA_ERR_NO_DEVICE without a GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/okvis_amd_ba.h"
+#include "ba_imu.hpp"
+#include "ba_linearize.hpp"
+#include "ba_schur.hpp"
+#include "ba_solve.hpp"
+
+using namespace ba;
+
+namespace {
+
+#define HIP_TRY(expr)                                              \
+  do {                                                             \
+    hipError_t _e = (expr);                                        \
+    if (_e != hipSuccess) {                                        \
+      s->last_hip_error = (int)_e;                                 \
+      return OKVIS_BA_HIP_ERROR_BASE + (int)_e;                    \
+    }                                                              \
+  } while (0)
+
+struct HostWin {  // host copy of what the queries and downloads need
+  int n_pose = 0, n_sb = 0, n_lm = 0, n_obs = 0, n_imu = 0, D = 0, Dp = 0, n_pair = 0, n_group = 0, n_chunk = 0;
+  std::vector<int> pair_lm, pair_block;
+  WinPtrs ptrs;  // device pointers
+  int acc = 0;
+  int64_t bytes_lin = 0, bytes_schur = 0, bytes_solve = 0, bytes_small = 0;
+};
+
+struct Arena {
+  std::vector<unsigned char> host;
+  size_t size = 0;
+  size_t alloc(size_t bytes) {
+    size_t off = (size + 255) & ~size_t(255);
+    size = off + bytes;
+    return off;
+  }
+};
+
+}  // namespace
+
+struct okvis_ba_solver {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  okvis_ba_options opt;
+  OptD* d_opt = nullptr;
+  unsigned char* d_arena = nullptr;
+  size_t arena_bytes = 0;
+  WinPtrs* d_wins = nullptr;
+  std::vector<HostWin> wins;
+  bool uploaded = false, begun = false, any_ext = false;
+  int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0;
+  std::map<int, hipGraphExec_t> graphs;
+  float last_iterate_ms = 0.f;
+  int last_hip_error = 0;
+};
+
+namespace {
+
+OptD make_optd(const okvis_ba_options& o) {
+  OptD d;
+  d.initial_radius = o.initial_radius;
+  d.max_radius = o.max_radius;
+  d.min_radius = o.min_radius;
+  d.min_lm_diag2 = o.min_lm_diagonal * o.min_lm_diagonal;
+  d.max_lm_diag2 = o.max_lm_diagonal * o.max_lm_diagonal;
+  d.min_relative_decrease = o.min_relative_decrease;
+  d.function_tolerance = o.function_tolerance;
+  d.gradient_tolerance = o.gradient_tolerance;
+  d.parameter_tolerance = o.parameter_tolerance;
+  return d;
+}
+
+void destroy_graphs(okvis_ba_solver* s) {
+  for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+  s->graphs.clear();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// structure building for one window; appends into the arena and fills HostWin/WinPtrs with OFFSETS
+// (converted to device pointers after the arena is allocated).
+// ---------------------------------------------------------------------------------------------------
+template <class T>
+size_t put(Arena& A, const std::vector<T>& v) {
+  size_t off = A.alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (A.host.size() < A.size) A.host.resize(A.size, 0);
+  if (!v.empty()) std::memcpy(A.host.data() + off, v.data(), v.size() * sizeof(T));
+  return off;
+}
+size_t put_zero(Arena& A, size_t bytes) {
+  size_t off = A.alloc(std::max<size_t>(bytes, 8));
+  if (A.host.size() < A.size) A.host.resize(A.size, 0);
+  return off;
+}
+template <class T>
+std::vector<T> vec(const T* p, size_t n) {
+  return (p && n) ? std::vector<T>(p, p + n) : std::vector<T>();
+}
+
+#define OFF(field, off) P.field = reinterpret_cast<std::remove_reference<decltype(P.field)>::type>(off)
+
+int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A, HostWin& H) {
+  if (w.n_pose < 0 || w.n_sb < 0 || w.n_lm < 0 || w.n_obs < 0 || w.n_imu < 0 || w.n_cam < 0) return OKVIS_BA_ERR_ARG;
+  if ((w.n_pose && (!w.pose || !w.pose_fixed)) || (w.n_sb && (!w.sb || !w.sb_fixed)) || (w.n_lm && !w.lm))
+    return OKVIS_BA_ERR_ARG;
+  if (w.n_obs && (!w.obs_lm || !w.obs_pose || !w.obs_ext || !w.obs_cam || !w.obs_uv || !w.obs_sqrtw || !w.cam_intr ||
+                  !w.cam_model))
+    return OKVIS_BA_ERR_ARG;
+  if (w.n_pose > 65535 || w.n_lm >= (1 << 24) || w.n_cam > 255) return OKVIS_BA_ERR_UNSUPPORTED;
+  WinPtrs& P = H.ptrs;
+  std::memset(&P, 0, sizeof(P));
+  const int npose = w.n_pose, nsb = w.n_sb, nlm = w.n_lm, nobs = w.n_obs;
+  // ---- reduced ordering: free pose blocks (6 each) then free speed/bias blocks (9 each) ----
+  std::vector<int> pose_off(npose, -1), sb_off(nsb, -1);
+  int off = 0;
+  for (int i = 0; i < npose; ++i)
+    if (!w.pose_fixed[i]) {
+      pose_off[i] = off;
+      off += 6;
+    }
+  const int Dp = off;
+  for (int i = 0; i < nsb; ++i)
+    if (!w.sb_fixed[i]) {
+      sb_off[i] = off;
+      off += 9;
+    }
+  const int D = off;
+  if (D > MAX_D_LDS || D == 0) return OKVIS_BA_ERR_UNSUPPORTED;
+  // ---- validate observations, roles ----
+  std::vector<int> role(npose, -1);  // 0 pose role, 1 extrinsics role
+  std::vector<int> lm_obs_begin(nlm + 1, 0);
+  bool has_ext = false;
+  for (int o = 0; o < nobs; ++o) {
+    const int l = w.obs_lm[o], ip = w.obs_pose[o], ie = w.obs_ext[o], c = w.obs_cam[o];
+    if (l < 0 || l >= nlm || ip < 0 || ip >= npose || ie < 0 || ie >= npose || c < 0 || c >= w.n_cam) return OKVIS_BA_ERR_ARG;
+    if (o > 0) {
+      const int pl = w.obs_lm[o - 1], pp = w.obs_pose[o - 1], pc = w.obs_cam[o - 1];
+      if (pl > l || (pl == l && (pp > ip || (pp == ip && pc >= c)))) return OKVIS_BA_ERR_ARG;  // unsorted / duplicate
+    }
+    if (role[ip] == 1 || role[ie] == 0 || ip == ie) return OKVIS_BA_ERR_UNSUPPORTED;
+    role[ip] = 0;
+    role[ie] = 1;
+    if (pose_off[ie] >= 0) has_ext = true;
+    lm_obs_begin[l + 1]++;
+  }
+  for (int l = 0; l < nlm; ++l) {
+    if (lm_obs_begin[l + 1] > GROUP_OBS) return OKVIS_BA_ERR_UNSUPPORTED;
+    lm_obs_begin[l + 1] += lm_obs_begin[l];
+  }
+  // ---- (landmark, free block) pairs ----
+  std::vector<int> pair_lm, pair_block, pair_off, pair_role, lm_pair_begin(nlm + 1, 0);
+  for (int l = 0; l < nlm; ++l) {
+    std::vector<int> blocks;
+    for (int o = lm_obs_begin[l]; o < lm_obs_begin[l + 1]; ++o) {
+      const int cand[2] = {w.obs_pose[o], w.obs_ext[o]};
+      for (int c = 0; c < 2; ++c)
+        if (pose_off[cand[c]] >= 0 && std::find(blocks.begin(), blocks.end(), cand[c]) == blocks.end())
+          blocks.push_back(cand[c]);
+    }
+    std::sort(blocks.begin(), blocks.end());
+    lm_pair_begin[l] = (int)pair_lm.size();
+    for (int b : blocks) {
+      pair_lm.push_back(l);
+      pair_block.push_back(b);
+      pair_off.push_back(pose_off[b]);
+      pair_role.push_back(role[b]);
+    }
+    if ((int)blocks.size() > GROUP_PAIRS) return OKVIS_BA_ERR_UNSUPPORTED;
+  }
+  lm_pair_begin[nlm] = (int)pair_lm.size();
+  const int npair = (int)pair_lm.size();
+  // ---- groups ----
+  std::vector<Group> groups;
+  {
+    int l = 0;
+    while (l < nlm) {
+      Group G;
+      G.lm_begin = l;
+      G.obs_begin = lm_obs_begin[l];
+      G.pair_begin = lm_pair_begin[l];
+      int no = 0, np = 0, nl = 0;
+      while (l < nlm) {
+        const int lo = lm_obs_begin[l + 1] - lm_obs_begin[l], lp = lm_pair_begin[l + 1] - lm_pair_begin[l];
+        if (nl > 0 && (no + lo > GROUP_OBS || np + lp > GROUP_PAIRS || nl + 1 > GROUP_LM)) break;
+        no += lo;
+        np += lp;
+        ++nl;
+        ++l;
+      }
+      G.lm_end = l;
+      G.obs_end = lm_obs_begin[l];
+      G.pair_end = lm_pair_begin[l];
+      G.task_begin = G.task_end = 0;
+      groups.push_back(G);
+    }
+  }
+  const int ngroup = (int)groups.size();
+  // ---- per-pair observation lists, per-group tasks ----
+  std::vector<int> pair_list_begin(npair + 1, 0);
+  std::vector<uint16_t> pair_list;
+  std::vector<Task> tasks;
+  std::vector<uint16_t> task_list;
+  int gpart_size = 0;
+  for (int g = 0; g < ngroup; ++g) {
+    Group& G = groups[g];
+    for (int p = G.pair_begin; p < G.pair_end; ++p) {
+      pair_list_begin[p] = (int)pair_list.size();
+      const int l = pair_lm[p], b = pair_block[p];
+      for (int o = lm_obs_begin[l]; o < lm_obs_begin[l + 1]; ++o)
+        if ((pair_role[p] == 0 ? w.obs_pose[o] : w.obs_ext[o]) == b) pair_list.push_back((uint16_t)(o - G.obs_begin));
+    }
+    G.task_begin = (int)tasks.size();
+    std::map<int, std::vector<uint16_t>> by_block;             // block -> obs (its own role)
+    std::map<std::pair<int, int>, std::vector<uint16_t>> cross;  // (pose, ext) -> obs
+    for (int o = G.obs_begin; o < G.obs_end; ++o) {
+      const int ip = w.obs_pose[o], ie = w.obs_ext[o];
+      const uint16_t lo = (uint16_t)(o - G.obs_begin);
+      if (pose_off[ip] >= 0) by_block[ip].push_back(lo);
+      if (pose_off[ie] >= 0) by_block[ie].push_back(lo);
+      if (pose_off[ip] >= 0 && pose_off[ie] >= 0) cross[{ip, ie}].push_back(lo);
+    }
+    for (auto& kv : by_block) {
+      Task T;
+      T.type = role[kv.first];
+      T.off_a = pose_off[kv.first];
+      T.off_b = -1;
+      T.list_begin = (int)task_list.size();
+      task_list.insert(task_list.end(), kv.second.begin(), kv.second.end());
+      T.list_end = (int)task_list.size();
+      T.out = gpart_size;
+      gpart_size += 27;
+      tasks.push_back(T);
+    }
+    for (auto& kv : cross) {
+      Task T;
+      T.type = 2;
+      T.off_a = pose_off[kv.first.first];
+      T.off_b = pose_off[kv.first.second];
+      T.list_begin = (int)task_list.size();
+      task_list.insert(task_list.end(), kv.second.begin(), kv.second.end());
+      T.list_end = (int)task_list.size();
+      T.out = gpart_size;
+      gpart_size += 36;
+      tasks.push_back(T);
+    }
+    G.task_end = (int)tasks.size();
+  }
+  pair_list_begin[npair] = (int)pair_list.size();
+  // ---- chunks (Schur workgroups) ----
+  std::vector<Chunk> chunks;
+  {
+    const int per = opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : 48;
+    int g = 0;
+    while (g < ngroup) {
+      Chunk C;
+      C.group_begin = g;
+      int nl = 0;
+      while (g < ngroup && (nl == 0 || nl + (groups[g].lm_end - groups[g].lm_begin) <= per)) {
+        nl += groups[g].lm_end - groups[g].lm_begin;
+        ++g;
+      }
+      C.group_end = g;
+      chunks.push_back(C);
+    }
+    if (chunks.empty()) {  // no landmarks: one empty chunk is not representable; handled by n_chunk = 0
+    }
+  }
+  const int nchunk = (int)chunks.size();
+  const int ntile = std::max(1, (Dp / 6 + SCHUR_TILE_BLOCKS - 1) / SCHUR_TILE_BLOCKS);
+  // ---- observation records ----
+  std::vector<ObsRec> recs(nobs);
+  for (int o = 0; o < nobs; ++o) {
+    recs[o].lm_cam = (uint32_t)w.obs_lm[o] | ((uint32_t)w.obs_cam[o] << 24);
+    recs[o].pose = (uint16_t)w.obs_pose[o];
+    recs[o].ext = (uint16_t)w.obs_ext[o];
+    recs[o].u = w.obs_uv[2 * o];
+    recs[o].v = w.obs_uv[2 * o + 1];
+    recs[o].sw = w.obs_sqrtw[o];
+  }
+  // ---- IMU ----
+  for (int f = 0; f < w.n_imu; ++f) {
+    if (w.imu_pose0[f] < 0 || w.imu_pose0[f] >= npose || w.imu_pose1[f] < 0 || w.imu_pose1[f] >= npose ||
+        w.imu_sb0[f] < 0 || w.imu_sb0[f] >= nsb || w.imu_sb1[f] < 0 || w.imu_sb1[f] >= nsb)
+      return OKVIS_BA_ERR_ARG;
+    if (w.imu_s_begin[f] < 0 || w.imu_s_count[f] < 2 || w.imu_s_begin[f] + w.imu_s_count[f] > w.n_imu_samples)
+      return OKVIS_BA_ERR_ARG;
+    if (w.imu_s_count[f] > IMU_N) return OKVIS_BA_ERR_UNSUPPORTED;
+    // ImuError::redoPreintegration returns -1 when the samples do not cover [t0,t1] (ImuError.cpp:87-89)
+    if (!(w.imu_s_t[w.imu_s_begin[f] + w.imu_s_count[f] - 1] >= w.imu_t1[f])) return OKVIS_BA_ERR_ARG;
+  }
+  // ---- marginalisation prior: H0 = J^T J ----
+  const int Dm = w.marg_dim;
+  if (Dm < 0 || Dm > MAX_MARG_DIM) return OKVIS_BA_ERR_UNSUPPORTED;
+  std::vector<double> H0((size_t)Dm * Dm, 0.0);
+  if (Dm > 0) {
+    if (!w.marg_J || !w.marg_e0 || !w.marg_lin || !w.marg_block_type || !w.marg_block_idx || !w.marg_block_off ||
+        w.marg_nblocks <= 0)
+      return OKVIS_BA_ERR_ARG;
+    for (int b = 0; b < w.marg_nblocks; ++b) {
+      const int lim = w.marg_block_type[b] == OKVIS_BA_BLOCK_POSE ? npose : nsb;
+      if (w.marg_block_idx[b] < 0 || w.marg_block_idx[b] >= lim || w.marg_block_off[b] < 0 ||
+          w.marg_block_off[b] + (w.marg_block_type[b] == OKVIS_BA_BLOCK_POSE ? 6 : 9) > Dm)
+        return OKVIS_BA_ERR_ARG;
+      if (b > 0 && w.marg_block_off[b] <= w.marg_block_off[b - 1]) return OKVIS_BA_ERR_ARG;
+    }
+    for (int i = 0; i < Dm; ++i)
+      for (int j = i; j < Dm; ++j) {
+        double s = 0;
+        for (int r = 0; r < Dm; ++r) s += w.marg_J[(size_t)r * Dm + i] * w.marg_J[(size_t)r * Dm + j];
+        H0[(size_t)i * Dm + j] = s;
+        H0[(size_t)j * Dm + i] = s;
+      }
+  }
+  const int nmb = Dm > 0 ? w.marg_nblocks : 0;
+
+  // ---- fill sizes ----
+  P.n_pose = npose; P.n_sb = nsb; P.n_lm = nlm; P.n_cam = w.n_cam; P.n_obs = nobs; P.n_imu = w.n_imu;
+  P.n_pprior = w.n_pprior; P.n_sbprior = w.n_sbprior; P.n_rel = w.n_relpose;
+  P.marg_dim = Dm; P.marg_nb = nmb;
+  P.D = D; P.Dp = Dp; P.n_pair = npair; P.n_group = ngroup; P.n_chunk = nchunk; P.n_task = (int)tasks.size();
+  P.has_ext = has_ext ? 1 : 0;
+  P.gpart_size = gpart_size;
+  P.n_tile = ntile;
+  P.cauchy_b = w.cauchy_b;
+  P.imu.sigma_g_c = w.imu_params.sigma_g_c; P.imu.sigma_a_c = w.imu_params.sigma_a_c;
+  P.imu.sigma_gw_c = w.imu_params.sigma_gw_c; P.imu.sigma_aw_c = w.imu_params.sigma_aw_c;
+  P.imu.g = w.imu_params.g; P.imu.g_max = w.imu_params.g_max; P.imu.a_max = w.imu_params.a_max;
+
+  // ---- arena: state ----
+  auto poses = vec(w.pose, 7 * (size_t)npose);
+  auto sbs = vec(w.sb, 9 * (size_t)nsb);
+  auto lms = vec(w.lm, 4 * (size_t)nlm);
+  for (int b = 0; b < 2; ++b) {
+    OFF(pose[b], put(A, poses));
+    OFF(sb[b], put(A, sbs));
+    OFF(lm[b], put(A, lms));
+  }
+  OFF(pose_off, put(A, pose_off));
+  OFF(sb_off, put(A, sb_off));
+  OFF(cam_intr, put(A, vec(w.cam_intr, 12 * (size_t)w.n_cam)));
+  OFF(cam_model, put(A, vec(w.cam_model, (size_t)w.n_cam)));
+  OFF(obs, put(A, recs));
+  OFF(groups, put(A, groups));
+  OFF(pair_lm, put(A, pair_lm));
+  OFF(pair_off, put(A, pair_off));
+  OFF(pair_role, put(A, pair_role));
+  OFF(pair_list_begin, put(A, pair_list_begin));
+  OFF(pair_list, put(A, pair_list));
+  OFF(lm_pair_begin, put(A, lm_pair_begin));
+  OFF(lm_obs_begin, put(A, lm_obs_begin));
+  OFF(tasks, put(A, tasks));
+  OFF(task_list, put(A, task_list));
+  OFF(chunks, put(A, chunks));
+  for (int b = 0; b < 2; ++b) {
+    OFF(V[b], put_zero(A, 48 * (size_t)nlm));
+    OFF(bl[b], put_zero(A, 24 * (size_t)nlm));
+    OFF(Hq[b], put_zero(A, 48 * (size_t)nlm));
+    OFF(W[b], put_zero(A, 144 * (size_t)npair));
+    OFF(gpart[b], put_zero(A, 8 * (size_t)gpart_size));
+    OFF(gscal[b], put_zero(A, 8 * (size_t)GS_COUNT * ngroup));
+    OFF(imu_lin[b], put_zero(A, 8 * (size_t)IMU_LIN_STRIDE * w.n_imu));
+    OFF(pp_lin[b], put_zero(A, 8 * 42 * (size_t)w.n_pprior));
+    OFF(sbp_lin[b], put_zero(A, 8 * 9 * (size_t)w.n_sbprior));
+    OFF(rel_lin[b], put_zero(A, 8 * 78 * (size_t)w.n_relpose));
+    OFF(marg_lin_e[b], put_zero(A, 8 * 2 * (size_t)Dm));
+    OFF(marg_lin_M[b], put_zero(A, 8 * 9 * (size_t)nmb));
+    OFF(small_cost[b], put_zero(A, 16));
+    if (opt.debug_arrays) OFF(obs_r[b], put_zero(A, 16 * (size_t)nobs));
+  }
+  OFF(spart, put_zero(A, 8 * (size_t)std::max(nchunk, 1) * ((size_t)Dp * Dp + 3 * Dp)));
+  if (opt.debug_arrays) {
+    OFF(S, put_zero(A, 8 * (size_t)D * D));
+    OFF(rhs, put_zero(A, 8 * (size_t)D));
+    OFF(Dp2, put_zero(A, 8 * (size_t)D));
+  }
+  OFF(step, put_zero(A, 8 * (size_t)D));
+  OFF(grad, put_zero(A, 8 * (size_t)D));
+  OFF(quality, put_zero(A, 8 * (size_t)nlm));
+  OFF(ctrl, put_zero(A, sizeof(Ctrl)));
+  OFF(imu_pose0, put(A, vec(w.imu_pose0, (size_t)w.n_imu)));
+  OFF(imu_sb0, put(A, vec(w.imu_sb0, (size_t)w.n_imu)));
+  OFF(imu_pose1, put(A, vec(w.imu_pose1, (size_t)w.n_imu)));
+  OFF(imu_sb1, put(A, vec(w.imu_sb1, (size_t)w.n_imu)));
+  {
+    std::vector<long long> t0(w.n_imu), t1(w.n_imu), st(w.n_imu ? w.n_imu_samples : 0);
+    for (int f = 0; f < w.n_imu; ++f) {
+      t0[f] = w.imu_t0[f];
+      t1[f] = w.imu_t1[f];
+    }
+    for (size_t i = 0; i < st.size(); ++i) st[i] = w.imu_s_t[i];
+    OFF(imu_t0, put(A, t0));
+    OFF(imu_t1, put(A, t1));
+    OFF(imu_s_t, put(A, st));
+  }
+  OFF(imu_s_begin, put(A, vec(w.imu_s_begin, (size_t)w.n_imu)));
+  OFF(imu_s_count, put(A, vec(w.imu_s_count, (size_t)w.n_imu)));
+  OFF(imu_s_gyr, put(A, vec(w.imu_s_gyr, w.n_imu ? 3 * (size_t)w.n_imu_samples : 0)));
+  OFF(imu_s_acc, put(A, vec(w.imu_s_acc, w.n_imu ? 3 * (size_t)w.n_imu_samples : 0)));
+  OFF(imu_cache, put_zero(A, sizeof(ImuCacheD) * (size_t)w.n_imu));
+  OFF(pprior_pose, put(A, vec(w.pprior_pose, (size_t)w.n_pprior)));
+  OFF(pprior_meas, put(A, vec(w.pprior_meas, 7 * (size_t)w.n_pprior)));
+  OFF(pprior_sqrtinfo, put(A, vec(w.pprior_sqrtinfo, 36 * (size_t)w.n_pprior)));
+  OFF(sbprior_sb, put(A, vec(w.sbprior_sb, (size_t)w.n_sbprior)));
+  OFF(sbprior_meas, put(A, vec(w.sbprior_meas, 9 * (size_t)w.n_sbprior)));
+  OFF(sbprior_sqrtinfo, put(A, vec(w.sbprior_sqrtinfo, 81 * (size_t)w.n_sbprior)));
+  OFF(rel_pose0, put(A, vec(w.rel_pose0, (size_t)w.n_relpose)));
+  OFF(rel_pose1, put(A, vec(w.rel_pose1, (size_t)w.n_relpose)));
+  OFF(rel_sqrtinfo, put(A, vec(w.rel_sqrtinfo, 36 * (size_t)w.n_relpose)));
+  OFF(marg_block_type, put(A, vec(w.marg_block_type, (size_t)nmb)));
+  OFF(marg_block_idx, put(A, vec(w.marg_block_idx, (size_t)nmb)));
+  OFF(marg_block_off, put(A, vec(w.marg_block_off, (size_t)nmb)));
+  OFF(marg_J, put(A, vec(w.marg_J, (size_t)Dm * Dm)));
+  OFF(marg_H0, put(A, H0));
+  OFF(marg_e0, put(A, vec(w.marg_e0, (size_t)Dm)));
+  OFF(marg_lin, put(A, vec(w.marg_lin, 9 * (size_t)nmb)));
+  for (int i = 0; i < w.n_pprior; ++i)
+    if (w.pprior_pose[i] < 0 || w.pprior_pose[i] >= npose) return OKVIS_BA_ERR_ARG;
+  for (int i = 0; i < w.n_sbprior; ++i)
+    if (w.sbprior_sb[i] < 0 || w.sbprior_sb[i] >= nsb) return OKVIS_BA_ERR_ARG;
+  for (int i = 0; i < w.n_relpose; ++i)
+    if (w.rel_pose0[i] < 0 || w.rel_pose0[i] >= npose || w.rel_pose1[i] < 0 || w.rel_pose1[i] >= npose) return OKVIS_BA_ERR_ARG;
+
+  H.n_pose = npose; H.n_sb = nsb; H.n_lm = nlm; H.n_obs = nobs; H.n_imu = w.n_imu; H.D = D; H.Dp = Dp;
+  H.n_pair = npair; H.n_group = ngroup; H.n_chunk = nchunk;
+  H.pair_lm = pair_lm;
+  H.pair_block = pair_block;
+  H.acc = 0;
+  // ---- algorithmic (compulsory) bytes per iteration, DESIGN.md §4 ----
+  const int64_t O = nobs, L = nlm, Pn = npair;
+  H.bytes_lin = 32 * O + 56 * (int64_t)npose + 32 * L + 8 * (int64_t)D + 72 * L + 144 * Pn  // reads
+                + 32 * L + 120 * L + 144 * Pn + 8 * (int64_t)gpart_size + 8 * GS_COUNT * (int64_t)ngroup;  // writes
+  H.bytes_schur = 72 * L + 144 * Pn + 8 * (int64_t)gpart_size + 8 * (int64_t)nchunk * ((int64_t)Dp * Dp + 3 * Dp);
+  H.bytes_solve = 8 * (int64_t)nchunk * ((int64_t)Dp * (Dp + 1) / 2 + 3 * Dp) + 8 * (int64_t)IMU_LIN_STRIDE * w.n_imu +
+                  8 * (int64_t)Dm * Dm + 8 * (int64_t)D + 2 * (56 * (int64_t)npose + 72 * (int64_t)nsb);
+  H.bytes_small = (int64_t)w.n_imu * (8 * IMU_LIN_STRIDE + (int64_t)sizeof(ImuCacheD) + 2 * 56 + 2 * 72) +
+                  8 * (int64_t)Dm * Dm * 2;
+  return OKVIS_BA_OK;
+}
+
+// convert the arena offsets stored in the pointer fields to device addresses
+void relocate(WinPtrs& P, unsigned char* base, bool debug) {
+  unsigned char** fields = reinterpret_cast<unsigned char**>(&P.pose[0]);
+  // all pointer members are laid out contiguously from pose[0] to marg_lin; relocate by scanning the
+  // struct region as an array of pointers (sizes/scalars precede pose[0])
+  const size_t first = offsetof(WinPtrs, pose);
+  const size_t n = (sizeof(WinPtrs) - first) / sizeof(void*);
+  for (size_t i = 0; i < n; ++i) {
+    const size_t off = reinterpret_cast<size_t>(fields[i]);
+    fields[i] = base + off;
+  }
+  // optional arrays that were never allocated hold offset 0 -> must be null
+  if (!debug) {
+    P.obs_r[0] = P.obs_r[1] = nullptr;
+    P.S = nullptr;
+    P.rhs = nullptr;
+    P.Dp2 = nullptr;
+  }
+  P.Hpp = nullptr;
+}
+
+size_t lin_smem(bool ext) { return (ext ? LinCfg<true>::SMEM_DOUBLES : LinCfg<false>::SMEM_DOUBLES) * sizeof(double); }
+size_t solve_smem(int Dpad) { return ((size_t)Dpad * (Dpad + 1) / 2 + 4 * (size_t)Dpad) * sizeof(double); }
+size_t small_smem() { return (size_t)ImuLds::TOTAL * sizeof(double); }
+
+hipError_t launch_schur(okvis_ba_solver* s) {
+  if (s->max_schur_blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(schur_kernel, dim3(s->max_schur_blocks, (unsigned)s->wins.size()), dim3(SCHUR_THREADS), 0, s->stream,
+                     s->d_wins, s->d_opt);
+  return hipGetLastError();
+}
+hipError_t launch_solve(okvis_ba_solver* s, int final_only) {
+  hipLaunchKernelGGL(solve_kernel, dim3((unsigned)s->wins.size()), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad), s->stream,
+                     s->d_wins, s->d_opt, final_only);
+  return hipGetLastError();
+}
+hipError_t launch_small(okvis_ba_solver* s, int init) {
+  hipLaunchKernelGGL(small_kernel, dim3(s->max_imu + 1, (unsigned)s->wins.size()), dim3(IMU_THREADS), small_smem(), s->stream,
+                     s->d_wins, init);
+  return hipGetLastError();
+}
+hipError_t launch_lin(okvis_ba_solver* s, int init) {
+  if (s->max_group == 0) return hipSuccess;
+  if (s->any_ext)
+    hipLaunchKernelGGL(linearize_kernel<true>, dim3(s->max_group, (unsigned)s->wins.size()), dim3(LIN_THREADS), lin_smem(true),
+                       s->stream, s->d_wins, s->d_opt, init);
+  else
+    hipLaunchKernelGGL(linearize_kernel<false>, dim3(s->max_group, (unsigned)s->wins.size()), dim3(LIN_THREADS), lin_smem(false),
+                       s->stream, s->d_wins, s->d_opt, init);
+  return hipGetLastError();
+}
+hipError_t launch_iteration(okvis_ba_solver* s) {
+  hipError_t e;
+  if ((e = launch_schur(s)) != hipSuccess) return e;
+  if ((e = launch_solve(s, 0)) != hipSuccess) return e;
+  if ((e = launch_small(s, 0)) != hipSuccess) return e;
+  return launch_lin(s, 0);
+}
+
+// the accepted-buffer index lives on the device while iterations are in flight: read it back
+int refresh_acc(okvis_ba_solver* s, int w) {
+  int acc = 0;
+  HIP_TRY(hipMemcpyAsync(&acc, &s->wins[w].ptrs.ctrl->acc, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->wins[w].acc = acc & 1;
+  return OKVIS_BA_OK;
+}
+
+int fetch_ctrl(okvis_ba_solver* s, std::vector<Ctrl>& out) {
+  out.resize(s->wins.size());
+  for (size_t i = 0; i < s->wins.size(); ++i)
+    HIP_TRY(hipMemcpyAsync(&out[i], s->wins[i].ptrs.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return OKVIS_BA_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int okvis_ba_abi_version(void) { return OKVIS_BA_ABI_VERSION; }
+
+void okvis_ba_get_limits(okvis_ba_limits* out) {
+  if (!out) return;
+  out->max_obs_per_lm = GROUP_OBS;
+  out->max_reduced_dim = MAX_D_LDS;
+  out->max_marg_dim = MAX_MARG_DIM;
+  out->max_imu_samples_per_factor = IMU_N;
+}
+
+void okvis_ba_default_options(okvis_ba_options* o) {
+  if (!o) return;
+  // Ceres 1.9 defaults restated from its documentation (not in the reference tree)
+  o->initial_radius = 1e4;
+  o->max_radius = 1e16;
+  o->min_radius = 1e-32;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->min_relative_decrease = 1e-3;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->use_graph = 1;
+  o->schur_lm_per_block = 0;
+  o->debug_arrays = 0;
+  o->reserved = 0;
+}
+
+const char* okvis_ba_error_string(int status) {
+  switch (status) {
+    case OKVIS_BA_OK: return "ok";
+    case OKVIS_BA_ERR_ARG: return "invalid argument (null pointer, index out of range, unsorted/duplicate observations)";
+    case OKVIS_BA_ERR_STATE: return "call order violated";
+    case OKVIS_BA_ERR_UNSUPPORTED: return "structure exceeds a documented limit (okvis_ba_get_limits)";
+    case OKVIS_BA_ERR_NO_DEVICE: return "no HIP device visible: this backend has no CPU path";
+    case OKVIS_BA_ERR_NUMERIC: return "numeric failure";
+  }
+  if (status >= OKVIS_BA_HIP_ERROR_BASE) return hipGetErrorString((hipError_t)(status - OKVIS_BA_HIP_ERROR_BASE));
+  return "unknown status";
+}
+
+int okvis_ba_create(okvis_ba_solver** out, int device) {
+  if (!out) return OKVIS_BA_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return OKVIS_BA_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return OKVIS_BA_ERR_ARG;
+  okvis_ba_solver* s = new okvis_ba_solver();
+  s->device = device;
+  okvis_ba_default_options(&s->opt);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+  if (e == hipSuccess) e = hipMalloc(&s->d_opt, sizeof(OptD));
+  // kernels may use more than the default 64 KB of dynamic LDS
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lin_smem(true));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lin_smem(false));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)solve_smem(MAX_D_LDS));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)small_smem());
+  if (e != hipSuccess) {
+    int code = OKVIS_BA_HIP_ERROR_BASE + (int)e;
+    okvis_ba_destroy(s);
+    return code;
+  }
+  *out = s;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_destroy(okvis_ba_solver* s) {
+  if (!s) return OKVIS_BA_OK;
+  (void)hipSetDevice(s->device);
+  destroy_graphs(s);
+  if (s->d_arena) (void)hipFree(s->d_arena);
+  if (s->d_wins) (void)hipFree(s->d_wins);
+  if (s->d_opt) (void)hipFree(s->d_opt);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt) {
+  if (!s || !opt) return OKVIS_BA_ERR_ARG;
+  if (!(opt->initial_radius > 0) || !(opt->min_lm_diagonal > 0) || !(opt->max_lm_diagonal >= opt->min_lm_diagonal))
+    return OKVIS_BA_ERR_ARG;
+  if (s->uploaded && (opt->debug_arrays != s->opt.debug_arrays || opt->schur_lm_per_block != s->opt.schur_lm_per_block))
+    return OKVIS_BA_ERR_STATE;  // these two shape the arena: set them before upload
+  s->opt = *opt;
+  HIP_TRY(hipSetDevice(s->device));
+  OptD d = make_optd(s->opt);
+  HIP_TRY(hipMemcpyAsync(s->d_opt, &d, sizeof(d), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows) {
+  if (!s || n_windows <= 0 || !windows) return OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  destroy_graphs(s);
+  s->uploaded = false;
+  s->begun = false;
+  Arena A;
+  std::vector<HostWin> wins(n_windows);
+  for (int i = 0; i < n_windows; ++i) {
+    int rc = build_window(windows[i], s->opt, A, wins[i]);
+    if (rc != OKVIS_BA_OK) return rc;
+  }
+  if (s->d_arena) {
+    HIP_TRY(hipFree(s->d_arena));
+    s->d_arena = nullptr;
+  }
+  if (s->d_wins) {
+    HIP_TRY(hipFree(s->d_wins));
+    s->d_wins = nullptr;
+  }
+  A.host.resize(A.size, 0);
+  HIP_TRY(hipMalloc(&s->d_arena, A.size));
+  s->arena_bytes = A.size;
+  HIP_TRY(hipMemcpy(s->d_arena, A.host.data(), A.size, hipMemcpyHostToDevice));
+  std::vector<WinPtrs> ptrs(n_windows);
+  s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = 0;
+  s->any_ext = false;
+  for (int i = 0; i < n_windows; ++i) {
+    relocate(wins[i].ptrs, s->d_arena, s->opt.debug_arrays != 0);
+    ptrs[i] = wins[i].ptrs;
+    const WinPtrs& P = ptrs[i];
+    s->max_group = std::max(s->max_group, P.n_group);
+    s->max_imu = std::max(s->max_imu, P.n_imu);
+    s->max_schur_blocks = std::max(s->max_schur_blocks, P.n_chunk * (P.n_tile * (P.n_tile + 1) / 2));
+    s->max_lm = std::max(s->max_lm, P.n_lm);
+    s->max_Dpad = std::max(s->max_Dpad, ((P.D + 5) / 6) * 6);
+    s->any_ext = s->any_ext || P.has_ext;
+  }
+  HIP_TRY(hipMalloc(&s->d_wins, sizeof(WinPtrs) * n_windows));
+  HIP_TRY(hipMemcpy(s->d_wins, ptrs.data(), sizeof(WinPtrs) * n_windows, hipMemcpyHostToDevice));
+  OptD d = make_optd(s->opt);
+  HIP_TRY(hipMemcpy(s->d_opt, &d, sizeof(d), hipMemcpyHostToDevice));
+  s->wins.swap(wins);
+  s->uploaded = true;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt, int64_t* stats) {
+  if (!w) return OKVIS_BA_ERR_ARG;
+  okvis_ba_options o;
+  if (opt) o = *opt; else okvis_ba_default_options(&o);
+  Arena A;
+  HostWin H;
+  int rc = build_window(*w, o, A, H);
+  if (rc != OKVIS_BA_OK) return rc;
+  if (stats) {
+    stats[0] = H.D; stats[1] = H.Dp; stats[2] = H.n_pair; stats[3] = H.n_group; stats[4] = H.n_chunk;
+    stats[5] = H.ptrs.n_task; stats[6] = H.ptrs.gpart_size; stats[7] = (int64_t)A.size;
+  }
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_set_state(okvis_ba_solver* s, int w, const double* pose, const double* sb, const double* lm) {
+  if (!s || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return s && !s->uploaded ? OKVIS_BA_ERR_STATE : OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = refresh_acc(s, w)) return rc;
+  HostWin& H = s->wins[w];
+  if (pose) HIP_TRY(hipMemcpyAsync(H.ptrs.pose[H.acc], pose, 56 * (size_t)H.n_pose, hipMemcpyHostToDevice, s->stream));
+  if (sb) HIP_TRY(hipMemcpyAsync(H.ptrs.sb[H.acc], sb, 72 * (size_t)H.n_sb, hipMemcpyHostToDevice, s->stream));
+  if (lm) HIP_TRY(hipMemcpyAsync(H.ptrs.lm[H.acc], lm, 32 * (size_t)H.n_lm, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->begun = false;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, double* lm) {
+  if (!s || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return s && !s->uploaded ? OKVIS_BA_ERR_STATE : OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = refresh_acc(s, w)) return rc;
+  HostWin& H = s->wins[w];
+  if (pose) HIP_TRY(hipMemcpyAsync(pose, H.ptrs.pose[H.acc], 56 * (size_t)H.n_pose, hipMemcpyDeviceToHost, s->stream));
+  if (sb) HIP_TRY(hipMemcpyAsync(sb, H.ptrs.sb[H.acc], 72 * (size_t)H.n_sb, hipMemcpyDeviceToHost, s->stream));
+  if (lm) HIP_TRY(hipMemcpyAsync(lm, H.ptrs.lm[H.acc], 32 * (size_t)H.n_lm, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_begin(okvis_ba_solver* s) {
+  if (!s) return OKVIS_BA_ERR_ARG;
+  if (!s->uploaded) return OKVIS_BA_ERR_STATE;
+  HIP_TRY(hipSetDevice(s->device));
+  for (auto& H : s->wins) {
+    const int acc = H.acc, tr = 1 - acc;
+    HIP_TRY(hipMemcpyAsync(H.ptrs.pose[tr], H.ptrs.pose[acc], 56 * (size_t)H.n_pose, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(H.ptrs.sb[tr], H.ptrs.sb[acc], 72 * (size_t)H.n_sb, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(H.ptrs.lm[tr], H.ptrs.lm[acc], 32 * (size_t)H.n_lm, hipMemcpyDeviceToDevice, s->stream));
+    Ctrl c;
+    std::memset(&c, 0, sizeof(c));
+    c.acc = acc;
+    c.pending = 1;
+    c.first = 1;
+    c.radius = s->opt.initial_radius;
+    c.decrease_factor = 2.0;
+    c.lambda = 1.0 / s->opt.initial_radius;
+    HIP_TRY(hipMemcpyAsync(H.ptrs.ctrl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
+  }
+  HIP_TRY(launch_small(s, 1));
+  HIP_TRY(launch_lin(s, 1));
+  s->begun = true;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_iterate(okvis_ba_solver* s, int n) {
+  if (!s || n < 0) return OKVIS_BA_ERR_ARG;
+  if (!s->begun) return OKVIS_BA_ERR_STATE;
+  if (n == 0) return OKVIS_BA_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventRecord(s->ev0, s->stream));
+  if (s->opt.use_graph) {
+    hipGraphExec_t exec = nullptr;
+    auto it = s->graphs.find(n);
+    if (it == s->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+      hipError_t e = hipSuccess;
+      for (int i = 0; i < n && e == hipSuccess; ++i) e = launch_iteration(s);
+      hipError_t e2 = hipStreamEndCapture(s->stream, &graph);
+      if (e != hipSuccess) HIP_TRY(e);
+      HIP_TRY(e2);
+      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      HIP_TRY(hipGraphDestroy(graph));
+      s->graphs[n] = exec;
+      // the capture swallowed the first event record: re-record outside the graph
+      HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    } else {
+      exec = it->second;
+    }
+    HIP_TRY(hipGraphLaunch(exec, s->stream));
+  } else {
+    for (int i = 0; i < n; ++i) HIP_TRY(launch_iteration(s));
+  }
+  HIP_TRY(hipEventRecord(s->ev1, s->stream));
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_last_iterate_ms(okvis_ba_solver* s, float* total_ms) {
+  if (!s || !total_ms) return OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  HIP_TRY(hipEventElapsedTime(total_ms, s->ev0, s->ev1));
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
+  if (!s) return OKVIS_BA_ERR_ARG;
+  if (!s->begun) return OKVIS_BA_ERR_STATE;
+  HIP_TRY(hipSetDevice(s->device));
+  // the final accept/reject needs the Schur partials of the buffer it may accept (gradient test)
+  HIP_TRY(launch_schur(s));
+  HIP_TRY(launch_solve(s, 1));
+  if (s->max_lm > 0) {
+    hipLaunchKernelGGL(quality_kernel, dim3((s->max_lm + 255) / 256, (unsigned)s->wins.size()), dim3(256), 0, s->stream, s->d_wins);
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<Ctrl> cs;
+  int rc = fetch_ctrl(s, cs);
+  if (rc != OKVIS_BA_OK) return rc;
+  for (size_t i = 0; i < s->wins.size(); ++i) {
+    s->wins[i].acc = cs[i].acc;
+    if (summaries) {
+      okvis_ba_summary& o = summaries[i];
+      o.initial_cost = cs[i].initial_cost;
+      o.final_cost = cs[i].cost;
+      o.iterations = cs[i].iter;
+      o.successful_steps = cs[i].successful;
+      o.termination = cs[i].done ? cs[i].done - 1 : 0;
+      o.reserved = cs[i].chol_fail;
+      o.final_radius = cs[i].radius;
+      o.gradient_max_norm = cs[i].grad_max;
+    }
+  }
+  s->begun = false;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_optimize(okvis_ba_solver* s, int num_iter, okvis_ba_summary* summaries) {
+  int rc = okvis_ba_begin(s);
+  if (rc != OKVIS_BA_OK) return rc;
+  rc = okvis_ba_iterate(s, num_iter);
+  if (rc != OKVIS_BA_OK) return rc;
+  return okvis_ba_finish(s, summaries);
+}
+
+int okvis_ba_optimize_timed(okvis_ba_solver* s, int max_iter, int min_iter, double time_limit_s,
+                            okvis_ba_summary* summaries) {
+  if (!s || max_iter < 0 || min_iter < 0) return OKVIS_BA_ERR_ARG;
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = okvis_ba_begin(s);
+  if (rc != OKVIS_BA_OK) return rc;
+  int done = 0;
+  if (time_limit_s < 0) {  // Estimator::setOptimizationTimeLimit: no limit -> min iterations = max iterations
+    rc = okvis_ba_iterate(s, max_iter);
+    if (rc != OKVIS_BA_OK) return rc;
+  } else {
+    const int first = std::min(min_iter, max_iter);
+    rc = okvis_ba_iterate(s, first);
+    if (rc != OKVIS_BA_OK) return rc;
+    done = first;
+    // CeresIterationCallback.hpp:77-86: stop once iteration >= min and the time budget is exceeded
+    while (done < max_iter) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (done >= min_iter && el > time_limit_s) break;
+      rc = okvis_ba_iterate(s, 1);
+      if (rc != OKVIS_BA_OK) return rc;
+      ++done;
+    }
+  }
+  return okvis_ba_finish(s, summaries);
+}
+
+int okvis_ba_evaluate_cost(okvis_ba_solver* s, double* costs) {
+  if (!s || !costs) return OKVIS_BA_ERR_ARG;
+  int rc = okvis_ba_begin(s);
+  if (rc != OKVIS_BA_OK) return rc;
+  std::vector<okvis_ba_summary> sum(s->wins.size());
+  rc = okvis_ba_finish(s, sum.data());
+  if (rc != OKVIS_BA_OK) return rc;
+  for (size_t i = 0; i < sum.size(); ++i) costs[i] = sum[i].final_cost;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_reduced_dim(okvis_ba_solver* s, int w, int32_t* dim) {
+  if (!s || !dim || w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
+  *dim = s->wins[w].D;
+  return OKVIS_BA_OK;
+}
+int okvis_ba_pair_count(okvis_ba_solver* s, int w, int32_t* n_pair) {
+  if (!s || !n_pair || w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
+  *n_pair = s->wins[w].n_pair;
+  return OKVIS_BA_OK;
+}
+int okvis_ba_pairs(okvis_ba_solver* s, int w, int32_t* pair_lm, int32_t* pair_block) {
+  if (!s || !pair_lm || !pair_block || w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
+  const HostWin& H = s->wins[w];
+  for (int i = 0; i < H.n_pair; ++i) {
+    pair_lm[i] = H.pair_lm[i];
+    pair_block[i] = H.pair_block[i];
+  }
+  return OKVIS_BA_OK;
+}
+
+static int locate(okvis_ba_solver* s, int w, int which, const double** ptr, int64_t* n) {
+  const HostWin& H = s->wins[w];
+  const WinPtrs& P = H.ptrs;
+  const int a = H.acc;
+  switch (which) {
+    case OKVIS_BA_ARR_POSE: *ptr = P.pose[a]; *n = 7 * (int64_t)H.n_pose; return 0;
+    case OKVIS_BA_ARR_SB: *ptr = P.sb[a]; *n = 9 * (int64_t)H.n_sb; return 0;
+    case OKVIS_BA_ARR_LM: *ptr = P.lm[a]; *n = 4 * (int64_t)H.n_lm; return 0;
+    case OKVIS_BA_ARR_OBS_RESIDUAL: *ptr = P.obs_r[a]; *n = 2 * (int64_t)H.n_obs; return P.obs_r[a] ? 0 : OKVIS_BA_ERR_STATE;
+    case OKVIS_BA_ARR_LM_V: *ptr = P.V[a]; *n = 6 * (int64_t)H.n_lm; return 0;
+    case OKVIS_BA_ARR_LM_B: *ptr = P.bl[a]; *n = 3 * (int64_t)H.n_lm; return 0;
+    case OKVIS_BA_ARR_LM_HQ: *ptr = P.Hq[a]; *n = 6 * (int64_t)H.n_lm; return 0;
+    case OKVIS_BA_ARR_PAIR_W: *ptr = P.W[a]; *n = 18 * (int64_t)H.n_pair; return 0;
+    case OKVIS_BA_ARR_REDUCED_S: *ptr = P.S; *n = (int64_t)H.D * H.D; return P.S ? 0 : OKVIS_BA_ERR_STATE;
+    case OKVIS_BA_ARR_REDUCED_RHS: *ptr = P.rhs; *n = H.D; return P.rhs ? 0 : OKVIS_BA_ERR_STATE;
+    case OKVIS_BA_ARR_STEP: *ptr = P.step; *n = H.D; return 0;
+    case OKVIS_BA_ARR_LM_QUALITY: *ptr = P.quality; *n = H.n_lm; return 0;
+    case OKVIS_BA_ARR_GRADIENT: *ptr = P.grad; *n = H.D; return 0;
+    case OKVIS_BA_ARR_DAMPING: *ptr = P.Dp2; *n = H.D; return P.Dp2 ? 0 : OKVIS_BA_ERR_STATE;
+    case OKVIS_BA_ARR_IMU_RESIDUAL: *ptr = nullptr; *n = 15 * (int64_t)H.n_imu; return 0;
+  }
+  return OKVIS_BA_ERR_ARG;
+}
+
+int okvis_ba_array_size(okvis_ba_solver* s, int w, int which, int64_t* n_doubles) {
+  if (!s || !n_doubles || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
+  const double* p;
+  return locate(s, w, which, &p, n_doubles);
+}
+
+int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t n_doubles) {
+  if (!s || !out || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  const double* p = nullptr;
+  int64_t n = 0;
+  if (int rc0 = refresh_acc(s, w)) return rc0;
+  int rc = locate(s, w, which, &p, &n);
+  if (rc != 0) return rc;
+  if (n != n_doubles) return OKVIS_BA_ERR_ARG;
+  if (which == OKVIS_BA_ARR_IMU_RESIDUAL) {
+    const HostWin& H = s->wins[w];
+    for (int f = 0; f < H.n_imu; ++f)
+      HIP_TRY(hipMemcpy(out + 15 * f, H.ptrs.imu_lin[H.acc] + (size_t)f * IMU_LIN_STRIDE + 450, 15 * 8, hipMemcpyDeviceToHost));
+    return OKVIS_BA_OK;
+  }
+  if (n > 0) HIP_TRY(hipMemcpy(out, p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4) {
+  if (!s || !ms4 || n <= 0) return OKVIS_BA_ERR_ARG;
+  if (!s->begun) return OKVIS_BA_ERR_STATE;
+  HIP_TRY(hipSetDevice(s->device));
+  std::vector<hipEvent_t> ev(5);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  for (int k = 0; k < 4; ++k) ms4[k] = 0.f;
+  for (int i = 0; i < n; ++i) {
+    HIP_TRY(hipEventRecord(ev[0], s->stream));
+    HIP_TRY(launch_schur(s));
+    HIP_TRY(hipEventRecord(ev[1], s->stream));
+    HIP_TRY(launch_solve(s, 0));
+    HIP_TRY(hipEventRecord(ev[2], s->stream));
+    HIP_TRY(launch_small(s, 0));
+    HIP_TRY(hipEventRecord(ev[3], s->stream));
+    HIP_TRY(launch_lin(s, 0));
+    HIP_TRY(hipEventRecord(ev[4], s->stream));
+    HIP_TRY(hipEventSynchronize(ev[4]));
+    for (int k = 0; k < 4; ++k) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, ev[k], ev[k + 1]));
+      ms4[k] += t;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_algorithmic_bytes(okvis_ba_solver* s, int64_t* lin, int64_t* schur, int64_t* solve, int64_t* small) {
+  if (!s || !s->uploaded) return OKVIS_BA_ERR_ARG;
+  int64_t a = 0, b = 0, c = 0, d = 0;
+  for (auto& H : s->wins) {
+    a += H.bytes_lin;
+    b += H.bytes_schur;
+    c += H.bytes_solve;
+    d += H.bytes_small;
+  }
+  if (lin) *lin = a;
+  if (schur) *schur = b;
+  if (solve) *solve = c;
+  if (small) *small = d;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_synchronize(okvis_ba_solver* s) {
+  if (!s) return OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return OKVIS_BA_OK;
+}
+
+}  // extern "C"

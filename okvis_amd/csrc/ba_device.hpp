@@ -1,0 +1,103 @@
+// Wave/workgroup helpers and the trust-region decision shared by all kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ba_math.hpp"
+#include "ba_types.hpp"
+
+namespace ba {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Sums of the per-group / per-factor partials of linearisation buffer `buf`, computed by ONE full wave
+// in a fixed order (lane-strided accumulation + xor butterfly) so that the Schur kernel and the solve
+// kernel obtain bit-identical values.  out: cost, g.delta (landmarks), delta^T D^2 delta, |delta|^2,
+// |x|^2, max|g_l|.
+__device__ __forceinline__ void wave_trial_sums(const WinPtrs& W, int buf, int lane, double out[6]) {
+  double cost = 0, gd = 0, ddd = 0, s2 = 0, x2 = 0, gm = 0;
+  const double* gs = W.gscal[buf];
+  for (int g = lane; g < W.n_group; g += 64) {
+    const double* p = gs + (size_t)g * GS_COUNT;
+    cost += p[GS_COST];
+    gd += p[GS_GD];
+    ddd += p[GS_DDD];
+    s2 += p[GS_STEP2];
+    x2 += p[GS_X2];
+    gm = fmax(gm, p[GS_GMAX]);
+  }
+  for (int f = lane; f < W.n_imu; f += 64) cost += W.imu_lin[buf][(size_t)f * IMU_LIN_STRIDE + 15 * 30 + 15];
+  if (lane == 0) cost += W.small_cost[buf][0];
+  out[0] = wave_sum(cost);
+  out[1] = wave_sum(gd);
+  out[2] = wave_sum(ddd);
+  out[3] = wave_sum(s2);
+  out[4] = wave_sum(x2);
+  out[5] = wave_max(gm);
+}
+
+struct Decision {
+  int accept;     // 1 = the pending trial becomes the accepted state
+  int term;       // 0 = continue, else termination reason (3 parameter tol, 4 radius, 5 numeric)
+  double radius, decrease_factor;
+  double rho, model_change;
+};
+
+// Accept/reject + trust-region radius update for the pending trial (Ceres LevenbergMarquardtStrategy
+// StepAccepted/StepRejected + TrustRegionMinimizer step evaluation, restated; DESIGN.md "solver policy").
+// Not inlined and contraction-free so that every kernel evaluating it gets the same bits.
+__device__ __noinline__ void decide(const Ctrl* c, const OptD* o, const double sums[6], Decision* d) {
+#pragma clang fp contract(off)
+  d->accept = 0;
+  d->term = 0;
+  d->radius = c->radius;
+  d->decrease_factor = c->decrease_factor;
+  d->rho = 0;
+  d->model_change = 0;
+  if (c->first) {
+    d->accept = 1;
+    return;
+  }
+  const double gd = c->gd_p + sums[1];
+  const double ddd = c->ddd_p + sums[2];
+  const double step2 = c->step2_p + sums[3];
+  const double x2 = c->x2_p + sums[4];
+  const double model = -0.5 * gd + 0.5 * c->lambda * ddd;
+  d->model_change = model;
+  if (!(model > 0.0)) {  // invalid step: handled like a rejected one
+    d->radius = c->radius / c->decrease_factor;
+    d->decrease_factor = c->decrease_factor * 2.0;
+    if (d->radius < o->min_radius) d->term = 5;
+    return;
+  }
+  if (o->parameter_tolerance > 0.0 &&
+      sqrt(step2) <= o->parameter_tolerance * (sqrt(x2) + o->parameter_tolerance)) {
+    d->term = 3;
+    return;
+  }
+  const double rho = (c->cost - sums[0]) / model;
+  d->rho = rho;
+  if (rho > o->min_relative_decrease) {
+    d->accept = 1;
+    const double t = 2.0 * rho - 1.0;
+    double r = c->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+    d->radius = fmin(o->max_radius, r);
+    d->decrease_factor = 2.0;
+  } else {
+    d->radius = c->radius / c->decrease_factor;
+    d->decrease_factor = c->decrease_factor * 2.0;
+    if (d->radius < o->min_radius) d->term = 4;
+  }
+}
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+}  // namespace ba

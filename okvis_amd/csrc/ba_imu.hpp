@@ -1,0 +1,758 @@
+// Kernel 4 — IMU factors, small priors and the marginalisation prior at the trial state (fp64).
+//
+// grid.x = n_imu workgroups (one per ImuError) + 1 workgroup for all PoseError / SpeedAndBiasError /
+// RelativePoseError / MarginalizationError terms of the window.
+//
+// IMU workgroup (ImuError::EvaluateWithMinimalJacobians, ImuError.cpp:514-685):
+//   * bias check |b_g - b_g,ref| * dt > 1e-4 (or first use) -> on-device re-preintegration
+//     (ImuError::redoPreintegration, ImuError.cpp:76-284), parallel over the raw samples:
+//       per-sample quantities in parallel, the ordered prefix products/sums by one work-item per sample
+//       (O(n^2) adds but only n deep), the 15x15 covariance recursion P <- F P F^T + Q with one
+//       work-item per matrix entry (2 barriers per sample), then P^-1 and its Cholesky factor in LDS.
+//     The cache (the reference's `mutable` members) lives in HBM and persists across iterations,
+//     including across rejected steps — exactly the reference's behaviour.
+//   * residual (15) and the 15x30 minimal Jacobian  sqrtInfo * [F0 | F1]
+#pragma once
+#include "ba_device.hpp"
+
+namespace ba {
+
+constexpr int IMU_N = 128;  // max integration steps handled (MAX per factor)
+// LDS layout (doubles) of the re-preintegration scratch, SoA over steps
+struct ImuLds {
+  static constexpr int DQ = 0;                   // 4N
+  static constexpr int DT = DQ + 4 * IMU_N;      // N
+  static constexpr int AB = DT + IMU_N;          // 3N   bias-corrected mean acceleration
+  static constexpr int JRDT = AB + 3 * IMU_N;    // 9N   rightJacobian(omega dt) * dt
+  static constexpr int RINV = JRDT + 9 * IMU_N;  // 9N   R(dq^-1); later aliased by dp_term
+  static constexpr int DQP = RINV + 9 * IMU_N;   // 4(N+1) prefix products Delta_q_k
+  static constexpr int CINT = DQP + 4 * (IMU_N + 1);  // 9N  0.5 (C+C1) dt
+  static constexpr int AINT = CINT + 9 * IMU_N;  // 3N
+  static constexpr int DAL = AINT + 3 * IMU_N;   // 9N   C1 Jr dt
+  static constexpr int C1 = DAL + 9 * IMU_N;     // 9N
+  static constexpr int ADBL = C1 + 9 * IMU_N;    // 3N
+  static constexpr int CDBL = ADBL + 3 * IMU_N;  // 9N
+  static constexpr int B012 = CDBL + 9 * IMU_N;  // 9N
+  static constexpr int GG = B012 + 9 * IMU_N;    // 9N
+  static constexpr int DVT = GG + 9 * IMU_N;     // 9N
+  static constexpr int SG2 = DVT + 9 * IMU_N;    // N
+  static constexpr int SA2 = SG2 + IMU_N;        // N
+  static constexpr int PM = SA2 + IMU_N;         // 225
+  static constexpr int TM = PM + 225;            // 225
+  static constexpr int FM = TM + 225;            // 450  F = [F0 | F1]
+  static constexpr int EV = FM + 450;            // 16   error vector
+  static constexpr int CA = EV + 16;             // cache copy: see below (300)
+  static constexpr int TOTAL = CA + 320;
+};
+// cache copy offsets inside CA
+enum { CA_DQ = 0, CA_CI = 4, CA_CD = 13, CA_AI = 22, CA_AD = 25, CA_DA = 28, CA_DV = 37, CA_DP = 46, CA_SI = 55 };
+
+__device__ __forceinline__ void ld9(const double* p, int k, double* o) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o[i] = p[9 * k + i];
+}
+__device__ __forceinline__ void st9(double* p, int k, const double* o) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) p[9 * k + i] = o[i];
+}
+
+// (F_k X)_(i, col) for the sparse F_delta of ImuError.cpp:209-226 applied to column `col` of X (15x15)
+__device__ __forceinline__ double imu_F_apply(const double* X, int i, int col, const double* adbl, double dt,
+                                              const double* dpt, const double* b012, const double* c1,
+                                              const double* aint, const double* dvt, const double* cint) {
+  double v = X[15 * i + col];
+  if (i < 3) {
+    // block(0,3) = -[adbl]x ; (0,6) = dt I ; (0,9) = dp_term ; (0,12) = b012
+    double cx[9];
+    cross_mx(adbl, cx);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      v -= cx[3 * i + m] * X[15 * (3 + m) + col];
+      v += dpt[3 * i + m] * X[15 * (9 + m) + col];
+      v += b012[3 * i + m] * X[15 * (12 + m) + col];
+    }
+    v += dt * X[15 * (6 + i) + col];
+  } else if (i < 6) {
+    const int r = i - 3;  // block(3,9) = -dt C1
+#pragma unroll
+    for (int m = 0; m < 3; ++m) v -= dt * c1[3 * r + m] * X[15 * (9 + m) + col];
+  } else if (i < 9) {
+    const int r = i - 6;  // (6,3) = -[aint]x ; (6,9) = dv_term ; (6,12) = -cint
+    double cx[9];
+    cross_mx(aint, cx);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      v -= cx[3 * r + m] * X[15 * (3 + m) + col];
+      v += dvt[3 * r + m] * X[15 * (9 + m) + col];
+      v -= cint[3 * r + m] * X[15 * (12 + m) + col];
+    }
+  }
+  return v;
+}
+
+// in-place Cholesky of a 15x15 SPD matrix in LDS by 225 work-items (A row-major, lower triangle = L)
+__device__ __forceinline__ void chol15(double* A, int e) {
+  const int i = e / 15, j = e % 15;
+  for (int k = 0; k < 15; ++k) {
+    __syncthreads();
+    if (e == 16 * k) A[e] = sqrt(A[e]);
+    __syncthreads();
+    if (e < 225 && j == k && i > k) A[e] /= A[16 * k];
+    __syncthreads();
+    if (e < 225 && j > k && i >= j) A[e] -= A[15 * i + k] * A[15 * j + k];
+  }
+  __syncthreads();
+}
+
+__device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds, int tid) {
+  __shared__ int s_it[IMU_N], s_flag[IMU_N];
+  __shared__ long long s_ts[IMU_N], s_tn[IMU_N];
+  __shared__ int s_nsteps;
+  const int n = W.imu_s_count[f];
+  const long long* ts = W.imu_s_t + W.imu_s_begin[f];
+  const double* gyr = W.imu_s_gyr + 3 * (size_t)W.imu_s_begin[f];
+  const double* acc = W.imu_s_acc + 3 * (size_t)W.imu_s_begin[f];
+  const long long t0 = W.imu_t0[f], t1 = W.imu_t1[f];
+  // ---- stage 0: loop control of ImuError.cpp:113-150,259-260 (integer time logic) by one work-item
+  if (tid == 0) {
+    long long time = t0;
+    bool started = false;
+    int k = 0;
+    for (int it = 0; it < n && k < IMU_N; ++it) {
+      long long nexttime = (it + 1 == n) ? t1 : ts[it + 1];
+      int flag = 0;
+      if (t1 < nexttime) {
+        nexttime = t1;
+        flag |= 1;  // interpolate the second sample to t1
+      }
+      if (nexttime - time <= 0) continue;
+      if (!started) {
+        started = true;
+        flag |= 2;  // interpolate the first sample to t0
+      }
+      s_it[k] = it;
+      s_flag[k] = flag;
+      s_ts[k] = time;
+      s_tn[k] = nexttime;
+      ++k;
+      time = nexttime;
+      if (nexttime == t1) break;
+    }
+    s_nsteps = k;
+  }
+  __syncthreads();
+  const int ns = s_nsteps;
+  const ImuParamsD prm = W.imu;
+  const double bg[3] = {sb0[3], sb0[4], sb0[5]}, ba[3] = {sb0[6], sb0[7], sb0[8]};
+  // ---- stage 1: per-step quantities
+  if (tid < ns) {
+    const int it = s_it[tid];
+    const int nx = (it + 1 < n) ? it + 1 : it;
+    double w0[3] = {gyr[3 * it], gyr[3 * it + 1], gyr[3 * it + 2]};
+    double a0[3] = {acc[3 * it], acc[3 * it + 1], acc[3 * it + 2]};
+    double w1[3] = {gyr[3 * nx], gyr[3 * nx + 1], gyr[3 * nx + 2]};
+    double a1[3] = {acc[3 * nx], acc[3 * nx + 1], acc[3 * nx + 2]};
+    const double dt = ns_to_sec(s_tn[tid] - s_ts[tid]);
+    if (s_flag[tid] & 1) {
+      const long long raw_next = (it + 1 == n) ? t1 : ts[it + 1];
+      const double interval = ns_to_sec(raw_next - ts[it]);
+      const double r = dt / interval;
+      for (int c = 0; c < 3; ++c) {
+        w1[c] = (1.0 - r) * w0[c] + r * w1[c];
+        a1[c] = (1.0 - r) * a0[c] + r * a1[c];
+      }
+    }
+    if (s_flag[tid] & 2) {
+      const double r = dt / ns_to_sec(s_tn[tid] - ts[it]);
+      for (int c = 0; c < 3; ++c) {
+        w0[c] = r * w0[c] + (1.0 - r) * w1[c];
+        a0[c] = r * a0[c] + (1.0 - r) * a1[c];
+      }
+    }
+    double sg = prm.sigma_g_c, sa = prm.sigma_a_c;
+    bool gs = false, as = false;
+    for (int c = 0; c < 3; ++c) {
+      gs = gs || fabs(w0[c]) > prm.g_max || fabs(w1[c]) > prm.g_max;
+      as = as || fabs(a0[c]) > prm.a_max || fabs(a1[c]) > prm.a_max;
+    }
+    if (gs) sg *= 100;
+    if (as) sa *= 100;
+    double om[3], ab[3];
+    for (int c = 0; c < 3; ++c) {
+      om[c] = 0.5 * (w0[c] + w1[c]) - bg[c];
+      ab[c] = 0.5 * (a0[c] + a1[c]) - ba[c];
+    }
+    const double th = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]) * 0.5 * dt;
+    const double sc = sinc(th), ct = cos(th);
+    double dq[4] = {sc * om[0] * 0.5 * dt, sc * om[1] * 0.5 * dt, sc * om[2] * 0.5 * dt, ct};
+    double phi[3] = {om[0] * dt, om[1] * dt, om[2] * dt};
+    double Jr[9], dqi[4], Ri[9];
+    right_jacobian(phi, Jr);
+    for (int c = 0; c < 9; ++c) Jr[c] *= dt;
+    qinv(dq, dqi);
+    qrot(dqi, Ri);
+    for (int c = 0; c < 4; ++c) lds[ImuLds::DQ + 4 * tid + c] = dq[c];
+    lds[ImuLds::DT + tid] = dt;
+    for (int c = 0; c < 3; ++c) lds[ImuLds::AB + 3 * tid + c] = ab[c];
+    st9(lds + ImuLds::JRDT, tid, Jr);
+    st9(lds + ImuLds::RINV, tid, Ri);
+    lds[ImuLds::SG2 + tid] = dt * sg * sg;
+    lds[ImuLds::SA2 + tid] = dt * sa * sa;
+  }
+  __syncthreads();
+  // ---- stage 2: Delta_q_k = dq_0 (x) ... (x) dq_(k-1), same product order as the reference
+  if (tid <= ns) {
+    double q[4] = {0, 0, 0, 1};
+    for (int j = 0; j < tid; ++j) {
+      double t[4];
+      qmul(q, lds + ImuLds::DQ + 4 * j, t);
+      q[0] = t[0]; q[1] = t[1]; q[2] = t[2]; q[3] = t[3];
+    }
+    for (int c = 0; c < 4; ++c) lds[ImuLds::DQP + 4 * tid + c] = q[c];
+  }
+  __syncthreads();
+  // ---- stage 3
+  double C[9], CC[9], dt = 0, ab[3] = {0, 0, 0};
+  if (tid < ns) {
+    double C1m[9];
+    qrot(lds + ImuLds::DQP + 4 * tid, C);
+    qrot(lds + ImuLds::DQP + 4 * (tid + 1), C1m);
+    dt = lds[ImuLds::DT + tid];
+    for (int c = 0; c < 3; ++c) ab[c] = lds[ImuLds::AB + 3 * tid + c];
+    for (int c = 0; c < 9; ++c) CC[c] = C[c] + C1m[c];
+    double t9[9], t3[3], h[9];
+    for (int c = 0; c < 9; ++c) h[c] = 0.5 * CC[c];
+    for (int c = 0; c < 9; ++c) t9[c] = h[c] * dt;
+    st9(lds + ImuLds::CINT, tid, t9);
+    mat3_vec(h, ab, t3);
+    for (int c = 0; c < 3; ++c) lds[ImuLds::AINT + 3 * tid + c] = t3[c] * dt;
+    double Jr[9];
+    ld9(lds + ImuLds::JRDT, tid, Jr);
+    mat3_mul(C1m, Jr, t9);
+    st9(lds + ImuLds::DAL, tid, t9);
+    st9(lds + ImuLds::C1, tid, C1m);
+  }
+  __syncthreads();
+  // ---- stage 4: ordered prefix sums + the cross recursion (registers)
+  double Cint[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, aint[3] = {0, 0, 0}, cross[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid < ns) {
+    for (int j = 0; j < tid; ++j) {
+      for (int c = 0; c < 9; ++c) Cint[c] += lds[ImuLds::CINT + 9 * j + c];
+      for (int c = 0; c < 3; ++c) aint[c] += lds[ImuLds::AINT + 3 * j + c];
+      double Ri[9], t9[9];
+      ld9(lds + ImuLds::RINV, j, Ri);
+      mat3_mul(Ri, cross, t9);
+      for (int c = 0; c < 9; ++c) cross[c] = t9[c] + lds[ImuLds::JRDT + 9 * j + c];
+    }
+  }
+  // ---- stage 5
+  double G[9];
+  if (tid < ns) {
+    double q[9], t3[3], t9[9];
+    for (int c = 0; c < 9; ++c) q[c] = 0.25 * CC[c];
+    mat3_vec(q, ab, t3);
+    for (int c = 0; c < 3; ++c) lds[ImuLds::ADBL + 3 * tid + c] = aint[c] * dt + t3[c] * dt * dt;
+    for (int c = 0; c < 9; ++c) t9[c] = Cint[c] * dt + q[c] * dt * dt;
+    st9(lds + ImuLds::CDBL, tid, t9);
+    for (int c = 0; c < 9; ++c) t9[c] = -Cint[c] * dt + q[c] * dt * dt;
+    st9(lds + ImuLds::B012, tid, t9);
+    double Ri[9], cross1[9], ax[9], C1m[9], u[9], v[9];
+    ld9(lds + ImuLds::RINV, tid, Ri);
+    mat3_mul(Ri, cross, cross1);
+    for (int c = 0; c < 9; ++c) cross1[c] += lds[ImuLds::JRDT + 9 * tid + c];
+    cross_mx(ab, ax);
+    ld9(lds + ImuLds::C1, tid, C1m);
+    mat3_mul(C, ax, u);
+    mat3_mul(u, cross, v);
+    for (int c = 0; c < 9; ++c) G[c] = v[c];
+    mat3_mul(C1m, ax, u);
+    mat3_mul(u, cross1, v);
+    for (int c = 0; c < 9; ++c) G[c] += v[c];
+    st9(lds + ImuLds::GG, tid, G);
+    for (int c = 0; c < 9; ++c) t9[c] = 0.5 * dt * G[c];
+    st9(lds + ImuLds::DVT, tid, t9);
+  }
+  __syncthreads();
+  // ---- stage 6: dp_term (aliases RINV, no longer needed)
+  if (tid < ns) {
+    double dv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t9[9];
+    for (int j = 0; j < tid; ++j)
+      for (int c = 0; c < 9; ++c) dv[c] += lds[ImuLds::DVT + 9 * j + c];
+    for (int c = 0; c < 9; ++c) t9[c] = dt * dv[c] + 0.25 * dt * dt * G[c];
+    st9(lds + ImuLds::RINV, tid, t9);
+  }
+  __syncthreads();
+  // ---- stage 7: totals -> cache copy in LDS
+  double* ca = lds + ImuLds::CA;
+  if (tid < 51) {
+    int base, stride, comp, dst;
+    if (tid < 9) { base = ImuLds::CINT; stride = 9; comp = tid; dst = CA_CI + tid; }
+    else if (tid < 18) { base = ImuLds::CDBL; stride = 9; comp = tid - 9; dst = CA_CD + tid - 9; }
+    else if (tid < 21) { base = ImuLds::AINT; stride = 3; comp = tid - 18; dst = CA_AI + tid - 18; }
+    else if (tid < 24) { base = ImuLds::ADBL; stride = 3; comp = tid - 21; dst = CA_AD + tid - 21; }
+    else if (tid < 33) { base = ImuLds::DAL; stride = 9; comp = tid - 24; dst = CA_DA + tid - 24; }
+    else if (tid < 42) { base = ImuLds::DVT; stride = 9; comp = tid - 33; dst = CA_DV + tid - 33; }
+    else { base = ImuLds::RINV; stride = 9; comp = tid - 42; dst = CA_DP + tid - 42; }
+    double s = 0;
+    for (int k = 0; k < ns; ++k) s += lds[base + stride * k + comp];
+    ca[dst] = s;
+  } else if (tid < 55) {
+    ca[CA_DQ + tid - 51] = lds[ImuLds::DQP + 4 * ns + (tid - 51)];
+  }
+  // ---- stage 8: covariance recursion
+  double* P = lds + ImuLds::PM;
+  double* T = lds + ImuLds::TM;
+  if (tid < 225) P[tid] = 0.0;
+  __syncthreads();
+  const int pi = tid / 15, pj = tid % 15;
+  for (int k = 0; k < ns; ++k) {
+    const double* adbl = lds + ImuLds::ADBL + 3 * k;
+    const double* dpt = lds + ImuLds::RINV + 9 * k;
+    const double* b012 = lds + ImuLds::B012 + 9 * k;
+    const double* c1 = lds + ImuLds::C1 + 9 * k;
+    const double* ai = lds + ImuLds::AINT + 3 * k;
+    const double* dvt = lds + ImuLds::DVT + 9 * k;
+    const double* ci = lds + ImuLds::CINT + 9 * k;
+    const double dtk = lds[ImuLds::DT + k];
+    if (tid < 225) T[tid] = imu_F_apply(P, pi, pj, adbl, dtk, dpt, b012, c1, ai, dvt, ci);
+    __syncthreads();
+    if (tid < 225) {
+      // (T F^T)_ij = (F T^T)_ji : apply F to column i of T^T, i.e. row i of T
+      // X := T^T  => X[15*m + i] = T[15*i + m]; evaluate row pj of F against it.
+      double v = T[15 * pi + pj];
+      if (pj < 3) {
+        double cx[9];
+        cross_mx(adbl, cx);
+        for (int m = 0; m < 3; ++m) {
+          v -= cx[3 * pj + m] * T[15 * pi + 3 + m];
+          v += dpt[3 * pj + m] * T[15 * pi + 9 + m];
+          v += b012[3 * pj + m] * T[15 * pi + 12 + m];
+        }
+        v += dtk * T[15 * pi + 6 + pj];
+      } else if (pj < 6) {
+        const int r = pj - 3;
+        for (int m = 0; m < 3; ++m) v -= dtk * c1[3 * r + m] * T[15 * pi + 9 + m];
+      } else if (pj < 9) {
+        const int r = pj - 6;
+        double cx[9];
+        cross_mx(ai, cx);
+        for (int m = 0; m < 3; ++m) {
+          v -= cx[3 * r + m] * T[15 * pi + 3 + m];
+          v += dvt[3 * r + m] * T[15 * pi + 9 + m];
+          v -= ci[3 * r + m] * T[15 * pi + 12 + m];
+        }
+      }
+      if (pi == pj) {  // noise (ImuError.cpp:228-249)
+        const double s2a = lds[ImuLds::SG2 + k], s2v = lds[ImuLds::SA2 + k];
+        if (pi < 3) v += 0.5 * dtk * dtk * s2v;
+        else if (pi < 6) v += s2a;
+        else if (pi < 9) v += s2v;
+        else if (pi < 12) v += dtk * prm.sigma_gw_c * prm.sigma_gw_c;
+        else v += dtk * prm.sigma_aw_c * prm.sigma_aw_c;
+      }
+      P[tid] = v;
+    }
+    __syncthreads();
+  }
+  // ---- stage 9: information = sym(P)^-1, sqrtInfo = chol(sym(information))^T  (ImuError.cpp:268-279)
+  if (tid < 225) T[tid] = 0.5 * P[15 * pi + pj] + 0.5 * P[15 * pj + pi];
+  __syncthreads();
+  chol15(T, tid);  // T lower = L
+  // Linv (lower) into P: column c solved by work-item c
+  if (tid < 225) P[tid] = 0.0;
+  __syncthreads();
+  if (tid < 15) {
+    const int cidx = tid;
+    for (int i = cidx; i < 15; ++i) {
+      double s = (i == cidx) ? 1.0 : 0.0;
+      for (int m = cidx; m < i; ++m) s -= T[15 * i + m] * P[15 * m + cidx];
+      P[15 * i + cidx] = s / T[15 * i + i];
+    }
+  }
+  __syncthreads();
+  // information = Linv^T Linv (symmetric by construction)
+  double info = 0;
+  if (tid < 225) {
+    const int lo = pi > pj ? pi : pj;
+    for (int m = lo; m < 15; ++m) info += P[15 * m + pi] * P[15 * m + pj];
+  }
+  __syncthreads();
+  if (tid < 225) T[tid] = info;
+  __syncthreads();
+  chol15(T, tid);
+  if (tid < 225) ca[CA_SI + 15 * pi + pj] = (pj >= pi) ? T[15 * pj + pi] : 0.0;  // upper = L^T
+  __syncthreads();
+  // ---- write the cache back to HBM
+  ImuCacheD* cg = W.imu_cache + f;
+  if (tid < 4) cg->Delta_q[tid] = ca[CA_DQ + tid];
+  if (tid < 9) {
+    cg->C_integral[tid] = ca[CA_CI + tid];
+    cg->C_doubleintegral[tid] = ca[CA_CD + tid];
+    cg->dalpha_db_g[tid] = ca[CA_DA + tid];
+    cg->dv_db_g[tid] = ca[CA_DV + tid];
+    cg->dp_db_g[tid] = ca[CA_DP + tid];
+    cg->sb_ref[tid] = sb0[tid];
+  }
+  if (tid < 3) {
+    cg->acc_integral[tid] = ca[CA_AI + tid];
+    cg->acc_doubleintegral[tid] = ca[CA_AD + tid];
+  }
+  if (tid < 225) cg->sqrt_info[tid] = ca[CA_SI + tid];
+  if (tid == 0) {
+    cg->valid = 1;
+    cg->redo_count += 1;
+  }
+  __syncthreads();
+}
+
+__device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int tid) {
+  __shared__ int s_redo;
+  __shared__ double s_db[6];
+  double* ca = lds + ImuLds::CA;
+  const double* p0 = W.pose[trial] + 7 * (size_t)W.imu_pose0[f];
+  const double* p1 = W.pose[trial] + 7 * (size_t)W.imu_pose1[f];
+  const double* b0 = W.sb[trial] + 9 * (size_t)W.imu_sb0[f];
+  const double* b1 = W.sb[trial] + 9 * (size_t)W.imu_sb1[f];
+  double sb0[9];
+  for (int i = 0; i < 9; ++i) sb0[i] = b0[i];
+  const double Dt = ns_to_sec(W.imu_t1[f] - W.imu_t0[f]);
+  const ImuCacheD* cg = W.imu_cache + f;
+  if (tid == 0) {
+    double db[6];
+    for (int i = 0; i < 6; ++i) db[i] = sb0[3 + i] - cg->sb_ref[3 + i];
+    const double nbg = sqrt(db[0] * db[0] + db[1] * db[1] + db[2] * db[2]);
+    const int redo = (!cg->valid) || (nbg * Dt > 0.0001);  // ImuError.cpp:549
+    s_redo = redo;
+    for (int i = 0; i < 6; ++i) s_db[i] = redo ? 0.0 : db[i];
+  }
+  __syncthreads();
+  if (s_redo) {
+    imu_redo(W, f, sb0, lds, tid);
+  } else {
+    // load the cache into LDS
+    if (tid < 4) ca[CA_DQ + tid] = cg->Delta_q[tid];
+    if (tid < 9) {
+      ca[CA_CI + tid] = cg->C_integral[tid];
+      ca[CA_CD + tid] = cg->C_doubleintegral[tid];
+      ca[CA_DA + tid] = cg->dalpha_db_g[tid];
+      ca[CA_DV + tid] = cg->dv_db_g[tid];
+      ca[CA_DP + tid] = cg->dp_db_g[tid];
+    }
+    if (tid < 3) {
+      ca[CA_AI + tid] = cg->acc_integral[tid];
+      ca[CA_AD + tid] = cg->acc_doubleintegral[tid];
+    }
+    if (tid < 225) ca[CA_SI + tid] = cg->sqrt_info[tid];
+    __syncthreads();
+  }
+  // ---- F = [F0 | F1] and the error vector by one work-item (ImuError.cpp:561-601)
+  double* F = lds + ImuLds::FM;
+  double* ev = lds + ImuLds::EV;
+  for (int i = tid; i < 450; i += IMU_THREADS) F[i] = 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    double q0[4] = {p0[3], p0[4], p0[5], p0[6]}, q1[4] = {p1[3], p1[4], p1[5], p1[6]};
+    qnormalize(q0);
+    qnormalize(q1);
+    double C0[9];
+    qrot(q0, C0);
+    const double g = W.imu.g;
+    const double v0[3] = {sb0[0], sb0[1], sb0[2]};
+    const double v1[3] = {b1[0], b1[1], b1[2]};
+    double dp[3], dv[3];
+    for (int c = 0; c < 3; ++c) {
+      const double gw = (c == 2) ? g : 0.0;
+      dp[c] = p0[c] - p1[c] + v0[c] * Dt - 0.5 * gw * Dt * Dt;
+      dv[c] = v0[c] - v1[c] - gw * Dt;
+    }
+    const double* da = ca + CA_DA;
+    double dal[3];
+    for (int c = 0; c < 3; ++c) dal[c] = -(da[3 * c] * s_db[0] + da[3 * c + 1] * s_db[1] + da[3 * c + 2] * s_db[2]);
+    const double hn = 0.5 * sqrt(dal[0] * dal[0] + dal[1] * dal[1] + dal[2] * dal[2]);
+    const double sc = sinc(hn) * 0.5;
+    const double dqa[4] = {sc * dal[0], sc * dal[1], sc * dal[2], cos(hn)};
+    double Dq[4];
+    qmul(dqa, ca + CA_DQ, Dq);
+    double q1i[4];
+    qinv(q1, q1i);
+    auto Fset = [&](int r, int cidx, const double* M, double sgn) {
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) F[30 * (r + i) + cidx + j] = sgn * M[3 * i + j];
+    };
+    double C0T[9], t9[9], cx[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) C0T[3 * i + j] = C0[3 * j + i];
+    // F0 = I with blocks
+    for (int i = 0; i < 15; ++i) F[30 * i + i] = 1.0;
+    Fset(0, 0, C0T, 1.0);
+    cross_mx(dp, cx);
+    mat3_mul(C0T, cx, t9);
+    Fset(0, 3, t9, 1.0);
+    for (int c = 0; c < 9; ++c) t9[c] = C0T[c] * Dt;
+    Fset(0, 6, t9, 1.0);
+    Fset(0, 9, ca + CA_DP, 1.0);
+    Fset(0, 12, ca + CA_CD, -1.0);
+    {
+      double qa[4], A[16], B[16];
+      qmul(Dq, q1i, qa);
+      qplus44(qa, A);
+      qoplus44(q0, B);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double s = 0;
+          for (int m = 0; m < 4; ++m) s += A[4 * i + m] * B[4 * m + j];
+          t9[3 * i + j] = s;
+        }
+      Fset(3, 3, t9, 1.0);
+      double qb[4], M3[9];
+      qmul(q1i, q0, qb);
+      qoplus44(qb, A);
+      qoplus44(Dq, B);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double s = 0;
+          for (int m = 0; m < 4; ++m) s += A[4 * i + m] * B[4 * m + j];
+          M3[3 * i + j] = s;
+        }
+      mat3_mul(M3, da, t9);
+      Fset(3, 9, t9, -1.0);
+    }
+    cross_mx(dv, cx);
+    mat3_mul(C0T, cx, t9);
+    Fset(6, 3, t9, 1.0);
+    Fset(6, 6, C0T, 1.0);
+    Fset(6, 9, ca + CA_DV, 1.0);
+    Fset(6, 12, ca + CA_CI, -1.0);
+    // F1 = -I with blocks (columns 15..29)
+    for (int i = 0; i < 15; ++i) F[30 * i + 15 + i] = -1.0;
+    Fset(0, 15, C0T, -1.0);
+    Fset(6, 21, C0T, -1.0);
+    {
+      double A[16], B[16], Cq[16], AB[16];
+      qplus44(Dq, A);
+      qoplus44(q0, B);
+      qplus44(q1i, Cq);
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          double s = 0;
+          for (int m = 0; m < 4; ++m) s += A[4 * i + m] * B[4 * m + j];
+          AB[4 * i + j] = s;
+        }
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double s = 0;
+          for (int m = 0; m < 4; ++m) s += AB[4 * i + m] * Cq[4 * m + j];
+          t9[3 * i + j] = s;
+        }
+      Fset(3, 18, t9, -1.0);
+    }
+    // error vector (:597-601)
+    double e0[3], e2[3];
+    mat3_vec(C0T, dp, e0);
+    mat3_vec(C0T, dv, e2);
+    for (int i = 0; i < 3; ++i) {
+      double s0 = e0[i] + ca[CA_AD + i], s2 = e2[i] + ca[CA_AI + i];
+      for (int m = 0; m < 6; ++m) {
+        s0 += F[30 * i + 9 + m] * s_db[m];
+        s2 += F[30 * (6 + i) + 9 + m] * s_db[m];
+      }
+      ev[i] = s0;
+      ev[6 + i] = s2;
+    }
+    double qe[4], qt[4];
+    qmul(q1i, q0, qt);
+    qmul(Dq, qt, qe);
+    ev[3] = 2 * qe[0];
+    ev[4] = 2 * qe[1];
+    ev[5] = 2 * qe[2];
+    for (int i = 0; i < 6; ++i) ev[9 + i] = sb0[3 + i] - b1[3 + i];
+  }
+  __syncthreads();
+  // ---- J = sqrtInfo (upper) * F, r = sqrtInfo * e
+  double* out = W.imu_lin[trial] + (size_t)f * IMU_LIN_STRIDE;
+  const double* SI = ca + CA_SI;
+  for (int wi = tid; wi < 450; wi += IMU_THREADS) {
+    const int i = wi / 30, j = wi - 30 * i;
+    double s = 0;
+    for (int m = i; m < 15; ++m) s += SI[15 * i + m] * F[30 * m + j];
+    out[wi] = s;
+  }
+  __shared__ double s_r[16];
+  if (tid < 15) {
+    double s = 0;
+    for (int m = tid; m < 15; ++m) s += SI[15 * tid + m] * ev[m];
+    out[450 + tid] = s;
+    s_r[tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0;
+    for (int i = 0; i < 15; ++i) s += s_r[i] * s_r[i];
+    out[465] = 0.5 * s;
+  }
+}
+
+// all PoseError / SpeedAndBiasError / RelativePoseError / MarginalizationError terms of one window
+__device__ void small_factors(const WinPtrs& W, int trial, double* lds, int tid) {
+  __shared__ double s_cost[IMU_THREADS / 64];
+  double cost = 0;
+  const int np = W.n_pprior, nsb = W.n_sbprior, nr = W.n_rel;
+  for (int f = tid; f < np; f += IMU_THREADS) {
+    // PoseError.cpp:91-118
+    const double* x = W.pose[trial] + 7 * (size_t)W.pprior_pose[f];
+    const double* m = W.pprior_meas + 7 * (size_t)f;
+    const double* SI = W.pprior_sqrtinfo + 36 * (size_t)f;
+    double q[4] = {x[3], x[4], x[5], x[6]}, qm[4] = {m[3], m[4], m[5], m[6]};
+    qnormalize(q);
+    qnormalize(qm);
+    double qi[4], dq[4];
+    qinv(q, qi);
+    qnormalize(qi);
+    qmul(qm, qi, dq);
+    qnormalize(dq);
+    const double e[6] = {m[0] - x[0], m[1] - x[1], m[2] - x[2], 2 * dq[0], 2 * dq[1], 2 * dq[2]};
+    double J0[36];
+    for (int i = 0; i < 36; ++i) J0[i] = 0;
+    J0[0] = J0[7] = J0[14] = -1.0;
+    double P3[9];
+    qplus33(dq, P3);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) J0[6 * (3 + i) + 3 + j] = -P3[3 * i + j];
+    double* out = W.pp_lin[trial] + 42 * (size_t)f;
+    for (int i = 0; i < 6; ++i) {
+      double r = 0;
+      for (int k = 0; k < 6; ++k) r += SI[6 * i + k] * e[k];
+      out[36 + i] = r;
+      cost += 0.5 * r * r;
+      for (int j = 0; j < 6; ++j) {
+        double s = 0;
+        for (int k = 0; k < 6; ++k) s += SI[6 * i + k] * J0[6 * k + j];
+        out[6 * i + j] = s;
+      }
+    }
+  }
+  for (int f = tid; f < nsb; f += IMU_THREADS) {
+    // SpeedAndBiasError.cpp:93-101
+    const double* x = W.sb[trial] + 9 * (size_t)W.sbprior_sb[f];
+    const double* m = W.sbprior_meas + 9 * (size_t)f;
+    const double* SI = W.sbprior_sqrtinfo + 81 * (size_t)f;
+    double* out = W.sbp_lin[trial] + 9 * (size_t)f;
+    for (int i = 0; i < 9; ++i) {
+      double r = 0;
+      for (int k = 0; k < 9; ++k) r += SI[9 * i + k] * (m[k] - x[k]);
+      out[i] = r;
+      cost += 0.5 * r * r;
+    }
+  }
+  for (int f = tid; f < nr; f += IMU_THREADS) {
+    // RelativePoseError.cpp:88-159
+    const double* x0 = W.pose[trial] + 7 * (size_t)W.rel_pose0[f];
+    const double* x1 = W.pose[trial] + 7 * (size_t)W.rel_pose1[f];
+    const double* SI = W.rel_sqrtinfo + 36 * (size_t)f;
+    double q0[4] = {x0[3], x0[4], x0[5], x0[6]}, q1[4] = {x1[3], x1[4], x1[5], x1[6]};
+    qnormalize(q0);
+    qnormalize(q1);
+    double qi[4], dq[4];
+    qinv(q0, qi);
+    qnormalize(qi);
+    qmul(q1, qi, dq);
+    qnormalize(dq);
+    const double e[6] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2], 2 * dq[0], 2 * dq[1], 2 * dq[2]};
+    double P3[9], O3[9];
+    qplus33(dq, P3);
+    qoplus33(dq, O3);
+    double J[72];  // 6 x 12 = [J0 | J1] before weighting
+    for (int i = 0; i < 72; ++i) J[i] = 0;
+    for (int i = 0; i < 3; ++i) {
+      J[12 * i + i] = -1.0;
+      J[12 * i + 6 + i] = 1.0;
+      for (int j = 0; j < 3; ++j) {
+        J[12 * (3 + i) + 3 + j] = -P3[3 * i + j];
+        J[12 * (3 + i) + 9 + j] = O3[3 * i + j];
+      }
+    }
+    double* out = W.rel_lin[trial] + 78 * (size_t)f;
+    for (int i = 0; i < 6; ++i) {
+      double r = 0;
+      for (int k = 0; k < 6; ++k) r += SI[6 * i + k] * e[k];
+      out[72 + i] = r;
+      cost += 0.5 * r * r;
+      for (int j = 0; j < 12; ++j) {
+        double s = 0;
+        for (int k = 0; k < 6; ++k) s += SI[6 * i + k] * J[12 * k + j];
+        out[12 * i + j] = s;
+      }
+    }
+  }
+  // ---- marginalisation prior: e = e0 + J dchi, J^T e, rotation blocks (MarginalizationError.cpp:867-946)
+  if (W.marg_dim > 0) {
+    const int Dm = W.marg_dim, nb = W.marg_nb;
+    double* dchi = lds;          // Dm
+    double* ee = lds + Dm;       // Dm
+    for (int i = tid; i < Dm; i += IMU_THREADS) dchi[i] = 0.0;
+    __syncthreads();
+    for (int b = tid; b < nb; b += IMU_THREADS) {
+      const int idx = W.marg_block_idx[b], o = W.marg_block_off[b];
+      const double* xl = W.marg_lin + 9 * (size_t)b;
+      double* M = W.marg_lin_M[trial] + 9 * (size_t)b;
+      if (W.marg_block_type[b] == 0) {
+        const double* x = W.pose[trial] + 7 * (size_t)idx;
+        if (W.pose_off[idx] >= 0) {
+          double d[6];
+          pose_ominus(xl, x, d);
+          for (int k = 0; k < 6; ++k) dchi[o + k] = d[k];
+          const double qli[4] = {-xl[3], -xl[4], -xl[5], xl[6]};
+          double qd[4];
+          qmul(x + 3, qli, qd);
+          qoplus33(qd, M);
+        } else {
+          for (int k = 0; k < 9; ++k) M[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        }
+      } else {
+        const double* x = W.sb[trial] + 9 * (size_t)idx;
+        if (W.sb_off[idx] >= 0)
+          for (int k = 0; k < 9; ++k) dchi[o + k] = x[k] - xl[k];
+      }
+    }
+    __syncthreads();
+    for (int r = tid; r < Dm; r += IMU_THREADS) {
+      double s = W.marg_e0[r];
+      const double* Jr = W.marg_J + (size_t)r * Dm;
+      for (int cidx = 0; cidx < Dm; ++cidx) s += Jr[cidx] * dchi[cidx];
+      ee[r] = s;
+      W.marg_lin_e[trial][r] = s;
+      cost += 0.5 * s * s;
+    }
+    __syncthreads();
+    for (int cidx = tid; cidx < Dm; cidx += IMU_THREADS) {
+      double s = 0;
+      for (int r = 0; r < Dm; ++r) s += W.marg_J[(size_t)r * Dm + cidx] * ee[r];
+      W.marg_lin_e[trial][Dm + cidx] = s;
+    }
+  }
+  cost = wave_sum(cost);
+  if ((tid & 63) == 0) s_cost[tid >> 6] = cost;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0;
+    for (int i = 0; i < IMU_THREADS / 64; ++i) s += s_cost[i];
+    W.small_cost[trial][0] = s;
+  }
+}
+
+__global__ __launch_bounds__(IMU_THREADS) void small_kernel(const WinPtrs* __restrict__ wins, int init) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const WinPtrs& W = wins[blockIdx.y];
+  const int bx = blockIdx.x;
+  if (bx > W.n_imu) return;
+  const Ctrl* ctrl = W.ctrl;
+  if (ctrl->done) return;
+  if (!init && !ctrl->pending) return;
+  const int trial = 1 - ctrl->acc;
+  if (bx < W.n_imu)
+    imu_factor(W, bx, trial, smem, threadIdx.x);
+  else
+    small_factors(W, trial, smem, threadIdx.x);
+}
+
+}  // namespace ba

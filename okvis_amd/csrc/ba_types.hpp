@@ -1,0 +1,178 @@
+// Device-side data model of a batch of sliding windows (shared by the kernels and the host uploader).
+//
+// One `WinPtrs` per window lives in device memory; kernels index it with blockIdx.y and then use plain
+// pointers.  All per-window arrays are carved out of one arena allocation (256-byte aligned), so a batch
+// is a single hipMalloc and stays resident in HBM across optimize() calls.
+#pragma once
+#include <stdint.h>
+
+namespace ba {
+
+constexpr int GROUP_OBS = 256;       // observations handled by one linearise workgroup (= block size)
+constexpr int GROUP_LM = 64;         // max landmarks per group
+constexpr int GROUP_PAIRS = 512;     // max (landmark, block) pairs per group
+constexpr int LIN_THREADS = 256;
+constexpr int SCHUR_THREADS = 256;
+constexpr int SCHUR_TILE_BLOCKS = 16;  // 16 x 16 blocks of 6x6 = 96 x 96 tile, one 6x6 block per thread
+constexpr int SCHUR_LM_BATCH = 8;      // landmarks staged per LDS pass in the Schur kernel
+constexpr int SOLVE_THREADS = 512;
+constexpr int MAX_D_LDS = 192;         // reduced systems up to this size are factorised in LDS (packed)
+constexpr int MAX_IMU_STEPS = 254;     // integration steps of one IMU factor (threads of its workgroup)
+constexpr int IMU_THREADS = 256;
+constexpr int IMU_LIN_STRIDE = 15 * 30 + 15 + 1;  // J(15x30) | r(15) | cost
+constexpr int MAX_MARG_DIM = 192;
+
+// 32-byte observation record (coalesced 2 x 16 B per lane).  idx0 = landmark | cam << 24.
+struct ObsRec {
+  uint32_t lm_cam;
+  uint16_t pose;
+  uint16_t ext;
+  double u, v, sw;
+};
+static_assert(sizeof(ObsRec) == 32, "ObsRec must be 32 bytes");
+
+struct Group {  // one linearise workgroup: whole landmarks, <= GROUP_OBS observations
+  int lm_begin, lm_end;
+  int obs_begin, obs_end;
+  int pair_begin, pair_end;
+  int task_begin, task_end;
+};
+
+// reduction task of a group: accumulate over a list of the group's observations
+//   type 0: block Hessian/gradient of a pose-role block   out = 27 doubles (21 upper-tri A + 6 g)
+//   type 1: same for an extrinsics-role block
+//   type 2: cross block  J_pose^T J_ext                    out = 36 doubles
+struct Task {
+  int type;
+  int off_a;       // reduced offset of the (first) block
+  int off_b;       // reduced offset of the second block (type 2)
+  int list_begin;  // into task_list (group-local observation indices)
+  int list_end;
+  int out;         // offset (doubles) into the lin buffer's gpart array
+};
+
+struct Chunk {  // one Schur workgroup: a range of groups
+  int group_begin, group_end;
+};
+
+struct ImuParamsD {
+  double sigma_g_c, sigma_a_c, sigma_gw_c, sigma_aw_c, g, g_max, a_max;
+};
+
+// IMU preintegration cache of one factor (the `mutable` members of ImuError, ImuError.hpp:248-276)
+struct ImuCacheD {
+  double Delta_q[4];
+  double C_integral[9], C_doubleintegral[9];
+  double acc_integral[3], acc_doubleintegral[3];
+  double dalpha_db_g[9], dv_db_g[9], dp_db_g[9];
+  double sqrt_info[225];   // upper-triangular L^T
+  double sb_ref[9];
+  int valid;               // 0 until the first preintegration (redo_ = true initially)
+  int redo_count;
+};
+
+// per-group scalar partials written by the linearise kernel
+enum { GS_COST = 0, GS_GD = 1, GS_DDD = 2, GS_STEP2 = 3, GS_X2 = 4, GS_GMAX = 5, GS_COUNT = 8 };
+
+// solver options on the device
+struct OptD {
+  double initial_radius, max_radius, min_radius, min_lm_diag2, max_lm_diag2;
+  double min_relative_decrease, function_tolerance, gradient_tolerance, parameter_tolerance;
+};
+
+// trust-region state of one window; written ONLY by the solve kernel (and the finish kernel)
+struct Ctrl {
+  int acc;          // index (0/1) of the accepted state + linearisation buffers
+  int pending;      // 1 = a trial linearisation sits in buffer 1-acc awaiting the accept/reject decision
+  int first;        // 1 = the pending trial is the initial evaluation (iteration 0): accept unconditionally
+  int done;         // 0 = running, else termination reason + 1
+  int iter;         // iterations started (excluding iteration 0)
+  int successful;
+  int chol_fail;    // diagnostics: number of non-PD factorisations
+  int pad;
+  double radius, decrease_factor;
+  double cost;          // cost at the accepted state
+  double lambda;        // 1/radius used for the pending step
+  double gd_p, ddd_p, step2_p, x2_p;  // pose/speed-bias part of g.delta, delta^T D^2 delta, |delta|^2, |x|^2
+  double initial_cost, abs_grad_tol, grad_max;
+  double last_rho, last_model_change;
+};
+
+struct WinPtrs {
+  // ---- sizes ----
+  int n_pose, n_sb, n_lm, n_cam, n_obs, n_imu, n_pprior, n_sbprior, n_rel;
+  int marg_dim, marg_nb;
+  int D, Dp;              // reduced dimension; leading part that belongs to pose blocks
+  int n_pair, n_group, n_chunk, n_task;
+  int has_ext;            // any non-fixed extrinsics-role block
+  int gpart_size;         // doubles in gpart
+  int n_tile;             // Schur tiles per dimension
+  double cauchy_b;
+  ImuParamsD imu;
+
+  // ---- state (index = buffer 0/1) ----
+  double* pose[2];
+  double* sb[2];
+  double* lm[2];
+  const int* pose_off;    // reduced offset or -1 (fixed)
+  const int* sb_off;
+
+  // ---- structure ----
+  const double* cam_intr;
+  const int* cam_model;
+  const ObsRec* obs;
+  const Group* groups;
+  const int* pair_lm;     // [n_pair]
+  const int* pair_off;    // [n_pair] reduced offset of the pair's block
+  const int* pair_role;   // [n_pair] 0 = pose role, 1 = extrinsics role
+  const int* pair_list_begin;  // [n_pair+1] into pair_list
+  const uint16_t* pair_list;   // group-local observation indices
+  const int* lm_pair_begin;    // [n_lm+1]
+  const int* lm_obs_begin;     // [n_lm+1] observation range of each landmark (sorted order)
+  const Task* tasks;
+  const uint16_t* task_list;
+  const Chunk* chunks;
+
+  // ---- linearisation (index = buffer 0/1) ----
+  double* V[2];           // [n_lm][6]
+  double* bl[2];          // [n_lm][3]
+  double* Hq[2];          // [n_lm][6]
+  double* W[2];           // [n_pair][18]
+  double* gpart[2];       // task outputs
+  double* gscal[2];       // [n_group][GS_COUNT]
+  double* imu_lin[2];     // [n_imu][IMU_LIN_STRIDE]
+  double* pp_lin[2];      // [n_pprior][36 J + 6 r]
+  double* sbp_lin[2];     // [n_sbprior][9 r]
+  double* rel_lin[2];     // [n_rel][36 J0 + 36 J1 + 6 r]
+  double* marg_lin_e[2];  // [marg_dim] e = e0 + J dchi
+  double* marg_lin_M[2];  // [marg_nb][9] rotation blocks oplus(q (x) q_lin^-1)[0:3,0:3]
+  double* small_cost[2];  // [2]: cost of priors+marg (one workgroup), spare
+  double* obs_r[2];       // [n_obs][2] (debug/parity)
+
+  // ---- Schur / solve ----
+  double* spart;          // [n_chunk][Dp*Dp + Dp]
+  double* S;              // [D][D]
+  double* rhs;            // [D]
+  double* step;           // [D]
+  double* grad;           // [D]
+  double* Dp2;            // [D]
+  double* Hpp;            // [D][D] undamped U (debug/parity), optional
+  double* quality;        // [n_lm]
+  Ctrl* ctrl;
+
+  // ---- IMU ----
+  const int* imu_pose0; const int* imu_sb0; const int* imu_pose1; const int* imu_sb1;
+  const long long* imu_t0; const long long* imu_t1;
+  const int* imu_s_begin; const int* imu_s_count;
+  const long long* imu_s_t; const double* imu_s_gyr; const double* imu_s_acc;
+  ImuCacheD* imu_cache;
+
+  // ---- priors ----
+  const int* pprior_pose; const double* pprior_meas; const double* pprior_sqrtinfo;
+  const int* sbprior_sb; const double* sbprior_meas; const double* sbprior_sqrtinfo;
+  const int* rel_pose0; const int* rel_pose1; const double* rel_sqrtinfo;
+  const int* marg_block_type; const int* marg_block_idx; const int* marg_block_off;
+  const double* marg_J; const double* marg_H0; const double* marg_e0; const double* marg_lin;
+};
+
+}  // namespace ba

@@ -1,0 +1,161 @@
+"""Host-side handle of a batch of windows on one MI355X (thin wrapper over the C-ABI).
+
+Mirrors how ``okvis::Estimator`` drives its backend: upload the window structure (what
+``addStates/addLandmark/addObservation`` build in the reference, okvis_ceres/src/Estimator.cpp:110-365,
+implementation/Estimator.hpp:43-90), ``optimize(numIter)`` (Estimator.cpp:843-906), read the states back
+(``get_T_WS/getSpeedAndBias/getLandmark``, Estimator.cpp:933-1200).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+from .window import LimitsC, OptionsC, SummaryC, Window, WindowC, default_options
+
+ARR = dict(POSE=0, SB=1, LM=2, OBS_RESIDUAL=3, LM_V=4, LM_B=5, LM_HQ=6, PAIR_W=7, REDUCED_S=8,
+           REDUCED_RHS=9, STEP=10, LM_QUALITY=11, GRADIENT=12, IMU_RESIDUAL=13, HPP=14, DAMPING=15)
+_dp = C.POINTER(C.c_double)
+
+
+def limits() -> dict:
+    lim = LimitsC()
+    _lib.lib().okvis_ba_get_limits(C.byref(lim))
+    return {n: getattr(lim, n) for n, _ in lim._fields_}
+
+
+def check_window(window: Window, options: OptionsC | None = None) -> dict:
+    """Host-only structure check (no GPU needed): the index building okvis_ba_upload performs."""
+    window.validate()
+    wc, keep = window.as_c()
+    st = (C.c_int64 * 8)()
+    _lib.check(_lib.lib().okvis_ba_check_window(C.byref(wc), C.byref(options) if options is not None else None, st),
+               "check_window")
+    del keep
+    return dict(D=st[0], Dp=st[1], n_pair=st[2], n_group=st[3], n_chunk=st[4], n_task=st[5], gpart=st[6],
+                arena_bytes=st[7])
+
+
+class WindowBatch:
+    """A batch of independent sliding windows resident in the HBM of one GPU."""
+
+    def __init__(self, windows: Sequence[Window], device: int = 0, options: OptionsC | None = None):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        _lib.check(self._L.okvis_ba_create(C.byref(self._h), int(device)), "create")
+        self.windows = list(windows)
+        self.options = options or default_options()
+        _lib.check(self._L.okvis_ba_set_options(self._h, C.byref(self.options)), "set_options")
+        arr = (WindowC * len(self.windows))()
+        keep = []
+        for i, w in enumerate(self.windows):
+            w.validate()
+            wc, k = w.as_c()
+            arr[i] = wc
+            keep.append(k)
+        _lib.check(self._L.okvis_ba_upload(self._h, len(self.windows), arr), "upload")
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.okvis_ba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return len(self.windows)
+
+    # ---- options ----
+    def set_options(self, options: OptionsC):
+        _lib.check(self._L.okvis_ba_set_options(self._h, C.byref(options)), "set_options")
+        self.options = options
+
+    # ---- hot path ----
+    def optimize(self, num_iter: int):
+        s = (SummaryC * len(self))()
+        _lib.check(self._L.okvis_ba_optimize(self._h, int(num_iter), s), "optimize")
+        return [x.as_dict() for x in s]
+
+    def optimize_timed(self, max_iter: int, min_iter: int, time_limit_s: float):
+        s = (SummaryC * len(self))()
+        _lib.check(self._L.okvis_ba_optimize_timed(self._h, int(max_iter), int(min_iter), float(time_limit_s), s),
+                   "optimize_timed")
+        return [x.as_dict() for x in s]
+
+    def begin(self):
+        _lib.check(self._L.okvis_ba_begin(self._h), "begin")
+
+    def iterate(self, n: int):
+        _lib.check(self._L.okvis_ba_iterate(self._h, int(n)), "iterate")
+
+    def finish(self):
+        s = (SummaryC * len(self))()
+        _lib.check(self._L.okvis_ba_finish(self._h, s), "finish")
+        return [x.as_dict() for x in s]
+
+    def evaluate_cost(self):
+        c = np.zeros(len(self))
+        _lib.check(self._L.okvis_ba_evaluate_cost(self._h, c.ctypes.data_as(_dp)), "evaluate_cost")
+        return c
+
+    def synchronize(self):
+        _lib.check(self._L.okvis_ba_synchronize(self._h), "synchronize")
+
+    # ---- results ----
+    def get_state(self, w: int = 0):
+        W = self.windows[w]
+        pose, sb, lm = np.zeros((W.n_pose, 7)), np.zeros((W.n_sb, 9)), np.zeros((W.n_lm, 4))
+        _lib.check(self._L.okvis_ba_get_state(self._h, w, pose.ctypes.data_as(_dp), sb.ctypes.data_as(_dp),
+                                              lm.ctypes.data_as(_dp)), "get_state")
+        return pose, sb, lm
+
+    def set_state(self, w: int, pose=None, sb=None, lm=None):
+        def p(a):
+            return None if a is None else np.ascontiguousarray(a, np.float64)
+        pose, sb, lm = p(pose), p(sb), p(lm)
+        _lib.check(self._L.okvis_ba_set_state(
+            self._h, w, None if pose is None else pose.ctypes.data_as(_dp),
+            None if sb is None else sb.ctypes.data_as(_dp), None if lm is None else lm.ctypes.data_as(_dp)), "set_state")
+
+    def array(self, name: str, w: int = 0) -> np.ndarray:
+        n = C.c_int64()
+        _lib.check(self._L.okvis_ba_array_size(self._h, w, ARR[name], C.byref(n)), f"array_size {name}")
+        out = np.zeros(max(n.value, 0))
+        _lib.check(self._L.okvis_ba_download(self._h, w, ARR[name], out.ctypes.data_as(_dp), n.value), f"download {name}")
+        return out
+
+    def reduced_dim(self, w: int = 0) -> int:
+        d = C.c_int32()
+        _lib.check(self._L.okvis_ba_reduced_dim(self._h, w, C.byref(d)))
+        return d.value
+
+    def pairs(self, w: int = 0):
+        n = C.c_int32()
+        _lib.check(self._L.okvis_ba_pair_count(self._h, w, C.byref(n)))
+        a, b = np.zeros(n.value, np.int32), np.zeros(n.value, np.int32)
+        ip = C.POINTER(C.c_int32)
+        _lib.check(self._L.okvis_ba_pairs(self._h, w, a.ctypes.data_as(ip), b.ctypes.data_as(ip)))
+        return a, b
+
+    # ---- measurement hooks ----
+    def last_iterate_ms(self) -> float:
+        t = C.c_float()
+        _lib.check(self._L.okvis_ba_last_iterate_ms(self._h, C.byref(t)))
+        return t.value
+
+    def profile_iterations(self, n: int):
+        ms = (C.c_float * 4)()
+        _lib.check(self._L.okvis_ba_profile_iterations(self._h, int(n), ms))
+        return dict(schur=ms[0], solve=ms[1], small=ms[2], linearize=ms[3])
+
+    def algorithmic_bytes(self):
+        v = [C.c_int64() for _ in range(4)]
+        _lib.check(self._L.okvis_ba_algorithmic_bytes(self._h, *[C.byref(x) for x in v]))
+        return dict(linearize=v[0].value, schur=v[1].value, solve=v[2].value, small=v[3].value)
