@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — Gauss-Newton (LM-safeguarded) iterations/s of the MI355X sliding-window BA backend.
+
+A "step" is one full trust-region iteration (Schur reduce -> reduced solve -> back-substitute + (+)update
++ re-linearise, BASELINE.md §"Path under measurement") on every window resident on this GPU.  Workload
+per GPU: `--windows` independent synthetic windows of BASELINE.json configs[1] (10 keyframes / 2 cams /
+400 landmarks / 100-sample IMU factors, fp64) — 8 per GPU is configs[3]'s shape (64 windows over 8 GPUs).
+Weak scaling: every rank owns its own windows (seeds 20240923 + rank*windows + i), there is no data-path
+collective; the only exchange is the gather of per-rank timings.  All convergence tolerances are disabled
+in the timed region so that every step performs the full work (accepted or rejected steps launch the
+same kernels).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--windows", type=int, default=8, help="independent windows per GPU")
+    p.add_argument("--keyframes", type=int, default=10)
+    p.add_argument("--landmarks", type=int, default=400)
+    p.add_argument("--visibility", type=float, default=1.0)
+    p.add_argument("--no-graph", action="store_true", help="eager launches (for rocprofv3 kernel traces)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-iters", type=int, default=0, help="oracle iterations for the CPU baseline (0 = auto ~12 s)")
+    p.add_argument("--profile-steps", type=int, default=20, help="eager per-kernel HIP-event pass for the roofline")
+    return p.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl")  # RCCL over xGMI
+        dist = dist_mod
+
+    from okvis_amd import solver, synthetic
+    from okvis_amd.window import default_options
+
+    seeds = [20240923 + rank * a.windows + i for i in range(a.windows)]
+    wins = [synthetic.make_window(a.keyframes, a.landmarks, a.visibility, s) for s in seeds]
+    opt = default_options()
+    opt.function_tolerance = 0.0
+    opt.gradient_tolerance = 0.0
+    opt.parameter_tolerance = 0.0
+    opt.use_graph = 0 if a.no_graph else 1
+    opt.gauss_newton = 1  # every timed iteration does identical full work (no trust-region collapse at the optimum)
+    batch = solver.WindowBatch(wins, device=local_rank, options=opt)
+
+    def barrier():
+        batch.synchronize()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    batch.begin()
+    if a.warmup > 0:
+        batch.iterate(a.warmup)
+    # build the graph of the timed call outside the timed region
+    if not a.no_graph and a.steps != a.warmup:
+        batch.iterate(a.steps)
+    barrier()
+    t0 = time.perf_counter()
+    batch.iterate(a.steps)
+    barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    ev_ms = batch.last_iterate_ms()
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        # the one collective of the design: all-gather of the per-rank timing records
+        rec = torch.tensor([float(rank), float(a.steps), ev_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        gathered = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(gathered, rec)
+        per_rank_ms = [float(g[2].item()) for g in gathered]
+    else:
+        per_rank_ms = [ev_ms]
+    summaries = None
+
+    # ---- per-kernel attribution for the roofline (eager launches bracketed by HIP events) ----
+    roofline = None
+    if rank == 0 and a.profile_steps > 0:
+        prof = batch.profile_iterations(a.profile_steps)
+        nbytes = batch.algorithmic_bytes()
+        dom = max(prof, key=lambda k: prof[k])
+        per_launch_s = prof[dom] * 1e-3 / a.profile_steps
+        achieved = nbytes[dom] / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": nbytes[dom], "avg_launch_us": per_launch_s * 1e6,
+                    "per_kernel_us": {k: v * 1e3 / a.profile_steps for k, v in prof.items()},
+                    "per_kernel_algorithmic_bytes": nbytes,
+                    "note": "single small windows are launch/latency-bound, not HBM-bound (SURVEY.md §7)"}
+    summaries = batch.finish()
+
+    single = None
+    if rank == 0:
+        # latency of ONE window (configs[1] exactly), graph replay
+        b1 = solver.WindowBatch(wins[:1], device=local_rank, options=opt)
+        b1.begin()
+        b1.iterate(a.steps)
+        b1.synchronize()
+        b1.iterate(a.steps)
+        ms1 = b1.last_iterate_ms()
+        b1.finish()
+        b1.close()
+        single = {"iterations_per_s": a.steps / (ms1 * 1e-3), "ms_per_iteration": ms1 / a.steps}
+
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        # CPU restatement (oracle), one thread, bounded sample of the same workload.  Test infrastructure:
+        # used here ONLY as the reported baseline, never in the measured path.
+        from tests import oracle_lib
+        ow = oracle_lib.OracleWindow(wins[0])
+        n_probe = 20
+        tp = ow.time_iterations(n_probe, opt)
+        n = a.cpu_iters if a.cpu_iters > 0 else max(50, int(12.0 / max(tp / n_probe, 1e-6)))
+        ow = oracle_lib.OracleWindow(wins[0])
+        tc = ow.time_iterations(n, opt)
+        cpu = {"value": n / tc, "unit": "iterations/s", "cores": 1, "kind": "port",
+               "sample": f"1 window (configs[1] shape) x {n} LM iterations of the CPU restatement (oracle/, "
+                         f"g++ -O3, not Ceres), {tc:.1f} s"}
+
+    if rank == 0:
+        total_iters = world * a.windows * a.steps
+        value = total_iters / wall
+        out = {
+            "metric": "Gauss-Newton iterations/sec on 10-KF x 2-cam x 400-landmark windows (window-iterations/s, batched)",
+            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.windows} independent windows per GPU of BASELINE configs[1] "
+                                   f"({a.keyframes} KF / 2 cam / {a.landmarks} landmarks / {wins[0].n_obs} obs / "
+                                   f"{wins[0].n_imu} IMU factors x ~100 samples, fp64); configs[3] is 8 such windows "
+                                   f"on each of 8 GPUs",
+                       "windows_per_gpu": a.windows, "observations_per_window": wins[0].n_obs,
+                       "reduced_dim": wins[0].reduced_dim(), "graph": not a.no_graph, "parallelism": f"windows x{world}"},
+            "hip_event_ms_per_step": max(per_rank_ms) / a.steps,
+            "single_window": single, "roofline": roofline, "cpu_baseline": cpu,
+            "final_cost_window0": summaries[0]["final_cost"],
+        }
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -163,7 +163,9 @@ typedef struct okvis_ba_options {
   int32_t schur_lm_per_block;   /* landmarks per Schur workgroup (0 = auto)                             */
   int32_t debug_arrays;         /* 1 = also write the parity/debug arrays (per-observation residuals,
                                    damped reduced matrix); off in production                            */
-  int32_t reserved;
+  int32_t gauss_newton;         /* 1 = plain Gauss-Newton: every step is accepted and the damping radius stays
+                                   at initial_radius (no trust-region logic); used by bench.py so that
+                                   every timed iteration performs identical, full work                   */
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */

@@ -82,6 +82,8 @@ OptD make_optd(const okvis_ba_options& o) {
   d.function_tolerance = o.function_tolerance;
   d.gradient_tolerance = o.gradient_tolerance;
   d.parameter_tolerance = o.parameter_tolerance;
+  d.gauss_newton = o.gauss_newton;
+  d.pad = 0;
   return d;
 }
 
@@ -557,7 +559,7 @@ void okvis_ba_default_options(okvis_ba_options* o) {
   o->use_graph = 1;
   o->schur_lm_per_block = 0;
   o->debug_arrays = 0;
-  o->reserved = 0;
+  o->gauss_newton = 0;
 }
 
 const char* okvis_ba_error_string(int status) {

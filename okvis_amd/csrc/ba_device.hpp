@@ -62,7 +62,7 @@ __device__ __noinline__ void decide(const Ctrl* c, const OptD* o, const double s
   d->decrease_factor = c->decrease_factor;
   d->rho = 0;
   d->model_change = 0;
-  if (c->first) {
+  if (c->first || o->gauss_newton) {
     d->accept = 1;
     return;
   }

@@ -78,6 +78,8 @@ enum { GS_COST = 0, GS_GD = 1, GS_DDD = 2, GS_STEP2 = 3, GS_X2 = 4, GS_GMAX = 5,
 struct OptD {
   double initial_radius, max_radius, min_radius, min_lm_diag2, max_lm_diag2;
   double min_relative_decrease, function_tolerance, gradient_tolerance, parameter_tolerance;
+  int gauss_newton;  // 1 = accept every step, keep the radius fixed
+  int pad;
 };
 
 // trust-region state of one window; written ONLY by the solve kernel (and the finish kernel)

@@ -525,7 +525,7 @@ void lm_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis_ba_
         dDd += h->Dl2[i] * h->step_l[i] * h->step_l[i];
       }
       model_change = -0.5 * gd + 0.5 * h->lambda * dDd;
-      if (!(model_change > 0)) ok = false;
+      if (!(model_change > 0) && !opt.gauss_newton) ok = false;
     }
     if (!ok) {  // invalid step: treated like a rejected step
       radius /= decrease_factor;
@@ -561,12 +561,15 @@ void lm_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis_ba_
     const double old_cost = h->cost;
     const double new_cost = evaluate(h, false);
     const double rho = (old_cost - new_cost) / model_change;
-    if (rho > opt.min_relative_decrease) {
+    if (opt.gauss_newton || rho > opt.min_relative_decrease) {
       evaluate(h, true);  // Ceres re-evaluates residuals + Jacobians at the accepted point
       s.successful_steps++;
-      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
-      radius = std::min(opt.max_radius, radius);
-      decrease_factor = 2.0;
+      if (!opt.gauss_newton) {
+        const double t = 2.0 * rho - 1.0;
+        radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+        radius = std::min(opt.max_radius, radius);
+        decrease_factor = 2.0;
+      }
       const double gm = gradient_max_norm(h);
       s.gradient_max_norm = gm;
       if (opt.gradient_tolerance > 0 && gm <= abs_grad_tol) {

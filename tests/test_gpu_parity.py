@@ -1,0 +1,185 @@
+"""GPU parity tests (pytest -m gpu): the HIP path through the C-ABI against the CPU oracle on the same
+seeded inputs.  Tolerances: intermediate arrays 1e-9 relative to the array's max magnitude (fp64, different
+summation order), final cost 1e-9 relative (north_star asks 1e-6), identical iteration bookkeeping."""
+import numpy as np
+import pytest
+
+from okvis_amd import synthetic
+from okvis_amd.window import DIST_EQUIDISTANT, DIST_NONE, DIST_RADTAN, DIST_RADTAN8, default_options
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(ws, **kw):
+    from okvis_amd import solver
+    opt = default_options()
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    return solver.WindowBatch(ws, options=opt)
+
+
+def _close(a, b, tol=1e-9):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    scale = max(np.abs(b).max() if b.size else 0.0, 1e-300)
+    assert np.abs(a - b).max() <= tol * scale, (np.abs(a - b).max(), scale)
+
+
+@pytest.mark.parametrize("ext", ["fixed", "shared", "perframe"])
+@pytest.mark.parametrize("model", [DIST_RADTAN, DIST_EQUIDISTANT])
+def test_linearisation_arrays_match_oracle(oracle, ext, model):
+    w = synthetic.small_window(seed=21, K=4, L=60, estimate_extrinsics=ext, cam_model=model)
+    b = _batch([w], debug_arrays=1, use_graph=0)
+    o = oracle.OracleWindow(w)
+    c_ref = o.linearize()
+    b.begin()
+    s = b.finish()[0]
+    assert abs(s["final_cost"] - c_ref) <= 1e-12 * c_ref
+    for name in ("OBS_RESIDUAL", "LM_V", "LM_B", "LM_HQ", "PAIR_W", "IMU_RESIDUAL"):
+        _close(b.array(name), o.array(name))
+    _close(b.array("LM_QUALITY"), o.array("LM_QUALITY"), 1e-7)
+    assert np.array_equal(b.pairs()[0], o.pairs()[0]) and np.array_equal(b.pairs()[1], o.pairs()[1])
+    # reduced system and step of the first iteration
+    b.begin()
+    b.iterate(1)
+    opt = default_options()
+    assert o.solve(opt.initial_radius, opt) == 0
+    S_g, S_r = b.array("REDUCED_S"), o.array("REDUCED_S")
+    _close(S_g, S_r, 1e-12)
+    _close(b.array("REDUCED_RHS"), o.array("REDUCED_RHS"), 1e-6)   # rhs = -g + Yb cancels 1e16-weighted terms
+    _close(b.array("STEP"), o.array("STEP"), 1e-8)
+    b.close()
+
+
+@pytest.mark.parametrize("model", [DIST_NONE, DIST_RADTAN8])
+def test_other_distortion_models(oracle, model):
+    w = synthetic.small_window(seed=22, K=3, L=40, cam_model=model)
+    b = _batch([w], debug_arrays=1)
+    o = oracle.OracleWindow(w)
+    o.linearize()
+    b.begin(); b.finish()
+    for name in ("OBS_RESIDUAL", "LM_V", "PAIR_W"):
+        _close(b.array(name), o.array(name))
+    b.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(K=4, L=40, ext="fixed"), dict(K=4, L=40, ext="shared"),
+                                 dict(K=3, L=30, ext="perframe"), dict(K=6, L=150, ext="fixed", vis=0.35)])
+def test_optimize_matches_oracle(oracle, cfg):
+    w = synthetic.make_window(cfg["K"], cfg["L"], cfg.get("vis", 0.7), seed=23, estimate_extrinsics=cfg["ext"])
+    for n in (1, 3, 10, 40):
+        b = _batch([w])
+        sg = b.optimize(n)[0]
+        o = oracle.OracleWindow(w)
+        sr = o.optimize(n)
+        assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"], (n, sg, sr)
+        assert (sg["iterations"], sg["successful_steps"], sg["termination"]) == \
+               (sr["iterations"], sr["successful_steps"], sr["termination"]), (n, sg, sr)
+        pg, sbg, lg = b.get_state()
+        pr, sbr, lr = o.get_state()
+        assert np.abs(pg - pr).max() < 1e-7 and np.abs(sbg - sbr).max() < 1e-7 and np.abs(lg - lr).max() < 1e-6
+        b.close()
+
+
+def test_config_A_full_size_and_batch(oracle):
+    # BASELINE configs[1] at full size, as a batch of 4 different windows through the hipGraph path
+    ws = [synthetic.config_A(seed=20240923 + i) for i in range(4)]
+    b = _batch(ws)
+    sg = b.optimize(10)
+    for i, w in enumerate(ws):
+        sr = oracle.OracleWindow(w).optimize(10)
+        assert abs(sg[i]["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+        assert sg[i]["iterations"] == sr["iterations"] and sg[i]["successful_steps"] == sr["successful_steps"]
+    # size-independent properties at full size: the cost never increases over accepted steps,
+    # optimisation is idempotent at the optimum (function tolerance), landmark w is untouched
+    s2 = b.optimize(50)
+    for i in range(4):
+        assert s2[i]["final_cost"] <= sg[i]["final_cost"] * (1 + 1e-12)
+        assert s2[i]["termination"] == 1
+    c = b.evaluate_cost()
+    s3 = b.optimize(5)
+    for i in range(4):
+        assert abs(s3[i]["final_cost"] - c[i]) <= 2e-6 * c[i]
+        assert np.array_equal(b.get_state(i)[2][:, 3], ws[i].lm[:, 3])
+    b.close()
+
+
+def test_eager_and_graph_paths_agree(oracle):
+    w = synthetic.small_window(seed=24)
+    a = _batch([w], use_graph=1).optimize(12)[0]
+    c = _batch([w], use_graph=0).optimize(12)[0]
+    assert a == c     # bitwise: same kernels, same order
+
+
+def test_gauss_newton_mode_matches_oracle(oracle):
+    w = synthetic.small_window(seed=25, K=4, L=50)
+    opt = dict(gauss_newton=1, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    b = _batch([w], **opt)
+    sg = b.optimize(8)[0]
+    o = oracle.OracleWindow(w)
+    op = default_options()
+    for k, v in opt.items():
+        setattr(op, k, v)
+    sr = o.optimize(8, op)
+    assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+    assert sg["successful_steps"] == sr["successful_steps"] == 8
+
+
+def test_set_state_and_restart(oracle):
+    w = synthetic.small_window(seed=26)
+    b = _batch([w])
+    b.optimize(5)
+    p, s, l = b.get_state()
+    b.set_state(0, w.pose, w.sb, w.lm)          # Estimator::set_T_WS / setSpeedAndBias / setLandmark
+    c0 = b.evaluate_cost()[0]
+    o = oracle.OracleWindow(w)
+    assert abs(c0 - o.linearize()) <= 1e-12 * c0
+    b.close()
+
+
+def test_edge_cases(oracle):
+    from okvis_amd import solver
+    # landmark without observations, a single landmark, and a ragged window
+    w = synthetic.small_window(seed=27, K=3, L=20)
+    keep = w.obs_lm != 5
+    for n in ("obs_lm", "obs_pose", "obs_ext", "obs_cam", "obs_uv", "obs_sqrtw"):
+        setattr(w, n, getattr(w, n)[keep])
+    b = _batch([w])
+    sg = b.optimize(6)[0]
+    sr = oracle.OracleWindow(w).optimize(6)
+    assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+    assert np.array_equal(b.get_state()[2][5], w.lm[5])      # unobserved landmark does not move
+    b.close()
+    # point behind / too close to a camera: residual kept, Jacobians zeroed (ReprojectionError.hpp:143-151)
+    w2 = synthetic.small_window(seed=28, K=3, L=20)
+    w2.lm = w2.lm.copy()
+    w2.lm[0, :3] = w2.pose[0, :3] + 0.01
+    b = _batch([w2], debug_arrays=1)
+    o = oracle.OracleWindow(w2)
+    c = o.linearize()
+    b.begin()
+    s = b.finish()[0]
+    assert abs(s["final_cost"] - c) <= 1e-12 * c
+    _close(b.array("LM_V"), o.array("LM_V"))
+    _close(b.array("OBS_RESIDUAL"), o.array("OBS_RESIDUAL"))
+    b.close()
+    # negative homogeneous scale (PinholeCamera.hpp:363-367)
+    w3 = synthetic.small_window(seed=29, K=3, L=20)
+    w3.lm = w3.lm.copy(); w3.lm[1] *= -1.0
+    b = _batch([w3], debug_arrays=1)
+    o = oracle.OracleWindow(w3)
+    c = o.linearize()
+    b.begin(); s = b.finish()[0]
+    assert abs(s["final_cost"] - c) <= 1e-12 * c
+    _close(b.array("PAIR_W"), o.array("PAIR_W"))
+    b.close()
+
+
+def test_time_limited_optimize_runs_min_iterations():
+    w = synthetic.small_window(seed=30)
+    b = _batch([w], function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    s = b.optimize_timed(10, 3, 0.0)[0]        # zero budget: exactly the minimum iterations
+    assert s["iterations"] == 3
+    s = b.optimize_timed(7, 3, -1.0)[0]        # negative limit: no limit -> max iterations
+    assert s["iterations"] == 7
+    b.close()

@@ -1,0 +1,108 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol the header
+declares, fails loudly without a GPU, and the structure building (what replaces okvis::ceres::Map's
+bookkeeping, reference okvis_ceres/src/Map.cpp:292-565) produces the documented ordering."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from okvis_amd import _lib, solver, synthetic
+from okvis_amd.window import OptionsC, WindowC, default_options
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "okvis_amd_ba.h")).read()
+    declared = set(re.findall(r"\b(okvis_ba_[a-z_]+)\s*\(", hdr))
+    declared -= {"okvis_ba_array"}
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert set(_lib.SYMBOLS) == declared
+    assert L.okvis_ba_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    # sizes computed by the C compiler for the same header (guards the ctypes mirror)
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include "okvis_amd_ba.h"\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(okvis_ba_window),sizeof(okvis_ba_options),sizeof(okvis_ba_summary),sizeof(okvis_ba_limits));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).split()
+    from okvis_amd.window import LimitsC, SummaryC
+    assert [int(x) for x in out] == [C.sizeof(WindowC), C.sizeof(OptionsC), C.sizeof(SummaryC), C.sizeof(LimitsC)]
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.okvis_ba_create(C.byref(h), 0) == -4          # OKVIS_BA_ERR_NO_DEVICE
+    with pytest.raises(_lib.BackendError):
+        solver.WindowBatch([synthetic.small_window()])
+
+
+def test_default_options_match_python_mirror():
+    o = OptionsC()
+    _lib.lib().okvis_ba_default_options(C.byref(o))
+    d = default_options()
+    for n, _ in OptionsC._fields_:
+        assert getattr(o, n) == getattr(d, n), n
+
+
+@pytest.mark.parametrize("ext,expD", [("fixed", 4 * 15), ("shared", 4 * 15 + 12), ("perframe", 4 * 15 + 4 * 12)])
+def test_structure_building_matches_oracle_ordering(oracle, ext, expD):
+    w = synthetic.small_window(seed=5, K=4, L=40, estimate_extrinsics=ext)
+    st = solver.check_window(w)
+    o = oracle.OracleWindow(w)
+    assert st["D"] == expD == o.D == w.reduced_dim()
+    assert st["n_pair"] == o.n_pair
+    assert st["n_group"] >= 1 and st["n_chunk"] >= 1
+
+
+def test_config_A_structure():
+    st = solver.check_window(synthetic.config_A())
+    assert st["D"] == 150 and st["Dp"] == 60 and st["n_pair"] == 4000
+    assert st["n_group"] == 34          # 12 landmarks x 20 observations per 256-lane group
+    assert st["arena_bytes"] < 4 << 20
+
+
+def test_upload_validation_errors():
+    w = synthetic.small_window(seed=6)
+    L = _lib.lib()
+
+    def status(win):
+        wc, keep = win.as_c()
+        return L.okvis_ba_check_window(C.byref(wc), None, None)
+    assert status(w) == 0
+    import copy
+    bad = copy.deepcopy(w); bad.obs_lm = bad.obs_lm[::-1].copy()          # unsorted
+    assert status(bad) == -1
+    bad = copy.deepcopy(w); bad.obs_pose = bad.obs_pose.copy(); bad.obs_pose[0] = 99   # out of range
+    assert status(bad) == -1
+    bad = copy.deepcopy(w)                                                 # duplicate observation
+    for n in ("obs_lm", "obs_pose", "obs_ext", "obs_cam", "obs_uv", "obs_sqrtw"):
+        a = getattr(bad, n); setattr(bad, n, np.concatenate([a[:1], a]))
+    assert status(bad) == -1
+    bad = copy.deepcopy(w); bad.imu_s_count = bad.imu_s_count.copy(); bad.imu_s_count[0] = 5   # samples do not reach t1
+    assert status(bad) == -1
+    big = synthetic.make_window(3, 5, 1.0, 1)
+    big.obs_lm = np.zeros(300, np.int32)                                   # > 256 observations of one landmark
+    big.obs_pose = np.arange(300, dtype=np.int32) % 3
+    assert status(big) in (-1, -3)
+    # too large a reduced system for the LDS solver is reported, not silently mis-solved
+    w50 = synthetic.make_window(20, 30, 1.0, 2, frame_dt=0.1)
+    assert status(w50) == -3
+
+
+def test_window_validate_rejects_bad_input():
+    w = synthetic.small_window(seed=7)
+    w.obs_lm = w.obs_lm.copy(); w.obs_lm[3] = 10**6
+    with pytest.raises(ValueError):
+        w.validate()
