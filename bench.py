@@ -33,7 +33,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--windows", type=int, default=8, help="independent windows per GPU")
+    p.add_argument("--windows", type=int, default=64, help="independent windows per GPU")
+    p.add_argument("--streams", type=int, default=0, help="sub-batch streams (0 = auto)")
     p.add_argument("--keyframes", type=int, default=10)
     p.add_argument("--landmarks", type=int, default=400)
     p.add_argument("--visibility", type=float, default=1.0)
@@ -67,6 +68,7 @@ def main():
     opt.gradient_tolerance = 0.0
     opt.parameter_tolerance = 0.0
     opt.use_graph = 0 if a.no_graph else 1
+    opt.n_streams = a.streams
     opt.gauss_newton = 1  # every timed iteration does identical full work (no trust-region collapse at the optimum)
     batch = solver.WindowBatch(wins, device=local_rank, options=opt)
 

@@ -166,6 +166,9 @@ typedef struct okvis_ba_options {
   int32_t gauss_newton;         /* 1 = plain Gauss-Newton: every step is accepted and the damping radius stays
                                    at initial_radius (no trust-region logic); used by bench.py so that
                                    every timed iteration performs identical, full work                   */
+  int32_t n_streams;            /* sub-batches of windows on separate HIP streams (phases of different
+                                   windows overlap); 0 = default (1: measured fastest on ROCm 7.2)       */
+  int32_t reserved;
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */

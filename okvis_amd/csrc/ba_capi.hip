@@ -55,7 +55,12 @@ struct Arena {
 struct okvis_ba_solver {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // sub-batches of windows run on their own streams so that the (latency-bound) phases of different
+  // windows overlap on the 256 CUs
+  std::vector<hipStream_t> sub_streams;
+  std::vector<hipEvent_t> sub_events;
+  std::vector<int> sub_begin;  // [n_sub+1] window ranges
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr;
   okvis_ba_options opt;
   OptD* d_opt = nullptr;
   unsigned char* d_arena = nullptr;
@@ -282,6 +287,63 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     }
   }
   const int nchunk = (int)chunks.size();
+  // ---- assembly targets: per reduced 6x6 block, the list of per-group partials that sum into it ----
+  std::vector<AsmTarget> asm_targets;
+  std::vector<int> asm_list;
+  {
+    std::map<std::pair<int, int>, std::vector<int>> by_target;  // (off_a, off_b or -1) -> task outs (group order)
+    std::map<std::pair<int, int>, int> ttype;
+    for (const Task& T : tasks) {
+      const std::pair<int, int> key(T.off_a, T.type == 2 ? T.off_b : -1);
+      by_target[key].push_back(T.out);
+      ttype[key] = T.type == 2 ? 2 : 0;
+    }
+    for (auto& kv : by_target) {
+      AsmTarget A;
+      A.type = ttype[kv.first];
+      A.off_a = kv.first.first;
+      A.off_b = kv.first.second;
+      A.list_begin = (int)asm_list.size();
+      asm_list.insert(asm_list.end(), kv.second.begin(), kv.second.end());
+      A.list_end = (int)asm_list.size();
+      A.pad = 0;
+      asm_targets.push_back(A);
+    }
+  }
+  // ---- greedy colouring of the IMU factors: factors of one colour share no parameter block ----
+  std::vector<int> imu_color(w.n_imu, 0);
+  int n_imu_color = 0;
+  for (int f = 0; f < w.n_imu; ++f) {
+    int col = 0;
+    for (;; ++col) {
+      bool clash = false;
+      for (int g2 = 0; g2 < f && !clash; ++g2) {
+        if (imu_color[g2] != col) continue;
+        const int pa[2] = {w.imu_pose0[f], w.imu_pose1[f]}, pb[2] = {w.imu_pose0[g2], w.imu_pose1[g2]};
+        const int sa[2] = {w.imu_sb0[f], w.imu_sb1[f]}, sbb[2] = {w.imu_sb0[g2], w.imu_sb1[g2]};
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 2; ++j) clash = clash || pa[i] == pb[j] || sa[i] == sbb[j];
+      }
+      if (!clash) break;
+    }
+    imu_color[f] = col;
+    n_imu_color = std::max(n_imu_color, col + 1);
+  }
+  std::vector<int> imu_order, imu_color_begin(n_imu_color + 1, 0), imu_coloff(30 * (size_t)w.n_imu, -1);
+  for (int c = 0; c < n_imu_color; ++c) {
+    imu_color_begin[c] = (int)imu_order.size();
+    for (int f = 0; f < w.n_imu; ++f)
+      if (imu_color[f] == c) imu_order.push_back(f);
+  }
+  imu_color_begin[n_imu_color] = (int)imu_order.size();
+  for (int f = 0; f < w.n_imu; ++f) {
+    const int offs[4] = {pose_off[w.imu_pose0[f]], sb_off[w.imu_sb0[f]], pose_off[w.imu_pose1[f]], sb_off[w.imu_sb1[f]]};
+    const int start[4] = {0, 6, 15, 21}, dims[4] = {6, 9, 6, 9};
+    for (int b = 0; b < 4; ++b)
+      for (int k = 0; k < dims[b]; ++k) imu_coloff[30 * (size_t)f + start[b] + k] = offs[b] < 0 ? -1 : offs[b] + k;
+  }
+  const int npose_blk = Dp / 6;
+  const int spart_stride = npose_blk * (npose_blk + 1) / 2 * 36 + Dp;
   const int ntile = std::max(1, (Dp / 6 + SCHUR_TILE_BLOCKS - 1) / SCHUR_TILE_BLOCKS);
   // ---- observation records ----
   std::vector<ObsRec> recs(nobs);
@@ -337,6 +399,9 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.has_ext = has_ext ? 1 : 0;
   P.gpart_size = gpart_size;
   P.n_tile = ntile;
+  P.n_asm = (int)asm_targets.size();
+  P.n_imu_color = n_imu_color;
+  P.spart_stride = spart_stride;
   P.cauchy_b = w.cauchy_b;
   P.imu.sigma_g_c = w.imu_params.sigma_g_c; P.imu.sigma_a_c = w.imu_params.sigma_a_c;
   P.imu.sigma_gw_c = w.imu_params.sigma_gw_c; P.imu.sigma_aw_c = w.imu_params.sigma_aw_c;
@@ -367,6 +432,11 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(tasks, put(A, tasks));
   OFF(task_list, put(A, task_list));
   OFF(chunks, put(A, chunks));
+  OFF(asm_targets, put(A, asm_targets));
+  OFF(asm_list, put(A, asm_list));
+  OFF(imu_order, put(A, imu_order));
+  OFF(imu_color_begin, put(A, imu_color_begin));
+  OFF(imu_coloff, put(A, imu_coloff));
   for (int b = 0; b < 2; ++b) {
     OFF(V[b], put_zero(A, 48 * (size_t)nlm));
     OFF(bl[b], put_zero(A, 24 * (size_t)nlm));
@@ -383,7 +453,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(small_cost[b], put_zero(A, 16));
     if (opt.debug_arrays) OFF(obs_r[b], put_zero(A, 16 * (size_t)nobs));
   }
-  OFF(spart, put_zero(A, 8 * (size_t)std::max(nchunk, 1) * ((size_t)Dp * Dp + 3 * Dp)));
+  OFF(spart, put_zero(A, 8 * (size_t)std::max(nchunk, 1) * (size_t)spart_stride));
   if (opt.debug_arrays) {
     OFF(S, put_zero(A, 8 * (size_t)D * D));
     OFF(rhs, put_zero(A, 8 * (size_t)D));
@@ -392,6 +462,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(step, put_zero(A, 8 * (size_t)D));
   OFF(grad, put_zero(A, 8 * (size_t)D));
   OFF(quality, put_zero(A, 8 * (size_t)nlm));
+  OFF(prof, put_zero(A, 8 * 64));
   OFF(ctrl, put_zero(A, sizeof(Ctrl)));
   OFF(imu_pose0, put(A, vec(w.imu_pose0, (size_t)w.n_imu)));
   OFF(imu_sb0, put(A, vec(w.imu_sb0, (size_t)w.n_imu)));
@@ -445,8 +516,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   const int64_t O = nobs, L = nlm, Pn = npair;
   H.bytes_lin = 32 * O + 56 * (int64_t)npose + 32 * L + 8 * (int64_t)D + 72 * L + 144 * Pn  // reads
                 + 32 * L + 120 * L + 144 * Pn + 8 * (int64_t)gpart_size + 8 * GS_COUNT * (int64_t)ngroup;  // writes
-  H.bytes_schur = 72 * L + 144 * Pn + 8 * (int64_t)gpart_size + 8 * (int64_t)nchunk * ((int64_t)Dp * Dp + 3 * Dp);
-  H.bytes_solve = 8 * (int64_t)nchunk * ((int64_t)Dp * (Dp + 1) / 2 + 3 * Dp) + 8 * (int64_t)IMU_LIN_STRIDE * w.n_imu +
+  H.bytes_schur = 72 * L + 144 * Pn + 8 * (int64_t)nchunk * spart_stride;
+  H.bytes_solve = 8 * (int64_t)nchunk * spart_stride + 8 * (int64_t)gpart_size + 8 * (int64_t)IMU_LIN_STRIDE * w.n_imu +
                   8 * (int64_t)Dm * Dm + 8 * (int64_t)D + 2 * (56 * (int64_t)npose + 72 * (int64_t)nsb);
   H.bytes_small = (int64_t)w.n_imu * (8 * IMU_LIN_STRIDE + (int64_t)sizeof(ImuCacheD) + 2 * 56 + 2 * 72) +
                   8 * (int64_t)Dm * Dm * 2;
@@ -475,41 +546,68 @@ void relocate(WinPtrs& P, unsigned char* base, bool debug) {
 }
 
 size_t lin_smem(bool ext) { return (ext ? LinCfg<true>::SMEM_DOUBLES : LinCfg<false>::SMEM_DOUBLES) * sizeof(double); }
-size_t solve_smem(int Dpad) { return ((size_t)Dpad * (Dpad + 1) / 2 + 4 * (size_t)Dpad) * sizeof(double); }
+size_t solve_smem(int Dpad) {
+  const size_t nbk = Dpad / 6;
+  return (nbk * (nbk + 1) / 2 * 38 + 4 * (size_t)Dpad + 2 * nbk * 36) * sizeof(double) + ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15));
+}
 size_t small_smem() { return (size_t)ImuLds::TOTAL * sizeof(double); }
 
-hipError_t launch_schur(okvis_ba_solver* s) {
+struct Sub {
+  hipStream_t st;
+  int w0, nw;
+};
+Sub whole(okvis_ba_solver* s) { return Sub{s->stream, 0, (int)s->wins.size()}; }
+
+hipError_t launch_schur(okvis_ba_solver* s, Sub b) {
   if (s->max_schur_blocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(schur_kernel, dim3(s->max_schur_blocks, (unsigned)s->wins.size()), dim3(SCHUR_THREADS), 0, s->stream,
-                     s->d_wins, s->d_opt);
+  hipLaunchKernelGGL(schur_kernel, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), 0, b.st, s->d_wins + b.w0,
+                     s->d_opt);
   return hipGetLastError();
 }
-hipError_t launch_solve(okvis_ba_solver* s, int final_only) {
-  hipLaunchKernelGGL(solve_kernel, dim3((unsigned)s->wins.size()), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad), s->stream,
-                     s->d_wins, s->d_opt, final_only);
+hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
+  hipLaunchKernelGGL(solve_kernel, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad), b.st, s->d_wins + b.w0,
+                     s->d_opt, final_only);
   return hipGetLastError();
 }
-hipError_t launch_small(okvis_ba_solver* s, int init) {
-  hipLaunchKernelGGL(small_kernel, dim3(s->max_imu + 1, (unsigned)s->wins.size()), dim3(IMU_THREADS), small_smem(), s->stream,
-                     s->d_wins, init);
+hipError_t launch_small(okvis_ba_solver* s, Sub b, int init) {
+  hipLaunchKernelGGL(small_kernel, dim3(s->max_imu + 1, (unsigned)b.nw), dim3(IMU_THREADS), small_smem(), b.st, s->d_wins + b.w0,
+                     init);
   return hipGetLastError();
 }
-hipError_t launch_lin(okvis_ba_solver* s, int init) {
+hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
   if (s->max_group == 0) return hipSuccess;
   if (s->any_ext)
-    hipLaunchKernelGGL(linearize_kernel<true>, dim3(s->max_group, (unsigned)s->wins.size()), dim3(LIN_THREADS), lin_smem(true),
-                       s->stream, s->d_wins, s->d_opt, init);
+    hipLaunchKernelGGL(linearize_kernel<true>, dim3(s->max_group, (unsigned)b.nw), dim3(LIN_THREADS), lin_smem(true), b.st,
+                       s->d_wins + b.w0, s->d_opt, init);
   else
-    hipLaunchKernelGGL(linearize_kernel<false>, dim3(s->max_group, (unsigned)s->wins.size()), dim3(LIN_THREADS), lin_smem(false),
-                       s->stream, s->d_wins, s->d_opt, init);
+    hipLaunchKernelGGL(linearize_kernel<false>, dim3(s->max_group, (unsigned)b.nw), dim3(LIN_THREADS), lin_smem(false), b.st,
+                       s->d_wins + b.w0, s->d_opt, init);
   return hipGetLastError();
 }
-hipError_t launch_iteration(okvis_ba_solver* s) {
+hipError_t launch_iteration(okvis_ba_solver* s, Sub b) {
   hipError_t e;
-  if ((e = launch_schur(s)) != hipSuccess) return e;
-  if ((e = launch_solve(s, 0)) != hipSuccess) return e;
-  if ((e = launch_small(s, 0)) != hipSuccess) return e;
-  return launch_lin(s, 0);
+  if ((e = launch_schur(s, b)) != hipSuccess) return e;
+  if ((e = launch_solve(s, b, 0)) != hipSuccess) return e;
+  if ((e = launch_small(s, b, 0)) != hipSuccess) return e;
+  return launch_lin(s, b, 0);
+}
+// n iterations of every sub-batch: fork from the main stream, one chain per sub-stream, join
+hipError_t launch_iterations_forked(okvis_ba_solver* s, int n) {
+  const int nsub = (int)s->sub_streams.size();
+  if (nsub <= 1) {
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n && e == hipSuccess; ++i) e = launch_iteration(s, whole(s));
+    return e;
+  }
+  hipError_t e = hipEventRecord(s->ev_fork, s->stream);
+  for (int k = 0; k < nsub && e == hipSuccess; ++k) {
+    e = hipStreamWaitEvent(s->sub_streams[k], s->ev_fork, 0);
+    const Sub b{s->sub_streams[k], s->sub_begin[k], s->sub_begin[k + 1] - s->sub_begin[k]};
+    for (int i = 0; i < n && e == hipSuccess; ++i) e = launch_iteration(s, b);
+    if (e == hipSuccess) e = hipEventRecord(s->sub_events[k], s->sub_streams[k]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->sub_events[k], 0);
+  }
+  return e;
 }
 
 // the accepted-buffer index lives on the device while iterations are in flight: read it back
@@ -560,6 +658,8 @@ void okvis_ba_default_options(okvis_ba_options* o) {
   o->schur_lm_per_block = 0;
   o->debug_arrays = 0;
   o->gauss_newton = 0;
+  o->n_streams = 0;
+  o->reserved = 0;
 }
 
 const char* okvis_ba_error_string(int status) {
@@ -588,6 +688,7 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&s->ev0);
   if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc(&s->d_opt, sizeof(OptD));
   // kernels may use more than the default 64 KB of dynamic LDS
   if (e == hipSuccess)
@@ -598,7 +699,7 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
                             (int)lin_smem(false));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)solve_smem(MAX_D_LDS));
+                            (int)solve_smem(((MAX_D_LDS + 5) / 6) * 6));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)small_smem());
@@ -620,6 +721,9 @@ int okvis_ba_destroy(okvis_ba_solver* s) {
   if (s->d_opt) (void)hipFree(s->d_opt);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  for (auto st : s->sub_streams) (void)hipStreamDestroy(st);
+  for (auto ev : s->sub_events) (void)hipEventDestroy(ev);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return OKVIS_BA_OK;
@@ -629,7 +733,8 @@ int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt) {
   if (!s || !opt) return OKVIS_BA_ERR_ARG;
   if (!(opt->initial_radius > 0) || !(opt->min_lm_diagonal > 0) || !(opt->max_lm_diagonal >= opt->min_lm_diagonal))
     return OKVIS_BA_ERR_ARG;
-  if (s->uploaded && (opt->debug_arrays != s->opt.debug_arrays || opt->schur_lm_per_block != s->opt.schur_lm_per_block))
+  if (s->uploaded && (opt->debug_arrays != s->opt.debug_arrays || opt->schur_lm_per_block != s->opt.schur_lm_per_block ||
+                      opt->n_streams != s->opt.n_streams))
     return OKVIS_BA_ERR_STATE;  // these two shape the arena: set them before upload
   s->opt = *opt;
   HIP_TRY(hipSetDevice(s->device));
@@ -683,6 +788,29 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   OptD d = make_optd(s->opt);
   HIP_TRY(hipMemcpy(s->d_opt, &d, sizeof(d), hipMemcpyHostToDevice));
   s->wins.swap(wins);
+  // ---- sub-batches: opt.n_streams (0 = auto: one stream per 8 windows, at most 8) ----
+  {
+    // measured on MI355X / ROCm 7.2: forked branches of a captured graph are not overlapped, so the
+    // default is a single stream (profiles/r01_notes.md)
+    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : 1;
+    nsub = std::max(1, std::min(nsub, n_windows));
+    for (auto st : s->sub_streams) (void)hipStreamDestroy(st);
+    for (auto ev : s->sub_events) (void)hipEventDestroy(ev);
+    s->sub_streams.clear();
+    s->sub_events.clear();
+    s->sub_begin.assign(nsub + 1, 0);
+    for (int k = 0; k <= nsub; ++k) s->sub_begin[k] = (int)((int64_t)n_windows * k / nsub);
+    if (nsub > 1) {
+      for (int k = 0; k < nsub; ++k) {
+        hipStream_t st;
+        hipEvent_t ev;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        s->sub_streams.push_back(st);
+        s->sub_events.push_back(ev);
+      }
+    }
+  }
   s->uploaded = true;
   return OKVIS_BA_OK;
 }
@@ -746,8 +874,8 @@ int okvis_ba_begin(okvis_ba_solver* s) {
     c.lambda = 1.0 / s->opt.initial_radius;
     HIP_TRY(hipMemcpyAsync(H.ptrs.ctrl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
   }
-  HIP_TRY(launch_small(s, 1));
-  HIP_TRY(launch_lin(s, 1));
+  HIP_TRY(launch_small(s, whole(s), 1));
+  HIP_TRY(launch_lin(s, whole(s), 1));
   s->begun = true;
   return OKVIS_BA_OK;
 }
@@ -763,9 +891,8 @@ int okvis_ba_iterate(okvis_ba_solver* s, int n) {
     auto it = s->graphs.find(n);
     if (it == s->graphs.end()) {
       hipGraph_t graph = nullptr;
-      HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-      hipError_t e = hipSuccess;
-      for (int i = 0; i < n && e == hipSuccess; ++i) e = launch_iteration(s);
+      HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+      hipError_t e = launch_iterations_forked(s, n);
       hipError_t e2 = hipStreamEndCapture(s->stream, &graph);
       if (e != hipSuccess) HIP_TRY(e);
       HIP_TRY(e2);
@@ -779,7 +906,7 @@ int okvis_ba_iterate(okvis_ba_solver* s, int n) {
     }
     HIP_TRY(hipGraphLaunch(exec, s->stream));
   } else {
-    for (int i = 0; i < n; ++i) HIP_TRY(launch_iteration(s));
+    HIP_TRY(launch_iterations_forked(s, n));
   }
   HIP_TRY(hipEventRecord(s->ev1, s->stream));
   return OKVIS_BA_OK;
@@ -798,8 +925,8 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
   if (!s->begun) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
   // the final accept/reject needs the Schur partials of the buffer it may accept (gradient test)
-  HIP_TRY(launch_schur(s));
-  HIP_TRY(launch_solve(s, 1));
+  HIP_TRY(launch_schur(s, whole(s)));
+  HIP_TRY(launch_solve(s, whole(s), 1));
   if (s->max_lm > 0) {
     hipLaunchKernelGGL(quality_kernel, dim3((s->max_lm + 255) / 256, (unsigned)s->wins.size()), dim3(256), 0, s->stream, s->d_wins);
     HIP_TRY(hipGetLastError());
@@ -911,6 +1038,7 @@ static int locate(okvis_ba_solver* s, int w, int which, const double** ptr, int6
     case OKVIS_BA_ARR_LM_QUALITY: *ptr = P.quality; *n = H.n_lm; return 0;
     case OKVIS_BA_ARR_GRADIENT: *ptr = P.grad; *n = H.D; return 0;
     case OKVIS_BA_ARR_DAMPING: *ptr = P.Dp2; *n = H.D; return P.Dp2 ? 0 : OKVIS_BA_ERR_STATE;
+    case 99: *ptr = P.prof; *n = 64; return 0;
     case OKVIS_BA_ARR_IMU_RESIDUAL: *ptr = nullptr; *n = 15 * (int64_t)H.n_imu; return 0;
   }
   return OKVIS_BA_ERR_ARG;
@@ -934,7 +1062,7 @@ int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t
   if (which == OKVIS_BA_ARR_IMU_RESIDUAL) {
     const HostWin& H = s->wins[w];
     for (int f = 0; f < H.n_imu; ++f)
-      HIP_TRY(hipMemcpy(out + 15 * f, H.ptrs.imu_lin[H.acc] + (size_t)f * IMU_LIN_STRIDE + 450, 15 * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(out + 15 * f, H.ptrs.imu_lin[H.acc] + (size_t)f * IMU_LIN_STRIDE + IMU_R, 15 * 8, hipMemcpyDeviceToHost));
     return OKVIS_BA_OK;
   }
   if (n > 0) HIP_TRY(hipMemcpy(out, p, (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -950,13 +1078,13 @@ int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4) {
   for (int k = 0; k < 4; ++k) ms4[k] = 0.f;
   for (int i = 0; i < n; ++i) {
     HIP_TRY(hipEventRecord(ev[0], s->stream));
-    HIP_TRY(launch_schur(s));
+    HIP_TRY(launch_schur(s, whole(s)));
     HIP_TRY(hipEventRecord(ev[1], s->stream));
-    HIP_TRY(launch_solve(s, 0));
+    HIP_TRY(launch_solve(s, whole(s), 0));
     HIP_TRY(hipEventRecord(ev[2], s->stream));
-    HIP_TRY(launch_small(s, 0));
+    HIP_TRY(launch_small(s, whole(s), 0));
     HIP_TRY(hipEventRecord(ev[3], s->stream));
-    HIP_TRY(launch_lin(s, 0));
+    HIP_TRY(launch_lin(s, whole(s), 0));
     HIP_TRY(hipEventRecord(ev[4], s->stream));
     HIP_TRY(hipEventSynchronize(ev[4]));
     for (int k = 0; k < 4; ++k) {

@@ -34,7 +34,7 @@ __device__ __forceinline__ void wave_trial_sums(const WinPtrs& W, int buf, int l
     x2 += p[GS_X2];
     gm = fmax(gm, p[GS_GMAX]);
   }
-  for (int f = lane; f < W.n_imu; f += 64) cost += W.imu_lin[buf][(size_t)f * IMU_LIN_STRIDE + 15 * 30 + 15];
+  for (int f = lane; f < W.n_imu; f += 64) cost += W.imu_lin[buf][(size_t)f * IMU_LIN_STRIDE + IMU_COST];
   if (lane == 0) cost += W.small_cost[buf][0];
   out[0] = wave_sum(cost);
   out[1] = wave_sum(gd);

@@ -568,27 +568,46 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
     for (int i = 0; i < 6; ++i) ev[9 + i] = sb0[3 + i] - b1[3 + i];
   }
   __syncthreads();
-  // ---- J = sqrtInfo (upper) * F, r = sqrtInfo * e
+  // ---- J = sqrtInfo (upper) * F (kept in LDS), r = sqrtInfo * e, then H = J^T J and g = J^T r
   double* out = W.imu_lin[trial] + (size_t)f * IMU_LIN_STRIDE;
   const double* SI = ca + CA_SI;
+  double* Jl = lds + ImuLds::PM;  // 450 doubles (PM | TM are free after the re-preintegration)
   for (int wi = tid; wi < 450; wi += IMU_THREADS) {
     const int i = wi / 30, j = wi - 30 * i;
     double s = 0;
     for (int m = i; m < 15; ++m) s += SI[15 * i + m] * F[30 * m + j];
-    out[wi] = s;
+    Jl[wi] = s;
   }
   __shared__ double s_r[16];
   if (tid < 15) {
     double s = 0;
     for (int m = tid; m < 15; ++m) s += SI[15 * tid + m] * ev[m];
-    out[450 + tid] = s;
+    out[IMU_R + tid] = s;
     s_r[tid] = s;
   }
   __syncthreads();
+  for (int wi = tid; wi < 465 + 30; wi += IMU_THREADS) {
+    if (wi < 465) {
+      int a = (int)((sqrtf(8.0f * wi + 1.0f) - 1.0f) * 0.5f);
+      while ((a + 1) * (a + 2) / 2 <= wi) ++a;
+      while (a * (a + 1) / 2 > wi) --a;
+      const int b = wi - a * (a + 1) / 2;
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) s += Jl[30 * k + a] * Jl[30 * k + b];
+      out[IMU_H + wi] = s;
+    } else {
+      const int a = wi - 465;
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) s += Jl[30 * k + a] * s_r[k];
+      out[IMU_G + a] = s;
+    }
+  }
   if (tid == 0) {
     double s = 0;
     for (int i = 0; i < 15; ++i) s += s_r[i] * s_r[i];
-    out[465] = 0.5 * s;
+    out[IMU_COST] = 0.5 * s;
   }
 }
 

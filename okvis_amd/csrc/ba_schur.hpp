@@ -3,11 +3,16 @@
 //   S_pp' = U_pp' - sum_l W_pl (V_l + lambda D_l^2)^-1 W_p'l^T ,  rhs_p = -g_p + sum_l W_pl Vinv_l b_l
 //
 // (the algebra Ceres' SPARSE_SCHUR performs, Estimator.cpp:854; in-tree analogue
-// MarginalizationError.cpp:617-689).  A workgroup owns (chunk of groups) x (96x96 tile pair of the pose
-// part); every work-item owns one 6x6 block of the tile in registers (36 fp64 accumulators) and sweeps
-// the chunk's landmarks, which are staged SCHUR_LM_BATCH at a time as dense [tile rows][3] tables in LDS
-// (Y = W Vinv for the row tile, W for the column tile).  Partials go to HBM per chunk and are summed in a
-// fixed order by the solve kernel: deterministic, no atomics.
+// MarginalizationError.cpp:617-689).  This kernel produces the landmark part  -sum Y W^T  and  sum Y b;
+// the U_pp / g_p parts are summed by the solve kernel from the linearise kernel's per-group partials.
+//
+// A workgroup owns (chunk of groups) x (tile pair of <=16x16 pose blocks).  Only the lower triangle is
+// computed.  The 256 work-items are (6x6 block pair) x (landmark slice): every work-item keeps its 6x6
+// block in 36 fp64 accumulators and sweeps every n_slice-th landmark of the current batch; the slices sit
+// in adjacent lanes and are combined with two xor-shuffles at the end.  Landmarks are staged
+// SCHUR_LM_BATCH at a time as dense [tile rows][3] tables in LDS (Y = W Vinv for the row tile, W for the
+// column tile).  Partials go to HBM per chunk in the solve kernel's block-packed layout and are summed
+// there in fixed chunk order: deterministic, no atomics.
 //
 // The accept/reject decision for the pending trial is recomputed here by wave 0 (bit-identical to the
 // solve kernel, see ba_device.hpp) because the reduction must read the buffer that is about to become the
@@ -73,15 +78,31 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
   const int nblk = W.Dp / 6;
   const int row0 = ti * SCHUR_TILE_BLOCKS, col0 = tj * SCHUR_TILE_BLOCKS;
   const int nrow = min(SCHUR_TILE_BLOCKS, nblk - row0), ncol = min(SCHUR_TILE_BLOCKS, nblk - col0);
-  const int bi = tid / SCHUR_TILE_BLOCKS, bj = tid % SCHUR_TILE_BLOCKS;
-  const bool active = (bi < nrow) && (bj < ncol);
+  const bool diag_tile = (ti == tj);
+  // block pairs of this tile pair and the landmark slicing
+  const int npairs = diag_tile ? nrow * (nrow + 1) / 2 : nrow * ncol;
+  int nslice = 1;
+  while (nslice < 4 && npairs * nslice * 2 <= SCHUR_THREADS) nslice *= 2;
+  const int pi = tid / nslice, slice = tid - pi * nslice;
+  const bool active = pi < npairs;
+  int bi = 0, bj = 0;
+  if (active) {
+    if (diag_tile) {
+      bi = (int)((sqrtf(8.0f * pi + 1.0f) - 1.0f) * 0.5f);
+      while ((bi + 1) * (bi + 2) / 2 <= pi) ++bi;
+      while (bi * (bi + 1) / 2 > pi) --bi;
+      bj = pi - bi * (bi + 1) / 2;
+    } else {
+      bi = pi / ncol;
+      bj = pi - bi * ncol;
+    }
+  }
+  const bool do_rhs = active && diag_tile && bi == bj;  // every row block of a diagonal tile exactly once
 
   double accS[36];
 #pragma unroll
   for (int i = 0; i < 36; ++i) accS[i] = 0.0;
-  double accR[6] = {0, 0, 0, 0, 0, 0};   // sum Y b   (only bj == 0 of column tile 0)
-  double accG[6] = {0, 0, 0, 0, 0, 0};   // sum g     (reprojection part of the gradient)
-  double accD[6] = {0, 0, 0, 0, 0, 0};   // diag(U)   (reprojection part, undamped)
+  double accR[6] = {0, 0, 0, 0, 0, 0};  // sum Y b
 
   const Chunk C = W.chunks[chunk];
   const int lm_begin = W.groups[C.group_begin].lm_begin;
@@ -92,10 +113,14 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
 
   for (int l0 = lm_begin; l0 < lm_end; l0 += SCHUR_LM_BATCH) {
     const int nb = min(SCHUR_LM_BATCH, lm_end - l0);
-    // zero the tables
-    for (int i = tid; i < SCHUR_LM_BATCH * TILE_DIM * 3; i += SCHUR_THREADS) {
-      (&s_Y[0][0][0])[i] = 0.0;
-      (&s_W[0][0][0])[i] = 0.0;
+    // zero the tables (missing (landmark, block) pairs contribute nothing)
+    {
+      double2* zy = reinterpret_cast<double2*>(&s_Y[0][0][0]);
+      double2* zw = reinterpret_cast<double2*>(&s_W[0][0][0]);
+      for (int i = tid; i < SCHUR_LM_BATCH * TILE_DIM * 3 / 2; i += SCHUR_THREADS) {
+        zy[i] = make_double2(0.0, 0.0);
+        zw[i] = make_double2(0.0, 0.0);
+      }
     }
     if (tid < nb) {
       const int l = l0 + tid;
@@ -137,7 +162,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
     }
     __syncthreads();
     if (active) {
-      for (int lb = 0; lb < nb; ++lb) {
+      for (int lb = slice; lb < nb; lb += nslice) {
         double y[18], w[18];
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
@@ -149,7 +174,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
 #pragma unroll
           for (int c = 0; c < 6; ++c)
             accS[6 * r + c] -= y[3 * r] * w[3 * c] + y[3 * r + 1] * w[3 * c + 1] + y[3 * r + 2] * w[3 * c + 2];
-        if (tj == 0 && bj == 0) {
+        if (do_rhs) {
 #pragma unroll
           for (int r = 0; r < 6; ++r)
             accR[r] += y[3 * r] * s_b[lb][0] + y[3 * r + 1] * s_b[lb][1] + y[3 * r + 2] * s_b[lb][2];
@@ -159,58 +184,24 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
     __syncthreads();
   }
 
-  // ---- add the per-group block partials of this chunk (U_pp, U_pe, g_p) ----
-  if (active) {
-    const double* gp = W.gpart[acc];
-    const int my_row = (row0 + bi) * 6, my_col = (col0 + bj) * 6;
-    for (int g = C.group_begin; g < C.group_end; ++g) {
-      const Group G = W.groups[g];
-      for (int t = G.task_begin; t < G.task_end; ++t) {
-        const Task T = W.tasks[t];
-        const double* o = gp + T.out;
-        if (T.type < 2) {
-          if (T.off_a == my_row && T.off_a == my_col) {
+  // ---- combine the landmark slices (adjacent lanes) in a fixed order ----
+  for (int o = 1; o < nslice; o <<= 1) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+    for (int i = 0; i < 36; ++i) accS[i] += __shfl_xor(accS[i], o, 64);
 #pragma unroll
-              for (int c = 0; c < 6; ++c) accS[6 * r + c] += (r <= c) ? o[ut6(r, c)] : o[ut6(c, r)];
-          }
-          if (tj == 0 && bj == 0 && T.off_a == my_row) {
+    for (int i = 0; i < 6; ++i) accR[i] += __shfl_xor(accR[i], o, 64);
+  }
+  // ---- write the partial in the solve kernel's block-packed layout ----
+  if (active && slice == 0) {
+    const int gbi = row0 + bi, gbj = col0 + bj;  // gbi >= gbj
+    double* sp = W.spart + (size_t)chunk * W.spart_stride;
+    double* blk = sp + (size_t)(gbi * (gbi + 1) / 2 + gbj) * 36;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-              accG[r] += o[21 + r];
-              accD[r] += o[ut6(r, r)];
-            }
-          }
-        } else {
-          if (T.off_a == my_row && T.off_b == my_col) {
+    for (int i = 0; i < 36; ++i) blk[i] = accS[i];
+    if (do_rhs) {
+      double* sr = sp + (size_t)(nblk * (nblk + 1) / 2) * 36;
 #pragma unroll
-            for (int i = 0; i < 36; ++i) accS[i] += o[i];
-          } else if (T.off_b == my_row && T.off_a == my_col) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-              for (int c = 0; c < 6; ++c) accS[6 * r + c] += o[6 * c + r];
-          }
-        }
-      }
-    }
-    // ---- write the partial ----
-    const int Dp = W.Dp;
-    double* sp = W.spart + (size_t)chunk * ((size_t)Dp * Dp + 3 * Dp);
-    const int r0 = (row0 + bi) * 6, c0 = (col0 + bj) * 6;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) sp[(size_t)(r0 + r) * Dp + c0 + c] = accS[6 * r + c];
-    if (tj == 0 && bj == 0) {
-      double* sr = sp + (size_t)Dp * Dp;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        sr[r0 + r] = accR[r];
-        sr[Dp + r0 + r] = accG[r];
-        sr[2 * Dp + r0 + r] = accD[r];
-      }
+      for (int r = 0; r < 6; ++r) sr[gbi * 6 + r] = accR[r];
     }
   }
 }

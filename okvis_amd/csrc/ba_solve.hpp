@@ -1,12 +1,18 @@
 // Kernel 3 — trust-region control + reduced-camera solve, one workgroup per window (fp64, LDS resident).
 //
 //   1. accept / reject the pending trial (Ceres LevenbergMarquardtStrategy semantics, ba_device.hpp)
-//   2. assemble the reduced system of the accepted linearisation in LDS (packed lower triangle):
-//        sum of the Schur partials (fixed chunk order)  +  IMU / prior / marginalisation-prior blocks
+//   2. assemble the reduced system of the accepted linearisation in LDS:
+//        sum of the Schur partials (fixed chunk order) + per-group U_pp/g_p partials (host-built lists)
+//        + precomputed IMU Hessian blocks (colour phases) + prior / marginalisation-prior blocks
 //   3. convergence tests of the step just accepted (gradient, function tolerance)
-//   4. LM damping  S += lambda * clamp(diag U),  blocked right-looking Cholesky with 6x6 register blocks,
-//      forward / backward substitution
+//   4. LM damping  S += lambda * clamp(diag U),  blocked right-looking Cholesky
 //   5. trial poses / speed-biases  x (+) delta  (PoseLocalParameterization::plus), model-decrease scalars
+//
+// LDS layout of S: lower triangle in 6x6 blocks, block (bi >= bj) at ((bi(bi+1)/2 + bj) * 36), row-major
+// inside; a work-item's operand block is 288 contiguous bytes.  Cholesky step kb: (P) every panel row
+// re-factors the 6x6 diagonal block in registers (no barrier between "factor" and "panel"), solves its
+// row and the right-hand side rides along as one more row (forward substitution for free); (T) trailing
+// update with one 6x6 register block per work-item.  Two barriers per block column.
 //
 // This is the only kernel that writes the window's Ctrl record.
 #pragma once
@@ -14,19 +20,33 @@
 
 namespace ba {
 
-__device__ __forceinline__ int pidx(int i, int j) { return (i * (i + 1)) / 2 + j; }  // i >= j
+// LDS layout of the reduced matrix: lower triangle in 6x6 blocks, stored block-COLUMN by block-column
+// (the panel of a Cholesky step is contiguous) with a block stride of 38 doubles: 16 consecutive blocks
+// start on 16 distinct 4-bank groups, so a wave's ds_read_b128 of "my block" is conflict-free.
+constexpr int SBS = 38;
+struct SLayout {
+  int nbk;
+  __device__ __forceinline__ int blk(int bi, int bj) const {  // bi >= bj
+    return (bj * nbk - (bj * (bj - 1)) / 2 + (bi - bj)) * SBS;
+  }
+  __device__ __forceinline__ int at(int i, int j) const {  // scalar index, i >= j
+    const int bi = i / 6, bj = j / 6;
+    return blk(bi, bj) + (i - 6 * bi) * 6 + (j - 6 * bj);
+  }
+};
 
 // accumulate J^T J (lower triangle, reduced coordinates) and J^T r of one small factor.
 // J: nres x ncol row-major (ncol = sum of dims), col_off[c] = reduced index of local column c or -1.
-__device__ __forceinline__ void add_small_factor(double* S, double* g, double* d2, const double* J, const double* r,
-                                                 int nres, int ncol, const int* col_off, int tid, int nthreads) {
+__device__ __forceinline__ void add_small_factor(double* S, const SLayout LY, double* g, double* d2, const double* J,
+                                                 const double* r, int nres, int ncol, const int* col_off, int tid,
+                                                 int nthreads) {
   for (int wi = tid; wi < ncol * ncol; wi += nthreads) {
     const int a = wi / ncol, b = wi - a * ncol;
     const int ra = col_off[a], rb = col_off[b];
     if (ra < 0 || rb < 0 || ra < rb) continue;
     double s = 0;
     for (int k = 0; k < nres; ++k) s += J[k * ncol + a] * J[k * ncol + b];
-    S[pidx(ra, rb)] += s;
+    S[LY.at(ra, rb)] += s;
     if (a == b) d2[ra] += s;
   }
   for (int a = tid; a < ncol; a += nthreads) {
@@ -36,6 +56,70 @@ __device__ __forceinline__ void add_small_factor(double* S, double* g, double* d
     for (int k = 0; k < nres; ++k) s += J[k * ncol + a] * r[k];
     g[ra] += s;
   }
+}
+
+// in-register Cholesky of a 6x6 SPD block given its lower triangle L[i][j] (i >= j); returns false if
+// a pivot is not positive.  inv[k] = 1 / L[k][k].
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  // 1/sqrt(d): hardware estimate + two Newton steps (short dependency chain, no fp64 divide / sqrt macro)
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+__device__ __forceinline__ bool chol6(double (&L)[6][6], double (&inv)[6]) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double d = L[k][k];
+#pragma unroll
+    for (int m = 0; m < k; ++m) d -= L[k][m] * L[k][m];
+    ok = ok && (d > 0.0);
+    const double dd = d > 0.0 ? d : 1.0;
+    inv[k] = rsqrt_nr(dd);
+    L[k][k] = dd * inv[k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      double v = L[i][k];
+#pragma unroll
+      for (int m = 0; m < k; ++m) v -= L[i][m] * L[k][m];
+      L[i][k] = v * inv[k];
+    }
+  }
+  return ok;
+}
+
+// inverse of a lower-triangular 6x6 factor (inv[k] = 1/L[k][k]); Li lower-triangular
+__device__ __forceinline__ void trinv6(const double (&L)[6][6], const double (&inv)[6], double (&Li)[6][6]) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    Li[j][j] = inv[j];
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double s = 0;
+#pragma unroll
+      for (int m = j; m < i; ++m) s += L[i][m] * Li[m][j];
+      Li[i][j] = -s * inv[i];
+    }
+  }
+}
+
+// factor the 6x6 diagonal block (lower triangle at dblk) and publish L (row-major 6x6) and 1/diag(L)
+__device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, double* inv_out) {
+  double L[6][6], inv[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) L[i][j] = dblk[6 * i + j];
+  const bool ok = chol6(L, inv);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) Lout[6 * i + j] = L[i][j];
+    inv_out[i] = inv[i];
+  }
+  return ok;
 }
 
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __restrict__ wins,
@@ -48,18 +132,25 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   const OptD opt = *optp;
   const int D = W.D, Dp = W.Dp;
   const int Dpad = ((D + 5) / 6) * 6, nbk = Dpad / 6;
+  const int nS = nbk * (nbk + 1) / 2 * SBS;
+  const SLayout LY{nbk};
 
-  double* S = smem;                                  // packed lower, Dpad
-  double* s_rhs = S + (size_t)Dpad * (Dpad + 1) / 2; // Dpad
-  double* s_g = s_rhs + Dpad;
-  double* s_d2 = s_g + Dpad;
-  double* s_x = s_d2 + Dpad;
+  double* S = smem;           // block-packed lower triangle
+  double* s_rhs = S + nS;     // Dpad: rhs, then y = L^-1 rhs in place
+  double* s_g = s_rhs + Dpad; // gradient (pose / speed-bias part)
+  double* s_d2 = s_g + Dpad;  // diag(U) -> clamp -> LM damping diagonal
+  double* s_x = s_d2 + Dpad;  // solution
+  double* s_diag = s_x + Dpad;       // nbk * 36: factored diagonal blocks L_kk
+  double* s_dinv = s_diag + nbk * 36;  // nbk * 36: their inverses
+  unsigned short* s_ptab = reinterpret_cast<unsigned short*>(s_dinv + nbk * 36);  // (bi<<8|bj) of the block-pair enumeration
   __shared__ Ctrl c;
   __shared__ int s_accepted, s_was_first, s_fail;
   __shared__ double s_cost_change, s_old_cost, s_lm_gmax;
   __shared__ int s_coloff[64];
   __shared__ double s_red[SOLVE_THREADS / 64];
 
+#define STAMP(k) do { if (tid == 0 && blockIdx.x == 0) W.prof[k] = (double)clock64(); } while (0)
+  STAMP(0);
   // ------------------------------------------------------------------ 1. decision
   if (tid < 64) {
     double sums[6] = {0, 0, 0, 0, 0, 0};
@@ -109,60 +200,126 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   }
   const int acc = c.acc;
 
+  STAMP(1);
   // ------------------------------------------------------------------ 2. assembly
-  const int npk = Dpad * (Dpad + 1) / 2;
-  for (int i = tid; i < npk; i += SOLVE_THREADS) S[i] = 0.0;
-  for (int i = tid; i < Dpad; i += SOLVE_THREADS) {
-    s_rhs[i] = 0.0;
-    s_g[i] = 0.0;
-    s_d2[i] = 0.0;
-    s_x[i] = 0.0;
-  }
-  __syncthreads();
   {
-    const size_t stride = (size_t)Dp * Dp + 3 * Dp;
-    const int np = Dp * (Dp + 1) / 2;
-    for (int k = tid; k < np; k += SOLVE_THREADS) {
-      // invert k = i(i+1)/2 + j
-      int i = (int)((sqrt(8.0 * k + 1.0) - 1.0) * 0.5);
-      while ((i + 1) * (i + 2) / 2 <= k) ++i;
-      while (i * (i + 1) / 2 > k) --i;
-      const int j = k - i * (i + 1) / 2;
-      double s = 0;
-      for (int ch = 0; ch < W.n_chunk; ++ch) s += W.spart[ch * stride + (size_t)i * Dp + j];
-      S[k] = s;
+    // pose part: the Schur partials already use this block layout (pose blocks come first)
+    const int npose_blk = Dp / 6;
+    const int nP = npose_blk * (npose_blk + 1) / 2 * 36;
+    const size_t stride = W.spart_stride;
+    const int nch = W.n_chunk;
+    const double* sp = W.spart;
+    // block-pair enumeration table (row-major lower triangle): entry wi -> (a, b), a >= b.  Used for the
+    // Schur partials' layout, the IMU 30x30 triangles and (mirrored) the trailing-update enumeration.
+    const int ntab = max(nbk * (nbk + 1) / 2, 465);
+    for (int wi = tid; wi < ntab; wi += SOLVE_THREADS) {
+      int bi = (int)((sqrtf(8.0f * wi + 1.0f) - 1.0f) * 0.5f);
+      while ((bi + 1) * (bi + 2) / 2 <= wi) ++bi;
+      while (bi * (bi + 1) / 2 > wi) --bi;
+      s_ptab[wi] = (unsigned short)((bi << 8) | (wi - bi * (bi + 1) / 2));
     }
-    for (int i = tid; i < Dp; i += SOLVE_THREADS) {
-      double yb = 0, g = 0, du = 0;
-      for (int ch = 0; ch < W.n_chunk; ++ch) {
-        const double* sr = W.spart + ch * stride + (size_t)Dp * Dp;
-        yb += sr[i];
-        g += sr[Dp + i];
-        du += sr[2 * Dp + i];
+    for (int i = tid; i < nS; i += SOLVE_THREADS) S[i] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < nP; i += SOLVE_THREADS) {
+      double s = 0;
+      for (int ch = 0; ch < nch; ch += 8) {  // 8 independent loads in flight
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride + i] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      const int q = i / 36, e = i - 36 * q;
+      S[LY.blk(s_ptab[q] >> 8, s_ptab[q] & 255) + e] = s;
+    }
+    for (int i = tid; i < Dpad; i += SOLVE_THREADS) {
+      double yb = 0;
+      if (i < Dp) {
+        for (int ch = 0; ch < nch; ch += 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride + nP + i] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) yb += v[u];
+        }
       }
       s_rhs[i] = yb;
-      s_g[i] = g;
-      s_d2[i] = du;
+      s_g[i] = 0.0;
+      s_d2[i] = 0.0;
+      s_x[i] = 0.0;
     }
   }
   __syncthreads();
-  // ---- IMU factors: J 15x30 | r 15 ----
-  for (int f = 0; f < W.n_imu; ++f) {
-    if (tid < 30) {
-      const int blk = tid < 6 ? 0 : (tid < 15 ? 1 : (tid < 21 ? 2 : 3));
-      const int within = tid - (blk == 0 ? 0 : (blk == 1 ? 6 : (blk == 2 ? 15 : 21)));
-      int off;
-      if (blk == 0) off = W.pose_off[W.imu_pose0[f]];
-      else if (blk == 1) off = W.sb_off[W.imu_sb0[f]];
-      else if (blk == 2) off = W.pose_off[W.imu_pose1[f]];
-      else off = W.sb_off[W.imu_sb1[f]];
-      s_coloff[tid] = off < 0 ? -1 : off + within;
+  STAMP(2);
+  // ---- per-group U_pp / U_pe / g_p partials of the linearise kernel (host-built lists, fixed order) ----
+  {
+    const double* gp = W.gpart[acc];
+    const int* alist = W.asm_list;
+    auto list_sum = [&](int lb, int le, int eo) -> double {
+      double s = 0;
+      for (int k = lb; k < le; k += 8) {
+        int o[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = (k + u < le) ? alist[k + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (o[u] >= 0) ? gp[o[u] + eo] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      return s;
+    };
+    for (int wi = tid; wi < W.n_asm * 42; wi += SOLVE_THREADS) {
+      const int t = wi / 42, e = wi - 42 * t;
+      const AsmTarget T = W.asm_targets[t];
+      if (T.type == 0) {
+        if (e < 36) {
+          const int r = e / 6, cidx = e - 6 * r;
+          if (r < cidx) continue;
+          const int u = cidx * 6 - (cidx * (cidx - 1)) / 2 + (r - cidx);  // upper-tri index of (cidx, r)
+          const double s = list_sum(T.list_begin, T.list_end, u);
+          S[LY.blk(T.off_a / 6, T.off_a / 6) + e] += s;
+          if (r == cidx) s_d2[T.off_a + r] += s;
+        } else {
+          const int r = e - 36;
+          s_g[T.off_a + r] += list_sum(T.list_begin, T.list_end, 21 + r);
+        }
+      } else if (e < 36) {
+        // X = J_pose^T J_ext (rows: pose, cols: ext); the extrinsics block has the larger offset
+        const int r = e / 6, cidx = e - 6 * r;
+        const double s = list_sum(T.list_begin, T.list_end, e);
+        if (T.off_b > T.off_a)
+          S[LY.blk(T.off_b / 6, T.off_a / 6) + cidx * 6 + r] += s;
+        else
+          S[LY.blk(T.off_a / 6, T.off_b / 6) + e] += s;
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(3);
+  // ---- IMU factors: precomputed H (30x30 lower) | g (30); factors of one colour touch disjoint blocks ----
+  for (int col = 0; col < W.n_imu_color; ++col) {
+    const int fb = W.imu_color_begin[col], fe = W.imu_color_begin[col + 1];
+    for (int wi = tid; wi < (fe - fb) * 512; wi += SOLVE_THREADS) {
+      const int f = W.imu_order[fb + (wi >> 9)], e = wi & 511;
+      if (e >= 495) continue;
+      const double* L = W.imu_lin[acc] + (size_t)f * IMU_LIN_STRIDE;
+      const int* co = W.imu_coloff + 30 * f;
+      const double v = L[e];
+      if (e < 465) {
+        const int a = s_ptab[e] >> 8, b = s_ptab[e] & 255;   // same lower-triangular enumeration
+        const int ra = co[a], rb = co[b];
+        if (ra < 0 || rb < 0) continue;
+        if (ra >= rb) S[LY.at(ra, rb)] += v; else S[LY.at(rb, ra)] += v;
+        if (a == b) s_d2[ra] += v;
+      } else {
+        const int ra = co[e - 465];
+        if (ra >= 0) s_g[ra] += v;
+      }
     }
     __syncthreads();
-    const double* L = W.imu_lin[acc] + (size_t)f * IMU_LIN_STRIDE;
-    add_small_factor(S, s_g, s_d2, L, L + 15 * 30, 15, 30, s_coloff, tid, SOLVE_THREADS);
-    __syncthreads();
   }
+  STAMP(4);
   // ---- pose priors: J 6x6 | r 6 ----
   for (int f = 0; f < W.n_pprior; ++f) {
     if (tid < 6) {
@@ -171,7 +328,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     __syncthreads();
     const double* L = W.pp_lin[acc] + (size_t)f * 42;
-    add_small_factor(S, s_g, s_d2, L, L + 36, 6, 6, s_coloff, tid, SOLVE_THREADS);
+    add_small_factor(S, LY, s_g, s_d2, L, L + 36, 6, 6, s_coloff, tid, SOLVE_THREADS);
     __syncthreads();
   }
   // ---- speed/bias priors: J = -sqrtInfo (9x9 const) | r 9 ----
@@ -190,7 +347,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       if (ra < 0 || rb < 0 || ra < rb) continue;
       double s = 0;
       for (int k = 0; k < 9; ++k) s += Jc[k * 9 + a] * Jc[k * 9 + b];
-      S[pidx(ra, rb)] += s;
+      S[LY.at(ra, rb)] += s;
       if (a == b) s_d2[ra] += s;
     }
     if (tid < 9 && s_coloff[tid] >= 0) {
@@ -208,7 +365,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     __syncthreads();
     const double* L = W.rel_lin[acc] + (size_t)f * 78;
-    add_small_factor(S, s_g, s_d2, L, L + 72, 6, 12, s_coloff, tid, SOLVE_THREADS);
+    add_small_factor(S, LY, s_g, s_d2, L, L + 72, 6, 12, s_coloff, tid, SOLVE_THREADS);
     __syncthreads();
   }
   // ---- marginalisation prior: H = B^T (J^T J) B, g = B^T J^T e ----
@@ -244,7 +401,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           }
         }
       }
-      S[pidx(Ri + li, Rj + lj)] += s;
+      S[LY.at(Ri + li, Rj + lj)] += s;
       if (Ri + li == Rj + lj) s_d2[Ri + li] += s;
     }
     for (int rr = tid; rr < Dm; rr += SOLVE_THREADS) {
@@ -266,6 +423,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     __syncthreads();
   }
 
+  STAMP(5);
   // ------------------------------------------------------------------ 3. convergence of the accepted step
   {
     double m = 0;
@@ -306,10 +464,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     if (i < D) {
       const double d2 = clampd(s_d2[i], opt.min_lm_diag2, opt.max_lm_diag2);
       s_d2[i] = d2;
-      S[pidx(i, i)] += lambda * d2;
+      S[LY.at(i, i)] += lambda * d2;
       s_rhs[i] = s_rhs[i] - s_g[i];
     } else {
-      S[pidx(i, i)] = 1.0;  // identity padding up to a multiple of 6
+      S[LY.at(i, i)] = 1.0;  // identity padding up to a multiple of 6
       s_rhs[i] = 0.0;
     }
   }
@@ -317,93 +475,105 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   if (W.S) {  // parity/debug copy of the damped system
     for (int k = tid; k < D * D; k += SOLVE_THREADS) {
       const int i = k / D, j = k - i * D;
-      W.S[k] = (i >= j) ? S[pidx(i, j)] : S[pidx(j, i)];
+      W.S[k] = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
     }
     for (int i = tid; i < D; i += SOLVE_THREADS) {
       W.rhs[i] = s_rhs[i];
       W.Dp2[i] = s_d2[i];
     }
   }
+  STAMP(6);
+  if (tid == 0) {
+    if (!factor_diag(S + LY.blk(0, 0), s_diag, s_dinv)) s_fail = 1;
+  }
+  __syncthreads();
   for (int kb = 0; kb < nbk; ++kb) {
     const int k0 = kb * 6;
-    // (1) factor the 6x6 diagonal block in registers of wave 0
-    if (tid < 64) {
-      const int i = tid / 6, j = tid - 6 * i;
-      const bool in = tid < 36 && i >= j;
-      double a = in ? S[pidx(k0 + i, k0 + j)] : 0.0;
-      int bad = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const double dk = __shfl(a, k * 6 + k, 64);
-        if (!(dk > 0.0)) bad = 1;
-        const double sd = sqrt(dk > 0.0 ? dk : 1.0);
-        if (in && j == k) a = (i == k) ? sd : a / sd;
-        const double aik = __shfl(a, (tid < 36 ? i : 0) * 6 + k, 64);
-        const double ajk = __shfl(a, (tid < 36 ? j : 0) * 6 + k, 64);
-        if (in && j > k) a -= aik * ajk;
-      }
-      if (in) S[pidx(k0 + i, k0 + j)] = a;
-      if (bad && tid == 0) s_fail = 1;
-    }
-    __syncthreads();
-    // (2) panel: rows below, L_ik = A_ik L_kk^-T  (plus the rhs row: forward substitution for free)
-    for (int r = k0 + 6 + tid; r < Dpad; r += SOLVE_THREADS) {
+    const int nrows = Dpad - k0 - 6;  // panel rows below the diagonal block
+    if (kb == 0) STAMP(10);
+    if (kb == 12) STAMP(13);
+    // (P) panel: row <- row * L_kk^-T (independent dot products with the published inverse); the
+    //     right-hand side rides along as one more row (forward substitution)
+    if (tid <= nrows) {
+      double* row = (tid < nrows) ? (S + LY.blk((k0 + 6 + tid) / 6, kb) + ((k0 + 6 + tid) % 6) * 6) : (s_rhs + k0);
+      const double* Ld = s_diag + 36 * kb;
+      const double* iv = s_dinv + 6 * kb;
       double x[6];
 #pragma unroll
       for (int cix = 0; cix < 6; ++cix) {
-        double v = S[pidx(r, k0 + cix)];
-        for (int m = 0; m < cix; ++m) v -= x[m] * S[pidx(k0 + cix, k0 + m)];
-        x[cix] = v / S[pidx(k0 + cix, k0 + cix)];
+        double v = row[cix];
+#pragma unroll
+        for (int m = 0; m < cix; ++m) v -= x[m] * Ld[6 * cix + m];
+        x[cix] = v * iv[cix];
       }
 #pragma unroll
-      for (int cix = 0; cix < 6; ++cix) S[pidx(r, k0 + cix)] = x[cix];
-    }
-    if (tid == SOLVE_THREADS - 1) {  // y_k = L_kk^-1 (rhs_k - ...), the rest of rhs is updated in (3)
-      double y[6];
-      for (int cix = 0; cix < 6; ++cix) {
-        double v = s_rhs[k0 + cix];
-        for (int m = 0; m < cix; ++m) v -= y[m] * S[pidx(k0 + cix, k0 + m)];
-        y[cix] = v / S[pidx(k0 + cix, k0 + cix)];
-      }
-      for (int cix = 0; cix < 6; ++cix) s_rhs[k0 + cix] = y[cix];
+      for (int cix = 0; cix < 6; ++cix) row[cix] = x[cix];
     }
     __syncthreads();
-    // (3) trailing update with 6x6 register blocks: A_(bi,bj) -= L_(bi,k) L_(bj,k)^T
+    if (kb == 0) STAMP(11);
+    if (kb == 12) STAMP(14);
+    // (T) trailing update with 6x6 register blocks  A_(bi,bj) -= L_(bi,k) L_(bj,k)^T ; rhs blocks ride
+    //     along; the owner of the next diagonal block factors it right away (look-ahead)
     const int nt = nbk - kb - 1;
-    for (int wi = tid; wi < nt * (nt + 1) / 2; wi += SOLVE_THREADS) {
-      int bi = (int)((sqrt(8.0 * wi + 1.0) - 1.0) * 0.5);
-      while ((bi + 1) * (bi + 2) / 2 <= wi) ++bi;
-      while (bi * (bi + 1) / 2 > wi) --bi;
-      const int bj = wi - bi * (bi + 1) / 2;
-      const int r0 = (kb + 1 + bi) * 6, c0 = (kb + 1 + bj) * 6;
-      double Li[36], Lj[36];
+    const int nblkpairs = nt * (nt + 1) / 2;
+    // four work-items per 6x6 block (3x3 register sub-tiles): many light waves hide the LDS / FMA latency
+    for (int wi = tid; wi < 4 * nblkpairs + nt; wi += SOLVE_THREADS) {
+      if (wi < 4 * nblkpairs) {
+        const int q = wi >> 2, sub = wi & 3;
+        const int sr = (sub >> 1) * 3, sc = (sub & 1) * 3;
+        // mirrored enumeration: consecutive blocks walk DOWN one block column (contiguous in LDS)
+        const int gbj = nbk - 1 - (s_ptab[q] >> 8), gbi = nbk - 1 - (s_ptab[q] & 255);  // gbi >= gbj > kb
+        const double* Li = S + LY.blk(gbi, kb) + 6 * sr;   // rows sr..sr+2 of L_(gbi,k)
+        const double* Lj = S + LY.blk(gbj, kb) + 6 * sc;   // rows sc..sc+2 of L_(gbj,k)
+        double* Cb = S + LY.blk(gbi, gbj) + 6 * sr + sc;
+        double li[18], lj[18];
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-          Li[6 * r + m] = S[pidx(r0 + r, k0 + m)];
-          Lj[6 * r + m] = S[pidx(c0 + r, k0 + m)];
+        for (int i = 0; i < 9; ++i) {
+          const double2 u = reinterpret_cast<const double2*>(Li)[i], v = reinterpret_cast<const double2*>(Lj)[i];
+          li[2 * i] = u.x; li[2 * i + 1] = u.y;
+          lj[2 * i] = v.x; lj[2 * i + 1] = v.y;
         }
+        if (!(gbi == gbj && sub == 1)) {   // the upper-right 3x3 of a diagonal block is never read
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+          for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int cix = 0; cix < 6; ++cix) {
-          if (bi == bj && cix > r) continue;
+            for (int cix = 0; cix < 3; ++cix) {
+              double s0 = 0;
+#pragma unroll
+              for (int m = 0; m < 6; ++m) s0 += li[6 * r + m] * lj[6 * cix + m];
+              Cb[6 * r + cix] -= s0;
+            }
+        }
+        if (gbi == kb + 1 && sub == 0) {
+          // block (kb+1, kb+1) is final once the four lanes of this quad have stored: factor it for the
+          // next panel phase (look-ahead).  Same wave => LDS operations are ordered; fence the compiler.
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          asm volatile("" ::: "memory");
+          if (!factor_diag(S + LY.blk(kb + 1, kb + 1), s_diag + 36 * (kb + 1), s_dinv + 6 * (kb + 1))) s_fail = 1;
+        }
+      } else {
+        // right-hand-side block: rhs_(bi) -= L_(bi,k) y_k
+        const int bi = wi - 4 * nblkpairs;
+        const double* Li = S + LY.blk(kb + 1 + bi, kb);
+        double* rr = s_rhs + (kb + 1 + bi) * 6;
+        double y[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) y[m] = s_rhs[k0 + m];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
           double s = 0;
 #pragma unroll
-          for (int m = 0; m < 6; ++m) s += Li[6 * r + m] * Lj[6 * cix + m];
-          S[pidx(r0 + r, c0 + cix)] -= s;
+          for (int m = 0; m < 6; ++m) s += Li[6 * r + m] * y[m];
+          rr[r] -= s;
         }
+      }
     }
-    // rhs rows below: rhs_i -= L_(i,k) y_k
-    for (int r = k0 + 6 + tid; r < Dpad; r += SOLVE_THREADS) {
-      double v = s_rhs[r];
-#pragma unroll
-      for (int m = 0; m < 6; ++m) v -= S[pidx(r, k0 + m)] * s_rhs[k0 + m];
-      s_rhs[r] = v;
-    }
+    if (kb == 0) STAMP(26);
     __syncthreads();
+    if (kb == 0) STAMP(12);
+    if (kb == 12) STAMP(15);
   }
+  STAMP(7);
   if (s_fail) {  // not positive definite: invalid step (handled like a rejection)
     if (tid == 0) {
       c.iter++;
@@ -416,27 +586,38 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     return;
   }
-  // back substitution  L^T x = y, blocked from the last block up
+  // back substitution  L^T x = y: block kb is solved redundantly by every work-item that owns a block
+  // above it, which then updates its own block — one barrier per block column
   for (int kb = nbk - 1; kb >= 0; --kb) {
-    const int k0 = kb * 6;
-    if (tid == 0) {
+    if (tid <= kb) {
+      const double* Ld = s_diag + 36 * kb;   // x_k = L_kk^-T y_k
+      const double* iv = s_dinv + 6 * kb;
       double x[6];
-      for (int cix = 5; cix >= 0; --cix) {
-        double v = s_rhs[k0 + cix];
-        for (int m = cix + 1; m < 6; ++m) v -= S[pidx(k0 + m, k0 + cix)] * x[m];
-        x[cix] = v / S[pidx(k0 + cix, k0 + cix)];
-      }
-      for (int cix = 0; cix < 6; ++cix) s_x[k0 + cix] = x[cix];
-    }
-    __syncthreads();
-    for (int j = tid; j < k0; j += SOLVE_THREADS) {
-      double v = s_rhs[j];
 #pragma unroll
-      for (int m = 0; m < 6; ++m) v -= S[pidx(k0 + m, j)] * s_x[k0 + m];
-      s_rhs[j] = v;
+      for (int cix = 5; cix >= 0; --cix) {
+        double v = s_rhs[kb * 6 + cix];
+#pragma unroll
+        for (int m = cix + 1; m < 6; ++m) v -= Ld[6 * m + cix] * x[m];
+        x[cix] = v * iv[cix];
+      }
+      if (tid == kb) {
+#pragma unroll
+        for (int cix = 0; cix < 6; ++cix) s_x[kb * 6 + cix] = x[cix];
+      } else {
+        const double* Lb = S + LY.blk(kb, tid);  // rows: block kb, columns: block tid
+        double* yy = s_rhs + tid * 6;
+#pragma unroll
+        for (int cix = 0; cix < 6; ++cix) {
+          double s = 0;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) s += Lb[6 * m + cix] * x[m];
+          yy[cix] -= s;
+        }
+      }
     }
     __syncthreads();
   }
+  STAMP(8);
 
   // ------------------------------------------------------------------ 5. scalars, trial state, ctrl
   {
@@ -506,6 +687,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       *gctrl = c;
     }
   }
+  STAMP(9);
+#undef STAMP
 }
 
 // landmark quality (Estimator.cpp:880-896): 3x3 eigenvalues of the un-robustified H_l of the accepted

@@ -14,12 +14,14 @@ constexpr int GROUP_PAIRS = 512;     // max (landmark, block) pairs per group
 constexpr int LIN_THREADS = 256;
 constexpr int SCHUR_THREADS = 256;
 constexpr int SCHUR_TILE_BLOCKS = 16;  // 16 x 16 blocks of 6x6 = 96 x 96 tile, one 6x6 block per thread
-constexpr int SCHUR_LM_BATCH = 8;      // landmarks staged per LDS pass in the Schur kernel
-constexpr int SOLVE_THREADS = 512;
-constexpr int MAX_D_LDS = 192;         // reduced systems up to this size are factorised in LDS (packed)
+constexpr int SCHUR_LM_BATCH = 16;     // landmarks staged per LDS pass in the Schur kernel
+constexpr int SOLVE_THREADS = 1024;
+constexpr int MAX_D_LDS = 174;         // reduced systems up to this size are factorised in LDS (block-packed)
 constexpr int MAX_IMU_STEPS = 254;     // integration steps of one IMU factor (threads of its workgroup)
 constexpr int IMU_THREADS = 256;
-constexpr int IMU_LIN_STRIDE = 15 * 30 + 15 + 1;  // J(15x30) | r(15) | cost
+// IMU factor linearisation record: H = J^T J (30x30 lower, packed a(a+1)/2+b) | g = J^T r (30) | r (15) | cost
+constexpr int IMU_H = 0, IMU_G = 465, IMU_R = 495, IMU_COST = 510;
+constexpr int IMU_LIN_STRIDE = 512;
 constexpr int MAX_MARG_DIM = 192;
 
 // 32-byte observation record (coalesced 2 x 16 B per lane).  idx0 = landmark | cam << 24.
@@ -53,6 +55,17 @@ struct Task {
 
 struct Chunk {  // one Schur workgroup: a range of groups
   int group_begin, group_end;
+};
+
+// assembly target of the solve kernel: one 6x6 block of the reduced matrix that collects the per-group
+// partials (tasks) of a pose block (diag) or a pose-extrinsics pair (cross)
+struct AsmTarget {
+  int type;        // 0 diag (task out = 21 upper-tri + 6 g), 2 cross (task out = 36, rows = pose, cols = ext)
+  int off_a;       // reduced offset of the block (diag) / of the pose block (cross)
+  int off_b;       // reduced offset of the extrinsics block (cross)
+  int list_begin;  // into asm_list (task 'out' offsets)
+  int list_end;
+  int pad;
 };
 
 struct ImuParamsD {
@@ -109,6 +122,8 @@ struct WinPtrs {
   int has_ext;            // any non-fixed extrinsics-role block
   int gpart_size;         // doubles in gpart
   int n_tile;             // Schur tiles per dimension
+  int n_asm, n_imu_color;
+  int spart_stride;       // doubles per chunk partial: (Dp/6)(Dp/6+1)/2*36 + Dp
   double cauchy_b;
   ImuParamsD imu;
 
@@ -134,6 +149,11 @@ struct WinPtrs {
   const Task* tasks;
   const uint16_t* task_list;
   const Chunk* chunks;
+  const AsmTarget* asm_targets;  // [n_asm]
+  const int* asm_list;           // task 'out' offsets, fixed order (group order)
+  const int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
+  const int* imu_color_begin;    // [n_imu_color+1]
+  const int* imu_coloff;         // [n_imu][30] reduced index of each local column (or -1)
 
   // ---- linearisation (index = buffer 0/1) ----
   double* V[2];           // [n_lm][6]
@@ -152,7 +172,7 @@ struct WinPtrs {
   double* obs_r[2];       // [n_obs][2] (debug/parity)
 
   // ---- Schur / solve ----
-  double* spart;          // [n_chunk][Dp*Dp + Dp]
+  double* spart;          // [n_chunk][spart_stride]: block-packed lower triangle | Y b
   double* S;              // [D][D]
   double* rhs;            // [D]
   double* step;           // [D]
@@ -160,6 +180,7 @@ struct WinPtrs {
   double* Dp2;            // [D]
   double* Hpp;            // [D][D] undamped U (debug/parity), optional
   double* quality;        // [n_lm]
+  double* prof;           // [64] clock64() phase stamps of workgroup 0 (diagnostics)
   Ctrl* ctrl;
 
   // ---- IMU ----

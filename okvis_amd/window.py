@@ -56,6 +56,7 @@ class OptionsC(C.Structure):
         ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("use_graph", C.c_int32), ("schur_lm_per_block", C.c_int32),
         ("debug_arrays", C.c_int32), ("gauss_newton", C.c_int32),
+        ("n_streams", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -77,7 +78,7 @@ class LimitsC(C.Structure):
 
 def default_options() -> OptionsC:
     """Ceres 1.9 defaults restated from its documentation (not in the reference tree)."""
-    return OptionsC(1e4, 1e16, 1e-32, 1e-6, 1e32, 1e-3, 1e-6, 1e-10, 1e-8, 1, 0, 0, 0)
+    return OptionsC(1e4, 1e16, 1e-32, 1e-6, 1e32, 1e-3, 1e-6, 1e-10, 1e-8, 1, 0, 0, 0, 0, 0)
 
 
 def _f64(a, shape):

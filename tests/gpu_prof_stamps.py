@@ -1,0 +1,21 @@
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from okvis_amd import solver, synthetic
+from okvis_amd.window import default_options
+opt = default_options(); opt.gauss_newton = 1; opt.function_tolerance = 0; opt.gradient_tolerance = 0; opt.parameter_tolerance = 0; opt.use_graph = 0
+b = solver.WindowBatch([synthetic.config_A()], options=opt)
+b.begin(); b.iterate(12); b.synchronize()
+p = b.array("PROF")
+names = {0:"start",1:"decision",2:"spart+vec",3:"imu",4:"priors+marg",5:"conv",6:"damping",7:"cholesky",8:"backsub",9:"end"}
+print("solve phases (cycles, us@2.1GHz):")
+for k in range(1,10):
+    d = p[k]-p[k-1]; print(f"  {names[k]:12s} {d:10.0f} cyc  {d/2100:8.2f} us")
+print("  total", p[9]-p[0], (p[9]-p[0])/2100)
+sn = {17:"decision",18:"landmark loop",19:"tasks",20:"write"}
+print("schur phases:")
+for k in range(17,21):
+    d = p[k]-p[k-1]; print(f"  {sn[k]:14s} {d:10.0f} cyc {d/2100:8.2f} us")
+
+print("kb=0: panel", p[11]-p[10], "trailing(thread0 work)", p[26]-p[11], "trailing+barrier", p[12]-p[11])
+print("kb=12: panel", p[14]-p[13], "trailing+barrier", p[15]-p[14])
