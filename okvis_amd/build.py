@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libokvis_amd_ba.so")
 SOURCES = ["ba_capi.hip"]
-HEADERS = ["ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_schur.hpp", "ba_solve.hpp",
+HEADERS = [os.path.join("host", "estimator.hpp"), os.path.join("host", "estimator.cpp"),
+           os.path.join("host", "estimator_capi.cpp"), "ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_schur.hpp", "ba_solve.hpp",
            "ba_imu.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
 
 
@@ -33,7 +34,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    build_host(verbose)
     return LIB
+
+
+HOST_LIB = os.path.join(HERE, "lib", "libokvis_amd_estimator.so")
+
+
+def build_host(verbose: bool = False) -> str:
+    """C++ host layer (okvis_amd::Estimator + flat C wrapper), linked against the HIP library."""
+    host = os.path.join(CSRC, "host")
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", os.path.join(host, "estimator.cpp"),
+           os.path.join(host, "estimator_capi.cpp"), "-o", HOST_LIB, "-L" + os.path.dirname(LIB), "-lokvis_amd_ba",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_LIB
 
 
 if __name__ == "__main__":

@@ -1,0 +1,639 @@
+// okvis_amd::Estimator implementation — window book-keeping on the host, optimisation on the GPU through
+// the C-ABI.  Citations are to the reference okvis_ceres/src/Estimator.cpp unless noted.
+#include "estimator.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "../ba_math.hpp"
+
+namespace okvis_amd {
+
+namespace {
+
+// squareRootInformation_ = LLT(information).matrixL().transpose() with Eigen's unblocked-LLT early exit on a
+// non-positive pivot (PoseError.cpp:70-76 applied to diag(1e8,1e8,1e8,0,0,1e8), Estimator.cpp:240-242).
+template <size_t N2>
+void sqrtInformation(const std::array<double, N2>& info, int n, std::array<double, N2>& out) {
+  std::array<double, N2> A = info;
+  for (int k = 0; k < n; ++k) {
+    double x = A[k * n + k];
+    for (int j = 0; j < k; ++j) x -= A[k * n + j] * A[k * n + j];
+    if (x <= 0.0) break;
+    x = std::sqrt(x);
+    A[k * n + k] = x;
+    for (int i = k + 1; i < n; ++i) {
+      double s = A[i * n + k];
+      for (int j = 0; j < k; ++j) s -= A[i * n + j] * A[k * n + j];
+      A[i * n + k] = s / x;
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) out[i * n + j] = (j >= i) ? A[j * n + i] : 0.0;
+}
+
+std::array<double, 36> poseSqrtInfo(double translationVariance, double rotationVariance) {
+  std::array<double, 36> info{}, out{};
+  for (int i = 0; i < 3; ++i) {
+    info[i * 6 + i] = 1.0 / translationVariance;
+    info[(3 + i) * 6 + 3 + i] = 1.0 / rotationVariance;
+  }
+  sqrtInformation(info, 6, out);
+  return out;
+}
+
+void check(int status, const char* what) {
+  if (status != OKVIS_BA_OK)
+    throw Estimator::Exception(std::string("okvis_amd backend: ") + what + ": " + okvis_ba_error_string(status));
+}
+
+}  // namespace
+
+Estimator::Estimator(int device) : device_(device) {
+  okvis_ba_default_options(&options_);
+  std::memset(&summary_, 0, sizeof(summary_));
+  // no GPU => hard failure: there is no CPU optimisation path behind this class
+  check(okvis_ba_create(&solver_, device), "okvis_ba_create");
+}
+
+Estimator::~Estimator() {
+  if (solver_) okvis_ba_destroy(solver_);
+}
+
+int Estimator::addCamera(const ExtrinsicsEstimationParameters& p) {
+  extrinsicsEstimationParametersVec_.push_back(p);
+  return (int)extrinsicsEstimationParametersVec_.size() - 1;  // Estimator.cpp:83-89
+}
+int Estimator::addImu(const ImuParameters& p) {
+  if (imuParametersVec_.size() > 1) return -1;  // "only one IMU currently supported", Estimator.cpp:93-96
+  imuParametersVec_.push_back(p);
+  return (int)imuParametersVec_.size() - 1;
+}
+void Estimator::clearCameras() { extrinsicsEstimationParametersVec_.clear(); }
+void Estimator::clearImus() { imuParametersVec_.clear(); }
+
+const Estimator::State* Estimator::findState(uint64_t id) const {
+  for (const State& s : states_)
+    if (s.id == id) return &s;
+  return nullptr;
+}
+Estimator::State* Estimator::findState(uint64_t id) {
+  for (State& s : states_)
+    if (s.id == id) return &s;
+  return nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// static ImuError::propagation (ImuError.cpp:287-504), state output only (covariance/jacobian == 0 as in
+// the addStates call, Estimator.cpp:145-147)
+// ---------------------------------------------------------------------------------------------------
+int Estimator::propagation(const ImuMeasurementDeque& m, const ImuParameters& prm, Transformation& T_WS,
+                           SpeedAndBias& sb, int64_t t_start, int64_t t_end) {
+  using namespace ba;
+  if (m.empty() || !(m.back().t_ns >= t_end)) return -1;  // :301-302
+  double q0[4] = {T_WS.p[3], T_WS.p[4], T_WS.p[5], T_WS.p[6]};
+  qnormalize(q0);
+  double C_WS_0[9];
+  qrot(q0, C_WS_0);
+  double Dq[4] = {0, 0, 0, 1};
+  double acc_integral[3] = {0, 0, 0}, acc_doubleintegral[3] = {0, 0, 0};
+  double Delta_t = 0;
+  bool hasStarted = false;
+  int i = 0;
+  int64_t time = t_start;
+  const size_t n = m.size();
+  for (size_t it = 0; it < n; ++it) {
+    double w0[3], a0[3], w1[3], a1[3];
+    const size_t nx = (it + 1 < n) ? it + 1 : it;
+    for (int c = 0; c < 3; ++c) {
+      w0[c] = m[it].gyr[c];
+      a0[c] = m[it].acc[c];
+      w1[c] = m[nx].gyr[c];
+      a1[c] = m[nx].acc[c];
+    }
+    int64_t nexttime = (it + 1 == n) ? t_end : m[it + 1].t_ns;
+    double dt = ns_to_sec(nexttime - time);
+    if (t_end < nexttime) {
+      const double interval = ns_to_sec(nexttime - m[it].t_ns);
+      nexttime = t_end;
+      dt = ns_to_sec(nexttime - time);
+      const double r = dt / interval;
+      for (int c = 0; c < 3; ++c) {
+        w1[c] = (1.0 - r) * w0[c] + r * w1[c];
+        a1[c] = (1.0 - r) * a0[c] + r * a1[c];
+      }
+    }
+    if (dt <= 0.0) continue;
+    Delta_t += dt;
+    if (!hasStarted) {
+      hasStarted = true;
+      const double r = dt / ns_to_sec(nexttime - m[it].t_ns);
+      for (int c = 0; c < 3; ++c) {
+        w0[c] = r * w0[c] + (1.0 - r) * w1[c];
+        a0[c] = r * a0[c] + (1.0 - r) * a1[c];
+      }
+    }
+    double om[3], ab[3];
+    for (int c = 0; c < 3; ++c) {
+      om[c] = 0.5 * (w0[c] + w1[c]) - sb[3 + c];
+      ab[c] = 0.5 * (a0[c] + a1[c]) - sb[6 + c];
+    }
+    const double th = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]) * 0.5 * dt;
+    const double sc = sinc(th);
+    const double dq[4] = {sc * om[0] * 0.5 * dt, sc * om[1] * 0.5 * dt, sc * om[2] * 0.5 * dt, std::cos(th)};
+    double Dq1[4], C[9], C1[9];
+    qmul(Dq, dq, Dq1);
+    qrot(Dq, C);
+    qrot(Dq1, C1);
+    double h[9], t3[3];
+    for (int c = 0; c < 9; ++c) h[c] = C[c] + C1[c];
+    mat3_vec(h, ab, t3);
+    for (int c = 0; c < 3; ++c) {
+      acc_doubleintegral[c] += acc_integral[c] * dt + 0.25 * t3[c] * dt * dt;
+      acc_integral[c] += 0.5 * t3[c] * dt;
+    }
+    for (int c = 0; c < 4; ++c) Dq[c] = Dq1[c];
+    time = nexttime;
+    ++i;
+    if (nexttime == t_end) break;
+  }
+  // :470-477
+  double r_new[3], tmp[3];
+  mat3_vec(C_WS_0, acc_doubleintegral, tmp);
+  for (int c = 0; c < 3; ++c) {
+    const double gW = (c == 2) ? prm.g : 0.0;
+    r_new[c] = T_WS.p[c] + sb[c] * Delta_t + tmp[c] - 0.5 * gW * Delta_t * Delta_t;
+  }
+  double qn[4];
+  qmul(q0, Dq, qn);
+  qnormalize(qn);
+  mat3_vec(C_WS_0, acc_integral, tmp);
+  for (int c = 0; c < 3; ++c) {
+    const double gW = (c == 2) ? prm.g : 0.0;
+    sb[c] += tmp[c] - gW * Delta_t;
+    T_WS.p[c] = r_new[c];
+  }
+  for (int c = 0; c < 4; ++c) T_WS.p[3 + c] = qn[c];
+  return i;
+}
+
+// Estimator.cpp:811-840
+bool Estimator::initPoseFromImu(const ImuMeasurementDeque& imuMeasurements, Transformation& T_WS) {
+  T_WS = Transformation();
+  if (imuMeasurements.empty()) return false;
+  double acc_B[3] = {0, 0, 0};
+  for (const ImuMeasurement& m : imuMeasurements)
+    for (int c = 0; c < 3; ++c) acc_B[c] += m.acc[c];
+  for (int c = 0; c < 3; ++c) acc_B[c] /= double(imuMeasurements.size());
+  const double n = std::sqrt(acc_B[0] * acc_B[0] + acc_B[1] * acc_B[1] + acc_B[2] * acc_B[2]);
+  const double e[3] = {acc_B[0] / n, acc_B[1] / n, acc_B[2] / n};
+  // poseIncrement.tail<3>() = ez_W.cross(e_acc).normalized() * acos(ez_W . e_acc); T_WS.oplus(-poseIncrement)
+  double ax[3] = {-e[1], e[0], 0.0};  // (0,0,1) x e
+  const double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1]);
+  const double angle = std::acos(e[2]);
+  double d[6] = {0, 0, 0, 0, 0, 0};
+  if (an > 0)
+    for (int c = 0; c < 3; ++c) d[3 + c] = -ax[c] / an * angle;
+  double out[7];
+  ba::pose_oplus(T_WS.p.data(), d, out);
+  for (int c = 0; c < 7; ++c) T_WS.p[c] = out[c];
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// addStates (Estimator.cpp:110-343)
+// ---------------------------------------------------------------------------------------------------
+bool Estimator::addStates(MultiFramePtr multiFrame, const ImuMeasurementDeque& imuMeasurements, bool asKeyframe) {
+  if (!multiFrame || imuParametersVec_.empty()) return false;
+  Transformation T_WS;
+  SpeedAndBias speedAndBias{};
+  if (states_.empty()) {
+    if (!initPoseFromImu(imuMeasurements, T_WS)) return false;  // :121-125
+    for (int c = 0; c < 3; ++c) speedAndBias[6 + c] = imuParametersVec_.at(0).a0[c];  // :126-127
+  } else {
+    const State& last = states_.back();
+    if (last.sbBlock < 0) return false;
+    T_WS.p = poseBlocks_[last.poseBlock].x;
+    speedAndBias = sbBlocks_[last.sbBlock].x;
+    const int used = propagation(imuMeasurements, imuParametersVec_.at(0), T_WS, speedAndBias, last.t_ns,
+                                 multiFrame->t_ns);  // :145-147
+    if (used < 1) return false;                     // :150-153
+  }
+  if (findState(multiFrame->id)) return false;  // "pose ID was used before" (:161-163)
+
+  State st;
+  st.id = multiFrame->id;
+  st.t_ns = multiFrame->t_ns;
+  st.isKeyframe = asKeyframe;
+  st.poseBlock = (int)poseBlocks_.size();
+  poseBlocks_.push_back(PoseBlock{T_WS.p, false, st.id});
+  const bool first = states_.empty();
+  // camera extrinsics (:191-218)
+  for (size_t i = 0; i < extrinsicsEstimationParametersVec_.size(); ++i) {
+    const ExtrinsicsEstimationParameters& ep = extrinsicsEstimationParametersVec_[i];
+    if ((ep.sigma_c_relative_translation < 1e-12 || ep.sigma_c_relative_orientation < 1e-12) && !first) {
+      st.extBlocks.push_back(states_.back().extBlocks.at(i));  // use the same block
+    } else {
+      if (i >= multiFrame->T_SC.size()) return false;
+      st.extBlocks.push_back((int)poseBlocks_.size());
+      poseBlocks_.push_back(PoseBlock{multiFrame->T_SC[i].p, false, nextId_++});
+    }
+  }
+  st.sbBlock = (int)sbBlocks_.size();
+  sbBlocks_.push_back(SbBlock{speedAndBias, false, nextId_++});  // :222-235
+
+  if (first) {
+    // pose prior with information diag(1e8,1e8,1e8,0,0,1e8) (:238-243)
+    std::array<double, 36> info{}, si{};
+    info[0] = info[7] = info[14] = 1.0e8;
+    info[35] = 1.0e8;
+    sqrtInformation(info, 6, si);
+    posePriors_.push_back(PosePrior{st.poseBlock, T_WS.p, si});
+    for (size_t i = 0; i < extrinsicsEstimationParametersVec_.size(); ++i) {  // :247-268
+      const ExtrinsicsEstimationParameters& ep = extrinsicsEstimationParametersVec_[i];
+      const double tv = ep.sigma_absolute_translation * ep.sigma_absolute_translation;
+      const double rv = ep.sigma_absolute_orientation * ep.sigma_absolute_orientation;
+      if (tv > 1.0e-16 && rv > 1.0e-16)
+        posePriors_.push_back(PosePrior{st.extBlocks[i], poseBlocks_[st.extBlocks[i]].x, poseSqrtInfo(tv, rv)});
+      else
+        poseBlocks_[st.extBlocks[i]].fixed = true;  // setParameterBlockConstant
+    }
+    {  // speed and bias prior (:269-284)
+      const ImuParameters& ip = imuParametersVec_.at(0);
+      std::array<double, 81> info9{}, si9{};
+      for (int c = 0; c < 3; ++c) {
+        info9[c * 9 + c] = 1.0;
+        info9[(3 + c) * 9 + 3 + c] = 1.0 / (ip.sigma_bg * ip.sigma_bg);
+        info9[(6 + c) * 9 + 6 + c] = 1.0 / (ip.sigma_ba * ip.sigma_ba);
+      }
+      sqrtInformation(info9, 9, si9);
+      sbPriors_.push_back(SbPrior{st.sbBlock, speedAndBias, si9});
+    }
+  } else {
+    const State& last = states_.back();
+    imuFactors_.push_back(ImuFactor{last.id, st.id, last.t_ns, st.t_ns, imuMeasurements});  // :288-307
+    for (size_t i = 0; i < extrinsicsEstimationParametersVec_.size(); ++i) {           // :310-336
+      if (last.extBlocks[i] != st.extBlocks[i]) {
+        const ExtrinsicsEstimationParameters& ep = extrinsicsEstimationParametersVec_[i];
+        const double dt = ba::ns_to_sec(st.t_ns - last.t_ns);
+        relPoses_.push_back(RelPose{last.extBlocks[i], st.extBlocks[i],
+                                    poseSqrtInfo(ep.sigma_c_relative_translation * ep.sigma_c_relative_translation * dt,
+                                                 ep.sigma_c_relative_orientation * ep.sigma_c_relative_orientation * dt)});
+      }
+    }
+  }
+  states_.push_back(st);
+  multiFramePtrMap_[st.id] = multiFrame;
+  return true;
+}
+
+// Estimator.cpp:346-365
+bool Estimator::addLandmark(uint64_t landmarkId, const std::array<double, 4>& landmark) {
+  if (landmarksMap_.count(landmarkId)) return false;  // Map::addParameterBlock fails on a duplicate id
+  MapPoint mp;
+  mp.id = landmarkId;
+  mp.point = landmark;
+  mp.quality = 0.0;
+  mp.distance = 1.7976931348623157e308;
+  if (std::fabs(landmark[3]) > 1.0e-8) {
+    const double x = landmark[0] / landmark[3], y = landmark[1] / landmark[3], z = landmark[2] / landmark[3];
+    mp.distance = std::sqrt(x * x + y * y + z * z);
+  }
+  landmarksMap_[landmarkId] = mp;
+  landmarkInitialized_[landmarkId] = false;
+  return true;
+}
+
+// implementation/Estimator.hpp:43-90
+uint64_t Estimator::addObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx) {
+  auto lit = landmarksMap_.find(landmarkId);
+  if (lit == landmarksMap_.end()) throw Exception("landmark not added");
+  const KeypointIdentifier kid{poseId, camIdx, keypointIdx};
+  if (lit->second.observations.count(kid)) return 0;  // duplicate -> NULL (:52-56)
+  auto mf = multiFramePtrMap_.find(poseId);
+  if (mf == multiFramePtrMap_.end() || camIdx >= mf->second->keypoints.size() ||
+      keypointIdx >= mf->second->keypoints[camIdx].size())
+    throw Exception("addObservation: unknown frame / camera / keypoint");
+  const Keypoint& kp = mf->second->keypoints[camIdx][keypointIdx];
+  Observation o;
+  o.handle = nextHandle_++;
+  o.landmarkId = landmarkId;
+  o.poseId = poseId;
+  o.camIdx = camIdx;
+  o.keypointIdx = keypointIdx;
+  o.u = (double)kp.x;  // float -> double (:60-61)
+  o.v = (double)kp.y;
+  o.sqrtw = 8.0 / (double)kp.size;  // information = 64/size^2 * I (:62-65)
+  observations_[o.handle] = o;
+  lit->second.observations[kid] = o.handle;
+  return o.handle;
+}
+
+// Estimator.cpp:368-413
+bool Estimator::removeObservation(uint64_t handle) {
+  auto it = observations_.find(handle);
+  if (it == observations_.end()) return false;
+  MapPoint& mp = landmarksMap_.at(it->second.landmarkId);
+  for (auto oit = mp.observations.begin(); oit != mp.observations.end();) {
+    if (oit->second == handle)
+      oit = mp.observations.erase(oit);
+    else
+      ++oit;
+  }
+  observations_.erase(it);
+  return true;
+}
+bool Estimator::removeObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx) {
+  auto lit = landmarksMap_.find(landmarkId);
+  if (lit == landmarksMap_.end()) throw Exception("landmark not added");
+  auto oit = lit->second.observations.find(KeypointIdentifier{poseId, camIdx, keypointIdx});
+  if (oit == lit->second.observations.end()) return false;  // observation not present
+  observations_.erase(oit->second);
+  lit->second.observations.erase(oit);
+  return true;
+}
+
+// Estimator.cpp:909-929
+bool Estimator::setOptimizationTimeLimit(double timeLimit, int minIterations) {
+  timeLimit_ = timeLimit;
+  minIterations_ = minIterations;
+  hasTimeLimit_ = true;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// flat window for the C-ABI
+// ---------------------------------------------------------------------------------------------------
+void Estimator::buildWindow(std::vector<std::vector<double>>& f64, std::vector<std::vector<int32_t>>& i32,
+                            std::vector<std::vector<int64_t>>& i64, std::vector<std::vector<uint8_t>>& u8,
+                            okvis_ba_window& w, std::vector<uint64_t>& lmOrder) const {
+  std::memset(&w, 0, sizeof(w));
+  f64.assign(24, {});
+  i32.assign(24, {});
+  i64.assign(4, {});
+  u8.assign(2, {});
+  enum { F_POSE, F_SB, F_LM, F_INTR, F_UV, F_SW, F_GYR, F_ACC, F_PPM, F_PPS, F_SBM, F_SBS, F_RELS };
+  enum { I_MODEL, I_OLM, I_OPOSE, I_OEXT, I_OCAM, I_IP0, I_IS0, I_IP1, I_IS1, I_SB, I_SC, I_PPP, I_SBP, I_R0, I_R1 };
+  // parameter blocks
+  for (const PoseBlock& b : poseBlocks_) {
+    f64[F_POSE].insert(f64[F_POSE].end(), b.x.begin(), b.x.end());
+    u8[0].push_back(b.fixed ? 1 : 0);
+  }
+  for (const SbBlock& b : sbBlocks_) {
+    f64[F_SB].insert(f64[F_SB].end(), b.x.begin(), b.x.end());
+    u8[1].push_back(b.fixed ? 1 : 0);
+  }
+  std::map<uint64_t, int> lmIndex;
+  lmOrder.clear();
+  for (const auto& kv : landmarksMap_) {
+    lmIndex[kv.first] = (int)lmOrder.size();
+    lmOrder.push_back(kv.first);
+    f64[F_LM].insert(f64[F_LM].end(), kv.second.point.begin(), kv.second.point.end());
+  }
+  // cameras: one intrinsics record per (distinct) camera index of the newest multiframe
+  size_t ncam = 0;
+  if (!states_.empty()) {
+    const MultiFramePtr& mf = multiFramePtrMap_.at(states_.back().id);
+    ncam = mf->geometry.size();
+    for (const CameraGeometry& g : mf->geometry) {
+      f64[F_INTR].insert(f64[F_INTR].end(), g.intr.begin(), g.intr.end());
+      i32[I_MODEL].push_back(g.model);
+    }
+  }
+  // observations sorted by (landmark index, pose block, camera)
+  struct Rec {
+    int lm, pose, ext, cam;
+    double u, v, sw;
+  };
+  std::vector<Rec> recs;
+  for (const auto& kv : observations_) {
+    const Observation& o = kv.second;
+    const State* st = findState(o.poseId);
+    if (!st || o.camIdx >= st->extBlocks.size() || o.camIdx >= ncam) continue;
+    recs.push_back(Rec{lmIndex.at(o.landmarkId), st->poseBlock, st->extBlocks[o.camIdx], (int)o.camIdx, o.u, o.v, o.sqrtw});
+  }
+  std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) {
+    if (a.lm != b.lm) return a.lm < b.lm;
+    if (a.pose != b.pose) return a.pose < b.pose;
+    return a.cam < b.cam;
+  });
+  for (const Rec& r : recs) {
+    i32[I_OLM].push_back(r.lm);
+    i32[I_OPOSE].push_back(r.pose);
+    i32[I_OEXT].push_back(r.ext);
+    i32[I_OCAM].push_back(r.cam);
+    f64[F_UV].push_back(r.u);
+    f64[F_UV].push_back(r.v);
+    f64[F_SW].push_back(r.sw);
+  }
+  // IMU factors
+  for (const ImuFactor& f : imuFactors_) {
+    const State* s0 = findState(f.pose0Id);
+    const State* s1 = findState(f.pose1Id);
+    if (!s0 || !s1 || s0->sbBlock < 0 || s1->sbBlock < 0) continue;
+    i32[I_IP0].push_back(s0->poseBlock);
+    i32[I_IS0].push_back(s0->sbBlock);
+    i32[I_IP1].push_back(s1->poseBlock);
+    i32[I_IS1].push_back(s1->sbBlock);
+    i64[0].push_back(f.t0);
+    i64[1].push_back(f.t1);
+    i32[I_SB].push_back((int)i64[2].size());
+    i32[I_SC].push_back((int)f.meas.size());
+    for (const ImuMeasurement& m : f.meas) {
+      i64[2].push_back(m.t_ns);
+      f64[F_GYR].insert(f64[F_GYR].end(), m.gyr.begin(), m.gyr.end());
+      f64[F_ACC].insert(f64[F_ACC].end(), m.acc.begin(), m.acc.end());
+    }
+  }
+  for (const PosePrior& p : posePriors_) {
+    i32[I_PPP].push_back(p.block);
+    f64[F_PPM].insert(f64[F_PPM].end(), p.meas.begin(), p.meas.end());
+    f64[F_PPS].insert(f64[F_PPS].end(), p.sqrtInfo.begin(), p.sqrtInfo.end());
+  }
+  for (const SbPrior& p : sbPriors_) {
+    i32[I_SBP].push_back(p.block);
+    f64[F_SBM].insert(f64[F_SBM].end(), p.meas.begin(), p.meas.end());
+    f64[F_SBS].insert(f64[F_SBS].end(), p.sqrtInfo.begin(), p.sqrtInfo.end());
+  }
+  for (const RelPose& r : relPoses_) {
+    i32[I_R0].push_back(r.block0);
+    i32[I_R1].push_back(r.block1);
+    f64[F_RELS].insert(f64[F_RELS].end(), r.sqrtInfo.begin(), r.sqrtInfo.end());
+  }
+  w.n_pose = (int)poseBlocks_.size(); w.pose = f64[F_POSE].data(); w.pose_fixed = u8[0].data();
+  w.n_sb = (int)sbBlocks_.size(); w.sb = f64[F_SB].data(); w.sb_fixed = u8[1].data();
+  w.n_lm = (int)lmOrder.size(); w.lm = f64[F_LM].data();
+  w.n_cam = (int)ncam; w.cam_intr = f64[F_INTR].data(); w.cam_model = i32[I_MODEL].data();
+  w.n_obs = (int)recs.size();
+  w.obs_lm = i32[I_OLM].data(); w.obs_pose = i32[I_OPOSE].data(); w.obs_ext = i32[I_OEXT].data(); w.obs_cam = i32[I_OCAM].data();
+  w.obs_uv = f64[F_UV].data(); w.obs_sqrtw = f64[F_SW].data();
+  w.cauchy_b = 1.0;  // cauchyLossFunctionPtr_(new ::ceres::CauchyLoss(1)), Estimator.cpp:60
+  w.n_imu = (int)i32[I_IP0].size();
+  w.imu_pose0 = i32[I_IP0].data(); w.imu_sb0 = i32[I_IS0].data(); w.imu_pose1 = i32[I_IP1].data(); w.imu_sb1 = i32[I_IS1].data();
+  w.imu_t0 = i64[0].data(); w.imu_t1 = i64[1].data(); w.imu_s_begin = i32[I_SB].data(); w.imu_s_count = i32[I_SC].data();
+  w.n_imu_samples = (int)i64[2].size(); w.imu_s_t = i64[2].data(); w.imu_s_gyr = f64[F_GYR].data(); w.imu_s_acc = f64[F_ACC].data();
+  if (!imuParametersVec_.empty()) {
+    const ImuParameters& ip = imuParametersVec_[0];
+    w.imu_params = okvis_ba_imu_params{ip.sigma_g_c, ip.sigma_a_c, ip.sigma_gw_c, ip.sigma_aw_c, ip.g, ip.g_max, ip.a_max};
+  }
+  w.n_pprior = (int)posePriors_.size(); w.pprior_pose = i32[I_PPP].data(); w.pprior_meas = f64[F_PPM].data(); w.pprior_sqrtinfo = f64[F_PPS].data();
+  w.n_sbprior = (int)sbPriors_.size(); w.sbprior_sb = i32[I_SBP].data(); w.sbprior_meas = f64[F_SBM].data(); w.sbprior_sqrtinfo = f64[F_SBS].data();
+  w.n_relpose = (int)relPoses_.size(); w.rel_pose0 = i32[I_R0].data(); w.rel_pose1 = i32[I_R1].data(); w.rel_sqrtinfo = f64[F_RELS].data();
+  w.marg_dim = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// optimize (Estimator.cpp:843-906)
+// ---------------------------------------------------------------------------------------------------
+void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/) {
+  if (states_.empty()) return;
+  std::vector<std::vector<double>> f64;
+  std::vector<std::vector<int32_t>> i32;
+  std::vector<std::vector<int64_t>> i64;
+  std::vector<std::vector<uint8_t>> u8;
+  okvis_ba_window w;
+  std::vector<uint64_t> lmOrder;
+  buildWindow(f64, i32, i64, u8, w, lmOrder);
+  check(okvis_ba_set_options(solver_, &options_), "set_options");
+  check(okvis_ba_upload(solver_, 1, &w), "upload");
+  if (hasTimeLimit_)  // CeresIterationCallback semantics (CeresIterationCallback.hpp:77-86)
+    check(okvis_ba_optimize_timed(solver_, (int)numIter, minIterations_, timeLimit_, &summary_), "optimize");
+  else
+    check(okvis_ba_optimize(solver_, (int)numIter, &summary_), "optimize");
+  // copy the estimates back (the reference's parameter blocks are updated in place by Ceres)
+  std::vector<double> pose(7 * poseBlocks_.size()), sb(9 * sbBlocks_.size()), lm(4 * lmOrder.size()), q(lmOrder.size());
+  check(okvis_ba_get_state(solver_, 0, pose.data(), sb.data(), lm.data()), "get_state");
+  if (!q.empty()) check(okvis_ba_download(solver_, 0, OKVIS_BA_ARR_LM_QUALITY, q.data(), (int64_t)q.size()), "quality");
+  for (size_t i = 0; i < poseBlocks_.size(); ++i) std::copy(pose.begin() + 7 * i, pose.begin() + 7 * i + 7, poseBlocks_[i].x.begin());
+  for (size_t i = 0; i < sbBlocks_.size(); ++i) std::copy(sb.begin() + 9 * i, sb.begin() + 9 * i + 9, sbBlocks_[i].x.begin());
+  {
+    // update landmarks: quality = sqrt(lambda_min)/sqrt(lambda_max) of the un-robustified H_l and the
+    // estimate (Estimator.cpp:880-900)
+    std::lock_guard<std::mutex> l(statesMutex_);
+    for (size_t i = 0; i < lmOrder.size(); ++i) {
+      MapPoint& mp = landmarksMap_.at(lmOrder[i]);
+      mp.quality = q[i];
+      std::copy(lm.begin() + 4 * i, lm.begin() + 4 * i + 4, mp.point.begin());
+    }
+  }
+}
+
+bool Estimator::applyMarginalizationStrategy(size_t, size_t, MapPointVector&) {
+  // construction of the marginalisation prior (MarginalizationError::addResidualBlock /
+  // marginalizeOut / updateErrorComputation) is the next row after the optimize() path; its *evaluation*
+  // inside optimize() is implemented on the GPU (okvis_ba_window::marg_*).
+  throw Exception("okvis_amd::Estimator::applyMarginalizationStrategy: not implemented yet (SURVEY.md §8f rank 1)");
+}
+
+// ---- getters / setters -------------------------------------------------------------------------------
+bool Estimator::isLandmarkInitialized(uint64_t id) const {
+  auto it = landmarkInitialized_.find(id);
+  if (it == landmarkInitialized_.end()) throw Exception("landmark not added");
+  return it->second;
+}
+bool Estimator::getLandmark(uint64_t id, MapPoint& mapPoint) const {
+  std::lock_guard<std::mutex> l(statesMutex_);
+  auto it = landmarksMap_.find(id);
+  if (it == landmarksMap_.end()) throw Exception("landmark with id = " + std::to_string(id) + " does not exist.");
+  mapPoint = it->second;
+  return true;
+}
+size_t Estimator::getLandmarks(PointMap& landmarks) const {
+  std::lock_guard<std::mutex> l(statesMutex_);
+  landmarks = landmarksMap_;
+  return landmarksMap_.size();
+}
+size_t Estimator::getLandmarks(MapPointVector& landmarks) const {
+  std::lock_guard<std::mutex> l(statesMutex_);
+  landmarks.clear();
+  landmarks.reserve(landmarksMap_.size());
+  for (const auto& kv : landmarksMap_) landmarks.push_back(kv.second);
+  return landmarksMap_.size();
+}
+MultiFramePtr Estimator::multiFrame(uint64_t frameId) const {
+  auto it = multiFramePtrMap_.find(frameId);
+  if (it == multiFramePtrMap_.end()) throw Exception("Requested multi-frame does not exist in estimator.");
+  return it->second;
+}
+bool Estimator::get_T_WS(uint64_t poseId, Transformation& T_WS) const {
+  const State* s = findState(poseId);
+  if (!s) return false;
+  T_WS.p = poseBlocks_[s->poseBlock].x;
+  return true;
+}
+bool Estimator::getSpeedAndBias(uint64_t poseId, uint64_t, SpeedAndBias& sb) const {
+  const State* s = findState(poseId);
+  if (!s || s->sbBlock < 0) return false;
+  sb = sbBlocks_[s->sbBlock].x;
+  return true;
+}
+bool Estimator::getCameraSensorStates(uint64_t poseId, size_t cameraIdx, Transformation& T_SCi) const {
+  const State* s = findState(poseId);
+  if (!s || cameraIdx >= s->extBlocks.size()) return false;
+  T_SCi.p = poseBlocks_[s->extBlocks[cameraIdx]].x;
+  return true;
+}
+uint64_t Estimator::currentKeyframeId() const {
+  for (auto it = states_.rbegin(); it != states_.rend(); ++it)
+    if (it->isKeyframe) return it->id;
+  throw Exception("no keyframes existing...");
+}
+uint64_t Estimator::frameIdByAge(size_t age) const {
+  if (age >= states_.size()) throw Exception("requested age " + std::to_string(age) + " out of range.");
+  return states_[states_.size() - 1 - age].id;
+}
+uint64_t Estimator::currentFrameId() const {
+  if (states_.empty()) throw Exception("no frames added yet.");
+  return states_.back().id;
+}
+bool Estimator::isKeyframe(uint64_t frameId) const {
+  const State* s = findState(frameId);
+  if (!s) throw Exception("frame does not exist");
+  return s->isKeyframe;
+}
+bool Estimator::isInImuWindow(uint64_t frameId) const {
+  const State* s = findState(frameId);
+  if (!s) return false;
+  return s->sbBlock >= 0;
+}
+int64_t Estimator::timestamp(uint64_t frameId) const {
+  const State* s = findState(frameId);
+  if (!s) throw Exception("frame does not exist");
+  return s->t_ns;
+}
+bool Estimator::set_T_WS(uint64_t poseId, const Transformation& T_WS) {
+  State* s = findState(poseId);
+  if (!s) return false;
+  poseBlocks_[s->poseBlock].x = T_WS.p;
+  return true;
+}
+bool Estimator::setSpeedAndBias(uint64_t poseId, size_t, const SpeedAndBias& sb) {
+  State* s = findState(poseId);
+  if (!s || s->sbBlock < 0) return false;
+  sbBlocks_[s->sbBlock].x = sb;
+  return true;
+}
+bool Estimator::setCameraSensorStates(uint64_t poseId, size_t cameraIdx, const Transformation& T_SCi) {
+  State* s = findState(poseId);
+  if (!s || cameraIdx >= s->extBlocks.size()) return false;
+  poseBlocks_[s->extBlocks[cameraIdx]].x = T_SCi.p;
+  return true;
+}
+bool Estimator::setLandmark(uint64_t landmarkId, const std::array<double, 4>& landmark) {
+  auto it = landmarksMap_.find(landmarkId);
+  if (it == landmarksMap_.end()) return false;
+  it->second.point = landmark;
+  return true;
+}
+void Estimator::setLandmarkInitialized(uint64_t landmarkId, bool initialized) {
+  if (!landmarksMap_.count(landmarkId)) throw Exception("landmark not added");
+  landmarkInitialized_[landmarkId] = initialized;
+}
+void Estimator::setKeyframe(uint64_t frameId, bool isKeyframe) {
+  State* s = findState(frameId);
+  if (s) s->isKeyframe = isKeyframe;
+}
+
+}  // namespace okvis_amd

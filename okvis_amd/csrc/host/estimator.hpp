@@ -1,0 +1,224 @@
+// okvis_amd::Estimator — the host side of the drop-in boundary, in C++ like the reference.
+//
+// Mirrors the public surface of okvis::Estimator (reference okvis_ceres/include/okvis/Estimator.hpp:77-581,
+// implementing okvis::VioBackendInterface, okvis_common/include/okvis/VioBackendInterface.hpp:67-336):
+// same method names, argument meaning, return values and error behaviour, but with plain-old-data types
+// because Eigen / OpenCV / glog are not available in this environment.  okvis_estimator_adapter.hpp wraps
+// this class into a source-compatible `okvis::Estimator` where those libraries exist.
+//
+// The graph book-keeping the reference keeps in okvis::ceres::Map (hash maps of shared_ptr parameter and
+// residual blocks, Map.hpp:348-402) is replaced by id->index maps over flat arrays; optimize() hands the
+// flat window to the GPU through the C-ABI of include/okvis_amd_ba.h and copies the estimates back.  No
+// numeric part of optimize() runs on the CPU.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <vector>
+
+#include "../../../include/okvis_amd_ba.h"
+
+namespace okvis_amd {
+
+// ---- POD stand-ins of the OKVIS types that cross the boundary ----
+struct Transformation {  // okvis::kinematics::Transformation: r, q(xyzw)
+  std::array<double, 7> p{{0, 0, 0, 0, 0, 0, 1}};
+};
+typedef std::array<double, 9> SpeedAndBias;  // okvis::SpeedAndBias (v_W, b_g, b_a)
+
+struct ExtrinsicsEstimationParameters {  // okvis_common Parameters.hpp
+  double sigma_absolute_translation = 0, sigma_absolute_orientation = 0;
+  double sigma_c_relative_translation = 0, sigma_c_relative_orientation = 0;
+};
+struct ImuParameters {  // okvis_common Parameters.hpp ImuParameters
+  double a_max = 176, g_max = 7.8, sigma_g_c = 12e-4, sigma_a_c = 8e-3, sigma_bg = 0.03, sigma_ba = 0.1;
+  double sigma_gw_c = 4e-6, sigma_aw_c = 4e-5, tau = 3600, g = 9.81007;
+  std::array<double, 3> a0{{0, 0, 0}};
+  int rate = 200;
+};
+struct ImuMeasurement {  // okvis::ImuMeasurement (Measurements.hpp)
+  int64_t t_ns;
+  std::array<double, 3> gyr, acc;
+};
+typedef std::vector<ImuMeasurement> ImuMeasurementDeque;
+
+struct CameraGeometry {  // PinholeCamera<D> intrinsics
+  std::array<double, 12> intr{};  // fu fv cu cv d0..d7
+  int model = OKVIS_BA_DIST_RADTAN;
+};
+struct Keypoint {  // cv::KeyPoint subset (floats, implementation/Frame.hpp:210-242)
+  float x, y, size;
+};
+struct MultiFrame {  // okvis::MultiFrame subset the backend reads
+  uint64_t id = 0;
+  int64_t t_ns = 0;
+  std::vector<Transformation> T_SC;
+  std::vector<CameraGeometry> geometry;
+  std::vector<std::vector<Keypoint>> keypoints;
+  size_t numFrames() const { return geometry.size(); }
+};
+typedef std::shared_ptr<MultiFrame> MultiFramePtr;
+
+struct KeypointIdentifier {  // okvis::KeypointIdentifier (FrameTypedefs.hpp)
+  uint64_t frameId;
+  size_t cameraIndex, keypointIndex;
+  bool operator<(const KeypointIdentifier& o) const {
+    if (frameId != o.frameId) return frameId < o.frameId;
+    if (cameraIndex != o.cameraIndex) return cameraIndex < o.cameraIndex;
+    return keypointIndex < o.keypointIndex;
+  }
+};
+struct MapPoint {  // okvis::MapPoint (FrameTypedefs.hpp)
+  uint64_t id = 0;
+  std::array<double, 4> point{{0, 0, 0, 1}};
+  double quality = 0, distance = 0;
+  std::map<KeypointIdentifier, uint64_t> observations;  // value: opaque residual handle
+};
+typedef std::vector<MapPoint> MapPointVector;
+typedef std::map<uint64_t, MapPoint> PointMap;
+
+class Estimator {
+ public:
+  typedef std::runtime_error Exception;  // OKVIS_DEFINE_EXCEPTION(Exception, std::runtime_error), Estimator.hpp:80
+
+  explicit Estimator(int device = 0);
+  ~Estimator();
+  Estimator(const Estimator&) = delete;
+  Estimator& operator=(const Estimator&) = delete;
+
+  // ---- sensor configuration (Estimator.hpp:102-121) ----
+  int addCamera(const ExtrinsicsEstimationParameters& p);
+  int addImu(const ImuParameters& p);
+  void clearCameras();
+  void clearImus();
+
+  // ---- window growth (Estimator.hpp:132-172) ----
+  bool addStates(MultiFramePtr multiFrame, const ImuMeasurementDeque& imuMeasurements, bool asKeyframe);
+  bool addLandmark(uint64_t landmarkId, const std::array<double, 4>& landmark);
+  // returns the opaque residual handle (reference: ::ceres::ResidualBlockId); 0 for a duplicate
+  uint64_t addObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx);
+  bool removeObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx);
+  bool removeObservation(uint64_t residualHandle);
+
+  // ---- the hot path (Estimator.hpp:183-211) ----
+  void optimize(size_t numIter, size_t numThreads = 1, bool verbose = false);
+  bool setOptimizationTimeLimit(double timeLimit, int minIterations);
+  bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks);
+  static bool initPoseFromImu(const ImuMeasurementDeque& imuMeasurements, Transformation& T_WS);
+
+  // ---- getters (Estimator.hpp:218-354) ----
+  bool isLandmarkAdded(uint64_t id) const { return landmarksMap_.count(id) != 0; }
+  bool isLandmarkInitialized(uint64_t id) const;
+  bool getLandmark(uint64_t id, MapPoint& mapPoint) const;
+  size_t getLandmarks(PointMap& landmarks) const;
+  size_t getLandmarks(MapPointVector& landmarks) const;
+  MultiFramePtr multiFrame(uint64_t frameId) const;
+  bool get_T_WS(uint64_t poseId, Transformation& T_WS) const;
+  bool getSpeedAndBias(uint64_t poseId, uint64_t imuIdx, SpeedAndBias& sb) const;
+  bool getCameraSensorStates(uint64_t poseId, size_t cameraIdx, Transformation& T_SCi) const;
+  size_t numFrames() const { return states_.size(); }
+  size_t numLandmarks() const { return landmarksMap_.size(); }
+  uint64_t currentKeyframeId() const;
+  uint64_t frameIdByAge(size_t age) const;
+  uint64_t currentFrameId() const;
+  bool isKeyframe(uint64_t frameId) const;
+  bool isInImuWindow(uint64_t frameId) const;
+  int64_t timestamp(uint64_t frameId) const;
+
+  // ---- setters (Estimator.hpp:366-411) ----
+  bool set_T_WS(uint64_t poseId, const Transformation& T_WS);
+  bool setSpeedAndBias(uint64_t poseId, size_t imuIdx, const SpeedAndBias& sb);
+  bool setCameraSensorStates(uint64_t poseId, size_t cameraIdx, const Transformation& T_SCi);
+  bool setLandmark(uint64_t landmarkId, const std::array<double, 4>& landmark);
+  void setLandmarkInitialized(uint64_t landmarkId, bool initialized);
+  void setKeyframe(uint64_t frameId, bool isKeyframe);
+
+  // ---- diagnostics of the last optimize() (what ::ceres::Solver::Summary exposes via Map::summary) ----
+  const okvis_ba_summary& summary() const { return summary_; }
+  okvis_ba_options& options() { return options_; }
+
+  // static ImuError::propagation (ImuError.cpp:287-504): used by addStates and, in OKVIS, by the frontend
+  // (Frontend.cpp:287, ThreadedKFVio.cpp:416).  Host code like in the reference; not part of optimize().
+  static int propagation(const ImuMeasurementDeque& imuMeasurements, const ImuParameters& imuParams,
+                         Transformation& T_WS, SpeedAndBias& speedAndBiases, int64_t t_start, int64_t t_end);
+
+ private:
+  struct State {  // one entry of the reference's statesMap_ (Estimator.hpp:434-503)
+    uint64_t id;
+    int64_t t_ns;
+    bool isKeyframe;
+    int poseBlock;                // index into poseBlocks_
+    std::vector<int> extBlocks;   // per camera: index into poseBlocks_
+    int sbBlock;                  // index into sbBlocks_, -1 once marginalised
+  };
+  struct PoseBlock {
+    std::array<double, 7> x;
+    bool fixed;
+    uint64_t id;
+  };
+  struct SbBlock {
+    SpeedAndBias x;
+    bool fixed;
+    uint64_t id;
+  };
+  struct Observation {
+    uint64_t handle, landmarkId, poseId;
+    size_t camIdx, keypointIdx;
+    double u, v, sqrtw;
+  };
+  struct ImuFactor {
+    uint64_t pose0Id, pose1Id;
+    int64_t t0, t1;
+    ImuMeasurementDeque meas;  // the deque is COPIED into the factor (ImuError.hpp:151-153)
+  };
+  struct PosePrior {
+    int block;
+    std::array<double, 7> meas;
+    std::array<double, 36> sqrtInfo;
+  };
+  struct SbPrior {
+    int block;
+    SpeedAndBias meas;
+    std::array<double, 81> sqrtInfo;
+  };
+  struct RelPose {
+    int block0, block1;
+    std::array<double, 36> sqrtInfo;
+  };
+
+  const State* findState(uint64_t id) const;
+  State* findState(uint64_t id);
+  void buildWindow(std::vector<std::vector<double>>& f64, std::vector<std::vector<int32_t>>& i32,
+                   std::vector<std::vector<int64_t>>& i64, std::vector<std::vector<uint8_t>>& u8,
+                   okvis_ba_window& w, std::vector<uint64_t>& lmOrder) const;
+
+  int device_;
+  okvis_ba_solver* solver_ = nullptr;
+  okvis_ba_options options_;
+  okvis_ba_summary summary_;
+  double timeLimit_ = -1.0;
+  int minIterations_ = 0;
+  bool hasTimeLimit_ = false;
+
+  std::vector<ExtrinsicsEstimationParameters> extrinsicsEstimationParametersVec_;
+  std::vector<ImuParameters> imuParametersVec_;
+  std::vector<State> states_;  // ordered by insertion (= by id/time like the reference's std::map)
+  std::map<uint64_t, MultiFramePtr> multiFramePtrMap_;
+  std::vector<PoseBlock> poseBlocks_;
+  std::vector<SbBlock> sbBlocks_;
+  PointMap landmarksMap_;
+  std::map<uint64_t, bool> landmarkInitialized_;
+  std::map<uint64_t, Observation> observations_;  // by handle
+  std::vector<ImuFactor> imuFactors_;
+  std::vector<PosePrior> posePriors_;
+  std::vector<SbPrior> sbPriors_;
+  std::vector<RelPose> relPoses_;
+  uint64_t nextId_ = 1ULL << 40;    // IdProvider::instance().newId() stand-in for internal blocks
+  uint64_t nextHandle_ = 1;
+  mutable std::mutex statesMutex_;  // guards getLandmark(s) like Estimator.cpp:936,956,965
+};
+
+}  // namespace okvis_amd

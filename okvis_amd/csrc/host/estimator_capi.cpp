@@ -1,0 +1,207 @@
+// Flat C wrapper of okvis_amd::Estimator so that the pytest suite (ctypes) can re-state the reference's
+// integration test (okvis_ceres/test/TestEstimator.cpp).  Exceptions never cross the boundary: every
+// function returns a status (>= 0 ok, -1 exception: message via okvis_est_last_error).
+#include <cstring>
+#include <string>
+
+#include "estimator.hpp"
+
+using namespace okvis_amd;
+
+namespace {
+thread_local std::string g_err;
+template <class F>
+int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* okvis_est_last_error() { return g_err.c_str(); }
+
+void* okvis_est_create(int device) {
+  try {
+    return new Estimator(device);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void okvis_est_destroy(void* h) { delete static_cast<Estimator*>(h); }
+
+int okvis_est_add_camera(void* h, const double sigmas[4]) {
+  return guarded([&] {
+    ExtrinsicsEstimationParameters p;
+    p.sigma_absolute_translation = sigmas[0];
+    p.sigma_absolute_orientation = sigmas[1];
+    p.sigma_c_relative_translation = sigmas[2];
+    p.sigma_c_relative_orientation = sigmas[3];
+    return static_cast<Estimator*>(h)->addCamera(p);
+  });
+}
+// prm = a_max g_max sigma_g_c sigma_a_c sigma_bg sigma_ba sigma_gw_c sigma_aw_c tau g a0x a0y a0z
+int okvis_est_add_imu(void* h, const double prm[13]) {
+  return guarded([&] {
+    ImuParameters p;
+    p.a_max = prm[0]; p.g_max = prm[1]; p.sigma_g_c = prm[2]; p.sigma_a_c = prm[3]; p.sigma_bg = prm[4];
+    p.sigma_ba = prm[5]; p.sigma_gw_c = prm[6]; p.sigma_aw_c = prm[7]; p.tau = prm[8]; p.g = prm[9];
+    p.a0 = {{prm[10], prm[11], prm[12]}};
+    return static_cast<Estimator*>(h)->addImu(p);
+  });
+}
+
+// a multiframe is created first, keypoints are appended, then it is handed to addStates
+void* okvis_est_frame_create(uint64_t id, int64_t t_ns, int ncam, const double* T_SC /*[ncam][7]*/,
+                             const double* intr /*[ncam][12]*/, const int* models) {
+  MultiFramePtr* mf = new MultiFramePtr(new MultiFrame);
+  (*mf)->id = id;
+  (*mf)->t_ns = t_ns;
+  for (int c = 0; c < ncam; ++c) {
+    Transformation T;
+    std::memcpy(T.p.data(), T_SC + 7 * c, 56);
+    (*mf)->T_SC.push_back(T);
+    CameraGeometry g;
+    std::memcpy(g.intr.data(), intr + 12 * c, 96);
+    g.model = models[c];
+    (*mf)->geometry.push_back(g);
+    (*mf)->keypoints.emplace_back();
+  }
+  return mf;
+}
+void okvis_est_frame_destroy(void* f) { delete static_cast<MultiFramePtr*>(f); }
+int okvis_est_frame_add_keypoint(void* f, int cam, float x, float y, float size) {
+  MultiFramePtr& mf = *static_cast<MultiFramePtr*>(f);
+  mf->keypoints[cam].push_back(Keypoint{x, y, size});
+  return (int)mf->keypoints[cam].size() - 1;
+}
+
+int okvis_est_add_states(void* h, void* frame, int n_imu, const int64_t* t, const double* gyr, const double* acc,
+                         int asKeyframe) {
+  return guarded([&] {
+    ImuMeasurementDeque d(n_imu);
+    for (int i = 0; i < n_imu; ++i) {
+      d[i].t_ns = t[i];
+      for (int c = 0; c < 3; ++c) {
+        d[i].gyr[c] = gyr[3 * i + c];
+        d[i].acc[c] = acc[3 * i + c];
+      }
+    }
+    return static_cast<Estimator*>(h)->addStates(*static_cast<MultiFramePtr*>(frame), d, asKeyframe != 0) ? 1 : 0;
+  });
+}
+int okvis_est_add_landmark(void* h, uint64_t id, const double hp[4]) {
+  return guarded([&] { return static_cast<Estimator*>(h)->addLandmark(id, {{hp[0], hp[1], hp[2], hp[3]}}) ? 1 : 0; });
+}
+// returns 1 added, 0 duplicate, -1 exception
+int okvis_est_add_observation(void* h, uint64_t lm, uint64_t pose, int cam, int kp, uint64_t* handle) {
+  return guarded([&] {
+    const uint64_t r = static_cast<Estimator*>(h)->addObservation(lm, pose, (size_t)cam, (size_t)kp);
+    if (handle) *handle = r;
+    return r ? 1 : 0;
+  });
+}
+int okvis_est_remove_observation(void* h, uint64_t lm, uint64_t pose, int cam, int kp) {
+  return guarded([&] { return static_cast<Estimator*>(h)->removeObservation(lm, pose, (size_t)cam, (size_t)kp) ? 1 : 0; });
+}
+int okvis_est_optimize(void* h, int numIter, int numThreads, int verbose, okvis_ba_summary* summary) {
+  return guarded([&] {
+    Estimator* e = static_cast<Estimator*>(h);
+    e->optimize((size_t)numIter, (size_t)numThreads, verbose != 0);
+    if (summary) *summary = e->summary();
+    return 0;
+  });
+}
+int okvis_est_set_time_limit(void* h, double limit, int minIter) {
+  return guarded([&] { return static_cast<Estimator*>(h)->setOptimizationTimeLimit(limit, minIter) ? 1 : 0; });
+}
+int okvis_est_apply_marginalization(void* h, int numKeyframes, int numImuFrames) {
+  return guarded([&] {
+    MapPointVector removed;
+    return static_cast<Estimator*>(h)->applyMarginalizationStrategy((size_t)numKeyframes, (size_t)numImuFrames, removed) ? 1 : 0;
+  });
+}
+int okvis_est_get_T_WS(void* h, uint64_t id, double out[7]) {
+  return guarded([&] {
+    Transformation T;
+    if (!static_cast<Estimator*>(h)->get_T_WS(id, T)) return 0;
+    std::memcpy(out, T.p.data(), 56);
+    return 1;
+  });
+}
+int okvis_est_get_speed_and_bias(void* h, uint64_t id, double out[9]) {
+  return guarded([&] {
+    SpeedAndBias sb;
+    if (!static_cast<Estimator*>(h)->getSpeedAndBias(id, 0, sb)) return 0;
+    std::memcpy(out, sb.data(), 72);
+    return 1;
+  });
+}
+int okvis_est_get_extrinsics(void* h, uint64_t id, int cam, double out[7]) {
+  return guarded([&] {
+    Transformation T;
+    if (!static_cast<Estimator*>(h)->getCameraSensorStates(id, (size_t)cam, T)) return 0;
+    std::memcpy(out, T.p.data(), 56);
+    return 1;
+  });
+}
+int okvis_est_get_landmark(void* h, uint64_t id, double point[4], double* quality, int* n_obs) {
+  return guarded([&] {
+    MapPoint mp;
+    static_cast<Estimator*>(h)->getLandmark(id, mp);
+    std::memcpy(point, mp.point.data(), 32);
+    if (quality) *quality = mp.quality;
+    if (n_obs) *n_obs = (int)mp.observations.size();
+    return 1;
+  });
+}
+int okvis_est_num_frames(void* h) { return (int)static_cast<Estimator*>(h)->numFrames(); }
+int okvis_est_num_landmarks(void* h) { return (int)static_cast<Estimator*>(h)->numLandmarks(); }
+int okvis_est_current_frame_id(void* h, uint64_t* id) {
+  return guarded([&] {
+    *id = static_cast<Estimator*>(h)->currentFrameId();
+    return 1;
+  });
+}
+// static helpers
+int okvis_est_init_pose_from_imu(int n, const double* acc, double out[7]) {
+  ImuMeasurementDeque d(n);
+  for (int i = 0; i < n; ++i) {
+    d[i].t_ns = i;
+    d[i].gyr = {{0, 0, 0}};
+    d[i].acc = {{acc[3 * i], acc[3 * i + 1], acc[3 * i + 2]}};
+  }
+  Transformation T;
+  const bool ok = Estimator::initPoseFromImu(d, T);
+  std::memcpy(out, T.p.data(), 56);
+  return ok ? 1 : 0;
+}
+int okvis_est_propagation(int n, const int64_t* t, const double* gyr, const double* acc, const double prm[13],
+                          double T_WS[7], double sb[9], int64_t t_start, int64_t t_end) {
+  ImuMeasurementDeque d(n);
+  for (int i = 0; i < n; ++i) {
+    d[i].t_ns = t[i];
+    for (int c = 0; c < 3; ++c) {
+      d[i].gyr[c] = gyr[3 * i + c];
+      d[i].acc[c] = acc[3 * i + c];
+    }
+  }
+  ImuParameters p;
+  p.a_max = prm[0]; p.g_max = prm[1]; p.sigma_g_c = prm[2]; p.sigma_a_c = prm[3]; p.sigma_bg = prm[4];
+  p.sigma_ba = prm[5]; p.sigma_gw_c = prm[6]; p.sigma_aw_c = prm[7]; p.tau = prm[8]; p.g = prm[9];
+  Transformation T;
+  std::memcpy(T.p.data(), T_WS, 56);
+  SpeedAndBias s;
+  std::memcpy(s.data(), sb, 72);
+  const int r = Estimator::propagation(d, p, T, s, t_start, t_end);
+  std::memcpy(T_WS, T.p.data(), 56);
+  std::memcpy(sb, s.data(), 72);
+  return r;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""ctypes view of the C++ host class ``okvis_amd::Estimator`` (okvis_amd/csrc/host/estimator.hpp), the
+mirror of ``okvis::Estimator`` (reference okvis_ceres/include/okvis/Estimator.hpp:77-581).  Used by the
+tests that re-state the reference's integration test; C++ callers use the class directly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .window import SummaryC
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libokvis_amd_estimator.so")
+_dp = C.POINTER(C.c_double)
+_lp = C.POINTER(C.c_int64)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} missing: run `python -m okvis_amd.build`")
+        L = C.CDLL(LIB_PATH)
+        L.okvis_est_last_error.restype = C.c_char_p
+        L.okvis_est_create.restype = C.c_void_p
+        L.okvis_est_create.argtypes = [C.c_int]
+        L.okvis_est_destroy.argtypes = [C.c_void_p]
+        L.okvis_est_add_camera.argtypes = [C.c_void_p, _dp]
+        L.okvis_est_add_imu.argtypes = [C.c_void_p, _dp]
+        L.okvis_est_frame_create.restype = C.c_void_p
+        L.okvis_est_frame_create.argtypes = [C.c_uint64, C.c_int64, C.c_int, _dp, _dp, C.POINTER(C.c_int)]
+        L.okvis_est_frame_destroy.argtypes = [C.c_void_p]
+        L.okvis_est_frame_add_keypoint.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.okvis_est_add_states.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _lp, _dp, _dp, C.c_int]
+        L.okvis_est_add_landmark.argtypes = [C.c_void_p, C.c_uint64, _dp]
+        L.okvis_est_add_observation.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.okvis_est_remove_observation.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+        L.okvis_est_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(SummaryC)]
+        L.okvis_est_set_time_limit.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        L.okvis_est_apply_marginalization.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.okvis_est_get_T_WS.argtypes = [C.c_void_p, C.c_uint64, _dp]
+        L.okvis_est_get_speed_and_bias.argtypes = [C.c_void_p, C.c_uint64, _dp]
+        L.okvis_est_get_extrinsics.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _dp]
+        L.okvis_est_get_landmark.argtypes = [C.c_void_p, C.c_uint64, _dp, _dp, C.POINTER(C.c_int)]
+        L.okvis_est_num_frames.argtypes = [C.c_void_p]
+        L.okvis_est_num_landmarks.argtypes = [C.c_void_p]
+        L.okvis_est_init_pose_from_imu.argtypes = [C.c_int, _dp, _dp]
+        L.okvis_est_propagation.argtypes = [C.c_int, _lp, _dp, _dp, _dp, _dp, _dp, C.c_int64, C.c_int64]
+        _lib = L
+    return _lib
+
+
+class EstimatorError(RuntimeError):
+    pass
+
+
+def _chk(r):
+    if r < 0:
+        raise EstimatorError(lib().okvis_est_last_error().decode())
+    return r
+
+
+def _d(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def imu_param_vector(p) -> np.ndarray:
+    """okvis_amd.window.ImuParams -> the 13-vector of the C wrapper."""
+    return np.array([p.a_max, p.g_max, p.sigma_g_c, p.sigma_a_c, p.sigma_bg, p.sigma_ba, p.sigma_gw_c, p.sigma_aw_c,
+                     3600.0, p.g, 0.0, 0.0, 0.0])
+
+
+def propagation(t, gyr, acc, prm13, T_WS, sb, t_start, t_end):
+    t = np.ascontiguousarray(t, np.int64); gyr = _d(gyr); acc = _d(acc); prm13 = _d(prm13)
+    T = _d(T_WS).copy(); s = _d(sb).copy()
+    n = lib().okvis_est_propagation(int(t.size), t.ctypes.data_as(_lp), gyr.ctypes.data_as(_dp), acc.ctypes.data_as(_dp),
+                                    prm13.ctypes.data_as(_dp), T.ctypes.data_as(_dp), s.ctypes.data_as(_dp),
+                                    C.c_int64(int(t_start)), C.c_int64(int(t_end)))
+    return T, s, n
+
+
+def init_pose_from_imu(acc):
+    acc = _d(acc).reshape(-1, 3)
+    out = np.zeros(7)
+    ok = lib().okvis_est_init_pose_from_imu(acc.shape[0], acc.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
+    return out, bool(ok)
+
+
+class Frame:
+    def __init__(self, frame_id, t_ns, T_SC, intr, models):
+        T_SC = _d(T_SC).reshape(-1, 7); intr = _d(intr).reshape(-1, 12)
+        m = (C.c_int * len(models))(*[int(x) for x in models])
+        self._h = lib().okvis_est_frame_create(C.c_uint64(frame_id), C.c_int64(int(t_ns)), T_SC.shape[0],
+                                               T_SC.ctypes.data_as(_dp), intr.ctypes.data_as(_dp), m)
+        self.id = frame_id
+
+    def add_keypoint(self, cam, x, y, size):
+        return lib().okvis_est_frame_add_keypoint(self._h, cam, C.c_float(x), C.c_float(y), C.c_float(size))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().okvis_est_frame_destroy(self._h)
+            self._h = None
+
+
+class Estimator:
+    def __init__(self, device=0):
+        self._h = lib().okvis_est_create(device)
+        if not self._h:
+            raise EstimatorError(lib().okvis_est_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().okvis_est_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def addCamera(self, sig_abs_t, sig_abs_r, sig_rel_t, sig_rel_r):
+        return _chk(lib().okvis_est_add_camera(self._h, _d([sig_abs_t, sig_abs_r, sig_rel_t, sig_rel_r]).ctypes.data_as(_dp)))
+
+    def addImu(self, prm13):
+        return _chk(lib().okvis_est_add_imu(self._h, _d(prm13).ctypes.data_as(_dp)))
+
+    def addStates(self, frame: Frame, t, gyr, acc, asKeyframe):
+        t = np.ascontiguousarray(t, np.int64); gyr = _d(gyr); acc = _d(acc)
+        return bool(_chk(lib().okvis_est_add_states(self._h, frame._h, int(t.size), t.ctypes.data_as(_lp),
+                                                   gyr.ctypes.data_as(_dp), acc.ctypes.data_as(_dp), int(asKeyframe))))
+
+    def addLandmark(self, lm_id, hp):
+        return bool(_chk(lib().okvis_est_add_landmark(self._h, C.c_uint64(lm_id), _d(hp).ctypes.data_as(_dp))))
+
+    def addObservation(self, lm_id, pose_id, cam, kp):
+        h = C.c_uint64()
+        r = _chk(lib().okvis_est_add_observation(self._h, C.c_uint64(lm_id), C.c_uint64(pose_id), cam, kp, C.byref(h)))
+        return h.value if r else 0
+
+    def removeObservation(self, lm_id, pose_id, cam, kp):
+        return bool(_chk(lib().okvis_est_remove_observation(self._h, C.c_uint64(lm_id), C.c_uint64(pose_id), cam, kp)))
+
+    def optimize(self, numIter, numThreads=1, verbose=False):
+        s = SummaryC()
+        _chk(lib().okvis_est_optimize(self._h, numIter, numThreads, int(verbose), C.byref(s)))
+        return s.as_dict()
+
+    def setOptimizationTimeLimit(self, limit, min_iter):
+        return bool(_chk(lib().okvis_est_set_time_limit(self._h, float(limit), int(min_iter))))
+
+    def applyMarginalizationStrategy(self, numKeyframes, numImuFrames):
+        return bool(_chk(lib().okvis_est_apply_marginalization(self._h, numKeyframes, numImuFrames)))
+
+    def get_T_WS(self, pose_id):
+        out = np.zeros(7)
+        return out if _chk(lib().okvis_est_get_T_WS(self._h, C.c_uint64(pose_id), out.ctypes.data_as(_dp))) else None
+
+    def getSpeedAndBias(self, pose_id):
+        out = np.zeros(9)
+        return out if _chk(lib().okvis_est_get_speed_and_bias(self._h, C.c_uint64(pose_id), out.ctypes.data_as(_dp))) else None
+
+    def getCameraSensorStates(self, pose_id, cam):
+        out = np.zeros(7)
+        return out if _chk(lib().okvis_est_get_extrinsics(self._h, C.c_uint64(pose_id), cam, out.ctypes.data_as(_dp))) else None
+
+    def getLandmark(self, lm_id):
+        p = np.zeros(4); q = C.c_double(); n = C.c_int()
+        _chk(lib().okvis_est_get_landmark(self._h, C.c_uint64(lm_id), p.ctypes.data_as(_dp), C.byref(q), C.byref(n)))
+        return p, q.value, n.value
+
+    def numFrames(self):
+        return lib().okvis_est_num_frames(self._h)
+
+    def numLandmarks(self):
+        return lib().okvis_est_num_landmarks(self._h)

@@ -1,0 +1,83 @@
+"""GPU: the reference's integration test re-stated on the C++ host class (okvis_ceres/test/TestEstimator.cpp
+:52-238): 2 equidistant cameras (baseline 0.1 m), a wall of landmarks at x = 3 m, constant-velocity motion,
+IMU at 100 Hz, pixel noise U(-1,1), keypoint size 8, optimize(10,4,false) after every frame; final errors
+||d speed&bias|| < 0.04, rotation < 1e-2, translation < 1e-1 (TestEstimator.cpp:229-236).
+applyMarginalizationStrategy (TestEstimator.cpp:210-214) is the next row and must say so."""
+import numpy as np
+import pytest
+
+from okvis_amd import estimator, synthetic
+from okvis_amd.window import DIST_EQUIDISTANT, ImuParams
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("c", [0, 1, 2, 3])
+def test_estimator_constant_velocity(c):
+    rng = np.random.default_rng(100 + c)
+    DURATION, IMU_RATE = 10.0, 100.0
+    DT = 1.0 / IMU_RATE
+    prm = ImuParams(sigma_g_c=6.0e-4, sigma_a_c=2.0e-3, sigma_gw_c=3.0e-6, sigma_aw_c=2.0e-5, g=9.81,
+                    g_max=1000.0, a_max=1000.0)
+    speed = np.array([0.0, 1.0, 0.0])
+    n_imu = int(DURATION * IMU_RATE) + 1
+    t_imu = (np.arange(n_imu) * int(round(DT * 1e9))).astype(np.int64) + 1_000_000_000
+    gyr = rng.uniform(-1, 1, (n_imu, 3)) * prm.sigma_g_c * np.sqrt(DT)
+    acc = np.array([0, 0, prm.g]) + rng.uniform(-1, 1, (n_imu, 3)) * prm.sigma_a_c * np.sqrt(DT)
+    T_SC = np.array([[0, 0, 0, 0, 0, 0, 1.0], [0, 0.1, 0, 0, 0, 0, 1.0]])
+    intr = np.stack([synthetic.TEST_INTR_EQUI, synthetic.TEST_INTR_EQUI])
+    est = estimator.Estimator(0)
+    sig = (1.0e-3 * (c % 2), 1.0e-4 * (c % 2), 1e-8 * (c // 2), 1e-7 * (c // 2))
+    est.addCamera(*sig)
+    est.addCamera(*sig)
+    est.addImu(estimator.imu_param_vector(prm))
+    # landmark wall at x = 3 m, the reference's 43 x 41 grid (TestEstimator.cpp:138-144)
+    pts, ids = [], []
+    nid = 1000
+    for y in np.arange(-10.0, DURATION * 0.1 + 10.0 + 1e-9, 0.5):
+        for z in np.arange(-10.0, 10.0 + 1e-9, 0.5):
+            pts.append([3.0, y, z, 1.0]); ids.append(nid); nid += 1
+            assert est.addLandmark(ids[-1], pts[-1])
+    assert not est.addLandmark(ids[0], pts[0])          # duplicate id -> false (Map.cpp:297-299)
+    pts = np.array(pts)
+    assert len(ids) == 1763
+    # per-frame extrinsics blocks (c >= 2) grow the reduced system by 12 per frame: fewer frames there
+    K = 6 if c < 2 else 4
+    frames = []
+    last_id = None
+    for k in range(K + 1):
+        t_k = 1_000_000_000 + int(round(k * DURATION / K * 1e9))
+        r_k = speed * k * DURATION / K
+        f = estimator.Frame(10 + k, t_k, T_SC, intr, [DIST_EQUIDISTANT] * 2)
+        n_obs = 0
+        cams = []
+        for i in range(2):
+            # identity rotations as in the reference: the fisheye camera looks along +z_W, the wall is to
+            # its side; points behind / outside the image are rejected by the projection status
+            p_C = pts[:, :3] - r_k - T_SC[i, :3]
+            uv, ok = synthetic.project_points(intr[i], DIST_EQUIDISTANT, p_C)
+            cams.append((uv, ok))
+        frames.append(f)
+        assert est.addStates(f, t_imu, gyr, acc, k % 3 == 0)
+        last_id = f.id
+        for j in range(len(ids)):
+            for i in range(2):
+                uv, ok = cams[i]
+                if ok[j]:
+                    m = uv[j] + rng.uniform(-1, 1, 2)
+                    kp = f.add_keypoint(i, m[0], m[1], 8.0)
+                    assert est.addObservation(ids[j], f.id, i, kp) != 0
+                    n_obs += 1
+        assert n_obs > 20
+        s = est.optimize(10, 4, False)
+        assert s["final_cost"] <= s["initial_cost"] * (1 + 1e-9)
+    # a duplicate observation returns NULL/0 (implementation/Estimator.hpp:52-56)
+    with pytest.raises(estimator.EstimatorError, match="not implemented"):
+        est.applyMarginalizationStrategy(2, 3)
+    T = est.get_T_WS(last_id)
+    sb = est.getSpeedAndBias(last_id)
+    r_true = speed * DURATION
+    assert np.linalg.norm(sb - np.r_[speed, np.zeros(6)]) < 0.04
+    assert 2 * np.linalg.norm(T[3:6]) < 1e-2
+    assert np.linalg.norm(T[:3] - r_true) < 1e-1
+    est.close()
