@@ -362,7 +362,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       return OKVIS_BA_ERR_ARG;
     if (w.imu_s_begin[f] < 0 || w.imu_s_count[f] < 2 || w.imu_s_begin[f] + w.imu_s_count[f] > w.n_imu_samples)
       return OKVIS_BA_ERR_ARG;
-    if (w.imu_s_count[f] > IMU_N) return OKVIS_BA_ERR_UNSUPPORTED;
+    if (w.imu_s_count[f] > MAX_IMU_SAMPLES) return OKVIS_BA_ERR_UNSUPPORTED;
     // ImuError::redoPreintegration returns -1 when the samples do not cover [t0,t1] (ImuError.cpp:87-89)
     if (!(w.imu_s_t[w.imu_s_begin[f] + w.imu_s_count[f] - 1] >= w.imu_t1[f])) return OKVIS_BA_ERR_ARG;
   }
@@ -639,7 +639,7 @@ void okvis_ba_get_limits(okvis_ba_limits* out) {
   out->max_obs_per_lm = GROUP_OBS;
   out->max_reduced_dim = MAX_D_LDS;
   out->max_marg_dim = MAX_MARG_DIM;
-  out->max_imu_samples_per_factor = IMU_N;
+  out->max_imu_samples_per_factor = MAX_IMU_SAMPLES;
 }
 
 void okvis_ba_default_options(okvis_ba_options* o) {

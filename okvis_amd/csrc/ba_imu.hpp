@@ -105,255 +105,317 @@ __device__ __forceinline__ void chol15(double* A, int e) {
 }
 
 __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds, int tid) {
+  // The integration steps are processed in chunks of IMU_N (the LDS scratch), with the running state
+  // (Delta_q, the integrals, the cross matrix, dv/db_g, the covariance) carried from chunk to chunk, so a
+  // factor may span any number of raw samples (the reference copies the whole deque into every ImuError).
   __shared__ int s_it[IMU_N], s_flag[IMU_N];
   __shared__ long long s_ts[IMU_N], s_tn[IMU_N];
-  __shared__ int s_nsteps;
+  __shared__ int s_nsteps, s_next_it, s_started, s_finished;
+  __shared__ long long s_time;
+  __shared__ double c_Dq[4], c_Cint[9], c_aint[3], c_cross[9], c_dv[9];  // carries
+  __shared__ double t_Cdbl[9], t_adbl[3], t_dal[9], t_dp[9];              // running totals
   const int n = W.imu_s_count[f];
   const long long* ts = W.imu_s_t + W.imu_s_begin[f];
   const double* gyr = W.imu_s_gyr + 3 * (size_t)W.imu_s_begin[f];
   const double* acc = W.imu_s_acc + 3 * (size_t)W.imu_s_begin[f];
   const long long t0 = W.imu_t0[f], t1 = W.imu_t1[f];
-  // ---- stage 0: loop control of ImuError.cpp:113-150,259-260 (integer time logic) by one work-item
-  if (tid == 0) {
-    long long time = t0;
-    bool started = false;
-    int k = 0;
-    for (int it = 0; it < n && k < IMU_N; ++it) {
-      long long nexttime = (it + 1 == n) ? t1 : ts[it + 1];
-      int flag = 0;
-      if (t1 < nexttime) {
-        nexttime = t1;
-        flag |= 1;  // interpolate the second sample to t1
-      }
-      if (nexttime - time <= 0) continue;
-      if (!started) {
-        started = true;
-        flag |= 2;  // interpolate the first sample to t0
-      }
-      s_it[k] = it;
-      s_flag[k] = flag;
-      s_ts[k] = time;
-      s_tn[k] = nexttime;
-      ++k;
-      time = nexttime;
-      if (nexttime == t1) break;
-    }
-    s_nsteps = k;
-  }
-  __syncthreads();
-  const int ns = s_nsteps;
   const ImuParamsD prm = W.imu;
   const double bg[3] = {sb0[3], sb0[4], sb0[5]}, ba[3] = {sb0[6], sb0[7], sb0[8]};
-  // ---- stage 1: per-step quantities
-  if (tid < ns) {
-    const int it = s_it[tid];
-    const int nx = (it + 1 < n) ? it + 1 : it;
-    double w0[3] = {gyr[3 * it], gyr[3 * it + 1], gyr[3 * it + 2]};
-    double a0[3] = {acc[3 * it], acc[3 * it + 1], acc[3 * it + 2]};
-    double w1[3] = {gyr[3 * nx], gyr[3 * nx + 1], gyr[3 * nx + 2]};
-    double a1[3] = {acc[3 * nx], acc[3 * nx + 1], acc[3 * nx + 2]};
-    const double dt = ns_to_sec(s_tn[tid] - s_ts[tid]);
-    if (s_flag[tid] & 1) {
-      const long long raw_next = (it + 1 == n) ? t1 : ts[it + 1];
-      const double interval = ns_to_sec(raw_next - ts[it]);
-      const double r = dt / interval;
-      for (int c = 0; c < 3; ++c) {
-        w1[c] = (1.0 - r) * w0[c] + r * w1[c];
-        a1[c] = (1.0 - r) * a0[c] + r * a1[c];
-      }
-    }
-    if (s_flag[tid] & 2) {
-      const double r = dt / ns_to_sec(s_tn[tid] - ts[it]);
-      for (int c = 0; c < 3; ++c) {
-        w0[c] = r * w0[c] + (1.0 - r) * w1[c];
-        a0[c] = r * a0[c] + (1.0 - r) * a1[c];
-      }
-    }
-    double sg = prm.sigma_g_c, sa = prm.sigma_a_c;
-    bool gs = false, as = false;
-    for (int c = 0; c < 3; ++c) {
-      gs = gs || fabs(w0[c]) > prm.g_max || fabs(w1[c]) > prm.g_max;
-      as = as || fabs(a0[c]) > prm.a_max || fabs(a1[c]) > prm.a_max;
-    }
-    if (gs) sg *= 100;
-    if (as) sa *= 100;
-    double om[3], ab[3];
-    for (int c = 0; c < 3; ++c) {
-      om[c] = 0.5 * (w0[c] + w1[c]) - bg[c];
-      ab[c] = 0.5 * (a0[c] + a1[c]) - ba[c];
-    }
-    const double th = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]) * 0.5 * dt;
-    const double sc = sinc(th), ct = cos(th);
-    double dq[4] = {sc * om[0] * 0.5 * dt, sc * om[1] * 0.5 * dt, sc * om[2] * 0.5 * dt, ct};
-    double phi[3] = {om[0] * dt, om[1] * dt, om[2] * dt};
-    double Jr[9], dqi[4], Ri[9];
-    right_jacobian(phi, Jr);
-    for (int c = 0; c < 9; ++c) Jr[c] *= dt;
-    qinv(dq, dqi);
-    qrot(dqi, Ri);
-    for (int c = 0; c < 4; ++c) lds[ImuLds::DQ + 4 * tid + c] = dq[c];
-    lds[ImuLds::DT + tid] = dt;
-    for (int c = 0; c < 3; ++c) lds[ImuLds::AB + 3 * tid + c] = ab[c];
-    st9(lds + ImuLds::JRDT, tid, Jr);
-    st9(lds + ImuLds::RINV, tid, Ri);
-    lds[ImuLds::SG2 + tid] = dt * sg * sg;
-    lds[ImuLds::SA2 + tid] = dt * sa * sa;
-  }
-  __syncthreads();
-  // ---- stage 2: Delta_q_k = dq_0 (x) ... (x) dq_(k-1), same product order as the reference
-  if (tid <= ns) {
-    double q[4] = {0, 0, 0, 1};
-    for (int j = 0; j < tid; ++j) {
-      double t[4];
-      qmul(q, lds + ImuLds::DQ + 4 * j, t);
-      q[0] = t[0]; q[1] = t[1]; q[2] = t[2]; q[3] = t[3];
-    }
-    for (int c = 0; c < 4; ++c) lds[ImuLds::DQP + 4 * tid + c] = q[c];
-  }
-  __syncthreads();
-  // ---- stage 3
-  double C[9], CC[9], dt = 0, ab[3] = {0, 0, 0};
-  if (tid < ns) {
-    double C1m[9];
-    qrot(lds + ImuLds::DQP + 4 * tid, C);
-    qrot(lds + ImuLds::DQP + 4 * (tid + 1), C1m);
-    dt = lds[ImuLds::DT + tid];
-    for (int c = 0; c < 3; ++c) ab[c] = lds[ImuLds::AB + 3 * tid + c];
-    for (int c = 0; c < 9; ++c) CC[c] = C[c] + C1m[c];
-    double t9[9], t3[3], h[9];
-    for (int c = 0; c < 9; ++c) h[c] = 0.5 * CC[c];
-    for (int c = 0; c < 9; ++c) t9[c] = h[c] * dt;
-    st9(lds + ImuLds::CINT, tid, t9);
-    mat3_vec(h, ab, t3);
-    for (int c = 0; c < 3; ++c) lds[ImuLds::AINT + 3 * tid + c] = t3[c] * dt;
-    double Jr[9];
-    ld9(lds + ImuLds::JRDT, tid, Jr);
-    mat3_mul(C1m, Jr, t9);
-    st9(lds + ImuLds::DAL, tid, t9);
-    st9(lds + ImuLds::C1, tid, C1m);
-  }
-  __syncthreads();
-  // ---- stage 4: ordered prefix sums + the cross recursion (registers)
-  double Cint[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, aint[3] = {0, 0, 0}, cross[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (tid < ns) {
-    for (int j = 0; j < tid; ++j) {
-      for (int c = 0; c < 9; ++c) Cint[c] += lds[ImuLds::CINT + 9 * j + c];
-      for (int c = 0; c < 3; ++c) aint[c] += lds[ImuLds::AINT + 3 * j + c];
-      double Ri[9], t9[9];
-      ld9(lds + ImuLds::RINV, j, Ri);
-      mat3_mul(Ri, cross, t9);
-      for (int c = 0; c < 9; ++c) cross[c] = t9[c] + lds[ImuLds::JRDT + 9 * j + c];
-    }
-  }
-  // ---- stage 5
-  double G[9];
-  if (tid < ns) {
-    double q[9], t3[3], t9[9];
-    for (int c = 0; c < 9; ++c) q[c] = 0.25 * CC[c];
-    mat3_vec(q, ab, t3);
-    for (int c = 0; c < 3; ++c) lds[ImuLds::ADBL + 3 * tid + c] = aint[c] * dt + t3[c] * dt * dt;
-    for (int c = 0; c < 9; ++c) t9[c] = Cint[c] * dt + q[c] * dt * dt;
-    st9(lds + ImuLds::CDBL, tid, t9);
-    for (int c = 0; c < 9; ++c) t9[c] = -Cint[c] * dt + q[c] * dt * dt;
-    st9(lds + ImuLds::B012, tid, t9);
-    double Ri[9], cross1[9], ax[9], C1m[9], u[9], v[9];
-    ld9(lds + ImuLds::RINV, tid, Ri);
-    mat3_mul(Ri, cross, cross1);
-    for (int c = 0; c < 9; ++c) cross1[c] += lds[ImuLds::JRDT + 9 * tid + c];
-    cross_mx(ab, ax);
-    ld9(lds + ImuLds::C1, tid, C1m);
-    mat3_mul(C, ax, u);
-    mat3_mul(u, cross, v);
-    for (int c = 0; c < 9; ++c) G[c] = v[c];
-    mat3_mul(C1m, ax, u);
-    mat3_mul(u, cross1, v);
-    for (int c = 0; c < 9; ++c) G[c] += v[c];
-    st9(lds + ImuLds::GG, tid, G);
-    for (int c = 0; c < 9; ++c) t9[c] = 0.5 * dt * G[c];
-    st9(lds + ImuLds::DVT, tid, t9);
-  }
-  __syncthreads();
-  // ---- stage 6: dp_term (aliases RINV, no longer needed)
-  if (tid < ns) {
-    double dv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t9[9];
-    for (int j = 0; j < tid; ++j)
-      for (int c = 0; c < 9; ++c) dv[c] += lds[ImuLds::DVT + 9 * j + c];
-    for (int c = 0; c < 9; ++c) t9[c] = dt * dv[c] + 0.25 * dt * dt * G[c];
-    st9(lds + ImuLds::RINV, tid, t9);
-  }
-  __syncthreads();
-  // ---- stage 7: totals -> cache copy in LDS
-  double* ca = lds + ImuLds::CA;
-  if (tid < 51) {
-    int base, stride, comp, dst;
-    if (tid < 9) { base = ImuLds::CINT; stride = 9; comp = tid; dst = CA_CI + tid; }
-    else if (tid < 18) { base = ImuLds::CDBL; stride = 9; comp = tid - 9; dst = CA_CD + tid - 9; }
-    else if (tid < 21) { base = ImuLds::AINT; stride = 3; comp = tid - 18; dst = CA_AI + tid - 18; }
-    else if (tid < 24) { base = ImuLds::ADBL; stride = 3; comp = tid - 21; dst = CA_AD + tid - 21; }
-    else if (tid < 33) { base = ImuLds::DAL; stride = 9; comp = tid - 24; dst = CA_DA + tid - 24; }
-    else if (tid < 42) { base = ImuLds::DVT; stride = 9; comp = tid - 33; dst = CA_DV + tid - 33; }
-    else { base = ImuLds::RINV; stride = 9; comp = tid - 42; dst = CA_DP + tid - 42; }
-    double s = 0;
-    for (int k = 0; k < ns; ++k) s += lds[base + stride * k + comp];
-    ca[dst] = s;
-  } else if (tid < 55) {
-    ca[CA_DQ + tid - 51] = lds[ImuLds::DQP + 4 * ns + (tid - 51)];
-  }
-  // ---- stage 8: covariance recursion
   double* P = lds + ImuLds::PM;
   double* T = lds + ImuLds::TM;
+  const int pi = tid / 15, pj = tid % 15;
+  if (tid == 0) {
+    s_next_it = 0;
+    s_started = 0;
+    s_finished = 0;
+    s_time = t0;
+    c_Dq[0] = c_Dq[1] = c_Dq[2] = 0.0;
+    c_Dq[3] = 1.0;
+  }
+  if (tid < 9) {
+    c_Cint[tid] = 0; c_cross[tid] = 0; c_dv[tid] = 0; t_Cdbl[tid] = 0; t_dal[tid] = 0; t_dp[tid] = 0;
+  }
+  if (tid < 3) {
+    c_aint[tid] = 0; t_adbl[tid] = 0;
+  }
   if (tid < 225) P[tid] = 0.0;
   __syncthreads();
-  const int pi = tid / 15, pj = tid % 15;
-  for (int k = 0; k < ns; ++k) {
-    const double* adbl = lds + ImuLds::ADBL + 3 * k;
-    const double* dpt = lds + ImuLds::RINV + 9 * k;
-    const double* b012 = lds + ImuLds::B012 + 9 * k;
-    const double* c1 = lds + ImuLds::C1 + 9 * k;
-    const double* ai = lds + ImuLds::AINT + 3 * k;
-    const double* dvt = lds + ImuLds::DVT + 9 * k;
-    const double* ci = lds + ImuLds::CINT + 9 * k;
-    const double dtk = lds[ImuLds::DT + k];
-    if (tid < 225) T[tid] = imu_F_apply(P, pi, pj, adbl, dtk, dpt, b012, c1, ai, dvt, ci);
-    __syncthreads();
-    if (tid < 225) {
-      // (T F^T)_ij = (F T^T)_ji : apply F to column i of T^T, i.e. row i of T
-      // X := T^T  => X[15*m + i] = T[15*i + m]; evaluate row pj of F against it.
-      double v = T[15 * pi + pj];
-      if (pj < 3) {
-        double cx[9];
-        cross_mx(adbl, cx);
-        for (int m = 0; m < 3; ++m) {
-          v -= cx[3 * pj + m] * T[15 * pi + 3 + m];
-          v += dpt[3 * pj + m] * T[15 * pi + 9 + m];
-          v += b012[3 * pj + m] * T[15 * pi + 12 + m];
+
+  for (;;) {
+    // ---- stage 0: loop control of ImuError.cpp:113-150,259-260 (integer time logic) by one work-item
+    if (tid == 0) {
+      long long time = s_time;
+      bool started = s_started != 0;
+      int k = 0, it = s_next_it;
+      bool fin = s_finished != 0;
+      for (; it < n && k < IMU_N && !fin; ++it) {
+        long long nexttime = (it + 1 == n) ? t1 : ts[it + 1];
+        int flag = 0;
+        if (t1 < nexttime) {
+          nexttime = t1;
+          flag |= 1;  // interpolate the second sample to t1
         }
-        v += dtk * T[15 * pi + 6 + pj];
-      } else if (pj < 6) {
-        const int r = pj - 3;
-        for (int m = 0; m < 3; ++m) v -= dtk * c1[3 * r + m] * T[15 * pi + 9 + m];
-      } else if (pj < 9) {
-        const int r = pj - 6;
-        double cx[9];
-        cross_mx(ai, cx);
-        for (int m = 0; m < 3; ++m) {
-          v -= cx[3 * r + m] * T[15 * pi + 3 + m];
-          v += dvt[3 * r + m] * T[15 * pi + 9 + m];
-          v -= ci[3 * r + m] * T[15 * pi + 12 + m];
+        if (nexttime - time <= 0) continue;
+        if (!started) {
+          started = true;
+          flag |= 2;  // interpolate the first sample to t0
         }
+        s_it[k] = it;
+        s_flag[k] = flag;
+        s_ts[k] = time;
+        s_tn[k] = nexttime;
+        ++k;
+        time = nexttime;
+        if (nexttime == t1) fin = true;
       }
-      if (pi == pj) {  // noise (ImuError.cpp:228-249)
-        const double s2a = lds[ImuLds::SG2 + k], s2v = lds[ImuLds::SA2 + k];
-        if (pi < 3) v += 0.5 * dtk * dtk * s2v;
-        else if (pi < 6) v += s2a;
-        else if (pi < 9) v += s2v;
-        else if (pi < 12) v += dtk * prm.sigma_gw_c * prm.sigma_gw_c;
-        else v += dtk * prm.sigma_aw_c * prm.sigma_aw_c;
-      }
-      P[tid] = v;
+      if (it >= n) fin = true;
+      s_nsteps = k;
+      s_next_it = it;
+      s_time = time;
+      s_started = started ? 1 : 0;
+      s_finished = fin ? 1 : 0;
     }
     __syncthreads();
+    const int ns = s_nsteps;
+    if (ns == 0) break;
+    // ---- stage 1: per-step quantities
+    if (tid < ns) {
+      const int it = s_it[tid];
+      const int nx = (it + 1 < n) ? it + 1 : it;
+      double w0[3] = {gyr[3 * it], gyr[3 * it + 1], gyr[3 * it + 2]};
+      double a0[3] = {acc[3 * it], acc[3 * it + 1], acc[3 * it + 2]};
+      double w1[3] = {gyr[3 * nx], gyr[3 * nx + 1], gyr[3 * nx + 2]};
+      double a1[3] = {acc[3 * nx], acc[3 * nx + 1], acc[3 * nx + 2]};
+      const double dt = ns_to_sec(s_tn[tid] - s_ts[tid]);
+      if (s_flag[tid] & 1) {
+        const long long raw_next = (it + 1 == n) ? t1 : ts[it + 1];
+        const double interval = ns_to_sec(raw_next - ts[it]);
+        const double r = dt / interval;
+        for (int c = 0; c < 3; ++c) {
+          w1[c] = (1.0 - r) * w0[c] + r * w1[c];
+          a1[c] = (1.0 - r) * a0[c] + r * a1[c];
+        }
+      }
+      if (s_flag[tid] & 2) {
+        const double r = dt / ns_to_sec(s_tn[tid] - ts[it]);
+        for (int c = 0; c < 3; ++c) {
+          w0[c] = r * w0[c] + (1.0 - r) * w1[c];
+          a0[c] = r * a0[c] + (1.0 - r) * a1[c];
+        }
+      }
+      double sg = prm.sigma_g_c, sa = prm.sigma_a_c;
+      bool gs = false, as = false;
+      for (int c = 0; c < 3; ++c) {
+        gs = gs || fabs(w0[c]) > prm.g_max || fabs(w1[c]) > prm.g_max;
+        as = as || fabs(a0[c]) > prm.a_max || fabs(a1[c]) > prm.a_max;
+      }
+      if (gs) sg *= 100;
+      if (as) sa *= 100;
+      double om[3], ab[3];
+      for (int c = 0; c < 3; ++c) {
+        om[c] = 0.5 * (w0[c] + w1[c]) - bg[c];
+        ab[c] = 0.5 * (a0[c] + a1[c]) - ba[c];
+      }
+      const double th = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]) * 0.5 * dt;
+      const double sc = sinc(th), ct = cos(th);
+      double dq[4] = {sc * om[0] * 0.5 * dt, sc * om[1] * 0.5 * dt, sc * om[2] * 0.5 * dt, ct};
+      double phi[3] = {om[0] * dt, om[1] * dt, om[2] * dt};
+      double Jr[9], dqi[4], Ri[9];
+      right_jacobian(phi, Jr);
+      for (int c = 0; c < 9; ++c) Jr[c] *= dt;
+      qinv(dq, dqi);
+      qrot(dqi, Ri);
+      for (int c = 0; c < 4; ++c) lds[ImuLds::DQ + 4 * tid + c] = dq[c];
+      lds[ImuLds::DT + tid] = dt;
+      for (int c = 0; c < 3; ++c) lds[ImuLds::AB + 3 * tid + c] = ab[c];
+      st9(lds + ImuLds::JRDT, tid, Jr);
+      st9(lds + ImuLds::RINV, tid, Ri);
+      lds[ImuLds::SG2 + tid] = dt * sg * sg;
+      lds[ImuLds::SA2 + tid] = dt * sa * sa;
+    }
+    __syncthreads();
+    // ---- stage 2: Delta_q_k = Delta_q_carry (x) dq_0 (x) ... (x) dq_(k-1), the reference's product order
+    if (tid <= ns) {
+      double q[4] = {c_Dq[0], c_Dq[1], c_Dq[2], c_Dq[3]};
+      for (int j = 0; j < tid; ++j) {
+        double t[4];
+        qmul(q, lds + ImuLds::DQ + 4 * j, t);
+        q[0] = t[0]; q[1] = t[1]; q[2] = t[2]; q[3] = t[3];
+      }
+      for (int c = 0; c < 4; ++c) lds[ImuLds::DQP + 4 * tid + c] = q[c];
+    }
+    __syncthreads();
+    // ---- stage 3
+    double C[9], CC[9], dt = 0, ab[3] = {0, 0, 0};
+    if (tid < ns) {
+      double C1m[9];
+      qrot(lds + ImuLds::DQP + 4 * tid, C);
+      qrot(lds + ImuLds::DQP + 4 * (tid + 1), C1m);
+      dt = lds[ImuLds::DT + tid];
+      for (int c = 0; c < 3; ++c) ab[c] = lds[ImuLds::AB + 3 * tid + c];
+      for (int c = 0; c < 9; ++c) CC[c] = C[c] + C1m[c];
+      double t9[9], t3[3], h[9];
+      for (int c = 0; c < 9; ++c) h[c] = 0.5 * CC[c];
+      for (int c = 0; c < 9; ++c) t9[c] = h[c] * dt;
+      st9(lds + ImuLds::CINT, tid, t9);
+      mat3_vec(h, ab, t3);
+      for (int c = 0; c < 3; ++c) lds[ImuLds::AINT + 3 * tid + c] = t3[c] * dt;
+      double Jr[9];
+      ld9(lds + ImuLds::JRDT, tid, Jr);
+      mat3_mul(C1m, Jr, t9);
+      st9(lds + ImuLds::DAL, tid, t9);
+      st9(lds + ImuLds::C1, tid, C1m);
+    }
+    __syncthreads();
+    // ---- stage 4: ordered prefix sums + the cross recursion (registers), starting from the carries
+    double Cint[9], aint[3], cross[9];
+    for (int c = 0; c < 9; ++c) {
+      Cint[c] = c_Cint[c];
+      cross[c] = c_cross[c];
+    }
+    for (int c = 0; c < 3; ++c) aint[c] = c_aint[c];
+    if (tid < ns) {
+      for (int j = 0; j < tid; ++j) {
+        for (int c = 0; c < 9; ++c) Cint[c] += lds[ImuLds::CINT + 9 * j + c];
+        for (int c = 0; c < 3; ++c) aint[c] += lds[ImuLds::AINT + 3 * j + c];
+        double Ri[9], t9[9];
+        ld9(lds + ImuLds::RINV, j, Ri);
+        mat3_mul(Ri, cross, t9);
+        for (int c = 0; c < 9; ++c) cross[c] = t9[c] + lds[ImuLds::JRDT + 9 * j + c];
+      }
+    }
+    // ---- stage 5
+    double G[9];
+    double cross1[9];
+    if (tid < ns) {
+      double q[9], t3[3], t9[9];
+      for (int c = 0; c < 9; ++c) q[c] = 0.25 * CC[c];
+      mat3_vec(q, ab, t3);
+      for (int c = 0; c < 3; ++c) lds[ImuLds::ADBL + 3 * tid + c] = aint[c] * dt + t3[c] * dt * dt;
+      for (int c = 0; c < 9; ++c) t9[c] = Cint[c] * dt + q[c] * dt * dt;
+      st9(lds + ImuLds::CDBL, tid, t9);
+      for (int c = 0; c < 9; ++c) t9[c] = -Cint[c] * dt + q[c] * dt * dt;
+      st9(lds + ImuLds::B012, tid, t9);
+      double Ri[9], ax[9], C1m[9], u[9], v[9];
+      ld9(lds + ImuLds::RINV, tid, Ri);
+      mat3_mul(Ri, cross, cross1);
+      for (int c = 0; c < 9; ++c) cross1[c] += lds[ImuLds::JRDT + 9 * tid + c];
+      cross_mx(ab, ax);
+      ld9(lds + ImuLds::C1, tid, C1m);
+      mat3_mul(C, ax, u);
+      mat3_mul(u, cross, v);
+      for (int c = 0; c < 9; ++c) G[c] = v[c];
+      mat3_mul(C1m, ax, u);
+      mat3_mul(u, cross1, v);
+      for (int c = 0; c < 9; ++c) G[c] += v[c];
+      st9(lds + ImuLds::GG, tid, G);
+      for (int c = 0; c < 9; ++c) t9[c] = 0.5 * dt * G[c];
+      st9(lds + ImuLds::DVT, tid, t9);
+    }
+    __syncthreads();
+    // ---- stage 6: dp_term (aliases RINV, no longer needed)
+    if (tid < ns) {
+      double dv[9], t9[9];
+      for (int c = 0; c < 9; ++c) dv[c] = c_dv[c];
+      for (int j = 0; j < tid; ++j)
+        for (int c = 0; c < 9; ++c) dv[c] += lds[ImuLds::DVT + 9 * j + c];
+      for (int c = 0; c < 9; ++c) t9[c] = dt * dv[c] + 0.25 * dt * dt * G[c];
+      st9(lds + ImuLds::RINV, tid, t9);
+    }
+    __syncthreads();
+    // ---- stage 8: covariance recursion over this chunk
+    for (int k = 0; k < ns; ++k) {
+      const double* adbl = lds + ImuLds::ADBL + 3 * k;
+      const double* dpt = lds + ImuLds::RINV + 9 * k;
+      const double* b012 = lds + ImuLds::B012 + 9 * k;
+      const double* c1 = lds + ImuLds::C1 + 9 * k;
+      const double* ai = lds + ImuLds::AINT + 3 * k;
+      const double* dvt = lds + ImuLds::DVT + 9 * k;
+      const double* ci = lds + ImuLds::CINT + 9 * k;
+      const double dtk = lds[ImuLds::DT + k];
+      if (tid < 225) T[tid] = imu_F_apply(P, pi, pj, adbl, dtk, dpt, b012, c1, ai, dvt, ci);
+      __syncthreads();
+      if (tid < 225) {
+        // (T F^T)_ij = sum_m T_im F_jm: row pj of the sparse F against row pi of T
+        double v = T[15 * pi + pj];
+        if (pj < 3) {
+          double cx[9];
+          cross_mx(adbl, cx);
+          for (int m = 0; m < 3; ++m) {
+            v -= cx[3 * pj + m] * T[15 * pi + 3 + m];
+            v += dpt[3 * pj + m] * T[15 * pi + 9 + m];
+            v += b012[3 * pj + m] * T[15 * pi + 12 + m];
+          }
+          v += dtk * T[15 * pi + 6 + pj];
+        } else if (pj < 6) {
+          const int r = pj - 3;
+          for (int m = 0; m < 3; ++m) v -= dtk * c1[3 * r + m] * T[15 * pi + 9 + m];
+        } else if (pj < 9) {
+          const int r = pj - 6;
+          double cx[9];
+          cross_mx(ai, cx);
+          for (int m = 0; m < 3; ++m) {
+            v -= cx[3 * r + m] * T[15 * pi + 3 + m];
+            v += dvt[3 * r + m] * T[15 * pi + 9 + m];
+            v -= ci[3 * r + m] * T[15 * pi + 12 + m];
+          }
+        }
+        if (pi == pj) {  // noise (ImuError.cpp:228-249)
+          const double s2a = lds[ImuLds::SG2 + k], s2v = lds[ImuLds::SA2 + k];
+          if (pi < 3) v += 0.5 * dtk * dtk * s2v;
+          else if (pi < 6) v += s2a;
+          else if (pi < 9) v += s2v;
+          else if (pi < 12) v += dtk * prm.sigma_gw_c * prm.sigma_gw_c;
+          else v += dtk * prm.sigma_aw_c * prm.sigma_aw_c;
+        }
+        P[tid] = v;
+      }
+      __syncthreads();
+    }
+    // ---- stage 7: fold this chunk into the carries / running totals (ordered sums)
+    {
+      double add = 0;
+      int base = -1, stride = 0, comp = 0;
+      if (tid < 9) { base = ImuLds::CINT; stride = 9; comp = tid; }
+      else if (tid < 18) { base = ImuLds::CDBL; stride = 9; comp = tid - 9; }
+      else if (tid < 21) { base = ImuLds::AINT; stride = 3; comp = tid - 18; }
+      else if (tid < 24) { base = ImuLds::ADBL; stride = 3; comp = tid - 21; }
+      else if (tid < 33) { base = ImuLds::DAL; stride = 9; comp = tid - 24; }
+      else if (tid < 42) { base = ImuLds::DVT; stride = 9; comp = tid - 33; }
+      else if (tid < 51) { base = ImuLds::RINV; stride = 9; comp = tid - 42; }
+      if (base >= 0)
+        for (int k = 0; k < ns; ++k) add += lds[base + stride * k + comp];
+      const double dqn = (tid >= 51 && tid < 55) ? lds[ImuLds::DQP + 4 * ns + (tid - 51)] : 0.0;
+      __syncthreads();  // every reader of the carries (stages 2/4/6 above) is done
+      if (tid < 9) c_Cint[tid] += add;
+      else if (tid < 18) t_Cdbl[tid - 9] += add;
+      else if (tid < 21) c_aint[tid - 18] += add;
+      else if (tid < 24) t_adbl[tid - 21] += add;
+      else if (tid < 33) t_dal[tid - 24] += add;
+      else if (tid < 42) c_dv[tid - 33] += add;
+      else if (tid < 51) t_dp[tid - 42] += add;
+      else if (tid < 55) c_Dq[tid - 51] = dqn;
+      if (tid == ns - 1)
+        for (int c = 0; c < 9; ++c) c_cross[c] = cross1[c];  // cross after the last step of the chunk
+    }
+    __syncthreads();
+    if (s_finished) break;
   }
+  // ---- cache copy in LDS
+  double* ca = lds + ImuLds::CA;
+  if (tid < 9) {
+    ca[CA_CI + tid] = c_Cint[tid];
+    ca[CA_CD + tid] = t_Cdbl[tid];
+    ca[CA_DA + tid] = t_dal[tid];
+    ca[CA_DV + tid] = c_dv[tid];
+    ca[CA_DP + tid] = t_dp[tid];
+  }
+  if (tid < 3) {
+    ca[CA_AI + tid] = c_aint[tid];
+    ca[CA_AD + tid] = t_adbl[tid];
+  }
+  if (tid < 4) ca[CA_DQ + tid] = c_Dq[tid];
+  __syncthreads();
   // ---- stage 9: information = sym(P)^-1, sqrtInfo = chol(sym(information))^T  (ImuError.cpp:268-279)
   if (tid < 225) T[tid] = 0.5 * P[15 * pi + pj] + 0.5 * P[15 * pj + pi];
   __syncthreads();

@@ -17,7 +17,7 @@ constexpr int SCHUR_TILE_BLOCKS = 16;  // 16 x 16 blocks of 6x6 = 96 x 96 tile, 
 constexpr int SCHUR_LM_BATCH = 16;     // landmarks staged per LDS pass in the Schur kernel
 constexpr int SOLVE_THREADS = 1024;
 constexpr int MAX_D_LDS = 174;         // reduced systems up to this size are factorised in LDS (block-packed)
-constexpr int MAX_IMU_STEPS = 254;     // integration steps of one IMU factor (threads of its workgroup)
+constexpr int MAX_IMU_SAMPLES = 1 << 20; // raw samples of one IMU factor (processed in LDS-sized chunks)
 constexpr int IMU_THREADS = 256;
 // IMU factor linearisation record: H = J^T J (30x30 lower, packed a(a+1)/2+b) | g = J^T r (30) | r (15) | cost
 constexpr int IMU_H = 0, IMU_G = 465, IMU_R = 495, IMU_COST = 510;

@@ -183,3 +183,56 @@ def test_time_limited_optimize_runs_min_iterations():
     s = b.optimize_timed(7, 3, -1.0)[0]        # negative limit: no limit -> max iterations
     assert s["iterations"] == 7
     b.close()
+
+
+def test_long_imu_factors_are_chunked(oracle):
+    # 400+ integration steps per factor: the on-device re-preintegration streams over LDS-sized chunks
+    w = synthetic.make_window(3, 40, 1.0, seed=31, imu_rate_hz=800)
+    assert w.imu_s_count.max() > 400
+    b = _batch([w], debug_arrays=1)
+    o = oracle.OracleWindow(w)
+    c = o.linearize()
+    b.begin()
+    s = b.finish()[0]
+    assert abs(s["final_cost"] - c) <= 1e-10 * c
+    _close(b.array("IMU_RESIDUAL"), o.array("IMU_RESIDUAL"), 1e-8)
+    sg = b.optimize(8)[0]
+    sr = oracle.OracleWindow(w).optimize(8)
+    assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+    b.close()
+
+
+def test_marginalisation_prior_evaluation(oracle):
+    # a synthetic dense prior e = e0 + J dchi over two poses and one speed/bias block
+    # (MarginalizationError::EvaluateWithMinimalJacobians, MarginalizationError.cpp:893-946)
+    rng = np.random.default_rng(32)
+    w = synthetic.small_window(seed=32, K=4, L=40)
+    Dm = 6 + 9 + 6
+    A = rng.standard_normal((Dm, Dm))
+    w.marg_J = np.triu(A) * 3.0
+    w.marg_e0 = rng.standard_normal(Dm) * 0.1
+    w.marg_block_type = np.array([0, 1, 0], np.int32)
+    w.marg_block_idx = np.array([0, 0, 1], np.int32)
+    w.marg_block_off = np.array([0, 6, 15], np.int32)
+    lin = np.zeros((3, 9))
+    lin[0, :7] = synthetic.pose_oplus(w.pose[0], rng.normal(0, 0.02, 6))
+    lin[1] = w.sb[0] + rng.normal(0, 0.01, 9)
+    lin[2, :7] = synthetic.pose_oplus(w.pose[1], rng.normal(0, 0.02, 6))
+    w.marg_lin = lin
+    for exact in (1,):
+        b = _batch([w], debug_arrays=1)
+        o = oracle.OracleWindow(w)
+        o.set_marg_exact(exact)
+        c = o.linearize()
+        b.begin()
+        s = b.finish()[0]
+        assert abs(s["final_cost"] - c) <= 1e-11 * c
+        b.begin(); b.iterate(1)
+        opt = default_options()
+        assert o.solve(opt.initial_radius, opt) == 0
+        _close(b.array("REDUCED_S"), o.array("REDUCED_S"), 1e-12)
+        _close(b.array("STEP"), o.array("STEP"), 1e-7)
+        sg = b.optimize(10)[0]
+        sr = o.optimize(10)
+        assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+        b.close()
