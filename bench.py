@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""bench.py — Gauss-Newton (LM-safeguarded) iterations/s of the MI355X sliding-window BA backend.
+"""bench.py — Gauss-Newton iterations/s of the MI355X sliding-window BA backend.
 
 A "step" is one full trust-region iteration (Schur reduce -> reduced solve -> back-substitute + (+)update
 + re-linearise, BASELINE.md §"Path under measurement") on every window resident on this GPU.  Workload
-per GPU: `--windows` independent synthetic windows of BASELINE.json configs[1] (10 keyframes / 2 cams /
-400 landmarks / 100-sample IMU factors, fp64) — 8 per GPU is configs[3]'s shape (64 windows over 8 GPUs).
+per GPU: `--windows` (default 64) independent synthetic windows of BASELINE.json configs[1] (10 keyframes /
+2 cams / 400 landmarks / 100-sample IMU factors, fp64); `--windows 8` is configs[3]'s per-GPU share (64
+windows over 8 GPUs) and `single_window` in the output is configs[1] alone (latency).
 Weak scaling: every rank owns its own windows (seeds 20240923 + rank*windows + i), there is no data-path
 collective; the only exchange is the gather of per-rank timings.  All convergence tolerances are disabled
 in the timed region so that every step performs the full work (accepted or rejected steps launch the
@@ -47,21 +48,15 @@ def parse():
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl")  # RCCL over xGMI
-        dist = dist_mod
+    from okvis_amd import dist as D
+    rk = D.Rank.from_env()
+    rank, world, local_rank = rk.rank, rk.world, rk.local_rank
+    dist = D.init()   # "nccl" (= RCCL over xGMI) on the GPU node
 
     from okvis_amd import solver, synthetic
     from okvis_amd.window import default_options
 
-    seeds = [20240923 + rank * a.windows + i for i in range(a.windows)]
+    seeds = D.shard_seeds(rank, world, a.windows)
     wins = [synthetic.make_window(a.keyframes, a.landmarks, a.visibility, s) for s in seeds]
     opt = default_options()
     opt.function_tolerance = 0.0
@@ -92,18 +87,10 @@ def main():
     t1 = time.perf_counter()
     wall = t1 - t0
     ev_ms = batch.last_iterate_ms()
-    if dist is not None:
-        import torch
-        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-        # the one collective of the design: all-gather of the per-rank timing records
-        rec = torch.tensor([float(rank), float(a.steps), ev_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
-        gathered = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(gathered, rec)
-        per_rank_ms = [float(g[2].item()) for g in gathered]
-    else:
-        per_rank_ms = [ev_ms]
+    wall = D.max_over_ranks(dist, wall)
+    # the one collective of the design: all-gather of the per-rank timing records
+    recs = D.gather_records(dist, [float(rank), float(a.windows), float(a.steps), ev_ms * 1e-3])
+    per_rank_ms = [r[3] * 1e3 for r in recs]
     summaries = None
 
     # ---- per-kernel attribution for the roofline (eager launches bracketed by HIP events) ----
@@ -136,7 +123,7 @@ def main():
         single = {"iterations_per_s": a.steps / (ms1 * 1e-3), "ms_per_iteration": ms1 / a.steps}
 
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:   # reported at N=1 only
         # CPU restatement (oracle), one thread, bounded sample of the same workload.  Test infrastructure:
         # used here ONLY as the reported baseline, never in the measured path.
         from tests import oracle_lib
@@ -154,14 +141,13 @@ def main():
         total_iters = world * a.windows * a.steps
         value = total_iters / wall
         out = {
-            "metric": "Gauss-Newton iterations/sec on 10-KF x 2-cam x 400-landmark windows (window-iterations/s, batched)",
+            "metric": "Gauss-Newton iterations/sec on 10-KF x 2-cam x 400-landmark windows (batch throughput: window-iterations/s)",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.windows} independent windows per GPU of BASELINE configs[1] "
                                    f"({a.keyframes} KF / 2 cam / {a.landmarks} landmarks / {wins[0].n_obs} obs / "
-                                   f"{wins[0].n_imu} IMU factors x ~100 samples, fp64); configs[3] is 8 such windows "
-                                   f"on each of 8 GPUs",
+                                   f"{wins[0].n_imu} IMU factors x ~100 samples, fp64), Gauss-Newton mode, tolerances off",
                        "windows_per_gpu": a.windows, "observations_per_window": wins[0].n_obs,
                        "reduced_dim": wins[0].reduced_dim(), "graph": not a.no_graph, "parallelism": f"windows x{world}"},
             "hip_event_ms_per_step": max(per_rank_ms) / a.steps,
@@ -171,6 +157,7 @@ def main():
         print(json.dumps(out), flush=True)
     batch.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

