@@ -167,7 +167,7 @@ typedef struct okvis_ba_options {
                                    at initial_radius (no trust-region logic); used by bench.py so that
                                    every timed iteration performs identical, full work                   */
   int32_t n_streams;            /* sub-batches of windows on separate HIP streams (phases of different
-                                   windows overlap); 0 = default (1: measured fastest on ROCm 7.2)       */
+                                   windows overlap); 0 = auto (2 for >= 32 windows, else 1)              */
   int32_t reserved;
 } okvis_ba_options;
 

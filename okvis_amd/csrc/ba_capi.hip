@@ -68,8 +68,9 @@ struct okvis_ba_solver {
   WinPtrs* d_wins = nullptr;
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
-  int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0;
+  int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0;
   std::map<int, hipGraphExec_t> graphs;
+  std::map<std::pair<int, int>, hipGraphExec_t> sub_graphs;  // (n, sub) -> graph of that sub-batch's chain
   float last_iterate_ms = 0.f;
   int last_hip_error = 0;
 };
@@ -95,6 +96,8 @@ OptD make_optd(const okvis_ba_options& o) {
 void destroy_graphs(okvis_ba_solver* s) {
   for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
   s->graphs.clear();
+  for (auto& kv : s->sub_graphs) (void)hipGraphExecDestroy(kv.second);
+  s->sub_graphs.clear();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -550,7 +553,7 @@ size_t solve_smem(int Dpad) {
   const size_t nbk = Dpad / 6;
   return (nbk * (nbk + 1) / 2 * 38 + 4 * (size_t)Dpad + 2 * nbk * 36) * sizeof(double) + ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15));
 }
-size_t small_smem() { return (size_t)ImuLds::TOTAL * sizeof(double); }
+size_t small_smem() { return (size_t)std::max<int>(std::max<int>(ImuLds::TOTAL, EvalLds::TOTAL), 2 * MAX_MARG_DIM) * sizeof(double); }
 
 struct Sub {
   hipStream_t st;
@@ -560,8 +563,9 @@ Sub whole(okvis_ba_solver* s) { return Sub{s->stream, 0, (int)s->wins.size()}; }
 
 hipError_t launch_schur(okvis_ba_solver* s, Sub b) {
   if (s->max_schur_blocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(schur_kernel, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), 0, b.st, s->d_wins + b.w0,
-                     s->d_opt);
+  const int trows = std::min(TILE_DIM, s->max_Dp);
+  hipLaunchKernelGGL(schur_kernel, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS),
+                     (size_t)2 * SCHUR_LM_BATCH * trows * 3 * sizeof(double), b.st, s->d_wins + b.w0, s->d_opt, trows);
   return hipGetLastError();
 }
 hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
@@ -698,11 +702,15 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lin_smem(false));
   if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(2 * SCHUR_LM_BATCH * TILE_DIM * 3 * sizeof(double)));
+  if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)solve_smem(((MAX_D_LDS + 5) / 6) * 6));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)small_smem());
+
   if (e != hipSuccess) {
     int code = OKVIS_BA_HIP_ERROR_BASE + (int)e;
     okvis_ba_destroy(s);
@@ -770,7 +778,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   s->arena_bytes = A.size;
   HIP_TRY(hipMemcpy(s->d_arena, A.host.data(), A.size, hipMemcpyHostToDevice));
   std::vector<WinPtrs> ptrs(n_windows);
-  s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = 0;
+  s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = 0;
   s->any_ext = false;
   for (int i = 0; i < n_windows; ++i) {
     relocate(wins[i].ptrs, s->d_arena, s->opt.debug_arrays != 0);
@@ -781,6 +789,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     s->max_schur_blocks = std::max(s->max_schur_blocks, P.n_chunk * (P.n_tile * (P.n_tile + 1) / 2));
     s->max_lm = std::max(s->max_lm, P.n_lm);
     s->max_Dpad = std::max(s->max_Dpad, ((P.D + 5) / 6) * 6);
+    s->max_Dp = std::max(s->max_Dp, P.Dp);
     s->any_ext = s->any_ext || P.has_ext;
   }
   HIP_TRY(hipMalloc(&s->d_wins, sizeof(WinPtrs) * n_windows));
@@ -790,9 +799,10 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   s->wins.swap(wins);
   // ---- sub-batches: opt.n_streams (0 = auto: one stream per 8 windows, at most 8) ----
   {
-    // measured on MI355X / ROCm 7.2: forked branches of a captured graph are not overlapped, so the
-    // default is a single stream (profiles/r01_notes.md)
-    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : 1;
+    // measured on MI355X / ROCm 7.2 (profiles/r01_notes.md): branches inside ONE captured graph are not
+    // overlapped, but two independently replayed graphs on two streams are (+29 % at 64 windows); more
+    // than two streams lose again
+    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 32 ? 2 : 1);
     nsub = std::max(1, std::min(nsub, n_windows));
     for (auto st : s->sub_streams) (void)hipStreamDestroy(st);
     for (auto ev : s->sub_events) (void)hipEventDestroy(ev);
@@ -886,7 +896,35 @@ int okvis_ba_iterate(okvis_ba_solver* s, int n) {
   if (n == 0) return OKVIS_BA_OK;
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
-  if (s->opt.use_graph) {
+  const int nsub = (int)s->sub_streams.size();
+  if (s->opt.use_graph && nsub > 1) {
+    // one graph per sub-batch, each replayed on its own stream (independent launches overlap; branches
+    // inside ONE captured graph were measured not to)
+    HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+    for (int k = 0; k < nsub; ++k) {
+      hipGraphExec_t exec = nullptr;
+      auto it = s->sub_graphs.find({n, k});
+      if (it == s->sub_graphs.end()) {
+        hipGraph_t graph = nullptr;
+        const Sub b{s->sub_streams[k], s->sub_begin[k], s->sub_begin[k + 1] - s->sub_begin[k]};
+        HIP_TRY(hipStreamBeginCapture(b.st, hipStreamCaptureModeRelaxed));
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < n && e == hipSuccess; ++i) e = launch_iteration(s, b);
+        hipError_t e2 = hipStreamEndCapture(b.st, &graph);
+        if (e != hipSuccess) HIP_TRY(e);
+        HIP_TRY(e2);
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_TRY(hipGraphDestroy(graph));
+        s->sub_graphs[{n, k}] = exec;
+      } else {
+        exec = it->second;
+      }
+      HIP_TRY(hipStreamWaitEvent(s->sub_streams[k], s->ev_fork, 0));
+      HIP_TRY(hipGraphLaunch(exec, s->sub_streams[k]));
+      HIP_TRY(hipEventRecord(s->sub_events[k], s->sub_streams[k]));
+      HIP_TRY(hipStreamWaitEvent(s->stream, s->sub_events[k], 0));
+    }
+  } else if (s->opt.use_graph) {
     hipGraphExec_t exec = nullptr;
     auto it = s->graphs.find(n);
     if (it == s->graphs.end()) {
@@ -1039,6 +1077,7 @@ static int locate(okvis_ba_solver* s, int w, int which, const double** ptr, int6
     case OKVIS_BA_ARR_GRADIENT: *ptr = P.grad; *n = H.D; return 0;
     case OKVIS_BA_ARR_DAMPING: *ptr = P.Dp2; *n = H.D; return P.Dp2 ? 0 : OKVIS_BA_ERR_STATE;
     case 99: *ptr = P.prof; *n = 64; return 0;
+    case 98: *ptr = nullptr; *n = H.n_imu; return 0;  // diagnostics: re-preintegration count per IMU factor
     case OKVIS_BA_ARR_IMU_RESIDUAL: *ptr = nullptr; *n = 15 * (int64_t)H.n_imu; return 0;
   }
   return OKVIS_BA_ERR_ARG;
@@ -1059,6 +1098,15 @@ int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t
   int rc = locate(s, w, which, &p, &n);
   if (rc != 0) return rc;
   if (n != n_doubles) return OKVIS_BA_ERR_ARG;
+  if (which == 98) {
+    const HostWin& H = s->wins[w];
+    for (int f = 0; f < H.n_imu; ++f) {
+      ImuCacheD c;
+      HIP_TRY(hipMemcpy(&c, H.ptrs.imu_cache + f, sizeof(c), hipMemcpyDeviceToHost));
+      out[f] = c.redo_count;
+    }
+    return OKVIS_BA_OK;
+  }
   if (which == OKVIS_BA_ARR_IMU_RESIDUAL) {
     const HostWin& H = s->wins[w];
     for (int f = 0; f < H.n_imu; ++f)
@@ -1073,26 +1121,30 @@ int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4) {
   if (!s || !ms4 || n <= 0) return OKVIS_BA_ERR_ARG;
   if (!s->begun) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
-  std::vector<hipEvent_t> ev(5);
+  // queue all n iterations with events between the kernels and synchronise ONCE: the kernels run
+  // back-to-back on the GPU, so the event intervals are kernel durations, not host launch latency
+  std::vector<hipEvent_t> ev(5 * (size_t)n);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   for (int k = 0; k < 4; ++k) ms4[k] = 0.f;
   for (int i = 0; i < n; ++i) {
-    HIP_TRY(hipEventRecord(ev[0], s->stream));
+    hipEvent_t* e = &ev[5 * (size_t)i];
+    HIP_TRY(hipEventRecord(e[0], s->stream));
     HIP_TRY(launch_schur(s, whole(s)));
-    HIP_TRY(hipEventRecord(ev[1], s->stream));
+    HIP_TRY(hipEventRecord(e[1], s->stream));
     HIP_TRY(launch_solve(s, whole(s), 0));
-    HIP_TRY(hipEventRecord(ev[2], s->stream));
+    HIP_TRY(hipEventRecord(e[2], s->stream));
     HIP_TRY(launch_small(s, whole(s), 0));
-    HIP_TRY(hipEventRecord(ev[3], s->stream));
+    HIP_TRY(hipEventRecord(e[3], s->stream));
     HIP_TRY(launch_lin(s, whole(s), 0));
-    HIP_TRY(hipEventRecord(ev[4], s->stream));
-    HIP_TRY(hipEventSynchronize(ev[4]));
+    HIP_TRY(hipEventRecord(e[4], s->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  for (int i = 0; i < n; ++i)
     for (int k = 0; k < 4; ++k) {
       float t = 0;
-      HIP_TRY(hipEventElapsedTime(&t, ev[k], ev[k + 1]));
+      HIP_TRY(hipEventElapsedTime(&t, ev[5 * (size_t)i + k], ev[5 * (size_t)i + k + 1]));
       ms4[k] += t;
     }
-  }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return OKVIS_BA_OK;
 }

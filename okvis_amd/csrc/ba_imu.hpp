@@ -17,7 +17,7 @@
 
 namespace ba {
 
-constexpr int IMU_N = 128;  // max integration steps handled (MAX per factor)
+constexpr int IMU_N = 32;  // integration steps per LDS chunk of the re-preintegration (factor length is unbounded)
 // LDS layout (doubles) of the re-preintegration scratch, SoA over steps
 struct ImuLds {
   static constexpr int DQ = 0;                   // 4N
@@ -43,6 +43,14 @@ struct ImuLds {
   static constexpr int EV = FM + 450;            // 16   error vector
   static constexpr int CA = EV + 16;             // cache copy: see below (300)
   static constexpr int TOTAL = CA + 320;
+};
+// compact LDS layout of the evaluate kernel (no re-preintegration scratch): J | F | e | cache copy
+struct EvalLds {
+  static constexpr int PM = 0;      // 450: J = sqrtInfo * F
+  static constexpr int FM = 450;    // 450: F = [F0 | F1]
+  static constexpr int EV = 900;    // 16
+  static constexpr int CA = 916;    // 320
+  static constexpr int TOTAL = 1236;
 };
 // cache copy offsets inside CA
 enum { CA_DQ = 0, CA_CI = 4, CA_CD = 13, CA_AI = 22, CA_AD = 25, CA_DA = 28, CA_DV = 37, CA_DP = 46, CA_SI = 55 };
@@ -467,10 +475,30 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
   __syncthreads();
 }
 
-__device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int tid) {
+// bias check of ImuError::EvaluateWithMinimalJacobians (ImuError.cpp:541-558): re-preintegrate on first use
+// or when |b_g - b_g,ref| * dt > 1e-4 (rarely taken).
+__device__ void imu_maybe_redo(const WinPtrs& W, int f, int trial, double* lds, int tid) {
   __shared__ int s_redo;
+  const double* b0 = W.sb[trial] + 9 * (size_t)W.imu_sb0[f];
+  double sb0[9];
+  for (int i = 0; i < 9; ++i) sb0[i] = b0[i];
+  const double Dt = ns_to_sec(W.imu_t1[f] - W.imu_t0[f]);
+  const ImuCacheD* cg = W.imu_cache + f;
+  if (tid == 0) {
+    double db[3];
+    for (int i = 0; i < 3; ++i) db[i] = sb0[3 + i] - cg->sb_ref[3 + i];
+    const double nbg = sqrt(db[0] * db[0] + db[1] * db[1] + db[2] * db[2]);
+    s_redo = (!cg->valid) || (nbg * Dt > 0.0001);  // ImuError.cpp:549
+  }
+  __syncthreads();
+  if (s_redo) imu_redo(W, f, sb0, lds, tid);
+}
+
+__device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int tid) {
   __shared__ double s_db[6];
-  double* ca = lds + ImuLds::CA;
+  imu_maybe_redo(W, f, trial, lds, tid);  // rarely taken; updates the HBM cache in place
+  __syncthreads();
+  double* ca = lds + EvalLds::CA;
   const double* p0 = W.pose[trial] + 7 * (size_t)W.imu_pose0[f];
   const double* p1 = W.pose[trial] + 7 * (size_t)W.imu_pose1[f];
   const double* b0 = W.sb[trial] + 9 * (size_t)W.imu_sb0[f];
@@ -479,37 +507,26 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
   for (int i = 0; i < 9; ++i) sb0[i] = b0[i];
   const double Dt = ns_to_sec(W.imu_t1[f] - W.imu_t0[f]);
   const ImuCacheD* cg = W.imu_cache + f;
-  if (tid == 0) {
-    double db[6];
-    for (int i = 0; i < 6; ++i) db[i] = sb0[3 + i] - cg->sb_ref[3 + i];
-    const double nbg = sqrt(db[0] * db[0] + db[1] * db[1] + db[2] * db[2]);
-    const int redo = (!cg->valid) || (nbg * Dt > 0.0001);  // ImuError.cpp:549
-    s_redo = redo;
-    for (int i = 0; i < 6; ++i) s_db[i] = redo ? 0.0 : db[i];
+  // the cache is valid now and, if it was just redone, its reference equals sb0 so that Delta_b is
+  // exactly zero (ImuError.cpp:553)
+  if (tid < 6) s_db[tid] = sb0[3 + tid] - cg->sb_ref[3 + tid];
+  if (tid < 4) ca[CA_DQ + tid] = cg->Delta_q[tid];
+  if (tid < 9) {
+    ca[CA_CI + tid] = cg->C_integral[tid];
+    ca[CA_CD + tid] = cg->C_doubleintegral[tid];
+    ca[CA_DA + tid] = cg->dalpha_db_g[tid];
+    ca[CA_DV + tid] = cg->dv_db_g[tid];
+    ca[CA_DP + tid] = cg->dp_db_g[tid];
   }
+  if (tid < 3) {
+    ca[CA_AI + tid] = cg->acc_integral[tid];
+    ca[CA_AD + tid] = cg->acc_doubleintegral[tid];
+  }
+  if (tid < 225) ca[CA_SI + tid] = cg->sqrt_info[tid];
   __syncthreads();
-  if (s_redo) {
-    imu_redo(W, f, sb0, lds, tid);
-  } else {
-    // load the cache into LDS
-    if (tid < 4) ca[CA_DQ + tid] = cg->Delta_q[tid];
-    if (tid < 9) {
-      ca[CA_CI + tid] = cg->C_integral[tid];
-      ca[CA_CD + tid] = cg->C_doubleintegral[tid];
-      ca[CA_DA + tid] = cg->dalpha_db_g[tid];
-      ca[CA_DV + tid] = cg->dv_db_g[tid];
-      ca[CA_DP + tid] = cg->dp_db_g[tid];
-    }
-    if (tid < 3) {
-      ca[CA_AI + tid] = cg->acc_integral[tid];
-      ca[CA_AD + tid] = cg->acc_doubleintegral[tid];
-    }
-    if (tid < 225) ca[CA_SI + tid] = cg->sqrt_info[tid];
-    __syncthreads();
-  }
   // ---- F = [F0 | F1] and the error vector by one work-item (ImuError.cpp:561-601)
-  double* F = lds + ImuLds::FM;
-  double* ev = lds + ImuLds::EV;
+  double* F = lds + EvalLds::FM;
+  double* ev = lds + EvalLds::EV;
   for (int i = tid; i < 450; i += IMU_THREADS) F[i] = 0.0;
   __syncthreads();
   if (tid == 0) {
@@ -633,7 +650,7 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
   // ---- J = sqrtInfo (upper) * F (kept in LDS), r = sqrtInfo * e, then H = J^T J and g = J^T r
   double* out = W.imu_lin[trial] + (size_t)f * IMU_LIN_STRIDE;
   const double* SI = ca + CA_SI;
-  double* Jl = lds + ImuLds::PM;  // 450 doubles (PM | TM are free after the re-preintegration)
+  double* Jl = lds + EvalLds::PM;
   for (int wi = tid; wi < 450; wi += IMU_THREADS) {
     const int i = wi / 30, j = wi - 30 * i;
     double s = 0;

@@ -25,7 +25,7 @@ namespace ba {
 constexpr int TILE_DIM = SCHUR_TILE_BLOCKS * 6;  // 96
 
 __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __restrict__ wins,
-                                                              const OptD* __restrict__ optp) {
+                                                              const OptD* __restrict__ optp, int tile_rows) {
   const WinPtrs& W = wins[blockIdx.y];
   const int n_tp = W.n_tile * (W.n_tile + 1) / 2;
   const int bx = blockIdx.x;
@@ -33,8 +33,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
   const Ctrl* ctrl = W.ctrl;
   if (ctrl->done) return;
 
-  __shared__ double s_Y[SCHUR_LM_BATCH][TILE_DIM][3];
-  __shared__ double s_W[SCHUR_LM_BATCH][TILE_DIM][3];
+  // dynamic LDS: [SCHUR_LM_BATCH][tile_rows][3] for Y and W, tile_rows = min(96, Dp) of the batch
+  extern __shared__ __attribute__((aligned(16))) double sch_smem[];
   __shared__ double s_vinv[SCHUR_LM_BATCH][6];
   __shared__ double s_b[SCHUR_LM_BATCH][3];
   __shared__ int s_dec[2];
@@ -42,6 +42,9 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
 
   const int tid = threadIdx.x;
   const OptD opt = *optp;
+  const int trows = tile_rows;
+  double* s_Y = sch_smem;
+  double* s_W = sch_smem + (size_t)SCHUR_LM_BATCH * trows * 3;
   // ---- decision (wave 0) ----
   if (tid < 64) {
     int acc = ctrl->acc, term = 0;
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
     const int nb = min(SCHUR_LM_BATCH, lm_end - l0);
     // zero the tables (missing (landmark, block) pairs contribute nothing)
     {
-      double2* zy = reinterpret_cast<double2*>(&s_Y[0][0][0]);
-      double2* zw = reinterpret_cast<double2*>(&s_W[0][0][0]);
-      for (int i = tid; i < SCHUR_LM_BATCH * TILE_DIM * 3 / 2; i += SCHUR_THREADS) {
+      double2* zy = reinterpret_cast<double2*>(s_Y);
+      double2* zw = reinterpret_cast<double2*>(s_W);
+      for (int i = tid; i < SCHUR_LM_BATCH * trows * 3 / 2; i += SCHUR_THREADS) {
         zy[i] = make_double2(0.0, 0.0);
         zw[i] = make_double2(0.0, 0.0);
       }
@@ -148,13 +151,13 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
       const double w0 = Wp[0], w1 = Wp[1], w2 = Wp[2];
       if (slot >= row0 && slot < row0 + nrow) {
         const double* vi = s_vinv[lb];
-        double* y = s_Y[lb][(slot - row0) * 6 + a];
+        double* y = s_Y + ((size_t)lb * trows + (slot - row0) * 6 + a) * 3;
         y[0] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
         y[1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
         y[2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
       }
       if (slot >= col0 && slot < col0 + ncol) {
-        double* w = s_W[lb][(slot - col0) * 6 + a];
+        double* w = s_W + ((size_t)lb * trows + (slot - col0) * 6 + a) * 3;
         w[0] = w0;
         w[1] = w1;
         w[2] = w2;
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
         double y[18], w[18];
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
-          y[i] = (&s_Y[lb][bi * 6][0])[i];
-          w[i] = (&s_W[lb][bj * 6][0])[i];
+          y[i] = s_Y[((size_t)lb * trows + bi * 6) * 3 + i];
+          w[i] = s_W[((size_t)lb * trows + bj * 6) * 3 + i];
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r)
