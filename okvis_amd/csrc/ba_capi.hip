@@ -69,6 +69,7 @@ struct okvis_ba_solver {
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0;
+  int max_Dpad_small = 0, max_Dpad_large = 0;
   std::map<int, hipGraphExec_t> graphs;
   std::map<std::pair<int, int>, hipGraphExec_t> sub_graphs;  // (n, sub) -> graph of that sub-batch's chain
   float last_iterate_ms = 0.f;
@@ -149,7 +150,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       off += 9;
     }
   const int D = off;
-  if (D > MAX_D_LDS || D == 0) return OKVIS_BA_ERR_UNSUPPORTED;
+  if (D > MAX_D || D == 0) return OKVIS_BA_ERR_UNSUPPORTED;
   // ---- validate observations, roles ----
   std::vector<int> role(npose, -1);  // 0 pose role, 1 extrinsics role
   std::vector<int> lm_obs_begin(nlm + 1, 0);
@@ -462,6 +463,10 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(rhs, put_zero(A, 8 * (size_t)D));
     OFF(Dp2, put_zero(A, 8 * (size_t)D));
   }
+  if (D > MAX_D_LDS) {
+    const size_t nbk = (D + 5) / 6;
+    OFF(Sg, put_zero(A, 8 * nbk * (nbk + 1) / 2 * 38));
+  }
   OFF(step, put_zero(A, 8 * (size_t)D));
   OFF(grad, put_zero(A, 8 * (size_t)D));
   OFF(quality, put_zero(A, 8 * (size_t)nlm));
@@ -546,12 +551,13 @@ void relocate(WinPtrs& P, unsigned char* base, bool debug) {
     P.Dp2 = nullptr;
   }
   P.Hpp = nullptr;
+  if (P.D <= MAX_D_LDS) P.Sg = nullptr;
 }
 
 size_t lin_smem(bool ext) { return (ext ? LinCfg<true>::SMEM_DOUBLES : LinCfg<false>::SMEM_DOUBLES) * sizeof(double); }
-size_t solve_smem(int Dpad) {
+size_t solve_smem(int Dpad, bool large = false) {
   const size_t nbk = Dpad / 6;
-  return (nbk * (nbk + 1) / 2 * 38 + 4 * (size_t)Dpad + 2 * nbk * 36) * sizeof(double) + ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15));
+  return ((large ? 0 : nbk * (nbk + 1) / 2 * 38) + 4 * (size_t)Dpad + 2 * nbk * 36) * sizeof(double) + ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15));
 }
 size_t small_smem() { return (size_t)std::max<int>(std::max<int>(ImuLds::TOTAL, EvalLds::TOTAL), 2 * MAX_MARG_DIM) * sizeof(double); }
 
@@ -569,8 +575,12 @@ hipError_t launch_schur(okvis_ba_solver* s, Sub b) {
   return hipGetLastError();
 }
 hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
-  hipLaunchKernelGGL(solve_kernel, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad), b.st, s->d_wins + b.w0,
-                     s->d_opt, final_only);
+  if (s->max_Dpad_small > 0)
+    hipLaunchKernelGGL(solve_kernel<false>, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small), b.st,
+                       s->d_wins + b.w0, s->d_opt, final_only);
+  if (s->max_Dpad_large > 0)
+    hipLaunchKernelGGL(solve_kernel<true>, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), b.st,
+                       s->d_wins + b.w0, s->d_opt, final_only);
   return hipGetLastError();
 }
 hipError_t launch_small(okvis_ba_solver* s, Sub b, int init) {
@@ -641,7 +651,7 @@ int okvis_ba_abi_version(void) { return OKVIS_BA_ABI_VERSION; }
 void okvis_ba_get_limits(okvis_ba_limits* out) {
   if (!out) return;
   out->max_obs_per_lm = GROUP_OBS;
-  out->max_reduced_dim = MAX_D_LDS;
+  out->max_reduced_dim = MAX_D;
   out->max_marg_dim = MAX_MARG_DIM;
   out->max_imu_samples_per_factor = MAX_IMU_SAMPLES;
 }
@@ -705,8 +715,11 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * SCHUR_LM_BATCH * TILE_DIM * 3 * sizeof(double)));
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)solve_smem(((MAX_D_LDS + 5) / 6) * 6));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)solve_smem(((MAX_D + 5) / 6) * 6, true));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)small_smem());
@@ -779,6 +792,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   HIP_TRY(hipMemcpy(s->d_arena, A.host.data(), A.size, hipMemcpyHostToDevice));
   std::vector<WinPtrs> ptrs(n_windows);
   s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = 0;
+  s->max_Dpad_small = s->max_Dpad_large = 0;
   s->any_ext = false;
   for (int i = 0; i < n_windows; ++i) {
     relocate(wins[i].ptrs, s->d_arena, s->opt.debug_arrays != 0);
@@ -790,6 +804,10 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     s->max_lm = std::max(s->max_lm, P.n_lm);
     s->max_Dpad = std::max(s->max_Dpad, ((P.D + 5) / 6) * 6);
     s->max_Dp = std::max(s->max_Dp, P.Dp);
+    if (P.D <= MAX_D_LDS)
+      s->max_Dpad_small = std::max(s->max_Dpad_small, ((P.D + 5) / 6) * 6);
+    else
+      s->max_Dpad_large = std::max(s->max_Dpad_large, ((P.D + 5) / 6) * 6);
     s->any_ext = s->any_ext || P.has_ext;
   }
   HIP_TRY(hipMalloc(&s->d_wins, sizeof(WinPtrs) * n_windows));

@@ -122,10 +122,14 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, do
   return ok;
 }
 
+// LARGE = false: the block matrix lives in LDS (D <= MAX_D_LDS).  LARGE = true: it lives in the window's HBM
+// workspace (L2-resident; same algorithm, one workgroup) — the functional path for BASELINE configs[2].
+template <bool LARGE>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __restrict__ wins,
                                                               const OptD* __restrict__ optp, int final_only) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const WinPtrs& W = wins[blockIdx.x];
+  if (LARGE != (W.Sg != nullptr)) return;  // each window is handled by the instantiation that fits it
   Ctrl* gctrl = W.ctrl;
   if (gctrl->done) return;
   const int tid = threadIdx.x;
@@ -135,8 +139,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   const int nS = nbk * (nbk + 1) / 2 * SBS;
   const SLayout LY{nbk};
 
-  double* S = smem;           // block-packed lower triangle
-  double* s_rhs = S + nS;     // Dpad: rhs, then y = L^-1 rhs in place
+  double* S = LARGE ? W.Sg : smem;            // block-packed lower triangle
+  double* s_rhs = LARGE ? smem : smem + nS;   // Dpad: rhs, then y = L^-1 rhs in place
   double* s_g = s_rhs + Dpad; // gradient (pose / speed-bias part)
   double* s_d2 = s_g + Dpad;  // diag(U) -> clamp -> LM damping diagonal
   double* s_x = s_d2 + Dpad;  // solution

@@ -17,6 +17,7 @@ constexpr int SCHUR_TILE_BLOCKS = 16;  // 16 x 16 blocks of 6x6 = 96 x 96 tile, 
 constexpr int SCHUR_LM_BATCH = 16;     // landmarks staged per LDS pass in the Schur kernel
 constexpr int SOLVE_THREADS = 1024;
 constexpr int MAX_D_LDS = 174;         // reduced systems up to this size are factorised in LDS (block-packed)
+constexpr int MAX_D = 900;             // larger ones (up to this) keep the block matrix in HBM/L2 (slower path)
 constexpr int MAX_IMU_SAMPLES = 1 << 20; // raw samples of one IMU factor (processed in LDS-sized chunks)
 constexpr int IMU_THREADS = 256;
 // IMU factor linearisation record: H = J^T J (30x30 lower, packed a(a+1)/2+b) | g = J^T r (30) | r (15) | cost
@@ -173,7 +174,8 @@ struct WinPtrs {
 
   // ---- Schur / solve ----
   double* spart;          // [n_chunk][spart_stride]: block-packed lower triangle | Y b
-  double* S;              // [D][D]
+  double* S;              // [D][D] debug copy of the damped reduced matrix
+  double* Sg;             // block-packed reduced matrix workspace in HBM when D > MAX_D_LDS, else null
   double* rhs;            // [D]
   double* step;           // [D]
   double* grad;           // [D]

@@ -236,3 +236,42 @@ def test_marginalisation_prior_evaluation(oracle):
         sr = o.optimize(10)
         assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
         b.close()
+
+
+def test_large_reduced_system_uses_hbm_resident_solve(oracle):
+    # D = 300 > 174: the block matrix of the reduced system lives in HBM/L2 (solve_kernel<true>)
+    w = synthetic.make_window(20, 200, 1.0, seed=33, frame_dt=0.1)
+    assert w.reduced_dim() == 300
+    b = _batch([w], debug_arrays=1)
+    o = oracle.OracleWindow(w)
+    o.linearize()
+    b.begin(); b.iterate(1)
+    opt = default_options()
+    assert o.solve(opt.initial_radius, opt) == 0
+    _close(b.array("REDUCED_S"), o.array("REDUCED_S"), 1e-12)
+    _close(b.array("STEP"), o.array("STEP"), 1e-7)
+    for n in (3, 12):
+        sg = _batch([w]).optimize(n)[0]
+        sr = oracle.OracleWindow(w).optimize(n)
+        assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"], (n, sg, sr)
+        assert sg["iterations"] == sr["iterations"] and sg["successful_steps"] == sr["successful_steps"]
+    b.close()
+
+
+def test_config_C_full_size(oracle):
+    # BASELINE configs[2]: 50 keyframes / 2000 landmarks / 200 000 observations, D = 750
+    w = synthetic.config_C()
+    assert w.n_obs == 200000 and w.reduced_dim() == 750
+    b = _batch([w])
+    sg = b.optimize(4)[0]
+    sr = oracle.OracleWindow(w).optimize(4)
+    assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-8 * sr["final_cost"], (sg, sr)
+    assert sg["successful_steps"] == sr["successful_steps"]
+    # mixed batch: a small and a large window side by side (both solve instantiations in one launch pair)
+    ws = [synthetic.small_window(seed=34), synthetic.make_window(20, 100, 1.0, seed=35, frame_dt=0.1)]
+    bb = _batch(ws)
+    s2 = bb.optimize(6)
+    for i, wi in enumerate(ws):
+        r = oracle.OracleWindow(wi).optimize(6)
+        assert abs(s2[i]["final_cost"] - r["final_cost"]) <= 1e-9 * r["final_cost"]
+    b.close(); bb.close()
