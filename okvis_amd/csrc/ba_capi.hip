@@ -291,29 +291,30 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     }
   }
   const int nchunk = (int)chunks.size();
-  // ---- assembly targets: per reduced 6x6 block, the list of per-group partials that sum into it ----
-  std::vector<AsmTarget> asm_targets;
-  std::vector<int> asm_list;
-  {
-    std::map<std::pair<int, int>, std::vector<int>> by_target;  // (off_a, off_b or -1) -> task outs (group order)
-    std::map<std::pair<int, int>, int> ttype;
-    for (const Task& T : tasks) {
-      const std::pair<int, int> key(T.off_a, T.type == 2 ? T.off_b : -1);
-      by_target[key].push_back(T.out);
-      ttype[key] = T.type == 2 ? 2 : 0;
-    }
-    for (auto& kv : by_target) {
-      AsmTarget A;
-      A.type = ttype[kv.first];
-      A.off_a = kv.first.first;
-      A.off_b = kv.first.second;
-      A.list_begin = (int)asm_list.size();
-      asm_list.insert(asm_list.end(), kv.second.begin(), kv.second.end());
-      A.list_end = (int)asm_list.size();
-      A.pad = 0;
-      asm_targets.push_back(A);
+  // ---- per-chunk lists: which per-group partials sum into which pose block / cross block ----
+  const int npose_blk_c = Dp / 6;
+  std::vector<int> chunk_diag_begin((size_t)nchunk * npose_blk_c + 1, 0), chunk_diag_out, chunk_cross_begin(nchunk + 1, 0), chunk_cross;
+  for (int c = 0; c < nchunk; ++c) {
+    std::vector<std::vector<int>> per_blk(npose_blk_c);
+    chunk_cross_begin[c] = (int)chunk_cross.size() / 3;
+    for (int g = chunks[c].group_begin; g < chunks[c].group_end; ++g)
+      for (int t = groups[g].task_begin; t < groups[g].task_end; ++t) {
+        const Task& T = tasks[t];
+        if (T.type < 2) {
+          per_blk[T.off_a / 6].push_back(T.out);
+        } else {
+          chunk_cross.push_back(T.off_a);
+          chunk_cross.push_back(T.off_b);
+          chunk_cross.push_back(T.out);
+        }
+      }
+    for (int bkk = 0; bkk < npose_blk_c; ++bkk) {
+      chunk_diag_begin[(size_t)c * npose_blk_c + bkk] = (int)chunk_diag_out.size();
+      chunk_diag_out.insert(chunk_diag_out.end(), per_blk[bkk].begin(), per_blk[bkk].end());
     }
   }
+  chunk_diag_begin[(size_t)nchunk * npose_blk_c] = (int)chunk_diag_out.size();
+  chunk_cross_begin[nchunk] = (int)chunk_cross.size() / 3;
   // ---- greedy colouring of the IMU factors: factors of one colour share no parameter block ----
   std::vector<int> imu_color(w.n_imu, 0);
   int n_imu_color = 0;
@@ -347,7 +348,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       for (int k = 0; k < dims[b]; ++k) imu_coloff[30 * (size_t)f + start[b] + k] = offs[b] < 0 ? -1 : offs[b] + k;
   }
   const int npose_blk = Dp / 6;
-  const int spart_stride = npose_blk * (npose_blk + 1) / 2 * 36 + Dp;
+  const int spart_stride = npose_blk * (npose_blk + 1) / 2 * 36 + 3 * Dp;
   const int ntile = std::max(1, (Dp / 6 + SCHUR_TILE_BLOCKS - 1) / SCHUR_TILE_BLOCKS);
   // ---- observation records ----
   std::vector<ObsRec> recs(nobs);
@@ -403,7 +404,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.has_ext = has_ext ? 1 : 0;
   P.gpart_size = gpart_size;
   P.n_tile = ntile;
-  P.n_asm = (int)asm_targets.size();
+  P.n_asm = 0;
   P.n_imu_color = n_imu_color;
   P.spart_stride = spart_stride;
   P.cauchy_b = w.cauchy_b;
@@ -436,8 +437,10 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(tasks, put(A, tasks));
   OFF(task_list, put(A, task_list));
   OFF(chunks, put(A, chunks));
-  OFF(asm_targets, put(A, asm_targets));
-  OFF(asm_list, put(A, asm_list));
+  OFF(chunk_diag_begin, put(A, chunk_diag_begin));
+  OFF(chunk_diag_out, put(A, chunk_diag_out));
+  OFF(chunk_cross_begin, put(A, chunk_cross_begin));
+  OFF(chunk_cross, put(A, chunk_cross));
   OFF(imu_order, put(A, imu_order));
   OFF(imu_color_begin, put(A, imu_color_begin));
   OFF(imu_coloff, put(A, imu_coloff));

@@ -194,17 +194,53 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
 #pragma unroll
     for (int i = 0; i < 6; ++i) accR[i] += __shfl_xor(accR[i], o, 64);
   }
-  // ---- write the partial in the solve kernel's block-packed layout ----
+  // ---- write the partial (pose part, row-major block-packed lower triangle | Y b | g | diag U) ----
   if (active && slice == 0) {
     const int gbi = row0 + bi, gbj = col0 + bj;  // gbi >= gbj
+    double accG[6] = {0, 0, 0, 0, 0, 0}, accD[6] = {0, 0, 0, 0, 0, 0};
+    const double* gp = W.gpart[acc];
+    if (gbi == gbj) {
+      // U_pp and g_p of this chunk's groups for pose block gbi (host-built list, fixed order)
+      const int lb = W.chunk_diag_begin[chunk * nblk + gbi], le = W.chunk_diag_begin[chunk * nblk + gbi + 1];
+      for (int k = lb; k < le; ++k) {
+        const double* o = gp + W.chunk_diag_out[k];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+          for (int c = 0; c <= r; ++c) accS[6 * r + c] += o[c * 6 - (c * (c - 1)) / 2 + (r - c)];
+          accG[r] += o[21 + r];
+          accD[r] += o[r * 6 - (r * (r - 1)) / 2];
+        }
+      }
+    } else {
+      // pose x extrinsics cross blocks J_pose^T J_ext
+      for (int k = W.chunk_cross_begin[chunk]; k < W.chunk_cross_begin[chunk + 1]; ++k) {
+        const int oa = W.chunk_cross[3 * k], ob = W.chunk_cross[3 * k + 1];
+        const double* o = gp + W.chunk_cross[3 * k + 2];
+        if (oa == gbi * 6 && ob == gbj * 6) {
+#pragma unroll
+          for (int i = 0; i < 36; ++i) accS[i] += o[i];
+        } else if (ob == gbi * 6 && oa == gbj * 6) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) accS[6 * r + c] += o[6 * c + r];
+        }
+      }
+    }
     double* sp = W.spart + (size_t)chunk * W.spart_stride;
     double* blk = sp + (size_t)(gbi * (gbi + 1) / 2 + gbj) * 36;
 #pragma unroll
     for (int i = 0; i < 36; ++i) blk[i] = accS[i];
     if (do_rhs) {
       double* sr = sp + (size_t)(nblk * (nblk + 1) / 2) * 36;
+      const int Dp = nblk * 6;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) sr[gbi * 6 + r] = accR[r];
+      for (int r = 0; r < 6; ++r) {
+        sr[gbi * 6 + r] = accR[r];
+        sr[Dp + gbi * 6 + r] = accG[r];
+        sr[2 * Dp + gbi * 6 + r] = accD[r];
+      }
     }
   }
 }

@@ -69,23 +69,22 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return y;
 }
 __device__ __forceinline__ bool chol6(double (&L)[6][6], double (&inv)[6]) {
+  // right-looking: after each pivot the remaining lower triangle is updated at once (independent FMAs),
+  // so the chain per pivot is rsqrt -> scale -> update, not a k-long dependent sum
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    double d = L[k][k];
-#pragma unroll
-    for (int m = 0; m < k; ++m) d -= L[k][m] * L[k][m];
+    const double d = L[k][k];
     ok = ok && (d > 0.0);
     const double dd = d > 0.0 ? d : 1.0;
     inv[k] = rsqrt_nr(dd);
     L[k][k] = dd * inv[k];
 #pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      double v = L[i][k];
+    for (int i = k + 1; i < 6; ++i) L[i][k] *= inv[k];
 #pragma unroll
-      for (int m = 0; m < k; ++m) v -= L[i][m] * L[k][m];
-      L[i][k] = v * inv[k];
-    }
+    for (int i = k + 1; i < 6; ++i)
+#pragma unroll
+      for (int j = k + 1; j <= i; ++j) L[i][j] -= L[i][k] * L[j][k];
   }
   return ok;
 }
@@ -120,6 +119,137 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, do
     inv_out[i] = inv[i];
   }
   return ok;
+}
+
+// IMU Hessian blocks, priors and the marginalisation prior of linearisation buffer `acc`, accumulated into S
+// (block layout LY), g and d2.  (The reprojection part U_pp / U_pe / g_p arrives inside the Schur partials.)
+__device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, double* S, double* g, double* d2,
+                              int* coloff, const unsigned short* ptab, int tid, int nthreads) {
+  // ---- IMU factors: precomputed H (30x30 lower) | g (30); factors of one colour touch disjoint blocks ----
+  for (int col = 0; col < W.n_imu_color; ++col) {
+    const int fb = W.imu_color_begin[col], fe = W.imu_color_begin[col + 1];
+    for (int wi = tid; wi < (fe - fb) * 512; wi += nthreads) {
+      const int f = W.imu_order[fb + (wi >> 9)], e = wi & 511;
+      if (e >= 495) continue;
+      const double* L = W.imu_lin[acc] + (size_t)f * IMU_LIN_STRIDE;
+      const int* co = W.imu_coloff + 30 * f;
+      const double v = L[e];
+      if (e < 465) {
+        const int a = ptab[e] >> 8, b = ptab[e] & 255;   // same lower-triangular enumeration
+        const int ra = co[a], rb = co[b];
+        if (ra < 0 || rb < 0) continue;
+        if (ra >= rb) S[LY.at(ra, rb)] += v; else S[LY.at(rb, ra)] += v;
+        if (a == b) d2[ra] += v;
+      } else {
+        const int ra = co[e - 465];
+        if (ra >= 0) g[ra] += v;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- pose priors: J 6x6 | r 6 ----
+  for (int f = 0; f < W.n_pprior; ++f) {
+    if (tid < 6) {
+      const int off = W.pose_off[W.pprior_pose[f]];
+      coloff[tid] = off < 0 ? -1 : off + tid;
+    }
+    __syncthreads();
+    const double* L = W.pp_lin[acc] + (size_t)f * 42;
+    add_small_factor(S, LY, g, d2, L, L + 36, 6, 6, coloff, tid, nthreads);
+    __syncthreads();
+  }
+  // ---- speed/bias priors: J = -sqrtInfo (9x9 const) | r 9 ----
+  for (int f = 0; f < W.n_sbprior; ++f) {
+    if (tid < 9) {
+      const int off = W.sb_off[W.sbprior_sb[f]];
+      coloff[tid] = off < 0 ? -1 : off + tid;
+    }
+    __syncthreads();
+    // J^T J and J^T r are sign-invariant / sign-flipped: use +sqrtInfo with -r
+    const double* Jc = W.sbprior_sqrtinfo + (size_t)f * 81;
+    const double* r = W.sbp_lin[acc] + (size_t)f * 9;
+    for (int wi = tid; wi < 81; wi += nthreads) {
+      const int a = wi / 9, b = wi - 9 * a;
+      const int ra = coloff[a], rb = coloff[b];
+      if (ra < 0 || rb < 0 || ra < rb) continue;
+      double s = 0;
+      for (int k = 0; k < 9; ++k) s += Jc[k * 9 + a] * Jc[k * 9 + b];
+      S[LY.at(ra, rb)] += s;
+      if (a == b) d2[ra] += s;
+    }
+    if (tid < 9 && coloff[tid] >= 0) {
+      double s = 0;
+      for (int k = 0; k < 9; ++k) s -= Jc[k * 9 + tid] * r[k];
+      g[coloff[tid]] += s;
+    }
+    __syncthreads();
+  }
+  // ---- relative pose factors: [J0 6x6 | J1 6x6 | r 6] stored as J 6x12 row-major | r ----
+  for (int f = 0; f < W.n_rel; ++f) {
+    if (tid < 12) {
+      const int off = W.pose_off[tid < 6 ? W.rel_pose0[f] : W.rel_pose1[f]];
+      coloff[tid] = off < 0 ? -1 : off + (tid % 6);
+    }
+    __syncthreads();
+    const double* L = W.rel_lin[acc] + (size_t)f * 78;
+    add_small_factor(S, LY, g, d2, L, L + 72, 6, 12, coloff, tid, nthreads);
+    __syncthreads();
+  }
+  // ---- marginalisation prior: H = B^T (J^T J) B, g = B^T J^T e ----
+  if (W.marg_dim > 0) {
+    const int Dm = W.marg_dim, nb = W.marg_nb;
+    const double* M = W.marg_lin_M[acc];
+    const double* JTe = W.marg_lin_e[acc] + Dm;  // [e | J^T e]
+    for (int wi = tid; wi < Dm * Dm; wi += nthreads) {
+      const int rr = wi / Dm, cc = wi - rr * Dm;
+      int bi = 0, bj = 0;
+      for (int b = 0; b < nb; ++b) {
+        if (W.marg_block_off[b] <= rr) bi = b;
+        if (W.marg_block_off[b] <= cc) bj = b;
+      }
+      const int oi = W.marg_block_off[bi], oj = W.marg_block_off[bj];
+      const int li = rr - oi, lj = cc - oj;
+      const int Ri = W.marg_block_type[bi] == 0 ? W.pose_off[W.marg_block_idx[bi]] : W.sb_off[W.marg_block_idx[bi]];
+      const int Rj = W.marg_block_type[bj] == 0 ? W.pose_off[W.marg_block_idx[bj]] : W.sb_off[W.marg_block_idx[bj]];
+      if (Ri < 0 || Rj < 0 || Ri + li < Rj + lj) continue;
+      const bool roti = (W.marg_block_type[bi] == 0) && li >= 3;
+      const bool rotj = (W.marg_block_type[bj] == 0) && lj >= 3;
+      double s = 0;
+      if (!roti && !rotj) {
+        s = W.marg_H0[(size_t)rr * Dm + cc];
+      } else {
+        for (int a = 0; a < (roti ? 3 : 1); ++a) {
+          const int r2 = roti ? oi + 3 + a : rr;
+          const double wa = roti ? M[9 * bi + 3 * a + (li - 3)] : 1.0;
+          for (int b = 0; b < (rotj ? 3 : 1); ++b) {
+            const int c2 = rotj ? oj + 3 + b : cc;
+            const double wb = rotj ? M[9 * bj + 3 * b + (lj - 3)] : 1.0;
+            s += wa * W.marg_H0[(size_t)r2 * Dm + c2] * wb;
+          }
+        }
+      }
+      S[LY.at(Ri + li, Rj + lj)] += s;
+      if (Ri + li == Rj + lj) d2[Ri + li] += s;
+    }
+    for (int rr = tid; rr < Dm; rr += nthreads) {
+      int bi = 0;
+      for (int b = 0; b < nb; ++b)
+        if (W.marg_block_off[b] <= rr) bi = b;
+      const int oi = W.marg_block_off[bi], li = rr - oi;
+      const int Ri = W.marg_block_type[bi] == 0 ? W.pose_off[W.marg_block_idx[bi]] : W.sb_off[W.marg_block_idx[bi]];
+      if (Ri < 0) continue;
+      double s;
+      if (W.marg_block_type[bi] == 0 && li >= 3) {
+        s = 0;
+        for (int a = 0; a < 3; ++a) s += M[9 * bi + 3 * a + (li - 3)] * JTe[oi + 3 + a];
+      } else {
+        s = JTe[rr];
+      }
+      g[Ri + li] += s;
+    }
+    __syncthreads();
+  }
+
 }
 
 // LARGE = false: the block matrix lives in LDS (D <= MAX_D_LDS).  LARGE = true: it lives in the window's HBM
@@ -236,197 +366,27 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       const int q = i / 36, e = i - 36 * q;
       S[LY.blk(s_ptab[q] >> 8, s_ptab[q] & 255) + e] = s;
     }
-    for (int i = tid; i < Dpad; i += SOLVE_THREADS) {
-      double yb = 0;
-      if (i < Dp) {
+    for (int i = tid; i < 3 * Dpad; i += SOLVE_THREADS) {
+      // vectors of the pose part: Y b -> rhs, g, diag U
+      const int which = i / Dpad, j = i - which * Dpad;
+      double a = 0;
+      if (j < Dp) {
         for (int ch = 0; ch < nch; ch += 8) {
           double v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride + nP + i] : 0.0;
+          for (int u = 0; u < 8; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride + nP + which * Dp + j] : 0.0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) yb += v[u];
+          for (int u = 0; u < 8; ++u) a += v[u];
         }
       }
-      s_rhs[i] = yb;
-      s_g[i] = 0.0;
-      s_d2[i] = 0.0;
-      s_x[i] = 0.0;
+      (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = a;
     }
+    for (int i = tid; i < Dpad; i += SOLVE_THREADS) s_x[i] = 0.0;
   }
   __syncthreads();
   STAMP(2);
-  // ---- per-group U_pp / U_pe / g_p partials of the linearise kernel (host-built lists, fixed order) ----
-  {
-    const double* gp = W.gpart[acc];
-    const int* alist = W.asm_list;
-    auto list_sum = [&](int lb, int le, int eo) -> double {
-      double s = 0;
-      for (int k = lb; k < le; k += 8) {
-        int o[8];
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) o[u] = (k + u < le) ? alist[k + u] : -1;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (o[u] >= 0) ? gp[o[u] + eo] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-      }
-      return s;
-    };
-    for (int wi = tid; wi < W.n_asm * 42; wi += SOLVE_THREADS) {
-      const int t = wi / 42, e = wi - 42 * t;
-      const AsmTarget T = W.asm_targets[t];
-      if (T.type == 0) {
-        if (e < 36) {
-          const int r = e / 6, cidx = e - 6 * r;
-          if (r < cidx) continue;
-          const int u = cidx * 6 - (cidx * (cidx - 1)) / 2 + (r - cidx);  // upper-tri index of (cidx, r)
-          const double s = list_sum(T.list_begin, T.list_end, u);
-          S[LY.blk(T.off_a / 6, T.off_a / 6) + e] += s;
-          if (r == cidx) s_d2[T.off_a + r] += s;
-        } else {
-          const int r = e - 36;
-          s_g[T.off_a + r] += list_sum(T.list_begin, T.list_end, 21 + r);
-        }
-      } else if (e < 36) {
-        // X = J_pose^T J_ext (rows: pose, cols: ext); the extrinsics block has the larger offset
-        const int r = e / 6, cidx = e - 6 * r;
-        const double s = list_sum(T.list_begin, T.list_end, e);
-        if (T.off_b > T.off_a)
-          S[LY.blk(T.off_b / 6, T.off_a / 6) + cidx * 6 + r] += s;
-        else
-          S[LY.blk(T.off_a / 6, T.off_b / 6) + e] += s;
-      }
-    }
-  }
+  assemble_base(W, acc, LY, S, s_g, s_d2, s_coloff, s_ptab, tid, SOLVE_THREADS);
   __syncthreads();
-  STAMP(3);
-  // ---- IMU factors: precomputed H (30x30 lower) | g (30); factors of one colour touch disjoint blocks ----
-  for (int col = 0; col < W.n_imu_color; ++col) {
-    const int fb = W.imu_color_begin[col], fe = W.imu_color_begin[col + 1];
-    for (int wi = tid; wi < (fe - fb) * 512; wi += SOLVE_THREADS) {
-      const int f = W.imu_order[fb + (wi >> 9)], e = wi & 511;
-      if (e >= 495) continue;
-      const double* L = W.imu_lin[acc] + (size_t)f * IMU_LIN_STRIDE;
-      const int* co = W.imu_coloff + 30 * f;
-      const double v = L[e];
-      if (e < 465) {
-        const int a = s_ptab[e] >> 8, b = s_ptab[e] & 255;   // same lower-triangular enumeration
-        const int ra = co[a], rb = co[b];
-        if (ra < 0 || rb < 0) continue;
-        if (ra >= rb) S[LY.at(ra, rb)] += v; else S[LY.at(rb, ra)] += v;
-        if (a == b) s_d2[ra] += v;
-      } else {
-        const int ra = co[e - 465];
-        if (ra >= 0) s_g[ra] += v;
-      }
-    }
-    __syncthreads();
-  }
-  STAMP(4);
-  // ---- pose priors: J 6x6 | r 6 ----
-  for (int f = 0; f < W.n_pprior; ++f) {
-    if (tid < 6) {
-      const int off = W.pose_off[W.pprior_pose[f]];
-      s_coloff[tid] = off < 0 ? -1 : off + tid;
-    }
-    __syncthreads();
-    const double* L = W.pp_lin[acc] + (size_t)f * 42;
-    add_small_factor(S, LY, s_g, s_d2, L, L + 36, 6, 6, s_coloff, tid, SOLVE_THREADS);
-    __syncthreads();
-  }
-  // ---- speed/bias priors: J = -sqrtInfo (9x9 const) | r 9 ----
-  for (int f = 0; f < W.n_sbprior; ++f) {
-    if (tid < 9) {
-      const int off = W.sb_off[W.sbprior_sb[f]];
-      s_coloff[tid] = off < 0 ? -1 : off + tid;
-    }
-    __syncthreads();
-    // J^T J and J^T r are sign-invariant / sign-flipped: use +sqrtInfo with -r
-    const double* Jc = W.sbprior_sqrtinfo + (size_t)f * 81;
-    const double* r = W.sbp_lin[acc] + (size_t)f * 9;
-    for (int wi = tid; wi < 81; wi += SOLVE_THREADS) {
-      const int a = wi / 9, b = wi - 9 * a;
-      const int ra = s_coloff[a], rb = s_coloff[b];
-      if (ra < 0 || rb < 0 || ra < rb) continue;
-      double s = 0;
-      for (int k = 0; k < 9; ++k) s += Jc[k * 9 + a] * Jc[k * 9 + b];
-      S[LY.at(ra, rb)] += s;
-      if (a == b) s_d2[ra] += s;
-    }
-    if (tid < 9 && s_coloff[tid] >= 0) {
-      double s = 0;
-      for (int k = 0; k < 9; ++k) s -= Jc[k * 9 + tid] * r[k];
-      s_g[s_coloff[tid]] += s;
-    }
-    __syncthreads();
-  }
-  // ---- relative pose factors: [J0 6x6 | J1 6x6 | r 6] stored as J 6x12 row-major | r ----
-  for (int f = 0; f < W.n_rel; ++f) {
-    if (tid < 12) {
-      const int off = W.pose_off[tid < 6 ? W.rel_pose0[f] : W.rel_pose1[f]];
-      s_coloff[tid] = off < 0 ? -1 : off + (tid % 6);
-    }
-    __syncthreads();
-    const double* L = W.rel_lin[acc] + (size_t)f * 78;
-    add_small_factor(S, LY, s_g, s_d2, L, L + 72, 6, 12, s_coloff, tid, SOLVE_THREADS);
-    __syncthreads();
-  }
-  // ---- marginalisation prior: H = B^T (J^T J) B, g = B^T J^T e ----
-  if (W.marg_dim > 0) {
-    const int Dm = W.marg_dim, nb = W.marg_nb;
-    const double* M = W.marg_lin_M[acc];
-    const double* JTe = W.marg_lin_e[acc] + Dm;  // [e | J^T e]
-    for (int wi = tid; wi < Dm * Dm; wi += SOLVE_THREADS) {
-      const int rr = wi / Dm, cc = wi - rr * Dm;
-      int bi = 0, bj = 0;
-      for (int b = 0; b < nb; ++b) {
-        if (W.marg_block_off[b] <= rr) bi = b;
-        if (W.marg_block_off[b] <= cc) bj = b;
-      }
-      const int oi = W.marg_block_off[bi], oj = W.marg_block_off[bj];
-      const int li = rr - oi, lj = cc - oj;
-      const int Ri = W.marg_block_type[bi] == 0 ? W.pose_off[W.marg_block_idx[bi]] : W.sb_off[W.marg_block_idx[bi]];
-      const int Rj = W.marg_block_type[bj] == 0 ? W.pose_off[W.marg_block_idx[bj]] : W.sb_off[W.marg_block_idx[bj]];
-      if (Ri < 0 || Rj < 0 || Ri + li < Rj + lj) continue;
-      const bool roti = (W.marg_block_type[bi] == 0) && li >= 3;
-      const bool rotj = (W.marg_block_type[bj] == 0) && lj >= 3;
-      double s = 0;
-      if (!roti && !rotj) {
-        s = W.marg_H0[(size_t)rr * Dm + cc];
-      } else {
-        for (int a = 0; a < (roti ? 3 : 1); ++a) {
-          const int r2 = roti ? oi + 3 + a : rr;
-          const double wa = roti ? M[9 * bi + 3 * a + (li - 3)] : 1.0;
-          for (int b = 0; b < (rotj ? 3 : 1); ++b) {
-            const int c2 = rotj ? oj + 3 + b : cc;
-            const double wb = rotj ? M[9 * bj + 3 * b + (lj - 3)] : 1.0;
-            s += wa * W.marg_H0[(size_t)r2 * Dm + c2] * wb;
-          }
-        }
-      }
-      S[LY.at(Ri + li, Rj + lj)] += s;
-      if (Ri + li == Rj + lj) s_d2[Ri + li] += s;
-    }
-    for (int rr = tid; rr < Dm; rr += SOLVE_THREADS) {
-      int bi = 0;
-      for (int b = 0; b < nb; ++b)
-        if (W.marg_block_off[b] <= rr) bi = b;
-      const int oi = W.marg_block_off[bi], li = rr - oi;
-      const int Ri = W.marg_block_type[bi] == 0 ? W.pose_off[W.marg_block_idx[bi]] : W.sb_off[W.marg_block_idx[bi]];
-      if (Ri < 0) continue;
-      double s;
-      if (W.marg_block_type[bi] == 0 && li >= 3) {
-        s = 0;
-        for (int a = 0; a < 3; ++a) s += M[9 * bi + 3 * a + (li - 3)] * JTe[oi + 3 + a];
-      } else {
-        s = JTe[rr];
-      }
-      s_g[Ri + li] += s;
-    }
-    __syncthreads();
-  }
-
   STAMP(5);
   // ------------------------------------------------------------------ 3. convergence of the accepted step
   {
@@ -490,6 +450,26 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   if (tid == 0) {
     if (!factor_diag(S + LY.blk(0, 0), s_diag, s_dinv)) s_fail = 1;
   }
+  // LDS path: every lane owns (at most) two fixed 3x3 sub-tiles of the trailing matrix for the whole
+  // factorisation (the mirrored enumeration does not depend on kb): coordinates and the C address are
+  // computed once; an item is active while its block column is right of the current one.
+  // wave 14 is the look-ahead wave (next diagonal block: update + factor, starts at once), wave 15 handles
+  // the right-hand-side blocks, waves 0-13 the bulk of the trailing update
+  constexpr int TU_THREADS = SOLVE_THREADS - 128;
+  int it_gbi[2] = {0, 0}, it_gbj[2] = {-1, -1}, it_sr[2] = {0, 0}, it_sc[2] = {0, 0}, it_c[2] = {0, 0};
+  if (!LARGE && tid < TU_THREADS) {
+    for (int u = 0; u < 2; ++u) {
+      const int wi = tid + u * TU_THREADS;
+      const int q = wi >> 2, sub = wi & 3;
+      if (q < (nbk - 1) * nbk / 2) {
+        it_gbj[u] = nbk - 1 - (s_ptab[q] >> 8);
+        it_gbi[u] = nbk - 1 - (s_ptab[q] & 255);
+        it_sr[u] = (sub >> 1) * 3;
+        it_sc[u] = (sub & 1) * 3;
+        it_c[u] = LY.blk(it_gbi[u], it_gbj[u]) + 6 * it_sr[u] + it_sc[u];
+      }
+    }
+  }
   __syncthreads();
   for (int kb = 0; kb < nbk; ++kb) {
     const int k0 = kb * 6;
@@ -520,12 +500,100 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     //     along; the owner of the next diagonal block factors it right away (look-ahead)
     const int nt = nbk - kb - 1;
     const int nblkpairs = nt * (nt + 1) / 2;
-    // four work-items per 6x6 block (3x3 register sub-tiles): many light waves hide the LDS / FMA latency
+    if (!LARGE) {
+      const int colk = LY.blk(kb, kb);  // start of block column kb (its diagonal block)
+      if (tid < TU_THREADS) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int gbi = it_gbi[u], gbj = it_gbj[u];
+          if (gbj <= kb) continue;  // not (or no longer) part of the trailing matrix
+          if (gbi == kb + 1) continue;  // block (kb+1, kb+1): the look-ahead wave (gbj > kb and gbj <= gbi)
+          const double* Li = S + colk + (gbi - kb) * SBS + 6 * it_sr[u];  // rows sr..sr+2 of L_(gbi,k)
+          const double* Lj = S + colk + (gbj - kb) * SBS + 6 * it_sc[u];  // rows sc..sc+2 of L_(gbj,k)
+          double* Cb = S + it_c[u];
+          double li[18], lj[18], cc[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            const double2 a = reinterpret_cast<const double2*>(Li)[i], b = reinterpret_cast<const double2*>(Lj)[i];
+            li[2 * i] = a.x; li[2 * i + 1] = a.y;
+            lj[2 * i] = b.x; lj[2 * i + 1] = b.y;
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cix = 0; cix < 3; ++cix) cc[3 * r + cix] = Cb[6 * r + cix];
+          const bool skip = (gbi == gbj && it_sr[u] == 0 && it_sc[u] == 3);  // upper-right of a diagonal block
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cix = 0; cix < 3; ++cix) {
+              double s0 = 0;
+#pragma unroll
+              for (int m = 0; m < 6; ++m) s0 += li[6 * r + m] * lj[6 * cix + m];
+              if (!skip) Cb[6 * r + cix] = cc[3 * r + cix] - s0;
+            }
+        }
+      } else if (tid < TU_THREADS + 64) {
+        // look-ahead wave: lanes 0-3 update the four 3x3 sub-tiles of block (kb+1, kb+1), lane 0 factors it
+        const int lane = tid - TU_THREADS;
+        if (lane < 4 && nt > 0) {
+          const int sr = (lane >> 1) * 3, sc = (lane & 1) * 3;
+          const double* Li = S + colk + SBS + 6 * sr;
+          const double* Lj = S + colk + SBS + 6 * sc;
+          double* Cb = S + LY.blk(kb + 1, kb + 1) + 6 * sr + sc;
+          double li[18], lj[18], cc[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            const double2 a = reinterpret_cast<const double2*>(Li)[i], b = reinterpret_cast<const double2*>(Lj)[i];
+            li[2 * i] = a.x; li[2 * i + 1] = a.y;
+            lj[2 * i] = b.x; lj[2 * i + 1] = b.y;
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cix = 0; cix < 3; ++cix) cc[3 * r + cix] = Cb[6 * r + cix];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cix = 0; cix < 3; ++cix) {
+              double s0 = 0;
+#pragma unroll
+              for (int m = 0; m < 6; ++m) s0 += li[6 * r + m] * lj[6 * cix + m];
+              if (lane != 1) Cb[6 * r + cix] = cc[3 * r + cix] - s0;   // the upper-right 3x3 is never read
+            }
+          // same wave => LDS operations are ordered; fence the compiler
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          asm volatile("" ::: "memory");
+          if (lane == 0) {
+            if (!factor_diag(S + LY.blk(kb + 1, kb + 1), s_diag + 36 * (kb + 1), s_dinv + 6 * (kb + 1))) s_fail = 1;
+            if (kb == 12 && blockIdx.x == 0) W.prof[32] = (double)clock64();
+          }
+        }
+      } else {
+        // last wave: right-hand-side blocks rhs_(bi) -= L_(bi,k) y_k
+        for (int bi = tid - TU_THREADS - 64; bi < nt; bi += 64) {
+          const double* Li = S + colk + (bi + 1) * SBS;
+          double* rr = s_rhs + (kb + 1 + bi) * 6;
+          double y[6];
+#pragma unroll
+          for (int m = 0; m < 6; ++m) y[m] = s_rhs[k0 + m];
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            double s0 = 0;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) s0 += Li[6 * r + m] * y[m];
+            rr[r] -= s0;
+          }
+        }
+        if (kb == 12 && blockIdx.x == 0 && tid == TU_THREADS + 64) W.prof[33] = (double)clock64();
+      }
+    } else {
+    // four work-items per 6x6 block (3x3 register sub-tiles): many light waves hide the latency
     for (int wi = tid; wi < 4 * nblkpairs + nt; wi += SOLVE_THREADS) {
       if (wi < 4 * nblkpairs) {
         const int q = wi >> 2, sub = wi & 3;
         const int sr = (sub >> 1) * 3, sc = (sub & 1) * 3;
-        // mirrored enumeration: consecutive blocks walk DOWN one block column (contiguous in LDS)
+        // mirrored enumeration: consecutive blocks walk DOWN one block column (contiguous in memory)
         const int gbj = nbk - 1 - (s_ptab[q] >> 8), gbi = nbk - 1 - (s_ptab[q] & 255);  // gbi >= gbj > kb
         const double* Li = S + LY.blk(gbi, kb) + 6 * sr;   // rows sr..sr+2 of L_(gbi,k)
         const double* Lj = S + LY.blk(gbj, kb) + 6 * sc;   // rows sc..sc+2 of L_(gbj,k)
@@ -548,13 +616,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
               Cb[6 * r + cix] -= s0;
             }
         }
-        if (gbi == kb + 1 && sub == 0) {
-          // block (kb+1, kb+1) is final once the four lanes of this quad have stored: factor it for the
-          // next panel phase (look-ahead).  Same wave => LDS operations are ordered; fence the compiler.
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          asm volatile("" ::: "memory");
-          if (!factor_diag(S + LY.blk(kb + 1, kb + 1), s_diag + 36 * (kb + 1), s_dinv + 6 * (kb + 1))) s_fail = 1;
-        }
       } else {
         // right-hand-side block: rhs_(bi) -= L_(bi,k) y_k
         const int bi = wi - 4 * nblkpairs;
@@ -571,6 +632,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           rr[r] -= s;
         }
       }
+    }
+    // the HBM-resident variant has no quad-local ordering guarantee through L2: factor the next diagonal
+    // block after a barrier
+    __syncthreads();
+    if (tid == 0 && kb + 1 < nbk) {
+      if (!factor_diag(S + LY.blk(kb + 1, kb + 1), s_diag + 36 * (kb + 1), s_dinv + 6 * (kb + 1))) s_fail = 1;
+    }
     }
     if (kb == 0) STAMP(26);
     __syncthreads();

@@ -124,7 +124,7 @@ struct WinPtrs {
   int gpart_size;         // doubles in gpart
   int n_tile;             // Schur tiles per dimension
   int n_asm, n_imu_color;
-  int spart_stride;       // doubles per chunk partial: (Dp/6)(Dp/6+1)/2*36 + Dp
+  int spart_stride;       // doubles per chunk partial: (Dp/6)(Dp/6+1)/2*36 + 3*Dp  (S | Y b | g | diag U)
   double cauchy_b;
   ImuParamsD imu;
 
@@ -150,8 +150,11 @@ struct WinPtrs {
   const Task* tasks;
   const uint16_t* task_list;
   const Chunk* chunks;
-  const AsmTarget* asm_targets;  // [n_asm]
-  const int* asm_list;           // task 'out' offsets, fixed order (group order)
+  // per-chunk lists of the per-group partials (task 'out' offsets) that sum into each pose block / cross block
+  const int* chunk_diag_begin;   // [n_chunk * (Dp/6) + 1] into chunk_diag_out
+  const int* chunk_diag_out;
+  const int* chunk_cross_begin;  // [n_chunk + 1] into chunk_cross (triples off_a, off_b, out)
+  const int* chunk_cross;
   const int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
   const int* imu_color_begin;    // [n_imu_color+1]
   const int* imu_coloff;         // [n_imu][30] reduced index of each local column (or -1)

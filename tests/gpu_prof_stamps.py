@@ -19,3 +19,5 @@ for k in range(17,21):
 
 print("kb=0: panel", p[11]-p[10], "trailing(thread0 work)", p[26]-p[11], "trailing+barrier", p[12]-p[11])
 print("kb=12: panel", p[14]-p[13], "trailing+barrier", p[15]-p[14])
+
+print("kb=12 T-phase (cycles from phase start): lane64 item done", p[30]-p[14], " look-ahead quad update done", p[31]-p[14], " factor done", p[32]-p[14], " rhs wave done", p[33]-p[14], " barrier released", p[15]-p[14])
