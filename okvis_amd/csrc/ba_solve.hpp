@@ -326,6 +326,18 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         c.pending = 0;
       }
     }
+  } else {
+    // meanwhile the other waves prepare what does not depend on the decision:
+    // block-pair enumeration table (row-major lower triangle): entry wi -> (a, b), a >= b.  Used for the
+    // Schur partials' layout, the IMU 30x30 triangles and (mirrored) the trailing-update enumeration.
+    const int ntab = max(nbk * (nbk + 1) / 2, 465);
+    for (int wi = tid - 64; wi < ntab; wi += SOLVE_THREADS - 64) {
+      int bi = (int)((sqrtf(8.0f * wi + 1.0f) - 1.0f) * 0.5f);
+      while ((bi + 1) * (bi + 2) / 2 <= wi) ++bi;
+      while (bi * (bi + 1) / 2 > wi) --bi;
+      s_ptab[wi] = (unsigned short)((bi << 8) | (wi - bi * (bi + 1) / 2));
+    }
+    for (int i = tid - 64; i < nS; i += SOLVE_THREADS - 64) S[i] = 0.0;
   }
   __syncthreads();
   if (c.done) {
@@ -343,17 +355,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     const size_t stride = W.spart_stride;
     const int nch = W.n_chunk;
     const double* sp = W.spart;
-    // block-pair enumeration table (row-major lower triangle): entry wi -> (a, b), a >= b.  Used for the
-    // Schur partials' layout, the IMU 30x30 triangles and (mirrored) the trailing-update enumeration.
-    const int ntab = max(nbk * (nbk + 1) / 2, 465);
-    for (int wi = tid; wi < ntab; wi += SOLVE_THREADS) {
-      int bi = (int)((sqrtf(8.0f * wi + 1.0f) - 1.0f) * 0.5f);
-      while ((bi + 1) * (bi + 2) / 2 <= wi) ++bi;
-      while (bi * (bi + 1) / 2 > wi) --bi;
-      s_ptab[wi] = (unsigned short)((bi << 8) | (wi - bi * (bi + 1) / 2));
-    }
-    for (int i = tid; i < nS; i += SOLVE_THREADS) S[i] = 0.0;
-    __syncthreads();
     for (int i = tid; i < nP; i += SOLVE_THREADS) {
       double s = 0;
       for (int ch = 0; ch < nch; ch += 8) {  // 8 independent loads in flight
@@ -658,10 +659,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     return;
   }
-  // back substitution  L^T x = y: block kb is solved redundantly by every work-item that owns a block
-  // above it, which then updates its own block — one barrier per block column
-  for (int kb = nbk - 1; kb >= 0; --kb) {
-    if (tid <= kb) {
+  // back substitution  L^T x = y by ONE wave without barriers (LDS operations of a wave are ordered):
+  // every lane owns the rows lane, lane+64, ... ; block kb is solved redundantly by all lanes, then each
+  // lane updates its rows above it.  25 dependent steps cost LDS round trips only, no s_barrier.
+  if (tid < 64) {
+    for (int kb = nbk - 1; kb >= 0; --kb) {
       const double* Ld = s_diag + 36 * kb;   // x_k = L_kk^-T y_k
       const double* iv = s_dinv + 6 * kb;
       double x[6];
@@ -672,23 +674,22 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         for (int m = cix + 1; m < 6; ++m) v -= Ld[6 * m + cix] * x[m];
         x[cix] = v * iv[cix];
       }
-      if (tid == kb) {
+      if (tid == 0) {
 #pragma unroll
         for (int cix = 0; cix < 6; ++cix) s_x[kb * 6 + cix] = x[cix];
-      } else {
-        const double* Lb = S + LY.blk(kb, tid);  // rows: block kb, columns: block tid
-        double* yy = s_rhs + tid * 6;
-#pragma unroll
-        for (int cix = 0; cix < 6; ++cix) {
-          double s = 0;
-#pragma unroll
-          for (int m = 0; m < 6; ++m) s += Lb[6 * m + cix] * x[m];
-          yy[cix] -= s;
-        }
       }
+      for (int j = tid; j < kb * 6; j += 64) {
+        const double* Lb = S + LY.blk(kb, j / 6) + (j % 6);  // column j of block row kb
+        double a = s_rhs[j];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) a -= Lb[6 * m] * x[m];
+        s_rhs[j] = a;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      asm volatile("" ::: "memory");
     }
-    __syncthreads();
   }
+  __syncthreads();
   STAMP(8);
 
   // ------------------------------------------------------------------ 5. scalars, trial state, ctrl
