@@ -35,7 +35,8 @@ def shard_windows(n_total: int, rank: int, world: int) -> List[int]:
 def init(backend: str | None = None):
     """Initialise torch.distributed from the torchrun environment (returns the module or None for 1 rank)."""
     r = Rank.from_env()
-    if r.world <= 1:
+    # OKVIS_FORCE_DIST=1 initialises the process group even for one rank (exercises the RCCL path on a 1-GPU box)
+    if r.world <= 1 and not os.environ.get("OKVIS_FORCE_DIST"):
         return None
     import torch
     import torch.distributed as dist
