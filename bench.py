@@ -43,7 +43,55 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-iters", type=int, default=0, help="oracle iterations for the CPU baseline (0 = auto ~12 s)")
     p.add_argument("--profile-steps", type=int, default=20, help="eager per-kernel HIP-event pass for the roofline")
+    p.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE passes (roofline.traffic = null)")
+    p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return p.parse_args()
+
+
+KERNEL_SYMBOL = {"schur": "schur_kernel", "solve": "solve_kernel", "small": "small_kernel", "linearize": "linearize_kernel"}
+
+
+def pmc_traffic(a, kernel):
+    """HBM bytes per launch of `kernel` from the TCC counters, collected the way MI355X_MICROARCH.md
+    prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (they do not fit one pass) over
+    an eager re-run of the same workload in a child process; FETCH_SIZE (KB) is doubled (gfx950 tallies
+    128-B requests at 64 B), WRITE_SIZE (KB) is taken as reported (uncalibrated).  Returns None when
+    rocprofv3 is unavailable or a pass fails — never fatal for the bench line."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    raw = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="okvis_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--windows", str(a.windows),
+               "--keyframes", str(a.keyframes), "--landmarks", str(a.landmarks), "--visibility", str(a.visibility),
+               "--steps", "12", "--warmup", "4", "--no-graph"]
+        try:
+            subprocess.run(cmd, timeout=240, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == ctr and KERNEL_SYMBOL[kernel] in r["Kernel_Name"]:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            vals = vals[len(vals) // 4:]          # skip the first launches (first-touch / cold L2)
+            raw[ctr] = sum(vals) / len(vals)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_b = 2.0 * raw["FETCH_SIZE"] * 1024.0
+    write_b = raw["WRITE_SIZE"] * 1024.0
+    return {"bytes": fetch_b + write_b, "fetch_bytes": fetch_b, "write_bytes": write_b,
+            "raw_kb": raw, "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1 (uncalibrated); separate --pmc passes, eager launches"}
 
 
 def main():
@@ -75,6 +123,11 @@ def main():
             torch.cuda.synchronize()
 
     batch.begin()
+    if a.pmc_child:   # counter-collection child of pmc_traffic(): a short eager loop, no output
+        batch.iterate(a.warmup + a.steps)
+        batch.finish()
+        batch.close()
+        return
     if a.warmup > 0:
         batch.iterate(a.warmup)
     # build the graph of the timed call outside the timed region
@@ -101,12 +154,15 @@ def main():
         dom = max(prof, key=lambda k: prof[k])
         per_launch_s = prof[dom] * 1e-3 / a.profile_steps
         achieved = nbytes[dom] / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        pmc = None if (a.no_pmc or world > 1) else pmc_traffic(a, dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None if pmc is None else pmc["bytes"],
+                    "traffic_detail": pmc,
                     "algorithmic_bytes_per_launch": nbytes[dom], "avg_launch_us": per_launch_s * 1e6,
                     "per_kernel_us": {k: v * 1e3 / a.profile_steps for k, v in prof.items()},
                     "per_kernel_algorithmic_bytes": nbytes,
-                    "note": "single small windows are launch/latency-bound, not HBM-bound (SURVEY.md §7)"}
+                    "note": "achieved = algorithmic bytes of the dominant kernel / its mean launch time; the batch is "
+                            "bound by fp64 issue + LDS reductions, one window alone by launch latency (DESIGN.md §5)"}
     summaries = batch.finish()
 
     single = None
