@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OKVIS_BA_ABI_VERSION 1
+#define OKVIS_BA_ABI_VERSION 2
 
 /* status codes (0 ok; >0 = hipError_t passthrough + 1000; <0 = argument / state errors) */
 #define OKVIS_BA_OK 0
@@ -287,6 +287,43 @@ int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4);
 int okvis_ba_algorithmic_bytes(okvis_ba_solver* s, int64_t* linearize_bytes, int64_t* schur_bytes,
                                int64_t* solve_bytes, int64_t* small_bytes);
 int okvis_ba_synchronize(okvis_ba_solver* s);
+
+/* ---- marginalisation -------------------------------------------------------
+ * Numeric core of okvis::Estimator::applyMarginalizationStrategy (Estimator.cpp:434-773), i.e. what the
+ * reference's MarginalizationError does between the first addResidualBlock and updateErrorComputation
+ * (MarginalizationError.cpp:127-435 linearise-and-accumulate, :507-802 marginalizeOut, :806-846
+ * updateErrorComputation).  The caller uploads, as an ordinary window, exactly the residuals that are to be
+ * linearised into the prior, with every block's VALUE set to its linearisation point (first-estimate
+ * Jacobians, :292-310): all landmarks of that window are eliminated (landmark path, :617-684, per-block
+ * preconditioned pseudo-inverse), then the flagged pose-type / speed-bias blocks (dense path, :686-739), and
+ * the remaining system is turned into the error-term form J, e0 (:806-846).  The previous prior enters as
+ * (H, b0) over blocks of this window (the reference keeps H_ and b0_ inside the object).  The window itself
+ * must not carry a marg_* prior.  Reduced dimension of the window <= OKVIS_BA_MARG_MAX_WINDOW_DIM. */
+#define OKVIS_BA_MARG_MAX_WINDOW_DIM 174
+typedef struct okvis_ba_marg_spec {
+  const uint8_t* pose_marg;          /* [n_pose] 1 = eliminate this (free) pose-type block */
+  const uint8_t* sb_marg;            /* [n_sb]   1 = eliminate this (free) speed/bias block */
+  int32_t prior_dim, prior_nblocks;  /* previous prior (0 = none) */
+  const int32_t* prior_block_type;   /* OKVIS_BA_BLOCK_POSE / OKVIS_BA_BLOCK_SPEEDBIAS */
+  const int32_t* prior_block_idx;    /* block index in this window */
+  const int32_t* prior_block_off;    /* first row/column of the block inside prior_H */
+  const double* prior_H;             /* [prior_dim][prior_dim] row-major (H_) */
+  const double* prior_b0;            /* [prior_dim] (b0_) */
+} okvis_ba_marg_spec;
+
+typedef struct okvis_ba_marg_result {
+  int32_t capacity_dim, capacity_blocks;  /* in: sizes of the caller-allocated arrays below */
+  int32_t dim, nblocks, rank;             /* out: size of the new prior, its blocks, numeric rank of H */
+  int32_t* block_type;                    /* [capacity_blocks] */
+  int32_t* block_idx;                     /* [capacity_blocks] index in the uploaded window */
+  int32_t* block_off;                     /* [capacity_blocks] */
+  double* H;                              /* [dim][dim] row-major, packed with leading dimension dim */
+  double* b0;                             /* [dim] */
+  double* J;                              /* [dim][dim]: J^T J = H up to the dropped eigenvalues */
+  double* e0;                             /* [dim] */
+} okvis_ba_marg_result;
+
+int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* result);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .window import LimitsC, OptionsC, SummaryC, WindowC
+from .window import LimitsC, MargResultC, MargSpecC, OptionsC, SummaryC, WindowC
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libokvis_amd_ba.so")
@@ -16,7 +16,7 @@ SYMBOLS = [
     "okvis_ba_optimize", "okvis_ba_optimize_timed", "okvis_ba_begin", "okvis_ba_iterate", "okvis_ba_finish",
     "okvis_ba_evaluate_cost", "okvis_ba_get_state", "okvis_ba_array_size", "okvis_ba_download",
     "okvis_ba_reduced_dim", "okvis_ba_pair_count", "okvis_ba_pairs", "okvis_ba_last_iterate_ms",
-    "okvis_ba_profile_iterations", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize",
+    "okvis_ba_profile_iterations", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize", "okvis_ba_marginalize",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -58,6 +58,7 @@ def lib():
     L.okvis_ba_begin.argtypes = [vp]
     L.okvis_ba_iterate.argtypes = [vp, C.c_int]
     L.okvis_ba_finish.argtypes = [vp, C.POINTER(SummaryC)]
+    L.okvis_ba_marginalize.argtypes = [vp, C.c_int, C.POINTER(MargSpecC), C.POINTER(MargResultC)]
     L.okvis_ba_evaluate_cost.argtypes = [vp, _dp]
     L.okvis_ba_array_size.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.okvis_ba_download.argtypes = [vp, C.c_int, C.c_int, _dp, C.c_int64]

@@ -16,6 +16,7 @@
 #include "../../include/okvis_amd_ba.h"
 #include "ba_imu.hpp"
 #include "ba_linearize.hpp"
+#include "ba_marg.hpp"
 #include "ba_schur.hpp"
 #include "ba_solve.hpp"
 
@@ -35,6 +36,8 @@ namespace {
 struct HostWin {  // host copy of what the queries and downloads need
   int n_pose = 0, n_sb = 0, n_lm = 0, n_obs = 0, n_imu = 0, D = 0, Dp = 0, n_pair = 0, n_group = 0, n_chunk = 0;
   std::vector<int> pair_lm, pair_block;
+  std::vector<int> pose_off, sb_off;  // reduced ordering (host copy)
+  int marg_dim = 0;
   WinPtrs ptrs;  // device pointers
   int acc = 0;
   int64_t bytes_lin = 0, bytes_schur = 0, bytes_solve = 0, bytes_small = 0;
@@ -90,7 +93,7 @@ OptD make_optd(const okvis_ba_options& o) {
   d.gradient_tolerance = o.gradient_tolerance;
   d.parameter_tolerance = o.parameter_tolerance;
   d.gauss_newton = o.gauss_newton;
-  d.pad = 0;
+  d.marg_mode = 0;
   return d;
 }
 
@@ -519,6 +522,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (w.rel_pose0[i] < 0 || w.rel_pose0[i] >= npose || w.rel_pose1[i] < 0 || w.rel_pose1[i] >= npose) return OKVIS_BA_ERR_ARG;
 
   H.n_pose = npose; H.n_sb = nsb; H.n_lm = nlm; H.n_obs = nobs; H.n_imu = w.n_imu; H.D = D; H.Dp = Dp;
+  H.pose_off = pose_off; H.sb_off = sb_off; H.marg_dim = Dm;
   H.n_pair = npair; H.n_group = ngroup; H.n_chunk = nchunk;
   H.pair_lm = pair_lm;
   H.pair_block = pair_block;
@@ -1190,6 +1194,146 @@ int okvis_ba_synchronize(okvis_ba_solver* s) {
   if (!s) return OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return OKVIS_BA_OK;
+}
+
+// MarginalizationError numerics (see include/okvis_amd_ba.h): linearise at the uploaded values, eliminate
+// the landmarks (schur_kernel in marg_mode), export the dense system (solve_kernel final_only = 2), then the
+// dense elimination + eigen-decomposition (marg_dense_kernel).
+int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* res) {
+  if (!s || !spec || !res) return OKVIS_BA_ERR_ARG;
+  if (!s->uploaded) return OKVIS_BA_ERR_STATE;
+  if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
+  HostWin& H = s->wins[w];
+  if (H.marg_dim != 0) return OKVIS_BA_ERR_ARG;                    // the previous prior comes in through spec
+  if (H.D > MAX_D_LDS || H.ptrs.Sg != nullptr) return OKVIS_BA_ERR_UNSUPPORTED;
+  if ((H.n_pose > 0 && !spec->pose_marg) || (H.n_sb > 0 && !spec->sb_marg)) return OKVIS_BA_ERR_ARG;
+  const int pd = spec->prior_dim, pnb = spec->prior_nblocks;
+  if (pd < 0 || pnb < 0 || pd > MAX_MARG_DIM) return pd > MAX_MARG_DIM ? OKVIS_BA_ERR_UNSUPPORTED : OKVIS_BA_ERR_ARG;
+  if (pd > 0 && (!spec->prior_block_type || !spec->prior_block_idx || !spec->prior_block_off || !spec->prior_H ||
+                 !spec->prior_b0 || pnb == 0))
+    return OKVIS_BA_ERR_ARG;
+  for (int k = 0, expect = 0; k < (pd > 0 ? pnb : 0); ++k) {
+    const int t = spec->prior_block_type[k], idx = spec->prior_block_idx[k];
+    if (spec->prior_block_off[k] != expect) return OKVIS_BA_ERR_ARG;
+    if (t == OKVIS_BA_BLOCK_POSE) {
+      if (idx < 0 || idx >= H.n_pose) return OKVIS_BA_ERR_ARG;
+      expect += 6;
+    } else if (t == OKVIS_BA_BLOCK_SPEEDBIAS) {
+      if (idx < 0 || idx >= H.n_sb) return OKVIS_BA_ERR_ARG;
+      expect += 9;
+    } else {
+      return OKVIS_BA_ERR_ARG;
+    }
+    if (k == pnb - 1 && expect != pd) return OKVIS_BA_ERR_ARG;
+  }
+  // kept blocks, in reduced order (pose-type blocks first)
+  std::vector<int> bt, bi, bo;
+  int na = 0;
+  for (int i = 0; i < H.n_pose; ++i)
+    if (H.pose_off[i] >= 0 && !spec->pose_marg[i]) {
+      bt.push_back(OKVIS_BA_BLOCK_POSE); bi.push_back(i); bo.push_back(na);
+      na += 6;
+    }
+  for (int i = 0; i < H.n_sb; ++i)
+    if (H.sb_off[i] >= 0 && !spec->sb_marg[i]) {
+      bt.push_back(OKVIS_BA_BLOCK_SPEEDBIAS); bi.push_back(i); bo.push_back(na);
+      na += 9;
+    }
+  if (na > res->capacity_dim || (int)bt.size() > res->capacity_blocks) return OKVIS_BA_ERR_ARG;
+  if (na > 0 && (!res->H || !res->b0 || !res->J || !res->e0 || !res->block_type || !res->block_idx || !res->block_off))
+    return OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+
+  // ---- one scratch allocation ----
+  const int D = H.D;
+  Arena A;
+  const size_t o_pm = A.alloc(std::max(1, H.n_pose)), o_sm = A.alloc(std::max(1, H.n_sb));
+  const size_t o_pt = A.alloc(sizeof(int) * std::max(1, pnb)), o_pi = A.alloc(sizeof(int) * std::max(1, pnb)),
+               o_po = A.alloc(sizeof(int) * std::max(1, pnb));
+  const size_t o_pH = A.alloc(8 * std::max<size_t>(1, (size_t)pd * pd)), o_pb = A.alloc(8 * std::max(1, pd));
+  const size_t host_part = A.size;
+  const size_t o_work = A.alloc(8 * 3 * std::max<size_t>(1, (size_t)D * D));
+  const size_t o_S = A.alloc(8 * std::max<size_t>(1, (size_t)D * D)), o_rhs = A.alloc(8 * std::max(1, D)),
+               o_d2 = A.alloc(8 * std::max(1, D));
+  const size_t o_out = A.alloc(8 * (2 * std::max<size_t>(1, (size_t)na * na) + 2 * std::max(1, na)));
+  const size_t o_info = A.alloc(sizeof(int) * (8 + std::max(1, D)));
+  const size_t o_win = A.alloc(sizeof(WinPtrs));
+  std::vector<unsigned char> hb(host_part, 0);
+  if (H.n_pose) std::memcpy(&hb[o_pm], spec->pose_marg, H.n_pose);
+  if (H.n_sb) std::memcpy(&hb[o_sm], spec->sb_marg, H.n_sb);
+  if (pd > 0) {
+    std::memcpy(&hb[o_pt], spec->prior_block_type, sizeof(int) * pnb);
+    std::memcpy(&hb[o_pi], spec->prior_block_idx, sizeof(int) * pnb);
+    std::memcpy(&hb[o_po], spec->prior_block_off, sizeof(int) * pnb);
+    std::memcpy(&hb[o_pH], spec->prior_H, 8 * (size_t)pd * pd);
+    std::memcpy(&hb[o_pb], spec->prior_b0, 8 * (size_t)pd);
+  }
+  unsigned char* d = nullptr;
+  HIP_TRY(hipMalloc(&d, A.size));
+  struct Free { unsigned char* p; ~Free() { if (p) (void)hipFree(p); } } guard{d};
+  HIP_TRY(hipMemcpyAsync(d, hb.data(), host_part, hipMemcpyHostToDevice, s->stream));
+  WinPtrs P = H.ptrs;   // this window with the export buffers attached
+  P.S = reinterpret_cast<double*>(d + o_S);
+  P.rhs = reinterpret_cast<double*>(d + o_rhs);
+  P.Dp2 = reinterpret_cast<double*>(d + o_d2);
+  P.grad = nullptr;
+  HIP_TRY(hipMemcpyAsync(d + o_win, &P, sizeof(P), hipMemcpyHostToDevice, s->stream));
+  const WinPtrs* d_win = reinterpret_cast<const WinPtrs*>(d + o_win);
+
+  // ---- linearise + landmark elimination + export ----
+  OptD od = make_optd(s->opt);
+  od.marg_mode = 1;
+  HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
+  int rc = okvis_ba_begin(s);
+  if (rc != OKVIS_BA_OK) return rc;
+  s->begun = false;
+  const Sub one{s->stream, w, 1};
+  HIP_TRY(launch_schur(s, one));
+  hipLaunchKernelGGL(solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small), s->stream, d_win,
+                     s->d_opt, 2);
+  HIP_TRY(hipGetLastError());
+  MargArgs ma;
+  ma.pose_marg = d + o_pm;
+  ma.sb_marg = d + o_sm;
+  ma.prior_dim = pd;
+  ma.prior_nb = pd > 0 ? pnb : 0;
+  ma.pb_type = reinterpret_cast<const int*>(d + o_pt);
+  ma.pb_idx = reinterpret_cast<const int*>(d + o_pi);
+  ma.pb_off = reinterpret_cast<const int*>(d + o_po);
+  ma.prior_H = reinterpret_cast<const double*>(d + o_pH);
+  ma.prior_b0 = reinterpret_cast<const double*>(d + o_pb);
+  ma.work = reinterpret_cast<double*>(d + o_work);
+  double* outp = reinterpret_cast<double*>(d + o_out);
+  const size_t nn = std::max<size_t>(1, (size_t)na * na), n1 = std::max(1, na);
+  ma.out_H = outp;
+  ma.out_J = outp + nn;
+  ma.out_b0 = outp + 2 * nn;
+  ma.out_e0 = outp + 2 * nn + n1;
+  ma.out_info = reinterpret_cast<int*>(d + o_info);
+  hipLaunchKernelGGL(marg_dense_kernel, dim3(1), dim3(MARG_THREADS), 0, s->stream, d_win, 0, ma);
+  HIP_TRY(hipGetLastError());
+  od.marg_mode = 0;
+  HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
+  int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(info, d + o_info, sizeof(info), hipMemcpyDeviceToHost, s->stream));
+  if (na > 0) {
+    HIP_TRY(hipMemcpyAsync(res->H, ma.out_H, 8 * (size_t)na * na, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(res->J, ma.out_J, 8 * (size_t)na * na, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(res->b0, ma.out_b0, 8 * (size_t)na, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(res->e0, ma.out_e0, 8 * (size_t)na, hipMemcpyDeviceToHost, s->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (info[0] != na) return OKVIS_BA_ERR_NUMERIC;
+  res->dim = na;
+  res->nblocks = (int)bt.size();
+  res->rank = info[2];
+  for (size_t k = 0; k < bt.size(); ++k) {
+    res->block_type[k] = bt[k];
+    res->block_idx[k] = bi[k];
+    res->block_off[k] = bo[k];
+  }
+  if (int rc2 = refresh_acc(s, w)) return rc2;
   return OKVIS_BA_OK;
 }
 

@@ -169,6 +169,57 @@ BA_HD void eig3sym_minmax(const double* v, double* emin, double* emax) {
   *emax = fmax(e0, fmax(e1, e2));
 }
 
+// Preconditioned pseudo-inverse of a symmetric PSD 3x3 (upper-tri 00 01 02 11 12 22): what
+// MarginalizationError::marginalizeOut applies to ONE landmark block (MarginalizationError.cpp:617-684 with
+// pseudoInverseSymmSqrt, implementation/MarginalizationError.hpp:215-243), written in unscaled variables:
+//   p_i = sqrt(V_ii) if V_ii > 1e-9 else 1e-3 (:619);  Vs = P^-1 V P^-1 = Q diag(l) Q^T;
+//   Vs^+ keeps the eigenvalues l > eps * 3 * l_max;  result = P^-1 Vs^+ P^-1
+// so that W result W^T equals the reference's unscale(M M^T), M = (P_a^-1 W P^-1) Q diag(l^-1/2): the kept-side
+// scaling P_a cancels.  Eigen-decomposition by cyclic Jacobi.
+BA_HD void pinv3sym_precond(const double* v, double* o) {
+  const double p[3] = {v[0] > 1.0e-9 ? sqrt(v[0]) : 1.0e-3, v[3] > 1.0e-9 ? sqrt(v[3]) : 1.0e-3,
+                       v[5] > 1.0e-9 ? sqrt(v[5]) : 1.0e-3};
+  double A[3][3] = {{v[0] / (p[0] * p[0]), v[1] / (p[0] * p[1]), v[2] / (p[0] * p[2])},
+                    {v[1] / (p[0] * p[1]), v[3] / (p[1] * p[1]), v[4] / (p[1] * p[2])},
+                    {v[2] / (p[0] * p[2]), v[4] / (p[1] * p[2]), v[5] / (p[2] * p[2])}};
+  double Q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    if (off < 1e-300) break;
+    for (int a = 0; a < 2; ++a)
+      for (int b = a + 1; b < 3; ++b) {
+        if (A[a][b] == 0.0) continue;
+        const double theta = (A[b][b] - A[a][a]) / (2.0 * A[a][b]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          const double aka = A[k][a], akb = A[k][b];
+          A[k][a] = c * aka - s * akb;
+          A[k][b] = s * aka + c * akb;
+          const double qka = Q[k][a], qkb = Q[k][b];
+          Q[k][a] = c * qka - s * qkb;
+          Q[k][b] = s * qka + c * qkb;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double aak = A[a][k], abk = A[b][k];
+          A[a][k] = c * aak - s * abk;
+          A[b][k] = s * aak + c * abk;
+        }
+      }
+  }
+  const double lmax = fmax(A[0][0], fmax(A[1][1], A[2][2]));
+  const double tol = 2.220446049250313e-16 * 3.0 * lmax;
+  double li[3];
+  for (int k = 0; k < 3; ++k) li[k] = A[k][k] > tol ? 1.0 / A[k][k] : 0.0;
+  const int ut[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+  for (int e = 0; e < 6; ++e) {
+    const int i = ut[e][0], j = ut[e][1];
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += Q[i][k] * li[k] * Q[j][k];
+    o[e] = s / (p[i] * p[j]);
+  }
+}
+
 // ---- pose (+) / (-) ----------------------------------------------------------------------------------
 // Transformation::oplus via PoseLocalParameterization::plus (PoseLocalParameterization.cpp:60-87):
 // constructs Transformation(r, q) (normalises q), r += d[0:3], q = normalise(dq(d[3:6]) (x) q)

@@ -129,11 +129,15 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
       const int l = l0 + tid;
       const double* Vl = Vb + 6 * (size_t)l;
       double v[6] = {Vl[0], Vl[1], Vl[2], Vl[3], Vl[4], Vl[5]};
-      v[0] += lambda * clampd(v[0], opt.min_lm_diag2, opt.max_lm_diag2);
-      v[3] += lambda * clampd(v[3], opt.min_lm_diag2, opt.max_lm_diag2);
-      v[5] += lambda * clampd(v[5], opt.min_lm_diag2, opt.max_lm_diag2);
       double vi[6];
-      inv3sym(v, vi);
+      if (opt.marg_mode) {
+        pinv3sym_precond(v, vi);   // MarginalizationError::marginalizeOut landmark path (no damping)
+      } else {
+        v[0] += lambda * clampd(v[0], opt.min_lm_diag2, opt.max_lm_diag2);
+        v[3] += lambda * clampd(v[3], opt.min_lm_diag2, opt.max_lm_diag2);
+        v[5] += lambda * clampd(v[5], opt.min_lm_diag2, opt.max_lm_diag2);
+        inv3sym(v, vi);
+      }
 #pragma unroll
       for (int e = 0; e < 6; ++e) s_vinv[tid][e] = vi[e];
       s_b[tid][0] = bb[3 * (size_t)l];

@@ -418,6 +418,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   }
   if (W.grad)
     for (int i = tid; i < D; i += SOLVE_THREADS) W.grad[i] = s_g[i];
+  if (final_only == 2) {
+    // marginalisation pass (okvis_ba_marginalize): export the undamped system left after the landmark
+    // elimination, H (D x D, full symmetric) and b0 = -(g - W V^+ b_l)  (MarginalizationError.cpp:682-684)
+    for (int k = tid; k < D * D; k += SOLVE_THREADS) {
+      const int i = k / D, j = k - i * D;
+      W.S[k] = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
+    }
+    for (int i = tid; i < D; i += SOLVE_THREADS) W.rhs[i] = s_rhs[i] - s_g[i];
+    if (tid == 0) *gctrl = c;
+    return;
+  }
   if (c.done || final_only) {
     if (tid == 0) *gctrl = c;
     return;

@@ -93,7 +93,7 @@ struct OptD {
   double initial_radius, max_radius, min_radius, min_lm_diag2, max_lm_diag2;
   double min_relative_decrease, function_tolerance, gradient_tolerance, parameter_tolerance;
   int gauss_newton;  // 1 = accept every step, keep the radius fixed
-  int pad;
+  int marg_mode;     // 1 = marginalisation pass: no damping, landmark blocks eliminated with the preconditioned pseudo-inverse
 };
 
 // trust-region state of one window; written ONLY by the solve kernel (and the finish kernel)

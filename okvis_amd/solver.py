@@ -105,6 +105,15 @@ class WindowBatch:
         _lib.check(self._L.okvis_ba_evaluate_cost(self._h, c.ctypes.data_as(_dp)), "evaluate_cost")
         return c
 
+    def marginalize(self, w: int, pose_marg, sb_marg, prior=None) -> dict:
+        """okvis_ba_marginalize on window w (all its landmarks + the flagged blocks are eliminated)."""
+        from .window import marg_call
+        win = self.windows[w]
+        st, out = marg_call(lambda sp, rs: self._L.okvis_ba_marginalize(self._h, int(w), sp, rs), win.n_pose, win.n_sb,
+                            pose_marg, sb_marg, prior)
+        _lib.check(st, "marginalize")
+        return out
+
     def synchronize(self):
         _lib.check(self._L.okvis_ba_synchronize(self._h), "synchronize")
 

@@ -76,6 +76,66 @@ class LimitsC(C.Structure):
                 ("max_marg_dim", C.c_int32), ("max_imu_samples_per_factor", C.c_int32)]
 
 
+class MargSpecC(C.Structure):
+    """ctypes image of ``okvis_ba_marg_spec``."""
+    _fields_ = [("pose_marg", _bp), ("sb_marg", _bp), ("prior_dim", C.c_int32), ("prior_nblocks", C.c_int32),
+                ("prior_block_type", _ip), ("prior_block_idx", _ip), ("prior_block_off", _ip),
+                ("prior_H", _dp), ("prior_b0", _dp)]
+
+
+class MargResultC(C.Structure):
+    """ctypes image of ``okvis_ba_marg_result``."""
+    _fields_ = [("capacity_dim", C.c_int32), ("capacity_blocks", C.c_int32), ("dim", C.c_int32),
+                ("nblocks", C.c_int32), ("rank", C.c_int32), ("block_type", _ip), ("block_idx", _ip),
+                ("block_off", _ip), ("H", _dp), ("b0", _dp), ("J", _dp), ("e0", _dp)]
+
+
+def marg_call(fn, n_pose, n_sb, pose_marg, sb_marg, prior=None):
+    """Marshal one okvis_ba_marginalize-shaped call ``fn(spec*, result*) -> status``.
+    prior = dict(block_type, block_idx, H, b0) over blocks of the uploaded window, or None."""
+    pm = np.ascontiguousarray(pose_marg, np.uint8).reshape(-1)
+    sm = np.ascontiguousarray(sb_marg, np.uint8).reshape(-1)
+    assert pm.size == n_pose and sm.size == n_sb
+    if pm.size == 0:
+        pm = np.zeros(1, np.uint8)
+    if sm.size == 0:
+        sm = np.zeros(1, np.uint8)
+    spec = MargSpecC()
+    spec.pose_marg = pm.ctypes.data_as(_bp)
+    spec.sb_marg = sm.ctypes.data_as(_bp)
+    keep = [pm, sm]
+    if prior is not None and len(prior["block_type"]) > 0:
+        bt = np.ascontiguousarray(prior["block_type"], np.int32)
+        bi = np.ascontiguousarray(prior["block_idx"], np.int32)
+        dims = np.where(bt == 0, 6, 9)
+        bo = np.ascontiguousarray(np.concatenate([[0], np.cumsum(dims)[:-1]]), np.int32)
+        pd = int(dims.sum())
+        Hm = np.ascontiguousarray(prior["H"], np.float64).reshape(pd, pd)
+        b0 = np.ascontiguousarray(prior["b0"], np.float64).reshape(pd)
+        spec.prior_dim, spec.prior_nblocks = pd, int(bt.size)
+        spec.prior_block_type, spec.prior_block_idx, spec.prior_block_off = (a.ctypes.data_as(_ip) for a in (bt, bi, bo))
+        spec.prior_H, spec.prior_b0 = Hm.ctypes.data_as(_dp), b0.ctypes.data_as(_dp)
+        keep += [bt, bi, bo, Hm, b0]
+    cap = 6 * n_pose + 9 * n_sb
+    capb = max(1, n_pose + n_sb)
+    out = dict(block_type=np.zeros(capb, np.int32), block_idx=np.zeros(capb, np.int32), block_off=np.zeros(capb, np.int32),
+               H=np.zeros(max(1, cap * cap)), b0=np.zeros(max(1, cap)), J=np.zeros(max(1, cap * cap)), e0=np.zeros(max(1, cap)))
+    res = MargResultC()
+    res.capacity_dim, res.capacity_blocks = cap, capb
+    for k in ("block_type", "block_idx", "block_off"):
+        setattr(res, k, out[k].ctypes.data_as(_ip))
+    for k in ("H", "b0", "J", "e0"):
+        setattr(res, k, out[k].ctypes.data_as(_dp))
+    status = fn(C.byref(spec), C.byref(res))
+    del keep
+    if status != 0:
+        return status, None
+    n, nb = int(res.dim), int(res.nblocks)
+    return 0, dict(dim=n, rank=int(res.rank), block_type=out["block_type"][:nb].copy(), block_idx=out["block_idx"][:nb].copy(),
+                   block_off=out["block_off"][:nb].copy(), H=out["H"][:n * n].reshape(n, n).copy(), b0=out["b0"][:n].copy(),
+                   J=out["J"][:n * n].reshape(n, n).copy(), e0=out["e0"][:n].copy())
+
+
 def default_options() -> OptionsC:
     """Ceres 1.9 defaults restated from its documentation (not in the reference tree)."""
     return OptionsC(1e4, 1e16, 1e-32, 1e-6, 1e32, 1e-3, 1e-6, 1e-10, 1e-8, 1, 0, 0, 0, 0, 0)

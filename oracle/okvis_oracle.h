@@ -87,6 +87,15 @@ int64_t orc_window_array_size(orc_window* h, int which);
 int orc_window_download(orc_window* h, int which, double* out, int64_t n);
 /* dense numeric check helper: full (un-reduced) gradient entry count = D + 3*n_lm */
 void orc_window_full_gradient(orc_window* h, double* g_full);
+/* MarginalizationError numerics, re-stated literally on the FULL (dense + landmark) matrix
+ * (okvis_ceres/src/MarginalizationError.cpp:127-435 addResidualBlock, :507-802 marginalizeOut, :806-846
+ * updateErrorComputation): linearise every residual of the window at its current values, add the previous
+ * prior (H_, b0_), eliminate all landmarks and the flagged blocks, compute J and e0.  Same argument structs as
+ * okvis_ba_marginalize. */
+int orc_window_marginalize(orc_window* h, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* res);
+/* symmetric eigen-decomposition used above (cyclic Jacobi): A [n*n] row-major in, eigenvalues out[n],
+ * eigenvectors as columns of Q [n*n] */
+void orc_sym_eig(const double* A, int n, double* eigenvalues, double* Q);
 
 #ifdef __cplusplus
 }

@@ -836,3 +836,279 @@ void orc_window_full_gradient(orc_window* h, double* g_full) {
 }
 
 }  // extern "C"
+
+// ===================================================================================================
+// Marginalisation (MarginalizationError.cpp), literal restatement on dense matrices
+// ===================================================================================================
+namespace {
+typedef std::vector<double> Vec;
+
+// Eigen::SelfAdjointEigenSolver stand-in: classical cyclic-by-row Jacobi; ascending eigenvalues like Eigen.
+void sym_eig(const Vec& Ain, int n, Vec* ev, Vec* Qout) {
+  Vec A(Ain), Q((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) Q[(size_t)i * n + i] = 1.0;
+  const double eps = std::numeric_limits<double>::epsilon();
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q], app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+        if (std::fabs(apq) < 1e-300 || std::fabs(apq) <= eps * std::sqrt(std::fabs(app * aqq))) continue;
+        rotated = true;
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - s * akq;
+          A[(size_t)k * n + q] = s * akp + c * akq;
+          const double qkp = Q[(size_t)k * n + p], qkq = Q[(size_t)k * n + q];
+          Q[(size_t)k * n + p] = c * qkp - s * qkq;
+          Q[(size_t)k * n + q] = s * qkp + c * qkq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - s * aqk;
+          A[(size_t)q * n + k] = s * apk + c * aqk;
+        }
+      }
+    if (!rotated) break;
+  }
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return A[(size_t)a * n + a] < A[(size_t)b * n + b]; });
+  ev->assign(n, 0.0);
+  Qout->assign((size_t)n * n, 0.0);
+  for (int k = 0; k < n; ++k) {
+    (*ev)[k] = A[(size_t)order[k] * n + order[k]];
+    for (int i = 0; i < n; ++i) (*Qout)[(size_t)i * n + k] = Q[(size_t)i * n + order[k]];
+  }
+}
+
+// pseudoInverseSymmSqrt (implementation/MarginalizationError.hpp:215-243): result = Q diag(sqrt(1/l) | 0)
+void pinv_symm_sqrt(const Vec& a, int n, Vec* result) {
+  Vec ev, Q;
+  sym_eig(a, n, &ev, &Q);
+  double mx = ev[0];
+  for (int i = 1; i < n; ++i) mx = std::max(mx, ev[i]);
+  const double tol = std::numeric_limits<double>::epsilon() * n * mx;
+  result->assign((size_t)n * n, 0.0);
+  for (int k = 0; k < n; ++k) {
+    const double s = ev[k] > tol ? std::sqrt(1.0 / ev[k]) : 0.0;
+    for (int i = 0; i < n; ++i) (*result)[(size_t)i * n + k] = Q[(size_t)i * n + k] * s;
+  }
+}
+
+// one Schur step of marginalizeOut on (H, b0) of size n: eliminate the index set `mb` (ascending), keeping the
+// others in order.  landmark = true: block-diagonal V in 3x3 blocks (:617-684); false: dense V (:686-739).
+void marginalize_out(Vec* Hp, Vec* bp, int n, const std::vector<int>& mb, bool landmark) {
+  Vec& H = *Hp;
+  Vec& b0 = *bp;
+  std::vector<char> is_m(n, 0);
+  for (int i : mb) is_m[i] = 1;
+  std::vector<int> ka;
+  for (int i = 0; i < n; ++i)
+    if (!is_m[i]) ka.push_back(i);
+  const int na = (int)ka.size(), nm = (int)mb.size();
+  // preconditioner (:619-625 / :689-695)
+  Vec p(n), Hs((size_t)n * n), bs(n);
+  for (int i = 0; i < n; ++i) p[i] = H[(size_t)i * n + i] > 1.0e-9 ? std::sqrt(H[(size_t)i * n + i]) : 1.0e-3;
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) Hs[(size_t)i * n + j] = (1.0 / p[i]) * H[(size_t)i * n + j] * (1.0 / p[j]);
+    bs[i] = (1.0 / p[i]) * b0[i];
+  }
+  // split (:627-647)
+  Vec U((size_t)na * na), W((size_t)na * nm), V((size_t)nm * nm), b_a(na), b_b(nm), p_a(na);
+  for (int i = 0; i < na; ++i) {
+    for (int j = 0; j < na; ++j) U[(size_t)i * na + j] = Hs[(size_t)ka[i] * n + ka[j]];
+    for (int j = 0; j < nm; ++j) W[(size_t)i * nm + j] = Hs[(size_t)ka[i] * n + mb[j]];
+    b_a[i] = bs[ka[i]];
+    p_a[i] = p[ka[i]];
+  }
+  for (int i = 0; i < nm; ++i) {
+    for (int j = 0; j < nm; ++j) V[(size_t)i * nm + j] = Hs[(size_t)mb[i] * n + mb[j]];
+    b_b[i] = bs[mb[i]];
+  }
+  Vec dH((size_t)na * na, 0.0), db(na, 0.0);
+  if (landmark) {
+    for (int i = 0; i < nm; i += 3) {  // :657-677
+      Vec V1(9), Vis;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) V1[3 * r + c] = V[(size_t)(i + r) * nm + i + c];
+      pinv_symm_sqrt(V1, 3, &Vis);
+      Vec M((size_t)na * 3), M1((size_t)na * 3);
+      for (int r = 0; r < na; ++r)
+        for (int c = 0; c < 3; ++c) {
+          double s = 0;
+          for (int k = 0; k < 3; ++k) s += W[(size_t)r * nm + i + k] * Vis[3 * k + c];
+          M[3 * r + c] = s;
+        }
+      for (int r = 0; r < na; ++r)
+        for (int c = 0; c < 3; ++c) {
+          double s = 0;
+          for (int k = 0; k < 3; ++k) s += M[3 * r + k] * Vis[3 * c + k];  // M * Vis^T
+          M1[3 * r + c] = s;
+        }
+      for (int r = 0; r < na; ++r) {
+        for (int c = 0; c < na; ++c) {
+          double s = 0;
+          for (int k = 0; k < 3; ++k) s += M[3 * r + k] * M[3 * c + k];
+          dH[(size_t)r * na + c] += s;
+        }
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += M1[3 * r + k] * b_b[i + k];
+        db[r] += s;
+      }
+    }
+  } else {
+    Vec V1((size_t)nm * nm), Vis;  // :724-736
+    for (int r = 0; r < nm; ++r)
+      for (int c = 0; c < nm; ++c) V1[(size_t)r * nm + c] = 0.5 * (V[(size_t)r * nm + c] + V[(size_t)c * nm + r]);
+    pinv_symm_sqrt(V1, nm, &Vis);
+    Vec M((size_t)na * nm), t(nm);
+    for (int r = 0; r < na; ++r)
+      for (int c = 0; c < nm; ++c) {
+        double s = 0;
+        for (int k = 0; k < nm; ++k) s += W[(size_t)r * nm + k] * Vis[(size_t)k * nm + c];
+        M[(size_t)r * nm + c] = s;
+      }
+    for (int c = 0; c < nm; ++c) {
+      double s = 0;
+      for (int k = 0; k < nm; ++k) s += Vis[(size_t)k * nm + c] * b_b[k];
+      t[c] = s;
+    }
+    for (int r = 0; r < na; ++r) {
+      double s = 0;
+      for (int k = 0; k < nm; ++k) s += M[(size_t)r * nm + k] * t[k];
+      db[r] = s;
+      for (int c = 0; c < na; ++c) {
+        double q = 0;
+        for (int k = 0; k < nm; ++k) q += M[(size_t)r * nm + k] * M[(size_t)c * nm + k];
+        dH[(size_t)r * na + c] = q;
+      }
+    }
+  }
+  // Schur + unscale (:679-684 / :731-739)
+  Vec Hn((size_t)na * na), bn(na);
+  for (int r = 0; r < na; ++r) {
+    bn[r] = p_a[r] * (b_a[r] - db[r]);
+    for (int c = 0; c < na; ++c) Hn[(size_t)r * na + c] = p_a[r] * (U[(size_t)r * na + c] - dH[(size_t)r * na + c]) * p_a[c];
+  }
+  H.swap(Hn);
+  b0.swap(bn);
+}
+}  // namespace
+
+void orc_sym_eig(const double* A, int n, double* eigenvalues, double* Q) {
+  Vec a(A, A + (size_t)n * n), ev, q;
+  sym_eig(a, n, &ev, &q);
+  std::copy(ev.begin(), ev.end(), eigenvalues);
+  std::copy(q.begin(), q.end(), Q);
+}
+
+int orc_window_marginalize(orc_window* h, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* res) {
+  if (!h || !spec || !res || h->marg_dim != 0) return -1;
+  // ---- addResidualBlock for every residual of the window: H += J~^T J~, b0 -= J~^T r~ (:367-420), evaluated
+  // at the current (= linearisation point) values with the loss-function corrector (:325-365)
+  evaluate(h, true);
+  const int D = h->D, L = h->n_lm, n = D + 3 * L;
+  Vec H((size_t)n * n, 0.0), b0(n, 0.0);
+  for (int i = 0; i < D; ++i) {
+    for (int j = 0; j < D; ++j) H[(size_t)i * n + j] = h->U[(size_t)i * D + j];
+    b0[i] = -h->g[i];
+  }
+  static const int ut[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+  for (int l = 0; l < L; ++l) {
+    for (int e = 0; e < 6; ++e) {
+      H[(size_t)(D + 3 * l + ut[e][0]) * n + D + 3 * l + ut[e][1]] = h->V[6 * l + e];
+      H[(size_t)(D + 3 * l + ut[e][1]) * n + D + 3 * l + ut[e][0]] = h->V[6 * l + e];
+    }
+    for (int i = 0; i < 3; ++i) b0[D + 3 * l + i] = -h->b[3 * l + i];
+  }
+  for (int pr = 0; pr < h->n_pair; ++pr) {
+    const int l = h->pair_lm[pr], off = h->pose_off[h->pair_block[pr]];
+    if (off < 0) continue;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 3; ++j) {
+        H[(size_t)(off + i) * n + D + 3 * l + j] = h->W[18 * pr + 3 * i + j];
+        H[(size_t)(D + 3 * l + j) * n + off + i] = h->W[18 * pr + 3 * i + j];
+      }
+  }
+  // ---- the previous prior's H_ and b0_ (they persist inside the MarginalizationError object) ----
+  if (spec->prior_dim > 0) {
+    const int pd = spec->prior_dim;
+    std::vector<int> ridx(pd, -1);
+    for (int k = 0; k < spec->prior_nblocks; ++k) {
+      const bool pose = spec->prior_block_type[k] == OKVIS_BA_BLOCK_POSE;
+      const int base = pose ? h->pose_off[spec->prior_block_idx[k]] : h->sb_off[spec->prior_block_idx[k]];
+      for (int i = 0; i < (pose ? 6 : 9); ++i) ridx[spec->prior_block_off[k] + i] = base < 0 ? -1 : base + i;
+    }
+    for (int r = 0; r < pd; ++r) {
+      if (ridx[r] < 0) continue;
+      b0[ridx[r]] += spec->prior_b0[r];
+      for (int c = 0; c < pd; ++c)
+        if (ridx[c] >= 0) H[(size_t)ridx[r] * n + ridx[c]] += spec->prior_H[(size_t)r * pd + c];
+    }
+  }
+  // ---- marginalizeOut: landmark part, then dense part ----
+  if (L > 0) {
+    std::vector<int> mb;
+    for (int i = D; i < n; ++i) mb.push_back(i);
+    marginalize_out(&H, &b0, n, mb, true);
+  }
+  std::vector<int> mb, bt, bi, bo;
+  int na = 0;
+  for (int i = 0; i < h->n_pose; ++i) {
+    if (h->pose_off[i] < 0) continue;
+    if (spec->pose_marg[i]) {
+      for (int k = 0; k < 6; ++k) mb.push_back(h->pose_off[i] + k);
+    } else {
+      bt.push_back(OKVIS_BA_BLOCK_POSE); bi.push_back(i); bo.push_back(na);
+      na += 6;
+    }
+  }
+  for (int i = 0; i < h->n_sb; ++i) {
+    if (h->sb_off[i] < 0) continue;
+    if (spec->sb_marg[i]) {
+      for (int k = 0; k < 9; ++k) mb.push_back(h->sb_off[i] + k);
+    } else {
+      bt.push_back(OKVIS_BA_BLOCK_SPEEDBIAS); bi.push_back(i); bo.push_back(na);
+      na += 9;
+    }
+  }
+  std::sort(mb.begin(), mb.end());
+  if (!mb.empty()) marginalize_out(&H, &b0, D, mb, false);
+  if (na > res->capacity_dim || (int)bt.size() > res->capacity_blocks) return -2;
+  res->dim = na;
+  res->nblocks = (int)bt.size();
+  for (size_t k = 0; k < bt.size(); ++k) {
+    res->block_type[k] = bt[k];
+    res->block_idx[k] = bi[k];
+    res->block_off[k] = bo[k];
+  }
+  res->rank = 0;
+  if (na == 0) return 0;
+  // ---- updateErrorComputation (:806-846) ----
+  Vec p(na), A((size_t)na * na), ev, Q;
+  for (int i = 0; i < na; ++i) p[i] = H[(size_t)i * na + i] > 1.0e-9 ? std::sqrt(H[(size_t)i * na + i]) : 1.0e-3;
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < na; ++j)
+      A[(size_t)i * na + j] = 0.5 * (1.0 / p[i]) * (H[(size_t)i * na + j] + H[(size_t)j * na + i]) * (1.0 / p[j]);
+  sym_eig(A, na, &ev, &Q);
+  double mx = ev[0];
+  for (int i = 1; i < na; ++i) mx = std::max(mx, ev[i]);
+  const double tol = std::numeric_limits<double>::epsilon() * na * mx;
+  for (int r = 0; r < na; ++r) {
+    const double S = ev[r] > tol ? ev[r] : 0.0, Sp = ev[r] > tol ? 1.0 / ev[r] : 0.0;
+    if (ev[r] > tol) res->rank++;
+    double s = 0;
+    for (int c = 0; c < na; ++c) {
+      res->J[(size_t)r * na + c] = p[c] * Q[(size_t)c * na + r] * std::sqrt(S);
+      s += std::sqrt(Sp) * Q[(size_t)c * na + r] * (1.0 / p[c]) * b0[c];
+    }
+    res->e0[r] = -s;
+  }
+  std::copy(H.begin(), H.end(), res->H);
+  std::copy(b0.begin(), b0.end(), res->b0);
+  return 0;
+}

@@ -180,3 +180,52 @@ def imu_residual_fresh(t_ns, gyr, acc, prm, t0, t1, pose0, sb0, pose1, sb1):
     info = 0.5 * (info + info.T)
     L = np.linalg.cholesky(info).T
     return L @ e, L, pre["n"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Marginalisation, matrix form with scipy's symmetric eigen-solver
+# ---------------------------------------------------------------------------------------------------
+def _pinv_sqrt(V):
+    import scipy.linalg as sl
+    lam, Q = sl.eigh(V)
+    tol = np.finfo(float).eps * V.shape[0] * lam.max()
+    s = np.where(lam > tol, 1.0 / np.sqrt(np.where(lam > tol, lam, 1.0)), 0.0)
+    return Q * s
+
+
+def schur_marginalize(H, b0, marg_idx, landmark_blocks=False):
+    """One marginalizeOut step: diagonal pre-scaling p (1e-3 where diag <= 1e-9), pseudo-inverse of the
+    eliminated block (per 3x3 block when landmark_blocks), Schur complement, un-scaling."""
+    n = H.shape[0]
+    marg_idx = np.asarray(marg_idx, int)
+    keep = np.setdiff1d(np.arange(n), marg_idx)
+    d = np.diag(H)
+    p = np.where(d > 1e-9, np.sqrt(np.where(d > 1e-9, d, 1.0)), 1e-3)
+    Hs = H / np.outer(p, p)
+    bs = b0 / p
+    U, W, V = Hs[np.ix_(keep, keep)], Hs[np.ix_(keep, marg_idx)], Hs[np.ix_(marg_idx, marg_idx)]
+    ba, bb = bs[keep], bs[marg_idx]
+    if landmark_blocks:
+        Vis = np.zeros_like(V)
+        for i in range(0, len(marg_idx), 3):
+            Vis[i:i + 3, i:i + 3] = _pinv_sqrt(V[i:i + 3, i:i + 3])
+    else:
+        Vis = _pinv_sqrt(0.5 * (V + V.T))
+    M = W @ Vis
+    Hn = (U - M @ M.T) * np.outer(p[keep], p[keep])
+    bn = (ba - M @ (Vis.T @ bb)) * p[keep]
+    return Hn, bn, keep
+
+
+def error_computation(H, b0):
+    """updateErrorComputation: J, e0 with J^T J = H (eigenvalues below eps*n*max dropped)."""
+    import scipy.linalg as sl
+    d = np.diag(H)
+    p = np.where(d > 1e-9, np.sqrt(np.where(d > 1e-9, d, 1.0)), 1e-3)
+    lam, Q = sl.eigh(0.5 * (H + H.T) / np.outer(p, p))
+    tol = np.finfo(float).eps * H.shape[0] * lam.max()
+    S = np.where(lam > tol, lam, 0.0)
+    Sp = np.where(lam > tol, 1.0 / np.where(lam > tol, lam, 1.0), 0.0)
+    J = (p[:, None] * Q * np.sqrt(S)).T
+    e0 = -(np.sqrt(Sp)[:, None] * Q.T / p) @ b0
+    return J, e0, int((lam > tol).sum())

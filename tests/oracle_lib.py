@@ -10,7 +10,8 @@ import subprocess
 
 import numpy as np
 
-from okvis_amd.window import ImuParamsC, OptionsC, SummaryC, Window, WindowC, default_options
+from okvis_amd.window import (ImuParamsC, MargResultC, MargSpecC, OptionsC, SummaryC, Window, WindowC,
+                              default_options, marg_call)
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
@@ -60,6 +61,8 @@ def lib():
     L.orc_window_array_size.argtypes = [C.c_void_p, C.c_int]
     L.orc_window_download.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64]
     L.orc_window_full_gradient.argtypes = [C.c_void_p, _dp]
+    L.orc_window_marginalize.argtypes = [C.c_void_p, C.POINTER(MargSpecC), C.POINTER(MargResultC)]
+    L.orc_sym_eig.argtypes = [_dp, C.c_int, _dp, _dp]
     L.orc_imu_propagation.argtypes = [C.c_int, _lp, _dp, _dp, C.POINTER(ImuParamsC), _dp, _dp, C.c_int64,
                                       C.c_int64, _dp, _dp]
     _lib = L
@@ -250,6 +253,12 @@ class OracleWindow:
         out = np.zeros(max(n, 0))
         if n > 0:
             assert lib().orc_window_download(self._h, which, _p(out), n) == 0
+        return out
+
+    def marginalize(self, pose_marg, sb_marg, prior=None):
+        st, out = marg_call(lambda sp, rs: lib().orc_window_marginalize(self._h, sp, rs), self.window.n_pose,
+                            self.window.n_sb, pose_marg, sb_marg, prior)
+        assert st == 0, st
         return out
 
     def full_gradient(self):
