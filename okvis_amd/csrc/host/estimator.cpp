@@ -273,7 +273,8 @@ bool Estimator::addStates(MultiFramePtr multiFrame, const ImuMeasurementDeque& i
     }
   } else {
     const State& last = states_.back();
-    imuFactors_.push_back(ImuFactor{last.id, st.id, last.t_ns, st.t_ns, imuMeasurements});  // :288-307
+    imuFactors_.push_back(ImuFactor{last.poseBlock, last.sbBlock, st.poseBlock, st.sbBlock, last.t_ns, st.t_ns,
+                                    imuMeasurements});  // :288-307
     for (size_t i = 0; i < extrinsicsEstimationParametersVec_.size(); ++i) {           // :310-336
       if (last.extBlocks[i] != st.extBlocks[i]) {
         const ExtrinsicsEstimationParameters& ep = extrinsicsEstimationParametersVec_[i];
@@ -366,33 +367,62 @@ bool Estimator::setOptimizationTimeLimit(double timeLimit, int minIterations) {
 // ---------------------------------------------------------------------------------------------------
 // flat window for the C-ABI
 // ---------------------------------------------------------------------------------------------------
-void Estimator::buildWindow(std::vector<std::vector<double>>& f64, std::vector<std::vector<int32_t>>& i32,
-                            std::vector<std::vector<int64_t>>& i64, std::vector<std::vector<uint8_t>>& u8,
-                            okvis_ba_window& w, std::vector<uint64_t>& lmOrder) const {
+Estimator::WindowSel Estimator::selectAll() const {
+  WindowSel sel;
+  for (size_t i = 0; i < poseBlocks_.size(); ++i)
+    if (poseBlocks_[i].alive) sel.pose.push_back((int)i);
+  for (size_t i = 0; i < sbBlocks_.size(); ++i)
+    if (sbBlocks_[i].alive) sel.sb.push_back((int)i);
+  for (const auto& kv : landmarksMap_) sel.landmarks.push_back(kv.first);
+  for (const auto& kv : observations_) sel.obs.push_back(kv.first);
+  for (size_t i = 0; i < imuFactors_.size(); ++i) sel.imu.push_back((int)i);
+  for (size_t i = 0; i < posePriors_.size(); ++i) sel.pprior.push_back((int)i);
+  for (size_t i = 0; i < sbPriors_.size(); ++i) sel.sbprior.push_back((int)i);
+  for (size_t i = 0; i < relPoses_.size(); ++i) sel.rel.push_back((int)i);
+  sel.withPrior = true;
+  return sel;
+}
+
+void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
+  okvis_ba_window& w = fw.w;
   std::memset(&w, 0, sizeof(w));
+  auto& f64 = fw.f64;
+  auto& i32 = fw.i32;
+  auto& i64 = fw.i64;
+  auto& u8 = fw.u8;
   f64.assign(24, {});
   i32.assign(24, {});
   i64.assign(4, {});
   u8.assign(2, {});
-  enum { F_POSE, F_SB, F_LM, F_INTR, F_UV, F_SW, F_GYR, F_ACC, F_PPM, F_PPS, F_SBM, F_SBS, F_RELS };
-  enum { I_MODEL, I_OLM, I_OPOSE, I_OEXT, I_OCAM, I_IP0, I_IS0, I_IP1, I_IS1, I_SB, I_SC, I_PPP, I_SBP, I_R0, I_R1 };
-  // parameter blocks
-  for (const PoseBlock& b : poseBlocks_) {
-    f64[F_POSE].insert(f64[F_POSE].end(), b.x.begin(), b.x.end());
-    u8[0].push_back(b.fixed ? 1 : 0);
+  enum { F_POSE, F_SB, F_LM, F_INTR, F_UV, F_SW, F_GYR, F_ACC, F_PPM, F_PPS, F_SBM, F_SBS, F_RELS, F_MJ, F_ME, F_ML };
+  enum { I_MODEL, I_OLM, I_OPOSE, I_OEXT, I_OCAM, I_IP0, I_IS0, I_IP1, I_IS1, I_SB, I_SC, I_PPP, I_SBP, I_R0, I_R1,
+         I_MT, I_MI, I_MO };
+  // parameter blocks (values: estimate, or the linearisation point of prior-connected blocks)
+  fw.poseMap.assign(poseBlocks_.size(), -1);
+  fw.sbMap.assign(sbBlocks_.size(), -1);
+  std::vector<const double*> poseLin(poseBlocks_.size(), nullptr), sbLin(sbBlocks_.size(), nullptr);
+  if (sel.atLinearizationPoint)
+    for (size_t k = 0; k < prior_.block.size(); ++k)
+      (prior_.type[k] == OKVIS_BA_BLOCK_POSE ? poseLin : sbLin)[prior_.block[k]] = prior_.lin[k].data();
+  for (int b : sel.pose) {
+    fw.poseMap[b] = (int)u8[0].size();
+    const double* x = poseLin[b] ? poseLin[b] : poseBlocks_[b].x.data();
+    f64[F_POSE].insert(f64[F_POSE].end(), x, x + 7);
+    u8[0].push_back(poseBlocks_[b].fixed ? 1 : 0);
   }
-  for (const SbBlock& b : sbBlocks_) {
-    f64[F_SB].insert(f64[F_SB].end(), b.x.begin(), b.x.end());
-    u8[1].push_back(b.fixed ? 1 : 0);
+  for (int b : sel.sb) {
+    fw.sbMap[b] = (int)u8[1].size();
+    const double* x = sbLin[b] ? sbLin[b] : sbBlocks_[b].x.data();
+    f64[F_SB].insert(f64[F_SB].end(), x, x + 9);
+    u8[1].push_back(sbBlocks_[b].fixed ? 1 : 0);
   }
   std::map<uint64_t, int> lmIndex;
-  lmOrder.clear();
-  for (const auto& kv : landmarksMap_) {
-    lmIndex[kv.first] = (int)lmOrder.size();
-    lmOrder.push_back(kv.first);
-    f64[F_LM].insert(f64[F_LM].end(), kv.second.point.begin(), kv.second.point.end());
+  for (uint64_t id : sel.landmarks) {
+    lmIndex[id] = (int)lmIndex.size();
+    const MapPoint& mp = landmarksMap_.at(id);
+    f64[F_LM].insert(f64[F_LM].end(), mp.point.begin(), mp.point.end());
   }
-  // cameras: one intrinsics record per (distinct) camera index of the newest multiframe
+  // cameras: one intrinsics record per camera index of the newest multiframe
   size_t ncam = 0;
   if (!states_.empty()) {
     const MultiFramePtr& mf = multiFramePtrMap_.at(states_.back().id);
@@ -408,11 +438,15 @@ void Estimator::buildWindow(std::vector<std::vector<double>>& f64, std::vector<s
     double u, v, sw;
   };
   std::vector<Rec> recs;
-  for (const auto& kv : observations_) {
-    const Observation& o = kv.second;
+  for (uint64_t hnd : sel.obs) {
+    const Observation& o = observations_.at(hnd);
     const State* st = findState(o.poseId);
     if (!st || o.camIdx >= st->extBlocks.size() || o.camIdx >= ncam) continue;
-    recs.push_back(Rec{lmIndex.at(o.landmarkId), st->poseBlock, st->extBlocks[o.camIdx], (int)o.camIdx, o.u, o.v, o.sqrtw});
+    auto li = lmIndex.find(o.landmarkId);
+    if (li == lmIndex.end()) continue;
+    const int ip = fw.poseMap[st->poseBlock], ie = fw.poseMap[st->extBlocks[o.camIdx]];
+    if (ip < 0 || ie < 0) throw Exception("flatten: observation refers to a block outside the window");
+    recs.push_back(Rec{li->second, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw});
   }
   std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) {
     if (a.lm != b.lm) return a.lm < b.lm;
@@ -429,14 +463,15 @@ void Estimator::buildWindow(std::vector<std::vector<double>>& f64, std::vector<s
     f64[F_SW].push_back(r.sw);
   }
   // IMU factors
-  for (const ImuFactor& f : imuFactors_) {
-    const State* s0 = findState(f.pose0Id);
-    const State* s1 = findState(f.pose1Id);
-    if (!s0 || !s1 || s0->sbBlock < 0 || s1->sbBlock < 0) continue;
-    i32[I_IP0].push_back(s0->poseBlock);
-    i32[I_IS0].push_back(s0->sbBlock);
-    i32[I_IP1].push_back(s1->poseBlock);
-    i32[I_IS1].push_back(s1->sbBlock);
+  for (int fi : sel.imu) {
+    const ImuFactor& f = imuFactors_[fi];
+    const int p0 = fw.poseMap[f.pose0Block], s0 = fw.sbMap[f.sb0Block], p1 = fw.poseMap[f.pose1Block],
+              s1 = fw.sbMap[f.sb1Block];
+    if (p0 < 0 || s0 < 0 || p1 < 0 || s1 < 0) throw Exception("flatten: IMU factor refers to a block outside the window");
+    i32[I_IP0].push_back(p0);
+    i32[I_IS0].push_back(s0);
+    i32[I_IP1].push_back(p1);
+    i32[I_IS1].push_back(s1);
     i64[0].push_back(f.t0);
     i64[1].push_back(f.t1);
     i32[I_SB].push_back((int)i64[2].size());
@@ -447,24 +482,27 @@ void Estimator::buildWindow(std::vector<std::vector<double>>& f64, std::vector<s
       f64[F_ACC].insert(f64[F_ACC].end(), m.acc.begin(), m.acc.end());
     }
   }
-  for (const PosePrior& p : posePriors_) {
-    i32[I_PPP].push_back(p.block);
+  for (int k : sel.pprior) {
+    const PosePrior& p = posePriors_[k];
+    i32[I_PPP].push_back(fw.poseMap[p.block]);
     f64[F_PPM].insert(f64[F_PPM].end(), p.meas.begin(), p.meas.end());
     f64[F_PPS].insert(f64[F_PPS].end(), p.sqrtInfo.begin(), p.sqrtInfo.end());
   }
-  for (const SbPrior& p : sbPriors_) {
-    i32[I_SBP].push_back(p.block);
+  for (int k : sel.sbprior) {
+    const SbPrior& p = sbPriors_[k];
+    i32[I_SBP].push_back(fw.sbMap[p.block]);
     f64[F_SBM].insert(f64[F_SBM].end(), p.meas.begin(), p.meas.end());
     f64[F_SBS].insert(f64[F_SBS].end(), p.sqrtInfo.begin(), p.sqrtInfo.end());
   }
-  for (const RelPose& r : relPoses_) {
-    i32[I_R0].push_back(r.block0);
-    i32[I_R1].push_back(r.block1);
+  for (int k : sel.rel) {
+    const RelPose& r = relPoses_[k];
+    i32[I_R0].push_back(fw.poseMap[r.block0]);
+    i32[I_R1].push_back(fw.poseMap[r.block1]);
     f64[F_RELS].insert(f64[F_RELS].end(), r.sqrtInfo.begin(), r.sqrtInfo.end());
   }
-  w.n_pose = (int)poseBlocks_.size(); w.pose = f64[F_POSE].data(); w.pose_fixed = u8[0].data();
-  w.n_sb = (int)sbBlocks_.size(); w.sb = f64[F_SB].data(); w.sb_fixed = u8[1].data();
-  w.n_lm = (int)lmOrder.size(); w.lm = f64[F_LM].data();
+  w.n_pose = (int)u8[0].size(); w.pose = f64[F_POSE].data(); w.pose_fixed = u8[0].data();
+  w.n_sb = (int)u8[1].size(); w.sb = f64[F_SB].data(); w.sb_fixed = u8[1].data();
+  w.n_lm = (int)lmIndex.size(); w.lm = f64[F_LM].data();
   w.n_cam = (int)ncam; w.cam_intr = f64[F_INTR].data(); w.cam_model = i32[I_MODEL].data();
   w.n_obs = (int)recs.size();
   w.obs_lm = i32[I_OLM].data(); w.obs_pose = i32[I_OPOSE].data(); w.obs_ext = i32[I_OEXT].data(); w.obs_cam = i32[I_OCAM].data();
@@ -478,10 +516,29 @@ void Estimator::buildWindow(std::vector<std::vector<double>>& f64, std::vector<s
     const ImuParameters& ip = imuParametersVec_[0];
     w.imu_params = okvis_ba_imu_params{ip.sigma_g_c, ip.sigma_a_c, ip.sigma_gw_c, ip.sigma_aw_c, ip.g, ip.g_max, ip.a_max};
   }
-  w.n_pprior = (int)posePriors_.size(); w.pprior_pose = i32[I_PPP].data(); w.pprior_meas = f64[F_PPM].data(); w.pprior_sqrtinfo = f64[F_PPS].data();
-  w.n_sbprior = (int)sbPriors_.size(); w.sbprior_sb = i32[I_SBP].data(); w.sbprior_meas = f64[F_SBM].data(); w.sbprior_sqrtinfo = f64[F_SBS].data();
-  w.n_relpose = (int)relPoses_.size(); w.rel_pose0 = i32[I_R0].data(); w.rel_pose1 = i32[I_R1].data(); w.rel_sqrtinfo = f64[F_RELS].data();
+  w.n_pprior = (int)i32[I_PPP].size(); w.pprior_pose = i32[I_PPP].data(); w.pprior_meas = f64[F_PPM].data(); w.pprior_sqrtinfo = f64[F_PPS].data();
+  w.n_sbprior = (int)i32[I_SBP].size(); w.sbprior_sb = i32[I_SBP].data(); w.sbprior_meas = f64[F_SBM].data(); w.sbprior_sqrtinfo = f64[F_SBS].data();
+  w.n_relpose = (int)i32[I_R0].size(); w.rel_pose0 = i32[I_R0].data(); w.rel_pose1 = i32[I_R1].data(); w.rel_sqrtinfo = f64[F_RELS].data();
   w.marg_dim = 0;
+  if (sel.withPrior && prior_.dim > 0) {  // the MarginalizationError residual block (Estimator.cpp:750-759)
+    int off = 0;
+    for (size_t k = 0; k < prior_.block.size(); ++k) {
+      const bool pose = prior_.type[k] == OKVIS_BA_BLOCK_POSE;
+      const int wi = pose ? fw.poseMap[prior_.block[k]] : fw.sbMap[prior_.block[k]];
+      if (wi < 0) throw Exception("flatten: marginalisation prior refers to a removed block");
+      i32[I_MT].push_back(prior_.type[k]);
+      i32[I_MI].push_back(wi);
+      i32[I_MO].push_back(off);
+      off += pose ? 6 : 9;
+      f64[F_ML].insert(f64[F_ML].end(), prior_.lin[k].begin(), prior_.lin[k].end());
+    }
+    f64[F_MJ] = prior_.J;
+    f64[F_ME] = prior_.e0;
+    w.marg_dim = prior_.dim;
+    w.marg_nblocks = (int)prior_.block.size();
+    w.marg_block_type = i32[I_MT].data(); w.marg_block_idx = i32[I_MI].data(); w.marg_block_off = i32[I_MO].data();
+    w.marg_J = f64[F_MJ].data(); w.marg_e0 = f64[F_ME].data(); w.marg_lin = f64[F_ML].data();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -489,42 +546,335 @@ void Estimator::buildWindow(std::vector<std::vector<double>>& f64, std::vector<s
 // ---------------------------------------------------------------------------------------------------
 void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/) {
   if (states_.empty()) return;
-  std::vector<std::vector<double>> f64;
-  std::vector<std::vector<int32_t>> i32;
-  std::vector<std::vector<int64_t>> i64;
-  std::vector<std::vector<uint8_t>> u8;
-  okvis_ba_window w;
-  std::vector<uint64_t> lmOrder;
-  buildWindow(f64, i32, i64, u8, w, lmOrder);
+  const WindowSel sel = selectAll();
+  FlatWindow fw;
+  flatten(sel, fw);
   check(okvis_ba_set_options(solver_, &options_), "set_options");
-  check(okvis_ba_upload(solver_, 1, &w), "upload");
+  check(okvis_ba_upload(solver_, 1, &fw.w), "upload");
   if (hasTimeLimit_)  // CeresIterationCallback semantics (CeresIterationCallback.hpp:77-86)
     check(okvis_ba_optimize_timed(solver_, (int)numIter, minIterations_, timeLimit_, &summary_), "optimize");
   else
     check(okvis_ba_optimize(solver_, (int)numIter, &summary_), "optimize");
   // copy the estimates back (the reference's parameter blocks are updated in place by Ceres)
-  std::vector<double> pose(7 * poseBlocks_.size()), sb(9 * sbBlocks_.size()), lm(4 * lmOrder.size()), q(lmOrder.size());
+  const size_t nl = sel.landmarks.size();
+  std::vector<double> pose(7 * sel.pose.size()), sb(9 * sel.sb.size()), lm(4 * nl), q(nl);
   check(okvis_ba_get_state(solver_, 0, pose.data(), sb.data(), lm.data()), "get_state");
   if (!q.empty()) check(okvis_ba_download(solver_, 0, OKVIS_BA_ARR_LM_QUALITY, q.data(), (int64_t)q.size()), "quality");
-  for (size_t i = 0; i < poseBlocks_.size(); ++i) std::copy(pose.begin() + 7 * i, pose.begin() + 7 * i + 7, poseBlocks_[i].x.begin());
-  for (size_t i = 0; i < sbBlocks_.size(); ++i) std::copy(sb.begin() + 9 * i, sb.begin() + 9 * i + 9, sbBlocks_[i].x.begin());
+  for (size_t i = 0; i < sel.pose.size(); ++i)
+    std::copy(pose.begin() + 7 * i, pose.begin() + 7 * i + 7, poseBlocks_[sel.pose[i]].x.begin());
+  for (size_t i = 0; i < sel.sb.size(); ++i)
+    std::copy(sb.begin() + 9 * i, sb.begin() + 9 * i + 9, sbBlocks_[sel.sb[i]].x.begin());
   {
     // update landmarks: quality = sqrt(lambda_min)/sqrt(lambda_max) of the un-robustified H_l and the
     // estimate (Estimator.cpp:880-900)
     std::lock_guard<std::mutex> l(statesMutex_);
-    for (size_t i = 0; i < lmOrder.size(); ++i) {
-      MapPoint& mp = landmarksMap_.at(lmOrder[i]);
+    for (size_t i = 0; i < nl; ++i) {
+      MapPoint& mp = landmarksMap_.at(sel.landmarks[i]);
       mp.quality = q[i];
       std::copy(lm.begin() + 4 * i, lm.begin() + 4 * i + 4, mp.point.begin());
     }
   }
 }
 
-bool Estimator::applyMarginalizationStrategy(size_t, size_t, MapPointVector&) {
-  // construction of the marginalisation prior (MarginalizationError::addResidualBlock /
-  // marginalizeOut / updateErrorComputation) is the next row after the optimize() path; its *evaluation*
-  // inside optimize() is implemented on the GPU (okvis_ba_window::marg_*).
-  throw Exception("okvis_amd::Estimator::applyMarginalizationStrategy: not implemented yet (SURVEY.md §8f rank 1)");
+// ---------------------------------------------------------------------------------------------------
+// applyMarginalizationStrategy (Estimator.cpp:434-773).  The decisions (which frames / blocks / landmarks /
+// observations go) are book-keeping and stay on the host like in the reference; everything the reference's
+// MarginalizationError computes (linearisation of the selected residuals at their linearisation points,
+// landmark and dense Schur complements with pseudo-inverses, eigen-decomposition into J, e0) runs on the GPU
+// through okvis_ba_marginalize.
+// ---------------------------------------------------------------------------------------------------
+bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks) {
+  // keep the newest numImuFrames (:439-446)
+  if (states_.size() <= numImuFrames) return true;
+  const size_t nOlder = states_.size() - numImuFrames;  // states_[0 .. nOlder-1], visited newest -> oldest
+
+  // distinguish if we marginalize everything or everything but pose (:468-483)
+  std::vector<uint64_t> removeFrames, allLinearizedFrames;
+  size_t countedKeyframes = 0;
+  for (size_t k = nOlder; k-- > 0;) {
+    const State& st = states_[k];
+    if (!st.isKeyframe || countedKeyframes >= numKeyframes)
+      removeFrames.push_back(st.id);
+    else
+      countedKeyframes++;
+    allLinearizedFrames.push_back(st.id);
+  }
+  auto contains = [](const std::vector<uint64_t>& v, uint64_t id) { return std::find(v.begin(), v.end(), id) != v.end(); };
+
+  WindowSel sel;  // the residuals that get linearised into the prior (MarginalizationError::addResidualBlock)
+  std::vector<char> imuSel(imuFactors_.size(), 0), ppSel(posePriors_.size(), 0), ppDrop(posePriors_.size(), 0),
+      sbpSel(sbPriors_.size(), 0), relSel(relPoses_.size(), 0);
+  std::vector<int> margPose, margSb;
+  std::vector<uint64_t> margLandmarks;
+  auto selectPoseResiduals = [&](int block, bool isT_WS, bool* sawPoseError) {
+    for (size_t i = 0; i < posePriors_.size(); ++i)
+      if (posePriors_[i].block == block && !ppSel[i] && !ppDrop[i]) {
+        if (isT_WS) {  // "avoids linearising initial pose error" (:569-574)
+          ppDrop[i] = 1;
+          if (sawPoseError) *sawPoseError = true;
+        } else {
+          ppSel[i] = 1;
+        }
+      }
+    for (size_t i = 0; i < imuFactors_.size(); ++i)
+      if (imuFactors_[i].pose0Block == block || imuFactors_[i].pose1Block == block) imuSel[i] = 1;
+    for (size_t i = 0; i < relPoses_.size(); ++i)
+      if (relPoses_[i].block0 == block || relPoses_[i].block1 == block) relSel[i] = 1;
+  };
+
+  // marginalize everything but pose (:485-554): the speed/bias block of every older state
+  for (size_t k = nOlder; k-- > 0;) {
+    State& st = states_[k];
+    if (st.sbBlock < 0 || sbBlocks_[st.sbBlock].fixed) continue;
+    const int b = st.sbBlock;
+    st.sbBlock = -1;  // "remember we removed"
+    margSb.push_back(b);
+    for (size_t i = 0; i < imuFactors_.size(); ++i)
+      if (imuFactors_[i].sb0Block == b || imuFactors_[i].sb1Block == b) imuSel[i] = 1;
+    for (size_t i = 0; i < sbPriors_.size(); ++i)
+      if (sbPriors_[i].block == b) sbpSel[i] = 1;
+  }
+
+  // marginalize ONLY pose now (:556-733)
+  bool reDoFixation = false;
+  const uint64_t currentKfId = allLinearizedFrames.at(0);
+  std::vector<uint64_t> selObs;
+  for (size_t rf = 0; rf < removeFrames.size(); ++rf) {
+    size_t k = 0;
+    while (states_[k].id != removeFrames[rf]) ++k;
+    State& st = states_[k];
+    margPose.push_back(st.poseBlock);
+    selectPoseResiduals(st.poseBlock, true, &reDoFixation);
+    // the camera extrinsics of this frame, if they are not shared with the next frame (:587-617)
+    for (size_t j = 0; j < st.extBlocks.size(); ++j) {
+      const int b = st.extBlocks[j];
+      if (b < 0 || poseBlocks_[b].fixed) continue;
+      if (k + 1 < states_.size() && states_[k + 1].extBlocks.at(j) == b) continue;
+      if (std::find(margPose.begin(), margPose.end(), b) != margPose.end()) continue;
+      margPose.push_back(b);
+      selectPoseResiduals(b, false, nullptr);
+    }
+    // now finally we treat all the observations (:620-725)
+    for (auto pit = landmarksMap_.begin(); pit != landmarksMap_.end();) {
+      MapPoint& mp = pit->second;
+      if (std::find(margLandmarks.begin(), margLandmarks.end(), pit->first) != margLandmarks.end()) {
+        ++pit;  // already scheduled (the reference erased it from landmarksMap_ at that point, :715-719)
+        continue;
+      }
+      std::vector<uint64_t> residuals;  // reprojection residuals still in the map
+      for (const auto& ob : mp.observations)
+        if (std::find(selObs.begin(), selObs.end(), ob.second) == selObs.end()) residuals.push_back(ob.second);
+      bool skipLandmark = true, hasNewObservations = false, justDelete = false, marginalize = true, errorTermAdded = false;
+      size_t obsCount = 0;
+      for (uint64_t hnd : residuals) {
+        const uint64_t poseId = observations_.at(hnd).poseId;
+        if (contains(removeFrames, poseId)) skipLandmark = false;
+        if (poseId >= currentKfId) {
+          marginalize = false;
+          hasNewObservations = true;
+        }
+        if (contains(allLinearizedFrames, poseId)) obsCount++;
+      }
+      if (residuals.empty()) {  // :663-668
+        removedLandmarks.push_back(mp);
+        landmarkInitialized_.erase(pit->first);
+        pit = landmarksMap_.erase(pit);
+        continue;
+      }
+      if (skipLandmark) {
+        ++pit;
+        continue;
+      }
+      for (size_t r = 0; r < residuals.size(); ++r) {
+        const uint64_t hnd = residuals[r];
+        const uint64_t poseId = observations_.at(hnd).poseId;
+        if ((contains(removeFrames, poseId) && hasNewObservations) ||
+            (!contains(allLinearizedFrames, poseId) && marginalize)) {
+          removeObservation(hnd);  // ok, let's ignore the observation
+          residuals.erase(residuals.begin() + r);
+          r--;
+        } else if (marginalize && contains(allLinearizedFrames, poseId)) {
+          if (obsCount < 2) {
+            removeObservation(hnd);
+            residuals.erase(residuals.begin() + r);
+            r--;
+          } else {
+            errorTermAdded = true;  // add information to be considered in marginalization later
+            selObs.push_back(hnd);
+          }
+        }
+        if (residuals.empty()) {
+          justDelete = true;
+          marginalize = false;
+        }
+      }
+      if (justDelete) {
+        removedLandmarks.push_back(mp);
+        landmarkInitialized_.erase(pit->first);
+        pit = landmarksMap_.erase(pit);
+        continue;
+      }
+      if (marginalize && errorTermAdded) {
+        margLandmarks.push_back(pit->first);
+        removedLandmarks.push_back(mp);
+        ++pit;  // the block itself is erased after the numerics below (its value is the linearisation point)
+        continue;
+      }
+      ++pit;
+    }
+  }
+
+  // ---- now apply the actual marginalization (:735-744) ----
+  const bool anything = !margPose.empty() || !margSb.empty() || !margLandmarks.empty();
+  if (anything) {
+    // every block a selected residual or the previous prior touches
+    std::vector<char> needPose(poseBlocks_.size(), 0), needSb(sbBlocks_.size(), 0);
+    for (size_t i = 0; i < imuFactors_.size(); ++i)
+      if (imuSel[i]) {
+        sel.imu.push_back((int)i);
+        needPose[imuFactors_[i].pose0Block] = needPose[imuFactors_[i].pose1Block] = 1;
+        needSb[imuFactors_[i].sb0Block] = needSb[imuFactors_[i].sb1Block] = 1;
+      }
+    for (size_t i = 0; i < posePriors_.size(); ++i)
+      if (ppSel[i]) {
+        sel.pprior.push_back((int)i);
+        needPose[posePriors_[i].block] = 1;
+      }
+    for (size_t i = 0; i < sbPriors_.size(); ++i)
+      if (sbpSel[i]) {
+        sel.sbprior.push_back((int)i);
+        needSb[sbPriors_[i].block] = 1;
+      }
+    for (size_t i = 0; i < relPoses_.size(); ++i)
+      if (relSel[i]) {
+        sel.rel.push_back((int)i);
+        needPose[relPoses_[i].block0] = needPose[relPoses_[i].block1] = 1;
+      }
+    for (uint64_t hnd : selObs) {
+      const Observation& o = observations_.at(hnd);
+      const State* st = findState(o.poseId);
+      needPose[st->poseBlock] = needPose[st->extBlocks.at(o.camIdx)] = 1;
+    }
+    for (int b : margPose) needPose[b] = 1;
+    for (int b : margSb) needSb[b] = 1;
+    for (size_t k = 0; k < prior_.block.size(); ++k)
+      (prior_.type[k] == OKVIS_BA_BLOCK_POSE ? needPose : needSb)[prior_.block[k]] = 1;
+    for (size_t i = 0; i < poseBlocks_.size(); ++i)
+      if (needPose[i]) sel.pose.push_back((int)i);
+    for (size_t i = 0; i < sbBlocks_.size(); ++i)
+      if (needSb[i]) sel.sb.push_back((int)i);
+    sel.landmarks = margLandmarks;
+    sel.obs = selObs;
+    sel.withPrior = false;
+    sel.atLinearizationPoint = true;  // first-estimate Jacobians (MarginalizationError.cpp:292-310)
+    FlatWindow fw;
+    flatten(sel, fw);
+
+    std::vector<uint8_t> pm(std::max<size_t>(1, sel.pose.size()), 0), sm(std::max<size_t>(1, sel.sb.size()), 0);
+    for (int b : margPose) pm[fw.poseMap[b]] = 1;
+    for (int b : margSb) sm[fw.sbMap[b]] = 1;
+    okvis_ba_marg_spec spec;
+    std::memset(&spec, 0, sizeof(spec));
+    spec.pose_marg = pm.data();
+    spec.sb_marg = sm.data();
+    std::vector<int32_t> pt, pi, po;
+    if (prior_.dim > 0) {
+      int off = 0;
+      for (size_t k = 0; k < prior_.block.size(); ++k) {
+        const bool pose = prior_.type[k] == OKVIS_BA_BLOCK_POSE;
+        pt.push_back(prior_.type[k]);
+        pi.push_back(pose ? fw.poseMap[prior_.block[k]] : fw.sbMap[prior_.block[k]]);
+        po.push_back(off);
+        off += pose ? 6 : 9;
+      }
+      spec.prior_dim = prior_.dim;
+      spec.prior_nblocks = (int)pt.size();
+      spec.prior_block_type = pt.data();
+      spec.prior_block_idx = pi.data();
+      spec.prior_block_off = po.data();
+      spec.prior_H = prior_.H.data();
+      spec.prior_b0 = prior_.b0.data();
+    }
+    const int cap = 6 * (int)sel.pose.size() + 9 * (int)sel.sb.size(), capb = (int)(sel.pose.size() + sel.sb.size());
+    std::vector<int32_t> bt(std::max(1, capb)), bi(std::max(1, capb)), bo(std::max(1, capb));
+    std::vector<double> Hn(std::max(1, cap * cap)), bn(std::max(1, cap)), Jn(std::max(1, cap * cap)), en(std::max(1, cap));
+    okvis_ba_marg_result res;
+    std::memset(&res, 0, sizeof(res));
+    res.capacity_dim = cap;
+    res.capacity_blocks = capb;
+    res.block_type = bt.data(); res.block_idx = bi.data(); res.block_off = bo.data();
+    res.H = Hn.data(); res.b0 = bn.data(); res.J = Jn.data(); res.e0 = en.data();
+    check(okvis_ba_set_options(solver_, &options_), "set_options");
+    check(okvis_ba_upload(solver_, 1, &fw.w), "upload (marginalisation window)");
+    check(okvis_ba_marginalize(solver_, 0, &spec, &res), "marginalize");
+
+    // the new prior over the remaining connected blocks; blocks that were connected before keep their
+    // linearisation point, newly connected ones are linearised at the current estimate
+    MargPrior np;
+    np.dim = res.dim;
+    for (int k = 0; k < res.nblocks; ++k) {
+      const bool pose = res.block_type[k] == OKVIS_BA_BLOCK_POSE;
+      const int blk = pose ? sel.pose[res.block_idx[k]] : sel.sb[res.block_idx[k]];
+      np.type.push_back(res.block_type[k]);
+      np.block.push_back(blk);
+      std::array<double, 9> lin{};
+      const double* x = (pose ? fw.f64[0].data() + 7 * res.block_idx[k] : fw.f64[1].data() + 9 * res.block_idx[k]);
+      std::copy(x, x + (pose ? 7 : 9), lin.begin());
+      np.lin.push_back(lin);
+    }
+    const size_t n = (size_t)res.dim;
+    np.H.assign(Hn.begin(), Hn.begin() + n * n);
+    np.b0.assign(bn.begin(), bn.begin() + n);
+    np.J.assign(Jn.begin(), Jn.begin() + n * n);
+    np.e0.assign(en.begin(), en.begin() + n);
+    if (np.dim == 0) np = MargPrior();  // "if(marginalizationErrorPtr_->num_residuals()==0) reset" (:747-749)
+    prior_ = np;
+  }
+
+  // ---- remove what was linearised / marginalised from the graph (Map::removeResidualBlock / removeParameterBlock)
+  auto compact = [](auto& vec, const std::vector<char>& drop) {
+    size_t o = 0;
+    for (size_t i = 0; i < vec.size(); ++i)
+      if (!drop[i]) {
+        if (o != i) vec[o] = std::move(vec[i]);
+        ++o;
+      }
+    vec.resize(o);
+  };
+  compact(imuFactors_, imuSel);
+  for (size_t i = 0; i < posePriors_.size(); ++i) ppSel[i] = ppSel[i] || ppDrop[i];
+  compact(posePriors_, ppSel);
+  compact(sbPriors_, sbpSel);
+  compact(relPoses_, relSel);
+  for (uint64_t hnd : selObs) observations_.erase(hnd);
+  {
+    std::lock_guard<std::mutex> l(statesMutex_);
+    for (uint64_t id : margLandmarks) {
+      landmarksMap_.erase(id);
+      landmarkInitialized_.erase(id);
+    }
+  }
+  for (int b : margPose) poseBlocks_[b].alive = false;
+  for (int b : margSb) sbBlocks_[b].alive = false;
+  // update book-keeping (:727-732)
+  for (uint64_t id : removeFrames) {
+    multiFramePtrMap_.erase(id);
+    for (size_t k = 0; k < states_.size(); ++k)
+      if (states_[k].id == id) {
+        states_.erase(states_.begin() + k);
+        break;
+      }
+  }
+
+  if (reDoFixation && !states_.empty()) {  // finally fix the first pose properly (:761-770)
+    std::array<double, 36> info{}, si{};
+    info[0] = info[7] = info[14] = 1.0e14;
+    info[35] = 1.0e14;
+    sqrtInformation(info, 6, si);
+    const int b = states_.front().poseBlock;
+    posePriors_.push_back(PosePrior{b, poseBlocks_[b].x, si});
+  }
+  return true;
 }
 
 // ---- getters / setters -------------------------------------------------------------------------------

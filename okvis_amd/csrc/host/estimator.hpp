@@ -136,6 +136,10 @@ class Estimator {
   void setLandmarkInitialized(uint64_t landmarkId, bool initialized);
   void setKeyframe(uint64_t frameId, bool isKeyframe);
 
+  // ---- diagnostics of the marginalisation prior (MarginalizationError::num_residuals etc.) ----
+  int priorDimension() const { return prior_.dim; }
+  size_t priorNumBlocks() const { return prior_.block.size(); }
+
   // ---- diagnostics of the last optimize() (what ::ceres::Solver::Summary exposes via Map::summary) ----
   const okvis_ba_summary& summary() const { return summary_; }
   okvis_ba_options& options() { return options_; }
@@ -158,11 +162,13 @@ class Estimator {
     std::array<double, 7> x;
     bool fixed;
     uint64_t id;
+    bool alive = true;  // false once marginalised out (Map::removeParameterBlock)
   };
   struct SbBlock {
     SpeedAndBias x;
     bool fixed;
     uint64_t id;
+    bool alive = true;
   };
   struct Observation {
     uint64_t handle, landmarkId, poseId;
@@ -170,7 +176,7 @@ class Estimator {
     double u, v, sqrtw;
   };
   struct ImuFactor {
-    uint64_t pose0Id, pose1Id;
+    int pose0Block, sb0Block, pose1Block, sb1Block;  // indices into poseBlocks_ / sbBlocks_
     int64_t t0, t1;
     ImuMeasurementDeque meas;  // the deque is COPIED into the factor (ImuError.hpp:151-153)
   };
@@ -189,11 +195,36 @@ class Estimator {
     std::array<double, 36> sqrtInfo;
   };
 
+  // The reference's MarginalizationError object (MarginalizationError.hpp:303-327): H_, b0_ persist between
+  // calls; J_, e0_ are what optimize() evaluates; one linearisation point per connected block.
+  struct MargPrior {
+    int dim = 0;
+    std::vector<int> type, block;               // OKVIS_BA_BLOCK_POSE / _SPEEDBIAS, index into poseBlocks_ / sbBlocks_
+    std::vector<std::array<double, 9>> lin;     // linearisation point (7 or 9 entries used)
+    std::vector<double> H, b0, J, e0;
+  };
+  // which blocks / factors go into one flat window
+  struct WindowSel {
+    std::vector<int> pose, sb;                  // block indices, window order
+    std::vector<uint64_t> landmarks;            // ids, window order
+    std::vector<uint64_t> obs;                  // observation handles
+    std::vector<int> imu, pprior, sbprior, rel; // indices into the factor vectors
+    bool withPrior = false;                     // attach prior_ as marg_* (optimize) or not (marginalisation)
+    bool atLinearizationPoint = false;          // values of prior-connected blocks = their linearisation point
+  };
+  struct FlatWindow {
+    std::vector<std::vector<double>> f64;
+    std::vector<std::vector<int32_t>> i32;
+    std::vector<std::vector<int64_t>> i64;
+    std::vector<std::vector<uint8_t>> u8;
+    std::vector<int> poseMap, sbMap;            // block index -> window index (-1 = not in the window)
+    okvis_ba_window w;
+  };
+
   const State* findState(uint64_t id) const;
   State* findState(uint64_t id);
-  void buildWindow(std::vector<std::vector<double>>& f64, std::vector<std::vector<int32_t>>& i32,
-                   std::vector<std::vector<int64_t>>& i64, std::vector<std::vector<uint8_t>>& u8,
-                   okvis_ba_window& w, std::vector<uint64_t>& lmOrder) const;
+  WindowSel selectAll() const;
+  void flatten(const WindowSel& sel, FlatWindow& fw) const;
 
   int device_;
   okvis_ba_solver* solver_ = nullptr;
@@ -216,6 +247,7 @@ class Estimator {
   std::vector<PosePrior> posePriors_;
   std::vector<SbPrior> sbPriors_;
   std::vector<RelPose> relPoses_;
+  MargPrior prior_;
   uint64_t nextId_ = 1ULL << 40;    // IdProvider::instance().newId() stand-in for internal blocks
   uint64_t nextHandle_ = 1;
   mutable std::mutex statesMutex_;  // guards getLandmark(s) like Estimator.cpp:936,956,965

@@ -160,6 +160,36 @@ int okvis_est_get_landmark(void* h, uint64_t id, double point[4], double* qualit
     return 1;
   });
 }
+// applyMarginalizationStrategy returning the removed landmark ids (the MapPointVector of the reference call)
+int okvis_est_apply_marginalization2(void* h, int numKeyframes, int numImuFrames, int* n_removed, uint64_t* removed_ids,
+                                     int capacity) {
+  return guarded([&] {
+    MapPointVector removed;
+    const bool ok = static_cast<Estimator*>(h)->applyMarginalizationStrategy((size_t)numKeyframes, (size_t)numImuFrames, removed);
+    if (n_removed) *n_removed = (int)removed.size();
+    for (int i = 0; i < capacity && i < (int)removed.size(); ++i) removed_ids[i] = removed[i].id;
+    return ok ? 1 : 0;
+  });
+}
+int okvis_est_prior_info(void* h, int* dim, int* nblocks) {
+  return guarded([&] {
+    *dim = static_cast<Estimator*>(h)->priorDimension();
+    *nblocks = (int)static_cast<Estimator*>(h)->priorNumBlocks();
+    return 1;
+  });
+}
+int okvis_est_frame_id_by_age(void* h, int age, uint64_t* id) {
+  return guarded([&] {
+    *id = static_cast<Estimator*>(h)->frameIdByAge((size_t)age);
+    return 1;
+  });
+}
+int okvis_est_is_keyframe(void* h, uint64_t id) {
+  return guarded([&] { return static_cast<Estimator*>(h)->isKeyframe(id) ? 1 : 0; });
+}
+int okvis_est_is_in_imu_window(void* h, uint64_t id) {
+  return guarded([&] { return static_cast<Estimator*>(h)->isInImuWindow(id) ? 1 : 0; });
+}
 int okvis_est_num_frames(void* h) { return (int)static_cast<Estimator*>(h)->numFrames(); }
 int okvis_est_num_landmarks(void* h) { return (int)static_cast<Estimator*>(h)->numLandmarks(); }
 int okvis_est_current_frame_id(void* h, uint64_t* id) {

@@ -45,6 +45,11 @@ def lib():
         L.okvis_est_get_extrinsics.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _dp]
         L.okvis_est_get_landmark.argtypes = [C.c_void_p, C.c_uint64, _dp, _dp, C.POINTER(C.c_int)]
         L.okvis_est_num_frames.argtypes = [C.c_void_p]
+        L.okvis_est_apply_marginalization2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.c_int]
+        L.okvis_est_prior_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.okvis_est_frame_id_by_age.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        L.okvis_est_is_keyframe.argtypes = [C.c_void_p, C.c_uint64]
+        L.okvis_est_is_in_imu_window.argtypes = [C.c_void_p, C.c_uint64]
         L.okvis_est_num_landmarks.argtypes = [C.c_void_p]
         L.okvis_est_init_pose_from_imu.argtypes = [C.c_int, _dp, _dp]
         L.okvis_est_propagation.argtypes = [C.c_int, _lp, _dp, _dp, _dp, _dp, _dp, C.c_int64, C.c_int64]
@@ -148,8 +153,31 @@ class Estimator:
     def setOptimizationTimeLimit(self, limit, min_iter):
         return bool(_chk(lib().okvis_est_set_time_limit(self._h, float(limit), int(min_iter))))
 
-    def applyMarginalizationStrategy(self, numKeyframes, numImuFrames):
-        return bool(_chk(lib().okvis_est_apply_marginalization(self._h, numKeyframes, numImuFrames)))
+    def applyMarginalizationStrategy(self, numKeyframes, numImuFrames, removed=None):
+        """removed: optional list that receives the ids of the removed landmarks (okvis::MapPointVector&)."""
+        n = C.c_int()
+        cap = 1 << 16
+        ids = (C.c_uint64 * cap)()
+        ok = bool(_chk(lib().okvis_est_apply_marginalization2(self._h, numKeyframes, numImuFrames, C.byref(n), ids, cap)))
+        if removed is not None:
+            removed.extend(int(ids[i]) for i in range(min(n.value, cap)))
+        return ok
+
+    def priorInfo(self):
+        d, nb = C.c_int(), C.c_int()
+        _chk(lib().okvis_est_prior_info(self._h, C.byref(d), C.byref(nb)))
+        return d.value, nb.value
+
+    def frameIdByAge(self, age):
+        i = C.c_uint64()
+        _chk(lib().okvis_est_frame_id_by_age(self._h, int(age), C.byref(i)))
+        return i.value
+
+    def isKeyframe(self, frame_id):
+        return bool(_chk(lib().okvis_est_is_keyframe(self._h, C.c_uint64(frame_id))))
+
+    def isInImuWindow(self, frame_id):
+        return bool(_chk(lib().okvis_est_is_in_imu_window(self._h, C.c_uint64(frame_id))))
 
     def get_T_WS(self, pose_id):
         out = np.zeros(7)

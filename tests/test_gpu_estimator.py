@@ -2,7 +2,7 @@
 :52-238): 2 equidistant cameras (baseline 0.1 m), a wall of landmarks at x = 3 m, constant-velocity motion,
 IMU at 100 Hz, pixel noise U(-1,1), keypoint size 8, optimize(10,4,false) after every frame; final errors
 ||d speed&bias|| < 0.04, rotation < 1e-2, translation < 1e-1 (TestEstimator.cpp:229-236).
-applyMarginalizationStrategy (TestEstimator.cpp:210-214) is the next row and must say so."""
+applyMarginalizationStrategy(2, 3) + a last optimize as in TestEstimator.cpp:207-213."""
 import numpy as np
 import pytest
 
@@ -72,8 +72,17 @@ def test_estimator_constant_velocity(c):
         s = est.optimize(10, 4, False)
         assert s["final_cost"] <= s["initial_cost"] * (1 + 1e-9)
     # a duplicate observation returns NULL/0 (implementation/Estimator.hpp:52-56)
-    with pytest.raises(estimator.EstimatorError, match="not implemented"):
-        est.applyMarginalizationStrategy(2, 3)
+    # try out the marginalization strategy, then the last optimization (TestEstimator.cpp:207-213)
+    removed = []
+    n_before, l_before = est.numFrames(), est.numLandmarks()
+    assert est.applyMarginalizationStrategy(2, 3, removed)
+    older_kf = sum(1 for k in range(K + 1 - 3) if k % 3 == 0)
+    assert est.numFrames() == 3 + min(2, older_kf)        # newest 3 + up to 2 keyframes kept among the older ones
+    assert est.numFrames() < n_before and est.numLandmarks() == l_before - len(removed)
+    dim, nb = est.priorInfo()
+    assert dim > 0 and nb >= 3                            # kept keyframe poses + the oldest IMU-window pose/speed-bias
+    s = est.optimize(10, 4, False)
+    assert s["final_cost"] <= s["initial_cost"] * (1 + 1e-9)
     T = est.get_T_WS(last_id)
     sb = est.getSpeedAndBias(last_id)
     r_true = speed * DURATION
