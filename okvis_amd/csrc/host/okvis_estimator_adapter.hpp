@@ -104,7 +104,13 @@ class Estimator : public VioBackendInterface {
   bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, okvis::MapPointVector& removed) override {
     okvis_amd::MapPointVector r;
     const bool ok = impl_.applyMarginalizationStrategy(numKeyframes, numImuFrames, r);
-    (void)removed;  // filled once the marginalisation row is built
+    for (const okvis_amd::MapPoint& m : r) {  // okvis::MapPoint(id, point, quality, distance), FrameTypedefs.hpp
+      okvis::MapPoint mp(m.id, Eigen::Vector4d(m.point[0], m.point[1], m.point[2], m.point[3]), m.quality, m.distance);
+      for (const auto& ob : m.observations)
+        mp.observations.insert(std::make_pair(
+            okvis::KeypointIdentifier(ob.first.frameId, ob.first.cameraIndex, ob.first.keypointIndex), ob.second));
+      removed.push_back(mp);
+    }
     return ok;
   }
   void optimize(size_t numIter, size_t numThreads = 1, bool verbose = false) override {

@@ -90,3 +90,80 @@ def test_estimator_constant_velocity(c):
     assert 2 * np.linalg.norm(T[3:6]) < 1e-2
     assert np.linalg.norm(T[:3] - r_true) < 1e-1
     est.close()
+
+
+def test_sliding_window_with_marginalization_every_frame():
+    """What ThreadedKFVio does per frame (ThreadedKFVio.cpp:736-765): optimize, then
+    applyMarginalizationStrategy(numKeyframes=5, numImuFrames=3) — 20 frames, so the prior is re-linearised
+    and re-marginalised many times (chained H_/b0_, first-estimate linearisation points kept per block)."""
+    rng = np.random.default_rng(7)
+    IMU_RATE, N_FRAMES, FRAME_DT = 100.0, 20, 0.5
+    DT = 1.0 / IMU_RATE
+    DURATION = N_FRAMES * FRAME_DT
+    prm = ImuParams(sigma_g_c=6.0e-4, sigma_a_c=2.0e-3, sigma_gw_c=3.0e-6, sigma_aw_c=2.0e-5, g=9.81,
+                    g_max=1000.0, a_max=1000.0)
+    speed = np.array([0.0, 1.0, 0.0])
+    n_imu = int(DURATION * IMU_RATE) + 2
+    t_imu = (np.arange(n_imu) * int(round(DT * 1e9))).astype(np.int64) + 1_000_000_000
+    gyr = rng.uniform(-1, 1, (n_imu, 3)) * prm.sigma_g_c * np.sqrt(DT)
+    acc = np.array([0, 0, prm.g]) + rng.uniform(-1, 1, (n_imu, 3)) * prm.sigma_a_c * np.sqrt(DT)
+    T_SC = np.array([[0, 0, 0, 0, 0, 0, 1.0], [0, 0.1, 0, 0, 0, 0, 1.0]])
+    intr = np.stack([synthetic.TEST_INTR_EQUI, synthetic.TEST_INTR_EQUI])
+    est = estimator.Estimator(0)
+    est.addCamera(0, 0, 0, 0)
+    est.addCamera(0, 0, 0, 0)
+    est.addImu(estimator.imu_param_vector(prm))
+    pts = np.array([[3.0, y, z, 1.0] for y in np.arange(-6.0, DURATION + 6.0, 0.75) for z in np.arange(-6.0, 6.0 + 1e-9, 0.75)])
+    ids = 5000 + np.arange(len(pts))
+    added, all_removed = set(), []
+    frames = []
+    prev_t = None
+    for k in range(N_FRAMES):
+        t_k = 1_000_000_000 + int(round(k * FRAME_DT * 1e9))
+        r_k = speed * k * FRAME_DT
+        f = estimator.Frame(100 + k, t_k, T_SC, intr, [DIST_EQUIDISTANT] * 2)
+        frames.append(f)
+        lo = np.searchsorted(t_imu, (prev_t if k else t_k) - 20_000_000)
+        hi = np.searchsorted(t_imu, t_k + 20_000_000) + 1
+        assert est.addStates(f, t_imu[lo:hi], gyr[lo:hi], acc[lo:hi], k % 3 == 0)
+        prev_t = t_k
+        n_obs = 0
+        for i in range(2):
+            p_C = pts[:, :3] - r_k - T_SC[i, :3]
+            uv, ok = synthetic.project_points(intr[i], DIST_EQUIDISTANT, p_C)
+            near = ok & (np.abs(pts[:, 1] - r_k[1]) < 5.0)
+            for j in np.flatnonzero(near):
+                lid = int(ids[j])
+                if lid in all_removed:
+                    continue
+                if lid not in added:
+                    assert est.addLandmark(lid, pts[j] + np.r_[rng.normal(size=3) * 0.05, 0])
+                    added.add(lid)
+                m = uv[j] + rng.uniform(-1, 1, 2)
+                kp = f.add_keypoint(i, m[0], m[1], 8.0)
+                assert est.addObservation(lid, f.id, i, kp) != 0
+                n_obs += 1
+        assert n_obs > 50
+        s = est.optimize(5, 2, False)
+        assert np.isfinite(s["final_cost"]) and s["final_cost"] <= s["initial_cost"] * (1 + 1e-9)
+        removed = []
+        assert est.applyMarginalizationStrategy(5, 3, removed)
+        all_removed += removed
+        assert est.numFrames() <= 8
+        if k >= 3:
+            dim, nb = est.priorInfo()
+            assert dim >= 6 + 9 and nb >= 2
+        # the newest three frames keep their speed/bias block, older ones do not (Estimator.cpp:485-554)
+        for age in range(est.numFrames()):
+            assert est.isInImuWindow(est.frameIdByAge(age)) == (age < 3)
+    assert len(all_removed) > 0 and len(set(all_removed)) == len(all_removed)
+    for lid in all_removed[:5]:
+        with pytest.raises(estimator.EstimatorError):
+            est.getLandmark(lid)
+    T = est.get_T_WS(frames[-1].id)
+    sb = est.getSpeedAndBias(frames[-1].id)
+    r_true = speed * (N_FRAMES - 1) * FRAME_DT
+    assert np.linalg.norm(sb - np.r_[speed, np.zeros(6)]) < 0.04
+    assert 2 * np.linalg.norm(T[3:6]) < 1e-2
+    assert np.linalg.norm(T[:3] - r_true) < 1e-1
+    est.close()
