@@ -321,6 +321,7 @@ typedef struct okvis_ba_marg_result {
   double* b0;                             /* [dim] */
   double* J;                              /* [dim][dim]: J^T J = H up to the dropped eigenvalues */
   double* e0;                             /* [dim] */
+  int32_t sweeps[2];                      /* out (diagnostic): Jacobi sweeps of the two eigen-decompositions */
 } okvis_ba_marg_result;
 
 int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* result);

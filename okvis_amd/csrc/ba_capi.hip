@@ -1311,7 +1311,16 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   ma.out_b0 = outp + 2 * nn;
   ma.out_e0 = outp + 2 * nn + n1;
   ma.out_info = reinterpret_cast<int*>(d + o_info);
-  hipLaunchKernelGGL(marg_dense_kernel, dim3(1), dim3(MARG_THREADS), 0, s->stream, d_win, 0, ma);
+  {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(marg_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  MARG_LDS_DOUBLES * 8));
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(marg_dense_kernel, dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES * 8, s->stream, d_win, 0, ma,
+                     MARG_LDS_DOUBLES);
   HIP_TRY(hipGetLastError());
   od.marg_mode = 0;
   HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
@@ -1328,6 +1337,8 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   res->dim = na;
   res->nblocks = (int)bt.size();
   res->rank = info[2];
+  res->sweeps[0] = info[3];
+  res->sweeps[1] = info[4];
   for (size_t k = 0; k < bt.size(); ++k) {
     res->block_type[k] = bt[k];
     res->block_idx[k] = bi[k];

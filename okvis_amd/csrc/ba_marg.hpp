@@ -17,7 +17,7 @@
 namespace ba {
 
 constexpr int MARG_THREADS = 1024;
-constexpr int MARG_MAX_PAIRS = (MAX_D_LDS + 2) / 2;
+constexpr int MARG_LDS_DOUBLES = 18 * 1024;  // 144 KB of dynamic LDS for the eigen-solver buffers
 
 struct MargArgs {
   const unsigned char* pose_marg;  // [n_pose] 1 = eliminate this block in the dense step
@@ -36,85 +36,124 @@ struct MargArgs {
   int* out_info;           // [0] na, [1] nm, [2] rank, [3] Jacobi sweeps (V), [4] Jacobi sweeps (H), [8 + i] kept reduced index i
 };
 
-struct JacobiScratch {
-  int p[MARG_MAX_PAIRS], q[MARG_MAX_PAIRS];
-  double c[MARG_MAX_PAIRS], s[MARG_MAX_PAIRS];
+// Round-robin pairing of m (even) players: round r in [0, m-1), pair k in [0, m/2) -> (p, q), p < q.
+__device__ __forceinline__ void rr_pair(int m, int r, int k, int* p, int* q) {
+  int a, b;
+  if (k == 0) {
+    a = m - 1;
+    b = r;
+  } else {
+    a = (r + k) % (m - 1);
+    b = (r - k + (m - 1)) % (m - 1);
+  }
+  *p = a < b ? a : b;
+  *q = a < b ? b : a;
+}
+// Jacobi rotation that annihilates X[p][q]: G = [[c, s], [-s, c]] (identity when already negligible or when
+// q is the padding index of an odd-sized matrix).  Every work-item that needs the rotation of a pair recomputes
+// it from the same three numbers, so all of them take the same decision.
+__device__ __forceinline__ bool jacobi_rot(const double* X, int n, int p, int q, double thr, double* c, double* s) {
+  *c = 1.0;
+  *s = 0.0;
+  if (q >= n) return false;
+  const double apq = X[p * n + q], app = X[p * n + p], aqq = X[q * n + q];
+  // negligible relative to the two diagonal entries, or below the absolute accuracy eps * max|diag| any
+  // backward-stable symmetric eigen-solver delivers (graded matrices never reach the relative test)
+  if (fabs(apq) <= thr || fabs(apq) <= 2.220446049250313e-16 * sqrt(fabs(app * aqq))) return false;
+  // tan of the rotation angle: only needs to be accurate enough to keep the quadratic convergence, so the two
+  // divisions and the square root use the hardware approximations (v_rcp_f64 / v_rsq_f64, ~1e-8 relative);
+  // c = (1 + t^2)^-1/2 is refined by two Newton steps to full precision, which is what keeps Q orthogonal
+  const double theta = (aqq - app) * (0.5 * __builtin_amdgcn_rcp(apq));
+  const double h2 = theta * theta + 1.0;
+  const double hyp = h2 * __builtin_amdgcn_rsq(h2);
+  const double t = (theta >= 0 ? 1.0 : -1.0) * __builtin_amdgcn_rcp(fabs(theta) + hyp);
+  const double u = t * t + 1.0;
+  double y = __builtin_amdgcn_rsq(u);
+  y = y * (1.5 - 0.5 * u * y * y);
+  y = y * (1.5 - 0.5 * u * y * y);
+  *c = y;
+  *s = t * y;
+  return true;
+}
+
+struct JacobiTab {  // the n/2 disjoint rotations of one round
+  int p[MAX_D_LDS / 2 + 1], q[MAX_D_LDS / 2 + 1];
+  double c[MAX_D_LDS / 2 + 1], s[MAX_D_LDS / 2 + 1];
   int rotated;
+  double thr;
 };
 
-// A (n x n row-major, symmetric) -> eigenvalues on its diagonal; Q <- eigenvectors (columns).  Returns sweeps.
-__device__ int jacobi_eig(double* A, double* Q, int n, int tid, JacobiScratch& js) {
+// Symmetric eigen-decomposition by cyclic Jacobi, round-robin parallel ordering.  Per round: (1) n/2 work-items
+// compute the disjoint rotations into LDS, (2) the rotations split the matrix into (n/2)^2 independent 2x2
+// blocks B(k1,k2) <- G_k1^T B G_k2 — one work-item each, in place — and Q <- Q G by column pairs.
+// X holds the input and the result (eigenvalues on the diagonal).  X / Q may live in LDS or in global memory.
+__device__ void jacobi_eig(double* X, double* Q, int n, int tid, JacobiTab& jt, int* sweeps) {
   for (int k = tid; k < n * n; k += MARG_THREADS) Q[k] = (k / n == k % n) ? 1.0 : 0.0;
+  if (tid == 0) {
+    double dmax = 0.0;
+    for (int i = 0; i < n; ++i) dmax = fmax(dmax, fabs(X[i * n + i]));
+    jt.thr = fmax(2.220446049250313e-16 * dmax, 1e-300);
+  }
   __syncthreads();
-  if (n < 2) return 0;
+  *sweeps = 0;
+  if (n < 2) return;
+  const double thr = jt.thr;
   const int m = (n + 1) & ~1, half = m / 2;
   int sweep = 0;
   for (; sweep < 60; ++sweep) {
-    if (tid == 0) js.rotated = 0;
+    if (tid == 0) jt.rotated = 0;
     __syncthreads();
     for (int r = 0; r < m - 1; ++r) {
       if (tid < half) {
-        int a, b;
-        if (tid == 0) {
-          a = m - 1;
-          b = r;
-        } else {
-          a = (r + tid) % (m - 1);
-          b = (r - tid + (m - 1)) % (m - 1);
-        }
-        const int p = a < b ? a : b, q = a < b ? b : a;
-        int pp = -1;
-        double c = 1.0, s = 0.0;
-        if (q < n) {
-          const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
-          if (fabs(apq) >= 1e-300 && fabs(apq) > 2.220446049250313e-16 * sqrt(fabs(app * aqq))) {
-            const double theta = (aqq - app) / (2.0 * apq);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            c = 1.0 / sqrt(t * t + 1.0);
-            s = t * c;
-            pp = p;
-            js.rotated = 1;
-          }
-        }
-        js.p[tid] = pp;
-        js.q[tid] = q;
-        js.c[tid] = c;
-        js.s[tid] = s;
+        int p, q;
+        rr_pair(m, r, tid, &p, &q);
+        double c, s;
+        const bool rot = jacobi_rot(X, n, p, q, thr, &c, &s);
+        jt.p[tid] = p;
+        jt.q[tid] = q < n ? q : -1;
+        jt.c[tid] = c;
+        jt.s[tid] = s;
+        if (rot) jt.rotated = 1;
       }
       __syncthreads();
-      for (int it = tid; it < half * n; it += MARG_THREADS) {  // A <- A G, Q <- Q G
+      for (int it = tid; it < half * half; it += MARG_THREADS) {
+        const int k1 = it / half, k2 = it - k1 * half;
+        const double c1 = jt.c[k1], s1 = jt.s[k1], c2 = jt.c[k2], s2 = jt.s[k2];
+        if (s1 == 0.0 && s2 == 0.0) continue;
+        const int p1 = jt.p[k1], q1 = jt.q[k1], p2 = jt.p[k2], q2 = jt.q[k2];
+        const bool v1 = q1 >= 0, v2 = q2 >= 0;  // -1: padding index of an odd-sized matrix
+        const double bpp = X[p1 * n + p2];
+        const double bpq = v2 ? X[p1 * n + q2] : 0.0;
+        const double bqp = v1 ? X[q1 * n + p2] : 0.0;
+        const double bqq = (v1 && v2) ? X[q1 * n + q2] : 0.0;
+        const double tpp = c2 * bpp - s2 * bpq, tpq = s2 * bpp + c2 * bpq;
+        const double tqp = c2 * bqp - s2 * bqq, tqq = s2 * bqp + c2 * bqq;
+        X[p1 * n + p2] = c1 * tpp - s1 * tqp;
+        if (v2) X[p1 * n + q2] = c1 * tpq - s1 * tqq;
+        if (v1) X[q1 * n + p2] = s1 * tpp + c1 * tqp;
+        if (v1 && v2) X[q1 * n + q2] = s1 * tpq + c1 * tqq;
+      }
+      for (int it = tid; it < half * n; it += MARG_THREADS) {  // Q <- Q G
         const int k = it / n, i = it - k * n;
-        const int p = js.p[k];
-        if (p < 0) continue;
-        const int q = js.q[k];
-        const double c = js.c[k], s = js.s[k];
-        const double aip = A[i * n + p], aiq = A[i * n + q];
-        A[i * n + p] = c * aip - s * aiq;
-        A[i * n + q] = s * aip + c * aiq;
+        const double s = jt.s[k];
+        if (s == 0.0) continue;
+        const double c = jt.c[k];
+        const int p = jt.p[k], q = jt.q[k];
         const double qip = Q[i * n + p], qiq = Q[i * n + q];
         Q[i * n + p] = c * qip - s * qiq;
         Q[i * n + q] = s * qip + c * qiq;
       }
       __syncthreads();
-      for (int it = tid; it < half * n; it += MARG_THREADS) {  // A <- G^T A
-        const int k = it / n, j = it - k * n;
-        const int p = js.p[k];
-        if (p < 0) continue;
-        const int q = js.q[k];
-        const double c = js.c[k], s = js.s[k];
-        const double apj = A[p * n + j], aqj = A[q * n + j];
-        A[p * n + j] = c * apj - s * aqj;
-        A[q * n + j] = s * apj + c * aqj;
-      }
-      __syncthreads();
     }
-    if (!js.rotated) break;
+    if (!jt.rotated) break;
     __syncthreads();
   }
-  return sweep;
+  *sweeps = sweep;
 }
 
-__global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs* __restrict__ wins, int w, MargArgs a) {
+__global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs* __restrict__ wins, int w, MargArgs a,
+                                                                   int lds_doubles) {
+  extern __shared__ __attribute__((aligned(16))) double marg_lds[];
   const WinPtrs& W = wins[w];
   const int tid = threadIdx.x;
   const int D = W.D;
@@ -122,9 +161,9 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   double* b = W.rhs;   // [D]
   __shared__ int s_kidx[MAX_D_LDS], s_midx[MAX_D_LDS], s_ridx[MAX_MARG_DIM];
   __shared__ double s_p[MAX_D_LDS], s_t[MAX_D_LDS], s_lam[MAX_D_LDS], s_ba[MAX_D_LDS];
-  __shared__ int s_na, s_nm, s_rank;
+  __shared__ int s_na, s_nm;
   __shared__ double s_max;
-  __shared__ JacobiScratch js;
+  __shared__ JacobiTab jt;
   const double EPS = 2.220446049250313e-16;
 
   // ---- previous prior: H_ and b0_ persist inside the reference's MarginalizationError object ----
@@ -168,22 +207,28 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
     if (s_ridx[rr] >= 0) b[s_ridx[rr]] += a.prior_b0[rr];
   __syncthreads();
   const int na = s_na, nm = s_nm;
-  double* A = a.work;
-  double* Q = a.work + (size_t)D * D;
+  // eigen-solver buffers (matrix + eigenvectors): in LDS when they fit, else in the HBM workspace
   double* M = a.work + 2 * (size_t)D * D;
+  auto pick = [&](int n, double** Xp, double** Qp) {
+    const int nn = n * n;
+    *Xp = nn <= lds_doubles ? marg_lds : a.work;
+    *Qp = 2 * nn <= lds_doubles ? marg_lds + nn : a.work + (size_t)D * D;
+  };
+  double *A, *Q;
   int sweeps_v = 0;
 
   if (nm > 0) {
     // ---- dense part of marginalizeOut (:686-736) ----
     for (int i = tid; i < D; i += MARG_THREADS) s_p[i] = H[i * D + i] > 1.0e-9 ? sqrt(H[i * D + i]) : 1.0e-3;  // :689
     __syncthreads();
+    pick(nm, &A, &Q);
     for (int k = tid; k < nm * nm; k += MARG_THREADS) {  // V1 = 0.5 (V + V^T) of the scaled system (:725)
       const int i = k / nm, j = k - i * nm;
       const int mi = s_midx[i], mj = s_midx[j];
       A[k] = 0.5 * (H[mi * D + mj] / (s_p[mi] * s_p[mj]) + H[mj * D + mi] / (s_p[mj] * s_p[mi]));
     }
     __syncthreads();
-    sweeps_v = jacobi_eig(A, Q, nm, tid, js);
+    jacobi_eig(A, Q, nm, tid, jt, &sweeps_v);
     if (tid == 0) {
       double mx = A[0];
       for (int i = 1; i < nm; ++i) mx = fmax(mx, A[i * nm + i]);
@@ -242,12 +287,14 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   const double* Ha = a.out_H;
   for (int i = tid; i < na; i += MARG_THREADS) s_p[i] = Ha[i * na + i] > 1.0e-9 ? sqrt(Ha[i * na + i]) : 1.0e-3;
   __syncthreads();
+  pick(na, &A, &Q);
   for (int k = tid; k < na * na; k += MARG_THREADS) {
     const int i = k / na, j = k - i * na;
     A[k] = 0.5 * (Ha[i * na + j] + Ha[j * na + i]) / (s_p[i] * s_p[j]);
   }
   __syncthreads();
-  const int sweeps_h = jacobi_eig(A, Q, na, tid, js);
+  int sweeps_h = 0;
+  jacobi_eig(A, Q, na, tid, jt, &sweeps_h);
   if (tid == 0) {
     double mx = A[0];
     for (int i = 1; i < na; ++i) mx = fmax(mx, A[i * na + i]);

@@ -87,7 +87,7 @@ class MargResultC(C.Structure):
     """ctypes image of ``okvis_ba_marg_result``."""
     _fields_ = [("capacity_dim", C.c_int32), ("capacity_blocks", C.c_int32), ("dim", C.c_int32),
                 ("nblocks", C.c_int32), ("rank", C.c_int32), ("block_type", _ip), ("block_idx", _ip),
-                ("block_off", _ip), ("H", _dp), ("b0", _dp), ("J", _dp), ("e0", _dp)]
+                ("block_off", _ip), ("H", _dp), ("b0", _dp), ("J", _dp), ("e0", _dp), ("sweeps", C.c_int32 * 2)]
 
 
 def marg_call(fn, n_pose, n_sb, pose_marg, sb_marg, prior=None):
@@ -131,7 +131,7 @@ def marg_call(fn, n_pose, n_sb, pose_marg, sb_marg, prior=None):
     if status != 0:
         return status, None
     n, nb = int(res.dim), int(res.nblocks)
-    return 0, dict(dim=n, rank=int(res.rank), block_type=out["block_type"][:nb].copy(), block_idx=out["block_idx"][:nb].copy(),
+    return 0, dict(dim=n, rank=int(res.rank), sweeps=(int(res.sweeps[0]), int(res.sweeps[1])), block_type=out["block_type"][:nb].copy(), block_idx=out["block_idx"][:nb].copy(),
                    block_off=out["block_off"][:nb].copy(), H=out["H"][:n * n].reshape(n, n).copy(), b0=out["b0"][:n].copy(),
                    J=out["J"][:n * n].reshape(n, n).copy(), e0=out["e0"][:n].copy())
 

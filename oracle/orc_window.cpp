@@ -848,12 +848,15 @@ void sym_eig(const Vec& Ain, int n, Vec* ev, Vec* Qout) {
   Vec A(Ain), Q((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i) Q[(size_t)i * n + i] = 1.0;
   const double eps = std::numeric_limits<double>::epsilon();
+  double dmax = 0.0;
+  for (int i = 0; i < n; ++i) dmax = std::max(dmax, std::fabs(A[(size_t)i * n + i]));
+  const double thr = std::max(eps * dmax, 1e-300);  // absolute accuracy of a backward-stable solver
   for (int sweep = 0; sweep < 100; ++sweep) {
     bool rotated = false;
     for (int p = 0; p < n - 1; ++p)
       for (int q = p + 1; q < n; ++q) {
         const double apq = A[(size_t)p * n + q], app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
-        if (std::fabs(apq) < 1e-300 || std::fabs(apq) <= eps * std::sqrt(std::fabs(app * aqq))) continue;
+        if (std::fabs(apq) <= thr || std::fabs(apq) <= eps * std::sqrt(std::fabs(app * aqq))) continue;
         rotated = true;
         const double theta = (aqq - app) / (2.0 * apq);
         const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
@@ -1087,6 +1090,7 @@ int orc_window_marginalize(orc_window* h, const okvis_ba_marg_spec* spec, okvis_
     res->block_off[k] = bo[k];
   }
   res->rank = 0;
+  res->sweeps[0] = res->sweeps[1] = 0;
   if (na == 0) return 0;
   // ---- updateErrorComputation (:806-846) ----
   Vec p(na), A((size_t)na * na), ev, Q;

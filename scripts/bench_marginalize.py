@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Timing of okvis_ba_marginalize next to the CPU oracle on the same sub-window.
+Prints one JSON line.  Two shapes: what the stock pipeline hands over per frame (6 frames, 150 landmarks,
+~1.4 k observations, one pose + two speed/bias blocks eliminated) and a BASELINE-configs[1]-sized window."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from okvis_amd import solver, synthetic  # noqa: E402
+from okvis_amd.window import default_options  # noqa: E402
+from tests import oracle_lib  # noqa: E402  (test infrastructure: CPU baseline only)
+
+
+def run(name, w, poses, sbs, reps=20):
+    pm = np.zeros(w.n_pose, np.uint8); sm = np.zeros(w.n_sb, np.uint8)
+    pm[poses] = 1; sm[sbs] = 1
+    b = solver.WindowBatch([w], options=default_options())
+    g = b.marginalize(0, pm, sm)          # warm-up (module load, allocations)
+    b.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g = b.marginalize(0, pm, sm)
+    t_gpu = (time.perf_counter() - t0) / reps
+    b.close()
+    o = oracle_lib.OracleWindow(w)
+    t0 = time.perf_counter()
+    n_cpu = 3
+    for _ in range(n_cpu):
+        r = oracle_lib.OracleWindow(w).marginalize(pm, sm)
+    t_cpu = (time.perf_counter() - t0) / n_cpu
+    err = np.abs(g["H"] - r["H"]).max() / np.abs(r["H"]).max()
+    return {"case": name, "observations": int(w.n_obs), "landmarks": int(w.n_lm), "reduced_dim": int(o.D),
+            "prior_dim": int(g["dim"]), "jacobi_sweeps": list(g["sweeps"]), "gpu_ms_per_call": t_gpu * 1e3, "cpu_oracle_ms_per_call": t_cpu * 1e3,
+            "H_rel_diff": float(err)}
+
+
+def main():
+    out = [run("pipeline-like", synthetic.small_window(seed=9, K=6, L=150, visibility=0.8), [0], [0, 1]),
+           run("configs[1]-sized", synthetic.config_A(), [0, 1], [0, 1, 2, 3, 4], reps=10)]
+    print(json.dumps({"marginalize": out, "note": "gpu = whole okvis_ba_marginalize call (linearise + landmark Schur + "
+                      "dense elimination + 2 Jacobi eigen-decompositions + download), window already uploaded; "
+                      "cpu = oracle restatement on the full dense matrix, 1 thread, not Eigen"}))
+
+
+if __name__ == "__main__":
+    main()
