@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-iters", type=int, default=0, help="oracle iterations for the CPU baseline (0 = auto ~12 s)")
     p.add_argument("--profile-steps", type=int, default=20, help="eager per-kernel HIP-event pass for the roofline")
+    p.add_argument("--fp32", action="store_true", help="BASELINE configs[4]: fp32 Jacobian/Hessian build, fp64 solve (dtype f32+f64)")
     p.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE passes (roofline.traffic = null)")
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return p.parse_args()
@@ -71,7 +72,7 @@ def pmc_traffic(a, kernel):
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--windows", str(a.windows),
                "--keyframes", str(a.keyframes), "--landmarks", str(a.landmarks), "--visibility", str(a.visibility),
-               "--steps", "12", "--warmup", "4", "--no-graph"]
+               "--steps", "12", "--warmup", "4", "--no-graph"] + (["--fp32"] if a.fp32 else [])
         try:
             subprocess.run(cmd, timeout=240, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
@@ -112,6 +113,7 @@ def main():
     opt.parameter_tolerance = 0.0
     opt.use_graph = 0 if a.no_graph else 1
     opt.n_streams = a.streams
+    opt.fp32_linearize = 1 if a.fp32 else 0
     opt.gauss_newton = 1  # every timed iteration does identical full work (no trust-region collapse at the optimum)
     batch = solver.WindowBatch(wins, device=local_rank, options=opt)
 
@@ -200,7 +202,7 @@ def main():
             "metric": "Gauss-Newton iterations/sec on 10-KF x 2-cam x 400-landmark windows (batch throughput: window-iterations/s)",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f32+f64" if a.fp32 else "f64", "data": "synthetic",
             "config": {"workload": f"{a.windows} independent windows per GPU of BASELINE configs[1] "
                                    f"({a.keyframes} KF / 2 cam / {a.landmarks} landmarks / {wins[0].n_obs} obs / "
                                    f"{wins[0].n_imu} IMU factors x ~100 samples, fp64), Gauss-Newton mode, tolerances off",

@@ -561,7 +561,11 @@ void relocate(WinPtrs& P, unsigned char* base, bool debug) {
   if (P.D <= MAX_D_LDS) P.Sg = nullptr;
 }
 
-size_t lin_smem(bool ext) { return (ext ? LinCfg<true>::SMEM_DOUBLES : LinCfg<false>::SMEM_DOUBLES) * sizeof(double); }
+size_t lin_smem(bool ext, bool f32 = false) {
+  const int d = f32 ? (ext ? LinCfg<true, float>::SMEM_DOUBLES : LinCfg<false, float>::SMEM_DOUBLES)
+                    : (ext ? LinCfg<true, double>::SMEM_DOUBLES : LinCfg<false, double>::SMEM_DOUBLES);
+  return (size_t)d * sizeof(double);
+}
 size_t solve_smem(int Dpad, bool large = false) {
   const size_t nbk = Dpad / 6;
   return ((large ? 0 : nbk * (nbk + 1) / 2 * 38) + 4 * (size_t)Dpad + 2 * nbk * 36) * sizeof(double) + ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15));
@@ -597,12 +601,19 @@ hipError_t launch_small(okvis_ba_solver* s, Sub b, int init) {
 }
 hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
   if (s->max_group == 0) return hipSuccess;
-  if (s->any_ext)
-    hipLaunchKernelGGL(linearize_kernel<true>, dim3(s->max_group, (unsigned)b.nw), dim3(LIN_THREADS), lin_smem(true), b.st,
-                       s->d_wins + b.w0, s->d_opt, init);
-  else
-    hipLaunchKernelGGL(linearize_kernel<false>, dim3(s->max_group, (unsigned)b.nw), dim3(LIN_THREADS), lin_smem(false), b.st,
-                       s->d_wins + b.w0, s->d_opt, init);
+  const dim3 grid(s->max_group, (unsigned)b.nw), blk(LIN_THREADS);
+  const bool f32 = s->opt.fp32_linearize != 0;
+  if (s->any_ext) {
+    if (f32)
+      hipLaunchKernelGGL((linearize_kernel<true, float>), grid, blk, lin_smem(true, true), b.st, s->d_wins + b.w0, s->d_opt, init);
+    else
+      hipLaunchKernelGGL((linearize_kernel<true, double>), grid, blk, lin_smem(true), b.st, s->d_wins + b.w0, s->d_opt, init);
+  } else {
+    if (f32)
+      hipLaunchKernelGGL((linearize_kernel<false, float>), grid, blk, lin_smem(false, true), b.st, s->d_wins + b.w0, s->d_opt, init);
+    else
+      hipLaunchKernelGGL((linearize_kernel<false, double>), grid, blk, lin_smem(false), b.st, s->d_wins + b.w0, s->d_opt, init);
+  }
   return hipGetLastError();
 }
 hipError_t launch_iteration(okvis_ba_solver* s, Sub b) {
@@ -680,7 +691,7 @@ void okvis_ba_default_options(okvis_ba_options* o) {
   o->debug_arrays = 0;
   o->gauss_newton = 0;
   o->n_streams = 0;
-  o->reserved = 0;
+  o->fp32_linearize = 0;
 }
 
 const char* okvis_ba_error_string(int status) {
@@ -713,10 +724,16 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   if (e == hipSuccess) e = hipMalloc(&s->d_opt, sizeof(OptD));
   // kernels may use more than the default 64 KB of dynamic LDS
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<true, double>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lin_smem(true));
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lin_smem(true, true));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<false, float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lin_smem(false, true));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<false, double>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lin_smem(false));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -764,6 +781,7 @@ int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt) {
   if (s->uploaded && (opt->debug_arrays != s->opt.debug_arrays || opt->schur_lm_per_block != s->opt.schur_lm_per_block ||
                       opt->n_streams != s->opt.n_streams))
     return OKVIS_BA_ERR_STATE;  // these two shape the arena: set them before upload
+  if (opt->fp32_linearize != s->opt.fp32_linearize) destroy_graphs(s);  // captured graphs name the other kernel
   s->opt = *opt;
   HIP_TRY(hipSetDevice(s->device));
   OptD d = make_optd(s->opt);

@@ -12,22 +12,30 @@
 //            J^T J / J^T r partials, pose-extrinsics cross blocks, cost
 //
 // HBM traffic per observation: the 32-byte record in, nothing out (W is per pair, not per observation).
+//
+// REAL = double: the reference's arithmetic.  REAL = float: BASELINE configs[4], "fp32 Jacobian/Hessian build
+// with fp64 reduced-camera solve" — phase B evaluates residual and Jacobians in fp32 (reproj_linearize_mixed),
+// the staged tiles and every phase-C accumulator are fp32; state, back-substitution (phase A) and everything
+// downstream (Schur, solve) stay fp64.
 #pragma once
+#include <type_traits>
+
 #include "ba_device.hpp"
 
 namespace ba {
 
 enum { ST_R = 0, ST_JP = 2, ST_JL = 14, ST_IRHO = 20, ST_COST = 21, ST_JE = 22 };
-template <bool EXT>
+template <bool EXT, class REAL = double>
 struct LinCfg {
   static constexpr int STRIDE = EXT ? 35 : 23;
-  // doubles of dynamic LDS
-  static constexpr int SMEM_DOUBLES = GROUP_OBS * STRIDE + GROUP_LM * 4 + GROUP_PAIRS * 3 + GROUP_LM * 16 + 1024;
+  // the per-observation stage (REAL) occupies this many doubles of the dynamic LDS
+  static constexpr int STAGE_DOUBLES = (GROUP_OBS * STRIDE * (int)sizeof(REAL) + 7) / 8;
+  static constexpr int SMEM_DOUBLES = STAGE_DOUBLES + GROUP_LM * 4 + GROUP_PAIRS * 3 + GROUP_LM * 16 + 1024;
 };
 
 __device__ __forceinline__ int ut6(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }
 
-template <bool EXT>
+template <bool EXT, class REAL>
 __global__ __launch_bounds__(LIN_THREADS) void linearize_kernel(const WinPtrs* __restrict__ wins,
                                                                 const OptD* __restrict__ optp, int init) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -41,9 +49,9 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_kernel(const WinPtrs* _
   const double lambda = ctrl->lambda;
   const OptD opt = *optp;
 
-  constexpr int STRIDE = LinCfg<EXT>::STRIDE;
-  double* s_stage = smem;
-  double* s_lm = s_stage + GROUP_OBS * STRIDE;
+  constexpr int STRIDE = LinCfg<EXT, REAL>::STRIDE;
+  REAL* s_stage = reinterpret_cast<REAL*>(smem);
+  double* s_lm = smem + LinCfg<EXT, REAL>::STAGE_DOUBLES;
   double* s_pair = s_lm + GROUP_LM * 4;
   double* s_lmres = s_pair + GROUP_PAIRS * 3;
   double* s_step = s_lmres + GROUP_LM * 16;
@@ -134,36 +142,50 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_kernel(const WinPtrs* _
     const double* lm = s_lm + 4 * (l - G.lm_begin);
     const double L4[4] = {lm[0], lm[1], lm[2], lm[3]};
     const bool ext_free = EXT && (W.pose_off[rec.ext] >= 0);
-    ReprojLin J;
-    reproj_linearize(P, E, L4, intr, W.cam_model[cam], rec.u, rec.v, rec.sw, ext_free, &J);
+    ReprojLinT<REAL> J;
+    if constexpr (std::is_same<REAL, double>::value) {
+      ReprojLin Jd;
+      reproj_linearize(P, E, L4, intr, W.cam_model[cam], rec.u, rec.v, rec.sw, ext_free, &Jd);
+      J.r[0] = Jd.r[0];
+      J.r[1] = Jd.r[1];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        J.Jp[i] = Jd.Jp[i];
+        J.Je[i] = Jd.Je[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) J.Jl[i] = Jd.Jl[i];
+    } else {
+      reproj_linearize_mixed<REAL>(P, E, L4, intr, W.cam_model[cam], rec.u, rec.v, rec.sw, ext_free, &J);
+    }
     if (W.obs_r[trial]) {
       W.obs_r[trial][2 * (size_t)o] = J.r[0];
       W.obs_r[trial][2 * (size_t)o + 1] = J.r[1];
     }
     // Cauchy corrector (Ceres Corrector with rho'' <= 0: scale r and J by sqrt(rho'))
-    const double s = J.r[0] * J.r[0] + J.r[1] * J.r[1];
-    double sr = 1.0, irho = 1.0, cost = 0.5 * s;
+    const REAL s = J.r[0] * J.r[0] + J.r[1] * J.r[1];
+    REAL sr = REAL(1), irho = REAL(1), cost = REAL(0.5) * s;
     if (W.cauchy_b > 0) {
-      const double bb = W.cauchy_b * W.cauchy_b;
-      const double sum = 1.0 + s / bb;
-      const double rho1 = 1.0 / sum;
-      cost = 0.5 * bb * log(sum);
+      const REAL bb = REAL(W.cauchy_b * W.cauchy_b);
+      const REAL sum = REAL(1) + s / bb;
+      const REAL rho1 = REAL(1) / sum;
+      cost = REAL(0.5) * bb * log(sum);
       sr = sqrt(rho1);
       irho = sum;
     }
-    double* st = s_stage + (size_t)tid * STRIDE;
+    REAL* st = s_stage + (size_t)tid * STRIDE;
     st[ST_R] = sr * J.r[0];
     st[ST_R + 1] = sr * J.r[1];
     const bool pose_free = W.pose_off[rec.pose] >= 0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) st[ST_JP + i] = pose_free ? sr * J.Jp[i] : 0.0;
+    for (int i = 0; i < 12; ++i) st[ST_JP + i] = pose_free ? sr * J.Jp[i] : REAL(0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) st[ST_JL + i] = sr * J.Jl[i];
     st[ST_IRHO] = irho;
     st[ST_COST] = cost;
     if (EXT) {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) st[ST_JE + i] = ext_free ? sr * J.Je[i] : 0.0;
+      for (int i = 0; i < 12; ++i) st[ST_JE + i] = ext_free ? sr * J.Je[i] : REAL(0);
     }
   }
   __syncthreads();
@@ -174,19 +196,19 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_kernel(const WinPtrs* _
     const int ll = wi >> 4, e = wi & 15;
     const int l = G.lm_begin + ll;
     const int o0 = W.lm_obs_begin[l] - G.obs_begin, o1 = W.lm_obs_begin[l + 1] - G.obs_begin;
-    double a = 0;
+    REAL a = 0;
     if (e < 6) {
       const int i = (e < 3) ? 0 : (e < 5 ? 1 : 2);
       const int j = (e < 3) ? e : (e < 5 ? e - 2 : 2);
       for (int o = o0; o < o1; ++o) {
-        const double* st = s_stage + (size_t)o * STRIDE + ST_JL;
+        const REAL* st = s_stage + (size_t)o * STRIDE + ST_JL;
         a += st[i] * st[j] + st[3 + i] * st[3 + j];
       }
       W.V[trial][6 * (size_t)l + e] = a;
     } else if (e < 9) {
       const int i = e - 6;
       for (int o = o0; o < o1; ++o) {
-        const double* st = s_stage + (size_t)o * STRIDE;
+        const REAL* st = s_stage + (size_t)o * STRIDE;
         a += st[ST_JL + i] * st[ST_R] + st[ST_JL + 3 + i] * st[ST_R + 1];
       }
       W.bl[trial][3 * (size_t)l + i] = a;
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_kernel(const WinPtrs* _
       const int i = (ee < 3) ? 0 : (ee < 5 ? 1 : 2);
       const int j = (ee < 3) ? ee : (ee < 5 ? ee - 2 : 2);
       for (int o = o0; o < o1; ++o) {
-        const double* st = s_stage + (size_t)o * STRIDE;
+        const REAL* st = s_stage + (size_t)o * STRIDE;
         a += (st[ST_JL + i] * st[ST_JL + j] + st[ST_JL + 3 + i] * st[ST_JL + 3 + j]) * st[ST_IRHO];
       }
       W.Hq[trial][6 * (size_t)l + ee] = a;
@@ -209,10 +231,10 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_kernel(const WinPtrs* _
     const int pp = wi / 6, a = wi - 6 * pp;
     const int p = G.pair_begin + pp;
     const int jofs = (EXT && W.pair_role[p]) ? ST_JE : ST_JP;
-    double w0 = 0, w1 = 0, w2 = 0;
+    REAL w0 = 0, w1 = 0, w2 = 0;
     for (int k = W.pair_list_begin[p]; k < W.pair_list_begin[p + 1]; ++k) {
-      const double* st = s_stage + (size_t)W.pair_list[k] * STRIDE;
-      const double j0 = st[jofs + a], j1 = st[jofs + 6 + a];
+      const REAL* st = s_stage + (size_t)W.pair_list[k] * STRIDE;
+      const REAL j0 = st[jofs + a], j1 = st[jofs + 6 + a];
       w0 += j0 * st[ST_JL] + j1 * st[ST_JL + 3];
       w1 += j0 * st[ST_JL + 1] + j1 * st[ST_JL + 4];
       w2 += j0 * st[ST_JL + 2] + j1 * st[ST_JL + 5];
@@ -230,11 +252,11 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_kernel(const WinPtrs* _
     double* out = W.gpart[trial] + T.out;
     if (T.type < 2) {
       const int jofs = (T.type == 1) ? ST_JE : ST_JP;
-      double acc6[6] = {0, 0, 0, 0, 0, 0};
-      double ga = 0;
+      REAL acc6[6] = {0, 0, 0, 0, 0, 0};
+      REAL ga = 0;
       for (int k = T.list_begin; k < T.list_end; ++k) {
-        const double* st = s_stage + (size_t)W.task_list[k] * STRIDE;
-        const double j0 = st[jofs + a], j1 = st[jofs + 6 + a];
+        const REAL* st = s_stage + (size_t)W.task_list[k] * STRIDE;
+        const REAL j0 = st[jofs + a], j1 = st[jofs + 6 + a];
 #pragma unroll
         for (int b = 0; b < 6; ++b) acc6[b] += j0 * st[jofs + b] + j1 * st[jofs + 6 + b];
         ga += j0 * st[ST_R] + j1 * st[ST_R + 1];
@@ -242,10 +264,10 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_kernel(const WinPtrs* _
       for (int b = a; b < 6; ++b) out[ut6(a, b)] = acc6[b];
       out[21 + a] = ga;
     } else if (EXT) {
-      double acc6[6] = {0, 0, 0, 0, 0, 0};
+      REAL acc6[6] = {0, 0, 0, 0, 0, 0};
       for (int k = T.list_begin; k < T.list_end; ++k) {
-        const double* st = s_stage + (size_t)W.task_list[k] * STRIDE;
-        const double j0 = st[ST_JP + a], j1 = st[ST_JP + 6 + a];
+        const REAL* st = s_stage + (size_t)W.task_list[k] * STRIDE;
+        const REAL j0 = st[ST_JP + a], j1 = st[ST_JP + 6 + a];
 #pragma unroll
         for (int b = 0; b < 6; ++b) acc6[b] += j0 * st[ST_JE + b] + j1 * st[ST_JE + 6 + b];
       }

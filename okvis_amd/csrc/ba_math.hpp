@@ -407,6 +407,169 @@ BA_HD bool reproj_linearize(const double* pose, const double* ext, const double*
   return true;
 }
 
+// ---- reduced-precision linearisation (BASELINE configs[4]: fp32 Jacobian/Hessian build, fp64 solve) ------
+// Same algebra as distort()/reproj_linearize() above with the arithmetic in T (float).  The only fp64
+// operations are the two translations hp_W - r_WS w and p_S - r_SC w_S: subtracting world-scale coordinates
+// in fp32 would lose the digits the residual lives in; everything after the points are expressed relative to
+// the sensor/camera (rotations, projection, distortion, Jacobians) is T.
+template <class T>
+BA_HD void qrot_t(const T* q, T* R) {
+  const T tx = T(2) * q[0], ty = T(2) * q[1], tz = T(2) * q[2];
+  const T twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+  const T txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+  const T tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  R[0] = T(1) - (tyy + tzz); R[1] = txy - twz;          R[2] = txz + twy;
+  R[3] = txy + twz;          R[4] = T(1) - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;          R[7] = tyz + twx;          R[8] = T(1) - (txx + tyy);
+}
+template <class T>
+BA_HD bool distort_t(int model, const T* k, T u0, T u1, T* d, T* J) {
+  if (model == DIST_RADTAN) {
+    const T k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3];
+    const T mx = u0 * u0, my = u1 * u1, mxy = u0 * u1, rho = mx + my;
+    const T rad = k1 * rho + k2 * rho * rho;
+    d[0] = u0 + u0 * rad + T(2) * p1 * mxy + p2 * (rho + T(2) * mx);
+    d[1] = u1 + u1 * rad + T(2) * p2 * mxy + p1 * (rho + T(2) * my);
+    J[0] = T(1) + rad + k1 * T(2) * mx + k2 * rho * T(4) * mx + T(2) * p1 * u1 + T(6) * p2 * u0;
+    J[2] = k1 * T(2) * u0 * u1 + k2 * T(4) * rho * u0 * u1 + p1 * T(2) * u0 + T(2) * p2 * u1;
+    J[1] = J[2];
+    J[3] = T(1) + rad + k1 * T(2) * my + k2 * rho * T(4) * my + T(6) * p1 * u1 + T(2) * p2 * u0;
+    return true;
+  } else if (model == DIST_EQUI) {
+    const T k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3];
+    const T r2 = u0 * u0 + u1 * u1;
+    const T r = sqrt(r2);
+    const T th = atan(r);
+    const T th2 = th * th, th4 = th2 * th2, th6 = th4 * th2, th8 = th4 * th4;
+    const T thd = th * (T(1) + k1 * th2 + k2 * th4 + k3 * th6 + k4 * th8);
+    if (r > T(1e-8)) {
+      const T sc = thd / r;
+      d[0] = sc * u0;
+      d[1] = sc * u1;
+      const T dpoly = T(1) + T(3) * k1 * th2 + T(5) * k2 * th4 + T(7) * k3 * th6 + T(9) * k4 * th8;
+      const T g = (dpoly / (T(1) + r2) - sc) / r2;
+      J[0] = sc + u0 * u0 * g;
+      J[1] = u0 * u1 * g;
+      J[2] = J[1];
+      J[3] = sc + u1 * u1 * g;
+    } else {
+      d[0] = u0;
+      d[1] = u1;
+      J[0] = T(1); J[1] = T(0); J[2] = T(0); J[3] = T(1);
+    }
+    return true;
+  } else if (model == DIST_RADTAN8) {
+    const T k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3], k3 = k[4], k4 = k[5], k5 = k[6], k6 = k[7];
+    const T mx = u0 * u0, my = u1 * u1, mxy = u0 * u1, rho = mx + my;
+    if (rho > T(9)) return false;
+    const T num = T(1) + ((k3 * rho + k2) * rho + k1) * rho;
+    const T den = T(1) + ((k6 * rho + k5) * rho + k4) * rho;
+    const T rad = num / den;
+    d[0] = u0 * rad + T(2) * p1 * mxy + p2 * (rho + T(2) * mx);
+    d[1] = u1 * rad + T(2) * p2 * mxy + p1 * (rho + T(2) * my);
+    const T dnum = k1 + rho * (T(2) * k2 + T(3) * k3 * rho);
+    const T dden = k4 + rho * (T(2) * k5 + T(3) * k6 * rho);
+    const T drad = (dnum * den - num * dden) / (den * den);
+    J[0] = rad + T(2) * mx * drad + T(2) * p1 * u1 + T(6) * p2 * u0;
+    J[1] = T(2) * mxy * drad + T(2) * p1 * u0 + T(2) * p2 * u1;
+    J[2] = J[1];
+    J[3] = rad + T(2) * my * drad + T(6) * p1 * u1 + T(2) * p2 * u0;
+    return true;
+  }
+  d[0] = u0;
+  d[1] = u1;
+  J[0] = T(1); J[1] = T(0); J[2] = T(0); J[3] = T(1);
+  return true;
+}
+
+template <class T>
+struct ReprojLinT {
+  T r[2], Jp[12], Jl[6], Je[12];
+};
+
+template <class T>
+BA_HD bool reproj_linearize_mixed(const double* pose, const double* ext, const double* lm, const double* intr,
+                                  int model, double mu, double mv, double sw, bool want_ext, ReprojLinT<T>* o) {
+  const T qp[4] = {T(pose[3]), T(pose[4]), T(pose[5]), T(pose[6])};
+  const T qe[4] = {T(ext[3]), T(ext[4]), T(ext[5]), T(ext[6])};
+  T C_WS[9], C_SC[9];
+  qrot_t(qp, C_WS);
+  qrot_t(qe, C_SC);
+  const double wd = lm[3];
+  const T w = T(wd);
+  const T dW[3] = {T(lm[0] - pose[0] * wd), T(lm[1] - pose[1] * wd), T(lm[2] - pose[2] * wd)};  // fp64 difference
+  T pS[3];
+  for (int j = 0; j < 3; ++j) pS[j] = C_WS[j] * dW[0] + C_WS[3 + j] * dW[1] + C_WS[6 + j] * dW[2];
+  const T eS[3] = {pS[0] - T(ext[0]) * w, pS[1] - T(ext[1]) * w, pS[2] - T(ext[2]) * w};  // |r_SC| ~ 0.1 m: T is enough
+  T pC[3];
+  for (int j = 0; j < 3; ++j) pC[j] = C_SC[j] * eS[0] + C_SC[3 + j] * eS[1] + C_SC[6 + j] * eS[2];
+  T x = pC[0], y = pC[1], z = pC[2];
+  if (wd < 0) {
+    x = -x; y = -y; z = -z;
+  }
+  for (int i = 0; i < 12; ++i) o->Jp[i] = T(0);
+  for (int i = 0; i < 6; ++i) o->Jl[i] = T(0);
+  for (int i = 0; i < 12; ++i) o->Je[i] = T(0);
+  bool defined = fabs(z) >= T(1.0e-12);
+  T dd[2] = {T(0), T(0)}, Jd[4] = {T(1), T(0), T(0), T(1)};
+  T rz = T(0), rz2 = T(0);
+  T kk[8];
+  for (int i = 0; i < 8; ++i) kk[i] = T(intr[4 + i]);
+  if (defined) {
+    rz = T(1) / z;
+    rz2 = rz * rz;
+    defined = distort_t<T>(model, kk, x * rz, y * rz, dd, Jd);
+  }
+  if (!defined) {
+    o->r[0] = T(0);
+    o->r[1] = T(0);
+    return false;
+  }
+  const T fu = T(intr[0]), fv = T(intr[1]), s = T(sw);
+  // the measurement minus the principal point is formed in fp64 (pixel coordinates ~1e2..1e3)
+  o->r[0] = s * (T(mu - intr[2]) - fu * dd[0]);
+  o->r[1] = s * (T(mv - intr[3]) - fv * dd[1]);
+  bool valid = true;
+  if (fabs(wd) > 1.0e-8)
+    if (pC[2] / w < T(0.2)) valid = false;
+  if (!valid) return false;
+  T Jw[6];
+  Jw[0] = s * fu * Jd[0] * rz;
+  Jw[1] = s * fu * Jd[1] * rz;
+  Jw[2] = -s * fu * (x * Jd[0] + y * Jd[1]) * rz2;
+  Jw[3] = s * fv * Jd[2] * rz;
+  Jw[4] = s * fv * Jd[3] * rz;
+  Jw[5] = -s * fv * (x * Jd[2] + y * Jd[3]) * rz2;
+  T B[6];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 3; ++j)
+      B[3 * i + j] = Jw[3 * i] * C_SC[3 * j] + Jw[3 * i + 1] * C_SC[3 * j + 1] + Jw[3 * i + 2] * C_SC[3 * j + 2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 3; ++j)
+      o->Jl[3 * i + j] = -(B[3 * i] * C_WS[3 * j] + B[3 * i + 1] * C_WS[3 * j + 1] + B[3 * i + 2] * C_WS[3 * j + 2]);
+  for (int i = 0; i < 2; ++i) {
+    const T a0 = o->Jl[3 * i], a1 = o->Jl[3 * i + 1], a2 = o->Jl[3 * i + 2];
+    o->Jp[6 * i + 0] = -w * a0;
+    o->Jp[6 * i + 1] = -w * a1;
+    o->Jp[6 * i + 2] = -w * a2;
+    o->Jp[6 * i + 3] = a1 * dW[2] - a2 * dW[1];
+    o->Jp[6 * i + 4] = a2 * dW[0] - a0 * dW[2];
+    o->Jp[6 * i + 5] = a0 * dW[1] - a1 * dW[0];
+  }
+  if (want_ext) {
+    for (int i = 0; i < 2; ++i) {
+      const T b0 = B[3 * i], b1 = B[3 * i + 1], b2 = B[3 * i + 2];
+      o->Je[6 * i + 0] = w * b0;
+      o->Je[6 * i + 1] = w * b1;
+      o->Je[6 * i + 2] = w * b2;
+      o->Je[6 * i + 3] = eS[1] * b2 - eS[2] * b1;
+      o->Je[6 * i + 4] = eS[2] * b0 - eS[0] * b2;
+      o->Je[6 * i + 5] = eS[0] * b1 - eS[1] * b0;
+    }
+  }
+  return true;
+}
+
 // okvis::Duration::toSec() of a signed ns difference (Duration.hpp:111-113, Duration.cpp:55-73)
 BA_HD double ns_to_sec(long long ns) {
   long long sec = ns / 1000000000LL;

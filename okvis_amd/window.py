@@ -56,7 +56,7 @@ class OptionsC(C.Structure):
         ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("use_graph", C.c_int32), ("schur_lm_per_block", C.c_int32),
         ("debug_arrays", C.c_int32), ("gauss_newton", C.c_int32),
-        ("n_streams", C.c_int32), ("reserved", C.c_int32),
+        ("n_streams", C.c_int32), ("fp32_linearize", C.c_int32),
     ]
 
 
