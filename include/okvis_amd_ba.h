@@ -328,6 +328,14 @@ typedef struct okvis_ba_marg_result {
 
 int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* result);
 
+/* ---- diagnostics ------------------------------------------------------------------------------------
+ * The dense solver behind windows whose reduced dimension exceeds the single-workgroup LDS path
+ * (OKVIS_BA_MARG_MAX_WINDOW_DIM): tiled multi-workgroup Cholesky with fp64 MFMA tile updates
+ * (okvis_amd/csrc/ba_chol_tiles.hpp), exposed stand-alone for tests and profiling.  Solves S x = rhs for a
+ * symmetric positive definite S [n][n] (row-major, full storage).  *info = 0 ok, 1 = not positive definite /
+ * dependency timeout. */
+int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* rhs, double* x, int32_t* info);
+
 #ifdef __cplusplus
 }
 #endif

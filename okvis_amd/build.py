@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "lib", "libokvis_amd_ba.so")
 SOURCES = ["ba_capi.hip"]
 HEADERS = [os.path.join("host", "estimator.hpp"), os.path.join("host", "estimator.cpp"),
            os.path.join("host", "estimator_capi.cpp"), "ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_schur.hpp", "ba_solve.hpp",
-           "ba_imu.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
+           "ba_imu.hpp", "ba_marg.hpp", "ba_chol_tiles.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
 
 
 def stale() -> bool:

@@ -15,6 +15,7 @@
 
 #include "../../include/okvis_amd_ba.h"
 #include "ba_imu.hpp"
+#include "ba_chol_tiles.hpp"
 #include "ba_linearize.hpp"
 #include "ba_marg.hpp"
 #include "ba_schur.hpp"
@@ -472,6 +473,15 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   if (D > MAX_D_LDS) {
     const size_t nbk = (D + 5) / 6;
     OFF(Sg, put_zero(A, 8 * nbk * (nbk + 1) / 2 * 38));
+    const size_t nT = (D + CT_TB - 1) / CT_TB, ntile = nT * (nT + 1) / 2;
+    P.ct_nT = (int)nT;
+    OFF(ct_T, put_zero(A, 8 * ntile * CT_TILE));
+    OFF(ct_Linv, put_zero(A, 8 * nT * CT_TILE));
+    OFF(ct_rhs, put_zero(A, 8 * nT * CT_TB));
+    OFF(ct_y, put_zero(A, 8 * nT * CT_TB));
+    OFF(ct_flag, put_zero(A, sizeof(int) * (ntile + 2)));
+    OFF(ct_g, put_zero(A, 8 * nT * CT_TB));
+    OFF(ct_d2, put_zero(A, 8 * nT * CT_TB));
   }
   OFF(step, put_zero(A, 8 * (size_t)D));
   OFF(grad, put_zero(A, 8 * (size_t)D));
@@ -558,7 +568,11 @@ void relocate(WinPtrs& P, unsigned char* base, bool debug) {
     P.Dp2 = nullptr;
   }
   P.Hpp = nullptr;
-  if (P.D <= MAX_D_LDS) P.Sg = nullptr;
+  if (P.D <= MAX_D_LDS) {
+    P.Sg = nullptr;
+    P.ct_T = P.ct_Linv = P.ct_rhs = P.ct_y = P.ct_g = P.ct_d2 = nullptr;
+    P.ct_flag = nullptr;
+  }
 }
 
 size_t lin_smem(bool ext, bool f32 = false) {
@@ -589,9 +603,18 @@ hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
   if (s->max_Dpad_small > 0)
     hipLaunchKernelGGL(solve_kernel<false>, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small), b.st,
                        s->d_wins + b.w0, s->d_opt, final_only);
-  if (s->max_Dpad_large > 0)
+  if (s->max_Dpad_large > 0) {
+    // large windows: assemble + export, tiled multi-workgroup Cholesky (fp64 MFMA), back-substitution + finish
     hipLaunchKernelGGL(solve_kernel<true>, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), b.st,
                        s->d_wins + b.w0, s->d_opt, final_only);
+    if (!final_only) {
+      const int nT = (s->max_Dpad_large + CT_TB - 1) / CT_TB;
+      hipLaunchKernelGGL(large_export_kernel, dim3(nT * (nT + 1) / 2, (unsigned)b.nw), dim3(CT_THREADS), 0, b.st, s->d_wins + b.w0);
+      hipLaunchKernelGGL(chol_tiles_window_kernel, dim3(nT * (nT + 1) / 2, (unsigned)b.nw), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8,
+                         b.st, s->d_wins + b.w0);
+      hipLaunchKernelGGL(solve_large_tail_kernel, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), 0, b.st, s->d_wins + b.w0, s->d_opt);
+    }
+  }
   return hipGetLastError();
 }
 hipError_t launch_small(okvis_ba_solver* s, Sub b, int init) {
@@ -744,6 +767,9 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)solve_smem(((MAX_D + 5) / 6) * 6, true));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_tiles_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CT_SMEM_DOUBLES * 8);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)small_smem());
@@ -1212,6 +1238,56 @@ int okvis_ba_synchronize(okvis_ba_solver* s) {
   if (!s) return OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* rhs, double* x, int32_t* info) {
+  if (n <= 0 || !S || !rhs || !x || !info) return OKVIS_BA_ERR_ARG;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return OKVIS_BA_ERR_NO_DEVICE;
+  const int nT = (n + CT_TB - 1) / CT_TB, ntiles = nT * (nT + 1) / 2, np = nT * CT_TB;
+  std::vector<double> tiles((size_t)ntiles * CT_TILE, 0.0), r(np, 0.0);
+  for (int i = 0; i < nT; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double* t = &tiles[(size_t)(i * (i + 1) / 2 + j) * CT_TILE];
+      for (int a = 0; a < CT_TB; ++a)
+        for (int b = 0; b < CT_TB; ++b) {
+          const int gi = CT_TB * i + a, gj = CT_TB * j + b;
+          t[a * CT_TB + b] = (gi < n && gj < n) ? S[(size_t)gi * n + gj] : ((gi == gj) ? 1.0 : 0.0);
+        }
+    }
+  for (int k = 0; k < n; ++k) r[k] = rhs[k];
+  Arena A;
+  const size_t oT = A.alloc(8 * tiles.size()), oL = A.alloc(8 * (size_t)nT * CT_TILE), oR = A.alloc(8 * (size_t)np),
+               oY = A.alloc(8 * (size_t)np), oX = A.alloc(8 * (size_t)np), oF = A.alloc(sizeof(int) * (ntiles + 1));
+  unsigned char* d = nullptr;
+  if (hipMalloc(&d, A.size) != hipSuccess) return OKVIS_BA_HIP_ERROR_BASE + (int)hipGetLastError();
+  struct Free { unsigned char* p; ~Free() { if (p) (void)hipFree(p); } } guard{d};
+  auto chk = [](hipError_t err) { return err == hipSuccess ? OKVIS_BA_OK : OKVIS_BA_HIP_ERROR_BASE + (int)err; };
+  int rc;
+  if ((rc = chk(hipMemcpy(d + oT, tiles.data(), 8 * tiles.size(), hipMemcpyHostToDevice)))) return rc;
+  if ((rc = chk(hipMemcpy(d + oR, r.data(), 8 * (size_t)np, hipMemcpyHostToDevice)))) return rc;
+  if ((rc = chk(hipMemset(d + oF, 0, sizeof(int) * (ntiles + 1))))) return rc;
+  CholTiles C;
+  C.nT = nT;
+  C.T = reinterpret_cast<double*>(d + oT);
+  C.Linv = reinterpret_cast<double*>(d + oL);
+  C.rhs = reinterpret_cast<double*>(d + oR);
+  C.y = reinterpret_cast<double*>(d + oY);
+  C.flag = reinterpret_cast<int*>(d + oF);
+  if ((rc = chk(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    CT_SMEM_DOUBLES * 8))))
+    return rc;
+  hipLaunchKernelGGL(chol_tile_kernel, dim3(ntiles), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8, 0, C);
+  hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(CT_THREADS), 0, 0, C, reinterpret_cast<double*>(d + oX));
+  if ((rc = chk(hipGetLastError()))) return rc;
+  if ((rc = chk(hipDeviceSynchronize()))) return rc;
+  std::vector<double> xs(np);
+  int fail = 0;
+  if ((rc = chk(hipMemcpy(xs.data(), d + oX, 8 * (size_t)np, hipMemcpyDeviceToHost)))) return rc;
+  if ((rc = chk(hipMemcpy(&fail, d + oF + sizeof(int) * ntiles, sizeof(int), hipMemcpyDeviceToHost)))) return rc;
+  for (int k = 0; k < n; ++k) x[k] = xs[k];
+  *info = fail;
   return OKVIS_BA_OK;
 }
 

@@ -16,6 +16,7 @@
 //
 // This is the only kernel that writes the window's Ctrl record.
 #pragma once
+#include "ba_chol_tiles.hpp"
 #include "ba_device.hpp"
 
 namespace ba {
@@ -261,8 +262,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   const WinPtrs& W = wins[blockIdx.x];
   if (LARGE != (W.Sg != nullptr)) return;  // each window is handled by the instantiation that fits it
   Ctrl* gctrl = W.ctrl;
-  if (gctrl->done) return;
   const int tid = threadIdx.x;
+  if (LARGE && tid == 0) W.ct_flag[W.ct_nT * (W.ct_nT + 1) / 2 + 1] = 0;  // no system exported (yet) this launch
+  if (gctrl->done) return;
   const OptD opt = *optp;
   const int D = W.D, Dp = W.Dp;
   const int Dpad = ((D + 5) / 6) * 6, nbk = Dpad / 6;
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     const size_t stride = W.spart_stride;
     const int nch = W.n_chunk;
     const double* sp = W.spart;
-    for (int i = tid; i < nP; i += SOLVE_THREADS) {
+    for (int i = tid; i < (LARGE ? 0 : nP); i += SOLVE_THREADS) {  // LARGE: summed by large_export_kernel
       double s = 0;
       for (int ch = 0; ch < nch; ch += 8) {  // 8 independent loads in flight
         double v[8];
@@ -459,6 +461,24 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
   }
   STAMP(6);
+  if constexpr (LARGE) {
+    // hand the damped system to the tiled multi-workgroup solver (ba_chol_tiles.hpp).  S (HBM, block-packed)
+    // holds the IMU / prior / marginalisation part plus the damping; large_export_kernel adds the Schur partials
+    // of the pose part and writes the 48x48 tiles on many CUs; the trust-region state travels in ctrl
+    const int nT = W.ct_nT, ntile = nT * (nT + 1) / 2;
+    for (int i = tid; i < nT * CT_TB; i += SOLVE_THREADS) {
+      W.ct_rhs[i] = i < Dpad ? s_rhs[i] : 0.0;
+      W.ct_g[i] = i < D ? s_g[i] : 0.0;
+      W.ct_d2[i] = i < D ? s_d2[i] : 0.0;
+    }
+    for (int i = tid; i < ntile + 1; i += SOLVE_THREADS) W.ct_flag[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+      *gctrl = c;
+      W.ct_flag[ntile + 1] = 1;
+    }
+    return;
+  }
   if (tid == 0) {
     if (!factor_diag(S + LY.blk(0, 0), s_diag, s_dinv)) s_fail = 1;
   }
@@ -773,6 +793,169 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   }
   STAMP(9);
 #undef STAMP
+}
+
+// ---- large windows (D > MAX_D_LDS): solve_kernel<true> assembles and exports the damped system, the tile
+// kernel factorises it on many CUs (fp64 MFMA), this kernel back-substitutes and finishes the iteration exactly
+// like section 5 of solve_kernel.
+// tile (ti, tj) of the damped reduced system: sum of the Schur partials (pose part) + the block-packed HBM matrix
+// solve_kernel<true> assembled (IMU, priors, marginalisation prior, damping); diagonal tiles full, identity padding
+__global__ __launch_bounds__(CT_THREADS) void large_export_kernel(const WinPtrs* __restrict__ wins) {
+  const WinPtrs& W = wins[blockIdx.y];
+  const int nT = W.ct_nT, ntile = nT * (nT + 1) / 2;
+  if (nT == 0 || (int)blockIdx.x >= ntile) return;
+  if (W.ct_flag[ntile + 1] == 0) return;
+  const int t = blockIdx.x;
+  int ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  const int tj = t - ti * (ti + 1) / 2;
+  const int D = W.D, Dp = W.Dp, Dpad = ((D + 5) / 6) * 6;
+  const SLayout LY{Dpad / 6};
+  const int nch = W.n_chunk;
+  const size_t stride = W.spart_stride;
+  for (int r = threadIdx.x; r < CT_TILE; r += CT_THREADS) {
+    int gi = CT_TB * ti + r / CT_TB, gj = CT_TB * tj + r % CT_TB;
+    const int oi = gi, oj = gj;
+    double v;
+    if (gi < Dpad && gj < Dpad) {
+      if (gi < gj) {
+        const int tmp = gi;
+        gi = gj;
+        gj = tmp;
+      }
+      v = W.Sg[LY.at(gi, gj)];
+      if (gi < Dp) {  // both indices in the pose part: add the chunk partials (block-packed, row-major lower blocks)
+        const int bi = gi / 6, bj = gj / 6;
+        const size_t o = (size_t)(bi * (bi + 1) / 2 + bj) * 36 + (gi - 6 * bi) * 6 + (gj - 6 * bj);
+        double a = 0;
+        for (int ch = 0; ch < nch; ++ch) a += W.spart[(size_t)ch * stride + o];
+        v += a;
+      }
+    } else {
+      v = (gi == gj) ? 1.0 : 0.0;
+    }
+    W.ct_T[(size_t)t * CT_TILE + r] = v;
+    if (W.S && oi < D && oj < D) {  // parity/debug copy of the damped system (full symmetric)
+      W.S[(size_t)oi * D + oj] = v;
+      if (ti > tj) W.S[(size_t)oj * D + oi] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(CT_THREADS) void chol_tiles_window_kernel(const WinPtrs* __restrict__ wins) {
+  extern __shared__ __attribute__((aligned(16))) double ct_smem[];
+  const WinPtrs& W = wins[blockIdx.y];
+  const int nT = W.ct_nT, ntile = nT * (nT + 1) / 2;
+  if (nT == 0 || (int)blockIdx.x >= ntile) return;
+  if (W.ct_flag[ntile + 1] == 0) return;  // nothing exported this iteration (terminated / final pass)
+  CholTiles C;
+  C.nT = nT;
+  C.T = W.ct_T;
+  C.Linv = W.ct_Linv;
+  C.rhs = W.ct_rhs;
+  C.y = W.ct_y;
+  C.flag = W.ct_flag;
+  chol_tile_task(C, blockIdx.x, ct_smem);
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const WinPtrs* __restrict__ wins,
+                                                                        const OptD* __restrict__ optp) {
+  const WinPtrs& W = wins[blockIdx.x];
+  const int nT = W.ct_nT, ntile = nT * (nT + 1) / 2;
+  if (nT == 0 || W.ct_flag[ntile + 1] == 0) return;
+  const int tid = threadIdx.x;
+  const OptD opt = *optp;
+  Ctrl* gctrl = W.ctrl;
+  __shared__ Ctrl c;
+  __shared__ double s_x[CT_TB * ((MAX_D + CT_TB - 1) / CT_TB)];
+  __shared__ double s_scratch[CT_BACKSUB_SCRATCH(SOLVE_THREADS)];
+  __shared__ double s_sc[4][SOLVE_THREADS / 64];
+  if (tid == 0) c = *gctrl;
+  __syncthreads();
+  if (W.ct_flag[ntile]) {  // not positive definite: invalid step (handled like a rejection)
+    if (tid == 0) {
+      c.iter++;
+      c.chol_fail++;
+      c.radius = c.radius / c.decrease_factor;
+      c.decrease_factor *= 2.0;
+      c.pending = 0;
+      if (c.radius < opt.min_radius) c.done = 5 + 1;
+      *gctrl = c;
+    }
+    return;
+  }
+  CholTiles C;
+  C.nT = nT;
+  C.T = W.ct_T;
+  C.Linv = W.ct_Linv;
+  C.rhs = W.ct_rhs;
+  C.y = W.ct_y;
+  C.flag = W.ct_flag;
+  chol_backsub(C, s_x, s_scratch, tid, SOLVE_THREADS);
+  const int D = W.D, acc = c.acc, trial = 1 - acc;
+  const double lambda = 1.0 / c.radius;
+  double gd = 0, ddd = 0, s2 = 0, x2 = 0;
+  for (int i = tid; i < D; i += SOLVE_THREADS) {
+    const double x = s_x[i];
+    W.step[i] = x;
+    gd += W.ct_g[i] * x;
+    ddd += W.ct_d2[i] * x * x;
+    s2 += x * x;
+  }
+  for (int b = tid; b < W.n_pose; b += SOLVE_THREADS) {
+    const double* xp = W.pose[acc] + 7 * (size_t)b;
+    double* xt = W.pose[trial] + 7 * (size_t)b;
+    const int off = W.pose_off[b];
+    if (off >= 0) {
+      double xin[7], xo[7];
+      for (int k = 0; k < 7; ++k) {
+        xin[k] = xp[k];
+        x2 += xp[k] * xp[k];
+      }
+      pose_oplus(xin, s_x + off, xo);
+      for (int k = 0; k < 7; ++k) xt[k] = xo[k];
+    } else {
+      for (int k = 0; k < 7; ++k) xt[k] = xp[k];
+    }
+  }
+  for (int b = tid; b < W.n_sb; b += SOLVE_THREADS) {
+    const double* xp = W.sb[acc] + 9 * (size_t)b;
+    double* xt = W.sb[trial] + 9 * (size_t)b;
+    const int off = W.sb_off[b];
+    for (int k = 0; k < 9; ++k) {
+      const double v = xp[k];
+      if (off >= 0) x2 += v * v;
+      xt[k] = off >= 0 ? v + s_x[off + k] : v;
+    }
+  }
+  gd = wave_sum(gd);
+  ddd = wave_sum(ddd);
+  s2 = wave_sum(s2);
+  x2 = wave_sum(x2);
+  if ((tid & 63) == 0) {
+    s_sc[0][tid >> 6] = gd;
+    s_sc[1][tid >> 6] = ddd;
+    s_sc[2][tid >> 6] = s2;
+    s_sc[3][tid >> 6] = x2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int i = 0; i < SOLVE_THREADS / 64; ++i) {
+      a0 += s_sc[0][i];
+      a1 += s_sc[1][i];
+      a2 += s_sc[2][i];
+      a3 += s_sc[3][i];
+    }
+    c.gd_p = a0;
+    c.ddd_p = a1;
+    c.step2_p = a2;
+    c.x2_p = a3;
+    c.lambda = lambda;
+    c.iter++;
+    c.pending = 1;
+    *gctrl = c;
+  }
 }
 
 // landmark quality (Estimator.cpp:880-896): 3x3 eigenvalues of the un-robustified H_l of the accepted

@@ -124,6 +124,7 @@ struct WinPtrs {
   int gpart_size;         // doubles in gpart
   int n_tile;             // Schur tiles per dimension
   int n_asm, n_imu_color;
+  int ct_nT;              // tile rows of the tiled dense solver (0 = the LDS solver handles this window)
   int spart_stride;       // doubles per chunk partial: (Dp/6)(Dp/6+1)/2*36 + 3*Dp  (S | Y b | g | diag U)
   double cauchy_b;
   ImuParamsD imu;
@@ -179,6 +180,14 @@ struct WinPtrs {
   double* spart;          // [n_chunk][spart_stride]: block-packed lower triangle | Y b
   double* S;              // [D][D] debug copy of the damped reduced matrix
   double* Sg;             // block-packed reduced matrix workspace in HBM when D > MAX_D_LDS, else null
+  // tiled multi-workgroup solver of the large windows (ba_chol_tiles.hpp), null when D <= MAX_D_LDS
+  double* ct_T;           // lower 48x48 tiles
+  double* ct_Linv;        // inverses of the diagonal tiles
+  double* ct_rhs;         // [48 nT]
+  double* ct_y;           // [48 nT]
+  int* ct_flag;           // [ntiles] done flags, [ntiles] failure, [ntiles + 1] 1 = a system was exported this iteration
+  double* ct_g;           // [48 nT] gradient of the accepted linearisation (for the step scalars)
+  double* ct_d2;          // [48 nT] damping diagonal
   double* rhs;            // [D]
   double* step;           // [D]
   double* grad;           // [D]
