@@ -86,27 +86,52 @@ __device__ __forceinline__ void ct_load_acc(ct_v4 acc[3], const double* src, int
     for (int i = 0; i < 4; ++i) acc[c][i] = src[(16 * strip + r0 + 4 * i) * ld + 16 * c + col];
 }
 
-// Cholesky of the 48x48 SPD matrix in LDS (stride CT_LD, lower triangle referenced) in 6-wide block columns;
-// returns false (through *fail) on a non-positive pivot.  Afterwards the lower triangle holds L.
-__device__ void ct_potrf48(double* M, int tid, int* s_fail) {
+__device__ __forceinline__ double ct_rsqrt(double x) {  // v_rsq_f64 + two Newton steps: full fp64 accuracy
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
+// Cholesky of the 48x48 SPD matrix in LDS (stride CT_LD, lower triangle referenced) in 6-wide block columns.
+// The 6x6 diagonal block is factored in registers by one work-item (reciprocal square roots instead of
+// divisions), its reciprocal diagonal is published in dinv[48] for the panel step.  A non-positive pivot sets
+// *s_fail.  Afterwards the lower triangle holds L.
+__device__ void ct_potrf48(double* M, double* dinv, int tid, int* s_fail) {
   for (int kb = 0; kb < 8; ++kb) {
     const int k0 = 6 * kb;
-    if (tid == 0) {  // 6x6 diagonal block by one work-item (sequential by nature)
+    if (tid == 0) {
+      double a[6][6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) a[r][c] = M[(k0 + r) * CT_LD + k0 + c];
+      bool bad = false;
+#pragma unroll
       for (int c = 0; c < 6; ++c) {
-        double d = M[(k0 + c) * CT_LD + k0 + c];
-        for (int m = 0; m < c; ++m) d -= M[(k0 + c) * CT_LD + k0 + m] * M[(k0 + c) * CT_LD + k0 + m];
+        double d = a[c][c];
+#pragma unroll
+        for (int m = 0; m < c; ++m) d -= a[c][m] * a[c][m];
         if (!(d > 0.0)) {
-          *s_fail = 1;
+          bad = true;
           d = 1.0;
         }
-        d = sqrt(d);
-        M[(k0 + c) * CT_LD + k0 + c] = d;
+        const double inv = ct_rsqrt(d);
+        a[c][c] = d * inv;
+        dinv[k0 + c] = inv;
+#pragma unroll
         for (int r = c + 1; r < 6; ++r) {
-          double v = M[(k0 + r) * CT_LD + k0 + c];
-          for (int m = 0; m < c; ++m) v -= M[(k0 + r) * CT_LD + k0 + m] * M[(k0 + c) * CT_LD + k0 + m];
-          M[(k0 + r) * CT_LD + k0 + c] = v / d;
+          double v = a[r][c];
+#pragma unroll
+          for (int m = 0; m < c; ++m) v -= a[r][m] * a[c][m];
+          a[r][c] = v * inv;
         }
       }
+      if (bad) *s_fail = 1;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) M[(k0 + r) * CT_LD + k0 + c] = a[r][c];
     }
     __syncthreads();
     const int nrows = CT_TB - k0 - 6;
@@ -118,16 +143,19 @@ __device__ void ct_potrf48(double* M, int tid, int* s_fail) {
         double v = row[c];
 #pragma unroll
         for (int m = 0; m < c; ++m) v -= x[m] * M[(k0 + c) * CT_LD + k0 + m];
-        x[c] = v / M[(k0 + c) * CT_LD + k0 + c];
+        x[c] = v * dinv[k0 + c];
       }
 #pragma unroll
       for (int c = 0; c < 6; ++c) row[c] = x[c];
     }
     __syncthreads();
     // trailing update, one work-item per entry of the lower triangle
-    for (int e = tid; e < nrows * nrows; e += CT_THREADS) {
-      const int r = e / nrows, c = e - r * nrows;
-      if (c > r) continue;
+    const int ntri = nrows * (nrows + 1) / 2;
+    for (int e = tid; e < ntri; e += CT_THREADS) {
+      int r = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+      while ((r + 1) * (r + 2) / 2 <= e) ++r;
+      while (r * (r + 1) / 2 > e) --r;
+      const int c = e - r * (r + 1) / 2;
       const double* a = M + (k0 + 6 + r) * CT_LD + k0;
       const double* b = M + (k0 + 6 + c) * CT_LD + k0;
       double s = 0;
@@ -139,20 +167,53 @@ __device__ void ct_potrf48(double* M, int tid, int* s_fail) {
   }
 }
 
-// X = L^-1 for the lower-triangular L in LDS (stride CT_LD): one work-item per column, forward substitution.
-// X is written to LDS (stride CT_LD, full square, zeros above the diagonal).
-__device__ void ct_trinv48(const double* L, double* X, int tid) {
-  if (tid < CT_TB) {
-    const int c = tid;
-    for (int r = 0; r < CT_TB; ++r) {
-      double v = (r == c) ? 1.0 : 0.0;
-      if (r < c) {
-        X[r * CT_LD + c] = 0.0;
-        continue;
+// X = L^-1 for the lower-triangular L in LDS (stride CT_LD), blocked by 6: the eight diagonal blocks are
+// inverted by eight work-items, then block row by block row  X_(bi,bj) = -X_(bi,bi) sum_(k=bj..bi-1) L_(bi,k) X_(k,bj).
+// X (stride CT_LD, full square, zeros above the diagonal); Tm = 6 x 48 scratch.
+__device__ void ct_trinv48(const double* L, const double* dinv, double* X, double* Tm, int tid) {
+  for (int e = tid; e < CT_TB * CT_TB; e += CT_THREADS) X[(e / CT_TB) * CT_LD + (e % CT_TB)] = 0.0;
+  __syncthreads();
+  if (tid < 8) {  // inverse of a 6x6 lower-triangular block, column by column
+    const int k0 = 6 * tid;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double x[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        if (r < c) {
+          x[r] = 0.0;
+          continue;
+        }
+        double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int m = 0; m < r; ++m)
+          if (m >= c) v -= L[(k0 + r) * CT_LD + k0 + m] * x[m];
+        x[r] = v * dinv[k0 + r];
       }
-      for (int m = c; m < r; ++m) v -= L[r * CT_LD + m] * X[m * CT_LD + c];
-      X[r * CT_LD + c] = v / L[r * CT_LD + r];
+#pragma unroll
+      for (int r = c; r < 6; ++r) X[(k0 + r) * CT_LD + k0 + c] = x[r];
     }
+  }
+  __syncthreads();
+  for (int bi = 1; bi < 8; ++bi) {
+    const int ncol = 6 * bi;  // columns 0 .. 6 bi - 1 of block row bi
+    for (int e = tid; e < 6 * ncol; e += CT_THREADS) {  // T = sum_k L_(bi,k) X_(k,.)
+      const int r = e / ncol, c = e - r * ncol;
+      const int m0 = (c / 6) * 6;  // X is lower triangular: rows >= the column's block start
+      double s = 0;
+      for (int m = m0; m < ncol; ++m) s += L[(6 * bi + r) * CT_LD + m] * X[m * CT_LD + c];
+      Tm[r * CT_TB + c] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < 6 * ncol; e += CT_THREADS) {  // X_(bi,.) = -X_(bi,bi) T
+      const int r = e / ncol, c = e - r * ncol;
+      double s = 0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+        if (m <= r) s += X[(6 * bi + r) * CT_LD + 6 * bi + m] * Tm[m * CT_TB + c];
+      X[(6 * bi + r) * CT_LD + c] = -s;
+    }
+    __syncthreads();
   }
 }
 
@@ -170,7 +231,7 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
   double* sB = lds + CT_TB * CT_LD;
   double* sC = lds + 2 * CT_TB * CT_LD;
   __shared__ int s_ok, s_fail;
-  __shared__ double s_r[CT_TB];
+  __shared__ double s_r[CT_TB], s_dinv[CT_TB], s_tm[6 * CT_TB];
   int* failflag = C.flag + nT * (nT + 1) / 2;
   if (tid == 0) {
     s_ok = 1;
@@ -213,9 +274,8 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
   if (diag) {
     if (wave < 3) ct_store_acc(acc, sC, CT_LD, wave, lane);
     __syncthreads();
-    ct_potrf48(sC, tid, &s_fail);
-    ct_trinv48(sC, sB, tid);
-    __syncthreads();
+    ct_potrf48(sC, s_dinv, tid, &s_fail);
+    ct_trinv48(sC, s_dinv, sB, s_tm, tid);
     // publish L_jj (lower, zeros above), Linv_j and y_j = Linv_j r_j
     double* Linv = C.Linv + (size_t)j * CT_TILE;
     for (int e = tid; e < CT_TILE; e += CT_THREADS) {
