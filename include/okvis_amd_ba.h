@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OKVIS_BA_ABI_VERSION 2
+#define OKVIS_BA_ABI_VERSION 3
 
 /* status codes (0 ok; >0 = hipError_t passthrough + 1000; <0 = argument / state errors) */
 #define OKVIS_BA_OK 0
@@ -141,6 +141,13 @@ typedef struct okvis_ba_window {
   const double* marg_J;            /* [marg_dim][marg_dim] row-major                                   */
   const double* marg_e0;           /* [marg_dim]                                                       */
   const double* marg_lin;          /* [marg_nblocks][9] linearisation points (7 or 9 used)             */
+
+  /* ImuError keeps a mutable preintegration cache whose reference bias (speedAndBiases_ref_, ImuError.hpp) is
+   * the bias of its last redoPreintegration and survives optimize() calls.  Optional: the reference bias each
+   * factor's cache starts from (download it after optimize with OKVIS_BA_ARR_IMU_SB_REF).  NULL / flag 0 = a
+   * brand-new factor: the first evaluation re-preintegrates at the current bias (redo_ = true, ImuError.cpp:62) */
+  const double* imu_sb_ref;        /* [n_imu][9] or NULL */
+  const uint8_t* imu_sb_ref_valid; /* [n_imu] or NULL */
 } okvis_ba_window;
 
 /*
@@ -212,7 +219,8 @@ enum okvis_ba_array {
   OKVIS_BA_ARR_GRADIENT = 12,   /* [D]          un-reduced gradient of the pose/speed-bias part          */
   OKVIS_BA_ARR_IMU_RESIDUAL = 13,/* [n_imu][15] weighted IMU residual at the accepted state             */
   OKVIS_BA_ARR_HPP = 14,        /* [D][D]       un-reduced, un-damped pose/speed-bias Hessian block U (oracle only) */
-  OKVIS_BA_ARR_DAMPING = 15     /* [D]          clamp(diag U) used for the LM damping of the last solve   */
+  OKVIS_BA_ARR_DAMPING = 15,    /* [D]          clamp(diag U) used for the LM damping of the last solve   */
+  OKVIS_BA_ARR_IMU_SB_REF = 16  /* [n_imu][9]   reference speed/bias of each ImuError's preintegration cache */
 };
 
 /* ---- lifecycle ----------------------------------------------------------------------------------- */

@@ -507,7 +507,17 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(imu_s_count, put(A, vec(w.imu_s_count, (size_t)w.n_imu)));
   OFF(imu_s_gyr, put(A, vec(w.imu_s_gyr, w.n_imu ? 3 * (size_t)w.n_imu_samples : 0)));
   OFF(imu_s_acc, put(A, vec(w.imu_s_acc, w.n_imu ? 3 * (size_t)w.n_imu_samples : 0)));
-  OFF(imu_cache, put_zero(A, sizeof(ImuCacheD) * (size_t)w.n_imu));
+  {
+    std::vector<ImuCacheD> caches((size_t)w.n_imu);
+    std::memset(caches.data(), 0, sizeof(ImuCacheD) * caches.size());
+    if (w.imu_sb_ref && w.imu_sb_ref_valid)
+      for (int f = 0; f < w.n_imu; ++f)
+        if (w.imu_sb_ref_valid[f]) {
+          caches[f].valid = 2;
+          for (int k = 0; k < 9; ++k) caches[f].sb_ref[k] = w.imu_sb_ref[9 * (size_t)f + k];
+        }
+    OFF(imu_cache, put(A, caches));
+  }
   OFF(pprior_pose, put(A, vec(w.pprior_pose, (size_t)w.n_pprior)));
   OFF(pprior_meas, put(A, vec(w.pprior_meas, 7 * (size_t)w.n_pprior)));
   OFF(pprior_sqrtinfo, put(A, vec(w.pprior_sqrtinfo, 36 * (size_t)w.n_pprior)));
@@ -1147,6 +1157,7 @@ static int locate(okvis_ba_solver* s, int w, int which, const double** ptr, int6
     case OKVIS_BA_ARR_DAMPING: *ptr = P.Dp2; *n = H.D; return P.Dp2 ? 0 : OKVIS_BA_ERR_STATE;
     case 99: *ptr = P.prof; *n = 64; return 0;
     case 98: *ptr = nullptr; *n = H.n_imu; return 0;  // diagnostics: re-preintegration count per IMU factor
+    case OKVIS_BA_ARR_IMU_SB_REF: *ptr = nullptr; *n = 9 * (int64_t)H.n_imu; return 0;
     case OKVIS_BA_ARR_IMU_RESIDUAL: *ptr = nullptr; *n = 15 * (int64_t)H.n_imu; return 0;
   }
   return OKVIS_BA_ERR_ARG;
@@ -1167,6 +1178,15 @@ int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t
   int rc = locate(s, w, which, &p, &n);
   if (rc != 0) return rc;
   if (n != n_doubles) return OKVIS_BA_ERR_ARG;
+  if (which == OKVIS_BA_ARR_IMU_SB_REF) {
+    const HostWin& H = s->wins[w];
+    for (int f = 0; f < H.n_imu; ++f) {
+      ImuCacheD c;
+      HIP_TRY(hipMemcpy(&c, H.ptrs.imu_cache + f, sizeof(c), hipMemcpyDeviceToHost));
+      for (int k = 0; k < 9; ++k) out[9 * f + k] = c.sb_ref[k];
+    }
+    return OKVIS_BA_OK;
+  }
   if (which == 98) {
     const HostWin& H = s->wins[w];
     for (int f = 0; f < H.n_imu; ++f) {

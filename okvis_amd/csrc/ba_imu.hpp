@@ -478,7 +478,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
 // bias check of ImuError::EvaluateWithMinimalJacobians (ImuError.cpp:541-558): re-preintegrate on first use
 // or when |b_g - b_g,ref| * dt > 1e-4 (rarely taken).
 __device__ void imu_maybe_redo(const WinPtrs& W, int f, int trial, double* lds, int tid) {
-  __shared__ int s_redo;
+  __shared__ int s_redo, s_redo_ref;
   const double* b0 = W.sb[trial] + 9 * (size_t)W.imu_sb0[f];
   double sb0[9];
   for (int i = 0; i < 9; ++i) sb0[i] = b0[i];
@@ -489,9 +489,18 @@ __device__ void imu_maybe_redo(const WinPtrs& W, int f, int trial, double* lds, 
     for (int i = 0; i < 3; ++i) db[i] = sb0[3 + i] - cg->sb_ref[3 + i];
     const double nbg = sqrt(db[0] * db[0] + db[1] * db[1] + db[2] * db[2]);
     s_redo = (!cg->valid) || (nbg * Dt > 0.0001);  // ImuError.cpp:549
+    // a cache inherited from a previous optimize() call (only its reference bias travels): rebuild it at that
+    // reference unless the bias moved past the threshold anyway
+    s_redo_ref = (!s_redo && cg->valid == 2) ? 1 : 0;
   }
   __syncthreads();
-  if (s_redo) imu_redo(W, f, sb0, lds, tid);
+  if (s_redo_ref) {
+    double sbr[9];
+    for (int i = 0; i < 9; ++i) sbr[i] = cg->sb_ref[i];
+    imu_redo(W, f, sbr, lds, tid);
+  } else if (s_redo) {
+    imu_redo(W, f, sb0, lds, tid);
+  }
 }
 
 __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int tid) {

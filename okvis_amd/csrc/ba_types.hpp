@@ -81,7 +81,8 @@ struct ImuCacheD {
   double dalpha_db_g[9], dv_db_g[9], dp_db_g[9];
   double sqrt_info[225];   // upper-triangular L^T
   double sb_ref[9];
-  int valid;               // 0 until the first preintegration (redo_ = true initially)
+  int valid;               // 0 until the first preintegration (redo_ = true initially); 2 = sb_ref was handed
+                           // over by the host (cache of a previous optimize call), integrals not computed yet
   int redo_count;
 };
 

@@ -274,7 +274,7 @@ bool Estimator::addStates(MultiFramePtr multiFrame, const ImuMeasurementDeque& i
   } else {
     const State& last = states_.back();
     imuFactors_.push_back(ImuFactor{last.poseBlock, last.sbBlock, st.poseBlock, st.sbBlock, last.t_ns, st.t_ns,
-                                    imuMeasurements});  // :288-307
+                                    imuMeasurements, {}, false});  // :288-307
     for (size_t i = 0; i < extrinsicsEstimationParametersVec_.size(); ++i) {           // :310-336
       if (last.extBlocks[i] != st.extBlocks[i]) {
         const ExtrinsicsEstimationParameters& ep = extrinsicsEstimationParametersVec_[i];
@@ -393,8 +393,8 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
   f64.assign(24, {});
   i32.assign(24, {});
   i64.assign(4, {});
-  u8.assign(2, {});
-  enum { F_POSE, F_SB, F_LM, F_INTR, F_UV, F_SW, F_GYR, F_ACC, F_PPM, F_PPS, F_SBM, F_SBS, F_RELS, F_MJ, F_ME, F_ML };
+  u8.assign(3, {});
+  enum { F_POSE, F_SB, F_LM, F_INTR, F_UV, F_SW, F_GYR, F_ACC, F_PPM, F_PPS, F_SBM, F_SBS, F_RELS, F_MJ, F_ME, F_ML, F_SBREF };
   enum { I_MODEL, I_OLM, I_OPOSE, I_OEXT, I_OCAM, I_IP0, I_IS0, I_IP1, I_IS1, I_SB, I_SC, I_PPP, I_SBP, I_R0, I_R1,
          I_MT, I_MI, I_MO };
   // parameter blocks (values: estimate, or the linearisation point of prior-connected blocks)
@@ -476,6 +476,8 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
     i64[1].push_back(f.t1);
     i32[I_SB].push_back((int)i64[2].size());
     i32[I_SC].push_back((int)f.meas.size());
+    f64[F_SBREF].insert(f64[F_SBREF].end(), f.sbRef.begin(), f.sbRef.end());
+    u8[2].push_back(f.hasRef ? 1 : 0);
     for (const ImuMeasurement& m : f.meas) {
       i64[2].push_back(m.t_ns);
       f64[F_GYR].insert(f64[F_GYR].end(), m.gyr.begin(), m.gyr.end());
@@ -512,6 +514,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
   w.imu_pose0 = i32[I_IP0].data(); w.imu_sb0 = i32[I_IS0].data(); w.imu_pose1 = i32[I_IP1].data(); w.imu_sb1 = i32[I_IS1].data();
   w.imu_t0 = i64[0].data(); w.imu_t1 = i64[1].data(); w.imu_s_begin = i32[I_SB].data(); w.imu_s_count = i32[I_SC].data();
   w.n_imu_samples = (int)i64[2].size(); w.imu_s_t = i64[2].data(); w.imu_s_gyr = f64[F_GYR].data(); w.imu_s_acc = f64[F_ACC].data();
+  w.imu_sb_ref = f64[F_SBREF].data(); w.imu_sb_ref_valid = u8[2].data();
   if (!imuParametersVec_.empty()) {
     const ImuParameters& ip = imuParametersVec_[0];
     w.imu_params = okvis_ba_imu_params{ip.sigma_g_c, ip.sigma_a_c, ip.sigma_gw_c, ip.sigma_aw_c, ip.g, ip.g_max, ip.a_max};
@@ -564,6 +567,15 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
     std::copy(pose.begin() + 7 * i, pose.begin() + 7 * i + 7, poseBlocks_[sel.pose[i]].x.begin());
   for (size_t i = 0; i < sel.sb.size(); ++i)
     std::copy(sb.begin() + 9 * i, sb.begin() + 9 * i + 9, sbBlocks_[sel.sb[i]].x.begin());
+  if (!sel.imu.empty()) {  // the ImuError caches live on: remember the bias each one was (re)built at
+    std::vector<double> ref(9 * sel.imu.size());
+    check(okvis_ba_download(solver_, 0, OKVIS_BA_ARR_IMU_SB_REF, ref.data(), (int64_t)ref.size()), "imu sb_ref");
+    for (size_t i = 0; i < sel.imu.size(); ++i) {
+      ImuFactor& f = imuFactors_[sel.imu[i]];
+      std::copy(ref.begin() + 9 * i, ref.begin() + 9 * i + 9, f.sbRef.begin());
+      f.hasRef = true;
+    }
+  }
   {
     // update landmarks: quality = sqrt(lambda_min)/sqrt(lambda_max) of the un-robustified H_l and the
     // estimate (Estimator.cpp:880-900)

@@ -179,6 +179,9 @@ class Estimator {
     int pose0Block, sb0Block, pose1Block, sb1Block;  // indices into poseBlocks_ / sbBlocks_
     int64_t t0, t1;
     ImuMeasurementDeque meas;  // the deque is COPIED into the factor (ImuError.hpp:151-153)
+    // reference bias of the factor's preintegration cache after the last optimize() (speedAndBiases_ref_)
+    std::array<double, 9> sbRef{};
+    bool hasRef = false;
   };
   struct PosePrior {
     int block;

@@ -45,6 +45,7 @@ class WindowC(C.Structure):
         ("marg_dim", C.c_int32), ("marg_nblocks", C.c_int32), ("marg_block_type", _ip),
         ("marg_block_idx", _ip), ("marg_block_off", _ip), ("marg_J", _dp), ("marg_e0", _dp),
         ("marg_lin", _dp),
+        ("imu_sb_ref", _dp), ("imu_sb_ref_valid", _bp),
     ]
 
 
@@ -216,6 +217,8 @@ class Window:
     marg_J: np.ndarray = field(default_factory=lambda: np.zeros((0, 0)))
     marg_e0: np.ndarray = field(default_factory=lambda: np.zeros(0))
     marg_lin: np.ndarray = field(default_factory=lambda: np.zeros((0, 9)))
+    imu_sb_ref: np.ndarray = field(default_factory=lambda: np.zeros((0, 9)))       # [n_imu,9] or empty
+    imu_sb_ref_valid: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint8))
     meta: dict = field(default_factory=dict)   # generator bookkeeping (truth etc.); never uploaded
 
     # ------------------------------------------------------------------------------------------
@@ -281,6 +284,8 @@ class Window:
         md = int(np.asarray(self.marg_e0).size)
         k["marg_J"] = _f64(self.marg_J, (md, md)); k["marg_e0"] = _f64(self.marg_e0, (-1,))
         k["marg_lin"] = _f64(self.marg_lin, (-1, 9))
+        k["imu_sb_ref"] = _f64(self.imu_sb_ref, (-1, 9))
+        k["imu_sb_ref_valid"] = np.ascontiguousarray(self.imu_sb_ref_valid, np.uint8)
 
         def p(name, typ):
             a = k[name]
@@ -312,4 +317,6 @@ class Window:
         w.marg_block_type = p("marg_block_type", _ip); w.marg_block_idx = p("marg_block_idx", _ip)
         w.marg_block_off = p("marg_block_off", _ip)
         w.marg_J = p("marg_J", _dp); w.marg_e0 = p("marg_e0", _dp); w.marg_lin = p("marg_lin", _dp)
+        if k["imu_sb_ref"].shape[0] == w.n_imu and k["imu_sb_ref_valid"].size == w.n_imu and w.n_imu > 0:
+            w.imu_sb_ref = p("imu_sb_ref", _dp); w.imu_sb_ref_valid = p("imu_sb_ref_valid", _bp)
         return w, k

@@ -736,6 +736,16 @@ orc_window* orc_window_create(const okvis_ba_window* w) {
   h->imu_s_acc = copyv(w->imu_s_acc, 3 * (size_t)w->n_imu_samples);
   h->imu_params = make_params(&w->imu_params);
   h->imu_cache.assign(w->n_imu, ImuCache());
+  // an ImuError object that lived through earlier optimize() calls: its cache was built at sb_ref
+  if (w->imu_sb_ref && w->imu_sb_ref_valid)
+    for (int f = 0; f < w->n_imu; ++f)
+      if (w->imu_sb_ref_valid[f]) {
+        ImuSamples smp{w->imu_s_count[f], w->imu_s_t + w->imu_s_begin[f], w->imu_s_gyr + 3 * (size_t)w->imu_s_begin[f],
+                       w->imu_s_acc + 3 * (size_t)w->imu_s_begin[f]};
+        imu_redo_preintegration(smp, h->imu_params, w->imu_t0[f], w->imu_t1[f], w->imu_sb_ref + 9 * (size_t)f,
+                                &h->imu_cache[f]);
+        h->imu_cache[f].redo = false;
+      }
   h->pprior_pose = copyv(w->pprior_pose, (size_t)w->n_pprior);
   h->pprior_meas = copyv(w->pprior_meas, 7 * (size_t)w->n_pprior);
   h->pprior_sqrtinfo = copyv(w->pprior_sqrtinfo, 36 * (size_t)w->n_pprior);
@@ -821,10 +831,17 @@ static const std::vector<double>* pick(orc_window* h, int which) {
   return nullptr;
 }
 int64_t orc_window_array_size(orc_window* h, int which) {
+  if (which == OKVIS_BA_ARR_IMU_SB_REF) return 9 * (int64_t)h->n_imu;
   const std::vector<double>* v = pick(h, which);
   return v ? (int64_t)v->size() : -1;
 }
 int orc_window_download(orc_window* h, int which, double* out, int64_t n) {
+  if (which == OKVIS_BA_ARR_IMU_SB_REF) {
+    if (n != 9 * (int64_t)h->n_imu) return -1;
+    for (int f = 0; f < h->n_imu; ++f)
+      for (int k = 0; k < 9; ++k) out[9 * f + k] = h->imu_cache[f].sb_ref[k];
+    return 0;
+  }
   const std::vector<double>* v = pick(h, which);
   if (!v || (int64_t)v->size() != n) return -1;
   std::memcpy(out, v->data(), n * 8);

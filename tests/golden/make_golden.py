@@ -172,7 +172,7 @@ def pack_window(prefix, w, out):
 
 
 def unpack_window(prefix, z):
-    kw = {k: z[prefix + k] for k in WINDOW_FIELDS}
+    kw = {k: z[prefix + k] for k in WINDOW_FIELDS if prefix + k in z}   # fields added later keep their defaults
     prm = ImuParams(**{f.name: float(v) for f, v in zip(dataclasses.fields(ImuParams), z[prefix + "imu_params"])})
     return Window(cauchy_b=float(z[prefix + "cauchy_b"]), imu_params=prm, **kw)
 

@@ -21,7 +21,7 @@ _ip = C.POINTER(C.c_int32)
 
 # array ids (include/okvis_amd_ba.h enum okvis_ba_array)
 ARR = dict(POSE=0, SB=1, LM=2, OBS_RESIDUAL=3, LM_V=4, LM_B=5, LM_HQ=6, PAIR_W=7, REDUCED_S=8,
-           REDUCED_RHS=9, STEP=10, LM_QUALITY=11, GRADIENT=12, IMU_RESIDUAL=13, HPP=14)
+           REDUCED_RHS=9, STEP=10, LM_QUALITY=11, GRADIENT=12, IMU_RESIDUAL=13, HPP=14, IMU_SB_REF=16)
 
 
 def build_oracle():

@@ -275,3 +275,35 @@ def test_config_C_full_size(oracle):
         r = oracle.OracleWindow(wi).optimize(6)
         assert abs(s2[i]["final_cost"] - r["final_cost"]) <= 1e-9 * r["final_cost"]
     b.close(); bb.close()
+
+
+def test_inherited_imu_reference_bias(oracle):
+    """ImuError's preintegration cache survives optimize() calls in the reference (speedAndBiases_ref_): a window
+    can hand over the reference bias of every factor.  Within the 1e-4 threshold the factor is evaluated with the
+    first-order bias correction around that reference (no re-preintegration at the current bias); beyond it the
+    cache is rebuilt (ImuError.cpp:541-558)."""
+    w = synthetic.small_window(seed=61, K=4, L=40)
+    n = w.n_imu
+    for scale, expect_same_ref in ((2e-5, True), (5e-3, False)):
+        ref = np.array([w.sb[w.imu_sb0[f]] for f in range(n)])
+        ref[:, 3:6] += scale * np.array([1.0, -1.0, 0.5])
+        w.imu_sb_ref = ref
+        w.imu_sb_ref_valid = np.ones(n, np.uint8)
+        b = _batch([w], debug_arrays=1)
+        o = oracle.OracleWindow(w)
+        c_ref = o.linearize()
+        b.begin()
+        s = b.finish()[0]
+        assert abs(s["final_cost"] - c_ref) <= 1e-11 * c_ref
+        _close(b.array("IMU_RESIDUAL"), o.array("IMU_RESIDUAL"), 1e-8)
+        gref = b.array("IMU_SB_REF").reshape(n, 9)
+        _close(gref, o.array("IMU_SB_REF").reshape(n, 9), 1e-15)
+        assert np.array_equal(gref, ref) == expect_same_ref
+        # and it changes the numbers: a fresh factor (no reference) evaluates differently when the reference is kept
+        w2 = synthetic.small_window(seed=61, K=4, L=40)
+        c_fresh = oracle.OracleWindow(w2).linearize()
+        assert (c_fresh != c_ref) == expect_same_ref
+        so = o.optimize(6)
+        sg = b.optimize(6)[0]
+        assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
+        b.close()

@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), name
     assert set(_lib.SYMBOLS) == declared
-    assert L.okvis_ba_abi_version() == 2
+    assert L.okvis_ba_abi_version() == 3
 
 
 def test_struct_layout_matches_header():
