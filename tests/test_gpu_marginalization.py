@@ -107,3 +107,39 @@ def test_optimize_after_marginalize_still_works(oracle):
     so = o.optimize(6)
     assert abs(s["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
     b.close()
+
+
+def test_argument_and_state_errors():
+    """Status codes of the C-ABI (no exceptions across the boundary): ERR_ARG (-1), ERR_STATE (-2),
+    ERR_UNSUPPORTED (-3)."""
+    import ctypes as C
+    from okvis_amd import _lib, solver
+    from okvis_amd.window import MargResultC, MargSpecC, marg_call
+    L = _lib.lib()
+    w = synthetic.small_window(seed=46, K=3, L=20)
+    b = solver.WindowBatch([w], options=default_options())
+    # call order: iterate / finish before begin
+    assert L.okvis_ba_iterate(b._h, 1) == -2 and L.okvis_ba_finish(b._h, None) == -2
+    # marginalize: window index, missing flags, inconsistent prior
+    st, _ = marg_call(lambda sp, rs: L.okvis_ba_marginalize(b._h, 5, sp, rs), w.n_pose, w.n_sb, np.zeros(w.n_pose), np.zeros(w.n_sb))
+    assert st == -1
+    assert L.okvis_ba_marginalize(b._h, 0, None, None) == -1
+    bad_prior = dict(block_type=[0], block_idx=[99], H=np.eye(6), b0=np.zeros(6))
+    st, _ = marg_call(lambda sp, rs: L.okvis_ba_marginalize(b._h, 0, sp, rs), w.n_pose, w.n_sb, np.zeros(w.n_pose), np.zeros(w.n_sb), bad_prior)
+    assert st == -1
+    # result arrays too small
+    spec, res = MargSpecC(), MargResultC()
+    pm = np.zeros(w.n_pose, np.uint8); sm = np.zeros(w.n_sb, np.uint8)
+    bp = C.POINTER(C.c_uint8)
+    spec.pose_marg, spec.sb_marg = pm.ctypes.data_as(bp), sm.ctypes.data_as(bp)
+    res.capacity_dim, res.capacity_blocks = 3, 1
+    assert L.okvis_ba_marginalize(b._h, 0, C.byref(spec), C.byref(res)) == -1
+    b.close()
+    # a window that already carries a marg_* prior, and one beyond the LDS solve path
+    big = synthetic.make_window(20, 30, 1.0, 2, frame_dt=0.1)    # D = 300
+    b2 = solver.WindowBatch([big], options=default_options())
+    st, _ = marg_call(lambda sp, rs: L.okvis_ba_marginalize(b2._h, 0, sp, rs), big.n_pose, big.n_sb, np.zeros(big.n_pose), np.zeros(big.n_sb))
+    assert st == -3
+    b2.close()
+    # dense solve: argument check
+    assert L.okvis_ba_dense_solve(0, 0, None, None, None, None) == -1

@@ -28,13 +28,14 @@ def test_library_exports_every_header_symbol():
 def test_struct_layout_matches_header():
     # sizes computed by the C compiler for the same header (guards the ctypes mirror)
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "okvis_amd_ba.h"\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(okvis_ba_window),sizeof(okvis_ba_options),sizeof(okvis_ba_summary),sizeof(okvis_ba_limits));return 0;}\n'
+    src = '#include <stdio.h>\n#include "okvis_amd_ba.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",sizeof(okvis_ba_window),sizeof(okvis_ba_options),sizeof(okvis_ba_summary),sizeof(okvis_ba_limits),sizeof(okvis_ba_marg_spec),sizeof(okvis_ba_marg_result));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).split()
-    from okvis_amd.window import LimitsC, SummaryC
-    assert [int(x) for x in out] == [C.sizeof(WindowC), C.sizeof(OptionsC), C.sizeof(SummaryC), C.sizeof(LimitsC)]
+    from okvis_amd.window import LimitsC, MargResultC, MargSpecC, SummaryC
+    assert [int(x) for x in out] == [C.sizeof(WindowC), C.sizeof(OptionsC), C.sizeof(SummaryC), C.sizeof(LimitsC),
+                                     C.sizeof(MargSpecC), C.sizeof(MargResultC)]
 
 
 def test_no_cpu_fallback_without_gpu():
