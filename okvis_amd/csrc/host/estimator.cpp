@@ -3,6 +3,7 @@
 #include "estimator.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -549,15 +550,21 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
 // ---------------------------------------------------------------------------------------------------
 void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/) {
   if (states_.empty()) return;
+  typedef std::chrono::steady_clock clk;
+  auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = clk::now();
   const WindowSel sel = selectAll();
   FlatWindow fw;
   flatten(sel, fw);
+  const auto t1 = clk::now();
   check(okvis_ba_set_options(solver_, &options_), "set_options");
   check(okvis_ba_upload(solver_, 1, &fw.w), "upload");
+  const auto t2 = clk::now();
   if (hasTimeLimit_)  // CeresIterationCallback semantics (CeresIterationCallback.hpp:77-86)
     check(okvis_ba_optimize_timed(solver_, (int)numIter, minIterations_, timeLimit_, &summary_), "optimize");
   else
     check(okvis_ba_optimize(solver_, (int)numIter, &summary_), "optimize");
+  const auto t3 = clk::now();
   // copy the estimates back (the reference's parameter blocks are updated in place by Ceres)
   const size_t nl = sel.landmarks.size();
   std::vector<double> pose(7 * sel.pose.size()), sb(9 * sel.sb.size()), lm(4 * nl), q(nl);
@@ -586,6 +593,7 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
       std::copy(lm.begin() + 4 * i, lm.begin() + 4 * i + 4, mp.point.begin());
     }
   }
+  timings_ = {ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, clk::now())};
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -136,6 +136,9 @@ class Estimator {
   void setLandmarkInitialized(uint64_t landmarkId, bool initialized);
   void setKeyframe(uint64_t frameId, bool isKeyframe);
 
+  // wall-clock split of the last optimize() in ms: flatten, okvis_ba_upload, iterations, downloads
+  const std::array<double, 4>& lastOptimizeTimings() const { return timings_; }
+
   // ---- diagnostics of the marginalisation prior (MarginalizationError::num_residuals etc.) ----
   int priorDimension() const { return prior_.dim; }
   size_t priorNumBlocks() const { return prior_.block.size(); }
@@ -251,6 +254,7 @@ class Estimator {
   std::vector<SbPrior> sbPriors_;
   std::vector<RelPose> relPoses_;
   MargPrior prior_;
+  std::array<double, 4> timings_{};
   uint64_t nextId_ = 1ULL << 40;    // IdProvider::instance().newId() stand-in for internal blocks
   uint64_t nextHandle_ = 1;
   mutable std::mutex statesMutex_;  // guards getLandmark(s) like Estimator.cpp:936,956,965

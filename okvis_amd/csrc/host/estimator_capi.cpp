@@ -190,6 +190,20 @@ int okvis_est_is_keyframe(void* h, uint64_t id) {
 int okvis_est_is_in_imu_window(void* h, uint64_t id) {
   return guarded([&] { return static_cast<Estimator*>(h)->isInImuWindow(id) ? 1 : 0; });
 }
+int okvis_est_last_timings(void* h, double out[4]) {
+  return guarded([&] {
+    const auto& t = static_cast<Estimator*>(h)->lastOptimizeTimings();
+    for (int i = 0; i < 4; ++i) out[i] = t[i];
+    return 1;
+  });
+}
+// solver options of the backend (okvis_ba_options): launch mode of the iteration loop
+int okvis_est_set_use_graph(void* h, int use_graph) {
+  return guarded([&] {
+    static_cast<Estimator*>(h)->options().use_graph = use_graph;
+    return 1;
+  });
+}
 int okvis_est_num_frames(void* h) { return (int)static_cast<Estimator*>(h)->numFrames(); }
 int okvis_est_num_landmarks(void* h) { return (int)static_cast<Estimator*>(h)->numLandmarks(); }
 int okvis_est_current_frame_id(void* h, uint64_t* id) {

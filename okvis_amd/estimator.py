@@ -45,6 +45,8 @@ def lib():
         L.okvis_est_get_extrinsics.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _dp]
         L.okvis_est_get_landmark.argtypes = [C.c_void_p, C.c_uint64, _dp, _dp, C.POINTER(C.c_int)]
         L.okvis_est_num_frames.argtypes = [C.c_void_p]
+        L.okvis_est_set_use_graph.argtypes = [C.c_void_p, C.c_int]
+        L.okvis_est_last_timings.argtypes = [C.c_void_p, _dp]
         L.okvis_est_apply_marginalization2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.c_int]
         L.okvis_est_prior_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.okvis_est_frame_id_by_age.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
@@ -162,6 +164,15 @@ class Estimator:
         if removed is not None:
             removed.extend(int(ids[i]) for i in range(min(n.value, cap)))
         return ok
+
+    def lastOptimizeTimings(self):
+        """ms: flatten, upload (host index build + H2D), iterations, downloads."""
+        out = np.zeros(4)
+        _chk(lib().okvis_est_last_timings(self._h, out.ctypes.data_as(_dp)))
+        return out
+
+    def setUseGraph(self, use_graph):
+        _chk(lib().okvis_est_set_use_graph(self._h, int(use_graph)))
 
     def priorInfo(self):
         d, nb = C.c_int(), C.c_int()

@@ -11,7 +11,7 @@ from okvis_amd import estimator, synthetic
 from okvis_amd.window import DIST_EQUIDISTANT, ImuParams
 
 
-def main(n_frames=40, num_iter=10, grid=0.5):
+def main(n_frames=40, num_iter=10, grid=0.5, use_graph=None):
     rng = np.random.default_rng(11)
     IMU_RATE, FRAME_DT = 200.0, 0.25
     DT = 1.0 / IMU_RATE
@@ -25,6 +25,8 @@ def main(n_frames=40, num_iter=10, grid=0.5):
     T_SC = np.array([[0, 0, 0, 0, 0, 0, 1.0], [0, 0.1, 0, 0, 0, 0, 1.0]])
     intr = np.stack([synthetic.TEST_INTR_EQUI, synthetic.TEST_INTR_EQUI])
     est = estimator.Estimator(0)
+    if use_graph is not None:
+        est.setUseGraph(use_graph)
     est.addCamera(0, 0, 0, 0); est.addCamera(0, 0, 0, 0)
     est.addImu(estimator.imu_param_vector(prm))
     pts = np.array([[3.0, y, z, 1.0] for y in np.arange(-6.0, DURATION + 6.0, grid) for z in np.arange(-4.0, 4.0 + 1e-9, grid)])
@@ -55,25 +57,27 @@ def main(n_frames=40, num_iter=10, grid=0.5):
         t1 = time.perf_counter()
         s = est.optimize(num_iter, 2, False)
         t2 = time.perf_counter()
+        tm = est.lastOptimizeTimings()
         removed = []
         est.applyMarginalizationStrategy(5, 3, removed)
         gone.update(removed)
         t3 = time.perf_counter()
         rows.append(dict(frame=k, new_obs=n_obs, landmarks=est.numLandmarks(), frames=est.numFrames(), iterations=s["iterations"],
-                         add_ms=(t1 - t0) * 1e3, optimize_ms=(t2 - t1) * 1e3, marginalize_ms=(t3 - t2) * 1e3, prior_dim=est.priorInfo()[0]))
+                         add_ms=(t1 - t0) * 1e3, optimize_ms=(t2 - t1) * 1e3, marginalize_ms=(t3 - t2) * 1e3, prior_dim=est.priorInfo()[0],
+                         flatten_ms=tm[0], upload_ms=tm[1], iterate_ms=tm[2], download_ms=tm[3]))
     T = est.get_T_WS(100 + n_frames - 1)
     err = float(np.linalg.norm(T[:3] - speed * (n_frames - 1) * FRAME_DT))
     est.close()
     steady = rows[10:]
     med = lambda key: float(np.median([r[key] for r in steady]))
-    print(json.dumps({"frames": n_frames, "num_iter": num_iter, "final_position_error_m": err,
+    print(json.dumps({"use_graph": use_graph, "frames": n_frames, "num_iter": num_iter, "final_position_error_m": err,
                       "steady_state_median": {"observations_added_per_frame": med("new_obs"), "landmarks_in_window": med("landmarks"),
                                               "frames_in_window": med("frames"), "prior_dim": med("prior_dim"),
                                               "optimize_ms": med("optimize_ms"), "marginalize_ms": med("marginalize_ms"),
-                                              "iterations": med("iterations")},
+                                              "iterations": med("iterations"), "optimize_split_ms": {k: med(k + "_ms") for k in ("flatten", "upload", "iterate", "download")}},
                       "note": "wall clock around the C++ host calls: optimize() = flatten + okvis_ba_upload (host index build + H2D) + "
                               "iterations on the GPU + state/quality/IMU-reference download; addStates/addObservation time is dominated by the Python test harness"}))
 
 
 if __name__ == "__main__":
-    main(grid=float(sys.argv[1]) if len(sys.argv) > 1 else 0.5)
+    main(grid=float(sys.argv[1]) if len(sys.argv) > 1 else 0.5, use_graph=int(sys.argv[2]) if len(sys.argv) > 2 else None)
