@@ -331,7 +331,30 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       st9(lds + ImuLds::RINV, tid, t9);
     }
     __syncthreads();
-    // ---- stage 8: covariance recursion over this chunk
+    // ---- stage 8: covariance recursion over this chunk.  Work-item -> matrix entry mapping: every wave owns
+    //      ONE row type in the first phase (T = F P) and ONE column type in the second (P = T F^T + Q), so no
+    //      wave executes more than one branch of the sparse F:  wave 0: p rows/cols (45 entries), wave 1: v,
+    //      wave 2: alpha, wave 3 + the spare lanes of waves 0/1: the 90 bias entries (plain copies).
+    int r1 = -1, c1i = 0, r2 = -1, c2i = 0;  // (row, col) of this work-item in phase 1 / phase 2
+    {
+      const int t = tid & 63, wv = tid >> 6;
+      int be = -1;  // index into the 90 bias entries
+      if (wv < 3 && t < 45) {
+        const int base = (wv == 0) ? 0 : (wv == 1 ? 6 : 3);
+        r1 = base + t / 15; c1i = t % 15;
+        r2 = t / 3; c2i = base + t % 3;
+      } else if (wv == 3) {
+        be = t;
+      } else if (wv == 0 && t >= 45) {
+        be = 64 + (t - 45);           // 64 .. 82
+      } else if (wv == 1 && t >= 45 && t < 52) {
+        be = 83 + (t - 45);           // 83 .. 89
+      }
+      if (be >= 0) {
+        r1 = 9 + be / 15; c1i = be % 15;   // bias rows
+        r2 = be / 6; c2i = 9 + be % 6;     // bias columns
+      }
+    }
     for (int k = 0; k < ns; ++k) {
       const double* adbl = lds + ImuLds::ADBL + 3 * k;
       const double* dpt = lds + ImuLds::RINV + 9 * k;
@@ -341,42 +364,43 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       const double* dvt = lds + ImuLds::DVT + 9 * k;
       const double* ci = lds + ImuLds::CINT + 9 * k;
       const double dtk = lds[ImuLds::DT + k];
-      if (tid < 225) T[tid] = imu_F_apply(P, pi, pj, adbl, dtk, dpt, b012, c1, ai, dvt, ci);
+      if (r1 >= 0) T[15 * r1 + c1i] = imu_F_apply(P, r1, c1i, adbl, dtk, dpt, b012, c1, ai, dvt, ci);
       __syncthreads();
-      if (tid < 225) {
+      if (r2 >= 0) {
+        const int pi2 = r2, pj2 = c2i;
         // (T F^T)_ij = sum_m T_im F_jm: row pj of the sparse F against row pi of T
-        double v = T[15 * pi + pj];
-        if (pj < 3) {
+        double v = T[15 * pi2 + pj2];
+        if (pj2 < 3) {
           double cx[9];
           cross_mx(adbl, cx);
           for (int m = 0; m < 3; ++m) {
-            v -= cx[3 * pj + m] * T[15 * pi + 3 + m];
-            v += dpt[3 * pj + m] * T[15 * pi + 9 + m];
-            v += b012[3 * pj + m] * T[15 * pi + 12 + m];
+            v -= cx[3 * pj2 + m] * T[15 * pi2 + 3 + m];
+            v += dpt[3 * pj2 + m] * T[15 * pi2 + 9 + m];
+            v += b012[3 * pj2 + m] * T[15 * pi2 + 12 + m];
           }
-          v += dtk * T[15 * pi + 6 + pj];
-        } else if (pj < 6) {
-          const int r = pj - 3;
-          for (int m = 0; m < 3; ++m) v -= dtk * c1[3 * r + m] * T[15 * pi + 9 + m];
-        } else if (pj < 9) {
-          const int r = pj - 6;
+          v += dtk * T[15 * pi2 + 6 + pj2];
+        } else if (pj2 < 6) {
+          const int r = pj2 - 3;
+          for (int m = 0; m < 3; ++m) v -= dtk * c1[3 * r + m] * T[15 * pi2 + 9 + m];
+        } else if (pj2 < 9) {
+          const int r = pj2 - 6;
           double cx[9];
           cross_mx(ai, cx);
           for (int m = 0; m < 3; ++m) {
-            v -= cx[3 * r + m] * T[15 * pi + 3 + m];
-            v += dvt[3 * r + m] * T[15 * pi + 9 + m];
-            v -= ci[3 * r + m] * T[15 * pi + 12 + m];
+            v -= cx[3 * r + m] * T[15 * pi2 + 3 + m];
+            v += dvt[3 * r + m] * T[15 * pi2 + 9 + m];
+            v -= ci[3 * r + m] * T[15 * pi2 + 12 + m];
           }
         }
-        if (pi == pj) {  // noise (ImuError.cpp:228-249)
+        if (pi2 == pj2) {  // noise (ImuError.cpp:228-249)
           const double s2a = lds[ImuLds::SG2 + k], s2v = lds[ImuLds::SA2 + k];
-          if (pi < 3) v += 0.5 * dtk * dtk * s2v;
-          else if (pi < 6) v += s2a;
-          else if (pi < 9) v += s2v;
-          else if (pi < 12) v += dtk * prm.sigma_gw_c * prm.sigma_gw_c;
+          if (pi2 < 3) v += 0.5 * dtk * dtk * s2v;
+          else if (pi2 < 6) v += s2a;
+          else if (pi2 < 9) v += s2v;
+          else if (pi2 < 12) v += dtk * prm.sigma_gw_c * prm.sigma_gw_c;
           else v += dtk * prm.sigma_aw_c * prm.sigma_aw_c;
         }
-        P[tid] = v;
+        P[15 * pi2 + pj2] = v;
       }
       __syncthreads();
     }
