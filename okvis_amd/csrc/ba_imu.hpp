@@ -42,7 +42,12 @@ struct ImuLds {
   static constexpr int FM = TM + 225;            // 450  F = [F0 | F1]
   static constexpr int EV = FM + 450;            // 16   error vector
   static constexpr int CA = EV + 16;             // cache copy: see below (300)
-  static constexpr int TOTAL = CA + 320;
+  // exclusive prefixes (index k = value BEFORE step k; index ns = carry into the next chunk)
+  static constexpr int CINTP = CA + 320;                 // 9(N+1)
+  static constexpr int AINTP = CINTP + 9 * (IMU_N + 1);  // 3(N+1)
+  static constexpr int CROSSP = AINTP + 3 * (IMU_N + 1); // 9(N+1)
+  static constexpr int DVP = CROSSP + 9 * (IMU_N + 1);   // 9(N+1)
+  static constexpr int TOTAL = DVP + 9 * (IMU_N + 1);
 };
 // compact LDS layout of the evaluate kernel (no re-preintegration scratch): J | F | e | cache copy
 struct EvalLds {
@@ -120,7 +125,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
   __shared__ long long s_ts[IMU_N], s_tn[IMU_N];
   __shared__ int s_nsteps, s_next_it, s_started, s_finished;
   __shared__ long long s_time;
-  __shared__ double c_Dq[4], c_Cint[9], c_aint[3], c_cross[9], c_dv[9];  // carries
+  __shared__ double c_Dq[4];  // carry of Delta_q; the other carries sit at index 0 of the prefix arrays
   __shared__ double t_Cdbl[9], t_adbl[3], t_dal[9], t_dp[9];              // running totals
   const int n = W.imu_s_count[f];
   const long long* ts = W.imu_s_t + W.imu_s_begin[f];
@@ -141,10 +146,11 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
     c_Dq[3] = 1.0;
   }
   if (tid < 9) {
-    c_Cint[tid] = 0; c_cross[tid] = 0; c_dv[tid] = 0; t_Cdbl[tid] = 0; t_dal[tid] = 0; t_dp[tid] = 0;
+    lds[ImuLds::CINTP + tid] = 0; lds[ImuLds::CROSSP + tid] = 0; lds[ImuLds::DVP + tid] = 0;
+    t_Cdbl[tid] = 0; t_dal[tid] = 0; t_dp[tid] = 0;
   }
   if (tid < 3) {
-    c_aint[tid] = 0; t_adbl[tid] = 0;
+    lds[ImuLds::AINTP + tid] = 0; t_adbl[tid] = 0;
   }
   if (tid < 225) P[tid] = 0.0;
   __syncthreads();
@@ -242,15 +248,32 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       lds[ImuLds::SA2 + tid] = dt * sa * sa;
     }
     __syncthreads();
-    // ---- stage 2: Delta_q_k = Delta_q_carry (x) dq_0 (x) ... (x) dq_(k-1), the reference's product order
-    if (tid <= ns) {
+    // ---- stage 2: Delta_q_k = Delta_q_carry (x) dq_0 (x) ... (x) dq_(k-1), the reference's product order, by
+    //      one work-item; meanwhile (another wave) the recursion cross_(k+1) = R(dq_k)^T cross_k + Jr_k dt_k,
+    //      one work-item per column of `cross`
+    if (tid == 0) {
       double q[4] = {c_Dq[0], c_Dq[1], c_Dq[2], c_Dq[3]};
-      for (int j = 0; j < tid; ++j) {
+      for (int c = 0; c < 4; ++c) lds[ImuLds::DQP + c] = q[c];
+      for (int j = 0; j < ns; ++j) {
         double t[4];
         qmul(q, lds + ImuLds::DQ + 4 * j, t);
         q[0] = t[0]; q[1] = t[1]; q[2] = t[2]; q[3] = t[3];
+        for (int c = 0; c < 4; ++c) lds[ImuLds::DQP + 4 * (j + 1) + c] = q[c];
       }
-      for (int c = 0; c < 4; ++c) lds[ImuLds::DQP + 4 * tid + c] = q[c];
+    } else if (tid >= 64 && tid < 67) {
+      const int col = tid - 64;
+      double x0 = lds[ImuLds::CROSSP + col], x1 = lds[ImuLds::CROSSP + 3 + col], x2 = lds[ImuLds::CROSSP + 6 + col];
+      for (int j = 0; j < ns; ++j) {
+        const double* Ri = lds + ImuLds::RINV + 9 * j;
+        const double* Jd = lds + ImuLds::JRDT + 9 * j;
+        const double y0 = Ri[0] * x0 + Ri[1] * x1 + Ri[2] * x2 + Jd[col];
+        const double y1 = Ri[3] * x0 + Ri[4] * x1 + Ri[5] * x2 + Jd[3 + col];
+        const double y2 = Ri[6] * x0 + Ri[7] * x1 + Ri[8] * x2 + Jd[6 + col];
+        x0 = y0; x1 = y1; x2 = y2;
+        lds[ImuLds::CROSSP + 9 * (j + 1) + col] = x0;
+        lds[ImuLds::CROSSP + 9 * (j + 1) + 3 + col] = x1;
+        lds[ImuLds::CROSSP + 9 * (j + 1) + 6 + col] = x2;
+      }
     }
     __syncthreads();
     // ---- stage 3
@@ -275,27 +298,26 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       st9(lds + ImuLds::C1, tid, C1m);
     }
     __syncthreads();
-    // ---- stage 4: ordered prefix sums + the cross recursion (registers), starting from the carries
-    double Cint[9], aint[3], cross[9];
-    for (int c = 0; c < 9; ++c) {
-      Cint[c] = c_Cint[c];
-      cross[c] = c_cross[c];
-    }
-    for (int c = 0; c < 3; ++c) aint[c] = c_aint[c];
-    if (tid < ns) {
-      for (int j = 0; j < tid; ++j) {
-        for (int c = 0; c < 9; ++c) Cint[c] += lds[ImuLds::CINT + 9 * j + c];
-        for (int c = 0; c < 3; ++c) aint[c] += lds[ImuLds::AINT + 3 * j + c];
-        double Ri[9], t9[9];
-        ld9(lds + ImuLds::RINV, j, Ri);
-        mat3_mul(Ri, cross, t9);
-        for (int c = 0; c < 9; ++c) cross[c] = t9[c] + lds[ImuLds::JRDT + 9 * j + c];
+    // ---- stage 4: ordered prefix sums of the integrals, one work-item per component
+    if (tid < 12) {
+      const int base_p = tid < 9 ? ImuLds::CINTP + tid : ImuLds::AINTP + (tid - 9);
+      const int base_i = tid < 9 ? ImuLds::CINT + tid : ImuLds::AINT + (tid - 9);
+      const int st = tid < 9 ? 9 : 3;
+      double a = lds[base_p];
+      for (int j = 0; j < ns; ++j) {
+        a += lds[base_i + st * j];
+        lds[base_p + st * (j + 1)] = a;
       }
     }
+    __syncthreads();
     // ---- stage 5
     double G[9];
-    double cross1[9];
     if (tid < ns) {
+      double Cint[9], aint[3], cross[9], cross1[9];
+      ld9(lds + ImuLds::CINTP, tid, Cint);
+      for (int c = 0; c < 3; ++c) aint[c] = lds[ImuLds::AINTP + 3 * tid + c];
+      ld9(lds + ImuLds::CROSSP, tid, cross);
+      ld9(lds + ImuLds::CROSSP, tid + 1, cross1);
       double q[9], t3[3], t9[9];
       for (int c = 0; c < 9; ++c) q[c] = 0.25 * CC[c];
       mat3_vec(q, ab, t3);
@@ -304,10 +326,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       st9(lds + ImuLds::CDBL, tid, t9);
       for (int c = 0; c < 9; ++c) t9[c] = -Cint[c] * dt + q[c] * dt * dt;
       st9(lds + ImuLds::B012, tid, t9);
-      double Ri[9], ax[9], C1m[9], u[9], v[9];
-      ld9(lds + ImuLds::RINV, tid, Ri);
-      mat3_mul(Ri, cross, cross1);
-      for (int c = 0; c < 9; ++c) cross1[c] += lds[ImuLds::JRDT + 9 * tid + c];
+      double ax[9], C1m[9], u[9], v[9];
       cross_mx(ab, ax);
       ld9(lds + ImuLds::C1, tid, C1m);
       mat3_mul(C, ax, u);
@@ -321,13 +340,18 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       st9(lds + ImuLds::DVT, tid, t9);
     }
     __syncthreads();
-    // ---- stage 6: dp_term (aliases RINV, no longer needed)
+    // ---- stage 6: prefix of dv/db_g (one work-item per component), then dp_term (aliases RINV, no longer needed)
+    if (tid < 9) {
+      double a = lds[ImuLds::DVP + tid];
+      for (int j = 0; j < ns; ++j) {
+        a += lds[ImuLds::DVT + 9 * j + tid];
+        lds[ImuLds::DVP + 9 * (j + 1) + tid] = a;
+      }
+    }
+    __syncthreads();
     if (tid < ns) {
-      double dv[9], t9[9];
-      for (int c = 0; c < 9; ++c) dv[c] = c_dv[c];
-      for (int j = 0; j < tid; ++j)
-        for (int c = 0; c < 9; ++c) dv[c] += lds[ImuLds::DVT + 9 * j + c];
-      for (int c = 0; c < 9; ++c) t9[c] = dt * dv[c] + 0.25 * dt * dt * G[c];
+      double t9[9];
+      for (int c = 0; c < 9; ++c) t9[c] = dt * lds[ImuLds::DVP + 9 * tid + c] + 0.25 * dt * dt * G[c];
       st9(lds + ImuLds::RINV, tid, t9);
     }
     __syncthreads();
@@ -404,31 +428,28 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       }
       __syncthreads();
     }
-    // ---- stage 7: fold this chunk into the carries / running totals (ordered sums)
+    // ---- stage 7: running totals (ordered sums, one work-item per component); the carries of the prefix arrays
+    //      move from index ns to index 0
     {
-      double add = 0;
-      int base = -1, stride = 0, comp = 0;
-      if (tid < 9) { base = ImuLds::CINT; stride = 9; comp = tid; }
-      else if (tid < 18) { base = ImuLds::CDBL; stride = 9; comp = tid - 9; }
-      else if (tid < 21) { base = ImuLds::AINT; stride = 3; comp = tid - 18; }
-      else if (tid < 24) { base = ImuLds::ADBL; stride = 3; comp = tid - 21; }
-      else if (tid < 33) { base = ImuLds::DAL; stride = 9; comp = tid - 24; }
-      else if (tid < 42) { base = ImuLds::DVT; stride = 9; comp = tid - 33; }
-      else if (tid < 51) { base = ImuLds::RINV; stride = 9; comp = tid - 42; }
-      if (base >= 0)
-        for (int k = 0; k < ns; ++k) add += lds[base + stride * k + comp];
-      const double dqn = (tid >= 51 && tid < 55) ? lds[ImuLds::DQP + 4 * ns + (tid - 51)] : 0.0;
-      __syncthreads();  // every reader of the carries (stages 2/4/6 above) is done
-      if (tid < 9) c_Cint[tid] += add;
-      else if (tid < 18) t_Cdbl[tid - 9] += add;
-      else if (tid < 21) c_aint[tid - 18] += add;
-      else if (tid < 24) t_adbl[tid - 21] += add;
-      else if (tid < 33) t_dal[tid - 24] += add;
-      else if (tid < 42) c_dv[tid - 33] += add;
-      else if (tid < 51) t_dp[tid - 42] += add;
-      else if (tid < 55) c_Dq[tid - 51] = dqn;
-      if (tid == ns - 1)
-        for (int c = 0; c < 9; ++c) c_cross[c] = cross1[c];  // cross after the last step of the chunk
+      int base_i = -1, stride = 0;
+      double* tot = nullptr;
+      if (tid < 9) { base_i = ImuLds::CDBL + tid; stride = 9; tot = t_Cdbl + tid; }
+      else if (tid < 12) { base_i = ImuLds::ADBL + (tid - 9); stride = 3; tot = t_adbl + (tid - 9); }
+      else if (tid < 21) { base_i = ImuLds::DAL + (tid - 12); stride = 9; tot = t_dal + (tid - 12); }
+      else if (tid < 30) { base_i = ImuLds::RINV + (tid - 21); stride = 9; tot = t_dp + (tid - 21); }
+      if (base_i >= 0) {
+        double add = 0;
+        for (int k = 0; k < ns; ++k) add += lds[base_i + stride * k];
+        *tot += add;
+      }
+      if (tid >= 32 && tid < 36) c_Dq[tid - 32] = lds[ImuLds::DQP + 4 * ns + (tid - 32)];
+      if (tid >= 64 && tid < 73) {
+        const int c = tid - 64;
+        lds[ImuLds::CINTP + c] = lds[ImuLds::CINTP + 9 * ns + c];
+        lds[ImuLds::CROSSP + c] = lds[ImuLds::CROSSP + 9 * ns + c];
+        lds[ImuLds::DVP + c] = lds[ImuLds::DVP + 9 * ns + c];
+        if (c < 3) lds[ImuLds::AINTP + c] = lds[ImuLds::AINTP + 3 * ns + c];
+      }
     }
     __syncthreads();
     if (s_finished) break;
@@ -436,14 +457,14 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
   // ---- cache copy in LDS
   double* ca = lds + ImuLds::CA;
   if (tid < 9) {
-    ca[CA_CI + tid] = c_Cint[tid];
+    ca[CA_CI + tid] = lds[ImuLds::CINTP + tid];
     ca[CA_CD + tid] = t_Cdbl[tid];
     ca[CA_DA + tid] = t_dal[tid];
-    ca[CA_DV + tid] = c_dv[tid];
+    ca[CA_DV + tid] = lds[ImuLds::DVP + tid];
     ca[CA_DP + tid] = t_dp[tid];
   }
   if (tid < 3) {
-    ca[CA_AI + tid] = c_aint[tid];
+    ca[CA_AI + tid] = lds[ImuLds::AINTP + tid];
     ca[CA_AD + tid] = t_adbl[tid];
   }
   if (tid < 4) ca[CA_DQ + tid] = c_Dq[tid];
