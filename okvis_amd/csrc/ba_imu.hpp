@@ -47,7 +47,8 @@ struct ImuLds {
   static constexpr int AINTP = CINTP + 9 * (IMU_N + 1);  // 3(N+1)
   static constexpr int CROSSP = AINTP + 3 * (IMU_N + 1); // 9(N+1)
   static constexpr int DVP = CROSSP + 9 * (IMU_N + 1);   // 9(N+1)
-  static constexpr int TOTAL = DVP + 9 * (IMU_N + 1);
+  static constexpr int TSBUF = DVP + 9 * (IMU_N + 1);    // (N+8) timestamps staged for the loop control (as long long)
+  static constexpr int TOTAL = TSBUF + IMU_N + 8;
 };
 // compact LDS layout of the evaluate kernel (no re-preintegration scratch): J | F | e | cache copy
 struct EvalLds {
@@ -123,7 +124,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
   // factor may span any number of raw samples (the reference copies the whole deque into every ImuError).
   __shared__ int s_it[IMU_N], s_flag[IMU_N];
   __shared__ long long s_ts[IMU_N], s_tn[IMU_N];
-  __shared__ int s_nsteps, s_next_it, s_started, s_finished;
+  __shared__ int s_nsteps, s_next_it, s_started, s_finished, s_first;
   __shared__ long long s_time;
   __shared__ double c_Dq[4];  // carry of Delta_q; the other carries sit at index 0 of the prefix arrays
   __shared__ double t_Cdbl[9], t_adbl[3], t_dal[9], t_dp[9];              // running totals
@@ -153,17 +154,90 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
     lds[ImuLds::AINTP + tid] = 0; t_adbl[tid] = 0;
   }
   if (tid < 225) P[tid] = 0.0;
+  if (tid == 0) s_first = n;
+  __syncthreads();
+  // the leading samples the reference skips with `continue` (nexttime - time <= 0 while time is still t0,
+  // ImuError.cpp:128-130): find the first step that advances, in parallel (same result as the serial scan)
+  {
+    int first = n;
+    for (int it = tid; it < n; it += IMU_THREADS) {
+      long long nexttime = (it + 1 == n) ? t1 : ts[it + 1];
+      if (t1 < nexttime) nexttime = t1;
+      if (nexttime - t0 > 0) {
+        first = it;
+        break;
+      }
+    }
+    if (first < n) atomicMin(&s_first, first);
+  }
+  __syncthreads();
+  if (tid == 0) s_next_it = s_first;
+  long long* tsbuf = reinterpret_cast<long long*>(lds + ImuLds::TSBUF);
   __syncthreads();
 
   for (;;) {
-    // ---- stage 0: loop control of ImuError.cpp:113-150,259-260 (integer time logic) by one work-item
-    if (tid == 0) {
+    // ---- stage 0: loop control of ImuError.cpp:113-150,259-260 (integer time logic) by one work-item, on
+    //      timestamps staged in LDS
+    const int base = s_next_it;
+    for (int j = tid; j < IMU_N + 8; j += IMU_THREADS) tsbuf[j] = (base + j < n) ? ts[base + j] : t1;
+    __syncthreads();
+    // fast path (wave 0, one lane per candidate step): when every candidate step of this chunk advances the
+    // time (strictly increasing timestamps — the normal case) step j is simply sample base + j, so the serial
+    // scan below is not needed; any non-advancing step falls back to it (identical results by construction)
+    bool fast_done = false;
+    if (tid < 64) {
+      const int j = tid;
+      const int it = base + j;
+      const bool cand = j < IMU_N && it < n && !s_finished;
+      long long nexttime = t1, before = s_time;
+      int flag = 0;
+      if (cand) {
+        nexttime = (it + 1 == n) ? t1 : tsbuf[j + 1];
+        if (t1 < nexttime) {
+          nexttime = t1;
+          flag |= 1;
+        }
+        if (j > 0) {
+          before = tsbuf[j];
+          if (t1 < before) before = t1;
+        }
+        if (j == 0 && !s_started) flag |= 2;
+      }
+      const bool adv = cand && (nexttime - before > 0);
+      const bool hit_end = cand && (nexttime == t1);
+      const unsigned long long m_cand = __ballot(cand), m_adv = __ballot(adv), m_end = __ballot(hit_end);
+      // steps are executed up to and including the first one that reaches t1
+      int ncand = __popcll(m_cand);
+      const int first_end = m_end ? (__ffsll((long long)m_end) - 1) : 64;
+      const int nsteps = first_end < ncand ? first_end + 1 : ncand;
+      const unsigned long long need = (nsteps >= 64) ? ~0ULL : ((1ULL << nsteps) - 1ULL);
+      const bool ok = nsteps > 0 && ((m_adv & need) == need);
+      if (ok) {
+        if (j < nsteps) {
+          s_it[j] = it;
+          s_flag[j] = flag;
+          s_ts[j] = before;
+          s_tn[j] = nexttime;
+        }
+        if (j == nsteps - 1) {
+          s_nsteps = nsteps;
+          s_next_it = it + 1;
+          s_time = nexttime;
+          s_started = 1;
+          s_finished = (nexttime == t1 || it + 1 >= n) ? 1 : 0;
+        }
+      }
+      fast_done = ok;
+      fast_done = __shfl(fast_done ? 1 : 0, 0) != 0;
+    }
+    if (tid == 0 && !fast_done) {
       long long time = s_time;
       bool started = s_started != 0;
-      int k = 0, it = s_next_it;
+      int k = 0, it = base;
       bool fin = s_finished != 0;
       for (; it < n && k < IMU_N && !fin; ++it) {
-        long long nexttime = (it + 1 == n) ? t1 : ts[it + 1];
+        const int jn = it + 1 - base;
+        long long nexttime = (it + 1 == n) ? t1 : (jn < IMU_N + 8 ? tsbuf[jn] : ts[it + 1]);
         int flag = 0;
         if (t1 < nexttime) {
           nexttime = t1;
