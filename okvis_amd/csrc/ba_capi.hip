@@ -78,6 +78,8 @@ struct okvis_ba_solver {
   std::map<std::pair<int, int>, hipGraphExec_t> sub_graphs;  // (n, sub) -> graph of that sub-batch's chain
   float last_iterate_ms = 0.f;
   int last_hip_error = 0;
+  unsigned char* marg_scratch = nullptr;  // grow-only device scratch of okvis_ba_marginalize
+  size_t marg_scratch_bytes = 0;
 };
 
 namespace {
@@ -800,6 +802,7 @@ int okvis_ba_destroy(okvis_ba_solver* s) {
   if (s->d_arena) (void)hipFree(s->d_arena);
   if (s->d_wins) (void)hipFree(s->d_wins);
   if (s->d_opt) (void)hipFree(s->d_opt);
+  if (s->marg_scratch) (void)hipFree(s->marg_scratch);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -1383,9 +1386,14 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
     std::memcpy(&hb[o_pH], spec->prior_H, 8 * (size_t)pd * pd);
     std::memcpy(&hb[o_pb], spec->prior_b0, 8 * (size_t)pd);
   }
-  unsigned char* d = nullptr;
-  HIP_TRY(hipMalloc(&d, A.size));
-  struct Free { unsigned char* p; ~Free() { if (p) (void)hipFree(p); } } guard{d};
+  if (A.size > s->marg_scratch_bytes) {
+    if (s->marg_scratch) HIP_TRY(hipFree(s->marg_scratch));
+    s->marg_scratch = nullptr;
+    s->marg_scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&s->marg_scratch, A.size));
+    s->marg_scratch_bytes = A.size;
+  }
+  unsigned char* d = s->marg_scratch;
   HIP_TRY(hipMemcpyAsync(d, hb.data(), host_part, hipMemcpyHostToDevice, s->stream));
   WinPtrs P = H.ptrs;   // this window with the export buffers attached
   P.S = reinterpret_cast<double*>(d + o_S);
