@@ -116,8 +116,12 @@ __device__ void jacobi_eig(double* X, double* Q, int n, int tid, JacobiTab& jt, 
         if (rot) jt.rotated = 1;
       }
       __syncthreads();
-      for (int it = tid; it < half * half; it += MARG_THREADS) {
-        const int k1 = it / half, k2 = it - k1 * half;
+      // the matrix stays symmetric: update the blocks with k2 >= k1 and write each one and its mirror image
+      for (int it = tid; it < half * (half + 1) / 2; it += MARG_THREADS) {
+        int k2 = (int)((sqrtf(8.0f * it + 1.0f) - 1.0f) * 0.5f);
+        while ((k2 + 1) * (k2 + 2) / 2 <= it) ++k2;
+        while (k2 * (k2 + 1) / 2 > it) --k2;
+        const int k1 = it - k2 * (k2 + 1) / 2;  // k1 <= k2
         const double c1 = jt.c[k1], s1 = jt.s[k1], c2 = jt.c[k2], s2 = jt.s[k2];
         if (s1 == 0.0 && s2 == 0.0) continue;
         const int p1 = jt.p[k1], q1 = jt.q[k1], p2 = jt.p[k2], q2 = jt.q[k2];
@@ -128,10 +132,18 @@ __device__ void jacobi_eig(double* X, double* Q, int n, int tid, JacobiTab& jt, 
         const double bqq = (v1 && v2) ? X[q1 * n + q2] : 0.0;
         const double tpp = c2 * bpp - s2 * bpq, tpq = s2 * bpp + c2 * bpq;
         const double tqp = c2 * bqp - s2 * bqq, tqq = s2 * bqp + c2 * bqq;
-        X[p1 * n + p2] = c1 * tpp - s1 * tqp;
-        if (v2) X[p1 * n + q2] = c1 * tpq - s1 * tqq;
-        if (v1) X[q1 * n + p2] = s1 * tpp + c1 * tqp;
-        if (v1 && v2) X[q1 * n + q2] = s1 * tpq + c1 * tqq;
+        const double npp = c1 * tpp - s1 * tqp, npq = c1 * tpq - s1 * tqq;
+        const double nqp = s1 * tpp + c1 * tqp, nqq = s1 * tpq + c1 * tqq;
+        X[p1 * n + p2] = npp;
+        if (v2) X[p1 * n + q2] = npq;
+        if (v1) X[q1 * n + p2] = nqp;
+        if (v1 && v2) X[q1 * n + q2] = nqq;
+        if (k1 != k2) {
+          X[p2 * n + p1] = npp;
+          if (v2) X[q2 * n + p1] = npq;
+          if (v1) X[p2 * n + q1] = nqp;
+          if (v1 && v2) X[q2 * n + q1] = nqq;
+        }
       }
       for (int it = tid; it < half * n; it += MARG_THREADS) {  // Q <- Q G
         const int k = it / n, i = it - k * n;
