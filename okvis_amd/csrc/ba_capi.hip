@@ -410,7 +410,6 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.has_ext = has_ext ? 1 : 0;
   P.gpart_size = gpart_size;
   P.n_tile = ntile;
-  P.n_asm = 0;
   P.n_imu_color = n_imu_color;
   P.spart_stride = spart_stride;
   P.cauchy_b = w.cauchy_b;

@@ -90,20 +90,6 @@ __device__ __forceinline__ bool chol6(double (&L)[6][6], double (&inv)[6]) {
   return ok;
 }
 
-// inverse of a lower-triangular 6x6 factor (inv[k] = 1/L[k][k]); Li lower-triangular
-__device__ __forceinline__ void trinv6(const double (&L)[6][6], const double (&inv)[6], double (&Li)[6][6]) {
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    Li[j][j] = inv[j];
-#pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      double s = 0;
-#pragma unroll
-      for (int m = j; m < i; ++m) s += L[i][m] * Li[m][j];
-      Li[i][j] = -s * inv[i];
-    }
-  }
-}
 
 // factor the 6x6 diagonal block (lower triangle at dblk) and publish L (row-major 6x6) and 1/diag(L)
 __device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, double* inv_out) {

@@ -58,16 +58,6 @@ struct Chunk {  // one Schur workgroup: a range of groups
   int group_begin, group_end;
 };
 
-// assembly target of the solve kernel: one 6x6 block of the reduced matrix that collects the per-group
-// partials (tasks) of a pose block (diag) or a pose-extrinsics pair (cross)
-struct AsmTarget {
-  int type;        // 0 diag (task out = 21 upper-tri + 6 g), 2 cross (task out = 36, rows = pose, cols = ext)
-  int off_a;       // reduced offset of the block (diag) / of the pose block (cross)
-  int off_b;       // reduced offset of the extrinsics block (cross)
-  int list_begin;  // into asm_list (task 'out' offsets)
-  int list_end;
-  int pad;
-};
 
 struct ImuParamsD {
   double sigma_g_c, sigma_a_c, sigma_gw_c, sigma_aw_c, g, g_max, a_max;
@@ -124,7 +114,7 @@ struct WinPtrs {
   int has_ext;            // any non-fixed extrinsics-role block
   int gpart_size;         // doubles in gpart
   int n_tile;             // Schur tiles per dimension
-  int n_asm, n_imu_color;
+  int n_imu_color;
   int ct_nT;              // tile rows of the tiled dense solver (0 = the LDS solver handles this window)
   int spart_stride;       // doubles per chunk partial: (Dp/6)(Dp/6+1)/2*36 + 3*Dp  (S | Y b | g | diag U)
   double cauchy_b;
