@@ -1369,7 +1369,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
                o_po = A.alloc(sizeof(int) * std::max(1, pnb));
   const size_t o_pH = A.alloc(8 * std::max<size_t>(1, (size_t)pd * pd)), o_pb = A.alloc(8 * std::max(1, pd));
   const size_t host_part = A.size;
-  const size_t o_work = A.alloc(8 * 3 * std::max<size_t>(1, (size_t)D * D));
+  const size_t o_work = A.alloc(8 * (3 * std::max<size_t>(1, (size_t)D * D) + 6 * ((size_t)D + 6)));
   const size_t o_S = A.alloc(8 * std::max<size_t>(1, (size_t)D * D)), o_rhs = A.alloc(8 * std::max(1, D)),
                o_d2 = A.alloc(8 * std::max(1, D));
   const size_t o_out = A.alloc(8 * (2 * std::max<size_t>(1, (size_t)na * na) + 2 * std::max(1, na)));

@@ -28,7 +28,7 @@ struct MargArgs {
   const int* pb_off;    // [prior_nb] offset inside the prior
   const double* prior_H;   // [prior_dim^2] row-major
   const double* prior_b0;  // [prior_dim]
-  double* work;            // 3 * D * D doubles
+  double* work;            // 3 D^2 + 6 (D + 6) doubles
   double* out_H;           // [na*na]
   double* out_b0;          // [na]
   double* out_J;           // [na*na]
@@ -163,6 +163,170 @@ __device__ void jacobi_eig(double* X, double* Q, int n, int tid, JacobiTab& jt, 
   *sweeps = sweep;
 }
 
+__device__ __forceinline__ double marg_rsqrt(double x) {  // v_rsq_f64 + two Newton steps
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
+// Fast path of the two symmetric decompositions.  The reference eigen-decomposes the pre-scaled matrix and drops
+// the eigenvalues <= eps * n * lambda_max.  If NO eigenvalue is that small the pseudo-inverse is the inverse and
+// any square root serves, so a Cholesky factor L and L^-1 replace the eigen-pairs (J and e0 are only defined up
+// to an orthogonal row transformation anyway).  "No eigenvalue that small" is PROVEN, not assumed:
+//   lambda_min >= 1 / trace(A^-1) = 1 / ||L^-1||_F^2        lambda_max <= max row sum of |A|
+// and the fast path is taken only if  1 / ||L^-1||_F^2 > 4 eps n (max row sum);  otherwise (or on a non-positive
+// pivot) the caller falls back to the Jacobi eigen-decomposition.  M: n x n (stride n, n a multiple of 6, identity
+// padded) -> L in the lower triangle; X <- L^-1 (full square, zeros above).  Returns true when the bound holds.
+__device__ bool marg_chol_inverse(double* M, double* X, int n, int n_true, double* dinv, double* Tm, double* red,
+                                  int* s_flag, int tid) {
+  const int nb = n / 6;
+  __shared__ double s_rowmax;
+  // lambda_max bound: max absolute row sum (before M is overwritten)
+  double rs = 0.0;
+  if (tid < n_true)
+    for (int c = 0; c < n_true; ++c) rs += fabs(M[tid * n + c]);
+  rs = wave_max(rs);
+  if ((tid & 63) == 0) red[tid >> 6] = rs;
+  if (tid == 0) *s_flag = 0;
+  __syncthreads();
+  if (tid == 0) {
+    double m = 0;
+    for (int i = 0; i < MARG_THREADS / 64; ++i) m = fmax(m, red[i]);
+    s_rowmax = m;
+  }
+  __syncthreads();
+  for (int kb = 0; kb < nb; ++kb) {
+    const int k0 = 6 * kb;
+    if (tid == 0) {
+      double a[6][6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) a[r][c] = M[(k0 + r) * n + k0 + c];
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double d = a[c][c];
+#pragma unroll
+        for (int m = 0; m < c; ++m) d -= a[c][m] * a[c][m];
+        if (!(d > 0.0)) {
+          bad = true;
+          d = 1.0;
+        }
+        const double inv = marg_rsqrt(d);
+        a[c][c] = d * inv;
+        dinv[k0 + c] = inv;
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+          double v = a[r][c];
+#pragma unroll
+          for (int m = 0; m < c; ++m) v -= a[r][m] * a[c][m];
+          a[r][c] = v * inv;
+        }
+      }
+      if (bad) *s_flag = 1;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) M[(k0 + r) * n + k0 + c] = a[r][c];
+    }
+    __syncthreads();
+    const int nrows = n - k0 - 6;
+    if (tid < nrows) {
+      double* row = M + (k0 + 6 + tid) * n + k0;
+      double x[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double v = row[c];
+#pragma unroll
+        for (int m = 0; m < c; ++m) v -= x[m] * M[(k0 + c) * n + k0 + m];
+        x[c] = v * dinv[k0 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) row[c] = x[c];
+    }
+    __syncthreads();
+    const int ntri = nrows * (nrows + 1) / 2;
+    for (int e = tid; e < ntri; e += MARG_THREADS) {
+      int r = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+      while ((r + 1) * (r + 2) / 2 <= e) ++r;
+      while (r * (r + 1) / 2 > e) --r;
+      const int c = e - r * (r + 1) / 2;
+      const double* a = M + (k0 + 6 + r) * n + k0;
+      const double* b = M + (k0 + 6 + c) * n + k0;
+      double sacc = 0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) sacc += a[m] * b[m];
+      M[(k0 + 6 + r) * n + k0 + 6 + c] -= sacc;
+    }
+    __syncthreads();
+  }
+  if (*s_flag) return false;
+  // X = L^-1, blocked by 6
+  for (int e = tid; e < n * n; e += MARG_THREADS) X[e] = 0.0;
+  __syncthreads();
+  if (tid < nb) {
+    const int k0 = 6 * tid;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double x[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        if (r < c) {
+          x[r] = 0.0;
+          continue;
+        }
+        double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int m = 0; m < r; ++m)
+          if (m >= c) v -= M[(k0 + r) * n + k0 + m] * x[m];
+        x[r] = v * dinv[k0 + r];
+      }
+#pragma unroll
+      for (int r = c; r < 6; ++r) X[(k0 + r) * n + k0 + c] = x[r];
+    }
+  }
+  __syncthreads();
+  for (int bi = 1; bi < nb; ++bi) {
+    const int ncol = 6 * bi;
+    for (int e = tid; e < 6 * ncol; e += MARG_THREADS) {
+      const int r = e / ncol, c = e - r * ncol;
+      const int m0 = (c / 6) * 6;
+      double sacc = 0;
+      for (int m = m0; m < ncol; ++m) sacc += M[(6 * bi + r) * n + m] * X[m * n + c];
+      Tm[r * n + c] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < 6 * ncol; e += MARG_THREADS) {
+      const int r = e / ncol, c = e - r * ncol;
+      double sacc = 0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m)
+        if (m <= r) sacc += X[(6 * bi + r) * n + 6 * bi + m] * Tm[m * n + c];
+      X[(6 * bi + r) * n + c] = -sacc;
+    }
+    __syncthreads();
+  }
+  // ||L^-1||_F^2 over the true part (the identity padding contributes nothing to either bound)
+  double fs = 0.0;
+  for (int e = tid; e < n_true * n_true; e += MARG_THREADS) {
+    const double v = X[(e / n_true) * n + (e % n_true)];
+    fs += v * v;
+  }
+  fs = wave_sum(fs);
+  if ((tid & 63) == 0) red[tid >> 6] = fs;
+  __syncthreads();
+  __shared__ int s_okb;
+  if (tid == 0) {
+    double f = 0;
+    for (int i = 0; i < MARG_THREADS / 64; ++i) f += red[i];
+    s_okb = (f > 0.0 && 1.0 / f > 4.0 * 2.220446049250313e-16 * n_true * s_rowmax) ? 1 : 0;
+  }
+  __syncthreads();
+  return s_okb != 0;
+}
+
 __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs* __restrict__ wins, int w, MargArgs a,
                                                                    int lds_doubles) {
   extern __shared__ __attribute__((aligned(16))) double marg_lds[];
@@ -173,9 +337,10 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   double* b = W.rhs;   // [D]
   __shared__ int s_kidx[MAX_D_LDS], s_midx[MAX_D_LDS], s_ridx[MAX_MARG_DIM];
   __shared__ double s_p[MAX_D_LDS], s_t[MAX_D_LDS], s_lam[MAX_D_LDS], s_ba[MAX_D_LDS];
-  __shared__ int s_na, s_nm;
+  __shared__ int s_na, s_nm, s_cflag;
   __shared__ double s_max;
   __shared__ JacobiTab jt;
+  __shared__ double s_dinv[MAX_D_LDS + 6], s_red[MARG_THREADS / 64];
   const double EPS = 2.220446049250313e-16;
 
   // ---- previous prior: H_ and b0_ persist inside the reference's MarginalizationError object ----
@@ -233,27 +398,58 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
     // ---- dense part of marginalizeOut (:686-736) ----
     for (int i = tid; i < D; i += MARG_THREADS) s_p[i] = H[i * D + i] > 1.0e-9 ? sqrt(H[i * D + i]) : 1.0e-3;  // :689
     __syncthreads();
-    pick(nm, &A, &Q);
-    for (int k = tid; k < nm * nm; k += MARG_THREADS) {  // V1 = 0.5 (V + V^T) of the scaled system (:725)
-      const int i = k / nm, j = k - i * nm;
-      const int mi = s_midx[i], mj = s_midx[j];
-      A[k] = 0.5 * (H[mi * D + mj] / (s_p[mi] * s_p[mj]) + H[mj * D + mi] / (s_p[mj] * s_p[mi]));
+    bool fast = false;
+    {  // Cholesky fast path (see marg_chol_inverse): V^+ = V^-1 proven, "V^(+1/2)" := L^-T
+      const int np6 = ((nm + 5) / 6) * 6;
+      if (2 * np6 * np6 <= lds_doubles) {
+        double* Mp = marg_lds;
+        double* Xp = marg_lds + np6 * np6;
+        for (int k = tid; k < np6 * np6; k += MARG_THREADS) {  // V1 = 0.5 (V + V^T) of the scaled system (:725), padded
+          const int i = k / np6, j = k - i * np6;
+          double v = (i == j) ? 1.0 : 0.0;
+          if (i < nm && j < nm) {
+            const int mi = s_midx[i], mj = s_midx[j];
+            v = 0.5 * (H[mi * D + mj] / (s_p[mi] * s_p[mj]) + H[mj * D + mi] / (s_p[mj] * s_p[mi]));
+          }
+          Mp[k] = v;
+        }
+        __syncthreads();
+        fast = marg_chol_inverse(Mp, Xp, np6, nm, s_dinv, a.work + 3 * (size_t)D * D, s_red, &s_cflag, tid);
+        if (fast) {
+          Q = a.work + (size_t)D * D;
+          for (int k = tid; k < nm * nm; k += MARG_THREADS) {
+            const int c = k / nm, j = k - c * nm;
+            Q[k] = Xp[j * np6 + c];            // (L^-T)[c][j] = Linv[j][c]
+          }
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
-    jacobi_eig(A, Q, nm, tid, jt, &sweeps_v);
-    if (tid == 0) {
-      double mx = A[0];
-      for (int i = 1; i < nm; ++i) mx = fmax(mx, A[i * nm + i]);
-      s_max = mx;
+    if (!fast) {
+      pick(nm, &A, &Q);
+      for (int k = tid; k < nm * nm; k += MARG_THREADS) {  // V1 = 0.5 (V + V^T) of the scaled system (:725)
+        const int i = k / nm, j = k - i * nm;
+        const int mi = s_midx[i], mj = s_midx[j];
+        A[k] = 0.5 * (H[mi * D + mj] / (s_p[mi] * s_p[mj]) + H[mj * D + mi] / (s_p[mj] * s_p[mi]));
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    {
-      const double tol = EPS * nm * s_max;  // pseudoInverseSymmSqrt (:225-233)
-      for (int i = tid; i < nm; i += MARG_THREADS) s_lam[i] = A[i * nm + i] > tol ? sqrt(1.0 / A[i * nm + i]) : 0.0;
+    if (!fast) {
+      jacobi_eig(A, Q, nm, tid, jt, &sweeps_v);
+      if (tid == 0) {
+        double mx = A[0];
+        for (int i = 1; i < nm; ++i) mx = fmax(mx, A[i * nm + i]);
+        s_max = mx;
+      }
+      __syncthreads();
+      {
+        const double tol = EPS * nm * s_max;  // pseudoInverseSymmSqrt (:225-233)
+        for (int i = tid; i < nm; i += MARG_THREADS) s_lam[i] = A[i * nm + i] > tol ? sqrt(1.0 / A[i * nm + i]) : 0.0;
+      }
+      __syncthreads();
+      for (int k = tid; k < nm * nm; k += MARG_THREADS) Q[k] *= s_lam[k % nm];  // V^(+1/2) = Q diag(l^-1/2)
+      __syncthreads();
     }
-    __syncthreads();
-    for (int k = tid; k < nm * nm; k += MARG_THREADS) Q[k] *= s_lam[k % nm];  // V^(+1/2) = Q diag(l^-1/2)
-    __syncthreads();
     for (int k = tid; k < na * nm; k += MARG_THREADS) {  // M = W V^(+1/2) (:729)
       const int i = k / nm, j = k - i * nm;
       const int ki = s_kidx[i];
@@ -299,13 +495,42 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   const double* Ha = a.out_H;
   for (int i = tid; i < na; i += MARG_THREADS) s_p[i] = Ha[i * na + i] > 1.0e-9 ? sqrt(Ha[i * na + i]) : 1.0e-3;
   __syncthreads();
+  int sweeps_h = 0;
+  {  // Cholesky fast path: full rank proven -> J = L^T P, e0 = -L^-1 P^-1 b0 (J^T J = H, J^T e0 = -b0)
+    const int np6 = ((na + 5) / 6) * 6;
+    if (2 * np6 * np6 <= lds_doubles) {
+      double* Mp = marg_lds;
+      double* Xp = marg_lds + np6 * np6;
+      for (int k = tid; k < np6 * np6; k += MARG_THREADS) {
+        const int i = k / np6, j = k - i * np6;
+        Mp[k] = (i < na && j < na) ? 0.5 * (Ha[i * na + j] + Ha[j * na + i]) / (s_p[i] * s_p[j]) : (i == j ? 1.0 : 0.0);
+      }
+      __syncthreads();
+      if (marg_chol_inverse(Mp, Xp, np6, na, s_dinv, a.work + 3 * (size_t)D * D, s_red, &s_cflag, tid)) {
+        for (int k = tid; k < na * na; k += MARG_THREADS) {
+          const int r = k / na, c = k - r * na;
+          a.out_J[k] = (c >= r) ? Mp[c * np6 + r] * s_p[c] : 0.0;
+        }
+        for (int r = tid; r < na; r += MARG_THREADS) {
+          double sacc = 0;
+          for (int c = 0; c <= r; ++c) sacc += Xp[r * np6 + c] * (s_ba[c] / s_p[c]);
+          a.out_e0[r] = -sacc;
+        }
+        if (tid == 0) {
+          a.out_info[2] = na;
+          a.out_info[3] = sweeps_v;
+          a.out_info[4] = 0;
+        }
+        return;
+      }
+    }
+  }
   pick(na, &A, &Q);
   for (int k = tid; k < na * na; k += MARG_THREADS) {
     const int i = k / na, j = k - i * na;
     A[k] = 0.5 * (Ha[i * na + j] + Ha[j * na + i]) / (s_p[i] * s_p[j]);
   }
   __syncthreads();
-  int sweeps_h = 0;
   jacobi_eig(A, Q, na, tid, jt, &sweeps_h);
   if (tid == 0) {
     double mx = A[0];

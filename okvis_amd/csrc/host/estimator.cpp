@@ -787,8 +787,12 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
     sel.obs = selObs;
     sel.withPrior = false;
     sel.atLinearizationPoint = true;  // first-estimate Jacobians (MarginalizationError.cpp:292-310)
+    typedef std::chrono::steady_clock clk;
+    auto msf = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto tm0 = clk::now();
     FlatWindow fw;
     flatten(sel, fw);
+    const auto tm1 = clk::now();
 
     std::vector<uint8_t> pm(std::max<size_t>(1, sel.pose.size()), 0), sm(std::max<size_t>(1, sel.sb.size()), 0);
     for (int b : margPose) pm[fw.poseMap[b]] = 1;
@@ -826,7 +830,10 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
     res.H = Hn.data(); res.b0 = bn.data(); res.J = Jn.data(); res.e0 = en.data();
     check(okvis_ba_set_options(solver_, &options_), "set_options");
     check(okvis_ba_upload(solver_, 1, &fw.w), "upload (marginalisation window)");
+    const auto tm2 = clk::now();
     check(okvis_ba_marginalize(solver_, 0, &spec, &res), "marginalize");
+    margInfo_ = {msf(tm0, tm1), msf(tm1, tm2), msf(tm2, clk::now()), (double)res.sweeps[0], (double)res.sweeps[1],
+                 (double)(6 * sel.pose.size() + 9 * sel.sb.size())};
 
     // the new prior over the remaining connected blocks; blocks that were connected before keep their
     // linearisation point, newly connected ones are linearised at the current estimate

@@ -139,6 +139,10 @@ class Estimator {
   // wall-clock split of the last optimize() in ms: flatten, okvis_ba_upload, iterations, downloads
   const std::array<double, 4>& lastOptimizeTimings() const { return timings_; }
 
+  // last applyMarginalizationStrategy(): ms flatten / upload / okvis_ba_marginalize, Jacobi sweeps of the two
+  // decompositions (0 = Cholesky fast path), reduced dimension of the marginalisation window
+  const std::array<double, 6>& lastMarginalizationInfo() const { return margInfo_; }
+
   // ---- diagnostics of the marginalisation prior (MarginalizationError::num_residuals etc.) ----
   int priorDimension() const { return prior_.dim; }
   size_t priorNumBlocks() const { return prior_.block.size(); }
@@ -255,6 +259,7 @@ class Estimator {
   std::vector<RelPose> relPoses_;
   MargPrior prior_;
   std::array<double, 4> timings_{};
+  std::array<double, 6> margInfo_{};  // last marginalisation: ms flatten, upload, marginalize; Jacobi sweeps (2); sub-window D
   uint64_t nextId_ = 1ULL << 40;    // IdProvider::instance().newId() stand-in for internal blocks
   uint64_t nextHandle_ = 1;
   mutable std::mutex statesMutex_;  // guards getLandmark(s) like Estimator.cpp:936,956,965

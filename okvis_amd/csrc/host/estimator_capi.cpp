@@ -190,6 +190,13 @@ int okvis_est_is_keyframe(void* h, uint64_t id) {
 int okvis_est_is_in_imu_window(void* h, uint64_t id) {
   return guarded([&] { return static_cast<Estimator*>(h)->isInImuWindow(id) ? 1 : 0; });
 }
+int okvis_est_last_marg_info(void* h, double out[6]) {
+  return guarded([&] {
+    const auto& t = static_cast<Estimator*>(h)->lastMarginalizationInfo();
+    for (int i = 0; i < 6; ++i) out[i] = t[i];
+    return 1;
+  });
+}
 int okvis_est_last_timings(void* h, double out[4]) {
   return guarded([&] {
     const auto& t = static_cast<Estimator*>(h)->lastOptimizeTimings();

@@ -47,6 +47,7 @@ def lib():
         L.okvis_est_num_frames.argtypes = [C.c_void_p]
         L.okvis_est_set_use_graph.argtypes = [C.c_void_p, C.c_int]
         L.okvis_est_last_timings.argtypes = [C.c_void_p, _dp]
+        L.okvis_est_last_marg_info.argtypes = [C.c_void_p, _dp]
         L.okvis_est_apply_marginalization2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.c_int]
         L.okvis_est_prior_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.okvis_est_frame_id_by_age.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
@@ -169,6 +170,12 @@ class Estimator:
         """ms: flatten, upload (host index build + H2D), iterations, downloads."""
         out = np.zeros(4)
         _chk(lib().okvis_est_last_timings(self._h, out.ctypes.data_as(_dp)))
+        return out
+
+    def lastMarginalizationInfo(self):
+        """ms flatten, upload, okvis_ba_marginalize; Jacobi sweeps (2, 0 = Cholesky fast path); sub-window D."""
+        out = np.zeros(6)
+        _chk(lib().okvis_est_last_marg_info(self._h, out.ctypes.data_as(_dp)))
         return out
 
     def setUseGraph(self, use_graph):

@@ -62,9 +62,11 @@ def main(n_frames=40, num_iter=10, grid=0.5, use_graph=None):
         est.applyMarginalizationStrategy(5, 3, removed)
         gone.update(removed)
         t3 = time.perf_counter()
+        mi = est.lastMarginalizationInfo()
         rows.append(dict(frame=k, new_obs=n_obs, landmarks=est.numLandmarks(), frames=est.numFrames(), iterations=s["iterations"],
                          add_ms=(t1 - t0) * 1e3, optimize_ms=(t2 - t1) * 1e3, marginalize_ms=(t3 - t2) * 1e3, prior_dim=est.priorInfo()[0],
-                         flatten_ms=tm[0], upload_ms=tm[1], iterate_ms=tm[2], download_ms=tm[3]))
+                         flatten_ms=tm[0], upload_ms=tm[1], iterate_ms=tm[2], download_ms=tm[3],
+                         mflatten_ms=mi[0], mupload_ms=mi[1], mgpu_ms=mi[2], sweeps_v=mi[3], sweeps_h=mi[4], marg_D=mi[5]))
     T = est.get_T_WS(100 + n_frames - 1)
     err = float(np.linalg.norm(T[:3] - speed * (n_frames - 1) * FRAME_DT))
     est.close()
@@ -74,7 +76,9 @@ def main(n_frames=40, num_iter=10, grid=0.5, use_graph=None):
                       "steady_state_median": {"observations_added_per_frame": med("new_obs"), "landmarks_in_window": med("landmarks"),
                                               "frames_in_window": med("frames"), "prior_dim": med("prior_dim"),
                                               "optimize_ms": med("optimize_ms"), "marginalize_ms": med("marginalize_ms"),
-                                              "iterations": med("iterations"), "optimize_split_ms": {k: med(k + "_ms") for k in ("flatten", "upload", "iterate", "download")}},
+                                              "iterations": med("iterations"), "optimize_split_ms": {k: med(k + "_ms") for k in ("flatten", "upload", "iterate", "download")},
+                                              "marginalize_split_ms": {k: med("m" + k + "_ms") for k in ("flatten", "upload", "gpu")},
+                                              "marginalize_window_dim": med("marg_D"), "jacobi_sweeps": [med("sweeps_v"), med("sweeps_h")]},
                       "note": "wall clock around the C++ host calls: optimize() = flatten + okvis_ba_upload (host index build + H2D) + "
                               "iterations on the GPU + state/quality/IMU-reference download; addStates/addObservation time is dominated by the Python test harness"}))
 
