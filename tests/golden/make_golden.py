@@ -226,12 +226,51 @@ def window_vectors():
     return out
 
 
+MARG = [dict(seed=71, K=5, L=40, estimate_extrinsics="fixed", pose=[0], sb=[0, 1]),
+        dict(seed=72, K=4, L=30, estimate_extrinsics="shared", pose=[0], sb=[0]),
+        dict(seed=73, K=4, L=24, estimate_extrinsics="perframe", pose=[0, 4, 5], sb=[0])]
+
+
+def marg_flags(w, kw):
+    pm = np.zeros(w.n_pose, np.uint8); sm = np.zeros(w.n_sb, np.uint8)
+    pm[kw["pose"]] = 1; sm[kw["sb"]] = 1
+    return pm, sm
+
+
+def marginalization_vectors():
+    """MarginalizationError numerics: oracle output, cross-checked against the scipy-eigh statement."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_marginalization import numpy_marginalize
+    out = {"n": np.int64(len(MARG))}
+    for i, kw in enumerate(MARG):
+        kw = dict(kw)
+        pose, sb = kw.pop("pose"), kw.pop("sb")
+        w = synthetic.small_window(**kw)
+        pm, sm = marg_flags(w, dict(pose=pose, sb=sb))
+        r = O.OracleWindow(w).marginalize(pm, sm)
+        Hn, bn = numpy_marginalize(O.OracleWindow(w), w, pm, sm)
+        _agree(r["H"] / np.abs(Hn).max(), Hn / np.abs(Hn).max(), "marginalised H")
+        assert np.abs(r["b0"] - bn).max() <= 1e-9 * np.abs(bn).max(), "marginalised b0"
+        Jn, e0n, rank = ind.error_computation(Hn, bn)
+        assert rank == r["rank"]
+        for k in ("H", "b0", "block_type", "block_idx", "block_off"):
+            out[f"m{i}_{k}"] = r[k]
+        out[f"m{i}_JtJ"] = r["J"].T @ r["J"]
+        out[f"m{i}_Jte0"] = r["J"].T @ r["e0"]
+        out[f"m{i}_rank"] = np.int64(r["rank"])
+        out[f"m{i}_digest"] = np.array(window_digest(w))
+        print(f"  marginalisation {i}: {kw} pose {pose} sb {sb} -> dim {r['dim']} rank {r['rank']}")
+    return out
+
+
 def main():
     f = factor_vectors()
     np.savez_compressed(os.path.join(HERE, "factors.npz"), **f)
     w = window_vectors()
     np.savez_compressed(os.path.join(HERE, "windows.npz"), **w)
-    for n in ("factors.npz", "windows.npz"):
+    m = marginalization_vectors()
+    np.savez_compressed(os.path.join(HERE, "marginalization.npz"), **m)
+    for n in ("factors.npz", "windows.npz", "marginalization.npz"):
         print(n, os.path.getsize(os.path.join(HERE, n)), "bytes")
 
 
