@@ -80,6 +80,7 @@ struct JacobiTab {  // the n/2 disjoint rotations of one round
   int p[MAX_D_LDS / 2 + 1], q[MAX_D_LDS / 2 + 1];
   double c[MAX_D_LDS / 2 + 1], s[MAX_D_LDS / 2 + 1];
   int rotated;
+  int round_rot[2];  // any rotation in the current round (two slots: rounds alternate, no extra barrier to reset)
   double thr;
 };
 
@@ -101,9 +102,15 @@ __device__ void jacobi_eig(double* X, double* Q, int n, int tid, JacobiTab& jt, 
   const int m = (n + 1) & ~1, half = m / 2;
   int sweep = 0;
   for (; sweep < 60; ++sweep) {
-    if (tid == 0) jt.rotated = 0;
+    if (tid == 0) {
+      jt.rotated = 0;
+      jt.round_rot[0] = 0;
+      jt.round_rot[1] = 0;
+    }
     __syncthreads();
     for (int r = 0; r < m - 1; ++r) {
+      const int slot = r & 1;
+      if (tid == 0) jt.round_rot[slot ^ 1] = 0;  // the other slot: last read before the previous round's final barrier
       if (tid < half) {
         int p, q;
         rr_pair(m, r, tid, &p, &q);
@@ -113,9 +120,13 @@ __device__ void jacobi_eig(double* X, double* Q, int n, int tid, JacobiTab& jt, 
         jt.q[tid] = q < n ? q : -1;
         jt.c[tid] = c;
         jt.s[tid] = s;
-        if (rot) jt.rotated = 1;
+        if (rot) {
+          jt.rotated = 1;
+          jt.round_rot[slot] = 1;
+        }
       }
       __syncthreads();
+      if (!jt.round_rot[slot]) continue;  // nothing to rotate in this round (late sweeps): skip the update phase
       // the matrix stays symmetric: update the blocks with k2 >= k1 and write each one and its mirror image
       for (int it = tid; it < half * (half + 1) / 2; it += MARG_THREADS) {
         int k2 = (int)((sqrtf(8.0f * it + 1.0f) - 1.0f) * 0.5f);
