@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <unordered_set>
 
 #include "../ba_math.hpp"
 
@@ -328,6 +329,12 @@ uint64_t Estimator::addObservation(uint64_t landmarkId, uint64_t poseId, size_t 
   o.u = (double)kp.x;  // float -> double (:60-61)
   o.v = (double)kp.y;
   o.sqrtw = 8.0 / (double)kp.size;  // information = 64/size^2 * I (:62-65)
+  {
+    const State* st = findState(poseId);
+    if (!st || camIdx >= st->extBlocks.size()) throw Exception("addObservation: unknown frame / camera");
+    o.poseBlock = st->poseBlock;
+    o.extBlock = st->extBlocks[camIdx];
+  }
   observations_[o.handle] = o;
   lit->second.observations[kid] = o.handle;
   return o.handle;
@@ -417,9 +424,11 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
     f64[F_SB].insert(f64[F_SB].end(), x, x + 9);
     u8[1].push_back(sbBlocks_[b].fixed ? 1 : 0);
   }
-  std::map<uint64_t, int> lmIndex;
+  std::unordered_map<uint64_t, int> lmIndex;
+  lmIndex.reserve(2 * sel.landmarks.size() + 1);
   for (uint64_t id : sel.landmarks) {
-    lmIndex[id] = (int)lmIndex.size();
+    const int idx = (int)lmIndex.size();
+    lmIndex[id] = idx;
     const MapPoint& mp = landmarksMap_.at(id);
     f64[F_LM].insert(f64[F_LM].end(), mp.point.begin(), mp.point.end());
   }
@@ -439,13 +448,13 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
     double u, v, sw;
   };
   std::vector<Rec> recs;
+  recs.reserve(sel.obs.size());
   for (uint64_t hnd : sel.obs) {
     const Observation& o = observations_.at(hnd);
-    const State* st = findState(o.poseId);
-    if (!st || o.camIdx >= st->extBlocks.size() || o.camIdx >= ncam) continue;
+    if (o.camIdx >= ncam) continue;
     auto li = lmIndex.find(o.landmarkId);
     if (li == lmIndex.end()) continue;
-    const int ip = fw.poseMap[st->poseBlock], ie = fw.poseMap[st->extBlocks[o.camIdx]];
+    const int ip = fw.poseMap[o.poseBlock], ie = fw.poseMap[o.extBlock];
     if (ip < 0 || ie < 0) throw Exception("flatten: observation refers to a block outside the window");
     recs.push_back(Rec{li->second, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw});
   }
@@ -659,6 +668,7 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
   bool reDoFixation = false;
   const uint64_t currentKfId = allLinearizedFrames.at(0);
   std::vector<uint64_t> selObs;
+  std::unordered_set<uint64_t> selObsSet;  // membership test of selObs
   for (size_t rf = 0; rf < removeFrames.size(); ++rf) {
     size_t k = 0;
     while (states_[k].id != removeFrames[rf]) ++k;
@@ -683,7 +693,7 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
       }
       std::vector<uint64_t> residuals;  // reprojection residuals still in the map
       for (const auto& ob : mp.observations)
-        if (std::find(selObs.begin(), selObs.end(), ob.second) == selObs.end()) residuals.push_back(ob.second);
+        if (!selObsSet.count(ob.second)) residuals.push_back(ob.second);
       bool skipLandmark = true, hasNewObservations = false, justDelete = false, marginalize = true, errorTermAdded = false;
       size_t obsCount = 0;
       for (uint64_t hnd : residuals) {
@@ -721,6 +731,7 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
           } else {
             errorTermAdded = true;  // add information to be considered in marginalization later
             selObs.push_back(hnd);
+            selObsSet.insert(hnd);
           }
         }
         if (residuals.empty()) {

@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <unordered_map>
 #include <vector>
 
 #include "../../../include/okvis_amd_ba.h"
@@ -181,6 +182,7 @@ class Estimator {
     uint64_t handle, landmarkId, poseId;
     size_t camIdx, keypointIdx;
     double u, v, sqrtw;
+    int poseBlock, extBlock;  // T_WS and T_SCi blocks of the observing frame (cached at addObservation)
   };
   struct ImuFactor {
     int pose0Block, sb0Block, pose1Block, sb1Block;  // indices into poseBlocks_ / sbBlocks_
@@ -252,7 +254,7 @@ class Estimator {
   std::vector<SbBlock> sbBlocks_;
   PointMap landmarksMap_;
   std::map<uint64_t, bool> landmarkInitialized_;
-  std::map<uint64_t, Observation> observations_;  // by handle
+  std::unordered_map<uint64_t, Observation> observations_;  // by handle
   std::vector<ImuFactor> imuFactors_;
   std::vector<PosePrior> posePriors_;
   std::vector<SbPrior> sbPriors_;
