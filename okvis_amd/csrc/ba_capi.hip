@@ -68,7 +68,7 @@ struct okvis_ba_solver {
   okvis_ba_options opt;
   OptD* d_opt = nullptr;
   unsigned char* d_arena = nullptr;
-  size_t arena_bytes = 0;
+  size_t arena_bytes = 0, arena_capacity = 0, wins_capacity = 0;
   WinPtrs* d_wins = nullptr;
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
@@ -841,16 +841,16 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     int rc = build_window(windows[i], s->opt, A, wins[i]);
     if (rc != OKVIS_BA_OK) return rc;
   }
-  if (s->d_arena) {
-    HIP_TRY(hipFree(s->d_arena));
-    s->d_arena = nullptr;
-  }
-  if (s->d_wins) {
-    HIP_TRY(hipFree(s->d_wins));
-    s->d_wins = nullptr;
-  }
+  // grow-only device allocations: the per-frame re-upload of okvis_amd::Estimator must not pay hipFree/hipMalloc
   A.host.resize(A.size, 0);
-  HIP_TRY(hipMalloc(&s->d_arena, A.size));
+  if (A.size > s->arena_capacity) {
+    if (s->d_arena) HIP_TRY(hipFree(s->d_arena));
+    s->d_arena = nullptr;
+    s->arena_capacity = 0;
+    const size_t cap = A.size + A.size / 4;
+    HIP_TRY(hipMalloc(&s->d_arena, cap));
+    s->arena_capacity = cap;
+  }
   s->arena_bytes = A.size;
   HIP_TRY(hipMemcpy(s->d_arena, A.host.data(), A.size, hipMemcpyHostToDevice));
   std::vector<WinPtrs> ptrs(n_windows);
@@ -873,7 +873,13 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
       s->max_Dpad_large = std::max(s->max_Dpad_large, ((P.D + 5) / 6) * 6);
     s->any_ext = s->any_ext || P.has_ext;
   }
-  HIP_TRY(hipMalloc(&s->d_wins, sizeof(WinPtrs) * n_windows));
+  if ((size_t)n_windows > s->wins_capacity) {
+    if (s->d_wins) HIP_TRY(hipFree(s->d_wins));
+    s->d_wins = nullptr;
+    s->wins_capacity = 0;
+    HIP_TRY(hipMalloc(&s->d_wins, sizeof(WinPtrs) * n_windows));
+    s->wins_capacity = (size_t)n_windows;
+  }
   HIP_TRY(hipMemcpy(s->d_wins, ptrs.data(), sizeof(WinPtrs) * n_windows, hipMemcpyHostToDevice));
   OptD d = make_optd(s->opt);
   HIP_TRY(hipMemcpy(s->d_opt, &d, sizeof(d), hipMemcpyHostToDevice));
@@ -885,13 +891,16 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     // than two streams lose again
     int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 32 ? 2 : 1);
     nsub = std::max(1, std::min(nsub, n_windows));
-    for (auto st : s->sub_streams) (void)hipStreamDestroy(st);
-    for (auto ev : s->sub_events) (void)hipEventDestroy(ev);
-    s->sub_streams.clear();
-    s->sub_events.clear();
     s->sub_begin.assign(nsub + 1, 0);
     for (int k = 0; k <= nsub; ++k) s->sub_begin[k] = (int)((int64_t)n_windows * k / nsub);
-    if (nsub > 1) {
+    const bool same = (nsub > 1 ? (int)s->sub_streams.size() == nsub : s->sub_streams.empty());
+    if (!same) {
+      for (auto st : s->sub_streams) (void)hipStreamDestroy(st);
+      for (auto ev : s->sub_events) (void)hipEventDestroy(ev);
+      s->sub_streams.clear();
+      s->sub_events.clear();
+    }
+    if (nsub > 1 && !same) {
       for (int k = 0; k < nsub; ++k) {
         hipStream_t st;
         hipEvent_t ev;
