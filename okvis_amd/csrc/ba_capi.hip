@@ -628,25 +628,23 @@ hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
   }
   return hipGetLastError();
 }
-hipError_t launch_small(okvis_ba_solver* s, Sub b, int init) {
-  hipLaunchKernelGGL(small_kernel, dim3(s->max_imu + 1, (unsigned)b.nw), dim3(IMU_THREADS), small_smem(), b.st, s->d_wins + b.w0,
-                     init);
-  return hipGetLastError();
-}
+// one launch for everything that depends only on the trial state: IMU / prior factors (first max_imu + 1
+// workgroups) and the reprojection groups
 hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
-  if (s->max_group == 0) return hipSuccess;
-  const dim3 grid(s->max_group, (unsigned)b.nw), blk(LIN_THREADS);
+  const int n_small = s->max_imu + 1;
+  const dim3 grid(n_small + s->max_group, (unsigned)b.nw), blk(LIN_THREADS);
   const bool f32 = s->opt.fp32_linearize != 0;
+  const size_t smem = std::max(lin_smem(s->any_ext, f32), small_smem());
   if (s->any_ext) {
     if (f32)
-      hipLaunchKernelGGL((linearize_kernel<true, float>), grid, blk, lin_smem(true, true), b.st, s->d_wins + b.w0, s->d_opt, init);
+      hipLaunchKernelGGL((linearize_kernel<true, float>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small);
     else
-      hipLaunchKernelGGL((linearize_kernel<true, double>), grid, blk, lin_smem(true), b.st, s->d_wins + b.w0, s->d_opt, init);
+      hipLaunchKernelGGL((linearize_kernel<true, double>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small);
   } else {
     if (f32)
-      hipLaunchKernelGGL((linearize_kernel<false, float>), grid, blk, lin_smem(false, true), b.st, s->d_wins + b.w0, s->d_opt, init);
+      hipLaunchKernelGGL((linearize_kernel<false, float>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small);
     else
-      hipLaunchKernelGGL((linearize_kernel<false, double>), grid, blk, lin_smem(false), b.st, s->d_wins + b.w0, s->d_opt, init);
+      hipLaunchKernelGGL((linearize_kernel<false, double>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small);
   }
   return hipGetLastError();
 }
@@ -654,7 +652,6 @@ hipError_t launch_iteration(okvis_ba_solver* s, Sub b) {
   hipError_t e;
   if ((e = launch_schur(s, b)) != hipSuccess) return e;
   if ((e = launch_solve(s, b, 0)) != hipSuccess) return e;
-  if ((e = launch_small(s, b, 0)) != hipSuccess) return e;
   return launch_lin(s, b, 0);
 }
 // n iterations of every sub-batch: fork from the main stream, one chain per sub-stream, join
@@ -759,16 +756,16 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   // kernels may use more than the default 64 KB of dynamic LDS
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<true, double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lin_smem(true));
+                            (int)std::max(lin_smem(true), small_smem()));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lin_smem(true, true));
+                            (int)std::max(lin_smem(true, true), small_smem()));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<false, float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lin_smem(false, true));
+                            (int)std::max(lin_smem(false, true), small_smem()));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<false, double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lin_smem(false));
+                            (int)std::max(lin_smem(false), small_smem()));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * SCHUR_LM_BATCH * TILE_DIM * 3 * sizeof(double)));
@@ -781,9 +778,6 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_tiles_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             CT_SMEM_DOUBLES * 8);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)small_smem());
 
   if (e != hipSuccess) {
     int code = OKVIS_BA_HIP_ERROR_BASE + (int)e;
@@ -974,7 +968,6 @@ int okvis_ba_begin(okvis_ba_solver* s) {
     c.lambda = 1.0 / s->opt.initial_radius;
     HIP_TRY(hipMemcpyAsync(H.ptrs.ctrl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
   }
-  HIP_TRY(launch_small(s, whole(s), 1));
   HIP_TRY(launch_lin(s, whole(s), 1));
   s->begun = true;
   return OKVIS_BA_OK;
@@ -1233,8 +1226,7 @@ int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4) {
     HIP_TRY(hipEventRecord(e[1], s->stream));
     HIP_TRY(launch_solve(s, whole(s), 0));
     HIP_TRY(hipEventRecord(e[2], s->stream));
-    HIP_TRY(launch_small(s, whole(s), 0));
-    HIP_TRY(hipEventRecord(e[3], s->stream));
+    HIP_TRY(hipEventRecord(e[3], s->stream));   // (the small factors run inside the linearise launch)
     HIP_TRY(launch_lin(s, whole(s), 0));
     HIP_TRY(hipEventRecord(e[4], s->stream));
   }

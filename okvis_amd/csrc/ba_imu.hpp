@@ -1,6 +1,7 @@
-// Kernel 4 — IMU factors, small priors and the marginalisation prior at the trial state (fp64).
+// IMU factors, small priors and the marginalisation prior at the trial state (fp64) — the first
+// (max_imu + 1) workgroups of the linearise launch (ba_linearize.hpp).
 //
-// grid.x = n_imu workgroups (one per ImuError) + 1 workgroup for all PoseError / SpeedAndBiasError /
+// n_imu workgroups (one per ImuError) + 1 workgroup for all PoseError / SpeedAndBiasError /
 // RelativePoseError / MarginalizationError terms of the window.
 //
 // IMU workgroup (ImuError::EvaluateWithMinimalJacobians, ImuError.cpp:514-685):
@@ -966,10 +967,11 @@ __device__ void small_factors(const WinPtrs& W, int trial, double* lds, int tid)
   }
 }
 
-__global__ __launch_bounds__(IMU_THREADS) void small_kernel(const WinPtrs* __restrict__ wins, int init) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const WinPtrs& W = wins[blockIdx.y];
-  const int bx = blockIdx.x;
+// Body of one "small factor" workgroup: bx < n_imu -> ImuError bx, bx == n_imu -> all priors + marginalisation
+// prior.  Runs inside the linearise launch (ba_linearize.hpp): the IMU / prior factors and the reprojection
+// factors both depend only on the trial state of the solve kernel, so they share one launch and a slow
+// re-preintegration overlaps with the (wide) reprojection work instead of holding a kernel boundary.
+__device__ void small_body(const WinPtrs& W, int init, int bx, double* smem) {
   if (bx > W.n_imu) return;
   const Ctrl* ctrl = W.ctrl;
   if (ctrl->done) return;

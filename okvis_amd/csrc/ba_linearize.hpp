@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "ba_device.hpp"
+#include "ba_imu.hpp"
 
 namespace ba {
 
@@ -35,12 +36,19 @@ struct LinCfg {
 
 __device__ __forceinline__ int ut6(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }
 
+// grid.x = n_small + (number of groups): the first n_small = max_imu + 1 workgroups evaluate the IMU / prior
+// factors (small_body, ba_imu.hpp; they start first because a re-preintegration is the longest workgroup of
+// the launch), the others one linearise group each.  Two workgroups per CU (LDS), hence at most 256 registers.
 template <bool EXT, class REAL>
-__global__ __launch_bounds__(LIN_THREADS) void linearize_kernel(const WinPtrs* __restrict__ wins,
-                                                                const OptD* __restrict__ optp, int init) {
+__global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs* __restrict__ wins,
+                                                                   const OptD* __restrict__ optp, int init, int n_small) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const WinPtrs& W = wins[blockIdx.y];
-  const int g = blockIdx.x;
+  if ((int)blockIdx.x < n_small) {
+    small_body(W, init, blockIdx.x, smem);
+    return;
+  }
+  const int g = blockIdx.x - n_small;
   if (g >= W.n_group) return;
   const Ctrl* ctrl = W.ctrl;
   if (ctrl->done) return;
