@@ -174,7 +174,7 @@ typedef struct okvis_ba_options {
                                    at initial_radius (no trust-region logic); used by bench.py so that
                                    every timed iteration performs identical, full work                   */
   int32_t n_streams;            /* sub-batches of windows on separate HIP streams (phases of different
-                                   windows overlap); 0 = auto (2 for >= 32 windows, else 1)              */
+                                   windows overlap); 0 = auto (2 for >= 16 windows, else 1)              */
   int32_t fp32_linearize;       /* BASELINE configs[4] (mixed-precision study): 1 = reprojection residuals, Jacobians
                                    and their J^T J / J^T r accumulation in fp32; state, Schur complement and the
                                    reduced solve stay fp64.  0 (default) = everything fp64 like the reference   */

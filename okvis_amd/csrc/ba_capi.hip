@@ -883,7 +883,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     // measured on MI355X / ROCm 7.2 (profiles/r01_notes.md): branches inside ONE captured graph are not
     // overlapped, but two independently replayed graphs on two streams are (+29 % at 64 windows); more
     // than two streams lose again
-    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 32 ? 2 : 1);
+    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 16 ? 2 : 1);
     nsub = std::max(1, std::min(nsub, n_windows));
     s->sub_begin.assign(nsub + 1, 0);
     for (int k = 0; k <= nsub; ++k) s->sub_begin[k] = (int)((int64_t)n_windows * k / nsub);
