@@ -351,13 +351,13 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       }
     }
     __syncthreads();
-    // ---- stage 3
-    double C[9], CC[9], dt = 0, ab[3] = {0, 0, 0};
+    // ---- stage 3 (every stage keeps its temporaries local and re-reads what it needs from LDS: nothing but
+    //      `tid` stays live in registers across the barriers — the launch is capped at 256 registers)
     if (tid < ns) {
-      double C1m[9];
+      double C[9], CC[9], ab[3], C1m[9];
       qrot(lds + ImuLds::DQP + 4 * tid, C);
       qrot(lds + ImuLds::DQP + 4 * (tid + 1), C1m);
-      dt = lds[ImuLds::DT + tid];
+      const double dt = lds[ImuLds::DT + tid];
       for (int c = 0; c < 3; ++c) ab[c] = lds[ImuLds::AB + 3 * tid + c];
       for (int c = 0; c < 9; ++c) CC[c] = C[c] + C1m[c];
       double t9[9], t3[3], h[9];
@@ -386,8 +386,12 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
     }
     __syncthreads();
     // ---- stage 5
-    double G[9];
     if (tid < ns) {
+      double G[9], C[9], CC[9], ab[3];
+      const double dt = lds[ImuLds::DT + tid];
+      qrot(lds + ImuLds::DQP + 4 * tid, C);
+      for (int c = 0; c < 3; ++c) ab[c] = lds[ImuLds::AB + 3 * tid + c];
+      for (int c = 0; c < 9; ++c) CC[c] = C[c] + lds[ImuLds::C1 + 9 * tid + c];
       double Cint[9], aint[3], cross[9], cross1[9];
       ld9(lds + ImuLds::CINTP, tid, Cint);
       for (int c = 0; c < 3; ++c) aint[c] = lds[ImuLds::AINTP + 3 * tid + c];
@@ -426,7 +430,9 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
     __syncthreads();
     if (tid < ns) {
       double t9[9];
-      for (int c = 0; c < 9; ++c) t9[c] = dt * lds[ImuLds::DVP + 9 * tid + c] + 0.25 * dt * dt * G[c];
+      const double dt = lds[ImuLds::DT + tid];
+      for (int c = 0; c < 9; ++c)
+        t9[c] = dt * lds[ImuLds::DVP + 9 * tid + c] + 0.25 * dt * dt * lds[ImuLds::GG + 9 * tid + c];
       st9(lds + ImuLds::RINV, tid, t9);
     }
     __syncthreads();
