@@ -977,7 +977,7 @@ __device__ void small_factors(const WinPtrs& W, int trial, double* lds, int tid)
 // prior.  Runs inside the linearise launch (ba_linearize.hpp): the IMU / prior factors and the reprojection
 // factors both depend only on the trial state of the solve kernel, so they share one launch and a slow
 // re-preintegration overlaps with the (wide) reprojection work instead of holding a kernel boundary.
-__device__ void small_body(const WinPtrs& W, int init, int bx, double* smem) {
+__device__ __forceinline__ void small_body(const WinPtrs& W, int init, int bx, double* smem) {
   if (bx > W.n_imu) return;
   const Ctrl* ctrl = W.ctrl;
   if (ctrl->done) return;
