@@ -234,6 +234,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   int gpart_size = 0;
   for (int g = 0; g < ngroup; ++g) {
     Group& G = groups[g];
+    G.plist_begin = (int)pair_list.size();
+    G.tlist_begin = (int)task_list.size();
     for (int p = G.pair_begin; p < G.pair_end; ++p) {
       pair_list_begin[p] = (int)pair_list.size();
       const int l = pair_lm[p], b = pair_block[p];
@@ -275,6 +277,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       tasks.push_back(T);
     }
     G.task_end = (int)tasks.size();
+    G.plist_end = (int)pair_list.size();
+    G.tlist_end = (int)task_list.size();
   }
   pair_list_begin[npair] = (int)pair_list.size();
   // ---- chunks (Schur workgroups) ----

@@ -18,6 +18,26 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// Lane exchange inside a quad with DPP (VALU speed; __shfl_xor goes through the LDS crossbar, ds_bpermute).
+// CTRL 0xB1 = quad_perm:[1,0,3,2] (xor 1), 0x4E = quad_perm:[2,3,0,1] (xor 2).
+template <int CTRL>
+__device__ __forceinline__ double quad_xchg(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_xchg(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over the four lanes of a quad (all four lanes obtain it; all four must be active)
+template <class T>
+__device__ __forceinline__ T quad_sum(T v) {
+  v += quad_xchg<0xB1>(v);
+  v += quad_xchg<0x4E>(v);
+  return v;
+}
+
 // Sums of the per-group / per-factor partials of linearisation buffer `buf`, computed by ONE full wave
 // in a fixed order (lane-strided accumulation + xor butterfly) so that the Schur kernel and the solve
 // kernel obtain bit-identical values.  out: cost, g.delta (landmarks), delta^T D^2 delta, |delta|^2,

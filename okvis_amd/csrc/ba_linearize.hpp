@@ -34,6 +34,11 @@ struct LinCfg {
   static constexpr int SMEM_DOUBLES = STAGE_DOUBLES + GROUP_LM * 4 + GROUP_PAIRS * 3 + GROUP_LM * 16 + 1024;
 };
 
+constexpr int LIN_TASK_CACHE = 64;   // Task records of a group kept in LDS (more: read from global memory)
+static_assert((GROUP_PAIRS + 1 + GROUP_LM + 1 + LIN_TASK_CACHE * 6) * 4 + (2 + 3) * GROUP_OBS * 2 + GROUP_PAIRS <=
+                  GROUP_PAIRS * 3 * 8, "index cache must fit the s_pair area");
+static_assert(sizeof(Task) == 24, "Task is cached as 6 ints");
+
 __device__ __forceinline__ int ut6(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }
 
 // grid.x = n_small + (number of groups): the first n_small = max_imu + 1 workgroups evaluate the IMU / prior
@@ -50,6 +55,8 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   }
   const int g = blockIdx.x - n_small;
   if (g >= W.n_group) return;
+#define LSTAMP(k) do { if (threadIdx.x == 0 && g == 0) W.prof[k] = (double)clock64(); } while (0)
+  LSTAMP(40);
   const Ctrl* ctrl = W.ctrl;
   if (ctrl->done) return;
   if (!init && !ctrl->pending) return;  // the solve produced no valid step: nothing to evaluate
@@ -69,14 +76,85 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   const int nlm = G.lm_end - G.lm_begin;
   const int nobs = G.obs_end - G.obs_begin;
   const int npair = G.pair_end - G.pair_begin;
+  const int ntask = G.task_end - G.task_begin;
+  const int nplist = G.plist_end - G.plist_begin;   // <= 2 nobs
+  const int ntlist = G.tlist_end - G.tlist_begin;   // <= 3 nobs
 
+  // The group's index lists (static structure) are fetched NOW into registers — nothing but G is needed for the
+  // addresses — and parked in LDS after phase A (in the s_pair area, dead by then), so that the reduction loops
+  // of phase C chase indices through LDS instead of through dependent global loads.
+  int* s_plb = reinterpret_cast<int*>(s_pair);                                // [GROUP_PAIRS + 1] pair list begins
+  int* s_lob = s_plb + GROUP_PAIRS + 1;                                       // [GROUP_LM + 1] landmark obs begins
+  int* s_task = s_lob + GROUP_LM + 1;                                         // [LIN_TASK_CACHE] Task records
+  uint16_t* s_plist = reinterpret_cast<uint16_t*>(s_task + LIN_TASK_CACHE * 6);  // [2 GROUP_OBS]
+  uint16_t* s_tlist = s_plist + 2 * GROUP_OBS;                                // [3 GROUP_OBS]
+  uint8_t* s_prole = reinterpret_cast<uint8_t*>(s_tlist + 3 * GROUP_OBS);     // [GROUP_PAIRS]
+  int pf_plb[2], pf_role[2], pf_lob = 0;
+  uint16_t pf_pl[2], pf_tl[3];
+  Task pf_task;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + j * LIN_THREADS;
+    pf_plb[j] = (i < npair) ? W.pair_list_begin[G.pair_begin + i] : 0;
+    pf_role[j] = (EXT && i < npair) ? W.pair_role[G.pair_begin + i] : 0;
+    pf_pl[j] = (i < nplist) ? W.pair_list[G.plist_begin + i] : (uint16_t)0;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = tid + j * LIN_THREADS;
+    pf_tl[j] = (i < ntlist) ? W.task_list[G.tlist_begin + i] : (uint16_t)0;
+  }
+  if (tid <= nlm) pf_lob = W.lm_obs_begin[G.lm_begin + tid];
+  const bool tasks_cached = ntask <= LIN_TASK_CACHE;
+  if (tasks_cached && tid < ntask) pf_task = W.tasks[G.task_begin + tid];
+
+  LSTAMP(41);
   // ------------------------------------------------------------------ phase A: back-substitution
   double sc_gd = 0, sc_ddd = 0, sc_s2 = 0, sc_x2 = 0;
   if (!init) {
+    // every operand that does not depend on the step is requested before the first barrier: the pair rows of the
+    // first pass (W, 18 doubles) and the landmark lanes' b, V, x — one memory round trip instead of three
+    const double* Wacc = W.W[acc];
+    double Wp0[18];
+    int poff0 = 0;
+    if (tid < npair) {
+      const double* Wp = Wacc + (size_t)(G.pair_begin + tid) * 18;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) Wp0[i] = Wp[i];
+      poff0 = W.pair_off[G.pair_begin + tid];
+    }
+    double bb[3] = {0, 0, 0}, v[6] = {1, 0, 0, 1, 0, 1}, xx[4] = {0, 0, 0, 0};
+    int lp0 = 0, lp1 = 0;
+    if (tid < nlm) {
+      const int l = G.lm_begin + tid;
+      const double* b = W.bl[acc] + 3 * (size_t)l;
+      const double* Vl = W.V[acc] + 6 * (size_t)l;
+      const double* x = W.lm[acc] + 4 * (size_t)l;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) bb[i] = b[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = Vl[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xx[i] = x[i];
+      lp0 = W.lm_pair_begin[l] - G.pair_begin;
+      lp1 = W.lm_pair_begin[l + 1] - G.pair_begin;
+    }
     for (int i = tid; i < W.D; i += LIN_THREADS) s_step[i] = W.step[i];
     __syncthreads();
-    const double* Wacc = W.W[acc];
-    for (int p = tid; p < npair; p += LIN_THREADS) {
+    if (tid < npair) {
+      const double* d = s_step + poff0;
+      double t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        t0 += Wp0[3 * i] * d[i];
+        t1 += Wp0[3 * i + 1] * d[i];
+        t2 += Wp0[3 * i + 2] * d[i];
+      }
+      s_pair[3 * tid] = t0;
+      s_pair[3 * tid + 1] = t1;
+      s_pair[3 * tid + 2] = t2;
+    }
+    for (int p = tid + LIN_THREADS; p < npair; p += LIN_THREADS) {
       const double* Wp = Wacc + (size_t)(G.pair_begin + p) * 18;
       const double* d = s_step + W.pair_off[G.pair_begin + p];
       double t0 = 0, t1 = 0, t2 = 0;
@@ -93,16 +171,13 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     __syncthreads();
     if (tid < nlm) {
       const int l = G.lm_begin + tid;
-      const double* b = W.bl[acc] + 3 * (size_t)l;
-      double t[3] = {b[0], b[1], b[2]};
-      for (int p = W.lm_pair_begin[l]; p < W.lm_pair_begin[l + 1]; ++p) {
-        const double* sp = s_pair + 3 * (p - G.pair_begin);
+      double t[3] = {bb[0], bb[1], bb[2]};
+      for (int p = lp0; p < lp1; ++p) {
+        const double* sp = s_pair + 3 * p;
         t[0] += sp[0];
         t[1] += sp[1];
         t[2] += sp[2];
       }
-      const double* Vl = W.V[acc] + 6 * (size_t)l;
-      double v[6] = {Vl[0], Vl[1], Vl[2], Vl[3], Vl[4], Vl[5]};
       const double d0 = clampd(v[0], opt.min_lm_diag2, opt.max_lm_diag2);
       const double d1 = clampd(v[3], opt.min_lm_diag2, opt.max_lm_diag2);
       const double d2 = clampd(v[5], opt.min_lm_diag2, opt.max_lm_diag2);
@@ -114,13 +189,12 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
       const double dl0 = -(vi[0] * t[0] + vi[1] * t[1] + vi[2] * t[2]);
       const double dl1 = -(vi[1] * t[0] + vi[3] * t[1] + vi[4] * t[2]);
       const double dl2 = -(vi[2] * t[0] + vi[4] * t[1] + vi[5] * t[2]);
-      const double* x = W.lm[acc] + 4 * (size_t)l;
-      const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+      const double x0 = xx[0], x1 = xx[1], x2 = xx[2], x3 = xx[3];
       double* xt = W.lm[trial] + 4 * (size_t)l;
       const double n0 = x0 + dl0, n1 = x1 + dl1, n2 = x2 + dl2;
       xt[0] = n0; xt[1] = n1; xt[2] = n2; xt[3] = x3;
       s_lm[4 * tid] = n0; s_lm[4 * tid + 1] = n1; s_lm[4 * tid + 2] = n2; s_lm[4 * tid + 3] = x3;
-      sc_gd = b[0] * dl0 + b[1] * dl1 + b[2] * dl2;
+      sc_gd = bb[0] * dl0 + bb[1] * dl1 + bb[2] * dl2;
       sc_ddd = d0 * dl0 * dl0 + d1 * dl1 * dl1 + d2 * dl2 * dl2;
       sc_s2 = dl0 * dl0 + dl1 * dl1 + dl2 * dl2;
       sc_x2 = x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
@@ -130,6 +204,27 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     s_lm[4 * tid] = x[0]; s_lm[4 * tid + 1] = x[1]; s_lm[4 * tid + 2] = x[2]; s_lm[4 * tid + 3] = x[3];
   }
   __syncthreads();
+  LSTAMP(42);
+  // park the prefetched index lists (s_pair is dead: its last reader was before the barrier above)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + j * LIN_THREADS;
+    if (i < npair) s_plb[i] = pf_plb[j] - G.plist_begin;
+    if (EXT && i < npair) s_prole[i] = (uint8_t)pf_role[j];
+    if (i < nplist) s_plist[i] = pf_pl[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = tid + j * LIN_THREADS;
+    if (i < ntlist) s_tlist[i] = pf_tl[j];
+  }
+  if (tid == 0) s_plb[npair] = nplist;
+  if (tid <= nlm) s_lob[tid] = pf_lob - G.obs_begin;
+  if (tasks_cached && tid < ntask) {
+    int* t = s_task + 6 * tid;
+    t[0] = pf_task.type; t[1] = pf_task.off_a; t[2] = pf_task.off_b;
+    t[3] = pf_task.list_begin - G.tlist_begin; t[4] = pf_task.list_end - G.tlist_begin; t[5] = pf_task.out;
+  }
 
   // ------------------------------------------------------------------ phase B: one observation per lane
   if (tid < nobs) {
@@ -181,6 +276,7 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
       sr = sqrt(rho1);
       irho = sum;
     }
+    LSTAMP(43);
     REAL* st = s_stage + (size_t)tid * STRIDE;
     st[ST_R] = sr * J.r[0];
     st[ST_R + 1] = sr * J.r[1];
@@ -197,51 +293,58 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     }
   }
   __syncthreads();
+  LSTAMP(44);
 
   // ------------------------------------------------------------------ phase C: LDS reductions
-  // (a) per landmark: V(6) b(3) Hq(6) cost(1)
-  for (int wi = tid; wi < nlm * 16; wi += LIN_THREADS) {
-    const int ll = wi >> 4, e = wi & 15;
-    const int l = G.lm_begin + ll;
-    const int o0 = W.lm_obs_begin[l] - G.obs_begin, o1 = W.lm_obs_begin[l + 1] - G.obs_begin;
-    REAL a = 0;
-    if (e < 6) {
-      const int i = (e < 3) ? 0 : (e < 5 ? 1 : 2);
-      const int j = (e < 3) ? e : (e < 5 ? e - 2 : 2);
-      for (int o = o0; o < o1; ++o) {
-        const REAL* st = s_stage + (size_t)o * STRIDE + ST_JL;
-        a += st[i] * st[j] + st[3 + i] * st[3 + j];
-      }
-      W.V[trial][6 * (size_t)l + e] = a;
-    } else if (e < 9) {
-      const int i = e - 6;
-      for (int o = o0; o < o1; ++o) {
+  // (a) per landmark: V(6) b(3) Hq(6) cost(1).  Four lanes per (landmark, entry), each takes every fourth
+  //     observation; every entry is the same expression  sum (x_A x_B + x_C x_D) m  with per-lane operand offsets
+  //     (no divergence between the entry classes, which cost four serialised loops per wave before).
+  {
+    const int e = (tid >> 2) & 15, part = tid & 3;   // loop invariant: LIN_THREADS is a multiple of 64
+    const bool is_cost = e == 15, use_irho = e >= 9 && e < 15, is_b = e >= 6 && e < 9;
+    const int ee = e < 6 ? e : (use_irho ? e - 9 : 0);
+    const int vi = (ee < 3) ? 0 : (ee < 5 ? 1 : 2);
+    const int vj = (ee < 3) ? ee : (ee < 5 ? ee - 2 : 2);
+    const int oA = is_cost ? ST_COST : ST_JL + (is_b ? e - 6 : vi);
+    const int oB = is_b ? ST_R : ST_JL + vj;
+    const int oC = ST_JL + 3 + (is_b ? e - 6 : vi);
+    const int oD = is_b ? ST_R + 1 : ST_JL + 3 + vj;
+    double* obase = e < 6 ? W.V[trial] : (is_b ? W.bl[trial] : W.Hq[trial]);
+    const int ostride = is_b ? 3 : 6, ooff = e < 6 ? e : (is_b ? e - 6 : e - 9);
+    for (int wi = tid; wi < nlm * 64; wi += LIN_THREADS) {
+      const int ll = wi >> 6;
+      const int o0 = s_lob[ll], o1 = s_lob[ll + 1];
+      REAL a = 0;
+      auto term = [&](int o) -> REAL {
         const REAL* st = s_stage + (size_t)o * STRIDE;
-        a += st[ST_JL + i] * st[ST_R] + st[ST_JL + 3 + i] * st[ST_R + 1];
+        const REAL t1 = st[oA] * (is_cost ? REAL(1) : st[oB]);
+        const REAL t2 = is_cost ? REAL(0) : st[oC] * st[oD];
+        const REAL m = use_irho ? st[ST_IRHO] : REAL(1);
+        return (t1 + t2) * m;
+      };
+      int o = o0 + part;
+      for (; o + 4 < o1; o += 8) {   // two observations per trip: both sets of LDS reads in flight together
+        const REAL ta = term(o), tb = term(o + 4);
+        a += ta;
+        a += tb;
       }
-      W.bl[trial][3 * (size_t)l + i] = a;
-    } else if (e < 15) {
-      const int ee = e - 9;
-      const int i = (ee < 3) ? 0 : (ee < 5 ? 1 : 2);
-      const int j = (ee < 3) ? ee : (ee < 5 ? ee - 2 : 2);
-      for (int o = o0; o < o1; ++o) {
-        const REAL* st = s_stage + (size_t)o * STRIDE;
-        a += (st[ST_JL + i] * st[ST_JL + j] + st[ST_JL + 3 + i] * st[ST_JL + 3 + j]) * st[ST_IRHO];
+      if (o < o1) a += term(o);
+      a = quad_sum(a);
+      if (part == 0) {
+        if (!is_cost) obase[ostride * (size_t)(G.lm_begin + ll) + ooff] = a;
+        s_lmres[16 * ll + e] = a;
       }
-      W.Hq[trial][6 * (size_t)l + ee] = a;
-    } else {
-      for (int o = o0; o < o1; ++o) a += s_stage[(size_t)o * STRIDE + ST_COST];
     }
-    s_lmres[wi] = a;
   }
+  LSTAMP(45);
   // (b) per (landmark, block) pair: W = sum J_block^T J_l, one work-item per row
   for (int wi = tid; wi < npair * 6; wi += LIN_THREADS) {
     const int pp = wi / 6, a = wi - 6 * pp;
     const int p = G.pair_begin + pp;
-    const int jofs = (EXT && W.pair_role[p]) ? ST_JE : ST_JP;
+    const int jofs = (EXT && s_prole[pp]) ? ST_JE : ST_JP;
     REAL w0 = 0, w1 = 0, w2 = 0;
-    for (int k = W.pair_list_begin[p]; k < W.pair_list_begin[p + 1]; ++k) {
-      const REAL* st = s_stage + (size_t)W.pair_list[k] * STRIDE;
+    for (int k = s_plb[pp]; k < s_plb[pp + 1]; ++k) {
+      const REAL* st = s_stage + (size_t)s_plist[k] * STRIDE;
       const REAL j0 = st[jofs + a], j1 = st[jofs + 6 + a];
       w0 += j0 * st[ST_JL] + j1 * st[ST_JL + 3];
       w1 += j0 * st[ST_JL + 1] + j1 * st[ST_JL + 4];
@@ -252,41 +355,64 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     Wt[1] = w1;
     Wt[2] = w2;
   }
+  LSTAMP(46);
   // (c) per-block J^T J / J^T r partials and pose-extrinsics cross blocks.  These are the long reductions of the
   //     group (every observation of one pose block): four lanes share one (task, row) item, each takes every
   //     fourth observation of the task's list, the partial sums are combined with two xor-shuffles
   //     (8 lanes per item measured slower: 109 vs 101 us on the 64-window launch).
-  const int ntask = G.task_end - G.task_begin;
   for (int wi = tid; wi < ntask * 24; wi += LIN_THREADS) {
     const int tt = wi / 24, a = (wi >> 2) % 6, part = wi & 3;
-    const Task T = W.tasks[G.task_begin + tt];
+    Task T;
+    if (tasks_cached) {
+      const int* t = s_task + 6 * tt;
+      T.type = t[0]; T.off_a = t[1]; T.off_b = t[2]; T.list_begin = t[3]; T.list_end = t[4]; T.out = t[5];
+    } else {
+      T = W.tasks[G.task_begin + tt];
+      T.list_begin -= G.tlist_begin;
+      T.list_end -= G.tlist_begin;
+    }
     double* out = W.gpart[trial] + T.out;
     REAL acc6[6] = {0, 0, 0, 0, 0, 0};
     REAL ga = 0;
-    if (T.type < 2) {
-      const int jofs = (T.type == 1) ? ST_JE : ST_JP;
-      for (int k = T.list_begin + part; k < T.list_end; k += 4) {
-        const REAL* st = s_stage + (size_t)W.task_list[k] * STRIDE;
-        const REAL j0 = st[jofs + a], j1 = st[jofs + 6 + a];
+    // jr = row operand block (J_a), jc = column operand block: pose/extrinsics Hessian  J_x^T J_x (+ J_x^T r),
+    // cross block J_pose^T J_ext
+    const int jr = (T.type == 1) ? ST_JE : ST_JP;
+    const int jc = (T.type == 0) ? ST_JP : ST_JE;
+    const bool with_g = T.type < 2;
+    auto term = [&](int o, REAL t6[6], REAL& tg) {
+      const REAL* st = s_stage + (size_t)o * STRIDE;
+      const REAL j0 = st[jr + a], j1 = st[jr + 6 + a];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) acc6[b] += j0 * st[jofs + b] + j1 * st[jofs + 6 + b];
-        ga += j0 * st[ST_R] + j1 * st[ST_R + 1];
+      for (int b = 0; b < 6; ++b) t6[b] = j0 * st[jc + b] + j1 * st[jc + 6 + b];
+      tg = j0 * st[ST_R] + j1 * st[ST_R + 1];
+    };
+    if (EXT || T.type == 0) {
+      int k = T.list_begin + part;
+      for (; k + 4 < T.list_end; k += 8) {   // two observations per trip (LDS reads of both in flight together)
+        const int oa = s_tlist[k], ob = s_tlist[k + 4];
+        REAL ta[6], tb[6], ga_a, ga_b;
+        term(oa, ta, ga_a);
+        term(ob, tb, ga_b);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          acc6[b] += ta[b];
+          acc6[b] += tb[b];
+        }
+        ga += ga_a;
+        ga += ga_b;
       }
-    } else if (EXT) {
-      for (int k = T.list_begin + part; k < T.list_end; k += 4) {
-        const REAL* st = s_stage + (size_t)W.task_list[k] * STRIDE;
-        const REAL j0 = st[ST_JP + a], j1 = st[ST_JP + 6 + a];
+      if (k < T.list_end) {
+        REAL ta[6], ga_a;
+        term(s_tlist[k], ta, ga_a);
 #pragma unroll
-        for (int b = 0; b < 6; ++b) acc6[b] += j0 * st[ST_JE + b] + j1 * st[ST_JE + 6 + b];
+        for (int b = 0; b < 6; ++b) acc6[b] += ta[b];
+        ga += ga_a;
       }
     }
+    if (!with_g) ga = 0;
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      acc6[b] += __shfl_xor(acc6[b], 1);
-      acc6[b] += __shfl_xor(acc6[b], 2);
-    }
-    ga += __shfl_xor(ga, 1);
-    ga += __shfl_xor(ga, 2);
+    for (int b = 0; b < 6; ++b) acc6[b] = quad_sum(acc6[b]);
+    ga = quad_sum(ga);
     if (part == 0) {
       if (T.type < 2) {
         for (int b = a; b < 6; ++b) out[ut6(a, b)] = acc6[b];
@@ -296,7 +422,9 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
       }
     }
   }
+  LSTAMP(47);
   __syncthreads();
+  LSTAMP(48);
   // (d) group scalars by wave 0
   if (tid < 64) {
     double cost = 0, gm = 0;
@@ -320,6 +448,7 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
       gs[GS_GMAX] = gm;
     }
   }
+  LSTAMP(49);
 }
 
 }  // namespace ba

@@ -39,6 +39,8 @@ struct Group {  // one linearise workgroup: whole landmarks, <= GROUP_OBS observ
   int obs_begin, obs_end;
   int pair_begin, pair_end;
   int task_begin, task_end;
+  int plist_begin, plist_end;  // the group's slice of pair_list (= pair_list_begin[pair_begin .. pair_end])
+  int tlist_begin, tlist_end;  // the group's slice of task_list
 };
 
 // reduction task of a group: accumulate over a list of the group's observations

@@ -21,3 +21,10 @@ print("kb=0: panel", p[11]-p[10], "trailing(thread0 work)", p[26]-p[11], "traili
 print("kb=12: panel", p[14]-p[13], "trailing+barrier", p[15]-p[14])
 
 print("kb=12 T-phase (cycles from phase start): lane64 item done", p[30]-p[14], " look-ahead quad update done", p[31]-p[14], " factor done", p[32]-p[14], " rhs wave done", p[33]-p[14], " barrier released", p[15]-p[14])
+
+ln = {41: "wins/ctrl/group loads", 42: "phase A (back-substitution)", 43: "phase B loads + residual/Jacobian", 44: "stage write + barrier",
+      45: "C(a) per landmark", 46: "C(b) per pair", 47: "C(c) per block (thread 0)", 48: "barrier", 49: "scalars"}
+print("linearise phases of group 0 (thread 0):")
+for k in range(41, 50):
+    d = p[k] - p[k - 1]; print(f"  {ln[k]:36s} {d:10.0f} cyc {d/2100:8.2f} us")
+print("  total", (p[49] - p[40]) / 2100, "us")
