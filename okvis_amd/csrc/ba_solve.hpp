@@ -91,21 +91,49 @@ __device__ __forceinline__ bool chol6(double (&L)[6][6], double (&inv)[6]) {
 }
 
 
-// factor the 6x6 diagonal block (lower triangle at dblk) and publish L (row-major 6x6) and 1/diag(L)
-__device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, double* inv_out) {
-  double L[6][6], inv[6];
+// explicit inverse of the lower-triangular factor (row-major, entries above the diagonal untouched):
+// six independent columns, so a later  x = L^-1 y  is six independent dot products instead of a 21-step chain
+__device__ __forceinline__ void trinv6(const double (&L)[6][6], const double (&inv)[6], double (&X)[6][6]) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    X[j][j] = inv[j];
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double a = 0;
+#pragma unroll
+      for (int m = j; m < i; ++m) a += L[i][m] * X[m][j];
+      X[i][j] = -a * inv[i];
+    }
+  }
+}
+
+// publish L (row-major 6x6) and L^-1 (row-major 6x6, lower triangle) of a factored diagonal block
+__device__ __forceinline__ void publish_diag(const double (&L)[6][6], const double (&X)[6][6], double* Lout, double* Xout) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      Lout[6 * i + j] = L[i][j];
+      Xout[6 * i + j] = X[i][j];
+    }
+}
+
+// factor the 6x6 diagonal block (lower triangle at dblk) and publish L and L^-1
+__device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, double* Xout) {
+  double L[6][6], X[6][6], inv[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int j = 0; j <= i; ++j) L[i][j] = dblk[6 * i + j];
   const bool ok = chol6(L, inv);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-#pragma unroll
-    for (int j = 0; j <= i; ++j) Lout[6 * i + j] = L[i][j];
-    inv_out[i] = inv[i];
-  }
+  trinv6(L, inv, X);
+  publish_diag(L, X, Lout, Xout);
   return ok;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
 // IMU Hessian blocks, priors and the marginalisation prior of linearisation buffer `acc`, accumulated into S
@@ -468,14 +496,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   if (tid == 0) {
     if (!factor_diag(S + LY.blk(0, 0), s_diag, s_dinv)) s_fail = 1;
   }
-  // LDS path: every lane owns (at most) two fixed 3x3 sub-tiles of the trailing matrix for the whole
-  // factorisation (the mirrored enumeration does not depend on kb): coordinates and the C address are
-  // computed once; an item is active while its block column is right of the current one.
-  // wave 14 is the look-ahead wave (next diagonal block: update + factor, starts at once), wave 15 handles
-  // the right-hand-side blocks, waves 0-13 the bulk of the trailing update
+  // every lane owns (at most) two fixed 3x3 sub-tiles of the trailing matrix for the whole factorisation (the
+  // mirrored enumeration does not depend on kb): coordinates and the C address are computed once; an item is
+  // active while its block column is right of the current one.
+  // wave 14 is the look-ahead wave (next diagonal block: update + factor + inverse, the dependency chain of the
+  // factorisation), wave 15 handles the right-hand-side blocks, waves 0-13 the bulk of the trailing update
   constexpr int TU_THREADS = SOLVE_THREADS - 128;
   int it_gbi[2] = {0, 0}, it_gbj[2] = {-1, -1}, it_sr[2] = {0, 0}, it_sc[2] = {0, 0}, it_c[2] = {0, 0};
-  if (!LARGE && tid < TU_THREADS) {
+  if (tid < TU_THREADS) {
     for (int u = 0; u < 2; ++u) {
       const int wi = tid + u * TU_THREADS;
       const int q = wi >> 2, sub = wi & 3;
@@ -488,25 +516,33 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       }
     }
   }
+  // look-ahead lane -> entry (li_i, li_j) of the lower triangle of a 6x6 block
+  const int la_lane = tid - TU_THREADS;
+  int la_i = 0, la_j = 0;
+  if (la_lane >= 0 && la_lane < 21) {
+    la_i = (la_lane >= 15) ? 5 : (la_lane >= 10) ? 4 : (la_lane >= 6) ? 3 : (la_lane >= 3) ? 2 : (la_lane >= 1) ? 1 : 0;
+    la_j = la_lane - la_i * (la_i + 1) / 2;
+  }
   __syncthreads();
   for (int kb = 0; kb < nbk; ++kb) {
     const int k0 = kb * 6;
     const int nrows = Dpad - k0 - 6;  // panel rows below the diagonal block
     if (kb == 0) STAMP(10);
     if (kb == 12) STAMP(13);
-    // (P) panel: row <- row * L_kk^-T (independent dot products with the published inverse); the
+    // (P) panel: row <- row * L_kk^-T as six independent dot products with the published inverse; the
     //     right-hand side rides along as one more row (forward substitution)
     if (tid <= nrows) {
       double* row = (tid < nrows) ? (S + LY.blk((k0 + 6 + tid) / 6, kb) + ((k0 + 6 + tid) % 6) * 6) : (s_rhs + k0);
-      const double* Ld = s_diag + 36 * kb;
-      const double* iv = s_dinv + 6 * kb;
-      double x[6];
+      const double* Xd = s_dinv + 36 * kb;
+      double v[6], x[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) v[m] = row[m];
 #pragma unroll
       for (int cix = 0; cix < 6; ++cix) {
-        double v = row[cix];
+        double a = 0;
 #pragma unroll
-        for (int m = 0; m < cix; ++m) v -= x[m] * Ld[6 * cix + m];
-        x[cix] = v * iv[cix];
+        for (int m = 0; m <= cix; ++m) a += v[m] * Xd[6 * cix + m];
+        x[cix] = a;
       }
 #pragma unroll
       for (int cix = 0; cix < 6; ++cix) row[cix] = x[cix];
@@ -514,149 +550,104 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     __syncthreads();
     if (kb == 0) STAMP(11);
     if (kb == 12) STAMP(14);
-    // (T) trailing update with 6x6 register blocks  A_(bi,bj) -= L_(bi,k) L_(bj,k)^T ; rhs blocks ride
-    //     along; the owner of the next diagonal block factors it right away (look-ahead)
+    // (T) trailing update with 3x3 register sub-tiles  A_(bi,bj) -= L_(bi,k) L_(bj,k)^T ; rhs blocks ride
+    //     along; the look-ahead wave prepares the next diagonal block meanwhile
     const int nt = nbk - kb - 1;
-    const int nblkpairs = nt * (nt + 1) / 2;
-    if (!LARGE) {
-      const int colk = LY.blk(kb, kb);  // start of block column kb (its diagonal block)
-      if (tid < TU_THREADS) {
+    const int colk = LY.blk(kb, kb);  // start of block column kb (its diagonal block)
+    if (tid < TU_THREADS) {
+      // let the look-ahead wave's few LDS reads enter the queue before the bulk's ~27 per lane (it carries the
+      // dependency chain; measured: its operands arrived after ~900 cycles without this head start)
+      __builtin_amdgcn_s_sleep(2);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int gbi = it_gbi[u], gbj = it_gbj[u];
-          if (gbj <= kb) continue;  // not (or no longer) part of the trailing matrix
-          if (gbi == kb + 1) continue;  // block (kb+1, kb+1): the look-ahead wave (gbj > kb and gbj <= gbi)
-          const double* Li = S + colk + (gbi - kb) * SBS + 6 * it_sr[u];  // rows sr..sr+2 of L_(gbi,k)
-          const double* Lj = S + colk + (gbj - kb) * SBS + 6 * it_sc[u];  // rows sc..sc+2 of L_(gbj,k)
-          double* Cb = S + it_c[u];
-          double li[18], lj[18], cc[9];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            const double2 a = reinterpret_cast<const double2*>(Li)[i], b = reinterpret_cast<const double2*>(Lj)[i];
-            li[2 * i] = a.x; li[2 * i + 1] = a.y;
-            lj[2 * i] = b.x; lj[2 * i + 1] = b.y;
-          }
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int cix = 0; cix < 3; ++cix) cc[3 * r + cix] = Cb[6 * r + cix];
-          const bool skip = (gbi == gbj && it_sr[u] == 0 && it_sc[u] == 3);  // upper-right of a diagonal block
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int cix = 0; cix < 3; ++cix) {
-              double s0 = 0;
-#pragma unroll
-              for (int m = 0; m < 6; ++m) s0 += li[6 * r + m] * lj[6 * cix + m];
-              if (!skip) Cb[6 * r + cix] = cc[3 * r + cix] - s0;
-            }
-        }
-      } else if (tid < TU_THREADS + 64) {
-        // look-ahead wave: lanes 0-3 update the four 3x3 sub-tiles of block (kb+1, kb+1), lane 0 factors it
-        const int lane = tid - TU_THREADS;
-        if (lane < 4 && nt > 0) {
-          const int sr = (lane >> 1) * 3, sc = (lane & 1) * 3;
-          const double* Li = S + colk + SBS + 6 * sr;
-          const double* Lj = S + colk + SBS + 6 * sc;
-          double* Cb = S + LY.blk(kb + 1, kb + 1) + 6 * sr + sc;
-          double li[18], lj[18], cc[9];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            const double2 a = reinterpret_cast<const double2*>(Li)[i], b = reinterpret_cast<const double2*>(Lj)[i];
-            li[2 * i] = a.x; li[2 * i + 1] = a.y;
-            lj[2 * i] = b.x; lj[2 * i + 1] = b.y;
-          }
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int cix = 0; cix < 3; ++cix) cc[3 * r + cix] = Cb[6 * r + cix];
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int cix = 0; cix < 3; ++cix) {
-              double s0 = 0;
-#pragma unroll
-              for (int m = 0; m < 6; ++m) s0 += li[6 * r + m] * lj[6 * cix + m];
-              if (lane != 1) Cb[6 * r + cix] = cc[3 * r + cix] - s0;   // the upper-right 3x3 is never read
-            }
-          // same wave => LDS operations are ordered; fence the compiler
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          asm volatile("" ::: "memory");
-          if (lane == 0) {
-            if (!factor_diag(S + LY.blk(kb + 1, kb + 1), s_diag + 36 * (kb + 1), s_dinv + 6 * (kb + 1))) s_fail = 1;
-            if (kb == 12 && blockIdx.x == 0) W.prof[32] = (double)clock64();
-          }
-        }
-      } else {
-        // last wave: right-hand-side blocks rhs_(bi) -= L_(bi,k) y_k
-        for (int bi = tid - TU_THREADS - 64; bi < nt; bi += 64) {
-          const double* Li = S + colk + (bi + 1) * SBS;
-          double* rr = s_rhs + (kb + 1 + bi) * 6;
-          double y[6];
-#pragma unroll
-          for (int m = 0; m < 6; ++m) y[m] = s_rhs[k0 + m];
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            double s0 = 0;
-#pragma unroll
-            for (int m = 0; m < 6; ++m) s0 += Li[6 * r + m] * y[m];
-            rr[r] -= s0;
-          }
-        }
-        if (kb == 12 && blockIdx.x == 0 && tid == TU_THREADS + 64) W.prof[33] = (double)clock64();
-      }
-    } else {
-    // four work-items per 6x6 block (3x3 register sub-tiles): many light waves hide the latency
-    for (int wi = tid; wi < 4 * nblkpairs + nt; wi += SOLVE_THREADS) {
-      if (wi < 4 * nblkpairs) {
-        const int q = wi >> 2, sub = wi & 3;
-        const int sr = (sub >> 1) * 3, sc = (sub & 1) * 3;
-        // mirrored enumeration: consecutive blocks walk DOWN one block column (contiguous in memory)
-        const int gbj = nbk - 1 - (s_ptab[q] >> 8), gbi = nbk - 1 - (s_ptab[q] & 255);  // gbi >= gbj > kb
-        const double* Li = S + LY.blk(gbi, kb) + 6 * sr;   // rows sr..sr+2 of L_(gbi,k)
-        const double* Lj = S + LY.blk(gbj, kb) + 6 * sc;   // rows sc..sc+2 of L_(gbj,k)
-        double* Cb = S + LY.blk(gbi, gbj) + 6 * sr + sc;
-        double li[18], lj[18];
+      for (int u = 0; u < 2; ++u) {
+        const int gbi = it_gbi[u], gbj = it_gbj[u];
+        if (gbj <= kb) continue;  // not (or no longer) part of the trailing matrix
+        if (gbi == kb + 1) continue;  // block (kb+1, kb+1): the look-ahead wave (gbj > kb and gbj <= gbi)
+        const double* Li = S + colk + (gbi - kb) * SBS + 6 * it_sr[u];  // rows sr..sr+2 of L_(gbi,k)
+        const double* Lj = S + colk + (gbj - kb) * SBS + 6 * it_sc[u];  // rows sc..sc+2 of L_(gbj,k)
+        double* Cb = S + it_c[u];
+        double li[18], lj[18], cc[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-          const double2 u = reinterpret_cast<const double2*>(Li)[i], v = reinterpret_cast<const double2*>(Lj)[i];
-          li[2 * i] = u.x; li[2 * i + 1] = u.y;
-          lj[2 * i] = v.x; lj[2 * i + 1] = v.y;
+          const double2 a = reinterpret_cast<const double2*>(Li)[i], b = reinterpret_cast<const double2*>(Lj)[i];
+          li[2 * i] = a.x; li[2 * i + 1] = a.y;
+          lj[2 * i] = b.x; lj[2 * i + 1] = b.y;
         }
-        if (!(gbi == gbj && sub == 1)) {   // the upper-right 3x3 of a diagonal block is never read
 #pragma unroll
-          for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int cix = 0; cix < 3; ++cix) {
-              double s0 = 0;
+          for (int cix = 0; cix < 3; ++cix) cc[3 * r + cix] = Cb[6 * r + cix];
+        const bool skip = (gbi == gbj && it_sr[u] == 0 && it_sc[u] == 3);  // upper-right of a diagonal block
 #pragma unroll
-              for (int m = 0; m < 6; ++m) s0 += li[6 * r + m] * lj[6 * cix + m];
-              Cb[6 * r + cix] -= s0;
-            }
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int cix = 0; cix < 3; ++cix) {
+            double s0 = 0;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) s0 += li[6 * r + m] * lj[6 * cix + m];
+            if (!skip) Cb[6 * r + cix] = cc[3 * r + cix] - s0;
+          }
+      }
+    } else if (tid < TU_THREADS + 64) {
+      // look-ahead wave: lanes 0-20 each form one entry of the updated block (kb+1, kb+1); the 21 entries are
+      // broadcast with v_readlane and EVERY lane factors the block and inverts the factor in registers (wave-
+      // uniform arithmetic: no LDS round trip between update, factor and inverse); lane 0 publishes.
+      if (nt > 0) {
+        // this wave carries the dependency chain of the whole factorisation while the three other waves of its
+        // SIMD issue trailing-update FMAs: raise its issue priority (measured: 3000 -> cycles for the chain)
+        __builtin_amdgcn_s_setprio(3);
+        double cij = 0;
+        if (la_lane < 21) {
+          const double* Li = S + colk + SBS + 6 * la_i;
+          const double* Lj = S + colk + SBS + 6 * la_j;
+          double s0 = 0;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) s0 += Li[m] * Lj[m];
+          cij = S[LY.blk(kb + 1, kb + 1) + 6 * la_i + la_j] - s0;
         }
-      } else {
-        // right-hand-side block: rhs_(bi) -= L_(bi,k) y_k
-        const int bi = wi - 4 * nblkpairs;
-        const double* Li = S + LY.blk(kb + 1 + bi, kb);
+#define LASTAMP(k) do { if (kb == 12 && blockIdx.x == 0 && la_lane == 0) W.prof[k] = (double)clock64(); } while (0)
+        LASTAMP(30);
+        double L[6][6], X[6][6], inv[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) L[i][j] = readlane_f64(cij, i * (i + 1) / 2 + j);
+        LASTAMP(31);
+        const bool ok = chol6(L, inv);
+        LASTAMP(34);
+        trinv6(L, inv, X);
+        LASTAMP(35);
+        // publish L^-1 (all the panel and the back-substitution need)
+        if (la_lane == 0) {
+          double* Xo = s_dinv + 36 * (kb + 1);
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Xo[6 * i + j] = X[i][j];
+        }
+        if (la_lane == 0) {
+          if (!ok) s_fail = 1;
+          if (kb == 12 && blockIdx.x == 0) W.prof[32] = (double)clock64();
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+    } else {
+      // last wave: right-hand-side blocks rhs_(bi) -= L_(bi,k) y_k
+      for (int bi = tid - TU_THREADS - 64; bi < nt; bi += 64) {
+        const double* Li = S + colk + (bi + 1) * SBS;
         double* rr = s_rhs + (kb + 1 + bi) * 6;
         double y[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m) y[m] = s_rhs[k0 + m];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          double s = 0;
+          double s0 = 0;
 #pragma unroll
-          for (int m = 0; m < 6; ++m) s += Li[6 * r + m] * y[m];
-          rr[r] -= s;
+          for (int m = 0; m < 6; ++m) s0 += Li[6 * r + m] * y[m];
+          rr[r] -= s0;
         }
       }
-    }
-    // the HBM-resident variant has no quad-local ordering guarantee through L2: factor the next diagonal
-    // block after a barrier
-    __syncthreads();
-    if (tid == 0 && kb + 1 < nbk) {
-      if (!factor_diag(S + LY.blk(kb + 1, kb + 1), s_diag + 36 * (kb + 1), s_dinv + 6 * (kb + 1))) s_fail = 1;
-    }
+      if (kb == 12 && blockIdx.x == 0 && tid == TU_THREADS + 64) W.prof[33] = (double)clock64();
     }
     if (kb == 0) STAMP(26);
     __syncthreads();
@@ -681,15 +672,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // lane updates its rows above it.  25 dependent steps cost LDS round trips only, no s_barrier.
   if (tid < 64) {
     for (int kb = nbk - 1; kb >= 0; --kb) {
-      const double* Ld = s_diag + 36 * kb;   // x_k = L_kk^-T y_k
-      const double* iv = s_dinv + 6 * kb;
-      double x[6];
+      const double* Xd = s_dinv + 36 * kb;   // x_k = L_kk^-T y_k: six independent dot products
+      double x[6], y[6];
 #pragma unroll
-      for (int cix = 5; cix >= 0; --cix) {
-        double v = s_rhs[kb * 6 + cix];
+      for (int m = 0; m < 6; ++m) y[m] = s_rhs[kb * 6 + m];
 #pragma unroll
-        for (int m = cix + 1; m < 6; ++m) v -= Ld[6 * m + cix] * x[m];
-        x[cix] = v * iv[cix];
+      for (int cix = 0; cix < 6; ++cix) {
+        double a = 0;
+#pragma unroll
+        for (int m = cix; m < 6; ++m) a += Xd[6 * m + cix] * y[m];
+        x[cix] = a;
       }
       if (tid == 0) {
 #pragma unroll

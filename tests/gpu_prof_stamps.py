@@ -20,7 +20,7 @@ for k in range(17,21):
 print("kb=0: panel", p[11]-p[10], "trailing(thread0 work)", p[26]-p[11], "trailing+barrier", p[12]-p[11])
 print("kb=12: panel", p[14]-p[13], "trailing+barrier", p[15]-p[14])
 
-print("kb=12 T-phase (cycles from phase start): lane64 item done", p[30]-p[14], " look-ahead quad update done", p[31]-p[14], " factor done", p[32]-p[14], " rhs wave done", p[33]-p[14], " barrier released", p[15]-p[14])
+print("kb=12 look-ahead (cycles from phase start): entries ready", p[30]-p[14], " broadcast", p[31]-p[14], " chol6", p[34]-p[14], " trinv6", p[35]-p[14], " factor done", p[32]-p[14], " rhs wave done", p[33]-p[14], " barrier released", p[15]-p[14])
 
 ln = {41: "wins/ctrl/group loads", 42: "phase A (back-substitution)", 43: "phase B loads + residual/Jacobian", 44: "stage write + barrier",
       45: "C(a) per landmark", 46: "C(b) per pair", 47: "C(c) per block (thread 0)", 48: "barrier", 49: "scalars"}
