@@ -284,7 +284,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   // ---- chunks (Schur workgroups) ----
   std::vector<Chunk> chunks;
   {
-    const int per = opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : 48;
+    const int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : 48, SCHUR_CHUNK_LM_MAX);
     int g = 0;
     while (g < ngroup) {
       Chunk C;
@@ -450,6 +450,16 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(chunk_diag_out, put(A, chunk_diag_out));
   OFF(chunk_cross_begin, put(A, chunk_cross_begin));
   OFF(chunk_cross, put(A, chunk_cross));
+  {
+    // pose block q = bi (bi + 1) / 2 + bj of the Schur partials -> offset in the solve kernel's LDS layout
+    // (SLayout, ba_solve.hpp: block-column major, block stride SBS)
+    const int nbk = (D + 5) / 6;
+    std::vector<int> sp_blk_off;
+    for (int bi = 0; bi < npose_blk_c; ++bi)
+      for (int bj = 0; bj <= bi; ++bj) sp_blk_off.push_back((bj * nbk - (bj * (bj - 1)) / 2 + (bi - bj)) * SBS);
+    if (sp_blk_off.empty()) sp_blk_off.push_back(0);
+    OFF(sp_blk_off, put(A, sp_blk_off));
+  }
   OFF(imu_order, put(A, imu_order));
   OFF(imu_color_begin, put(A, imu_color_begin));
   OFF(imu_coloff, put(A, imu_coloff));
@@ -491,7 +501,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(step, put_zero(A, 8 * (size_t)D));
   OFF(grad, put_zero(A, 8 * (size_t)D));
   OFF(quality, put_zero(A, 8 * (size_t)nlm));
-  OFF(prof, put_zero(A, 8 * 64));
+  if (opt.debug_arrays) OFF(prof, put_zero(A, 8 * 64));   // clock64() phase stamps: diagnostics only
   OFF(ctrl, put_zero(A, sizeof(Ctrl)));
   OFF(imu_pose0, put(A, vec(w.imu_pose0, (size_t)w.n_imu)));
   OFF(imu_sb0, put(A, vec(w.imu_sb0, (size_t)w.n_imu)));
@@ -581,6 +591,7 @@ void relocate(WinPtrs& P, unsigned char* base, bool debug) {
     P.S = nullptr;
     P.rhs = nullptr;
     P.Dp2 = nullptr;
+    P.prof = nullptr;
   }
   P.Hpp = nullptr;
   if (P.D <= MAX_D_LDS) {
@@ -1163,7 +1174,7 @@ static int locate(okvis_ba_solver* s, int w, int which, const double** ptr, int6
     case OKVIS_BA_ARR_LM_QUALITY: *ptr = P.quality; *n = H.n_lm; return 0;
     case OKVIS_BA_ARR_GRADIENT: *ptr = P.grad; *n = H.D; return 0;
     case OKVIS_BA_ARR_DAMPING: *ptr = P.Dp2; *n = H.D; return P.Dp2 ? 0 : OKVIS_BA_ERR_STATE;
-    case 99: *ptr = P.prof; *n = 64; return 0;
+    case 99: *ptr = P.prof; *n = 64; return P.prof ? 0 : OKVIS_BA_ERR_STATE;
     case 98: *ptr = nullptr; *n = H.n_imu; return 0;  // diagnostics: re-preintegration count per IMU factor
     case OKVIS_BA_ARR_IMU_SB_REF: *ptr = nullptr; *n = 9 * (int64_t)H.n_imu; return 0;
     case OKVIS_BA_ARR_IMU_RESIDUAL: *ptr = nullptr; *n = 15 * (int64_t)H.n_imu; return 0;

@@ -38,8 +38,30 @@ __device__ __forceinline__ T quad_sum(T v) {
   return v;
 }
 
+// Whole-wave reductions on the VALU: two quad permutes, row_half_mirror (0x141) and row_mirror (0x140) leave every
+// lane with the total of its row of 16, four v_readlane combine the rows.  ALL 64 LANES MUST BE ACTIVE.  Every lane
+// obtains the same bits; ~25 instructions instead of six ds_bpermute round trips (the butterfly of wave_sum).
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum_full(double v) {
+  v += quad_xchg<0xB1>(v);
+  v += quad_xchg<0x4E>(v);
+  v += quad_xchg<0x141>(v);
+  v += quad_xchg<0x140>(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max_full(double v) {
+  v = fmax(v, quad_xchg<0xB1>(v));
+  v = fmax(v, quad_xchg<0x4E>(v));
+  v = fmax(v, quad_xchg<0x141>(v));
+  v = fmax(v, quad_xchg<0x140>(v));
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
 // Sums of the per-group / per-factor partials of linearisation buffer `buf`, computed by ONE full wave
-// in a fixed order (lane-strided accumulation + xor butterfly) so that the Schur kernel and the solve
+// in a fixed order (lane-strided accumulation + wave_sum_full) so that the Schur kernel and the solve
 // kernel obtain bit-identical values.  out: cost, g.delta (landmarks), delta^T D^2 delta, |delta|^2,
 // |x|^2, max|g_l|.
 __device__ __forceinline__ void wave_trial_sums(const WinPtrs& W, int buf, int lane, double out[6]) {
@@ -56,12 +78,12 @@ __device__ __forceinline__ void wave_trial_sums(const WinPtrs& W, int buf, int l
   }
   for (int f = lane; f < W.n_imu; f += 64) cost += W.imu_lin[buf][(size_t)f * IMU_LIN_STRIDE + IMU_COST];
   if (lane == 0) cost += W.small_cost[buf][0];
-  out[0] = wave_sum(cost);
-  out[1] = wave_sum(gd);
-  out[2] = wave_sum(ddd);
-  out[3] = wave_sum(s2);
-  out[4] = wave_sum(x2);
-  out[5] = wave_max(gm);
+  out[0] = wave_sum_full(cost);
+  out[1] = wave_sum_full(gd);
+  out[2] = wave_sum_full(ddd);
+  out[3] = wave_sum_full(s2);
+  out[4] = wave_sum_full(x2);
+  out[5] = wave_max_full(gm);
 }
 
 struct Decision {

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   }
   const int g = blockIdx.x - n_small;
   if (g >= W.n_group) return;
-#define LSTAMP(k) do { if (threadIdx.x == 0 && g == 0) W.prof[k] = (double)clock64(); } while (0)
+#define LSTAMP(k) do { if (W.prof && threadIdx.x == 0 && g == 0) W.prof[k] = (double)clock64(); } while (0)
   LSTAMP(40);
   const Ctrl* ctrl = W.ctrl;
   if (ctrl->done) return;
@@ -432,12 +432,12 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
       cost = s_lmres[16 * tid + 15];
       gm = fmax(fabs(s_lmres[16 * tid + 6]), fmax(fabs(s_lmres[16 * tid + 7]), fabs(s_lmres[16 * tid + 8])));
     }
-    cost = wave_sum(cost);
-    gm = wave_max(gm);
-    sc_gd = wave_sum(sc_gd);
-    sc_ddd = wave_sum(sc_ddd);
-    sc_s2 = wave_sum(sc_s2);
-    sc_x2 = wave_sum(sc_x2);
+    cost = wave_sum_full(cost);
+    gm = wave_max_full(gm);
+    sc_gd = wave_sum_full(sc_gd);
+    sc_ddd = wave_sum_full(sc_ddd);
+    sc_s2 = wave_sum_full(sc_s2);
+    sc_x2 = wave_sum_full(sc_x2);
     if (tid == 0) {
       double* gs = W.gscal[trial] + (size_t)g * GS_COUNT;
       gs[GS_COST] = cost;

@@ -35,16 +35,30 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
 
   // dynamic LDS: [SCHUR_LM_BATCH][tile_rows][3] for Y and W, tile_rows = min(96, Dp) of the batch
   extern __shared__ __attribute__((aligned(16))) double sch_smem[];
-  __shared__ double s_vinv[SCHUR_LM_BATCH][6];
-  __shared__ double s_b[SCHUR_LM_BATCH][3];
+  __shared__ double s_vinv[SCHUR_CHUNK_LM_MAX][6];   // (V_l + lambda D_l^2)^-1 of every landmark of the chunk
+  __shared__ double s_b[SCHUR_CHUNK_LM_MAX][3];
+  __shared__ int s_boff[SCHUR_THREADS];               // output offset of block pair pi
   __shared__ int s_dec[2];
   __shared__ double s_lambda;
 
   const int tid = threadIdx.x;
+#define SSTAMP(k) do { if (W.prof && tid == 0 && bx == 0 && blockIdx.y == 0) W.prof[k] = (double)clock64(); } while (0)
+  SSTAMP(16);
   const OptD opt = *optp;
   const int trows = tile_rows;
   double* s_Y = sch_smem;
   double* s_W = sch_smem + (size_t)SCHUR_LM_BATCH * trows * 3;
+  // static structure of this workgroup's chunk: requested before the decision (scalar loads, three dependent
+  // round trips that overlap with wave 0's reduction instead of following it)
+  const int chunk = bx / n_tp;
+  const Chunk C = W.chunks[chunk];
+  const int lm_begin = W.groups[C.group_begin].lm_begin;
+  const int lm_end = W.groups[C.group_end - 1].lm_end;
+  const int nbatch = (lm_end - lm_begin + SCHUR_LM_BATCH - 1) / SCHUR_LM_BATCH;
+  int pbeg[SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH + 1];
+#pragma unroll
+  for (int i = 0; i <= SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH; ++i)
+    pbeg[i] = (i <= nbatch) ? W.lm_pair_begin[min(lm_begin + i * SCHUR_LM_BATCH, lm_end)] : 0;
   // ---- decision (wave 0) ----
   if (tid < 64) {
     int acc = ctrl->acc, term = 0;
@@ -65,12 +79,12 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
     }
   }
   __syncthreads();
+  SSTAMP(17);
   if (s_dec[1]) return;  // terminated by the decision; the solve kernel records it
   const int acc = s_dec[0];
   const double lambda = s_lambda;
 
-  // ---- which chunk / tile pair ----
-  const int chunk = bx / n_tp;
+  // ---- which tile pair ----
   int tp = bx - chunk * n_tp;
   int ti = 0;
   while (tp >= ti + 1) {  // lower-triangular enumeration: (0,0) (1,0) (1,1) (2,0) ...
@@ -107,15 +121,55 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
   for (int i = 0; i < 36; ++i) accS[i] = 0.0;
   double accR[6] = {0, 0, 0, 0, 0, 0};  // sum Y b
 
-  const Chunk C = W.chunks[chunk];
-  const int lm_begin = W.groups[C.group_begin].lm_begin;
-  const int lm_end = W.groups[C.group_end - 1].lm_end;
   const double* Vb = W.V[acc];
   const double* bb = W.bl[acc];
   const double* Wb = W.W[acc];
 
-  for (int l0 = lm_begin; l0 < lm_end; l0 += SCHUR_LM_BATCH) {
+  // (V_l + lambda D_l^2)^-1 and b_l of every landmark of the chunk: one memory round trip for the whole chunk
+  for (int i = tid; i < lm_end - lm_begin; i += SCHUR_THREADS) {
+    const int l = lm_begin + i;
+    const double* Vl = Vb + 6 * (size_t)l;
+    double v[6] = {Vl[0], Vl[1], Vl[2], Vl[3], Vl[4], Vl[5]};
+    const double b0 = bb[3 * (size_t)l], b1 = bb[3 * (size_t)l + 1], b2 = bb[3 * (size_t)l + 2];
+    double vi[6];
+    if (opt.marg_mode) {
+      pinv3sym_precond(v, vi);   // MarginalizationError::marginalizeOut landmark path (no damping)
+    } else {
+      v[0] += lambda * clampd(v[0], opt.min_lm_diag2, opt.max_lm_diag2);
+      v[3] += lambda * clampd(v[3], opt.min_lm_diag2, opt.max_lm_diag2);
+      v[5] += lambda * clampd(v[5], opt.min_lm_diag2, opt.max_lm_diag2);
+      inv3sym(v, vi);
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) s_vinv[i][e] = vi[e];
+    s_b[i][0] = b0;
+    s_b[i][1] = b1;
+    s_b[i][2] = b2;
+  }
+
+  int ib = 0;
+  for (int l0 = lm_begin; l0 < lm_end; l0 += SCHUR_LM_BATCH, ++ib) {
     const int nb = min(SCHUR_LM_BATCH, lm_end - l0);
+    const int lc0 = l0 - lm_begin;
+    // fill operands of this batch: one work-item per (landmark, block) pair; requested before the tables are
+    // zeroed so that the loads are in flight meanwhile
+    int p0 = 0, p1 = 0;
+#pragma unroll
+    for (int i = 0; i < SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH; ++i)   // static indexing keeps pbeg in registers
+      if (i == ib) {
+        p0 = pbeg[i];
+        p1 = pbeg[i + 1];
+      }
+    const int pp = p0 + tid;
+    double wp[18];
+    int f_slot = 0, f_lb = 0;
+    if (pp < p1) {
+      const double* Wp = Wb + (size_t)pp * 18;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) wp[i] = Wp[i];
+      f_slot = W.pair_off[pp] / 6;
+      f_lb = W.pair_lm[pp] - l0;
+    }
     // zero the tables (missing (landmark, block) pairs contribute nothing)
     {
       double2* zy = reinterpret_cast<double2*>(s_Y);
@@ -125,49 +179,37 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
         zw[i] = make_double2(0.0, 0.0);
       }
     }
-    if (tid < nb) {
-      const int l = l0 + tid;
-      const double* Vl = Vb + 6 * (size_t)l;
-      double v[6] = {Vl[0], Vl[1], Vl[2], Vl[3], Vl[4], Vl[5]};
-      double vi[6];
-      if (opt.marg_mode) {
-        pinv3sym_precond(v, vi);   // MarginalizationError::marginalizeOut landmark path (no damping)
-      } else {
-        v[0] += lambda * clampd(v[0], opt.min_lm_diag2, opt.max_lm_diag2);
-        v[3] += lambda * clampd(v[3], opt.min_lm_diag2, opt.max_lm_diag2);
-        v[5] += lambda * clampd(v[5], opt.min_lm_diag2, opt.max_lm_diag2);
-        inv3sym(v, vi);
-      }
-#pragma unroll
-      for (int e = 0; e < 6; ++e) s_vinv[tid][e] = vi[e];
-      s_b[tid][0] = bb[3 * (size_t)l];
-      s_b[tid][1] = bb[3 * (size_t)l + 1];
-      s_b[tid][2] = bb[3 * (size_t)l + 2];
-    }
     __syncthreads();
-    // fill: one work-item per (pair, row a)
-    const int p0 = W.lm_pair_begin[l0], p1 = W.lm_pair_begin[l0 + nb];
-    for (int wi = tid; wi < (p1 - p0) * 6; wi += SCHUR_THREADS) {
-      const int p = p0 + wi / 6, a = wi % 6;
-      const int slot = W.pair_off[p] / 6;
-      const int lb = W.pair_lm[p] - l0;
-      const double* Wp = Wb + (size_t)p * 18 + 3 * a;
-      const double w0 = Wp[0], w1 = Wp[1], w2 = Wp[2];
+    if (l0 == lm_begin) SSTAMP(18);
+    auto fill = [&](const double (&w18)[18], int slot, int lb) {
       if (slot >= row0 && slot < row0 + nrow) {
-        const double* vi = s_vinv[lb];
-        double* y = s_Y + ((size_t)lb * trows + (slot - row0) * 6 + a) * 3;
-        y[0] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
-        y[1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
-        y[2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+        const double* vi = s_vinv[lc0 + lb];
+        const double v0 = vi[0], v1 = vi[1], v2 = vi[2], v3 = vi[3], v4 = vi[4], v5 = vi[5];
+        double* y = s_Y + ((size_t)lb * trows + (slot - row0) * 6) * 3;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double w0 = w18[3 * a], w1 = w18[3 * a + 1], w2 = w18[3 * a + 2];
+          y[3 * a] = w0 * v0 + w1 * v1 + w2 * v2;
+          y[3 * a + 1] = w0 * v1 + w1 * v3 + w2 * v4;
+          y[3 * a + 2] = w0 * v2 + w1 * v4 + w2 * v5;
+        }
       }
       if (slot >= col0 && slot < col0 + ncol) {
-        double* w = s_W + ((size_t)lb * trows + (slot - col0) * 6 + a) * 3;
-        w[0] = w0;
-        w[1] = w1;
-        w[2] = w2;
+        double* w = s_W + ((size_t)lb * trows + (slot - col0) * 6) * 3;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) w[i] = w18[i];
       }
+    };
+    if (pp < p1) fill(wp, f_slot, f_lb);
+    for (int q = pp + SCHUR_THREADS; q < p1; q += SCHUR_THREADS) {   // more than 256 pairs in the batch
+      const double* Wp = Wb + (size_t)q * 18;
+      double w2[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) w2[i] = Wp[i];
+      fill(w2, W.pair_off[q] / 6, W.pair_lm[q] - l0);
     }
     __syncthreads();
+    if (l0 == lm_begin) SSTAMP(19);
     if (active) {
       for (int lb = slice; lb < nb; lb += nslice) {
         double y[18], w[18];
@@ -184,41 +226,38 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
         if (do_rhs) {
 #pragma unroll
           for (int r = 0; r < 6; ++r)
-            accR[r] += y[3 * r] * s_b[lb][0] + y[3 * r + 1] * s_b[lb][1] + y[3 * r + 2] * s_b[lb][2];
+            accR[r] += y[3 * r] * s_b[lc0 + lb][0] + y[3 * r + 1] * s_b[lc0 + lb][1] + y[3 * r + 2] * s_b[lc0 + lb][2];
         }
       }
     }
     __syncthreads();
+    if (l0 == lm_begin) SSTAMP(20);
   }
+  SSTAMP(21);
 
-  // ---- combine the landmark slices (adjacent lanes) in a fixed order ----
-  for (int o = 1; o < nslice; o <<= 1) {
-#pragma unroll
-    for (int i = 0; i < 36; ++i) accS[i] += __shfl_xor(accS[i], o, 64);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) accR[i] += __shfl_xor(accR[i], o, 64);
-  }
-  // ---- write the partial (pose part, row-major block-packed lower triangle | Y b | g | diag U) ----
-  if (active && slice == 0) {
-    const int gbi = row0 + bi, gbj = col0 + bj;  // gbi >= gbj
-    double accG[6] = {0, 0, 0, 0, 0, 0}, accD[6] = {0, 0, 0, 0, 0, 0};
+  // ---- U_pp / g_p (diagonal blocks) and pose x extrinsics cross blocks of this chunk's groups: the host-built
+  //      lists are split over the landmark slices (adjacent lanes), so that the slice reduction below sums them
+  double accG[6] = {0, 0, 0, 0, 0, 0}, accD[6] = {0, 0, 0, 0, 0, 0};
+  const int gbi = row0 + bi, gbj = col0 + bj;  // gbi >= gbj
+  if (active) {
     const double* gp = W.gpart[acc];
     if (gbi == gbj) {
-      // U_pp and g_p of this chunk's groups for pose block gbi (host-built list, fixed order)
       const int lb = W.chunk_diag_begin[chunk * nblk + gbi], le = W.chunk_diag_begin[chunk * nblk + gbi + 1];
-      for (int k = lb; k < le; ++k) {
+      for (int k = lb + slice; k < le; k += nslice) {
         const double* o = gp + W.chunk_diag_out[k];
+        double ov[27];
+#pragma unroll
+        for (int i = 0; i < 27; ++i) ov[i] = o[i];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
 #pragma unroll
-          for (int c = 0; c <= r; ++c) accS[6 * r + c] += o[c * 6 - (c * (c - 1)) / 2 + (r - c)];
-          accG[r] += o[21 + r];
-          accD[r] += o[r * 6 - (r * (r - 1)) / 2];
+          for (int c = 0; c <= r; ++c) accS[6 * r + c] += ov[c * 6 - (c * (c - 1)) / 2 + (r - c)];
+          accG[r] += ov[21 + r];
+          accD[r] += ov[r * 6 - (r * (r - 1)) / 2];
         }
       }
     } else {
-      // pose x extrinsics cross blocks J_pose^T J_ext
-      for (int k = W.chunk_cross_begin[chunk]; k < W.chunk_cross_begin[chunk + 1]; ++k) {
+      for (int k = W.chunk_cross_begin[chunk] + slice; k < W.chunk_cross_begin[chunk + 1]; k += nslice) {
         const int oa = W.chunk_cross[3 * k], ob = W.chunk_cross[3 * k + 1];
         const double* o = gp + W.chunk_cross[3 * k + 2];
         if (oa == gbi * 6 && ob == gbj * 6) {
@@ -232,10 +271,36 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
         }
       }
     }
-    double* sp = W.spart + (size_t)chunk * W.spart_stride;
-    double* blk = sp + (size_t)(gbi * (gbi + 1) / 2 + gbj) * 36;
+  }
+  SSTAMP(22);
+  // ---- combine the slices (adjacent lanes of a quad: DPP, no LDS crossbar) in a fixed order ----
+  if (nslice >= 2) {
 #pragma unroll
-    for (int i = 0; i < 36; ++i) blk[i] = accS[i];
+    for (int i = 0; i < 36; ++i) accS[i] += quad_xchg<0xB1>(accS[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      accR[i] += quad_xchg<0xB1>(accR[i]);
+      accG[i] += quad_xchg<0xB1>(accG[i]);
+      accD[i] += quad_xchg<0xB1>(accD[i]);
+    }
+  }
+  if (nslice == 4) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) accS[i] += quad_xchg<0x4E>(accS[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      accR[i] += quad_xchg<0x4E>(accR[i]);
+      accG[i] += quad_xchg<0x4E>(accG[i]);
+      accD[i] += quad_xchg<0x4E>(accD[i]);
+    }
+  }
+  // ---- write the partial (pose part, row-major block-packed lower triangle | Y b | g | diag U) ----
+  if (active && slice == 0) {
+    double* sp = W.spart + (size_t)chunk * W.spart_stride;
+    // the 6x6 blocks go out through LDS (the landmark tables are free now) so that the stores are coalesced
+    s_boff[pi] = (gbi * (gbi + 1) / 2 + gbj) * 36;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) sch_smem[pi * 36 + i] = accS[i];
     if (do_rhs) {
       double* sr = sp + (size_t)(nblk * (nblk + 1) / 2) * 36;
       const int Dp = nblk * 6;
@@ -247,6 +312,12 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
       }
     }
   }
+  __syncthreads();
+  {
+    double* sp = W.spart + (size_t)chunk * W.spart_stride;
+    for (int i = tid; i < npairs * 36; i += SCHUR_THREADS) sp[s_boff[i / 36] + (i % 36)] = sch_smem[i];
+  }
+  SSTAMP(23);
 }
 
 }  // namespace ba

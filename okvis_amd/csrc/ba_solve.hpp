@@ -131,11 +131,6 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, do
   return ok;
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
-                          __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-
 // IMU Hessian blocks, priors and the marginalisation prior of linearisation buffer `acc`, accumulated into S
 // (block layout LY), g and d2.  (The reprojection part U_pp / U_pe / g_p arrives inside the Schur partials.)
 __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, double* S, double* g, double* d2,
@@ -299,7 +294,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   __shared__ int s_coloff[64];
   __shared__ double s_red[SOLVE_THREADS / 64];
 
-#define STAMP(k) do { if (tid == 0 && blockIdx.x == 0) W.prof[k] = (double)clock64(); } while (0)
+#define STAMP(k) do { if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[k] = (double)clock64(); } while (0)
   STAMP(0);
   // ------------------------------------------------------------------ 1. decision
   if (tid < 64) {
@@ -341,6 +336,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         }
         c.pending = 0;
       }
+      if (W.prof && blockIdx.x == 0) W.prof[3] = (double)clock64();
     }
   } else {
     // meanwhile the other waves prepare what does not depend on the decision:
@@ -353,7 +349,76 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       while (bi * (bi + 1) / 2 > wi) --bi;
       s_ptab[wi] = (unsigned short)((bi << 8) | (wi - bi * (bi + 1) / 2));
     }
-    for (int i = tid - 64; i < nS; i += SOLVE_THREADS - 64) S[i] = 0.0;
+    if constexpr (LARGE) {
+      for (int i = tid - 64; i < nS; i += SOLVE_THREADS - 64) S[i] = 0.0;
+    } else {
+      // The Schur partials do not depend on this kernel's decision (the Schur kernel made the same one and
+      // reduced the buffer that is being accepted): sum them into S while wave 0 decides.  Pose blocks come
+      // first in the row-major lower-triangular enumeration, which is the partials' own layout.
+      const int npose_blk = Dp / 6;
+      const int nblocks = nbk * (nbk + 1) / 2;
+      const size_t stride = W.spart_stride;
+      const int nch = W.n_chunk;
+      const double* sp = W.spart;
+      const int nPblk = npose_blk * (npose_blk + 1) / 2;
+      // one item = one double of the partials' record (pose blocks, then  Y b | g | diag U): its sum over the
+      // chunks.  Three items per lane and eight chunks per trip are requested together — the loads come from
+      // other CUs' stores (L2 misses, ~1 us each round trip), so what counts is the number of dependent rounds.
+      const int nP = nPblk * 36, ntot = nP + 3 * Dp;
+      constexpr int NL = SOLVE_THREADS - 64;
+      for (int base = tid - 64; base < ntot; base += 3 * NL) {
+        double a[3] = {0, 0, 0};
+        int boff[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {   // LDS offsets of the items' blocks: requested together with the data
+          const int i = base + t * NL;
+          boff[t] = (i < nP) ? W.sp_blk_off[i / 36] : 0;
+        }
+        for (int ch = 0; ch < nch; ch += 8) {
+          double v[3][8];
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              v[t][u] = (ch + u < nch && base + t * NL < ntot) ? sp[(size_t)(ch + u) * stride + base + t * NL] : 0.0;
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[t] += v[t][u];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int i = base + t * NL;
+          if (i < nP) {
+            const int q = i / 36, e = i - 36 * q;
+            S[boff[t] + e] = a[t];
+          } else if (i < ntot) {
+            const int which = (i - nP) / Dp, j = (i - nP) - which * Dp;
+            (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = a[t];
+          }
+        }
+      }
+      for (int i = tid - 64; i < 3 * (Dpad - Dp); i += NL) {   // speed/bias part of the vectors starts from zero
+        const int which = i / (Dpad - Dp), j = Dp + i - which * (Dpad - Dp);
+        (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = 0.0;
+      }
+      // the other blocks (speed/bias rows; filled by assemble_base) start from zero: one wave per block
+      {
+        // (bi, bj) of block q advance incrementally with wave-uniform (scalar) arithmetic
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6) - 1;
+        int bi = npose_blk, bj = wv;
+        for (int q = nPblk + wv; q < nblocks; q += SOLVE_THREADS / 64 - 1) {
+          while (bj > bi) {
+            bj -= bi + 1;
+            ++bi;
+          }
+          if ((tid & 63) < 36) S[LY.blk(bi, bj) + (tid & 63)] = 0.0;
+          bj += SOLVE_THREADS / 64 - 1;
+        }
+      }
+      for (int i = tid - 64; i < Dpad; i += SOLVE_THREADS - 64) s_x[i] = 0.0;
+    }
+    if (W.prof && tid == 64 && blockIdx.x == 0) W.prof[4] = (double)clock64();
   }
   __syncthreads();
   if (c.done) {
@@ -364,27 +429,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
 
   STAMP(1);
   // ------------------------------------------------------------------ 2. assembly
-  {
-    // pose part: the Schur partials already use this block layout (pose blocks come first)
+  if constexpr (LARGE) {
+    // pose part of the matrix: summed by large_export_kernel; vectors here
     const int npose_blk = Dp / 6;
     const int nP = npose_blk * (npose_blk + 1) / 2 * 36;
     const size_t stride = W.spart_stride;
     const int nch = W.n_chunk;
     const double* sp = W.spart;
-    for (int i = tid; i < (LARGE ? 0 : nP); i += SOLVE_THREADS) {  // LARGE: summed by large_export_kernel
-      double s = 0;
-      for (int ch = 0; ch < nch; ch += 8) {  // 8 independent loads in flight
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride + i] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-      }
-      const int q = i / 36, e = i - 36 * q;
-      S[LY.blk(s_ptab[q] >> 8, s_ptab[q] & 255) + e] = s;
-    }
     for (int i = tid; i < 3 * Dpad; i += SOLVE_THREADS) {
-      // vectors of the pose part: Y b -> rhs, g, diag U
       const int which = i / Dpad, j = i - which * Dpad;
       double a = 0;
       if (j < Dp) {
@@ -409,7 +461,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   {
     double m = 0;
     for (int i = tid; i < D; i += SOLVE_THREADS) m = fmax(m, fabs(s_g[i]));
-    m = wave_max(m);
+    m = wave_max_full(m);
     if ((tid & 63) == 0) s_red[tid >> 6] = m;
     __syncthreads();
     if (tid == 0) {
@@ -605,7 +657,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           for (int m = 0; m < 6; ++m) s0 += Li[m] * Lj[m];
           cij = S[LY.blk(kb + 1, kb + 1) + 6 * la_i + la_j] - s0;
         }
-#define LASTAMP(k) do { if (kb == 12 && blockIdx.x == 0 && la_lane == 0) W.prof[k] = (double)clock64(); } while (0)
+#define LASTAMP(k) do { if (W.prof && kb == 12 && blockIdx.x == 0 && la_lane == 0) W.prof[k] = (double)clock64(); } while (0)
         LASTAMP(30);
         double L[6][6], X[6][6], inv[6];
 #pragma unroll
@@ -627,7 +679,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         }
         if (la_lane == 0) {
           if (!ok) s_fail = 1;
-          if (kb == 12 && blockIdx.x == 0) W.prof[32] = (double)clock64();
+          if (W.prof && kb == 12 && blockIdx.x == 0) W.prof[32] = (double)clock64();
         }
         __builtin_amdgcn_s_setprio(0);
       }
@@ -647,7 +699,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           rr[r] -= s0;
         }
       }
-      if (kb == 12 && blockIdx.x == 0 && tid == TU_THREADS + 64) W.prof[33] = (double)clock64();
+      if (W.prof && kb == 12 && blockIdx.x == 0 && tid == TU_THREADS + 64) W.prof[33] = (double)clock64();
     }
     if (kb == 0) STAMP(26);
     __syncthreads();
@@ -740,10 +792,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       }
     }
     __shared__ double s_sc[4][SOLVE_THREADS / 64];
-    gd = wave_sum(gd);
-    ddd = wave_sum(ddd);
-    s2 = wave_sum(s2);
-    x2 = wave_sum(x2);
+    gd = wave_sum_full(gd);
+    ddd = wave_sum_full(ddd);
+    s2 = wave_sum_full(s2);
+    x2 = wave_sum_full(x2);
     if ((tid & 63) == 0) {
       s_sc[0][tid >> 6] = gd;
       s_sc[1][tid >> 6] = ddd;

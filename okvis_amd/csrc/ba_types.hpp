@@ -15,6 +15,7 @@ constexpr int LIN_THREADS = 256;
 constexpr int SCHUR_THREADS = 256;
 constexpr int SCHUR_TILE_BLOCKS = 16;  // 16 x 16 blocks of 6x6 = 96 x 96 tile, one 6x6 block per thread
 constexpr int SCHUR_LM_BATCH = 16;     // landmarks staged per LDS pass in the Schur kernel
+constexpr int SCHUR_CHUNK_LM_MAX = 128;  // landmarks of one Schur workgroup (chunk); a group has at most GROUP_LM
 constexpr int SOLVE_THREADS = 1024;
 constexpr int MAX_D_LDS = 174;         // reduced systems up to this size are factorised in LDS (block-packed)
 constexpr int MAX_D = 900;             // larger ones (up to this) keep the block matrix in HBM/L2 (slower path)
@@ -148,6 +149,7 @@ struct WinPtrs {
   const int* chunk_diag_begin;   // [n_chunk * (Dp/6) + 1] into chunk_diag_out
   const int* chunk_diag_out;
   const int* chunk_cross_begin;  // [n_chunk + 1] into chunk_cross (triples off_a, off_b, out)
+  const int* sp_blk_off;         // [Dp/6 (Dp/6+1)/2] offset (doubles) of pose block q of the partials in the solve kernel's LDS layout
   const int* chunk_cross;
   const int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
   const int* imu_color_begin;    // [n_imu_color+1]

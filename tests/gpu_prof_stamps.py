@@ -3,20 +3,23 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
-opt = default_options(); opt.gauss_newton = 1; opt.function_tolerance = 0; opt.gradient_tolerance = 0; opt.parameter_tolerance = 0; opt.use_graph = 0
+opt = default_options(); opt.gauss_newton = 1; opt.function_tolerance = 0; opt.gradient_tolerance = 0; opt.parameter_tolerance = 0; opt.use_graph = 0; opt.debug_arrays = 1
 b = solver.WindowBatch([synthetic.config_A()], options=opt)
 b.begin(); b.iterate(12); b.synchronize()
 p = b.array("PROF")
-names = {0:"start",1:"decision",2:"spart+vec",3:"imu",4:"priors+marg",5:"conv",6:"damping",7:"cholesky",8:"backsub",9:"end"}
+names = {0:"start",1:"decision+spart",2:"-",5:"imu+priors+marg",6:"damping",7:"cholesky",8:"backsub",9:"end"}
+print("solve: wave 0 decision done at", (p[3]-p[0])/2100, "us; wave 1 shadow assembly done at", (p[4]-p[0])/2100, "us")
 print("solve phases (cycles, us@2.1GHz):")
-for k in range(1,10):
-    d = p[k]-p[k-1]; print(f"  {names[k]:12s} {d:10.0f} cyc  {d/2100:8.2f} us")
+prev = 0
+for k in (1, 2, 5, 6, 7, 8, 9):
+    d = p[k]-p[prev]; prev = k; print(f"  {names[k]:16s} {d:10.0f} cyc  {d/2100:8.2f} us")
 print("  total", p[9]-p[0], (p[9]-p[0])/2100)
-sn = {17:"decision",18:"landmark loop",19:"tasks",20:"write"}
-print("schur phases:")
-for k in range(17,21):
-    d = p[k]-p[k-1]; print(f"  {sn[k]:14s} {d:10.0f} cyc {d/2100:8.2f} us")
-
+sn = {17: "decision", 18: "batch 0: zero tables + V^-1", 19: "batch 0: fill Y / W tables", 20: "batch 0: block products",
+      21: "remaining batches", 22: "U_pp / cross lists", 23: "slice reduction + write"}
+print("schur phases (workgroup 0, thread 0):")
+for k in range(17, 24):
+    d = p[k]-p[k-1]; print(f"  {sn[k]:30s} {d:10.0f} cyc {d/2100:8.2f} us")
+print("  total", (p[23]-p[16])/2100, "us")
 print("kb=0: panel", p[11]-p[10], "trailing(thread0 work)", p[26]-p[11], "trailing+barrier", p[12]-p[11])
 print("kb=12: panel", p[14]-p[13], "trailing+barrier", p[15]-p[14])
 
