@@ -463,6 +463,33 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(imu_order, put(A, imu_order));
   OFF(imu_color_begin, put(A, imu_color_begin));
   OFF(imu_coloff, put(A, imu_coloff));
+  {
+    // destination of every entry of the IMU factors' H (30x30 lower, packed) | g records in the solve kernel's
+    // LDS layout (SLayout, ba_solve.hpp), so that the kernel can prefetch value + destination in one round trip
+    std::vector<int4> imu_asm;
+    if (D <= MAX_D_LDS) {
+      const int nbk = (D + 5) / 6;
+      auto at = [&](int i, int j) {
+        const int bi = i / 6, bj = j / 6;
+        return (bj * nbk - (bj * (bj - 1)) / 2 + (bi - bj)) * SBS + (i - 6 * bi) * 6 + (j - 6 * bj);
+      };
+      imu_asm.assign(512 * (size_t)w.n_imu, make_int4(-1, -1, 0, 0));
+      for (int f = 0; f < w.n_imu; ++f) {
+        const int* co = imu_coloff.data() + 30 * (size_t)f;
+        int e = 0;
+        for (int a = 0; a < 30; ++a)
+          for (int b = 0; b <= a; ++b, ++e) {
+            const int ra = co[a], rb = co[b];
+            if (ra < 0 || rb < 0) continue;
+            imu_asm[512 * (size_t)f + e] = make_int4((ra >= rb ? at(ra, rb) : at(rb, ra)) | (imu_color[f] << 24), a == b ? ra : -1, 0, 0);
+          }
+        for (int a = 0; a < 30; ++a)
+          if (co[a] >= 0) imu_asm[512 * (size_t)f + 465 + a] = make_int4(co[a] | (1 << 20) | (imu_color[f] << 24), -1, 0, 0);
+      }
+    }
+    if (imu_asm.empty()) imu_asm.push_back(make_int4(-1, -1, 0, 0));
+    OFF(imu_asm, put(A, imu_asm));
+  }
   for (int b = 0; b < 2; ++b) {
     OFF(V[b], put_zero(A, 48 * (size_t)nlm));
     OFF(bl[b], put_zero(A, 24 * (size_t)nlm));

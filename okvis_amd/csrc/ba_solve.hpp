@@ -131,12 +131,17 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, do
   return ok;
 }
 
+constexpr int PRI_STAGE = 2;  // pose / speed-bias priors whose records the solve kernel stages in LDS ahead of time
+
 // IMU Hessian blocks, priors and the marginalisation prior of linearisation buffer `acc`, accumulated into S
 // (block layout LY), g and d2.  (The reprojection part U_pp / U_pe / g_p arrives inside the Schur partials.)
 __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, double* S, double* g, double* d2,
-                              int* coloff, const unsigned short* ptab, int tid, int nthreads) {
+                              int* coloff, const unsigned short* ptab, int tid, int nthreads, bool skip_imu,
+                              const double* pri = nullptr, const int* pricol = nullptr, int n_pri = 0) {
+  // pri / pricol: LDS copies of the first n_pri (<= PRI_STAGE) pose priors [f][42], speed/bias priors r [f][9] and
+  // sqrtInfo [f][81] of buffer `acc` and their reduced column offsets [f][6] | [f][9], staged by the caller
   // ---- IMU factors: precomputed H (30x30 lower) | g (30); factors of one colour touch disjoint blocks ----
-  for (int col = 0; col < W.n_imu_color; ++col) {
+  for (int col = 0; col < (skip_imu ? 0 : W.n_imu_color); ++col) {
     const int fb = W.imu_color_begin[col], fe = W.imu_color_begin[col + 1];
     for (int wi = tid; wi < (fe - fb) * 512; wi += nthreads) {
       const int f = W.imu_order[fb + (wi >> 9)], e = wi & 511;
@@ -159,6 +164,12 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, doubl
   }
   // ---- pose priors: J 6x6 | r 6 ----
   for (int f = 0; f < W.n_pprior; ++f) {
+    if (f < n_pri) {
+      const double* L = pri + 42 * f;
+      add_small_factor(S, LY, g, d2, L, L + 36, 6, 6, pricol + 6 * f, tid, nthreads);
+      __syncthreads();
+      continue;
+    }
     if (tid < 6) {
       const int off = W.pose_off[W.pprior_pose[f]];
       coloff[tid] = off < 0 ? -1 : off + tid;
@@ -170,27 +181,31 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, doubl
   }
   // ---- speed/bias priors: J = -sqrtInfo (9x9 const) | r 9 ----
   for (int f = 0; f < W.n_sbprior; ++f) {
-    if (tid < 9) {
-      const int off = W.sb_off[W.sbprior_sb[f]];
-      coloff[tid] = off < 0 ? -1 : off + tid;
+    const bool st = f < n_pri;
+    if (!st) {
+      if (tid < 9) {
+        const int off = W.sb_off[W.sbprior_sb[f]];
+        coloff[tid] = off < 0 ? -1 : off + tid;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // J^T J and J^T r are sign-invariant / sign-flipped: use +sqrtInfo with -r
-    const double* Jc = W.sbprior_sqrtinfo + (size_t)f * 81;
-    const double* r = W.sbp_lin[acc] + (size_t)f * 9;
+    const double* Jc = st ? pri + PRI_STAGE * 42 + PRI_STAGE * 9 + 81 * f : W.sbprior_sqrtinfo + (size_t)f * 81;
+    const double* r = st ? pri + PRI_STAGE * 42 + 9 * f : W.sbp_lin[acc] + (size_t)f * 9;
+    const int* co = st ? pricol + PRI_STAGE * 6 + 9 * f : coloff;
     for (int wi = tid; wi < 81; wi += nthreads) {
       const int a = wi / 9, b = wi - 9 * a;
-      const int ra = coloff[a], rb = coloff[b];
+      const int ra = co[a], rb = co[b];
       if (ra < 0 || rb < 0 || ra < rb) continue;
       double s = 0;
       for (int k = 0; k < 9; ++k) s += Jc[k * 9 + a] * Jc[k * 9 + b];
       S[LY.at(ra, rb)] += s;
       if (a == b) d2[ra] += s;
     }
-    if (tid < 9 && coloff[tid] >= 0) {
+    if (tid < 9 && co[tid] >= 0) {
       double s = 0;
       for (int k = 0; k < 9; ++k) s -= Jc[k * 9 + tid] * r[k];
-      g[coloff[tid]] += s;
+      g[co[tid]] += s;
     }
     __syncthreads();
   }
@@ -289,13 +304,60 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   double* s_dinv = s_diag + nbk * 36;  // nbk * 36: their inverses
   unsigned short* s_ptab = reinterpret_cast<unsigned short*>(s_dinv + nbk * 36);  // (bi<<8|bj) of the block-pair enumeration
   __shared__ Ctrl c;
-  __shared__ int s_accepted, s_was_first, s_fail;
+  __shared__ int s_accepted, s_was_first, s_fail, s_was_pending;
   __shared__ double s_cost_change, s_old_cost, s_lm_gmax;
   __shared__ int s_coloff[64];
   __shared__ double s_red[SOLVE_THREADS / 64];
 
 #define STAMP(k) do { if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[k] = (double)clock64(); } while (0)
   STAMP(0);
+  // IMU factor records (H | g, 495 doubles each): value and destination (host-built imu_asm) of up to IMU_NPF entries
+  // per lane are requested now, from the buffer that is accepted if the pending step is (the common case), and
+  // scattered after the decision without any further global round trip.
+  constexpr int IMU_NPF = 6, IMU_NL = SOLVE_THREADS - 64;
+  const int imu_items = W.n_imu * 512;
+  const bool imu_fast = !LARGE && imu_items <= IMU_NPF * IMU_NL;
+  double imu_v[IMU_NPF];
+  int imu_dst[IMU_NPF], imu_d2[IMU_NPF];
+  int imu_spec = 0;
+#pragma unroll
+  for (int j = 0; j < IMU_NPF; ++j) {
+    imu_v[j] = 0;
+    imu_dst[j] = -1;
+    imu_d2[j] = -1;
+  }
+  __shared__ double s_pri[PRI_STAGE * (42 + 9 + 81)];
+  __shared__ int s_pricol[PRI_STAGE * (6 + 9)];
+  const int n_pri = (!LARGE && W.n_pprior <= PRI_STAGE && W.n_sbprior <= PRI_STAGE) ? PRI_STAGE : 0;
+  if (n_pri && tid >= 64) {   // prior records of the speculated buffer and their column offsets -> LDS
+    const int spec = gctrl->pending ? 1 - gctrl->acc : gctrl->acc;
+    const int t = tid - 64;
+    if (t < W.n_pprior * 42) s_pri[t] = W.pp_lin[spec][t];
+    if (t < W.n_sbprior * 9) s_pri[PRI_STAGE * 42 + t] = W.sbp_lin[spec][t];
+    if (t < W.n_sbprior * 81) s_pri[PRI_STAGE * 51 + t] = W.sbprior_sqrtinfo[t];
+    if (t < W.n_pprior * 6) {
+      const int off = W.pose_off[W.pprior_pose[t / 6]];
+      s_pricol[t] = off < 0 ? -1 : off + t % 6;
+    }
+    if (t < W.n_sbprior * 9) {
+      const int off = W.sb_off[W.sbprior_sb[t / 9]];
+      s_pricol[PRI_STAGE * 6 + t] = off < 0 ? -1 : off + t % 9;
+    }
+  }
+  if (imu_fast && tid >= 64) {
+    imu_spec = gctrl->pending ? 1 - gctrl->acc : gctrl->acc;
+    const double* src = W.imu_lin[imu_spec];
+#pragma unroll
+    for (int j = 0; j < IMU_NPF; ++j) {
+      const int idx = tid - 64 + j * IMU_NL;
+      if (idx < imu_items) {
+        const int4 d = W.imu_asm[idx];
+        imu_dst[j] = d.x;
+        imu_d2[j] = d.y;
+        imu_v[j] = src[idx];
+      }
+    }
+  }
   // ------------------------------------------------------------------ 1. decision
   if (tid < 64) {
     double sums[6] = {0, 0, 0, 0, 0, 0};
@@ -309,6 +371,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     if (tid == 0) {
       c = *gctrl;
       s_accepted = 0;
+      s_was_pending = pending;
       s_was_first = c.first;
       s_cost_change = 0;
       s_old_cost = c.cost;
@@ -454,7 +517,38 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   }
   __syncthreads();
   STAMP(2);
-  assemble_base(W, acc, LY, S, s_g, s_d2, s_coloff, s_ptab, tid, SOLVE_THREADS);
+  if (imu_fast) {
+    if (tid >= 64 && acc != imu_spec) {   // the step was rejected: the records of the other buffer are needed
+      const double* src = W.imu_lin[acc];
+#pragma unroll
+      for (int j = 0; j < IMU_NPF; ++j)
+        if (imu_dst[j] >= 0) imu_v[j] = src[tid - 64 + j * IMU_NL];
+    }
+    for (int col = 0; col < W.n_imu_color; ++col) {   // factors of one colour touch disjoint blocks
+#pragma unroll
+      for (int j = 0; j < IMU_NPF; ++j) {
+        const int d = imu_dst[j];
+        if (d >= 0 && (d >> 24) == col) {
+          const int off = d & 0xFFFFF;
+          if (d & (1 << 20)) {
+            s_g[off] += imu_v[j];
+          } else {
+            S[off] += imu_v[j];
+            if (imu_d2[j] >= 0) s_d2[imu_d2[j]] += imu_v[j];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (n_pri) {
+    if (s_was_pending && !s_accepted) {   // rejected step: restage the records of the buffer that stays accepted
+      if (tid < W.n_pprior * 42) s_pri[tid] = W.pp_lin[acc][tid];
+      if (tid < W.n_sbprior * 9) s_pri[PRI_STAGE * 42 + tid] = W.sbp_lin[acc][tid];
+      __syncthreads();
+    }
+  }
+  assemble_base(W, acc, LY, S, s_g, s_d2, s_coloff, s_ptab, tid, SOLVE_THREADS, imu_fast, s_pri, s_pricol, n_pri);
   __syncthreads();
   STAMP(5);
   // ------------------------------------------------------------------ 3. convergence of the accepted step

@@ -154,6 +154,8 @@ struct WinPtrs {
   const int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
   const int* imu_color_begin;    // [n_imu_color+1]
   const int* imu_coloff;         // [n_imu][30] reduced index of each local column (or -1)
+  const int4* imu_asm;           // [n_imu][512] where entry e of factor f's H|g record lands in the solve kernel's LDS
+                                 // system: x = offset | is_g << 20 | colour << 24 (or -1), y = d2 index or -1 (D <= MAX_D_LDS)
 
   // ---- linearisation (index = buffer 0/1) ----
   double* V[2];           // [n_lm][6]
