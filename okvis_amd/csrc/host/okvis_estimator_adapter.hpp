@@ -67,18 +67,7 @@ class Estimator : public VioBackendInterface {
     }
     frames_[mf->id] = multiFrame;
     pods_[mf->id] = mf;
-    okvis_amd::ImuMeasurementDeque d;
-    d.reserve(imuMeasurements.size());
-    for (const auto& m : imuMeasurements) {
-      okvis_amd::ImuMeasurement q;
-      q.t_ns = toNs(m.timeStamp);
-      for (int c = 0; c < 3; ++c) {
-        q.gyr[c] = m.measurement.gyroscopes[c];
-        q.acc[c] = m.measurement.accelerometers[c];
-      }
-      d.push_back(q);
-    }
-    return impl_.addStates(mf, d, asKeyframe);
+    return impl_.addStates(mf, toPod(imuMeasurements), asKeyframe);
   }
   bool addLandmark(uint64_t landmarkId, const Eigen::Vector4d& landmark) override {
     return impl_.addLandmark(landmarkId, {{landmark[0], landmark[1], landmark[2], landmark[3]}});
@@ -101,16 +90,11 @@ class Estimator : public VioBackendInterface {
   bool removeObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx) override {
     return impl_.removeObservation(landmarkId, poseId, camIdx, keypointIdx);
   }
-  bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, okvis::MapPointVector& removed) override {
+  bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, okvis::MapPointVector& removed) {  // Estimator.hpp:183
     okvis_amd::MapPointVector r;
     const bool ok = impl_.applyMarginalizationStrategy(numKeyframes, numImuFrames, r);
-    for (const okvis_amd::MapPoint& m : r) {  // okvis::MapPoint(id, point, quality, distance), FrameTypedefs.hpp
-      okvis::MapPoint mp(m.id, Eigen::Vector4d(m.point[0], m.point[1], m.point[2], m.point[3]), m.quality, m.distance);
-      for (const auto& ob : m.observations)
-        mp.observations.insert(std::make_pair(
-            okvis::KeypointIdentifier(ob.first.frameId, ob.first.cameraIndex, ob.first.keypointIndex), ob.second));
-      removed.push_back(mp);
-    }
+    for (const okvis_amd::MapPoint& m : r) removed.push_back(toOkvis(m));
+    releaseMarginalizedFrames();
     return ok;
   }
   void optimize(size_t numIter, size_t numThreads = 1, bool verbose = false) override {
@@ -133,20 +117,107 @@ class Estimator : public VioBackendInterface {
   }
   size_t numFrames() const override { return impl_.numFrames(); }
   size_t numLandmarks() const override { return impl_.numLandmarks(); }
-  uint64_t currentKeyframeId() const override { return impl_.currentKeyframeId(); }
-  uint64_t frameIdByAge(size_t age) const override { return impl_.frameIdByAge(age); }
+  uint64_t currentKeyframeId() const { return impl_.currentKeyframeId(); }
+  uint64_t frameIdByAge(size_t age) const { return impl_.frameIdByAge(age); }
   uint64_t currentFrameId() const override { return impl_.currentFrameId(); }
   bool isKeyframe(uint64_t frameId) const override { return impl_.isKeyframe(frameId); }
-  bool isInImuWindow(uint64_t frameId) const override { return impl_.isInImuWindow(frameId); }
+  bool isInImuWindow(uint64_t frameId) const { return impl_.isInImuWindow(frameId); }
   okvis::Time timestamp(uint64_t frameId) const override {
     const int64_t t = impl_.timestamp(frameId);
     return okvis::Time((uint32_t)(t / 1000000000LL), (uint32_t)(t % 1000000000LL));
   }
-  // ... the remaining getters/setters (getLandmark(s), setLandmark, set_T_WS, setSpeedAndBias,
-  // getCameraSensorStates, multiFrame, setKeyframe, isLandmarkAdded/Initialized) forward one-to-one.
+  static bool initPoseFromImu(const okvis::ImuMeasurementDeque& imuMeasurements, okvis::kinematics::Transformation& T_WS) {
+    okvis_amd::Transformation T;
+    const bool ok = okvis_amd::Estimator::initPoseFromImu(toPod(imuMeasurements), T);
+    if (ok) T_WS = fromPod(T);
+    return ok;
+  }
+  bool isLandmarkAdded(uint64_t landmarkId) const override { return impl_.isLandmarkAdded(landmarkId); }
+  bool isLandmarkInitialized(uint64_t landmarkId) const override { return impl_.isLandmarkInitialized(landmarkId); }
+  bool getLandmark(uint64_t landmarkId, okvis::MapPoint& mapPoint) const override {
+    okvis_amd::MapPoint m;
+    if (!impl_.getLandmark(landmarkId, m)) return false;
+    mapPoint = toOkvis(m);
+    return true;
+  }
+  size_t getLandmarks(okvis::PointMap& landmarks) const override {
+    okvis_amd::PointMap pm;
+    impl_.getLandmarks(pm);
+    landmarks.clear();
+    for (const auto& kv : pm) landmarks.insert(std::make_pair(kv.first, toOkvis(kv.second)));
+    return landmarks.size();
+  }
+  size_t getLandmarks(okvis::MapPointVector& landmarks) const {  // Estimator.hpp (not part of VioBackendInterface)
+    okvis_amd::MapPointVector v;
+    impl_.getLandmarks(v);
+    landmarks.clear();
+    for (const auto& m : v) landmarks.push_back(toOkvis(m));
+    return landmarks.size();
+  }
+  okvis::MultiFramePtr multiFrame(uint64_t frameId) const override {
+    auto it = frames_.find(frameId);
+    return it == frames_.end() ? okvis::MultiFramePtr() : it->second;   // dropped when the frame is marginalised
+  }
+  bool getCameraSensorStates(uint64_t poseId, size_t cameraIdx, okvis::kinematics::Transformation& T_SCi) const override {
+    okvis_amd::Transformation T;
+    if (!impl_.getCameraSensorStates(poseId, cameraIdx, T)) return false;
+    T_SCi = fromPod(T);
+    return true;
+  }
+  bool set_T_WS(uint64_t poseId, const okvis::kinematics::Transformation& T_WS) override {
+    return impl_.set_T_WS(poseId, toPod(T_WS));
+  }
+  bool setSpeedAndBias(uint64_t poseId, size_t imuIdx, const okvis::SpeedAndBias& sb) override {
+    okvis_amd::SpeedAndBias s;
+    for (int i = 0; i < 9; ++i) s[i] = sb[i];
+    return impl_.setSpeedAndBias(poseId, imuIdx, s);
+  }
+  bool setCameraSensorStates(uint64_t poseId, size_t cameraIdx, const okvis::kinematics::Transformation& T_SCi) override {
+    return impl_.setCameraSensorStates(poseId, cameraIdx, toPod(T_SCi));
+  }
+  bool setLandmark(uint64_t landmarkId, const Eigen::Vector4d& landmark) override {
+    return impl_.setLandmark(landmarkId, {{landmark[0], landmark[1], landmark[2], landmark[3]}});
+  }
+  void setLandmarkInitialized(uint64_t landmarkId, bool initialized) override {
+    impl_.setLandmarkInitialized(landmarkId, initialized);
+  }
+  void setKeyframe(uint64_t frameId, bool isKeyframe) override { impl_.setKeyframe(frameId, isKeyframe); }
+  void setMap(std::shared_ptr<okvis::ceres::Map>) override {}   // VioBackendInterface.hpp:329 — no Ceres graph behind this backend
+  // frames whose states were marginalised are released like Estimator.cpp:730 does (multiFramePtrMap_.erase)
+  void releaseMarginalizedFrames() {
+    for (auto it = frames_.begin(); it != frames_.end();) {
+      if (impl_.multiFrame(it->first)) {
+        ++it;
+      } else {
+        pods_.erase(it->first);
+        it = frames_.erase(it);
+      }
+    }
+  }
 
  private:
   static int64_t toNs(const okvis::Time& t) { return (int64_t)t.sec * 1000000000LL + (int64_t)t.nsec; }
+  static okvis::MapPoint toOkvis(const okvis_amd::MapPoint& m) {  // okvis::MapPoint(id, point, quality, distance), FrameTypedefs.hpp
+    okvis::MapPoint mp(m.id, Eigen::Vector4d(m.point[0], m.point[1], m.point[2], m.point[3]), m.quality, m.distance);
+    for (const auto& ob : m.observations)
+      mp.observations.insert(std::make_pair(
+          okvis::KeypointIdentifier(ob.first.frameId, ob.first.cameraIndex, ob.first.keypointIndex), ob.second));
+    return mp;
+  }
+  static okvis_amd::ImuMeasurementDeque toPod(const okvis::ImuMeasurementDeque& imuMeasurements) {
+    okvis_amd::ImuMeasurementDeque d;
+    d.reserve(imuMeasurements.size());
+    for (const auto& m : imuMeasurements) {
+      okvis_amd::ImuMeasurement q;
+      q.t_ns = toNs(m.timeStamp);
+      for (int c = 0; c < 3; ++c) {
+        q.gyr[c] = m.measurement.gyroscopes[c];
+        q.acc[c] = m.measurement.accelerometers[c];
+      }
+      d.push_back(q);
+    }
+    return d;
+  }
   static okvis_amd::Transformation toPod(const okvis::kinematics::Transformation& T) {
     okvis_amd::Transformation P;
     const Eigen::Matrix<double, 7, 1> c = T.coeffs();
