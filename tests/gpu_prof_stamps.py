@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
 opt = default_options(); opt.gauss_newton = 1; opt.function_tolerance = 0; opt.gradient_tolerance = 0; opt.parameter_tolerance = 0; opt.use_graph = 0; opt.debug_arrays = 1
-b = solver.WindowBatch([synthetic.config_A()], options=opt)
+NW = int(sys.argv[1]) if len(sys.argv) > 1 else 1   # stamps are taken by window 0; NW > 1 shows them under load
+b = solver.WindowBatch([synthetic.config_A(seed=20240923 + i) for i in range(NW)], options=opt)
 b.begin(); b.iterate(12); b.synchronize()
 p = b.array("PROF")
 names = {0:"start",1:"decision+spart",2:"-",5:"imu+priors+marg",6:"damping",7:"cholesky",8:"backsub",9:"end"}
