@@ -15,7 +15,8 @@ constexpr int LIN_THREADS = 256;
 constexpr int SCHUR_THREADS = 256;
 constexpr int SCHUR_TILE_BLOCKS = 16;  // 16 x 16 blocks of 6x6 = 96 x 96 tile, one 6x6 block per thread
 constexpr int SCHUR_LM_BATCH = 16;     // landmarks staged per LDS pass in the Schur kernel
-constexpr int SCHUR_CHUNK_LM_MAX = 128;  // landmarks of one Schur workgroup (chunk); a group has at most GROUP_LM
+constexpr int SCHUR_CHUNK_LM_MAX = 64;   // landmarks of one Schur workgroup (chunk) = GROUP_LM: a chunk is at least one group;
+                                        // more would push the kernel past 80 KB of LDS at 96-row tiles (one workgroup per CU)
 constexpr int SOLVE_THREADS = 1024;
 constexpr int MAX_D_LDS = 174;         // reduced systems up to this size are factorised in LDS (block-packed)
 constexpr int MAX_D = 900;             // larger ones (up to this) keep the block matrix in HBM/L2 (slower path)
