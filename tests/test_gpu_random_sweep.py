@@ -1,0 +1,59 @@
+"""Randomised GPU-vs-oracle sweep over window shapes (pytest -m gpu): keyframes, landmarks, visibility, extrinsics
+mode, distortion model, IMU on/off and the landmark-grouping limits vary per seed, so that ragged groups, tiny
+chunks, single-observation landmarks and odd pair/task counts all go through the kernels.  Same tolerances as
+tests/test_gpu_parity.py (final cost 1e-9 relative, identical iteration bookkeeping)."""
+import numpy as np
+import pytest
+
+from okvis_amd import solver, synthetic
+from okvis_amd.window import DIST_EQUIDISTANT, DIST_NONE, DIST_RADTAN, DIST_RADTAN8, default_options
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    K = int(rng.integers(2, 9))
+    L = int(rng.integers(3, 140))
+    vis = float(rng.uniform(0.15, 1.0))
+    ext = ["fixed", "shared", "perframe"][int(rng.integers(0, 3))]
+    model = [DIST_RADTAN, DIST_EQUIDISTANT, DIST_RADTAN8, DIST_NONE][int(rng.integers(0, 4))]
+    w = synthetic.make_window(K, L, vis, seed=2000 + seed, estimate_extrinsics=ext, cam_model=model,
+                              frame_dt=float(rng.choice([0.1, 0.25, 0.5])))
+    opt = dict(schur_lm_per_block=int(rng.choice([0, 0, 8, 24, 64])))
+    if rng.random() < 0.3:
+        opt["gauss_newton"] = 1
+        opt.update(function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    return w, opt, int(rng.integers(1, 9))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_window(oracle, seed):
+    w, opt, n = _case(seed)
+    o = default_options()
+    for k, v in opt.items():
+        setattr(o, k, v)
+    b = solver.WindowBatch([w], options=o)
+    sg = b.optimize(n)[0]
+    ow = oracle.OracleWindow(w)
+    sr = ow.optimize(n, o)
+    assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-9 * max(sr["final_cost"], 1e-12), (sg, sr)
+    assert (sg["iterations"], sg["successful_steps"], sg["termination"]) == \
+           (sr["iterations"], sr["successful_steps"], sr["termination"]), (sg, sr)
+    pg, sbg, lg = b.get_state()
+    pr, sbr, lr = ow.get_state()
+    assert np.abs(pg - pr).max() < 1e-7 and np.abs(sbg - sbr).max() < 1e-7 and np.abs(lg - lr).max() < 1e-6
+    b.close()
+
+
+def test_random_batch_of_mixed_shapes(oracle):
+    # one batch with windows of different shapes (grid sizes come from the largest; the others exit early)
+    cases = [_case(s) for s in (3, 7, 11, 19, 23)]
+    ws = [c[0] for c in cases if c[0].obs_lm.size]
+    b = solver.WindowBatch(ws)
+    sg = b.optimize(5)
+    for i, w in enumerate(ws):
+        sr = oracle.OracleWindow(w).optimize(5)
+        assert abs(sg[i]["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
+        assert sg[i]["iterations"] == sr["iterations"] and sg[i]["successful_steps"] == sr["successful_steps"]
+    b.close()
