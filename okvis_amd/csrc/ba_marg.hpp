@@ -43,8 +43,10 @@ __device__ __forceinline__ void rr_pair(int m, int r, int k, int* p, int* q) {
     a = m - 1;
     b = r;
   } else {
-    a = (r + k) % (m - 1);
-    b = (r - k + (m - 1)) % (m - 1);
+    a = r + k;   // r, k < m - 1: one conditional subtraction instead of an integer division
+    if (a >= m - 1) a -= m - 1;
+    b = r - k;
+    if (b < 0) b += m - 1;
   }
   *p = a < b ? a : b;
   *q = a < b ? b : a;
@@ -100,6 +102,60 @@ __device__ void jacobi_eig(double* X, double* Q, int n, int tid, JacobiTab& jt, 
   if (n < 2) return;
   const double thr = jt.thr;
   const int m = (n + 1) & ~1, half = m / 2;
+  // Which 2x2 block / which (pair, row) of Q a work-item updates does not depend on the round: decode the item
+  // indices ONCE (the integer square root and the division cost more instructions than the update itself, and with
+  // 16 waves per CU a round is bound by the number of instructions issued).  Two block items and two Q items per
+  // lane are kept in registers; larger matrices decode the rest on the fly.
+  const int nblk = half * (half + 1) / 2, nq = half * n;
+  int xk1[2] = {-1, -1}, xk2[2] = {0, 0}, qk[2] = {-1, -1}, qi[2] = {0, 0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int it = tid + u * MARG_THREADS;
+    if (it < nblk) {
+      int k2 = (int)((sqrtf(8.0f * it + 1.0f) - 1.0f) * 0.5f);
+      while ((k2 + 1) * (k2 + 2) / 2 <= it) ++k2;
+      while (k2 * (k2 + 1) / 2 > it) --k2;
+      xk2[u] = k2;
+      xk1[u] = it - k2 * (k2 + 1) / 2;  // k1 <= k2
+    }
+    if (it < nq) {
+      qk[u] = it / n;
+      qi[u] = it - qk[u] * n;
+    }
+  }
+  auto block_update = [&](int k1, int k2) {
+    const double c1 = jt.c[k1], s1 = jt.s[k1], c2 = jt.c[k2], s2 = jt.s[k2];
+    if (s1 == 0.0 && s2 == 0.0) return;
+    const int p1 = jt.p[k1], q1 = jt.q[k1], p2 = jt.p[k2], q2 = jt.q[k2];
+    const bool v1 = q1 >= 0, v2 = q2 >= 0;  // -1: padding index of an odd-sized matrix
+    const double bpp = X[p1 * n + p2];
+    const double bpq = v2 ? X[p1 * n + q2] : 0.0;
+    const double bqp = v1 ? X[q1 * n + p2] : 0.0;
+    const double bqq = (v1 && v2) ? X[q1 * n + q2] : 0.0;
+    const double tpp = c2 * bpp - s2 * bpq, tpq = s2 * bpp + c2 * bpq;
+    const double tqp = c2 * bqp - s2 * bqq, tqq = s2 * bqp + c2 * bqq;
+    const double npp = c1 * tpp - s1 * tqp, npq = c1 * tpq - s1 * tqq;
+    const double nqp = s1 * tpp + c1 * tqp, nqq = s1 * tpq + c1 * tqq;
+    X[p1 * n + p2] = npp;
+    if (v2) X[p1 * n + q2] = npq;
+    if (v1) X[q1 * n + p2] = nqp;
+    if (v1 && v2) X[q1 * n + q2] = nqq;
+    if (k1 != k2) {
+      X[p2 * n + p1] = npp;
+      if (v2) X[q2 * n + p1] = npq;
+      if (v1) X[p2 * n + q1] = nqp;
+      if (v1 && v2) X[q2 * n + q1] = nqq;
+    }
+  };
+  auto q_update = [&](int k, int i) {  // Q <- Q G
+    const double sk = jt.s[k];
+    if (sk == 0.0) return;
+    const double ck = jt.c[k];
+    const int p = jt.p[k], q = jt.q[k];
+    const double qip = Q[i * n + p], qiq = Q[i * n + q];
+    Q[i * n + p] = ck * qip - sk * qiq;
+    Q[i * n + q] = sk * qip + ck * qiq;
+  };
   int sweep = 0;
   for (; sweep < 60; ++sweep) {
     if (tid == 0) {
@@ -128,44 +184,19 @@ __device__ void jacobi_eig(double* X, double* Q, int n, int tid, JacobiTab& jt, 
       __syncthreads();
       if (!jt.round_rot[slot]) continue;  // nothing to rotate in this round (late sweeps): skip the update phase
       // the matrix stays symmetric: update the blocks with k2 >= k1 and write each one and its mirror image
-      for (int it = tid; it < half * (half + 1) / 2; it += MARG_THREADS) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (xk1[u] >= 0) block_update(xk1[u], xk2[u]);
+      for (int it = tid + 2 * MARG_THREADS; it < nblk; it += MARG_THREADS) {
         int k2 = (int)((sqrtf(8.0f * it + 1.0f) - 1.0f) * 0.5f);
         while ((k2 + 1) * (k2 + 2) / 2 <= it) ++k2;
         while (k2 * (k2 + 1) / 2 > it) --k2;
-        const int k1 = it - k2 * (k2 + 1) / 2;  // k1 <= k2
-        const double c1 = jt.c[k1], s1 = jt.s[k1], c2 = jt.c[k2], s2 = jt.s[k2];
-        if (s1 == 0.0 && s2 == 0.0) continue;
-        const int p1 = jt.p[k1], q1 = jt.q[k1], p2 = jt.p[k2], q2 = jt.q[k2];
-        const bool v1 = q1 >= 0, v2 = q2 >= 0;  // -1: padding index of an odd-sized matrix
-        const double bpp = X[p1 * n + p2];
-        const double bpq = v2 ? X[p1 * n + q2] : 0.0;
-        const double bqp = v1 ? X[q1 * n + p2] : 0.0;
-        const double bqq = (v1 && v2) ? X[q1 * n + q2] : 0.0;
-        const double tpp = c2 * bpp - s2 * bpq, tpq = s2 * bpp + c2 * bpq;
-        const double tqp = c2 * bqp - s2 * bqq, tqq = s2 * bqp + c2 * bqq;
-        const double npp = c1 * tpp - s1 * tqp, npq = c1 * tpq - s1 * tqq;
-        const double nqp = s1 * tpp + c1 * tqp, nqq = s1 * tpq + c1 * tqq;
-        X[p1 * n + p2] = npp;
-        if (v2) X[p1 * n + q2] = npq;
-        if (v1) X[q1 * n + p2] = nqp;
-        if (v1 && v2) X[q1 * n + q2] = nqq;
-        if (k1 != k2) {
-          X[p2 * n + p1] = npp;
-          if (v2) X[q2 * n + p1] = npq;
-          if (v1) X[p2 * n + q1] = nqp;
-          if (v1 && v2) X[q2 * n + q1] = nqq;
-        }
+        block_update(it - k2 * (k2 + 1) / 2, k2);
       }
-      for (int it = tid; it < half * n; it += MARG_THREADS) {  // Q <- Q G
-        const int k = it / n, i = it - k * n;
-        const double s = jt.s[k];
-        if (s == 0.0) continue;
-        const double c = jt.c[k];
-        const int p = jt.p[k], q = jt.q[k];
-        const double qip = Q[i * n + p], qiq = Q[i * n + q];
-        Q[i * n + p] = c * qip - s * qiq;
-        Q[i * n + q] = s * qip + c * qiq;
-      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (qk[u] >= 0) q_update(qk[u], qi[u]);
+      for (int it = tid + 2 * MARG_THREADS; it < nq; it += MARG_THREADS) q_update(it / n, it % n);
       __syncthreads();
     }
     if (!jt.rotated) break;
