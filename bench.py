@@ -74,7 +74,7 @@ def pmc_traffic(a, kernel):
                "--keyframes", str(a.keyframes), "--landmarks", str(a.landmarks), "--visibility", str(a.visibility),
                "--steps", "12", "--warmup", "4", "--no-graph"] + (["--fp32"] if a.fp32 else [])
         try:
-            subprocess.run(cmd, timeout=240, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
+            subprocess.run(cmd, timeout=120, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
