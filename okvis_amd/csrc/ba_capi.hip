@@ -635,7 +635,7 @@ size_t lin_smem(bool ext, bool f32 = false) {
 }
 size_t solve_smem(int Dpad, bool large = false) {
   const size_t nbk = Dpad / 6;
-  return ((large ? 0 : nbk * (nbk + 1) / 2 * 38) + 4 * (size_t)Dpad + 2 * nbk * 36) * sizeof(double) + ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15));
+  return ((large ? 0 : nbk * (nbk + 1) / 2 * 38) + 4 * (size_t)Dpad + nbk * 36) * sizeof(double) + ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15));
 }
 size_t small_smem() { return (size_t)std::max<int>(std::max<int>(ImuLds::TOTAL, EvalLds::TOTAL), 2 * MAX_MARG_DIM) * sizeof(double); }
 

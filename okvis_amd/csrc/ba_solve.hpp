@@ -107,19 +107,9 @@ __device__ __forceinline__ void trinv6(const double (&L)[6][6], const double (&i
   }
 }
 
-// publish L (row-major 6x6) and L^-1 (row-major 6x6, lower triangle) of a factored diagonal block
-__device__ __forceinline__ void publish_diag(const double (&L)[6][6], const double (&X)[6][6], double* Lout, double* Xout) {
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j) {
-      Lout[6 * i + j] = L[i][j];
-      Xout[6 * i + j] = X[i][j];
-    }
-}
-
-// factor the 6x6 diagonal block (lower triangle at dblk) and publish L and L^-1
-__device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, double* Xout) {
+// factor the 6x6 diagonal block (lower triangle at dblk) and publish L^-1 (row-major 6x6, lower triangle): the
+// panel and the back-substitution only ever need the inverse
+__device__ __forceinline__ bool factor_diag(const double* dblk, double* Xout) {
   double L[6][6], X[6][6], inv[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
@@ -127,7 +117,10 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Lout, do
     for (int j = 0; j <= i; ++j) L[i][j] = dblk[6 * i + j];
   const bool ok = chol6(L, inv);
   trinv6(L, inv, X);
-  publish_diag(L, X, Lout, Xout);
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) Xout[6 * i + j] = X[i][j];
   return ok;
 }
 
@@ -300,8 +293,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   double* s_g = s_rhs + Dpad; // gradient (pose / speed-bias part)
   double* s_d2 = s_g + Dpad;  // diag(U) -> clamp -> LM damping diagonal
   double* s_x = s_d2 + Dpad;  // solution
-  double* s_diag = s_x + Dpad;       // nbk * 36: factored diagonal blocks L_kk
-  double* s_dinv = s_diag + nbk * 36;  // nbk * 36: their inverses
+  double* s_dinv = s_x + Dpad;       // nbk * 36: inverses of the factored diagonal blocks, L_kk^-1
   unsigned short* s_ptab = reinterpret_cast<unsigned short*>(s_dinv + nbk * 36);  // (bi<<8|bj) of the block-pair enumeration
   __shared__ Ctrl c;
   __shared__ int s_accepted, s_was_first, s_fail, s_was_pending;
@@ -640,7 +632,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     return;
   }
   if (tid == 0) {
-    if (!factor_diag(S + LY.blk(0, 0), s_diag, s_dinv)) s_fail = 1;
+    if (!factor_diag(S + LY.blk(0, 0), s_dinv)) s_fail = 1;
   }
   // every lane owns (at most) two fixed 3x3 sub-tiles of the trailing matrix for the whole factorisation (the
   // mirrored enumeration does not depend on kb): coordinates and the C address are computed once; an item is
