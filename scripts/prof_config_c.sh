@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/prof_c
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c/trace -o p -- python $R/scripts/bench_config_c.py > $R/gpurun_out/prof_c/bench.json 2>/dev/null
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d $R/gpurun_out/prof_c/pmc -o p -- python $R/scripts/bench_config_c.py > /dev/null 2>&1
+timeout 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d $R/gpurun_out/prof_c/pmc -o p -- python $R/scripts/bench_config_c.py > /dev/null 2>&1
 python - <<PY
 import csv, glob, collections, os
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")

@@ -7,9 +7,9 @@ W=${1:-256}
 OUT=$R/gpurun_out/prof_lin
 mkdir -p $OUT
 CMD="python $R/bench.py --windows $W --streams 1 --steps 20 --warmup 30 --no-graph --no-cpu-baseline --no-pmc --profile-steps 0"
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/p1 -o p -- $CMD > /dev/null 2>$OUT/p1.err
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $OUT/p2 -o p -- $CMD > /dev/null 2>$OUT/p2.err
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/p3 -o p -- $CMD > /dev/null 2>$OUT/p3.err
+timeout 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/p1 -o p -- $CMD > /dev/null 2>$OUT/p1.err
+timeout 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $OUT/p2 -o p -- $CMD > /dev/null 2>$OUT/p2.err
+timeout 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/p3 -o p -- $CMD > /dev/null 2>$OUT/p3.err
 python - <<PY > $OUT/summary.txt
 import csv, glob, collections, os
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -23,4 +23,4 @@ for p in ("p1", "p2", "p3"):
             print(p, k[0], k[1], len(v), sum(v) / len(v))
 PY
 cat $OUT/summary.txt
-tail -3 $OUT/p1.err $OUT/p3.err
+tail -n 3 $OUT/p1.err; tail -n 3 $OUT/p3.err
