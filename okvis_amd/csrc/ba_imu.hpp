@@ -49,7 +49,9 @@ struct ImuLds {
   static constexpr int CROSSP = AINTP + 3 * (IMU_N + 1); // 9(N+1)
   static constexpr int DVP = CROSSP + 9 * (IMU_N + 1);   // 9(N+1)
   static constexpr int TSBUF = DVP + 9 * (IMU_N + 1);    // (N+8) timestamps staged for the loop control (as long long)
-  static constexpr int TOTAL = TSBUF + IMU_N + 8;
+  static constexpr int SKA = TSBUF + IMU_N + 8;          // 9N   [adbl]x  (skew matrices of the covariance transition,
+  static constexpr int SKI = SKA + 9 * IMU_N;            // 9N   [aint]x   formed once per step instead of per matrix entry)
+  static constexpr int TOTAL = SKI + 9 * IMU_N;
 };
 // compact LDS layout of the evaluate kernel (no re-preintegration scratch): J | F | e | cache copy
 struct EvalLds {
@@ -72,17 +74,15 @@ __device__ __forceinline__ void st9(double* p, int k, const double* o) {
 }
 
 // (F_k X)_(i, col) for the sparse F_delta of ImuError.cpp:209-226 applied to column `col` of X (15x15)
-__device__ __forceinline__ double imu_F_apply(const double* X, int i, int col, const double* adbl, double dt,
+__device__ __forceinline__ double imu_F_apply(const double* X, int i, int col, const double* ska, double dt,
                                               const double* dpt, const double* b012, const double* c1,
-                                              const double* aint, const double* dvt, const double* cint) {
+                                              const double* ski, const double* dvt, const double* cint) {
   double v = X[15 * i + col];
   if (i < 3) {
     // block(0,3) = -[adbl]x ; (0,6) = dt I ; (0,9) = dp_term ; (0,12) = b012
-    double cx[9];
-    cross_mx(adbl, cx);
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      v -= cx[3 * i + m] * X[15 * (3 + m) + col];
+      v -= ska[3 * i + m] * X[15 * (3 + m) + col];
       v += dpt[3 * i + m] * X[15 * (9 + m) + col];
       v += b012[3 * i + m] * X[15 * (12 + m) + col];
     }
@@ -93,11 +93,9 @@ __device__ __forceinline__ double imu_F_apply(const double* X, int i, int col, c
     for (int m = 0; m < 3; ++m) v -= dt * c1[3 * r + m] * X[15 * (9 + m) + col];
   } else if (i < 9) {
     const int r = i - 6;  // (6,3) = -[aint]x ; (6,9) = dv_term ; (6,12) = -cint
-    double cx[9];
-    cross_mx(aint, cx);
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      v -= cx[3 * r + m] * X[15 * (3 + m) + col];
+      v -= ski[3 * r + m] * X[15 * (3 + m) + col];
       v += dvt[3 * r + m] * X[15 * (9 + m) + col];
       v -= cint[3 * r + m] * X[15 * (12 + m) + col];
     }
@@ -400,7 +398,18 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       double q[9], t3[3], t9[9];
       for (int c = 0; c < 9; ++c) q[c] = 0.25 * CC[c];
       mat3_vec(q, ab, t3);
-      for (int c = 0; c < 3; ++c) lds[ImuLds::ADBL + 3 * tid + c] = aint[c] * dt + t3[c] * dt * dt;
+      double adbl_k[3], sk[9];
+      for (int c = 0; c < 3; ++c) {
+        adbl_k[c] = aint[c] * dt + t3[c] * dt * dt;
+        lds[ImuLds::ADBL + 3 * tid + c] = adbl_k[c];
+      }
+      cross_mx(adbl_k, sk);
+      st9(lds + ImuLds::SKA, tid, sk);
+      {
+        const double ai_k[3] = {lds[ImuLds::AINT + 3 * tid], lds[ImuLds::AINT + 3 * tid + 1], lds[ImuLds::AINT + 3 * tid + 2]};
+        cross_mx(ai_k, sk);
+        st9(lds + ImuLds::SKI, tid, sk);
+      }
       for (int c = 0; c < 9; ++c) t9[c] = Cint[c] * dt + q[c] * dt * dt;
       st9(lds + ImuLds::CDBL, tid, t9);
       for (int c = 0; c < 9; ++c) t9[c] = -Cint[c] * dt + q[c] * dt * dt;
@@ -461,25 +470,23 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       }
     }
     for (int k = 0; k < ns; ++k) {
-      const double* adbl = lds + ImuLds::ADBL + 3 * k;
+      const double* ska = lds + ImuLds::SKA + 9 * k;
       const double* dpt = lds + ImuLds::RINV + 9 * k;
       const double* b012 = lds + ImuLds::B012 + 9 * k;
       const double* c1 = lds + ImuLds::C1 + 9 * k;
-      const double* ai = lds + ImuLds::AINT + 3 * k;
+      const double* ski = lds + ImuLds::SKI + 9 * k;
       const double* dvt = lds + ImuLds::DVT + 9 * k;
       const double* ci = lds + ImuLds::CINT + 9 * k;
       const double dtk = lds[ImuLds::DT + k];
-      if (r1 >= 0) T[15 * r1 + c1i] = imu_F_apply(P, r1, c1i, adbl, dtk, dpt, b012, c1, ai, dvt, ci);
+      if (r1 >= 0) T[15 * r1 + c1i] = imu_F_apply(P, r1, c1i, ska, dtk, dpt, b012, c1, ski, dvt, ci);
       __syncthreads();
       if (r2 >= 0) {
         const int pi2 = r2, pj2 = c2i;
         // (T F^T)_ij = sum_m T_im F_jm: row pj of the sparse F against row pi of T
         double v = T[15 * pi2 + pj2];
         if (pj2 < 3) {
-          double cx[9];
-          cross_mx(adbl, cx);
           for (int m = 0; m < 3; ++m) {
-            v -= cx[3 * pj2 + m] * T[15 * pi2 + 3 + m];
+            v -= ska[3 * pj2 + m] * T[15 * pi2 + 3 + m];
             v += dpt[3 * pj2 + m] * T[15 * pi2 + 9 + m];
             v += b012[3 * pj2 + m] * T[15 * pi2 + 12 + m];
           }
@@ -489,10 +496,8 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
           for (int m = 0; m < 3; ++m) v -= dtk * c1[3 * r + m] * T[15 * pi2 + 9 + m];
         } else if (pj2 < 9) {
           const int r = pj2 - 6;
-          double cx[9];
-          cross_mx(ai, cx);
           for (int m = 0; m < 3; ++m) {
-            v -= cx[3 * r + m] * T[15 * pi2 + 3 + m];
+            v -= ski[3 * r + m] * T[15 * pi2 + 3 + m];
             v += dvt[3 * r + m] * T[15 * pi2 + 9 + m];
             v -= ci[3 * r + m] * T[15 * pi2 + 12 + m];
           }
