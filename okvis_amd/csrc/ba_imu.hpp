@@ -49,10 +49,14 @@ struct ImuLds {
   static constexpr int CROSSP = AINTP + 3 * (IMU_N + 1); // 9(N+1)
   static constexpr int DVP = CROSSP + 9 * (IMU_N + 1);   // 9(N+1)
   static constexpr int TSBUF = DVP + 9 * (IMU_N + 1);    // (N+8) timestamps staged for the loop control (as long long)
-  static constexpr int SKA = TSBUF + IMU_N + 8;          // 9N   [adbl]x  (skew matrices of the covariance transition,
-  static constexpr int SKI = SKA + 9 * IMU_N;            // 9N   [aint]x   formed once per step instead of per matrix entry)
-  static constexpr int TOTAL = SKI + 9 * IMU_N;
+  // coefficient block of the covariance transition F_k = I + N_k per step (signs folded in, so that every matrix entry
+  // of F P and (F P) F^T is a plain sum of coefficient * entry):  -[adbl]x (9) | dt | dp_term (9) | b012 (9) | -dt C1 (9)
+  // | -[aint]x (9) | dv_term (9) | -C_int (9) | noise diagonal of p, alpha, v, b_g, b_a (5) | 0
+  static constexpr int CB = TSBUF + IMU_N + 8;
+  static constexpr int CB_STRIDE = 70;
+  static constexpr int TOTAL = CB + CB_STRIDE * IMU_N;
 };
+enum { CB_A1 = 0, CB_DT = 9, CB_DPT = 10, CB_B012 = 19, CB_DTC1 = 28, CB_SKI = 37, CB_DVT = 46, CB_CINT = 55, CB_NOISE = 64, CB_ZERO = 69 };
 // compact LDS layout of the evaluate kernel (no re-preintegration scratch): J | F | e | cache copy
 struct EvalLds {
   static constexpr int PM = 0;      // 450: J = sqrtInfo * F
@@ -73,36 +77,6 @@ __device__ __forceinline__ void st9(double* p, int k, const double* o) {
   for (int i = 0; i < 9; ++i) p[9 * k + i] = o[i];
 }
 
-// (F_k X)_(i, col) for the sparse F_delta of ImuError.cpp:209-226 applied to column `col` of X (15x15)
-__device__ __forceinline__ double imu_F_apply(const double* X, int i, int col, const double* ska, double dt,
-                                              const double* dpt, const double* b012, const double* c1,
-                                              const double* ski, const double* dvt, const double* cint) {
-  double v = X[15 * i + col];
-  if (i < 3) {
-    // block(0,3) = -[adbl]x ; (0,6) = dt I ; (0,9) = dp_term ; (0,12) = b012
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      v -= ska[3 * i + m] * X[15 * (3 + m) + col];
-      v += dpt[3 * i + m] * X[15 * (9 + m) + col];
-      v += b012[3 * i + m] * X[15 * (12 + m) + col];
-    }
-    v += dt * X[15 * (6 + i) + col];
-  } else if (i < 6) {
-    const int r = i - 3;  // block(3,9) = -dt C1
-#pragma unroll
-    for (int m = 0; m < 3; ++m) v -= dt * c1[3 * r + m] * X[15 * (9 + m) + col];
-  } else if (i < 9) {
-    const int r = i - 6;  // (6,3) = -[aint]x ; (6,9) = dv_term ; (6,12) = -cint
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      v -= ski[3 * r + m] * X[15 * (3 + m) + col];
-      v += dvt[3 * r + m] * X[15 * (9 + m) + col];
-      v -= cint[3 * r + m] * X[15 * (12 + m) + col];
-    }
-  }
-  return v;
-}
-
 // in-place Cholesky of a 15x15 SPD matrix in LDS by 225 work-items (A row-major, lower triangle = L)
 __device__ __forceinline__ void chol15(double* A, int e) {
   const int i = e / 15, j = e % 15;
@@ -117,7 +91,11 @@ __device__ __forceinline__ void chol15(double* A, int e) {
   __syncthreads();
 }
 
+// diagnostics (debug_arrays): cycles per stage of the re-preintegration of factor 0, accumulated over the chunks
+#define RSTAMP(k) do { if (W.prof && f == 0 && tid == 0) { const long long t_ = clock64(); W.prof[50 + (k)] += (double)(t_ - rs_t); rs_t = t_; } } while (0)
 __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds, int tid) {
+  long long rs_t = clock64();
+  if (W.prof && f == 0 && tid < 12) W.prof[50 + tid] = 0.0;
   // The integration steps are processed in chunks of IMU_N (the LDS scratch), with the running state
   // (Delta_q, the integrals, the cross matrix, dv/db_g, the covariance) carried from chunk to chunk, so a
   // factor may span any number of raw samples (the reference copies the whole deque into every ImuError).
@@ -265,6 +243,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
     __syncthreads();
     const int ns = s_nsteps;
     if (ns == 0) break;
+    RSTAMP(0);
     // ---- stage 1: per-step quantities
     if (tid < ns) {
       const int it = s_it[tid];
@@ -321,6 +300,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       lds[ImuLds::SA2 + tid] = dt * sa * sa;
     }
     __syncthreads();
+    RSTAMP(1);
     // ---- stage 2: Delta_q_k = Delta_q_carry (x) dq_0 (x) ... (x) dq_(k-1), the reference's product order, by
     //      one work-item; meanwhile (another wave) the recursion cross_(k+1) = R(dq_k)^T cross_k + Jr_k dt_k,
     //      one work-item per column of `cross`
@@ -349,6 +329,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       }
     }
     __syncthreads();
+    RSTAMP(2);
     // ---- stage 3 (every stage keeps its temporaries local and re-reads what it needs from LDS: nothing but
     //      `tid` stays live in registers across the barriers — the launch is capped at 256 registers)
     if (tid < ns) {
@@ -371,6 +352,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       st9(lds + ImuLds::C1, tid, C1m);
     }
     __syncthreads();
+    RSTAMP(3);
     // ---- stage 4: ordered prefix sums of the integrals, one work-item per component
     if (tid < 12) {
       const int base_p = tid < 9 ? ImuLds::CINTP + tid : ImuLds::AINTP + (tid - 9);
@@ -383,6 +365,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       }
     }
     __syncthreads();
+    RSTAMP(4);
     // ---- stage 5
     if (tid < ns) {
       double G[9], C[9], CC[9], ab[3];
@@ -404,11 +387,12 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
         lds[ImuLds::ADBL + 3 * tid + c] = adbl_k[c];
       }
       cross_mx(adbl_k, sk);
-      st9(lds + ImuLds::SKA, tid, sk);
       {
+        double* cb = lds + ImuLds::CB + ImuLds::CB_STRIDE * tid;
+        for (int c = 0; c < 9; ++c) cb[CB_A1 + c] = -sk[c];
         const double ai_k[3] = {lds[ImuLds::AINT + 3 * tid], lds[ImuLds::AINT + 3 * tid + 1], lds[ImuLds::AINT + 3 * tid + 2]};
         cross_mx(ai_k, sk);
-        st9(lds + ImuLds::SKI, tid, sk);
+        for (int c = 0; c < 9; ++c) cb[CB_SKI + c] = -sk[c];
       }
       for (int c = 0; c < 9; ++c) t9[c] = Cint[c] * dt + q[c] * dt * dt;
       st9(lds + ImuLds::CDBL, tid, t9);
@@ -428,6 +412,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       st9(lds + ImuLds::DVT, tid, t9);
     }
     __syncthreads();
+    RSTAMP(5);
     // ---- stage 6: prefix of dv/db_g (one work-item per component), then dp_term (aliases RINV, no longer needed)
     if (tid < 9) {
       double a = lds[ImuLds::DVP + tid];
@@ -443,8 +428,32 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       for (int c = 0; c < 9; ++c)
         t9[c] = dt * lds[ImuLds::DVP + 9 * tid + c] + 0.25 * dt * dt * lds[ImuLds::GG + 9 * tid + c];
       st9(lds + ImuLds::RINV, tid, t9);
+      // the rest of this step's coefficient block (ImuError.cpp:209-249); operands first, stores afterwards
+      double* cb = lds + ImuLds::CB + ImuLds::CB_STRIDE * tid;
+      double b9[9], c9[9], d9[9], i9[9];
+      ld9(lds + ImuLds::B012, tid, b9);
+      ld9(lds + ImuLds::C1, tid, c9);
+      ld9(lds + ImuLds::DVT, tid, d9);
+      ld9(lds + ImuLds::CINT, tid, i9);
+      const double s2a = lds[ImuLds::SG2 + tid], s2v = lds[ImuLds::SA2 + tid];
+      cb[CB_DT] = dt;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        cb[CB_DPT + c] = t9[c];
+        cb[CB_B012 + c] = b9[c];
+        cb[CB_DTC1 + c] = -(dt * c9[c]);
+        cb[CB_DVT + c] = d9[c];
+        cb[CB_CINT + c] = -i9[c];
+      }
+      cb[CB_NOISE + 0] = 0.5 * dt * dt * s2v;
+      cb[CB_NOISE + 1] = s2a;
+      cb[CB_NOISE + 2] = s2v;
+      cb[CB_NOISE + 3] = dt * prm.sigma_gw_c * prm.sigma_gw_c;
+      cb[CB_NOISE + 4] = dt * prm.sigma_aw_c * prm.sigma_aw_c;
+      cb[CB_ZERO] = 0.0;
     }
     __syncthreads();
+    RSTAMP(6);
     // ---- stage 8: covariance recursion over this chunk.  Work-item -> matrix entry mapping: every wave owns
     //      ONE row type in the first phase (T = F P) and ONE column type in the second (P = T F^T + Q), so no
     //      wave executes more than one branch of the sparse F:  wave 0: p rows/cols (45 entries), wave 1: v,
@@ -469,51 +478,88 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
         r2 = be / 6; c2i = 9 + be % 6;     // bias columns
       }
     }
+    // Every entry is  own + sum_t coefficient[t] * entry[t]  with at most ten terms (same order of the terms as the
+    // block-wise expressions they replace); the term lists depend only on the entry, the loop over the steps is
+    // straight-line code: 2 x (10 coefficient reads + 10 entry reads + 10 FMAs) and two barriers per step.
+    int co1[10], xo1[10], co2[10], xo2[10], noff = CB_ZERO;
+    const int own1 = r1 >= 0 ? 15 * r1 + c1i : 0, own2 = r2 >= 0 ? 15 * r2 + c2i : 0;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      co1[t] = CB_ZERO; xo1[t] = own1;
+      co2[t] = CB_ZERO; xo2[t] = own2;
+    }
+    if (r1 >= 0 && r1 < 3) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        co1[3 * m] = CB_A1 + 3 * r1 + m;       xo1[3 * m] = 15 * (3 + m) + c1i;
+        co1[3 * m + 1] = CB_DPT + 3 * r1 + m;  xo1[3 * m + 1] = 15 * (9 + m) + c1i;
+        co1[3 * m + 2] = CB_B012 + 3 * r1 + m; xo1[3 * m + 2] = 15 * (12 + m) + c1i;
+      }
+      co1[9] = CB_DT; xo1[9] = 15 * (6 + r1) + c1i;
+    } else if (r1 >= 3 && r1 < 6) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { co1[m] = CB_DTC1 + 3 * (r1 - 3) + m; xo1[m] = 15 * (9 + m) + c1i; }
+    } else if (r1 >= 6 && r1 < 9) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        co1[3 * m] = CB_SKI + 3 * (r1 - 6) + m;      xo1[3 * m] = 15 * (3 + m) + c1i;
+        co1[3 * m + 1] = CB_DVT + 3 * (r1 - 6) + m;  xo1[3 * m + 1] = 15 * (9 + m) + c1i;
+        co1[3 * m + 2] = CB_CINT + 3 * (r1 - 6) + m; xo1[3 * m + 2] = 15 * (12 + m) + c1i;
+      }
+    }
+    if (r2 >= 0) {   // (T F^T)_ij = T_ij + sum_m T_im N_jm: row c2i of the coefficients against row r2 of T
+      if (c2i < 3) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          co2[3 * m] = CB_A1 + 3 * c2i + m;       xo2[3 * m] = 15 * r2 + 3 + m;
+          co2[3 * m + 1] = CB_DPT + 3 * c2i + m;  xo2[3 * m + 1] = 15 * r2 + 9 + m;
+          co2[3 * m + 2] = CB_B012 + 3 * c2i + m; xo2[3 * m + 2] = 15 * r2 + 12 + m;
+        }
+        co2[9] = CB_DT; xo2[9] = 15 * r2 + 6 + c2i;
+      } else if (c2i < 6) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { co2[m] = CB_DTC1 + 3 * (c2i - 3) + m; xo2[m] = 15 * r2 + 9 + m; }
+      } else if (c2i < 9) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          co2[3 * m] = CB_SKI + 3 * (c2i - 6) + m;      xo2[3 * m] = 15 * r2 + 3 + m;
+          co2[3 * m + 1] = CB_DVT + 3 * (c2i - 6) + m;  xo2[3 * m + 1] = 15 * r2 + 9 + m;
+          co2[3 * m + 2] = CB_CINT + 3 * (c2i - 6) + m; xo2[3 * m + 2] = 15 * r2 + 12 + m;
+        }
+      }
+      if (r2 == c2i) noff = CB_NOISE + (r2 < 3 ? 0 : (r2 < 6 ? 1 : (r2 < 9 ? 2 : (r2 < 12 ? 3 : 4))));   // (ImuError.cpp:228-249)
+    }
     for (int k = 0; k < ns; ++k) {
-      const double* ska = lds + ImuLds::SKA + 9 * k;
-      const double* dpt = lds + ImuLds::RINV + 9 * k;
-      const double* b012 = lds + ImuLds::B012 + 9 * k;
-      const double* c1 = lds + ImuLds::C1 + 9 * k;
-      const double* ski = lds + ImuLds::SKI + 9 * k;
-      const double* dvt = lds + ImuLds::DVT + 9 * k;
-      const double* ci = lds + ImuLds::CINT + 9 * k;
-      const double dtk = lds[ImuLds::DT + k];
-      if (r1 >= 0) T[15 * r1 + c1i] = imu_F_apply(P, r1, c1i, ska, dtk, dpt, b012, c1, ski, dvt, ci);
+      const double* cb = lds + ImuLds::CB + ImuLds::CB_STRIDE * k;
+      if (r1 >= 0) {
+        double cv[10], xv[10];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {   // all twenty operands requested before the first is used: one LDS round trip
+          cv[t] = cb[co1[t]];
+          xv[t] = P[xo1[t]];
+        }
+        double v = P[own1];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) v += cv[t] * xv[t];
+        T[own1] = v;
+      }
       __syncthreads();
       if (r2 >= 0) {
-        const int pi2 = r2, pj2 = c2i;
-        // (T F^T)_ij = sum_m T_im F_jm: row pj of the sparse F against row pi of T
-        double v = T[15 * pi2 + pj2];
-        if (pj2 < 3) {
-          for (int m = 0; m < 3; ++m) {
-            v -= ska[3 * pj2 + m] * T[15 * pi2 + 3 + m];
-            v += dpt[3 * pj2 + m] * T[15 * pi2 + 9 + m];
-            v += b012[3 * pj2 + m] * T[15 * pi2 + 12 + m];
-          }
-          v += dtk * T[15 * pi2 + 6 + pj2];
-        } else if (pj2 < 6) {
-          const int r = pj2 - 3;
-          for (int m = 0; m < 3; ++m) v -= dtk * c1[3 * r + m] * T[15 * pi2 + 9 + m];
-        } else if (pj2 < 9) {
-          const int r = pj2 - 6;
-          for (int m = 0; m < 3; ++m) {
-            v -= ski[3 * r + m] * T[15 * pi2 + 3 + m];
-            v += dvt[3 * r + m] * T[15 * pi2 + 9 + m];
-            v -= ci[3 * r + m] * T[15 * pi2 + 12 + m];
-          }
+        double cv[10], xv[10];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+          cv[t] = cb[co2[t]];
+          xv[t] = T[xo2[t]];
         }
-        if (pi2 == pj2) {  // noise (ImuError.cpp:228-249)
-          const double s2a = lds[ImuLds::SG2 + k], s2v = lds[ImuLds::SA2 + k];
-          if (pi2 < 3) v += 0.5 * dtk * dtk * s2v;
-          else if (pi2 < 6) v += s2a;
-          else if (pi2 < 9) v += s2v;
-          else if (pi2 < 12) v += dtk * prm.sigma_gw_c * prm.sigma_gw_c;
-          else v += dtk * prm.sigma_aw_c * prm.sigma_aw_c;
-        }
-        P[15 * pi2 + pj2] = v;
+        const double nz = cb[noff];
+        double v = T[own2];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) v += cv[t] * xv[t];
+        P[own2] = v + nz;
       }
       __syncthreads();
     }
+    RSTAMP(7);
     // ---- stage 7: running totals (ordered sums, one work-item per component); the carries of the prefix arrays
     //      move from index ns to index 0
     {
@@ -538,6 +584,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       }
     }
     __syncthreads();
+    RSTAMP(8);
     if (s_finished) break;
   }
   // ---- cache copy in LDS
@@ -555,6 +602,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
   }
   if (tid < 4) ca[CA_DQ + tid] = c_Dq[tid];
   __syncthreads();
+  RSTAMP(9);
   // ---- stage 9: information = sym(P)^-1, sqrtInfo = chol(sym(information))^T  (ImuError.cpp:268-279)
   if (tid < 225) T[tid] = 0.5 * P[15 * pi + pj] + 0.5 * P[15 * pj + pi];
   __syncthreads();
@@ -604,7 +652,9 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
     cg->redo_count += 1;
   }
   __syncthreads();
+  RSTAMP(10);
 }
+#undef RSTAMP
 
 // bias check of ImuError::EvaluateWithMinimalJacobians (ImuError.cpp:541-558): re-preintegrate on first use
 // or when |b_g - b_g,ref| * dt > 1e-4 (rarely taken).
