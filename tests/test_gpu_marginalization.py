@@ -143,3 +143,19 @@ def test_argument_and_state_errors():
     b2.close()
     # dense solve: argument check
     assert L.okvis_ba_dense_solve(0, 0, None, None, None, None) == -1
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_marginalization(oracle, seed):
+    # random window shapes and random choices of the blocks to eliminate (poses, speed/bias blocks, all landmarks)
+    rng = np.random.default_rng(500 + seed)
+    K = int(rng.integers(3, 8))
+    L = int(rng.integers(5, 90))
+    ext = ["fixed", "shared"][int(rng.integers(0, 2))]
+    w = synthetic.make_window(K, L, float(rng.uniform(0.3, 1.0)), seed=700 + seed, estimate_extrinsics=ext)
+    n_p = int(rng.integers(0, min(3, K - 1) + 1))
+    poses = sorted(rng.choice(K, size=n_p, replace=False).tolist())        # frame poses only (indices < K)
+    sbs = sorted(rng.choice(K, size=int(rng.integers(0, min(3, K - 1) + 1)), replace=False).tolist())
+    pm, sm = flags(w, poses, sbs)
+    g, r = both(oracle, w, pm, sm)
+    check(g, r)
