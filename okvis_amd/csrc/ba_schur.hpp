@@ -60,14 +60,18 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
   for (int i = 0; i <= SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH; ++i)
     pbeg[i] = (i <= nbatch) ? W.lm_pair_begin[min(lm_begin + i * SCHUR_LM_BATCH, lm_end)] : 0;
   // ---- decision (wave 0) ----
+  __shared__ Ctrl s_ctrl;   // the control record is fetched with ONE coalesced load; decide() then reads the LDS copy
   if (tid < 64) {
-    int acc = ctrl->acc, term = 0;
-    double radius = ctrl->radius;
-    if (ctrl->pending) {
+    if (tid < (int)(sizeof(Ctrl) / 8)) reinterpret_cast<double*>(&s_ctrl)[tid] = reinterpret_cast<const double*>(ctrl)[tid];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("" ::: "memory");
+    int acc = s_ctrl.acc, term = 0;
+    double radius = s_ctrl.radius;
+    if (s_ctrl.pending) {
       double sums[6];
       wave_trial_sums(W, 1 - acc, tid, sums);
       Decision d;
-      decide(ctrl, &opt, sums, &d);
+      decide(&s_ctrl, &opt, sums, &d);
       if (d.accept) acc = 1 - acc;
       radius = d.radius;
       term = d.term;

@@ -355,13 +355,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     double sums[6] = {0, 0, 0, 0, 0, 0};
     Decision d;
     d.accept = 0; d.term = 0;
-    const int pending = gctrl->pending;
+    // the control record: one coalesced load into the LDS copy, which decide() reads and lane 0 then updates
+    if (tid < (int)(sizeof(Ctrl) / 8)) reinterpret_cast<double*>(&c)[tid] = reinterpret_cast<const double*>(gctrl)[tid];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("" ::: "memory");
+    const int pending = c.pending;
     if (pending) {
-      wave_trial_sums(W, 1 - gctrl->acc, tid, sums);
-      decide(gctrl, &opt, sums, &d);
+      wave_trial_sums(W, 1 - c.acc, tid, sums);
+      decide(&c, &opt, sums, &d);
     }
     if (tid == 0) {
-      c = *gctrl;
       s_accepted = 0;
       s_was_pending = pending;
       s_was_first = c.first;
