@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE configs[2] (50 keyframes / 2000 landmarks / 200 000 observations, D = 750): per-iteration time on the
-GPU (Gauss-Newton mode, graph replay) with the per-kernel split, next to the CPU oracle.  One JSON line."""
+GPU (Gauss-Newton mode, graph replay) with the per-kernel split, next to the CPU oracle.  One JSON line.
+
+Measurement script, not product code: the oracle (tests/oracle_lib.py -> oracle/) is called here in the same role
+as in bench.py's `cpu_baseline` leg — a reported CPU column, never part of the measured GPU path."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

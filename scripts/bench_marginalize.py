@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Timing of okvis_ba_marginalize next to the CPU oracle on the same sub-window.
 Prints one JSON line.  Two shapes: what the stock pipeline hands over per frame (6 frames, 150 landmarks,
-~1.4 k observations, one pose + two speed/bias blocks eliminated) and a BASELINE-configs[1]-sized window."""
+~1.4 k observations, one pose + two speed/bias blocks eliminated) and a BASELINE-configs[1]-sized window.
+
+Measurement script, not product code: the oracle is called in the same role as in bench.py's `cpu_baseline` leg (a
+reported CPU column and the H-parity figure), never part of the measured GPU path."""
 import json
 import os
 import sys
