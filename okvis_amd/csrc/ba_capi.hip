@@ -44,14 +44,26 @@ struct HostWin {  // host copy of what the queries and downloads need
   int64_t bytes_lin = 0, bytes_schur = 0, bytes_solve = 0, bytes_small = 0;
 };
 
+// Device arena of a batch = [data part, built on the host and copied over PCIe | zero part, cleared on the device].
+// Offsets into the zero part carry ARENA_ZFLAG until relocate() turns them into pointers: the linearisation buffers,
+// Schur partials and work areas are more than half of a window's bytes and need not cross PCIe as zeros.
+constexpr size_t ARENA_ZFLAG = size_t(1) << 62;
 struct Arena {
-  std::vector<unsigned char> host;
-  size_t size = 0;
+  std::vector<unsigned char> host;   // data part
+  size_t size = 0;                   // bytes of the data part
+  size_t zsize = 0;                  // bytes of the zero part
   size_t alloc(size_t bytes) {
     size_t off = (size + 255) & ~size_t(255);
     size = off + bytes;
     return off;
   }
+  size_t zalloc(size_t bytes) {
+    size_t off = (zsize + 255) & ~size_t(255);
+    zsize = off + bytes;
+    return off | ARENA_ZFLAG;
+  }
+  size_t data_bytes() const { return (size + 255) & ~size_t(255); }
+  size_t total() const { return data_bytes() + zsize; }
 };
 
 }  // namespace
@@ -118,11 +130,7 @@ size_t put(Arena& A, const std::vector<T>& v) {
   if (!v.empty()) std::memcpy(A.host.data() + off, v.data(), v.size() * sizeof(T));
   return off;
 }
-size_t put_zero(Arena& A, size_t bytes) {
-  size_t off = A.alloc(std::max<size_t>(bytes, 8));
-  if (A.host.size() < A.size) A.host.resize(A.size, 0);
-  return off;
-}
+size_t put_zero(Arena& A, size_t bytes) { return A.zalloc(std::max<size_t>(bytes, 8)); }
 template <class T>
 std::vector<T> vec(const T* p, size_t n) {
   return (p && n) ? std::vector<T>(p, p + n) : std::vector<T>();
@@ -602,7 +610,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
 }
 
 // convert the arena offsets stored in the pointer fields to device addresses
-void relocate(WinPtrs& P, unsigned char* base, bool debug) {
+void relocate(WinPtrs& P, unsigned char* base, unsigned char* zbase, bool debug) {
   unsigned char** fields = reinterpret_cast<unsigned char**>(&P.pose[0]);
   // all pointer members are laid out contiguously from pose[0] to marg_lin; relocate by scanning the
   // struct region as an array of pointers (sizes/scalars precede pose[0])
@@ -610,7 +618,7 @@ void relocate(WinPtrs& P, unsigned char* base, bool debug) {
   const size_t n = (sizeof(WinPtrs) - first) / sizeof(void*);
   for (size_t i = 0; i < n; ++i) {
     const size_t off = reinterpret_cast<size_t>(fields[i]);
-    fields[i] = base + off;
+    fields[i] = (off & ARENA_ZFLAG) ? zbase + (off & ~ARENA_ZFLAG) : base + off;
   }
   // optional arrays that were never allocated hold offset 0 -> must be null
   if (!debug) {
@@ -879,22 +887,24 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   }
   // grow-only device allocations: the per-frame re-upload of okvis_amd::Estimator must not pay hipFree/hipMalloc
   A.host.resize(A.size, 0);
-  if (A.size > s->arena_capacity) {
+  if (A.total() > s->arena_capacity) {
     if (s->d_arena) HIP_TRY(hipFree(s->d_arena));
     s->d_arena = nullptr;
     s->arena_capacity = 0;
-    const size_t cap = A.size + A.size / 4;
+    const size_t cap = A.total() + A.total() / 4;
     HIP_TRY(hipMalloc(&s->d_arena, cap));
     s->arena_capacity = cap;
   }
-  s->arena_bytes = A.size;
+  s->arena_bytes = A.total();
+  unsigned char* zbase = s->d_arena + A.data_bytes();
+  if (A.zsize) HIP_TRY(hipMemsetAsync(zbase, 0, A.zsize, s->stream));   // overlaps with the copy below
   HIP_TRY(hipMemcpy(s->d_arena, A.host.data(), A.size, hipMemcpyHostToDevice));
   std::vector<WinPtrs> ptrs(n_windows);
   s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = 0;
   s->max_Dpad_small = s->max_Dpad_large = 0;
   s->any_ext = false;
   for (int i = 0; i < n_windows; ++i) {
-    relocate(wins[i].ptrs, s->d_arena, s->opt.debug_arrays != 0);
+    relocate(wins[i].ptrs, s->d_arena, zbase, s->opt.debug_arrays != 0);
     ptrs[i] = wins[i].ptrs;
     const WinPtrs& P = ptrs[i];
     s->max_group = std::max(s->max_group, P.n_group);
@@ -961,7 +971,7 @@ int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt,
   if (rc != OKVIS_BA_OK) return rc;
   if (stats) {
     stats[0] = H.D; stats[1] = H.Dp; stats[2] = H.n_pair; stats[3] = H.n_group; stats[4] = H.n_chunk;
-    stats[5] = H.ptrs.n_task; stats[6] = H.ptrs.gpart_size; stats[7] = (int64_t)A.size;
+    stats[5] = H.ptrs.n_task; stats[6] = H.ptrs.gpart_size; stats[7] = (int64_t)A.total();
   }
   return OKVIS_BA_OK;
 }
