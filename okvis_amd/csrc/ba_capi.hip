@@ -48,8 +48,39 @@ struct HostWin {  // host copy of what the queries and downloads need
 // Offsets into the zero part carry ARENA_ZFLAG until relocate() turns them into pointers: the linearisation buffers,
 // Schur partials and work areas are more than half of a window's bytes and need not cross PCIe as zeros.
 constexpr size_t ARENA_ZFLAG = size_t(1) << 62;
+// Page-locked host memory for the staging buffers (H2D copies from pinned memory are asynchronous and about twice as
+// fast as from pageable memory); plain malloc when there is no device (okvis_ba_check_window on a CPU-only host).
+template <class T>
+struct StageAlloc {
+  typedef T value_type;
+  StageAlloc() = default;
+  template <class U>
+  StageAlloc(const StageAlloc<U>&) {}
+  T* allocate(size_t n) {
+    const size_t bytes = n * sizeof(T) + 16;
+    void* p = nullptr;
+    unsigned char tag = 1;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      p = std::malloc(bytes);
+      tag = 0;
+      if (!p) throw std::bad_alloc();
+    }
+    static_cast<unsigned char*>(p)[0] = tag;
+    return reinterpret_cast<T*>(static_cast<unsigned char*>(p) + 16);
+  }
+  void deallocate(T* q, size_t) {
+    unsigned char* p = reinterpret_cast<unsigned char*>(q) - 16;
+    if (p[0]) (void)hipHostFree(p); else std::free(p);
+  }
+  template <class U>
+  bool operator==(const StageAlloc<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const StageAlloc<U>&) const { return false; }
+};
+typedef std::vector<unsigned char, StageAlloc<unsigned char>> StageVec;
 struct Arena {
-  std::vector<unsigned char> host;   // data part
+  StageVec host;   // data part
   size_t size = 0;                   // bytes of the data part
   size_t zsize = 0;                  // bytes of the zero part
   size_t alloc(size_t bytes) {
@@ -82,6 +113,7 @@ struct okvis_ba_solver {
   unsigned char* d_arena = nullptr;
   size_t arena_bytes = 0, arena_capacity = 0, wins_capacity = 0;
   WinPtrs* d_wins = nullptr;
+  StageVec stage, stage_small;   // pinned staging of the arena's data part / of the WinPtrs + OptD records (kept across uploads)
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0;
@@ -880,6 +912,13 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   s->uploaded = false;
   s->begun = false;
   Arena A;
+  A.host.swap(s->stage);   // page-locked, capacity kept from the previous upload (the stream is idle: see the sync above)
+  A.host.clear();
+  struct GiveBack {
+    StageVec& a;
+    StageVec& b;
+    ~GiveBack() { a.swap(b); }
+  } give_back{A.host, s->stage};
   std::vector<HostWin> wins(n_windows);
   for (int i = 0; i < n_windows; ++i) {
     int rc = build_window(windows[i], s->opt, A, wins[i]);
@@ -898,7 +937,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   s->arena_bytes = A.total();
   unsigned char* zbase = s->d_arena + A.data_bytes();
   if (A.zsize) HIP_TRY(hipMemsetAsync(zbase, 0, A.zsize, s->stream));   // overlaps with the copy below
-  HIP_TRY(hipMemcpy(s->d_arena, A.host.data(), A.size, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(s->d_arena, A.host.data(), A.size, hipMemcpyHostToDevice, s->stream));
   std::vector<WinPtrs> ptrs(n_windows);
   s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = 0;
   s->max_Dpad_small = s->max_Dpad_large = 0;
@@ -926,9 +965,15 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     HIP_TRY(hipMalloc(&s->d_wins, sizeof(WinPtrs) * n_windows));
     s->wins_capacity = (size_t)n_windows;
   }
-  HIP_TRY(hipMemcpy(s->d_wins, ptrs.data(), sizeof(WinPtrs) * n_windows, hipMemcpyHostToDevice));
-  OptD d = make_optd(s->opt);
-  HIP_TRY(hipMemcpy(s->d_opt, &d, sizeof(d), hipMemcpyHostToDevice));
+  {
+    const size_t wb = sizeof(WinPtrs) * (size_t)n_windows;
+    s->stage_small.resize(wb + sizeof(OptD));
+    std::memcpy(s->stage_small.data(), ptrs.data(), wb);
+    const OptD d = make_optd(s->opt);
+    std::memcpy(s->stage_small.data() + wb, &d, sizeof(d));
+    HIP_TRY(hipMemcpyAsync(s->d_wins, s->stage_small.data(), wb, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_opt, s->stage_small.data() + wb, sizeof(OptD), hipMemcpyHostToDevice, s->stream));
+  }
   s->wins.swap(wins);
   // ---- sub-batches: opt.n_streams (0 = auto: one stream per 8 windows, at most 8) ----
   {
