@@ -116,6 +116,7 @@ struct okvis_ba_solver {
   StageVec stage, stage_small;   // pinned staging of the arena's data part / of the WinPtrs + OptD records (kept across uploads)
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
+  bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
   std::map<int, hipGraphExec_t> graphs;
@@ -757,6 +758,7 @@ hipError_t launch_iterations_forked(okvis_ba_solver* s, int n) {
 
 // the accepted-buffer index lives on the device while iterations are in flight: read it back
 int refresh_acc(okvis_ba_solver* s, int w) {
+  if (s->acc_fresh) return OKVIS_BA_OK;   // read by okvis_ba_finish / set at upload, nothing launched since
   int acc = 0;
   HIP_TRY(hipMemcpyAsync(&acc, &s->wins[w].ptrs.ctrl->acc, sizeof(int), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1003,6 +1005,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     }
   }
   s->uploaded = true;
+  s->acc_fresh = true;   // Ctrl starts zeroed: accepted buffer 0, like HostWin::acc
   return OKVIS_BA_OK;
 }
 
@@ -1047,6 +1050,7 @@ int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, doub
 }
 
 int okvis_ba_begin(okvis_ba_solver* s) {
+  if (s) s->acc_fresh = false;
   if (!s) return OKVIS_BA_ERR_ARG;
   if (!s->uploaded) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
@@ -1071,6 +1075,7 @@ int okvis_ba_begin(okvis_ba_solver* s) {
 }
 
 int okvis_ba_iterate(okvis_ba_solver* s, int n) {
+  if (s) s->acc_fresh = false;
   if (!s || n < 0) return OKVIS_BA_ERR_ARG;
   if (!s->begun) return OKVIS_BA_ERR_STATE;
   if (n == 0) return OKVIS_BA_OK;
@@ -1167,6 +1172,7 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
     }
   }
   s->begun = false;
+  s->acc_fresh = true;
   return OKVIS_BA_OK;
 }
 
@@ -1207,6 +1213,7 @@ int okvis_ba_optimize_timed(okvis_ba_solver* s, int max_iter, int min_iter, doub
 }
 
 int okvis_ba_evaluate_cost(okvis_ba_solver* s, double* costs) {
+  if (s) s->acc_fresh = false;
   if (!s || !costs) return OKVIS_BA_ERR_ARG;
   int rc = okvis_ba_begin(s);
   if (rc != OKVIS_BA_OK) return rc;
@@ -1281,11 +1288,10 @@ int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t
   if (n != n_doubles) return OKVIS_BA_ERR_ARG;
   if (which == OKVIS_BA_ARR_IMU_SB_REF) {
     const HostWin& H = s->wins[w];
-    for (int f = 0; f < H.n_imu; ++f) {
-      ImuCacheD c;
-      HIP_TRY(hipMemcpy(&c, H.ptrs.imu_cache + f, sizeof(c), hipMemcpyDeviceToHost));
-      for (int k = 0; k < 9; ++k) out[9 * f + k] = c.sb_ref[k];
-    }
+    // one strided copy gathers the reference biases out of the per-factor cache records
+    if (H.n_imu > 0)
+      HIP_TRY(hipMemcpy2D(out, 9 * sizeof(double), reinterpret_cast<const unsigned char*>(H.ptrs.imu_cache) + offsetof(ImuCacheD, sb_ref),
+                          sizeof(ImuCacheD), 9 * sizeof(double), (size_t)H.n_imu, hipMemcpyDeviceToHost));
     return OKVIS_BA_OK;
   }
   if (which == 98) {
@@ -1308,6 +1314,7 @@ int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t
 }
 
 int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4) {
+  if (s) s->acc_fresh = false;
   if (!s || !ms4 || n <= 0) return OKVIS_BA_ERR_ARG;
   if (!s->begun) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
@@ -1415,6 +1422,7 @@ int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* r
 // the landmarks (schur_kernel in marg_mode), export the dense system (solve_kernel final_only = 2), then the
 // dense elimination + eigen-decomposition (marg_dense_kernel).
 int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* res) {
+  if (s) s->acc_fresh = false;
   if (!s || !spec || !res) return OKVIS_BA_ERR_ARG;
   if (!s->uploaded) return OKVIS_BA_ERR_STATE;
   if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
