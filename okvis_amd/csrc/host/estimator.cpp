@@ -430,6 +430,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
   }
   std::unordered_map<uint64_t, int> lmIndex;
   lmIndex.reserve(2 * sel.landmarks.size() + 1);
+  f64[F_LM].reserve(4 * sel.landmarks.size());
   for (uint64_t id : sel.landmarks) {
     const int idx = (int)lmIndex.size();
     lmIndex[id] = idx;
@@ -462,11 +463,29 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
     if (ip < 0 || ie < 0) throw Exception("flatten: observation refers to a block outside the window");
     recs.push_back(Rec{li->second, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw});
   }
-  std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) {
-    if (a.lm != b.lm) return a.lm < b.lm;
-    if (a.pose != b.pose) return a.pose < b.pose;
-    return a.cam < b.cam;
-  });
+  {
+    // counting sort by landmark (dense indices), then the handful of observations of each landmark by (pose, camera):
+    // linear instead of n log n comparisons on the whole list
+    const size_t nl = lmIndex.size();
+    std::vector<int> start(nl + 1, 0);
+    for (const Rec& r : recs) ++start[r.lm + 1];
+    for (size_t l = 0; l < nl; ++l) start[l + 1] += start[l];
+    std::vector<Rec> sorted(recs.size());
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (const Rec& r : recs) sorted[fill[r.lm]++] = r;
+    for (size_t l = 0; l < nl; ++l)
+      std::sort(sorted.begin() + start[l], sorted.begin() + start[l + 1], [](const Rec& a, const Rec& b) {
+        if (a.pose != b.pose) return a.pose < b.pose;
+        return a.cam < b.cam;
+      });
+    recs.swap(sorted);
+  }
+  i32[I_OLM].reserve(recs.size());
+  i32[I_OPOSE].reserve(recs.size());
+  i32[I_OEXT].reserve(recs.size());
+  i32[I_OCAM].reserve(recs.size());
+  f64[F_UV].reserve(2 * recs.size());
+  f64[F_SW].reserve(recs.size());
   for (const Rec& r : recs) {
     i32[I_OLM].push_back(r.lm);
     i32[I_OPOSE].push_back(r.pose);
