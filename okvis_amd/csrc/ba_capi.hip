@@ -273,37 +273,70 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   std::vector<Task> tasks;
   std::vector<uint16_t> task_list;
   int gpart_size = 0;
+  pair_list.reserve(2 * (size_t)nobs);
+  task_list.reserve(3 * (size_t)nobs);
+  std::vector<int> blk_slot(npose, -1);                 // scratch: block -> pair of the current landmark / task of the group
+  std::vector<std::vector<uint16_t>> blk_obs(npose);    // scratch: block -> observations of the current group (own role)
+  std::vector<int> touched;
   for (int g = 0; g < ngroup; ++g) {
     Group& G = groups[g];
     G.plist_begin = (int)pair_list.size();
     G.tlist_begin = (int)task_list.size();
-    for (int p = G.pair_begin; p < G.pair_end; ++p) {
-      pair_list_begin[p] = (int)pair_list.size();
-      const int l = pair_lm[p], b = pair_block[p];
-      for (int o = lm_obs_begin[l]; o < lm_obs_begin[l + 1]; ++o)
-        if ((pair_role[p] == 0 ? w.obs_pose[o] : w.obs_ext[o]) == b) pair_list.push_back((uint16_t)(o - G.obs_begin));
+    // per-pair observation lists: one pass over a landmark's observations (two-pass counting fill)
+    for (int l = G.lm_begin; l < G.lm_end; ++l) {
+      const int p0 = lm_pair_begin[l], p1 = lm_pair_begin[l + 1];
+      for (int p = p0; p < p1; ++p) blk_slot[pair_block[p]] = p;
+      for (int p = p0; p < p1; ++p) pair_list_begin[p] = 0;
+      for (int o = lm_obs_begin[l]; o < lm_obs_begin[l + 1]; ++o) {
+        const int pp = blk_slot[w.obs_pose[o]], pe = blk_slot[w.obs_ext[o]];
+        if (pp >= 0) ++pair_list_begin[pp];
+        if (pe >= 0) ++pair_list_begin[pe];
+      }
+      int run = (int)pair_list.size();
+      for (int p = p0; p < p1; ++p) {
+        const int c = pair_list_begin[p];
+        pair_list_begin[p] = run;
+        run += c;
+      }
+      const size_t base = pair_list.size();
+      pair_list.resize((size_t)run);
+      std::vector<int>& cur = touched;   // reuse as the per-pair fill cursor
+      cur.assign(p1 - p0, 0);
+      for (int o = lm_obs_begin[l]; o < lm_obs_begin[l + 1]; ++o) {
+        const int cand[2] = {blk_slot[w.obs_pose[o]], blk_slot[w.obs_ext[o]]};
+        for (int c = 0; c < 2; ++c)
+          if (cand[c] >= 0) pair_list[(size_t)pair_list_begin[cand[c]] + cur[cand[c] - p0]++] = (uint16_t)(o - G.obs_begin);
+      }
+      (void)base;
+      for (int p = p0; p < p1; ++p) blk_slot[pair_block[p]] = -1;
     }
     G.task_begin = (int)tasks.size();
-    std::map<int, std::vector<uint16_t>> by_block;             // block -> obs (its own role)
-    std::map<std::pair<int, int>, std::vector<uint16_t>> cross;  // (pose, ext) -> obs
+    touched.clear();
+    std::map<std::pair<int, int>, std::vector<uint16_t>> cross;  // (pose, ext) -> obs (only with free extrinsics)
     for (int o = G.obs_begin; o < G.obs_end; ++o) {
       const int ip = w.obs_pose[o], ie = w.obs_ext[o];
       const uint16_t lo = (uint16_t)(o - G.obs_begin);
-      if (pose_off[ip] >= 0) by_block[ip].push_back(lo);
-      if (pose_off[ie] >= 0) by_block[ie].push_back(lo);
+      const int cand[2] = {ip, ie};
+      for (int c = 0; c < 2; ++c)
+        if (pose_off[cand[c]] >= 0) {
+          if (blk_obs[cand[c]].empty()) touched.push_back(cand[c]);
+          blk_obs[cand[c]].push_back(lo);
+        }
       if (pose_off[ip] >= 0 && pose_off[ie] >= 0) cross[{ip, ie}].push_back(lo);
     }
-    for (auto& kv : by_block) {
+    std::sort(touched.begin(), touched.end());   // ascending block index, as a std::map would iterate
+    for (int b : touched) {
       Task T;
-      T.type = role[kv.first];
-      T.off_a = pose_off[kv.first];
+      T.type = role[b];
+      T.off_a = pose_off[b];
       T.off_b = -1;
       T.list_begin = (int)task_list.size();
-      task_list.insert(task_list.end(), kv.second.begin(), kv.second.end());
+      task_list.insert(task_list.end(), blk_obs[b].begin(), blk_obs[b].end());
       T.list_end = (int)task_list.size();
       T.out = gpart_size;
       gpart_size += 27;
       tasks.push_back(T);
+      blk_obs[b].clear();
     }
     for (auto& kv : cross) {
       Task T;
