@@ -107,3 +107,27 @@ def test_window_validate_rejects_bad_input():
     w.obs_lm = w.obs_lm.copy(); w.obs_lm[3] = 10**6
     with pytest.raises(ValueError):
         w.validate()
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    # the drop-in boundary is a C ABI: the header must compile as strict C99 and the library link from a C program
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text(
+        '#include "okvis_amd_ba.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "  okvis_ba_options o; okvis_ba_limits l; okvis_ba_solver* s = 0;\n"
+        "  okvis_ba_default_options(&o); okvis_ba_get_limits(&l);\n"
+        "  int rc = okvis_ba_create(&s, 0);\n"
+        '  printf("%d %d %d %s\\n", okvis_ba_abi_version(), (int)l.max_reduced_dim, rc, okvis_ba_error_string(rc));\n'
+        "  if (rc == 0) okvis_ba_destroy(s);\n"
+        "  return 0;\n}\n")
+    libdir = os.path.join(ROOT, "okvis_amd", "lib")
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-lokvis_amd_ba", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)]).decode().split(None, 3)
+    assert int(out[0]) == 3 and int(out[1]) == 900
+    import torch
+    if not torch.cuda.is_available():
+        assert int(out[2]) == -4 and "no CPU path" in out[3]      # fails loudly without a GPU
