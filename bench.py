@@ -160,7 +160,15 @@ def main():
         # the IMU / prior factors run inside the linearise launch (first workgroups of its grid): one kernel, one row
         prof["linearize"] += prof.pop("small")
         nbytes["linearize"] += nbytes.pop("small")
-        dom = max(prof, key=lambda k: prof[k])
+        # dominant kernel = most GPU time, i.e. launch time x the share of the 256 CUs the launch fills (the solve
+        # kernel runs ONE workgroup per window on one CU each: at 64 windows it lasts as long as the linearise launch
+        # but occupies a quarter of the device; which of the two has the longer wall time flips from box to box)
+        st = solver.check_window(wins[0])
+        n_cu, wg_per_cu = 256, 2
+        share = {"solve": min(1.0, a.windows / n_cu),
+                 "linearize": min(1.0, (st["n_group"] + a.keyframes) * a.windows / (n_cu * wg_per_cu)),
+                 "schur": min(1.0, st["n_chunk"] * a.windows / (n_cu * wg_per_cu))}
+        dom = max(prof, key=lambda k: prof[k] * share[k])
         per_launch_s = prof[dom] * 1e-3 / a.profile_steps
         achieved = nbytes[dom] / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
         pmc = None if (a.no_pmc or world > 1) else pmc_traffic(a, dom)
@@ -169,8 +177,9 @@ def main():
                     "traffic_detail": pmc,
                     "algorithmic_bytes_per_launch": nbytes[dom], "avg_launch_us": per_launch_s * 1e6,
                     "per_kernel_us": {k: v * 1e3 / a.profile_steps for k, v in prof.items()},
-                    "per_kernel_algorithmic_bytes": nbytes,
-                    "note": "achieved = algorithmic bytes of the dominant kernel / its mean launch time; the batch is "
+                    "per_kernel_algorithmic_bytes": nbytes, "per_kernel_cu_share": share,
+                    "note": "dominant kernel = largest launch time x share of the CUs it fills; "
+                            "achieved = algorithmic bytes of the dominant kernel / its mean launch time; the batch is "
                             "bound by fp64 issue + LDS reductions, one window alone by launch latency (DESIGN.md §5)"}
     summaries = batch.finish()
 
