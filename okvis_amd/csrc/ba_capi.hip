@@ -113,6 +113,7 @@ struct okvis_ba_solver {
   unsigned char* d_arena = nullptr;
   size_t arena_bytes = 0, arena_capacity = 0, wins_capacity = 0;
   WinPtrs* d_wins = nullptr;
+  StageVec stage_dl;             // pinned staging of result downloads (okvis_ba_marginalize)
   StageVec stage, stage_small;   // pinned staging of the arena's data part / of the WinPtrs + OptD records (kept across uploads)
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
@@ -1584,15 +1585,21 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   HIP_TRY(hipGetLastError());
   od.marg_mode = 0;
   HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
+  // H | J | b0 | e0 are contiguous on the device: one copy into page-locked staging (+ the info record), one sync
   int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(info, d + o_info, sizeof(info), hipMemcpyDeviceToHost, s->stream));
-  if (na > 0) {
-    HIP_TRY(hipMemcpyAsync(res->H, ma.out_H, 8 * (size_t)na * na, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(res->J, ma.out_J, 8 * (size_t)na * na, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(res->b0, ma.out_b0, 8 * (size_t)na, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(res->e0, ma.out_e0, 8 * (size_t)na, hipMemcpyDeviceToHost, s->stream));
-  }
+  const size_t out_bytes = 8 * (2 * nn + 2 * n1);
+  s->stage_dl.resize(out_bytes + sizeof(info));
+  HIP_TRY(hipMemcpyAsync(s->stage_dl.data() + out_bytes, d + o_info, sizeof(info), hipMemcpyDeviceToHost, s->stream));
+  if (na > 0) HIP_TRY(hipMemcpyAsync(s->stage_dl.data(), outp, out_bytes, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  std::memcpy(info, s->stage_dl.data() + out_bytes, sizeof(info));
+  if (na > 0) {
+    const double* h = reinterpret_cast<const double*>(s->stage_dl.data());
+    std::memcpy(res->H, h, 8 * (size_t)na * na);
+    std::memcpy(res->J, h + nn, 8 * (size_t)na * na);
+    std::memcpy(res->b0, h + 2 * nn, 8 * (size_t)na);
+    std::memcpy(res->e0, h + 2 * nn + n1, 8 * (size_t)na);
+  }
   if (info[0] != na) return OKVIS_BA_ERR_NUMERIC;
   res->dim = na;
   res->nblocks = (int)bt.size();
