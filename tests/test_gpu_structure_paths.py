@@ -94,3 +94,11 @@ def test_low_visibility_large_groups_and_custom_chunks(oracle):
     w = synthetic.make_window(6, 300, 0.3, seed=48)
     for per in (0, 16, 100, 1000):                          # Schur workgroup size: default, small, > 64, clamped
         _compare(oracle, w, 6, schur_lm_per_block=per)
+
+
+@pytest.mark.parametrize("K,ext,expect_lds", [(11, "fixed", True), (10, "shared", True), (11, "shared", False)])
+def test_around_the_lds_solve_limit(oracle, K, ext, expect_lds):
+    # D = 165 and 162 (block matrix still LDS resident: 28 / 27 block columns) and D = 177 (first size on the tiled path)
+    w = synthetic.make_window(K, 80, 0.7, seed=77, frame_dt=0.2, estimate_extrinsics=ext)
+    assert (solver.check_window(w)["D"] <= 174) == expect_lds
+    _compare(oracle, w, 8)
