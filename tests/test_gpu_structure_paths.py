@@ -102,3 +102,17 @@ def test_around_the_lds_solve_limit(oracle, K, ext, expect_lds):
     w = synthetic.make_window(K, 80, 0.7, seed=77, frame_dt=0.2, estimate_extrinsics=ext)
     assert (solver.check_window(w)["D"] <= 174) == expect_lds
     _compare(oracle, w, 8)
+
+
+def test_window_without_observations(oracle):
+    # IMU factors and priors only: no linearise groups, no Schur chunks (n_chunk = 0), the solve kernel alone
+    w = synthetic.small_window(seed=5, K=4, L=10)
+    for n in ("obs_lm", "obs_pose", "obs_ext", "obs_cam", "obs_uv", "obs_sqrtw"):
+        setattr(w, n, getattr(w, n)[:0])
+    b = _batch([w])
+    sg = b.optimize(6)[0]
+    sr = oracle.OracleWindow(w).optimize(6)
+    assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-9 * max(sr["final_cost"], 1e-3)
+    assert (sg["iterations"], sg["successful_steps"]) == (sr["iterations"], sr["successful_steps"])
+    assert np.array_equal(b.get_state()[2], w.lm)          # unobserved landmarks do not move
+    b.close()
