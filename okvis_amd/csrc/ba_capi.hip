@@ -896,6 +896,9 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_tiles_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             CT_SMEM_DOUBLES * 8);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&marg_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            MARG_LDS_DOUBLES * 8);
 
   if (e != hipSuccess) {
     int code = OKVIS_BA_HIP_ERROR_BASE + (int)e;
@@ -1572,14 +1575,6 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   ma.out_b0 = outp + 2 * nn;
   ma.out_e0 = outp + 2 * nn + n1;
   ma.out_info = reinterpret_cast<int*>(d + o_info);
-  {
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(marg_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  MARG_LDS_DOUBLES * 8));
-      attr_set = true;
-    }
-  }
   hipLaunchKernelGGL(marg_dense_kernel, dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES * 8, s->stream, d_win, 0, ma,
                      MARG_LDS_DOUBLES);
   HIP_TRY(hipGetLastError());

@@ -1,4 +1,5 @@
-import sys, time; sys.path.insert(0, '/root/repo')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
 w = synthetic.small_window(seed=9, K=8, L=350, visibility=0.8)

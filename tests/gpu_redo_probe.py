@@ -1,5 +1,6 @@
 """Diagnostic (not a test): how often does ImuError's re-preintegration trigger fire in the bench loop?"""
-import sys; sys.path.insert(0, '/root/repo')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
