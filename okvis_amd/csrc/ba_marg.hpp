@@ -212,6 +212,166 @@ __device__ __forceinline__ double marg_rsqrt(double x) {  // v_rsq_f64 + two New
   return y;
 }
 
+// Second fast path, for a matrix that IS rank deficient (the prior that stays behind after a marginalisation
+// typically has a null space of dimension 3): Cholesky with diagonal pivoting  Pi^T A Pi = [L11; L21][L11; L21]^T + R.
+// It is taken only if the numerical rank is unambiguous with respect to the reference's truncation threshold
+// tau = eps n lambda_max, using the bounds
+//   * the r leading pivots:   lambda_r(A) >= lambda_min(A11) >= 1 / ||L11^-1||_F^2     (Cauchy interlacing),
+//   * the rest:               lambda_(r+1)(A) <= (1 + ||L21 L11^-1||_F)^2 trace(R)      (Ostrowski, A = C diag(A11, R) C^T),
+//   * the threshold itself:   eps n max_i A_ii <= tau <= eps n max_i sum_j |A_ij| =: tau_hi.
+// The kept eigenvalues are PROVEN to lie above every possible threshold (> 4 tau_hi).  The remainder R of a
+// rank-deficient matrix is rounding noise of the size of tau itself (measured: trace(R) = 1e-14 .. 3e-13 for
+// tau = 1e-14 .. 6e-14), so "below tau" cannot be proven for the dropped ones; required instead: bound < 1e3 tau_hi
+// AND a gap of at least 100 to the smallest kept eigenvalue.  NUMERICAL POLICY (the one place where this backend may
+// decide differently from the reference): an eigen-direction with lambda in (tau, 1e3 tau) — information below
+// 1e-11 of the strongest direction — that is separated from the rest by two decades is dropped here, kept there.  Then
+// A_r = M M^T with M = Pi [L11; L21] differs from the reference's truncated eigen-sum by O(eps n lambda_max), and J, e0
+// follow from M instead of the eigen-pairs (same J^T J, same J^T e0 up to that order).  B: n x n, stride n, full
+// symmetric storage (destroyed: the lower trapezoid becomes L); X: n x n scratch (X11 = L11^-1, row-major).
+// Returns the rank, or -1 when the bounds do not decide (the caller then runs the Jacobi eigen-solver).
+__device__ int marg_pivoted_chol(double* B, double* X, int n, int* perm, double* red, int tid) {
+  const double EPS = 2.220446049250313e-16;
+  __shared__ double s_pv, s_dmax, s_rowmax, s_acc[2];
+  __shared__ int s_piv, s_rank;
+  // threshold bracket
+  double dm = 0.0, rs = 0.0;
+  if (tid < n) {
+    dm = B[tid * n + tid];
+    for (int c = 0; c < n; ++c) rs += fabs(B[tid * n + c]);
+    perm[tid] = tid;
+  }
+  dm = wave_max(dm);
+  rs = wave_max(rs);
+  if ((tid & 63) == 0) {
+    red[tid >> 6] = dm;
+    red[MARG_THREADS / 64 + (tid >> 6)] = rs;
+  }
+  if (tid == 0) s_rank = n;
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0, b = 0;
+    for (int i = 0; i < MARG_THREADS / 64; ++i) {
+      a = fmax(a, red[i]);
+      b = fmax(b, red[MARG_THREADS / 64 + i]);
+    }
+    s_dmax = a;
+    s_rowmax = b;
+  }
+  __syncthreads();
+  const double tau_lo = EPS * n * s_dmax, tau_hi = EPS * n * s_rowmax;
+  for (int k = 0; k < n; ++k) {
+    if (tid < 64) {  // pivot = largest remaining diagonal entry (lowest index among equals)
+      double best = -1.0;
+      int bi = k;
+      for (int i = k + tid; i < n; i += 64) {
+        const double v = B[i * n + i];
+        if (v > best) {
+          best = v;
+          bi = i;
+        }
+      }
+      const double m = wave_max_full(best);
+      const unsigned long long mask = __ballot(best == m);
+      const int src = __ffsll((long long)mask) - 1;
+      const int idx = __shfl(bi, src, 64);
+      if (tid == 0) {
+        s_pv = m;
+        s_piv = idx;
+      }
+    }
+    __syncthreads();
+    if (!(s_pv > 16.0 * tau_hi)) {  // everything that is left is a candidate for truncation
+      if (tid == 0) s_rank = k;
+      break;
+    }
+    const int piv = s_piv;
+    if (piv != k) {  // symmetric interchange on the full storage: rows, then columns
+      for (int j = tid; j < n; j += MARG_THREADS) {
+        const double t = B[k * n + j];
+        B[k * n + j] = B[piv * n + j];
+        B[piv * n + j] = t;
+      }
+      __syncthreads();
+      for (int i = tid; i < n; i += MARG_THREADS) {
+        const double t = B[i * n + k];
+        B[i * n + k] = B[i * n + piv];
+        B[i * n + piv] = t;
+      }
+      if (tid == 0) {
+        const int t = perm[k];
+        perm[k] = perm[piv];
+        perm[piv] = t;
+      }
+      __syncthreads();
+    }
+    const double l = sqrt(B[k * n + k]);
+    __syncthreads();
+    for (int i = k + 1 + tid; i < n; i += MARG_THREADS) {
+      const double v = B[i * n + k] / l;
+      B[i * n + k] = v;
+      B[k * n + i] = v;
+    }
+    if (tid == 0) B[k * n + k] = l;
+    __syncthreads();
+    const int mrem = n - k - 1;
+    for (int idx = tid; idx < mrem * mrem; idx += MARG_THREADS) {
+      const int i = k + 1 + idx / mrem, j = k + 1 + idx % mrem;
+      B[i * n + j] -= B[i * n + k] * B[j * n + k];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const int r = s_rank;
+  if (r == 0) return -1;
+  // X11 = L11^-1, one column per work-item (forward substitution)
+  for (int j = tid; j < r; j += MARG_THREADS) {
+    X[j * n + j] = 1.0 / B[j * n + j];
+    for (int i = j + 1; i < r; ++i) {
+      double sacc = 0.0;
+      for (int m = j; m < i; ++m) sacc += B[i * n + m] * X[m * n + j];
+      X[i * n + j] = -sacc / B[i * n + i];
+    }
+  }
+  __syncthreads();
+  // ||X11||_F^2, ||L21 X11||_F^2, trace(R)
+  double xf = 0.0, wf = 0.0, tr = 0.0;
+  for (int idx = tid; idx < r * r; idx += MARG_THREADS) {
+    const int i = idx / r, j = idx - i * r;
+    if (j <= i) xf += X[i * n + j] * X[i * n + j];
+  }
+  for (int idx = tid; idx < (n - r) * r; idx += MARG_THREADS) {
+    const int i = r + idx / r, t = idx % r;
+    double w = 0.0;
+    for (int m = t; m < r; ++m) w += B[i * n + m] * X[m * n + t];
+    wf += w * w;
+  }
+  for (int i = r + tid; i < n; i += MARG_THREADS) tr += fmax(B[i * n + i], 0.0);
+  xf = wave_sum(xf);
+  wf = wave_sum(wf);
+  tr = wave_sum(tr);
+  if ((tid & 63) == 0) {
+    red[tid >> 6] = xf;
+    red[MARG_THREADS / 64 + (tid >> 6)] = wf;
+    red[2 * (MARG_THREADS / 64) + (tid >> 6)] = tr;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0, b = 0, c = 0;
+    for (int i = 0; i < MARG_THREADS / 64; ++i) {
+      a += red[i];
+      b += red[MARG_THREADS / 64 + i];
+      c += red[2 * (MARG_THREADS / 64) + i];
+    }
+    const double lam_kept = 1.0 / a;                       // <= lambda_r(A)
+    const double cw = 1.0 + sqrt(b);
+    const double lam_dropped = cw * cw * c;                // >= lambda_(r+1)(A)
+    (void)tau_lo;
+    s_acc[0] = (lam_kept > 4.0 * tau_hi && lam_dropped < 1.0e3 * tau_hi && lam_kept > 100.0 * lam_dropped) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  return s_acc[0] != 0.0 ? r : -1;
+}
+
 // Fast path of the two symmetric decompositions.  The reference eigen-decomposes the pre-scaled matrix and drops
 // the eigenvalues <= eps * n * lambda_max.  If NO eigenvalue is that small the pseudo-inverse is the inverse and
 // any square root serves, so a Cholesky factor L and L^-1 replace the eigen-pairs (J and e0 are only defined up
@@ -382,7 +542,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   __shared__ int s_na, s_nm, s_cflag;
   __shared__ double s_max;
   __shared__ JacobiTab jt;
-  __shared__ double s_dinv[MAX_D_LDS + 6], s_red[MARG_THREADS / 64];
+  __shared__ double s_dinv[MAX_D_LDS + 6], s_red[MARG_THREADS / 64], s_red_big[3 * (MARG_THREADS / 64)];
   const double EPS = 2.220446049250313e-16;
 
   // ---- previous prior: H_ and b0_ persist inside the reference's MarginalizationError object ----
@@ -566,6 +726,40 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
         return;
       }
     }
+  }
+  if (2 * na * na <= lds_doubles) {   // rank-deficient prior with an unambiguous numerical rank: pivoted Cholesky
+    double* Bp = marg_lds;
+    double* Xq = marg_lds + na * na;
+    int* perm = s_midx;   // (the eliminated-index list is not needed any more)
+    int* pos = s_ridx;    // (neither is the index map of the previous prior; MAX_MARG_DIM >= MAX_D_LDS)
+    __syncthreads();
+    for (int k = tid; k < na * na; k += MARG_THREADS) {
+      const int i = k / na, j = k - i * na;
+      Bp[k] = 0.5 * (Ha[i * na + j] + Ha[j * na + i]) / (s_p[i] * s_p[j]);
+    }
+    __syncthreads();
+    const int r = marg_pivoted_chol(Bp, Xq, na, perm, s_red_big, tid);
+    if (r > 0) {
+      if (tid < na) pos[perm[tid]] = tid;
+      __syncthreads();
+      for (int k = tid; k < na * na; k += MARG_THREADS) {   // J = [M^T; 0] P with M = Pi [L11; L21]
+        const int t = k / na, j = k - t * na;
+        a.out_J[k] = (t < r && pos[j] >= t) ? Bp[pos[j] * na + t] * s_p[j] : 0.0;
+      }
+      for (int t = tid; t < na; t += MARG_THREADS) {        // e0 = -[L11^-1 (Pi^T P^-1 b0)_(1..r); 0]
+        double sacc = 0.0;
+        if (t < r)
+          for (int m = 0; m <= t; ++m) sacc += Xq[t * na + m] * (s_ba[perm[m]] / s_p[perm[m]]);
+        a.out_e0[t] = t < r ? -sacc : 0.0;
+      }
+      if (tid == 0) {
+        a.out_info[2] = r;
+        a.out_info[3] = sweeps_v;
+        a.out_info[4] = 0;
+      }
+      return;
+    }
+    __syncthreads();
   }
   pick(na, &A, &Q);
   for (int k = tid; k < na * na; k += MARG_THREADS) {

@@ -86,6 +86,21 @@ def test_rank_deficient_landmark(oracle):
     check(g, r)
 
 
+@pytest.mark.parametrize("seed", [51, 52, 53])
+def test_gauge_deficient_kept_block_takes_pivoted_cholesky(oracle, seed):
+    """Without the first-pose prior the kept block is singular along the gauge directions (what every prior of the
+    running pipeline looks like): rank < dim, same rank as the reference's eigen truncation, and the rank-r factor
+    comes from the pivoted-Cholesky path (no Jacobi sweep for the kept block)."""
+    w = synthetic.small_window(seed=seed, K=5, L=40)
+    w.pprior_pose = np.zeros(0, np.int32); w.pprior_meas = np.zeros((0, 7)); w.pprior_sqrtinfo = np.zeros((0, 36))
+    pm, sm = flags(w, [0], [0])
+    g, r = both(oracle, w, pm, sm)
+    assert r["rank"] < r["dim"]
+    check(g, r)
+    assert g["sweeps"][1] == 0
+    assert np.all(g["J"][g["rank"]:] == 0.0) and np.all(g["e0"][g["rank"]:] == 0.0)
+
+
 def test_config_A_size(oracle):
     """Everything an applyMarginalizationStrategy call of the stock pipeline could hand over, and more: 400
     landmarks / 8000 observations / D = 150, two poses and five speed/bias blocks eliminated."""
