@@ -56,6 +56,7 @@ struct ImuLds {
   static constexpr int CB_STRIDE = 70;
   static constexpr int TOTAL = CB + CB_STRIDE * IMU_N;
 };
+typedef double imu_v4 __attribute__((ext_vector_type(4)));
 enum { CB_A1 = 0, CB_DT = 9, CB_DPT = 10, CB_B012 = 19, CB_DTC1 = 28, CB_SKI = 37, CB_DVT = 46, CB_CINT = 55, CB_NOISE = 64, CB_ZERO = 69 };
 // compact LDS layout of the evaluate kernel (no re-preintegration scratch): J | F | e | cache copy
 struct EvalLds {
@@ -454,111 +455,88 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
     }
     __syncthreads();
     RSTAMP(6);
-    // ---- stage 8: covariance recursion over this chunk.  Work-item -> matrix entry mapping: every wave owns
-    //      ONE row type in the first phase (T = F P) and ONE column type in the second (P = T F^T + Q), so no
-    //      wave executes more than one branch of the sparse F:  wave 0: p rows/cols (45 entries), wave 1: v,
-    //      wave 2: alpha, wave 3 + the spare lanes of waves 0/1: the 90 bias entries (plain copies).
-    int r1 = -1, c1i = 0, r2 = -1, c2i = 0;  // (row, col) of this work-item in phase 1 / phase 2
-    {
-      const int t = tid & 63, wv = tid >> 6;
-      int be = -1;  // index into the 90 bias entries
-      if (wv < 3 && t < 45) {
-        const int base = (wv == 0) ? 0 : (wv == 1 ? 6 : 3);
-        r1 = base + t / 15; c1i = t % 15;
-        r2 = t / 3; c2i = base + t % 3;
-      } else if (wv == 3) {
-        be = t;
-      } else if (wv == 0 && t >= 45) {
-        be = 64 + (t - 45);           // 64 .. 82
-      } else if (wv == 1 && t >= 45 && t < 52) {
-        be = 83 + (t - 45);           // 83 .. 89
-      }
-      if (be >= 0) {
-        r1 = 9 + be / 15; c1i = be % 15;   // bias rows
-        r2 = be / 6; c2i = 9 + be % 6;     // bias columns
-      }
-    }
-    // Every entry is  own + sum_t coefficient[t] * entry[t]  with at most ten terms (same order of the terms as the
-    // block-wise expressions they replace); the term lists depend only on the entry, the loop over the steps is
-    // straight-line code: 2 x (10 coefficient reads + 10 entry reads + 10 FMAs) and two barriers per step.
-    int co1[10], xo1[10], co2[10], xo2[10], noff = CB_ZERO;
-    const int own1 = r1 >= 0 ? 15 * r1 + c1i : 0, own2 = r2 >= 0 ? 15 * r2 + c2i : 0;
+    // ---- stage 8: covariance recursion over this chunk on the fp64 matrix core, ONE wave, no barrier and no LDS
+    //      round trip inside the chain.  P (15x15 padded to 16x16) lives in the accumulator layout of
+    //      v_mfma_f64_16x16x4_f64 (lane l, register r = entry [(l >> 4) + 4 r][l & 15]).  Feeding register r of a
+    //      matrix U in that layout as the A operand and register r of V as the B operand of the r-th k-block gives
+    //      sum_k U[k][m] V[k][n] = (U^T V)[m][n], again in accumulator layout.  With G = F^T:
+    //          Z = P^T G = (F P)^T,     P' = Z^T G + Q = F P F^T + Q          (ImuError.cpp:228-249)
+    //      so the recursion never leaves the registers and needs no transposition (and no symmetry assumption).
+    //      F = I + N with the 3x3 blocks of the coefficient record of the step; every lane fetches its four entries of
+    //      G (and its noise entry, if it holds a diagonal element) through per-lane offsets into that record.
+    if ((tid >> 6) == 0) {
+      const int col = tid & 15, rb = tid >> 4;
+      int go[4], qo[4];
+      double one[4];
 #pragma unroll
-    for (int t = 0; t < 10; ++t) {
-      co1[t] = CB_ZERO; xo1[t] = own1;
-      co2[t] = CB_ZERO; xo2[t] = own2;
-    }
-    if (r1 >= 0 && r1 < 3) {
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        co1[3 * m] = CB_A1 + 3 * r1 + m;       xo1[3 * m] = 15 * (3 + m) + c1i;
-        co1[3 * m + 1] = CB_DPT + 3 * r1 + m;  xo1[3 * m + 1] = 15 * (9 + m) + c1i;
-        co1[3 * m + 2] = CB_B012 + 3 * r1 + m; xo1[3 * m + 2] = 15 * (12 + m) + c1i;
-      }
-      co1[9] = CB_DT; xo1[9] = 15 * (6 + r1) + c1i;
-    } else if (r1 >= 3 && r1 < 6) {
-#pragma unroll
-      for (int m = 0; m < 3; ++m) { co1[m] = CB_DTC1 + 3 * (r1 - 3) + m; xo1[m] = 15 * (9 + m) + c1i; }
-    } else if (r1 >= 6 && r1 < 9) {
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        co1[3 * m] = CB_SKI + 3 * (r1 - 6) + m;      xo1[3 * m] = 15 * (3 + m) + c1i;
-        co1[3 * m + 1] = CB_DVT + 3 * (r1 - 6) + m;  xo1[3 * m + 1] = 15 * (9 + m) + c1i;
-        co1[3 * m + 2] = CB_CINT + 3 * (r1 - 6) + m; xo1[3 * m + 2] = 15 * (12 + m) + c1i;
-      }
-    }
-    if (r2 >= 0) {   // (T F^T)_ij = T_ij + sum_m T_im N_jm: row c2i of the coefficients against row r2 of T
-      if (c2i < 3) {
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          co2[3 * m] = CB_A1 + 3 * c2i + m;       xo2[3 * m] = 15 * r2 + 3 + m;
-          co2[3 * m + 1] = CB_DPT + 3 * c2i + m;  xo2[3 * m + 1] = 15 * r2 + 9 + m;
-          co2[3 * m + 2] = CB_B012 + 3 * c2i + m; xo2[3 * m + 2] = 15 * r2 + 12 + m;
+      for (int r = 0; r < 4; ++r) {
+        const int i = col, j = rb + 4 * r;   // G[j][i] = F[i][j]
+        int o = CB_ZERO;
+        if (i < 3) {
+          if (j >= 3 && j < 6) o = CB_A1 + 3 * i + (j - 3);
+          else if (j == 6 + i) o = CB_DT;
+          else if (j >= 9 && j < 12) o = CB_DPT + 3 * i + (j - 9);
+          else if (j >= 12 && j < 15) o = CB_B012 + 3 * i + (j - 12);
+        } else if (i < 6) {
+          if (j >= 9 && j < 12) o = CB_DTC1 + 3 * (i - 3) + (j - 9);
+        } else if (i < 9) {
+          if (j >= 3 && j < 6) o = CB_SKI + 3 * (i - 6) + (j - 3);
+          else if (j >= 9 && j < 12) o = CB_DVT + 3 * (i - 6) + (j - 9);
+          else if (j >= 12 && j < 15) o = CB_CINT + 3 * (i - 6) + (j - 12);
         }
-        co2[9] = CB_DT; xo2[9] = 15 * r2 + 6 + c2i;
-      } else if (c2i < 6) {
+        go[r] = o;
+        one[r] = (i == j && i < 15) ? 1.0 : 0.0;
+        qo[r] = (i == j && i < 15) ? CB_NOISE + i / 3 : CB_ZERO;
+      }
+      imu_v4 Pc;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) { co2[m] = CB_DTC1 + 3 * (c2i - 3) + m; xo2[m] = 15 * r2 + 9 + m; }
-      } else if (c2i < 9) {
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb + 4 * r;
+        Pc[r] = (row < 15 && col < 15) ? P[15 * row + col] : 0.0;
+      }
+      const double* cb = lds + ImuLds::CB;
+      double g[4], q[4];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          co2[3 * m] = CB_SKI + 3 * (c2i - 6) + m;      xo2[3 * m] = 15 * r2 + 3 + m;
-          co2[3 * m + 1] = CB_DVT + 3 * (c2i - 6) + m;  xo2[3 * m + 1] = 15 * r2 + 9 + m;
-          co2[3 * m + 2] = CB_CINT + 3 * (c2i - 6) + m; xo2[3 * m + 2] = 15 * r2 + 12 + m;
+      for (int r = 0; r < 4; ++r) {
+        g[r] = cb[go[r]] + one[r];
+        q[r] = cb[qo[r]];
+      }
+      for (int k = 0; k < ns; ++k) {
+        double gn[4], qn[4];   // next step's coefficients, requested before this step's chain starts
+        const double* cbn = cb + ImuLds::CB_STRIDE * (k + 1 < ns ? k + 1 : k);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gn[r] = cbn[go[r]];
+          qn[r] = cbn[qo[r]];
+        }
+        asm volatile("" ::: "memory");   // (keeps the reads above the chain: hipcc otherwise sinks them to their first use)
+        // two accumulator chains of two k-blocks each per product: a dependent v_mfma_f64_16x16x4 costs ~114 cycles,
+        // an independent one 64
+        const imu_v4 zero = {0.0, 0.0, 0.0, 0.0};
+        imu_v4 Za = __builtin_amdgcn_mfma_f64_16x16x4f64(Pc[0], g[0], zero, 0, 0, 0);
+        imu_v4 Zb = __builtin_amdgcn_mfma_f64_16x16x4f64(Pc[2], g[2], zero, 0, 0, 0);
+        Za = __builtin_amdgcn_mfma_f64_16x16x4f64(Pc[1], g[1], Za, 0, 0, 0);
+        Zb = __builtin_amdgcn_mfma_f64_16x16x4f64(Pc[3], g[3], Zb, 0, 0, 0);
+        const imu_v4 Z = Za + Zb;
+        const imu_v4 qv = {q[0], q[1], q[2], q[3]};
+        imu_v4 Pa = __builtin_amdgcn_mfma_f64_16x16x4f64(Z[0], g[0], qv, 0, 0, 0);
+        imu_v4 Pb = __builtin_amdgcn_mfma_f64_16x16x4f64(Z[2], g[2], zero, 0, 0, 0);
+        Pa = __builtin_amdgcn_mfma_f64_16x16x4f64(Z[1], g[1], Pa, 0, 0, 0);
+        Pb = __builtin_amdgcn_mfma_f64_16x16x4f64(Z[3], g[3], Pb, 0, 0, 0);
+        Pc = Pa + Pb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          g[r] = gn[r] + one[r];
+          q[r] = qn[r];
         }
       }
-      if (r2 == c2i) noff = CB_NOISE + (r2 < 3 ? 0 : (r2 < 6 ? 1 : (r2 < 9 ? 2 : (r2 < 12 ? 3 : 4))));   // (ImuError.cpp:228-249)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb + 4 * r;
+        if (row < 15 && col < 15) P[15 * row + col] = Pc[r];
+      }
     }
-    for (int k = 0; k < ns; ++k) {
-      const double* cb = lds + ImuLds::CB + ImuLds::CB_STRIDE * k;
-      if (r1 >= 0) {
-        double cv[10], xv[10];
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {   // all twenty operands requested before the first is used: one LDS round trip
-          cv[t] = cb[co1[t]];
-          xv[t] = P[xo1[t]];
-        }
-        double v = P[own1];
-#pragma unroll
-        for (int t = 0; t < 10; ++t) v += cv[t] * xv[t];
-        T[own1] = v;
-      }
-      __syncthreads();
-      if (r2 >= 0) {
-        double cv[10], xv[10];
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {
-          cv[t] = cb[co2[t]];
-          xv[t] = T[xo2[t]];
-        }
-        const double nz = cb[noff];
-        double v = T[own2];
-#pragma unroll
-        for (int t = 0; t < 10; ++t) v += cv[t] * xv[t];
-        P[own2] = v + nz;
-      }
-      __syncthreads();
-    }
+    __syncthreads();
     RSTAMP(7);
     // ---- stage 7: running totals (ordered sums, one work-item per component); the carries of the prefix arrays
     //      move from index ns to index 0
