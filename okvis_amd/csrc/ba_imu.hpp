@@ -535,26 +535,24 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
         const int row = rb + 4 * r;
         if (row < 15 && col < 15) P[15 * row + col] = Pc[r];
       }
-    }
-    __syncthreads();
-    RSTAMP(7);
-    // ---- stage 7: running totals (ordered sums, one work-item per component); the carries of the prefix arrays
-    //      move from index ns to index 0
-    {
+    } else {
+      // ---- stage 7, by the other waves while wave 0 runs the recursion (disjoint LDS regions): running totals (ordered
+      //      sums, one work-item per component); the carries of the prefix arrays move from index ns to index 0
+      const int u = tid - 64;
       int base_i = -1, stride = 0;
       double* tot = nullptr;
-      if (tid < 9) { base_i = ImuLds::CDBL + tid; stride = 9; tot = t_Cdbl + tid; }
-      else if (tid < 12) { base_i = ImuLds::ADBL + (tid - 9); stride = 3; tot = t_adbl + (tid - 9); }
-      else if (tid < 21) { base_i = ImuLds::DAL + (tid - 12); stride = 9; tot = t_dal + (tid - 12); }
-      else if (tid < 30) { base_i = ImuLds::RINV + (tid - 21); stride = 9; tot = t_dp + (tid - 21); }
+      if (u < 9) { base_i = ImuLds::CDBL + u; stride = 9; tot = t_Cdbl + u; }
+      else if (u < 12) { base_i = ImuLds::ADBL + (u - 9); stride = 3; tot = t_adbl + (u - 9); }
+      else if (u < 21) { base_i = ImuLds::DAL + (u - 12); stride = 9; tot = t_dal + (u - 12); }
+      else if (u < 30) { base_i = ImuLds::RINV + (u - 21); stride = 9; tot = t_dp + (u - 21); }
       if (base_i >= 0) {
         double add = 0;
         for (int k = 0; k < ns; ++k) add += lds[base_i + stride * k];
         *tot += add;
       }
-      if (tid >= 32 && tid < 36) c_Dq[tid - 32] = lds[ImuLds::DQP + 4 * ns + (tid - 32)];
-      if (tid >= 64 && tid < 73) {
-        const int c = tid - 64;
+      if (u >= 32 && u < 36) c_Dq[u - 32] = lds[ImuLds::DQP + 4 * ns + (u - 32)];
+      if (u >= 64 && u < 73) {
+        const int c = u - 64;
         lds[ImuLds::CINTP + c] = lds[ImuLds::CINTP + 9 * ns + c];
         lds[ImuLds::CROSSP + c] = lds[ImuLds::CROSSP + 9 * ns + c];
         lds[ImuLds::DVP + c] = lds[ImuLds::DVP + 9 * ns + c];
@@ -562,6 +560,7 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
       }
     }
     __syncthreads();
+    RSTAMP(7);
     RSTAMP(8);
     if (s_finished) break;
   }
