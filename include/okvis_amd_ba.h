@@ -329,9 +329,12 @@ typedef struct okvis_ba_marg_result {
   int32_t* block_off;                     /* [capacity_blocks] */
   double* H;                              /* [dim][dim] row-major, packed with leading dimension dim */
   double* b0;                             /* [dim] */
-  double* J;                              /* [dim][dim]: J^T J = H up to the dropped eigenvalues */
+  double* J;                              /* [dim][dim]: J^T J = H up to the dropped eigenvalues; defined up to an
+                                             orthogonal transformation of its rows (eigen form, or a (pivoted)
+                                             Cholesky factor with zero rows below the rank) */
   double* e0;                             /* [dim] */
-  int32_t sweeps[2];                      /* out (diagnostic): Jacobi sweeps of the two eigen-decompositions */
+  int32_t sweeps[2];                      /* out (diagnostic): Jacobi sweeps of the two decompositions (0 = a Cholesky
+                                             path decided the rank) */
 } okvis_ba_marg_result;
 
 int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* result);

@@ -48,7 +48,7 @@ def main():
     out = [run("pipeline-like", synthetic.small_window(seed=9, K=6, L=150, visibility=0.8), [0], [0, 1]),
            run("configs[1]-sized", synthetic.config_A(), [0, 1], [0, 1, 2, 3, 4], reps=10)]
     print(json.dumps({"marginalize": out, "note": "gpu = whole okvis_ba_marginalize call (linearise + landmark Schur + "
-                      "dense elimination + 2 Jacobi eigen-decompositions + download), window already uploaded; "
+                      "dense elimination + the two decompositions (Cholesky / pivoted Cholesky / Jacobi, see jacobi_sweeps) + download), window already uploaded; "
                       "cpu = oracle restatement on the full dense matrix, 1 thread, not Eigen"}))
 
 
