@@ -38,6 +38,15 @@ __device__ __forceinline__ T quad_sum(T v) {
   return v;
 }
 
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  // 1/sqrt(d): hardware estimate + two Newton steps (short dependency chain, no fp64 divide / sqrt macro)
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+
 // Whole-wave reductions on the VALU: two quad permutes, row_half_mirror (0x141) and row_mirror (0x140) leave every
 // lane with the total of its row of 16, four v_readlane combine the rows.  ALL 64 LANES MUST BE ACTIVE.  Every lane
 // obtains the same bits; ~25 instructions instead of six ds_bpermute round trips (the butterfly of wave_sum).

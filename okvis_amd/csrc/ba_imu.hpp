@@ -78,18 +78,24 @@ __device__ __forceinline__ void st9(double* p, int k, const double* o) {
   for (int i = 0; i < 9; ++i) p[9 * k + i] = o[i];
 }
 
-// in-place Cholesky of a 15x15 SPD matrix in LDS by 225 work-items (A row-major, lower triangle = L)
-__device__ __forceinline__ void chol15(double* A, int e) {
-  const int i = e / 15, j = e % 15;
+// Cholesky of a 15x15 SPD matrix by ONE wave.  Lane j (< 15) holds column j of the full symmetric matrix in c[0..14].
+// Step k: the pivot column is read from lane k with v_readlane (wave-uniform l_i = A_ik / sqrt(A_kk)); the lane's own
+// L_jk is its entry of row k (= A_jk by symmetry, the whole trailing matrix is kept up to date), so the update
+// c_i -= l_i L_jk needs nothing else.  Lane t >= k stores L_tk to out[rs t + cs k]; invd[k] = 1 / L_kk on every lane.
+__device__ __forceinline__ void chol15_wave(double (&c)[15], double (&invd)[15], double* out, int rs, int cs, int lane, bool act) {
+#pragma unroll
   for (int k = 0; k < 15; ++k) {
-    __syncthreads();
-    if (e == 16 * k) A[e] = sqrt(A[e]);
-    __syncthreads();
-    if (e < 225 && j == k && i > k) A[e] /= A[16 * k];
-    __syncthreads();
-    if (e < 225 && j > k && i >= j) A[e] -= A[15 * i + k] * A[15 * j + k];
+    const double d = readlane_f64(c[k], k);
+    const double inv = rsqrt_nr(d > 0.0 ? d : 1.0);
+    invd[k] = inv;
+    const double mine = c[k] * inv;   // L_jk for lanes j >= k
+    if (act && lane >= k) out[rs * lane + cs * k] = mine;
+#pragma unroll
+    for (int i = k + 1; i < 15; ++i) {
+      const double li = readlane_f64(c[i], k) * inv;
+      c[i] -= li * mine;
+    }
   }
-  __syncthreads();
 }
 
 // diagnostics (debug_arrays): cycles per stage of the re-preintegration of factor 0, accumulated over the chunks
@@ -580,33 +586,51 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
   if (tid < 4) ca[CA_DQ + tid] = c_Dq[tid];
   __syncthreads();
   RSTAMP(9);
-  // ---- stage 9: information = sym(P)^-1, sqrtInfo = chol(sym(information))^T  (ImuError.cpp:268-279)
-  if (tid < 225) T[tid] = 0.5 * P[15 * pi + pj] + 0.5 * P[15 * pj + pi];
+  // ---- stage 9: information = sym(P)^-1, sqrtInfo = chol(sym(information))^T  (ImuError.cpp:268-279), by ONE wave
+  //      without barriers: lane j holds column j of the (full, symmetric) matrix in registers; a right-looking
+  //      Cholesky step reads the pivot column through v_readlane (wave-uniform values), the lane's own entry of the
+  //      pivot ROW is its L_jk by symmetry, and every lane updates the rest of its column (see chol15_wave).
+  if (tid < 225) ca[CA_SI + tid] = 0.0;   // the strictly lower part of sqrtInfo
   __syncthreads();
-  chol15(T, tid);  // T lower = L
-  // Linv (lower) into P: column c solved by work-item c
-  if (tid < 225) P[tid] = 0.0;
-  __syncthreads();
-  if (tid < 15) {
-    const int cidx = tid;
-    for (int i = cidx; i < 15; ++i) {
-      double s = (i == cidx) ? 1.0 : 0.0;
-      for (int m = cidx; m < i; ++m) s -= T[15 * i + m] * P[15 * m + cidx];
-      P[15 * i + cidx] = s / T[15 * i + i];
+  if ((tid >> 6) == 0) {
+    const int j = tid < 15 ? tid : 14;    // (lanes 15..63 shadow lane 14 and never store)
+    const bool act = tid < 15;
+    double c[15], invd[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) c[i] = 0.5 * P[15 * i + j] + 0.5 * P[15 * j + i];
+    chol15_wave(c, invd, T, 15, 1, tid, act);          // T[15 i + k] = L_ik
+    __builtin_amdgcn_wave_barrier();
+    // X = L^-1, column j by lane j:  x_i = ((i == j) - sum_{m < i} L_im x_m) / L_ii  (zero above the diagonal by itself)
+    double x[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+      double lrow[15];
+#pragma unroll
+      for (int m = 0; m < i; ++m) lrow[m] = T[15 * i + m];   // wave-uniform addresses
+      double sacc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+      for (int m = 0; m < i; ++m) sacc -= lrow[m] * x[m];
+      x[i] = sacc * invd[i];
     }
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+#pragma unroll
+      for (int m = 0; m < 15; ++m) P[15 * m + j] = x[m];     // P := X (lower triangular)
+    }
+    __builtin_amdgcn_wave_barrier();
+    // information = X^T X: column j on lane j, info_ij = sum_{m >= max(i,j)} X_mi X_mj  (x_m = 0 for m < j)
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+      double xc[15];
+#pragma unroll
+      for (int m = i; m < 15; ++m) xc[m] = P[15 * m + i];    // wave-uniform addresses
+      double sacc = 0.0;
+#pragma unroll
+      for (int m = i; m < 15; ++m) sacc += xc[m] * x[m];
+      c[i] = sacc;
+    }
+    chol15_wave(c, invd, ca + CA_SI, 1, 15, tid, act);  // sqrtInfo = L^T: entry (k, t) = L_tk
   }
-  __syncthreads();
-  // information = Linv^T Linv (symmetric by construction)
-  double info = 0;
-  if (tid < 225) {
-    const int lo = pi > pj ? pi : pj;
-    for (int m = lo; m < 15; ++m) info += P[15 * m + pi] * P[15 * m + pj];
-  }
-  __syncthreads();
-  if (tid < 225) T[tid] = info;
-  __syncthreads();
-  chol15(T, tid);
-  if (tid < 225) ca[CA_SI + 15 * pi + pj] = (pj >= pi) ? T[15 * pj + pi] : 0.0;  // upper = L^T
   __syncthreads();
   // ---- write the cache back to HBM
   ImuCacheD* cg = W.imu_cache + f;

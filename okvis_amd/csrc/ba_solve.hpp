@@ -61,14 +61,6 @@ __device__ __forceinline__ void add_small_factor(double* S, const SLayout LY, do
 
 // in-register Cholesky of a 6x6 SPD block given its lower triangle L[i][j] (i >= j); returns false if
 // a pivot is not positive.  inv[k] = 1 / L[k][k].
-__device__ __forceinline__ double rsqrt_nr(double d) {
-  // 1/sqrt(d): hardware estimate + two Newton steps (short dependency chain, no fp64 divide / sqrt macro)
-  double y = __builtin_amdgcn_rsq(d);
-  const double h = 0.5 * d;
-  y = y * (1.5 - h * y * y);
-  y = y * (1.5 - h * y * y);
-  return y;
-}
 __device__ __forceinline__ bool chol6(double (&L)[6][6], double (&inv)[6]) {
   // right-looking: after each pivot the remaining lower triangle is updated at once (independent FMAs),
   // so the chain per pivot is rsqrt -> scale -> update, not a k-long dependent sum
