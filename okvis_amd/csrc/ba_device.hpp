@@ -54,6 +54,14 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
                           __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// sum over the 16 lanes of a DPP row (all of them obtain it; all 16 must be active)
+__device__ __forceinline__ double row16_sum(double v) {
+  v += quad_xchg<0xB1>(v);
+  v += quad_xchg<0x4E>(v);
+  v += quad_xchg<0x141>(v);
+  v += quad_xchg<0x140>(v);
+  return v;
+}
 __device__ __forceinline__ double wave_sum_full(double v) {
   v += quad_xchg<0xB1>(v);
   v += quad_xchg<0x4E>(v);

@@ -121,7 +121,6 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
   const double bg[3] = {sb0[3], sb0[4], sb0[5]}, ba[3] = {sb0[6], sb0[7], sb0[8]};
   double* P = lds + ImuLds::PM;
   double* T = lds + ImuLds::TM;
-  const int pi = tid / 15, pj = tid % 15;
   if (tid == 0) {
     s_next_it = 0;
     s_started = 0;

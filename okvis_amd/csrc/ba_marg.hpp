@@ -17,6 +17,7 @@
 namespace ba {
 
 constexpr int MARG_THREADS = 1024;
+constexpr int MARG_PC_NMAX = 96;     // largest matrix of the pivoted-Cholesky path (two n x n matrices in LDS)
 constexpr int MARG_LDS_DOUBLES = 18 * 1024;  // 144 KB of dynamic LDS for the eigen-solver buffers
 
 struct MargArgs {
@@ -229,10 +230,10 @@ __device__ __forceinline__ double marg_rsqrt(double x) {  // v_rsq_f64 + two New
 // follow from M instead of the eigen-pairs (same J^T J, same J^T e0 up to that order).  B: n x n, stride n, full
 // symmetric storage (destroyed: the lower trapezoid becomes L); X: n x n scratch (X11 = L11^-1, row-major).
 // Returns the rank, or -1 when the bounds do not decide (the caller then runs the Jacobi eigen-solver).
-__device__ int marg_pivoted_chol(double* B, double* X, int n, int* perm, double* red, int tid) {
+__device__ int marg_pivoted_chol(double* B, double* X, int n, int* perm, double* rsc, double* red, int tid, double* prof) {
+#define PSTAMP(k) do { if (prof && tid == 0) prof[k] = (double)clock64(); } while (0)
   const double EPS = 2.220446049250313e-16;
-  __shared__ double s_pv, s_dmax, s_rowmax, s_acc[2];
-  __shared__ int s_piv, s_rank;
+  __shared__ double s_dmax, s_rowmax, s_acc[2];
   // threshold bracket
   double dm = 0.0, rs = 0.0;
   if (tid < n) {
@@ -246,7 +247,6 @@ __device__ int marg_pivoted_chol(double* B, double* X, int n, int* perm, double*
     red[tid >> 6] = dm;
     red[MARG_THREADS / 64 + (tid >> 6)] = rs;
   }
-  if (tid == 0) s_rank = n;
   __syncthreads();
   if (tid == 0) {
     double a = 0, b = 0;
@@ -259,92 +259,138 @@ __device__ int marg_pivoted_chol(double* B, double* X, int n, int* perm, double*
   }
   __syncthreads();
   const double tau_lo = EPS * n * s_dmax, tau_hi = EPS * n * s_rowmax;
+  PSTAMP(9);
+  // Elimination WITHOUT interchanges and with ONE barrier per pivot: the matrix stays in place, a pivot only retires
+  // its row and column.  Every wave finds the pivot for itself (same data, same result), every work-item owns up to
+  // PC_Q fixed entries (i, j) of the full symmetric storage and updates those whose row and column are still alive:
+  //   B_ij -= B_i,piv B_j,piv / d     (column piv is dead from now on, so it keeps the UNSCALED l_i sqrt(d))
+  // The factor is gathered into the permuted trapezoid afterwards:  L_ab = B[perm a][perm b] / sqrt(d_b).
+  constexpr int PC_Q = (MARG_PC_NMAX * MARG_PC_NMAX + MARG_THREADS - 1) / MARG_THREADS;   // n <= MARG_PC_NMAX (caller)
+  int eij[PC_Q];
+  unsigned alive = 0u;
+#pragma unroll
+  for (int q = 0; q < PC_Q; ++q) {
+    const int idx = q * MARG_THREADS + tid;
+    const int i = idx / n, j = idx - i * n;
+    eij[q] = (i << 8) | j;
+    if (idx < n * n) alive |= 1u << q;
+  }
+  const int lane = tid & 63;
+  const int nq = (n * n + MARG_THREADS - 1) / MARG_THREADS;
+  unsigned own = 0u;            // bit t: diagonal entry lane + 64 t has been a pivot (every wave keeps its own copy)
+  int r = n;
   for (int k = 0; k < n; ++k) {
-    if (tid < 64) {  // pivot = largest remaining diagonal entry (lowest index among equals)
-      double best = -1.0;
-      int bi = k;
-      for (int i = k + tid; i < n; i += 64) {
+    double best = -1.0;
+    int bi = 0;
+#pragma unroll
+    for (int t = 0; t < (MARG_PC_NMAX + 63) / 64; ++t) {
+      const int i = lane + 64 * t;
+      if (i < n && !((own >> t) & 1u)) {
         const double v = B[i * n + i];
         if (v > best) {
           best = v;
           bi = i;
         }
       }
-      const double m = wave_max_full(best);
-      const unsigned long long mask = __ballot(best == m);
-      const int src = __ffsll((long long)mask) - 1;
-      const int idx = __shfl(bi, src, 64);
-      if (tid == 0) {
-        s_pv = m;
-        s_piv = idx;
-      }
     }
-    __syncthreads();
-    if (!(s_pv > 16.0 * tau_hi)) {  // everything that is left is a candidate for truncation
-      if (tid == 0) s_rank = k;
+    const double m = wave_max_full(best);
+    const unsigned long long mask = __ballot(best == m);
+    const int piv = __shfl(bi, __ffsll((long long)mask) - 1, 64);
+    if (!(m > 16.0 * tau_hi)) {  // everything that is left is a candidate for truncation
+      r = k;
       break;
     }
-    const int piv = s_piv;
-    if (piv != k) {  // symmetric interchange on the full storage: rows, then columns
-      for (int j = tid; j < n; j += MARG_THREADS) {
-        const double t = B[k * n + j];
-        B[k * n + j] = B[piv * n + j];
-        B[piv * n + j] = t;
-      }
-      __syncthreads();
-      for (int i = tid; i < n; i += MARG_THREADS) {
-        const double t = B[i * n + k];
-        B[i * n + k] = B[i * n + piv];
-        B[i * n + piv] = t;
-      }
-      if (tid == 0) {
-        const int t = perm[k];
-        perm[k] = perm[piv];
-        perm[piv] = t;
-      }
-      __syncthreads();
+    if ((piv & 63) == lane) own |= 1u << (piv >> 6);
+    const double rs = marg_rsqrt(m);
+    const double invd = rs * rs;
+    if (tid == 0) {
+      perm[k] = piv;
+      rsc[k] = rs;             // 1 / sqrt(d_k)
     }
-    const double l = sqrt(B[k * n + k]);
-    __syncthreads();
-    for (int i = k + 1 + tid; i < n; i += MARG_THREADS) {
-      const double v = B[i * n + k] / l;
-      B[i * n + k] = v;
-      B[k * n + i] = v;
-    }
-    if (tid == 0) B[k * n + k] = l;
-    __syncthreads();
-    const int mrem = n - k - 1;
-    for (int idx = tid; idx < mrem * mrem; idx += MARG_THREADS) {
-      const int i = k + 1 + idx / mrem, j = k + 1 + idx % mrem;
-      B[i * n + j] -= B[i * n + k] * B[j * n + k];
+#pragma unroll
+    for (int q = 0; q < PC_Q; ++q) {
+      if (q < nq) {
+        const int i = eij[q] >> 8, j = eij[q] & 255;
+        if (i == piv || j == piv) alive &= ~(1u << q);
+        if ((alive >> q) & 1u) B[i * n + j] -= B[i * n + piv] * B[j * n + piv] * invd;
+      }
     }
     __syncthreads();
   }
+  PSTAMP(10);
+  // the permutation is completed with the indices that never became a pivot (ascending), then the gather
+  if (tid < 64) {
+    int cnt = r;
+#pragma unroll
+    for (int t = 0; t < (MARG_PC_NMAX + 63) / 64; ++t) {
+      const int i = lane + 64 * t;
+      const bool left = i < n && !((own >> t) & 1u);
+      const unsigned long long mk = __ballot(left);
+      if (left) perm[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = i;
+      cnt += __popcll(mk);
+    }
+  }
   __syncthreads();
-  const int r = s_rank;
+  {
+    double val[PC_Q];
+#pragma unroll
+    for (int q = 0; q < PC_Q; ++q) {
+      const int a_ = eij[q] >> 8, b_ = eij[q] & 255;
+      val[q] = 0.0;
+      if (q * MARG_THREADS + tid < n * n) {
+        if (b_ < r && a_ >= b_) val[q] = B[perm[a_] * n + perm[b_]] * rsc[b_];
+        else if (a_ == b_) val[q] = B[perm[a_] * n + perm[a_]];          // remainder diagonal (trace R)
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PC_Q; ++q)
+      if (q * MARG_THREADS + tid < n * n) B[(eij[q] >> 8) * n + (eij[q] & 255)] = val[q];
+  }
+  __syncthreads();
   if (r == 0) return -1;
-  // X11 = L11^-1, one column per work-item (forward substitution)
-  for (int j = tid; j < r; j += MARG_THREADS) {
-    X[j * n + j] = 1.0 / B[j * n + j];
-    for (int i = j + 1; i < r; ++i) {
-      double sacc = 0.0;
-      for (int m = j; m < i; ++m) sacc += B[i * n + m] * X[m * n + j];
-      X[i * n + j] = -sacc / B[i * n + i];
+  PSTAMP(11);
+  // X11 = L11^-1 by forward substitution, one column per group of 16 lanes (a DPP row): the column stays in registers
+  // (lane t of the group holds X_mj for m = j + t + 16 s), a row costs one batch of reads of L, <= PC_S FMAs and a
+  // four-step DPP sum; the same groups then form the rows of L21 X11.  ||X11||_F^2 and ||L21 X11||_F^2 on the fly.
+  constexpr int PC_S = (MARG_PC_NMAX + 15) / 16;
+  double xf = 0.0, wf = 0.0, tr = 0.0;
+  {
+    const int g = tid >> 4, t = tid & 15;
+    for (int j0 = 0; j0 < r; j0 += MARG_THREADS / 16) {   // (uniform trip count: the DPP sums need whole rows of lanes)
+      const int j = j0 + g;
+      const bool col = j < r;
+      double xr[PC_S];
+#pragma unroll
+      for (int sidx = 0; sidx < PC_S; ++sidx) xr[sidx] = 0.0;
+      for (int i = j0; i < n; ++i) {
+        double part = 0.0;
+#pragma unroll
+        for (int sidx = 0; sidx < PC_S; ++sidx) {
+          const int m = j + t + 16 * sidx;
+          const double bv = (col && m < i && m < r) ? B[i * n + m] : 0.0;
+          part += bv * xr[sidx];
+        }
+        const double tot = row16_sum(part);
+        if (col && i >= j) {
+          if (i < r) {
+            const double x = (i == j) ? rsc[j] : -tot * rsc[i];
+            const int d = i - j;
+            if ((d & 15) == t) {
+#pragma unroll
+              for (int sidx = 0; sidx < PC_S; ++sidx)
+                if (sidx == (d >> 4)) xr[sidx] = x;
+              X[i * n + j] = x;
+              xf += x * x;
+            }
+          } else if (t == 0) {
+            wf += tot * tot;
+          }
+        }
+      }
     }
   }
-  __syncthreads();
-  // ||X11||_F^2, ||L21 X11||_F^2, trace(R)
-  double xf = 0.0, wf = 0.0, tr = 0.0;
-  for (int idx = tid; idx < r * r; idx += MARG_THREADS) {
-    const int i = idx / r, j = idx - i * r;
-    if (j <= i) xf += X[i * n + j] * X[i * n + j];
-  }
-  for (int idx = tid; idx < (n - r) * r; idx += MARG_THREADS) {
-    const int i = r + idx / r, t = idx % r;
-    double w = 0.0;
-    for (int m = t; m < r; ++m) w += B[i * n + m] * X[m * n + t];
-    wf += w * w;
-  }
+  PSTAMP(12);
   for (int i = r + tid; i < n; i += MARG_THREADS) tr += fmax(B[i * n + i], 0.0);
   xf = wave_sum(xf);
   wf = wave_sum(wf);
@@ -544,6 +590,8 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   __shared__ JacobiTab jt;
   __shared__ double s_dinv[MAX_D_LDS + 6], s_red[MARG_THREADS / 64], s_red_big[3 * (MARG_THREADS / 64)];
   const double EPS = 2.220446049250313e-16;
+#define MSTAMP(k) do { if (W.prof && tid == 0) W.prof[k] = (double)clock64(); } while (0)   // diagnostics (debug_arrays)
+  MSTAMP(0);
 
   // ---- previous prior: H_ and b0_ persist inside the reference's MarginalizationError object ----
   for (int rr = tid; rr < a.prior_dim; rr += MARG_THREADS) {
@@ -586,6 +634,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
     if (s_ridx[rr] >= 0) b[s_ridx[rr]] += a.prior_b0[rr];
   __syncthreads();
   const int na = s_na, nm = s_nm;
+  MSTAMP(1);
   // eigen-solver buffers (matrix + eigenvectors): in LDS when they fit, else in the HBM workspace
   double* M = a.work + 2 * (size_t)D * D;
   auto pick = [&](int n, double** Xp, double** Qp) {
@@ -652,6 +701,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
       for (int k = tid; k < nm * nm; k += MARG_THREADS) Q[k] *= s_lam[k % nm];  // V^(+1/2) = Q diag(l^-1/2)
       __syncthreads();
     }
+    MSTAMP(2);
     for (int k = tid; k < na * nm; k += MARG_THREADS) {  // M = W V^(+1/2) (:729)
       const int i = k / nm, j = k - i * nm;
       const int ki = s_kidx[i];
@@ -693,6 +743,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
     return;
   }
 
+  MSTAMP(3);
   // ---- updateErrorComputation (:806-846) ----
   const double* Ha = a.out_H;
   for (int i = tid; i < na; i += MARG_THREADS) s_p[i] = Ha[i * na + i] > 1.0e-9 ? sqrt(Ha[i * na + i]) : 1.0e-3;
@@ -700,7 +751,8 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   int sweeps_h = 0;
   {  // Cholesky fast path: full rank proven -> J = L^T P, e0 = -L^-1 P^-1 b0 (J^T J = H, J^T e0 = -b0)
     const int np6 = ((na + 5) / 6) * 6;
-    if (2 * np6 * np6 <= lds_doubles) {
+    // (with a previous prior the kept block carries its gauge null space: straight to the pivoted factorisation)
+    if (2 * np6 * np6 <= lds_doubles && !(a.prior_dim > 0 && na <= MARG_PC_NMAX)) {
       double* Mp = marg_lds;
       double* Xp = marg_lds + np6 * np6;
       for (int k = tid; k < np6 * np6; k += MARG_THREADS) {
@@ -708,7 +760,10 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
         Mp[k] = (i < na && j < na) ? 0.5 * (Ha[i * na + j] + Ha[j * na + i]) / (s_p[i] * s_p[j]) : (i == j ? 1.0 : 0.0);
       }
       __syncthreads();
-      if (marg_chol_inverse(Mp, Xp, np6, na, s_dinv, a.work + 3 * (size_t)D * D, s_red, &s_cflag, tid)) {
+      MSTAMP(4);
+      const bool full = marg_chol_inverse(Mp, Xp, np6, na, s_dinv, a.work + 3 * (size_t)D * D, s_red, &s_cflag, tid);
+      MSTAMP(5);
+      if (full) {
         for (int k = tid; k < na * na; k += MARG_THREADS) {
           const int r = k / na, c = k - r * na;
           a.out_J[k] = (c >= r) ? Mp[c * np6 + r] * s_p[c] : 0.0;
@@ -723,11 +778,12 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
           a.out_info[3] = sweeps_v;
           a.out_info[4] = 0;
         }
+        MSTAMP(8);
         return;
       }
     }
   }
-  if (2 * na * na <= lds_doubles) {   // rank-deficient prior with an unambiguous numerical rank: pivoted Cholesky
+  if (2 * na * na <= lds_doubles && na <= MARG_PC_NMAX) {   // rank-deficient prior with an unambiguous numerical rank: pivoted Cholesky
     double* Bp = marg_lds;
     double* Xq = marg_lds + na * na;
     int* perm = s_midx;   // (the eliminated-index list is not needed any more)
@@ -738,7 +794,9 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
       Bp[k] = 0.5 * (Ha[i * na + j] + Ha[j * na + i]) / (s_p[i] * s_p[j]);
     }
     __syncthreads();
-    const int r = marg_pivoted_chol(Bp, Xq, na, perm, s_red_big, tid);
+    MSTAMP(6);
+    const int r = marg_pivoted_chol(Bp, Xq, na, perm, s_lam, s_red_big, tid, W.prof);
+    MSTAMP(7);
     if (r > 0) {
       if (tid < na) pos[perm[tid]] = tid;
       __syncthreads();
@@ -757,6 +815,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
         a.out_info[3] = sweeps_v;
         a.out_info[4] = 0;
       }
+      MSTAMP(8);
       return;
     }
     __syncthreads();
