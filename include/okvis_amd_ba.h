@@ -277,6 +277,12 @@ int okvis_ba_evaluate_cost(okvis_ba_solver* s, double* costs);
 /* Estimator::get_T_WS / getSpeedAndBias / getLandmark (Estimator.cpp:933-1200): copy the accepted state
  * of window w back; any pointer may be NULL. */
 int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, double* lm);
+/* Everything Estimator::optimize copies back after the solve (Estimator.cpp:880-906: landmark quality + estimates;
+ * plus the bias each ImuError cache was (re)built at, which the reference keeps inside the ImuError object) with ONE
+ * stream synchronisation: pose [n_pose][7], sb [n_sb][9], lm [n_lm][4], lm_quality [n_lm] (OKVIS_BA_ARR_LM_QUALITY),
+ * imu_sb_ref [n_imu][9] (OKVIS_BA_ARR_IMU_SB_REF); any pointer may be NULL. */
+int okvis_ba_fetch_results(okvis_ba_solver* s, int w, double* pose, double* sb, double* lm, double* lm_quality,
+                           double* imu_sb_ref);
 /* size (in doubles) and contents of an intermediate array of window w (parity tests) */
 int okvis_ba_array_size(okvis_ba_solver* s, int w, int which, int64_t* n_doubles);
 int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t n_doubles);

@@ -1086,6 +1086,36 @@ int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, doub
   return OKVIS_BA_OK;
 }
 
+int okvis_ba_fetch_results(okvis_ba_solver* s, int w, double* pose, double* sb, double* lm, double* lm_quality,
+                           double* imu_sb_ref) {
+  if (!s || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return s && !s->uploaded ? OKVIS_BA_ERR_STATE : OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = refresh_acc(s, w)) return rc;
+  HostWin& H = s->wins[w];
+  // all pieces go into page-locked staging back to back; one synchronisation, then plain copies to the caller
+  const size_t b_pose = pose ? 56 * (size_t)H.n_pose : 0, b_sb = sb ? 72 * (size_t)H.n_sb : 0, b_lm = lm ? 32 * (size_t)H.n_lm : 0;
+  const size_t b_q = lm_quality ? 8 * (size_t)H.n_lm : 0, b_ref = imu_sb_ref ? 72 * (size_t)H.n_imu : 0;
+  const size_t o_sb = b_pose, o_lm = o_sb + b_sb, o_q = o_lm + b_lm, o_ref = o_q + b_q, total = o_ref + b_ref;
+  if (total == 0) return OKVIS_BA_OK;
+  s->stage_dl.resize(total);
+  unsigned char* st = s->stage_dl.data();
+  if (b_pose) HIP_TRY(hipMemcpyAsync(st, H.ptrs.pose[H.acc], b_pose, hipMemcpyDeviceToHost, s->stream));
+  if (b_sb) HIP_TRY(hipMemcpyAsync(st + o_sb, H.ptrs.sb[H.acc], b_sb, hipMemcpyDeviceToHost, s->stream));
+  if (b_lm) HIP_TRY(hipMemcpyAsync(st + o_lm, H.ptrs.lm[H.acc], b_lm, hipMemcpyDeviceToHost, s->stream));
+  if (b_q) HIP_TRY(hipMemcpyAsync(st + o_q, H.ptrs.quality, b_q, hipMemcpyDeviceToHost, s->stream));
+  if (b_ref)
+    HIP_TRY(hipMemcpy2DAsync(st + o_ref, 9 * sizeof(double),
+                             reinterpret_cast<const unsigned char*>(H.ptrs.imu_cache) + offsetof(ImuCacheD, sb_ref), sizeof(ImuCacheD),
+                             9 * sizeof(double), (size_t)H.n_imu, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (b_pose) std::memcpy(pose, st, b_pose);
+  if (b_sb) std::memcpy(sb, st + o_sb, b_sb);
+  if (b_lm) std::memcpy(lm, st + o_lm, b_lm);
+  if (b_q) std::memcpy(lm_quality, st + o_q, b_q);
+  if (b_ref) std::memcpy(imu_sb_ref, st + o_ref, b_ref);
+  return OKVIS_BA_OK;
+}
+
 int okvis_ba_begin(okvis_ba_solver* s) {
   if (s) s->acc_fresh = false;
   if (!s) return OKVIS_BA_ERR_ARG;

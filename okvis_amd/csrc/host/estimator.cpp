@@ -600,15 +600,14 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
   // copy the estimates back (the reference's parameter blocks are updated in place by Ceres)
   const size_t nl = sel.landmarks.size();
   std::vector<double> pose(7 * sel.pose.size()), sb(9 * sel.sb.size()), lm(4 * nl), q(nl);
-  check(okvis_ba_get_state(solver_, 0, pose.data(), sb.data(), lm.data()), "get_state");
-  if (!q.empty()) check(okvis_ba_download(solver_, 0, OKVIS_BA_ARR_LM_QUALITY, q.data(), (int64_t)q.size()), "quality");
+  std::vector<double> ref(9 * sel.imu.size());
+  check(okvis_ba_fetch_results(solver_, 0, pose.data(), sb.data(), lm.data(), q.empty() ? nullptr : q.data(),
+                               ref.empty() ? nullptr : ref.data()), "fetch_results");
   for (size_t i = 0; i < sel.pose.size(); ++i)
     std::copy(pose.begin() + 7 * i, pose.begin() + 7 * i + 7, poseBlocks_[sel.pose[i]].x.begin());
   for (size_t i = 0; i < sel.sb.size(); ++i)
     std::copy(sb.begin() + 9 * i, sb.begin() + 9 * i + 9, sbBlocks_[sel.sb[i]].x.begin());
   if (!sel.imu.empty()) {  // the ImuError caches live on: remember the bias each one was (re)built at
-    std::vector<double> ref(9 * sel.imu.size());
-    check(okvis_ba_download(solver_, 0, OKVIS_BA_ARR_IMU_SB_REF, ref.data(), (int64_t)ref.size()), "imu sb_ref");
     for (size_t i = 0; i < sel.imu.size(); ++i) {
       ImuFactor& f = imuFactors_[sel.imu[i]];
       std::copy(ref.begin() + 9 * i, ref.begin() + 9 * i + 9, f.sbRef.begin());

@@ -125,6 +125,15 @@ class WindowBatch:
                                               lm.ctypes.data_as(_dp)), "get_state")
         return pose, sb, lm
 
+    def fetch_results(self, w: int = 0):
+        """okvis_ba_fetch_results: state, landmark quality and the IMU caches' reference biases with one synchronisation."""
+        W = self.windows[w]
+        pose, sb, lm = np.zeros((W.n_pose, 7)), np.zeros((W.n_sb, 9)), np.zeros((W.n_lm, 4))
+        q, ref = np.zeros(W.n_lm), np.zeros((W.n_imu, 9))
+        _lib.check(self._L.okvis_ba_fetch_results(self._h, w, pose.ctypes.data_as(_dp), sb.ctypes.data_as(_dp), lm.ctypes.data_as(_dp),
+                                                  q.ctypes.data_as(_dp), ref.ctypes.data_as(_dp)), "fetch_results")
+        return dict(pose=pose, sb=sb, lm=lm, quality=q, imu_sb_ref=ref)
+
     def set_state(self, w: int, pose=None, sb=None, lm=None):
         def p(a):
             return None if a is None else np.ascontiguousarray(a, np.float64)

@@ -116,3 +116,17 @@ def test_window_without_observations(oracle):
     assert (sg["iterations"], sg["successful_steps"]) == (sr["iterations"], sr["successful_steps"])
     assert np.array_equal(b.get_state()[2], w.lm)          # unobserved landmarks do not move
     b.close()
+
+
+def test_fetch_results_equals_the_single_downloads():
+    """okvis_ba_fetch_results (one synchronisation) returns what get_state + the two array downloads return."""
+    from okvis_amd import solver
+    w = synthetic.small_window(seed=71, K=5, L=40)
+    b = solver.WindowBatch([w], options=default_options())
+    b.optimize(4)
+    f = b.fetch_results(0)
+    pose, sb, lm = b.get_state(0)
+    assert np.array_equal(f["pose"], pose) and np.array_equal(f["sb"], sb) and np.array_equal(f["lm"], lm)
+    assert np.array_equal(f["quality"], b.array("LM_QUALITY"))
+    assert np.array_equal(f["imu_sb_ref"].ravel(), b.array("IMU_SB_REF"))
+    b.close()
