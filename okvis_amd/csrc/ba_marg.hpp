@@ -233,35 +233,24 @@ __device__ __forceinline__ double marg_rsqrt(double x) {  // v_rsq_f64 + two New
 __device__ int marg_pivoted_chol(double* B, double* X, int n, int* perm, double* rsc, double* red, int tid, double* prof) {
 #define PSTAMP(k) do { if (prof && tid == 0) prof[k] = (double)clock64(); } while (0)
   const double EPS = 2.220446049250313e-16;
-  __shared__ double s_dmax, s_rowmax, s_acc[2];
-  // threshold bracket
-  double dm = 0.0, rs = 0.0;
-  if (tid < n) {
-    dm = B[tid * n + tid];
+  __shared__ double s_rowmax, s_acc[2];
+  // upper end of the threshold bracket: eps n max_i sum_j |A_ij|
+  double rs = 0.0;
+  if (tid < n)
     for (int c = 0; c < n; ++c) rs += fabs(B[tid * n + c]);
-    perm[tid] = tid;
-  }
-  dm = wave_max(dm);
   rs = wave_max(rs);
-  if ((tid & 63) == 0) {
-    red[tid >> 6] = dm;
-    red[MARG_THREADS / 64 + (tid >> 6)] = rs;
-  }
+  if ((tid & 63) == 0) red[tid >> 6] = rs;
   __syncthreads();
   if (tid == 0) {
-    double a = 0, b = 0;
-    for (int i = 0; i < MARG_THREADS / 64; ++i) {
-      a = fmax(a, red[i]);
-      b = fmax(b, red[MARG_THREADS / 64 + i]);
-    }
-    s_dmax = a;
+    double b = 0;
+    for (int i = 0; i < MARG_THREADS / 64; ++i) b = fmax(b, red[i]);
     s_rowmax = b;
   }
   __syncthreads();
-  const double tau_lo = EPS * n * s_dmax, tau_hi = EPS * n * s_rowmax;
+  const double tau_hi = EPS * n * s_rowmax;
   PSTAMP(9);
   // Elimination WITHOUT interchanges and with ONE barrier per pivot: the matrix stays in place, a pivot only retires
-  // its row and column.  Every wave finds the pivot for itself (same data, same result), every work-item owns up to
+  // its row and column.  Every work-item owns up to
   // PC_Q fixed entries (i, j) of the full symmetric storage and updates those whose row and column are still alive:
   //   B_ij -= B_i,piv B_j,piv / d     (column piv is dead from now on, so it keeps the UNSCALED l_i sqrt(d))
   // The factor is gathered into the permuted trapezoid afterwards:  L_ab = B[perm a][perm b] / sqrt(d_b).
@@ -277,25 +266,29 @@ __device__ int marg_pivoted_chol(double* B, double* X, int n, int* perm, double*
   }
   const int lane = tid & 63;
   const int nq = (n * n + MARG_THREADS - 1) / MARG_THREADS;
+  // The pivot (largest remaining diagonal entry) is found by the owners of the diagonal entries themselves: after its
+  // update each publishes  (bits of max(d, 0) with the low 7 bits replaced by the index)  with a 64-bit LDS atomic max,
+  // which orders non-negative doubles like integers; the 128-ulp perturbation only touches the choice, the pivot value
+  // is read back from the matrix.  Three rotating slots: read k, publish k + 1, clear k + 2.
+  __shared__ unsigned long long s_key[3];
+  auto pkey = [](double v, int i) -> unsigned long long {
+    return ((unsigned long long)__double_as_longlong(fmax(v, 0.0)) & ~127ull) | (unsigned long long)i;
+  };
+  if (tid < 3) s_key[tid] = 0ull;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PC_Q; ++q) {
+    if (q < nq && ((alive >> q) & 1u)) {
+      const int i = eij[q] >> 8, j = eij[q] & 255;
+      if (i == j) atomicMax(&s_key[0], pkey(B[i * n + i], i));
+    }
+  }
+  __syncthreads();
   unsigned own = 0u;            // bit t: diagonal entry lane + 64 t has been a pivot (every wave keeps its own copy)
   int r = n;
   for (int k = 0; k < n; ++k) {
-    double best = -1.0;
-    int bi = 0;
-#pragma unroll
-    for (int t = 0; t < (MARG_PC_NMAX + 63) / 64; ++t) {
-      const int i = lane + 64 * t;
-      if (i < n && !((own >> t) & 1u)) {
-        const double v = B[i * n + i];
-        if (v > best) {
-          best = v;
-          bi = i;
-        }
-      }
-    }
-    const double m = wave_max_full(best);
-    const unsigned long long mask = __ballot(best == m);
-    const int piv = __shfl(bi, __ffsll((long long)mask) - 1, 64);
+    const int piv = (int)(s_key[k % 3] & 127ull);
+    const double m = B[piv * n + piv];
     if (!(m > 16.0 * tau_hi)) {  // everything that is left is a candidate for truncation
       r = k;
       break;
@@ -306,13 +299,20 @@ __device__ int marg_pivoted_chol(double* B, double* X, int n, int* perm, double*
     if (tid == 0) {
       perm[k] = piv;
       rsc[k] = rs;             // 1 / sqrt(d_k)
+      s_key[(k + 2) % 3] = 0ull;
     }
+    unsigned long long* nxt = &s_key[(k + 1) % 3];
+    const double* rowp = B + piv * n;
 #pragma unroll
     for (int q = 0; q < PC_Q; ++q) {
       if (q < nq) {
         const int i = eij[q] >> 8, j = eij[q] & 255;
         if (i == piv || j == piv) alive &= ~(1u << q);
-        if ((alive >> q) & 1u) B[i * n + j] -= B[i * n + piv] * B[j * n + piv] * invd;
+        if ((alive >> q) & 1u) {
+          const double v = B[i * n + j] - rowp[i] * rowp[j] * invd;   // row piv = column piv bit for bit, without the stride-n bank conflicts
+          B[i * n + j] = v;
+          if (i == j) atomicMax(nxt, pkey(v, i));
+        }
       }
     }
     __syncthreads();
@@ -411,11 +411,11 @@ __device__ int marg_pivoted_chol(double* B, double* X, int n, int* perm, double*
     const double lam_kept = 1.0 / a;                       // <= lambda_r(A)
     const double cw = 1.0 + sqrt(b);
     const double lam_dropped = cw * cw * c;                // >= lambda_(r+1)(A)
-    (void)tau_lo;
     s_acc[0] = (lam_kept > 4.0 * tau_hi && lam_dropped < 1.0e3 * tau_hi && lam_kept > 100.0 * lam_dropped) ? 1.0 : 0.0;
   }
   __syncthreads();
   return s_acc[0] != 0.0 ? r : -1;
+#undef PSTAMP
 }
 
 // Fast path of the two symmetric decompositions.  The reference eigen-decomposes the pre-scaled matrix and drops

@@ -131,3 +131,14 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     import torch
     if not torch.cuda.is_available():
         assert int(out[2]) == -4 and "no CPU path" in out[3]      # fails loudly without a GPU
+
+
+def test_null_solver_is_an_argument_error_everywhere():
+    """Entry points check their handle before touching the device (no GPU needed): OKVIS_BA_ERR_ARG = -1."""
+    L = _lib.lib()
+    assert L.okvis_ba_fetch_results(None, 0, None, None, None, None, None) == -1
+    assert L.okvis_ba_get_state(None, 0, None, None, None) == -1
+    assert L.okvis_ba_begin(None) == -1
+    assert L.okvis_ba_iterate(None, 1) == -1
+    assert L.okvis_ba_finish(None, None) == -1
+    assert L.okvis_ba_marginalize(None, 0, None, None) == -1
