@@ -1636,7 +1636,8 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
     res->block_idx[k] = bi[k];
     res->block_off[k] = bo[k];
   }
-  if (int rc2 = refresh_acc(s, w)) return rc2;
+  H.acc = info[5] & 1;   // read by marg_dense_kernel after the export: no separate copy + synchronisation
+  s->acc_fresh = true;
   return OKVIS_BA_OK;
 }
 

@@ -622,6 +622,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
     s_nm = nm;
     a.out_info[0] = na;
     a.out_info[1] = nm;
+    a.out_info[5] = W.ctrl->acc;   // accepted-buffer index after the export (saves the host a separate read)
     for (int i = 0; i < na; ++i) a.out_info[8 + i] = s_kidx[i];
   }
   __syncthreads();
