@@ -3,7 +3,8 @@
 // Converts the Eigen / OKVIS types of the reference's public signatures to the PODs of
 // okvis_amd::Estimator (estimator.hpp).  It can only be compiled where Eigen, OpenCV and the OKVIS headers
 // exist, which is NOT the case in the build container of this repository: everything below
-// the `__has_include` guard is therefore compile-checked only on a machine with those dependencies.
+// the `__has_include` guard is therefore compiled against the real headers only on a machine with those dependencies;
+// here it is compile-checked against stand-in declarations of that interface (tests/mock_okvis/, CPU test suite).
 // See INTEGRATION.md for how a maintainer wires it into okvis_ceres.
 #pragma once
 #include "estimator.hpp"

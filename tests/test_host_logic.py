@@ -3,7 +3,9 @@ declares, fails loudly without a GPU, and the structure building (what replaces 
 bookkeeping, reference okvis_ceres/src/Map.cpp:292-565) produces the documented ordering."""
 import ctypes as C
 import os
+import pathlib
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -142,3 +144,19 @@ def test_null_solver_is_an_argument_error_everywhere():
     assert L.okvis_ba_iterate(None, 1) == -1
     assert L.okvis_ba_finish(None, None) == -1
     assert L.okvis_ba_marginalize(None, 0, None, None) == -1
+
+
+def test_okvis_adapter_compiles_against_the_interface():
+    """okvis_estimator_adapter.hpp against stand-in declarations of the Eigen / OKVIS types it touches
+    (tests/mock_okvis/, signatures of the reference's VioBackendInterface.hpp:67-336 etc.): well-formed, every pure
+    virtual overridden with the exact signature (the class is instantiated), addObservation<> instantiates."""
+    import shutil
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = pathlib.Path(__file__).resolve().parents[1]
+    cmd = [gxx, "-std=c++17", "-Wall", "-Werror", "-c", "-o", os.devnull, "-I", str(root / "tests" / "mock_okvis"),
+           "-I", str(root / "include"), "-I", str(root / "okvis_amd" / "csrc" / "host"),
+           str(root / "tests" / "mock_okvis" / "adapter_check.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
