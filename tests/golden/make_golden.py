@@ -228,7 +228,10 @@ def window_vectors():
 
 MARG = [dict(seed=71, K=5, L=40, estimate_extrinsics="fixed", pose=[0], sb=[0, 1]),
         dict(seed=72, K=4, L=30, estimate_extrinsics="shared", pose=[0], sb=[0]),
-        dict(seed=73, K=4, L=24, estimate_extrinsics="perframe", pose=[0, 4, 5], sb=[0])]
+        dict(seed=73, K=4, L=24, estimate_extrinsics="perframe", pose=[0, 4, 5], sb=[0]),
+        # no first-pose prior: the kept block is singular along the gauge directions (rank < dim), as every prior of
+        # the running pipeline is — the case the GPU decides with its pivoted-Cholesky path
+        dict(seed=74, K=5, L=40, estimate_extrinsics="fixed", pose=[0], sb=[0], drop_pose_prior=True)]
 
 
 def marg_flags(w, kw):
@@ -237,16 +240,23 @@ def marg_flags(w, kw):
     return pm, sm
 
 
+def marg_window(kw):
+    """window + flags of one MARG case"""
+    kw = dict(kw)
+    pose, sb, drop = kw.pop("pose"), kw.pop("sb"), kw.pop("drop_pose_prior", False)
+    w = synthetic.small_window(**kw)
+    if drop:
+        w.pprior_pose = np.zeros(0, np.int32); w.pprior_meas = np.zeros((0, 7)); w.pprior_sqrtinfo = np.zeros((0, 36))
+    return w, marg_flags(w, dict(pose=pose, sb=sb))
+
+
 def marginalization_vectors():
     """MarginalizationError numerics: oracle output, cross-checked against the scipy-eigh statement."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_oracle_marginalization import numpy_marginalize
     out = {"n": np.int64(len(MARG))}
     for i, kw in enumerate(MARG):
-        kw = dict(kw)
-        pose, sb = kw.pop("pose"), kw.pop("sb")
-        w = synthetic.small_window(**kw)
-        pm, sm = marg_flags(w, dict(pose=pose, sb=sb))
+        w, (pm, sm) = marg_window(kw)
         r = O.OracleWindow(w).marginalize(pm, sm)
         Hn, bn = numpy_marginalize(O.OracleWindow(w), w, pm, sm)
         _agree(r["H"] / np.abs(Hn).max(), Hn / np.abs(Hn).max(), "marginalised H")
@@ -259,7 +269,7 @@ def marginalization_vectors():
         out[f"m{i}_Jte0"] = r["J"].T @ r["e0"]
         out[f"m{i}_rank"] = np.int64(r["rank"])
         out[f"m{i}_digest"] = np.array(window_digest(w))
-        print(f"  marginalisation {i}: {kw} pose {pose} sb {sb} -> dim {r['dim']} rank {r['rank']}")
+        print(f"  marginalisation {i}: {kw} -> dim {r['dim']} rank {r['rank']}")
     return out
 
 
