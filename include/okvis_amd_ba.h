@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OKVIS_BA_ABI_VERSION 3
+#define OKVIS_BA_ABI_VERSION 4
 
 /* status codes (0 ok; >0 = hipError_t passthrough + 1000; <0 = argument / state errors) */
 #define OKVIS_BA_OK 0
@@ -151,11 +151,15 @@ typedef struct okvis_ba_window {
 } okvis_ba_window;
 
 /*
- * Solver policy.  The reference configures Ceres 1.9 TRUST_REGION/DOGLEG/SPARSE_SCHUR with defaults
- * (Estimator.cpp:854-873); Ceres is not in the reference tree.  This backend runs a Schur-complement
- * Gauss-Newton with a Levenberg-Marquardt trust-region safeguard (Ceres' LevenbergMarquardtStrategy
- * semantics restated from its documentation; see DESIGN.md "solver policy").
+ * Solver policy.  The reference configures Ceres 1.9 TRUST_REGION / DOGLEG / SPARSE_SCHUR with defaults
+ * (Estimator.cpp:854-873: trust_region_strategy_type = DOGLEG, dogleg_type TRADITIONAL_DOGLEG, jacobi_scaling on);
+ * Ceres is not in the reference tree.  The default here is that policy, restated from Ceres' documentation / public
+ * sources (DESIGN.md "solver policy" lists what is unverified): traditional dogleg between the Cauchy point and the
+ * Gauss-Newton point of the Schur-reduced system in Jacobi-scaled, D-normalised variables.  The Levenberg-Marquardt
+ * safeguard of round 1 stays available as OKVIS_BA_STRATEGY_LM.
  */
+#define OKVIS_BA_STRATEGY_DOGLEG 0
+#define OKVIS_BA_STRATEGY_LM 1
 typedef struct okvis_ba_options {
   double initial_radius;        /* 1e4   */
   double max_radius;            /* 1e16  */
@@ -178,6 +182,12 @@ typedef struct okvis_ba_options {
   int32_t fp32_linearize;       /* BASELINE configs[4] (mixed-precision study): 1 = reprojection residuals, Jacobians
                                    and their J^T J / J^T r accumulation in fp32; state, Schur complement and the
                                    reduced solve stay fp64.  0 (default) = everything fp64 like the reference   */
+  int32_t strategy;             /* OKVIS_BA_STRATEGY_DOGLEG (default, what Estimator.cpp:858 configures) or _LM   */
+  int32_t jacobi_scaling;       /* 1 (default, Ceres Solver::Options::jacobi_scaling): columns scaled by
+                                   1/(1+sqrt(diag J^T J)) of the FIRST linearisation of the optimize() call;
+                                   dogleg strategy only                                                          */
+  int32_t max_consecutive_invalid_steps; /* 5 (Ceres max_num_consecutive_invalid_steps): then termination 5     */
+  int32_t reserved0;
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */

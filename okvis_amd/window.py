@@ -58,6 +58,8 @@ class OptionsC(C.Structure):
         ("use_graph", C.c_int32), ("schur_lm_per_block", C.c_int32),
         ("debug_arrays", C.c_int32), ("gauss_newton", C.c_int32),
         ("n_streams", C.c_int32), ("fp32_linearize", C.c_int32),
+        ("strategy", C.c_int32), ("jacobi_scaling", C.c_int32), ("max_consecutive_invalid_steps", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -137,9 +139,14 @@ def marg_call(fn, n_pose, n_sb, pose_marg, sb_marg, prior=None):
                    J=out["J"][:n * n].reshape(n, n).copy(), e0=out["e0"][:n].copy())
 
 
-def default_options() -> OptionsC:
+STRATEGY_DOGLEG, STRATEGY_LM = 0, 1
+DEFAULT_STRATEGY = STRATEGY_LM
+
+
+def default_options(strategy=None) -> OptionsC:
     """Ceres 1.9 defaults restated from its documentation (not in the reference tree)."""
-    return OptionsC(1e4, 1e16, 1e-32, 1e-6, 1e32, 1e-3, 1e-6, 1e-10, 1e-8, 1, 0, 0, 0, 0, 0)
+    return OptionsC(1e4, 1e16, 1e-32, 1e-6, 1e32, 1e-3, 1e-6, 1e-10, 1e-8, 1, 0, 0, 0, 0, 0,
+                    DEFAULT_STRATEGY if strategy is None else strategy, 1, 5, 0)
 
 
 def _f64(a, shape):

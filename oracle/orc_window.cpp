@@ -364,19 +364,14 @@ bool chol_solve(std::vector<double> A, int n, const std::vector<double>& b, std:
   return true;
 }
 
-// (H + lambda D^2) delta = -g via landmark Schur complement. Returns false if S is not PD.
-bool solve(orc_window* h, double radius, const okvis_ba_options& opt) {
+// (H + lambda Dd) delta = -g via landmark Schur complement, Dd = diag(h->Dp2, h->Dl2) given by the caller.
+// Returns false if S is not PD.
+bool solve_damped(orc_window* h, double lambda) {
   const int D = h->D;
-  const double lambda = 1.0 / radius;
   h->lambda = lambda;
-  const double dmin = opt.min_lm_diagonal * opt.min_lm_diagonal;
-  const double dmax = opt.max_lm_diagonal * opt.max_lm_diagonal;
-  h->Dp2.assign(D, 0.0);
-  h->Dl2.assign(3 * (size_t)h->n_lm, 0.0);
   h->S = h->U;
   h->rhs.assign(D, 0.0);
   for (int i = 0; i < D; ++i) {
-    h->Dp2[i] = clampd(h->U[(size_t)i * D + i], dmin, dmax);
     h->S[(size_t)i * D + i] += lambda * h->Dp2[i];
     h->rhs[i] = -h->g[i];
   }
@@ -384,9 +379,6 @@ bool solve(orc_window* h, double radius, const okvis_ba_options& opt) {
   for (int l = 0; l < h->n_lm; ++l) {
     double v[6];
     for (int e = 0; e < 6; ++e) v[e] = h->V[6 * l + e];
-    h->Dl2[3 * l + 0] = clampd(v[0], dmin, dmax);
-    h->Dl2[3 * l + 1] = clampd(v[3], dmin, dmax);
-    h->Dl2[3 * l + 2] = clampd(v[5], dmin, dmax);
     v[0] += lambda * h->Dl2[3 * l + 0];
     v[3] += lambda * h->Dl2[3 * l + 1];
     v[5] += lambda * h->Dl2[3 * l + 2];
@@ -430,6 +422,17 @@ bool solve(orc_window* h, double radius, const okvis_ba_options& opt) {
     h->step_l[3 * l + 2] = -(vi[2] * t[0] + vi[4] * t[1] + vi[5] * t[2]);
   }
   return true;
+}
+
+// LevenbergMarquardtStrategy: D^2 = clamp(diag J^T J, min_lm_diagonal, max_lm_diagonal), damping D^2 / radius
+bool solve(orc_window* h, double radius, const okvis_ba_options& opt) {
+  h->Dp2.assign(h->D, 0.0);
+  h->Dl2.assign(3 * (size_t)h->n_lm, 0.0);
+  for (int i = 0; i < h->D; ++i) h->Dp2[i] = clampd(h->U[(size_t)i * h->D + i], opt.min_lm_diagonal, opt.max_lm_diagonal);
+  static const int dg[3] = {0, 3, 5};
+  for (int l = 0; l < h->n_lm; ++l)
+    for (int k = 0; k < 3; ++k) h->Dl2[3 * l + k] = clampd(h->V[6 * l + dg[k]], opt.min_lm_diagonal, opt.max_lm_diagonal);
+  return solve_damped(h, 1.0 / radius);
 }
 
 void apply_step(orc_window* h, std::vector<double>* pose, std::vector<double>* sb, std::vector<double>* lm) {
@@ -589,6 +592,263 @@ void lm_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis_ba_
         s.termination = 4;
         done = true;
       }
+    }
+  }
+  s.final_cost = h->cost;
+  s.final_radius = radius;
+  landmark_quality(h);
+  if (sum) *sum = s;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// The reference's configured policy (Estimator.cpp:854-873): Ceres 1.9 TrustRegionMinimizer with
+// trust_region_strategy_type = DOGLEG (dogleg_type = TRADITIONAL_DOGLEG by default), jacobi_scaling = true,
+// linear solver SPARSE_SCHUR (exact: here the landmark Schur complement + dense Cholesky).  Ceres is not in the
+// reference tree; this follows its documented algorithm (trust_region_minimizer.cc / dogleg_strategy.cc of 1.9,
+// restated, not copied).  Written in UNSCALED variables; with s = Jacobi scale (from the first linearisation of
+// this call), h_i = diag(J^T J)_i and d_i = sqrt(clamp(s_i^2 h_i, min_lm_diagonal, max_lm_diagonal)) (Ceres'
+// `diagonal_` of the column-scaled Jacobian):
+//   gradient_ (D-normalised, scaled)      ghat_i  = s_i g_i / d_i
+//   Cauchy direction in unscaled space    xv_i    = s_i^2 g_i / d_i^2,  alpha = |ghat|^2 / |J xv|^2
+//   Gauss-Newton point                    (H + mu diag(d^2/s^2)) dGN = -g,   gnhat_i = d_i dGN_i / s_i
+//   step                                  delta = -cA xv + beta dGN  (dogleg interpolation in the hat space)
+// ---------------------------------------------------------------------------------------------------
+struct Full {  // a vector over [reduced pose/speed-bias part | 3 per landmark]
+  std::vector<double> p, l;
+};
+static double dotf(const Full& a, const Full& b) {
+  double s = 0;
+  for (size_t i = 0; i < a.p.size(); ++i) s += a.p[i] * b.p[i];
+  for (size_t i = 0; i < a.l.size(); ++i) s += a.l[i] * b.l[i];
+  return s;
+}
+// y = H x with H = [U W; W^T V] of the current linearisation
+static void hessian_times(const orc_window* h, const Full& x, Full* y) {
+  const int D = h->D;
+  y->p.assign(D, 0.0);
+  y->l.assign(3 * (size_t)h->n_lm, 0.0);
+  for (int i = 0; i < D; ++i) {
+    double s = 0;
+    for (int j = 0; j < D; ++j) s += h->U[(size_t)i * D + j] * x.p[j];
+    y->p[i] = s;
+  }
+  for (int l = 0; l < h->n_lm; ++l) {
+    const double* v = &h->V[6 * l];
+    const double* xl = &x.l[3 * l];
+    y->l[3 * l + 0] = v[0] * xl[0] + v[1] * xl[1] + v[2] * xl[2];
+    y->l[3 * l + 1] = v[1] * xl[0] + v[3] * xl[1] + v[4] * xl[2];
+    y->l[3 * l + 2] = v[2] * xl[0] + v[4] * xl[1] + v[5] * xl[2];
+    for (int pr = h->lm_pair_begin[l]; pr < h->lm_pair_begin[l + 1]; ++pr) {
+      const double* Wp = &h->W[18 * pr];  // 6x3 row-major block (pose block rows, landmark columns)
+      const int o = h->pose_off[h->pair_block[pr]];
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 3; ++j) {
+          y->p[o + i] += Wp[3 * i + j] * xl[j];
+          y->l[3 * l + j] += Wp[3 * i + j] * x.p[o + i];
+        }
+    }
+  }
+}
+// Ceres 1.9: gradient_max_norm = || x - Plus(x, -g) ||_inf over the ambient coordinates
+static double projected_gradient_max_norm(const orc_window* h) {
+  double m = 0;
+  for (int i = 0; i < h->n_pose; ++i)
+    if (h->pose_off[i] >= 0) {
+      double d[6], xp[7];
+      for (int k = 0; k < 6; ++k) d[k] = -h->g[h->pose_off[i] + k];
+      pose_plus(&h->pose[7 * i], d, xp);
+      for (int k = 0; k < 7; ++k) m = std::max(m, std::fabs(h->pose[7 * i + k] - xp[k]));
+    }
+  for (int i = 0; i < h->n_sb; ++i)
+    if (h->sb_off[i] >= 0)
+      for (int k = 0; k < 9; ++k) m = std::max(m, std::fabs(h->g[h->sb_off[i] + k]));
+  for (double v : h->b) m = std::max(m, std::fabs(v));
+  return m;
+}
+static double free_x_norm(const orc_window* h) {
+  double x2 = 0;
+  for (int i = 0; i < h->n_pose; ++i)
+    if (h->pose_off[i] >= 0)
+      for (int k = 0; k < 7; ++k) x2 += h->pose[7 * i + k] * h->pose[7 * i + k];
+  for (int i = 0; i < h->n_sb; ++i)
+    if (h->sb_off[i] >= 0)
+      for (int k = 0; k < 9; ++k) x2 += h->sb[9 * i + k] * h->sb[9 * i + k];
+  for (double v : h->lm) x2 += v * v;
+  return std::sqrt(x2);
+}
+
+void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis_ba_summary* sum) {
+  const double kMinMu = 1e-8, kMaxMu = 1.0, kMuIncrease = 10.0;  // DoglegStrategy constants
+  const int D = h->D, NL = 3 * h->n_lm;
+  static const int dg[3] = {0, 3, 5};
+  double radius = opt.initial_radius, mu = kMinMu;
+  bool reuse = false, gn_ok = false;
+  double alpha = 0, dogleg_step_norm = 0;
+  int invalid_steps = 0;
+  evaluate(h, true);
+  okvis_ba_summary s;
+  std::memset(&s, 0, sizeof(s));
+  s.initial_cost = h->cost;
+  // Jacobi scaling, estimated once (TrustRegionMinimizer: EstimateScale at the initial point only)
+  Full scale, dd, ghat, xv, gn, gnhat, step, g;
+  scale.p.assign(D, 1.0);
+  scale.l.assign(NL, 1.0);
+  if (opt.jacobi_scaling) {
+    for (int i = 0; i < D; ++i) scale.p[i] = 1.0 / (1.0 + std::sqrt(h->U[(size_t)i * D + i]));
+    for (int l = 0; l < h->n_lm; ++l)
+      for (int k = 0; k < 3; ++k) scale.l[3 * l + k] = 1.0 / (1.0 + std::sqrt(h->V[6 * l + dg[k]]));
+  }
+  s.gradient_max_norm = projected_gradient_max_norm(h);
+  bool done = false;
+  if (opt.gradient_tolerance > 0 && s.gradient_max_norm <= opt.gradient_tolerance) {
+    s.termination = 2;
+    done = true;
+  }
+  double x_norm = free_x_norm(h);
+  for (int it = 1; it <= num_iter && !done; ++it) {
+    s.iterations = it;
+    // ---------------- DoglegStrategy::ComputeStep ----------------
+    if (!reuse) {
+      reuse = true;
+      dd.p.assign(D, 0.0), dd.l.assign(NL, 0.0);
+      g.p = h->g, g.l = h->b;
+      for (int i = 0; i < D; ++i)
+        dd.p[i] = std::sqrt(clampd(scale.p[i] * scale.p[i] * h->U[(size_t)i * D + i], opt.min_lm_diagonal, opt.max_lm_diagonal));
+      for (int l = 0; l < h->n_lm; ++l)
+        for (int k = 0; k < 3; ++k)
+          dd.l[3 * l + k] = std::sqrt(clampd(scale.l[3 * l + k] * scale.l[3 * l + k] * h->V[6 * l + dg[k]],
+                                             opt.min_lm_diagonal, opt.max_lm_diagonal));
+      ghat = g, xv = g;
+      for (int i = 0; i < D; ++i) {
+        ghat.p[i] = scale.p[i] * g.p[i] / dd.p[i];
+        xv.p[i] = scale.p[i] * (ghat.p[i] / dd.p[i]);
+      }
+      for (int i = 0; i < NL; ++i) {
+        ghat.l[i] = scale.l[i] * g.l[i] / dd.l[i];
+        xv.l[i] = scale.l[i] * (ghat.l[i] / dd.l[i]);
+      }
+      // Cauchy point: alpha * -gradient_
+      Full Hxv;
+      hessian_times(h, xv, &Hxv);
+      alpha = dotf(ghat, ghat) / dotf(xv, Hxv);
+      // Gauss-Newton step, regularised by mu * diagonal_^2 (in scaled variables) until the factorisation succeeds
+      h->Dp2.assign(D, 0.0), h->Dl2.assign(NL, 0.0);
+      for (int i = 0; i < D; ++i) h->Dp2[i] = (dd.p[i] / scale.p[i]) * (dd.p[i] / scale.p[i]);
+      for (int i = 0; i < NL; ++i) h->Dl2[i] = (dd.l[i] / scale.l[i]) * (dd.l[i] / scale.l[i]);
+      gn_ok = false;
+      while (mu < kMaxMu) {
+        bool ok = solve_damped(h, mu);
+        if (ok) {
+          for (double v : h->step_p) ok = ok && std::isfinite(v);
+          for (double v : h->step_l) ok = ok && std::isfinite(v);
+        }
+        if (!ok) {
+          mu *= kMuIncrease;
+          continue;
+        }
+        gn_ok = true;
+        break;
+      }
+      if (gn_ok) {
+        gn.p = h->step_p, gn.l = h->step_l;
+        gnhat = gn;
+        for (int i = 0; i < D; ++i) gnhat.p[i] = dd.p[i] * gn.p[i] / scale.p[i];
+        for (int i = 0; i < NL; ++i) gnhat.l[i] = dd.l[i] * gn.l[i] / scale.l[i];
+      }
+    }
+    bool valid = gn_ok;
+    double model_change = 0;
+    if (gn_ok) {
+      // ---------------- ComputeTraditionalDoglegStep ----------------
+      double cA = 0, beta = 1;
+      const double gradient_norm = std::sqrt(dotf(ghat, ghat)), gn_norm = std::sqrt(dotf(gnhat, gnhat));
+      if (opt.gauss_newton || gn_norm <= radius) {  // case 1: the Gauss-Newton point lies inside the trust region
+        cA = 0, beta = 1;
+        dogleg_step_norm = gn_norm;
+      } else if (gradient_norm * alpha >= radius) {  // case 2: even the Cauchy point lies outside
+        cA = radius / gradient_norm, beta = 0;
+        dogleg_step_norm = radius;
+      } else {  // case 3: on the segment Cauchy point -> Gauss-Newton point
+        const double b_dot_a = -alpha * dotf(ghat, gnhat);
+        const double a2 = (alpha * gradient_norm) * (alpha * gradient_norm);
+        const double bma2 = a2 - 2 * b_dot_a + gn_norm * gn_norm;
+        const double c = b_dot_a - a2;
+        const double dsc = std::sqrt(c * c + bma2 * (radius * radius - a2));
+        beta = (c <= 0) ? (dsc - c) / bma2 : (radius * radius - a2) / (dsc + c);
+        cA = alpha * (1.0 - beta);
+        Full t = gnhat;
+        for (int i = 0; i < D; ++i) t.p[i] = -cA * ghat.p[i] + beta * gnhat.p[i];
+        for (int i = 0; i < NL; ++i) t.l[i] = -cA * ghat.l[i] + beta * gnhat.l[i];
+        dogleg_step_norm = std::sqrt(dotf(t, t));
+      }
+      step = gn;
+      for (int i = 0; i < D; ++i) step.p[i] = -cA * xv.p[i] + beta * gn.p[i];
+      for (int i = 0; i < NL; ++i) step.l[i] = -cA * xv.l[i] + beta * gn.l[i];
+      // model_cost_change = -(J step)^T (r + J step / 2) = -g^T step - step^T H step / 2
+      Full Hs;
+      hessian_times(h, step, &Hs);
+      model_change = -dotf(g, step) - 0.5 * dotf(step, Hs);
+      if (model_change < 0.0 && !opt.gauss_newton) valid = false;
+    }
+    if (!valid) {  // StepIsInvalid: counted as an unsuccessful iteration of zero length
+      if (++invalid_steps >= std::max(1, opt.max_consecutive_invalid_steps)) {
+        s.termination = 5;
+        done = true;
+        continue;
+      }
+      mu *= kMuIncrease;
+      reuse = false;
+      continue;
+    }
+    invalid_steps = 0;
+    h->step_p = step.p, h->step_l = step.l;
+    std::vector<double> pose_t, sb_t, lm_t, pose_s = h->pose, sb_s = h->sb, lm_s = h->lm;
+    apply_step(h, &pose_t, &sb_t, &lm_t);
+    double dx2 = 0;
+    for (size_t i = 0; i < pose_t.size(); ++i) dx2 += (pose_t[i] - pose_s[i]) * (pose_t[i] - pose_s[i]);
+    for (size_t i = 0; i < sb_t.size(); ++i) dx2 += (sb_t[i] - sb_s[i]) * (sb_t[i] - sb_s[i]);
+    for (size_t i = 0; i < lm_t.size(); ++i) dx2 += (lm_t[i] - lm_s[i]) * (lm_t[i] - lm_s[i]);
+    h->pose = pose_t, h->sb = sb_t, h->lm = lm_t;
+    const double old_cost = h->cost;
+    const double new_cost = evaluate(h, false);
+    h->pose = pose_s, h->sb = sb_s, h->lm = lm_s;
+    if (!opt.gauss_newton) {
+      if (opt.parameter_tolerance > 0 && std::sqrt(dx2) <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
+        s.termination = 3;  // returns WITHOUT taking the step
+        done = true;
+        continue;
+      }
+      if (opt.function_tolerance > 0 && std::fabs(old_cost - new_cost) < opt.function_tolerance * old_cost) {
+        s.termination = 1;  // Ceres <= 1.10 returns here WITHOUT taking the step
+        done = true;
+        continue;
+      }
+    }
+    const double rho = (old_cost - new_cost) / model_change;
+    if (opt.gauss_newton || rho > opt.min_relative_decrease) {
+      s.successful_steps++;
+      if (!opt.gauss_newton) {  // StepAccepted
+        if (rho < 0.25) radius *= 0.5;
+        if (rho > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
+        mu = std::max(kMinMu, 2.0 * mu / kMuIncrease);
+      }
+      reuse = false;
+      h->pose = pose_t, h->sb = sb_t, h->lm = lm_t;
+      x_norm = free_x_norm(h);
+      evaluate(h, true);
+      s.gradient_max_norm = projected_gradient_max_norm(h);
+      if (opt.gradient_tolerance > 0 && s.gradient_max_norm <= opt.gradient_tolerance) {
+        s.termination = 2;
+        done = true;
+      }
+    } else {  // StepRejected: only the interpolation is redone with the smaller radius
+      radius *= 0.5;
+      reuse = true;
+    }
+    if (!done && radius < opt.min_radius) {
+      s.termination = 4;
+      done = true;
     }
   }
   s.final_cost = h->cost;
@@ -787,6 +1047,10 @@ int orc_window_solve(orc_window* h, double radius, const okvis_ba_options* opt) 
   return solve(h, radius, *opt) ? 0 : 1;
 }
 void orc_window_optimize(orc_window* h, const okvis_ba_options* opt, int num_iter, okvis_ba_summary* summary) {
+  if (opt->strategy == OKVIS_BA_STRATEGY_DOGLEG) {
+    dogleg_loop(h, *opt, num_iter, summary);
+    return;
+  }
   lm_loop(h, *opt, num_iter, summary);
 }
 double orc_window_time_iterations(orc_window* h, const okvis_ba_options* opt, int n) {
@@ -795,7 +1059,8 @@ double orc_window_time_iterations(orc_window* h, const okvis_ba_options* opt, in
   o.gradient_tolerance = 0;
   o.parameter_tolerance = 0;
   auto t0 = std::chrono::steady_clock::now();
-  lm_loop(h, o, n, nullptr);
+  if (o.strategy == OKVIS_BA_STRATEGY_DOGLEG) dogleg_loop(h, o, n, nullptr);
+  else lm_loop(h, o, n, nullptr);
   auto t1 = std::chrono::steady_clock::now();
   return std::chrono::duration<double>(t1 - t0).count();
 }

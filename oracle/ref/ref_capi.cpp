@@ -648,6 +648,8 @@ void ref_window_optimize(ref_window* h, const okvis_ba_options* opt, int num_ite
     o.function_tolerance = opt->function_tolerance;
     o.gradient_tolerance = opt->gradient_tolerance;
     o.parameter_tolerance = opt->parameter_tolerance;
+    o.jacobi_scaling = opt->jacobi_scaling != 0;
+    o.max_num_consecutive_invalid_steps = opt->max_consecutive_invalid_steps > 0 ? opt->max_consecutive_invalid_steps : 5;
   }
   h->map->solve();
   const ::ceres::Solver::Summary& s = h->map->summary;
@@ -655,9 +657,16 @@ void ref_window_optimize(ref_window* h, const okvis_ba_options* opt, int num_ite
     std::memset(out, 0, sizeof(*out));
     out->initial_cost = s.initial_cost;
     out->final_cost = s.final_cost;
-    out->iterations = (int32_t)s.iterations.size() - 1;
+    // same conventions as okvis_ba_summary: the iteration in which a tolerance fired counts (Ceres does not record it)
+    int term = 0, extra = 0;
+    if (s.message.find("Function tolerance") == 0) term = 1, extra = 1;
+    else if (s.message.find("Gradient tolerance") == 0) term = 2;
+    else if (s.message.find("Parameter tolerance") == 0) term = 3, extra = 1;
+    else if (s.message.find("Termination. Minimum trust region") == 0) term = 4, extra = 1;
+    else if (s.message.find("Number of successive invalid") == 0) term = 5, extra = 1;
+    out->iterations = (int32_t)s.iterations.size() - 1 + extra;
     out->successful_steps = s.num_successful_steps;
-    out->termination = -1;
+    out->termination = term;
     if (!s.iterations.empty()) {
       out->final_radius = s.iterations.back().trust_region_radius;
       out->gradient_max_norm = s.iterations.back().gradient_max_norm;
