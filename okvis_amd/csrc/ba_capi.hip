@@ -135,14 +135,18 @@ OptD make_optd(const okvis_ba_options& o) {
   d.initial_radius = o.initial_radius;
   d.max_radius = o.max_radius;
   d.min_radius = o.min_radius;
-  d.min_lm_diag2 = o.min_lm_diagonal * o.min_lm_diagonal;
-  d.max_lm_diag2 = o.max_lm_diagonal * o.max_lm_diagonal;
+  d.min_lm_diag2 = o.min_lm_diagonal;   // Ceres clamps the squared column norm itself to [min_lm_diagonal, max_lm_diagonal]
+  d.max_lm_diag2 = o.max_lm_diagonal;
   d.min_relative_decrease = o.min_relative_decrease;
   d.function_tolerance = o.function_tolerance;
   d.gradient_tolerance = o.gradient_tolerance;
   d.parameter_tolerance = o.parameter_tolerance;
   d.gauss_newton = o.gauss_newton;
   d.marg_mode = 0;
+  d.dogleg = o.strategy == OKVIS_BA_STRATEGY_DOGLEG;
+  d.jacobi_scaling = o.jacobi_scaling != 0;
+  d.max_invalid = o.max_consecutive_invalid_steps > 0 ? o.max_consecutive_invalid_steps : 5;
+  d.pad = 0;
   return d;
 }
 
@@ -601,6 +605,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(ct_d2, put_zero(A, 8 * nT * CT_TB));
   }
   OFF(step, put_zero(A, 8 * (size_t)D));
+  OFF(scale_p, put_zero(A, 8 * (size_t)D));
+  OFF(lm_scale, put_zero(A, 24 * (size_t)nlm));
   OFF(grad, put_zero(A, 8 * (size_t)D));
   OFF(quality, put_zero(A, 8 * (size_t)nlm));
   if (opt.debug_arrays) OFF(prof, put_zero(A, 8 * 64));   // clock64() phase stamps: diagnostics only
@@ -720,11 +726,12 @@ struct Sub {
 };
 Sub whole(okvis_ba_solver* s) { return Sub{s->stream, 0, (int)s->wins.size()}; }
 
-hipError_t launch_schur(okvis_ba_solver* s, Sub b) {
+hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
   if (s->max_schur_blocks == 0) return hipSuccess;
   const int trows = std::min(TILE_DIM, s->max_Dp);
   hipLaunchKernelGGL(schur_kernel, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS),
-                     (size_t)2 * SCHUR_LM_BATCH * trows * 3 * sizeof(double), b.st, s->d_wins + b.w0, s->d_opt, trows);
+                     (size_t)2 * SCHUR_LM_BATCH * trows * 3 * sizeof(double), b.st, s->d_wins + b.w0, s->d_opt, trows,
+                     final_call);
   return hipGetLastError();
 }
 hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
@@ -772,10 +779,16 @@ hipError_t launch_iteration(okvis_ba_solver* s, Sub b) {
   return launch_lin(s, b, 0);
 }
 // n iterations of every sub-batch: fork from the main stream, one chain per sub-stream, join
-hipError_t launch_iterations_forked(okvis_ba_solver* s, int n) {
+hipError_t launch_budget(okvis_ba_solver* s, Sub b, int n) {
+  if (s->opt.strategy != OKVIS_BA_STRATEGY_DOGLEG || n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(add_budget_kernel, dim3((unsigned)b.nw), dim3(64), 0, b.st, s->d_wins + b.w0, n);
+  return hipGetLastError();
+}
+hipError_t launch_iterations_forked(okvis_ba_solver* s, int n, int budget = -1) {
   const int nsub = (int)s->sub_streams.size();
+  if (budget < 0) budget = n;
   if (nsub <= 1) {
-    hipError_t e = hipSuccess;
+    hipError_t e = launch_budget(s, whole(s), budget);
     for (int i = 0; i < n && e == hipSuccess; ++i) e = launch_iteration(s, whole(s));
     return e;
   }
@@ -783,6 +796,7 @@ hipError_t launch_iterations_forked(okvis_ba_solver* s, int n) {
   for (int k = 0; k < nsub && e == hipSuccess; ++k) {
     e = hipStreamWaitEvent(s->sub_streams[k], s->ev_fork, 0);
     const Sub b{s->sub_streams[k], s->sub_begin[k], s->sub_begin[k + 1] - s->sub_begin[k]};
+    if (e == hipSuccess) e = launch_budget(s, b, budget);
     for (int i = 0; i < n && e == hipSuccess; ++i) e = launch_iteration(s, b);
     if (e == hipSuccess) e = hipEventRecord(s->sub_events[k], s->sub_streams[k]);
     if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->sub_events[k], 0);
@@ -841,6 +855,10 @@ void okvis_ba_default_options(okvis_ba_options* o) {
   o->gauss_newton = 0;
   o->n_streams = 0;
   o->fp32_linearize = 0;
+  o->strategy = OKVIS_BA_STRATEGY_DOGLEG;   // what the reference configures (Estimator.cpp:858)
+  o->jacobi_scaling = 1;
+  o->max_consecutive_invalid_steps = 5;
+  o->reserved0 = 0;
 }
 
 const char* okvis_ba_error_string(int status) {
@@ -1134,6 +1152,7 @@ int okvis_ba_begin(okvis_ba_solver* s) {
     c.radius = s->opt.initial_radius;
     c.decrease_factor = 2.0;
     c.lambda = 1.0 / s->opt.initial_radius;
+    c.mu = DL_MIN_MU;
     HIP_TRY(hipMemcpyAsync(H.ptrs.ctrl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
   }
   HIP_TRY(launch_lin(s, whole(s), 1));
@@ -1160,7 +1179,7 @@ int okvis_ba_iterate(okvis_ba_solver* s, int n) {
         hipGraph_t graph = nullptr;
         const Sub b{s->sub_streams[k], s->sub_begin[k], s->sub_begin[k + 1] - s->sub_begin[k]};
         HIP_TRY(hipStreamBeginCapture(b.st, hipStreamCaptureModeRelaxed));
-        hipError_t e = hipSuccess;
+        hipError_t e = launch_budget(s, b, n);
         for (int i = 0; i < n && e == hipSuccess; ++i) e = launch_iteration(s, b);
         hipError_t e2 = hipStreamEndCapture(b.st, &graph);
         if (e != hipSuccess) HIP_TRY(e);
@@ -1215,8 +1234,30 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
   if (!s->begun) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
   // the final accept/reject needs the Schur partials of the buffer it may accept (gradient test)
-  HIP_TRY(launch_schur(s, whole(s)));
+  HIP_TRY(launch_schur(s, whole(s), 1));
   HIP_TRY(launch_solve(s, whole(s), 1));
+  if (s->opt.strategy == OKVIS_BA_STRATEGY_DOGLEG && !s->opt.gauss_newton) {
+    // Dogleg: a launch slot that had to redo a mis-speculated Gauss-Newton trial as an explicit dogleg step did not
+    // finish an iteration, and the decision just taken may itself ask for such a redo.  Windows that still owe
+    // iterations of this call's budget get the missing slots (the others are stopped by the budget), then the final
+    // decision is taken again.  Rare: only when the Gauss-Newton point lies outside the trust region.
+    for (int round = 0; round < 64; ++round) {
+      std::vector<Ctrl> cs;
+      int rc = fetch_ctrl(s, cs);
+      if (rc != OKVIS_BA_OK) return rc;
+      int need = 0;
+      for (const Ctrl& c : cs) {
+        if (c.done) continue;
+        int k = c.max_iter - c.iter;
+        if (c.explicit_next == 2) k += 1;   // the current iteration itself is unfinished
+        need = std::max(need, k);
+      }
+      if (need <= 0) break;
+      for (int i = 0; i < need; ++i) HIP_TRY(launch_iteration(s, whole(s)));
+      HIP_TRY(launch_schur(s, whole(s), 1));
+      HIP_TRY(launch_solve(s, whole(s), 1));
+    }
+  }
   if (s->max_lm > 0) {
     hipLaunchKernelGGL(quality_kernel, dim3((s->max_lm + 255) / 256, (unsigned)s->wins.size()), dim3(256), 0, s->stream, s->d_wins);
     HIP_TRY(hipGetLastError());
@@ -1232,7 +1273,7 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
       o.final_cost = cs[i].cost;
       o.iterations = cs[i].iter;
       o.successful_steps = cs[i].successful;
-      o.termination = cs[i].done ? cs[i].done - 1 : 0;
+      o.termination = cs[i].done ? (cs[i].done - 1 == 6 ? 0 : cs[i].done - 1) : 0;   // 6 = budget used up = max iterations
       o.reserved = cs[i].chol_fail;
       o.final_radius = cs[i].radius;
       o.gradient_max_norm = cs[i].grad_max;
@@ -1332,6 +1373,7 @@ static int locate(okvis_ba_solver* s, int w, int which, const double** ptr, int6
     case OKVIS_BA_ARR_DAMPING: *ptr = P.Dp2; *n = H.D; return P.Dp2 ? 0 : OKVIS_BA_ERR_STATE;
     case 99: *ptr = P.prof; *n = 64; return P.prof ? 0 : OKVIS_BA_ERR_STATE;
     case 98: *ptr = nullptr; *n = H.n_imu; return 0;  // diagnostics: re-preintegration count per IMU factor
+    case 97: *ptr = nullptr; *n = 24; return 0;       // diagnostics: trust-region control record
     case OKVIS_BA_ARR_IMU_SB_REF: *ptr = nullptr; *n = 9 * (int64_t)H.n_imu; return 0;
     case OKVIS_BA_ARR_IMU_RESIDUAL: *ptr = nullptr; *n = 15 * (int64_t)H.n_imu; return 0;
   }
@@ -1359,6 +1401,16 @@ int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t
     if (H.n_imu > 0)
       HIP_TRY(hipMemcpy2D(out, 9 * sizeof(double), reinterpret_cast<const unsigned char*>(H.ptrs.imu_cache) + offsetof(ImuCacheD, sb_ref),
                           sizeof(ImuCacheD), 9 * sizeof(double), (size_t)H.n_imu, hipMemcpyDeviceToHost));
+    return OKVIS_BA_OK;
+  }
+  if (which == 97) {
+    Ctrl c;
+    HIP_TRY(hipMemcpy(&c, s->wins[w].ptrs.ctrl, sizeof(c), hipMemcpyDeviceToHost));
+    const double v[24] = {c.radius, c.mu, c.cost, c.cA, c.beta, c.dl_norm, c.pend_model, c.tot_A, c.tot_C, c.tot_E, c.gd_p,
+                          c.ddd_p, c.last_rho, c.last_model_change, (double)c.iter, (double)c.successful, (double)c.tr_kind,
+                          (double)c.explicit_next, (double)c.pending, (double)c.acc, (double)c.done, (double)c.max_iter,
+                          (double)c.invalid_steps, (double)c.chol_fail};
+    for (int i = 0; i < 24; ++i) out[i] = v[i];
     return OKVIS_BA_OK;
   }
   if (which == 98) {
@@ -1390,6 +1442,7 @@ int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4) {
   std::vector<hipEvent_t> ev(5 * (size_t)n);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   for (int k = 0; k < 4; ++k) ms4[k] = 0.f;
+  HIP_TRY(launch_budget(s, whole(s), n));
   for (int i = 0; i < n; ++i) {
     hipEvent_t* e = &ev[5 * (size_t)i];
     HIP_TRY(hipEventRecord(e[0], s->stream));
@@ -1578,6 +1631,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   // ---- linearise + landmark elimination + export ----
   OptD od = make_optd(s->opt);
   od.marg_mode = 1;
+  od.dogleg = 0;   // no trust region in the marginalisation pass: one linearisation, no damping
   HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
   int rc = okvis_ba_begin(s);
   if (rc != OKVIS_BA_OK) return rc;
@@ -1608,7 +1662,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   hipLaunchKernelGGL(marg_dense_kernel, dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES * 8, s->stream, d_win, 0, ma,
                      MARG_LDS_DOUBLES);
   HIP_TRY(hipGetLastError());
-  od.marg_mode = 0;
+  od = make_optd(s->opt);
   HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
   // H | J | b0 | e0 are contiguous on the device: one copy into page-locked staging (+ the info record), one sync
   int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};

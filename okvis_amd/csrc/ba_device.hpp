@@ -157,6 +157,102 @@ __device__ __noinline__ void decide(const Ctrl* c, const OptD* o, const double s
   }
 }
 
+// ---- dogleg strategy (the reference's configuration, Estimator.cpp:858) -----------------------------------------
+// Decision for the pending trial under Ceres' TrustRegionMinimizer + DoglegStrategy rules (restated; DESIGN.md
+// "solver policy").  sums = wave_trial_sums of the trial buffer.  Evaluated bit-identically by the Schur kernel and
+// the solve kernel (not inlined, contraction-free).
+struct DecisionDL {
+  int accept;         // the pending trial becomes the accepted state
+  int term;           // 0 = continue, else termination reason (1 function tol, 3 parameter tol, 4 radius, 5 invalid steps,
+                      // 6 = iteration budget of this call used up)
+  int explicit_next;  // the next trial is an explicit dogleg step from the stored Gauss-Newton point (no new solve)
+  int judged;         // an iteration was completed (accepted / rejected / invalid); 0 = mis-speculation or first
+  int invalid_steps, have_tot;
+  double radius, mu, rho, model_change, tot_C, tot_E;
+};
+__device__ __noinline__ void decide_dl(const Ctrl* c, const OptD* o, const double sums[6], int final_call, DecisionDL* d) {
+#pragma clang fp contract(off)
+  d->accept = 0;
+  d->term = 0;
+  d->explicit_next = 0;
+  d->judged = 0;
+  d->invalid_steps = c->invalid_steps;
+  d->have_tot = c->have_tot;
+  d->radius = c->radius;
+  d->mu = c->mu;
+  d->rho = 0;
+  d->model_change = 0;
+  d->tot_C = c->tot_C;
+  d->tot_E = c->tot_E;
+  if (c->first) {
+    d->accept = 1;
+  } else if (o->gauss_newton) {
+    d->accept = 1;
+    d->judged = 1;
+  } else {
+    double model, dl_norm;
+    bool have = true;
+    if (c->tr_kind == 0) {  // the speculative Gauss-Newton point: is it inside the trust region?
+      const double C = c->gd_p + sums[1], E = c->ddd_p + sums[2];
+      d->tot_C = C;
+      d->tot_E = E;
+      d->have_tot = 1;
+      dl_norm = sqrt(E);
+      model = -0.5 * C + 0.5 * c->mu * E;
+      if (dl_norm > c->radius) {
+        d->explicit_next = 1;  // no: replace the trial by the proper dogleg step, nothing judged
+        have = false;
+      }
+    } else {
+      model = c->pend_model;
+      dl_norm = c->dl_norm;
+    }
+    if (have) {
+      d->judged = 1;
+      d->model_change = model;
+      if (model < 0.0) {  // invalid step (StepIsInvalid)
+        d->invalid_steps = c->invalid_steps + 1;
+        if (d->invalid_steps >= o->max_invalid) d->term = 5;
+        d->mu = c->mu * DL_MU_INCREASE;
+      } else {
+        d->invalid_steps = 0;
+        const double step2 = c->step2_p + sums[3], x2 = c->x2_p + sums[4];
+        const double cost_change = c->cost - sums[0];
+        if (o->parameter_tolerance > 0.0 && sqrt(step2) <= o->parameter_tolerance * (sqrt(x2) + o->parameter_tolerance)) {
+          d->term = 3;
+        } else if (o->function_tolerance > 0.0 && fabs(cost_change) < o->function_tolerance * c->cost) {
+          d->term = 1;  // Ceres <= 1.10 returns here without taking the step
+        } else {
+          const double rho = cost_change / model;
+          d->rho = rho;
+          if (rho > o->min_relative_decrease) {  // StepAccepted
+            d->accept = 1;
+            if (rho < 0.25) d->radius = c->radius * 0.5;
+            if (rho > 0.75) d->radius = fmax(c->radius, 3.0 * dl_norm);
+            d->mu = fmax(DL_MIN_MU, 2.0 * c->mu / DL_MU_INCREASE);
+            d->have_tot = 0;
+          } else {  // StepRejected: only the interpolation is redone
+            d->radius = c->radius * 0.5;
+            d->explicit_next = 1;
+          }
+          if (d->radius < o->min_radius) d->term = 4;
+        }
+      }
+    }
+  }
+  // a NEW iteration would start now (anything but the redo of a mis-speculated trial): is there budget left?
+  if (!final_call && !d->term && !(d->explicit_next && !d->judged) && c->iter >= c->max_iter) d->term = 6;
+}
+
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Damping diagonal of one column.  LM: clamp(h) with h = diag(J^T J).  Dogleg: Ceres works on the column-scaled
+// Jacobian (scale s, estimated at the first linearisation): diagonal_^2 = clamp(s^2 h); in unscaled variables the
+// regulariser mu * diagonal_^2 becomes mu * clamp(s^2 h) / s^2.
+__device__ __forceinline__ double damp_diag(double h, double s, const OptD& o) {
+  if (!o.dogleg) return clampd(h, o.min_lm_diag2, o.max_lm_diag2);
+  const double s2 = s * s;
+  return clampd(s2 * h, o.min_lm_diag2, o.max_lm_diag2) / s2;
+}
 
 }  // namespace ba

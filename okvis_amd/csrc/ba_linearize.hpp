@@ -63,6 +63,8 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   const int acc = ctrl->acc, trial = 1 - acc;
   const double lambda = ctrl->lambda;
   const OptD opt = *optp;
+  const bool dl_explicit = opt.dogleg && ctrl->tr_kind == 1;
+  const double dl_cA = ctrl->cA, dl_beta = ctrl->beta;
 
   constexpr int STRIDE = LinCfg<EXT, REAL>::STRIDE;
   REAL* s_stage = reinterpret_cast<REAL*>(smem);
@@ -178,25 +180,38 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
         t[1] += sp[1];
         t[2] += sp[2];
       }
-      const double d0 = clampd(v[0], opt.min_lm_diag2, opt.max_lm_diag2);
-      const double d1 = clampd(v[3], opt.min_lm_diag2, opt.max_lm_diag2);
-      const double d2 = clampd(v[5], opt.min_lm_diag2, opt.max_lm_diag2);
+      double sc[3] = {1.0, 1.0, 1.0};
+      if (opt.dogleg) {
+        const double* sl = W.lm_scale + 3 * (size_t)l;
+        sc[0] = sl[0], sc[1] = sl[1], sc[2] = sl[2];
+      }
+      const double d0 = damp_diag(v[0], sc[0], opt);
+      const double d1 = damp_diag(v[3], sc[1], opt);
+      const double d2 = damp_diag(v[5], sc[2], opt);
       v[0] += lambda * d0;
       v[3] += lambda * d1;
       v[5] += lambda * d2;
       double vi[6];
       inv3sym(v, vi);
+      // (dogleg: this is the landmark part of the Gauss-Newton point; the scalars g.delta and delta^T D^2 delta below
+      //  always refer to it, they decide whether the point lies inside the trust region)
       const double dl0 = -(vi[0] * t[0] + vi[1] * t[1] + vi[2] * t[2]);
       const double dl1 = -(vi[1] * t[0] + vi[3] * t[1] + vi[4] * t[2]);
       const double dl2 = -(vi[2] * t[0] + vi[4] * t[1] + vi[5] * t[2]);
+      double st0 = dl0, st1 = dl1, st2 = dl2;
+      if (dl_explicit) {   // explicit dogleg step  -cA xv + beta dGN,  xv_l = b_l / Dt2_l
+        st0 = -dl_cA * (bb[0] / d0) + dl_beta * dl0;
+        st1 = -dl_cA * (bb[1] / d1) + dl_beta * dl1;
+        st2 = -dl_cA * (bb[2] / d2) + dl_beta * dl2;
+      }
       const double x0 = xx[0], x1 = xx[1], x2 = xx[2], x3 = xx[3];
       double* xt = W.lm[trial] + 4 * (size_t)l;
-      const double n0 = x0 + dl0, n1 = x1 + dl1, n2 = x2 + dl2;
+      const double n0 = x0 + st0, n1 = x1 + st1, n2 = x2 + st2;
       xt[0] = n0; xt[1] = n1; xt[2] = n2; xt[3] = x3;
       s_lm[4 * tid] = n0; s_lm[4 * tid + 1] = n1; s_lm[4 * tid + 2] = n2; s_lm[4 * tid + 3] = x3;
       sc_gd = bb[0] * dl0 + bb[1] * dl1 + bb[2] * dl2;
       sc_ddd = d0 * dl0 * dl0 + d1 * dl1 * dl1 + d2 * dl2 * dl2;
-      sc_s2 = dl0 * dl0 + dl1 * dl1 + dl2 * dl2;
+      sc_s2 = st0 * st0 + st1 * st1 + st2 * st2;
       sc_x2 = x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
     }
   } else if (tid < nlm) {
@@ -333,6 +348,11 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
       if (part == 0) {
         if (!is_cost) obase[ostride * (size_t)(G.lm_begin + ll) + ooff] = a;
         s_lmres[16 * ll + e] = a;
+        // first linearisation of an optimize() call: Jacobi scale of the landmark columns (Ceres EstimateScale,
+        // 1 / (1 + sqrt(diag J^T J)); e = 0, 3, 5 are the diagonal entries of V)
+        if (init && opt.dogleg && (e == 0 || e == 3 || e == 5))
+          W.lm_scale[3 * (size_t)(G.lm_begin + ll) + (e == 0 ? 0 : (e == 3 ? 1 : 2))] =
+              opt.jacobi_scaling ? 1.0 / (1.0 + sqrt((double)a)) : 1.0;
       }
     }
   }

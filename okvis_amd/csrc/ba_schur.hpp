@@ -25,7 +25,7 @@ namespace ba {
 constexpr int TILE_DIM = SCHUR_TILE_BLOCKS * 6;  // 96
 
 __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __restrict__ wins,
-                                                              const OptD* __restrict__ optp, int tile_rows) {
+                                                              const OptD* __restrict__ optp, int tile_rows, int final_call) {
   const WinPtrs& W = wins[blockIdx.y];
   const int n_tp = W.n_tile * (W.n_tile + 1) / 2;
   const int bx = blockIdx.x;
@@ -66,20 +66,43 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     asm volatile("" ::: "memory");
     int acc = s_ctrl.acc, term = 0;
-    double radius = s_ctrl.radius;
-    if (s_ctrl.pending) {
-      double sums[6];
-      wave_trial_sums(W, 1 - acc, tid, sums);
-      Decision d;
-      decide(&s_ctrl, &opt, sums, &d);
-      if (d.accept) acc = 1 - acc;
-      radius = d.radius;
-      term = d.term;
+    double lam;
+    if (opt.dogleg) {
+      // dogleg: the regulariser of the Gauss-Newton solve is mu * diagonal^2; a decision that asks for an explicit
+      // dogleg step (rejected step / mis-speculated Gauss-Newton trial) needs no new reduction at all
+      double mu = s_ctrl.mu;
+      int expl = s_ctrl.explicit_next;
+      if (s_ctrl.pending) {
+        double sums[6];
+        wave_trial_sums(W, 1 - acc, tid, sums);
+        DecisionDL d;
+        decide_dl(&s_ctrl, &opt, sums, final_call, &d);
+        if (d.accept) acc = 1 - acc;
+        term = d.term;
+        mu = d.mu;
+        expl = d.explicit_next ? (d.judged ? 1 : 2) : 0;
+      } else if (!final_call && expl != 2 && s_ctrl.iter >= s_ctrl.max_iter) {
+        term = 6;
+      }
+      if (expl) term = 7;   // nothing to reduce in this slot
+      lam = mu;
+    } else {
+      double radius = s_ctrl.radius;
+      if (s_ctrl.pending) {
+        double sums[6];
+        wave_trial_sums(W, 1 - acc, tid, sums);
+        Decision d;
+        decide(&s_ctrl, &opt, sums, &d);
+        if (d.accept) acc = 1 - acc;
+        radius = d.radius;
+        term = d.term;
+      }
+      lam = 1.0 / radius;
     }
     if (tid == 0) {
       s_dec[0] = acc;
       s_dec[1] = term;
-      s_lambda = 1.0 / radius;
+      s_lambda = lam;
     }
   }
   __syncthreads();
@@ -139,9 +162,14 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
     if (opt.marg_mode) {
       pinv3sym_precond(v, vi);   // MarginalizationError::marginalizeOut landmark path (no damping)
     } else {
-      v[0] += lambda * clampd(v[0], opt.min_lm_diag2, opt.max_lm_diag2);
-      v[3] += lambda * clampd(v[3], opt.min_lm_diag2, opt.max_lm_diag2);
-      v[5] += lambda * clampd(v[5], opt.min_lm_diag2, opt.max_lm_diag2);
+      double sc[3] = {1.0, 1.0, 1.0};
+      if (opt.dogleg) {
+        const double* sl = W.lm_scale + 3 * (size_t)l;
+        sc[0] = sl[0], sc[1] = sl[1], sc[2] = sl[2];
+      }
+      v[0] += lambda * damp_diag(v[0], sc[0], opt);
+      v[3] += lambda * damp_diag(v[3], sc[1], opt);
+      v[5] += lambda * damp_diag(v[5], sc[2], opt);
       inv3sym(v, vi);
     }
 #pragma unroll

@@ -262,6 +262,131 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, doubl
 
 }
 
+// trial poses / speed-biases  x (+) delta  of buffer 1-acc (PoseLocalParameterization::plus, PoseLocalParameterization.cpp:60-87).
+// Adds |x|^2 over the free blocks to *x2 and, when `ambient`, |x - x(+)delta|^2 to *s2.
+__device__ __forceinline__ void trial_states(const WinPtrs& W, int acc, const double* s_x, int tid, bool ambient, double* s2,
+                                             double* x2) {
+  const int trial = 1 - acc;
+  double a2 = 0, b2 = 0;
+  for (int b = tid; b < W.n_pose; b += SOLVE_THREADS) {
+    const double* xp = W.pose[acc] + 7 * (size_t)b;
+    double* xt = W.pose[trial] + 7 * (size_t)b;
+    const int off = W.pose_off[b];
+    if (off >= 0) {
+      double xin[7], xo[7];
+      for (int k = 0; k < 7; ++k) {
+        xin[k] = xp[k];
+        b2 += xp[k] * xp[k];
+      }
+      pose_oplus(xin, s_x + off, xo);
+      for (int k = 0; k < 7; ++k) {
+        xt[k] = xo[k];
+        if (ambient) a2 += (xo[k] - xin[k]) * (xo[k] - xin[k]);
+      }
+    } else {
+      for (int k = 0; k < 7; ++k) xt[k] = xp[k];
+    }
+  }
+  for (int b = tid; b < W.n_sb; b += SOLVE_THREADS) {
+    const double* xp = W.sb[acc] + 9 * (size_t)b;
+    double* xt = W.sb[trial] + 9 * (size_t)b;
+    const int off = W.sb_off[b];
+    for (int k = 0; k < 9; ++k) {
+      const double v = xp[k];
+      if (off >= 0) b2 += v * v;
+      const double nv = off >= 0 ? v + s_x[off + k] : v;
+      xt[k] = nv;
+      if (ambient && off >= 0) a2 += (nv - v) * (nv - v);
+    }
+  }
+  *s2 += a2;
+  *x2 += b2;
+}
+
+// landmark part of the Cauchy-point scalars of the dogleg step (xv = Cauchy direction, pose part in xvp):
+//   *Al += b_l . xv_l ,   *Bl += t^T (V_l + mu Dt2_l)^-1 t + 2 t . xv_l + xv_l^T V_l xv_l ,   t = W_l^T xv_p
+__device__ __forceinline__ void dl_landmark_sums(const WinPtrs& W, int acc, const double* xvp, double mu, const OptD& opt,
+                                                 int tid, double* Al_out, double* Bl_out) {
+  double Al = 0, Bl = 0;
+  const double* s_x = xvp;
+  for (int l = tid; l < W.n_lm; l += SOLVE_THREADS) {
+        const double* Vl = W.V[acc] + 6 * (size_t)l;
+        const double* bl = W.bl[acc] + 3 * (size_t)l;
+        const double* sl = W.lm_scale + 3 * (size_t)l;
+        double v[6] = {Vl[0], Vl[1], Vl[2], Vl[3], Vl[4], Vl[5]};
+        const double dt[3] = {damp_diag(v[0], sl[0], opt), damp_diag(v[3], sl[1], opt), damp_diag(v[5], sl[2], opt)};
+        const double xl[3] = {bl[0] / dt[0], bl[1] / dt[1], bl[2] / dt[2]};
+        double t[3] = {0, 0, 0};
+        for (int pr = W.lm_pair_begin[l]; pr < W.lm_pair_begin[l + 1]; ++pr) {
+          const double* Wp = W.W[acc] + 18 * (size_t)pr;
+          const double* xp = s_x + W.pair_off[pr];
+          for (int i = 0; i < 6; ++i) {
+            t[0] += Wp[3 * i] * xp[i];
+            t[1] += Wp[3 * i + 1] * xp[i];
+            t[2] += Wp[3 * i + 2] * xp[i];
+          }
+        }
+        const double quad3 = xl[0] * (v[0] * xl[0] + v[1] * xl[1] + v[2] * xl[2]) +
+                             xl[1] * (v[1] * xl[0] + v[3] * xl[1] + v[4] * xl[2]) +
+                             xl[2] * (v[2] * xl[0] + v[4] * xl[1] + v[5] * xl[2]);
+        v[0] += mu * dt[0];
+        v[3] += mu * dt[1];
+        v[5] += mu * dt[2];
+        double vi[6];
+        inv3sym(v, vi);
+        const double quad1 = t[0] * (vi[0] * t[0] + vi[1] * t[1] + vi[2] * t[2]) +
+                             t[1] * (vi[1] * t[0] + vi[3] * t[1] + vi[4] * t[2]) +
+                             t[2] * (vi[2] * t[0] + vi[4] * t[1] + vi[5] * t[2]);
+        Al += bl[0] * xl[0] + bl[1] * xl[1] + bl[2] * xl[2];
+        Bl += quad1 + 2.0 * (t[0] * xl[0] + t[1] * xl[1] + t[2] * xl[2]) + quad3;
+      }
+  *Al_out += Al;
+  *Bl_out += Bl;
+}
+
+// DoglegStrategy::ComputeTraditionalDoglegStep in terms of the scalars of the current point:
+//   A = |ghat|^2 = g.xv,  B = xv^T H xv,  C = g.dGN = ghat.gnhat,  E = |gnhat|^2  (hat = Jacobi-scaled, D-normalised).
+// Step delta = -cA xv + beta dGN; *dln = its hat-norm (dogleg_step_norm_); *model = -g.delta - delta^T H delta / 2 using
+// H dGN = -g - mu Dt2 dGN.
+__device__ __noinline__ void dogleg_coefficients(double A, double B, double C, double E, double mu, double radius, double* cA,
+                                                 double* beta, double* dln, double* model) {
+#pragma clang fp contract(off)
+  const double alpha = A / B;
+  const double gradient_norm = sqrt(A), gn_norm = sqrt(E);
+  double a, b, n;
+  if (gn_norm <= radius) {  // case 1: the Gauss-Newton point lies inside the trust region
+    a = 0.0, b = 1.0, n = gn_norm;
+  } else if (gradient_norm * alpha >= radius) {  // case 2: even the Cauchy point lies outside
+    a = radius / gradient_norm, b = 0.0, n = radius;
+  } else {  // case 3: on the segment Cauchy point -> Gauss-Newton point
+    const double b_dot_a = -alpha * C;
+    const double a2 = (alpha * gradient_norm) * (alpha * gradient_norm);
+    const double bma2 = a2 - 2.0 * b_dot_a + gn_norm * gn_norm;
+    const double cc = b_dot_a - a2;
+    const double dsc = sqrt(cc * cc + bma2 * (radius * radius - a2));
+    b = (cc <= 0.0) ? (dsc - cc) / bma2 : (radius * radius - a2) / (dsc + cc);
+    a = alpha * (1.0 - b);
+    n = sqrt(a * a * A - 2.0 * a * b * C + b * b * E);
+  }
+  *cA = a;
+  *beta = b;
+  *dln = n;
+  *model = a * A - b * C - 0.5 * (a * a * B + 2.0 * a * b * (A + mu * C) + b * b * (-C - mu * E));
+}
+
+// the Gauss-Newton factorisation failed (or mu has reached max_mu): DoglegStrategy raises mu; once it cannot be
+// raised any more the step counts as an invalid iteration (TrustRegionMinimizer: StepIsInvalid, limited number)
+__device__ __forceinline__ void solve_failed_dl(Ctrl* c, const OptD& opt) {
+  c->explicit_next = 0;
+  c->have_tot = 0;
+  c->mu *= DL_MU_INCREASE;
+  if (c->mu >= DL_MAX_MU) {
+    c->iter++;
+    c->invalid_steps++;
+    if (c->invalid_steps >= opt.max_invalid) c->done = 5 + 1;
+  }
+}
+
 // LARGE = false: the block matrix lives in LDS (D <= MAX_D_LDS).  LARGE = true: it lives in the window's HBM
 // workspace (L2-resident; same algorithm, one workgroup) — the functional path for BASELINE configs[2].
 template <bool LARGE>
@@ -352,9 +477,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     asm volatile("" ::: "memory");
     const int pending = c.pending;
+    DecisionDL dl;
+    dl.accept = 0; dl.term = 0; dl.explicit_next = 0; dl.judged = 0;
     if (pending) {
       wave_trial_sums(W, 1 - c.acc, tid, sums);
-      decide(&c, &opt, sums, &d);
+      if (opt.dogleg) decide_dl(&c, &opt, sums, final_only != 0, &dl);
+      else decide(&c, &opt, sums, &d);
     }
     if (tid == 0) {
       s_accepted = 0;
@@ -364,7 +492,31 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       s_old_cost = c.cost;
       s_lm_gmax = 0;
       s_fail = 0;
-      if (pending) {
+      if (opt.dogleg) {
+        if (pending) {
+          c.last_rho = dl.rho;
+          c.last_model_change = dl.model_change;
+          c.have_tot = dl.have_tot;
+          c.tot_C = dl.tot_C;
+          c.tot_E = dl.tot_E;
+          c.invalid_steps = dl.invalid_steps;
+          c.mu = dl.mu;
+          c.radius = dl.radius;
+          if (dl.accept) {
+            s_accepted = 1;
+            s_cost_change = c.cost - sums[0];
+            c.acc = 1 - c.acc;
+            c.cost = sums[0];
+            if (!c.first) c.successful++;
+            s_lm_gmax = sums[5];
+          }
+          c.explicit_next = dl.explicit_next ? (dl.judged ? 1 : 2) : 0;
+          if (dl.term) c.done = dl.term + 1;
+          c.pending = 0;
+        } else if (!final_only && c.explicit_next != 2 && c.iter >= c.max_iter) {
+          c.done = 6 + 1;   // the iteration budget of this call is used up
+        }
+      } else if (pending) {
         c.last_rho = d.rho;
         c.last_model_change = d.model_change;
         if (d.term) {
@@ -541,7 +693,24 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // ------------------------------------------------------------------ 3. convergence of the accepted step
   {
     double m = 0;
-    for (int i = tid; i < D; i += SOLVE_THREADS) m = fmax(m, fabs(s_g[i]));
+    if (opt.dogleg) {
+      // Ceres 1.9: gradient_max_norm = || x - Plus(x, -g) ||_inf over the ambient coordinates: the gradient itself for
+      // Euclidean blocks, the change of the quaternion coefficients for the rotation part of a pose
+      for (int b = tid; b < W.n_pose; b += SOLVE_THREADS) {
+        const int off = W.pose_off[b];
+        if (off < 0) continue;
+        const double* xp = W.pose[acc] + 7 * (size_t)b;
+        double xin[7], dneg[6], xo[7];
+        for (int k = 0; k < 7; ++k) xin[k] = xp[k];
+        for (int k = 0; k < 6; ++k) dneg[k] = -s_g[off + k];
+        pose_oplus(xin, dneg, xo);
+        for (int k = 0; k < 7; ++k) m = fmax(m, fabs(xin[k] - xo[k]));
+      }
+      for (int i = Dp + tid; i < D; i += SOLVE_THREADS) m = fmax(m, fabs(s_g[i]));
+      // (extrinsics-role blocks are pose blocks of the same array: covered by the loop over n_pose)
+    } else {
+      for (int i = tid; i < D; i += SOLVE_THREADS) m = fmax(m, fabs(s_g[i]));
+    }
     m = wave_max_full(m);
     if ((tid & 63) == 0) s_red[tid >> 6] = m;
     __syncthreads();
@@ -552,13 +721,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         c.grad_max = gm;
         if (s_was_first) {
           c.initial_cost = c.cost;
-          c.abs_grad_tol = opt.gradient_tolerance * fmax(gm, 2.220446049250313e-16);
+          c.abs_grad_tol = opt.dogleg ? opt.gradient_tolerance : opt.gradient_tolerance * fmax(gm, 2.220446049250313e-16);
         }
         if (opt.gradient_tolerance > 0 && gm <= c.abs_grad_tol) {
           c.done = 2 + 1;
-        } else if (!s_was_first && opt.function_tolerance > 0 &&
+        } else if (!opt.dogleg && !s_was_first && opt.function_tolerance > 0 &&
                    fabs(s_cost_change) < opt.function_tolerance * s_old_cost) {
-          c.done = 1 + 1;
+          c.done = 1 + 1;   // (dogleg: tested before the step is taken, in decide_dl)
         }
         c.first = 0;
       }
@@ -584,10 +753,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   }
 
   // ------------------------------------------------------------------ 4. damping + Cholesky
-  const double lambda = 1.0 / c.radius;
+  const double lambda = opt.dogleg ? c.mu : 1.0 / c.radius;
+  const bool est_scale = s_was_first && s_accepted;   // first linearisation of this call: estimate the Jacobi scale
   for (int i = tid; i < Dpad; i += SOLVE_THREADS) {
     if (i < D) {
-      const double d2 = clampd(s_d2[i], opt.min_lm_diag2, opt.max_lm_diag2);
+      double sc = 1.0;
+      if (opt.dogleg) {
+        if (est_scale) {
+          sc = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(s_d2[i])) : 1.0;
+          W.scale_p[i] = sc;
+        } else {
+          sc = W.scale_p[i];
+        }
+      }
+      const double d2 = damp_diag(s_d2[i], sc, opt);
       s_d2[i] = d2;
       S[LY.at(i, i)] += lambda * d2;
       s_rhs[i] = s_rhs[i] - s_g[i];
@@ -608,6 +787,93 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
   }
   STAMP(6);
+  if constexpr (!LARGE) {
+    if (opt.dogleg && c.explicit_next) {
+      // ------------------------------------------------------------ explicit dogleg step (no factorisation)
+      // delta = -cA xv + beta dGN from the stored Gauss-Newton point dGN (W.step): after a rejected step (radius halved,
+      // Ceres' reuse_) or when the speculative Gauss-Newton trial turned out to lie outside the trust region.
+      // xv_i = g_i / Dt2_i is the Cauchy direction; its step length needs xv^T H xv, evaluated here from the damped
+      // reduced matrix S (just assembled, not factorised) and one pass over the landmarks:
+      //   xv^T H xv = xv_p^T S xv_p - mu sum Dt2 xv_p^2 + sum_l [ t^T (V_l+mu Dt2_l)^-1 t + 2 t.xv_l + xv_l^T V_l xv_l ],  t = W_l^T xv_p
+      __shared__ double s_dl[2];
+      __shared__ double s_sc5[5][SOLVE_THREADS / 64];
+      const double mu = c.mu;
+      for (int i = tid; i < Dpad; i += SOLVE_THREADS) {
+        s_x[i] = i < D ? s_g[i] / s_d2[i] : 0.0;
+        s_rhs[i] = i < D ? W.step[i] : 0.0;
+      }
+      __syncthreads();
+      double q1 = 0, q2 = 0, Ap = 0, Al = 0, Bl = 0;
+      for (int k = tid; k < D * D; k += SOLVE_THREADS) {
+        const int i = k / D, j = k - i * D;
+        const double v = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
+        q1 += v * s_x[i] * s_x[j];
+      }
+      for (int i = tid; i < D; i += SOLVE_THREADS) {
+        q2 += s_d2[i] * s_x[i] * s_x[i];
+        Ap += s_g[i] * s_x[i];
+      }
+      dl_landmark_sums(W, acc, s_x, mu, opt, tid, &Al, &Bl);
+      q1 = wave_sum_full(q1);
+      q2 = wave_sum_full(q2);
+      Ap = wave_sum_full(Ap);
+      Al = wave_sum_full(Al);
+      Bl = wave_sum_full(Bl);
+      if ((tid & 63) == 0) {
+        s_sc5[0][tid >> 6] = q1;
+        s_sc5[1][tid >> 6] = q2;
+        s_sc5[2][tid >> 6] = Ap;
+        s_sc5[3][tid >> 6] = Al;
+        s_sc5[4][tid >> 6] = Bl;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double a[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < 5; ++k)
+          for (int i = 0; i < SOLVE_THREADS / 64; ++i) a[k] += s_sc5[k][i];
+        double cA, beta, dln, model;
+        dogleg_coefficients(a[2] + a[3], (a[0] - mu * a[1]) + a[4], c.tot_C, c.tot_E, mu, c.radius, &cA, &beta, &dln, &model);
+        s_dl[0] = cA;
+        s_dl[1] = beta;
+        c.cA = cA;
+        c.beta = beta;
+        c.dl_norm = dln;
+        c.pend_model = model;
+        c.tot_A = a[2] + a[3];
+      }
+      __syncthreads();
+      {
+        const double cA = s_dl[0], beta = s_dl[1];
+        for (int i = tid; i < Dpad; i += SOLVE_THREADS) s_x[i] = -cA * s_x[i] + beta * s_rhs[i];
+      }
+      __syncthreads();
+      double s2 = 0, x2 = 0;
+      trial_states(W, acc, s_x, tid, true, &s2, &x2);
+      s2 = wave_sum_full(s2);
+      x2 = wave_sum_full(x2);
+      if ((tid & 63) == 0) {
+        s_sc5[0][tid >> 6] = s2;
+        s_sc5[1][tid >> 6] = x2;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double a0 = 0, a1 = 0;
+        for (int i = 0; i < SOLVE_THREADS / 64; ++i) {
+          a0 += s_sc5[0][i];
+          a1 += s_sc5[1][i];
+        }
+        c.step2_p = a0;
+        c.x2_p = a1;
+        c.tr_kind = 1;
+        if (c.explicit_next == 1) c.iter++;   // a new iteration (after a rejection); 2 = same iteration redone
+        c.explicit_next = 0;
+        c.lambda = mu;
+        c.pending = 1;
+        *gctrl = c;
+      }
+      return;
+    }
+  }
   if constexpr (LARGE) {
     // hand the damped system to the tiled multi-workgroup solver (ba_chol_tiles.hpp).  S (HBM, block-packed)
     // holds the IMU / prior / marginalisation part plus the damping; large_export_kernel adds the Schur partials
@@ -622,12 +888,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     __syncthreads();
     if (tid == 0) {
       *gctrl = c;
-      W.ct_flag[ntile + 1] = 1;
+      W.ct_flag[ntile + 1] = (opt.dogleg && c.explicit_next) ? 2 : 1;   // 2 = tiles wanted for the dogleg scalars only
     }
     return;
   }
   if (tid == 0) {
     if (!factor_diag(S + LY.blk(0, 0), s_dinv)) s_fail = 1;
+    if (opt.dogleg && c.mu >= DL_MAX_MU) s_fail = 1;   // DoglegStrategy: no solve is attempted once mu has reached max_mu
   }
   // every lane owns (at most) two fixed 3x3 sub-tiles of the trailing matrix for the whole factorisation (the
   // mirrored enumeration does not depend on kb): coordinates and the C address are computed once; an item is
@@ -790,12 +1057,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   STAMP(7);
   if (s_fail) {  // not positive definite: invalid step (handled like a rejection)
     if (tid == 0) {
-      c.iter++;
       c.chol_fail++;
-      c.radius = c.radius / c.decrease_factor;
-      c.decrease_factor *= 2.0;
       c.pending = 0;
-      if (c.radius < opt.min_radius) c.done = 5 + 1;
+      if (opt.dogleg) {
+        solve_failed_dl(&c, opt);
+      } else {
+        c.iter++;
+        c.radius = c.radius / c.decrease_factor;
+        c.decrease_factor *= 2.0;
+        if (c.radius < opt.min_radius) c.done = 5 + 1;
+      }
       *gctrl = c;
     }
     return;
@@ -844,34 +1115,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       ddd += s_d2[i] * x * x;
       s2 += x * x;
     }
-    double x2 = 0;
-    const int trial = 1 - acc;
-    for (int b = tid; b < W.n_pose; b += SOLVE_THREADS) {
-      const double* xp = W.pose[acc] + 7 * (size_t)b;
-      double* xt = W.pose[trial] + 7 * (size_t)b;
-      const int off = W.pose_off[b];
-      if (off >= 0) {
-        double xin[7], xo[7];
-        for (int k = 0; k < 7; ++k) {
-          xin[k] = xp[k];
-          x2 += xp[k] * xp[k];
-        }
-        pose_oplus(xin, s_x + off, xo);
-        for (int k = 0; k < 7; ++k) xt[k] = xo[k];
-      } else {
-        for (int k = 0; k < 7; ++k) xt[k] = xp[k];
-      }
-    }
-    for (int b = tid; b < W.n_sb; b += SOLVE_THREADS) {
-      const double* xp = W.sb[acc] + 9 * (size_t)b;
-      double* xt = W.sb[trial] + 9 * (size_t)b;
-      const int off = W.sb_off[b];
-      for (int k = 0; k < 9; ++k) {
-        const double v = xp[k];
-        if (off >= 0) x2 += v * v;
-        xt[k] = off >= 0 ? v + s_x[off + k] : v;
-      }
-    }
+    double x2 = 0, s2a = 0;
+    trial_states(W, acc, s_x, tid, opt.dogleg != 0, &s2a, &x2);
+    if (opt.dogleg) s2 = s2a;   // Ceres' step_norm is |x - x_plus_delta| over the ambient coordinates
     __shared__ double s_sc[4][SOLVE_THREADS / 64];
     gd = wave_sum_full(gd);
     ddd = wave_sum_full(ddd);
@@ -897,6 +1143,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       c.step2_p = a2;
       c.x2_p = a3;
       c.lambda = lambda;
+      c.tr_kind = 0;         // dogleg: the Gauss-Newton point, launched speculatively
+      c.explicit_next = 0;
+      c.have_tot = 0;
       c.iter++;
       c.pending = 1;
       *gctrl = c;
@@ -958,7 +1207,7 @@ __global__ __launch_bounds__(CT_THREADS) void chol_tiles_window_kernel(const Win
   const WinPtrs& W = wins[blockIdx.y];
   const int nT = W.ct_nT, ntile = nT * (nT + 1) / 2;
   if (nT == 0 || (int)blockIdx.x >= ntile) return;
-  if (W.ct_flag[ntile + 1] == 0) return;  // nothing exported this iteration (terminated / final pass)
+  if (W.ct_flag[ntile + 1] != 1) return;  // nothing to factorise this iteration (terminated / final pass / explicit dogleg step)
   CholTiles C;
   C.nT = nT;
   C.T = W.ct_T;
@@ -983,14 +1232,103 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
   __shared__ double s_sc[4][SOLVE_THREADS / 64];
   if (tid == 0) c = *gctrl;
   __syncthreads();
-  if (W.ct_flag[ntile]) {  // not positive definite: invalid step (handled like a rejection)
+  if (W.ct_flag[ntile + 1] == 2) {
+    // explicit dogleg step of a large window (see solve_kernel<false>): the damped reduced matrix sits un-factorised in the
+    // 48x48 tiles written by large_export_kernel
+    __shared__ double s_sc5[5][SOLVE_THREADS / 64];
+    __shared__ double s_dl[2];
+    const int D = W.D, acc = c.acc;
+    const double mu = c.mu;
+    for (int i = tid; i < nT * CT_TB; i += SOLVE_THREADS) s_x[i] = i < D ? W.ct_g[i] / W.ct_d2[i] : 0.0;
+    __syncthreads();
+    double q1 = 0, q2 = 0, Ap = 0, Al = 0, Bl = 0;
+    for (int k = tid; k < D * D; k += SOLVE_THREADS) {
+      int i = k / D, j = k - i * D;
+      const double xx = s_x[i] * s_x[j];
+      if (i < j) {
+        const int t = i;
+        i = j;
+        j = t;
+      }
+      const int ti = i / CT_TB, tj = j / CT_TB;
+      q1 += W.ct_T[(size_t)(ti * (ti + 1) / 2 + tj) * CT_TILE + (i - CT_TB * ti) * CT_TB + (j - CT_TB * tj)] * xx;
+    }
+    for (int i = tid; i < D; i += SOLVE_THREADS) {
+      q2 += W.ct_d2[i] * s_x[i] * s_x[i];
+      Ap += W.ct_g[i] * s_x[i];
+    }
+    dl_landmark_sums(W, acc, s_x, mu, opt, tid, &Al, &Bl);
+    q1 = wave_sum_full(q1);
+    q2 = wave_sum_full(q2);
+    Ap = wave_sum_full(Ap);
+    Al = wave_sum_full(Al);
+    Bl = wave_sum_full(Bl);
+    if ((tid & 63) == 0) {
+      s_sc5[0][tid >> 6] = q1;
+      s_sc5[1][tid >> 6] = q2;
+      s_sc5[2][tid >> 6] = Ap;
+      s_sc5[3][tid >> 6] = Al;
+      s_sc5[4][tid >> 6] = Bl;
+    }
+    __syncthreads();
     if (tid == 0) {
-      c.iter++;
+      double a[5] = {0, 0, 0, 0, 0};
+      for (int k = 0; k < 5; ++k)
+        for (int i = 0; i < SOLVE_THREADS / 64; ++i) a[k] += s_sc5[k][i];
+      double cA, beta, dln, model;
+      dogleg_coefficients(a[2] + a[3], (a[0] - mu * a[1]) + a[4], c.tot_C, c.tot_E, mu, c.radius, &cA, &beta, &dln, &model);
+      s_dl[0] = cA;
+      s_dl[1] = beta;
+      c.cA = cA;
+      c.beta = beta;
+      c.dl_norm = dln;
+      c.pend_model = model;
+      c.tot_A = a[2] + a[3];
+    }
+    __syncthreads();
+    {
+      const double cA = s_dl[0], beta = s_dl[1];
+      for (int i = tid; i < D; i += SOLVE_THREADS) s_x[i] = -cA * s_x[i] + beta * W.step[i];
+    }
+    __syncthreads();
+    double s2 = 0, x2 = 0;
+    trial_states(W, acc, s_x, tid, true, &s2, &x2);
+    s2 = wave_sum_full(s2);
+    x2 = wave_sum_full(x2);
+    if ((tid & 63) == 0) {
+      s_sc5[0][tid >> 6] = s2;
+      s_sc5[1][tid >> 6] = x2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double a0 = 0, a1 = 0;
+      for (int i = 0; i < SOLVE_THREADS / 64; ++i) {
+        a0 += s_sc5[0][i];
+        a1 += s_sc5[1][i];
+      }
+      c.step2_p = a0;
+      c.x2_p = a1;
+      c.tr_kind = 1;
+      if (c.explicit_next == 1) c.iter++;
+      c.explicit_next = 0;
+      c.lambda = mu;
+      c.pending = 1;
+      *gctrl = c;
+    }
+    return;
+  }
+  if (W.ct_flag[ntile] || (opt.dogleg && c.mu >= DL_MAX_MU)) {  // not positive definite: invalid step (handled like a rejection)
+    if (tid == 0) {
       c.chol_fail++;
-      c.radius = c.radius / c.decrease_factor;
-      c.decrease_factor *= 2.0;
       c.pending = 0;
-      if (c.radius < opt.min_radius) c.done = 5 + 1;
+      if (opt.dogleg) {
+        solve_failed_dl(&c, opt);
+      } else {
+        c.iter++;
+        c.radius = c.radius / c.decrease_factor;
+        c.decrease_factor *= 2.0;
+        if (c.radius < opt.min_radius) c.done = 5 + 1;
+      }
       *gctrl = c;
     }
     return;
@@ -1003,8 +1341,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
   C.y = W.ct_y;
   C.flag = W.ct_flag;
   chol_backsub(C, s_x, s_scratch, tid, SOLVE_THREADS);
-  const int D = W.D, acc = c.acc, trial = 1 - acc;
-  const double lambda = 1.0 / c.radius;
+  const int D = W.D, acc = c.acc;
+  const double lambda = opt.dogleg ? c.mu : 1.0 / c.radius;
   double gd = 0, ddd = 0, s2 = 0, x2 = 0;
   for (int i = tid; i < D; i += SOLVE_THREADS) {
     const double x = s_x[i];
@@ -1013,31 +1351,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
     ddd += W.ct_d2[i] * x * x;
     s2 += x * x;
   }
-  for (int b = tid; b < W.n_pose; b += SOLVE_THREADS) {
-    const double* xp = W.pose[acc] + 7 * (size_t)b;
-    double* xt = W.pose[trial] + 7 * (size_t)b;
-    const int off = W.pose_off[b];
-    if (off >= 0) {
-      double xin[7], xo[7];
-      for (int k = 0; k < 7; ++k) {
-        xin[k] = xp[k];
-        x2 += xp[k] * xp[k];
-      }
-      pose_oplus(xin, s_x + off, xo);
-      for (int k = 0; k < 7; ++k) xt[k] = xo[k];
-    } else {
-      for (int k = 0; k < 7; ++k) xt[k] = xp[k];
-    }
-  }
-  for (int b = tid; b < W.n_sb; b += SOLVE_THREADS) {
-    const double* xp = W.sb[acc] + 9 * (size_t)b;
-    double* xt = W.sb[trial] + 9 * (size_t)b;
-    const int off = W.sb_off[b];
-    for (int k = 0; k < 9; ++k) {
-      const double v = xp[k];
-      if (off >= 0) x2 += v * v;
-      xt[k] = off >= 0 ? v + s_x[off + k] : v;
-    }
+  {
+    double s2a = 0;
+    trial_states(W, acc, s_x, tid, opt.dogleg != 0, &s2a, &x2);
+    if (opt.dogleg) s2 = s2a;
   }
   gd = wave_sum(gd);
   ddd = wave_sum(ddd);
@@ -1063,10 +1380,19 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
     c.step2_p = a2;
     c.x2_p = a3;
     c.lambda = lambda;
+    c.tr_kind = 0;
+    c.explicit_next = 0;
+    c.have_tot = 0;
     c.iter++;
     c.pending = 1;
     *gctrl = c;
   }
+}
+
+// iteration budget of the dogleg strategy: okvis_ba_iterate(n) allows n more iterations (launch slots spent on the redo
+// of a mis-speculated Gauss-Newton trial do not count as iterations, so slots and iterations can differ)
+__global__ void add_budget_kernel(const WinPtrs* __restrict__ wins, int n) {
+  if (threadIdx.x == 0) wins[blockIdx.x].ctrl->max_iter += n;
 }
 
 // landmark quality (Estimator.cpp:880-896): 3x3 eigenvalues of the un-robustified H_l of the accepted

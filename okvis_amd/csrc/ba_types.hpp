@@ -85,11 +85,18 @@ enum { GS_COST = 0, GS_GD = 1, GS_DDD = 2, GS_STEP2 = 3, GS_X2 = 4, GS_GMAX = 5,
 
 // solver options on the device
 struct OptD {
-  double initial_radius, max_radius, min_radius, min_lm_diag2, max_lm_diag2;
+  double initial_radius, max_radius, min_radius, min_lm_diag2, max_lm_diag2;  // diag2 bounds: Ceres clamps the SQUARED column norm
   double min_relative_decrease, function_tolerance, gradient_tolerance, parameter_tolerance;
   int gauss_newton;  // 1 = accept every step, keep the radius fixed
   int marg_mode;     // 1 = marginalisation pass: no damping, landmark blocks eliminated with the preconditioned pseudo-inverse
+  int dogleg;        // 1 = Ceres' DOGLEG strategy (the reference's configuration), 0 = Levenberg-Marquardt
+  int jacobi_scaling;
+  int max_invalid;   // max_num_consecutive_invalid_steps
+  int pad;
 };
+
+// DoglegStrategy constants (Ceres: kMinMu, kMaxMu, mu_increase_factor_)
+constexpr double DL_MIN_MU = 1e-8, DL_MAX_MU = 1.0, DL_MU_INCREASE = 10.0;
 
 // trust-region state of one window; written ONLY by the solve kernel (and the finish kernel)
 struct Ctrl {
@@ -107,7 +114,25 @@ struct Ctrl {
   double gd_p, ddd_p, step2_p, x2_p;  // pose/speed-bias part of g.delta, delta^T D^2 delta, |delta|^2, |x|^2
   double initial_cost, abs_grad_tol, grad_max;
   double last_rho, last_model_change;
+  // ---- dogleg strategy (OptD::dogleg) ----
+  // The trial after a fresh Gauss-Newton solve is launched SPECULATIVELY as the Gauss-Newton point itself (kind 0):
+  // whether it lies inside the trust region is only known once the landmark part of its norm has been reduced by
+  // the linearise kernel.  The next decision either judges it (inside) or replaces it by an explicit dogleg step
+  // delta = -cA xv + beta dGN (kind 1), which is also what follows every rejected step (Ceres' reuse_).
+  int tr_kind;        // kind of the pending trial: 0 = Gauss-Newton point / LM step, 1 = explicit coefficients
+  int explicit_next;  // the decision just taken asks for an explicit dogleg step (no new Schur reduce / factorisation):
+                      // 1 = after a rejected step (a new iteration), 2 = redo of a mis-speculated Gauss-Newton trial (same iteration)
+  int invalid_steps;  // consecutive invalid steps
+  int max_iter;       // iteration budget of this optimize call (slots spent on mis-speculation do not count)
+  double mu;          // regularisation multiplier of the Gauss-Newton solve
+  double cA, beta;    // coefficients of the pending explicit trial
+  double dl_norm;     // dogleg_step_norm_ of the pending explicit trial
+  double pend_model;  // model cost change of the pending explicit trial
+  double tot_C, tot_E;  // g.dGN and |gnhat|^2 of the accepted point (pose + landmark parts), valid when have_tot
+  double tot_A;       // (diagnostic) |ghat|^2 of the last explicit step
+  int have_tot, pad2;
 };
+static_assert(sizeof(Ctrl) % 8 == 0 && sizeof(Ctrl) / 8 <= 64, "Ctrl is fetched by one wave, one double per lane");
 
 struct WinPtrs {
   // ---- sizes ----
@@ -187,7 +212,9 @@ struct WinPtrs {
   double* ct_g;           // [48 nT] gradient of the accepted linearisation (for the step scalars)
   double* ct_d2;          // [48 nT] damping diagonal
   double* rhs;            // [D]
-  double* step;           // [D]
+  double* step;           // [D] reduced step of the last solve (dogleg: the Gauss-Newton point dGN)
+  double* scale_p;        // [D] Jacobi scale of the pose/speed-bias columns (first linearisation of the call)
+  double* lm_scale;       // [n_lm][3] Jacobi scale of the landmark columns
   double* grad;           // [D]
   double* Dp2;            // [D]
   double* Hpp;            // [D][D] undamped U (debug/parity), optional

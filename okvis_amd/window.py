@@ -140,7 +140,7 @@ def marg_call(fn, n_pose, n_sb, pose_marg, sb_marg, prior=None):
 
 
 STRATEGY_DOGLEG, STRATEGY_LM = 0, 1
-DEFAULT_STRATEGY = STRATEGY_LM
+DEFAULT_STRATEGY = STRATEGY_DOGLEG
 
 
 def default_options(strategy=None) -> OptionsC:

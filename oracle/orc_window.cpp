@@ -790,6 +790,10 @@ void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis
       hessian_times(h, step, &Hs);
       model_change = -dotf(g, step) - 0.5 * dotf(step, Hs);
       if (model_change < 0.0 && !opt.gauss_newton) valid = false;
+      if (std::getenv("ORC_TRACE"))
+        std::fprintf(stderr, "orc it %d radius %.17g mu %g A %.17g B %.17g C %.17g E %.17g alpha %.17g cA %.17g beta %.17g dl %.17g model %.17g\n",
+                     it, radius, mu, dotf(ghat, ghat), dotf(ghat, ghat) / alpha, dotf(ghat, gnhat), dotf(gnhat, gnhat), alpha, cA,
+                     beta, dogleg_step_norm, model_change);
     }
     if (!valid) {  // StepIsInvalid: counted as an unsuccessful iteration of zero length
       if (++invalid_steps >= std::max(1, opt.max_consecutive_invalid_steps)) {
@@ -1044,6 +1048,25 @@ double orc_window_linearize(orc_window* h) {
 }
 double orc_window_cost(orc_window* h) { return evaluate(h, false); }
 int orc_window_solve(orc_window* h, double radius, const okvis_ba_options* opt) {
+  if (opt->strategy == OKVIS_BA_STRATEGY_DOGLEG) {
+    // the Gauss-Newton solve of the FIRST dogleg iteration: Jacobi scale from the current linearisation, mu = min_mu
+    static const int dg[3] = {0, 3, 5};
+    const int D = h->D;
+    h->Dp2.assign(D, 0.0);
+    h->Dl2.assign(3 * (size_t)h->n_lm, 0.0);
+    for (int i = 0; i < D; ++i) {
+      const double hh = h->U[(size_t)i * D + i];
+      const double sc = opt->jacobi_scaling ? 1.0 / (1.0 + std::sqrt(hh)) : 1.0;
+      h->Dp2[i] = clampd(sc * sc * hh, opt->min_lm_diagonal, opt->max_lm_diagonal) / (sc * sc);
+    }
+    for (int l = 0; l < h->n_lm; ++l)
+      for (int k = 0; k < 3; ++k) {
+        const double hh = h->V[6 * l + dg[k]];
+        const double sc = opt->jacobi_scaling ? 1.0 / (1.0 + std::sqrt(hh)) : 1.0;
+        h->Dl2[3 * l + k] = clampd(sc * sc * hh, opt->min_lm_diagonal, opt->max_lm_diagonal) / (sc * sc);
+      }
+    return solve_damped(h, 1e-8) ? 0 : 1;
+  }
   return solve(h, radius, *opt) ? 0 : 1;
 }
 void orc_window_optimize(orc_window* h, const okvis_ba_options* opt, int num_iter, okvis_ba_summary* summary) {

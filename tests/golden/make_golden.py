@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Generate the committed fixtures tests/golden/*.npz.
 
-TEST INFRASTRUCTURE ONLY.  The reference (ethz-asl/okvis) holds no golden vectors for this path and
-cannot be built here (no Eigen / Ceres / glog), so the vectors are produced by the C++
-oracle (`oracle/`) and every factor value is cross-checked, before it is written, against the independent
-numpy/scipy statement in `independent.py` (agreement required to 1e-11 relative).  Re-run with
+TEST INFRASTRUCTURE ONLY.  The reference (ethz-asl/okvis) holds no golden vectors for this path.  The vectors are
+produced by the C++ oracle (`oracle/`) and every factor value is cross-checked, before it is written, against
+(a) the reference's OWN classes compiled unmodified into oracle/_ref (tests/ref_lib.py; required to 1e-12 when the
+reference tree is present — it is in the authoring container) and (b) the independent numpy/scipy statement in
+`independent.py` (1e-11).  tests/test_oracle_vs_ref.py re-checks (a) on every CPU run.  The window-level vectors
+are results of the DOGLEG policy (the default, Estimator.cpp:858).  Re-run with
 
     python tests/golden/make_golden.py
 
@@ -28,6 +30,9 @@ sys.path.insert(0, HERE)
 
 import independent as ind  # noqa: E402
 import oracle_lib as O  # noqa: E402
+import ref_lib as R  # noqa: E402
+
+HAVE_REF = R.available()
 from okvis_amd import synthetic  # noqa: E402
 from okvis_amd.window import ImuParams, Window, default_options  # noqa: E402
 
@@ -84,6 +89,10 @@ def factor_vectors():
         intr = np.array(INTR[model], float)
         r, Jp, Jl, Je, valid, _defined = O.reprojection(pose, pt, extr, intr, model, uv, sw * np.eye(2))
         _agree(r, ind.reprojection_residual(pose, pt, extr, intr, model, uv, sw), "reprojection residual")
+        if HAVE_REF:
+            rr = R.reprojection(pose, pt, extr, intr, model, uv, sw * np.eye(2))
+            for a, b, n in zip((r, Jp, Jl, Je), rr, ("r", "Jp", "Jl", "Je")):
+                assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), f"reprojection {n} vs reference"
         for k, v in zip(rp, (model, pose, pt, extr, intr, uv, sw, r, Jp, Jl, Je, valid)):
             rp[k].append(v)
     out.update({"reproj_" + k: np.array(v) for k, v in rp.items()})
@@ -152,6 +161,11 @@ def factor_vectors():
         _agree(si.T @ si / np.abs(si.T @ si).max(), L2.T @ L2 / np.abs(L2.T @ L2).max(), "IMU information")
         e = np.abs(r - r2).max() / max(1.0, np.abs(r2).max())
         assert e < 1e-10, f"IMU residual: {e:.3e}"   # measured ~1e-13 (covariance cond ~1e9)
+        if HAVE_REF:
+            rr, Jr, sir, _ = R.imu_evaluate_fresh(t, gyr, acc, prm, t0, t1, pose0, sb0, pose1, sb1)
+            assert np.abs(r - rr).max() <= 1e-12 * max(1.0, np.abs(rr).max()), "IMU residual vs reference"
+            for a, b in zip(Js, Jr):
+                assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), "IMU Jacobian vs reference"
         streams.append((t, gyr, acc))
         for k, v in zip(im, (t0, t1, pose0, sb0, pose1, sb1, r, *Js, si, cnt)):
             im[k].append(v)

@@ -72,12 +72,12 @@ def test_schur_step_equals_dense_solve(oracle, ext):
     w = synthetic.small_window(seed=12, K=4, L=30, estimate_extrinsics=ext)
     o = oracle.OracleWindow(w)
     o.linearize()
-    opt = default_options()
+    opt = default_options(1)      # Levenberg-Marquardt damping D^2 / radius (the Schur algebra is what is tested here)
     radius = 1e4
     assert o.solve(radius, opt) == 0
     H = _assemble_full(o, w)
     g = o.full_gradient()
-    D2 = np.clip(np.diag(H), opt.min_lm_diagonal ** 2, opt.max_lm_diagonal ** 2)
+    D2 = np.clip(np.diag(H), opt.min_lm_diagonal, opt.max_lm_diagonal)   # Ceres clamps the squared column norm
     delta = np.linalg.solve(H + np.diag(D2) / radius, -g)
     step = o.array("STEP")
     # condition number ~1e16/1e0: compare in the metric of the system
