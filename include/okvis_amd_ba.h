@@ -309,6 +309,9 @@ int okvis_ba_last_iterate_ms(okvis_ba_solver* s, float* total_ms);
  * time of the {Schur, solve, IMU/prior, linearise} kernels over n iterations. Slower than graph replay;
  * used only to attribute time for the roofline object. */
 int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4);
+/* the same pass with one record per iteration: ms[i][4] = durations of the {Schur, solve, -, linearise} launches of
+ * iteration i (bench.py reports the median launch and the launches that carry an IMU re-preintegration separately) */
+int okvis_ba_profile_launches(okvis_ba_solver* s, int n, float* ms /* [n][4] */);
 /* algorithmic bytes one iteration moves for the uploaded batch (formula in DESIGN.md §4) */
 int okvis_ba_algorithmic_bytes(okvis_ba_solver* s, int64_t* linearize_bytes, int64_t* schur_bytes,
                                int64_t* solve_bytes, int64_t* small_bytes);

@@ -16,7 +16,7 @@ SYMBOLS = [
     "okvis_ba_optimize", "okvis_ba_optimize_timed", "okvis_ba_begin", "okvis_ba_iterate", "okvis_ba_finish",
     "okvis_ba_evaluate_cost", "okvis_ba_get_state", "okvis_ba_fetch_results", "okvis_ba_array_size", "okvis_ba_download",
     "okvis_ba_reduced_dim", "okvis_ba_pair_count", "okvis_ba_pairs", "okvis_ba_last_iterate_ms",
-    "okvis_ba_profile_iterations", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize", "okvis_ba_marginalize",
+    "okvis_ba_profile_iterations", "okvis_ba_profile_launches", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize", "okvis_ba_marginalize",
     "okvis_ba_dense_solve",
 ]
 
@@ -70,6 +70,7 @@ def lib():
     L.okvis_ba_pairs.argtypes = [vp, C.c_int, _ip, _ip]
     L.okvis_ba_last_iterate_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.okvis_ba_profile_iterations.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.okvis_ba_profile_launches.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.okvis_ba_algorithmic_bytes.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     L.okvis_ba_synchronize.argtypes = [vp]
     _lib = L

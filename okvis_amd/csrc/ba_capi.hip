@@ -1432,16 +1432,17 @@ int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t
   return OKVIS_BA_OK;
 }
 
-int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4) {
+static int profile_impl(okvis_ba_solver* s, int n, float* ms4, float* per_launch) {
   if (s) s->acc_fresh = false;
-  if (!s || !ms4 || n <= 0) return OKVIS_BA_ERR_ARG;
+  if (!s || n <= 0) return OKVIS_BA_ERR_ARG;
   if (!s->begun) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
   // queue all n iterations with events between the kernels and synchronise ONCE: the kernels run
   // back-to-back on the GPU, so the event intervals are kernel durations, not host launch latency
   std::vector<hipEvent_t> ev(5 * (size_t)n);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-  for (int k = 0; k < 4; ++k) ms4[k] = 0.f;
+  if (ms4)
+    for (int k = 0; k < 4; ++k) ms4[k] = 0.f;
   HIP_TRY(launch_budget(s, whole(s), n));
   for (int i = 0; i < n; ++i) {
     hipEvent_t* e = &ev[5 * (size_t)i];
@@ -1459,10 +1460,19 @@ int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4) {
     for (int k = 0; k < 4; ++k) {
       float t = 0;
       HIP_TRY(hipEventElapsedTime(&t, ev[5 * (size_t)i + k], ev[5 * (size_t)i + k + 1]));
-      ms4[k] += t;
+      if (ms4) ms4[k] += t;
+      if (per_launch) per_launch[4 * (size_t)i + k] = t;
     }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return OKVIS_BA_OK;
+}
+int okvis_ba_profile_iterations(okvis_ba_solver* s, int n, float* ms4) {
+  if (!ms4) return OKVIS_BA_ERR_ARG;
+  return profile_impl(s, n, ms4, nullptr);
+}
+int okvis_ba_profile_launches(okvis_ba_solver* s, int n, float* ms) {
+  if (!ms) return OKVIS_BA_ERR_ARG;
+  return profile_impl(s, n, nullptr, ms);
 }
 
 int okvis_ba_algorithmic_bytes(okvis_ba_solver* s, int64_t* lin, int64_t* schur, int64_t* solve, int64_t* small) {

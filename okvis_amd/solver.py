@@ -173,6 +173,13 @@ class WindowBatch:
         _lib.check(self._L.okvis_ba_profile_iterations(self._h, int(n), ms))
         return dict(schur=ms[0], solve=ms[1], small=ms[2], linearize=ms[3])
 
+    def profile_launches(self, n: int):
+        """per-iteration launch durations [n][3] in ms: schur, solve, linearise (incl. the IMU / prior workgroups)"""
+        ms = (C.c_float * (4 * int(n)))()
+        _lib.check(self._L.okvis_ba_profile_launches(self._h, int(n), ms))
+        a = np.array(ms[:], dtype=np.float64).reshape(int(n), 4)
+        return dict(schur=a[:, 0], solve=a[:, 1], linearize=a[:, 2] + a[:, 3])
+
     def algorithmic_bytes(self):
         v = [C.c_int64() for _ in range(4)]
         _lib.check(self._L.okvis_ba_algorithmic_bytes(self._h, *[C.byref(x) for x in v]))
