@@ -946,6 +946,19 @@ typename MatrixBase<A>::PlainObject operator/(const MatrixBase<A>& a, const T& s
     for (Index i = 0; i < a.rows(); ++i) r.coeffRef(i, j) = a.coeff(i, j) / (typename A::Scalar)s;
   return r;
 }
+// a fixed 1x1 result (inner product written as a^T b) used as a scalar in arithmetic with scalars
+#define ESHIM_1X1_OP(OP)                                                                                     \
+  template <class S, int O, class T, class = typename std::enable_if<internal::is_scalar<T>::value>::type>  \
+  S operator OP(const Matrix<S, 1, 1, O, 1, 1>& a, const T& s) {                                             \
+    return a.coeff(0, 0) OP(S) s;                                                                            \
+  }                                                                                                          \
+  template <class S, int O, class T, class = typename std::enable_if<internal::is_scalar<T>::value>::type>  \
+  S operator OP(const T& s, const Matrix<S, 1, 1, O, 1, 1>& a) {                                             \
+    return (S)s OP a.coeff(0, 0);                                                                            \
+  }
+ESHIM_1X1_OP(+)
+ESHIM_1X1_OP(-)
+#undef ESHIM_1X1_OP
 template <class A, class B>
 bool operator==(const MatrixBase<A>& a, const MatrixBase<B>& b) {
   if (a.rows() != b.rows() || a.cols() != b.cols()) return false;

@@ -30,6 +30,12 @@ class Mat {
     data = buf_.empty() ? 0 : buf_.data();
     return *this;
   }
+  static Mat zeros(int r, int c, int t) { return Mat(r, c, t); }
+  static Mat ones(int r, int c, int t) {
+    Mat m(r, c, t);
+    for (auto& v : m.buf_) v = 1;
+    return m;
+  }
   bool empty() const { return rows == 0 || cols == 0; }
   int type() const { return CV_8UC1; }
   Mat clone() const { return *this; }

@@ -261,3 +261,25 @@ class RefWindow:
         s = SummaryC()
         lib().ref_window_optimize(self._h, C.byref(opt), int(num_iter), int(bool(dogleg)), C.byref(s))
         return s.as_dict()
+
+
+# ---- the reference's okvis::Estimator behind the same Python surface as okvis_amd.estimator.Estimator -------------
+def estimator_api():
+    """flat estimator API of the reference build (ref_est_*), usable as `api=` of okvis_amd.estimator.Estimator / Frame"""
+    from okvis_amd import estimator as E
+    global _est_api
+    try:
+        return _est_api
+    except NameError:
+        _est_api = E.Api(lib(), "ref_est_")
+        return _est_api
+
+
+def RefEstimator():
+    from okvis_amd import estimator as E
+    return E.Estimator(0, api=estimator_api())
+
+
+def RefFrame(frame_id, t_ns, T_SC, intr, models):
+    from okvis_amd import estimator as E
+    return E.Frame(frame_id, t_ns, T_SC, intr, models, api=estimator_api())
