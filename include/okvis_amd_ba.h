@@ -85,7 +85,8 @@ typedef struct okvis_ba_window {
   const int32_t* cam_model;   /* [n_cam] OKVIS_BA_DIST_*                                               */
 
   /* ---- reprojection observations (ReprojectionError<G>, implementation/Estimator.hpp:43-90) ----
-   * MUST be sorted by (lm, pose, cam); every landmark referenced by <= okvis_ba_limits.max_obs_per_lm. */
+   * MUST be sorted by (lm, pose, cam) (repeated triples allowed: two keypoints of one image matched to one landmark);
+   * every landmark referenced by <= okvis_ba_limits.max_obs_per_lm. */
   int32_t n_obs;
   const int32_t* obs_lm;      /* [n_obs] landmark index                                                */
   const int32_t* obs_pose;    /* [n_obs] pose block index of T_WS                                      */

@@ -212,7 +212,9 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (l < 0 || l >= nlm || ip < 0 || ip >= npose || ie < 0 || ie >= npose || c < 0 || c >= w.n_cam) return OKVIS_BA_ERR_ARG;
     if (o > 0) {
       const int pl = w.obs_lm[o - 1], pp = w.obs_pose[o - 1], pc = w.obs_cam[o - 1];
-      if (pl > l || (pl == l && (pp > ip || (pp == ip && pc >= c)))) return OKVIS_BA_ERR_ARG;  // unsorted / duplicate
+      // sorted by (landmark, pose, cam); REPEATED (landmark, pose, cam) entries are legal: the reference adds one residual
+      // block per matched keypoint (implementation/Estimator.hpp:52-56 only rejects an identical KeypointIdentifier)
+      if (pl > l || (pl == l && (pp > ip || (pp == ip && pc > c)))) return OKVIS_BA_ERR_ARG;  // unsorted
     }
     if (role[ip] == 1 || role[ie] == 0 || ip == ie) return OKVIS_BA_ERR_UNSUPPORTED;
     role[ip] = 0;

@@ -962,6 +962,25 @@ size_t Estimator::getLandmarks(MapPointVector& landmarks) const {
   for (const auto& kv : landmarksMap_) landmarks.push_back(kv.second);
   return landmarksMap_.size();
 }
+void Estimator::printStates(uint64_t poseId, std::ostream& buffer) const {
+  const State* st = findState(poseId);
+  if (!st) throw Exception("Requested state does not exist in estimator.");   // statesMap_.at(poseId) throws in the reference
+  auto item = [&](uint64_t id, bool fixed, const char* type) {
+    if (fixed) buffer << "(";
+    buffer << "id=" << id << ":" << type;
+    if (fixed) buffer << ")";
+    buffer << ", ";
+  };
+  buffer << "GLOBAL: ";
+  if (st->poseBlock >= 0 && poseBlocks_[st->poseBlock].alive)
+    item(poseBlocks_[st->poseBlock].id, poseBlocks_[st->poseBlock].fixed, "PoseParameterBlock");
+  buffer << "SENSOR: ";
+  for (int e : st->extBlocks)
+    if (e >= 0 && poseBlocks_[e].alive) item(poseBlocks_[e].id, poseBlocks_[e].fixed, "PoseParameterBlock");
+  if (st->sbBlock >= 0 && sbBlocks_[st->sbBlock].alive)
+    item(sbBlocks_[st->sbBlock].id, sbBlocks_[st->sbBlock].fixed, "SpeedAndBiasParameterBlock");
+  buffer << std::endl;
+}
 MultiFramePtr Estimator::multiFrame(uint64_t frameId) const {
   auto it = multiFramePtrMap_.find(frameId);
   if (it == multiFramePtrMap_.end()) throw Exception("Requested multi-frame does not exist in estimator.");

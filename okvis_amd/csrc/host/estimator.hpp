@@ -14,6 +14,7 @@
 #include <array>
 #include <cstdint>
 #include <map>
+#include <ostream>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -116,7 +117,10 @@ class Estimator {
   bool getLandmark(uint64_t id, MapPoint& mapPoint) const;
   size_t getLandmarks(PointMap& landmarks) const;
   size_t getLandmarks(MapPointVector& landmarks) const;
-  MultiFramePtr multiFrame(uint64_t frameId) const;
+  MultiFramePtr multiFrame(uint64_t frameId) const;   // throws for an unknown id, like Estimator.cpp:1114-1120
+  /// Estimator::printStates (Estimator.hpp:141, Estimator.cpp:776-809): the blocks of one state, fixed ones in parentheses
+  void printStates(uint64_t poseId, std::ostream& buffer) const;
+  bool hasFrame(uint64_t frameId) const { return multiFramePtrMap_.count(frameId) != 0; }   // non-throwing query
   bool get_T_WS(uint64_t poseId, Transformation& T_WS) const;
   bool getSpeedAndBias(uint64_t poseId, uint64_t imuIdx, SpeedAndBias& sb) const;
   bool getCameraSensorStates(uint64_t poseId, size_t cameraIdx, Transformation& T_SCi) const;

@@ -1,10 +1,11 @@
 // okvis::Estimator adapter — source-compatible drop-in for okvis_ceres/include/okvis/Estimator.hpp.
 //
 // Converts the Eigen / OKVIS types of the reference's public signatures to the PODs of
-// okvis_amd::Estimator (estimator.hpp).  It can only be compiled where Eigen, OpenCV and the OKVIS headers
-// exist, which is NOT the case in the build container of this repository: everything below
-// the `__has_include` guard is therefore compiled against the real headers only on a machine with those dependencies;
-// here it is compile-checked against stand-in declarations of that interface (tests/mock_okvis/, CPU test suite).
+// okvis_amd::Estimator (estimator.hpp).  It needs Eigen, OpenCV and the OKVIS headers.  In this repository it is
+// (a) compiled against the reference's REAL okvis headers (VioBackendInterface.hpp, MultiFrame.hpp, Frame.hpp,
+// NCameraSystem.hpp, Parameters.hpp ...) with the stand-in Eigen / glog / OpenCV / ceres headers of oracle/shim, and
+// RUN on the GPU through a sliding window with marginalisation (oracle/ref/adapter_runtime.cpp, tests/test_gpu_adapter.py),
+// (b) compile-checked against the minimal stand-in declarations of tests/mock_okvis/ (CPU suite, no reference tree needed).
 // See INTEGRATION.md for how a maintainer wires it into okvis_ceres.
 #pragma once
 #include "estimator.hpp"
@@ -116,6 +117,7 @@ class Estimator : public VioBackendInterface {
     for (int i = 0; i < 9; ++i) sb[i] = s[i];
     return true;
   }
+  void printStates(uint64_t poseId, std::ostream& buffer) const { impl_.printStates(poseId, buffer); }   // Estimator.hpp:141
   size_t numFrames() const override { return impl_.numFrames(); }
   size_t numLandmarks() const override { return impl_.numLandmarks(); }
   uint64_t currentKeyframeId() const { return impl_.currentKeyframeId(); }
@@ -187,7 +189,7 @@ class Estimator : public VioBackendInterface {
   // frames whose states were marginalised are released like Estimator.cpp:730 does (multiFramePtrMap_.erase)
   void releaseMarginalizedFrames() {
     for (auto it = frames_.begin(); it != frames_.end();) {
-      if (impl_.multiFrame(it->first)) {
+      if (impl_.hasFrame(it->first)) {
         ++it;
       } else {
         pods_.erase(it->first);

@@ -264,8 +264,8 @@ class Window:
             k = (key[:, 0] * (npz + 1) + key[:, 1]) * (len(self.cam_model) + 1) + key[:, 2]
             if np.any(np.diff(k) < 0):
                 raise ValueError("observations must be sorted by (lm, pose, cam)")
-            if np.any(np.diff(k) == 0):
-                raise ValueError("duplicate observation (implementation/Estimator.hpp:52-56)")
+            # equal keys are legal: one landmark matched to two keypoints of the same image gives two residual blocks in
+            # the reference (implementation/Estimator.hpp:52-56 only rejects an identical KeypointIdentifier)
         md = np.asarray(self.marg_e0).size
         if md and np.asarray(self.marg_J).shape != (md, md):
             raise ValueError("marg_J must be [marg_dim, marg_dim]")

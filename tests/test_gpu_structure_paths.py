@@ -130,3 +130,21 @@ def test_fetch_results_equals_the_single_downloads():
     assert np.array_equal(f["quality"], b.array("LM_QUALITY"))
     assert np.array_equal(f["imu_sb_ref"].ravel(), b.array("IMU_SB_REF"))
     b.close()
+
+
+def test_repeated_landmark_pose_camera_observations(oracle):
+    """one landmark matched to two keypoints of the same image (via different keyframes): the reference adds two residual
+    blocks (implementation/Estimator.hpp:52-56 only rejects an identical KeypointIdentifier); the window format allows
+    repeated (landmark, pose, cam) triples"""
+    w = synthetic.small_window(seed=47, K=4, L=40)
+    rng = np.random.default_rng(47)
+    dup = rng.choice(w.obs_lm.size, 25, replace=False)
+    order = np.sort(np.concatenate([np.arange(w.obs_lm.size), dup]))      # every duplicate right after its original
+    for name in ("obs_lm", "obs_pose", "obs_ext", "obs_cam", "obs_sqrtw"):
+        setattr(w, name, np.asarray(getattr(w, name))[order].copy())
+    uv = np.asarray(w.obs_uv)[order].copy()
+    is_dup = np.r_[False, order[1:] == order[:-1]]
+    uv[is_dup] += rng.uniform(-1.5, 1.5, (int(is_dup.sum()), 2))          # a different keypoint
+    w.obs_uv = uv
+    assert is_dup.sum() == 25
+    _compare(oracle, w, 8)

@@ -89,10 +89,10 @@ def test_upload_validation_errors():
     assert status(bad) == -1
     bad = copy.deepcopy(w); bad.obs_pose = bad.obs_pose.copy(); bad.obs_pose[0] = 99   # out of range
     assert status(bad) == -1
-    bad = copy.deepcopy(w)                                                 # duplicate observation
-    for n in ("obs_lm", "obs_pose", "obs_ext", "obs_cam", "obs_uv", "obs_sqrtw"):
-        a = getattr(bad, n); setattr(bad, n, np.concatenate([a[:1], a]))
-    assert status(bad) == -1
+    rep = copy.deepcopy(w)                                                 # a repeated (landmark, pose, cam) triple is legal:
+    for n in ("obs_lm", "obs_pose", "obs_ext", "obs_cam", "obs_uv", "obs_sqrtw"):   # two keypoints of one image matched to one landmark
+        a = getattr(rep, n); setattr(rep, n, np.concatenate([a[:1], a]))
+    assert status(rep) == 0
     bad = copy.deepcopy(w); bad.imu_s_count = bad.imu_s_count.copy(); bad.imu_s_count[0] = 5   # samples do not reach t1
     assert status(bad) == -1
     big = synthetic.make_window(3, 5, 1.0, 1)
