@@ -66,6 +66,10 @@ void orc_sqrt_information(const double* info, int n, double* out);
 /* ---- window-level ---- */
 orc_window* orc_window_create(const okvis_ba_window* w);
 void orc_window_destroy(orc_window* h);
+/* CPU-baseline mode (bench.py): OpenMP threads for the observation sweep and the landmark Schur reduction; 1 = the
+ * serial reference order used by every parity test */
+int orc_set_threads(int n);
+int orc_max_threads(void);
 /* marginalisation-prior Jacobian convention: 1 (default) = what Ceres effectively uses,
  * J_min * lift(x_lin) * plusJacobian(x); 0 = constant J_min columns (MarginalizationError.cpp:904-938) */
 void orc_window_set_marg_exact(orc_window* h, int exact);

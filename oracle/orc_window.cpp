@@ -13,10 +13,15 @@
 #include <map>
 #include <vector>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "okvis_oracle.h"
 #include "orc_factors.hpp"
 
 using namespace orc;
+
+static int g_threads = 1;  // > 1: OpenMP CPU-baseline mode (bench.py only), see orc_set_threads
 
 struct orc_window {
   // ---- copied structure ----
@@ -42,7 +47,7 @@ struct orc_window {
   // ---- derived ordering ----
   int D = 0;
   std::vector<int> pose_off, sb_off;
-  std::vector<int> pair_lm, pair_block, lm_pair_begin, obs_pair_p, obs_pair_e;
+  std::vector<int> pair_lm, pair_block, lm_pair_begin, obs_pair_p, obs_pair_e, lm_obs_begin;
   int n_pair = 0;
 
   // ---- linearisation at the accepted state ----
@@ -107,6 +112,9 @@ void build_ordering(orc_window* h) {
   }
   h->lm_pair_begin[h->n_lm] = (int)h->pair_lm.size();
   h->n_pair = (int)h->pair_lm.size();
+  h->lm_obs_begin.assign(h->n_lm + 1, 0);
+  for (int o = 0; o < h->n_obs; ++o) h->lm_obs_begin[h->obs_lm[o] + 1]++;
+  for (int l = 0; l < h->n_lm; ++l) h->lm_obs_begin[l + 1] += h->lm_obs_begin[l];
   h->obs_pair_p.assign(h->n_obs, -1);
   h->obs_pair_e.assign(h->n_obs, -1);
   for (int o = 0; o < h->n_obs; ++o) {
@@ -119,15 +127,20 @@ void build_ordering(orc_window* h) {
 }
 
 // accumulate a factor's J^T J and J^T r into the dense pose-side system
+void add_factor_to(double* U, double* g, int D, int nres, const double* r, int nb, const int* off, const int* dim,
+                   const double* const* J);
 void add_factor(orc_window* h, int nres, const double* r, int nb, const int* off, const int* dim,
                 const double* const* J) {
-  const int D = h->D;
+  add_factor_to(h->U.data(), h->g.data(), h->D, nres, r, nb, off, dim, J);
+}
+void add_factor_to(double* U, double* g, int D, int nres, const double* r, int nb, const int* off, const int* dim,
+                   const double* const* J) {
   for (int a = 0; a < nb; ++a) {
     if (off[a] < 0) continue;
     for (int i = 0; i < dim[a]; ++i) {
       double s = 0;
       for (int k = 0; k < nres; ++k) s += J[a][k * dim[a] + i] * r[k];
-      h->g[off[a] + i] += s;
+      g[off[a] + i] += s;
     }
     for (int bb = 0; bb < nb; ++bb) {
       if (off[bb] < 0) continue;
@@ -135,29 +148,18 @@ void add_factor(orc_window* h, int nres, const double* r, int nb, const int* off
         for (int j = 0; j < dim[bb]; ++j) {
           double s = 0;
           for (int k = 0; k < nres; ++k) s += J[a][k * dim[a] + i] * J[bb][k * dim[bb] + j];
-          h->U[(size_t)(off[a] + i) * D + off[bb] + j] += s;
+          U[(size_t)(off[a] + i) * D + off[bb] + j] += s;
         }
     }
   }
 }
 
-// Evaluate all error terms at the current state.  lin=true additionally fills the linearisation.
-double evaluate(orc_window* h, bool lin) {
-  const int D = h->D;
-  if (lin) {
-    h->V.assign(6 * (size_t)h->n_lm, 0.0);
-    h->b.assign(3 * (size_t)h->n_lm, 0.0);
-    h->Hq.assign(6 * (size_t)h->n_lm, 0.0);
-    h->W.assign(18 * (size_t)h->n_pair, 0.0);
-    h->U.assign((size_t)D * D, 0.0);
-    h->g.assign(D, 0.0);
-    h->obs_r.assign(2 * (size_t)h->n_obs, 0.0);
-    h->imu_r.assign(15 * (size_t)h->n_imu, 0.0);
-  }
-  double cost = 0;
+// reprojection residuals o0 <= o < o1 (ReprojectionError + CauchyLoss, implementation/Estimator.hpp:68-82); the
+// landmark-side sums (V, b, Hq, W) go to the window (observations are sorted by landmark: ranges cut at landmark
+// boundaries never share an entry), the pose-side sums to U / g of the caller (per thread in the OpenMP baseline)
+static void reprojection_range(orc_window* h, bool lin, int o0, int o1, double* U, double* g, double* cost) {
   static const int ut[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
-  // ---- reprojection (ReprojectionError + CauchyLoss, implementation/Estimator.hpp:68-82) ----
-  for (int o = 0; o < h->n_obs; ++o) {
+  for (int o = o0; o < o1; ++o) {
     const int l = h->obs_lm[o], ip = h->obs_pose[o], ie = h->obs_ext[o];
     const double w = h->obs_sqrtw[o];
     const double sqrtInfo[4] = {w, 0, 0, w};
@@ -169,10 +171,10 @@ double evaluate(orc_window* h, bool lin) {
     if (h->cauchy_b > 0) {
       double rho[3];
       cauchy_loss(h->cauchy_b, s, rho);
-      cost += 0.5 * rho[0];
+      *cost += 0.5 * rho[0];
       sr = std::sqrt(rho[1]);  // Corrector: rho'' <= 0 -> residual_scaling = sqrt(rho'), alpha = 0
     } else {
-      cost += 0.5 * s;
+      *cost += 0.5 * s;
     }
     if (!lin) continue;
     h->obs_r[2 * o] = out.r[0];
@@ -197,7 +199,52 @@ double evaluate(orc_window* h, bool lin) {
     const int off[2] = {h->pose_off[ip], h->pose_off[ie]};
     const int dim[2] = {6, 6};
     const double* J[2] = {Jp.a, Je.a};
-    add_factor(h, 2, rt, 2, off, dim, J);
+    add_factor_to(U, g, h->D, 2, rt, 2, off, dim, J);
+  }
+}
+
+// Evaluate all error terms at the current state.  lin=true additionally fills the linearisation.
+double evaluate(orc_window* h, bool lin) {
+  const int D = h->D;
+  if (lin) {
+    h->V.assign(6 * (size_t)h->n_lm, 0.0);
+    h->b.assign(3 * (size_t)h->n_lm, 0.0);
+    h->Hq.assign(6 * (size_t)h->n_lm, 0.0);
+    h->W.assign(18 * (size_t)h->n_pair, 0.0);
+    h->U.assign((size_t)D * D, 0.0);
+    h->g.assign(D, 0.0);
+    h->obs_r.assign(2 * (size_t)h->n_obs, 0.0);
+    h->imu_r.assign(15 * (size_t)h->n_imu, 0.0);
+  }
+  double cost = 0;
+  // ---- reprojection ----
+  if (g_threads <= 1 || h->n_lm < 2 * g_threads) {
+    reprojection_range(h, lin, 0, h->n_obs, h->U.data(), h->g.data(), &cost);
+  } else {
+#ifdef _OPENMP
+    // CPU-baseline mode (orc_set_threads): landmark ranges per thread, private pose-side accumulators summed in thread
+    // order.  Same arithmetic per observation; the order of the pose-side sums differs from the serial path.
+    const int T = g_threads;
+    std::vector<std::vector<double>> Ut(T), gt(T);
+    std::vector<double> ct(T, 0.0);
+#pragma omp parallel num_threads(T)
+    {
+      const int t = omp_get_thread_num();
+      const int l0 = (int)((long long)h->n_lm * t / T), l1 = (int)((long long)h->n_lm * (t + 1) / T);
+      if (lin) {
+        Ut[t].assign((size_t)D * D, 0.0);
+        gt[t].assign(D, 0.0);
+      }
+      reprojection_range(h, lin, h->lm_obs_begin[l0], h->lm_obs_begin[l1], Ut[t].data(), gt[t].data(), &ct[t]);
+    }
+    for (int t = 0; t < T; ++t) {
+      cost += ct[t];
+      if (lin) {
+        for (size_t i = 0; i < (size_t)D * D; ++i) h->U[i] += Ut[t][i];
+        for (int i = 0; i < D; ++i) h->g[i] += gt[t][i];
+      }
+    }
+#endif
   }
   // ---- IMU ----
   for (int f = 0; f < h->n_imu; ++f) {
@@ -376,7 +423,8 @@ bool solve_damped(orc_window* h, double lambda) {
     h->rhs[i] = -h->g[i];
   }
   std::vector<double> Vinv(6 * (size_t)h->n_lm);
-  for (int l = 0; l < h->n_lm; ++l) {
+  auto reduce_range = [&](int l0, int l1, double* S_, double* rhs_) {
+    for (int l = l0; l < l1; ++l) {
     double v[6];
     for (int e = 0; e < 6; ++e) v[e] = h->V[6 * l + e];
     v[0] += lambda * h->Dl2[3 * l + 0];
@@ -394,16 +442,36 @@ bool solve_damped(orc_window* h, double lambda) {
           Y[3 * i + j] = Wa[3 * i + 0] * Vi[0][j] + Wa[3 * i + 1] * Vi[1][j] + Wa[3 * i + 2] * Vi[2][j];
       const int oa = h->pose_off[h->pair_block[pa]];
       for (int i = 0; i < 6; ++i)
-        h->rhs[oa + i] += Y[3 * i] * h->b[3 * l] + Y[3 * i + 1] * h->b[3 * l + 1] + Y[3 * i + 2] * h->b[3 * l + 2];
+        rhs_[oa + i] += Y[3 * i] * h->b[3 * l] + Y[3 * i + 1] * h->b[3 * l + 1] + Y[3 * i + 2] * h->b[3 * l + 2];
       for (int pb = p0; pb < p1; ++pb) {
         const double* Wb = &h->W[18 * pb];
         const int ob = h->pose_off[h->pair_block[pb]];
         for (int i = 0; i < 6; ++i)
           for (int j = 0; j < 6; ++j)
-            h->S[(size_t)(oa + i) * D + ob + j] -=
+            S_[(size_t)(oa + i) * D + ob + j] -=
                 Y[3 * i] * Wb[3 * j] + Y[3 * i + 1] * Wb[3 * j + 1] + Y[3 * i + 2] * Wb[3 * j + 2];
       }
     }
+    }
+  };
+  if (g_threads <= 1 || h->n_lm < 2 * g_threads) {
+    reduce_range(0, h->n_lm, h->S.data(), h->rhs.data());
+  } else {
+#ifdef _OPENMP
+    const int T = g_threads;   // CPU-baseline mode: private partial reduced systems, summed in thread order
+    std::vector<std::vector<double>> St(T), rt(T);
+#pragma omp parallel num_threads(T)
+    {
+      const int t = omp_get_thread_num();
+      St[t].assign((size_t)D * D, 0.0);
+      rt[t].assign(D, 0.0);
+      reduce_range((int)((long long)h->n_lm * t / T), (int)((long long)h->n_lm * (t + 1) / T), St[t].data(), rt[t].data());
+    }
+    for (int t = 0; t < T; ++t) {
+      for (size_t i = 0; i < (size_t)D * D; ++i) h->S[i] += St[t][i];
+      for (int i = 0; i < D; ++i) h->rhs[i] += rt[t][i];
+    }
+#endif
   }
   if (!chol_solve(h->S, D, h->rhs, &h->step_p)) return false;
   // back-substitution: delta_l = -Vinv (g_l + W^T delta_p)
@@ -1032,6 +1100,25 @@ orc_window* orc_window_create(const okvis_ba_window* w) {
 }
 
 void orc_window_destroy(orc_window* h) { delete h; }
+// CPU-baseline mode of bench.py: n > 1 evaluates the reprojection residuals and the landmark Schur reduction with n
+// OpenMP threads (private accumulators; the order of the sums differs from the serial path, so parity tests use 1).
+// Returns the number of threads that will actually be used.
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+  g_threads = n < 1 ? 1 : n;
+#else
+  (void)n;
+  g_threads = 1;
+#endif
+  return g_threads;
+}
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 void orc_window_set_marg_exact(orc_window* h, int exact) { h->marg_exact = exact != 0; }
 int orc_window_reduced_dim(orc_window* h) { return h->D; }
 int orc_window_pair_count(orc_window* h) { return h->n_pair; }

@@ -63,6 +63,7 @@ def lib():
     L.orc_window_full_gradient.argtypes = [C.c_void_p, _dp]
     L.orc_window_marginalize.argtypes = [C.c_void_p, C.POINTER(MargSpecC), C.POINTER(MargResultC)]
     L.orc_sym_eig.argtypes = [_dp, C.c_int, _dp, _dp]
+    L.orc_set_threads.argtypes = [C.c_int]
     L.orc_imu_propagation.argtypes = [C.c_int, _lp, _dp, _dp, C.POINTER(ImuParamsC), _dp, _dp, C.c_int64,
                                       C.c_int64, _dp, _dp]
     _lib = L
