@@ -104,7 +104,7 @@ def main():
     a = parse()
     from okvis_amd import dist as D
     rk = D.Rank.from_env()
-    rank, world, local_rank = rk.rank, rk.world, rk.local_rank
+    rank, world, local_rank = rk.rank, rk.world, D.local_device(rk)
     dist = D.init()   # "nccl" (= RCCL over xGMI) on the GPU node
 
     from okvis_amd import solver, synthetic
@@ -133,7 +133,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     batch.begin()
     if a.pmc_child:   # counter-collection child of pmc_traffic(): a short eager loop, no output
@@ -287,7 +288,7 @@ def main():
                                               "first": walls[0] * 1e3 / a.steps, "min": min(walls) * 1e3 / a.steps,
                                               "max": max(walls) * 1e3 / a.steps}},
             "window_records": {"fields": ["window_id", "iterations", "final_cost", "seconds"], "n": len(records),
-                               "first": records[:2], "collective": "one all_gather over RCCL" if dist is not None else "none (1 rank)"},
+                               "first": records[:2], "collective": (f"one all_gather, backend {dist.get_backend()}" + (" (= RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else "none (1 rank)"},
             "single_window": single, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "speedup_vs_cpu": None if cpu is None else {
                 "single_window_vs_1_core": single["iterations_per_s"] / cpu["value"],

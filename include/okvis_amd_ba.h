@@ -359,6 +359,24 @@ typedef struct okvis_ba_marg_result {
 
 int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* result);
 
+/* ---- multi-GPU driver --------------------------------------------------------------
+ * Windows are independent units: window i of a job runs on rank i mod world, one process per GPU, no data-path
+ * collective.  The only exchange is ONE all-gather of these fixed-size records after all windows finished (RCCL over
+ * xGMI through torch.distributed in bench.py / okvis_amd/dist.py; the launcher owns the communicator, this library the
+ * sharding rule, the run and the records). */
+typedef struct okvis_ba_window_record {
+  uint32_t window_id;   /* index of the window in the job */
+  uint32_t iterations;  /* trust-region iterations performed */
+  double final_cost;
+  double seconds;       /* wall time of the rank's batch that contained this window */
+} okvis_ba_window_record;
+/* ids_out[*n_out] = the windows of rank `rank` (capacity: (n_total + world - 1) / world entries) */
+int okvis_ba_shard(int32_t n_total, int32_t rank, int32_t world, int32_t* ids_out, int32_t* n_out);
+/* shard -> upload the rank's windows on `device` -> optimize(num_iter) -> one record per local window.
+ * all_windows: the n_total windows of the job (only the rank's share is touched).  records_out capacity as above. */
+int okvis_ba_batch_run(int device, int32_t rank, int32_t world, int32_t n_total, const okvis_ba_window* all_windows,
+                       const okvis_ba_options* opt, int num_iter, okvis_ba_window_record* records_out, int32_t* n_out);
+
 /* ---- diagnostics ------------------------------------------------------------------------------------
  * The dense solver behind windows whose reduced dimension exceeds the single-workgroup LDS path
  * (OKVIS_BA_MARG_MAX_WINDOW_DIM): tiled multi-workgroup Cholesky with fp64 MFMA tile updates

@@ -17,7 +17,7 @@ SYMBOLS = [
     "okvis_ba_evaluate_cost", "okvis_ba_get_state", "okvis_ba_fetch_results", "okvis_ba_array_size", "okvis_ba_download",
     "okvis_ba_reduced_dim", "okvis_ba_pair_count", "okvis_ba_pairs", "okvis_ba_last_iterate_ms",
     "okvis_ba_profile_iterations", "okvis_ba_profile_launches", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize", "okvis_ba_marginalize",
-    "okvis_ba_dense_solve",
+    "okvis_ba_dense_solve", "okvis_ba_shard", "okvis_ba_batch_run",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -61,6 +61,9 @@ def lib():
     L.okvis_ba_iterate.argtypes = [vp, C.c_int]
     L.okvis_ba_finish.argtypes = [vp, C.POINTER(SummaryC)]
     L.okvis_ba_dense_solve.argtypes = [C.c_int, C.c_int32, _dp, _dp, _dp, C.POINTER(C.c_int32)]
+    L.okvis_ba_shard.argtypes = [C.c_int32, C.c_int32, C.c_int32, _ip, C.POINTER(C.c_int32)]
+    L.okvis_ba_batch_run.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.POINTER(WindowC), C.POINTER(OptionsC), C.c_int,
+                                     C.c_void_p, C.POINTER(C.c_int32)]
     L.okvis_ba_marginalize.argtypes = [vp, C.c_int, C.POINTER(MargSpecC), C.POINTER(MargResultC)]
     L.okvis_ba_evaluate_cost.argtypes = [vp, _dp]
     L.okvis_ba_array_size.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64)]

@@ -1500,6 +1500,48 @@ int okvis_ba_synchronize(okvis_ba_solver* s) {
   return OKVIS_BA_OK;
 }
 
+int okvis_ba_shard(int32_t n_total, int32_t rank, int32_t world, int32_t* ids_out, int32_t* n_out) {
+  if (n_total < 0 || world <= 0 || rank < 0 || rank >= world || !ids_out || !n_out) return OKVIS_BA_ERR_ARG;
+  int32_t n = 0;
+  for (int32_t i = rank; i < n_total; i += world) ids_out[n++] = i;   // window i -> rank i mod world
+  *n_out = n;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_batch_run(int device, int32_t rank, int32_t world, int32_t n_total, const okvis_ba_window* all_windows,
+                       const okvis_ba_options* opt, int num_iter, okvis_ba_window_record* records_out, int32_t* n_out) {
+  if (!all_windows || !records_out || !n_out || num_iter < 0) return OKVIS_BA_ERR_ARG;
+  std::vector<int32_t> ids((size_t)std::max(1, (n_total + std::max(world, 1) - 1) / std::max(world, 1)));
+  int32_t n = 0;
+  int rc = okvis_ba_shard(n_total, rank, world, ids.data(), &n);
+  if (rc != OKVIS_BA_OK) return rc;
+  *n_out = n;
+  if (n == 0) return OKVIS_BA_OK;
+  std::vector<okvis_ba_window> mine((size_t)n);
+  for (int32_t k = 0; k < n; ++k) mine[(size_t)k] = all_windows[ids[(size_t)k]];
+  okvis_ba_solver* s = nullptr;
+  rc = okvis_ba_create(&s, device);
+  if (rc != OKVIS_BA_OK) return rc;
+  if (opt) rc = okvis_ba_set_options(s, opt);
+  if (rc == OKVIS_BA_OK) rc = okvis_ba_upload(s, n, mine.data());
+  std::vector<okvis_ba_summary> sum((size_t)n);
+  double seconds = 0;
+  if (rc == OKVIS_BA_OK) {
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = okvis_ba_optimize(s, num_iter, sum.data());   // ends with a stream synchronisation (summaries are read back)
+    seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  if (rc == OKVIS_BA_OK)
+    for (int32_t k = 0; k < n; ++k) {
+      records_out[k].window_id = (uint32_t)ids[(size_t)k];
+      records_out[k].iterations = (uint32_t)sum[(size_t)k].iterations;
+      records_out[k].final_cost = sum[(size_t)k].final_cost;
+      records_out[k].seconds = seconds;
+    }
+  (void)okvis_ba_destroy(s);
+  return rc;
+}
+
 int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* rhs, double* x, int32_t* info) {
   if (n <= 0 || !S || !rhs || !x || !info) return OKVIS_BA_ERR_ARG;
   hipError_t e = hipSetDevice(device);

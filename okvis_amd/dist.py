@@ -28,8 +28,47 @@ def shard_seeds(rank: int, world: int, windows_per_gpu: int, base_seed: int = 20
 
 
 def shard_windows(n_total: int, rank: int, world: int) -> List[int]:
-    """Strong-scaling variant (BASELINE configs[3]: 64 windows over N GPUs): window i -> rank i mod world."""
-    return [i for i in range(n_total) if i % world == rank]
+    """BASELINE configs[3] (64 windows over N GPUs): window i -> rank i mod world.  The rule lives in the C-ABI
+    (okvis_ba_shard); this is its Python view (falls back to the same one-liner if the library is not built)."""
+    try:
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        ids = (C.c_int32 * max(1, (n_total + world - 1) // world))()
+        n = C.c_int32()
+        _lib.check(L.okvis_ba_shard(n_total, rank, world, ids, C.byref(n)), "shard")
+        return [int(ids[i]) for i in range(n.value)]
+    except ImportError:
+        return [i for i in range(n_total) if i % world == rank]
+
+
+class WindowRecordC(__import__("ctypes").Structure):
+    """okvis_ba_window_record (include/okvis_amd_ba.h): the fixed-size record of the one all-gather"""
+    _fields_ = [("window_id", __import__("ctypes").c_uint32), ("iterations", __import__("ctypes").c_uint32),
+                ("final_cost", __import__("ctypes").c_double), ("seconds", __import__("ctypes").c_double)]
+
+
+def batch_run(windows, rank: int, world: int, device: int, num_iter: int, options=None):
+    """okvis_ba_batch_run: shard the job's windows (i -> rank i mod world), run this rank's share on `device`, return its
+    records [[window_id, iterations, final_cost, seconds], ...].  The caller all-gathers them (gather_records)."""
+    import ctypes as C
+    from . import _lib
+    from .window import WindowC
+    L = _lib.lib()
+    arr = (WindowC * len(windows))()
+    keep = []
+    for i, w in enumerate(windows):
+        w.validate()
+        wc, k = w.as_c()
+        arr[i] = wc
+        keep.append(k)
+    cap = max(1, (len(windows) + world - 1) // world)
+    recs = (WindowRecordC * cap)()
+    n = C.c_int32()
+    _lib.check(L.okvis_ba_batch_run(device, rank, world, len(windows), arr, C.byref(options) if options is not None else None,
+                                    num_iter, C.cast(recs, C.c_void_p), C.byref(n)), "batch_run")
+    del keep
+    return [[float(recs[i].window_id), float(recs[i].iterations), recs[i].final_cost, recs[i].seconds] for i in range(n.value)]
 
 
 def init(backend: str | None = None):
@@ -41,17 +80,24 @@ def init(backend: str | None = None):
     import torch
     import torch.distributed as dist
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("OKVIS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
-        torch.cuda.set_device(r.local_rank)
+        torch.cuda.set_device(local_device(r))
     dist.init_process_group(backend=backend)
     return dist
+
+
+def local_device(r: "Rank | None" = None) -> int:
+    """HIP ordinal of this rank: LOCAL_RANK, or 0 for every rank with OKVIS_SHARE_GPU=1 (several processes on ONE GPU:
+    the 2-process check that fits a 1-GPU lease; RCCL refuses two ranks on one device, so that run uses gloo)."""
+    r = r or Rank.from_env()
+    return 0 if os.environ.get("OKVIS_SHARE_GPU") else r.local_rank
 
 
 def _device(dist):
     import torch
     if dist is not None and dist.get_backend() == "nccl":
-        return torch.device("cuda", Rank.from_env().local_rank)
+        return torch.device("cuda", local_device())
     return torch.device("cpu")
 
 

@@ -39,3 +39,8 @@ def test_two_ranks_gloo(tmp_path):
     assert [x[0] for x in recs] == [0.0, 1.0] and all(x[1] == 3.0 for x in recs)
     assert recs[0][3] == 0.5 and recs[1][3] == 0.75
     assert r["seeds0"] == D.shard_seeds(0, 2, 3)
+    # configs[3]-style job: every window exactly once, its record carried by the one all-gather
+    wr = sorted(r["window_records"])
+    assert [int(x[0]) for x in wr] == list(range(7))
+    assert all(x[1] == 5.0 and x[2] == 100.0 + x[0] for x in wr)
+    assert {x[3] for x in wr} == {0.5, 0.75}                    # rank 0 / rank 1 batch seconds

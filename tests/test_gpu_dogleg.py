@@ -134,3 +134,23 @@ def test_stepwise_api_and_restart(oracle):
 def test_levenberg_marquardt_option(oracle):
     w = synthetic.small_window(**G.SMALL[2])
     _compare(oracle, w, 10, strategy=STRATEGY_LM)
+
+
+def test_batch_run_shards_windows_over_ranks(oracle):
+    """okvis_ba_batch_run (the C++ side of the multi-GPU driver): window i runs on rank i mod world; the records of all
+    ranks together cover every window once and equal a single-batch optimize of the same windows"""
+    from okvis_amd import dist as D
+    ws = [synthetic.small_window(seed=60 + i, K=4, L=40) for i in range(5)]
+    opt = _opts()
+    recs = []
+    for rank in range(2):     # two ranks, run one after the other on the one GPU of this box
+        r = D.batch_run(ws, rank, 2, 0, 6, opt)
+        assert [int(x[0]) for x in r] == D.shard_windows(5, rank, 2) == list(range(rank, 5, 2))
+        recs += r
+    assert sorted(int(x[0]) for x in recs) == list(range(5))
+    b = solver.WindowBatch(ws, options=opt)
+    sg = b.optimize(6)
+    for x in recs:
+        i = int(x[0])
+        assert int(x[1]) == sg[i]["iterations"] and x[2] == sg[i]["final_cost"] and x[3] > 0
+    b.close()
