@@ -1,5 +1,9 @@
 // okvis_amd::Estimator implementation — window book-keeping on the host, optimisation on the GPU through
 // the C-ABI.  Citations are to the reference okvis_ceres/src/Estimator.cpp unless noted.
+//
+// Derived work: the decision logic of addStates / applyMarginalizationStrategy follows okvis_ceres/src/Estimator.cpp
+// (Copyright (c) 2015, Autonomous Systems Lab / ETH Zurich, BSD 3-clause) because a drop-in must behave identically;
+// see LICENSE for the attribution and the original licence text.
 #include "estimator.hpp"
 
 #include <algorithm>
