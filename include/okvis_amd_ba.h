@@ -179,7 +179,7 @@ typedef struct okvis_ba_options {
                                    at initial_radius (no trust-region logic); used by bench.py so that
                                    every timed iteration performs identical, full work                   */
   int32_t n_streams;            /* sub-batches of windows on separate HIP streams (phases of different
-                                   windows overlap); 0 = auto (2 for >= 16 windows, else 1)              */
+                                   windows overlap); 0 = auto (3 for >= 48 windows, 2 for >= 16, else 1)  */
   int32_t fp32_linearize;       /* BASELINE configs[4] (mixed-precision study): 1 = reprojection residuals, Jacobians
                                    and their J^T J / J^T r accumulation in fp32; state, Schur complement and the
                                    reduced solve stay fp64.  0 (default) = everything fp64 like the reference   */
@@ -188,7 +188,9 @@ typedef struct okvis_ba_options {
                                    1/(1+sqrt(diag J^T J)) of the FIRST linearisation of the optimize() call;
                                    dogleg strategy only                                                          */
   int32_t max_consecutive_invalid_steps; /* 5 (Ceres max_num_consecutive_invalid_steps): then termination 5     */
-  int32_t reserved0;
+  int32_t reserved0;            /* 0.  Bit 0 = experimental: eliminate the speed/bias blocks of the LDS solve by
+                                   independence levels before the dense factorisation (same result to rounding;
+                                   measured no faster than the dense order)                       */
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */

@@ -116,6 +116,7 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Xout) {
   return ok;
 }
 
+constexpr int SOLVE_LDS_LIMIT = 156 * 1024;   // dynamic LDS of the solve kernel (160 KB per workgroup minus its static arrays)
 constexpr int PRI_STAGE = 2;  // pose / speed-bias priors whose records the solve kernel stages in LDS ahead of time
 
 // IMU Hessian blocks, priors and the marginalisation prior of linearisation buffer `acc`, accumulated into S
@@ -260,6 +261,35 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, doubl
     __syncthreads();
   }
 
+}
+
+// ---- speed/bias blocks of the reduced system, eliminated FIRST and in parallel by levels -------------------------
+// The 9x9 speed/bias diagonal blocks couple only through ImuError (sb_k - sb_k+1) and the marginalisation prior, never
+// through landmarks: the reduced matrix is [pose-pose dense | banded pose-sb | block-tridiagonal sb-sb].  Instead of
+// walking through them as part of 25 sequential 6x6 block columns, blocks that are mutually uncoupled (host-built levels:
+// for an IMU chain of n states ceil(log2 n) of them, e.g. {0,2,4,6,8} {1,5,9} {3} {7}) are factorised at the same time by
+// different waves and eliminated with one symmetric update; the dense blocked Cholesky then only sees the pose part.
+// Storage stays in place: the eliminated block's column (Y = C L^-T) overwrites the entries it was computed from.
+__device__ __forceinline__ int sym_at(const SLayout& LY, int i, int j) { return i >= j ? LY.at(i, j) : LY.at(j, i); }
+
+// Cholesky of a 9x9 SPD block by ONE wave: lane r < 9 keeps row r of the lower triangle in registers, the pivot column
+// travels through v_readlane.  Lrow[j] (j <= r) = L[r][j]; returns false on a non-positive pivot.  All 64 lanes must call.
+__device__ __forceinline__ bool chol9_wave(double (&Lrow)[9], int lane) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double d = readlane_f64(Lrow[k], k);          // L[k][k] before the square root (lane k holds row k)
+    ok = ok && (d > 0.0);
+    const double inv = rsqrt_nr(d > 0.0 ? d : 1.0);
+    if (lane == k) Lrow[k] = d * inv;
+    if (lane > k) Lrow[k] *= inv;
+#pragma unroll
+    for (int j = k + 1; j < 9; ++j) {
+      const double ljk = readlane_f64(Lrow[k], j);      // L[j][k]
+      if (lane >= j) Lrow[j] -= Lrow[k] * ljk;
+    }
+  }
+  return ok;
 }
 
 // trial poses / speed-biases  x (+) delta  of buffer 1-acc (PoseLocalParameterization::plus, PoseLocalParameterization.cpp:60-87).
@@ -420,6 +450,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
 
 #define STAMP(k) do { if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[k] = (double)clock64(); } while (0)
   STAMP(0);
+  // level-scheduled elimination of the speed/bias blocks (section 4a): its LDS sits behind the block-pair table - per 9x9
+  // block the lower triangle of the factor row by row (45) + 1 / diagonal (9), the rows of Y = C L^-T of all levels, the
+  // schedule table (requested now, used after the assembly)
+  const bool sbl = !LARGE && W.sbe_nlev > 0 && !opt.no_sb_levels;
+  const int nbs = sbl ? Dp / 6 : nbk;          // block columns of the dense part
+  const int Dsys = sbl ? Dp : Dpad;            // its dimension
+  double* s_L9 = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(s_ptab) + ((max(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~15));
+  double* s_stage = s_L9 + 54 * (sbl ? W.sbe_nblk : 0);
+  int* s_tab = reinterpret_cast<int*>(s_stage + 9 * (sbl ? W.sbe_nstage : 0));
+  if (sbl)
+    for (int i = tid; i < W.sbe_ntab; i += SOLVE_THREADS) s_tab[i] = W.sbe_tab[i];
   // IMU factor records (H | g, 495 doubles each): value and destination (host-built imu_asm) of up to IMU_NPF entries
   // per lane are requested now, from the buffer that is accepted if the pending step is (the common case), and
   // scattered after the decision without any further global round trip.
@@ -892,6 +933,134 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     return;
   }
+  // ------------------------------------------------------------------ 4a. speed/bias blocks by levels
+  // (table layout: build_window in ba_capi.hip.)  Level by level: (1) factor the 9x9 blocks, (2) Y = C L^-T for the row-blocks
+  // they couple with, staged contiguously, (3) S -= Y Y^T on the coupled block pairs, rhs -= Y y.  The eliminated rows and
+  // columns of S are never touched again; the dense factorisation below works on the pose part.
+  STAMP(52);
+  if (sbl) {
+    for (int lev = 0; lev < W.sbe_nlev; ++lev) {
+      const int* hd = s_tab + W.sbe_nblk + 8 * lev;
+      const int b0 = hd[0], nb = hd[1];
+      // (1) factor the blocks of this level, one thread each (165 multiply-adds in registers: a dependent chain that a wave
+      //     would not shorten); the block's right-hand side becomes y = L^-1 rhs
+      if (tid < nb) {
+        const int o = s_tab[b0 + tid];
+        double L[45], y[9], dinv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          y[i] = s_rhs[o + i];
+#pragma unroll
+          for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = S[LY.at(o + i, o + j)];
+        }
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            double v = L[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int m = 0; m < j; ++m) v -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+            if (j == i) {
+              ok = ok && (v > 0.0);
+              dinv[i] = rsqrt_nr(v > 0.0 ? v : 1.0);
+              L[i * (i + 1) / 2 + i] = v * dinv[i];
+            } else {
+              L[i * (i + 1) / 2 + j] = v * dinv[j];
+            }
+          }
+          double t = y[i];
+#pragma unroll
+          for (int m = 0; m < i; ++m) t -= L[i * (i + 1) / 2 + m] * y[m];
+          y[i] = t * dinv[i];
+        }
+        double* L9 = s_L9 + 54 * (b0 + tid);
+#pragma unroll
+        for (int q = 0; q < 45; ++q) L9[q] = L[q];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          L9[45 + i] = dinv[i];
+          s_rhs[o + i] = y[i];
+        }
+        if (!ok) s_fail = 1;
+      }
+      __syncthreads();
+      if (lev == 0) STAMP(53);
+      // (2) Y = C L^-T, one thread per row of every coupling entry
+      const int* ent = s_tab + hd[2];
+      const int nent = s_tab[hd[3] + nb];
+      for (int it = tid; it < nent * 9; it += SOLVE_THREADS) {
+        const int e = it / 9, r = it - e * 9;
+        const int en = ent[e];
+        if (r >= ((en >> 8) & 15)) continue;
+        const int i = (en & 255) + r, bb = (en >> 12) & 15;
+        const int o = s_tab[b0 + bb];
+        const double* L9 = s_L9 + 54 * (b0 + bb);
+        double v[9];
+#pragma unroll
+        for (int a = 0; a < 9; ++a) v[a] = S[sym_at(LY, i, o + a)];
+        double* st = s_stage + 9 * ((en >> 16) + r);
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {   // y L^T = v  ->  forward substitution
+          double t = v[a];
+#pragma unroll
+          for (int m = 0; m < 9; ++m)
+            if (m < a) t -= L9[a * (a + 1) / 2 + m] * v[m];
+          v[a] = t * L9[45 + a];
+          st[a] = v[a];
+        }
+      }
+      __syncthreads();
+      if (lev == 0) STAMP(54);
+      // (3) S[R1][R2] -= sum over the common level blocks of Y_R1 Y_R2^T, one thread per element; rhs_R -= Y_R y
+      const int* pidx = s_tab + hd[6];
+      for (int it = tid; it < hd[7] * 9; it += SOLVE_THREADS) {   // one 3x3 tile of a block pair per thread
+        const int p = it / 9, e = it - p * 9;
+        const int t1 = e / 3, t2 = e - t1 * 3;
+        const int* rec = s_tab + pidx[p];
+        const int h = rec[0];
+        const int o1 = h & 255, o2 = (h >> 8) & 255;
+        if (3 * t1 >= ((h >> 16) & 15) || 3 * t2 >= ((h >> 20) & 15) || (o1 == o2 && t2 > t1)) continue;
+        double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int c = 1; c <= (h >> 24); ++c) {
+          const double* y1 = s_stage + 9 * ((rec[c] & 0xffff) + 3 * t1);
+          const double* y2 = s_stage + 9 * ((rec[c] >> 16) + 3 * t2);
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            const double a0 = y1[q], a1 = y1[9 + q], a2 = y1[18 + q];
+            const double c0 = y2[q], c1 = y2[9 + q], c2 = y2[18 + q];
+            acc[0][0] += a0 * c0, acc[0][1] += a0 * c1, acc[0][2] += a0 * c2;
+            acc[1][0] += a1 * c0, acc[1][1] += a1 * c1, acc[1][2] += a1 * c2;
+            acc[2][0] += a2 * c0, acc[2][1] += a2 * c1, acc[2][2] += a2 * c2;
+          }
+        }
+        const bool diag = o1 == o2 && t1 == t2;   // (o1 >= o2: the lower triangle)
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+          for (int v = 0; v < 3; ++v)
+            if (!diag || v <= u) S[LY.at(o1 + 3 * t1 + u, o2 + 3 * t2 + v)] -= acc[u][v];
+      }
+      const int* gidx = s_tab + hd[4];
+      for (int it = tid; it < hd[5] * 9; it += SOLVE_THREADS) {
+        const int g = it / 9, r = it - g * 9;
+        const int* rec = s_tab + gidx[g];
+        const int h = rec[0];
+        if (r >= ((h >> 8) & 15)) continue;
+        double acc = 0;
+        for (int c = 1; c <= (h >> 12); ++c) {
+          const double* y1 = s_stage + 9 * ((rec[c] & 0xffff) + r);
+          const double* yy = s_rhs + s_tab[b0 + (rec[c] >> 16)];
+#pragma unroll
+          for (int q = 0; q < 9; ++q) acc += y1[q] * yy[q];
+        }
+        s_rhs[(h & 255) + r] -= acc;
+      }
+      __syncthreads();
+      if (lev == 0) STAMP(55);
+    }
+  }
+  STAMP(56);
   if (tid == 0) {
     if (!factor_diag(S + LY.blk(0, 0), s_dinv)) s_fail = 1;
     if (opt.dogleg && c.mu >= DL_MAX_MU) s_fail = 1;   // DoglegStrategy: no solve is attempted once mu has reached max_mu
@@ -907,9 +1076,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     for (int u = 0; u < 2; ++u) {
       const int wi = tid + u * TU_THREADS;
       const int q = wi >> 2, sub = wi & 3;
-      if (q < (nbk - 1) * nbk / 2) {
-        it_gbj[u] = nbk - 1 - (s_ptab[q] >> 8);
-        it_gbi[u] = nbk - 1 - (s_ptab[q] & 255);
+      if (q < (nbs - 1) * nbs / 2) {
+        it_gbj[u] = nbs - 1 - (s_ptab[q] >> 8);
+        it_gbi[u] = nbs - 1 - (s_ptab[q] & 255);
         it_sr[u] = (sub >> 1) * 3;
         it_sc[u] = (sub & 1) * 3;
         it_c[u] = LY.blk(it_gbi[u], it_gbj[u]) + 6 * it_sr[u] + it_sc[u];
@@ -924,9 +1093,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     la_j = la_lane - la_i * (la_i + 1) / 2;
   }
   __syncthreads();
-  for (int kb = 0; kb < nbk; ++kb) {
+  for (int kb = 0; kb < nbs; ++kb) {
     const int k0 = kb * 6;
-    const int nrows = Dpad - k0 - 6;  // panel rows below the diagonal block
+    const int nrows = Dsys - k0 - 6;  // panel rows below the diagonal block
     if (kb == 0) STAMP(10);
     if (kb == 12) STAMP(13);
     // (P) panel: row <- row * L_kk^-T as six independent dot products with the published inverse; the
@@ -952,7 +1121,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     if (kb == 12) STAMP(14);
     // (T) trailing update with 3x3 register sub-tiles  A_(bi,bj) -= L_(bi,k) L_(bj,k)^T ; rhs blocks ride
     //     along; the look-ahead wave prepares the next diagonal block meanwhile
-    const int nt = nbk - kb - 1;
+    const int nt = nbs - kb - 1;
     const int colk = LY.blk(kb, kb);  // start of block column kb (its diagonal block)
     if (tid < TU_THREADS) {
       // let the look-ahead wave's few LDS reads enter the queue before the bulk's ~27 per lane (it carries the
@@ -1075,7 +1244,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // every lane owns the rows lane, lane+64, ... ; block kb is solved redundantly by all lanes, then each
   // lane updates its rows above it.  25 dependent steps cost LDS round trips only, no s_barrier.
   if (tid < 64) {
-    for (int kb = nbk - 1; kb >= 0; --kb) {
+    for (int kb = nbs - 1; kb >= 0; --kb) {
       const double* Xd = s_dinv + 36 * kb;   // x_k = L_kk^-T y_k: six independent dot products
       double x[6], y[6];
 #pragma unroll
@@ -1103,6 +1272,47 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
   }
   __syncthreads();
+  STAMP(57);
+  if (sbl) {
+    // speed/bias blocks in reverse level order:  x_b = L^-T (y_b - sum_R Y_R^T x_R)  over the row-blocks the block was coupled
+    // with when it was eliminated (poses and the blocks of later levels)
+    for (int lev = W.sbe_nlev - 1; lev >= 0; --lev) {
+      const int* hd = s_tab + W.sbe_nblk + 8 * lev;
+      const int b0 = hd[0], nb = hd[1];
+      const int* ent = s_tab + hd[2];
+      for (int bb = tid >> 6; bb < nb; bb += SOLVE_THREADS / 64) {   // one wave per block
+        const int lane = tid & 63;
+        const int o = s_tab[b0 + bb];
+        const int e0 = s_tab[hd[3] + bb], e1 = s_tab[hd[3] + bb + 1];
+        double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int it = lane; it < (e1 - e0) * 9; it += 64) {
+          const int e = it / 9, r = it - e * 9;
+          const int en = ent[e0 + e];
+          if (r >= ((en >> 8) & 15)) continue;
+          const double xi = s_x[(en & 255) + r];
+          const double* st = s_stage + 9 * ((en >> 16) + r);
+#pragma unroll
+          for (int a = 0; a < 9; ++a) t[a] += st[a] * xi;
+        }
+        double res = 0;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+          const double ta = wave_sum_full(t[a]);
+          if (lane == a) res = s_rhs[o + a] - ta;
+        }
+        const double* L9 = s_L9 + 54 * (b0 + bb);
+        double xres = 0;
+#pragma unroll
+        for (int a = 8; a >= 0; --a) {   // L^T x = res: lane a finishes x_a, the lanes above take it out
+          const double xa = readlane_f64(res, a) * L9[45 + a];
+          if (lane == a) xres = xa;
+          if (lane < a) res -= L9[a * (a + 1) / 2 + lane] * xa;
+        }
+        if (lane < 9) s_x[o + lane] = xres;
+      }
+      __syncthreads();
+    }
+  }
   STAMP(8);
 
   // ------------------------------------------------------------------ 5. scalars, trial state, ctrl

@@ -92,7 +92,7 @@ struct OptD {
   int dogleg;        // 1 = Ceres' DOGLEG strategy (the reference's configuration), 0 = Levenberg-Marquardt
   int jacobi_scaling;
   int max_invalid;   // max_num_consecutive_invalid_steps
-  int pad;
+  int no_sb_levels;  // 1 = factorise the speed/bias blocks as part of the dense block columns (A/B switch, diagnostics)
 };
 
 // DoglegStrategy constants (Ceres: kMinMu, kMaxMu, mu_increase_factor_)
@@ -145,6 +145,8 @@ struct WinPtrs {
   int n_tile;             // Schur tiles per dimension
   int n_imu_color;
   int ct_nT;              // tile rows of the tiled dense solver (0 = the LDS solver handles this window)
+  int sbe_nlev, sbe_nblk; // levels / blocks of the speed/bias elimination schedule (0 = not used)
+  int sbe_ntab, sbe_nstage; // ints in sbe_tab; rows of the LDS stage the schedule needs
   int spart_stride;       // doubles per chunk partial: (Dp/6)(Dp/6+1)/2*36 + 3*Dp  (S | Y b | g | diag U)
   double cauchy_b;
   ImuParamsD imu;
@@ -180,6 +182,9 @@ struct WinPtrs {
   const int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
   const int* imu_color_begin;    // [n_imu_color+1]
   const int* imu_coloff;         // [n_imu][30] reduced index of each local column (or -1)
+  // level schedule of the speed/bias blocks for the LDS solve (ba_solve.hpp; layout documented where build_window makes it)
+  // (the counts sbe_nlev / sbe_nblk / sbe_ntab sit with the other sizes: this region must hold pointers only, see relocate())
+  const int* sbe_tab;
   const int4* imu_asm;           // [n_imu][512] where entry e of factor f's H|g record lands in the solve kernel's LDS
                                  // system: x = offset | is_g << 20 | colour << 24 (or -1), y = d2 index or -1 (D <= MAX_D_LDS)
 

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
 opt = default_options(); opt.gauss_newton = 1; opt.function_tolerance = 0; opt.gradient_tolerance = 0; opt.parameter_tolerance = 0; opt.use_graph = 0; opt.debug_arrays = 1
-NW = int(sys.argv[1]) if len(sys.argv) > 1 else 1   # stamps are taken by window 0; NW > 1 shows them under load
+NW = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+opt.reserved0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # 1 = level-scheduled speed/bias elimination on (experimental)   # stamps are taken by window 0; NW > 1 shows them under load
 b = solver.WindowBatch([synthetic.config_A(seed=20240923 + i) for i in range(NW)], options=opt)
 b.begin(); b.iterate(12); b.synchronize()
 p = b.array("PROF")
@@ -21,6 +22,7 @@ print("schur phases (workgroup 0, thread 0):")
 for k in range(17, 24):
     d = p[k]-p[k-1]; print(f"  {sn[k]:30s} {d:10.0f} cyc {d/2100:8.2f} us")
 print("  total", (p[23]-p[16])/2100, "us")
+print("sb levels (us): level 0 factor", (p[53]-p[52])/2100, " Y", (p[54]-p[53])/2100, " update", (p[55]-p[54])/2100, " all levels", (p[56]-p[52])/2100, " dense chol", (p[7]-p[56])/2100, " dense backsub", (p[57]-p[7])/2100, " sb recovery", (p[8]-p[57])/2100)
 print("kb=0: panel", p[11]-p[10], "trailing(thread0 work)", p[26]-p[11], "trailing+barrier", p[12]-p[11])
 print("kb=12: panel", p[14]-p[13], "trailing+barrier", p[15]-p[14])
 

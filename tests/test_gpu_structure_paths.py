@@ -148,3 +148,32 @@ def test_repeated_landmark_pose_camera_observations(oracle):
     w.obs_uv = uv
     assert is_dup.sum() == 25
     _compare(oracle, w, 8)
+
+
+@pytest.mark.parametrize("maker", ["config_A", "small_ext", "small_marg"])
+def test_speed_bias_blocks_eliminated_by_levels(oracle, maker):
+    # options.reserved0 bit 0 (experimental): the free speed/bias blocks of the LDS solve are eliminated by independence
+    # levels before the dense factorisation of the pose part.  Same system, other elimination order: the result must agree
+    # with the oracle (and therefore with the dense order) to rounding.
+    if maker == "config_A":
+        w = synthetic.config_A(seed=77)
+    elif maker == "small_ext":
+        w = synthetic.small_window(seed=5, K=6, L=90, estimate_extrinsics="shared")
+    else:
+        # a dense prior over two poses and two speed/bias blocks: couples speed/bias blocks that no IMU factor couples
+        rng = np.random.default_rng(6)
+        w = synthetic.small_window(seed=6, K=5, L=70)
+        Dm = 6 + 9 + 6 + 9
+        w.marg_J = np.triu(rng.standard_normal((Dm, Dm))) * 3.0
+        w.marg_e0 = rng.standard_normal(Dm) * 0.1
+        w.marg_block_type = np.array([0, 1, 0, 1], np.int32)
+        w.marg_block_idx = np.array([0, 0, 1, 2], np.int32)
+        w.marg_block_off = np.array([0, 6, 15, 21], np.int32)
+        lin = np.zeros((4, 9))
+        lin[0, :7] = synthetic.pose_oplus(w.pose[0], rng.normal(0, 0.02, 6))
+        lin[1] = w.sb[0] + rng.normal(0, 0.01, 9)
+        lin[2, :7] = synthetic.pose_oplus(w.pose[1], rng.normal(0, 0.02, 6))
+        lin[3] = w.sb[2] + rng.normal(0, 0.01, 9)
+        w.marg_lin = lin
+    _compare(oracle, w, 6, tol=1e-6, reserved0=1)
+    _compare(oracle, w, 6, tol=1e-6, reserved0=1, strategy=1)   # Levenberg-Marquardt damping
