@@ -174,7 +174,8 @@ typedef struct okvis_ba_options {
   int32_t use_graph;            /* 1 = replay the captured hipGraph of the iteration sequence           */
   int32_t schur_lm_per_block;   /* landmarks per Schur workgroup (0 = auto)                             */
   int32_t debug_arrays;         /* 1 = also write the parity/debug arrays (per-observation residuals,
-                                   damped reduced matrix); off in production                            */
+                                   damped reduced matrix); 2 = clock64() phase stamps only (diagnostics,
+                                   OKVIS_BA_ARR_PROF); 0 in production                                    */
   int32_t gauss_newton;         /* 1 = plain Gauss-Newton: every step is accepted and the damping radius stays
                                    at initial_radius (no trust-region logic); used by bench.py so that
                                    every timed iteration performs identical, full work                   */

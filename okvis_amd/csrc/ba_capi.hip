@@ -848,7 +848,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
 }
 
 // convert the arena offsets stored in the pointer fields to device addresses
-void relocate(WinPtrs& P, unsigned char* base, unsigned char* zbase, bool debug) {
+void relocate(WinPtrs& P, unsigned char* base, unsigned char* zbase, int debug) {
   unsigned char** fields = reinterpret_cast<unsigned char**>(&P.pose[0]);
   // all pointer members are laid out contiguously from pose[0] to marg_lin; relocate by scanning the
   // struct region as an array of pointers (sizes/scalars precede pose[0])
@@ -859,13 +859,13 @@ void relocate(WinPtrs& P, unsigned char* base, unsigned char* zbase, bool debug)
     fields[i] = (off & ARENA_ZFLAG) ? zbase + (off & ~ARENA_ZFLAG) : base + off;
   }
   // optional arrays that were never allocated hold offset 0 -> must be null
-  if (!debug) {
+  if (debug != 1) {   // 2 = phase stamps only: the copies of the linearisation / system would distort the stamps
     P.obs_r[0] = P.obs_r[1] = nullptr;
     P.S = nullptr;
     P.rhs = nullptr;
     P.Dp2 = nullptr;
-    P.prof = nullptr;
   }
+  if (!debug) P.prof = nullptr;
   P.Hpp = nullptr;
   if (P.D <= MAX_D_LDS) {
     P.Sg = nullptr;
@@ -1169,7 +1169,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   s->max_sbl_blk = s->max_sbl_stage = s->max_sbl_tab = 0;
   s->any_ext = false;
   for (int i = 0; i < n_windows; ++i) {
-    relocate(wins[i].ptrs, s->d_arena, zbase, s->opt.debug_arrays != 0);
+    relocate(wins[i].ptrs, s->d_arena, zbase, s->opt.debug_arrays);
     ptrs[i] = wins[i].ptrs;
     const WinPtrs& P = ptrs[i];
     s->max_group = std::max(s->max_group, P.n_group);

@@ -232,6 +232,15 @@ bool Estimator::addStates(MultiFramePtr multiFrame, const ImuMeasurementDeque& i
     if (used < 1) return false;                     // :150-153
   }
   if (findState(multiFrame->id)) return false;  // "pose ID was used before" (:161-163)
+  // the reference orders its states by frame id (statesMap_, std::map) and takes rbegin() as the previous one; ids come from
+  // IdProvider and increase.  This class keeps insertion order, which is the same thing only for increasing ids: enforced.
+  if (!states_.empty() && multiFrame->id <= states_.back().id) return false;
+  // nothing is changed before every input is known to be usable (extrinsics of the cameras that get a block of their own)
+  for (size_t i = 0; i < extrinsicsEstimationParametersVec_.size(); ++i) {
+    const ExtrinsicsEstimationParameters& ep = extrinsicsEstimationParametersVec_[i];
+    const bool shared = (ep.sigma_c_relative_translation < 1e-12 || ep.sigma_c_relative_orientation < 1e-12) && !states_.empty();
+    if (!shared && i >= multiFrame->T_SC.size()) return false;
+  }
 
   State st;
   st.id = multiFrame->id;
@@ -638,7 +647,63 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
 // landmark and dense Schur complements with pseudo-inverses, eigen-decomposition into J, e0) runs on the GPU
 // through okvis_ba_marginalize.
 // ---------------------------------------------------------------------------------------------------
+struct Estimator::MargUndo {
+  // decisions and deletions of Estimator.cpp:485-725 are interleaved, so they are applied as the reference applies them and
+  // logged; the log is replayed backwards if the numerics (upload / okvis_ba_marginalize) throw
+  struct Op {
+    enum Kind { SB_CLEARED, OBSERVATION_REMOVED, LANDMARK_ERASED } kind;
+    size_t stateIdx = 0;
+    int sbBlock = -1;
+    Observation obs{};
+    MapPoint landmark;
+    bool initialized = false;
+  };
+  std::vector<Op> ops;
+  size_t removedSize = 0;
+};
+
 bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks) {
+  MargUndo undo;
+  undo.removedSize = removedLandmarks.size();
+  try {
+    return applyMarginalizationStrategyImpl(numKeyframes, numImuFrames, removedLandmarks, undo);
+  } catch (...) {
+    std::lock_guard<std::mutex> l(statesMutex_);
+    for (size_t k = undo.ops.size(); k-- > 0;) {
+      MargUndo::Op& op = undo.ops[k];
+      if (op.kind == MargUndo::Op::SB_CLEARED) {
+        states_[op.stateIdx].sbBlock = op.sbBlock;
+      } else if (op.kind == MargUndo::Op::OBSERVATION_REMOVED) {
+        observations_[op.obs.handle] = op.obs;
+        landmarksMap_.at(op.obs.landmarkId).observations[KeypointIdentifier{op.obs.poseId, op.obs.camIdx, op.obs.keypointIdx}] =
+            op.obs.handle;
+      } else {
+        landmarkInitialized_[op.landmark.id] = op.initialized;
+        landmarksMap_[op.landmark.id] = std::move(op.landmark);
+      }
+    }
+    removedLandmarks.resize(undo.removedSize);
+    throw;
+  }
+}
+
+bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks,
+                                                 MargUndo& undo) {
+  auto logLandmarkErase = [&](const MapPoint& mp) {
+    MargUndo::Op op;
+    op.kind = MargUndo::Op::LANDMARK_ERASED;
+    op.landmark = mp;
+    auto it = landmarkInitialized_.find(mp.id);
+    op.initialized = it != landmarkInitialized_.end() && it->second;
+    undo.ops.push_back(std::move(op));
+  };
+  auto removeObservationLogged = [&](uint64_t hnd) {
+    MargUndo::Op op;
+    op.kind = MargUndo::Op::OBSERVATION_REMOVED;
+    op.obs = observations_.at(hnd);
+    undo.ops.push_back(std::move(op));
+    removeObservation(hnd);
+  };
   // keep the newest numImuFrames (:439-446)
   if (states_.size() <= numImuFrames) return true;
   const size_t nOlder = states_.size() - numImuFrames;  // states_[0 .. nOlder-1], visited newest -> oldest
@@ -682,6 +747,13 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
     State& st = states_[k];
     if (st.sbBlock < 0 || sbBlocks_[st.sbBlock].fixed) continue;
     const int b = st.sbBlock;
+    {
+      MargUndo::Op op;
+      op.kind = MargUndo::Op::SB_CLEARED;
+      op.stateIdx = k;
+      op.sbBlock = b;
+      undo.ops.push_back(std::move(op));
+    }
     st.sbBlock = -1;  // "remember we removed"
     margSb.push_back(b);
     for (size_t i = 0; i < imuFactors_.size(); ++i)
@@ -733,6 +805,7 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
       }
       if (residuals.empty()) {  // :663-668
         removedLandmarks.push_back(mp);
+        logLandmarkErase(mp);
         landmarkInitialized_.erase(pit->first);
         pit = landmarksMap_.erase(pit);
         continue;
@@ -746,12 +819,12 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
         const uint64_t poseId = observations_.at(hnd).poseId;
         if ((contains(removeFrames, poseId) && hasNewObservations) ||
             (!contains(allLinearizedFrames, poseId) && marginalize)) {
-          removeObservation(hnd);  // ok, let's ignore the observation
+          removeObservationLogged(hnd);  // ok, let's ignore the observation
           residuals.erase(residuals.begin() + r);
           r--;
         } else if (marginalize && contains(allLinearizedFrames, poseId)) {
           if (obsCount < 2) {
-            removeObservation(hnd);
+            removeObservationLogged(hnd);
             residuals.erase(residuals.begin() + r);
             r--;
           } else {
@@ -767,6 +840,7 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
       }
       if (justDelete) {
         removedLandmarks.push_back(mp);
+        logLandmarkErase(mp);
         landmarkInitialized_.erase(pit->first);
         pit = landmarksMap_.erase(pit);
         continue;
@@ -865,6 +939,10 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
     res.capacity_blocks = capb;
     res.block_type = bt.data(); res.block_idx = bi.data(); res.block_off = bo.data();
     res.H = Hn.data(); res.b0 = bn.data(); res.J = Jn.data(); res.e0 = en.data();
+    if (debugFailMarg_) {
+      debugFailMarg_ = false;
+      throw Exception("applyMarginalizationStrategy: injected failure (debugFailNextMarginalization)");
+    }
     check(okvis_ba_set_options(solver_, &options_), "set_options");
     check(okvis_ba_upload(solver_, 1, &fw.w), "upload (marginalisation window)");
     const auto tm2 = clk::now();

@@ -108,7 +108,10 @@ class Estimator {
   // ---- the hot path (Estimator.hpp:183-211) ----
   void optimize(size_t numIter, size_t numThreads = 1, bool verbose = false);
   bool setOptimizationTimeLimit(double timeLimit, int minIterations);
+  // Strong guarantee: when the GPU part fails (exception), the book-keeping is rolled back to the state before the call.
   bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks);
+  // test hook: the next applyMarginalizationStrategy throws where the GPU call would be (exercises the roll-back)
+  void debugFailNextMarginalization() { debugFailMarg_ = true; }
   static bool initPoseFromImu(const ImuMeasurementDeque& imuMeasurements, Transformation& T_WS);
 
   // ---- getters (Estimator.hpp:218-354) ----
@@ -265,6 +268,9 @@ class Estimator {
   std::vector<RelPose> relPoses_;
   MargPrior prior_;
   std::array<double, 4> timings_{};
+  bool debugFailMarg_ = false;
+  struct MargUndo;  // what applyMarginalizationStrategy changed before its GPU call (estimator.cpp)
+  bool applyMarginalizationStrategyImpl(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks, MargUndo& undo);
   std::array<double, 6> margInfo_{};  // last marginalisation: ms flatten, upload, marginalize; Jacobi sweeps (2); sub-window D
   uint64_t nextId_ = 1ULL << 40;    // IdProvider::instance().newId() stand-in for internal blocks
   uint64_t nextHandle_ = 1;

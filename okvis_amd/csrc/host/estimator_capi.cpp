@@ -126,6 +126,13 @@ int okvis_est_apply_marginalization(void* h, int numKeyframes, int numImuFrames)
     return static_cast<Estimator*>(h)->applyMarginalizationStrategy((size_t)numKeyframes, (size_t)numImuFrames, removed) ? 1 : 0;
   });
 }
+// test hook (tests/test_gpu_estimator.py): the next applyMarginalizationStrategy throws where its GPU call would be
+int okvis_est_debug_fail_next_marginalization(void* h) {
+  return guarded([&] {
+    static_cast<Estimator*>(h)->debugFailNextMarginalization();
+    return 1;
+  });
+}
 int okvis_est_get_T_WS(void* h, uint64_t id, double out[7]) {
   return guarded([&] {
     Transformation T;

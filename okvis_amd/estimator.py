@@ -187,6 +187,12 @@ class Estimator:
             removed.extend(int(ids[i]) for i in range(min(n.value, cap)))
         return ok
 
+    def debugFailNextMarginalization(self):
+        """test hook: the next applyMarginalizationStrategy raises where its GPU call would be (roll-back test)"""
+        fn = self._api.okvis_est_debug_fail_next_marginalization
+        fn.argtypes = [C.c_void_p]
+        self._c(fn(self._h))
+
     def lastOptimizeTimings(self):
         """ms: flatten, upload (host index build + H2D), iterations, downloads."""
         out = np.zeros(4)

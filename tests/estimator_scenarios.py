@@ -8,7 +8,7 @@ from okvis_amd.window import DIST_EQUIDISTANT, DIST_RADTAN, ImuParams
 
 
 def sliding_window(make_estimator, make_frame, n_frames=12, num_keyframes=5, num_imu_frames=3, iters=5, seed=7,
-                   model=DIST_EQUIDISTANT, extrinsics_sigmas=(0, 0, 0, 0), marginalize=True):
+                   model=DIST_EQUIDISTANT, extrinsics_sigmas=(0, 0, 0, 0), marginalize=True, fail_marginalization_at=()):
     """What ThreadedKFVio does per frame (ThreadedKFVio.cpp:736-765): addStates, addLandmark / addObservation for the
     visible wall points, optimize(iters), applyMarginalizationStrategy(numKeyframes, numImuFrames).  Returns a trace:
     one dict per frame with the states of every frame in the window, a sample of landmarks, counts and removed ids."""
@@ -68,6 +68,16 @@ def sliding_window(make_estimator, make_frame, n_frames=12, num_keyframes=5, num
                 n_obs += 1
         s = est.optimize(iters, 2, False)
         removed = []
+        if marginalize and k in fail_marginalization_at:
+            # the numerics of this call fail (injected): the estimator has to be exactly where it was before the call
+            before = (est.numFrames(), est.numLandmarks(), est.priorInfo())
+            est.debugFailNextMarginalization()
+            failed = False
+            try:
+                est.applyMarginalizationStrategy(num_keyframes, num_imu_frames, removed)
+            except Exception:
+                failed = True
+            assert failed and removed == [] and before == (est.numFrames(), est.numLandmarks(), est.priorInfo())
         if marginalize:
             assert est.applyMarginalizationStrategy(num_keyframes, num_imu_frames, removed)
         all_removed += removed

@@ -167,3 +167,26 @@ def test_sliding_window_with_marginalization_every_frame():
     assert 2 * np.linalg.norm(T[3:6]) < 1e-2
     assert np.linalg.norm(T[:3] - r_true) < 1e-1
     est.close()
+
+
+def test_failed_marginalization_is_rolled_back():
+    """applyMarginalizationStrategy interleaves decisions with deletions (Estimator.cpp:485-725); when its numerics fail the
+    book-keeping is rolled back (strong guarantee).  A run in which the call fails at three frames (injected) and is then
+    repeated must be indistinguishable from a run without failures: same windows, same removed landmarks, same states."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import estimator_scenarios as S
+    kw = dict(n_frames=16, num_keyframes=3, num_imu_frames=2, iters=4, seed=11)
+    clean, _ = S.sliding_window(lambda: estimator.Estimator(0), estimator.Frame, **kw)
+    rough, _ = S.sliding_window(lambda: estimator.Estimator(0), estimator.Frame, fail_marginalization_at=(4, 9, 13, 14, 15), **kw)
+    assert all(clean[k]["n_frames"] < k + 1 for k in (4, 9, 13, 14, 15)), "no frame leaves the window at the failing frames"
+    assert any(clean[k]["removed"] for k in (13, 14, 15)), "no landmark is marginalised at the failing frames"
+    for a, b in zip(clean, rough):
+        assert (a["removed"], a["n_frames"], a["n_landmarks"], a["prior"]) == (b["removed"], b["n_frames"], b["n_landmarks"], b["prior"])
+        for fid in a["poses"]:
+            assert np.array_equal(a["poses"][fid], b["poses"][fid])
+        for fid in a["sbs"]:
+            assert np.array_equal(a["sbs"][fid], b["sbs"][fid])
+        for lid in a["landmarks"]:
+            assert np.array_equal(a["landmarks"][lid], b["landmarks"][lid])
