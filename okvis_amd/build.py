@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libokvis_amd_ba.so")
 SOURCES = ["ba_capi.hip"]
-HEADERS = [os.path.join("host", "estimator.hpp"), os.path.join("host", "estimator.cpp"),
+HEADERS = [os.path.join("host", "estimator.hpp"), os.path.join("host", "estimator.cpp"), os.path.join("host", "replay.hpp"),
+           os.path.join("host", "replay.cpp"), os.path.join("host", "replay_main.cpp"),
            os.path.join("host", "estimator_capi.cpp"), "ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_schur.hpp", "ba_solve.hpp",
            "ba_imu.hpp", "ba_marg.hpp", "ba_chol_tiles.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
 
@@ -39,17 +40,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 HOST_LIB = os.path.join(HERE, "lib", "libokvis_amd_estimator.so")
+REPLAY_EXE = os.path.join(HERE, "lib", "okvis_amd_replay")
 
 
 def build_host(verbose: bool = False) -> str:
     """C++ host layer (okvis_amd::Estimator + flat C wrapper), linked against the HIP library."""
     host = os.path.join(CSRC, "host")
     cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", os.path.join(host, "estimator.cpp"),
-           os.path.join(host, "estimator_capi.cpp"), "-o", HOST_LIB, "-L" + os.path.dirname(LIB), "-lokvis_amd_ba",
+           os.path.join(host, "estimator_capi.cpp"), os.path.join(host, "replay.cpp"), "-o", HOST_LIB, "-L" + os.path.dirname(LIB), "-lokvis_amd_ba",
            "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    # okvis_amd_replay <dataset folder> [trajectory.csv]: the backend-side counterpart of okvis_app_synchronous
+    exe = ["g++", "-std=c++17", "-O2", "-Wall", os.path.join(host, "replay_main.cpp"), "-o", REPLAY_EXE,
+           "-L" + os.path.dirname(LIB), "-lokvis_amd_estimator", "-lokvis_amd_ba", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(exe), flush=True)
+    subprocess.check_call(exe)
     return HOST_LIB
 
 

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "estimator.hpp"
+#include "replay.hpp"
 
 using namespace okvis_amd;
 
@@ -263,3 +264,46 @@ int okvis_est_propagation(int n, const int64_t* t, const double* gyr, const doub
 }
 
 }  // extern "C"
+
+// ---- dataset replay (replay.hpp): reads an ASL folder + recorded tracks and drives a fresh Estimator over it -------------
+// opts: numKeyframes, numImuFrames, numIterations, numThreads, maxFrames, minObservationsPerLandmark, imuAsFloat (ints);
+// imuOverlap (s).  stats[8]: frames, landmarks removed, has ground truth, rms position, final position, final rotation,
+// mean ms optimize, mean ms marginalize.  trajectory_csv may be null.
+extern "C" int okvis_replay_run(const char* path, int device, const int* opts, double imuOverlap, const char* trajectory_csv,
+                                double* stats) {
+  return guarded([&] {
+    okvis_amd::ReplayOptions o;
+    o.numKeyframes = opts[0], o.numImuFrames = opts[1], o.numIterations = opts[2], o.numThreads = opts[3];
+    o.maxFrames = opts[4], o.minObservationsPerLandmark = opts[5];
+    o.imuOverlap = imuOverlap;
+    const okvis_amd::Recording rec = okvis_amd::readRecording(path, opts[6] != 0);
+    Estimator est(device);
+    const okvis_amd::ReplayResult r = okvis_amd::replay(rec, o, est);
+    if (trajectory_csv && trajectory_csv[0]) okvis_amd::writeTrajectoryCsv(trajectory_csv, r);
+    double mo = 0, mm = 0;
+    for (const auto& f : r.frames) mo += f.msOptimize, mm += f.msMarginalize;
+    const double n = r.frames.empty() ? 1.0 : (double)r.frames.size();
+    stats[0] = (double)r.frames.size(), stats[1] = (double)r.landmarksRemoved, stats[2] = r.hasGroundTruth ? 1 : 0;
+    stats[3] = r.rmsPosition, stats[4] = r.finalPosition, stats[5] = r.finalRotation, stats[6] = mo / n, stats[7] = mm / n;
+    return 1;
+  });
+}
+// readers alone (no GPU): counts of what a folder holds, for the CPU tests.  counts[6]: imu samples, cameras, ground-truth
+// rows, frames, observations, landmarks
+extern "C" int okvis_replay_probe(const char* path, int imuAsFloat, long long* counts, double* first_imu7, double* cam0_T_SC7,
+                                  double* cam0_intr12, int* cam0_model, double* imu_params4) {
+  return guarded([&] {
+    const okvis_amd::Recording rec = okvis_amd::readRecording(path, imuAsFloat != 0);
+    counts[0] = (long long)rec.imu.size(), counts[1] = (long long)rec.cameras.size(), counts[2] = (long long)rec.groundTruth.size();
+    counts[3] = (long long)rec.frames.size(), counts[4] = (long long)rec.observations.size(), counts[5] = (long long)rec.landmarks.size();
+    first_imu7[0] = (double)rec.imu[0].t_ns;
+    for (int k = 0; k < 3; ++k) first_imu7[1 + k] = rec.imu[0].gyr[k], first_imu7[4 + k] = rec.imu[0].acc[k];
+    const okvis_amd::Transformation T = rec.cameras[0].T_SC();
+    for (int k = 0; k < 7; ++k) cam0_T_SC7[k] = T.p[k];
+    for (int k = 0; k < 12; ++k) cam0_intr12[k] = rec.cameras[0].geometry.intr[k];
+    *cam0_model = rec.cameras[0].geometry.model;
+    imu_params4[0] = rec.imuParameters.sigma_g_c, imu_params4[1] = rec.imuParameters.sigma_gw_c;
+    imu_params4[2] = rec.imuParameters.sigma_a_c, imu_params4[3] = rec.imuParameters.sigma_aw_c;
+    return 1;
+  });
+}

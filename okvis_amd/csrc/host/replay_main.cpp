@@ -1,0 +1,62 @@
+// okvis_amd_replay <dataset folder> [trajectory.csv] [--keyframes N] [--imu-frames N] [--iterations N] [--max-frames N]
+//
+// The backend-side counterpart of `okvis_app_synchronous <config> <dataset folder>` (reference
+// okvis_apps/src/okvis_app_synchronous.cpp): reads the ASL folder plus the recorded tracks (replay.hpp) and runs the per-frame
+// loop of ThreadedKFVio on okvis_amd::Estimator.  Prints one line per 20 frames and a summary.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "replay.hpp"
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    std::fprintf(stderr, "usage: %s <dataset folder> [trajectory.csv] [--keyframes N] [--imu-frames N] [--iterations N] [--max-frames N]\n", argv[0]);
+    return -1;  // okvis_app_synchronous.cpp:208-212
+  }
+  okvis_amd::ReplayOptions opt;
+  std::string out;
+  for (int i = 2; i < argc; ++i) {
+    auto val = [&](int& dst) {
+      if (i + 1 >= argc) {
+        std::fprintf(stderr, "%s needs a value\n", argv[i]);
+        std::exit(-1);
+      }
+      dst = std::atoi(argv[++i]);
+    };
+    if (!std::strcmp(argv[i], "--keyframes")) val(opt.numKeyframes);
+    else if (!std::strcmp(argv[i], "--imu-frames")) val(opt.numImuFrames);
+    else if (!std::strcmp(argv[i], "--iterations")) val(opt.numIterations);
+    else if (!std::strcmp(argv[i], "--max-frames")) val(opt.maxFrames);
+    else out = argv[i];
+  }
+  try {
+    const okvis_amd::Recording rec = okvis_amd::readRecording(argv[1]);
+    std::printf("No. IMU measurements: %zu\n", rec.imu.size());  // okvis_app_synchronous.cpp:249
+    std::printf("No. frames: %zu, cameras: %zu, recorded observations: %zu, landmarks: %zu\n", rec.frames.size(), rec.cameras.size(),
+                rec.observations.size(), rec.landmarks.size());
+    okvis_amd::Estimator estimator(0);
+    const okvis_amd::ReplayResult r = okvis_amd::replay(rec, opt, estimator);
+    double mo = 0, mm = 0;
+    for (size_t k = 0; k < r.frames.size(); ++k) {
+      const okvis_amd::ReplayFrameResult& f = r.frames[k];
+      mo += f.msOptimize, mm += f.msMarginalize;
+      if (k % 20 == 0)
+        std::printf("frame %4zu  window %d frames / %d landmarks / %d new observations  cost %.4g -> %.4g (%d it)  %.2f + %.2f ms\n", k,
+                    f.framesInWindow, f.landmarksInWindow, f.observations, f.initialCost, f.finalCost, f.iterations, f.msOptimize,
+                    f.msMarginalize);
+    }
+    const double n = r.frames.empty() ? 1.0 : (double)r.frames.size();
+    std::printf("Finished: %zu frames, %zu landmarks marginalised or dropped, optimize %.3f ms + marginalise %.3f ms per frame\n",
+                r.frames.size(), r.landmarksRemoved, mo / n, mm / n);
+    if (r.hasGroundTruth)
+      std::printf("against the ground truth (first pose aligned): rms position %.4f m, final position %.4f m, final rotation %.5f rad\n",
+                  r.rmsPosition, r.finalPosition, r.finalRotation);
+    if (!out.empty()) okvis_amd::writeTrajectoryCsv(out, r);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
