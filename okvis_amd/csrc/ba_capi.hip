@@ -765,6 +765,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(ct_Linv, put_zero(A, 8 * nT * CT_TILE));
     OFF(ct_rhs, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_y, put_zero(A, 8 * nT * CT_TB));
+    OFF(ct_x, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_flag, put_zero(A, sizeof(int) * (ntile + 2)));
     OFF(ct_g, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_d2, put_zero(A, 8 * nT * CT_TB));
@@ -774,7 +775,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(lm_scale, put_zero(A, 24 * (size_t)nlm));
   OFF(grad, put_zero(A, 8 * (size_t)D));
   OFF(quality, put_zero(A, 8 * (size_t)nlm));
-  if (opt.debug_arrays) OFF(prof, put_zero(A, 8 * 64));   // clock64() phase stamps: diagnostics only
+  if (opt.debug_arrays) OFF(prof, put_zero(A, 8 * (64 + 4 * 160)));   // clock64() phase stamps + tile task timeline: diagnostics only
   OFF(ctrl, put_zero(A, sizeof(Ctrl)));
   OFF(imu_pose0, put(A, vec(w.imu_pose0, (size_t)w.n_imu)));
   OFF(imu_sb0, put(A, vec(w.imu_sb0, (size_t)w.n_imu)));
@@ -869,7 +870,7 @@ void relocate(WinPtrs& P, unsigned char* base, unsigned char* zbase, int debug) 
   P.Hpp = nullptr;
   if (P.D <= MAX_D_LDS) {
     P.Sg = nullptr;
-    P.ct_T = P.ct_Linv = P.ct_rhs = P.ct_y = P.ct_g = P.ct_d2 = nullptr;
+    P.ct_T = P.ct_Linv = P.ct_rhs = P.ct_y = P.ct_x = P.ct_g = P.ct_d2 = nullptr;
     P.ct_flag = nullptr;
   }
 }
@@ -913,7 +914,7 @@ hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
     if (!final_only) {
       const int nT = (s->max_Dpad_large + CT_TB - 1) / CT_TB;
       hipLaunchKernelGGL(large_export_kernel, dim3(nT * (nT + 1) / 2, (unsigned)b.nw), dim3(CT_THREADS), 0, b.st, s->d_wins + b.w0);
-      hipLaunchKernelGGL(chol_tiles_window_kernel, dim3(nT * (nT + 1) / 2, (unsigned)b.nw), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8,
+      hipLaunchKernelGGL(chol_tiles_window_kernel, dim3(nT * (nT + 1) / 2 + nT, (unsigned)b.nw), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8,
                          b.st, s->d_wins + b.w0);
       hipLaunchKernelGGL(solve_large_tail_kernel, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), 0, b.st, s->d_wins + b.w0, s->d_opt);
     }
@@ -1552,7 +1553,7 @@ static int locate(okvis_ba_solver* s, int w, int which, const double** ptr, int6
     case OKVIS_BA_ARR_LM_QUALITY: *ptr = P.quality; *n = H.n_lm; return 0;
     case OKVIS_BA_ARR_GRADIENT: *ptr = P.grad; *n = H.D; return 0;
     case OKVIS_BA_ARR_DAMPING: *ptr = P.Dp2; *n = H.D; return P.Dp2 ? 0 : OKVIS_BA_ERR_STATE;
-    case 99: *ptr = P.prof; *n = 64; return P.prof ? 0 : OKVIS_BA_ERR_STATE;
+    case 99: *ptr = P.prof; *n = 64 + 4 * 160; return P.prof ? 0 : OKVIS_BA_ERR_STATE;
     case 98: *ptr = nullptr; *n = H.n_imu; return 0;  // diagnostics: re-preintegration count per IMU factor
     case 97: *ptr = nullptr; *n = 24; return 0;       // diagnostics: trust-region control record
     case OKVIS_BA_ARR_IMU_SB_REF: *ptr = nullptr; *n = 9 * (int64_t)H.n_imu; return 0;
@@ -1748,6 +1749,10 @@ int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* r
   if ((rc = chk(hipMemcpy(d + oT, tiles.data(), 8 * tiles.size(), hipMemcpyHostToDevice)))) return rc;
   if ((rc = chk(hipMemcpy(d + oR, r.data(), 8 * (size_t)np, hipMemcpyHostToDevice)))) return rc;
   if ((rc = chk(hipMemset(d + oF, 0, sizeof(int) * (ntiles + 1))))) return rc;
+  {
+    std::vector<unsigned long long> sentinel(np, CT_X_SENTINEL);
+    if ((rc = chk(hipMemcpy(d + oX, sentinel.data(), 8 * (size_t)np, hipMemcpyHostToDevice)))) return rc;
+  }
   CholTiles C;
   C.nT = nT;
   C.T = reinterpret_cast<double*>(d + oT);
@@ -1755,11 +1760,11 @@ int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* r
   C.rhs = reinterpret_cast<double*>(d + oR);
   C.y = reinterpret_cast<double*>(d + oY);
   C.flag = reinterpret_cast<int*>(d + oF);
+  C.x = reinterpret_cast<double*>(d + oX);
   if ((rc = chk(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     CT_SMEM_DOUBLES * 8))))
     return rc;
-  hipLaunchKernelGGL(chol_tile_kernel, dim3(ntiles), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8, 0, C);
-  hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(CT_THREADS), 0, 0, C, reinterpret_cast<double*>(d + oX));
+  hipLaunchKernelGGL(chol_tile_kernel, dim3(ntiles + nT), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8, 0, C);
   if ((rc = chk(hipGetLastError()))) return rc;
   if ((rc = chk(hipDeviceSynchronize()))) return rc;
   std::vector<double> xs(np);

@@ -4,17 +4,21 @@
 //
 //   tiles      48 x 48 (8 blocks of the 6-wide pose/speed-bias granularity, 3 MFMA sub-tiles of 16), row-major,
 //              lower triangle only, tile (i,j) at ((i(i+1)/2 + j) * 48 * 48
-//   one workgroup per tile, launched in COLUMN-major task order.  Tile (i,j) needs tiles (i,k), (j,k), k < j,
+//   one workgroup per tile (the tile left of a diagonal tile is made by the diagonal tile's workgroup, see chol_tile_task),
+//   launched in COLUMN-major task order.  Tile (i,j) needs tiles (i,k), (j,k), k < j,
 //   and the diagonal tile (j,j): all of them have a smaller task index.  Workgroups are dispatched in index
 //   order, so every dependency is resident or finished when a workgroup starts spinning on its flag: no
 //   host synchronisation, no cooperative launch, no deadlock.  (Spins are bounded anyway: a stuck
 //   dependency marks the factorisation as failed instead of hanging the GPU.)
 //
 //     off-diagonal (i,j):  C = A_ij - sum_k L_ik L_jk^T  (MFMA);  L_ij = C L_jj^-T = C (Linv_j)^T  (MFMA)
-//     diagonal (j,j):      C = A_jj - sum_k L_jk L_jk^T  (MFMA);  L_jj = chol(C) in LDS (6-wide blocks),
+//     diagonal (j,j):      C = A_jj - sum_k L_jk L_jk^T  (MFMA);  L_jj = chol(C) in LDS (ct_potrf_trinv48),
 //                          Linv_j = L_jj^-1 (published for the column's TRSMs and for the back-substitution),
 //                          y_j = Linv_j (rhs_j - sum_k L_jk y_k)  (forward substitution rides along)
-//   back-substitution L^T x = y: chol_backsub(), one workgroup, tile column by tile column with Linv_j^T.
+//   back-substitution L^T x = y: nT more tasks behind the tiles (chol_backsub_task): workgroup b owns tile row j = nT-1-b,
+//   keeps t_j = y_j - sum_(i>j) L_ij^T x_i, takes every x_i as it appears (the VALUES are polled: x is pre-set to a sentinel,
+//   so a value and its readiness are one memory round trip), holds Linv_j and the last tile it will need, L_(j+1,j), in LDS
+//   and prefetches the others - the serial chain is one poll + two 48x48 products from LDS per tile row.
 #pragma once
 #include "ba_device.hpp"
 #include "ba_types.hpp"
@@ -26,6 +30,7 @@ constexpr int CT_LD = 49;            // LDS row stride (doubles): conflict-free 
 constexpr int CT_THREADS = 256;
 constexpr int CT_TILE = CT_TB * CT_TB;
 constexpr int CT_SPIN_LIMIT = 1 << 22;
+constexpr int CT_NB = 6;             // block-column width inside a diagonal tile (ct_potrf_trinv48)
 
 typedef double ct_v4 __attribute__((ext_vector_type(4)));
 
@@ -36,6 +41,8 @@ struct CholTiles {   // per-window workspace of the tiled solver (device pointer
   double* rhs;       // [48 nT] right-hand side on entry
   double* y;         // [48 nT] L^-1 rhs
   int* flag;         // [nT(nT+1)/2 + 1]: tile done flags; last entry = failure (non-PD pivot / dependency timeout)
+  double* x = nullptr;   // [48 nT] solution; when set, tasks nT(nT+1)/2 .. + nT - 1 are the back-substitution (below)
+  double* tl = nullptr;  // diagnostics: per task 4 wall_clock64() stamps (start, dependencies met, own work done, flag set)
 };
 
 __device__ __forceinline__ int ct_tile_index(int i, int j) { return i * (i + 1) / 2 + j; }
@@ -93,127 +100,238 @@ __device__ __forceinline__ double ct_rsqrt(double x) {  // v_rsq_f64 + two Newto
   return y;
 }
 
-// Cholesky of the 48x48 SPD matrix in LDS (stride CT_LD, lower triangle referenced) in 6-wide block columns.
-// The 6x6 diagonal block is factored in registers by one work-item (reciprocal square roots instead of
-// divisions), its reciprocal diagonal is published in dinv[48] for the panel step.  A non-positive pivot sets
-// *s_fail.  Afterwards the lower triangle holds L.
-__device__ void ct_potrf48(double* M, double* dinv, int tid, int* s_fail) {
-  for (int kb = 0; kb < 8; ++kb) {
-    const int k0 = 6 * kb;
-    if (tid == 0) {
-      double a[6][6];
+// Cholesky factor AND inverse of a diagonal tile (the serial chain of the tiled solver) in LDS: right-looking NB-wide block
+// columns (NB = CT_NB; the diagonal block by one work-item in registers, reciprocal square roots instead of divisions), with
+//   * look-ahead: while waves 1-3 apply the trailing update of block column kb, wave 0 updates the NEXT 6x6 diagonal block
+//     alone (one lane per entry), then factors and inverts it in registers (lane 0) - two barriers per block column
+//     instead of three, and the serial factorisation is off the critical path;
+//   * the triangular inverse rides along: block row bi of X = L^-1 needs the L rows of block row bi (final after the panel
+//     steps kb < bi), X_(bi,bi) (from the look-ahead) and the X rows above; its two products are spread over the panel and
+//     update phases of step kb = bi, so the inverse costs no barrier phases of its own.
+// M: 48x48 SPD in LDS (stride CT_LD, lower triangle referenced) -> L.  X: L^-1 (stride CT_LD, full square, zeros above the
+// diagonal).  Tm: 6 x 48 scratch.  A non-positive pivot sets *s_fail.
+template <int NB>
+__device__ __forceinline__ void ct_factor_inv_block(double* M, double* X, double* dinv, int k0, int* s_fail) {
+  // one work-item: NB x NB Cholesky of M[k0.., k0..] in registers (reciprocal square roots), its inverse into X
+  double a[NB][NB], di[NB];
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+  for (int r = 0; r < NB; ++r)
 #pragma unroll
-        for (int c = 0; c <= r; ++c) a[r][c] = M[(k0 + r) * CT_LD + k0 + c];
-      bool bad = false;
+    for (int c = 0; c <= r; ++c) a[r][c] = M[(k0 + r) * CT_LD + k0 + c];
+  bool bad = false;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double d = a[c][c];
+  for (int c = 0; c < NB; ++c) {
+    double d = a[c][c];
 #pragma unroll
-        for (int m = 0; m < c; ++m) d -= a[c][m] * a[c][m];
-        if (!(d > 0.0)) {
-          bad = true;
-          d = 1.0;
-        }
-        const double inv = ct_rsqrt(d);
-        a[c][c] = d * inv;
-        dinv[k0 + c] = inv;
-#pragma unroll
-        for (int r = c + 1; r < 6; ++r) {
-          double v = a[r][c];
-#pragma unroll
-          for (int m = 0; m < c; ++m) v -= a[r][m] * a[c][m];
-          a[r][c] = v * inv;
-        }
-      }
-      if (bad) *s_fail = 1;
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c <= r; ++c) M[(k0 + r) * CT_LD + k0 + c] = a[r][c];
+    for (int m = 0; m < c; ++m) d -= a[c][m] * a[c][m];
+    if (!(d > 0.0)) {
+      bad = true;
+      d = 1.0;
     }
-    __syncthreads();
-    const int nrows = CT_TB - k0 - 6;
-    if (tid < nrows) {  // panel: row <- row L_kk^-T
-      double* row = M + (k0 + 6 + tid) * CT_LD + k0;
-      double x[6];
+    const double inv = ct_rsqrt(d);
+    a[c][c] = d * inv;
+    di[c] = inv;
+    dinv[k0 + c] = inv;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
+    for (int r = c + 1; r < NB; ++r) {
+      double v = a[r][c];
+#pragma unroll
+      for (int m = 0; m < c; ++m) v -= a[r][m] * a[c][m];
+      a[r][c] = v * inv;
+    }
+  }
+  if (bad) *s_fail = 1;
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) M[(k0 + r) * CT_LD + k0 + c] = a[r][c];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {  // inverse, column by column
+    double x[NB];
+#pragma unroll
+    for (int r = c; r < NB; ++r) {
+      double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int m = c; m < r; ++m) v -= a[r][m] * x[m];
+      x[r] = v * di[r];
+      X[(k0 + r) * CT_LD + k0 + c] = x[r];
+    }
+  }
+}
+
+template <int NB>
+__device__ void ct_potrf_trinv48(double* M, double* X, double* dinv, double* Tm, int tid, int* s_fail) {
+  constexpr int NS = CT_TB / NB, NTRI = NB * (NB + 1) / 2;
+  static_assert(NS * NB == CT_TB && NTRI <= 64 && NB <= 16, "block width");
+  for (int e = tid; e < CT_TB * CT_TB; e += CT_THREADS) X[(e / CT_TB) * CT_LD + (e % CT_TB)] = 0.0;
+  __syncthreads();
+  if (tid == 0) ct_factor_inv_block<NB>(M, X, dinv, 0, s_fail);
+  __syncthreads();
+  for (int kb = 0; kb < NS; ++kb) {
+    const int k0 = NB * kb, nrows = CT_TB - k0 - NB;
+    // ---- phase P: panel of block column kb: row <- row L_kk^-T; first product of the inverse row (threads from the top)
+    if (tid < nrows) {
+      double* row = M + (k0 + NB + tid) * CT_LD + k0;
+      double x[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
         double v = row[c];
 #pragma unroll
         for (int m = 0; m < c; ++m) v -= x[m] * M[(k0 + c) * CT_LD + k0 + m];
         x[c] = v * dinv[k0 + c];
       }
 #pragma unroll
-      for (int c = 0; c < 6; ++c) row[c] = x[c];
+      for (int c = 0; c < NB; ++c) row[c] = x[c];
+    }
+    if (kb > 0) {   // T = L_(kb, 0..kb-1) X_(0..kb-1, .)   (NB x NB kb), by the threads from the top
+      const int ncol = k0;
+      for (int e = CT_THREADS - 1 - tid; e < NB * ncol; e += CT_THREADS) {
+        const int r = e / ncol, c = e - r * ncol;
+        const int m0 = (c / NB) * NB;   // X is lower triangular: rows >= the column's block start
+        double t = 0;
+        for (int m = m0; m < ncol; ++m) t += M[(k0 + r) * CT_LD + m] * X[m * CT_LD + c];
+        Tm[r * CT_TB + c] = t;
+      }
     }
     __syncthreads();
-    // trailing update, one work-item per entry of the lower triangle
-    const int ntri = nrows * (nrows + 1) / 2;
-    for (int e = tid; e < ntri; e += CT_THREADS) {
-      int r = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
-      while ((r + 1) * (r + 2) / 2 <= e) ++r;
-      while (r * (r + 1) / 2 > e) --r;
-      const int c = e - r * (r + 1) / 2;
-      const double* a = M + (k0 + 6 + r) * CT_LD + k0;
-      const double* b = M + (k0 + 6 + c) * CT_LD + k0;
-      double s = 0;
+    // ---- phase U: wave 0 prepares the next diagonal block; the others apply the trailing update and finish the inverse row
+    if (tid < 64) {
+      if (kb < NS - 1) {
+        if (tid < NTRI) {   // entry (r, c), c <= r, of the next diagonal block -= panel row r . panel row c
+          int r = 0;
+          while ((r + 1) * (r + 2) / 2 <= tid) ++r;
+          const int c = tid - r * (r + 1) / 2;
+          const double* pa = M + (k0 + NB + r) * CT_LD + k0;
+          const double* pb = M + (k0 + NB + c) * CT_LD + k0;
+          double t = 0;
 #pragma unroll
-      for (int m = 0; m < 6; ++m) s += a[m] * b[m];
-      M[(k0 + 6 + r) * CT_LD + k0 + 6 + c] -= s;
+          for (int m = 0; m < NB; ++m) t += pa[m] * pb[m];
+          M[(k0 + NB + r) * CT_LD + k0 + NB + c] -= t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid == 0) ct_factor_inv_block<NB>(M, X, dinv, k0 + NB, s_fail);
+      }
+    } else {
+      const int t2 = tid - 64, nt2 = CT_THREADS - 64;
+      // trailing update of the lower triangle below / right of the next diagonal block (that block is wave 0's)
+      const int ntri = nrows * (nrows + 1) / 2;
+      for (int e = NTRI + t2; e < ntri; e += nt2) {   // row-major lower triangle; its first NTRI entries are the next diagonal block
+        int r = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        while (r * (r + 1) / 2 > e) --r;
+        const int c = e - r * (r + 1) / 2;
+        const double* pa = M + (k0 + NB + r) * CT_LD + k0;
+        const double* pb = M + (k0 + NB + c) * CT_LD + k0;
+        double t = 0;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) t += pa[m] * pb[m];
+        M[(k0 + NB + r) * CT_LD + k0 + NB + c] -= t;
+      }
+      if (kb > 0) {   // X_(kb, .) = -X_(kb,kb) T
+        const int ncol = k0;
+        for (int e = t2; e < NB * ncol; e += nt2) {
+          const int r = e / ncol, c = e - r * ncol;
+          double t = 0;
+#pragma unroll
+          for (int m = 0; m < NB; ++m)
+            if (m <= r) t += X[(k0 + r) * CT_LD + k0 + m] * Tm[m * CT_TB + c];
+          X[(k0 + r) * CT_LD + c] = -t;
+        }
+      }
     }
     __syncthreads();
   }
 }
 
-// X = L^-1 for the lower-triangular L in LDS (stride CT_LD), blocked by 6: the eight diagonal blocks are
-// inverted by eight work-items, then block row by block row  X_(bi,bj) = -X_(bi,bi) sum_(k=bj..bi-1) L_(bi,k) X_(k,bj).
-// X (stride CT_LD, full square, zeros above the diagonal); Tm = 6 x 48 scratch.
-__device__ void ct_trinv48(const double* L, const double* dinv, double* X, double* Tm, int tid) {
-  for (int e = tid; e < CT_TB * CT_TB; e += CT_THREADS) X[(e / CT_TB) * CT_LD + (e % CT_TB)] = 0.0;
-  __syncthreads();
-  if (tid < 8) {  // inverse of a 6x6 lower-triangular block, column by column
-    const int k0 = 6 * tid;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      double x[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        if (r < c) {
-          x[r] = 0.0;
-          continue;
-        }
-        double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int m = 0; m < r; ++m)
-          if (m >= c) v -= L[(k0 + r) * CT_LD + k0 + m] * x[m];
-        x[r] = v * dinv[k0 + r];
-      }
-#pragma unroll
-      for (int r = c; r < 6; ++r) X[(k0 + r) * CT_LD + k0 + c] = x[r];
-    }
+// x is pre-set to this pattern (a signalling-NaN payload no computation produces); a slot that holds anything else is final
+constexpr unsigned long long CT_X_SENTINEL = 0x7ff4dead0badf00dULL;
+
+// back-substitution task for tile row j (see the header comment).  256 work-items; lds: three 48 x CT_LD tiles.
+__device__ void chol_backsub_task(const CholTiles& C, int j, double* lds) {
+  const int tid = threadIdx.x, nT = C.nT;
+  double* sL = lds;                         // Linv_j
+  double* sNear = lds + CT_TB * CT_LD;      // tile (j+1, j): the last one this row needs, i.e. the one on the serial chain
+  double* sFar = lds + 2 * CT_TB * CT_LD;   // tiles (i, j), i > j+1, one at a time
+  __shared__ double s_t[CT_TB], s_xi[CT_TB], s_part[5][CT_TB];
+  __shared__ int s_ok;
+  int* failflag = C.flag + nT * (nT + 1) / 2;
+  const unsigned long long* xs = reinterpret_cast<const unsigned long long*>(C.x);
+  auto poll = [&](int slot) {
+    unsigned long long v;
+    int it = 0;
+    do {
+      v = __atomic_load_n(xs + slot, __ATOMIC_RELAXED);
+      if (v != CT_X_SENTINEL) break;
+      __builtin_amdgcn_s_sleep(1);
+    } while (++it < CT_SPIN_LIMIT);
+    return v;
+  };
+  if (tid == 0) {
+    bool ok = ct_wait(C.flag + ct_tile_index(j, j));
+    if (ok && j + 1 < nT) ok = ct_wait(C.flag + ct_tile_index(j + 1, j));
+    s_ok = ok ? 1 : 0;
   }
   __syncthreads();
-  for (int bi = 1; bi < 8; ++bi) {
-    const int ncol = 6 * bi;  // columns 0 .. 6 bi - 1 of block row bi
-    for (int e = tid; e < 6 * ncol; e += CT_THREADS) {  // T = sum_k L_(bi,k) X_(k,.)
-      const int r = e / ncol, c = e - r * ncol;
-      const int m0 = (c / 6) * 6;  // X is lower triangular: rows >= the column's block start
-      double s = 0;
-      for (int m = m0; m < ncol; ++m) s += L[(6 * bi + r) * CT_LD + m] * X[m * CT_LD + c];
-      Tm[r * CT_TB + c] = s;
-    }
-    __syncthreads();
-    for (int e = tid; e < 6 * ncol; e += CT_THREADS) {  // X_(bi,.) = -X_(bi,bi) T
-      const int r = e / ncol, c = e - r * ncol;
-      double s = 0;
+  if (!s_ok) {
+    if (tid == 0) __atomic_store_n(failflag, 1, __ATOMIC_RELEASE);
+    for (int c = tid; c < CT_TB; c += CT_THREADS) C.x[CT_TB * j + c] = 0.0;   // let the rows above run out
+    return;
+  }
+  ct_load_tile(C.Linv + (size_t)j * CT_TILE, sL, tid);
+  if (j + 1 < nT) ct_load_tile(C.T + (size_t)ct_tile_index(j + 1, j) * CT_TILE, sNear, tid);
+  if (tid < CT_TB) s_t[tid] = C.y[CT_TB * j + tid];
+  constexpr int PER = CT_TILE / CT_THREADS;   // 9 entries of a tile per work-item
+  double pre[PER];
+  auto fetch = [&](int i) {
+    const double* g = C.T + (size_t)ct_tile_index(i, j) * CT_TILE;
 #pragma unroll
-      for (int m = 0; m < 6; ++m)
-        if (m <= r) s += X[(6 * bi + r) * CT_LD + 6 * bi + m] * Tm[m * CT_TB + c];
-      X[(6 * bi + r) * CT_LD + c] = -s;
+    for (int k = 0; k < PER; ++k) pre[k] = g[tid + k * CT_THREADS];
+  };
+  const int c = tid % CT_TB, p = tid / CT_TB;   // (component of a 48-vector, part 0..4 of the rows; p = 5: idle)
+  if (nT - 1 >= j + 2) {
+    // the far tiles of the column are final at the latest when the factorisation is, i.e. when x_(nT-1) appears
+    if (tid == 0) (void)poll(CT_TB * (nT - 1));
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    fetch(nT - 1);
+  }
+  for (int i = nT - 1; i > j; --i) {
+    const double* cur = (i == j + 1) ? sNear : sFar;
+    if (i != j + 1) {   // park the fetched tile (the previous step's reads of sFar ended before its second barrier)
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int e = tid + k * CT_THREADS;
+        sFar[(e / CT_TB) * CT_LD + (e % CT_TB)] = pre[k];
+      }
+    }
+    if (i - 1 >= j + 2) fetch(i - 1);   // next far tile: in flight while this step waits and computes
+    if (tid < CT_TB) s_xi[tid] = __longlong_as_double((long long)poll(CT_TB * i + tid));   // x_i, value-polled
+    __syncthreads();
+    if (p < 5) {                         // t_j -= L_ij^T x_i
+      double a = 0;
+      for (int r = p; r < CT_TB; r += 5) a += cur[r * CT_LD + c] * s_xi[r];
+      s_part[p][c] = a;
     }
     __syncthreads();
+    if (tid < CT_TB) s_t[tid] -= s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid] + s_part[4][tid];
+  }
+  __syncthreads();
+  if (p < 5) {             // x_j = Linv_j^T t_j
+    double a = 0;
+    for (int r = p; r < CT_TB; r += 5)
+      if (r >= c) a += sL[r * CT_LD + c] * s_t[r];
+    s_part[p][c] = a;
+  }
+  __syncthreads();
+  if (tid < CT_TB) {
+    double v = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid] + s_part[4][tid];
+    if (__double_as_longlong(v) == (long long)CT_X_SENTINEL) v = __longlong_as_double(0x7ff8000000000000LL);   // a NaN stays a NaN
+    __threadfence();   // whoever sees x_j may read everything this workgroup has seen
+    if (C.tl && tid == 0) C.tl[4 * (nT * (nT + 1) / 2 + nT - 1 - j) + 3] = (double)wall_clock64();
+    __atomic_store_n(reinterpret_cast<unsigned long long*>(C.x) + CT_TB * j + tid, (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED);
   }
 }
 
@@ -221,6 +339,10 @@ __device__ void ct_trinv48(const double* L, const double* dinv, double* X, doubl
 __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nT = C.nT;
+  if (task >= nT * (nT + 1) / 2) {   // the back-substitution tasks sit behind the tiles, last tile row first
+    chol_backsub_task(C, nT - 1 - (task - nT * (nT + 1) / 2), lds);
+    return;
+  }
   int j = 0, rem = task;
   while (rem >= nT - j) {
     rem -= nT - j;
@@ -231,30 +353,46 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
   double* sB = lds + CT_TB * CT_LD;
   double* sC = lds + 2 * CT_TB * CT_LD;
   __shared__ int s_ok, s_fail;
-  __shared__ double s_r[CT_TB], s_dinv[CT_TB], s_tm[6 * CT_TB];
+  __shared__ double s_r[CT_TB], s_dinv[CT_TB], s_tm[CT_NB * CT_TB];
   int* failflag = C.flag + nT * (nT + 1) / 2;
   if (tid == 0) {
     s_ok = 1;
     s_fail = 0;
   }
   const bool diag = (i == j);
-  ct_v4 acc[3];
+  // The diagonal task of row j >= 1 also produces the tile left of it, L_(j,j-1): that tile is the last input of the diagonal
+  // tile, so making it here keeps it in LDS and takes one flag + store + load round trip out of the serial chain
+  // diag(j-1) -> L_(j,j-1) -> diag(j).  The grid slot of tile (j, j-1) stays empty.
+  if (i == j + 1) return;
+  const bool merged = diag && j >= 1;
+  const int kend = merged ? j - 1 : j;
+  if (C.tl && tid == 0) C.tl[4 * task] = (double)wall_clock64();
+  ct_v4 acc[3], acc2[3];
   double* Tij = C.T + (size_t)ct_tile_index(i, j) * CT_TILE;
-  if (wave < 3) ct_load_acc(acc, Tij, CT_TB, wave, lane);
+  double* Tsub = merged ? C.T + (size_t)ct_tile_index(j, j - 1) * CT_TILE : nullptr;
+  if (wave < 3) {
+    ct_load_acc(acc, Tij, CT_TB, wave, lane);
+    if (merged) ct_load_acc(acc2, Tsub, CT_TB, wave, lane);
+  }
   if (diag && tid < CT_TB) s_r[tid] = C.rhs[CT_TB * j + tid];
   __syncthreads();
-  for (int k = 0; k < j; ++k) {
+  for (int k = 0; k < kend; ++k) {
     if (tid == 0) {
       bool ok = ct_wait(C.flag + ct_tile_index(i, k));
       if (ok && !diag) ok = ct_wait(C.flag + ct_tile_index(j, k));
+      if (ok && merged) ok = ct_wait(C.flag + ct_tile_index(j - 1, k));
       if (!ok) s_ok = 0;
     }
     __syncthreads();
     if (!s_ok) break;
     ct_load_tile(C.T + (size_t)ct_tile_index(i, k) * CT_TILE, sA, tid);
     if (!diag) ct_load_tile(C.T + (size_t)ct_tile_index(j, k) * CT_TILE, sB, tid);
+    if (merged) ct_load_tile(C.T + (size_t)ct_tile_index(j - 1, k) * CT_TILE, sB, tid);
     __syncthreads();
-    if (wave < 3) ct_gemm_nt(acc, sA, diag ? sA : sB, wave, lane, -1.0);
+    if (wave < 3) {
+      ct_gemm_nt(acc, sA, diag ? sA : sB, wave, lane, -1.0);
+      if (merged) ct_gemm_nt(acc2, sA, sB, wave, lane, -1.0);
+    }
     if (diag && tid >= 192 && tid < 192 + CT_TB) {  // forward substitution rides along: r_j -= L_jk y_k
       const int r = tid - 192;
       const double* yk = C.y + CT_TB * k;
@@ -264,35 +402,73 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
     }
     __syncthreads();
   }
+  if (s_ok && merged) {
+    // L_(j,j-1) = C2 Linv_(j-1)^T as soon as the previous diagonal tile is there, then the last update of this one from LDS
+    if (wave < 3) ct_store_acc(acc2, sA, CT_LD, wave, lane);
+    if (tid == 0 && !ct_wait(C.flag + ct_tile_index(j - 1, j - 1))) s_ok = 0;
+    __syncthreads();
+    if (s_ok) {
+      ct_load_tile(C.Linv + (size_t)(j - 1) * CT_TILE, sB, tid);
+      __syncthreads();
+      if (wave < 3) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc2[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
+        ct_gemm_nt(acc2, sA, sB, wave, lane, 1.0);
+        ct_store_acc(acc2, Tsub, CT_TB, wave, lane);   // for the tiles below in column j and the back-substitution (in flight
+        ct_store_acc(acc2, sC, CT_LD, wave, lane);     // while the update below runs)
+      }
+      __syncthreads();
+      if (wave < 3) ct_gemm_nt(acc, sC, sC, wave, lane, -1.0);
+      if (tid >= 192 && tid < 192 + CT_TB) {
+        const int r = tid - 192;
+        const double* yk = C.y + CT_TB * (j - 1);
+        double s = 0;
+        for (int m = 0; m < CT_TB; ++m) s += sC[r * CT_LD + m] * yk[m];
+        s_r[r] -= s;
+      }
+      __threadfence();
+      __syncthreads();   // (sC is overwritten next)
+      if (tid == 0) __atomic_store_n(C.flag + ct_tile_index(j, j - 1), 1, __ATOMIC_RELEASE);
+    }
+  }
   if (!s_ok) {
     if (tid == 0) {
       __atomic_store_n(failflag, 1, __ATOMIC_RELEASE);
       __atomic_store_n(C.flag + ct_tile_index(i, j), 1, __ATOMIC_RELEASE);  // let the dependants run out
+      if (merged) __atomic_store_n(C.flag + ct_tile_index(j, j - 1), 1, __ATOMIC_RELEASE);
     }
     return;
   }
   if (diag) {
+    if (C.tl && tid == 0) C.tl[4 * task + 1] = (double)wall_clock64();
     if (wave < 3) ct_store_acc(acc, sC, CT_LD, wave, lane);
     __syncthreads();
-    ct_potrf48(sC, s_dinv, tid, &s_fail);
-    ct_trinv48(sC, s_dinv, sB, s_tm, tid);
-    // publish L_jj (lower, zeros above), Linv_j and y_j = Linv_j r_j
+    ct_potrf_trinv48<CT_NB>(sC, sB, s_dinv, s_tm, tid, &s_fail);
+    if (C.tl && tid == 0) C.tl[4 * task + 2] = (double)wall_clock64();
+    // publish Linv_j and y_j = Linv_j r_j: what the rest of the solve reads (column j's TRSMs, the next diagonal tile, the
+    // back-substitution).  L_jj itself (lower, zeros above) is stored afterwards, off the chain: no task reads it.
     double* Linv = C.Linv + (size_t)j * CT_TILE;
-    for (int e = tid; e < CT_TILE; e += CT_THREADS) {
-      const int r = e / CT_TB, c = e - r * CT_TB;
-      Tij[e] = (c <= r) ? sC[r * CT_LD + c] : 0.0;
-      Linv[e] = sB[r * CT_LD + c];
-    }
+    for (int e = tid; e < CT_TILE; e += CT_THREADS) Linv[e] = sB[(e / CT_TB) * CT_LD + (e % CT_TB)];
     if (tid < CT_TB) {
       double s = 0;
       for (int m = 0; m <= tid; ++m) s += sB[tid * CT_LD + m] * s_r[m];
       C.y[CT_TB * j + tid] = s;
     }
     if (tid == 0 && s_fail) __atomic_store_n(failflag, 1, __ATOMIC_RELEASE);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __atomic_store_n(C.flag + ct_tile_index(i, j), 1, __ATOMIC_RELEASE);
+    if (C.tl && tid == 0) C.tl[4 * task + 3] = (double)wall_clock64();
+    for (int e = tid; e < CT_TILE; e += CT_THREADS) {
+      const int r = e / CT_TB, c = e - r * CT_TB;
+      Tij[e] = (c <= r) ? sC[r * CT_LD + c] : 0.0;
+    }
+    return;
   } else {
     // L_ij = C Linv_j^T
     if (wave < 3) ct_store_acc(acc, sA, CT_LD, wave, lane);
     if (tid == 0 && !ct_wait(C.flag + ct_tile_index(j, j))) s_ok = 0;
+    if (C.tl && tid == 0) C.tl[4 * task + 1] = (double)wall_clock64();
     __syncthreads();
     ct_load_tile(C.Linv + (size_t)j * CT_TILE, sB, tid);
     __syncthreads();
@@ -307,55 +483,14 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
   __threadfence();
   __syncthreads();
   if (tid == 0) __atomic_store_n(C.flag + ct_tile_index(i, j), 1, __ATOMIC_RELEASE);
+  if (C.tl && tid == 0) C.tl[4 * task + 3] = (double)wall_clock64();
 }
-
-// back-substitution L^T x = y by one workgroup (any size): x_j = Linv_j^T (y_j - sum_(i>j) L_ij^T x_i).
-// x (LDS or global, 48 nT doubles) may alias nothing else; scratch needs 48 doubles of LDS.
-__device__ void chol_backsub(const CholTiles& C, double* x, double* scratch, int tid, int nthreads) {
-  const int nT = C.nT;
-  // scratch: [48] t, then [nparts][48] partial sums
-  const int nparts = nthreads / CT_TB;  // work-items (part, component): the rows of the column below are split into parts
-  double* part = scratch + CT_TB;
-  for (int j = nT - 1; j >= 0; --j) {
-    // t = y_j - sum_(i>j) L_ij^T x_i
-    const int nrows = (nT - 1 - j) * CT_TB;  // rows below the diagonal tile
-    if (tid < nparts * CT_TB) {
-      const int p = tid / CT_TB, c = tid - p * CT_TB;
-      double a = 0;
-      for (int rr = p; rr < nrows; rr += nparts) {
-        const int i = j + 1 + rr / CT_TB, r = rr % CT_TB;
-        a += C.T[(size_t)ct_tile_index(i, j) * CT_TILE + r * CT_TB + c] * x[CT_TB * i + r];
-      }
-      part[p * CT_TB + c] = a;
-    }
-    __syncthreads();
-    for (int c = tid; c < CT_TB; c += nthreads) {
-      double s = C.y[CT_TB * j + c];
-      for (int p = 0; p < nparts; ++p) s -= part[p * CT_TB + c];
-      scratch[c] = s;
-    }
-    __syncthreads();
-    const double* Linv = C.Linv + (size_t)j * CT_TILE;
-    for (int c = tid; c < CT_TB; c += nthreads) {
-      double s = 0;
-      for (int r = c; r < CT_TB; ++r) s += Linv[r * CT_TB + c] * scratch[r];
-      x[CT_TB * j + c] = s;
-    }
-    __syncthreads();
-  }
-}
-constexpr int CT_BACKSUB_SCRATCH(int nthreads) { return CT_TB + (nthreads / CT_TB) * CT_TB; }
 
 constexpr int CT_SMEM_DOUBLES = 3 * CT_TB * CT_LD;
 
-// stand-alone solve of one dense SPD system (tests / diagnostics): grid.x = number of lower tiles
+// stand-alone solve of one dense SPD system (tests / diagnostics): grid.x = number of lower tiles + nT
 __global__ __launch_bounds__(CT_THREADS) void chol_tile_kernel(CholTiles C) {
   extern __shared__ __attribute__((aligned(16))) double ct_smem[];
   chol_tile_task(C, blockIdx.x, ct_smem);
 }
-__global__ __launch_bounds__(CT_THREADS) void chol_backsub_kernel(CholTiles C, double* x) {
-  __shared__ double scratch[CT_BACKSUB_SCRATCH(CT_THREADS)];
-  chol_backsub(C, x, scratch, threadIdx.x, CT_THREADS);
-}
-
 }  // namespace ba

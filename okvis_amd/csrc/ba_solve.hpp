@@ -926,6 +926,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       W.ct_d2[i] = i < D ? s_d2[i] : 0.0;
     }
     for (int i = tid; i < ntile + 1; i += SOLVE_THREADS) W.ct_flag[i] = 0;
+    for (int i = tid; i < nT * CT_TB; i += SOLVE_THREADS)
+      reinterpret_cast<unsigned long long*>(W.ct_x)[i] = CT_X_SENTINEL;   // no value yet (chol_backsub_task polls the values)
     __syncthreads();
     if (tid == 0) {
       *gctrl = c;
@@ -1416,7 +1418,7 @@ __global__ __launch_bounds__(CT_THREADS) void chol_tiles_window_kernel(const Win
   extern __shared__ __attribute__((aligned(16))) double ct_smem[];
   const WinPtrs& W = wins[blockIdx.y];
   const int nT = W.ct_nT, ntile = nT * (nT + 1) / 2;
-  if (nT == 0 || (int)blockIdx.x >= ntile) return;
+  if (nT == 0 || (int)blockIdx.x >= ntile + nT) return;
   if (W.ct_flag[ntile + 1] != 1) return;  // nothing to factorise this iteration (terminated / final pass / explicit dogleg step)
   CholTiles C;
   C.nT = nT;
@@ -1425,6 +1427,8 @@ __global__ __launch_bounds__(CT_THREADS) void chol_tiles_window_kernel(const Win
   C.rhs = W.ct_rhs;
   C.y = W.ct_y;
   C.flag = W.ct_flag;
+  C.x = W.ct_x;
+  C.tl = (W.prof && blockIdx.y == 0) ? W.prof + 64 : nullptr;   // diagnostics (debug_arrays): task timeline behind the phase stamps
   chol_tile_task(C, blockIdx.x, ct_smem);
 }
 
@@ -1438,7 +1442,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
   Ctrl* gctrl = W.ctrl;
   __shared__ Ctrl c;
   __shared__ double s_x[CT_TB * ((MAX_D + CT_TB - 1) / CT_TB)];
-  __shared__ double s_scratch[CT_BACKSUB_SCRATCH(SOLVE_THREADS)];
   __shared__ double s_sc[4][SOLVE_THREADS / 64];
   if (tid == 0) c = *gctrl;
   __syncthreads();
@@ -1543,14 +1546,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
     }
     return;
   }
-  CholTiles C;
-  C.nT = nT;
-  C.T = W.ct_T;
-  C.Linv = W.ct_Linv;
-  C.rhs = W.ct_rhs;
-  C.y = W.ct_y;
-  C.flag = W.ct_flag;
-  chol_backsub(C, s_x, s_scratch, tid, SOLVE_THREADS);
+  // the back-substitution ran as the last tasks of the tile kernel (chol_backsub_task)
+  for (int i = tid; i < nT * CT_TB; i += SOLVE_THREADS) s_x[i] = W.ct_x[i];
+  __syncthreads();
   const int D = W.D, acc = c.acc;
   const double lambda = opt.dogleg ? c.mu : 1.0 / c.radius;
   double gd = 0, ddd = 0, s2 = 0, x2 = 0;

@@ -213,6 +213,7 @@ struct WinPtrs {
   double* ct_Linv;        // inverses of the diagonal tiles
   double* ct_rhs;         // [48 nT]
   double* ct_y;           // [48 nT]
+  double* ct_x;           // [48 nT] solution of the tiled solver (sentinel until a value is final, ba_chol_tiles.hpp)
   int* ct_flag;           // [ntiles] done flags, [ntiles] failure, [ntiles + 1] 1 = a system was exported this iteration
   double* ct_g;           // [48 nT] gradient of the accepted linearisation (for the step scalars)
   double* ct_d2;          // [48 nT] damping diagonal
