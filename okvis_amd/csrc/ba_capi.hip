@@ -913,7 +913,8 @@ hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
                        s->d_wins + b.w0, s->d_opt, final_only);
     if (!final_only) {
       const int nT = (s->max_Dpad_large + CT_TB - 1) / CT_TB;
-      hipLaunchKernelGGL(large_export_kernel, dim3(nT * (nT + 1) / 2, (unsigned)b.nw), dim3(CT_THREADS), 0, b.st, s->d_wins + b.w0);
+      hipLaunchKernelGGL(large_export_kernel, dim3(nT * (nT + 1) / 2, (unsigned)b.nw, CT_TILE / CT_THREADS), dim3(CT_THREADS), 0, b.st,
+                         s->d_wins + b.w0);
       hipLaunchKernelGGL(chol_tiles_window_kernel, dim3(nT * (nT + 1) / 2 + nT, (unsigned)b.nw), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8,
                          b.st, s->d_wins + b.w0);
       hipLaunchKernelGGL(solve_large_tail_kernel, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), 0, b.st, s->d_wins + b.w0, s->d_opt);

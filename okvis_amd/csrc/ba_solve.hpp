@@ -1385,7 +1385,9 @@ __global__ __launch_bounds__(CT_THREADS) void large_export_kernel(const WinPtrs*
   const SLayout LY{Dpad / 6};
   const int nch = W.n_chunk;
   const size_t stride = W.spart_stride;
-  for (int r = threadIdx.x; r < CT_TILE; r += CT_THREADS) {
+  // grid.z slices the tile: one entry per work-item, so the chunk partials of the 28 pose-part tiles are summed by 9 x as many
+  // workgroups (the sums are chains of dependent loads: latency, not bandwidth)
+  for (int r = blockIdx.z * CT_THREADS + threadIdx.x; r < CT_TILE; r += gridDim.z * CT_THREADS) {
     int gi = CT_TB * ti + r / CT_TB, gj = CT_TB * tj + r % CT_TB;
     const int oi = gi, oj = gj;
     double v;
@@ -1400,6 +1402,7 @@ __global__ __launch_bounds__(CT_THREADS) void large_export_kernel(const WinPtrs*
         const int bi = gi / 6, bj = gj / 6;
         const size_t o = (size_t)(bi * (bi + 1) / 2 + bj) * 36 + (gi - 6 * bi) * 6 + (gj - 6 * bj);
         double a = 0;
+#pragma unroll 8
         for (int ch = 0; ch < nch; ++ch) a += W.spart[(size_t)ch * stride + o];
         v += a;
       }
