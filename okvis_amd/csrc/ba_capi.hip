@@ -703,10 +703,10 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(imu_coloff, put(A, imu_coloff));
   {
     // destination of every entry of the IMU factors' H (30x30 lower, packed) | g records in the solve kernel's
-    // LDS layout (SLayout, ba_solve.hpp), so that the kernel can prefetch value + destination in one round trip
+    // matrix layout (SLayout, ba_solve.hpp), so that the kernel can prefetch value + destination in one round trip
     std::vector<int4> imu_asm;
-    if (D <= MAX_D_LDS) {
-      const int nbk = (D + 5) / 6;
+    {
+      const int nbk = (D + 5) / 6;   // (the HBM matrix of the large windows has the same block layout)
       auto at = [&](int i, int j) {
         const int bi = i / 6, bj = j / 6;
         return (bj * nbk - (bj * (bj - 1)) / 2 + (bi - bj)) * SBS + (i - 6 * bi) * 6 + (j - 6 * bj);
@@ -766,7 +766,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(ct_rhs, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_y, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_x, put_zero(A, 8 * nT * CT_TB));
-    OFF(ct_flag, put_zero(A, sizeof(int) * (ntile + 2)));
+    OFF(ct_flag, put_zero(A, sizeof(int) * (ntile + 3)));
     OFF(ct_g, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_d2, put_zero(A, 8 * nT * CT_TB));
   }

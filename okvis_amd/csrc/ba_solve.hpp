@@ -16,6 +16,7 @@
 //
 // This is the only kernel that writes the window's Ctrl record.
 #pragma once
+#include <climits>
 #include "ba_chol_tiles.hpp"
 #include "ba_device.hpp"
 
@@ -123,31 +124,61 @@ constexpr int PRI_STAGE = 2;  // pose / speed-bias priors whose records the solv
 // (block layout LY), g and d2.  (The reprojection part U_pp / U_pe / g_p arrives inside the Schur partials.)
 __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, double* S, double* g, double* d2,
                               int* coloff, const unsigned short* ptab, int tid, int nthreads, bool skip_imu,
-                              const double* pri = nullptr, const int* pricol = nullptr, int n_pri = 0) {
+                              const double* pri = nullptr, const int* pricol = nullptr, int n_pri = 0,
+                              bool first_colour_stores = false) {
   // pri / pricol: LDS copies of the first n_pri (<= PRI_STAGE) pose priors [f][42], speed/bias priors r [f][9] and
   // sqrtInfo [f][81] of buffer `acc` and their reduced column offsets [f][6] | [f][9], staged by the caller
   // ---- IMU factors: precomputed H (30x30 lower) | g (30); factors of one colour touch disjoint blocks ----
-  for (int col = 0; col < (skip_imu ? 0 : W.n_imu_color); ++col) {
-    const int fb = W.imu_color_begin[col], fe = W.imu_color_begin[col + 1];
-    for (int wi = tid; wi < (fe - fb) * 512; wi += nthreads) {
-      const int f = W.imu_order[fb + (wi >> 9)], e = wi & 511;
-      if (e >= 495) continue;
-      const double* L = W.imu_lin[acc] + (size_t)f * IMU_LIN_STRIDE;
-      const int* co = W.imu_coloff + 30 * f;
-      const double v = L[e];
-      if (e < 465) {
-        const int a = ptab[e] >> 8, b = ptab[e] & 255;   // same lower-triangular enumeration
-        const int ra = co[a], rb = co[b];
-        if (ra < 0 || rb < 0) continue;
-        if (ra >= rb) S[LY.at(ra, rb)] += v; else S[LY.at(rb, ra)] += v;
-        if (a == b) d2[ra] += v;
-      } else {
-        const int ra = co[e - 465];
-        if (ra >= 0) g[ra] += v;
+  // Destination (host-built imu_asm) and value of up to NE entries per work-item are requested together, then applied colour
+  // by colour (the destinations of one colour are disjoint, so nothing orders them and their read-modify-writes are batched).
+  // `first_colour_stores`: S is known to be zero and the IMU factors are its first writers (large windows, matrix in HBM):
+  // the first colour stores instead of adding.
+  static_assert(IMU_LIN_STRIDE == 512, "imu_asm and the factor records share the index");
+  {
+    const int items = skip_imu ? 0 : W.n_imu * 512;
+    constexpr int NE = 6;
+    const double* src = W.imu_lin[acc];
+    for (int col = 0; col < (skip_imu ? 0 : W.n_imu_color); ++col) {   // colour by colour: ALL of one colour before the next
+      const bool store = first_colour_stores && col == 0;
+      for (int base = tid; base < items; base += NE * nthreads) {
+        double v[NE], old[NE];
+        int dst[NE], d2i[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+          const int idx = base + u * nthreads;
+          dst[u] = -1;
+          d2i[u] = -1;
+          v[u] = 0;
+          if (idx < items) {
+            const int4 d = W.imu_asm[idx];
+            if (d.x >= 0 && (d.x >> 24) == col) {
+              dst[u] = d.x;
+              d2i[u] = d.y;
+            }
+            v[u] = (idx & 511) < 495 ? src[idx] : 0.0;
+          }
+        }
+        if (!store) {
+#pragma unroll
+          for (int u = 0; u < NE; ++u) old[u] = (dst[u] >= 0 && !(dst[u] & (1 << 20))) ? S[dst[u] & 0xFFFFF] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+          const int d = dst[u];
+          if (d < 0) continue;
+          const int off = d & 0xFFFFF;
+          if (d & (1 << 20)) {
+            g[off] += v[u];
+          } else {
+            S[off] = store ? v[u] : old[u] + v[u];
+            if (d2i[u] >= 0) d2[d2i[u]] += v[u];
+          }
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
+  if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[58] = (double)clock64();   // diagnostics: end of the IMU part
   // ---- pose priors: J 6x6 | r 6 ----
   for (int f = 0; f < W.n_pprior; ++f) {
     if (f < n_pri) {
@@ -593,7 +624,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       s_ptab[wi] = (unsigned short)((bi << 8) | (wi - bi * (bi + 1) / 2));
     }
     if constexpr (LARGE) {
-      for (int i = tid - 64; i < nS; i += SOLVE_THREADS - 64) S[i] = 0.0;
+      // the HBM matrix is normally left zero by large_export_kernel, which clears every entry it reads (the flag behind the
+      // mode word says so; set by solve_large_tail_kernel, dropped below as soon as this launch starts to assemble)
+      if (W.ct_flag[W.ct_nT * (W.ct_nT + 1) / 2 + 2] == 0)
+        for (int i = tid - 64; i < nS; i += SOLVE_THREADS - 64) S[i] = 0.0;
     } else {
       // The Schur partials do not depend on this kernel's decision (the Schur kernel made the same one and
       // reduced the buffer that is being accepted): sum them into S while wave 0 decides.  Pose blocks come
@@ -669,6 +703,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     return;
   }
   const int acc = c.acc;
+  if (LARGE && tid == 0) W.ct_flag[W.ct_nT * (W.ct_nT + 1) / 2 + 2] = 0;   // S is being written from here on
 
   STAMP(1);
   // ------------------------------------------------------------------ 2. assembly
@@ -728,7 +763,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       __syncthreads();
     }
   }
-  assemble_base(W, acc, LY, S, s_g, s_d2, s_coloff, s_ptab, tid, SOLVE_THREADS, imu_fast, s_pri, s_pricol, n_pri);
+  assemble_base(W, acc, LY, S, s_g, s_d2, s_coloff, s_ptab, tid, SOLVE_THREADS, imu_fast, s_pri, s_pricol, n_pri, LARGE);
   __syncthreads();
   STAMP(5);
   // ------------------------------------------------------------------ 3. convergence of the accepted step
@@ -1391,13 +1426,17 @@ __global__ __launch_bounds__(CT_THREADS) void large_export_kernel(const WinPtrs*
     int gi = CT_TB * ti + r / CT_TB, gj = CT_TB * tj + r % CT_TB;
     const int oi = gi, oj = gj;
     double v;
-    if (gi < Dpad && gj < Dpad) {
-      if (gi < gj) {
+    if (ti == tj && oi < oj && !W.S) {
+      v = 0.0;   // upper triangle of a diagonal tile: never referenced by the factorisation
+    } else if (gi < Dpad && gj < Dpad) {
+      const bool owner = gi >= gj;   // the work-item that visits the lower-triangle entry itself (not its mirror image)
+      if (!owner) {
         const int tmp = gi;
         gi = gj;
         gj = tmp;
       }
-      v = W.Sg[LY.at(gi, gj)];
+      const int at = LY.at(gi, gj);
+      v = W.Sg[at];
       if (gi < Dp) {  // both indices in the pose part: add the chunk partials (block-packed, row-major lower blocks)
         const int bi = gi / 6, bj = gj / 6;
         const size_t o = (size_t)(bi * (bi + 1) / 2 + bj) * 36 + (gi - 6 * bi) * 6 + (gj - 6 * bj);
@@ -1405,6 +1444,12 @@ __global__ __launch_bounds__(CT_THREADS) void large_export_kernel(const WinPtrs*
 #pragma unroll 8
         for (int ch = 0; ch < nch; ++ch) a += W.spart[(size_t)ch * stride + o];
         v += a;
+      }
+      if (owner && !W.S) {
+        // leave the matrix zero for the next assembly (solve_kernel<true> then skips its own clearing pass); inside a
+        // diagonal 6x6 block the mirrored entry as well.  (Not with the debug copy on: there the mirror images are read too.)
+        W.Sg[at] = 0.0;
+        if (gi / 6 == gj / 6 && gi != gj) W.Sg[LY.at(gj, gi)] = 0.0;
       }
     } else {
       v = (gi == gj) ? 1.0 : 0.0;
@@ -1441,6 +1486,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
   const int nT = W.ct_nT, ntile = nT * (nT + 1) / 2;
   if (nT == 0 || W.ct_flag[ntile + 1] == 0) return;
   const int tid = threadIdx.x;
+  if (tid == 0) W.ct_flag[ntile + 2] = W.S ? 0 : 1;   // the export of this iteration left the HBM matrix cleared (see there)
   const OptD opt = *optp;
   Ctrl* gctrl = W.ctrl;
   __shared__ Ctrl c;

@@ -214,7 +214,8 @@ struct WinPtrs {
   double* ct_rhs;         // [48 nT]
   double* ct_y;           // [48 nT]
   double* ct_x;           // [48 nT] solution of the tiled solver (sentinel until a value is final, ba_chol_tiles.hpp)
-  int* ct_flag;           // [ntiles] done flags, [ntiles] failure, [ntiles + 1] 1 = a system was exported this iteration
+  int* ct_flag;           // [ntiles] done flags, [ntiles] failure, [ntiles + 1] 1 = a system was exported this iteration,
+                          // [ntiles + 2] 1 = the HBM matrix Sg is all zero (cleared by the export)
   double* ct_g;           // [48 nT] gradient of the accepted linearisation (for the step scalars)
   double* ct_d2;          // [48 nT] damping diagonal
   double* rhs;            // [D]

@@ -12,3 +12,4 @@ names = {1: "decision + schur-partial sums", 2: "-", 5: "imu + priors + marg ass
 prev = 0
 for k in (1, 2, 5, 6):
     print(f"  {names[k]:32s} {(p[k] - p[prev]) / 2100:8.2f} us"); prev = k
+print(f"  of the assembly: IMU factors {(p[58] - p[2]) / 2100:.2f} us, priors and the rest {(p[5] - p[58]) / 2100:.2f} us")
