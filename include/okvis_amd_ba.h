@@ -189,9 +189,9 @@ typedef struct okvis_ba_options {
                                    1/(1+sqrt(diag J^T J)) of the FIRST linearisation of the optimize() call;
                                    dogleg strategy only                                                          */
   int32_t max_consecutive_invalid_steps; /* 5 (Ceres max_num_consecutive_invalid_steps): then termination 5     */
-  int32_t reserved0;            /* 0.  Bit 0 = experimental: eliminate the speed/bias blocks of the LDS solve by
-                                   independence levels before the dense factorisation (same result to rounding;
-                                   measured no faster than the dense order)                       */
+  int32_t reserved0;            /* 0 = auto.  The LDS solve can eliminate the speed/bias blocks by independence
+                                   levels before the dense factorisation (same result to rounding):
+                                   auto = below 16 windows; bit 0 forces it on, bit 1 forces it off               */
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */

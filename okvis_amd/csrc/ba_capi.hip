@@ -134,7 +134,7 @@ namespace {
 
 size_t solve_smem(int Dpad, bool large, int sbl_blocks, int sbl_stage, int sbl_tab);
 
-OptD make_optd(const okvis_ba_options& o) {
+OptD make_optd(const okvis_ba_options& o, int n_windows) {
   OptD d;
   d.initial_radius = o.initial_radius;
   d.max_radius = o.max_radius;
@@ -150,7 +150,10 @@ OptD make_optd(const okvis_ba_options& o) {
   d.dogleg = o.strategy == OKVIS_BA_STRATEGY_DOGLEG;
   d.jacobi_scaling = o.jacobi_scaling != 0;
   d.max_invalid = o.max_consecutive_invalid_steps > 0 ? o.max_consecutive_invalid_steps : 5;
-  d.no_sb_levels = !(o.reserved0 & 1);   // experimental: bit 0 of reserved0 switches the level-scheduled speed/bias elimination on
+  // level-scheduled elimination of the speed/bias blocks in the LDS solve: -6 us per solve for one window, but its 30 KB of
+  // extra LDS keep other kernels' workgroups off the CU, which costs more than it saves once the device is shared by many
+  // windows (64 windows: 213 vs 201 us per step).  Auto: on below 16 windows; reserved0 bit 0 forces it on, bit 1 off.
+  d.no_sb_levels = (o.reserved0 & 2) ? 1 : (o.reserved0 & 1) ? 0 : (n_windows >= 16);
   return d;
 }
 
@@ -1125,7 +1128,7 @@ int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt) {
   if (opt->fp32_linearize != s->opt.fp32_linearize) destroy_graphs(s);  // captured graphs name the other kernel
   s->opt = *opt;
   HIP_TRY(hipSetDevice(s->device));
-  OptD d = make_optd(s->opt);
+  OptD d = make_optd(s->opt, (int)s->wins.size());
   HIP_TRY(hipMemcpyAsync(s->d_opt, &d, sizeof(d), hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return OKVIS_BA_OK;
@@ -1207,7 +1210,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     const size_t wb = sizeof(WinPtrs) * (size_t)n_windows;
     s->stage_small.resize(wb + sizeof(OptD));
     std::memcpy(s->stage_small.data(), ptrs.data(), wb);
-    const OptD d = make_optd(s->opt);
+    const OptD d = make_optd(s->opt, n_windows);
     std::memcpy(s->stage_small.data() + wb, &d, sizeof(d));
     HIP_TRY(hipMemcpyAsync(s->d_wins, s->stage_small.data(), wb, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->d_opt, s->stage_small.data() + wb, sizeof(OptD), hipMemcpyHostToDevice, s->stream));
@@ -1868,7 +1871,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   const WinPtrs* d_win = reinterpret_cast<const WinPtrs*>(d + o_win);
 
   // ---- linearise + landmark elimination + export ----
-  OptD od = make_optd(s->opt);
+  OptD od = make_optd(s->opt, (int)s->wins.size());
   od.marg_mode = 1;
   od.dogleg = 0;   // no trust region in the marginalisation pass: one linearisation, no damping
   HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
@@ -1901,7 +1904,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   hipLaunchKernelGGL(marg_dense_kernel, dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES * 8, s->stream, d_win, 0, ma,
                      MARG_LDS_DOUBLES);
   HIP_TRY(hipGetLastError());
-  od = make_optd(s->opt);
+  od = make_optd(s->opt, (int)s->wins.size());
   HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
   // H | J | b0 | e0 are contiguous on the device: one copy into page-locked staging (+ the info record), one sync
   int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -5,7 +5,7 @@ from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
 opt = default_options(); opt.gauss_newton = 1; opt.function_tolerance = 0; opt.gradient_tolerance = 0; opt.parameter_tolerance = 0; opt.use_graph = 0; opt.debug_arrays = 2
 NW = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-opt.reserved0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # 1 = level-scheduled speed/bias elimination on (experimental)   # stamps are taken by window 0; NW > 1 shows them under load
+opt.reserved0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # reserved0: 1 = level-scheduled speed/bias elimination forced on, 2 = forced off, 0 = auto   # stamps are taken by window 0; NW > 1 shows them under load
 b = solver.WindowBatch([synthetic.config_A(seed=20240923 + i) for i in range(NW)], options=opt)
 b.begin(); b.iterate(12); b.synchronize()
 p = b.array("PROF")

@@ -152,9 +152,9 @@ def test_repeated_landmark_pose_camera_observations(oracle):
 
 @pytest.mark.parametrize("maker", ["config_A", "small_ext", "small_marg"])
 def test_speed_bias_blocks_eliminated_by_levels(oracle, maker):
-    # options.reserved0 bit 0 (experimental): the free speed/bias blocks of the LDS solve are eliminated by independence
-    # levels before the dense factorisation of the pose part.  Same system, other elimination order: the result must agree
-    # with the oracle (and therefore with the dense order) to rounding.
+    # the free speed/bias blocks of the LDS solve are eliminated by independence levels before the dense factorisation of the
+    # pose part (automatic below 16 windows; options.reserved0 bit 0 forces it on, bit 1 off).  Same system, other
+    # elimination order: both orders must agree with the oracle to rounding.
     if maker == "config_A":
         w = synthetic.config_A(seed=77)
     elif maker == "small_ext":
@@ -175,5 +175,6 @@ def test_speed_bias_blocks_eliminated_by_levels(oracle, maker):
         lin[2, :7] = synthetic.pose_oplus(w.pose[1], rng.normal(0, 0.02, 6))
         lin[3] = w.sb[2] + rng.normal(0, 0.01, 9)
         w.marg_lin = lin
-    _compare(oracle, w, 6, tol=1e-6, reserved0=1)
-    _compare(oracle, w, 6, tol=1e-6, reserved0=1, strategy=1)   # Levenberg-Marquardt damping
+    for force in (1, 2):
+        _compare(oracle, w, 6, tol=1e-6, reserved0=force)
+        _compare(oracle, w, 6, tol=1e-6, reserved0=force, strategy=1)   # Levenberg-Marquardt damping
