@@ -1652,6 +1652,23 @@ __global__ void add_budget_kernel(const WinPtrs* __restrict__ wins, int n) {
   if (threadIdx.x == 0) wins[blockIdx.x].ctrl->max_iter += n;
 }
 
+// the results of one window in one contiguous record for okvis_ba_fetch_results: pose[7 n_pose] | sb[9 n_sb] | lm[4 n_lm] |
+// quality[n_lm] | reference bias of every IMU factor [9 n_imu]
+__global__ void pack_results_kernel(const WinPtrs* __restrict__ win, int acc) {
+  const WinPtrs& W = *win;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  double* out = W.results;
+  for (int i = t; i < 7 * W.n_pose; i += nt) out[i] = W.pose[acc][i];
+  out += 7 * (size_t)W.n_pose;
+  for (int i = t; i < 9 * W.n_sb; i += nt) out[i] = W.sb[acc][i];
+  out += 9 * (size_t)W.n_sb;
+  for (int i = t; i < 4 * W.n_lm; i += nt) out[i] = W.lm[acc][i];
+  out += 4 * (size_t)W.n_lm;
+  for (int i = t; i < W.n_lm; i += nt) out[i] = W.quality[i];
+  out += W.n_lm;
+  for (int i = t; i < 9 * W.n_imu; i += nt) out[i] = W.imu_cache[i / 9].sb_ref[i % 9];
+}
+
 // landmark quality (Estimator.cpp:880-896): 3x3 eigenvalues of the un-robustified H_l of the accepted
 // linearisation; quality = 0 if lambda_min < 1e-12 else sqrt(lambda_min)/sqrt(lambda_max).
 __global__ void quality_kernel(const WinPtrs* __restrict__ wins) {

@@ -226,6 +226,7 @@ struct WinPtrs {
   double* Dp2;            // [D]
   double* Hpp;            // [D][D] undamped U (debug/parity), optional
   double* quality;        // [n_lm]
+  double* results;        // [7 n_pose + 9 n_sb + 4 n_lm + n_lm + 9 n_imu] packed by pack_results_kernel for okvis_ba_fetch_results
   double* prof;           // [64] clock64() phase stamps of workgroup 0 (diagnostics)
   Ctrl* ctrl;
 

@@ -393,6 +393,7 @@ ReplayResult replay(const Recording& rec, const ReplayOptions& opt, Estimator& e
     const auto a = clk::now();
     est.optimize((size_t)opt.numIterations, (size_t)opt.numThreads, false);
     const auto b = clk::now();
+    const std::array<double, 4> optT = est.lastOptimizeTimings();
     MapPointVector removed;
     est.applyMarginalizationStrategy((size_t)opt.numKeyframes, (size_t)opt.numImuFrames, removed);
     const auto c = clk::now();
@@ -411,6 +412,7 @@ ReplayResult replay(const Recording& rec, const ReplayOptions& opt, Estimator& e
     r.finalCost = est.summary().final_cost;
     r.msOptimize = ms(a, b);
     r.msMarginalize = ms(b, c);
+    r.msFlatten = optT[0], r.msUpload = optT[1], r.msIterations = optT[2], r.msDownload = optT[3];
     out.frames.push_back(r);
   }
 

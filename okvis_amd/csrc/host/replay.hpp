@@ -90,6 +90,7 @@ struct ReplayFrameResult {
   SpeedAndBias speedAndBias;
   int observations, landmarksInWindow, framesInWindow, iterations;
   double initialCost, finalCost, msOptimize, msMarginalize;
+  double msFlatten, msUpload, msIterations, msDownload;   // split of msOptimize (Estimator::lastOptimizeTimings)
 };
 struct ReplayResult {
   std::vector<ReplayFrameResult> frames;

@@ -38,10 +38,11 @@ int main(int argc, char** argv) {
                 rec.observations.size(), rec.landmarks.size());
     okvis_amd::Estimator estimator(0);
     const okvis_amd::ReplayResult r = okvis_amd::replay(rec, opt, estimator);
-    double mo = 0, mm = 0;
+    double mo = 0, mm = 0, t4[4] = {0, 0, 0, 0};
     for (size_t k = 0; k < r.frames.size(); ++k) {
       const okvis_amd::ReplayFrameResult& f = r.frames[k];
       mo += f.msOptimize, mm += f.msMarginalize;
+      t4[0] += f.msFlatten, t4[1] += f.msUpload, t4[2] += f.msIterations, t4[3] += f.msDownload;
       if (k % 20 == 0)
         std::printf("frame %4zu  window %d frames / %d landmarks / %d new observations  cost %.4g -> %.4g (%d it)  %.2f + %.2f ms\n", k,
                     f.framesInWindow, f.landmarksInWindow, f.observations, f.initialCost, f.finalCost, f.iterations, f.msOptimize,
@@ -50,6 +51,8 @@ int main(int argc, char** argv) {
     const double n = r.frames.empty() ? 1.0 : (double)r.frames.size();
     std::printf("Finished: %zu frames, %zu landmarks marginalised or dropped, optimize %.3f ms + marginalise %.3f ms per frame\n",
                 r.frames.size(), r.landmarksRemoved, mo / n, mm / n);
+    std::printf("optimize split per frame: flatten %.3f + upload %.3f + iterations %.3f + download %.3f ms\n", t4[0] / n, t4[1] / n, t4[2] / n,
+                t4[3] / n);
     if (r.hasGroundTruth)
       std::printf("against the ground truth (first pose aligned): rms position %.4f m, final position %.4f m, final rotation %.5f rad\n",
                   r.rmsPosition, r.finalPosition, r.finalRotation);
