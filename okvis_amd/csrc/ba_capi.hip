@@ -183,7 +183,7 @@ std::vector<T> vec(const T* p, size_t n) {
 
 #define OFF(field, off) P.field = reinterpret_cast<std::remove_reference<decltype(P.field)>::type>(off)
 
-int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A, HostWin& H) {
+int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A, HostWin& H, int n_windows_total = 1) {
   if (w.n_pose < 0 || w.n_sb < 0 || w.n_lm < 0 || w.n_obs < 0 || w.n_imu < 0 || w.n_cam < 0) return OKVIS_BA_ERR_ARG;
   if ((w.n_pose && (!w.pose || !w.pose_fixed)) || (w.n_sb && (!w.sb || !w.sb_fixed)) || (w.n_lm && !w.lm))
     return OKVIS_BA_ERR_ARG;
@@ -372,7 +372,10 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   // ---- chunks (Schur workgroups) ----
   std::vector<Chunk> chunks;
   {
-    const int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : 48, SCHUR_CHUNK_LM_MAX);
+    // landmarks per Schur workgroup: 48 (three staged batches of 16) keeps the workgroup count low when many windows share
+    // the device; a few windows have the device to themselves and finish sooner with 32 (measured, tests/gpu_chunk_diag.py:
+    // one window 114.7 vs 119.7 us per iteration, 64 windows 239 vs 217)
+    const int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : (n_windows_total < 16 ? 32 : 48), SCHUR_CHUNK_LM_MAX);
     int g = 0;
     while (g < ngroup) {
       Chunk C;
@@ -1156,7 +1159,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   const bool dbg_t = std::getenv("OKVIS_BA_DEBUG_UPLOAD") != nullptr;
   const auto t_u0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n_windows; ++i) {
-    int rc = build_window(windows[i], s->opt, A, wins[i]);
+    int rc = build_window(windows[i], s->opt, A, wins[i], n_windows);
     if (rc != OKVIS_BA_OK) return rc;
   }
   const auto t_u1 = std::chrono::steady_clock::now();
