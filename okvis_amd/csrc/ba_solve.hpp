@@ -1318,32 +1318,38 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       const int b0 = hd[0], nb = hd[1];
       const int* ent = s_tab + hd[2];
       for (int bb = tid >> 6; bb < nb; bb += SOLVE_THREADS / 64) {   // one wave per block
-        const int lane = tid & 63;
+        // lane = 16 part + a: component a (< 9) of t = sum_R Y_R^T x_R over the rows r = part (mod 4) of every coupled
+        // row-block; the four parts are combined with two cross-row shuffles.  What the substitution needs of L (column `lane`
+        // below the diagonal, 1 / diagonal) is requested before the sums, so the chain afterwards runs on registers.
+        const int lane = tid & 63, a = lane & 15, part = lane >> 4;
         const int o = s_tab[b0 + bb];
         const int e0 = s_tab[hd[3] + bb], e1 = s_tab[hd[3] + bb + 1];
-        double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int it = lane; it < (e1 - e0) * 9; it += 64) {
-          const int e = it / 9, r = it - e * 9;
-          const int en = ent[e0 + e];
-          if (r >= ((en >> 8) & 15)) continue;
-          const double xi = s_x[(en & 255) + r];
-          const double* st = s_stage + 9 * ((en >> 16) + r);
-#pragma unroll
-          for (int a = 0; a < 9; ++a) t[a] += st[a] * xi;
-        }
-        double res = 0;
-#pragma unroll
-        for (int a = 0; a < 9; ++a) {
-          const double ta = wave_sum_full(t[a]);
-          if (lane == a) res = s_rhs[o + a] - ta;
-        }
         const double* L9 = s_L9 + 54 * (b0 + bb);
+        double Lc[9], di = 0, res = 0;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) Lc[m] = (lane < 9 && m > lane) ? L9[m * (m + 1) / 2 + lane] : 0.0;
+        if (lane < 9) {
+          di = L9[45 + lane];
+          res = s_rhs[o + lane];
+        }
+        double t = 0;
+        if (a < 9)
+          for (int e = e0; e < e1; ++e) {
+            const int en = ent[e];
+            const int n = (en >> 8) & 15;
+            const double* st = s_stage + 9 * (en >> 16) + a;
+            const double* xr = s_x + (en & 255);
+            for (int r = part; r < n; r += 4) t += st[9 * r] * xr[r];
+          }
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        res -= t;   // (lanes 0..8: their own component)
         double xres = 0;
 #pragma unroll
-        for (int a = 8; a >= 0; --a) {   // L^T x = res: lane a finishes x_a, the lanes above take it out
-          const double xa = readlane_f64(res, a) * L9[45 + a];
-          if (lane == a) xres = xa;
-          if (lane < a) res -= L9[a * (a + 1) / 2 + lane] * xa;
+        for (int m = 8; m >= 0; --m) {   // L^T x = res: lane m finishes x_m, the lanes above take it out
+          const double xm = readlane_f64(res, m) * readlane_f64(di, m);
+          if (lane == m) xres = xm;
+          if (lane < m) res -= Lc[m] * xm;
         }
         if (lane < 9) s_x[o + lane] = xres;
       }
