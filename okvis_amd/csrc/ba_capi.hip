@@ -733,6 +733,23 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     }
     if (imu_asm.empty()) imu_asm.push_back(make_int4(-1, -1, 0, 0));
     OFF(imu_asm, put(A, imu_asm));
+    // large windows: the reverse map, so that the tile export (many workgroups) gathers the IMU contributions instead of one
+    // workgroup scattering them into HBM.  At most two factors meet in one entry (the chain couples consecutive states).
+    std::vector<int2> imu_rev;
+    if (D > MAX_D_LDS) {
+      const size_t nbk = (D + 5) / 6;
+      imu_rev.assign(nbk * (nbk + 1) / 2 * SBS, make_int2(-1, -1));
+      for (size_t idx = 0; idx < 512 * (size_t)w.n_imu; ++idx) {
+        const int4 d = imu_asm[idx];
+        if (d.x < 0 || (d.x & (1 << 20))) continue;   // nothing / an entry of g
+        int2& r = imu_rev[d.x & 0xFFFFF];
+        if (r.x < 0) r.x = (int)idx;
+        else if (r.y < 0) r.y = (int)idx;
+        else return OKVIS_BA_ERR_UNSUPPORTED;   // three IMU factors on one block: not a chain
+      }
+    }
+    if (imu_rev.empty()) imu_rev.push_back(make_int2(-1, -1));
+    OFF(imu_rev, put(A, imu_rev));
   }
   P.sbe_nlev = sbe_nlev;
   P.sbe_nblk = sbe_nblk;

@@ -125,21 +125,34 @@ constexpr int PRI_STAGE = 2;  // pose / speed-bias priors whose records the solv
 __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, double* S, double* g, double* d2,
                               int* coloff, const unsigned short* ptab, int tid, int nthreads, bool skip_imu,
                               const double* pri = nullptr, const int* pricol = nullptr, int n_pri = 0,
-                              bool first_colour_stores = false) {
+                              bool imu_matrix_elsewhere = false) {
   // pri / pricol: LDS copies of the first n_pri (<= PRI_STAGE) pose priors [f][42], speed/bias priors r [f][9] and
   // sqrtInfo [f][81] of buffer `acc` and their reduced column offsets [f][6] | [f][9], staged by the caller
   // ---- IMU factors: precomputed H (30x30 lower) | g (30); factors of one colour touch disjoint blocks ----
   // Destination (host-built imu_asm) and value of up to NE entries per work-item are requested together, then applied colour
   // by colour (the destinations of one colour are disjoint, so nothing orders them and their read-modify-writes are batched).
-  // `first_colour_stores`: S is known to be zero and the IMU factors are its first writers (large windows, matrix in HBM):
-  // the first colour stores instead of adding.
+  // `imu_matrix_elsewhere` (large windows, matrix in HBM): only the gradient and the diagonal (for the damping) are taken
+  // here; the matrix entries are gathered by large_export_kernel through imu_rev, by many workgroups instead of this one.
   static_assert(IMU_LIN_STRIDE == 512, "imu_asm and the factor records share the index");
   {
     const int items = skip_imu ? 0 : W.n_imu * 512;
     constexpr int NE = 6;
     const double* src = W.imu_lin[acc];
     for (int col = 0; col < (skip_imu ? 0 : W.n_imu_color); ++col) {   // colour by colour: ALL of one colour before the next
-      const bool store = first_colour_stores && col == 0;
+      if (imu_matrix_elsewhere) {
+        // only the 30 diagonal entries (for the damping diagonal) and the 30 gradient entries of every record
+        for (int it = tid; it < W.n_imu * 60; it += nthreads) {
+          const int f = it / 60, k = it - 60 * f;
+          const int e = k < 30 ? k * (k + 3) / 2 : 465 + (k - 30);   // diagonal entry (k, k) of the packed lower triangle | g_k
+          const int4 d = W.imu_asm[512 * f + e];
+          if (d.x < 0 || (d.x >> 24) != col) continue;
+          const double v = src[512 * f + e];
+          if (d.x & (1 << 20)) g[d.x & 0xFFFFF] += v;
+          else if (d.y >= 0) d2[d.y] += v;
+        }
+        __syncthreads();
+        continue;
+      }
       for (int base = tid; base < items; base += NE * nthreads) {
         double v[NE], old[NE];
         int dst[NE], d2i[NE];
@@ -158,10 +171,8 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, doubl
             v[u] = (idx & 511) < 495 ? src[idx] : 0.0;
           }
         }
-        if (!store) {
 #pragma unroll
-          for (int u = 0; u < NE; ++u) old[u] = (dst[u] >= 0 && !(dst[u] & (1 << 20))) ? S[dst[u] & 0xFFFFF] : 0.0;
-        }
+        for (int u = 0; u < NE; ++u) old[u] = (dst[u] >= 0 && !(dst[u] & (1 << 20))) ? S[dst[u] & 0xFFFFF] : 0.0;
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
           const int d = dst[u];
@@ -170,7 +181,7 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, doubl
           if (d & (1 << 20)) {
             g[off] += v[u];
           } else {
-            S[off] = store ? v[u] : old[u] + v[u];
+            S[off] = old[u] + v[u];
             if (d2i[u] >= 0) d2[d2i[u]] += v[u];
           }
         }
@@ -1443,6 +1454,12 @@ __global__ __launch_bounds__(CT_THREADS) void large_export_kernel(const WinPtrs*
       }
       const int at = LY.at(gi, gj);
       v = W.Sg[at];
+      {   // IMU factors (at most two per entry): gathered here from the accepted buffer's records
+        const int2 sr = W.imu_rev[at];
+        const double* lin = W.imu_lin[W.ctrl->acc];
+        if (sr.x >= 0) v += lin[sr.x];
+        if (sr.y >= 0) v += lin[sr.y];
+      }
       if (gi < Dp) {  // both indices in the pose part: add the chunk partials (block-packed, row-major lower blocks)
         const int bi = gi / 6, bj = gj / 6;
         const size_t o = (size_t)(bi * (bi + 1) / 2 + bj) * 36 + (gi - 6 * bi) * 6 + (gj - 6 * bj);

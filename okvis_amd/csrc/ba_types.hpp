@@ -185,6 +185,8 @@ struct WinPtrs {
   // level schedule of the speed/bias blocks for the LDS solve (ba_solve.hpp; layout documented where build_window makes it)
   // (the counts sbe_nlev / sbe_nblk / sbe_ntab sit with the other sizes: this region must hold pointers only, see relocate())
   const int* sbe_tab;
+  const int2* imu_rev;           // large windows (matrix in HBM): per entry of the block-packed matrix the (up to two) IMU record
+                                 // entries f * 512 + e that land there, or -1: gathered by large_export_kernel
   const int4* imu_asm;           // [n_imu][512] where entry e of factor f's H|g record lands in the solve kernel's LDS
                                  // system: x = offset | is_g << 20 | colour << 24 (or -1), y = d2 index or -1 (D <= MAX_D_LDS)
 
