@@ -229,3 +229,150 @@ def error_computation(H, b0):
     J = (p[:, None] * Q * np.sqrt(S)).T
     e0 = -(np.sqrt(Sp)[:, None] * Q.T / p) @ b0
     return J, e0, int((lam > tol).sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Third statement of the trust-region policy the reference configures (Estimator.cpp:854-873: TRUST_REGION, DOGLEG with
+# Ceres 1.9 defaults: traditional dogleg, Jacobi scaling) - numpy, dense, on the FULL normal equations (no Schur complement),
+# written from the description of Ceres 1.9's TrustRegionMinimizer / DoglegStrategy, not from the oracle's code.  It drives
+# any object with  cost() -> float,  full_system() -> (H, b0 = -gradient, [(type, index)] with 0 pose / 1 speed-bias /
+# 2 landmark in column order),  get_state() / set_state(pose, sb, lm);  tests/test_dogleg_policy.py hands it the reference's
+# own factors (tests/ref_lib.RefWindow).
+def _oplus_blocks(state, blocks, delta):
+    pose, sb, lm = (a.copy() for a in state)
+    o = 0
+    for typ, idx in blocks:
+        if typ == 0:
+            d = delta[o:o + 6]
+            dq_v = d[3:]                      # quaternion increment of the reference: dq = (sinc(|da|/2) da/2, cos(|da|/2))
+            n = np.linalg.norm(dq_v)
+            half = 0.5 * n
+            s = 0.5 if n < 1e-12 else np.sin(half) / n
+            dq = np.r_[s * dq_v, np.cos(half)]
+            pose[idx, :3] += d[:3]
+            q = _qmul(dq, pose[idx, 3:])
+            pose[idx, 3:] = q / np.linalg.norm(q)
+            o += 6
+        elif typ == 1:
+            sb[idx] += delta[o:o + 9]
+            o += 9
+        else:
+            lm[idx, :3] += delta[o:o + 3]
+            o += 3
+    return pose, sb, lm
+
+
+def _ambient(state, blocks):
+    pose, sb, lm = state
+    return np.concatenate([pose[i] if t == 0 else sb[i] if t == 1 else lm[i] for t, i in blocks])
+
+
+def dogleg_minimize(win, max_iter, initial_radius=1e4, jacobi_scaling=True, function_tolerance=1e-6, gradient_tolerance=1e-10,
+                    parameter_tolerance=1e-8, min_relative_decrease=1e-3, max_invalid=5, min_radius=1e-32, max_radius=1e16):
+    """returns dict(iterations, successful_steps, termination, final_cost, initial_cost, final_radius)
+    termination: 0 iteration limit, 1 function tolerance, 2 gradient tolerance, 3 parameter tolerance, 4 radius, 5 invalid steps"""
+    MIN_DIAG, MAX_DIAG, MIN_MU, MAX_MU, MU_UP = 1e-6, 1e32, 1e-8, 1.0, 10.0
+    x = win.get_state()
+    cost = win.cost()
+    H, b0, blocks = win.full_system()
+    g = -b0
+    n = g.size
+    scale = 1.0 / (1.0 + np.sqrt(np.maximum(np.diag(H), 0.0))) if jacobi_scaling else np.ones(n)
+    out = dict(initial_cost=cost, iterations=0, successful_steps=0, termination=0)
+
+    def gradient_max_norm(x, g, blocks):
+        xm = _oplus_blocks(x, blocks, -g)
+        return np.abs(_ambient(x, blocks) - _ambient(xm, blocks)).max()
+
+    radius, mu, reuse, invalid = float(initial_radius), MIN_MU, False, 0
+    if gradient_max_norm(x, g, blocks) <= gradient_tolerance:
+        out.update(termination=2, final_cost=cost, final_radius=radius)
+        return out
+    gn = cauchy_alpha = ghat = d = None
+    while out["iterations"] < max_iter:
+        out["iterations"] += 1
+        Ht = H * np.outer(scale, scale)          # J S
+        gt = g * scale
+        ok = True
+        if not reuse:
+            d = np.sqrt(np.clip(np.diag(Ht), MIN_DIAG, MAX_DIAG))
+            ghat = gt / d                        # gradient in the diagonally scaled space
+            v = ghat / d
+            cauchy_alpha = (ghat @ ghat) / (v @ Ht @ v)
+            gn = None
+            while True:                          # Gauss-Newton point with a little regularisation mu D^2, raised on failure
+                try:
+                    L = np.linalg.cholesky(Ht + mu * np.diag(d * d))
+                    sol = np.linalg.solve(L.T, np.linalg.solve(L, gt))
+                    if np.all(np.isfinite(sol)):
+                        gn = -sol * d
+                        break
+                except np.linalg.LinAlgError:
+                    pass
+                mu *= MU_UP
+                if mu > MAX_MU:
+                    break
+            ok = gn is not None
+        if ok:
+            gn_norm, g_norm = np.linalg.norm(gn), np.linalg.norm(ghat)
+            if gn_norm <= radius:
+                dl, dl_norm = gn, gn_norm
+            elif cauchy_alpha * g_norm >= radius:
+                dl, dl_norm = -(radius / g_norm) * ghat, radius
+            else:
+                b_dot_a = -cauchy_alpha * (ghat @ gn)
+                a2 = (cauchy_alpha * g_norm) ** 2
+                bma2 = a2 - 2.0 * b_dot_a + gn_norm ** 2
+                c = b_dot_a - a2
+                dd = np.sqrt(c * c + bma2 * (radius ** 2 - a2))
+                beta = (dd - c) / bma2 if c <= 0 else (radius ** 2 - a2) / (dd + c)
+                dl, dl_norm = (-cauchy_alpha * (1.0 - beta)) * ghat + beta * gn, radius
+            step_t = dl / d                      # Jacobi-scaled variables
+            model_change = -(gt @ step_t + 0.5 * step_t @ Ht @ step_t)
+            ok = np.all(np.isfinite(step_t)) and model_change > 0.0
+        if not ok:                               # DoglegStrategy::StepIsInvalid: mu goes up, nothing is re-used, the radius stays
+            invalid += 1
+            if invalid >= max_invalid:
+                out["termination"] = 5
+                break
+            mu *= MU_UP
+            reuse = False
+            continue
+        invalid = 0
+        delta = step_t * scale
+        x_new = _oplus_blocks(x, blocks, delta)
+        xa, xb = _ambient(x, blocks), _ambient(x_new, blocks)
+        if np.linalg.norm(xb - xa) <= parameter_tolerance * (np.linalg.norm(xa) + parameter_tolerance):
+            out["termination"] = 3
+            break
+        win.set_state(*x_new)
+        new_cost = win.cost()
+        change = cost - new_cost
+        if abs(change) < function_tolerance * cost:      # Ceres <= 1.10: returns WITHOUT taking the step
+            win.set_state(*x)
+            out["termination"] = 1
+            break
+        rho = change / model_change
+        if rho > min_relative_decrease:
+            x, cost = x_new, new_cost
+            out["successful_steps"] += 1
+            H, b0, blocks = win.full_system()
+            g = -b0
+            if rho < 0.25:
+                radius *= 0.5
+            if rho > 0.75:
+                radius = min(max_radius, max(radius, 3.0 * dl_norm))
+            mu = max(MIN_MU, 2.0 * mu / MU_UP)
+            reuse = False
+            if gradient_max_norm(x, g, blocks) <= gradient_tolerance:
+                out["termination"] = 2
+                break
+        else:
+            win.set_state(*x)
+            radius *= 0.5
+            reuse = True
+        if radius < min_radius:
+            out["termination"] = 4
+            break
+    out.update(final_cost=cost, final_radius=radius)
+    return out

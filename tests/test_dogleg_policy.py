@@ -101,3 +101,37 @@ def test_dogleg_config_A_costs(oracle):
     so, sr, xo, xr = _both(oracle, w, 5, opt)
     assert abs(so["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"]
     assert so["iterations"] == sr["iterations"] and so["successful_steps"] == sr["successful_steps"]
+
+
+@pytest.mark.parametrize("case", range(len(G.SMALL)))
+@pytest.mark.parametrize("radius", [1e4, 30.0, 1.0])
+def test_numpy_statement_of_the_policy(oracle, case, radius):
+    """Third statement: the policy in numpy on the full dense normal equations (tests/golden/independent.py::dogleg_minimize,
+    written from the description of Ceres 1.9's minimiser), fed by the REFERENCE's own factors through RefWindow
+    (cost / full_system / set_state).  It has to agree with the oracle (Schur complement, C++) and with the ceres-shim."""
+    import independent as I
+    w = synthetic.small_window(**G.SMALL[case])
+    opt = default_options(STRATEGY_DOGLEG)
+    opt.initial_radius = radius
+    so = oracle.OracleWindow(w).optimize(10, opt)
+    r = R.RefWindow(w)
+    sn = I.dogleg_minimize(r, 10, initial_radius=radius)
+    assert abs(sn["final_cost"] - so["final_cost"]) <= 1e-8 * so["final_cost"], (sn, so)
+    assert (sn["iterations"], sn["successful_steps"], sn["termination"]) == (so["iterations"], so["successful_steps"], so["termination"]), (sn, so)
+    assert abs(sn["final_radius"] - so["final_radius"]) <= 1e-5 * so["final_radius"]
+    assert abs(sn["initial_cost"] - so["initial_cost"]) <= 1e-12 * so["initial_cost"]
+
+
+def test_numpy_statement_with_rejected_steps(oracle):
+    import independent as I
+    found = False
+    for seed in (41, 42, 43, 44):
+        w = synthetic.small_window(seed=seed, K=5, L=60, pose_noise=(0.4, np.deg2rad(6.0)), landmark_noise=0.8)
+        opt = default_options(STRATEGY_DOGLEG)
+        opt.function_tolerance = opt.gradient_tolerance = opt.parameter_tolerance = 0.0
+        so = oracle.OracleWindow(w).optimize(20, opt)
+        sn = I.dogleg_minimize(R.RefWindow(w), 20, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+        found = found or sn["successful_steps"] < sn["iterations"]
+        assert (sn["iterations"], sn["successful_steps"]) == (so["iterations"], so["successful_steps"]), (sn, so)
+        assert abs(sn["final_cost"] - so["final_cost"]) <= 1e-6 * so["final_cost"]
+    assert found
