@@ -183,7 +183,31 @@ std::vector<T> vec(const T* p, size_t n) {
 
 #define OFF(field, off) P.field = reinterpret_cast<std::remove_reference<decltype(P.field)>::type>(off)
 
+// diagnostics: OKVIS_BA_DEBUG_BUILD=1 accumulates the host time of build_window's sections and prints them at exit
+struct BuildTimes {
+  bool on = std::getenv("OKVIS_BA_DEBUG_BUILD") != nullptr;
+  std::map<std::string, double> ms;
+  long calls = 0;
+  ~BuildTimes() {
+    if (!on || !calls) return;
+    std::fprintf(stderr, "build_window: %ld calls, mean ms per section:", calls);
+    for (const auto& kv : ms) std::fprintf(stderr, "  %s %.4f", kv.first.c_str(), kv.second / calls);
+    std::fprintf(stderr, "\n");
+  }
+};
+BuildTimes g_build_times;
+
 int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A, HostWin& H, int n_windows_total = 1) {
+  auto bw_t0 = std::chrono::steady_clock::now();
+  if (g_build_times.on) g_build_times.calls++;
+#define BW_T(name)                                                                                       \
+  do {                                                                                                   \
+    if (g_build_times.on) {                                                                              \
+      const auto t_ = std::chrono::steady_clock::now();                                                  \
+      g_build_times.ms[name] += std::chrono::duration<double, std::milli>(t_ - bw_t0).count();           \
+      bw_t0 = t_;                                                                                        \
+    }                                                                                                    \
+  } while (0)
   if (w.n_pose < 0 || w.n_sb < 0 || w.n_lm < 0 || w.n_obs < 0 || w.n_imu < 0 || w.n_cam < 0) return OKVIS_BA_ERR_ARG;
   if ((w.n_pose && (!w.pose || !w.pose_fixed)) || (w.n_sb && (!w.sb || !w.sb_fixed)) || (w.n_lm && !w.lm))
     return OKVIS_BA_ERR_ARG;
@@ -233,6 +257,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (lm_obs_begin[l + 1] > GROUP_OBS) return OKVIS_BA_ERR_UNSUPPORTED;
     lm_obs_begin[l + 1] += lm_obs_begin[l];
   }
+  BW_T("validate");
   // ---- (landmark, free block) pairs ----
   std::vector<int> pair_lm, pair_block, pair_off, pair_role, lm_pair_begin(nlm + 1, 0);
   for (int l = 0; l < nlm; ++l) {
@@ -255,6 +280,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   }
   lm_pair_begin[nlm] = (int)pair_lm.size();
   const int npair = (int)pair_lm.size();
+  BW_T("pairs");
   // ---- groups ----
   std::vector<Group> groups;
   {
@@ -281,6 +307,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     }
   }
   const int ngroup = (int)groups.size();
+  BW_T("groups");
   // ---- per-pair observation lists, per-group tasks ----
   std::vector<int> pair_list_begin(npair + 1, 0);
   std::vector<uint16_t> pair_list;
@@ -369,6 +396,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     G.tlist_end = (int)task_list.size();
   }
   pair_list_begin[npair] = (int)pair_list.size();
+  BW_T("lists+tasks");
   // ---- chunks (Schur workgroups) ----
   std::vector<Chunk> chunks;
   {
@@ -416,6 +444,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   }
   chunk_diag_begin[(size_t)nchunk * npose_blk_c] = (int)chunk_diag_out.size();
   chunk_cross_begin[nchunk] = (int)chunk_cross.size() / 3;
+  BW_T("chunks");
   // ---- greedy colouring of the IMU factors: factors of one colour share no parameter block ----
   std::vector<int> imu_color(w.n_imu, 0);
   int n_imu_color = 0;
@@ -448,6 +477,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     for (int b = 0; b < 4; ++b)
       for (int k = 0; k < dims[b]; ++k) imu_coloff[30 * (size_t)f + start[b] + k] = offs[b] < 0 ? -1 : offs[b] + k;
   }
+  BW_T("imu colouring");
   // ---- level schedule of the free speed/bias blocks for the LDS solve: blocks that share no factor (ImuError couples
   //      sb_k - sb_k+1, the marginalisation prior all the blocks it contains) can be eliminated at the same time; taking
   //      a block out couples its remaining neighbours pairwise (fill), which the next levels respect ----
@@ -604,6 +634,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   const int npose_blk = Dp / 6;
   const int spart_stride = npose_blk * (npose_blk + 1) / 2 * 36 + 3 * Dp;
   const int ntile = std::max(1, (Dp / 6 + SCHUR_TILE_BLOCKS - 1) / SCHUR_TILE_BLOCKS);
+  BW_T("sb levels");
   // ---- observation records ----
   std::vector<ObsRec> recs(nobs);
   for (int o = 0; o < nobs; ++o) {
@@ -625,6 +656,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // ImuError::redoPreintegration returns -1 when the samples do not cover [t0,t1] (ImuError.cpp:87-89)
     if (!(w.imu_s_t[w.imu_s_begin[f] + w.imu_s_count[f] - 1] >= w.imu_t1[f])) return OKVIS_BA_ERR_ARG;
   }
+  BW_T("obs records + imu");
   // ---- marginalisation prior: H0 = J^T J ----
   const int Dm = w.marg_dim;
   if (Dm < 0 || Dm > MAX_MARG_DIM) return OKVIS_BA_ERR_UNSUPPORTED;
@@ -665,6 +697,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.imu.sigma_gw_c = w.imu_params.sigma_gw_c; P.imu.sigma_aw_c = w.imu_params.sigma_aw_c;
   P.imu.g = w.imu_params.g; P.imu.g_max = w.imu_params.g_max; P.imu.a_max = w.imu_params.a_max;
 
+  BW_T("prior + sizes");
   // ---- arena: state ----
   auto poses = vec(w.pose, 7 * (size_t)npose);
   auto sbs = vec(w.sb, 9 * (size_t)nsb);
@@ -860,6 +893,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   H.pair_lm = pair_lm;
   H.pair_block = pair_block;
   H.acc = 0;
+  BW_T("arena");
   // ---- algorithmic (compulsory) bytes per iteration, DESIGN.md §4 ----
   const int64_t O = nobs, L = nlm, Pn = npair;
   H.bytes_lin = 32 * O + 56 * (int64_t)npose + 32 * L + 8 * (int64_t)D + 72 * L + 144 * Pn  // reads
