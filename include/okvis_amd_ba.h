@@ -180,7 +180,7 @@ typedef struct okvis_ba_options {
                                    at initial_radius (no trust-region logic); used by bench.py so that
                                    every timed iteration performs identical, full work                   */
   int32_t n_streams;            /* sub-batches of windows on separate HIP streams (phases of different
-                                   windows overlap); 0 = auto (3 for >= 48 windows, 2 for >= 16, else 1)  */
+                                   windows overlap); 0 = auto (3 for >= 56 windows, 2 for >= 16, else 1)  */
   int32_t fp32_linearize;       /* BASELINE configs[4] (mixed-precision study): 1 = reprojection residuals, Jacobians
                                    and their J^T J / J^T r accumulation in fp32; state, Schur complement and the
                                    reduced solve stay fp64.  0 (default) = everything fp64 like the reference   */
@@ -191,7 +191,7 @@ typedef struct okvis_ba_options {
   int32_t max_consecutive_invalid_steps; /* 5 (Ceres max_num_consecutive_invalid_steps): then termination 5     */
   int32_t reserved0;            /* 0 = auto.  The LDS solve can eliminate the speed/bias blocks by independence
                                    levels before the dense factorisation (same result to rounding):
-                                   auto = below 16 windows; bit 0 forces it on, bit 1 forces it off               */
+                                   auto = below 40 windows; bit 0 forces it on, bit 1 forces it off               */
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */

@@ -134,6 +134,8 @@ namespace {
 
 size_t solve_smem(int Dpad, bool large, int sbl_blocks, int sbl_stage, int sbl_tab);
 
+constexpr int SMALL_BATCH_WINDOWS = 40;   // below: the device is not full - settings that shorten one window's chain win
+
 OptD make_optd(const okvis_ba_options& o, int n_windows) {
   OptD d;
   d.initial_radius = o.initial_radius;
@@ -152,8 +154,10 @@ OptD make_optd(const okvis_ba_options& o, int n_windows) {
   d.max_invalid = o.max_consecutive_invalid_steps > 0 ? o.max_consecutive_invalid_steps : 5;
   // level-scheduled elimination of the speed/bias blocks in the LDS solve: -6 us per solve for one window, but its 30 KB of
   // extra LDS keep other kernels' workgroups off the CU, which costs more than it saves once the device is shared by many
-  // windows (64 windows: 213 vs 201 us per step).  Auto: on below 16 windows; reserved0 bit 0 forces it on, bit 1 off.
-  d.no_sb_levels = (o.reserved0 & 2) ? 1 : (o.reserved0 & 1) ? 0 : (n_windows >= 16);
+  // windows (64 windows: 213 vs 201 us per step).  Auto: on below
+  // SMALL_BATCH_WINDOWS (tests/gpu_auto_rules.py: best up to 32 windows, dense order from 48); reserved0 bit 0 forces it on,
+  // bit 1 off.
+  d.no_sb_levels = (o.reserved0 & 2) ? 1 : (o.reserved0 & 1) ? 0 : (n_windows >= SMALL_BATCH_WINDOWS);
   return d;
 }
 
@@ -403,7 +407,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // landmarks per Schur workgroup: 48 (three staged batches of 16) keeps the workgroup count low when many windows share
     // the device; a few windows have the device to themselves and finish sooner with 32 (measured, tests/gpu_chunk_diag.py:
     // one window 114.7 vs 119.7 us per iteration, 64 windows 239 vs 217)
-    const int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : (n_windows_total < 16 ? 32 : 48), SCHUR_CHUNK_LM_MAX);
+    const int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : (n_windows_total < SMALL_BATCH_WINDOWS ? 32 : 48), SCHUR_CHUNK_LM_MAX);
     int g = 0;
     while (g < ngroup) {
       Chunk C;
@@ -1283,7 +1287,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     // measured on MI355X / ROCm 7.2 (profiles/r01_notes.md): branches inside ONE captured graph are not
     // overlapped, but two independently replayed graphs on two streams are (+29 % at 64 windows); more
     // than two streams lose again
-    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 48 ? 3 : (n_windows >= 16 ? 2 : 1));
+    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 56 ? 3 : (n_windows >= 16 ? 2 : 1));   // (48 windows: 2 is better)
     nsub = std::max(1, std::min(nsub, n_windows));
     s->sub_begin.assign(nsub + 1, 0);
     for (int k = 0; k <= nsub; ++k) s->sub_begin[k] = (int)((int64_t)n_windows * k / nsub);
