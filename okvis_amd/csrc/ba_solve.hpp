@@ -310,29 +310,9 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, doubl
 // through landmarks: the reduced matrix is [pose-pose dense | banded pose-sb | block-tridiagonal sb-sb].  Instead of
 // walking through them as part of 25 sequential 6x6 block columns, blocks that are mutually uncoupled (host-built levels:
 // for an IMU chain of n states ceil(log2 n) of them, e.g. {0,2,4,6,8} {1,5,9} {3} {7}) are factorised at the same time by
-// different waves and eliminated with one symmetric update; the dense blocked Cholesky then only sees the pose part.
-// Storage stays in place: the eliminated block's column (Y = C L^-T) overwrites the entries it was computed from.
+// different work-items and eliminated with one symmetric update; the dense blocked Cholesky then only sees the pose part.
+// The rows Y = C L^-T of every level stay in an LDS stage for the recovery after the dense back-substitution.
 __device__ __forceinline__ int sym_at(const SLayout& LY, int i, int j) { return i >= j ? LY.at(i, j) : LY.at(j, i); }
-
-// Cholesky of a 9x9 SPD block by ONE wave: lane r < 9 keeps row r of the lower triangle in registers, the pivot column
-// travels through v_readlane.  Lrow[j] (j <= r) = L[r][j]; returns false on a non-positive pivot.  All 64 lanes must call.
-__device__ __forceinline__ bool chol9_wave(double (&Lrow)[9], int lane) {
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const double d = readlane_f64(Lrow[k], k);          // L[k][k] before the square root (lane k holds row k)
-    ok = ok && (d > 0.0);
-    const double inv = rsqrt_nr(d > 0.0 ? d : 1.0);
-    if (lane == k) Lrow[k] = d * inv;
-    if (lane > k) Lrow[k] *= inv;
-#pragma unroll
-    for (int j = k + 1; j < 9; ++j) {
-      const double ljk = readlane_f64(Lrow[k], j);      // L[j][k]
-      if (lane >= j) Lrow[j] -= Lrow[k] * ljk;
-    }
-  }
-  return ok;
-}
 
 // trial poses / speed-biases  x (+) delta  of buffer 1-acc (PoseLocalParameterization::plus, PoseLocalParameterization.cpp:60-87).
 // Adds |x|^2 over the free blocks to *x2 and, when `ambient`, |x - x(+)delta|^2 to *s2.
