@@ -178,3 +178,69 @@ def test_speed_bias_blocks_eliminated_by_levels(oracle, maker):
     for force in (1, 2):
         _compare(oracle, w, 6, tol=1e-6, reserved0=force)
         _compare(oracle, w, 6, tol=1e-6, reserved0=force, strategy=1)   # Levenberg-Marquardt damping
+
+
+def _random_structure(seed):
+    """a window whose speed/bias coupling graph is NOT the plain chain: IMU factors removed at random (the chain breaks),
+    speed/bias blocks fixed at random, and a dense prior over a random subset of pose and speed/bias blocks (which couples
+    everything it contains pairwise) - what the host-side level schedule has to analyse symbolically"""
+    rng = np.random.default_rng(7000 + seed)
+    K = int(rng.integers(3, 10))
+    w = synthetic.make_window(K, int(rng.integers(20, 90)), float(rng.uniform(0.5, 1.0)), seed=7100 + seed,
+                              estimate_extrinsics=["fixed", "shared"][int(rng.integers(0, 2))])
+    n_imu = w.n_imu
+    if n_imu > 1 and rng.random() < 0.6:            # drop up to a third of the IMU factors
+        keep = np.sort(rng.choice(n_imu, size=max(1, n_imu - int(rng.integers(1, max(2, n_imu // 3 + 1)))), replace=False))
+        for name in ("imu_pose0", "imu_sb0", "imu_pose1", "imu_sb1", "imu_t0", "imu_t1", "imu_s_begin", "imu_s_count"):
+            setattr(w, name, np.asarray(getattr(w, name))[keep])
+    if rng.random() < 0.5:                          # fix one or two speed/bias blocks
+        fx = rng.choice(K, size=int(rng.integers(1, 3)), replace=False)
+        w.sb_fixed = np.asarray(w.sb_fixed).copy()
+        w.sb_fixed[fx] = 1
+    if rng.random() < 0.7:                          # dense prior over 2 .. 5 blocks, at least one speed/bias block
+        nb = int(rng.integers(2, 6))
+        types = [1] + [int(rng.integers(0, 2)) for _ in range(nb - 1)]
+        used, bt, bi = set(), [], []
+        for t in types:
+            i = int(rng.integers(0, K))
+            if (t, i) in used or (t == 1 and w.sb_fixed[i]) or (t == 0 and w.pose_fixed[i]):
+                continue
+            used.add((t, i)); bt.append(t); bi.append(i)
+        if bt:
+            dims = [6 if t == 0 else 9 for t in bt]
+            Dm = sum(dims)
+            w.marg_J = np.triu(rng.standard_normal((Dm, Dm))) * 2.0 + 3.0 * np.eye(Dm)
+            w.marg_e0 = rng.standard_normal(Dm) * 0.05
+            w.marg_block_type = np.array(bt, np.int32)
+            w.marg_block_idx = np.array(bi, np.int32)
+            w.marg_block_off = np.concatenate([[0], np.cumsum(dims)[:-1]]).astype(np.int32)
+            lin = np.zeros((len(bt), 9))
+            for k, (t, i) in enumerate(zip(bt, bi)):
+                if t == 0:
+                    lin[k, :7] = synthetic.pose_oplus(w.pose[i], rng.normal(0, 0.01, 6))
+                else:
+                    lin[k] = w.sb[i] + rng.normal(0, 0.005, 9)
+            w.marg_lin = lin
+    return w
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_level_schedule_on_random_coupling_graphs(oracle, seed):
+    """level-scheduled elimination forced on against the dense order forced off and against the oracle, on windows with broken
+    IMU chains, fixed speed/bias blocks and dense priors over random block subsets"""
+    w = _random_structure(seed)
+    res = {}
+    for force in (1, 2):
+        b = _batch([w], reserved0=force, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+        s = b.optimize(4)[0]
+        res[force] = (s, b.get_state())
+        b.close()
+    (s1, x1), (s2, x2) = res[1], res[2]
+    assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-7 * s2["final_cost"], (s1, s2)
+    assert (s1["iterations"], s1["successful_steps"]) == (s2["iterations"], s2["successful_steps"])
+    for a, c in zip(x1, x2):
+        assert np.abs(a - c).max() < 1e-5
+    op = default_options()
+    op.function_tolerance = op.gradient_tolerance = op.parameter_tolerance = 0.0
+    sr = oracle.OracleWindow(w).optimize(4, op)
+    assert abs(s1["final_cost"] - sr["final_cost"]) <= 1e-6 * sr["final_cost"], (s1, sr)
