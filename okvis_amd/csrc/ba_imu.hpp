@@ -686,6 +686,7 @@ __device__ void imu_maybe_redo(const WinPtrs& W, int f, int trial, double* lds, 
 
 __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int tid) {
   __shared__ double s_db[6];
+  if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[62] = (double)clock64();   // diagnostics: length of one IMU workgroup
   imu_maybe_redo(W, f, trial, lds, tid);  // rarely taken; updates the HBM cache in place
   __syncthreads();
   double* ca = lds + EvalLds::CA;
@@ -877,6 +878,7 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
     double s = 0;
     for (int i = 0; i < 15; ++i) s += s_r[i] * s_r[i];
     out[IMU_COST] = 0.5 * s;
+    if (W.prof && f == 0 && blockIdx.y == 0) W.prof[63] = (double)clock64();
   }
 }
 

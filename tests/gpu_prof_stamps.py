@@ -34,3 +34,4 @@ print("linearise phases of group 0 (thread 0):")
 for k in range(41, 50):
     d = p[k] - p[k - 1]; print(f"  {ln[k]:36s} {d:10.0f} cyc {d/2100:8.2f} us")
 print("  total", (p[49] - p[40]) / 2100, "us")
+print("one IMU workgroup (factor 0, no re-preintegration):", (p[63] - p[62]) / 2100, "us")
