@@ -631,8 +631,12 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
     // update landmarks: quality = sqrt(lambda_min)/sqrt(lambda_max) of the un-robustified H_l and the
     // estimate (Estimator.cpp:880-900)
     std::lock_guard<std::mutex> l(statesMutex_);
-    for (size_t i = 0; i < nl; ++i) {
-      MapPoint& mp = landmarksMap_.at(sel.landmarks[i]);
+    // sel.landmarks was filled by walking landmarksMap_ (selectAll): same order, so the map is walked again instead of
+    // nl lookups (nothing was inserted or erased in between: optimize() runs under the caller's estimator mutex)
+    auto it = landmarksMap_.begin();
+    for (size_t i = 0; i < nl; ++i, ++it) {
+      if (it == landmarksMap_.end() || it->first != sel.landmarks[i]) it = landmarksMap_.find(sel.landmarks[i]);
+      MapPoint& mp = it->second;
       mp.quality = q[i];
       std::copy(lm.begin() + 4 * i, lm.begin() + 4 * i + 4, mp.point.begin());
     }
