@@ -264,23 +264,32 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   BW_T("validate");
   // ---- (landmark, free block) pairs ----
   std::vector<int> pair_lm, pair_block, pair_off, pair_role, lm_pair_begin(nlm + 1, 0);
-  for (int l = 0; l < nlm; ++l) {
-    std::vector<int> blocks;
-    for (int o = lm_obs_begin[l]; o < lm_obs_begin[l + 1]; ++o) {
-      const int cand[2] = {w.obs_pose[o], w.obs_ext[o]};
-      for (int c = 0; c < 2; ++c)
-        if (pose_off[cand[c]] >= 0 && std::find(blocks.begin(), blocks.end(), cand[c]) == blocks.end())
-          blocks.push_back(cand[c]);
+  {
+    // (one scratch list and a "seen for this landmark" stamp per block instead of a fresh vector + std::find per landmark:
+    // this loop runs once per frame in the host class)
+    const size_t guess = 2 * (size_t)nobs;
+    pair_lm.reserve(guess), pair_block.reserve(guess), pair_off.reserve(guess), pair_role.reserve(guess);
+    std::vector<int> blocks, seen(npose, -1);
+    for (int l = 0; l < nlm; ++l) {
+      blocks.clear();
+      for (int o = lm_obs_begin[l]; o < lm_obs_begin[l + 1]; ++o) {
+        const int cand[2] = {w.obs_pose[o], w.obs_ext[o]};
+        for (int c = 0; c < 2; ++c)
+          if (pose_off[cand[c]] >= 0 && seen[cand[c]] != l) {
+            seen[cand[c]] = l;
+            blocks.push_back(cand[c]);
+          }
+      }
+      std::sort(blocks.begin(), blocks.end());
+      lm_pair_begin[l] = (int)pair_lm.size();
+      for (int b : blocks) {
+        pair_lm.push_back(l);
+        pair_block.push_back(b);
+        pair_off.push_back(pose_off[b]);
+        pair_role.push_back(role[b]);
+      }
+      if ((int)blocks.size() > GROUP_PAIRS) return OKVIS_BA_ERR_UNSUPPORTED;
     }
-    std::sort(blocks.begin(), blocks.end());
-    lm_pair_begin[l] = (int)pair_lm.size();
-    for (int b : blocks) {
-      pair_lm.push_back(l);
-      pair_block.push_back(b);
-      pair_off.push_back(pose_off[b]);
-      pair_role.push_back(role[b]);
-    }
-    if ((int)blocks.size() > GROUP_PAIRS) return OKVIS_BA_ERR_UNSUPPORTED;
   }
   lm_pair_begin[nlm] = (int)pair_lm.size();
   const int npair = (int)pair_lm.size();
