@@ -1,0 +1,137 @@
+// Micro-benchmark + correctness check of the MFMA LDL^T solver (okvis_amd/csrc/ba_ldl16.hpp) on random SPD systems.
+//   hipcc --offload-arch=gfx950 -O3 -I../../okvis_amd/csrc ldl16.hip -o ldl16 && ./ldl16
+// Prints, per dimension, the relative error against a host Cholesky solve and the clock64 cycles of the phases.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "ba_ldl16.hpp"
+
+constexpr int NW = 16;
+
+__global__ __launch_bounds__(NW * 64) void k_solve(const double* __restrict__ Sg, int D, double* xg, long long* stamps, int* fail,
+                                                     int reps) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int area = ba::ldl16_area_doubles(D);
+  const size_t off = (size_t)blockIdx.x * area;
+  double* S = smem;
+  double* x = smem + area;
+  __shared__ int s_fail;
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int i = threadIdx.x; i < area; i += blockDim.x) S[i] = Sg[off + i];
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    ba::ldl16_solve<NW>(S, D, threadIdx.x, x, &s_fail, (blockIdx.x == 0 && rep == reps - 1) ? stamps : nullptr);
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < D; i += blockDim.x) xg[(size_t)blockIdx.x * 192 + i] = x[i];
+  if (threadIdx.x == 0) fail[blockIdx.x] = s_fail;
+}
+
+static int at_host(int nb, int i, int j) {   // i >= j
+  const int I = j >> 4, J = i >> 4, r = j & 15, c = i & 15;
+  return (I * nb - (I * (I - 1)) / 2 + (J - I)) * 256 + (r >> 2) * 64 + (r & 3) * 16 + c;
+}
+
+int main(int argc, char** argv) {
+  const int dims[] = {150, 162, 174, 175, 160, 144, 90, 31, 16, 15, 6};
+  const int nwg = argc > 1 ? atoi(argv[1]) : 1;
+  for (int D : dims) {
+    const int nb = ba::ldl16_nb(D), area = ba::ldl16_area_doubles(D);
+    std::vector<double> A((size_t)D * D), b(D), G((size_t)D * D);
+    srand(D);
+    for (auto& v : G) v = rand() / (double)RAND_MAX - 0.5;
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) {
+        double s = 0;
+        for (int k = 0; k < D; ++k) s += G[(size_t)i * D + k] * G[(size_t)j * D + k];
+        A[(size_t)i * D + j] = s + (i == j ? 0.05 * D : 0.0);
+      }
+    for (auto& v : b) v = rand() / (double)RAND_MAX - 0.5;
+    std::vector<double> S((size_t)area * nwg, 0.0);
+    for (int w = 0; w < nwg; ++w) {
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j <= i; ++j) S[(size_t)w * area + at_host(nb, i, j)] = A[(size_t)i * D + j];
+      for (int i = 0; i < D; ++i) S[(size_t)w * area + at_host(nb, D, i)] = b[i];
+    }
+    // host Cholesky
+    std::vector<double> L(A), y(b), x(D);
+    for (int k = 0; k < D; ++k) {
+      L[(size_t)k * D + k] = sqrt(L[(size_t)k * D + k]);
+      for (int i = k + 1; i < D; ++i) L[(size_t)i * D + k] /= L[(size_t)k * D + k];
+      for (int j = k + 1; j < D; ++j)
+        for (int i = j; i < D; ++i) L[(size_t)i * D + j] -= L[(size_t)i * D + k] * L[(size_t)j * D + k];
+    }
+    for (int i = 0; i < D; ++i) {
+      double s = y[i];
+      for (int k = 0; k < i; ++k) s -= L[(size_t)i * D + k] * y[k];
+      y[i] = s / L[(size_t)i * D + i];
+    }
+    for (int i = D - 1; i >= 0; --i) {
+      double s = y[i];
+      for (int k = i + 1; k < D; ++k) s -= L[(size_t)k * D + i] * x[k];
+      x[i] = s / L[(size_t)i * D + i];
+    }
+    double *dS, *dx;
+    long long* dst;
+    int* dfail;
+    hipMalloc(&dS, S.size() * 8);
+    hipMalloc(&dx, (size_t)nwg * 192 * 8);
+    hipMalloc(&dst, 128 * 8);
+    hipMalloc(&dfail, nwg * 4);
+    hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice);
+    hipMemset(dst, 0, 128 * 8);
+    const size_t shmem = (size_t)(area + 192) * 8;
+    hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 3);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      printf("D=%d: %s\n", D, hipGetErrorString(e));
+      return 1;
+    }
+    // wall time of 20 back-to-back solves inside one launch
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0);
+    k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 23);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventRecord(e0);
+    k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 3);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms3 = 0;
+    hipEventElapsedTime(&ms3, e0, e1);
+    std::vector<double> xg((size_t)nwg * 192);
+    std::vector<long long> st(128);
+    std::vector<int> fl(nwg);
+    hipMemcpy(xg.data(), dx, xg.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(st.data(), dst, 128 * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(fl.data(), dfail, nwg * 4, hipMemcpyDeviceToHost);
+    double err = 0, nrm = 0;
+    for (int w = 0; w < nwg; ++w)
+      for (int i = 0; i < D; ++i) {
+        err = fmax(err, fabs(xg[(size_t)w * 192 + i] - x[i]));
+        nrm = fmax(nrm, fabs(x[i]));
+      }
+    printf("D=%3d nb=%2d  rel err %.2e  fail %d  | cycles: load %lld  factor %lld  backsub %lld  total %lld | %.2f us per solve (incl. LDS fill)\n",
+           D, nb, err / nrm, fl[0], st[1] - st[0], st[2] - st[1], st[3] - st[2], st[3] - st[0], (ms - ms3) * 1000.0 / 20.0);
+    if (D == 150) {
+      for (int kb = 0; kb < nb; ++kb)
+        printf("   step %2d: eliminate %5lld  ->B1 %5lld  panel->B2 %5lld  diag update+convert %5lld\n", kb,
+               st[16 + 4 * kb] - (kb ? st[19 + 4 * (kb - 1)] : st[1]), st[17 + 4 * kb] - st[16 + 4 * kb], st[18 + 4 * kb] - st[17 + 4 * kb],
+               kb + 1 < nb ? st[19 + 4 * kb] - st[18 + 4 * kb] : 0LL);
+    }
+    hipFree(dS);
+    hipFree(dx);
+    hipFree(dst);
+    hipFree(dfail);
+  }
+  return 0;
+}
