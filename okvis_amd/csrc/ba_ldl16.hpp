@@ -1,29 +1,36 @@
 // Dense solve of the reduced camera system of one window by ONE workgroup on the fp64 matrix core (gfx950):
 // blocked LDL^T with 16-wide panels, the matrix resident in MFMA accumulator registers, forward substitution riding
-// along as one more column, back-substitution from the register-resident factor.
+// along as one more column, back-substitution from the register-resident factor.  No workgroup barrier between the
+// first and the last instruction of the factorisation: the waves hand data to each other through LDS flags.
 //
 // This is the algebra of the reduced-camera solve of SPARSE_SCHUR (Estimator.cpp:854; in-tree analogue
 // MarginalizationError.cpp:617-689): S x = b with S symmetric positive definite, D <= 175.
 //
-// Why this shape (measured in profiles/r02_notes.md: the previous 6-wide right-looking Cholesky in LDS spent 25 block
-// columns x 2.3 us, i.e. barrier + LDS round trips, not flops):
-//   * 16-wide panels: ceil((D+1)/16) <= 11 dependent steps;
-//   * upper-triangular 16x16 blocks, each owned for the whole factorisation by one wave and held in the accumulator
-//     layout of v_mfma_f64_16x16x4_f64 (lane l, register r = element (row (l>>4)+4r, column l&15)).  Feeding the
-//     accumulator registers of U as the A operand and those of V as the B operand of four MFMAs yields U^T V in
+// Why this shape (profiles/r02_notes.md: the previous 6-wide right-looking Cholesky in LDS spent 25 block columns x
+// 2.3 us in barriers and LDS round trips, not in flops):
+//   * 16-wide panels: nb = ceil((D+1)/16) <= 11 dependent steps;
+//   * upper-triangular 16x16 blocks, each owned for the whole factorisation by one of the waves 1..NW-1 and held in the
+//     accumulator layout of v_mfma_f64_16x16x4_f64 (lane l, register r = element (row (l>>4)+4r, column l&15)).  Feeding
+//     the accumulator registers of U as the A operand and those of V as the B operand of four MFMAs yields U^T V in
 //     accumulator layout again, so the trailing update  A_IJ -= R_I^T D^-1 R_J  needs no transposition and the matrix
-//     never returns to LDS; only the current panel row R (one 16 x n strip, plain and scaled by -D^-1) goes through LDS;
-//   * the dependent chain — the 16x16 diagonal block — is carried by wave 0 alone: column per lane, pivot column through
-//     v_readlane, Gauss elimination in LDL^T form (reciprocals, no square roots) on [A | I], so that lanes 16..31 end up
-//     with the unit-lower inverse L^-1 without a single extra instruction; the panel is then a GEMM with that inverse;
-//   * the right-hand side is column D of the matrix (any spare column of the last block): the elimination turns it into
-//     L^-1 b for free, and with x[D] = -1 the back-substitution is one uniform sweep  t_I = -sum_J R_IJ x_J.
+//     never returns to LDS; only the current panel row R_J = L_kk^-1 A_kJ goes through LDS (double buffered);
+//   * the dependent chain — the 16x16 diagonal blocks — is carried by wave 0 alone and never waits at a barrier:
+//     column per lane (16 lanes), pivot column broadcast with DPP row_newbcast, Gauss elimination in LDL^T form
+//     (reciprocals, no square roots) on [A | I], so that the unit-lower inverse L^-1 falls out of the same instruction
+//     stream; wave 0 then forms the next diagonal block privately (R = L^-1 A_k,k+1 and P_k+1 -= R^T D^-1 R, eight
+//     MFMAs on copies handed over by the owners) while the other waves run the panel GEMM with the published inverse
+//     and the trailing update one step behind;
+//   * the right-hand side is column D of the matrix (a spare column of the last block): the elimination turns it into
+//     L^-1 b for free, and with x[D] = -1 the back-substitution is one uniform sweep  t_K = -sum_J R_KJ x_J, whose
+//     critical path (the super-diagonal blocks) again stays inside wave 0.
 //
 // LDS layout of the assembled system (what the caller fills): block (I <= J) at blk(I, J), 256 doubles, element
-// (r, c) of the block at (r>>2)*64 + (r&3)*16 + c  (= accumulator register r>>2... of lane (r&3)*16 + c).  Only entries
+// (r, c) of the block at (r>>2)*64 + (r&3)*16 + c  (= accumulator register r>>2 of lane (r&3)*16 + c).  Only entries
 // with row <= column are referenced (diagonal blocks: upper triangle).  Everything that is not written must be zero.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <climits>
 
 #include "ba_device.hpp"
 
@@ -46,8 +53,12 @@ struct L16 {
   __host__ __device__ static int blocks(int nb) { return nb * (nb + 1) / 2; }
 };
 
+constexpr int LDL_RS = 18;   // stride of the 16-vectors that one lane reads or writes as a whole (conflict-free b128 accesses)
+constexpr int LDL_XB = 16 * LDL_RS;
 // doubles of LDS the solver needs from the start of the assembly buffer (it overwrites the assembled matrix)
-__host__ __device__ inline int ldl16_work_doubles(int nb) { return 3 * nb * 256 + 2 * 256 + 16 * 17 + 3 * nb * 16; }
+__host__ __device__ inline int ldl16_work_doubles(int nb) {
+  return 2 * nb * 256 /* Rp */ + 3 * nb * LDL_XB /* Xs, XB, Rsup */ + 4 * 256 /* qbuf, dpart */ + 2 * nb * 16 /* dinv, xv */;
+}
 __host__ __device__ inline int ldl16_nb(int D) { return (D + 1 + 15) / 16; }
 // size of the matrix area (doubles): the assembled blocks or the work area, whichever is larger
 __host__ __device__ inline int ldl16_area_doubles(int D) {
@@ -63,28 +74,94 @@ __device__ __forceinline__ double rcp_nr(double d) {   // 1/d: hardware estimate
   return y;
 }
 
-// LDL^T elimination of the symmetric 16x16 block held column per lane (lanes 0..15: c(i) = A[i][lane]; lanes 16..31:
-// c(i) = (i == lane - 16), the identity that becomes L^-1; the other lanes idle along).  npiv <= 16 pivots.
-// The column lives in c4[i >> 2][i & 3] (the register slots that hold accumulator blocks on the other waves).
-// dinv_out[k] = 1 / d_k (0 beyond npiv), written by lane 0.  Returns false when a pivot is not positive.
-#define LDL_C(i) c4[(i) >> 2][(i) & 3]
-__device__ __forceinline__ bool ldl16_eliminate(ldl_v4 (&c4)[4], double* dinv_out, int npiv, int lane) {
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    double rd = 0.0;
-    if (k < npiv) {
-      double d = readlane_f64(LDL_C(k), k);
-      ok = ok && (d > 0.0);
-      d = d > 0.0 ? d : 1.0;
-      rd = rcp_nr(d);
-      const double u = -LDL_C(k) * rd;
-#pragma unroll
-      for (int i = k + 1; i < 16; ++i) LDL_C(i) = fma(readlane_f64(LDL_C(i), k), u, LDL_C(i));
-    }
-    if (lane == 0) dinv_out[k] = rd;
+// DPP row_newbcast (gfx90a+): lane K of the caller's row of 16 lanes, as the first source of a 64-bit VALU operation.
+// Written as volatile inline assembly (one instruction per element instead of v_mov_b64_dpp + copy + v_fmac), which the
+// compiler's hazard recogniser does not see through: a VGPR written by a VALU instruction must not be read through DPP by
+// one of the next two instructions.  The callers keep that distance by construction (volatile statements stay in program
+// order) and use the *_nop forms where they cannot.
+template <int K>
+__device__ __forceinline__ void fmac_bcast(double& acc, const double& src, const double& mul) {   // acc += src[lane K] * mul
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void fmac_bcast_nop(double& acc, const double& src, const double& mul) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ double bcast_nop(const double& src) {
+  double d;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(src), "n"(K));
+  return d;
+}
+
+// ---- flags in LDS (workgroup scope): monotone counters written by one wave, polled by others
+__device__ __forceinline__ void ldl_wait_ge(const int* flag, int need) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void ldl_wait_eq(const int* flag, int need) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != need) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// bit l of the result: flags[l] >= need (l < n; the other bits are set).  One LDS round trip for all the flags.
+__device__ __forceinline__ unsigned long long ldl_ready_mask(const int* flags, int n, int need, int lane) {
+  const int v = lane < n ? __hip_atomic_load(&flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : INT_MAX;
+  return __ballot(v >= need);
+}
+// the calling wave's LDS writes become visible before the flag does
+__device__ __forceinline__ void ldl_signal(int* flag, int v, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One elimination step of the 16x16 diagonal block held column per lane, r[i] = entry (i, lane & 15), A and the inverse
+// of its unit-lower factor IN THE SAME REGISTERS: before step K the lanes j >= K hold the columns of the partially
+// eliminated A, the lanes j < K the columns of  Bh = L^-1 D  (L^-1 so far, every column scaled by its pivot; the diagonal
+// entry r[j] of lane j stays d_j).  With m_i = A[i][K] (lane K) and 1/d:
+//   lanes j > K:  A[i][j]  -= m_i A[K][j] / d          (Schur complement)
+//   lanes j < K:  Bh[i][j] -= m_i Bh[K][j] / d         (row operation on the inverse: the same formula, r[K] is Bh[K][j])
+//   lane  j = K:  Bh[i][K]  = -m_i = r[i] + m_i (-2)    (exact: no reciprocal involved)
+// i.e. ONE v_fmac_f64_dpp per row for the factorisation and the inverse together.  What is left above the diagonal of
+// lane j (rows i < j: entries of D L^T) is dead and masked when the block is published.
+// d = r[K] of lane K (already broadcast).  FULL: all 16 pivots exist; otherwise act = (K < npiv) and an inactive step
+// changes nothing.  Lane K keeps 1 / d_K (0 when inactive) in `mine`.  Returns the next pivot, broadcast as soon as its
+// entry is final so that its reciprocal (the dependent chain) overlaps the remaining updates of this step.
+template <int K, bool FULL>
+__device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool act, double& mine, int j) {
+  double rd = rcp_nr(d);
+  if (!FULL) rd = act ? rd : 0.0;
+  const bool me = (j == K);
+  double v = -r[K] * rd;
+  v = me ? ((FULL || act) ? -2.0 : 0.0) : v;
+  mine = me ? rd : mine;
+  double dn = 1.0;
+  if constexpr (K < 15) {
+    fmac_bcast<K>(r[K + 1], r[K + 1], v);
+    dn = bcast_nop<K + 1>(r[K + 1]);
   }
-  return ok;
+#pragma unroll
+  for (int i = K + 2; i < 16; ++i) fmac_bcast<K>(r[i], r[i], v);
+  return dn;
+}
+template <bool FULL>
+__device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, double& mine, int j) {
+  double d = bcast_nop<0>(r[0]);
+  d = ldl16_pivot<0, FULL>(r, d, 0 < npiv, mine, j);
+  d = ldl16_pivot<1, FULL>(r, d, 1 < npiv, mine, j);
+  d = ldl16_pivot<2, FULL>(r, d, 2 < npiv, mine, j);
+  d = ldl16_pivot<3, FULL>(r, d, 3 < npiv, mine, j);
+  d = ldl16_pivot<4, FULL>(r, d, 4 < npiv, mine, j);
+  d = ldl16_pivot<5, FULL>(r, d, 5 < npiv, mine, j);
+  d = ldl16_pivot<6, FULL>(r, d, 6 < npiv, mine, j);
+  d = ldl16_pivot<7, FULL>(r, d, 7 < npiv, mine, j);
+  d = ldl16_pivot<8, FULL>(r, d, 8 < npiv, mine, j);
+  d = ldl16_pivot<9, FULL>(r, d, 9 < npiv, mine, j);
+  d = ldl16_pivot<10, FULL>(r, d, 10 < npiv, mine, j);
+  d = ldl16_pivot<11, FULL>(r, d, 11 < npiv, mine, j);
+  d = ldl16_pivot<12, FULL>(r, d, 12 < npiv, mine, j);
+  d = ldl16_pivot<13, FULL>(r, d, 13 < npiv, mine, j);
+  d = ldl16_pivot<14, FULL>(r, d, 14 < npiv, mine, j);
+  d = ldl16_pivot<15, FULL>(r, d, 15 < npiv, mine, j);
 }
 
 // NW waves (NW * 64 threads), all of which must call.  S: the assembled system (see above) for an nb = ldl16_nb(D)
@@ -93,212 +170,427 @@ __device__ __forceinline__ bool ldl16_eliminate(ldl_v4 (&c4)[4], double* dinv_ou
 // Ends with a barrier: x_out and *s_fail are visible to every thread on return.
 template <int NW>
 __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x_out, int* s_fail, long long* stamps = nullptr) {
-  constexpr int NREG = NW - 1;                                        // waves that own blocks
-  constexpr int SLOTS_ = (LDL_MAX_NB * (LDL_MAX_NB + 1) / 2 + NREG - 1) / NREG;
-  constexpr int SLOTS = SLOTS_ < 4 ? 4 : SLOTS_;   // (wave 0 keeps its 16-entry column in four of them)
+  // Wave 0 carries the diagonal chain at raised priority and wants its SIMD for itself: the waves that share it (4, 8, 12:
+  // waves w, w+4, w+8, w+12 of a workgroup sit on one SIMD, tests/micro/hwid.hip) would be starved exactly when the chain
+  // needs their hand-offs (measured: a flag seen 5500 cycles late), so they own nothing and go straight to the last barrier.
+  static_assert(NW == 16, "wave roles below assume 16 waves");
+  constexpr int NREG = 12;                                            // waves that own blocks: (wave & 3) != 0
+  constexpr int SLOTS = (LDL_MAX_NB * (LDL_MAX_NB + 1) / 2 + NREG - 1) / NREG;
   const int nb = ldl16_nb(D);
   const L16 LY{nb};
   const int nblk = L16::blocks(nb);
   const int npl = D - 16 * (nb - 1);                                  // pivots of the last block (its column npl is the rhs)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int ridx = (wave >> 2) * 3 + (wave & 3) - 1;                  // 0..11 for the block-owning waves
   // work area (aliases the assembled matrix once every block sits in registers)
-  double* Rp = S;                          // [nb][256] panel row R_J of the current step, accumulator layout
-  double* Rn = Rp + nb * 256;              // [nb][256] -D^-1 R_J
-  double* Xs = Rn + nb * 256;              // [nb][256] L_II^-1, element (m, k) at k * 16 + m
-  double* dpart = Xs + nb * 256;           // [2][256] diagonal block I with the updates k <= I - 2, accumulator layout
-  double* conv = dpart + 512;              // [16][17] diagonal block on its way to the column-per-lane layout
-  double* dinv = conv + 16 * 17;           // [nb][16]
-  double* tv = dinv + nb * 16;             // [nb][16] t_I of the back-substitution
-  double* xv = tv + nb * 16;               // [nb][16] solution incl. x[D] = -1
+  double* Rp = S;                          // [2][nb][256] panel row R_J of step kb in buffer kb & 1, accumulator layout
+  double* Xs = Rp + 2 * nb * 256;          // [nb][16][LDL_RS] Bh = L_II^-1 D_I as wave 0 leaves it: column j at j * LDL_RS (rows < j: dead)
+  double* XB = Xs + nb * LDL_XB;           // [nb][16][LDL_RS] D^-1 Bh^T ... for the back-substitution: entry (i, j) of D^-1 Bh D^-1 masked, at j * LDL_RS + i
+  double* Rsup = XB + nb * LDL_XB;         // [nb][16][LDL_RS] wave 0's copies of R_(K,K+1), row-major
+  double* qbuf = Rsup + nb * LDL_XB;       // [2][256] block (I, I+1) with all its updates, accumulator layout
+  double* dpart = qbuf + 512;              // [2][256] diagonal block I with the updates k <= I - 2, accumulator layout
+  double* dinv = dpart + 512;              // [nb][16]
+  double* xv = dinv + nb * 16;             // [nb][16] solution incl. x[D] = -1
+  double* tcon = Rp;                       // [nb][nb][16] back-substitution: R_KJ x_J, one slot per block (the panel rows are dead by then)
+  // flags (outside the matrix area: they are zeroed before the assembled matrix is dead)
+  __shared__ int f_xready;                 // k + 1: Bh_k and 1/d_k published
+  // [m & 1] = m + 1: block (m, m+1) complete in qbuf[m & 1] / diagonal block m with the updates <= m - 2 in dpart[m & 1].
+  // One flag per buffer, not one counter: the hand-offs of consecutive steps come from different waves and may complete
+  // out of order (the hand-off for step m + 1 does not depend on wave 0 having consumed the one for step m).
+  __shared__ int f_hq[2], f_hp[2];
+  __shared__ int f_prdy[LDL_MAX_NB];       // [J] k + 1: R_J of step k published in Rp[k & 1]
+  __shared__ int f_tdn[16];                // [wave] k + 1: the wave has finished its trailing updates of step k
+  __shared__ int f_x;                      // back-substitution: number of solved blocks (from the last one)
+  __shared__ int f_tc[LDL_MAX_NB];         // [K] number of slots tcon[K][.] written
+  __shared__ int f_xb[LDL_MAX_NB];         // [K] 1: XB[K] prepared
 #define LDL_STAMP(k) do { if (stamps && tid == 0) stamps[k] = clock64(); } while (0)
+#ifdef LDL_TRACE   // diagnostics (tests/micro/ldl16.hip): per-wave event log {clock, code} in LDS, dumped behind the stamps
+  __shared__ long long tr_log[16][64];
+  int tr_n = 0;
+#define LDL_EV(code) do { if (stamps && lane == 0 && tr_n < 64) tr_log[wave][tr_n++] = (clock64() << 12) | (unsigned)(code); } while (0)
+#else
+#define LDL_EV(code) do { } while (0)
+#endif
   LDL_STAMP(0);
+  if (tid == 0) {
+    f_xready = 0;
+    f_hq[0] = f_hq[1] = 0;
+    f_hp[0] = f_hp[1] = 0;
+    f_x = 0;
+  }
+  if (tid < LDL_MAX_NB) {
+    f_prdy[tid] = 0;
+    f_tc[tid] = 0;
+    f_xb[tid] = 0;
+  }
+  if (tid < 16) f_tdn[tid] = 0;
 
-  ldl_v4 acc[SLOTS];
-  ldl_v4 (&c4)[4] = reinterpret_cast<ldl_v4 (&)[4]>(acc);   // wave 0: the diagonal block, column per lane
-  int sI[SLOTS], sJ[SLOTS];
-  if (wave > 0) {
+  if (wave > 0 && (wave & 3) == 0) {
+    __syncthreads();   // (the barrier after the initial loads)
+  } else if (wave > 0) {
+    // =============================================================================== the twelve block-owning waves
+    ldl_v4 acc[SLOTS];
+    int sI[SLOTS], sJ[SLOTS];
+    int lastStep = -1;   // last step in which this wave has panel or trailing work
+    // block number -> (I, J) of the row-major upper triangle: lane s works out slot s, the results travel by v_readlane
+    int uI = 0, uR = lane * NREG + ridx;
+    while (uR >= nb - uI && uI < nb) {
+      uR -= nb - uI;
+      ++uI;
+    }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-      const int b = s * NREG + wave - 1;
+      const int b = s * NREG + ridx;
       sI[s] = nb;                          // inactive
       sJ[s] = nb;
       acc[s] = ldl_v4{0, 0, 0, 0};
       if (b < nblk) {
-        int I = 0, rem = b;
-        while (rem >= nb - I) {
-          rem -= nb - I;
-          ++I;
-        }
+        const int I = __builtin_amdgcn_readlane(uI, s), rem = __builtin_amdgcn_readlane(uR, s);
         sI[s] = I;
         sJ[s] = I + rem;
-        const double* p = S + LY.blk(I, I + rem) + lane;
+        lastStep = max(lastStep, rem > 0 ? I : I - 2);
+        const double* p = S + LY.blk(I, I + rem);
+        if (rem > 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[s][r] = p[64 * r];
+          for (int r = 0; r < 4; ++r) acc[s][r] = p[64 * r + lane];
+        } else {   // a diagonal block: only its upper triangle is assembled, the accumulators hold the full symmetric block
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) + 4 * r, col = lane & 15;
+            const int lo = row < col ? row : col, hi = row < col ? col : row;
+            acc[s][r] = p[(lo >> 2) * 64 + (lo & 3) * 16 + hi];
+          }
+        }
       }
     }
-  } else {
-    const int j = lane & 15;
+    __syncthreads();   // every block is in registers: the matrix area is free
+    LDL_EV(0xB00);
+    // the copies wave 0 needs first: block (0, 1) and the diagonal block 1
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int lo = i < j ? i : j, hi = i < j ? j : i;
-      const double v = S[(lo >> 2) * 64 + (lo & 3) * 16 + hi];       // block (0, 0) sits at offset 0
-      LDL_C(i) = lane < 16 ? v : ((lane < 32 && i == j) ? 1.0 : 0.0);
-    }
-  }
-  __syncthreads();   // every block is in registers: the matrix area is free
-  if (wave > 0) {
+    for (int s = 0; s < SLOTS; ++s) {
+      if (sI[s] == 0 && sJ[s] == 1) {
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s)
+        for (int r = 0; r < 4; ++r) qbuf[64 * r + lane] = acc[s][r];
+        ldl_signal(&f_hq[0], 1, lane);
+      }
       if (sI[s] == 1 && sJ[s] == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) dpart[256 + 64 * r + lane] = acc[s][r];
-      }
-    for (int i = tid - 64; i < (nb - 1) * 16; i += (NW - 1) * 64) tv[i] = 0.0;   // (the last block's t comes from wave 0)
-  }
-  LDL_STAMP(1);
-
-  for (int kb = 0; kb < nb; ++kb) {
-    const int npiv = (kb == nb - 1) ? npl : 16;
-    if (wave == 0) {
-      const bool ok = ldl16_eliminate(c4, dinv + kb * 16, npiv, lane);
-      if (stamps && tid == 0 && kb < 12) stamps[16 + 4 * kb] = clock64();
-      if (lane >= 16 && lane < 32) {
-        double* xo = Xs + kb * 256 + (lane - 16) * 16;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) xo[i] = LDL_C(i);
-      }
-      if (lane == 0 && !ok) *s_fail = 1;
-      if (kb == nb - 1 && lane == npl) {   // the rhs column after the elimination: L^-1 b of the last block
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tv[kb * 16 + k] = k < npl ? LDL_C(k) : 0.0;
+        ldl_signal(&f_hp[1], 2, lane);
       }
     }
-    __syncthreads();   // B1: L_kk^-1 and 1/d published; every trailing update of step kb - 1 done
-    if (stamps && tid == 0 && kb < 12) stamps[17 + 4 * kb] = clock64();
-    if (wave > 0 && kb + 1 < nb) {
-      // panel row: R_J = L_kk^-1 A_kJ for the owned blocks (kb, J > kb)
+    int lastHelp = -1;   // the steps kb = ridx (mod NREG): this wave prepares XB[kb] for the back-substitution
+    for (int k = ridx; k < nb; k += NREG) lastHelp = k;
+    bool tdn_final = false;
+    for (int kb = 0; kb < nb; ++kb) {
+      const bool helper = (kb % NREG == ridx);
+      if (kb > lastStep && !tdn_final) {   // no panel or trailing work any more: the wave never reads a panel row again
+        ldl_signal(&f_tdn[wave], INT_MAX, lane);
+        tdn_final = true;
+      }
+      if (kb > lastStep && !helper) {
+        if (kb > lastHelp) break;
+        continue;
+      }
+      LDL_EV(0xA00 | kb);   // at the wait for X_kb
+      ldl_wait_ge(&f_xready, kb + 1);
+      LDL_EV(0x100 | kb);   // X_kb seen
+      const int am = lane & 15;
       double a[4], dq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        a[q] = Xs[kb * 256 + 64 * q + lane];
-        dq[q] = -dinv[kb * 16 + (lane >> 4) + 4 * q];
+        const int ak = (lane >> 4) + 4 * q;
+        dq[q] = -dinv[kb * 16 + ak];
+        const double xh = Xs[kb * LDL_XB + ak * LDL_RS + am];
+        a[q] = am > ak ? xh * -dq[q] : (am == ak ? 1.0 : 0.0);   // L^-1 = Bh D^-1, unit diagonal, exact zeros above it
       }
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        if (sI[s] == kb && sJ[s] > kb) {
-          ldl_v4 R{0, 0, 0, 0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], acc[s][q], R, 0, 0, 0);
-          acc[s] = R;
-          double* rp = Rp + sJ[s] * 256 + lane;
-          double* rn = Rn + sJ[s] * 256 + lane;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            rp[64 * r] = R[r];
-            rn[64 * r] = dq[r] * R[r];
-          }
-        }
-      }
-    }
-    __syncthreads();   // B2: panel row published
-    if (stamps && tid == 0 && kb < 12) stamps[18 + 4 * kb] = clock64();
-    if (kb + 1 >= nb) break;
-    if (wave == 0) {
-      // the next diagonal block: its last update, then over to the column-per-lane layout (upper triangle mirrored)
-      ldl_v4 P;
-      const double* dp = dpart + ((kb + 1) & 1) * 256 + lane;
-      const double* rp = Rp + (kb + 1) * 256 + lane;
-      const double* rn = Rn + (kb + 1) * 256 + lane;
-      double a[4], b[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        P[q] = dp[64 * q];
-        a[q] = rp[64 * q];
-        b[q] = rn[64 * q];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) P = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], P, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) conv[((lane >> 4) + 4 * r) * 17 + (lane & 15)] = P[r];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int j = lane & 15;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        const double v = conv[lo * 17 + hi];
-        LDL_C(i) = lane < 16 ? v : ((lane < 32 && i == j) ? 1.0 : 0.0);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (stamps && tid == 0 && kb < 12) stamps[19 + 4 * kb] = clock64();
-    } else {
-      // trailing update of the owned blocks (I > kb); the diagonal block kb + 2 first: wave 0 wants it one step later.
-      // Block (kb + 1, kb + 1) is completed by wave 0 itself (above).
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
+      if (kb <= lastStep) {
+        double* Rk = Rp + (kb & 1) * nb * 256;
+        // ---- panel row: R_J = L_kk^-1 A_kJ for the owned blocks (kb, J > kb)
+        bool waited = kb < 2;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-          const int I = sI[s], J = sJ[s];
-          const bool first = (I == kb + 2 && J == kb + 2);
-          if (I <= kb || I >= nb || (I == kb + 1 && J == kb + 1) || first != (pass == 0)) continue;
-          const double* rp = Rp + I * 256 + lane;
-          const double* rn = Rn + J * 256 + lane;
-          double a[4], b[4];
+          int pI = sI[s], pJ = sJ[s];
+          asm volatile("" : "+s"(pI), "+s"(pJ));   // (what is derived from the slot coordinates is recomputed, not hoisted and spilled)
+          if (pI == kb && pJ > kb) {
+            // (the SIMD issues oldest-wave-first: without a priority the youngest of its four waves publishes last, whatever the
+            // chain is waiting for)
+            if (pJ <= kb + 2) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(1);
+            ldl_v4 R{0, 0, 0, 0};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            a[q] = rp[64 * q];
-            b[q] = rn[64 * q];
-          }
+            for (int q = 0; q < 4; ++q) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], acc[s][q], R, 0, 0, 0);
+            acc[s] = R;
+            if (!waited) {   // the buffer still holds the panel row of step kb - 2: every wave must be through with it
+              for (;;) {
+                const int v = (lane < NW && (lane & 3) != 0) ? __hip_atomic_load(&f_tdn[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : INT_MAX;
+                if (__all(v >= kb - 1)) break;
+                __builtin_amdgcn_s_sleep(1);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              waited = true;
+            }
+            double* rp = Rk + pJ * 256 + lane;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[s], 0, 0, 0);
-          if (first) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dpart[(I & 1) * 256 + 64 * r + lane] = acc[s][r];
+            for (int r = 0; r < 4; ++r) rp[64 * r] = R[r];
+            ldl_signal(&f_prdy[pJ], kb + 1, lane);
+            LDL_EV(0x200 | (kb << 4) | pJ);   // panel block (kb, J) published
+            __builtin_amdgcn_s_setprio(0);
           }
         }
-      }
-    }
-  }
-  LDL_STAMP(2);
-  // ---- back-substitution: x_I = L_II^-T D_I^-1 t_I,  t_K -= R_KI x_I for the owners of (K < I, I)
-  for (int I = nb - 1; I >= 0; --I) {
-    if (wave == 0) {
-      if (lane < 16) {
-        const double* xc = Xs + I * 256 + lane * 16;   // column `lane` of L^-1: entries (i, lane), i = 0..15
-        double s0 = 0, s1 = 0;
+        // ---- trailing update of the owned blocks (I > kb).  Two of them are handed to wave 0 afterwards: (kb+1, kb+2), complete
+        // with this update, and the diagonal block kb + 2.  The diagonal block kb + 1 is completed by wave 0 itself.
+        // (a wave's slots are in row-major order, which is the order in which the chain needs them)
+        {
+          unsigned long long ready = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          s0 = fma(xc[i], dinv[I * 16 + i] * tv[I * 16 + i], s0);
-          s1 = fma(xc[i + 1], dinv[I * 16 + i + 1] * tv[I * 16 + i + 1], s1);
+          for (int s = 0; s < SLOTS; ++s) {
+            int I = sI[s], J = sJ[s];
+            asm volatile("" : "+s"(I), "+s"(J));
+            const bool hq = (I == kb + 1 && J == kb + 2), hp = (I == kb + 2 && J == kb + 2);
+            if (I <= kb || I >= nb || (I == kb + 1 && J == kb + 1)) continue;
+            if (hq || hp) __builtin_amdgcn_s_setprio(3);
+            {   // the panel blocks R_I and R_J of this step (one poll fetches the state of the whole panel row)
+              const unsigned long long nd = (1ull << I) | (1ull << J);
+              while ((ready & nd) != nd) {
+                ready = ldl_ready_mask(f_prdy, nb, kb + 1, lane);
+                if ((ready & nd) != nd) __builtin_amdgcn_s_sleep(1);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            const double* rp = Rk + I * 256 + lane;
+            const double* rn = Rk + J * 256 + lane;
+            double ra[4], rb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              ra[q] = rp[64 * q];
+              rb[q] = rn[64 * q] * dq[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[q], rb[q], acc[s], 0, 0, 0);
+            if (hq) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) qbuf[(I & 1) * 256 + 64 * r + lane] = acc[s][r];
+              ldl_signal(&f_hq[I & 1], I + 1, lane);
+              LDL_EV(0x400 | I);   // Q_I handed over
+            }
+            if (hp) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dpart[(I & 1) * 256 + 64 * r + lane] = acc[s][r];
+              ldl_signal(&f_hp[I & 1], I + 1, lane);
+              LDL_EV(0x500 | I);   // P_I handed over
+            }
+            if (hq || hp) __builtin_amdgcn_s_setprio(0);
+          }
         }
-        double x = s0 + s1;
-        if (I == nb - 1) x = lane == npl ? -1.0 : (lane < npl ? x : 0.0);
-        xv[I * 16 + lane] = x;
-        const int gi = I * 16 + lane;
-        if (gi < D) x_out[gi] = x;
+        ldl_signal(&f_tdn[wave], kb + 1, lane);
+        LDL_EV(0x300 | kb);   // trailing updates of step kb done
+      }
+      if (helper) {
+        // XB[kb] = D^-1 Bh D^-1 with exact zeros above the diagonal: what the back-substitution multiplies t_K with.
+        // Entry (i, j): lane = 16 (i >> 2) + j handles i = 4 (lane >> 4) .. + 3 of column j.
+        const int j = lane & 15;
+        const double dj = dinv[kb * 16 + j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * (lane >> 4) + e;
+          const double v = Xs[kb * LDL_XB + j * LDL_RS + i] * dinv[kb * 16 + i] * dj;
+          XB[kb * LDL_XB + j * LDL_RS + i] = i > j ? v : (i == j ? dj : 0.0);
+        }
+        ldl_signal(&f_xb[kb], 1, lane);
       }
     }
-    __syncthreads();
-    if (wave > 0 && I > 0) {
-      const double xj = xv[I * 16 + (lane & 15)];
+    // ---- back-substitution: R_KJ x_J of the owned blocks with K <= J - 2, block column by block column, each into its own
+    // slot (wave 0 adds the slots of a block row in a fixed order, so the result does not depend on who finishes first)
+    for (int J = nb - 1; J >= 2; --J) {
+      bool any = false;
 #pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        if (sJ[s] == I && sI[s] < I) {
+      for (int s = 0; s < SLOTS; ++s) any = any || (sJ[s] == J && sI[s] + 2 <= J);
+      if (!any) continue;
+      ldl_wait_ge(&f_x, nb - J);
+      const double xj = xv[J * 16 + (lane & 15)];
+#pragma unroll
+      for (int s = SLOTS - 1; s >= 0; --s) {   // (the block row closest to J first: wave 0 asks for it first)
+        int K = sI[s], sj = sJ[s];
+        asm volatile("" : "+s"(K), "+s"(sj));
+        if (sj == J && K + 2 <= J) {
+          if (K + 2 == J) __builtin_amdgcn_s_setprio(3);   // the slot wave 0 asks for next
           double p[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) p[r] = row16_sum(acc[s][r] * xj);
           if ((lane & 15) == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tv[sI[s] * 16 + (lane >> 4) + 4 * r] -= p[r];
+            for (int r = 0; r < 4; ++r) tcon[(K * nb + J) * 16 + (lane >> 4) + 4 * r] = p[r];
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(&f_tc[K], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          LDL_EV(0xF00 | (K << 4) | J);   // slot (K, J) written
+          __builtin_amdgcn_s_setprio(0);
         }
       }
     }
+  } else {
+    // =============================================================================== wave 0: the diagonal chain
+    // Lanes 0..15 carry the chain (column j = lane); the other three DPP rows execute along on data that is never stored.
+    double c[16];
+    const int j = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      c[i] = S[(lo >> 2) * 64 + (lo & 3) * 16 + hi];   // block (0, 0) sits at offset 0
+    }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(3);
+    LDL_STAMP(1);
+    bool bad = false;
+    double mine = 0.0;
+    for (int kb = 0; kb < nb; ++kb) {
+      const int npiv = (kb == nb - 1) ? npl : 16;
+      mine = 0.0;
+      if (kb < nb - 1) ldl16_eliminate<true>(c, 16, mine, j);
+      else ldl16_eliminate<false>(c, npiv, mine, j);
+      bad = bad || (j < npiv && !(mine > 0.0 && mine < 1.0e300));   // a pivot was not positive
+      if (stamps && tid == 0 && kb < 12) stamps[16 + 4 * kb] = clock64();
+      // publish Bh (column `lane` as it is: the consumers mask the dead entries above the diagonal) and 1/d
+      if (lane < 16) {
+        ldl_v4* xo = reinterpret_cast<ldl_v4*>(Xs + kb * LDL_XB + lane * LDL_RS);
+        typedef double ldl_v2 __attribute__((ext_vector_type(2)));
+        ldl_v2* xo2 = reinterpret_cast<ldl_v2*>(xo);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xo2[i] = ldl_v2{c[2 * i], c[2 * i + 1]};
+        dinv[kb * 16 + lane] = mine;
+        if (kb + 1 >= nb && lane == npl) {   // the rhs column after the elimination: L^-1 b of the last block in its rows < npl
+#pragma unroll
+          for (int i = 0; i < 16; ++i) xv[kb * 16 + i] = c[i];
+        }
+      }
+      ldl_signal(&f_xready, kb + 1, lane);
+      if (stamps && tid == 0 && kb < 12) stamps[17 + 4 * kb] = clock64();
+      if (kb + 1 >= nb) break;
+      // ---- R = L_kk^-1 A_(k,k+1) privately, then the last update of the next diagonal block
+      double a[4], dq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ak = (lane >> 4) + 4 * q;
+        dq[q] = -dinv[kb * 16 + ak];
+        const double xh = Xs[kb * LDL_XB + ak * LDL_RS + j];
+        a[q] = j > ak ? xh * -dq[q] : (j == ak ? 1.0 : 0.0);
+      }
+      LDL_EV(0x600 | kb);   // wave 0: X_kb published, waiting for Q_kb and P_(kb+1)
+      for (;;) {
+        const int fq = __hip_atomic_load(&f_hq[kb & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int fp = __hip_atomic_load(&f_hp[(kb + 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (fq >= kb + 1 && fp >= kb + 2) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      LDL_EV(0x700 | kb);   // both there
+      ldl_v4 Q, R{0, 0, 0, 0}, P;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Q[q] = qbuf[(kb & 1) * 256 + 64 * q + lane];
+        P[q] = dpart[((kb + 1) & 1) * 256 + 64 * q + lane];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], Q[q], R, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P = __builtin_amdgcn_mfma_f64_16x16x4f64(R[q], R[q] * dq[q], P, 0, 0, 0);
+      if (stamps && tid == 0 && kb < 12) stamps[18 + 4 * kb] = clock64();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Rsup[kb * LDL_XB + ((lane >> 4) + 4 * r) * LDL_RS + j] = R[r];   // for the back-substitution
+      // accumulator layout -> column per lane: P[r] of DPP row p is entry (p + 4 r, j); rows 1..3 travel to row 0 with
+      // v_permlane16_swap (odd rows of the first operand <-> even rows of the second) and v_permlane32_swap (upper half of
+      // the first <-> lower half of the second)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned lo = (unsigned)__double2loint(P[r]), hi = (unsigned)__double2hiint(P[r]);
+        const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [0] = rows (0,0,2,2), [1] = rows (1,1,3,3)
+        const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const auto l2 = __builtin_amdgcn_permlane32_swap(l16[0], l16[0], false, false);   // [1] = rows (2,2,..)
+        const auto h2 = __builtin_amdgcn_permlane32_swap(h16[0], h16[0], false, false);
+        const auto l3 = __builtin_amdgcn_permlane32_swap(l16[1], l16[1], false, false);   // [1] = rows (3,3,..)
+        const auto h3 = __builtin_amdgcn_permlane32_swap(h16[1], h16[1], false, false);
+        c[4 * r] = P[r];
+        c[4 * r + 1] = __hiloint2double((int)h16[1], (int)l16[1]);
+        c[4 * r + 2] = __hiloint2double((int)h2[1], (int)l2[1]);
+        c[4 * r + 3] = __hiloint2double((int)h3[1], (int)l3[1]);
+      }
+      if (stamps && tid == 0 && kb < 12) stamps[19 + 4 * kb] = clock64();
+    }
+    if (__any(bad && lane < 16) && lane == 0) *s_fail = 1;
+    LDL_STAMP(2);
+    // ---- back-substitution, block by block from the last one.  Lane i holds entry i of the 16-vectors.
+    //   t_K = -(slots of the block columns >= K+2, by the other waves) - R_(K,K+1) x_(K+1) ;  x_K = L_KK^-T D_K^-1 t_K = (D^-1 Bh D^-1)^T t_K
+    double x = 0.0;
+    double rrow[16], xcol[16];   // row j of R_(K,K+1) and column j of XB[K]: fetched one step ahead (they are final long before)
+    ldl_wait_ge(&f_xb[nb - 1], 1);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      xcol[n] = XB[(nb - 1) * LDL_XB + j * LDL_RS + n];
+      rrow[n] = 0.0;
+    }
+    for (int K = nb - 1; K >= 0; --K) {
+      double t;
+      if (K == nb - 1) {
+        t = j < npl ? xv[K * 16 + j] : 0.0;   // (parked there by lane npl)
+      } else {
+        double s0 = 0.0, s1 = 0.0;
+        if (K + 2 < nb) {
+          LDL_EV(0xC00 | K);   // wave 0 back-substitution: waiting for the slots of block row K
+          ldl_wait_ge(&f_tc[K], nb - K - 2);
+          LDL_EV(0xD00 | K);
+          double tc[LDL_MAX_NB - 2];
+#pragma unroll
+          for (int u = 0; u < LDL_MAX_NB - 2; ++u) {   // block columns nb-1, nb-2, ..., K+2 in this order
+            const int J = nb - 1 - u;
+            tc[u] = J >= K + 2 ? tcon[(K * nb + J) * 16 + j] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < LDL_MAX_NB - 2; ++u) s0 -= tc[u];
+        }
+        const double xn = -x;
+        fmac_bcast_nop<0>(s0, xn, rrow[0]);
+        fmac_bcast<1>(s1, xn, rrow[1]);
+#define LDL_MV(n) fmac_bcast<n>(s0, xn, rrow[n]); fmac_bcast<n + 1>(s1, xn, rrow[n + 1]);
+        LDL_MV(2) LDL_MV(4) LDL_MV(6) LDL_MV(8) LDL_MV(10) LDL_MV(12) LDL_MV(14)
+#undef LDL_MV
+        t = s0 + s1;
+      }
+      LDL_EV(0xE00 | K);   // t_K complete
+      double s0 = 0.0, s1 = 0.0;
+      fmac_bcast_nop<0>(s0, t, xcol[0]);
+      fmac_bcast<1>(s1, t, xcol[1]);
+#define LDL_MV(n) fmac_bcast<n>(s0, t, xcol[n]); fmac_bcast<n + 1>(s1, t, xcol[n + 1]);
+      LDL_MV(2) LDL_MV(4) LDL_MV(6) LDL_MV(8) LDL_MV(10) LDL_MV(12) LDL_MV(14)
+#undef LDL_MV
+      x = s0 + s1;
+      if (K == nb - 1) x = j == npl ? -1.0 : (j < npl ? x : 0.0);
+      if (lane < 16) {
+        xv[K * 16 + lane] = x;
+        if (K * 16 + lane < D) x_out[K * 16 + lane] = x;
+      }
+      ldl_signal(&f_x, nb - K, lane);
+      if (K > 0) {   // operands of the next step
+        ldl_wait_ge(&f_xb[K - 1], 1);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          rrow[n] = Rsup[(K - 1) * LDL_XB + j * LDL_RS + n];
+          xcol[n] = XB[(K - 1) * LDL_XB + j * LDL_RS + n];
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    LDL_STAMP(3);
   }
-  LDL_STAMP(3);
+  __syncthreads();
+#ifdef LDL_TRACE
+  if (stamps && lane == 0) {
+    stamps[128 + wave * 65] = tr_n;
+    for (int i = 0; i < tr_n; ++i) stamps[128 + wave * 65 + 1 + i] = tr_log[wave][i];
+  }
+#endif
 #undef LDL_STAMP
+#undef LDL_EV
 }
 
 }  // namespace ba

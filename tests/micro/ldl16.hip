@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
+// #define LDL_TRACE   // (per-wave event log: perturbs the timing by a few hundred cycles per event)
 #include "ba_ldl16.hpp"
 
 constexpr int NW = 16;
@@ -31,6 +33,62 @@ __global__ __launch_bounds__(NW * 64) void k_solve(const double* __restrict__ Sg
   if (threadIdx.x == 0) fail[blockIdx.x] = s_fail;
 }
 
+
+// the diagonal chain alone: one wave eliminates a 16x16 block `n` times (the result of one is perturbed into the next so
+// that nothing is hoisted); the other waves of the workgroup either wait at the barrier (mode 0) or poll an LDS flag (1)
+__global__ __launch_bounds__(NW * 64) void k_elim(const double* __restrict__ A, double* out, long long* cyc, int mode, int n) {
+  __shared__ double sA[256];
+  __shared__ int flag;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15;
+  if (tid < 256) sA[tid] = A[tid];
+  if (tid == 0) flag = 0;
+  __syncthreads();
+  if (tid >= 64) {
+    if (mode == 1) ba::ldl_wait_ge(&flag, 1);
+    return;
+  }
+  double c[16], b[16], acc = 0;
+  const long long t0 = clock64();
+  for (int it = 0; it < n; ++it) {
+    int jj = j;
+    asm volatile("" : "+v"(jj));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      c[i] = sA[i * 16 + jj] + 1e-9 * acc;
+
+    }
+
+    double mine = 0.0;
+    ba::ldl16_eliminate<true>(c, 16, mine, j);
+    acc += mine + c[15];
+  }
+  const long long t1 = clock64();
+  if (tid == 0) {
+    cyc[0] = (t1 - t0) / n;
+    __hip_atomic_store(&flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  out[tid] = acc;
+}
+
+static void run_elim() {
+  std::vector<double> A(256);
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j) A[i * 16 + j] = (i == j ? 20.0 : 0.0) + 1.0 / (1 + abs(i - j));
+  double *dA, *dout;
+  long long* dc;
+  hipMalloc(&dA, 256 * 8);
+  hipMalloc(&dout, 64 * 8);
+  hipMalloc(&dc, 8);
+  hipMemcpy(dA, A.data(), 256 * 8, hipMemcpyHostToDevice);
+  for (int mode = 0; mode < 2; ++mode) {
+    long long c = 0;
+    k_elim<<<1, NW * 64>>>(dA, dout, dc, mode, 50);
+    hipDeviceSynchronize();
+    hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
+    printf("elimination of one 16x16 block by one wave, %s: %lld cycles\n", mode ? "15 waves polling an LDS flag" : "other waves gone", c);
+  }
+}
+
 static int at_host(int nb, int i, int j) {   // i >= j
   const int I = j >> 4, J = i >> 4, r = j & 15, c = i & 15;
   return (I * nb - (I * (I - 1)) / 2 + (J - I)) * 256 + (r >> 2) * 64 + (r & 3) * 16 + c;
@@ -39,6 +97,7 @@ static int at_host(int nb, int i, int j) {   // i >= j
 int main(int argc, char** argv) {
   const int dims[] = {150, 162, 174, 175, 160, 144, 90, 31, 16, 15, 6};
   const int nwg = argc > 1 ? atoi(argv[1]) : 1;
+  run_elim();
   for (int D : dims) {
     const int nb = ba::ldl16_nb(D), area = ba::ldl16_area_doubles(D);
     std::vector<double> A((size_t)D * D), b(D), G((size_t)D * D);
@@ -80,10 +139,10 @@ int main(int argc, char** argv) {
     int* dfail;
     hipMalloc(&dS, S.size() * 8);
     hipMalloc(&dx, (size_t)nwg * 192 * 8);
-    hipMalloc(&dst, 128 * 8);
+    hipMalloc(&dst, 2048 * 8);
     hipMalloc(&dfail, nwg * 4);
     hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice);
-    hipMemset(dst, 0, 128 * 8);
+    hipMemset(dst, 0, 2048 * 8);
     const size_t shmem = (size_t)(area + 192) * 8;
     hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 3);
@@ -109,10 +168,10 @@ int main(int argc, char** argv) {
     float ms3 = 0;
     hipEventElapsedTime(&ms3, e0, e1);
     std::vector<double> xg((size_t)nwg * 192);
-    std::vector<long long> st(128);
+    std::vector<long long> st(2048);
     std::vector<int> fl(nwg);
     hipMemcpy(xg.data(), dx, xg.size() * 8, hipMemcpyDeviceToHost);
-    hipMemcpy(st.data(), dst, 128 * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(st.data(), dst, 2048 * 8, hipMemcpyDeviceToHost);
     hipMemcpy(fl.data(), dfail, nwg * 4, hipMemcpyDeviceToHost);
     double err = 0, nrm = 0;
     for (int w = 0; w < nwg; ++w)
@@ -124,9 +183,19 @@ int main(int argc, char** argv) {
            D, nb, err / nrm, fl[0], st[1] - st[0], st[2] - st[1], st[3] - st[2], st[3] - st[0], (ms - ms3) * 1000.0 / 20.0);
     if (D == 150) {
       for (int kb = 0; kb < nb; ++kb)
-        printf("   step %2d: eliminate %5lld  ->B1 %5lld  panel->B2 %5lld  diag update+convert %5lld\n", kb,
-               st[16 + 4 * kb] - (kb ? st[19 + 4 * (kb - 1)] : st[1]), st[17 + 4 * kb] - st[16 + 4 * kb], st[18 + 4 * kb] - st[17 + 4 * kb],
-               kb + 1 < nb ? st[19 + 4 * kb] - st[18 + 4 * kb] : 0LL);
+        printf("   step %2d: eliminate %5lld  publish %5lld  wait+R+P (8 MFMA) %5lld  convert %5lld\n", kb,
+               st[16 + 4 * kb] - (kb ? st[19 + 4 * (kb - 1)] : st[1]), kb + 1 < nb ? st[17 + 4 * kb] - st[16 + 4 * kb] : 0LL,
+               kb + 1 < nb ? st[18 + 4 * kb] - st[17 + 4 * kb] : 0LL, kb + 1 < nb ? st[19 + 4 * kb] - st[18 + 4 * kb] : 0LL);
+    }
+    if (D == 150 && argc > 2) {   // timeline of all waves, merged and sorted
+      std::vector<std::pair<long long, int>> ev;
+      for (int w = 0; w < 16; ++w)
+        for (int i = 0; i < st[128 + w * 65]; ++i) {
+          const long long e = st[128 + w * 65 + 1 + i];
+          ev.push_back({(e >> 12), (int)((w << 12) | (e & 0xfff))});
+        }
+      std::sort(ev.begin(), ev.end());
+      for (auto& e : ev) printf("   t=%6lld  wave %2d  %03x\n", e.first - (st[1] & 0xfffffffffffffLL), e.second >> 12, e.second & 0xfff);
     }
     hipFree(dS);
     hipFree(dx);
