@@ -15,7 +15,7 @@ SOURCES = ["ba_capi.hip"]
 HEADERS = [os.path.join("host", "estimator.hpp"), os.path.join("host", "estimator.cpp"), os.path.join("host", "replay.hpp"),
            os.path.join("host", "replay.cpp"), os.path.join("host", "replay_main.cpp"),
            os.path.join("host", "estimator_capi.cpp"), "ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_schur.hpp", "ba_solve.hpp",
-           "ba_imu.hpp", "ba_marg.hpp", "ba_chol_tiles.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
+           "ba_imu.hpp", "ba_marg.hpp", "ba_chol_tiles.hpp", "ba_ldl16.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
 
 
 def stale() -> bool:

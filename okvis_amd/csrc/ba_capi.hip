@@ -771,7 +771,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
           for (int b = 0; b <= a; ++b, ++e) {
             const int ra = co[a], rb = co[b];
             if (ra < 0 || rb < 0) continue;
-            imu_asm[512 * (size_t)f + e] = make_int4((ra >= rb ? at(ra, rb) : at(rb, ra)) | (imu_color[f] << 24), a == b ? ra : -1, 0, 0);
+            imu_asm[512 * (size_t)f + e] = make_int4((ra >= rb ? at(ra, rb) : at(rb, ra)) | (imu_color[f] << 24), a == b ? ra : -1,
+                                                     ra >= rb ? (ra << 16 | rb) : (rb << 16 | ra), 0);   // z: the reduced indices (LDS layout of ba_ldl16.hpp)
           }
         for (int a = 0; a < 30; ++a)
           if (co[a] >= 0) imu_asm[512 * (size_t)f + 465 + a] = make_int4(co[a] | (1 << 20) | (imu_color[f] << 24), -1, 0, 0);
@@ -797,7 +798,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (imu_rev.empty()) imu_rev.push_back(make_int2(-1, -1));
     OFF(imu_rev, put(A, imu_rev));
   }
-  P.sbe_nlev = sbe_nlev;
+  P.sbe_nlev = 0;   // (the level schedule of the old LDS Cholesky is not used by the LDL^T solver)
+  (void)sbe_nlev;
   P.sbe_nblk = sbe_nblk;
   P.sbe_ntab = (int)sbe_tab.size();
   P.sbe_nstage = sbe_nstage;
@@ -951,12 +953,11 @@ size_t lin_smem(bool ext, bool f32 = false) {
                     : (ext ? LinCfg<true, double>::SMEM_DOUBLES : LinCfg<false, double>::SMEM_DOUBLES);
   return (size_t)d * sizeof(double);
 }
-size_t solve_smem(int Dpad, bool large, int sbl_blocks, int sbl_stage, int sbl_tab) {
+size_t solve_smem(int Dpad, bool large, int, int, int) {
   const size_t nbk = Dpad / 6;
-  // + the level-scheduled speed/bias elimination of the LDS solve: 54 doubles per 9x9 block, the stage, the table
-  const size_t sbl = large ? 0 : ((size_t)sbl_blocks * 54 + 9 * (size_t)sbl_stage) * sizeof(double) + 4 * (size_t)sbl_tab + 16;
-  return ((large ? 0 : nbk * (nbk + 1) / 2 * 38) + 4 * (size_t)Dpad + nbk * 36) * sizeof(double) +
-         ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15)) + sbl;
+  // LDS-resident: the matrix area of the LDL^T solver (ba_ldl16.hpp; Dpad >= D bounds it) + five vectors + the block table
+  return ((large ? 0 : (size_t)ldl16_area_doubles(Dpad)) + 4 * (size_t)Dpad + nbk * 36) * sizeof(double) +
+         ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15)) + 16;
 }
 size_t small_smem() { return (size_t)std::max<int>(std::max<int>(ImuLds::TOTAL, EvalLds::TOTAL), 2 * MAX_MARG_DIM) * sizeof(double); }
 

@@ -19,6 +19,7 @@
 #include <climits>
 #include "ba_chol_tiles.hpp"
 #include "ba_device.hpp"
+#include "ba_ldl16.hpp"
 
 namespace ba {
 
@@ -37,9 +38,18 @@ struct SLayout {
   }
 };
 
+// the layout of the reduced matrix by instantiation: HBM-resident (LARGE) = SLayout, LDS-resident = the 16x16 accumulator
+// blocks of the MFMA LDL^T solver (ba_ldl16.hpp).  Both offer at(i, j) for i >= j.
+template <bool LARGE> struct SolveLayout { typedef SLayout type; };
+template <> struct SolveLayout<false> { typedef L16 type; };
+// where entry d of the host-built IMU destination table lands: x carries the SLayout offset, z the reduced indices (i << 16 | j)
+__device__ __forceinline__ int imu_dst_off(const SLayout&, const int4& d) { return d.x & 0xFFFFF; }
+__device__ __forceinline__ int imu_dst_off(const L16& LY, const int4& d) { return LY.at(d.z >> 16, d.z & 0xFFFF); }
+
 // accumulate J^T J (lower triangle, reduced coordinates) and J^T r of one small factor.
 // J: nres x ncol row-major (ncol = sum of dims), col_off[c] = reduced index of local column c or -1.
-__device__ __forceinline__ void add_small_factor(double* S, const SLayout LY, double* g, double* d2, const double* J,
+template <class LYT>
+__device__ __forceinline__ void add_small_factor(double* S, const LYT LY, double* g, double* d2, const double* J,
                                                  const double* r, int nres, int ncol, const int* col_off, int tid,
                                                  int nthreads) {
   for (int wi = tid; wi < ncol * ncol; wi += nthreads) {
@@ -117,12 +127,13 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Xout) {
   return ok;
 }
 
-constexpr int SOLVE_LDS_LIMIT = 156 * 1024;   // dynamic LDS of the solve kernel (160 KB per workgroup minus its static arrays)
+constexpr int SOLVE_LDS_LIMIT = 155 * 1024;   // dynamic LDS of the solve kernel (160 KB per workgroup minus its static arrays, 4.2 KB)
 constexpr int PRI_STAGE = 2;  // pose / speed-bias priors whose records the solve kernel stages in LDS ahead of time
 
 // IMU Hessian blocks, priors and the marginalisation prior of linearisation buffer `acc`, accumulated into S
 // (block layout LY), g and d2.  (The reprojection part U_pp / U_pe / g_p arrives inside the Schur partials.)
-__device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, double* S, double* g, double* d2,
+template <class LYT>
+__device__ void assemble_base(const WinPtrs& W, int acc, const LYT LY, double* S, double* g, double* d2,
                               int* coloff, const unsigned short* ptab, int tid, int nthreads, bool skip_imu,
                               const double* pri = nullptr, const int* pricol = nullptr, int n_pri = 0,
                               bool imu_matrix_elsewhere = false) {
@@ -155,29 +166,31 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, doubl
       }
       for (int base = tid; base < items; base += NE * nthreads) {
         double v[NE], old[NE];
-        int dst[NE], d2i[NE];
+        int dst[NE], d2i[NE], soff[NE];
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
           const int idx = base + u * nthreads;
           dst[u] = -1;
           d2i[u] = -1;
+          soff[u] = 0;
           v[u] = 0;
           if (idx < items) {
             const int4 d = W.imu_asm[idx];
             if (d.x >= 0 && (d.x >> 24) == col) {
               dst[u] = d.x;
               d2i[u] = d.y;
+              soff[u] = (d.x & (1 << 20)) ? (d.x & 0xFFFFF) : imu_dst_off(LY, d);
             }
             v[u] = (idx & 511) < 495 ? src[idx] : 0.0;
           }
         }
 #pragma unroll
-        for (int u = 0; u < NE; ++u) old[u] = (dst[u] >= 0 && !(dst[u] & (1 << 20))) ? S[dst[u] & 0xFFFFF] : 0.0;
+        for (int u = 0; u < NE; ++u) old[u] = (dst[u] >= 0 && !(dst[u] & (1 << 20))) ? S[soff[u]] : 0.0;
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
           const int d = dst[u];
           if (d < 0) continue;
-          const int off = d & 0xFFFFF;
+          const int off = soff[u];
           if (d & (1 << 20)) {
             g[off] += v[u];
           } else {
@@ -312,7 +325,6 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const SLayout LY, doubl
 // for an IMU chain of n states ceil(log2 n) of them, e.g. {0,2,4,6,8} {1,5,9} {3} {7}) are factorised at the same time by
 // different work-items and eliminated with one symmetric update; the dense blocked Cholesky then only sees the pose part.
 // The rows Y = C L^-T of every level stay in an LDS stage for the recovery after the dense back-substitution.
-__device__ __forceinline__ int sym_at(const SLayout& LY, int i, int j) { return i >= j ? LY.at(i, j) : LY.at(j, i); }
 
 // trial poses / speed-biases  x (+) delta  of buffer 1-acc (PoseLocalParameterization::plus, PoseLocalParameterization.cpp:60-87).
 // Adds |x|^2 over the free blocks to *x2 and, when `ambient`, |x - x(+)delta|^2 to *s2.
@@ -454,8 +466,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   const OptD opt = *optp;
   const int D = W.D, Dp = W.Dp;
   const int Dpad = ((D + 5) / 6) * 6, nbk = Dpad / 6;
-  const int nS = nbk * (nbk + 1) / 2 * SBS;
-  const SLayout LY{nbk};
+  // LDS-resident: the matrix area of the LDL^T solver (upper 16x16 blocks incl. the rhs column D, or its work area)
+  const int nS = LARGE ? nbk * (nbk + 1) / 2 * SBS : ldl16_area_doubles(D);
+  typedef typename SolveLayout<LARGE>::type LYT;
+  const LYT LY{LARGE ? nbk : ldl16_nb(D)};
 
   double* S = LARGE ? W.Sg : smem;            // block-packed lower triangle
   double* s_rhs = LARGE ? smem : smem + nS;   // Dpad: rhs, then y = L^-1 rhs in place
@@ -472,17 +486,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
 
 #define STAMP(k) do { if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[k] = (double)clock64(); } while (0)
   STAMP(0);
-  // level-scheduled elimination of the speed/bias blocks (section 4a): its LDS sits behind the block-pair table - per 9x9
-  // block the lower triangle of the factor row by row (45) + 1 / diagonal (9), the rows of Y = C L^-T of all levels, the
-  // schedule table (requested now, used after the assembly)
-  const bool sbl = !LARGE && W.sbe_nlev > 0 && !opt.no_sb_levels;
-  const int nbs = sbl ? Dp / 6 : nbk;          // block columns of the dense part
-  const int Dsys = sbl ? Dp : Dpad;            // its dimension
-  double* s_L9 = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(s_ptab) + ((max(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~15));
-  double* s_stage = s_L9 + 54 * (sbl ? W.sbe_nblk : 0);
-  int* s_tab = reinterpret_cast<int*>(s_stage + 9 * (sbl ? W.sbe_nstage : 0));
-  if (sbl)
-    for (int i = tid; i < W.sbe_ntab; i += SOLVE_THREADS) s_tab[i] = W.sbe_tab[i];
   // IMU factor records (H | g, 495 doubles each): value and destination (host-built imu_asm) of up to IMU_NPF entries
   // per lane are requested now, from the buffer that is accepted if the pending step is (the common case), and
   // scattered after the decision without any further global round trip.
@@ -490,13 +493,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   const int imu_items = W.n_imu * 512;
   const bool imu_fast = !LARGE && imu_items <= IMU_NPF * IMU_NL;
   double imu_v[IMU_NPF];
-  int imu_dst[IMU_NPF], imu_d2[IMU_NPF];
+  int imu_dst[IMU_NPF], imu_d2[IMU_NPF], imu_rc[IMU_NPF];
   int imu_spec = 0;
 #pragma unroll
   for (int j = 0; j < IMU_NPF; ++j) {
     imu_v[j] = 0;
     imu_dst[j] = -1;
     imu_d2[j] = -1;
+    imu_rc[j] = 0;
   }
   __shared__ double s_pri[PRI_STAGE * (42 + 9 + 81)];
   __shared__ int s_pricol[PRI_STAGE * (6 + 9)];
@@ -526,6 +530,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         const int4 d = W.imu_asm[idx];
         imu_dst[j] = d.x;
         imu_d2[j] = d.y;
+        imu_rc[j] = d.z;
         imu_v[j] = src[idx];
       }
     }
@@ -621,68 +626,82 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         for (int i = tid - 64; i < nS; i += SOLVE_THREADS - 64) S[i] = 0.0;
     } else {
       // The Schur partials do not depend on this kernel's decision (the Schur kernel made the same one and
-      // reduced the buffer that is being accepted): sum them into S while wave 0 decides.  Pose blocks come
-      // first in the row-major lower-triangular enumeration, which is the partials' own layout.
+      // reduced the buffer that is being accepted): sum them into S while wave 0 decides.  One item = one double of the
+      // partials' record (lower triangle of the pose part in 6x6 blocks, then  Y b | g | diag U): its sum over the chunks,
+      // lanes on consecutive doubles (coalesced; three items per lane and eight chunks per trip are requested together —
+      // the loads come from other CUs' stores, what counts is the number of dependent rounds), scattered into the 16x16
+      // accumulator-layout blocks of the LDL^T solver.  Everything no item writes starts from zero.
       const int npose_blk = Dp / 6;
-      const int nblocks = nbk * (nbk + 1) / 2;
       const size_t stride = W.spart_stride;
       const int nch = W.n_chunk;
       const double* sp = W.spart;
-      const int nPblk = npose_blk * (npose_blk + 1) / 2;
-      // one item = one double of the partials' record (pose blocks, then  Y b | g | diag U): its sum over the
-      // chunks.  Three items per lane and eight chunks per trip are requested together — the loads come from
-      // other CUs' stores (L2 misses, ~1 us each round trip), so what counts is the number of dependent rounds.
-      const int nP = nPblk * 36, ntot = nP + 3 * Dp;
+      const int nP = npose_blk * (npose_blk + 1) / 2 * 36, ntot = nP + 3 * Dp;
       constexpr int NL = SOLVE_THREADS - 64;
-      for (int base = tid - 64; base < ntot; base += 3 * NL) {
-        double a[3] = {0, 0, 0};
-        int boff[3];
+      {
+        const int nb16 = LY.nb, nblk16 = L16::blocks(nb16);
+        const int nbp = (Dp + 15) >> 4;   // block rows / columns that hold pose entries
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6) - 1, l = tid & 63;
+        int I = 0, rem = wv;   // block wv, wv + 15, ... of the row-major upper triangle -> (I, I + rem)
+        for (int b = wv; b < nblk16; b += SOLVE_THREADS / 64 - 1) {
+          while (rem >= nb16 - I) {
+            rem -= nb16 - I;
+            ++I;
+          }
+          const int J = I + rem;
+          if (J >= nbp || 16 * J + (l & 15) >= Dp) {   // not a pose column: no item lands here
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {   // LDS offsets of the items' blocks: requested together with the data
+            for (int r = 0; r < 4; ++r) S[b * 256 + 64 * r + l] = 0.0;
+          }
+          rem += SOLVE_THREADS / 64 - 1;
+        }
+      }
+      for (int base = tid - 64; base < nP; base += 3 * NL) {
+        double a[3] = {0, 0, 0};
+        int dst[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
           const int i = base + t * NL;
-          boff[t] = (i < nP) ? W.sp_blk_off[i / 36] : 0;
+          dst[t] = -1;
+          if (i < nP) {
+            const int q = i / 36, e = i - 36 * q, ii = e / 6, jj = e - 6 * ii;
+            int bi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+            while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
+            while (bi * (bi + 1) / 2 > q) --bi;
+            const int bj = q - bi * (bi + 1) / 2;
+            if (bi > bj || ii >= jj) dst[t] = LY.at(6 * bi + ii, 6 * bj + jj);   // (the upper halves of the diagonal blocks are not part of the lower triangle)
+          }
         }
         for (int ch = 0; ch < nch; ch += 8) {
           double v[3][8];
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-              v[t][u] = (ch + u < nch && base + t * NL < ntot) ? sp[(size_t)(ch + u) * stride + base + t * NL] : 0.0;
+            for (int u = 0; u < 8; ++u) v[t][u] = (ch + u < nch && base + t * NL < nP) ? sp[(size_t)(ch + u) * stride + base + t * NL] : 0.0;
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int u = 0; u < 8; ++u) a[t] += v[t][u];
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const int i = base + t * NL;
-          if (i < nP) {
-            const int q = i / 36, e = i - 36 * q;
-            S[boff[t] + e] = a[t];
-          } else if (i < ntot) {
-            const int which = (i - nP) / Dp, j = (i - nP) - which * Dp;
-            (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = a[t];
-          }
+        for (int t = 0; t < 3; ++t)
+          if (dst[t] >= 0) S[dst[t]] = a[t];
+      }
+      // Y b | g | diag U of the pose part: the same sums
+      for (int i = nP + tid - 64; i < ntot; i += NL) {
+        double a = 0;
+        for (int ch = 0; ch < nch; ch += 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride + i] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a += v[u];
         }
+        const int which = (i - nP) / Dp, j = (i - nP) - which * Dp;
+        (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = a;
       }
       for (int i = tid - 64; i < 3 * (Dpad - Dp); i += NL) {   // speed/bias part of the vectors starts from zero
         const int which = i / (Dpad - Dp), j = Dp + i - which * (Dpad - Dp);
         (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = 0.0;
-      }
-      // the other blocks (speed/bias rows; filled by assemble_base) start from zero: one wave per block
-      {
-        // (bi, bj) of block q advance incrementally with wave-uniform (scalar) arithmetic
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6) - 1;
-        int bi = npose_blk, bj = wv;
-        for (int q = nPblk + wv; q < nblocks; q += SOLVE_THREADS / 64 - 1) {
-          while (bj > bi) {
-            bj -= bi + 1;
-            ++bi;
-          }
-          if ((tid & 63) < 36) S[LY.blk(bi, bj) + (tid & 63)] = 0.0;
-          bj += SOLVE_THREADS / 64 - 1;
-        }
       }
       for (int i = tid - 64; i < Dpad; i += SOLVE_THREADS - 64) s_x[i] = 0.0;
     }
@@ -735,11 +754,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       for (int j = 0; j < IMU_NPF; ++j) {
         const int d = imu_dst[j];
         if (d >= 0 && (d >> 24) == col) {
-          const int off = d & 0xFFFFF;
           if (d & (1 << 20)) {
-            s_g[off] += imu_v[j];
+            s_g[d & 0xFFFFF] += imu_v[j];
           } else {
-            S[off] += imu_v[j];
+            S[imu_dst_off(LY, make_int4(d, 0, imu_rc[j], 0))] += imu_v[j];
             if (imu_d2[j] >= 0) s_d2[imu_d2[j]] += imu_v[j];
           }
         }
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       S[LY.at(i, i)] += lambda * d2;
       s_rhs[i] = s_rhs[i] - s_g[i];
     } else {
-      S[LY.at(i, i)] = 1.0;  // identity padding up to a multiple of 6
+      if constexpr (LARGE) S[LY.at(i, i)] = 1.0;  // identity padding up to a multiple of 6
       s_rhs[i] = 0.0;
     }
   }
@@ -961,295 +979,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     return;
   }
-  // ------------------------------------------------------------------ 4a. speed/bias blocks by levels
-  // (table layout: build_window in ba_capi.hip.)  Level by level: (1) factor the 9x9 blocks, (2) Y = C L^-T for the row-blocks
-  // they couple with, staged contiguously, (3) S -= Y Y^T on the coupled block pairs, rhs -= Y y.  The eliminated rows and
-  // columns of S are never touched again; the dense factorisation below works on the pose part.
-  STAMP(52);
-  if (sbl) {
-    for (int lev = 0; lev < W.sbe_nlev; ++lev) {
-      const int* hd = s_tab + W.sbe_nblk + 8 * lev;
-      const int b0 = hd[0], nb = hd[1];
-      // (1) factor the blocks of this level, one thread each (165 multiply-adds in registers: a dependent chain that a wave
-      //     would not shorten); the block's right-hand side becomes y = L^-1 rhs
-      if (tid < nb) {
-        const int o = s_tab[b0 + tid];
-        double L[45], y[9], dinv[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          y[i] = s_rhs[o + i];
-#pragma unroll
-          for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = S[LY.at(o + i, o + j)];
-        }
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-#pragma unroll
-          for (int j = 0; j <= i; ++j) {
-            double v = L[i * (i + 1) / 2 + j];
-#pragma unroll
-            for (int m = 0; m < j; ++m) v -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
-            if (j == i) {
-              ok = ok && (v > 0.0);
-              dinv[i] = rsqrt_nr(v > 0.0 ? v : 1.0);
-              L[i * (i + 1) / 2 + i] = v * dinv[i];
-            } else {
-              L[i * (i + 1) / 2 + j] = v * dinv[j];
-            }
-          }
-          double t = y[i];
-#pragma unroll
-          for (int m = 0; m < i; ++m) t -= L[i * (i + 1) / 2 + m] * y[m];
-          y[i] = t * dinv[i];
-        }
-        double* L9 = s_L9 + 54 * (b0 + tid);
-#pragma unroll
-        for (int q = 0; q < 45; ++q) L9[q] = L[q];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          L9[45 + i] = dinv[i];
-          s_rhs[o + i] = y[i];
-        }
-        if (!ok) s_fail = 1;
-      }
-      __syncthreads();
-      if (lev == 0) STAMP(53);
-      // (2) Y = C L^-T, one thread per row of every coupling entry
-      const int* ent = s_tab + hd[2];
-      const int nent = s_tab[hd[3] + nb];
-      for (int it = tid; it < nent * 9; it += SOLVE_THREADS) {
-        const int e = it / 9, r = it - e * 9;
-        const int en = ent[e];
-        if (r >= ((en >> 8) & 15)) continue;
-        const int i = (en & 255) + r, bb = (en >> 12) & 15;
-        const int o = s_tab[b0 + bb];
-        const double* L9 = s_L9 + 54 * (b0 + bb);
-        double v[9];
-#pragma unroll
-        for (int a = 0; a < 9; ++a) v[a] = S[sym_at(LY, i, o + a)];
-        double* st = s_stage + 9 * ((en >> 16) + r);
-#pragma unroll
-        for (int a = 0; a < 9; ++a) {   // y L^T = v  ->  forward substitution
-          double t = v[a];
-#pragma unroll
-          for (int m = 0; m < 9; ++m)
-            if (m < a) t -= L9[a * (a + 1) / 2 + m] * v[m];
-          v[a] = t * L9[45 + a];
-          st[a] = v[a];
-        }
-      }
-      __syncthreads();
-      if (lev == 0) STAMP(54);
-      // (3) S[R1][R2] -= sum over the common level blocks of Y_R1 Y_R2^T, one thread per element; rhs_R -= Y_R y
-      const int* pidx = s_tab + hd[6];
-      for (int it = tid; it < hd[7] * 9; it += SOLVE_THREADS) {   // one 3x3 tile of a block pair per thread
-        const int p = it / 9, e = it - p * 9;
-        const int t1 = e / 3, t2 = e - t1 * 3;
-        const int* rec = s_tab + pidx[p];
-        const int h = rec[0];
-        const int o1 = h & 255, o2 = (h >> 8) & 255;
-        if (3 * t1 >= ((h >> 16) & 15) || 3 * t2 >= ((h >> 20) & 15) || (o1 == o2 && t2 > t1)) continue;
-        double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        for (int c = 1; c <= (h >> 24); ++c) {
-          const double* y1 = s_stage + 9 * ((rec[c] & 0xffff) + 3 * t1);
-          const double* y2 = s_stage + 9 * ((rec[c] >> 16) + 3 * t2);
-#pragma unroll
-          for (int q = 0; q < 9; ++q) {
-            const double a0 = y1[q], a1 = y1[9 + q], a2 = y1[18 + q];
-            const double c0 = y2[q], c1 = y2[9 + q], c2 = y2[18 + q];
-            acc[0][0] += a0 * c0, acc[0][1] += a0 * c1, acc[0][2] += a0 * c2;
-            acc[1][0] += a1 * c0, acc[1][1] += a1 * c1, acc[1][2] += a1 * c2;
-            acc[2][0] += a2 * c0, acc[2][1] += a2 * c1, acc[2][2] += a2 * c2;
-          }
-        }
-        const bool diag = o1 == o2 && t1 == t2;   // (o1 >= o2: the lower triangle)
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-          for (int v = 0; v < 3; ++v)
-            if (!diag || v <= u) S[LY.at(o1 + 3 * t1 + u, o2 + 3 * t2 + v)] -= acc[u][v];
-      }
-      const int* gidx = s_tab + hd[4];
-      for (int it = tid; it < hd[5] * 9; it += SOLVE_THREADS) {
-        const int g = it / 9, r = it - g * 9;
-        const int* rec = s_tab + gidx[g];
-        const int h = rec[0];
-        if (r >= ((h >> 8) & 15)) continue;
-        double acc = 0;
-        for (int c = 1; c <= (h >> 12); ++c) {
-          const double* y1 = s_stage + 9 * ((rec[c] & 0xffff) + r);
-          const double* yy = s_rhs + s_tab[b0 + (rec[c] >> 16)];
-#pragma unroll
-          for (int q = 0; q < 9; ++q) acc += y1[q] * yy[q];
-        }
-        s_rhs[(h & 255) + r] -= acc;
-      }
-      __syncthreads();
-      if (lev == 0) STAMP(55);
-    }
-  }
-  STAMP(56);
-  if (tid == 0) {
-    if (!factor_diag(S + LY.blk(0, 0), s_dinv)) s_fail = 1;
-    if (opt.dogleg && c.mu >= DL_MAX_MU) s_fail = 1;   // DoglegStrategy: no solve is attempted once mu has reached max_mu
-  }
-  // every lane owns (at most) two fixed 3x3 sub-tiles of the trailing matrix for the whole factorisation (the
-  // mirrored enumeration does not depend on kb): coordinates and the C address are computed once; an item is
-  // active while its block column is right of the current one.
-  // wave 14 is the look-ahead wave (next diagonal block: update + factor + inverse, the dependency chain of the
-  // factorisation), wave 15 handles the right-hand-side blocks, waves 0-13 the bulk of the trailing update
-  constexpr int TU_THREADS = SOLVE_THREADS - 128;
-  int it_gbi[2] = {0, 0}, it_gbj[2] = {-1, -1}, it_sr[2] = {0, 0}, it_sc[2] = {0, 0}, it_c[2] = {0, 0};
-  if (tid < TU_THREADS) {
-    for (int u = 0; u < 2; ++u) {
-      const int wi = tid + u * TU_THREADS;
-      const int q = wi >> 2, sub = wi & 3;
-      if (q < (nbs - 1) * nbs / 2) {
-        it_gbj[u] = nbs - 1 - (s_ptab[q] >> 8);
-        it_gbi[u] = nbs - 1 - (s_ptab[q] & 255);
-        it_sr[u] = (sub >> 1) * 3;
-        it_sc[u] = (sub & 1) * 3;
-        it_c[u] = LY.blk(it_gbi[u], it_gbj[u]) + 6 * it_sr[u] + it_sc[u];
-      }
-    }
-  }
-  // look-ahead lane -> entry (li_i, li_j) of the lower triangle of a 6x6 block
-  const int la_lane = tid - TU_THREADS;
-  int la_i = 0, la_j = 0;
-  if (la_lane >= 0 && la_lane < 21) {
-    la_i = (la_lane >= 15) ? 5 : (la_lane >= 10) ? 4 : (la_lane >= 6) ? 3 : (la_lane >= 3) ? 2 : (la_lane >= 1) ? 1 : 0;
-    la_j = la_lane - la_i * (la_i + 1) / 2;
-  }
-  __syncthreads();
-  for (int kb = 0; kb < nbs; ++kb) {
-    const int k0 = kb * 6;
-    const int nrows = Dsys - k0 - 6;  // panel rows below the diagonal block
-    if (kb == 0) STAMP(10);
-    if (kb == 12) STAMP(13);
-    // (P) panel: row <- row * L_kk^-T as six independent dot products with the published inverse; the
-    //     right-hand side rides along as one more row (forward substitution)
-    if (tid <= nrows) {
-      double* row = (tid < nrows) ? (S + LY.blk((k0 + 6 + tid) / 6, kb) + ((k0 + 6 + tid) % 6) * 6) : (s_rhs + k0);
-      const double* Xd = s_dinv + 36 * kb;
-      double v[6], x[6];
-#pragma unroll
-      for (int m = 0; m < 6; ++m) v[m] = row[m];
-#pragma unroll
-      for (int cix = 0; cix < 6; ++cix) {
-        double a = 0;
-#pragma unroll
-        for (int m = 0; m <= cix; ++m) a += v[m] * Xd[6 * cix + m];
-        x[cix] = a;
-      }
-#pragma unroll
-      for (int cix = 0; cix < 6; ++cix) row[cix] = x[cix];
-    }
+  // ------------------------------------------------------------------ 4b. blocked LDL^T on the matrix core (ba_ldl16.hpp)
+  // The right-hand side rides along as column D of the matrix: the elimination turns it into L^-1 b.
+  if constexpr (!LARGE) {
+    for (int i = tid; i < D; i += SOLVE_THREADS) S[LY.at(D, i)] = s_rhs[i];
+    if (tid == 0 && opt.dogleg && c.mu >= DL_MAX_MU) s_fail = 1;   // DoglegStrategy: no solve is attempted once mu has reached max_mu
     __syncthreads();
-    if (kb == 0) STAMP(11);
-    if (kb == 12) STAMP(14);
-    // (T) trailing update with 3x3 register sub-tiles  A_(bi,bj) -= L_(bi,k) L_(bj,k)^T ; rhs blocks ride
-    //     along; the look-ahead wave prepares the next diagonal block meanwhile
-    const int nt = nbs - kb - 1;
-    const int colk = LY.blk(kb, kb);  // start of block column kb (its diagonal block)
-    if (tid < TU_THREADS) {
-      // let the look-ahead wave's few LDS reads enter the queue before the bulk's ~27 per lane (it carries the
-      // dependency chain; measured: its operands arrived after ~900 cycles without this head start)
-      __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int gbi = it_gbi[u], gbj = it_gbj[u];
-        if (gbj <= kb) continue;  // not (or no longer) part of the trailing matrix
-        if (gbi == kb + 1) continue;  // block (kb+1, kb+1): the look-ahead wave (gbj > kb and gbj <= gbi)
-        const double* Li = S + colk + (gbi - kb) * SBS + 6 * it_sr[u];  // rows sr..sr+2 of L_(gbi,k)
-        const double* Lj = S + colk + (gbj - kb) * SBS + 6 * it_sc[u];  // rows sc..sc+2 of L_(gbj,k)
-        double* Cb = S + it_c[u];
-        double li[18], lj[18], cc[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          const double2 a = reinterpret_cast<const double2*>(Li)[i], b = reinterpret_cast<const double2*>(Lj)[i];
-          li[2 * i] = a.x; li[2 * i + 1] = a.y;
-          lj[2 * i] = b.x; lj[2 * i + 1] = b.y;
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int cix = 0; cix < 3; ++cix) cc[3 * r + cix] = Cb[6 * r + cix];
-        const bool skip = (gbi == gbj && it_sr[u] == 0 && it_sc[u] == 3);  // upper-right of a diagonal block
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int cix = 0; cix < 3; ++cix) {
-            double s0 = 0;
-#pragma unroll
-            for (int m = 0; m < 6; ++m) s0 += li[6 * r + m] * lj[6 * cix + m];
-            if (!skip) Cb[6 * r + cix] = cc[3 * r + cix] - s0;
-          }
-      }
-    } else if (tid < TU_THREADS + 64) {
-      // look-ahead wave: lanes 0-20 each form one entry of the updated block (kb+1, kb+1); the 21 entries are
-      // broadcast with v_readlane and EVERY lane factors the block and inverts the factor in registers (wave-
-      // uniform arithmetic: no LDS round trip between update, factor and inverse); lane 0 publishes.
-      if (nt > 0) {
-        // this wave carries the dependency chain of the whole factorisation while the three other waves of its
-        // SIMD issue trailing-update FMAs: raise its issue priority (measured: 3000 -> cycles for the chain)
-        __builtin_amdgcn_s_setprio(3);
-        double cij = 0;
-        if (la_lane < 21) {
-          const double* Li = S + colk + SBS + 6 * la_i;
-          const double* Lj = S + colk + SBS + 6 * la_j;
-          double s0 = 0;
-#pragma unroll
-          for (int m = 0; m < 6; ++m) s0 += Li[m] * Lj[m];
-          cij = S[LY.blk(kb + 1, kb + 1) + 6 * la_i + la_j] - s0;
-        }
-#define LASTAMP(k) do { if (W.prof && kb == 12 && blockIdx.x == 0 && la_lane == 0) W.prof[k] = (double)clock64(); } while (0)
-        LASTAMP(30);
-        double L[6][6], X[6][6], inv[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int j = 0; j <= i; ++j) L[i][j] = readlane_f64(cij, i * (i + 1) / 2 + j);
-        LASTAMP(31);
-        const bool ok = chol6(L, inv);
-        LASTAMP(34);
-        trinv6(L, inv, X);
-        LASTAMP(35);
-        // publish L^-1 (all the panel and the back-substitution need)
-        if (la_lane == 0) {
-          double* Xo = s_dinv + 36 * (kb + 1);
-#pragma unroll
-          for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) Xo[6 * i + j] = X[i][j];
-        }
-        if (la_lane == 0) {
-          if (!ok) s_fail = 1;
-          if (W.prof && kb == 12 && blockIdx.x == 0) W.prof[32] = (double)clock64();
-        }
-        __builtin_amdgcn_s_setprio(0);
-      }
-    } else {
-      // last wave: right-hand-side blocks rhs_(bi) -= L_(bi,k) y_k
-      for (int bi = tid - TU_THREADS - 64; bi < nt; bi += 64) {
-        const double* Li = S + colk + (bi + 1) * SBS;
-        double* rr = s_rhs + (kb + 1 + bi) * 6;
-        double y[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) y[m] = s_rhs[k0 + m];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          double s0 = 0;
-#pragma unroll
-          for (int m = 0; m < 6; ++m) s0 += Li[6 * r + m] * y[m];
-          rr[r] -= s0;
-        }
-      }
-      if (W.prof && kb == 12 && blockIdx.x == 0 && tid == TU_THREADS + 64) W.prof[33] = (double)clock64();
-    }
-    if (kb == 0) STAMP(26);
-    __syncthreads();
-    if (kb == 0) STAMP(12);
-    if (kb == 12) STAMP(15);
+    STAMP(10);
+    ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail);
   }
   STAMP(7);
   if (s_fail) {  // not positive definite: invalid step (handled like a rejection)
@@ -1267,85 +1004,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       *gctrl = c;
     }
     return;
-  }
-  // back substitution  L^T x = y by ONE wave without barriers (LDS operations of a wave are ordered):
-  // every lane owns the rows lane, lane+64, ... ; block kb is solved redundantly by all lanes, then each
-  // lane updates its rows above it.  25 dependent steps cost LDS round trips only, no s_barrier.
-  if (tid < 64) {
-    for (int kb = nbs - 1; kb >= 0; --kb) {
-      const double* Xd = s_dinv + 36 * kb;   // x_k = L_kk^-T y_k: six independent dot products
-      double x[6], y[6];
-#pragma unroll
-      for (int m = 0; m < 6; ++m) y[m] = s_rhs[kb * 6 + m];
-#pragma unroll
-      for (int cix = 0; cix < 6; ++cix) {
-        double a = 0;
-#pragma unroll
-        for (int m = cix; m < 6; ++m) a += Xd[6 * m + cix] * y[m];
-        x[cix] = a;
-      }
-      if (tid == 0) {
-#pragma unroll
-        for (int cix = 0; cix < 6; ++cix) s_x[kb * 6 + cix] = x[cix];
-      }
-      for (int j = tid; j < kb * 6; j += 64) {
-        const double* Lb = S + LY.blk(kb, j / 6) + (j % 6);  // column j of block row kb
-        double a = s_rhs[j];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) a -= Lb[6 * m] * x[m];
-        s_rhs[j] = a;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      asm volatile("" ::: "memory");
-    }
-  }
-  __syncthreads();
-  STAMP(57);
-  if (sbl) {
-    // speed/bias blocks in reverse level order:  x_b = L^-T (y_b - sum_R Y_R^T x_R)  over the row-blocks the block was coupled
-    // with when it was eliminated (poses and the blocks of later levels)
-    for (int lev = W.sbe_nlev - 1; lev >= 0; --lev) {
-      const int* hd = s_tab + W.sbe_nblk + 8 * lev;
-      const int b0 = hd[0], nb = hd[1];
-      const int* ent = s_tab + hd[2];
-      for (int bb = tid >> 6; bb < nb; bb += SOLVE_THREADS / 64) {   // one wave per block
-        // lane = 16 part + a: component a (< 9) of t = sum_R Y_R^T x_R over the rows r = part (mod 4) of every coupled
-        // row-block; the four parts are combined with two cross-row shuffles.  What the substitution needs of L (column `lane`
-        // below the diagonal, 1 / diagonal) is requested before the sums, so the chain afterwards runs on registers.
-        const int lane = tid & 63, a = lane & 15, part = lane >> 4;
-        const int o = s_tab[b0 + bb];
-        const int e0 = s_tab[hd[3] + bb], e1 = s_tab[hd[3] + bb + 1];
-        const double* L9 = s_L9 + 54 * (b0 + bb);
-        double Lc[9], di = 0, res = 0;
-#pragma unroll
-        for (int m = 0; m < 9; ++m) Lc[m] = (lane < 9 && m > lane) ? L9[m * (m + 1) / 2 + lane] : 0.0;
-        if (lane < 9) {
-          di = L9[45 + lane];
-          res = s_rhs[o + lane];
-        }
-        double t = 0;
-        if (a < 9)
-          for (int e = e0; e < e1; ++e) {
-            const int en = ent[e];
-            const int n = (en >> 8) & 15;
-            const double* st = s_stage + 9 * (en >> 16) + a;
-            const double* xr = s_x + (en & 255);
-            for (int r = part; r < n; r += 4) t += st[9 * r] * xr[r];
-          }
-        t += __shfl_xor(t, 16);
-        t += __shfl_xor(t, 32);
-        res -= t;   // (lanes 0..8: their own component)
-        double xres = 0;
-#pragma unroll
-        for (int m = 8; m >= 0; --m) {   // L^T x = res: lane m finishes x_m, the lanes above take it out
-          const double xm = readlane_f64(res, m) * readlane_f64(di, m);
-          if (lane == m) xres = xm;
-          if (lane < m) res -= Lc[m] * xm;
-        }
-        if (lane < 9) s_x[o + lane] = xres;
-      }
-      __syncthreads();
-    }
   }
   STAMP(8);
 

@@ -1,0 +1,18 @@
+"""Diagnostics (not a test): phase stamps of the solve kernel of window 0 (clock64 ticks and us at 2.38 GHz).  python tests/gpu_solve_stamps.py [n_windows]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from okvis_amd import solver, synthetic
+from okvis_amd.window import default_options
+opt = default_options(); opt.gauss_newton = 1; opt.function_tolerance = 0; opt.gradient_tolerance = 0; opt.parameter_tolerance = 0; opt.use_graph = 0; opt.debug_arrays = 2
+NW = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+b = solver.WindowBatch([synthetic.config_A(seed=20240923 + i) for i in range(NW)], options=opt)
+b.begin(); b.iterate(12); b.synchronize()
+p = b.array("PROF")
+T = 2380.0
+print("wave 0 decision done at %.2f us; shadow assembly (Schur partials) done at %.2f us" % ((p[3] - p[0]) / T, (p[4] - p[0]) / T))
+names = [(1, "decision + Schur partial sums"), (2, "(barrier)"), (58, "IMU records"), (5, "priors + marginalisation prior"), (6, "convergence + damping"),
+         (10, "rhs column + barrier"), (7, "LDL^T + back-substitution"), (9, "scalars, trial states, ctrl")]
+prev = 0
+for k, n in names:
+    print("  %-34s %8.0f ticks %7.2f us" % (n, p[k] - p[prev], (p[k] - p[prev]) / T)); prev = k
+print("  total %.2f us" % ((p[9] - p[0]) / T))
