@@ -954,10 +954,8 @@ size_t lin_smem(bool ext, bool f32 = false) {
   return (size_t)d * sizeof(double);
 }
 size_t solve_smem(int Dpad, bool large, int, int, int) {
-  const size_t nbk = Dpad / 6;
-  // LDS-resident: the matrix area of the LDL^T solver (ba_ldl16.hpp; Dpad >= D bounds it) + five vectors + the block table
-  return ((large ? 0 : (size_t)ldl16_area_doubles(Dpad)) + 4 * (size_t)Dpad + nbk * 36) * sizeof(double) +
-         ((std::max<size_t>(nbk * (nbk + 1) / 2, 465) * 2 + 15) & ~size_t(15)) + 16;
+  // LDS-resident: the matrix area of the LDL^T solver (ba_ldl16.hpp; Dpad >= D bounds it) + four vectors
+  return ((large ? 0 : (size_t)ldl16_area_doubles(Dpad)) + 4 * (size_t)Dpad) * sizeof(double) + 16;
 }
 size_t small_smem() { return (size_t)std::max<int>(std::max<int>(ImuLds::TOTAL, EvalLds::TOTAL), 2 * MAX_MARG_DIM) * sizeof(double); }
 
@@ -1939,9 +1937,9 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   unsigned char* d = s->marg_scratch;
   HIP_TRY(hipMemcpyAsync(d, hb.data(), host_part, hipMemcpyHostToDevice, s->stream));
   WinPtrs P = H.ptrs;   // this window with the export buffers attached
-  P.S = reinterpret_cast<double*>(d + o_S);
-  P.rhs = reinterpret_cast<double*>(d + o_rhs);
-  P.Dp2 = reinterpret_cast<double*>(d + o_d2);
+  P.S = (decltype(P.S))(d + o_S);
+  P.rhs = (decltype(P.rhs))(d + o_rhs);
+  P.Dp2 = (decltype(P.Dp2))(d + o_d2);
   P.grad = nullptr;
   HIP_TRY(hipMemcpyAsync(d + o_win, &P, sizeof(P), hipMemcpyHostToDevice, s->stream));
   const WinPtrs* d_win = reinterpret_cast<const WinPtrs*>(d + o_win);

@@ -7,6 +7,15 @@
 
 namespace ba {
 
+// A pointer that is read from memory (every pointer of WinPtrs) is a generic-address-space pointer for the compiler: its
+// accesses become FLAT instructions, which count on the LDS counter as well, so that the next LDS wait also waits for
+// them (a global store followed by an LDS read costs a full memory round trip).  as_global() states that the pointer
+// refers to HBM: global_load / global_store, which only the vector-memory counter tracks.
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T* as_global(T* p) {
+  return (__attribute__((address_space(1))) T*)p;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -45,6 +54,38 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   y = y * (1.5 - h * y * y);
   y = y * (1.5 - h * y * y);
   return y;
+}
+
+// PoseLocalParameterization::plus (PoseLocalParameterization.cpp:60-87, Transformation.hpp:246-258) as the solve kernel
+// evaluates it twice per launch on its critical path: the same function as pose_oplus (ba_math.hpp) without the library
+// calls.  Square roots and divisions become v_rsq_f64 + Newton steps; sin(h) / h and cos(h) of the half angle are Taylor
+// polynomials of h^2 for h <= 0.5 (truncation < 5e-17: a rotation update of up to one radian), the library functions
+// beyond.  About 100 instructions instead of about 700; agrees with pose_oplus to the last bit or two.
+__device__ __forceinline__ void pose_oplus_dev(const double* x, const double* d, double* out) {
+  out[0] = x[0] + d[0];
+  out[1] = x[1] + d[1];
+  out[2] = x[2] + d[2];
+  const double qn2 = x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6];
+  const double qi = rsqrt_nr(qn2);
+  const double q[4] = {x[3] * qi, x[4] * qi, x[5] * qi, x[6] * qi};
+  const double h2 = 0.25 * (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);   // (half angle)^2
+  double sc, cs;
+  if (h2 <= 0.25) {
+    sc = fma(h2, fma(h2, fma(h2, fma(h2, fma(h2, fma(h2, fma(h2, -1.0 / 1307674368000.0, 1.0 / 6227020800.0), -1.0 / 39916800.0),
+                                                     1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+    cs = fma(h2, fma(h2, fma(h2, fma(h2, fma(h2, fma(h2, fma(h2, fma(h2, 1.0 / 20922789888000.0, -1.0 / 87178291200.0), 1.0 / 479001600.0),
+                                                              -1.0 / 3628800.0), 1.0 / 40320.0), -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
+  } else {
+    const double h = sqrt(h2);
+    sc = sin(h) / h;
+    cs = cos(h);
+  }
+  const double s = 0.5 * sc;
+  const double dq[4] = {s * d[3], s * d[4], s * d[5], cs};
+  double qn[4];
+  qmul(dq, q, qn);
+  const double ni = rsqrt_nr(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+  out[3] = qn[0] * ni; out[4] = qn[1] * ni; out[5] = qn[2] * ni; out[6] = qn[3] * ni;
 }
 
 // Whole-wave reductions on the VALU: two quad permutes, row_half_mirror (0x141) and row_mirror (0x140) leave every

@@ -521,7 +521,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
     LDL_STAMP(2);
     // ---- back-substitution, block by block from the last one.  Lane i holds entry i of the 16-vectors.
     //   t_K = -(slots of the block columns >= K+2, by the other waves) - R_(K,K+1) x_(K+1) ;  x_K = L_KK^-T D_K^-1 t_K = (D^-1 Bh D^-1)^T t_K
-    double x = 0.0;
+    double x = 0.0, tsum = 0.0;
     double rrow[16], xcol[16];   // row j of R_(K,K+1) and column j of XB[K]: fetched one step ahead (they are final long before)
     ldl_wait_ge(&f_xb[nb - 1], 1);
 #pragma unroll
@@ -530,24 +530,12 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
       rrow[n] = 0.0;
     }
     for (int K = nb - 1; K >= 0; --K) {
+      // the chain: t_K = tsum_K - R_(K,K+1) x_(K+1), x_K = XB_K^T t_K, publish
       double t;
       if (K == nb - 1) {
         t = j < npl ? xv[K * 16 + j] : 0.0;   // (parked there by lane npl)
       } else {
-        double s0 = 0.0, s1 = 0.0;
-        if (K + 2 < nb) {
-          LDL_EV(0xC00 | K);   // wave 0 back-substitution: waiting for the slots of block row K
-          ldl_wait_ge(&f_tc[K], nb - K - 2);
-          LDL_EV(0xD00 | K);
-          double tc[LDL_MAX_NB - 2];
-#pragma unroll
-          for (int u = 0; u < LDL_MAX_NB - 2; ++u) {   // block columns nb-1, nb-2, ..., K+2 in this order
-            const int J = nb - 1 - u;
-            tc[u] = J >= K + 2 ? tcon[(K * nb + J) * 16 + j] : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < LDL_MAX_NB - 2; ++u) s0 -= tc[u];
-        }
+        double s0 = tsum, s1 = 0.0;
         const double xn = -x;
         fmac_bcast_nop<0>(s0, xn, rrow[0]);
         fmac_bcast<1>(s1, xn, rrow[1]);
@@ -570,12 +558,29 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
         if (K * 16 + lane < D) x_out[K * 16 + lane] = x;
       }
       ldl_signal(&f_x, nb - K, lane);
-      if (K > 0) {   // operands of the next step
+      if (K > 0) {
+        // off the chain: the operands of the next step; its slots (block columns >= K+1: none of them needs x_K) summed
+        // in the fixed order nb-1, nb-2, ...
         ldl_wait_ge(&f_xb[K - 1], 1);
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
           rrow[n] = Rsup[(K - 1) * LDL_XB + j * LDL_RS + n];
           xcol[n] = XB[(K - 1) * LDL_XB + j * LDL_RS + n];
+        }
+        tsum = 0.0;
+        if (K + 1 < nb) {
+          LDL_EV(0xC00 | (K - 1));
+          ldl_wait_ge(&f_tc[K - 1], nb - K - 1);
+          LDL_EV(0xD00 | (K - 1));
+          double tc[LDL_MAX_NB - 2];
+#pragma unroll
+          for (int u = 0; u < LDL_MAX_NB - 2; ++u) {
+            const int J = nb - 1 - u;
+            const int Jc = J >= K + 1 ? J : K + 1;   // (clamped: a load, not a branch; the copy is not added)
+            tc[u] = tcon[((K - 1) * nb + Jc) * 16 + j];
+          }
+#pragma unroll
+          for (int u = 0; u < LDL_MAX_NB - 2; ++u) tsum -= (nb - 1 - u >= K + 1) ? tc[u] : 0.0;
         }
       }
     }

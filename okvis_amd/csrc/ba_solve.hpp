@@ -127,14 +127,15 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Xout) {
   return ok;
 }
 
-constexpr int SOLVE_LDS_LIMIT = 155 * 1024;   // dynamic LDS of the solve kernel (160 KB per workgroup minus its static arrays, 4.2 KB)
+constexpr int SOLVE_LDS_LIMIT = 150 * 1024;   // dynamic LDS of the solve kernel (160 KB per workgroup minus its static arrays, about 8.5 KB)
 constexpr int PRI_STAGE = 2;  // pose / speed-bias priors whose records the solve kernel stages in LDS ahead of time
+constexpr int PRE_BLOCKS = 32;  // pose / speed-bias blocks whose accepted values the solve kernel stages in LDS ahead of time
 
 // IMU Hessian blocks, priors and the marginalisation prior of linearisation buffer `acc`, accumulated into S
 // (block layout LY), g and d2.  (The reprojection part U_pp / U_pe / g_p arrives inside the Schur partials.)
 template <class LYT>
 __device__ void assemble_base(const WinPtrs& W, int acc, const LYT LY, double* S, double* g, double* d2,
-                              int* coloff, const unsigned short* ptab, int tid, int nthreads, bool skip_imu,
+                              int* coloff, int tid, int nthreads, bool skip_imu,
                               const double* pri = nullptr, const int* pricol = nullptr, int n_pri = 0,
                               bool imu_matrix_elsewhere = false) {
   // pri / pricol: LDS copies of the first n_pri (<= PRI_STAGE) pose priors [f][42], speed/bias priors r [f][9] and
@@ -328,39 +329,64 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const LYT LY, double* S
 
 // trial poses / speed-biases  x (+) delta  of buffer 1-acc (PoseLocalParameterization::plus, PoseLocalParameterization.cpp:60-87).
 // Adds |x|^2 over the free blocks to *x2 and, when `ambient`, |x - x(+)delta|^2 to *s2.
+// pre (LDS, may be null): the accepted values of the first PRE_BLOCKS pose blocks [b][7] and speed/bias blocks
+// [PRE_BLOCKS * 7 + 9 b], preoff their reduced offsets.  Every value is read before the first store is issued and the LDS /
+// HBM sources are separate code paths (a pointer that may be either is a generic pointer: its loads are FLAT instructions
+// whose wait also waits for the stores before them — nine serialised store round trips, 1.6 us, in the first version).
 __device__ __forceinline__ void trial_states(const WinPtrs& W, int acc, const double* s_x, int tid, bool ambient, double* s2,
-                                             double* x2) {
+                                             double* x2, const double* pre = nullptr, const int* preoff = nullptr) {
   const int trial = 1 - acc;
   double a2 = 0, b2 = 0;
   for (int b = tid; b < W.n_pose; b += SOLVE_THREADS) {
-    const double* xp = W.pose[acc] + 7 * (size_t)b;
-    double* xt = W.pose[trial] + 7 * (size_t)b;
-    const int off = W.pose_off[b];
+    auto xt = as_global(W.pose[trial] + 7 * (size_t)b);
+    double xin[7], xo[7];
+    int off;
+    if (pre && b < PRE_BLOCKS) {
+      off = preoff[b];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) xin[k] = pre[7 * b + k];
+    } else {
+      off = W.pose_off[b];
+      auto xp = as_global(W.pose[acc] + 7 * (size_t)b);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) xin[k] = xp[k];
+    }
     if (off >= 0) {
-      double xin[7], xo[7];
-      for (int k = 0; k < 7; ++k) {
-        xin[k] = xp[k];
-        b2 += xp[k] * xp[k];
-      }
-      pose_oplus(xin, s_x + off, xo);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) b2 += xin[k] * xin[k];
+      pose_oplus_dev(xin, s_x + off, xo);
+#pragma unroll
       for (int k = 0; k < 7; ++k) {
         xt[k] = xo[k];
         if (ambient) a2 += (xo[k] - xin[k]) * (xo[k] - xin[k]);
       }
     } else {
-      for (int k = 0; k < 7; ++k) xt[k] = xp[k];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) xt[k] = xin[k];
     }
   }
   for (int b = tid; b < W.n_sb; b += SOLVE_THREADS) {
-    const double* xp = W.sb[acc] + 9 * (size_t)b;
-    double* xt = W.sb[trial] + 9 * (size_t)b;
-    const int off = W.sb_off[b];
+    auto xt = as_global(W.sb[trial] + 9 * (size_t)b);
+    double v[9], d[9];
+    int off;
+    if (pre && b < PRE_BLOCKS) {
+      off = preoff[PRE_BLOCKS + b];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = pre[PRE_BLOCKS * 7 + 9 * b + k];
+    } else {
+      off = W.sb_off[b];
+      auto xp = as_global(W.sb[acc] + 9 * (size_t)b);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = xp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = off >= 0 ? s_x[off + k] : 0.0;
+#pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const double v = xp[k];
-      if (off >= 0) b2 += v * v;
-      const double nv = off >= 0 ? v + s_x[off + k] : v;
+      if (off >= 0) b2 += v[k] * v[k];
+      const double nv = v[k] + d[k];
       xt[k] = nv;
-      if (ambient && off >= 0) a2 += (nv - v) * (nv - v);
+      if (ambient && off >= 0) a2 += (nv - v[k]) * (nv - v[k]);
     }
   }
   *s2 += a2;
@@ -461,6 +487,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   if (LARGE != (W.Sg != nullptr)) return;  // each window is handled by the instantiation that fits it
   Ctrl* gctrl = W.ctrl;
   const int tid = threadIdx.x;
+  // The window record (sizes and ~140 pointers, 1.3 KB in HBM) is copied to LDS once: every later W.field is an LDS read
+  // instead of a scalar load that misses its cache line by line (measured: 3 us of the 4.6 us tail were such misses)
+  __shared__ double s_Wd[(sizeof(WinPtrs) + 7) / 8];
+  static_assert(sizeof(WinPtrs) % 8 == 0, "copied as doubles");
+  if (!LARGE && tid >= 64 && tid < 64 + (int)(sizeof(WinPtrs) / 8)) s_Wd[tid - 64] = reinterpret_cast<const double*>(&W)[tid - 64];
   if (LARGE && tid == 0) W.ct_flag[W.ct_nT * (W.ct_nT + 1) / 2 + 1] = 0;  // no system exported (yet) this launch
   if (gctrl->done) return;
   const OptD opt = *optp;
@@ -476,8 +507,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   double* s_g = s_rhs + Dpad; // gradient (pose / speed-bias part)
   double* s_d2 = s_g + Dpad;  // diag(U) -> clamp -> LM damping diagonal
   double* s_x = s_d2 + Dpad;  // solution
-  double* s_dinv = s_x + Dpad;       // nbk * 36: inverses of the factored diagonal blocks, L_kk^-1
-  unsigned short* s_ptab = reinterpret_cast<unsigned short*>(s_dinv + nbk * 36);  // (bi<<8|bj) of the block-pair enumeration
   __shared__ Ctrl c;
   __shared__ int s_accepted, s_was_first, s_fail, s_was_pending;
   __shared__ double s_cost_change, s_old_cost, s_lm_gmax;
@@ -502,6 +531,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     imu_d2[j] = -1;
     imu_rc[j] = 0;
   }
+  // the Jacobi scale of this lane's column (used by the damping, section 4): requested now, the value is only wrong in the
+  // launch that estimates it
+  const double scale_pref = (tid < D && opt.dogleg) ? W.scale_p[tid] : 1.0;
   __shared__ double s_pri[PRI_STAGE * (42 + 9 + 81)];
   __shared__ int s_pricol[PRI_STAGE * (6 + 9)];
   const int n_pri = (!LARGE && W.n_pprior <= PRI_STAGE && W.n_sbprior <= PRI_STAGE) ? PRI_STAGE : 0;
@@ -518,6 +550,31 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     if (t < W.n_sbprior * 9) {
       const int off = W.sb_off[W.sbprior_sb[t / 9]];
       s_pricol[PRI_STAGE * 6 + t] = off < 0 ? -1 : off + t % 9;
+    }
+  }
+  // accepted pose / speed-bias values of the speculated buffer -> LDS (the convergence test and the trial states read them;
+  // one memory round trip here instead of two on the critical path later)
+  __shared__ double s_pre[PRE_BLOCKS * 16];
+  __shared__ int s_preoff[2 * PRE_BLOCKS];   // reduced offsets of the first PRE_BLOCKS pose blocks | speed/bias blocks
+  const bool pre_on = !LARGE;
+  double pre_v[2] = {0, 0};
+  int pre_o = -1;
+  if (pre_on && tid >= 64 + PRE_BLOCKS * 8 && tid < 64 + PRE_BLOCKS * 10) {
+    const int t = tid - 64 - PRE_BLOCKS * 8;
+    if (t < PRE_BLOCKS) pre_o = t < W.n_pose ? W.pose_off[t] : -1;
+    else pre_o = t - PRE_BLOCKS < W.n_sb ? W.sb_off[t - PRE_BLOCKS] : -1;
+  }
+  if (pre_on && tid >= 64 && tid < 64 + PRE_BLOCKS * 8) {
+    const int spec = gctrl->pending ? 1 - gctrl->acc : gctrl->acc;
+    const int t = tid - 64;   // two doubles per lane
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = 2 * t + u;
+      if (i < PRE_BLOCKS * 7) {
+        if (i < 7 * W.n_pose) pre_v[u] = W.pose[spec][i];
+      } else if (i - PRE_BLOCKS * 7 < 9 * W.n_sb) {
+        pre_v[u] = W.sb[spec][i - PRE_BLOCKS * 7];
+      }
     }
   }
   if (imu_fast && tid >= 64) {
@@ -609,16 +666,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       if (W.prof && blockIdx.x == 0) W.prof[3] = (double)clock64();
     }
   } else {
-    // meanwhile the other waves prepare what does not depend on the decision:
-    // block-pair enumeration table (row-major lower triangle): entry wi -> (a, b), a >= b.  Used for the
-    // Schur partials' layout, the IMU 30x30 triangles and (mirrored) the trailing-update enumeration.
-    const int ntab = max(nbk * (nbk + 1) / 2, 465);
-    for (int wi = tid - 64; wi < ntab; wi += SOLVE_THREADS - 64) {
-      int bi = (int)((sqrtf(8.0f * wi + 1.0f) - 1.0f) * 0.5f);
-      while ((bi + 1) * (bi + 2) / 2 <= wi) ++bi;
-      while (bi * (bi + 1) / 2 > wi) --bi;
-      s_ptab[wi] = (unsigned short)((bi << 8) | (wi - bi * (bi + 1) / 2));
-    }
+    // meanwhile the other waves prepare what does not depend on the decision
     if constexpr (LARGE) {
       // the HBM matrix is normally left zero by large_export_kernel, which clears every entry it reads (the flag behind the
       // mode word says so; set by solve_large_tail_kernel, dropped below as soon as this launch starts to assemble)
@@ -705,6 +753,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       }
       for (int i = tid - 64; i < Dpad; i += SOLVE_THREADS - 64) s_x[i] = 0.0;
     }
+    if (pre_on && tid < 64 + PRE_BLOCKS * 8) {
+      s_pre[2 * (tid - 64)] = pre_v[0];
+      s_pre[2 * (tid - 64) + 1] = pre_v[1];
+    } else if (pre_on && tid < 64 + PRE_BLOCKS * 10) {
+      s_preoff[tid - 64 - PRE_BLOCKS * 8] = pre_o;
+    }
     if (W.prof && tid == 64 && blockIdx.x == 0) W.prof[4] = (double)clock64();
   }
   __syncthreads();
@@ -713,7 +767,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     return;
   }
   const int acc = c.acc;
-  if (LARGE && tid == 0) W.ct_flag[W.ct_nT * (W.ct_nT + 1) / 2 + 2] = 0;   // S is being written from here on
+  const WinPtrs& Wl = *[&]() -> const WinPtrs* {
+    if constexpr (LARGE) return &W;
+    else return reinterpret_cast<const WinPtrs*>(s_Wd);
+  }();
+  if (LARGE && tid == 0) Wl.ct_flag[Wl.ct_nT * (Wl.ct_nT + 1) / 2 + 2] = 0;   // S is being written from here on
 
   STAMP(1);
   // ------------------------------------------------------------------ 2. assembly
@@ -721,9 +779,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     // pose part of the matrix: summed by large_export_kernel; vectors here
     const int npose_blk = Dp / 6;
     const int nP = npose_blk * (npose_blk + 1) / 2 * 36;
-    const size_t stride = W.spart_stride;
-    const int nch = W.n_chunk;
-    const double* sp = W.spart;
+    const size_t stride = Wl.spart_stride;
+    const int nch = Wl.n_chunk;
+    const double* sp = Wl.spart;
     for (int i = tid; i < 3 * Dpad; i += SOLVE_THREADS) {
       const int which = i / Dpad, j = i - which * Dpad;
       double a = 0;
@@ -744,12 +802,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   STAMP(2);
   if (imu_fast) {
     if (tid >= 64 && acc != imu_spec) {   // the step was rejected: the records of the other buffer are needed
-      const double* src = W.imu_lin[acc];
+      const double* src = Wl.imu_lin[acc];
 #pragma unroll
       for (int j = 0; j < IMU_NPF; ++j)
         if (imu_dst[j] >= 0) imu_v[j] = src[tid - 64 + j * IMU_NL];
     }
-    for (int col = 0; col < W.n_imu_color; ++col) {   // factors of one colour touch disjoint blocks
+    for (int col = 0; col < Wl.n_imu_color; ++col) {   // factors of one colour touch disjoint blocks
 #pragma unroll
       for (int j = 0; j < IMU_NPF; ++j) {
         const int d = imu_dst[j];
@@ -765,14 +823,26 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       __syncthreads();
     }
   }
+  if (pre_on && s_was_pending && !s_accepted) {   // rejected step: the other buffer stays accepted
+    for (int i = tid; i < PRE_BLOCKS * 16; i += SOLVE_THREADS) {
+      double v = 0;
+      if (i < PRE_BLOCKS * 7) {
+        if (i < 7 * Wl.n_pose) v = Wl.pose[acc][i];
+      } else if (i - PRE_BLOCKS * 7 < 9 * Wl.n_sb) {
+        v = Wl.sb[acc][i - PRE_BLOCKS * 7];
+      }
+      s_pre[i] = v;
+    }
+    __syncthreads();
+  }
   if (n_pri) {
     if (s_was_pending && !s_accepted) {   // rejected step: restage the records of the buffer that stays accepted
-      if (tid < W.n_pprior * 42) s_pri[tid] = W.pp_lin[acc][tid];
-      if (tid < W.n_sbprior * 9) s_pri[PRI_STAGE * 42 + tid] = W.sbp_lin[acc][tid];
+      if (tid < Wl.n_pprior * 42) s_pri[tid] = Wl.pp_lin[acc][tid];
+      if (tid < Wl.n_sbprior * 9) s_pri[PRI_STAGE * 42 + tid] = Wl.sbp_lin[acc][tid];
       __syncthreads();
     }
   }
-  assemble_base(W, acc, LY, S, s_g, s_d2, s_coloff, s_ptab, tid, SOLVE_THREADS, imu_fast, s_pri, s_pricol, n_pri, LARGE);
+  assemble_base(Wl, acc, LY, S, s_g, s_d2, s_coloff, tid, SOLVE_THREADS, imu_fast, s_pri, s_pricol, n_pri, LARGE);
   __syncthreads();
   STAMP(5);
   // ------------------------------------------------------------------ 3. convergence of the accepted step
@@ -781,14 +851,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     if (opt.dogleg) {
       // Ceres 1.9: gradient_max_norm = || x - Plus(x, -g) ||_inf over the ambient coordinates: the gradient itself for
       // Euclidean blocks, the change of the quaternion coefficients for the rotation part of a pose
-      for (int b = tid; b < W.n_pose; b += SOLVE_THREADS) {
-        const int off = W.pose_off[b];
+      for (int b = tid; b < Wl.n_pose; b += SOLVE_THREADS) {
+        const int off = (pre_on && b < PRE_BLOCKS) ? s_preoff[b] : Wl.pose_off[b];
         if (off < 0) continue;
-        const double* xp = W.pose[acc] + 7 * (size_t)b;
+        const double* xp = (pre_on && b < PRE_BLOCKS) ? s_pre + 7 * b : Wl.pose[acc] + 7 * (size_t)b;
         double xin[7], dneg[6], xo[7];
         for (int k = 0; k < 7; ++k) xin[k] = xp[k];
         for (int k = 0; k < 6; ++k) dneg[k] = -s_g[off + k];
-        pose_oplus(xin, dneg, xo);
+        pose_oplus_dev(xin, dneg, xo);
         for (int k = 0; k < 7; ++k) m = fmax(m, fabs(xin[k] - xo[k]));
       }
       for (int i = Dp + tid; i < D; i += SOLVE_THREADS) m = fmax(m, fabs(s_g[i]));
@@ -819,16 +889,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     __syncthreads();
   }
-  if (W.grad)
-    for (int i = tid; i < D; i += SOLVE_THREADS) W.grad[i] = s_g[i];
+  STAMP(30);
+  if (Wl.grad)
+    for (int i = tid; i < D; i += SOLVE_THREADS) Wl.grad[i] = s_g[i];
   if (final_only == 2) {
     // marginalisation pass (okvis_ba_marginalize): export the undamped system left after the landmark
     // elimination, H (D x D, full symmetric) and b0 = -(g - W V^+ b_l)  (MarginalizationError.cpp:682-684)
     for (int k = tid; k < D * D; k += SOLVE_THREADS) {
       const int i = k / D, j = k - i * D;
-      W.S[k] = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
+      Wl.S[k] = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
     }
-    for (int i = tid; i < D; i += SOLVE_THREADS) W.rhs[i] = s_rhs[i] - s_g[i];
+    for (int i = tid; i < D; i += SOLVE_THREADS) Wl.rhs[i] = s_rhs[i] - s_g[i];
     if (tid == 0) *gctrl = c;
     return;
   }
@@ -846,9 +917,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       if (opt.dogleg) {
         if (est_scale) {
           sc = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(s_d2[i])) : 1.0;
-          W.scale_p[i] = sc;
+          Wl.scale_p[i] = sc;
         } else {
-          sc = W.scale_p[i];
+          sc = i == tid ? scale_pref : Wl.scale_p[i];
         }
       }
       const double d2 = damp_diag(s_d2[i], sc, opt);
@@ -861,21 +932,21 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
   }
   __syncthreads();
-  if (W.S) {  // parity/debug copy of the damped system
+  if (Wl.S) {  // parity/debug copy of the damped system
     for (int k = tid; k < D * D; k += SOLVE_THREADS) {
       const int i = k / D, j = k - i * D;
-      W.S[k] = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
+      Wl.S[k] = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
     }
     for (int i = tid; i < D; i += SOLVE_THREADS) {
-      W.rhs[i] = s_rhs[i];
-      W.Dp2[i] = s_d2[i];
+      Wl.rhs[i] = s_rhs[i];
+      Wl.Dp2[i] = s_d2[i];
     }
   }
   STAMP(6);
   if constexpr (!LARGE) {
     if (opt.dogleg && c.explicit_next) {
       // ------------------------------------------------------------ explicit dogleg step (no factorisation)
-      // delta = -cA xv + beta dGN from the stored Gauss-Newton point dGN (W.step): after a rejected step (radius halved,
+      // delta = -cA xv + beta dGN from the stored Gauss-Newton point dGN (Wl.step): after a rejected step (radius halved,
       // Ceres' reuse_) or when the speculative Gauss-Newton trial turned out to lie outside the trust region.
       // xv_i = g_i / Dt2_i is the Cauchy direction; its step length needs xv^T H xv, evaluated here from the damped
       // reduced matrix S (just assembled, not factorised) and one pass over the landmarks:
@@ -885,7 +956,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       const double mu = c.mu;
       for (int i = tid; i < Dpad; i += SOLVE_THREADS) {
         s_x[i] = i < D ? s_g[i] / s_d2[i] : 0.0;
-        s_rhs[i] = i < D ? W.step[i] : 0.0;
+        s_rhs[i] = i < D ? Wl.step[i] : 0.0;
       }
       __syncthreads();
       double q1 = 0, q2 = 0, Ap = 0, Al = 0, Bl = 0;
@@ -898,7 +969,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         q2 += s_d2[i] * s_x[i] * s_x[i];
         Ap += s_g[i] * s_x[i];
       }
-      dl_landmark_sums(W, acc, s_x, mu, opt, tid, &Al, &Bl);
+      dl_landmark_sums(Wl, acc, s_x, mu, opt, tid, &Al, &Bl);
       q1 = wave_sum_full(q1);
       q2 = wave_sum_full(q2);
       Ap = wave_sum_full(Ap);
@@ -933,7 +1004,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       }
       __syncthreads();
       double s2 = 0, x2 = 0;
-      trial_states(W, acc, s_x, tid, true, &s2, &x2);
+      trial_states(Wl, acc, s_x, tid, true, &s2, &x2, pre_on ? s_pre : nullptr, pre_on ? s_preoff : nullptr);
       s2 = wave_sum_full(s2);
       x2 = wave_sum_full(x2);
       if ((tid & 63) == 0) {
@@ -963,19 +1034,19 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     // hand the damped system to the tiled multi-workgroup solver (ba_chol_tiles.hpp).  S (HBM, block-packed)
     // holds the IMU / prior / marginalisation part plus the damping; large_export_kernel adds the Schur partials
     // of the pose part and writes the 48x48 tiles on many CUs; the trust-region state travels in ctrl
-    const int nT = W.ct_nT, ntile = nT * (nT + 1) / 2;
+    const int nT = Wl.ct_nT, ntile = nT * (nT + 1) / 2;
     for (int i = tid; i < nT * CT_TB; i += SOLVE_THREADS) {
-      W.ct_rhs[i] = i < Dpad ? s_rhs[i] : 0.0;
-      W.ct_g[i] = i < D ? s_g[i] : 0.0;
-      W.ct_d2[i] = i < D ? s_d2[i] : 0.0;
+      Wl.ct_rhs[i] = i < Dpad ? s_rhs[i] : 0.0;
+      Wl.ct_g[i] = i < D ? s_g[i] : 0.0;
+      Wl.ct_d2[i] = i < D ? s_d2[i] : 0.0;
     }
-    for (int i = tid; i < ntile + 1; i += SOLVE_THREADS) W.ct_flag[i] = 0;
+    for (int i = tid; i < ntile + 1; i += SOLVE_THREADS) Wl.ct_flag[i] = 0;
     for (int i = tid; i < nT * CT_TB; i += SOLVE_THREADS)
-      reinterpret_cast<unsigned long long*>(W.ct_x)[i] = CT_X_SENTINEL;   // no value yet (chol_backsub_task polls the values)
+      reinterpret_cast<unsigned long long*>(Wl.ct_x)[i] = CT_X_SENTINEL;   // no value yet (chol_backsub_task polls the values)
     __syncthreads();
     if (tid == 0) {
       *gctrl = c;
-      W.ct_flag[ntile + 1] = (opt.dogleg && c.explicit_next) ? 2 : 1;   // 2 = tiles wanted for the dogleg scalars only
+      Wl.ct_flag[ntile + 1] = (opt.dogleg && c.explicit_next) ? 2 : 1;   // 2 = tiles wanted for the dogleg scalars only
     }
     return;
   }
@@ -1012,13 +1083,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     double gd = 0, ddd = 0, s2 = 0;
     for (int i = tid; i < D; i += SOLVE_THREADS) {
       const double x = s_x[i];
-      W.step[i] = x;
+      Wl.step[i] = x;
       gd += s_g[i] * x;
       ddd += s_d2[i] * x * x;
       s2 += x * x;
     }
+    STAMP(31);
     double x2 = 0, s2a = 0;
-    trial_states(W, acc, s_x, tid, opt.dogleg != 0, &s2a, &x2);
+    trial_states(Wl, acc, s_x, tid, opt.dogleg != 0, &s2a, &x2, pre_on ? s_pre : nullptr, pre_on ? s_preoff : nullptr);
+    STAMP(32);
     if (opt.dogleg) s2 = s2a;   // Ceres' step_norm is |x - x_plus_delta| over the ambient coordinates
     __shared__ double s_sc[4][SOLVE_THREADS / 64];
     gd = wave_sum_full(gd);
@@ -1032,6 +1105,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       s_sc[3][tid >> 6] = x2;
     }
     __syncthreads();
+    STAMP(33);
     if (tid == 0) {
       double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
       for (int i = 0; i < SOLVE_THREADS / 64; ++i) {

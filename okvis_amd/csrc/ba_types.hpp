@@ -134,6 +134,13 @@ struct Ctrl {
 };
 static_assert(sizeof(Ctrl) % 8 == 0 && sizeof(Ctrl) / 8 <= 64, "Ctrl is fetched by one wave, one double per lane");
 
+// On the device every pointer of the record refers to HBM: typed as global-address-space pointers, their accesses are
+// global_load / global_store (tracked by the vector-memory counter only) instead of FLAT instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BA_G __attribute__((address_space(1)))
+#else
+#define BA_G
+#endif
 struct WinPtrs {
   // ---- sizes ----
   int n_pose, n_sb, n_lm, n_cam, n_obs, n_imu, n_pprior, n_sbprior, n_rel;
@@ -152,99 +159,99 @@ struct WinPtrs {
   ImuParamsD imu;
 
   // ---- state (index = buffer 0/1) ----
-  double* pose[2];
-  double* sb[2];
-  double* lm[2];
-  const int* pose_off;    // reduced offset or -1 (fixed)
-  const int* sb_off;
+  BA_G double* pose[2];
+  BA_G double* sb[2];
+  BA_G double* lm[2];
+  const BA_G int* pose_off;    // reduced offset or -1 (fixed)
+  const BA_G int* sb_off;
 
   // ---- structure ----
-  const double* cam_intr;
-  const int* cam_model;
-  const ObsRec* obs;
-  const Group* groups;
-  const int* pair_lm;     // [n_pair]
-  const int* pair_off;    // [n_pair] reduced offset of the pair's block
-  const int* pair_role;   // [n_pair] 0 = pose role, 1 = extrinsics role
-  const int* pair_list_begin;  // [n_pair+1] into pair_list
-  const uint16_t* pair_list;   // group-local observation indices
-  const int* lm_pair_begin;    // [n_lm+1]
-  const int* lm_obs_begin;     // [n_lm+1] observation range of each landmark (sorted order)
-  const Task* tasks;
-  const uint16_t* task_list;
-  const Chunk* chunks;
+  const BA_G double* cam_intr;
+  const BA_G int* cam_model;
+  const BA_G ObsRec* obs;
+  const BA_G Group* groups;
+  const BA_G int* pair_lm;     // [n_pair]
+  const BA_G int* pair_off;    // [n_pair] reduced offset of the pair's block
+  const BA_G int* pair_role;   // [n_pair] 0 = pose role, 1 = extrinsics role
+  const BA_G int* pair_list_begin;  // [n_pair+1] into pair_list
+  const BA_G uint16_t* pair_list;   // group-local observation indices
+  const BA_G int* lm_pair_begin;    // [n_lm+1]
+  const BA_G int* lm_obs_begin;     // [n_lm+1] observation range of each landmark (sorted order)
+  const BA_G Task* tasks;
+  const BA_G uint16_t* task_list;
+  const BA_G Chunk* chunks;
   // per-chunk lists of the per-group partials (task 'out' offsets) that sum into each pose block / cross block
-  const int* chunk_diag_begin;   // [n_chunk * (Dp/6) + 1] into chunk_diag_out
-  const int* chunk_diag_out;
-  const int* chunk_cross_begin;  // [n_chunk + 1] into chunk_cross (triples off_a, off_b, out)
-  const int* sp_blk_off;         // [Dp/6 (Dp/6+1)/2] offset (doubles) of pose block q of the partials in the solve kernel's LDS layout
-  const int* chunk_cross;
-  const int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
-  const int* imu_color_begin;    // [n_imu_color+1]
-  const int* imu_coloff;         // [n_imu][30] reduced index of each local column (or -1)
+  const BA_G int* chunk_diag_begin;   // [n_chunk * (Dp/6) + 1] into chunk_diag_out
+  const BA_G int* chunk_diag_out;
+  const BA_G int* chunk_cross_begin;  // [n_chunk + 1] into chunk_cross (triples off_a, off_b, out)
+  const BA_G int* sp_blk_off;         // [Dp/6 (Dp/6+1)/2] offset (doubles) of pose block q of the partials in the solve kernel's LDS layout
+  const BA_G int* chunk_cross;
+  const BA_G int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
+  const BA_G int* imu_color_begin;    // [n_imu_color+1]
+  const BA_G int* imu_coloff;         // [n_imu][30] reduced index of each local column (or -1)
   // level schedule of the speed/bias blocks for the LDS solve (ba_solve.hpp; layout documented where build_window makes it)
   // (the counts sbe_nlev / sbe_nblk / sbe_ntab sit with the other sizes: this region must hold pointers only, see relocate())
-  const int* sbe_tab;
-  const int2* imu_rev;           // large windows (matrix in HBM): per entry of the block-packed matrix the (up to two) IMU record
+  const BA_G int* sbe_tab;
+  const BA_G int2* imu_rev;           // large windows (matrix in HBM): per entry of the block-packed matrix the (up to two) IMU record
                                  // entries f * 512 + e that land there, or -1: gathered by large_export_kernel
-  const int4* imu_asm;           // [n_imu][512] where entry e of factor f's H|g record lands in the solve kernel's LDS
+  const BA_G int4* imu_asm;           // [n_imu][512] where entry e of factor f's H|g record lands in the solve kernel's LDS
                                  // system: x = offset | is_g << 20 | colour << 24 (or -1), y = d2 index or -1 (D <= MAX_D_LDS)
 
   // ---- linearisation (index = buffer 0/1) ----
-  double* V[2];           // [n_lm][6]
-  double* bl[2];          // [n_lm][3]
-  double* Hq[2];          // [n_lm][6]
-  double* W[2];           // [n_pair][18]
-  double* gpart[2];       // task outputs
-  double* gscal[2];       // [n_group][GS_COUNT]
-  double* imu_lin[2];     // [n_imu][IMU_LIN_STRIDE]
-  double* pp_lin[2];      // [n_pprior][36 J + 6 r]
-  double* sbp_lin[2];     // [n_sbprior][9 r]
-  double* rel_lin[2];     // [n_rel][36 J0 + 36 J1 + 6 r]
-  double* marg_lin_e[2];  // [marg_dim] e = e0 + J dchi
-  double* marg_lin_M[2];  // [marg_nb][9] rotation blocks oplus(q (x) q_lin^-1)[0:3,0:3]
-  double* small_cost[2];  // [2]: cost of priors+marg (one workgroup), spare
-  double* obs_r[2];       // [n_obs][2] (debug/parity)
+  BA_G double* V[2];           // [n_lm][6]
+  BA_G double* bl[2];          // [n_lm][3]
+  BA_G double* Hq[2];          // [n_lm][6]
+  BA_G double* W[2];           // [n_pair][18]
+  BA_G double* gpart[2];       // task outputs
+  BA_G double* gscal[2];       // [n_group][GS_COUNT]
+  BA_G double* imu_lin[2];     // [n_imu][IMU_LIN_STRIDE]
+  BA_G double* pp_lin[2];      // [n_pprior][36 J + 6 r]
+  BA_G double* sbp_lin[2];     // [n_sbprior][9 r]
+  BA_G double* rel_lin[2];     // [n_rel][36 J0 + 36 J1 + 6 r]
+  BA_G double* marg_lin_e[2];  // [marg_dim] e = e0 + J dchi
+  BA_G double* marg_lin_M[2];  // [marg_nb][9] rotation blocks oplus(q (x) q_lin^-1)[0:3,0:3]
+  BA_G double* small_cost[2];  // [2]: cost of priors+marg (one workgroup), spare
+  BA_G double* obs_r[2];       // [n_obs][2] (debug/parity)
 
   // ---- Schur / solve ----
-  double* spart;          // [n_chunk][spart_stride]: block-packed lower triangle | Y b
-  double* S;              // [D][D] debug copy of the damped reduced matrix
-  double* Sg;             // block-packed reduced matrix workspace in HBM when D > MAX_D_LDS, else null
+  BA_G double* spart;          // [n_chunk][spart_stride]: block-packed lower triangle | Y b
+  BA_G double* S;              // [D][D] debug copy of the damped reduced matrix
+  BA_G double* Sg;             // block-packed reduced matrix workspace in HBM when D > MAX_D_LDS, else null
   // tiled multi-workgroup solver of the large windows (ba_chol_tiles.hpp), null when D <= MAX_D_LDS
-  double* ct_T;           // lower 48x48 tiles
-  double* ct_Linv;        // inverses of the diagonal tiles
-  double* ct_rhs;         // [48 nT]
-  double* ct_y;           // [48 nT]
-  double* ct_x;           // [48 nT] solution of the tiled solver (sentinel until a value is final, ba_chol_tiles.hpp)
-  int* ct_flag;           // [ntiles] done flags, [ntiles] failure, [ntiles + 1] 1 = a system was exported this iteration,
+  BA_G double* ct_T;           // lower 48x48 tiles
+  BA_G double* ct_Linv;        // inverses of the diagonal tiles
+  BA_G double* ct_rhs;         // [48 nT]
+  BA_G double* ct_y;           // [48 nT]
+  BA_G double* ct_x;           // [48 nT] solution of the tiled solver (sentinel until a value is final, ba_chol_tiles.hpp)
+  BA_G int* ct_flag;           // [ntiles] done flags, [ntiles] failure, [ntiles + 1] 1 = a system was exported this iteration,
                           // [ntiles + 2] 1 = the HBM matrix Sg is all zero (cleared by the export)
-  double* ct_g;           // [48 nT] gradient of the accepted linearisation (for the step scalars)
-  double* ct_d2;          // [48 nT] damping diagonal
-  double* rhs;            // [D]
-  double* step;           // [D] reduced step of the last solve (dogleg: the Gauss-Newton point dGN)
-  double* scale_p;        // [D] Jacobi scale of the pose/speed-bias columns (first linearisation of the call)
-  double* lm_scale;       // [n_lm][3] Jacobi scale of the landmark columns
-  double* grad;           // [D]
-  double* Dp2;            // [D]
-  double* Hpp;            // [D][D] undamped U (debug/parity), optional
-  double* quality;        // [n_lm]
-  double* results;        // [7 n_pose + 9 n_sb + 4 n_lm + n_lm + 9 n_imu] packed by pack_results_kernel for okvis_ba_fetch_results
-  double* prof;           // [64] clock64() phase stamps of workgroup 0 (diagnostics)
-  Ctrl* ctrl;
+  BA_G double* ct_g;           // [48 nT] gradient of the accepted linearisation (for the step scalars)
+  BA_G double* ct_d2;          // [48 nT] damping diagonal
+  BA_G double* rhs;            // [D]
+  BA_G double* step;           // [D] reduced step of the last solve (dogleg: the Gauss-Newton point dGN)
+  BA_G double* scale_p;        // [D] Jacobi scale of the pose/speed-bias columns (first linearisation of the call)
+  BA_G double* lm_scale;       // [n_lm][3] Jacobi scale of the landmark columns
+  BA_G double* grad;           // [D]
+  BA_G double* Dp2;            // [D]
+  BA_G double* Hpp;            // [D][D] undamped U (debug/parity), optional
+  BA_G double* quality;        // [n_lm]
+  BA_G double* results;        // [7 n_pose + 9 n_sb + 4 n_lm + n_lm + 9 n_imu] packed by pack_results_kernel for okvis_ba_fetch_results
+  BA_G double* prof;           // [64] clock64() phase stamps of workgroup 0 (diagnostics)
+  BA_G Ctrl* ctrl;
 
   // ---- IMU ----
-  const int* imu_pose0; const int* imu_sb0; const int* imu_pose1; const int* imu_sb1;
+  const BA_G int* imu_pose0; const BA_G int* imu_sb0; const BA_G int* imu_pose1; const BA_G int* imu_sb1;
   const long long* imu_t0; const long long* imu_t1;
-  const int* imu_s_begin; const int* imu_s_count;
-  const long long* imu_s_t; const double* imu_s_gyr; const double* imu_s_acc;
-  ImuCacheD* imu_cache;
+  const BA_G int* imu_s_begin; const BA_G int* imu_s_count;
+  const long long* imu_s_t; const BA_G double* imu_s_gyr; const BA_G double* imu_s_acc;
+  BA_G ImuCacheD* imu_cache;
 
   // ---- priors ----
-  const int* pprior_pose; const double* pprior_meas; const double* pprior_sqrtinfo;
-  const int* sbprior_sb; const double* sbprior_meas; const double* sbprior_sqrtinfo;
-  const int* rel_pose0; const int* rel_pose1; const double* rel_sqrtinfo;
-  const int* marg_block_type; const int* marg_block_idx; const int* marg_block_off;
-  const double* marg_J; const double* marg_H0; const double* marg_e0; const double* marg_lin;
+  const BA_G int* pprior_pose; const BA_G double* pprior_meas; const BA_G double* pprior_sqrtinfo;
+  const BA_G int* sbprior_sb; const BA_G double* sbprior_meas; const BA_G double* sbprior_sqrtinfo;
+  const BA_G int* rel_pose0; const BA_G int* rel_pose1; const BA_G double* rel_sqrtinfo;
+  const BA_G int* marg_block_type; const BA_G int* marg_block_idx; const BA_G int* marg_block_off;
+  const BA_G double* marg_J; const BA_G double* marg_H0; const BA_G double* marg_e0; const BA_G double* marg_lin;
 };
 
 }  // namespace ba

@@ -16,3 +16,6 @@ prev = 0
 for k, n in names:
     print("  %-34s %8.0f ticks %7.2f us" % (n, p[k] - p[prev], (p[k] - p[prev]) / T)); prev = k
 print("  total %.2f us" % ((p[9] - p[0]) / T))
+print("  convergence test %.2f us, damping (+ debug copies) %.2f us" % ((p[30] - p[5]) / T, (p[6] - p[30]) / T))
+print("  tail: step vector %.2f, trial states %.2f, sums + barrier %.2f, ctrl %.2f us" % ((p[31] - p[7]) / T, (p[32] - p[31]) / T, (p[33] - p[32]) / T, (p[9] - p[33]) / T))
+print("  trial states: poses %.2f us, speed/bias %.2f us" % ((p[34] - p[31]) / T, (p[32] - p[34]) / T))
