@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--total-windows", type=int, default=0,
                    help="BASELINE configs[3]: this many windows IN TOTAL, window i on rank i mod N (strong scaling); "
                         "overrides --windows")
-    p.add_argument("--repeats", type=int, default=15, help="timed regions of --steps iterations each (median / p10 / p90)")
+    p.add_argument("--repeats", type=int, default=50, help="timed regions of --steps iterations each (median / p10 / p90)")
     p.add_argument("--streams", type=int, default=0, help="sub-batch streams (0 = auto)")
     p.add_argument("--keyframes", type=int, default=10)
     p.add_argument("--landmarks", type=int, default=400)
@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--cpu-iters", type=int, default=0, help="oracle iterations for the CPU baseline (0 = auto ~12 s)")
     p.add_argument("--profile-steps", type=int, default=20, help="eager per-kernel HIP-event pass for the roofline")
     p.add_argument("--fp32", action="store_true", help="BASELINE configs[4]: fp32 Jacobian/Hessian build, fp64 solve (dtype f32+f64)")
+    p.add_argument("--no-extras", action="store_true", help="skip the dogleg / configs[2] / strong-scaling sub-records")
     p.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE passes (roofline.traffic = null)")
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return p.parse_args()
@@ -164,71 +165,83 @@ def main():
     # {window_id, iterations, final_cost (filled after finish), seconds}; ranks with fewer windows pad with id -1
     summaries = None
 
-    # ---- per-kernel attribution for the roofline (eager launches bracketed by HIP events) ----
+    # ---- per-kernel attribution for the roofline (eager launches bracketed by HIP events on the solver's stream) ----
     roofline = None
     if rank == 0 and a.profile_steps > 0:
-        # per-launch durations of an eager pass bracketed by HIP events on the solver's stream; the MEDIAN launch is what
-        # the roofline uses.  Launches in which an IMU factor re-preintegrates (the slowest workgroup of the linearise
-        # launch, ~100 us) are reported separately: they depend on how far the biases move, not on the kernel.
-        pl = batch.profile_launches(max(a.profile_steps, 30))
-        prof = {k: float(np.median(v)) for k, v in pl.items()}          # ms per launch
-        slow = pl["linearize"] > 1.5 * prof["linearize"]
-        nbytes = batch.algorithmic_bytes()
-        nbytes["linearize"] += nbytes.pop("small")
-        # dominant kernel = most GPU time, i.e. launch time x the share of the 256 CUs the launch fills (the solve
-        # kernel runs ONE workgroup per window on one CU each: at 64 windows it lasts as long as the linearise launch
-        # but occupies a quarter of the device)
         st = solver.check_window(wins[0])
+        D_red = int(st["D"])
         n_cu, wg_per_cu = 256, 2
-        share = {"solve": min(1.0, a.windows / n_cu),
-                 "linearize": min(1.0, (st["n_group"] + a.keyframes) * a.windows / (n_cu * wg_per_cu)),
-                 "schur": min(1.0, st["n_chunk"] * a.windows / (n_cu * wg_per_cu))}
-        dom = max(prof, key=lambda k: prof[k] * share[k])
-        per_launch_s = prof[dom] * 1e-3
-        achieved = nbytes[dom] / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-        pmc = None if (a.no_pmc or world > 1) else pmc_traffic(a, dom)
-        # fp64 work of the linearise launch (~1.25 kflop per observation for residual + Jacobian +
-        # J^T J / J^T r, + 0.25 kflop for the cost): what the vector ALUs have to issue, against the fp64 vector peak
-        lin_flops = 1.5e3 * sum(w.n_obs for w in wins)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None if pmc is None else pmc["bytes"],
-                    "traffic_detail": pmc,
-                    "measured_traffic_frac": None if pmc is None else pmc["bytes"] / per_launch_s / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": nbytes[dom], "avg_launch_us": per_launch_s * 1e6,
-                    "launch_us": {k: {"median": float(np.median(v)) * 1e3, "p10": float(np.percentile(v, 10)) * 1e3,
-                                      "p90": float(np.percentile(v, 90)) * 1e3, "n": int(v.size)} for k, v in pl.items()},
-                    "linearize_launches_with_imu_redo": {"count": int(slow.sum()),
-                                                         "mean_us": float(pl["linearize"][slow].mean() * 1e3) if slow.any() else None},
-                    "fp64": {"kernel": "linearize", "flops_per_launch": lin_flops,
-                             "achieved_tflops": lin_flops / (prof["linearize"] * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS,
-                             "frac": lin_flops / (prof["linearize"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
-                    "per_kernel_us": {k: v * 1e3 for k, v in prof.items()},
-                    "per_kernel_algorithmic_bytes": nbytes, "per_kernel_cu_share": share,
-                    "note": "dominant kernel = largest MEDIAN launch time x share of the CUs it fills; achieved = its "
-                            "algorithmic (requested) bytes / median launch time.  Counters (profiles/) show the launch "
-                            "latency-bound, neither HBM- nor FMA-bound: measured_traffic_frac (TCC bytes / 8 TB/s) and fp64.frac "
-                            "say how far from either roof; W / V / b round trips between launches are served by L2 / "
-                            "Infinity Cache, so measured traffic is below the algorithmic bytes"}
-        # the timed loop does not launch all windows at once: it runs n_streams sub-batches side by side.  Launch medians at
-        # THAT shape (one sub-batch alone on the device) and which kernel the stream time goes to.
+
+        def flops_per_launch(nw):
+            # ~1.5 kflop per observation (residual + 2x15 Jacobian + J^T J / J^T r + cost) in the linearise
+            # launch; landmark Schur complement 3 E_l^2 per landmark (E_l = 6 x blocks seeing it); reduced solve D^3 / 3 + 2 D^2
+            obs = sum(w.n_obs for w in wins[:nw])
+            lm = sum(w.n_lm for w in wins[:nw])
+            E = 6.0 * a.keyframes
+            return {"linearize": 1.5e3 * obs, "schur": 3.0 * E * E * lm, "solve": nw * (D_red ** 3 / 3.0 + 2.0 * D_red ** 2)}
+
+        def kernel_table(b, nw):
+            """median launch time (us) per kernel of batch b (nw windows per launch), with both roofline fractions"""
+            pl = b.profile_launches(max(a.profile_steps, 30))
+            nbytes = b.algorithmic_bytes()
+            nbytes["linearize"] += nbytes.pop("small")
+            fl = flops_per_launch(nw)
+            share = {"solve": min(1.0, nw / n_cu),
+                     "linearize": min(1.0, (st["n_group"] + a.keyframes) * nw / (n_cu * wg_per_cu)),
+                     "schur": min(1.0, st["n_chunk"] * nw / (n_cu * wg_per_cu))}
+            out = {}
+            for k, v in pl.items():
+                us = float(np.median(v)) * 1e3
+                gbs = nbytes[k] / (us * 1e-6) / 1e9
+                tf = fl[k] / (us * 1e-6) / 1e12
+                out[k] = {"launch_us": us, "p10_us": float(np.percentile(v, 10)) * 1e3, "p90_us": float(np.percentile(v, 90)) * 1e3,
+                          "n": int(v.size), "algorithmic_bytes": nbytes[k], "achieved_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                          "flops": fl[k], "achieved_tflops": tf, "fp64_frac": tf / FP64_PEAK_TFLOPS, "cu_share": share[k]}
+            slow = pl["linearize"] > 1.5 * float(np.median(pl["linearize"]))
+            return out, {"count": int(slow.sum()), "mean_us": float(pl["linearize"][slow].mean() * 1e3) if slow.any() else None}
+
+        # (a) the shape the timed loop launches: n_streams sub-batches side by side, each a dependent chain schur -> solve ->
+        #     linearise.  The roofline entry names the kernel that takes most of that chain.
         nst = a.streams if a.streams > 0 else (3 if a.windows >= 48 else 2 if a.windows >= 16 else 1)
         sub = (a.windows + nst - 1) // nst
         bs = solver.WindowBatch(wins[:sub], device=local_rank, options=opt)
         bs.begin()
-        pls = {k: float(np.median(v)) * 1e3 for k, v in bs.profile_launches(30).items()}
-        sb_bytes = bs.algorithmic_bytes()
+        loop_tab, _ = kernel_table(bs, sub)
         bs.finish()
         bs.close()
-        chain = sum(pls.values())
-        tdom = max(pls, key=pls.get)
-        roofline["timed_loop_shape"] = {
-            "streams": nst, "windows_per_launch": sub, "launch_us": pls, "stream_chain_us": chain,
-            "measured_us_per_step": wall * 1e6 / a.steps, "time_dominant_kernel": tdom,
-            "time_dominant_share_of_chain": pls[tdom] / chain,
-            "time_dominant_algorithmic_GBps": sb_bytes[tdom] / (pls[tdom] * 1e-6) / 1e9,
-            "note": "one iteration of a sub-batch is the dependent chain schur -> solve -> linearise on its stream; the solve "
-                    "kernel (one 1024-thread workgroup per window, a 25-step block Cholesky in LDS) takes the same time for 1 "
-                    "window or 64: it is bound by the latency of its dependent phases, not by HBM or the FMA rate"}
+        chain = sum(v["launch_us"] for v in loop_tab.values())
+        dom = max(loop_tab, key=lambda k: loop_tab[k]["launch_us"])
+        # (b) all windows of the GPU in one launch (the launch that fills the device: the linearise kernel)
+        full_tab, redo = kernel_table(batch, a.windows)
+        pmc = None if (a.no_pmc or world > 1) else pmc_traffic(a, dom)
+        pmc_lin = None if (a.no_pmc or world > 1 or dom == "linearize") else pmc_traffic(a, "linearize")
+        d = loop_tab[dom]
+        roofline = {
+            # the time-dominant kernel at the launch shape of the timed loop.  "latency": the SQ counters (profiles/) show its
+            # waves waiting (dependent LDS / flag round trips of the block factorisation), neither roof is close; achieved /
+            # peak / frac are its algorithmic bytes against the HBM roof, fp64 its flops against the fp64 (vector = matrix) peak
+            "bound": "latency", "kernel": dom, "launch_shape": {"streams": nst, "windows_per_launch": sub},
+            "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["hbm_frac"],
+            "traffic": None if pmc is None else pmc["bytes"], "traffic_detail": pmc,
+            "traffic_note": "PMC pass runs all windows in one launch (eager): bytes per launch of that shape" if pmc else None,
+            "avg_launch_us": d["launch_us"], "algorithmic_bytes_per_launch": d["algorithmic_bytes"],
+            "fp64": {"kernel": dom, "flops_per_launch": d["flops"], "achieved_tflops": d["achieved_tflops"],
+                     "peak_tflops": FP64_PEAK_TFLOPS, "frac": d["fp64_frac"]},
+            "share_of_stream_chain": d["launch_us"] / chain, "stream_chain_us": chain,
+            "measured_us_per_step": wall * 1e6 / a.steps,
+            "kernels_timed_loop_shape": loop_tab,
+            "kernels_all_windows_one_launch": full_tab,
+            "device_filling_kernel": {"kernel": "linearize", "windows_per_launch": a.windows, **full_tab["linearize"],
+                                      "traffic": None if pmc_lin is None else pmc_lin["bytes"],
+                                      "measured_traffic_frac": None if pmc_lin is None else
+                                      pmc_lin["bytes"] / (full_tab["linearize"]["launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
+            "launch_us": {k: {"median": v["launch_us"], "p10": v["p10_us"], "p90": v["p90_us"], "n": v["n"]} for k, v in full_tab.items()},
+            "linearize_launches_with_imu_redo": redo,
+            "note": "one iteration of a sub-batch is the dependent chain schur -> solve -> linearise on its stream; `kernel` is the "
+                    "longest link of that chain.  The solve kernel is one 1024-thread workgroup per window (decision, assembly, "
+                    "blocked LDL^T on the fp64 matrix core with a one-wave diagonal chain, back-substitution, trial states); the "
+                    "linearise launch is the one that fills all CUs (device_filling_kernel).  Algorithmic bytes / flops per "
+                    "SURVEY.md section 8d; W / V / b round trips between launches are served by L2 / Infinity Cache"}
     summaries = batch.finish()
     n_rec = (a.total_windows + world - 1) // world if a.total_windows > 0 else a.windows
     rec = []
@@ -305,6 +318,88 @@ def main():
                                 f"), one window of the batch each, {n_each} iterations per window, {tm:.1f} s",
                       "speedup_over_1_core": vm / v1}
 
+    # ---- the reference's configured mode: DOGLEG with default tolerances from the perturbed start, optimize(10) per window
+    #      (Estimator::optimize, Estimator.cpp:843-906: first-linearisation redoPreintegration included) over fresh windows
+    dogleg = None
+    config_c = None
+    strong = None
+    if rank == 0 and not a.no_extras and not a.pmc_child:
+        dopt = default_options()
+        dopt.use_graph = 0 if a.no_graph else 1
+        dopt.n_streams = a.streams
+        n_batches, per_batch = 4, max(16, min(64, a.windows))
+        it_total = slot_total = redo_total = 0
+        t_total = 0.0
+        term = {}
+        for bi in range(n_batches + 1):   # the first batch warms the graph cache up and is not counted
+            fresh = [synthetic.make_window(a.keyframes, a.landmarks, a.visibility, 7_000_000 + 1000 * bi + i) for i in range(per_batch)]
+            bd = solver.WindowBatch(fresh, device=local_rank, options=dopt)
+            bd.synchronize()
+            t0 = time.perf_counter()
+            sm = bd.optimize(10)
+            bd.synchronize()
+            dt = time.perf_counter() - t0
+            if bi > 0:
+                t_total += dt
+                it_total += sum(x["iterations"] for x in sm)
+                slot_total += int(bd.array("SLOTS")[0]) * per_batch
+                redo_total += int(sum(bd.array("IMU_REDO_COUNT", w).sum() for w in range(per_batch)))
+                for x in sm:
+                    term[x["termination"]] = term.get(x["termination"], 0) + 1
+            bd.close()
+        dogleg = {"mode": "DOGLEG, Jacobi scaling, default tolerances (Estimator.cpp:854-873), optimize(10) from the perturbed start",
+                  "windows": n_batches * per_batch, "windows_per_call": per_batch,
+                  "counted_iterations": it_total, "iterations_per_s": it_total / t_total,
+                  "windows_per_s": n_batches * per_batch / t_total, "ms_per_optimize_call": t_total / n_batches * 1e3,
+                  "launch_slots": slot_total, "launch_slots_per_counted_iteration": slot_total / max(1, it_total),
+                  "imu_repreintegrations": redo_total, "imu_repreintegrations_per_factor": redo_total / max(1, n_batches * per_batch * fresh[0].n_imu),
+                  "termination_histogram": {str(k): v for k, v in sorted(term.items())},
+                  "note": "wall time of okvis_ba_optimize (begin + first linearisation incl. IMU re-preintegration + 10 iteration "
+                          "slots + top-up slots + final decision + landmark quality), upload excluded; a launch slot is one schur + "
+                          "solve + linearise triple for the whole batch; termination 0 = iteration cap, 1 = function tolerance"}
+        # ---- BASELINE configs[2]: 50 keyframes / 2000 landmarks / 200 000 observations (HBM-resident tiled solve), one window
+        wc = synthetic.config_C(seed=20240923, visibility=a.visibility)
+        bc = solver.WindowBatch([wc], device=local_rank, options=opt)
+        bc.begin()
+        bc.iterate(5)
+        bc.synchronize()
+        msc = []
+        for _ in range(7):
+            bc.iterate(20)
+            bc.synchronize()
+            msc.append(bc.last_iterate_ms() / 20)
+        plc = {k: float(np.median(v)) * 1e3 for k, v in bc.profile_launches(12).items()}
+        bc.finish()
+        bc.close()
+        config_c = {"workload": f"1 window, 50 KF / 2 cam / 2000 landmarks / {wc.n_obs} observations, D = {wc.reduced_dim()}, Gauss-Newton mode",
+                    "ms_per_iteration": float(np.median(msc)), "iterations_per_s": 1e3 / float(np.median(msc)),
+                    "launch_us": plc, "note": "launch_us.solve = assembly + tile export + tiled fp64-MFMA Cholesky + tail (four launches)"}
+    if not a.no_extras and not a.pmc_child and world > 1 and a.total_windows == 0:
+        # ---- BASELINE configs[3] as written: 64 windows IN TOTAL over the ranks (strong scaling), next to the weak line
+        tw = 64
+        ids_s = D.shard_windows(tw, rank, world)
+        wins_s = [synthetic.make_window(a.keyframes, a.landmarks, a.visibility, 20240923 + i) for i in ids_s]
+        bsx = solver.WindowBatch(wins_s, device=local_rank, options=opt)
+        bsx.begin()
+        bsx.iterate(a.warmup)
+        bsx.iterate(a.steps)
+        ws = []
+        for _ in range(max(5, a.repeats // 5)):
+            barrier()
+            t0 = time.perf_counter()
+            bsx.iterate(a.steps)
+            bsx.synchronize()
+            if dist is not None:
+                dist.barrier()
+            ws.append(D.max_over_ranks(dist, time.perf_counter() - t0))
+        bsx.finish()
+        bsx.close()
+        if rank == 0:
+            wmed = float(np.median(ws))
+            strong = {"total_windows": tw, "windows_on_rank0": len(wins_s), "ranks": world,
+                      "backend": dist.get_backend() if dist is not None else None,
+                      "value": tw * a.steps / wmed, "unit": "iterations/s", "ms_per_step": wmed * 1e3 / a.steps,
+                      "scaling": "strong", "note": "BASELINE configs[3]: 64 independent windows sharded over the GPUs (8 per GPU at 8 GPUs)"}
     if rank == 0:
         n_windows_total = a.total_windows if a.total_windows > 0 else world * a.windows
         total_iters = n_windows_total * a.steps
@@ -329,7 +424,9 @@ def main():
                                               "max": max(walls) * 1e3 / a.steps}},
             "window_records": {"fields": ["window_id", "iterations", "final_cost", "seconds"], "n": len(records),
                                "first": records[:2], "collective": (f"one all_gather, backend {dist.get_backend()}" + (" (= RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else "none (1 rank)"},
-            "single_window": single, "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
+            "single_window": single, "roofline": roofline, "dogleg": dogleg, "config_C": config_c, "strong_scaling_64_windows": strong,
+            "ranks_seen_by_collective": world if dist is None else dist.get_world_size(),
+            "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "speedup_vs_cpu": None if cpu is None else {
                 "single_window_vs_1_core": single["iterations_per_s"] / cpu["value"],
                 "batch_vs_all_cores": None if cpu_mt is None else value / cpu_mt["value"],

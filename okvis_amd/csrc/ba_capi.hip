@@ -121,7 +121,8 @@ struct okvis_ba_solver {
   bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
-  int max_sbl_blk = 0, max_sbl_stage = 0, max_sbl_tab = 0;   // LDS of the speed/bias level schedule over the small windows
+  int max_sbl_blk = 0, max_sbl_stage = 0, max_sbl_tab = 0;   // (unused since the LDL^T solver replaced the level schedule)
+  long long slots = 0;   // launch slots (schur + solve + linearise triples) since okvis_ba_begin: diagnostics (array 96)
   std::map<int, hipGraphExec_t> graphs;
   std::map<std::pair<int, int>, hipGraphExec_t> sub_graphs;  // (n, sub) -> graph of that sub-batch's chain
   float last_iterate_ms = 0.f;
@@ -1399,6 +1400,7 @@ int okvis_ba_begin(okvis_ba_solver* s) {
   if (!s) return OKVIS_BA_ERR_ARG;
   if (!s->uploaded) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
+  s->slots = 0;
   for (auto& H : s->wins) {
     const int acc = H.acc, tr = 1 - acc;
     HIP_TRY(hipMemcpyAsync(H.ptrs.pose[tr], H.ptrs.pose[acc], 56 * (size_t)H.n_pose, hipMemcpyDeviceToDevice, s->stream));
@@ -1426,6 +1428,7 @@ int okvis_ba_iterate(okvis_ba_solver* s, int n) {
   if (!s->begun) return OKVIS_BA_ERR_STATE;
   if (n == 0) return OKVIS_BA_OK;
   HIP_TRY(hipSetDevice(s->device));
+  s->slots += n;
   HIP_TRY(hipEventRecord(s->ev0, s->stream));
   const int nsub = (int)s->sub_streams.size();
   if (s->opt.use_graph && nsub > 1) {
@@ -1513,6 +1516,7 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
         need = std::max(need, k);
       }
       if (need <= 0) break;
+      s->slots += need;
       for (int i = 0; i < need; ++i) HIP_TRY(launch_iteration(s, whole(s)));
       HIP_TRY(launch_schur(s, whole(s), 1));
       HIP_TRY(launch_solve(s, whole(s), 1));
@@ -1634,6 +1638,7 @@ static int locate(okvis_ba_solver* s, int w, int which, const double** ptr, int6
     case 99: *ptr = P.prof; *n = 64 + 4 * 160; return P.prof ? 0 : OKVIS_BA_ERR_STATE;
     case 98: *ptr = nullptr; *n = H.n_imu; return 0;  // diagnostics: re-preintegration count per IMU factor
     case 97: *ptr = nullptr; *n = 24; return 0;       // diagnostics: trust-region control record
+    case 96: *ptr = nullptr; *n = 1; return 0;        // diagnostics: launch slots since okvis_ba_begin
     case OKVIS_BA_ARR_IMU_SB_REF: *ptr = nullptr; *n = 9 * (int64_t)H.n_imu; return 0;
     case OKVIS_BA_ARR_IMU_RESIDUAL: *ptr = nullptr; *n = 15 * (int64_t)H.n_imu; return 0;
   }
@@ -1661,6 +1666,10 @@ int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t
     if (H.n_imu > 0)
       HIP_TRY(hipMemcpy2D(out, 9 * sizeof(double), reinterpret_cast<const unsigned char*>(H.ptrs.imu_cache) + offsetof(ImuCacheD, sb_ref),
                           sizeof(ImuCacheD), 9 * sizeof(double), (size_t)H.n_imu, hipMemcpyDeviceToHost));
+    return OKVIS_BA_OK;
+  }
+  if (which == 96) {   // diagnostics: launch slots since okvis_ba_begin (the same for every window of the batch)
+    out[0] = (double)s->slots;
     return OKVIS_BA_OK;
   }
   if (which == 97) {

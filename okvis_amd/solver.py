@@ -16,7 +16,7 @@ from . import _lib
 from .window import LimitsC, OptionsC, SummaryC, Window, WindowC, default_options
 
 ARR = dict(POSE=0, SB=1, LM=2, OBS_RESIDUAL=3, LM_V=4, LM_B=5, LM_HQ=6, PAIR_W=7, REDUCED_S=8,
-           REDUCED_RHS=9, STEP=10, LM_QUALITY=11, GRADIENT=12, IMU_RESIDUAL=13, HPP=14, DAMPING=15, IMU_SB_REF=16, PROF=99, IMU_REDO_COUNT=98, CTRL=97)
+           REDUCED_RHS=9, STEP=10, LM_QUALITY=11, GRADIENT=12, IMU_RESIDUAL=13, HPP=14, DAMPING=15, IMU_SB_REF=16, PROF=99, IMU_REDO_COUNT=98, CTRL=97, SLOTS=96)
 _dp = C.POINTER(C.c_double)
 
 
