@@ -119,9 +119,10 @@ struct okvis_ba_solver {
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
   bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
-  int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0;
+  int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0, max_spart_stride = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
   int max_sbl_blk = 0, max_sbl_stage = 0, max_sbl_tab = 0;   // (unused since the LDL^T solver replaced the level schedule)
+  long long stagger_ticks = 0;   // start offset between consecutive sub-batch streams (wall_clock64 ticks, 100 MHz); OKVIS_BA_STAGGER_US
   long long slots = 0;   // launch slots (schur + solve + linearise triples) since okvis_ba_begin: diagnostics (array 96)
   std::map<int, hipGraphExec_t> graphs;
   std::map<std::pair<int, int>, hipGraphExec_t> sub_graphs;  // (n, sub) -> graph of that sub-batch's chain
@@ -823,6 +824,9 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (opt.debug_arrays) OFF(obs_r[b], put_zero(A, 16 * (size_t)nobs));
   }
   OFF(spart, put_zero(A, 8 * (size_t)std::max(nchunk, 1) * (size_t)spart_stride));
+  OFF(spart_sum, put_zero(A, 8 * (size_t)std::max(spart_stride, 1)));
+  OFF(sum_sync, put_zero(A, 16));
+  OFF(dec, put_zero(A, 8 * (size_t)DEC_COUNT));
   if (opt.debug_arrays) {
     OFF(S, put_zero(A, 8 * (size_t)D * D));
     OFF(rhs, put_zero(A, 8 * (size_t)D));
@@ -960,6 +964,12 @@ size_t solve_smem(int Dpad, bool large, int, int, int) {
 }
 size_t small_smem() { return (size_t)std::max<int>(std::max<int>(ImuLds::TOTAL, EvalLds::TOTAL), 2 * MAX_MARG_DIM) * sizeof(double); }
 
+// keeps one wave busy for `ticks` of the 100 MHz wall clock (the start stagger of the sub-batch streams)
+__global__ void delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 struct Sub {
   hipStream_t st;
   int w0, nw;
@@ -976,7 +986,7 @@ hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
 }
 hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
   if (s->max_Dpad_small > 0)
-    hipLaunchKernelGGL(solve_kernel<false>, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false, s->max_sbl_blk, s->max_sbl_stage, s->max_sbl_tab), b.st,
+    hipLaunchKernelGGL(solve_kernel<false>, dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false, s->max_sbl_blk, s->max_sbl_stage, s->max_sbl_tab), b.st,
                        s->d_wins + b.w0, s->d_opt, final_only);
   if (s->max_Dpad_large > 0) {
     // large windows: assemble + export, tiled multi-workgroup Cholesky (fp64 MFMA), back-substitution + finish
@@ -1124,6 +1134,10 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   okvis_ba_solver* s = new okvis_ba_solver();
   s->device = device;
   okvis_ba_default_options(&s->opt);
+  {   // start offset of the sub-batch streams (us; default 20: measured 20 / 45 / 70 us all lock the fast interleaving; 0 = none)
+    const char* e = std::getenv("OKVIS_BA_STAGGER_US");
+    s->stagger_ticks = (long long)((e ? std::atof(e) : 20.0) * 100.0);
+  }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&s->ev0);
@@ -1242,7 +1256,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   if (A.zsize) HIP_TRY(hipMemsetAsync(zbase, 0, A.zsize, s->stream));   // overlaps with the copy below
   HIP_TRY(hipMemcpyAsync(s->d_arena, A.host.data(), A.size, hipMemcpyHostToDevice, s->stream));
   std::vector<WinPtrs> ptrs(n_windows);
-  s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = 0;
+  s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = s->max_spart_stride = 0;
   s->max_Dpad_small = s->max_Dpad_large = 0;
   s->max_sbl_blk = s->max_sbl_stage = s->max_sbl_tab = 0;
   s->any_ext = false;
@@ -1253,6 +1267,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     s->max_group = std::max(s->max_group, P.n_group);
     s->max_imu = std::max(s->max_imu, P.n_imu);
     s->max_schur_blocks = std::max(s->max_schur_blocks, P.n_chunk * (P.n_tile * (P.n_tile + 1) / 2));
+    s->max_spart_stride = std::max(s->max_spart_stride, P.spart_stride);
     s->max_lm = std::max(s->max_lm, P.n_lm);
     s->max_Dpad = std::max(s->max_Dpad, ((P.D + 5) / 6) * 6);
     s->max_Dp = std::max(s->max_Dp, P.Dp);
@@ -1454,6 +1469,13 @@ int okvis_ba_iterate(okvis_ba_solver* s, int n) {
         exec = it->second;
       }
       HIP_TRY(hipStreamWaitEvent(s->sub_streams[k], s->ev_fork, 0));
+      // the sub-batches start staggered by a third (1 / nsub) of one iteration chain: started together, the streams lock into
+      // one of two interleavings (0.162 or 0.179 ms per step at 64 windows, whole timed regions in either); the stagger
+      // starts them in the pipelined pattern
+      if (k > 0 && s->stagger_ticks > 0) {
+        hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s->sub_streams[k], (long long)k * s->stagger_ticks);
+        HIP_TRY(hipGetLastError());
+      }
       HIP_TRY(hipGraphLaunch(exec, s->sub_streams[k]));
       HIP_TRY(hipEventRecord(s->sub_events[k], s->sub_streams[k]));
       HIP_TRY(hipStreamWaitEvent(s->stream, s->sub_events[k], 0));
@@ -1963,7 +1985,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   s->begun = false;
   const Sub one{s->stream, w, 1};
   HIP_TRY(launch_schur(s, one));
-  hipLaunchKernelGGL(solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false, s->max_sbl_blk, s->max_sbl_stage, s->max_sbl_tab), s->stream, d_win,
+  hipLaunchKernelGGL(solve_kernel<false>, dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false, s->max_sbl_blk, s->max_sbl_stage, s->max_sbl_tab), s->stream, d_win,
                      s->d_opt, 2);
   HIP_TRY(hipGetLastError());
   MargArgs ma;

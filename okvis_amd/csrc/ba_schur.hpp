@@ -77,6 +77,14 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
         wave_trial_sums(W, 1 - acc, tid, sums);
         DecisionDL d;
         decide_dl(&s_ctrl, &opt, sums, final_call, &d);
+        if (bx == 0 && tid == 0) {   // published for the solve kernel (it would compute exactly this)
+          auto o = W.dec;
+          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
+          o[DEC_DL + 0] = d.accept; o[DEC_DL + 1] = d.term; o[DEC_DL + 2] = d.explicit_next; o[DEC_DL + 3] = d.judged;
+          o[DEC_DL + 4] = d.invalid_steps; o[DEC_DL + 5] = d.have_tot; o[DEC_DL + 6] = d.radius; o[DEC_DL + 7] = d.mu;
+          o[DEC_DL + 8] = d.rho; o[DEC_DL + 9] = d.model_change; o[DEC_DL + 10] = d.tot_C; o[DEC_DL + 11] = d.tot_E;
+          o[DEC_VALID] = 1.0;
+        }
         if (d.accept) acc = 1 - acc;
         term = d.term;
         mu = d.mu;
@@ -93,6 +101,13 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
         wave_trial_sums(W, 1 - acc, tid, sums);
         Decision d;
         decide(&s_ctrl, &opt, sums, &d);
+        if (bx == 0 && tid == 0) {
+          auto o = W.dec;
+          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
+          o[DEC_LM + 0] = d.accept; o[DEC_LM + 1] = d.term; o[DEC_LM + 2] = d.radius; o[DEC_LM + 3] = d.decrease_factor;
+          o[DEC_LM + 4] = d.rho; o[DEC_LM + 5] = d.model_change;
+          o[DEC_VALID] = 1.0;
+        }
         if (d.accept) acc = 1 - acc;
         radius = d.radius;
         term = d.term;

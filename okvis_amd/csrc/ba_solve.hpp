@@ -129,6 +129,8 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Xout) {
 
 constexpr int SOLVE_LDS_LIMIT = 150 * 1024;   // dynamic LDS of the solve kernel (160 KB per workgroup minus its static arrays, about 8.5 KB)
 constexpr int PRI_STAGE = 2;  // pose / speed-bias priors whose records the solve kernel stages in LDS ahead of time
+constexpr int SOLVE_HELPERS = 4;   // workgroups per window (blockIdx.y < SOLVE_HELPERS) that sum the Schur chunk partials for the solving one
+constexpr int SOLVE_HELPED_MAX_WINDOWS = 8;   // launches of more windows sum inside the solving workgroup (a helper takes a whole CU)
 constexpr int PRE_BLOCKS = 32;  // pose / speed-bias blocks whose accepted values the solve kernel stages in LDS ahead of time
 
 // IMU Hessian blocks, priors and the marginalisation prior of linearisation buffer `acc`, accumulated into S
@@ -487,6 +489,49 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   if (LARGE != (W.Sg != nullptr)) return;  // each window is handled by the instantiation that fits it
   Ctrl* gctrl = W.ctrl;
   const int tid = threadIdx.x;
+  if constexpr (!LARGE) {
+    // ---- helper workgroups (blockIdx.y < gridDim.y - 1; dispatched before the solving workgroup of their window): the sum
+    // of the Schur chunk partials, one item (double of the partials' record) per work-item, every chunk requested at once and
+    // added in chunk order.  One CU pulling the partials alone could keep only so many loads in flight (11.5 of the solve
+    // kernel's 52 us); four more CUs do it while the solving workgroup takes the trust-region decision.  Every helper arrives
+    // exactly once per launch (also for a finished window), the solving workgroup counts the launches: the two stay in step.
+    if (blockIdx.y + 1 < gridDim.y) {   // (the last workgroup in y is the solving one; launches of many windows have no helpers)
+      const int nh = (int)gridDim.y - 1;
+      const int ntot = W.spart_stride, per = (ntot + nh - 1) / nh;
+      if (W.n_chunk > 0) {   // (also for a finished window: the sums are not used then, but nothing has to be read to find out)
+        for (int k = tid; k < per; k += SOLVE_THREADS) {
+          const int i = blockIdx.y * per + k;
+          if (i >= ntot) break;
+          const size_t stride = W.spart_stride;
+          const int nch = W.n_chunk;
+          auto sp = W.spart + i;
+          double a = 0;
+          for (int ch = 0; ch < nch; ch += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += v[u];
+          }
+          W.spart_sum[i] = a;
+        }
+      }
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(W.sum_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  // (solving workgroup) helpers delivered so far must reach SOLVE_HELPERS x the number of solve launches of this window
+  // (work-item 64 alone keeps this book and polls; the other waves follow its LDS flag)
+  int sum_expected = 0;
+  __shared__ int s_sum_ready;   // 1 = the helpers' sums are there, 2 = they never arrived
+  const bool helped = !LARGE && gridDim.y > 1;   // small launches only: a helper occupies a whole CU (the kernel's LDS footprint)
+  if (!LARGE && tid == 64) {
+    sum_expected = W.sum_sync[1] + ((int)gridDim.y - 1);   // helper arrivals this window must have seen after this launch
+    W.sum_sync[1] = sum_expected;
+    s_sum_ready = helped ? 0 : 1;
+  }
   // The window record (sizes and ~140 pointers, 1.3 KB in HBM) is copied to LDS once: every later W.field is an LDS read
   // instead of a scalar load that misses its cache line by line (measured: 3 us of the 4.6 us tail were such misses)
   __shared__ double s_Wd[(sizeof(WinPtrs) + 7) / 8];
@@ -531,6 +576,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     imu_d2[j] = -1;
     imu_rc[j] = 0;
   }
+  const double dec_pref = (!LARGE && tid < DEC_COUNT) ? W.dec[tid] : 0.0;   // the Schur kernel's decision record (wave 0 reads it below)
   // the Jacobi scale of this lane's column (used by the damping, section 4): requested now, the value is only wrong in the
   // launch that estimates it
   const double scale_pref = (tid < D && opt.dogleg) ? W.scale_p[tid] : 1.0;
@@ -605,9 +651,29 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     DecisionDL dl;
     dl.accept = 0; dl.term = 0; dl.explicit_next = 0; dl.judged = 0;
     if (pending) {
-      wave_trial_sums(W, 1 - c.acc, tid, sums);
-      if (opt.dogleg) decide_dl(&c, &opt, sums, final_only != 0, &dl);
-      else decide(&c, &opt, sums, &d);
+      // the Schur kernel of this iteration has taken the decision on the same inputs with the same function and left it in
+      // W.dec (requested together with the control record above); without a Schur launch it is computed here
+      __shared__ double s_dec[DEC_COUNT];
+      if (tid < DEC_COUNT) s_dec[tid] = dec_pref;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      asm volatile("" ::: "memory");
+      if (s_dec[DEC_VALID] != 0.0) {
+        for (int k = 0; k < 6; ++k) sums[k] = s_dec[DEC_SUMS + k];
+        if (opt.dogleg) {
+          dl.accept = (int)s_dec[DEC_DL + 0]; dl.term = (int)s_dec[DEC_DL + 1]; dl.explicit_next = (int)s_dec[DEC_DL + 2];
+          dl.judged = (int)s_dec[DEC_DL + 3]; dl.invalid_steps = (int)s_dec[DEC_DL + 4]; dl.have_tot = (int)s_dec[DEC_DL + 5];
+          dl.radius = s_dec[DEC_DL + 6]; dl.mu = s_dec[DEC_DL + 7]; dl.rho = s_dec[DEC_DL + 8]; dl.model_change = s_dec[DEC_DL + 9];
+          dl.tot_C = s_dec[DEC_DL + 10]; dl.tot_E = s_dec[DEC_DL + 11];
+        } else {
+          d.accept = (int)s_dec[DEC_LM + 0]; d.term = (int)s_dec[DEC_LM + 1]; d.radius = s_dec[DEC_LM + 2];
+          d.decrease_factor = s_dec[DEC_LM + 3]; d.rho = s_dec[DEC_LM + 4]; d.model_change = s_dec[DEC_LM + 5];
+        }
+        if (tid == 0) W.dec[DEC_VALID] = 0.0;   // consumed
+      } else {
+        wave_trial_sums(W, 1 - c.acc, tid, sums);
+        if (opt.dogleg) decide_dl(&c, &opt, sums, final_only != 0, &dl);
+        else decide(&c, &opt, sums, &d);
+      }
     }
     if (tid == 0) {
       s_accepted = 0;
@@ -680,9 +746,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       // the loads come from other CUs' stores, what counts is the number of dependent rounds), scattered into the 16x16
       // accumulator-layout blocks of the LDL^T solver.  Everything no item writes starts from zero.
       const int npose_blk = Dp / 6;
-      const size_t stride = W.spart_stride;
-      const int nch = W.n_chunk;
-      const double* sp = W.spart;
       const int nP = npose_blk * (npose_blk + 1) / 2 * 36, ntot = nP + 3 * Dp;
       constexpr int NL = SOLVE_THREADS - 64;
       {
@@ -703,12 +766,47 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           rem += SOLVE_THREADS / 64 - 1;
         }
       }
-      for (int base = tid - 64; base < nP; base += 3 * NL) {
+      // the chunk partials, summed by the helper workgroups: wait for all of them (bounded; a helper that never arrives would
+      // mean a broken launch: the window then fails its solve instead of hanging the GPU)
+      if (helped && tid == 64) {
+        int polls = 0;
+        while (__hip_atomic_load(W.sum_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sum_expected && polls < (1 << 22)) {
+          __builtin_amdgcn_s_sleep(2);
+          ++polls;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&s_sum_ready, polls >= (1 << 22) ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (helped) {
+        while (__hip_atomic_load(&s_sum_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      auto ssum = W.spart_sum;
+      const size_t stride = W.spart_stride;
+      const int nch = W.n_chunk;
+      auto sp = W.spart;
+      for (int base = tid - 64; base < ntot; base += 3 * NL) {
         double a[3] = {0, 0, 0};
         int dst[3];
+        if (!helped) {
+          // large launches: summed here, lanes on consecutive doubles, three items per lane and eight chunks per trip requested
+          // together (the loads come from other CUs' stores: what counts is the number of dependent rounds)
+          for (int ch = 0; ch < nch; ch += 8) {
+            double v[3][8];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int u = 0; u < 8; ++u) v[t][u] = (ch + u < nch && base + t * NL < ntot) ? sp[(size_t)(ch + u) * stride + base + t * NL] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int u = 0; u < 8; ++u) a[t] += v[t][u];
+          }
+        }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           const int i = base + t * NL;
+          if (helped) a[t] = i < ntot ? ssum[i] : 0.0;
           dst[t] = -1;
           if (i < nP) {
             const int q = i / 36, e = i - 36 * q, ii = e / 6, jj = e - 6 * ii;
@@ -719,33 +817,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
             if (bi > bj || ii >= jj) dst[t] = LY.at(6 * bi + ii, 6 * bj + jj);   // (the upper halves of the diagonal blocks are not part of the lower triangle)
           }
         }
-        for (int ch = 0; ch < nch; ch += 8) {
-          double v[3][8];
 #pragma unroll
-          for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[t][u] = (ch + u < nch && base + t * NL < nP) ? sp[(size_t)(ch + u) * stride + base + t * NL] : 0.0;
-#pragma unroll
-          for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[t] += v[t][u];
+        for (int t = 0; t < 3; ++t) {
+          const int i = base + t * NL;
+          if (dst[t] >= 0) {
+            S[dst[t]] = a[t];
+          } else if (i >= nP && i < ntot) {   // Y b | g | diag U of the pose part
+            const int which = (i - nP) / Dp, j = (i - nP) - which * Dp;
+            (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = a[t];
+          }
         }
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-          if (dst[t] >= 0) S[dst[t]] = a[t];
-      }
-      // Y b | g | diag U of the pose part: the same sums
-      for (int i = nP + tid - 64; i < ntot; i += NL) {
-        double a = 0;
-        for (int ch = 0; ch < nch; ch += 8) {
-          double v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride + i] : 0.0;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) a += v[u];
-        }
-        const int which = (i - nP) / Dp, j = (i - nP) - which * Dp;
-        (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = a;
       }
       for (int i = tid - 64; i < 3 * (Dpad - Dp); i += NL) {   // speed/bias part of the vectors starts from zero
         const int which = i / (Dpad - Dp), j = Dp + i - which * (Dpad - Dp);
@@ -762,6 +843,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     if (W.prof && tid == 64 && blockIdx.x == 0) W.prof[4] = (double)clock64();
   }
   __syncthreads();
+  if (!LARGE && s_sum_ready == 2) {   // (cannot happen in a healthy launch) the window stops as a numeric failure
+    if (tid == 0) {
+      c.done = 5 + 1;
+      *gctrl = c;
+    }
+    return;
+  }
   if (c.done) {
     if (tid == 0) *gctrl = c;
     return;

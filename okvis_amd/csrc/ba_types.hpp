@@ -80,6 +80,9 @@ struct ImuCacheD {
   int redo_count;
 };
 
+// layout of WinPtrs::dec (doubles)
+enum { DEC_VALID = 0, DEC_SUMS = 1, DEC_DL = 7, DEC_LM = 19, DEC_COUNT = 32 };
+
 // per-group scalar partials written by the linearise kernel
 enum { GS_COST = 0, GS_GD = 1, GS_DDD = 2, GS_STEP2 = 3, GS_X2 = 4, GS_GMAX = 5, GS_COUNT = 8 };
 
@@ -215,6 +218,10 @@ struct WinPtrs {
 
   // ---- Schur / solve ----
   BA_G double* spart;          // [n_chunk][spart_stride]: block-packed lower triangle | Y b
+  BA_G double* spart_sum;      // [spart_stride] the sum of the chunk partials, made by the helper workgroups of the solve launch
+  BA_G int* sum_sync;          // [0] number of helper workgroups that have delivered (all launches), [1] solve launches so far
+  BA_G double* dec;            // [DEC_COUNT] the accept / reject decision the Schur kernel took on the pending trial (same function, same
+                               // inputs as the solve kernel would use): [0] valid, [1..6] trial sums, then the DecisionDL / Decision fields
   BA_G double* S;              // [D][D] debug copy of the damped reduced matrix
   BA_G double* Sg;             // block-packed reduced matrix workspace in HBM when D > MAX_D_LDS, else null
   // tiled multi-workgroup solver of the large windows (ba_chol_tiles.hpp), null when D <= MAX_D_LDS
