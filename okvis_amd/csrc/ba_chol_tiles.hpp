@@ -21,6 +21,7 @@
 //   and prefetches the others - the serial chain is one poll + two 48x48 products from LDS per tile row.
 #pragma once
 #include "ba_device.hpp"
+#include "ba_ldl16.hpp"
 #include "ba_types.hpp"
 
 namespace ba {
@@ -245,6 +246,111 @@ __device__ void ct_potrf_trinv48(double* M, double* X, double* dinv, double* Tm,
   }
 }
 
+// The inverse Cholesky factor of a diagonal tile through a blocked LDL^T with 16-wide panels: the three 16x16 diagonal
+// blocks are eliminated by ONE wave in registers (ldl16_eliminate, ba_ldl16.hpp: column per lane, pivot column by DPP
+// row_newbcast, the unit-lower inverse in the same registers), everything between them is 16x16x16 products by all 256
+// work-items from LDS.  Twelve barrier phases of ~0.3 us and three eliminations of ~0.85 us instead of the 8 block
+// columns x (panel, look-ahead factor + inverse by one work-item, trailing update) of ct_potrf_trinv48 (20.5 us per tile:
+// the serial chain of the tiled solver).
+//   M: 48x48 SPD in LDS (stride CT_LD, lower triangle referenced; overwritten).  X: L^-1 with A = L L^T (full square, zeros
+//   above the diagonal) = D^-1/2 Lt^-1 for A = Lt D Lt^T.  R: 48 x CT_LD scratch.  dinv: 48 doubles scratch.
+__device__ void ct_ldl_inv48(double* M, double* X, double* R, double* dinv, int tid, int* s_fail) {
+  const int lane = tid & 63, wave = tid >> 6, j = lane & 15;
+  // ---- one elimination step of the chain: diagonal block b (rows / columns 16 b ..) of M -> unit-lower inverse into X
+  auto eliminate = [&](int b) {
+    if (wave == 0) {
+      double c[16];
+      double mine = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {   // full symmetric block from the lower triangle
+        const int hi = i > j ? i : j, lo = i > j ? j : i;
+        c[i] = M[(16 * b + hi) * CT_LD + 16 * b + lo];
+      }
+      bool bad = false;
+      ldl16_eliminate<true, true>(c, 16, mine, j, &bad);   // (guarded: a pivot that is not positive becomes 1, the tile reports failure)
+      if (bad && lane == 0) *s_fail = 1;
+      if (lane < 16) {
+        dinv[16 * b + j] = mine;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) X[(16 * b + i) * CT_LD + 16 * b + j] = i > j ? c[i] * mine : (i == j ? 1.0 : 0.0);
+      }
+    }
+  };
+  // C (16x16 at rows rc, columns cc of Cm) = sign * sum_k A(i, k) B(k, n), A / B given by element functions; 256 outputs
+  auto product = [&](auto&& a_at, auto&& b_at, auto&& store) {
+    const int i = tid >> 4, n = tid & 15;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s = fma(a_at(i, k), b_at(k, n), s);
+    store(i, n, s);
+  };
+  eliminate(0);
+  __syncthreads();
+  // R_0J = Lt_0^-1 A_0J (J = 1, 2), A_0J(k, n) = M(16 J + n, k)
+  for (int J = 1; J <= 2; ++J)
+    product([&](int i, int k) { return X[i * CT_LD + k]; }, [&](int k, int n) { return M[(16 * J + n) * CT_LD + k]; },
+            [&](int i, int n, double v) { R[i * CT_LD + 16 * J + n] = v; });
+  __syncthreads();
+  // trailing update of the lower triangle of rows / columns 16..47:  A(r, c) -= sum_k R_0(k, r) R_0(k, c) / d_k
+  for (int e = tid; e < 32 * 33 / 2; e += CT_THREADS) {
+    int r = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+    while ((r + 1) * (r + 2) / 2 <= e) ++r;
+    while (r * (r + 1) / 2 > e) --r;
+    const int c = e - r * (r + 1) / 2;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s = fma(R[k * CT_LD + 16 + r] * dinv[k], R[k * CT_LD + 16 + c], s);
+    M[(16 + r) * CT_LD + 16 + c] -= s;
+  }
+  __syncthreads();
+  eliminate(1);
+  __syncthreads();
+  product([&](int i, int k) { return X[(16 + i) * CT_LD + 16 + k]; }, [&](int k, int n) { return M[(32 + n) * CT_LD + 16 + k]; },
+          [&](int i, int n, double v) { R[(16 + i) * CT_LD + 32 + n] = v; });
+  __syncthreads();
+  for (int e = tid; e < 16 * 17 / 2; e += CT_THREADS) {
+    int r = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+    while ((r + 1) * (r + 2) / 2 <= e) ++r;
+    while (r * (r + 1) / 2 > e) --r;
+    const int c = e - r * (r + 1) / 2;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s = fma(R[(16 + k) * CT_LD + 32 + r] * dinv[16 + k], R[(16 + k) * CT_LD + 32 + c], s);
+    M[(32 + r) * CT_LD + 32 + c] -= s;
+  }
+  __syncthreads();
+  eliminate(2);
+  __syncthreads();
+  // ---- the off-diagonal blocks of Lt^-1 (Y): with Lt_IJ = R_JI^T D_J^-1,
+  //   Y10 = -Y11 (Lt10 Y00),  Y21 = -Y22 (Lt21 Y11),  Y20 = -Y22 (Lt20 Y00 + Lt21 Y10)
+  // T blocks go to the (dead) lower-left part of R: T10 at rows 16.., T21 at rows 32.. columns 16.., T20 at rows 32.. columns 0..
+  product([&](int i, int k) { return R[k * CT_LD + 16 + i] * dinv[k]; }, [&](int k, int n) { return X[k * CT_LD + n]; },
+          [&](int i, int n, double v) { R[(16 + i) * CT_LD + n] = v; });
+  product([&](int i, int k) { return R[(16 + k) * CT_LD + 32 + i] * dinv[16 + k]; }, [&](int k, int n) { return X[(16 + k) * CT_LD + 16 + n]; },
+          [&](int i, int n, double v) { R[(32 + i) * CT_LD + 16 + n] = v; });
+  product([&](int i, int k) { return R[k * CT_LD + 32 + i] * dinv[k]; }, [&](int k, int n) { return X[k * CT_LD + n]; },
+          [&](int i, int n, double v) { R[(32 + i) * CT_LD + n] = v; });
+  __syncthreads();
+  product([&](int i, int k) { return X[(16 + i) * CT_LD + 16 + k]; }, [&](int k, int n) { return R[(16 + k) * CT_LD + n]; },
+          [&](int i, int n, double v) { X[(16 + i) * CT_LD + n] = -v; });
+  product([&](int i, int k) { return X[(32 + i) * CT_LD + 32 + k]; }, [&](int k, int n) { return R[(32 + k) * CT_LD + 16 + n]; },
+          [&](int i, int n, double v) { X[(32 + i) * CT_LD + 16 + n] = -v; });
+  __syncthreads();
+  // T20 += Lt21 Y10
+  product([&](int i, int k) { return R[(16 + k) * CT_LD + 32 + i] * dinv[16 + k]; }, [&](int k, int n) { return X[(16 + k) * CT_LD + n]; },
+          [&](int i, int n, double v) { R[(32 + i) * CT_LD + n] += v; });
+  __syncthreads();
+  product([&](int i, int k) { return X[(32 + i) * CT_LD + 32 + k]; }, [&](int k, int n) { return R[(32 + k) * CT_LD + n]; },
+          [&](int i, int n, double v) { X[(32 + i) * CT_LD + n] = -v; });
+  __syncthreads();
+  // L^-1 = D^-1/2 Lt^-1: rows scaled, zeros above the diagonal blocks
+  for (int e = tid; e < CT_TB * CT_TB; e += CT_THREADS) {
+    const int r = e / CT_TB, c = e - r * CT_TB;
+    X[r * CT_LD + c] = (c >> 4) > (r >> 4) ? 0.0 : X[r * CT_LD + c] * sqrt(dinv[r]);
+  }
+  __syncthreads();
+}
+
 // x is pre-set to this pattern (a signalling-NaN payload no computation produces); a slot that holds anything else is final
 constexpr unsigned long long CT_X_SENTINEL = 0x7ff4dead0badf00dULL;
 
@@ -443,7 +549,7 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
     if (C.tl && tid == 0) C.tl[4 * task + 1] = (double)wall_clock64();
     if (wave < 3) ct_store_acc(acc, sC, CT_LD, wave, lane);
     __syncthreads();
-    ct_potrf_trinv48<CT_NB>(sC, sB, s_dinv, s_tm, tid, &s_fail);
+    ct_ldl_inv48(sC, sB, sA, s_dinv, tid, &s_fail);   // (sA is free here: the tile's inputs have been consumed)
     if (C.tl && tid == 0) C.tl[4 * task + 2] = (double)wall_clock64();
     // publish Linv_j and y_j = Linv_j r_j: what the rest of the solve reads (column j's TRSMs, the next diagonal tile, the
     // back-substitution).  L_jj itself (lower, zeros above) is stored afterwards, off the chain: no task reads it.

@@ -126,8 +126,14 @@ __device__ __forceinline__ void ldl_signal(int* flag, int v, int lane) {
 // d = r[K] of lane K (already broadcast).  FULL: all 16 pivots exist; otherwise act = (K < npiv) and an inactive step
 // changes nothing.  Lane K keeps 1 / d_K (0 when inactive) in `mine`.  Returns the next pivot, broadcast as soon as its
 // entry is final so that its reciprocal (the dependent chain) overlaps the remaining updates of this step.
-template <int K, bool FULL>
-__device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool act, double& mine, int j) {
+// GUARD: a pivot that is not positive is replaced by 1 (everything stays finite; the caller reports the failure).
+template <int K, bool FULL, bool GUARD = false>
+__device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool act, double& mine, int j, bool* bad = nullptr) {
+  if constexpr (GUARD) {
+    const bool neg = !(d > 0.0);
+    *bad = *bad || neg;
+    d = neg ? 1.0 : d;
+  }
   double rd = rcp_nr(d);
   if (!FULL) rd = act ? rd : 0.0;
   const bool me = (j == K);
@@ -143,25 +149,25 @@ __device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool ac
   for (int i = K + 2; i < 16; ++i) fmac_bcast<K>(r[i], r[i], v);
   return dn;
 }
-template <bool FULL>
-__device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, double& mine, int j) {
+template <bool FULL, bool GUARD = false>
+__device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, double& mine, int j, bool* bad = nullptr) {
   double d = bcast_nop<0>(r[0]);
-  d = ldl16_pivot<0, FULL>(r, d, 0 < npiv, mine, j);
-  d = ldl16_pivot<1, FULL>(r, d, 1 < npiv, mine, j);
-  d = ldl16_pivot<2, FULL>(r, d, 2 < npiv, mine, j);
-  d = ldl16_pivot<3, FULL>(r, d, 3 < npiv, mine, j);
-  d = ldl16_pivot<4, FULL>(r, d, 4 < npiv, mine, j);
-  d = ldl16_pivot<5, FULL>(r, d, 5 < npiv, mine, j);
-  d = ldl16_pivot<6, FULL>(r, d, 6 < npiv, mine, j);
-  d = ldl16_pivot<7, FULL>(r, d, 7 < npiv, mine, j);
-  d = ldl16_pivot<8, FULL>(r, d, 8 < npiv, mine, j);
-  d = ldl16_pivot<9, FULL>(r, d, 9 < npiv, mine, j);
-  d = ldl16_pivot<10, FULL>(r, d, 10 < npiv, mine, j);
-  d = ldl16_pivot<11, FULL>(r, d, 11 < npiv, mine, j);
-  d = ldl16_pivot<12, FULL>(r, d, 12 < npiv, mine, j);
-  d = ldl16_pivot<13, FULL>(r, d, 13 < npiv, mine, j);
-  d = ldl16_pivot<14, FULL>(r, d, 14 < npiv, mine, j);
-  d = ldl16_pivot<15, FULL>(r, d, 15 < npiv, mine, j);
+  d = ldl16_pivot<0, FULL, GUARD>(r, d, 0 < npiv, mine, j, bad);
+  d = ldl16_pivot<1, FULL, GUARD>(r, d, 1 < npiv, mine, j, bad);
+  d = ldl16_pivot<2, FULL, GUARD>(r, d, 2 < npiv, mine, j, bad);
+  d = ldl16_pivot<3, FULL, GUARD>(r, d, 3 < npiv, mine, j, bad);
+  d = ldl16_pivot<4, FULL, GUARD>(r, d, 4 < npiv, mine, j, bad);
+  d = ldl16_pivot<5, FULL, GUARD>(r, d, 5 < npiv, mine, j, bad);
+  d = ldl16_pivot<6, FULL, GUARD>(r, d, 6 < npiv, mine, j, bad);
+  d = ldl16_pivot<7, FULL, GUARD>(r, d, 7 < npiv, mine, j, bad);
+  d = ldl16_pivot<8, FULL, GUARD>(r, d, 8 < npiv, mine, j, bad);
+  d = ldl16_pivot<9, FULL, GUARD>(r, d, 9 < npiv, mine, j, bad);
+  d = ldl16_pivot<10, FULL, GUARD>(r, d, 10 < npiv, mine, j, bad);
+  d = ldl16_pivot<11, FULL, GUARD>(r, d, 11 < npiv, mine, j, bad);
+  d = ldl16_pivot<12, FULL, GUARD>(r, d, 12 < npiv, mine, j, bad);
+  d = ldl16_pivot<13, FULL, GUARD>(r, d, 13 < npiv, mine, j, bad);
+  d = ldl16_pivot<14, FULL, GUARD>(r, d, 14 < npiv, mine, j, bad);
+  d = ldl16_pivot<15, FULL, GUARD>(r, d, 15 < npiv, mine, j, bad);
 }
 
 // NW waves (NW * 64 threads), all of which must call.  S: the assembled system (see above) for an nb = ldl16_nb(D)
