@@ -276,71 +276,66 @@ __device__ void ct_ldl_inv48(double* M, double* X, double* R, double* dinv, int 
       }
     }
   };
-  // C (16x16 at rows rc, columns cc of Cm) = sign * sum_k A(i, k) B(k, n), A / B given by element functions; 256 outputs
-  auto product = [&](auto&& a_at, auto&& b_at, auto&& store) {
-    const int i = tid >> 4, n = tid & 15;
-    double s = 0.0;
+  // one 16x16x16 product per wave on the matrix core: C(i, n) = sum_k A(i, k) B(k, n), A / B / C given by element functions
+  // (lane l supplies A(l & 15, (l >> 4) + 4 q) and B((l >> 4) + 4 q, l & 15), receives C((l >> 4) + 4 r, l & 15))
+  auto product = [&](int w, auto&& a_at, auto&& b_at, auto&& store) {
+    if (wave != w) return;
+    double a[4], bb[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s = fma(a_at(i, k), b_at(k, n), s);
-    store(i, n, s);
+    for (int q = 0; q < 4; ++q) {
+      a[q] = a_at(lane & 15, (lane >> 4) + 4 * q);
+      bb[q] = b_at((lane >> 4) + 4 * q, lane & 15);
+    }
+    ct_v4 acc{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bb[q], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) store((lane >> 4) + 4 * r, lane & 15, acc[r]);
   };
   eliminate(0);
   __syncthreads();
   // R_0J = Lt_0^-1 A_0J (J = 1, 2), A_0J(k, n) = M(16 J + n, k)
   for (int J = 1; J <= 2; ++J)
-    product([&](int i, int k) { return X[i * CT_LD + k]; }, [&](int k, int n) { return M[(16 * J + n) * CT_LD + k]; },
+    product(J, [&](int i, int k) { return X[i * CT_LD + k]; }, [&](int k, int n) { return M[(16 * J + n) * CT_LD + k]; },
             [&](int i, int n, double v) { R[i * CT_LD + 16 * J + n] = v; });
   __syncthreads();
-  // trailing update of the lower triangle of rows / columns 16..47:  A(r, c) -= sum_k R_0(k, r) R_0(k, c) / d_k
-  for (int e = tid; e < 32 * 33 / 2; e += CT_THREADS) {
-    int r = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
-    while ((r + 1) * (r + 2) / 2 <= e) ++r;
-    while (r * (r + 1) / 2 > e) --r;
-    const int c = e - r * (r + 1) / 2;
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s = fma(R[k * CT_LD + 16 + r] * dinv[k], R[k * CT_LD + 16 + c], s);
-    M[(16 + r) * CT_LD + 16 + c] -= s;
+  // trailing update of rows / columns 16..47 (lower blocks (1,1), (2,1), (2,2)):  A_IJ -= R_0I^T D_0^-1 R_0J
+  {
+    const int I = wave == 0 ? 1 : 2, J = wave <= 1 ? 1 : 2;   // wave 0: (1,1), wave 1: (2,1), wave 2: (2,2)
+    product(wave < 3 ? wave : -1, [&](int i, int k) { return R[k * CT_LD + 16 * I + i] * dinv[k]; }, [&](int k, int n) { return R[k * CT_LD + 16 * J + n]; },
+            [&](int i, int n, double v) { if (I > J || n <= i) M[(16 * I + i) * CT_LD + 16 * J + n] -= v; });
   }
   __syncthreads();
   eliminate(1);
   __syncthreads();
-  product([&](int i, int k) { return X[(16 + i) * CT_LD + 16 + k]; }, [&](int k, int n) { return M[(32 + n) * CT_LD + 16 + k]; },
+  product(1, [&](int i, int k) { return X[(16 + i) * CT_LD + 16 + k]; }, [&](int k, int n) { return M[(32 + n) * CT_LD + 16 + k]; },
           [&](int i, int n, double v) { R[(16 + i) * CT_LD + 32 + n] = v; });
   __syncthreads();
-  for (int e = tid; e < 16 * 17 / 2; e += CT_THREADS) {
-    int r = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
-    while ((r + 1) * (r + 2) / 2 <= e) ++r;
-    while (r * (r + 1) / 2 > e) --r;
-    const int c = e - r * (r + 1) / 2;
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s = fma(R[(16 + k) * CT_LD + 32 + r] * dinv[16 + k], R[(16 + k) * CT_LD + 32 + c], s);
-    M[(32 + r) * CT_LD + 32 + c] -= s;
-  }
+  product(0, [&](int i, int k) { return R[(16 + k) * CT_LD + 32 + i] * dinv[16 + k]; }, [&](int k, int n) { return R[(16 + k) * CT_LD + 32 + n]; },
+          [&](int i, int n, double v) { if (n <= i) M[(32 + i) * CT_LD + 32 + n] -= v; });
   __syncthreads();
   eliminate(2);
   __syncthreads();
   // ---- the off-diagonal blocks of Lt^-1 (Y): with Lt_IJ = R_JI^T D_J^-1,
   //   Y10 = -Y11 (Lt10 Y00),  Y21 = -Y22 (Lt21 Y11),  Y20 = -Y22 (Lt20 Y00 + Lt21 Y10)
   // T blocks go to the (dead) lower-left part of R: T10 at rows 16.., T21 at rows 32.. columns 16.., T20 at rows 32.. columns 0..
-  product([&](int i, int k) { return R[k * CT_LD + 16 + i] * dinv[k]; }, [&](int k, int n) { return X[k * CT_LD + n]; },
+  product(1, [&](int i, int k) { return R[k * CT_LD + 16 + i] * dinv[k]; }, [&](int k, int n) { return X[k * CT_LD + n]; },
           [&](int i, int n, double v) { R[(16 + i) * CT_LD + n] = v; });
-  product([&](int i, int k) { return R[(16 + k) * CT_LD + 32 + i] * dinv[16 + k]; }, [&](int k, int n) { return X[(16 + k) * CT_LD + 16 + n]; },
+  product(2, [&](int i, int k) { return R[(16 + k) * CT_LD + 32 + i] * dinv[16 + k]; }, [&](int k, int n) { return X[(16 + k) * CT_LD + 16 + n]; },
           [&](int i, int n, double v) { R[(32 + i) * CT_LD + 16 + n] = v; });
-  product([&](int i, int k) { return R[k * CT_LD + 32 + i] * dinv[k]; }, [&](int k, int n) { return X[k * CT_LD + n]; },
+  product(3, [&](int i, int k) { return R[k * CT_LD + 32 + i] * dinv[k]; }, [&](int k, int n) { return X[k * CT_LD + n]; },
           [&](int i, int n, double v) { R[(32 + i) * CT_LD + n] = v; });
   __syncthreads();
-  product([&](int i, int k) { return X[(16 + i) * CT_LD + 16 + k]; }, [&](int k, int n) { return R[(16 + k) * CT_LD + n]; },
+  product(1, [&](int i, int k) { return X[(16 + i) * CT_LD + 16 + k]; }, [&](int k, int n) { return R[(16 + k) * CT_LD + n]; },
           [&](int i, int n, double v) { X[(16 + i) * CT_LD + n] = -v; });
-  product([&](int i, int k) { return X[(32 + i) * CT_LD + 32 + k]; }, [&](int k, int n) { return R[(32 + k) * CT_LD + 16 + n]; },
+  product(2, [&](int i, int k) { return X[(32 + i) * CT_LD + 32 + k]; }, [&](int k, int n) { return R[(32 + k) * CT_LD + 16 + n]; },
           [&](int i, int n, double v) { X[(32 + i) * CT_LD + 16 + n] = -v; });
   __syncthreads();
   // T20 += Lt21 Y10
-  product([&](int i, int k) { return R[(16 + k) * CT_LD + 32 + i] * dinv[16 + k]; }, [&](int k, int n) { return X[(16 + k) * CT_LD + n]; },
+  product(3, [&](int i, int k) { return R[(16 + k) * CT_LD + 32 + i] * dinv[16 + k]; }, [&](int k, int n) { return X[(16 + k) * CT_LD + n]; },
           [&](int i, int n, double v) { R[(32 + i) * CT_LD + n] += v; });
   __syncthreads();
-  product([&](int i, int k) { return X[(32 + i) * CT_LD + 32 + k]; }, [&](int k, int n) { return R[(32 + k) * CT_LD + n]; },
+  product(3, [&](int i, int k) { return X[(32 + i) * CT_LD + 32 + k]; }, [&](int k, int n) { return R[(32 + k) * CT_LD + n]; },
           [&](int i, int n, double v) { X[(32 + i) * CT_LD + n] = -v; });
   __syncthreads();
   // L^-1 = D^-1/2 Lt^-1: rows scaled, zeros above the diagonal blocks
