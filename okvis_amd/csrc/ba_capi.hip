@@ -123,6 +123,7 @@ struct okvis_ba_solver {
   int max_Dpad_small = 0, max_Dpad_large = 0;
   int max_sbl_blk = 0, max_sbl_stage = 0, max_sbl_tab = 0;   // (unused since the LDL^T solver replaced the level schedule)
   long long stagger_ticks = 0;   // start offset between consecutive sub-batch streams (wall_clock64 ticks, 100 MHz); OKVIS_BA_STAGGER_US
+  bool skip_topup = false;   // okvis_ba_optimize_timed ran out of time: finish() must not grant the slots mis-speculated steps still owe
   long long slots = 0;   // launch slots (schur + solve + linearise triples) since okvis_ba_begin: diagnostics (array 96)
   std::map<int, hipGraphExec_t> graphs;
   std::map<std::pair<int, int>, hipGraphExec_t> sub_graphs;  // (n, sub) -> graph of that sub-batch's chain
@@ -1209,7 +1210,10 @@ int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt) {
     return OKVIS_BA_ERR_STATE;  // these two shape the arena: set them before upload
   // unchanged options (the host class sets them before every upload): nothing to do - every upload writes the device copy
   if (std::memcmp(opt, &s->opt, sizeof(*opt)) == 0) return OKVIS_BA_OK;
-  if (opt->fp32_linearize != s->opt.fp32_linearize) destroy_graphs(s);  // captured graphs name the other kernel
+  // captured graphs name the kernels and the launch sequence of the options they were captured under: another linearise
+  // kernel (fp32) or another trust-region strategy (the DOGLEG graphs carry the iteration-budget kernel) invalidates them
+  if (opt->fp32_linearize != s->opt.fp32_linearize || opt->strategy != s->opt.strategy || opt->gauss_newton != s->opt.gauss_newton)
+    destroy_graphs(s);
   s->opt = *opt;
   HIP_TRY(hipSetDevice(s->device));
   OptD d = make_optd(s->opt, (int)s->wins.size());
@@ -1526,7 +1530,7 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
     // finish an iteration, and the decision just taken may itself ask for such a redo.  Windows that still owe
     // iterations of this call's budget get the missing slots (the others are stopped by the budget), then the final
     // decision is taken again.  Rare: only when the Gauss-Newton point lies outside the trust region.
-    for (int round = 0; round < 64; ++round) {
+    for (int round = 0; round < 64 && !s->skip_topup; ++round) {
       std::vector<Ctrl> cs;
       int rc = fetch_ctrl(s, cs);
       if (rc != OKVIS_BA_OK) return rc;
@@ -1597,13 +1601,18 @@ int okvis_ba_optimize_timed(okvis_ba_solver* s, int max_iter, int min_iter, doub
     while (done < max_iter) {
       HIP_TRY(hipStreamSynchronize(s->stream));
       const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (done >= min_iter && el > time_limit_s) break;
+      if (done >= min_iter && el > time_limit_s) {
+        s->skip_topup = true;   // the time limit ends the call (CeresIterationCallback terminates the solve)
+        break;
+      }
       rc = okvis_ba_iterate(s, 1);
       if (rc != OKVIS_BA_OK) return rc;
       ++done;
     }
   }
-  return okvis_ba_finish(s, summaries);
+  rc = okvis_ba_finish(s, summaries);
+  s->skip_topup = false;
+  return rc;
 }
 
 int okvis_ba_evaluate_cost(okvis_ba_solver* s, double* costs) {
@@ -1980,6 +1989,15 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   od.marg_mode = 1;
   od.dogleg = 0;   // no trust region in the marginalisation pass: one linearisation, no damping
   HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
+  struct RestoreOptions {   // whatever happens below, the device copy of the options leaves the marginalisation mode again
+    okvis_ba_solver* s;
+    bool armed = true;
+    ~RestoreOptions() {
+      if (!armed) return;
+      const OptD o = make_optd(s->opt, (int)s->wins.size());
+      if (hipMemcpyAsync(s->d_opt, &o, sizeof(o), hipMemcpyHostToDevice, s->stream) == hipSuccess) (void)hipStreamSynchronize(s->stream);
+    }
+  } restore_options{s};
   int rc = okvis_ba_begin(s);
   if (rc != OKVIS_BA_OK) return rc;
   s->begun = false;
@@ -2011,6 +2029,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   HIP_TRY(hipGetLastError());
   od = make_optd(s->opt, (int)s->wins.size());
   HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
+  restore_options.armed = false;   // (restored in stream order just above; the guard covers the early returns)
   // H | J | b0 | e0 are contiguous on the device: one copy into page-locked staging (+ the info record), one sync
   int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const size_t out_bytes = 8 * (2 * nn + 2 * n1);

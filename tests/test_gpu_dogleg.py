@@ -154,3 +154,20 @@ def test_batch_run_shards_windows_over_ranks(oracle):
         i = int(x[0])
         assert int(x[1]) == sg[i]["iterations"] and x[2] == sg[i]["final_cost"] and x[3] > 0
     b.close()
+
+
+def test_strategy_switch_after_graphs_were_captured(oracle):
+    """set_options(strategy=...) on a batch whose launch graphs already exist: the graphs of the other strategy (no
+    iteration-budget kernel under LM) must not be replayed, or every window returns after 0 iterations."""
+    w = synthetic.small_window(**G.SMALL[1])
+    b = solver.WindowBatch([w], options=_opts(strategy=STRATEGY_LM))
+    o = oracle.OracleWindow(w)
+    for _ in range(3):                       # repeated calls of one shape replay a captured graph
+        b.optimize(2)
+        o.optimize(2, _opts(strategy=STRATEGY_LM))
+    b.set_options(_opts())
+    sg = b.optimize(4)[0]
+    sr = o.optimize(4, _opts())
+    assert sg["iterations"] == sr["iterations"] > 0, (sg, sr)
+    assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-6 * sr["final_cost"], (sg, sr)
+    b.close()
