@@ -1,10 +1,12 @@
 """Randomised GPU-vs-oracle sweep over window shapes (pytest -m gpu): keyframes, landmarks, visibility, extrinsics
 mode, distortion model, IMU on/off and the landmark-grouping limits vary per seed, so that ragged groups, tiny
 chunks, single-observation landmarks and odd pair/task counts all go through the kernels.  Identical iteration
-bookkeeping; final cost within 1e-6 relative (the north_star tolerance): under the reference's DOGLEG policy the
-Gauss-Newton systems are regularised by mu = 1e-8 only, and the sweep contains windows with two frames / a handful of
-landmarks / 15 % visibility whose weakly constrained directions make the step itself uncertain at 1e-8 (condition of
-the reduced matrix up to 1e15); 27 of the 32 seeds agree to 1e-9, the worst to 2.4e-7 (gpurun_out of round 2)."""
+bookkeeping; final cost within 1e-9 relative, poses and speed/bias within 1e-7, landmarks within 1e-6.  Three seeds
+(ILL_CONDITIONED) get the north_star bound of 1e-6 instead: under the reference's DOGLEG policy the Gauss-Newton
+systems are regularised by mu = 1e-8 only, and those windows (two frames / a handful of landmarks / 15 % visibility)
+have weakly constrained directions that make the step itself uncertain at 1e-8 (condition of the reduced matrix up to
+1e15).  Measured per seed with tests/gpu_sweep_gaps.py (round 3): 29 seeds <= 3.4e-10 on the cost, <= 2.8e-10 on the
+poses, <= 5.7e-8 on the landmarks; seeds 0 / 7 / 21 at 2.7e-9 / 2.2e-7 / 2.0e-9 on the cost."""
 import numpy as np
 import pytest
 
@@ -12,6 +14,8 @@ from okvis_amd import solver, synthetic
 from okvis_amd.window import DIST_EQUIDISTANT, DIST_NONE, DIST_RADTAN, DIST_RADTAN8, default_options
 
 pytestmark = pytest.mark.gpu
+
+ILL_CONDITIONED = (0, 7, 21)
 
 
 def _case(seed):
@@ -40,12 +44,14 @@ def test_random_window(oracle, seed):
     sg = b.optimize(n)[0]
     ow = oracle.OracleWindow(w)
     sr = ow.optimize(n, o)
-    assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-6 * max(sr["final_cost"], 1e-12), (sg, sr)
+    loose = seed in ILL_CONDITIONED
+    ctol, stol, ltol = (1e-6, 1e-5, 1e-4) if loose else (1e-9, 1e-7, 1e-6)
+    assert abs(sg["final_cost"] - sr["final_cost"]) <= ctol * max(sr["final_cost"], 1e-12), (sg, sr)
     assert (sg["iterations"], sg["successful_steps"], sg["termination"]) == \
            (sr["iterations"], sr["successful_steps"], sr["termination"]), (sg, sr)
     pg, sbg, lg = b.get_state()
     pr, sbr, lr = ow.get_state()
-    assert np.abs(pg - pr).max() < 1e-5 and np.abs(sbg - sbr).max() < 1e-5 and np.abs(lg - lr).max() < 1e-4
+    assert np.abs(pg - pr).max() < stol and np.abs(sbg - sbr).max() < stol and np.abs(lg - lr).max() < ltol
     b.close()
 
 
