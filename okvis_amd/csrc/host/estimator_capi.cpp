@@ -307,3 +307,40 @@ extern "C" int okvis_replay_probe(const char* path, int imuAsFloat, long long* c
     return 1;
   });
 }
+// the whole recording as flat arrays (sizes from okvis_replay_probe): lets a test hand exactly what readRecording() read to
+// another Estimator implementation.  imu_t[n], imu_ga[n][6] (gyr, acc); cam_T_SC[c][7], cam_intr[c][12], cam_model[c];
+// imu_params13 as okvis_est_add_imu takes them; frames[n][3] = t_ns, id, keyframe; obs_i[n][3] = t_ns, cam, landmark,
+// obs_f[n][3] = u, v, size (time order as replay() walks them); lm_i[n][2] = id, t_ns, lm_hp[n][4]
+extern "C" int okvis_replay_read(const char* path, int imuAsFloat, long long* imu_t, double* imu_ga, double* cam_T_SC,
+                                 double* cam_intr, int* cam_model, double* imu_params13, long long* frames, long long* obs_i,
+                                 float* obs_f, long long* lm_i, double* lm_hp) {
+  return guarded([&] {
+    const okvis_amd::Recording rec = okvis_amd::readRecording(path, imuAsFloat != 0);
+    for (size_t i = 0; i < rec.imu.size(); ++i) {
+      imu_t[i] = rec.imu[i].t_ns;
+      for (int k = 0; k < 3; ++k) imu_ga[6 * i + k] = rec.imu[i].gyr[k], imu_ga[6 * i + 3 + k] = rec.imu[i].acc[k];
+    }
+    for (size_t c = 0; c < rec.cameras.size(); ++c) {
+      const okvis_amd::Transformation T = rec.cameras[c].T_SC();
+      for (int k = 0; k < 7; ++k) cam_T_SC[7 * c + k] = T.p[k];
+      for (int k = 0; k < 12; ++k) cam_intr[12 * c + k] = rec.cameras[c].geometry.intr[k];
+      cam_model[c] = rec.cameras[c].geometry.model;
+    }
+    const ImuParameters& p = rec.imuParameters;
+    const double prm[13] = {p.a_max, p.g_max, p.sigma_g_c, p.sigma_a_c, p.sigma_bg, p.sigma_ba, p.sigma_gw_c, p.sigma_aw_c,
+                            p.tau, p.g, p.a0[0], p.a0[1], p.a0[2]};
+    std::memcpy(imu_params13, prm, sizeof(prm));
+    for (size_t i = 0; i < rec.frames.size(); ++i)
+      frames[3 * i] = rec.frames[i].t_ns, frames[3 * i + 1] = (long long)rec.frames[i].id, frames[3 * i + 2] = rec.frames[i].keyframe;
+    for (size_t i = 0; i < rec.observations.size(); ++i) {
+      const okvis_amd::RecordedObservation& o = rec.observations[i];
+      obs_i[3 * i] = o.t_ns, obs_i[3 * i + 1] = o.cam, obs_i[3 * i + 2] = (long long)o.landmark;
+      obs_f[3 * i] = o.u, obs_f[3 * i + 1] = o.v, obs_f[3 * i + 2] = o.size;
+    }
+    for (size_t i = 0; i < rec.landmarks.size(); ++i) {
+      lm_i[2 * i] = (long long)rec.landmarks[i].id, lm_i[2 * i + 1] = rec.landmarks[i].t_ns;
+      for (int k = 0; k < 4; ++k) lm_hp[4 * i + k] = rec.landmarks[i].hp_S[k];
+    }
+    return 1;
+  });
+}

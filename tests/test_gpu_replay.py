@@ -4,11 +4,13 @@ through okvis_amd::Estimator frame by frame like ThreadedKFVio does (addStates /
 applyMarginalizationStrategy), from C++ — through the library entry and through the okvis_amd_replay executable."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 
-from okvis_amd import recording
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from okvis_amd import recording  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -63,3 +65,70 @@ def test_replay_executable(folder):
     p = subprocess.run([exe, os.path.join(d, "nowhere")], capture_output=True, text=True, timeout=60)
     assert p.returncode == 1 and "cannot open" in p.stderr
     assert subprocess.run([exe], capture_output=True, text=True).returncode != 0
+
+
+# ---- the same recording through the reference's own okvis::Estimator ---------------------------------------------------
+def _ref_available():
+    import ref_lib
+    return ref_lib.available()
+
+
+def test_python_frame_loop_is_the_cpp_replay(folder):
+    """tests/replay_scenario.py (the loop the next test runs on both estimators) makes the calls replay.cpp makes: driven
+    over the MI355X backend it lands on the trajectory of okvis_replay_run"""
+    import replay_scenario as RS
+    from okvis_amd import estimator as E
+    d, _ = folder
+    n = 30
+    out = os.path.join(d, "cpp30.csv")
+    recording.run_replay(d, max_frames=n, trajectory_csv=out)
+    rows = np.loadtxt(out, delimiter=",", comments="#")
+    tr = RS.replay(RS.read(d), lambda: E.Estimator(0), E.Frame, max_frames=n)
+    assert len(tr) == n
+    for r, row in zip(tr, rows):
+        assert (r["n_frames"], r["n_landmarks"], r["n_obs"], r["summary"]["iterations"]) == tuple(int(x) for x in row[17:21])
+        assert np.abs(r["T_WS"] - row[1:8]).max() < 1e-9 and np.abs(r["sb"] - row[8:17]).max() < 1e-9
+        assert abs(r["summary"]["final_cost"] - row[22]) <= 1e-9 * row[22]
+
+
+@pytest.fixture(scope="module")
+def small_folder(tmp_path_factory):
+    # the reference side solves densely over ALL parameters (oracle/ref/ceres_shim_solve.cpp): ~200 landmarks per window keep
+    # 45 frames at a quarter of a minute (the 535-landmark windows of `folder` take 11 s per frame there)
+    d = str(tmp_path_factory.mktemp("asl_small"))
+    return d, recording.write_synthetic_recording(d, duration_s=6.0, n_points=280, seed=5)
+
+
+@pytest.mark.skipif(not _ref_available(), reason="oracle/_ref not available")
+def test_replay_matches_the_reference_estimator(small_folder):
+    """Replay parity against the reference, not against ground truth: the recording goes through okvis::Estimator
+    (Estimator.cpp / Map.cpp / MarginalizationError.cpp compiled unmodified, oracle/_ref) and through the backend; after
+    EVERY frame the window composition, the removed landmarks and the prior size are equal and the states agree."""
+    import ref_lib as R
+    import replay_scenario as RS
+    from okvis_amd import estimator as E
+    d, _ = small_folder
+    rec = RS.read(d)
+    n = 45
+    tr_r = RS.replay(rec, R.RefEstimator, R.RefFrame, max_frames=n)
+    tr_g = RS.replay(rec, lambda: E.Estimator(0), E.Frame, max_frames=n)
+    worst = dict(pos=0.0, rot=0.0, sb=0.0, lm=0.0, cost=0.0)
+    for a, b in zip(tr_r, tr_g):
+        k = a["frame"]
+        assert (a["n_obs"], a["n_frames"], a["n_landmarks"]) == (b["n_obs"], b["n_frames"], b["n_landmarks"]), k
+        assert a["removed"] == b["removed"], k
+        assert a["prior"][0] == b["prior"][0], (k, a["prior"], b["prior"])
+        assert list(a["poses"]) == list(b["poses"]) and list(a["sbs"]) == list(b["sbs"]), k
+        assert a["summary"]["iterations"] == b["summary"]["iterations"], (k, a["summary"], b["summary"])
+        for i in a["poses"]:
+            worst["pos"] = max(worst["pos"], np.abs(a["poses"][i][:3] - b["poses"][i][:3]).max())
+            worst["rot"] = max(worst["rot"], np.abs(a["poses"][i][3:] - b["poses"][i][3:]).max())
+        for i in a["sbs"]:
+            worst["sb"] = max(worst["sb"], np.abs(a["sbs"][i] - b["sbs"][i]).max())
+        for i in a["landmarks"]:
+            worst["lm"] = max(worst["lm"], np.abs(a["landmarks"][i] - b["landmarks"][i]).max())
+        ca, cb = a["summary"]["final_cost"], b["summary"]["final_cost"]
+        worst["cost"] = max(worst["cost"], abs(ca - cb) / ca)
+    print("replay, worst deviations from the reference Estimator:", worst)
+    assert worst["cost"] <= 1e-6, worst
+    assert worst["pos"] <= 1e-5 and worst["rot"] <= 1e-5 and worst["sb"] <= 1e-4 and worst["lm"] <= 2e-3, worst
