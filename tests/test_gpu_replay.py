@@ -119,7 +119,12 @@ def test_replay_matches_the_reference_estimator(small_folder):
         assert a["removed"] == b["removed"], k
         assert a["prior"][0] == b["prior"][0], (k, a["prior"], b["prior"])
         assert list(a["poses"]) == list(b["poses"]) and list(a["sbs"]) == list(b["sbs"]), k
-        assert a["summary"]["iterations"] == b["summary"]["iterations"], (k, a["summary"], b["summary"])
+        # iteration book-keeping: the reference side counts what Ceres logs (trust_region_minimizer.cc returns from the
+        # function-tolerance test before the iteration is pushed to summary.iterations); the backend counts the
+        # linearisations it did, the one that met the tolerance included, and says so in `termination` (1)
+        sa, sb = a["summary"], b["summary"]
+        assert sa["successful_steps"] == sb["successful_steps"], (k, sa, sb)
+        assert sa["iterations"] == sb["iterations"] - (sb["termination"] == 1), (k, sa, sb)
         for i in a["poses"]:
             worst["pos"] = max(worst["pos"], np.abs(a["poses"][i][:3] - b["poses"][i][:3]).max())
             worst["rot"] = max(worst["rot"], np.abs(a["poses"][i][3:] - b["poses"][i][3:]).max())
@@ -131,4 +136,6 @@ def test_replay_matches_the_reference_estimator(small_folder):
         worst["cost"] = max(worst["cost"], abs(ca - cb) / ca)
     print("replay, worst deviations from the reference Estimator:", worst)
     assert worst["cost"] <= 1e-6, worst
-    assert worst["pos"] <= 1e-5 and worst["rot"] <= 1e-5 and worst["sb"] <= 1e-4 and worst["lm"] <= 2e-3, worst
+    # measured (round 3): pos 9.2e-8 m, rot 2.5e-7, speed/bias 1.3e-6, landmarks 7.0e-5 m, cost 6.3e-7 (frame 3, a window with
+    # seven rejected steps out of ten)
+    assert worst["pos"] <= 1e-6 and worst["rot"] <= 3e-6 and worst["sb"] <= 2e-5 and worst["lm"] <= 7e-4, worst
