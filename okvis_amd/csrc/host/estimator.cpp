@@ -602,6 +602,7 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
   FlatWindow fw;
   flatten(sel, fw);
   const auto t1 = clk::now();
+  if (windowObserver_) windowObserver_(&fw.w, 0, windowObserverUser_);
   check(okvis_ba_set_options(solver_, &options_), "set_options");
   check(okvis_ba_upload(solver_, 1, &fw.w), "upload");
   const auto t2 = clk::now();
@@ -616,6 +617,11 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
   std::vector<double> ref(9 * sel.imu.size());
   check(okvis_ba_fetch_results(solver_, 0, pose.data(), sb.data(), lm.data(), q.empty() ? nullptr : q.data(),
                                ref.empty() ? nullptr : ref.data()), "fetch_results");
+  if (windowObserver_) {
+    okvis_ba_window after = fw.w;
+    after.pose = pose.data(), after.sb = sb.data(), after.lm = lm.data();
+    windowObserver_(&after, 1, windowObserverUser_);
+  }
   for (size_t i = 0; i < sel.pose.size(); ++i)
     std::copy(pose.begin() + 7 * i, pose.begin() + 7 * i + 7, poseBlocks_[sel.pose[i]].x.begin());
   for (size_t i = 0; i < sel.sb.size(); ++i)

@@ -112,6 +112,11 @@ class Estimator {
   bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks);
   // test hook: the next applyMarginalizationStrategy throws where the GPU call would be (exercises the roll-back)
   void debugFailNextMarginalization() { debugFailMarg_ = true; }
+  // diagnostics hook: called by optimize() with the flattened window it is about to upload (stage 0) and again with the
+  // same window carrying the optimised pose / sb / lm arrays (stage 1); pointers are valid during the call only.  Lets a
+  // test hand the very same problem to another solver and compare in the window's own indexing; not used by the product.
+  typedef void (*WindowObserver)(const okvis_ba_window* window, int stage, void* user);
+  void setWindowObserver(WindowObserver f, void* user) { windowObserver_ = f, windowObserverUser_ = user; }
   static bool initPoseFromImu(const ImuMeasurementDeque& imuMeasurements, Transformation& T_WS);
 
   // ---- getters (Estimator.hpp:218-354) ----
@@ -269,6 +274,8 @@ class Estimator {
   MargPrior prior_;
   std::array<double, 4> timings_{};
   bool debugFailMarg_ = false;
+  WindowObserver windowObserver_ = nullptr;
+  void* windowObserverUser_ = nullptr;
   struct MargUndo;  // what applyMarginalizationStrategy changed before its GPU call (estimator.cpp)
   bool applyMarginalizationStrategyImpl(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks, MargUndo& undo);
   std::array<double, 6> margInfo_{};  // last marginalisation: ms flatten, upload, marginalize; Jacobi sweeps (2); sub-window D

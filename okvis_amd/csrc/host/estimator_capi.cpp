@@ -134,6 +134,19 @@ int okvis_est_debug_fail_next_marginalization(void* h) {
     return 1;
   });
 }
+// diagnostics hook (Estimator::setWindowObserver): cb(window, user) sees each window optimize() flattens
+int okvis_est_set_window_observer(void* h, void (*cb)(const okvis_ba_window*, int, void*), void* user) {
+  return guarded([&] {
+    static_cast<Estimator*>(h)->setWindowObserver(cb, user);
+    return 1;
+  });
+}
+int okvis_est_get_options(void* h, okvis_ba_options* out) {
+  return guarded([&] {
+    *out = static_cast<Estimator*>(h)->options();
+    return 1;
+  });
+}
 int okvis_est_get_T_WS(void* h, uint64_t id, double out[7]) {
   return guarded([&] {
     Transformation T;

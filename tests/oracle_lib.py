@@ -204,6 +204,18 @@ class OracleWindow:
         self.D = lib().orc_window_reduced_dim(self._h)
         self.n_pair = lib().orc_window_pair_count(self._h)
 
+    @classmethod
+    def from_c(cls, wc_ptr):
+        """from a POINTER(WindowC) somebody else owns (the library copies what it needs)"""
+        import types
+        self = cls.__new__(cls)
+        wc = wc_ptr.contents
+        self.window = types.SimpleNamespace(n_pose=wc.n_pose, n_sb=wc.n_sb, n_lm=wc.n_lm)
+        self._h = lib().orc_window_create(wc_ptr)
+        self.D = lib().orc_window_reduced_dim(self._h)
+        self.n_pair = lib().orc_window_pair_count(self._h)
+        return self
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().orc_window_destroy(self._h)

@@ -189,6 +189,16 @@ class RefWindow:
         self._wc, self._keep = window.as_c()
         self._h = lib().ref_window_create(C.byref(self._wc))
 
+    @classmethod
+    def from_c(cls, wc_ptr):
+        """from a POINTER(WindowC) somebody else owns (the library copies what it needs)"""
+        import types
+        self = cls.__new__(cls)
+        wc = wc_ptr.contents
+        self.window = types.SimpleNamespace(n_pose=wc.n_pose, n_sb=wc.n_sb, n_lm=wc.n_lm)
+        self._h = lib().ref_window_create(wc_ptr)
+        return self
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().ref_window_destroy(self._h)
