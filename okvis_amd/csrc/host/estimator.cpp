@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_set>
@@ -398,7 +400,10 @@ Estimator::WindowSel Estimator::selectAll() const {
     if (poseBlocks_[i].alive) sel.pose.push_back((int)i);
   for (size_t i = 0; i < sbBlocks_.size(); ++i)
     if (sbBlocks_[i].alive) sel.sb.push_back((int)i);
-  for (const auto& kv : landmarksMap_) sel.landmarks.push_back(kv.first);
+  // a landmark nobody observes has no residual block: Ceres drops such parameter blocks from the program it solves (they
+  // keep their value); optimize() gives them the quality 0 the reference derives from their zero H (Estimator.cpp:890-893)
+  for (const auto& kv : landmarksMap_)
+    if (!kv.second.observations.empty()) sel.landmarks.push_back(kv.first);
   for (const auto& kv : observations_) sel.obs.push_back(kv.first);
   for (size_t i = 0; i < imuFactors_.size(); ++i) sel.imu.push_back((int)i);
   for (size_t i = 0; i < posePriors_.size(); ++i) sel.pprior.push_back((int)i);
@@ -593,7 +598,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
 // ---------------------------------------------------------------------------------------------------
 // optimize (Estimator.cpp:843-906)
 // ---------------------------------------------------------------------------------------------------
-void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/) {
+void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
   if (states_.empty()) return;
   typedef std::chrono::steady_clock clk;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -603,6 +608,12 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
   flatten(sel, fw);
   const auto t1 = clk::now();
   if (windowObserver_) windowObserver_(&fw.w, 0, windowObserverUser_);
+  if (std::getenv("OKVIS_AMD_TRACE"))
+    for (size_t a = 0; a < fw.f64.size(); ++a) {
+      size_t bad = 0;
+      for (double v : fw.f64[a]) bad += !std::isfinite(v);
+      if (bad) std::printf("okvis_amd::Estimator::optimize: input array %zu holds %zu non-finite values of %zu\n", a, bad, fw.f64[a].size());
+    }
   check(okvis_ba_set_options(solver_, &options_), "set_options");
   check(okvis_ba_upload(solver_, 1, &fw.w), "upload");
   const auto t2 = clk::now();
@@ -611,6 +622,11 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
   else
     check(okvis_ba_optimize(solver_, (int)numIter, &summary_), "optimize");
   const auto t3 = clk::now();
+  if (verbose || std::getenv("OKVIS_AMD_TRACE"))  // the reference prints summary.FullReport() when verbose (Estimator.cpp:870-872)
+    std::printf("okvis_amd::Estimator::optimize: %d poses, %d speed/bias, %d landmarks, %d observations, %d IMU terms, prior %d | "
+                "iterations %d (%d successful), cost %.9g -> %.9g, termination %d, radius %.3g\n",
+                fw.w.n_pose, fw.w.n_sb, fw.w.n_lm, fw.w.n_obs, fw.w.n_imu, fw.w.marg_dim, summary_.iterations,
+                summary_.successful_steps, summary_.initial_cost, summary_.final_cost, summary_.termination, summary_.final_radius);
   // copy the estimates back (the reference's parameter blocks are updated in place by Ceres)
   const size_t nl = sel.landmarks.size();
   std::vector<double> pose(7 * sel.pose.size()), sb(9 * sel.sb.size()), lm(4 * nl), q(nl);
@@ -641,11 +657,15 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool /*verbose*/
     // nl lookups (nothing was inserted or erased in between: optimize() runs under the caller's estimator mutex)
     auto it = landmarksMap_.begin();
     for (size_t i = 0; i < nl; ++i, ++it) {
+      for (; it != landmarksMap_.end() && it->first != sel.landmarks[i] && it->second.observations.empty(); ++it)
+        it->second.quality = 0.0;  // unobserved, not part of the problem
       if (it == landmarksMap_.end() || it->first != sel.landmarks[i]) it = landmarksMap_.find(sel.landmarks[i]);
       MapPoint& mp = it->second;
       mp.quality = q[i];
       std::copy(lm.begin() + 4 * i, lm.begin() + 4 * i + 4, mp.point.begin());
     }
+    for (; it != landmarksMap_.end(); ++it)
+      if (it->second.observations.empty()) it->second.quality = 0.0;
   }
   timings_ = {ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, clk::now())};
 }
