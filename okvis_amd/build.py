@@ -11,30 +11,56 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libokvis_amd_ba.so")
-SOURCES = ["ba_capi.hip"]
-HEADERS = [os.path.join("host", "estimator.hpp"), os.path.join("host", "estimator.cpp"), os.path.join("host", "replay.hpp"),
-           os.path.join("host", "replay.cpp"), os.path.join("host", "replay_main.cpp"),
-           os.path.join("host", "estimator_capi.cpp"), "ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_schur.hpp", "ba_solve.hpp",
-           "ba_imu.hpp", "ba_marg.hpp", "ba_chol_tiles.hpp", "ba_ldl16.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
+# translation units of the HIP library and the headers each one is rebuilt for
+BA_HEADERS = ["ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_schur.hpp", "ba_solve.hpp", "ba_imu.hpp",
+              "ba_marg.hpp", "ba_chol_tiles.hpp", "ba_ldl16.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
+UNITS = {
+    "ba_capi.hip": BA_HEADERS,                                     # the bundle-adjustment path (include/okvis_amd_ba.h)
+    "fe_capi.hip": ["fe_kernels.hpp", "ba_math.hpp", os.path.join("..", "..", "include", "okvis_amd_frontend.h"),
+                    os.path.join("..", "..", "include", "okvis_amd_ba.h")],   # frontend pieces (include/okvis_amd_frontend.h)
+}
+SOURCES = list(UNITS)
+HOST_SOURCES = [os.path.join("host", f) for f in ("estimator.hpp", "estimator.cpp", "replay.hpp", "replay.cpp", "replay_main.cpp",
+                                                   "estimator_capi.cpp", "okvis_estimator_adapter.hpp")]
+HEADERS = sorted({h for hs in UNITS.values() for h in hs} | set(HOST_SOURCES))
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in deps)
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
 
 
 def stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return (any(_newer(_obj(s), [s] + UNITS[s]) for s in SOURCES) or _newer(LIB, []) or
+            any(os.path.getmtime(_obj(s)) > os.path.getmtime(LIB) for s in SOURCES) or _newer(HOST_LIB, HOST_SOURCES))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    relink = force or not os.path.exists(LIB)
+    for s in SOURCES:
+        if force or _newer(_obj(s), [s] + UNITS[s]):
+            cmd = [hipcc, *flags, "-c", os.path.join(CSRC, s), "-o", _obj(s)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            relink = True
+    if relink or any(os.path.getmtime(_obj(s)) > os.path.getmtime(LIB) for s in SOURCES):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj(s) for s in SOURCES], "-o", LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     build_host(verbose)
     return LIB
 

@@ -16,6 +16,9 @@
 //     first-pose prior depends on that;
 //   * inverse(): closed form up to 3x3, partial-pivot LU above;
 //   * SelfAdjointEigenSolver: cyclic Jacobi, eigenvalues ascending;
+//   * ColPivHouseholderQR: Householder reflections with the largest remaining column first (norms down-dated, the
+//     chosen one recomputed), rank() = pivots above epsilon * size * largest pivot — the rank test of
+//     ProbabilisticStereoTriangulator::getUncertainty;
 //   * Quaternion product / toRotationMatrix / rotation-matrix -> quaternion: the standard formulas.
 #pragma once
 #include <algorithm>
@@ -93,6 +96,8 @@ template <class S>
 class AngleAxis;
 template <class M>
 class LLT;
+template <class M>
+class ColPivHouseholderQR;
 
 // ------------------------------------------------------------------------------------------------------
 // comma initialiser:  m << a, b, c;
@@ -441,6 +446,13 @@ class MatrixBase {
   PlainObject inverse() const;
   Scalar determinant() const;
   LLT<PlainObject> llt() const;
+  ColPivHouseholderQR<PlainObject> colPivHouseholderQr() const;
+  // fixed sizes up to 4x4 in Eigen: invertible = |det| > threshold, the inverse from the cofactors / det
+  template <class Result>
+  void computeInverseWithCheck(Result& inverse, bool& invertible, const Scalar& absDeterminantThreshold = Scalar(1e-12)) const {
+    invertible = std::fabs(determinant()) > absDeterminantThreshold;
+    if (invertible) inverse = this->inverse();
+  }
   Matrix<Scalar, internal::pick(SizeAtCompileTime, Dynamic) == Dynamic ? Dynamic : SizeAtCompileTime + 1, 1>
   homogeneous() const {
     Matrix<Scalar, internal::pick(SizeAtCompileTime, Dynamic) == Dynamic ? Dynamic : SizeAtCompileTime + 1, 1> r(
@@ -1291,6 +1303,100 @@ class LLT {
 template <class Derived>
 LLT<typename MatrixBase<Derived>::PlainObject> MatrixBase<Derived>::llt() const {
   return LLT<PlainObject>(*this);
+}
+
+// a 1x1 result compared with a scalar (`v.transpose() * v < 4.0`): the conversion operator is a template and is not
+// found for the built-in comparison
+template <class S, int O, int MR, int MC>
+inline bool operator<(const Matrix<S, 1, 1, O, MR, MC>& a, const S& b) { return a.coeff(0, 0) < b; }
+template <class S, int O, int MR, int MC>
+inline bool operator>(const Matrix<S, 1, 1, O, MR, MC>& a, const S& b) { return a.coeff(0, 0) > b; }
+template <class S, int O, int MR, int MC>
+inline bool operator<(const S& a, const Matrix<S, 1, 1, O, MR, MC>& b) { return a < b.coeff(0, 0); }
+template <class S, int O, int MR, int MC>
+inline bool operator>(const S& a, const Matrix<S, 1, 1, O, MR, MC>& b) { return a > b.coeff(0, 0); }
+
+// ------------------------------------------------------------------------------------------------------
+// ColPivHouseholderQR: A P = Q R.  Only what the reference asks of it: rank() (and the R factor for inspection).
+// The algorithm is the published one (Golub & Van Loan 5.4.2 with Eigen's thresholds): at step k the remaining column
+// of largest norm is swapped in (norms are down-dated after every reflection; the winner's norm is recomputed from its
+// entries), a column whose squared norm falls below eps^2 * max column norm^2 * (rows - k) / rows ends the list of non-zero
+// pivots, and rank() counts the pivots |R_ii| > eps * min(rows, cols) * max_i |R_ii|.
+// ------------------------------------------------------------------------------------------------------
+template <class M>
+class ColPivHouseholderQR {
+ public:
+  typedef typename M::Scalar Scalar;
+  template <class D>
+  explicit ColPivHouseholderQR(const MatrixBase<D>& a) : qr_(a) {
+    const Index rows = qr_.rows(), cols = qr_.cols(), size = std::min(rows, cols);
+    std::vector<Scalar> cn((size_t)cols);
+    Scalar maxn = 0;
+    for (Index c = 0; c < cols; ++c) {
+      Scalar s = 0;
+      for (Index r = 0; r < rows; ++r) s += qr_(r, c) * qr_(r, c);
+      cn[(size_t)c] = s;
+      maxn = std::max(maxn, s);
+    }
+    const Scalar eps = std::numeric_limits<Scalar>::epsilon();
+    const Scalar threshold_helper = maxn * eps * eps / Scalar(rows);
+    nonzero_ = size;
+    maxpivot_ = 0;
+    for (Index k = 0; k < size; ++k) {
+      Index big = k;
+      for (Index c = k + 1; c < cols; ++c)
+        if (cn[(size_t)c] > cn[(size_t)big]) big = c;
+      Scalar bn = 0;
+      for (Index r = k; r < rows; ++r) bn += qr_(r, big) * qr_(r, big);
+      cn[(size_t)big] = bn;
+      if (nonzero_ == size && bn < threshold_helper * Scalar(rows - k)) nonzero_ = k;
+      if (big != k) {
+        for (Index r = 0; r < rows; ++r) std::swap(qr_(r, k), qr_(r, big));
+        std::swap(cn[(size_t)k], cn[(size_t)big]);
+      }
+      const Scalar c0 = qr_(k, k);
+      Scalar tail = 0;
+      for (Index r = k + 1; r < rows; ++r) tail += qr_(r, k) * qr_(r, k);
+      Scalar beta, tau;
+      if (tail <= std::numeric_limits<Scalar>::min()) {
+        tau = 0, beta = c0;
+        for (Index r = k + 1; r < rows; ++r) qr_(r, k) = 0;
+      } else {
+        beta = std::sqrt(c0 * c0 + tail);
+        if (c0 >= 0) beta = -beta;
+        for (Index r = k + 1; r < rows; ++r) qr_(r, k) /= (c0 - beta);
+        tau = (beta - c0) / beta;
+      }
+      qr_(k, k) = beta;
+      maxpivot_ = std::max(maxpivot_, std::fabs(beta));
+      for (Index c = k + 1; c < cols; ++c) {
+        Scalar t = qr_(k, c);
+        for (Index r = k + 1; r < rows; ++r) t += qr_(r, k) * qr_(r, c);
+        t *= tau;
+        qr_(k, c) -= t;
+        for (Index r = k + 1; r < rows; ++r) qr_(r, c) -= t * qr_(r, k);
+      }
+      for (Index c = k + 1; c < cols; ++c) cn[(size_t)c] -= qr_(k, c) * qr_(k, c);
+    }
+  }
+  Index rank() const {
+    const Index size = std::min(qr_.rows(), qr_.cols());
+    const Scalar thr = maxpivot_ * (std::numeric_limits<Scalar>::epsilon() * Scalar(size));
+    Index r = 0;
+    for (Index i = 0; i < nonzero_; ++i) r += (std::fabs(qr_(i, i)) > thr) ? 1 : 0;
+    return r;
+  }
+  bool isInvertible() const { return rank() == qr_.rows() && qr_.rows() == qr_.cols(); }
+  const M& matrixQR() const { return qr_; }
+
+ private:
+  M qr_;
+  Index nonzero_;
+  Scalar maxpivot_;
+};
+template <class Derived>
+ColPivHouseholderQR<typename MatrixBase<Derived>::PlainObject> MatrixBase<Derived>::colPivHouseholderQr() const {
+  return ColPivHouseholderQR<PlainObject>(*this);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -1,0 +1,179 @@
+"""GPU: the batched frontend pieces (include/okvis_amd_frontend.h) against the reference's own classes in oracle/_ref:
+okvis_frontend/src/ProbabilisticStereoTriangulator.cpp + stereo_triangulation.cpp compiled unmodified, and the reference's
+PinholeCamera<D> behind the restated 3D-2D lines of VioKeyframeWindowMatchingAlgorithm.cpp (oracle/ref/ref_frontend_capi.cpp).
+Every candidate goes through both; flags must be identical, numbers agree to rounding."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_lib as R  # noqa: E402
+from okvis_amd import frontend as F, synthetic  # noqa: E402
+from okvis_amd.window import DIST_EQUIDISTANT, DIST_NONE, DIST_RADTAN, DIST_RADTAN8  # noqa: E402
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.available(), reason="oracle/_ref not available")]
+
+INTR = {DIST_EQUIDISTANT: synthetic.TEST_INTR_EQUI, DIST_RADTAN: synthetic.TEST_INTR_RADTAN,
+        DIST_RADTAN8: np.array([350.0, 360.0, 378.0, 238.0, -0.16, 0.15, 0.0003, 0.0002, 0.01, 0.02, -0.01, 0.005]),
+        DIST_NONE: np.array([350.0, 360.0, 378.0, 238.0, 0, 0, 0, 0, 0, 0, 0, 0])}
+
+
+def _ref():
+    return F.Frontend(api=(R.lib(), "ref_fe_"))
+
+
+def _quat(axis, angle):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    return np.r_[axis * np.sin(angle / 2), np.cos(angle / 2)]
+
+
+def _rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _stereo_case(model, seed, n=400, baseline=0.11, far=False):
+    """points in front of camera A, seen by B = A moved by T_AB; keypoints = projections + noise; candidates = the true
+    matches, wrong matches, and matches to keypoints that see nothing sensible"""
+    rng = np.random.default_rng(seed)
+    cam = F.camera(INTR[model], model)
+    T_AB = np.r_[baseline * np.array([1.0, 0.05, -0.02]), _quat(rng.normal(size=3), 0.02)]
+    depth = rng.uniform(60.0, 4000.0, n) if far else rng.uniform(0.6, 25.0, n)
+    p_A = np.c_[rng.uniform(-0.55, 0.55, n) * depth, rng.uniform(-0.4, 0.4, n) * depth, depth]
+    p_B = (p_A - T_AB[:3]) @ _rot(T_AB[3:])          # C_AB^T (p - r)
+    uvA, okA = synthetic.project_points(INTR[model], model, p_A)
+    uvB, okB = synthetic.project_points(INTR[model], model, p_B)
+    uvA = np.where(okA[:, None], uvA, 100.0) + rng.normal(size=(n, 2)) * 0.5
+    uvB = np.where(okB[:, None], uvB, 100.0) + rng.normal(size=(n, 2)) * 0.5
+    size = rng.choice([4.0, 8.0, 12.0, 31.0], n)
+    kpA, kpB = np.c_[uvA, size].astype(np.float32), np.c_[uvB, rng.permutation(size)].astype(np.float32)
+    true = np.c_[np.arange(n), np.arange(n)]
+    wrong = np.c_[rng.integers(0, n, n // 2), rng.integers(0, n, n // 2)]
+    pairs = np.r_[true, wrong].astype(np.int32)
+    scale2 = max(1.0, 1.3) ** 2 * 1e-2                # doSetup: UOplus of a frame-to-frame match at 1.3 m/s (:126-137)
+    UOplus = np.diag([scale2] * 3 + [1e-8] * 3) if seed % 2 else np.diag([4e-8] * 3 + [1e-8] * 3)
+    sigma = None if seed % 3 == 0 else np.where(rng.random(len(pairs)) < 0.3, -1.0,
+                                                2 ** 0.25 * 0.8 * rng.choice([4.0, 8.0], len(pairs)) / 12.0 / INTR[model][0])
+    return cam, T_AB, UOplus, kpA, kpB, pairs, sigma
+
+
+def _compare_tri(args, want_uncertainty=True):
+    g, r = F.Frontend(0), _ref()
+    hg, cg, fg = g.stereo_triangulate(*args, want_uncertainty=want_uncertainty)
+    hr, cr, fr = r.stereo_triangulate(*args, want_uncertainty=want_uncertainty)
+    g.close()
+    assert np.array_equal(fg, fr), np.flatnonzero(fg != fr)[:10]
+    assert np.abs(hg - hr).max() <= 1e-12
+    ok = (fr & F.TRI_VALID != 0) & (fr & F.TRI_RANK_DEFICIENT == 0)
+    if want_uncertainty and ok.any():
+        scale = np.abs(cr[ok]).max(axis=(1, 2))[:, None, None]
+        assert (np.abs(cg[ok] - cr[ok]) / scale).max() <= 1e-9
+        assert (cg[~ok] == 0).all()
+    return fr, hr, cr
+
+
+@pytest.mark.parametrize("model", [DIST_EQUIDISTANT, DIST_RADTAN, DIST_RADTAN8])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_stereo_triangulation_with_uncertainty(model, seed):
+    cam, T_AB, U, kpA, kpB, pairs, sigma = _stereo_case(model, seed)
+    flags, hp, cov = _compare_tri((cam, cam, T_AB, U, kpA, kpB, pairs, sigma))
+    n = len(kpA)
+    valid = flags & F.TRI_VALID != 0
+    assert valid[:n].mean() > 0.6 and valid[n:].mean() < 0.2            # true matches pass, wrong ones are rejected
+    assert (flags & F.TRI_CAN_INIT != 0).sum() > 0.3 * n
+    ok = valid & (flags & F.TRI_RANK_DEFICIENT == 0)
+    assert (np.linalg.eigvalsh(cov[ok]) > 0).all()                      # a covariance
+
+
+def test_verify_only_stops_after_the_triangulation():
+    cam, T_AB, U, kpA, kpB, pairs, sigma = _stereo_case(DIST_RADTAN, 5)
+    flags, _, cov = _compare_tri((cam, cam, T_AB, U, kpA, kpB, pairs, sigma), want_uncertainty=False)
+    assert (flags & (F.TRI_CAN_INIT | F.TRI_RANK_DEFICIENT) == 0).all() and (cov == 0).all()
+
+
+def test_far_points_and_parallel_rays():
+    """points hundreds of baselines away: the 2x2 system of the midpoint method is singular (|det| <= 1e-6) -> parallel rays,
+    w = 1e-3 points, not initialisable; in between, depth is not observable and getUncertainty says so"""
+    cam, T_AB, U, kpA, kpB, pairs, sigma = _stereo_case(DIST_EQUIDISTANT, 7, baseline=0.05, far=True)
+    flags, hp, _ = _compare_tri((cam, cam, T_AB, U, kpA, kpB, pairs, sigma))
+    parallel = flags & F.TRI_NOT_PARALLEL == 0
+    assert parallel.sum() > 20 and ((flags & F.TRI_VALID != 0) & parallel).sum() > 5
+    assert (flags[parallel] & F.TRI_CAN_INIT == 0).all()
+    assert ((flags & F.TRI_VALID != 0) & ~parallel & (flags & F.TRI_CAN_INIT == 0)).sum() > 5
+
+
+def test_two_different_cameras_and_a_large_rotation():
+    rng = np.random.default_rng(11)
+    cam, T_AB, U, kpA, kpB, pairs, sigma = _stereo_case(DIST_RADTAN, 9)
+    intr_b = INTR[DIST_RADTAN].copy()
+    intr_b[:4] = [420.0, 415.0, 360.0, 250.0]
+    cam_b = F.camera(intr_b, DIST_RADTAN, 720, 500)
+    T_AB = np.r_[0.3, -0.1, 0.05, _quat([0.2, 1.0, 0.1], 0.35)]
+    n = 300
+    depth = rng.uniform(1.0, 12.0, n)
+    p_A = np.c_[rng.uniform(-0.4, 0.4, n) * depth, rng.uniform(-0.3, 0.3, n) * depth, depth]
+    p_B = (p_A - T_AB[:3]) @ _rot(T_AB[3:])
+    uvA, _ = synthetic.project_points(INTR[DIST_RADTAN], DIST_RADTAN, p_A)
+    uvB, _ = synthetic.project_points(intr_b, DIST_RADTAN, p_B)
+    kpA = np.c_[np.nan_to_num(uvA, nan=50.0), np.full(n, 8.0)].astype(np.float32)
+    kpB = np.c_[np.nan_to_num(uvB, nan=50.0), np.full(n, 6.0)].astype(np.float32)
+    pairs = np.c_[np.arange(n), np.arange(n)].astype(np.int32)
+    Ufull = np.diag([2e-2] * 3 + [1e-6] * 3)
+    Ufull[0, 1] = Ufull[1, 0] = 5e-3                                     # a full (non-diagonal) relative uncertainty
+    flags, _, _ = _compare_tri((cam, cam_b, T_AB, Ufull, kpA, kpB, pairs, None))
+    assert (flags & F.TRI_VALID != 0).sum() > 100
+
+
+def test_empty_and_bad_arguments():
+    g = F.Frontend(0)
+    cam = F.camera(INTR[DIST_RADTAN], DIST_RADTAN)
+    hp, cov, fl = g.stereo_triangulate(cam, cam, [0.1, 0, 0, 0, 0, 0, 1], np.eye(6), np.zeros((3, 3)), np.zeros((3, 3)),
+                                       np.zeros((0, 2), np.int32))
+    assert hp.shape == (0, 4) and fl.size == 0
+    from okvis_amd._lib import BackendError
+    with pytest.raises(BackendError):                                    # pair index out of range
+        g.stereo_triangulate(cam, cam, [0.1, 0, 0, 0, 0, 0, 1], np.eye(6), np.zeros((3, 3)), np.zeros((3, 3)), [[0, 3]])
+    with pytest.raises(BackendError):                                    # UOplus not positive definite
+        g.stereo_triangulate(cam, cam, [0.1, 0, 0, 0, 0, 0, 1], -np.eye(6), np.zeros((3, 3)), np.zeros((3, 3)), [[0, 0]])
+    g.close()
+
+
+@pytest.mark.parametrize("model", [DIST_EQUIDISTANT, DIST_RADTAN, DIST_RADTAN8, DIST_NONE])
+def test_projection_and_gating_3d2d(model):
+    rng = np.random.default_rng(20 + model)
+    cam = F.camera(INTR[model], model)
+    n = 1500
+    T_CbW = np.r_[rng.normal(size=3), _quat(rng.normal(size=3), 0.4)]
+    # landmarks all around the camera: in front, behind, outside the image, w < 0, w = 0 and one on the principal plane
+    p_C = np.c_[rng.uniform(-8, 8, n), rng.uniform(-6, 6, n), rng.uniform(-4, 12, n)]
+    p_C[0] = [1.0, 1.0, 0.0]
+    w = rng.choice([1.0, 1.0, 1.0, 0.5, -1.0, 0.0, 1e-3], n)
+    C = _rot(T_CbW[3:])
+    hp_W = np.c_[(p_C - w[:, None] * T_CbW[:3]) @ C, w]                  # T_CbW hp_W = (p_C, w)
+    P3 = np.eye(3) * 1.69e-2 if model % 2 else np.eye(3) * 4e-8
+    g, r = F.Frontend(0), _ref()
+    uvg, Ug, sg = g.project_landmarks(cam, T_CbW, P3, hp_W)
+    uvr, Ur, sr = r.project_landmarks(cam, T_CbW, P3, hp_W)
+    assert np.array_equal(sg, sr)
+    assert set(np.unique(sr)) >= {F.PROJ_SUCCESSFUL, F.PROJ_OUTSIDE_IMAGE, F.PROJ_BEHIND}
+    good = sr == F.PROJ_SUCCESSFUL
+    assert good.sum() > 50
+    assert np.abs(uvg[good] - uvr[good]).max() <= 1e-9
+    assert (np.abs(Ug[good] - Ur[good]) / np.abs(Ur[good]).max(axis=(1, 2))[:, None, None]).max() <= 1e-10
+    # gating: keypoints near the projections (some within 2 sigma, some not) and random pairs
+    idx = np.flatnonzero(good)
+    kpB = np.c_[uvr[idx] + rng.normal(size=(len(idx), 2)) * rng.choice([0.3, 2.0, 6.0], len(idx))[:, None],
+                rng.choice([4.0, 8.0, 16.0, 60.0], len(idx))].astype(np.float32)
+    pairs = np.r_[np.c_[idx, np.arange(len(idx))], np.c_[rng.choice(idx, 200), rng.integers(0, len(idx), 200)]].astype(np.int32)
+    cg, fg = g.gate_3d2d(uvr, Ur, kpB, pairs)
+    cr, fr = r.gate_3d2d(uvr, Ur, kpB, pairs)
+    g.close()
+    assert np.abs(cg - cr).max() <= 1e-9 * max(1.0, np.abs(cr).max())
+    # flags: identical except where chi2 sits within rounding of the threshold 4
+    edge = np.abs(cr - 4.0) < 1e-9
+    assert np.array_equal(fg[~edge], fr[~edge])
+    assert 0.2 < (fr & F.GATE_VERIFIED != 0).mean() < 0.9 and (fr & F.GATE_UNCERTAIN != 0).any()
