@@ -1224,8 +1224,10 @@ int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt) {
 
 int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows) {
   if (!s || n_windows <= 0 || !windows) return OKVIS_BA_ERR_ARG;
+  const auto t_enter = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  const auto t_synced = std::chrono::steady_clock::now();
   destroy_graphs(s);
   s->uploaded = false;
   s->begun = false;
@@ -1341,7 +1343,9 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   s->acc_fresh = true;   // Ctrl starts zeroed: accepted buffer 0, like HostWin::acc
   if (dbg_t) {
     const auto t_u2 = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "upload: index build %.3f ms, staging + enqueue %.3f ms, arena %zu bytes data + %zu zero\n",
+    std::fprintf(stderr, "upload: sync %.3f ms, graphs %.3f ms, index build %.3f ms, staging + enqueue %.3f ms, arena %zu bytes data + %zu zero\n",
+                 std::chrono::duration<double, std::milli>(t_synced - t_enter).count(),
+                 std::chrono::duration<double, std::milli>(t_u0 - t_synced).count(),
                  std::chrono::duration<double, std::milli>(t_u1 - t_u0).count(),
                  std::chrono::duration<double, std::milli>(t_u2 - t_u1).count(), (size_t)A.size, (size_t)A.zsize);
   }

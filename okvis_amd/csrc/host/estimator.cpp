@@ -615,8 +615,10 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
       if (bad) std::printf("okvis_amd::Estimator::optimize: input array %zu holds %zu non-finite values of %zu\n", a, bad, fw.f64[a].size());
     }
   check(okvis_ba_set_options(solver_, &options_), "set_options");
+  const auto t1b = clk::now();
   check(okvis_ba_upload(solver_, 1, &fw.w), "upload");
   const auto t2 = clk::now();
+  if (std::getenv("OKVIS_AMD_TRACE")) std::printf("set_options %.4f ms, upload %.4f ms\n", ms(t1, t1b), ms(t1b, t2));
   if (hasTimeLimit_)  // CeresIterationCallback semantics (CeresIterationCallback.hpp:77-86)
     check(okvis_ba_optimize_timed(solver_, (int)numIter, minIterations_, timeLimit_, &summary_), "optimize");
   else
