@@ -189,9 +189,8 @@ typedef struct okvis_ba_options {
                                    1/(1+sqrt(diag J^T J)) of the FIRST linearisation of the optimize() call;
                                    dogleg strategy only                                                          */
   int32_t max_consecutive_invalid_steps; /* 5 (Ceres max_num_consecutive_invalid_steps): then termination 5     */
-  int32_t reserved0;            /* 0 = auto.  The LDS solve can eliminate the speed/bias blocks by independence
-                                   levels before the dense factorisation (same result to rounding):
-                                   auto = below 40 windows; bit 0 forces it on, bit 1 forces it off               */
+  int32_t reserved0;            /* not read (rounds 1-2: forced the level-scheduled elimination of the speed/bias
+                                   blocks on or off; the blocked LDL^T solver of round 3 has no such switch)     */
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */

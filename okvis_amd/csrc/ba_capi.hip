@@ -121,7 +121,6 @@ struct okvis_ba_solver {
   bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0, max_spart_stride = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
-  int max_sbl_blk = 0, max_sbl_stage = 0, max_sbl_tab = 0;   // (unused since the LDL^T solver replaced the level schedule)
   long long stagger_ticks = 0;   // start offset between consecutive sub-batch streams (wall_clock64 ticks, 100 MHz); OKVIS_BA_STAGGER_US
   bool skip_topup = false;   // okvis_ba_optimize_timed ran out of time: finish() must not grant the slots mis-speculated steps still owe
   long long slots = 0;   // launch slots (schur + solve + linearise triples) since okvis_ba_begin: diagnostics (array 96)
@@ -135,7 +134,7 @@ struct okvis_ba_solver {
 
 namespace {
 
-size_t solve_smem(int Dpad, bool large, int sbl_blocks, int sbl_stage, int sbl_tab);
+size_t solve_smem(int Dpad, bool large);
 
 constexpr int SMALL_BATCH_WINDOWS = 40;   // below: the device is not full - settings that shorten one window's chain win
 
@@ -155,12 +154,6 @@ OptD make_optd(const okvis_ba_options& o, int n_windows) {
   d.dogleg = o.strategy == OKVIS_BA_STRATEGY_DOGLEG;
   d.jacobi_scaling = o.jacobi_scaling != 0;
   d.max_invalid = o.max_consecutive_invalid_steps > 0 ? o.max_consecutive_invalid_steps : 5;
-  // level-scheduled elimination of the speed/bias blocks in the LDS solve: -6 us per solve for one window, but its 30 KB of
-  // extra LDS keep other kernels' workgroups off the CU, which costs more than it saves once the device is shared by many
-  // windows (64 windows: 213 vs 201 us per step).  Auto: on below
-  // SMALL_BATCH_WINDOWS (tests/gpu_auto_rules.py: best up to 32 windows, dense order from 48); reserved0 bit 0 forces it on,
-  // bit 1 off.
-  d.no_sb_levels = (o.reserved0 & 2) ? 1 : (o.reserved0 & 1) ? 0 : (n_windows >= SMALL_BATCH_WINDOWS);
   return d;
 }
 
@@ -494,163 +487,9 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       for (int k = 0; k < dims[b]; ++k) imu_coloff[30 * (size_t)f + start[b] + k] = offs[b] < 0 ? -1 : offs[b] + k;
   }
   BW_T("imu colouring");
-  // ---- level schedule of the free speed/bias blocks for the LDS solve: blocks that share no factor (ImuError couples
-  //      sb_k - sb_k+1, the marginalisation prior all the blocks it contains) can be eliminated at the same time; taking
-  //      a block out couples its remaining neighbours pairwise (fill), which the next levels respect ----
-  //      Everything the kernel needs is one int table (copied to LDS): tab[0 .. nblk) the offsets of the eliminated blocks in
-  //      order, tab[nblk + 8 lev ..] the level headers {first block, #blocks, coupling entries, per-block ranges, row groups,
-  //      #row groups, pair index, #pairs}, then the payload:
-  //        coupling entry (row-block R, level block bb):  off | n << 8 | bb << 12 | slot << 16   (slot: first of the n rows of
-  //          Y = C L^-T in the LDS stage; sorted by bb, ranges [nb + 1] relative to the first entry)
-  //        row group (right-hand side update):  index -> { off | n << 8 | cnt << 12, cnt x (slot | bb << 16) }
-  //        pair (matrix update, off1 >= off2):  index -> { off1 | off2 << 8 | n1 << 16 | n2 << 20 | cnt << 24, cnt x (slot1 | slot2 << 16) }
-  std::vector<int> sbe_tab;
-  int sbe_nlev = 0, sbe_nblk = 0, sbe_nstage = 0;
-  {
-    std::vector<int> fsb;   // free speed/bias blocks in reduced order
-    for (int i = 0; i < nsb; ++i)
-      if (sb_off[i] >= 0) fsb.push_back(i);
-    const int nf = (int)fsb.size();
-    std::vector<int> idx_of(nsb, -1);
-    for (int k = 0; k < nf; ++k) idx_of[fsb[k]] = k;
-    // row-blocks: free pose blocks as ids 0 .. npb-1 (6 rows each), free speed/bias blocks as npb + k (9 rows);
-    // nbr[k][R] = speed/bias block k is coupled with row-block R (symbolic; fill added as blocks are eliminated)
-    std::vector<int> rb_off, rb_n, pose_id(npose, -1);
-    for (int i = 0; i < npose; ++i)
-      if (pose_off[i] >= 0) {
-        pose_id[i] = (int)rb_off.size();
-        rb_off.push_back(pose_off[i]);
-        rb_n.push_back(6);
-      }
-    const int npb = (int)rb_off.size();
-    for (int k = 0; k < nf; ++k) {
-      rb_off.push_back(sb_off[fsb[k]]);
-      rb_n.push_back(9);
-    }
-    std::vector<std::vector<char>> nbr(nf, std::vector<char>(npb + nf, 0));
-    auto couple = [&](const std::vector<int>& blocks) {   // all blocks of one factor are pairwise coupled
-      for (int a : blocks)
-        for (int b : blocks)
-          if (a != b && a >= npb) nbr[a - npb][b] = 1;
-    };
-    for (int f = 0; f < w.n_imu; ++f) {
-      std::vector<int> bl;
-      if (pose_id[w.imu_pose0[f]] >= 0) bl.push_back(pose_id[w.imu_pose0[f]]);
-      if (pose_id[w.imu_pose1[f]] >= 0) bl.push_back(pose_id[w.imu_pose1[f]]);
-      if (idx_of[w.imu_sb0[f]] >= 0) bl.push_back(npb + idx_of[w.imu_sb0[f]]);
-      if (idx_of[w.imu_sb1[f]] >= 0) bl.push_back(npb + idx_of[w.imu_sb1[f]]);
-      couple(bl);
-    }
-    {
-      std::vector<int> bl;
-      for (int b = 0; b < w.marg_nblocks; ++b) {
-        if (w.marg_block_type[b] == OKVIS_BA_BLOCK_SPEEDBIAS) {
-          if (idx_of[w.marg_block_idx[b]] >= 0) bl.push_back(npb + idx_of[w.marg_block_idx[b]]);
-        } else if (pose_id[w.marg_block_idx[b]] >= 0) {
-          bl.push_back(pose_id[w.marg_block_idx[b]]);
-        }
-      }
-      couple(bl);
-    }
-    std::vector<char> gone(nf, 0);
-    int left = nf, slot_next = 0;
-    bool ok = D <= MAX_D_LDS && nf >= 2;
-    std::vector<int> order;                          // offsets of the eliminated blocks
-    std::vector<std::array<int, 8>> headers;
-    std::vector<int> payload;                        // indices relative to the payload start until the table is put together
-    while (ok && left > 0) {
-      std::vector<int> level;
-      for (int k = 0; k < nf; ++k) {
-        if (gone[k]) continue;
-        bool indep = true;
-        for (int m : level) indep = indep && !nbr[k][npb + m];
-        if (indep) level.push_back(k);
-      }
-      if ((int)level.size() > 15) level.resize(15);   // 4-bit block index in the entries
-      const int nb = (int)level.size();
-      std::array<int, 8> hd;
-      hd[0] = (int)order.size();
-      hd[1] = nb;
-      // coupling entries sorted by level block
-      struct Ent { int R, bb, slot; };
-      std::vector<Ent> ents;
-      std::vector<int> range(1, 0);
-      for (int bb = 0; bb < nb; ++bb) {
-        const int k = level[bb];
-        for (int R = 0; R < npb + nf; ++R) {
-          if (!nbr[k][R] || (R >= npb && gone[R - npb])) continue;
-          ents.push_back(Ent{R, bb, slot_next});
-          slot_next += rb_n[R];
-        }
-        range.push_back((int)ents.size());
-      }
-      hd[2] = (int)payload.size();
-      for (const Ent& e : ents) payload.push_back(rb_off[e.R] | rb_n[e.R] << 8 | e.bb << 12 | e.slot << 16);
-      hd[3] = (int)payload.size();
-      for (int r : range) payload.push_back(r);
-      // row groups and pairs
-      std::map<int, std::vector<int>> groups;                    // R -> slot | bb << 16
-      std::map<std::pair<int, int>, std::vector<int>> pairs;     // (R1, R2), off1 >= off2 -> slot1 | slot2 << 16
-      for (const Ent& e : ents) groups[e.R].push_back(e.slot | e.bb << 16);
-      for (const Ent& e1 : ents)
-        for (const Ent& e2 : ents)
-          if (e1.bb == e2.bb && rb_off[e1.R] >= rb_off[e2.R]) pairs[{e1.R, e2.R}].push_back(e1.slot | e2.slot << 16);
-      std::vector<int> gidx, pidx;
-      for (const auto& g : groups) {
-        gidx.push_back((int)payload.size());
-        payload.push_back(rb_off[g.first] | rb_n[g.first] << 8 | (int)g.second.size() << 12);
-        payload.insert(payload.end(), g.second.begin(), g.second.end());
-      }
-      for (const auto& pr : pairs) {
-        pidx.push_back((int)payload.size());
-        payload.push_back(rb_off[pr.first.first] | rb_off[pr.first.second] << 8 | rb_n[pr.first.first] << 16 |
-                          rb_n[pr.first.second] << 20 | (int)pr.second.size() << 24);
-        payload.insert(payload.end(), pr.second.begin(), pr.second.end());
-      }
-      hd[4] = (int)payload.size();
-      hd[5] = (int)gidx.size();
-      payload.insert(payload.end(), gidx.begin(), gidx.end());
-      hd[6] = (int)payload.size();
-      hd[7] = (int)pidx.size();
-      payload.insert(payload.end(), pidx.begin(), pidx.end());
-      headers.push_back(hd);
-      for (int k : level) {
-        gone[k] = 1;
-        --left;
-        order.push_back(sb_off[fsb[k]]);
-      }
-      for (int k : level)   // fill: the remaining neighbours of an eliminated block become coupled
-        for (int a = 0; a < nf; ++a) {
-          if (gone[a] || !nbr[k][npb + a]) continue;
-          for (int R = 0; R < npb + nf; ++R)
-            if (nbr[k][R] && R != npb + a && !(R >= npb && gone[R - npb])) nbr[a][R] = 1;
-        }
-      if (slot_next >= 65536) ok = false;   // 16-bit slots in the table
-    }
-    if (std::getenv("OKVIS_BA_DEBUG_SBL"))
-      std::fprintf(stderr, "sbl: ok %d nf %d D %d levels %zu blocks %zu stage rows %d table %zu\n", (int)ok, nf, D, headers.size(), order.size(), slot_next, order.size() + 8 * headers.size() + payload.size());
-    // (the stage and the table have to fit in LDS next to the matrix; windows that do not fit use the dense order)
-    if (ok && solve_smem(((D + 5) / 6) * 6, false, (int)order.size(), slot_next, (int)(order.size() + 8 * headers.size() + payload.size())) > (size_t)SOLVE_LDS_LIMIT) ok = false;
-    if (ok && !order.empty()) {
-      sbe_nstage = slot_next;
-      sbe_nlev = (int)headers.size();
-      sbe_nblk = (int)order.size();
-      const int base = sbe_nblk + 8 * sbe_nlev;
-      sbe_tab = order;
-      for (const auto& hd : headers)
-        for (int q = 0; q < 8; ++q) sbe_tab.push_back((q == 0 || q == 1 || q == 5 || q == 7) ? hd[q] : hd[q] + base);
-      for (size_t q = 0; q < payload.size(); ++q) sbe_tab.push_back(payload[q]);
-      // the group / pair index arrays hold payload positions: make them absolute
-      for (const auto& hd : headers) {
-        for (int q = 0; q < hd[5]; ++q) sbe_tab[base + hd[4] + q] += base;
-        for (int q = 0; q < hd[7]; ++q) sbe_tab[base + hd[6] + q] += base;
-      }
-    }
-  }
   const int npose_blk = Dp / 6;
   const int spart_stride = npose_blk * (npose_blk + 1) / 2 * 36 + 3 * Dp;
   const int ntile = std::max(1, (Dp / 6 + SCHUR_TILE_BLOCKS - 1) / SCHUR_TILE_BLOCKS);
-  BW_T("sb levels");
   // ---- observation records ----
   std::vector<ObsRec> recs(nobs);
   for (int o = 0; o < nobs; ++o) {
@@ -743,16 +582,6 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(chunk_diag_out, put(A, chunk_diag_out));
   OFF(chunk_cross_begin, put(A, chunk_cross_begin));
   OFF(chunk_cross, put(A, chunk_cross));
-  {
-    // pose block q = bi (bi + 1) / 2 + bj of the Schur partials -> offset in the solve kernel's LDS layout
-    // (SLayout, ba_solve.hpp: block-column major, block stride SBS)
-    const int nbk = (D + 5) / 6;
-    std::vector<int> sp_blk_off;
-    for (int bi = 0; bi < npose_blk_c; ++bi)
-      for (int bj = 0; bj <= bi; ++bj) sp_blk_off.push_back((bj * nbk - (bj * (bj - 1)) / 2 + (bi - bj)) * SBS);
-    if (sp_blk_off.empty()) sp_blk_off.push_back(0);
-    OFF(sp_blk_off, put(A, sp_blk_off));
-  }
   OFF(imu_order, put(A, imu_order));
   OFF(imu_color_begin, put(A, imu_color_begin));
   OFF(imu_coloff, put(A, imu_coloff));
@@ -801,13 +630,6 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (imu_rev.empty()) imu_rev.push_back(make_int2(-1, -1));
     OFF(imu_rev, put(A, imu_rev));
   }
-  P.sbe_nlev = 0;   // (the level schedule of the old LDS Cholesky is not used by the LDL^T solver)
-  (void)sbe_nlev;
-  P.sbe_nblk = sbe_nblk;
-  P.sbe_ntab = (int)sbe_tab.size();
-  P.sbe_nstage = sbe_nstage;
-  if (sbe_tab.empty()) sbe_tab.push_back(0);
-  OFF(sbe_tab, put(A, sbe_tab));
   for (int b = 0; b < 2; ++b) {
     OFF(V[b], put_zero(A, 48 * (size_t)nlm));
     OFF(bl[b], put_zero(A, 24 * (size_t)nlm));
@@ -959,7 +781,7 @@ size_t lin_smem(bool ext, bool f32 = false) {
                     : (ext ? LinCfg<true, double>::SMEM_DOUBLES : LinCfg<false, double>::SMEM_DOUBLES);
   return (size_t)d * sizeof(double);
 }
-size_t solve_smem(int Dpad, bool large, int, int, int) {
+size_t solve_smem(int Dpad, bool large) {
   // LDS-resident: the matrix area of the LDL^T solver (ba_ldl16.hpp; Dpad >= D bounds it) + four vectors
   return ((large ? 0 : (size_t)ldl16_area_doubles(Dpad)) + 4 * (size_t)Dpad) * sizeof(double) + 16;
 }
@@ -987,11 +809,11 @@ hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
 }
 hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
   if (s->max_Dpad_small > 0)
-    hipLaunchKernelGGL(solve_kernel<false>, dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false, s->max_sbl_blk, s->max_sbl_stage, s->max_sbl_tab), b.st,
+    hipLaunchKernelGGL(solve_kernel<false>, dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), b.st,
                        s->d_wins + b.w0, s->d_opt, final_only);
   if (s->max_Dpad_large > 0) {
     // large windows: assemble + export, tiled multi-workgroup Cholesky (fp64 MFMA), back-substitution + finish
-    hipLaunchKernelGGL(solve_kernel<true>, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true, 0, 0, 0), b.st,
+    hipLaunchKernelGGL(solve_kernel<true>, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), b.st,
                        s->d_wins + b.w0, s->d_opt, final_only);
     if (!final_only) {
       const int nT = (s->max_Dpad_large + CT_TB - 1) / CT_TB;
@@ -1163,10 +985,10 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
                             (int)(2 * SCHUR_LM_BATCH * TILE_DIM * 3 * sizeof(double)));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            std::max((int)solve_smem(((MAX_D_LDS + 5) / 6) * 6, false, 0, 0, 0), SOLVE_LDS_LIMIT));
+                            std::max((int)solve_smem(((MAX_D_LDS + 5) / 6) * 6, false), SOLVE_LDS_LIMIT));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)solve_smem(((MAX_D + 5) / 6) * 6, true, 0, 0, 0));
+                            (int)solve_smem(((MAX_D + 5) / 6) * 6, true));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_tiles_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             CT_SMEM_DOUBLES * 8);
@@ -1264,7 +1086,6 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   std::vector<WinPtrs> ptrs(n_windows);
   s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = s->max_spart_stride = 0;
   s->max_Dpad_small = s->max_Dpad_large = 0;
-  s->max_sbl_blk = s->max_sbl_stage = s->max_sbl_tab = 0;
   s->any_ext = false;
   for (int i = 0; i < n_windows; ++i) {
     relocate(wins[i].ptrs, s->d_arena, zbase, s->opt.debug_arrays);
@@ -1279,19 +1100,9 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     s->max_Dp = std::max(s->max_Dp, P.Dp);
     if (P.D <= MAX_D_LDS) {
       s->max_Dpad_small = std::max(s->max_Dpad_small, ((P.D + 5) / 6) * 6);
-      if (P.sbe_nlev > 0) {
-        s->max_sbl_blk = std::max(s->max_sbl_blk, P.sbe_nblk);
-        s->max_sbl_stage = std::max(s->max_sbl_stage, P.sbe_nstage);
-        s->max_sbl_tab = std::max(s->max_sbl_tab, P.sbe_ntab);
-      }
     } else
       s->max_Dpad_large = std::max(s->max_Dpad_large, ((P.D + 5) / 6) * 6);
     s->any_ext = s->any_ext || P.has_ext;
-  }
-  if (solve_smem(s->max_Dpad_small, false, s->max_sbl_blk, s->max_sbl_stage, s->max_sbl_tab) > (size_t)SOLVE_LDS_LIMIT) {
-    // the largest matrix and the largest schedule belong to different windows and do not fit together: dense order for all
-    for (int i = 0; i < n_windows; ++i) ptrs[i].sbe_nlev = 0;
-    s->max_sbl_blk = s->max_sbl_stage = s->max_sbl_tab = 0;
   }
   if ((size_t)n_windows > s->wins_capacity) {
     if (s->d_wins) HIP_TRY(hipFree(s->d_wins));
@@ -2007,7 +1818,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   s->begun = false;
   const Sub one{s->stream, w, 1};
   HIP_TRY(launch_schur(s, one));
-  hipLaunchKernelGGL(solve_kernel<false>, dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false, s->max_sbl_blk, s->max_sbl_stage, s->max_sbl_tab), s->stream, d_win,
+  hipLaunchKernelGGL(solve_kernel<false>, dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream, d_win,
                      s->d_opt, 2);
   HIP_TRY(hipGetLastError());
   MargArgs ma;

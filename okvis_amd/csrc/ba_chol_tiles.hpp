@@ -12,7 +12,7 @@
 //   dependency marks the factorisation as failed instead of hanging the GPU.)
 //
 //     off-diagonal (i,j):  C = A_ij - sum_k L_ik L_jk^T  (MFMA);  L_ij = C L_jj^-T = C (Linv_j)^T  (MFMA)
-//     diagonal (j,j):      C = A_jj - sum_k L_jk L_jk^T  (MFMA);  L_jj = chol(C) in LDS (ct_potrf_trinv48),
+//     diagonal (j,j):      C = A_jj - sum_k L_jk L_jk^T  (MFMA);  L_jj^-1 in LDS (ct_ldl_inv48),
 //                          Linv_j = L_jj^-1 (published for the column's TRSMs and for the back-substitution),
 //                          y_j = Linv_j (rhs_j - sum_k L_jk y_k)  (forward substitution rides along)
 //   back-substitution L^T x = y: nT more tasks behind the tiles (chol_backsub_task): workgroup b owns tile row j = nT-1-b,
@@ -31,7 +31,6 @@ constexpr int CT_LD = 49;            // LDS row stride (doubles): conflict-free 
 constexpr int CT_THREADS = 256;
 constexpr int CT_TILE = CT_TB * CT_TB;
 constexpr int CT_SPIN_LIMIT = 1 << 22;
-constexpr int CT_NB = 6;             // block-column width inside a diagonal tile (ct_potrf_trinv48)
 
 typedef double ct_v4 __attribute__((ext_vector_type(4)));
 
@@ -101,157 +100,11 @@ __device__ __forceinline__ double ct_rsqrt(double x) {  // v_rsq_f64 + two Newto
   return y;
 }
 
-// Cholesky factor AND inverse of a diagonal tile (the serial chain of the tiled solver) in LDS: right-looking NB-wide block
-// columns (NB = CT_NB; the diagonal block by one work-item in registers, reciprocal square roots instead of divisions), with
-//   * look-ahead: while waves 1-3 apply the trailing update of block column kb, wave 0 updates the NEXT 6x6 diagonal block
-//     alone (one lane per entry), then factors and inverts it in registers (lane 0) - two barriers per block column
-//     instead of three, and the serial factorisation is off the critical path;
-//   * the triangular inverse rides along: block row bi of X = L^-1 needs the L rows of block row bi (final after the panel
-//     steps kb < bi), X_(bi,bi) (from the look-ahead) and the X rows above; its two products are spread over the panel and
-//     update phases of step kb = bi, so the inverse costs no barrier phases of its own.
-// M: 48x48 SPD in LDS (stride CT_LD, lower triangle referenced) -> L.  X: L^-1 (stride CT_LD, full square, zeros above the
-// diagonal).  Tm: 6 x 48 scratch.  A non-positive pivot sets *s_fail.
-template <int NB>
-__device__ __forceinline__ void ct_factor_inv_block(double* M, double* X, double* dinv, int k0, int* s_fail) {
-  // one work-item: NB x NB Cholesky of M[k0.., k0..] in registers (reciprocal square roots), its inverse into X
-  double a[NB][NB], di[NB];
-#pragma unroll
-  for (int r = 0; r < NB; ++r)
-#pragma unroll
-    for (int c = 0; c <= r; ++c) a[r][c] = M[(k0 + r) * CT_LD + k0 + c];
-  bool bad = false;
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double d = a[c][c];
-#pragma unroll
-    for (int m = 0; m < c; ++m) d -= a[c][m] * a[c][m];
-    if (!(d > 0.0)) {
-      bad = true;
-      d = 1.0;
-    }
-    const double inv = ct_rsqrt(d);
-    a[c][c] = d * inv;
-    di[c] = inv;
-    dinv[k0 + c] = inv;
-#pragma unroll
-    for (int r = c + 1; r < NB; ++r) {
-      double v = a[r][c];
-#pragma unroll
-      for (int m = 0; m < c; ++m) v -= a[r][m] * a[c][m];
-      a[r][c] = v * inv;
-    }
-  }
-  if (bad) *s_fail = 1;
-#pragma unroll
-  for (int r = 0; r < NB; ++r)
-#pragma unroll
-    for (int c = 0; c <= r; ++c) M[(k0 + r) * CT_LD + k0 + c] = a[r][c];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {  // inverse, column by column
-    double x[NB];
-#pragma unroll
-    for (int r = c; r < NB; ++r) {
-      double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int m = c; m < r; ++m) v -= a[r][m] * x[m];
-      x[r] = v * di[r];
-      X[(k0 + r) * CT_LD + k0 + c] = x[r];
-    }
-  }
-}
-
-template <int NB>
-__device__ void ct_potrf_trinv48(double* M, double* X, double* dinv, double* Tm, int tid, int* s_fail) {
-  constexpr int NS = CT_TB / NB, NTRI = NB * (NB + 1) / 2;
-  static_assert(NS * NB == CT_TB && NTRI <= 64 && NB <= 16, "block width");
-  for (int e = tid; e < CT_TB * CT_TB; e += CT_THREADS) X[(e / CT_TB) * CT_LD + (e % CT_TB)] = 0.0;
-  __syncthreads();
-  if (tid == 0) ct_factor_inv_block<NB>(M, X, dinv, 0, s_fail);
-  __syncthreads();
-  for (int kb = 0; kb < NS; ++kb) {
-    const int k0 = NB * kb, nrows = CT_TB - k0 - NB;
-    // ---- phase P: panel of block column kb: row <- row L_kk^-T; first product of the inverse row (threads from the top)
-    if (tid < nrows) {
-      double* row = M + (k0 + NB + tid) * CT_LD + k0;
-      double x[NB];
-#pragma unroll
-      for (int c = 0; c < NB; ++c) {
-        double v = row[c];
-#pragma unroll
-        for (int m = 0; m < c; ++m) v -= x[m] * M[(k0 + c) * CT_LD + k0 + m];
-        x[c] = v * dinv[k0 + c];
-      }
-#pragma unroll
-      for (int c = 0; c < NB; ++c) row[c] = x[c];
-    }
-    if (kb > 0) {   // T = L_(kb, 0..kb-1) X_(0..kb-1, .)   (NB x NB kb), by the threads from the top
-      const int ncol = k0;
-      for (int e = CT_THREADS - 1 - tid; e < NB * ncol; e += CT_THREADS) {
-        const int r = e / ncol, c = e - r * ncol;
-        const int m0 = (c / NB) * NB;   // X is lower triangular: rows >= the column's block start
-        double t = 0;
-        for (int m = m0; m < ncol; ++m) t += M[(k0 + r) * CT_LD + m] * X[m * CT_LD + c];
-        Tm[r * CT_TB + c] = t;
-      }
-    }
-    __syncthreads();
-    // ---- phase U: wave 0 prepares the next diagonal block; the others apply the trailing update and finish the inverse row
-    if (tid < 64) {
-      if (kb < NS - 1) {
-        if (tid < NTRI) {   // entry (r, c), c <= r, of the next diagonal block -= panel row r . panel row c
-          int r = 0;
-          while ((r + 1) * (r + 2) / 2 <= tid) ++r;
-          const int c = tid - r * (r + 1) / 2;
-          const double* pa = M + (k0 + NB + r) * CT_LD + k0;
-          const double* pb = M + (k0 + NB + c) * CT_LD + k0;
-          double t = 0;
-#pragma unroll
-          for (int m = 0; m < NB; ++m) t += pa[m] * pb[m];
-          M[(k0 + NB + r) * CT_LD + k0 + NB + c] -= t;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (tid == 0) ct_factor_inv_block<NB>(M, X, dinv, k0 + NB, s_fail);
-      }
-    } else {
-      const int t2 = tid - 64, nt2 = CT_THREADS - 64;
-      // trailing update of the lower triangle below / right of the next diagonal block (that block is wave 0's)
-      const int ntri = nrows * (nrows + 1) / 2;
-      for (int e = NTRI + t2; e < ntri; e += nt2) {   // row-major lower triangle; its first NTRI entries are the next diagonal block
-        int r = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
-        while ((r + 1) * (r + 2) / 2 <= e) ++r;
-        while (r * (r + 1) / 2 > e) --r;
-        const int c = e - r * (r + 1) / 2;
-        const double* pa = M + (k0 + NB + r) * CT_LD + k0;
-        const double* pb = M + (k0 + NB + c) * CT_LD + k0;
-        double t = 0;
-#pragma unroll
-        for (int m = 0; m < NB; ++m) t += pa[m] * pb[m];
-        M[(k0 + NB + r) * CT_LD + k0 + NB + c] -= t;
-      }
-      if (kb > 0) {   // X_(kb, .) = -X_(kb,kb) T
-        const int ncol = k0;
-        for (int e = t2; e < NB * ncol; e += nt2) {
-          const int r = e / ncol, c = e - r * ncol;
-          double t = 0;
-#pragma unroll
-          for (int m = 0; m < NB; ++m)
-            if (m <= r) t += X[(k0 + r) * CT_LD + k0 + m] * Tm[m * CT_TB + c];
-          X[(k0 + r) * CT_LD + c] = -t;
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
 // The inverse Cholesky factor of a diagonal tile through a blocked LDL^T with 16-wide panels: the three 16x16 diagonal
 // blocks are eliminated by ONE wave in registers (ldl16_eliminate, ba_ldl16.hpp: column per lane, pivot column by DPP
 // row_newbcast, the unit-lower inverse in the same registers), everything between them is 16x16x16 products by all 256
-// work-items from LDS.  Twelve barrier phases of ~0.3 us and three eliminations of ~0.85 us instead of the 8 block
-// columns x (panel, look-ahead factor + inverse by one work-item, trailing update) of ct_potrf_trinv48 (20.5 us per tile:
-// the serial chain of the tiled solver).
+// work-items from LDS.  Twelve barrier phases of ~0.3 us and three eliminations of ~0.85 us: 9 us per tile (rounds 1-2: a
+// right-looking factorisation with 6-wide block columns, the diagonal block factored and inverted by one work-item, 20.5 us).
 //   M: 48x48 SPD in LDS (stride CT_LD, lower triangle referenced; overwritten).  X: L^-1 with A = L L^T (full square, zeros
 //   above the diagonal) = D^-1/2 Lt^-1 for A = Lt D Lt^T.  R: 48 x CT_LD scratch.  dinv: 48 doubles scratch.
 __device__ void ct_ldl_inv48(double* M, double* X, double* R, double* dinv, int tid, int* s_fail) {
@@ -454,7 +307,7 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
   double* sB = lds + CT_TB * CT_LD;
   double* sC = lds + 2 * CT_TB * CT_LD;
   __shared__ int s_ok, s_fail;
-  __shared__ double s_r[CT_TB], s_dinv[CT_TB], s_tm[CT_NB * CT_TB];
+  __shared__ double s_r[CT_TB], s_dinv[CT_TB];
   int* failflag = C.flag + nT * (nT + 1) / 2;
   if (tid == 0) {
     s_ok = 1;

@@ -95,7 +95,6 @@ struct OptD {
   int dogleg;        // 1 = Ceres' DOGLEG strategy (the reference's configuration), 0 = Levenberg-Marquardt
   int jacobi_scaling;
   int max_invalid;   // max_num_consecutive_invalid_steps
-  int no_sb_levels;  // 1 = factorise the speed/bias blocks as part of the dense block columns (A/B switch, diagnostics)
 };
 
 // DoglegStrategy constants (Ceres: kMinMu, kMaxMu, mu_increase_factor_)
@@ -155,8 +154,6 @@ struct WinPtrs {
   int n_tile;             // Schur tiles per dimension
   int n_imu_color;
   int ct_nT;              // tile rows of the tiled dense solver (0 = the LDS solver handles this window)
-  int sbe_nlev, sbe_nblk; // levels / blocks of the speed/bias elimination schedule (0 = not used)
-  int sbe_ntab, sbe_nstage; // ints in sbe_tab; rows of the LDS stage the schedule needs
   int spart_stride;       // doubles per chunk partial: (Dp/6)(Dp/6+1)/2*36 + 3*Dp  (S | Y b | g | diag U)
   double cauchy_b;
   ImuParamsD imu;
@@ -187,14 +184,10 @@ struct WinPtrs {
   const BA_G int* chunk_diag_begin;   // [n_chunk * (Dp/6) + 1] into chunk_diag_out
   const BA_G int* chunk_diag_out;
   const BA_G int* chunk_cross_begin;  // [n_chunk + 1] into chunk_cross (triples off_a, off_b, out)
-  const BA_G int* sp_blk_off;         // [Dp/6 (Dp/6+1)/2] offset (doubles) of pose block q of the partials in the solve kernel's LDS layout
   const BA_G int* chunk_cross;
   const BA_G int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
   const BA_G int* imu_color_begin;    // [n_imu_color+1]
   const BA_G int* imu_coloff;         // [n_imu][30] reduced index of each local column (or -1)
-  // level schedule of the speed/bias blocks for the LDS solve (ba_solve.hpp; layout documented where build_window makes it)
-  // (the counts sbe_nlev / sbe_nblk / sbe_ntab sit with the other sizes: this region must hold pointers only, see relocate())
-  const BA_G int* sbe_tab;
   const BA_G int2* imu_rev;           // large windows (matrix in HBM): per entry of the block-packed matrix the (up to two) IMU record
                                  // entries f * 512 + e that land there, or -1: gathered by large_export_kernel
   const BA_G int4* imu_asm;           // [n_imu][512] where entry e of factor f's H|g record lands in the solve kernel's LDS
