@@ -378,6 +378,17 @@ int okvis_ba_shard(int32_t n_total, int32_t rank, int32_t world, int32_t* ids_ou
  * all_windows: the n_total windows of the job (only the rank's share is touched).  records_out capacity as above. */
 int okvis_ba_batch_run(int device, int32_t rank, int32_t world, int32_t n_total, const okvis_ba_window* all_windows,
                        const okvis_ba_options* opt, int num_iter, okvis_ba_window_record* records_out, int32_t* n_out);
+/* The all-gather of the records WITHOUT a Python launcher in the data path: RCCL loaded at run time (dlopen librccl.so;
+ * OKVIS_BA_RCCL_LIB names another file), one communicator per call.  Every rank passes n_per_rank records (ranks with
+ * fewer windows pad with window_id = 0xffffffff); all [world][n_per_rank].  The ncclUniqueId goes from rank 0 to the others
+ * through `id_file` (a path every rank sees; written with an atomic rename, polled for up to timeout_s; not needed for
+ * world = 1).  OKVIS_BA_ERR_UNSUPPORTED: no RCCL library found; OKVIS_BA_ERR_STATE: id file timeout or an RCCL error. */
+int okvis_ba_gather_records(int32_t rank, int32_t world, int device, const char* id_file, double timeout_s,
+                            const okvis_ba_window_record* mine, int32_t n_per_rank, okvis_ba_window_record* all);
+/* okvis_ba_batch_run + okvis_ba_gather_records: every rank returns the records of ALL n_total windows in window order */
+int okvis_ba_batch_run_gathered(int device, int32_t rank, int32_t world, int32_t n_total, const okvis_ba_window* all_windows,
+                                const okvis_ba_options* opt, int num_iter, const char* id_file, double timeout_s,
+                                okvis_ba_window_record* all_records);
 
 /* ---- diagnostics ------------------------------------------------------------------------------------
  * The dense solver behind windows whose reduced dimension exceeds the single-workgroup LDS path

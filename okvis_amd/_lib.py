@@ -17,7 +17,7 @@ SYMBOLS = [
     "okvis_ba_evaluate_cost", "okvis_ba_get_state", "okvis_ba_fetch_results", "okvis_ba_array_size", "okvis_ba_download",
     "okvis_ba_reduced_dim", "okvis_ba_pair_count", "okvis_ba_pairs", "okvis_ba_last_iterate_ms",
     "okvis_ba_profile_iterations", "okvis_ba_profile_launches", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize", "okvis_ba_marginalize",
-    "okvis_ba_dense_solve", "okvis_ba_shard", "okvis_ba_batch_run",
+    "okvis_ba_dense_solve", "okvis_ba_shard", "okvis_ba_batch_run", "okvis_ba_gather_records", "okvis_ba_batch_run_gathered",
 ]
 
 _dp = C.POINTER(C.c_double)

@@ -17,6 +17,7 @@ BA_HEADERS = ["ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp"
               "ba_marg.hpp", "ba_chol_tiles.hpp", "ba_ldl16.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
 UNITS = {
     "ba_capi.hip": BA_HEADERS,                                     # the bundle-adjustment path (include/okvis_amd_ba.h)
+    "dist_capi.hip": [os.path.join("..", "..", "include", "okvis_amd_ba.h")],   # record all-gather over RCCL (dlopen)
     "fe_capi.hip": ["fe_kernels.hpp", "ba_math.hpp", os.path.join("..", "..", "include", "okvis_amd_frontend.h"),
                     os.path.join("..", "..", "include", "okvis_amd_ba.h")],   # frontend pieces (include/okvis_amd_frontend.h)
 }
@@ -57,7 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             subprocess.check_call(cmd)
             relink = True
     if relink or any(os.path.getmtime(_obj(s)) > os.path.getmtime(LIB) for s in SOURCES):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj(s) for s in SOURCES], "-o", LIB]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj(s) for s in SOURCES], "-ldl", "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -71,6 +71,31 @@ def batch_run(windows, rank: int, world: int, device: int, num_iter: int, option
     return [[float(recs[i].window_id), float(recs[i].iterations), recs[i].final_cost, recs[i].seconds] for i in range(n.value)]
 
 
+def batch_run_gathered(windows, rank: int, world: int, device: int, num_iter: int, id_file: str, options=None, timeout_s=60.0):
+    """okvis_ba_batch_run_gathered: the whole multi-GPU job from C++ — shard, run this rank's share, all-gather the records over
+    RCCL (loaded by the library with dlopen; `id_file` carries the ncclUniqueId between the ranks).  Returns the records of
+    ALL windows in window order; Python / torch is only the process launcher."""
+    import ctypes as C
+    from . import _lib
+    from .window import OptionsC, WindowC
+    L = _lib.lib()
+    L.okvis_ba_batch_run_gathered.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.POINTER(WindowC), C.POINTER(OptionsC),
+                                              C.c_int, C.c_char_p, C.c_double, C.c_void_p]
+    arr = (WindowC * len(windows))()
+    keep = []
+    for i, w in enumerate(windows):
+        w.validate()
+        wc, k = w.as_c()
+        arr[i] = wc
+        keep.append(k)
+    recs = (WindowRecordC * len(windows))()
+    _lib.check(L.okvis_ba_batch_run_gathered(device, rank, world, len(windows), arr, C.byref(options) if options is not None else None,
+                                             num_iter, os.fsencode(id_file), float(timeout_s), C.cast(recs, C.c_void_p)),
+               "batch_run_gathered")
+    del keep
+    return [[float(r.window_id), float(r.iterations), r.final_cost, r.seconds] for r in recs]
+
+
 def init(backend: str | None = None):
     """Initialise torch.distributed from the torchrun environment (returns the module or None for 1 rank)."""
     r = Rank.from_env()

@@ -156,6 +156,21 @@ def test_batch_run_shards_windows_over_ranks(oracle):
     b.close()
 
 
+def test_batch_run_gathered_over_rccl_from_cpp(oracle, tmp_path):
+    """okvis_ba_batch_run_gathered: shard + run + the record all-gather through RCCL, all inside the C++ library (librccl.so by
+    dlopen).  One rank on this one-GPU box: the communicator, the device buffers and ncclAllGather are the real ones."""
+    from okvis_amd import dist as D
+    ws = [synthetic.small_window(seed=70 + i, K=4, L=40) for i in range(3)]
+    opt = _opts()
+    recs = D.batch_run_gathered(ws, 0, 1, 0, 5, str(tmp_path / "nccl_id"), opt)
+    assert [int(r[0]) for r in recs] == [0, 1, 2]
+    b = solver.WindowBatch(ws, options=opt)
+    sg = b.optimize(5)
+    for r, s in zip(recs, sg):
+        assert int(r[1]) == s["iterations"] and r[2] == s["final_cost"] and r[3] > 0
+    b.close()
+
+
 def test_strategy_switch_after_graphs_were_captured(oracle):
     """set_options(strategy=...) on a batch whose launch graphs already exist: the graphs of the other strategy (no
     iteration-budget kernel under LM) must not be replayed, or every window returns after 0 iterations."""

@@ -160,3 +160,20 @@ def test_okvis_adapter_compiles_against_the_interface():
            str(root / "tests" / "mock_okvis" / "adapter_check.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_record_gather_checks_its_arguments_and_times_out_without_an_id_file(tmp_path):
+    """okvis_ba_gather_records before any device is touched: bad ranks are argument errors; a rank > 0 whose rank 0 never
+    publishes the ncclUniqueId gives up after timeout_s with a state error instead of hanging"""
+    import ctypes as C
+    import time
+    from okvis_amd.dist import WindowRecordC
+    L = _lib.lib()
+    L.okvis_ba_gather_records.argtypes = [C.c_int32, C.c_int32, C.c_int, C.c_char_p, C.c_double, C.c_void_p, C.c_int32, C.c_void_p]
+    mine, out = (WindowRecordC * 2)(), (WindowRecordC * 4)()
+    assert L.okvis_ba_gather_records(2, 2, 0, b"x", 0.1, mine, 2, out) == -1          # rank out of range
+    assert L.okvis_ba_gather_records(0, 2, 0, None, 0.1, mine, 2, out) == -1          # two ranks need an id file
+    assert L.okvis_ba_gather_records(0, 1, 0, None, 0.1, mine, 0, out) == 0           # nothing to gather
+    t = time.time()
+    assert L.okvis_ba_gather_records(1, 2, 0, os.fsencode(str(tmp_path / "never")), 0.2, mine, 2, out) == -2
+    assert 0.15 < time.time() - t < 5.0
