@@ -412,7 +412,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // landmarks per Schur workgroup: 48 (three staged batches of 16) keeps the workgroup count low when many windows share
     // the device; a few windows have the device to themselves and finish sooner with 32 (measured, tests/gpu_chunk_diag.py:
     // one window 114.7 vs 119.7 us per iteration, 64 windows 239 vs 217)
-    const int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : (n_windows_total < SMALL_BATCH_WINDOWS ? 32 : 48), SCHUR_CHUNK_LM_MAX);
+    const int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : (n_windows_total <= 8 ? 16 : n_windows_total < SMALL_BATCH_WINDOWS ? 32 : 48), SCHUR_CHUNK_LM_MAX);
     int g = 0;
     while (g < ngroup) {
       Chunk C;
@@ -1128,7 +1128,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     // measured on MI355X / ROCm 7.2 (profiles/r01_notes.md): branches inside ONE captured graph are not
     // overlapped, but two independently replayed graphs on two streams are (+29 % at 64 windows); more
     // than two streams lose again
-    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 56 ? 3 : (n_windows >= 16 ? 2 : 1));   // (48 windows: 2 is better)
+    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 56 ? 3 : (n_windows >= 8 ? 2 : 1));   // (48 windows: 2 is better)
     nsub = std::max(1, std::min(nsub, n_windows));
     s->sub_begin.assign(nsub + 1, 0);
     for (int k = 0; k <= nsub; ++k) s->sub_begin[k] = (int)((int64_t)n_windows * k / nsub);
