@@ -189,8 +189,9 @@ typedef struct okvis_ba_options {
                                    1/(1+sqrt(diag J^T J)) of the FIRST linearisation of the optimize() call;
                                    dogleg strategy only                                                          */
   int32_t max_consecutive_invalid_steps; /* 5 (Ceres max_num_consecutive_invalid_steps): then termination 5     */
-  int32_t reserved0;            /* not read (rounds 1-2: forced the level-scheduled elimination of the speed/bias
-                                   blocks on or off; the blocked LDL^T solver of round 3 has no such switch)     */
+  int32_t reserved0;            /* diagnostics.  Bit 2 (value 4): keep the landmark Schur reduction in its own launch
+                                   (default: DOGLEG / fixed-radius runs whose windows fit reduce each group inside the
+                                   linearise launch).  Bits 0-1: not read any more              */
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */

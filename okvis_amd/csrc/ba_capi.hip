@@ -40,6 +40,7 @@ struct HostWin {  // host copy of what the queries and downloads need
   std::vector<int> pair_lm, pair_block;
   std::vector<int> pose_off, sb_off;  // reduced ordering (host copy)
   int marg_dim = 0;
+  bool group_chunks = false;   // one Schur chunk per linearise group (what the fused linearise + reduce launch needs)
   WinPtrs ptrs;  // device pointers
   int acc = 0;
   int64_t bytes_lin = 0, bytes_schur = 0, bytes_solve = 0, bytes_small = 0;
@@ -118,6 +119,8 @@ struct okvis_ba_solver {
   StageVec stage, stage_small;   // pinned staging of the arena's data part / of the WinPtrs + OptD records (kept across uploads)
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
+  bool group_chunks = false;   // every window of the batch has one Schur chunk per linearise group (see fused())
+  bool fp32_at_upload = false;
   bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0, max_spart_stride = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
@@ -136,6 +139,7 @@ namespace {
 
 size_t solve_smem(int Dpad, bool large);
 
+constexpr int FUSED_MAX_WINDOWS = 24;    // up to here the fused linearise + reduce launch beats the separate Schur launch (tests/gpu_fused_sweep.py)
 constexpr int SMALL_BATCH_WINDOWS = 40;   // below: the device is not full - settings that shorten one window's chain win
 
 OptD make_optd(const okvis_ba_options& o, int n_windows) {
@@ -412,7 +416,15 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // landmarks per Schur workgroup: 48 (three staged batches of 16) keeps the workgroup count low when many windows share
     // the device; a few windows have the device to themselves and finish sooner with 32 (measured, tests/gpu_chunk_diag.py:
     // one window 114.7 vs 119.7 us per iteration, 64 windows 239 vs 217)
-    const int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : (n_windows_total <= 8 ? 16 : n_windows_total < SMALL_BATCH_WINDOWS ? 32 : 48), SCHUR_CHUNK_LM_MAX);
+    int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : (n_windows_total <= 8 ? 16 : n_windows_total < SMALL_BATCH_WINDOWS ? 32 : 48), SCHUR_CHUNK_LM_MAX);
+    // fused mode (the linearise workgroup reduces its own group, no Schur launch: DOGLEG and fixed-radius runs): possible when
+    // the reduced system is solved in LDS, the pose part is one Schur tile and the reduction's landmark tables fit the observation stage of the linearise kernel;
+    // then chunk = group.  options.reserved0 bit 2 keeps the separate launch (A/B switch).
+    const int stage = opt.fp32_linearize ? (has_ext ? LinCfg<true, float>::STAGE_DOUBLES : LinCfg<false, float>::STAGE_DOUBLES)
+                                         : (has_ext ? LinCfg<true, double>::STAGE_DOUBLES : LinCfg<false, double>::STAGE_DOUBLES);
+    H.group_chunks = !(opt.reserved0 & 4) && opt.schur_lm_per_block == 0 && D <= MAX_D_LDS && Dp <= TILE_DIM && n_windows_total <= FUSED_MAX_WINDOWS && 2 * SCHUR_LM_BATCH * 3 * Dp <= stage &&
+                     (opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || opt.gauss_newton);
+    if (H.group_chunks) per = 1;
     int g = 0;
     while (g < ngroup) {
       Chunk C;
@@ -547,6 +559,17 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.n_tile = ntile;
   P.n_imu_color = n_imu_color;
   P.spart_stride = spart_stride;
+  P.spart_buf_stride = H.group_chunks ? std::max(nchunk, 1) * spart_stride : 0;
+  {
+    int max_tasks = 0, max_pairs = 0;
+    for (const Group& Gq : groups) {
+      max_tasks = std::max(max_tasks, Gq.task_end - Gq.task_begin);
+      max_pairs = std::max(max_pairs, Gq.pair_end - Gq.pair_begin);
+    }
+    const int stage = opt.fp32_linearize ? LinCfg<false, float>::STAGE_DOUBLES : LinCfg<false, double>::STAGE_DOUBLES;
+    P.fuse_fast = H.group_chunks && !has_ext && max_tasks <= FUSE_MAX_TASKS && 6 * max_pairs <= FUSE_WIT * LIN_THREADS &&
+                  fuse_nlb(Dp, stage) >= 4;
+  }
   P.cauchy_b = w.cauchy_b;
   P.imu.sigma_g_c = w.imu_params.sigma_g_c; P.imu.sigma_a_c = w.imu_params.sigma_a_c;
   P.imu.sigma_gw_c = w.imu_params.sigma_gw_c; P.imu.sigma_aw_c = w.imu_params.sigma_aw_c;
@@ -646,7 +669,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(small_cost[b], put_zero(A, 16));
     if (opt.debug_arrays) OFF(obs_r[b], put_zero(A, 16 * (size_t)nobs));
   }
-  OFF(spart, put_zero(A, 8 * (size_t)std::max(nchunk, 1) * (size_t)spart_stride));
+  OFF(spart, put_zero(A, 8 * (size_t)std::max(nchunk, 1) * (size_t)spart_stride * (H.group_chunks ? 2 : 1)));
   OFF(spart_sum, put_zero(A, 8 * (size_t)std::max(spart_stride, 1)));
   OFF(sum_sync, put_zero(A, 16));
   OFF(dec, put_zero(A, 8 * (size_t)DEC_COUNT));
@@ -799,8 +822,14 @@ struct Sub {
 };
 Sub whole(okvis_ba_solver* s) { return Sub{s->stream, 0, (int)s->wins.size()}; }
 
+// fused mode: the linearise launch reduces every group it has linearised (ba_linearize.hpp); no Schur launch
+bool fused(const okvis_ba_solver* s) {
+  // (the fused reduction was sized at upload for the observation stage of one precision)
+  return s->group_chunks && (s->opt.fp32_linearize != 0) == s->fp32_at_upload &&
+         (s->opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || s->opt.gauss_newton);
+}
 hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
-  if (s->max_schur_blocks == 0) return hipSuccess;
+  if (s->max_schur_blocks == 0 || fused(s)) return hipSuccess;
   const int trows = std::min(TILE_DIM, s->max_Dp);
   hipLaunchKernelGGL(schur_kernel, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS),
                      (size_t)2 * SCHUR_LM_BATCH * trows * 3 * sizeof(double), b.st, s->d_wins + b.w0, s->d_opt, trows,
@@ -833,16 +862,17 @@ hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
   const dim3 grid(n_small + s->max_group, (unsigned)b.nw), blk(LIN_THREADS);
   const bool f32 = s->opt.fp32_linearize != 0;
   const size_t smem = std::max(lin_smem(s->any_ext, f32), small_smem());
+  const int fuse = fused(s) ? 1 : 0;
   if (s->any_ext) {
     if (f32)
-      hipLaunchKernelGGL((linearize_kernel<true, float>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small);
+      hipLaunchKernelGGL((linearize_kernel<true, float>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small, fuse);
     else
-      hipLaunchKernelGGL((linearize_kernel<true, double>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small);
+      hipLaunchKernelGGL((linearize_kernel<true, double>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small, fuse);
   } else {
     if (f32)
-      hipLaunchKernelGGL((linearize_kernel<false, float>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small);
+      hipLaunchKernelGGL((linearize_kernel<false, float>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small, fuse);
     else
-      hipLaunchKernelGGL((linearize_kernel<false, double>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small);
+      hipLaunchKernelGGL((linearize_kernel<false, double>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small, fuse);
   }
   return hipGetLastError();
 }
@@ -1087,6 +1117,8 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = s->max_spart_stride = 0;
   s->max_Dpad_small = s->max_Dpad_large = 0;
   s->any_ext = false;
+  s->group_chunks = true;
+  s->fp32_at_upload = s->opt.fp32_linearize != 0;
   for (int i = 0; i < n_windows; ++i) {
     relocate(wins[i].ptrs, s->d_arena, zbase, s->opt.debug_arrays);
     ptrs[i] = wins[i].ptrs;
@@ -1103,6 +1135,7 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     } else
       s->max_Dpad_large = std::max(s->max_Dpad_large, ((P.D + 5) / 6) * 6);
     s->any_ext = s->any_ext || P.has_ext;
+    s->group_chunks = s->group_chunks && wins[i].group_chunks;
   }
   if ((size_t)n_windows > s->wins_capacity) {
     if (s->d_wins) HIP_TRY(hipFree(s->d_wins));

@@ -22,6 +22,7 @@
 
 #include "ba_device.hpp"
 #include "ba_imu.hpp"
+#include "ba_schur.hpp"
 
 namespace ba {
 
@@ -35,18 +36,179 @@ struct LinCfg {
 };
 
 constexpr int LIN_TASK_CACHE = 64;   // Task records of a group kept in LDS (more: read from global memory)
-static_assert((GROUP_PAIRS + 1 + GROUP_LM + 1 + LIN_TASK_CACHE * 6) * 4 + (2 + 3) * GROUP_OBS * 2 + GROUP_PAIRS <=
+static_assert((GROUP_PAIRS + 1 + GROUP_LM + 1 + LIN_TASK_CACHE * 6) * 4 + (2 + 3) * GROUP_OBS * 2 + 3 * GROUP_PAIRS <=
                   GROUP_PAIRS * 3 * 8, "index cache must fit the s_pair area");
 static_assert(sizeof(Task) == 24, "Task is cached as 6 ints");
 
 __device__ __forceinline__ int ut6(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }
+
+// ---- fused mode, fast path (WinPtrs::fuse_fast; no free extrinsics, <= FUSE_MAX_TASKS reduction tasks and <= FUSE_WIT x
+// LIN_THREADS (pair, row) items per group): the group's part of the reduced camera system straight from what phase C has in
+// LDS and registers, on the fp64 matrix core.
+//   S~ = [Y; (V^-1 b)^T] W^T  with  Y = W V^-1  (rows = reduced pose offsets, contraction index = 3 x landmark + coordinate)
+// Y and W are dense row-major tiles [R][K + 1] in the dead observation stage (missing (landmark, block) pairs are zeros), a
+// lower-triangular grid of 16x16 output tiles is spread over the four waves (v_mfma_f64_16x16x4_f64: A lane l = Y[row l & 15]
+// [k l >> 4], B lane l = W[col l & 15][k l >> 4]), landmarks in batches of FuseCfg::nlb; the partial leaves in the block-packed
+// layout of the Schur kernel with the group's own J^T J / J^T r blocks (phase C(c), kept in LDS) added on the way out.
+constexpr int FUSE_WIT = 4;         // (pair, row) items of phase C(b) one work-item keeps in registers
+constexpr int FUSE_MAX_TASKS = 12;  // J^T J / J^T r blocks of one group kept in LDS
+typedef double lin_v4 __attribute__((ext_vector_type(4)));
+__host__ __device__ constexpr int fuse_rows(int Dp) { return ((Dp + 1 + 15) / 16) * 16; }
+// landmarks per batch so that two [rows][3 nlb + 1] tiles fit `stage` doubles (a multiple of 4: 3 nlb is a multiple of 4)
+__host__ __device__ constexpr int fuse_nlb(int Dp, int stage) { return 4 * (((stage / (2 * fuse_rows(Dp))) - 1) / 12); }
+
+struct FuseItems {      // what phase C(b) hands over: W rows in registers
+  double w[FUSE_WIT][3];
+  int row[FUSE_WIT];    // reduced offset of the row (pose part), -1 = none
+  int lm[FUSE_WIT];     // landmark of the row, group-local
+};
+
+template <int STAGE_DOUBLES>
+__device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& opt, int g, int buf, double lam, int nlm, int lm_begin,
+                                                  int ntask, const FuseItems& it, double* tiles, const double* s_lmres, double* aux,
+                                                  const int* s_task) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define FSTAMP(k) do { if (W.prof && tid == 0 && g == 0 && blockIdx.y == 0) W.prof[k] = (double)clock64(); } while (0)
+  const int Dp = W.Dp, R = fuse_rows(Dp), RT = R / 16;
+  const int nlb = fuse_nlb(Dp, STAGE_DOUBLES), K = 3 * nlb, KP = K + 1;
+  double* tY = tiles;
+  double* tW = tiles + (size_t)R * KP;
+  double(*vinv)[6] = reinterpret_cast<double(*)[6]>(aux);
+  double(*vb)[3] = reinterpret_cast<double(*)[3]>(aux + GROUP_LM * 6);
+  const double* s_U = aux + GROUP_LM * 9;
+  int* blktask = reinterpret_cast<int*>(aux + GROUP_LM * 9 + FUSE_MAX_TASKS * 36);
+  // ---- (V_l + lambda D_l^2)^-1 and V^-1 b per landmark; which task holds the J^T J block of pose block bi
+  if (tid < nlm) {
+    const double* r = s_lmres + 16 * tid;
+    double v[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, vi[6];
+    if (opt.marg_mode) {
+      pinv3sym_precond(v, vi);
+    } else {
+      double sc[3] = {1.0, 1.0, 1.0};
+      if (opt.dogleg) {
+        const double* sl = W.lm_scale + 3 * (size_t)(lm_begin + tid);
+        sc[0] = sl[0], sc[1] = sl[1], sc[2] = sl[2];
+      }
+      v[0] += lam * damp_diag(v[0], sc[0], opt);
+      v[3] += lam * damp_diag(v[3], sc[1], opt);
+      v[5] += lam * damp_diag(v[5], sc[2], opt);
+      inv3sym(v, vi);
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) vinv[tid][e] = vi[e];
+    vb[tid][0] = vi[0] * r[6] + vi[1] * r[7] + vi[2] * r[8];
+    vb[tid][1] = vi[1] * r[6] + vi[3] * r[7] + vi[4] * r[8];
+    vb[tid][2] = vi[2] * r[6] + vi[4] * r[7] + vi[5] * r[8];
+  }
+  if (tid >= 64 && tid < 64 + 32) blktask[tid - 64] = -1;
+  __syncthreads();
+  FSTAMP(18);
+  if (tid < ntask) blktask[s_task[6 * tid + 1] / 6] = tid;   // (fast path: every task is a block Hessian, type 0)
+  // ---- tiles and products, one landmark batch at a time
+  constexpr int MAXT = 7;   // output tiles per wave: 7 x 4 >= 28 = the lower triangle of 7 x 7 tiles (R <= 112)
+  lin_v4 acc[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) acc[t] = lin_v4{0.0, 0.0, 0.0, 0.0};
+  const int ntiles = RT * (RT + 1) / 2;
+  for (int l0 = 0; l0 < nlm; l0 += nlb) {
+    for (int i = tid; i < 2 * R * KP; i += LIN_THREADS) tiles[i] = 0.0;
+    __syncthreads();
+    if (l0 == 0) FSTAMP(19);
+#pragma unroll
+    for (int q = 0; q < FUSE_WIT; ++q) {
+      const int lb = it.lm[q] - l0;
+      if (it.row[q] >= 0 && lb >= 0 && lb < nlb) {
+        const double w0 = it.w[q][0], w1 = it.w[q][1], w2 = it.w[q][2];
+        const double* vi = vinv[it.lm[q]];
+        double* y = tY + (size_t)it.row[q] * KP + 3 * lb;
+        double* w = tW + (size_t)it.row[q] * KP + 3 * lb;
+        y[0] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+        y[1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+        y[2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+        w[0] = w0, w[1] = w1, w[2] = w2;
+      }
+    }
+    if (tid >= l0 && tid < min(nlm, l0 + nlb)) {   // row Dp of Y: V^-1 b (gives Y b = W V^-1 b in row Dp of the product)
+      double* y = tY + (size_t)Dp * KP + 3 * (tid - l0);
+      y[0] = vb[tid][0], y[1] = vb[tid][1], y[2] = vb[tid][2];
+    }
+    __syncthreads();
+    if (l0 == 0) FSTAMP(20);
+    {
+      int I = 0, rem = wave;   // tile wave, wave + 4, ... of the row-major lower triangle -> (I, J = rem)
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int tt = wave + 4 * t;
+        if (tt < ntiles) {
+          while (rem > I) {
+            rem -= I + 1;
+            ++I;
+          }
+          const int J = rem;
+          const double* pa = tY + (size_t)(16 * I + (lane & 15)) * KP + (lane >> 4);
+          const double* pb = tW + (size_t)(16 * J + (lane & 15)) * KP + (lane >> 4);
+          lin_v4 a = acc[t];
+          for (int k = 0; k < K; k += 4) a = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k], pb[k], a, 0, 0, 0);
+          acc[t] = a;
+          rem += 4;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  FSTAMP(21);
+  // ---- out: block-packed lower triangle | Y b | g | diag U
+  const int nblk = Dp / 6;
+  double* sp = W.spart + (size_t)buf * W.spart_buf_stride + (size_t)g * W.spart_stride;
+  double* sr = sp + (size_t)(nblk * (nblk + 1) / 2) * 36;
+  {
+    int I = 0, rem = wave;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int tt = wave + 4 * t;
+      if (tt < ntiles) {
+        while (rem > I) {
+          rem -= I + 1;
+          ++I;
+        }
+        const int J = rem;
+        const int j = 16 * J + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + (lane >> 4) + 4 * r;
+          const double v = acc[t][r];
+          if (j < Dp && i == Dp) {
+            sr[j] = v;
+          } else if (i < Dp && j <= i) {
+            const int bi = i / 6, ii = i - 6 * bi, bj = j / 6, jj = j - 6 * bj;
+            double o = -v;
+            if (bi == bj) {
+              const int tk = blktask[bi];
+              if (tk >= 0) o += s_U[tk * 36 + ut6(jj, ii)];
+            }
+            sp[(bi * (bi + 1) / 2 + bj) * 36 + 6 * ii + jj] = o;
+          }
+        }
+        rem += 4;
+      }
+    }
+  }
+  if (tid < Dp) {
+    const int bi = tid / 6, a = tid - 6 * bi, tk = blktask[bi];
+    sr[Dp + tid] = tk >= 0 ? s_U[tk * 36 + 21 + a] : 0.0;
+    sr[2 * Dp + tid] = tk >= 0 ? s_U[tk * 36 + ut6(a, a)] : 0.0;
+  }
+  FSTAMP(22);
+  FSTAMP(23);
+#undef FSTAMP
+}
 
 // grid.x = n_small + (number of groups): the first n_small = max_imu + 1 workgroups evaluate the IMU / prior
 // factors (small_body, ba_imu.hpp; they start first because a re-preintegration is the longest workgroup of
 // the launch), the others one linearise group each.  Two workgroups per CU (LDS), hence at most 256 registers.
 template <bool EXT, class REAL>
 __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs* __restrict__ wins,
-                                                                   const OptD* __restrict__ optp, int init, int n_small) {
+                                                                   const OptD* __restrict__ optp, int init, int n_small, int fuse) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const WinPtrs& W = wins[blockIdx.y];
   if ((int)blockIdx.x < n_small) {
@@ -59,10 +221,40 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   LSTAMP(40);
   const Ctrl* ctrl = W.ctrl;
   if (ctrl->done) return;
-  if (!init && !ctrl->pending) return;  // the solve produced no valid step: nothing to evaluate
+  const OptD opt = *optp;
+  // ---- fused mode (fuse != 0; the host picks it for DOGLEG / fixed-radius runs whose groups fit): this
+  //      workgroup also reduces its own group — chunk g of the window — to the partial reduced-camera system right after
+  //      linearising it, with the regulariser the NEXT solve will use if the trial is accepted (a rejected dogleg trial needs
+  //      no new solve).  There is no Schur launch in this mode. ----
+  static_assert(LIN_THREADS == SCHUR_THREADS, "the fused reduction runs in the linearise workgroup");
+  auto reduce_own_group = [&](int buf, double lam) {
+    const Group Gr = W.groups[g];
+    const int trows = min(TILE_DIM, W.Dp);
+    // LDS: the observation stage is dead (tables), so is the step vector of phase A (inverse landmark blocks, offsets)
+    double* tables = smem;
+    double* aux = smem + LinCfg<EXT, REAL>::STAGE_DOUBLES + GROUP_LM * 4 + GROUP_PAIRS * 3 + GROUP_LM * 16;
+    double(*vinv)[6] = reinterpret_cast<double(*)[6]>(aux);
+    double(*bvec)[3] = reinterpret_cast<double(*)[3]>(aux + SCHUR_CHUNK_LM_MAX * 6);
+    int* boff = reinterpret_cast<int*>(aux + SCHUR_CHUNK_LM_MAX * 9);
+    static_assert(SCHUR_CHUNK_LM_MAX * 9 + SCHUR_THREADS / 2 <= 1024, "aux area of the fused reduction");
+    const SchurPairBeginGlobal pb{W.lm_pair_begin, Gr.lm_begin, Gr.lm_end};
+    const int n_tp = W.n_tile * (W.n_tile + 1) / 2;
+    for (int tp = 0; tp < n_tp; ++tp) {
+      schur_reduce_chunk(W, opt, g, tp, Gr.lm_begin, Gr.lm_end, buf, lam, trows, tables, vinv, bvec, boff, pb, g == 0 && blockIdx.y == 0);
+      __syncthreads();
+    }
+  };
+  if (!init && !ctrl->pending) {
+    // the solve produced no valid step: nothing to evaluate.  Fused mode: the accepted linearisation is reduced again with the
+    // regulariser the failed solve has raised
+    if (fuse) reduce_own_group(ctrl->acc, opt.dogleg ? ctrl->mu : 1.0 / ctrl->radius);
+    return;
+  }
   const int acc = ctrl->acc, trial = 1 - acc;
   const double lambda = ctrl->lambda;
-  const OptD opt = *optp;
+  // regulariser of the solve that follows an accepted trial (decide_dl / decide, ba_device.hpp)
+  const double lam_next = opt.dogleg ? ((init || ctrl->first || opt.gauss_newton) ? ctrl->mu : fmax(DL_MIN_MU, 2.0 * ctrl->mu / DL_MU_INCREASE))
+                                     : 1.0 / ctrl->radius;
   const bool dl_explicit = opt.dogleg && ctrl->tr_kind == 1;
   const double dl_cA = ctrl->cA, dl_beta = ctrl->beta;
 
@@ -91,6 +283,8 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   uint16_t* s_plist = reinterpret_cast<uint16_t*>(s_task + LIN_TASK_CACHE * 6);  // [2 GROUP_OBS]
   uint16_t* s_tlist = s_plist + 2 * GROUP_OBS;                                // [3 GROUP_OBS]
   uint8_t* s_prole = reinterpret_cast<uint8_t*>(s_tlist + 3 * GROUP_OBS);     // [GROUP_PAIRS]
+  uint8_t* s_ppoff = s_prole + GROUP_PAIRS;                                   // [GROUP_PAIRS] reduced block offset / 6 (fast fused path)
+  uint8_t* s_pplm = s_ppoff + GROUP_PAIRS;                                    // [GROUP_PAIRS] group-local landmark
   int pf_plb[2], pf_role[2], pf_lob = 0;
   uint16_t pf_pl[2], pf_tl[3];
   Task pf_task;
@@ -107,6 +301,18 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     pf_tl[j] = (i < ntlist) ? W.task_list[G.tlist_begin + i] : (uint16_t)0;
   }
   if (tid <= nlm) pf_lob = W.lm_obs_begin[G.lm_begin + tid];
+  const bool fast = fuse && W.fuse_fast;
+  int pf_poff[2] = {0, 0}, pf_plm[2] = {0, 0};
+  if (fast) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = tid + j * LIN_THREADS;
+      if (i < npair) {
+        pf_poff[j] = W.pair_off[G.pair_begin + i];
+        pf_plm[j] = W.pair_lm[G.pair_begin + i] - G.lm_begin;
+      }
+    }
+  }
   const bool tasks_cached = ntask <= LIN_TASK_CACHE;
   if (tasks_cached && tid < ntask) pf_task = W.tasks[G.task_begin + tid];
 
@@ -226,6 +432,10 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     const int i = tid + j * LIN_THREADS;
     if (i < npair) s_plb[i] = pf_plb[j] - G.plist_begin;
     if (EXT && i < npair) s_prole[i] = (uint8_t)pf_role[j];
+    if (fast && i < npair) {
+      s_ppoff[i] = (uint8_t)(pf_poff[j] / 6);
+      s_pplm[i] = (uint8_t)pf_plm[j];
+    }
     if (i < nplist) s_plist[i] = pf_pl[j];
   }
 #pragma unroll
@@ -357,12 +567,15 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     }
   }
   LSTAMP(45);
-  // (b) per (landmark, block) pair: W = sum J_block^T J_l, one work-item per row
-  for (int wi = tid; wi < npair * 6; wi += LIN_THREADS) {
+  // (b) per (landmark, block) pair: W = sum J_block^T J_l, one work-item per row (fast fused path: the first FUSE_WIT rows of
+  //     every work-item — all of them, the host checks — stay in registers for the reduction behind phase C)
+  FuseItems fit;
+#pragma unroll
+  for (int q = 0; q < FUSE_WIT; ++q) fit.row[q] = -1, fit.lm[q] = 0, fit.w[q][0] = fit.w[q][1] = fit.w[q][2] = 0.0;
+  auto w_row = [&](int wi, REAL& w0, REAL& w1, REAL& w2) {
     const int pp = wi / 6, a = wi - 6 * pp;
-    const int p = G.pair_begin + pp;
     const int jofs = (EXT && s_prole[pp]) ? ST_JE : ST_JP;
-    REAL w0 = 0, w1 = 0, w2 = 0;
+    w0 = 0, w1 = 0, w2 = 0;
     for (int k = s_plb[pp]; k < s_plb[pp + 1]; ++k) {
       const REAL* st = s_stage + (size_t)s_plist[k] * STRIDE;
       const REAL j0 = st[jofs + a], j1 = st[jofs + 6 + a];
@@ -370,10 +583,29 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
       w1 += j0 * st[ST_JL + 1] + j1 * st[ST_JL + 4];
       w2 += j0 * st[ST_JL + 2] + j1 * st[ST_JL + 5];
     }
-    double* Wt = W.W[trial] + (size_t)p * 18 + 3 * a;
+    double* Wt = W.W[trial] + (size_t)(G.pair_begin + pp) * 18 + 3 * a;
     Wt[0] = w0;
     Wt[1] = w1;
     Wt[2] = w2;
+  };
+  if (fast) {
+#pragma unroll
+    for (int q = 0; q < FUSE_WIT; ++q) {
+      const int wi = tid + q * LIN_THREADS;
+      if (wi < npair * 6) {
+        REAL w0, w1, w2;
+        w_row(wi, w0, w1, w2);
+        const int pp = wi / 6;
+        fit.w[q][0] = w0, fit.w[q][1] = w1, fit.w[q][2] = w2;
+        fit.row[q] = 6 * s_ppoff[pp] + (wi - 6 * pp);
+        fit.lm[q] = s_pplm[pp];
+      }
+    }
+  } else {
+    for (int wi = tid; wi < npair * 6; wi += LIN_THREADS) {
+      REAL w0, w1, w2;
+      w_row(wi, w0, w1, w2);
+    }
   }
   LSTAMP(46);
   // (c) per-block J^T J / J^T r partials and pose-extrinsics cross blocks.  These are the long reductions of the
@@ -434,6 +666,11 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     for (int b = 0; b < 6; ++b) acc6[b] = quad_sum(acc6[b]);
     ga = quad_sum(ga);
     if (part == 0) {
+      if (fast) {   // (type 0 only on this path) the group's own J^T J / J^T r blocks for the reduction below
+        double* u = s_step + GROUP_LM * 9 + tt * 36;
+        for (int b = a; b < 6; ++b) u[ut6(a, b)] = acc6[b];
+        u[21 + a] = ga;
+      }
       if (T.type < 2) {
         for (int b = a; b < 6; ++b) out[ut6(a, b)] = acc6[b];
         out[21 + a] = ga;
@@ -469,6 +706,14 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     }
   }
   LSTAMP(49);
+  if (fuse) {
+    __syncthreads();   // V, b, W, the per-group partials (global memory) and the last reads of the stage are behind this barrier
+    if (fast)
+      fused_reduce_fast<LinCfg<EXT, REAL>::STAGE_DOUBLES>(W, opt, g, trial, lam_next, nlm, G.lm_begin, ntask, fit, smem, s_lmres, s_step, s_task);
+    else
+      reduce_own_group(trial, lam_next);
+  }
+  LSTAMP(50);
 }
 
 }  // namespace ba

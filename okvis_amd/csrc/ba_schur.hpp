@@ -24,110 +24,38 @@ namespace ba {
 
 constexpr int TILE_DIM = SCHUR_TILE_BLOCKS * 6;  // 96
 
-__global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __restrict__ wins,
-                                                              const OptD* __restrict__ optp, int tile_rows, int final_call) {
-  const WinPtrs& W = wins[blockIdx.y];
-  const int n_tp = W.n_tile * (W.n_tile + 1) / 2;
-  const int bx = blockIdx.x;
-  if (bx >= W.n_chunk * n_tp) return;
-  const Ctrl* ctrl = W.ctrl;
-  if (ctrl->done) return;
+// pair-list offsets of the landmark batches of a chunk: prefetched into registers (stand-alone kernel: the loads overlap with
+// the decision) or read where they are needed (fused call: nothing to hide behind)
+struct SchurPairBeginRegs {
+  int v[SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH + 1];
+  __device__ __forceinline__ int begin(int ib) const {
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i <= SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH; ++i)   // static indexing keeps the values in registers
+      if (i == ib) r = v[i];
+    return r;
+  }
+};
+struct SchurPairBeginGlobal {
+  const BA_G int* lm_pair_begin;
+  int lm_begin, lm_end;
+  __device__ __forceinline__ int begin(int ib) const { return lm_pair_begin[min(lm_begin + ib * SCHUR_LM_BATCH, lm_end)]; }
+};
 
-  // dynamic LDS: [SCHUR_LM_BATCH][tile_rows][3] for Y and W, tile_rows = min(96, Dp) of the batch
-  extern __shared__ __attribute__((aligned(16))) double sch_smem[];
-  __shared__ double s_vinv[SCHUR_CHUNK_LM_MAX][6];   // (V_l + lambda D_l^2)^-1 of every landmark of the chunk
-  __shared__ double s_b[SCHUR_CHUNK_LM_MAX][3];
-  __shared__ int s_boff[SCHUR_THREADS];               // output offset of block pair pi
-  __shared__ int s_dec[2];
-  __shared__ double s_lambda;
-
+// The reduction of one chunk for one tile pair: everything of schur_kernel after the decision, also called by the linearise
+// kernel for its own group right after it has written V, b, W and the per-group J^T J partials (fused mode, ba_linearize.hpp).
+// LDS: tables = 2 x SCHUR_LM_BATCH x trows x 3 doubles, vinv [SCHUR_CHUNK_LM_MAX][6], bvec [SCHUR_CHUNK_LM_MAX][3],
+// boff [SCHUR_THREADS].  PB supplies the pair-list offset of the ib-th landmark batch (the stand-alone kernel prefetches them).
+// All SCHUR_THREADS work-items of the workgroup call it (it contains barriers).
+template <class PB>
+__device__ __forceinline__ void schur_reduce_chunk(const WinPtrs& W, const OptD& opt, int chunk, int tp, int lm_begin, int lm_end,
+                                                   int acc, double lambda, int trows, double* sch_smem, double (*s_vinv)[6],
+                                                   double (*s_b)[3], int* s_boff, const PB& pb, bool stamps) {
   const int tid = threadIdx.x;
-#define SSTAMP(k) do { if (W.prof && tid == 0 && bx == 0 && blockIdx.y == 0) W.prof[k] = (double)clock64(); } while (0)
-  SSTAMP(16);
-  const OptD opt = *optp;
-  const int trows = tile_rows;
+#undef SSTAMP
+#define SSTAMP(k) do { if (stamps && W.prof && tid == 0) W.prof[k] = (double)clock64(); } while (0)
   double* s_Y = sch_smem;
   double* s_W = sch_smem + (size_t)SCHUR_LM_BATCH * trows * 3;
-  // static structure of this workgroup's chunk: requested before the decision (scalar loads, three dependent
-  // round trips that overlap with wave 0's reduction instead of following it)
-  const int chunk = bx / n_tp;
-  const Chunk C = W.chunks[chunk];
-  const int lm_begin = W.groups[C.group_begin].lm_begin;
-  const int lm_end = W.groups[C.group_end - 1].lm_end;
-  const int nbatch = (lm_end - lm_begin + SCHUR_LM_BATCH - 1) / SCHUR_LM_BATCH;
-  int pbeg[SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH + 1];
-#pragma unroll
-  for (int i = 0; i <= SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH; ++i)
-    pbeg[i] = (i <= nbatch) ? W.lm_pair_begin[min(lm_begin + i * SCHUR_LM_BATCH, lm_end)] : 0;
-  // ---- decision (wave 0) ----
-  __shared__ Ctrl s_ctrl;   // the control record is fetched with ONE coalesced load; decide() then reads the LDS copy
-  if (tid < 64) {
-    if (tid < (int)(sizeof(Ctrl) / 8)) reinterpret_cast<double*>(&s_ctrl)[tid] = reinterpret_cast<const double*>(ctrl)[tid];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    asm volatile("" ::: "memory");
-    int acc = s_ctrl.acc, term = 0;
-    double lam;
-    if (opt.dogleg) {
-      // dogleg: the regulariser of the Gauss-Newton solve is mu * diagonal^2; a decision that asks for an explicit
-      // dogleg step (rejected step / mis-speculated Gauss-Newton trial) needs no new reduction at all
-      double mu = s_ctrl.mu;
-      int expl = s_ctrl.explicit_next;
-      if (s_ctrl.pending) {
-        double sums[6];
-        wave_trial_sums(W, 1 - acc, tid, sums);
-        DecisionDL d;
-        decide_dl(&s_ctrl, &opt, sums, final_call, &d);
-        if (bx == 0 && tid == 0) {   // published for the solve kernel (it would compute exactly this)
-          auto o = W.dec;
-          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
-          o[DEC_DL + 0] = d.accept; o[DEC_DL + 1] = d.term; o[DEC_DL + 2] = d.explicit_next; o[DEC_DL + 3] = d.judged;
-          o[DEC_DL + 4] = d.invalid_steps; o[DEC_DL + 5] = d.have_tot; o[DEC_DL + 6] = d.radius; o[DEC_DL + 7] = d.mu;
-          o[DEC_DL + 8] = d.rho; o[DEC_DL + 9] = d.model_change; o[DEC_DL + 10] = d.tot_C; o[DEC_DL + 11] = d.tot_E;
-          o[DEC_VALID] = 1.0;
-        }
-        if (d.accept) acc = 1 - acc;
-        term = d.term;
-        mu = d.mu;
-        expl = d.explicit_next ? (d.judged ? 1 : 2) : 0;
-      } else if (!final_call && expl != 2 && s_ctrl.iter >= s_ctrl.max_iter) {
-        term = 6;
-      }
-      if (expl) term = 7;   // nothing to reduce in this slot
-      lam = mu;
-    } else {
-      double radius = s_ctrl.radius;
-      if (s_ctrl.pending) {
-        double sums[6];
-        wave_trial_sums(W, 1 - acc, tid, sums);
-        Decision d;
-        decide(&s_ctrl, &opt, sums, &d);
-        if (bx == 0 && tid == 0) {
-          auto o = W.dec;
-          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
-          o[DEC_LM + 0] = d.accept; o[DEC_LM + 1] = d.term; o[DEC_LM + 2] = d.radius; o[DEC_LM + 3] = d.decrease_factor;
-          o[DEC_LM + 4] = d.rho; o[DEC_LM + 5] = d.model_change;
-          o[DEC_VALID] = 1.0;
-        }
-        if (d.accept) acc = 1 - acc;
-        radius = d.radius;
-        term = d.term;
-      }
-      lam = 1.0 / radius;
-    }
-    if (tid == 0) {
-      s_dec[0] = acc;
-      s_dec[1] = term;
-      s_lambda = lam;
-    }
-  }
-  __syncthreads();
-  SSTAMP(17);
-  if (s_dec[1]) return;  // terminated by the decision; the solve kernel records it
-  const int acc = s_dec[0];
-  const double lambda = s_lambda;
-
-  // ---- which tile pair ----
-  int tp = bx - chunk * n_tp;
   int ti = 0;
   while (tp >= ti + 1) {  // lower-triangular enumeration: (0,0) (1,0) (1,1) (2,0) ...
     tp -= ti + 1;
@@ -200,13 +128,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
     const int lc0 = l0 - lm_begin;
     // fill operands of this batch: one work-item per (landmark, block) pair; requested before the tables are
     // zeroed so that the loads are in flight meanwhile
-    int p0 = 0, p1 = 0;
-#pragma unroll
-    for (int i = 0; i < SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH; ++i)   // static indexing keeps pbeg in registers
-      if (i == ib) {
-        p0 = pbeg[i];
-        p1 = pbeg[i + 1];
-      }
+    const int p0 = pb.begin(ib), p1 = pb.begin(ib + 1);
     const int pp = p0 + tid;
     double wp[18];
     int f_slot = 0, f_lb = 0;
@@ -343,7 +265,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
   }
   // ---- write the partial (pose part, row-major block-packed lower triangle | Y b | g | diag U) ----
   if (active && slice == 0) {
-    double* sp = W.spart + (size_t)chunk * W.spart_stride;
+    double* sp = W.spart + (size_t)acc * W.spart_buf_stride + (size_t)chunk * W.spart_stride;
     // the 6x6 blocks go out through LDS (the landmark tables are free now) so that the stores are coalesced
     s_boff[pi] = (gbi * (gbi + 1) / 2 + gbj) * 36;
 #pragma unroll
@@ -361,10 +283,112 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
   }
   __syncthreads();
   {
-    double* sp = W.spart + (size_t)chunk * W.spart_stride;
+    double* sp = W.spart + (size_t)acc * W.spart_buf_stride + (size_t)chunk * W.spart_stride;
     for (int i = tid; i < npairs * 36; i += SCHUR_THREADS) sp[s_boff[i / 36] + (i % 36)] = sch_smem[i];
   }
   SSTAMP(23);
+}
+
+__global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __restrict__ wins,
+                                                              const OptD* __restrict__ optp, int tile_rows, int final_call) {
+  const WinPtrs& W = wins[blockIdx.y];
+  const int n_tp = W.n_tile * (W.n_tile + 1) / 2;
+  const int bx = blockIdx.x;
+  if (bx >= W.n_chunk * n_tp) return;
+  const Ctrl* ctrl = W.ctrl;
+  if (ctrl->done) return;
+
+  // dynamic LDS: [SCHUR_LM_BATCH][tile_rows][3] for Y and W, tile_rows = min(96, Dp) of the batch
+  extern __shared__ __attribute__((aligned(16))) double sch_smem[];
+  __shared__ double s_vinv[SCHUR_CHUNK_LM_MAX][6];   // (V_l + lambda D_l^2)^-1 of every landmark of the chunk
+  __shared__ double s_b[SCHUR_CHUNK_LM_MAX][3];
+  __shared__ int s_boff[SCHUR_THREADS];               // output offset of block pair pi
+  __shared__ int s_dec[2];
+  __shared__ double s_lambda;
+
+  const int tid = threadIdx.x;
+#undef SSTAMP
+#define SSTAMP(k) do { if (W.prof && tid == 0 && bx == 0 && blockIdx.y == 0) W.prof[k] = (double)clock64(); } while (0)
+  SSTAMP(16);
+  const OptD opt = *optp;
+  const int trows = tile_rows;
+  // static structure of this workgroup's chunk: requested before the decision (scalar loads, three dependent
+  // round trips that overlap with wave 0's reduction instead of following it)
+  const int chunk = bx / n_tp;
+  const Chunk C = W.chunks[chunk];
+  const int lm_begin = W.groups[C.group_begin].lm_begin;
+  const int lm_end = W.groups[C.group_end - 1].lm_end;
+  const int nbatch = (lm_end - lm_begin + SCHUR_LM_BATCH - 1) / SCHUR_LM_BATCH;
+  SchurPairBeginRegs pb;
+#pragma unroll
+  for (int i = 0; i <= SCHUR_CHUNK_LM_MAX / SCHUR_LM_BATCH; ++i)
+    pb.v[i] = (i <= nbatch) ? W.lm_pair_begin[min(lm_begin + i * SCHUR_LM_BATCH, lm_end)] : 0;
+  // ---- decision (wave 0) ----
+  __shared__ Ctrl s_ctrl;   // the control record is fetched with ONE coalesced load; decide() then reads the LDS copy
+  if (tid < 64) {
+    if (tid < (int)(sizeof(Ctrl) / 8)) reinterpret_cast<double*>(&s_ctrl)[tid] = reinterpret_cast<const double*>(ctrl)[tid];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("" ::: "memory");
+    int acc = s_ctrl.acc, term = 0;
+    double lam;
+    if (opt.dogleg) {
+      // dogleg: the regulariser of the Gauss-Newton solve is mu * diagonal^2; a decision that asks for an explicit
+      // dogleg step (rejected step / mis-speculated Gauss-Newton trial) needs no new reduction at all
+      double mu = s_ctrl.mu;
+      int expl = s_ctrl.explicit_next;
+      if (s_ctrl.pending) {
+        double sums[6];
+        wave_trial_sums(W, 1 - acc, tid, sums);
+        DecisionDL d;
+        decide_dl(&s_ctrl, &opt, sums, final_call, &d);
+        if (bx == 0 && tid == 0) {   // published for the solve kernel (it would compute exactly this)
+          auto o = W.dec;
+          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
+          o[DEC_DL + 0] = d.accept; o[DEC_DL + 1] = d.term; o[DEC_DL + 2] = d.explicit_next; o[DEC_DL + 3] = d.judged;
+          o[DEC_DL + 4] = d.invalid_steps; o[DEC_DL + 5] = d.have_tot; o[DEC_DL + 6] = d.radius; o[DEC_DL + 7] = d.mu;
+          o[DEC_DL + 8] = d.rho; o[DEC_DL + 9] = d.model_change; o[DEC_DL + 10] = d.tot_C; o[DEC_DL + 11] = d.tot_E;
+          o[DEC_VALID] = 1.0;
+        }
+        if (d.accept) acc = 1 - acc;
+        term = d.term;
+        mu = d.mu;
+        expl = d.explicit_next ? (d.judged ? 1 : 2) : 0;
+      } else if (!final_call && expl != 2 && s_ctrl.iter >= s_ctrl.max_iter) {
+        term = 6;
+      }
+      if (expl) term = 7;   // nothing to reduce in this slot
+      lam = mu;
+    } else {
+      double radius = s_ctrl.radius;
+      if (s_ctrl.pending) {
+        double sums[6];
+        wave_trial_sums(W, 1 - acc, tid, sums);
+        Decision d;
+        decide(&s_ctrl, &opt, sums, &d);
+        if (bx == 0 && tid == 0) {
+          auto o = W.dec;
+          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
+          o[DEC_LM + 0] = d.accept; o[DEC_LM + 1] = d.term; o[DEC_LM + 2] = d.radius; o[DEC_LM + 3] = d.decrease_factor;
+          o[DEC_LM + 4] = d.rho; o[DEC_LM + 5] = d.model_change;
+          o[DEC_VALID] = 1.0;
+        }
+        if (d.accept) acc = 1 - acc;
+        radius = d.radius;
+        term = d.term;
+      }
+      lam = 1.0 / radius;
+    }
+    if (tid == 0) {
+      s_dec[0] = acc;
+      s_dec[1] = term;
+      s_lambda = lam;
+    }
+  }
+  __syncthreads();
+  SSTAMP(17);
+  if (s_dec[1]) return;  // terminated by the decision; the solve kernel records it
+  schur_reduce_chunk(W, opt, chunk, bx - chunk * n_tp, lm_begin, lm_end, s_dec[0], s_lambda, trows, sch_smem, s_vinv, s_b, s_boff, pb,
+                     bx == 0 && blockIdx.y == 0);
 }
 
 }  // namespace ba

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           if (i >= ntot) break;
           const size_t stride = W.spart_stride;
           const int nch = W.n_chunk;
-          auto sp = W.spart + i;
+          auto sp = W.spart + (size_t)(gctrl->pending ? 1 - gctrl->acc : gctrl->acc) * W.spart_buf_stride + i;   // the speculated buffer
           double a = 0;
           for (int ch = 0; ch < nch; ch += 16) {
             double v[16];
@@ -638,6 +638,66 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       }
     }
   }
+  // The chunk partials of linearisation buffer `buf` -> S and the pose part of the three vectors (waves 1 .. 15).  use_sums:
+  // the helper workgroups have summed them (into W.spart_sum).  One item = one double of the partials' record (lower triangle
+  // of the pose part in 6x6 blocks, then  Y b | g | diag U): lanes on consecutive doubles (coalesced; three items per lane
+  // and eight chunks per trip are requested together — the loads come from other CUs' stores, what counts is the number of
+  // dependent rounds), scattered into the 16x16 accumulator-layout blocks of the LDL^T solver.
+  const int sum_spec = gctrl->pending ? 1 - gctrl->acc : gctrl->acc;   // the buffer that is accepted if the pending trial is
+  auto sum_partials = [&](int buf, bool use_sums) {
+    if constexpr (!LARGE) {
+      const int npose_blk = Dp / 6;
+      const int nP = npose_blk * (npose_blk + 1) / 2 * 36, ntot = nP + 3 * Dp;
+      constexpr int NL = SOLVE_THREADS - 64;
+      auto ssum = W.spart_sum;
+      const size_t stride = W.spart_stride;
+      const int nch = W.n_chunk;
+      auto sp = W.spart + (size_t)buf * W.spart_buf_stride;
+      for (int base = tid - 64; base < ntot; base += 3 * NL) {
+        double a[3] = {0, 0, 0};
+        int dst[3];
+        if (!use_sums) {
+          // large launches: summed here, lanes on consecutive doubles, three items per lane and eight chunks per trip requested
+          // together (the loads come from other CUs' stores: what counts is the number of dependent rounds)
+          for (int ch = 0; ch < nch; ch += 8) {
+            double v[3][8];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int u = 0; u < 8; ++u) v[t][u] = (ch + u < nch && base + t * NL < ntot) ? sp[(size_t)(ch + u) * stride + base + t * NL] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+              for (int u = 0; u < 8; ++u) a[t] += v[t][u];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int i = base + t * NL;
+          if (use_sums) a[t] = i < ntot ? ssum[i] : 0.0;
+          dst[t] = -1;
+          if (i < nP) {
+            const int q = i / 36, e = i - 36 * q, ii = e / 6, jj = e - 6 * ii;
+            int bi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+            while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
+            while (bi * (bi + 1) / 2 > q) --bi;
+            const int bj = q - bi * (bi + 1) / 2;
+            if (bi > bj || ii >= jj) dst[t] = LY.at(6 * bi + ii, 6 * bj + jj);   // (the upper halves of the diagonal blocks are not part of the lower triangle)
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int i = base + t * NL;
+          if (dst[t] >= 0) {
+            S[dst[t]] = a[t];
+          } else if (i >= nP && i < ntot) {   // Y b | g | diag U of the pose part
+            const int which = (i - nP) / Dp, j = (i - nP) - which * Dp;
+            (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = a[t];
+          }
+        }
+      }
+    }
+  };
   // ------------------------------------------------------------------ 1. decision
   if (tid < 64) {
     double sums[6] = {0, 0, 0, 0, 0, 0};
@@ -781,53 +841,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         while (__hip_atomic_load(&s_sum_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
-      auto ssum = W.spart_sum;
-      const size_t stride = W.spart_stride;
-      const int nch = W.n_chunk;
-      auto sp = W.spart;
-      for (int base = tid - 64; base < ntot; base += 3 * NL) {
-        double a[3] = {0, 0, 0};
-        int dst[3];
-        if (!helped) {
-          // large launches: summed here, lanes on consecutive doubles, three items per lane and eight chunks per trip requested
-          // together (the loads come from other CUs' stores: what counts is the number of dependent rounds)
-          for (int ch = 0; ch < nch; ch += 8) {
-            double v[3][8];
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-              for (int u = 0; u < 8; ++u) v[t][u] = (ch + u < nch && base + t * NL < ntot) ? sp[(size_t)(ch + u) * stride + base + t * NL] : 0.0;
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-              for (int u = 0; u < 8; ++u) a[t] += v[t][u];
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const int i = base + t * NL;
-          if (helped) a[t] = i < ntot ? ssum[i] : 0.0;
-          dst[t] = -1;
-          if (i < nP) {
-            const int q = i / 36, e = i - 36 * q, ii = e / 6, jj = e - 6 * ii;
-            int bi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
-            while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
-            while (bi * (bi + 1) / 2 > q) --bi;
-            const int bj = q - bi * (bi + 1) / 2;
-            if (bi > bj || ii >= jj) dst[t] = LY.at(6 * bi + ii, 6 * bj + jj);   // (the upper halves of the diagonal blocks are not part of the lower triangle)
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const int i = base + t * NL;
-          if (dst[t] >= 0) {
-            S[dst[t]] = a[t];
-          } else if (i >= nP && i < ntot) {   // Y b | g | diag U of the pose part
-            const int which = (i - nP) / Dp, j = (i - nP) - which * Dp;
-            (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = a[t];
-          }
-        }
-      }
+      sum_partials(sum_spec, helped);
       for (int i = tid - 64; i < 3 * (Dpad - Dp); i += NL) {   // speed/bias part of the vectors starts from zero
         const int which = i / (Dpad - Dp), j = Dp + i - which * (Dpad - Dp);
         (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = 0.0;
@@ -855,6 +869,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     return;
   }
   const int acc = c.acc;
+  if constexpr (!LARGE) {
+    // fused mode keeps one set of partials per linearisation buffer; the sums above were taken from the buffer that is accepted
+    // if the pending trial is.  It was not: take them again from the other one (a rejected or mis-speculated dogleg trial).
+    if (W.spart_buf_stride && acc != sum_spec) {
+      if (tid >= 64) sum_partials(acc, false);
+      __syncthreads();
+    }
+  }
   const WinPtrs& Wl = *[&]() -> const WinPtrs* {
     if constexpr (LARGE) return &W;
     else return reinterpret_cast<const WinPtrs*>(s_Wd);

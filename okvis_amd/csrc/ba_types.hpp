@@ -155,6 +155,8 @@ struct WinPtrs {
   int n_imu_color;
   int ct_nT;              // tile rows of the tiled dense solver (0 = the LDS solver handles this window)
   int spart_stride;       // doubles per chunk partial: (Dp/6)(Dp/6+1)/2*36 + 3*Dp  (S | Y b | g | diag U)
+  int fuse_fast;          // fused mode: the groups of this window qualify for the matrix-core reduction (ba_linearize.hpp)
+  int spart_buf_stride;   // doubles between the partials of linearisation buffer 0 and 1 (fused mode: one set per buffer); 0 = one set
   double cauchy_b;
   ImuParamsD imu;
 
@@ -210,7 +212,7 @@ struct WinPtrs {
   BA_G double* obs_r[2];       // [n_obs][2] (debug/parity)
 
   // ---- Schur / solve ----
-  BA_G double* spart;          // [n_chunk][spart_stride]: block-packed lower triangle | Y b
+  BA_G double* spart;          // [1 or 2][n_chunk][spart_stride]: block-packed lower triangle | Y b
   BA_G double* spart_sum;      // [spart_stride] the sum of the chunk partials, made by the helper workgroups of the solve launch
   BA_G int* sum_sync;          // [0] number of helper workgroups that have delivered (all launches), [1] solve launches so far
   BA_G double* dec;            // [DEC_COUNT] the accept / reject decision the Schur kernel took on the pending trial (same function, same
