@@ -837,12 +837,15 @@ hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
   return hipGetLastError();
 }
 hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
-  if (s->max_Dpad_small > 0)
-    hipLaunchKernelGGL(solve_kernel<false>, dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), b.st,
+  if (s->max_Dpad_small > 0 && s->group_chunks)   // (one set of partials per linearisation buffer)
+    hipLaunchKernelGGL((solve_kernel<false, true>), dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), b.st,
+                       s->d_wins + b.w0, s->d_opt, final_only);
+  else if (s->max_Dpad_small > 0)
+    hipLaunchKernelGGL((solve_kernel<false, false>), dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), b.st,
                        s->d_wins + b.w0, s->d_opt, final_only);
   if (s->max_Dpad_large > 0) {
     // large windows: assemble + export, tiled multi-workgroup Cholesky (fp64 MFMA), back-substitution + finish
-    hipLaunchKernelGGL(solve_kernel<true>, dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), b.st,
+    hipLaunchKernelGGL((solve_kernel<true, false>), dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), b.st,
                        s->d_wins + b.w0, s->d_opt, final_only);
     if (!final_only) {
       const int nT = (s->max_Dpad_large + CT_TB - 1) / CT_TB;
@@ -862,17 +865,14 @@ hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
   const dim3 grid(n_small + s->max_group, (unsigned)b.nw), blk(LIN_THREADS);
   const bool f32 = s->opt.fp32_linearize != 0;
   const size_t smem = std::max(lin_smem(s->any_ext, f32), small_smem());
-  const int fuse = fused(s) ? 1 : 0;
+  const bool fuse = fused(s);
+  auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small); };
   if (s->any_ext) {
-    if (f32)
-      hipLaunchKernelGGL((linearize_kernel<true, float>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small, fuse);
-    else
-      hipLaunchKernelGGL((linearize_kernel<true, double>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small, fuse);
+    if (f32) fuse ? go(linearize_kernel<true, float, true>) : go(linearize_kernel<true, float, false>);
+    else fuse ? go(linearize_kernel<true, double, true>) : go(linearize_kernel<true, double, false>);
   } else {
-    if (f32)
-      hipLaunchKernelGGL((linearize_kernel<false, float>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small, fuse);
-    else
-      hipLaunchKernelGGL((linearize_kernel<false, double>), grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small, fuse);
+    if (f32) fuse ? go(linearize_kernel<false, float, true>) : go(linearize_kernel<false, float, false>);
+    else fuse ? go(linearize_kernel<false, double, true>) : go(linearize_kernel<false, double, false>);
   }
   return hipGetLastError();
 }
@@ -998,26 +998,28 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc(&s->d_opt, sizeof(OptD));
   // kernels may use more than the default 64 KB of dynamic LDS
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<true, double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)std::max(lin_smem(true), small_smem()));
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<true, float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)std::max(lin_smem(true, true), small_smem()));
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<false, float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)std::max(lin_smem(false, true), small_smem()));
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linearize_kernel<false, double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)std::max(lin_smem(false), small_smem()));
+  auto lds = [&](const void* f, size_t bytes) {
+    if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  };
+  lds(reinterpret_cast<const void*>(&linearize_kernel<true, double, false>), std::max(lin_smem(true), small_smem()));
+  lds(reinterpret_cast<const void*>(&linearize_kernel<true, double, true>), std::max(lin_smem(true), small_smem()));
+  lds(reinterpret_cast<const void*>(&linearize_kernel<true, float, false>), std::max(lin_smem(true, true), small_smem()));
+  lds(reinterpret_cast<const void*>(&linearize_kernel<true, float, true>), std::max(lin_smem(true, true), small_smem()));
+  lds(reinterpret_cast<const void*>(&linearize_kernel<false, float, false>), std::max(lin_smem(false, true), small_smem()));
+  lds(reinterpret_cast<const void*>(&linearize_kernel<false, float, true>), std::max(lin_smem(false, true), small_smem()));
+  lds(reinterpret_cast<const void*>(&linearize_kernel<false, double, false>), std::max(lin_smem(false), small_smem()));
+  lds(reinterpret_cast<const void*>(&linearize_kernel<false, double, true>), std::max(lin_smem(false), small_smem()));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * SCHUR_LM_BATCH * TILE_DIM * 3 * sizeof(double)));
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             std::max((int)solve_smem(((MAX_D_LDS + 5) / 6) * 6, false), SOLVE_LDS_LIMIT));
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            std::max((int)solve_smem(((MAX_D_LDS + 5) / 6) * 6, false), SOLVE_LDS_LIMIT));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)solve_smem(((MAX_D + 5) / 6) * 6, true));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_tiles_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1137,6 +1139,8 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     s->any_ext = s->any_ext || P.has_ext;
     s->group_chunks = s->group_chunks && wins[i].group_chunks;
   }
+  if (!s->group_chunks)   // a batch is fused as a whole or not at all: one set of partials for everybody
+    for (int i = 0; i < n_windows; ++i) ptrs[i].spart_buf_stride = 0, ptrs[i].fuse_fast = 0;
   if ((size_t)n_windows > s->wins_capacity) {
     if (s->d_wins) HIP_TRY(hipFree(s->d_wins));
     s->d_wins = nullptr;
@@ -1851,8 +1855,12 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   s->begun = false;
   const Sub one{s->stream, w, 1};
   HIP_TRY(launch_schur(s, one));
-  hipLaunchKernelGGL(solve_kernel<false>, dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream, d_win,
-                     s->d_opt, 2);
+  if (s->group_chunks)
+    hipLaunchKernelGGL((solve_kernel<false, true>), dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream,
+                       d_win, s->d_opt, 2);
+  else
+    hipLaunchKernelGGL((solve_kernel<false, false>), dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream,
+                       d_win, s->d_opt, 2);
   HIP_TRY(hipGetLastError());
   MargArgs ma;
   ma.pose_marg = d + o_pm;

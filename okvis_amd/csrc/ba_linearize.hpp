@@ -64,9 +64,9 @@ struct FuseItems {      // what phase C(b) hands over: W rows in registers
 };
 
 template <int STAGE_DOUBLES>
-__device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& opt, int g, int buf, double lam, int nlm, int lm_begin,
-                                                  int ntask, const FuseItems& it, double* tiles, const double* s_lmres, double* aux,
-                                                  const int* s_task) {
+__device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& opt, int g, int buf, double lam, int nlm, bool init,
+                                                  const double (&pf_sc)[3], const FuseItems& it, double* tiles,
+                                                  const double* s_lmres, double* aux) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define FSTAMP(k) do { if (W.prof && tid == 0 && g == 0 && blockIdx.y == 0) W.prof[k] = (double)clock64(); } while (0)
   const int Dp = W.Dp, R = fuse_rows(Dp), RT = R / 16;
@@ -76,8 +76,8 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
   double(*vinv)[6] = reinterpret_cast<double(*)[6]>(aux);
   double(*vb)[3] = reinterpret_cast<double(*)[3]>(aux + GROUP_LM * 6);
   const double* s_U = aux + GROUP_LM * 9;
-  int* blktask = reinterpret_cast<int*>(aux + GROUP_LM * 9 + FUSE_MAX_TASKS * 36);
-  // ---- (V_l + lambda D_l^2)^-1 and V^-1 b per landmark; which task holds the J^T J block of pose block bi
+  const int* blktask = reinterpret_cast<const int*>(aux + GROUP_LM * 9 + FUSE_MAX_TASKS * 36);   // filled when the index lists were parked
+  // ---- (V_l + lambda D_l^2)^-1 and V^-1 b per landmark (one work-item each)
   if (tid < nlm) {
     const double* r = s_lmres + 16 * tid;
     double v[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, vi[6];
@@ -86,8 +86,13 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
     } else {
       double sc[3] = {1.0, 1.0, 1.0};
       if (opt.dogleg) {
-        const double* sl = W.lm_scale + 3 * (size_t)(lm_begin + tid);
-        sc[0] = sl[0], sc[1] = sl[1], sc[2] = sl[2];
+        if (init) {   // the scale estimated from this very linearisation (phase C(a) has stored the same expression)
+          sc[0] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(v[0])) : 1.0;
+          sc[1] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(v[3])) : 1.0;
+          sc[2] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(v[5])) : 1.0;
+        } else {
+          sc[0] = pf_sc[0], sc[1] = pf_sc[1], sc[2] = pf_sc[2];
+        }
       }
       v[0] += lam * damp_diag(v[0], sc[0], opt);
       v[3] += lam * damp_diag(v[3], sc[1], opt);
@@ -100,18 +105,19 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
     vb[tid][1] = vi[1] * r[6] + vi[3] * r[7] + vi[4] * r[8];
     vb[tid][2] = vi[2] * r[6] + vi[4] * r[7] + vi[5] * r[8];
   }
-  if (tid >= 64 && tid < 64 + 32) blktask[tid - 64] = -1;
-  __syncthreads();
-  FSTAMP(18);
-  if (tid < ntask) blktask[s_task[6 * tid + 1] / 6] = tid;   // (fast path: every task is a block Hessian, type 0)
-  // ---- tiles and products, one landmark batch at a time
   constexpr int MAXT = 7;   // output tiles per wave: 7 x 4 >= 28 = the lower triangle of 7 x 7 tiles (R <= 112)
   lin_v4 acc[MAXT];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) acc[t] = lin_v4{0.0, 0.0, 0.0, 0.0};
   const int ntiles = RT * (RT + 1) / 2;
+  // ---- tiles and products, one landmark batch at a time
   for (int l0 = 0; l0 < nlm; l0 += nlb) {
-    for (int i = tid; i < 2 * R * KP; i += LIN_THREADS) tiles[i] = 0.0;
+    {
+      double2* z = reinterpret_cast<double2*>(tiles);
+      const int n2 = R * KP;   // 2 R KP doubles
+      for (int i = tid; i < n2; i += LIN_THREADS) z[i] = make_double2(0.0, 0.0);
+    }
+    if (l0 == 0) FSTAMP(18);
     __syncthreads();
     if (l0 == 0) FSTAMP(19);
 #pragma unroll
@@ -135,7 +141,7 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
     __syncthreads();
     if (l0 == 0) FSTAMP(20);
     {
-      int I = 0, rem = wave;   // tile wave, wave + 4, ... of the row-major lower triangle -> (I, J = rem)
+      int I = 0, rem = wave;
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
         const int tt = wave + 4 * t;
@@ -154,13 +160,16 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
         }
       }
     }
-    __syncthreads();
+    if (l0 + nlb < nlm) __syncthreads();
   }
   FSTAMP(21);
-  // ---- out: block-packed lower triangle | Y b | g | diag U
+  // ---- out: block-packed lower triangle | Y b | g | diag U.  Off-diagonal 6x6 blocks go straight from the accumulators to
+  //      global memory; the diagonal ones meet the group's own J^T J blocks in LDS first (the inverse landmark blocks are no
+  //      longer needed: every wave is past the barrier behind the last fill) and leave as whole blocks
   const int nblk = Dp / 6;
   double* sp = W.spart + (size_t)buf * W.spart_buf_stride + (size_t)g * W.spart_stride;
   double* sr = sp + (size_t)(nblk * (nblk + 1) / 2) * 36;
+  double* s_diag = aux;   // [nblk][36], nblk <= 16
   {
     int I = 0, rem = wave;
 #pragma unroll
@@ -172,7 +181,7 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
           ++I;
         }
         const int J = rem;
-        const int j = 16 * J + (lane & 15);
+        const int j = 16 * J + (lane & 15), bj = j / 6, jj = j - 6 * bj;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * I + (lane >> 4) + 4 * r;
@@ -180,17 +189,21 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
           if (j < Dp && i == Dp) {
             sr[j] = v;
           } else if (i < Dp && j <= i) {
-            const int bi = i / 6, ii = i - 6 * bi, bj = j / 6, jj = j - 6 * bj;
-            double o = -v;
-            if (bi == bj) {
-              const int tk = blktask[bi];
-              if (tk >= 0) o += s_U[tk * 36 + ut6(jj, ii)];
-            }
-            sp[(bi * (bi + 1) / 2 + bj) * 36 + 6 * ii + jj] = o;
+            const int bi = i / 6, ii = i - 6 * bi;
+            if (bi == bj) s_diag[bi * 36 + 6 * ii + jj] = v;
+            else sp[(bi * (bi + 1) / 2 + bj) * 36 + 6 * ii + jj] = -v;
           }
         }
         rem += 4;
       }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < nblk * 36; e += LIN_THREADS) {
+    const int bi = e / 36, k = e - 36 * bi, ii = k / 6, jj = k - 6 * ii;
+    if (jj <= ii) {
+      const int tk = blktask[bi];
+      sp[(bi * (bi + 1) / 2 + bi) * 36 + k] = (tk >= 0 ? s_U[tk * 36 + ut6(jj, ii)] : 0.0) - s_diag[e];
     }
   }
   if (tid < Dp) {
@@ -206,9 +219,11 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
 // grid.x = n_small + (number of groups): the first n_small = max_imu + 1 workgroups evaluate the IMU / prior
 // factors (small_body, ba_imu.hpp; they start first because a re-preintegration is the longest workgroup of
 // the launch), the others one linearise group each.  Two workgroups per CU (LDS), hence at most 256 registers.
-template <bool EXT, class REAL>
+// FUSE: fused mode (see below); a separate instantiation so that the plain kernel carries none of its registers.
+template <bool EXT, class REAL, bool FUSE>
 __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs* __restrict__ wins,
-                                                                   const OptD* __restrict__ optp, int init, int n_small, int fuse) {
+                                                                   const OptD* __restrict__ optp, int init, int n_small) {
+  constexpr bool fuse = FUSE;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const WinPtrs& W = wins[blockIdx.y];
   if ((int)blockIdx.x < n_small) {
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   if (!init && !ctrl->pending) {
     // the solve produced no valid step: nothing to evaluate.  Fused mode: the accepted linearisation is reduced again with the
     // regulariser the failed solve has raised
-    if (fuse) reduce_own_group(ctrl->acc, opt.dogleg ? ctrl->mu : 1.0 / ctrl->radius);
+    if constexpr (FUSE) reduce_own_group(ctrl->acc, opt.dogleg ? ctrl->mu : 1.0 / ctrl->radius);
     return;
   }
   const int acc = ctrl->acc, trial = 1 - acc;
@@ -301,8 +316,13 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     pf_tl[j] = (i < ntlist) ? W.task_list[G.tlist_begin + i] : (uint16_t)0;
   }
   if (tid <= nlm) pf_lob = W.lm_obs_begin[G.lm_begin + tid];
-  const bool fast = fuse && W.fuse_fast;
+  const bool fast = FUSE && W.fuse_fast;
   int pf_poff[2] = {0, 0}, pf_plm[2] = {0, 0};
+  double pf_sc[3] = {1.0, 1.0, 1.0};   // Jacobi scale of this work-item's landmark (fast fused path; estimated in this launch when init)
+  if (fast && !init && tid < nlm) {
+    const double* sl = W.lm_scale + 3 * (size_t)(G.lm_begin + tid);
+    pf_sc[0] = sl[0], pf_sc[1] = sl[1], pf_sc[2] = sl[2];
+  }
   if (fast) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -445,6 +465,10 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   }
   if (tid == 0) s_plb[npair] = nplist;
   if (tid <= nlm) s_lob[tid] = pf_lob - G.obs_begin;
+  if (fast) {   // which of the group's tasks holds the J^T J block of pose block bi (s_step is free after phase A)
+    int* blktask = reinterpret_cast<int*>(s_step + GROUP_LM * 9 + FUSE_MAX_TASKS * 36);
+    if (tid >= 64 && tid < 64 + 32) blktask[tid - 64] = -1;
+  }
   if (tasks_cached && tid < ntask) {
     int* t = s_task + 6 * tid;
     t[0] = pf_task.type; t[1] = pf_task.off_a; t[2] = pf_task.off_b;
@@ -519,6 +543,7 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   }
   __syncthreads();
   LSTAMP(44);
+  if (fast && tid < ntask) reinterpret_cast<int*>(s_step + GROUP_LM * 9 + FUSE_MAX_TASKS * 36)[pf_task.off_a / 6] = tid;   // (type 0 tasks only on this path)
 
   // ------------------------------------------------------------------ phase C: LDS reductions
   // (a) per landmark: V(6) b(3) Hq(6) cost(1).  Four lanes per (landmark, entry), each takes every fourth
@@ -682,6 +707,15 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   LSTAMP(47);
   __syncthreads();
   LSTAMP(48);
+  LSTAMP(49);
+  if constexpr (FUSE) {
+    // (the barrier before (d) has V, b, W, the per-group partials in global memory and the last reads of the stage behind it)
+    if (fast)
+      fused_reduce_fast<LinCfg<EXT, REAL>::STAGE_DOUBLES>(W, opt, g, trial, lam_next, nlm, init != 0, pf_sc, fit, smem, s_lmres, s_step);
+    else
+      reduce_own_group(trial, lam_next);
+  }
+  LSTAMP(50);
   // (d) group scalars by wave 0
   if (tid < 64) {
     double cost = 0, gm = 0;
@@ -705,15 +739,7 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
       gs[GS_GMAX] = gm;
     }
   }
-  LSTAMP(49);
-  if (fuse) {
-    __syncthreads();   // V, b, W, the per-group partials (global memory) and the last reads of the stage are behind this barrier
-    if (fast)
-      fused_reduce_fast<LinCfg<EXT, REAL>::STAGE_DOUBLES>(W, opt, g, trial, lam_next, nlm, G.lm_begin, ntask, fit, smem, s_lmres, s_step, s_task);
-    else
-      reduce_own_group(trial, lam_next);
-  }
-  LSTAMP(50);
+  LSTAMP(51);
 }
 
 }  // namespace ba

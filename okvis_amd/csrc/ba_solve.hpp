@@ -481,9 +481,12 @@ __device__ __forceinline__ void solve_failed_dl(Ctrl* c, const OptD& opt) {
 
 // LARGE = false: the block matrix lives in LDS (D <= MAX_D_LDS).  LARGE = true: it lives in the window's HBM
 // workspace (L2-resident; same algorithm, one workgroup) — the functional path for BASELINE configs[2].
-template <bool LARGE>
+// DBUF: the batch keeps one set of Schur partials per linearisation buffer (fused mode, WinPtrs::spart_buf_stride): the sums
+// are taken from the buffer that is accepted if the pending trial is, and taken again when it was not.
+template <bool LARGE, bool DBUF>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __restrict__ wins,
                                                               const OptD* __restrict__ optp, int final_only) {
+  static_assert(!(LARGE && DBUF), "windows solved in HBM are never fused");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const WinPtrs& W = wins[blockIdx.x];
   if (LARGE != (W.Sg != nullptr)) return;  // each window is handled by the instantiation that fits it
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           if (i >= ntot) break;
           const size_t stride = W.spart_stride;
           const int nch = W.n_chunk;
-          auto sp = W.spart + (size_t)(gctrl->pending ? 1 - gctrl->acc : gctrl->acc) * W.spart_buf_stride + i;   // the speculated buffer
+          auto sp = W.spart + (DBUF ? (size_t)(gctrl->pending ? 1 - gctrl->acc : gctrl->acc) * W.spart_buf_stride : (size_t)0) + i;   // (the speculated buffer)
           double a = 0;
           for (int ch = 0; ch < nch; ch += 16) {
             double v[16];
@@ -532,6 +535,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     W.sum_sync[1] = sum_expected;
     s_sum_ready = helped ? 0 : 1;
   }
+
   // The window record (sizes and ~140 pointers, 1.3 KB in HBM) is copied to LDS once: every later W.field is an LDS read
   // instead of a scalar load that misses its cache line by line (measured: 3 us of the 4.6 us tail were such misses)
   __shared__ double s_Wd[(sizeof(WinPtrs) + 7) / 8];
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // of the pose part in 6x6 blocks, then  Y b | g | diag U): lanes on consecutive doubles (coalesced; three items per lane
   // and eight chunks per trip are requested together — the loads come from other CUs' stores, what counts is the number of
   // dependent rounds), scattered into the 16x16 accumulator-layout blocks of the LDL^T solver.
-  const int sum_spec = gctrl->pending ? 1 - gctrl->acc : gctrl->acc;   // the buffer that is accepted if the pending trial is
+  const int sum_spec = DBUF ? (gctrl->pending ? 1 - gctrl->acc : gctrl->acc) : 0;   // the buffer that is accepted if the pending trial is
   auto sum_partials = [&](int buf, bool use_sums) {
     if constexpr (!LARGE) {
       const int npose_blk = Dp / 6;
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       auto ssum = W.spart_sum;
       const size_t stride = W.spart_stride;
       const int nch = W.n_chunk;
-      auto sp = W.spart + (size_t)buf * W.spart_buf_stride;
+      auto sp = W.spart + (DBUF ? (size_t)buf * W.spart_buf_stride : (size_t)0);
       for (int base = tid - 64; base < ntot; base += 3 * NL) {
         double a[3] = {0, 0, 0};
         int dst[3];
@@ -869,14 +873,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     return;
   }
   const int acc = c.acc;
-  if constexpr (!LARGE) {
-    // fused mode keeps one set of partials per linearisation buffer; the sums above were taken from the buffer that is accepted
-    // if the pending trial is.  It was not: take them again from the other one (a rejected or mis-speculated dogleg trial).
-    if (W.spart_buf_stride && acc != sum_spec) {
-      if (tid >= 64) sum_partials(acc, false);
-      __syncthreads();
-    }
-  }
   const WinPtrs& Wl = *[&]() -> const WinPtrs* {
     if constexpr (LARGE) return &W;
     else return reinterpret_cast<const WinPtrs*>(s_Wd);
@@ -944,6 +940,35 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       s_pre[i] = v;
     }
     __syncthreads();
+  }
+  if constexpr (DBUF) {
+    // one set of Schur partials per linearisation buffer (fused mode): the sums in S and in the three vectors were taken from the
+    // buffer of the trial; it was rejected (or replaced by an explicit dogleg step), so they are corrected by the difference of
+    // the two sets — here, where the registers of the speculative prefetches are free again, and only in this rare case
+    if (s_was_pending && !s_accepted && Wl.spart_buf_stride) {
+      const int npose_blk = Dp / 6;
+      const int nP = npose_blk * (npose_blk + 1) / 2 * 36, ntot = nP + 3 * Dp;
+      const size_t stride = Wl.spart_stride;
+      const int nch = Wl.n_chunk;
+      auto right = Wl.spart + (size_t)acc * Wl.spart_buf_stride;
+      auto wrong = Wl.spart + (size_t)(1 - acc) * Wl.spart_buf_stride;
+      for (int i = tid; i < ntot; i += SOLVE_THREADS) {
+        double a = 0;
+        for (int ch = 0; ch < nch; ++ch) a += right[(size_t)ch * stride + i] - wrong[(size_t)ch * stride + i];
+        if (i < nP) {
+          const int q = i / 36, e = i - 36 * q, ii = e / 6, jj = e - 6 * ii;
+          int bi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+          while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
+          while (bi * (bi + 1) / 2 > q) --bi;
+          const int bj = q - bi * (bi + 1) / 2;
+          if (bi > bj || ii >= jj) S[LY.at(6 * bi + ii, 6 * bj + jj)] += a;
+        } else {
+          const int which = (i - nP) / Dp, j = (i - nP) - which * Dp;
+          (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] += a;
+        }
+      }
+      __syncthreads();
+    }
   }
   if (n_pri) {
     if (s_was_pending && !s_accepted) {   // rejected step: restage the records of the buffer that stays accepted

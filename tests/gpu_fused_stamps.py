@@ -16,7 +16,7 @@ for r0 in (0, 4):
     print("  solve: decision done %.2f us, shadow assembly done %.2f, barrier %.2f, imu+priors %.2f, damping %.2f, ldl %.2f, backsub %.2f, end %.2f" % (
         (p[3]-p[0])/T, (p[4]-p[0])/T, (p[1]-p[0])/T, (p[5]-p[0])/T, (p[6]-p[0])/T, (p[7]-p[0])/T, (p[8]-p[0])/T, (p[9]-p[0])/T))
     print("  linearise group 0: loads %.2f A %.2f B %.2f stage %.2f Ca %.2f Cb %.2f Cc %.2f barrier %.2f scalars %.2f | reduce %.2f | total %.2f us" % (
-        tuple((p[k]-p[k-1])/T for k in range(41, 50)) + ((p[50]-p[49])/T, (p[50]-p[40])/T)))
+        tuple((p[k]-p[k-1])/T for k in range(41, 49)) + ((p[51]-p[50])/T, (p[50]-p[49])/T, (p[51]-p[40])/T)))
     if True:
         print("  reduction (schur wg 0 / fused group 0): decision %.2f, tables+V^-1 (fast: V^-1) %.2f, fill (zero) %.2f, products (fill) %.2f, more batches (mfma) %.2f, lists (store) %.2f, write %.2f | total %.2f us" % (
             ((p[17]-p[16])/T if r0 else 0.0, (p[18]-(p[17] if r0 else p[49]))/T) + tuple((p[k]-p[k-1])/T for k in range(19, 24)) + ((p[23]-(p[16] if r0 else p[49]))/T,)))
