@@ -202,9 +202,15 @@ def main():
 
         # (a) the shape the timed loop launches: n_streams sub-batches side by side, each a dependent chain schur -> solve ->
         #     linearise.  The roofline entry names the kernel that takes most of that chain.
-        nst = a.streams if a.streams > 0 else (3 if a.windows >= 48 else 2 if a.windows >= 16 else 1)
+        nst = a.streams if a.streams > 0 else (3 if a.windows >= 56 else 2 if a.windows >= 8 else 1)   # the library's rule (okvis_ba_upload)
         sub = (a.windows + nst - 1) // nst
-        bs = solver.WindowBatch(wins[:sub], device=local_rank, options=opt)
+        # a batch of `sub` windows on its own would run in fused mode (up to 24 windows); the sub-batches of a
+        # larger upload do not: profile the kernels the timed loop launches
+        import copy
+        opt_sub = copy.copy(opt)
+        if a.windows > 24:
+            opt_sub.reserved0 = opt_sub.reserved0 | 4
+        bs = solver.WindowBatch(wins[:sub], device=local_rank, options=opt_sub)
         bs.begin()
         loop_tab, _ = kernel_table(bs, sub)
         bs.finish()
@@ -323,6 +329,7 @@ def main():
     dogleg = None
     config_c = None
     strong = None
+    frontend = None
     if rank == 0 and not a.no_extras and not a.pmc_child:
         dopt = default_options()
         dopt.use_graph = 0 if a.no_graph else 1
@@ -357,6 +364,35 @@ def main():
                   "note": "wall time of okvis_ba_optimize (begin + first linearisation incl. IMU re-preintegration + 10 iteration "
                           "slots + top-up slots + final decision + landmark quality), upload excluded; a launch slot is one schur + "
                           "solve + linearise triple for the whole batch; termination 0 = iteration cap, 1 = function tolerance"}
+        # ---- frontend pieces (include/okvis_amd_frontend.h): stereo triangulation + uncertainty for the candidate matches of one
+        #      frame pair, host buffers in and out (the PCIe-inclusive rate a matcher sees)
+        from okvis_amd import frontend as FE
+        rng = np.random.default_rng(7)
+        n_kp, n_pairs = 2000, 4096
+        fcam = FE.camera(synthetic.TEST_INTR_RADTAN, 1)
+        T_AB = np.array([0.11, 0.005, -0.002, 0.0, 0.01, 0.0, 1.0]); T_AB[3:] /= np.linalg.norm(T_AB[3:])
+        depth = rng.uniform(0.8, 20.0, n_kp)
+        pA = np.c_[rng.uniform(-0.5, 0.5, n_kp) * depth, rng.uniform(-0.35, 0.35, n_kp) * depth, depth]
+        uvA, _ = synthetic.project_points(synthetic.TEST_INTR_RADTAN, 1, pA)
+        uvB, _ = synthetic.project_points(synthetic.TEST_INTR_RADTAN, 1, pA - T_AB[:3])
+        kpA = np.c_[np.nan_to_num(uvA, nan=100.0), np.full(n_kp, 8.0)].astype(np.float32)
+        kpB = np.c_[np.nan_to_num(uvB, nan=100.0) + rng.normal(size=(n_kp, 2)) * 0.4, np.full(n_kp, 8.0)].astype(np.float32)
+        fpairs = np.c_[rng.integers(0, n_kp, n_pairs), rng.integers(0, n_kp, n_pairs)].astype(np.int32)
+        fpairs[: n_kp] = np.c_[np.arange(n_kp), np.arange(n_kp)]
+        fctx = FE.Frontend(local_rank)
+        UO = np.diag([1e-2] * 3 + [1e-8] * 3)
+        for _ in range(3):
+            fctx.stereo_triangulate(fcam, fcam, T_AB, UO, kpA, kpB, fpairs)
+        tf0 = time.perf_counter()
+        n_calls = 50
+        for _ in range(n_calls):
+            _, _, fflags = fctx.stereo_triangulate(fcam, fcam, T_AB, UO, kpA, kpB, fpairs)
+        tf1 = time.perf_counter()
+        fctx.close()
+        frontend = {"entry": "okvis_fe_stereo_triangulate with uncertainty (ProbabilisticStereoTriangulator.cpp:178-355)",
+                    "candidates_per_call": n_pairs, "keypoints_per_image": n_kp, "ms_per_call": (tf1 - tf0) / n_calls * 1e3,
+                    "candidates_per_s": n_pairs * n_calls / (tf1 - tf0), "valid_fraction": float((fflags & 1).mean()),
+                    "note": "host buffers in and out (one H2D, one kernel, one D2H per call), ctypes overhead included"}
         # ---- BASELINE configs[2]: 50 keyframes / 2000 landmarks / 200 000 observations (HBM-resident tiled solve), one window
         wc = synthetic.config_C(seed=20240923, visibility=a.visibility)
         bc = solver.WindowBatch([wc], device=local_rank, options=opt)
@@ -424,7 +460,7 @@ def main():
                                               "max": max(walls) * 1e3 / a.steps}},
             "window_records": {"fields": ["window_id", "iterations", "final_cost", "seconds"], "n": len(records),
                                "first": records[:2], "collective": (f"one all_gather, backend {dist.get_backend()}" + (" (= RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else "none (1 rank)"},
-            "single_window": single, "roofline": roofline, "dogleg": dogleg, "config_C": config_c, "strong_scaling_64_windows": strong,
+            "single_window": single, "roofline": roofline, "dogleg": dogleg, "config_C": config_c, "frontend": frontend, "strong_scaling_64_windows": strong,
             "ranks_seen_by_collective": world if dist is None else dist.get_world_size(),
             "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "speedup_vs_cpu": None if cpu is None else {
