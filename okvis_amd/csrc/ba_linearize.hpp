@@ -77,9 +77,10 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
   double(*vb)[3] = reinterpret_cast<double(*)[3]>(aux + GROUP_LM * 6);
   const double* s_U = aux + GROUP_LM * 9;
   const int* blktask = reinterpret_cast<const int*>(aux + GROUP_LM * 9 + FUSE_MAX_TASKS * 36);   // filled when the index lists were parked
-  // ---- (V_l + lambda D_l^2)^-1 and V^-1 b per landmark (one work-item each)
-  if (tid < nlm) {
-    const double* r = s_lmres + 16 * tid;
+  // ---- (V_l + lambda D_l^2)^-1 and V^-1 b per landmark (one work-item each, wave 1: wave 0 is still writing the group scalars)
+  const int lt = tid - 64;   // landmark of this work-item
+  if (lt >= 0 && lt < nlm) {
+    const double* r = s_lmres + 16 * lt;
     double v[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, vi[6];
     if (opt.marg_mode) {
       pinv3sym_precond(v, vi);
@@ -100,10 +101,10 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
       inv3sym(v, vi);
     }
 #pragma unroll
-    for (int e = 0; e < 6; ++e) vinv[tid][e] = vi[e];
-    vb[tid][0] = vi[0] * r[6] + vi[1] * r[7] + vi[2] * r[8];
-    vb[tid][1] = vi[1] * r[6] + vi[3] * r[7] + vi[4] * r[8];
-    vb[tid][2] = vi[2] * r[6] + vi[4] * r[7] + vi[5] * r[8];
+    for (int e = 0; e < 6; ++e) vinv[lt][e] = vi[e];
+    vb[lt][0] = vi[0] * r[6] + vi[1] * r[7] + vi[2] * r[8];
+    vb[lt][1] = vi[1] * r[6] + vi[3] * r[7] + vi[4] * r[8];
+    vb[lt][2] = vi[2] * r[6] + vi[4] * r[7] + vi[5] * r[8];
   }
   constexpr int MAXT = 7;   // output tiles per wave: 7 x 4 >= 28 = the lower triangle of 7 x 7 tiles (R <= 112)
   lin_v4 acc[MAXT];
@@ -134,9 +135,9 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
         w[0] = w0, w[1] = w1, w[2] = w2;
       }
     }
-    if (tid >= l0 && tid < min(nlm, l0 + nlb)) {   // row Dp of Y: V^-1 b (gives Y b = W V^-1 b in row Dp of the product)
-      double* y = tY + (size_t)Dp * KP + 3 * (tid - l0);
-      y[0] = vb[tid][0], y[1] = vb[tid][1], y[2] = vb[tid][2];
+    if (lt >= l0 && lt < min(nlm, l0 + nlb)) {   // row Dp of Y: V^-1 b (gives Y b = W V^-1 b in row Dp of the product)
+      double* y = tY + (size_t)Dp * KP + 3 * (lt - l0);
+      y[0] = vb[lt][0], y[1] = vb[lt][1], y[2] = vb[lt][2];
     }
     __syncthreads();
     if (l0 == 0) FSTAMP(20);
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   const bool fast = FUSE && W.fuse_fast;
   int pf_poff[2] = {0, 0}, pf_plm[2] = {0, 0};
   double pf_sc[3] = {1.0, 1.0, 1.0};   // Jacobi scale of this work-item's landmark (fast fused path; estimated in this launch when init)
-  if (fast && !init && tid < nlm) {
-    const double* sl = W.lm_scale + 3 * (size_t)(G.lm_begin + tid);
+  if (fast && !init && tid >= 64 && tid - 64 < nlm) {   // (the landmark work of the reduction is done by wave 1)
+    const double* sl = W.lm_scale + 3 * (size_t)(G.lm_begin + tid - 64);
     pf_sc[0] = sl[0], pf_sc[1] = sl[1], pf_sc[2] = sl[2];
   }
   if (fast) {
@@ -708,37 +709,41 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
   __syncthreads();
   LSTAMP(48);
   LSTAMP(49);
+  auto group_scalars = [&]() {   // (d) group scalars by wave 0
+  if (tid < 64) {
+      double cost = 0, gm = 0;
+      if (tid < nlm) {
+        cost = s_lmres[16 * tid + 15];
+        gm = fmax(fabs(s_lmres[16 * tid + 6]), fmax(fabs(s_lmres[16 * tid + 7]), fabs(s_lmres[16 * tid + 8])));
+      }
+      cost = wave_sum_full(cost);
+      gm = wave_max_full(gm);
+      sc_gd = wave_sum_full(sc_gd);
+      sc_ddd = wave_sum_full(sc_ddd);
+      sc_s2 = wave_sum_full(sc_s2);
+      sc_x2 = wave_sum_full(sc_x2);
+      if (tid == 0) {
+        double* gs = W.gscal[trial] + (size_t)g * GS_COUNT;
+        gs[GS_COST] = cost;
+        gs[GS_GD] = sc_gd;
+        gs[GS_DDD] = sc_ddd;
+        gs[GS_STEP2] = sc_s2;
+        gs[GS_X2] = sc_x2;
+        gs[GS_GMAX] = gm;
+      }
+    }
+  };
   if constexpr (FUSE) {
-    // (the barrier before (d) has V, b, W, the per-group partials in global memory and the last reads of the stage behind it)
+    // (the barrier above has V, b, W, the per-group partials in global memory and the last reads of the stage behind it)
+    // the scalars first, by wave 0; the landmark work of the fast reduction belongs to wave 1, so the two overlap
+    group_scalars();
     if (fast)
       fused_reduce_fast<LinCfg<EXT, REAL>::STAGE_DOUBLES>(W, opt, g, trial, lam_next, nlm, init != 0, pf_sc, fit, smem, s_lmres, s_step);
     else
       reduce_own_group(trial, lam_next);
   }
   LSTAMP(50);
-  // (d) group scalars by wave 0
-  if (tid < 64) {
-    double cost = 0, gm = 0;
-    if (tid < nlm) {
-      cost = s_lmres[16 * tid + 15];
-      gm = fmax(fabs(s_lmres[16 * tid + 6]), fmax(fabs(s_lmres[16 * tid + 7]), fabs(s_lmres[16 * tid + 8])));
-    }
-    cost = wave_sum_full(cost);
-    gm = wave_max_full(gm);
-    sc_gd = wave_sum_full(sc_gd);
-    sc_ddd = wave_sum_full(sc_ddd);
-    sc_s2 = wave_sum_full(sc_s2);
-    sc_x2 = wave_sum_full(sc_x2);
-    if (tid == 0) {
-      double* gs = W.gscal[trial] + (size_t)g * GS_COUNT;
-      gs[GS_COST] = cost;
-      gs[GS_GD] = sc_gd;
-      gs[GS_DDD] = sc_ddd;
-      gs[GS_STEP2] = sc_s2;
-      gs[GS_X2] = sc_x2;
-      gs[GS_GMAX] = gm;
-    }
-  }
+  if constexpr (!FUSE) group_scalars();
   LSTAMP(51);
 }
 

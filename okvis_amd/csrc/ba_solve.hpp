@@ -507,7 +507,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           if (i >= ntot) break;
           const size_t stride = W.spart_stride;
           const int nch = W.n_chunk;
-          auto sp = W.spart + (DBUF ? (size_t)(gctrl->pending ? 1 - gctrl->acc : gctrl->acc) * W.spart_buf_stride : (size_t)0) + i;   // (the speculated buffer)
+          auto sp = W.spart + (DBUF ? (size_t)__builtin_amdgcn_readfirstlane(gctrl->pending ? 1 - gctrl->acc : gctrl->acc) * W.spart_buf_stride : (size_t)0) + i;   // (the speculated buffer)
           double a = 0;
           for (int ch = 0; ch < nch; ch += 16) {
             double v[16];
@@ -647,7 +647,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // of the pose part in 6x6 blocks, then  Y b | g | diag U): lanes on consecutive doubles (coalesced; three items per lane
   // and eight chunks per trip are requested together — the loads come from other CUs' stores, what counts is the number of
   // dependent rounds), scattered into the 16x16 accumulator-layout blocks of the LDL^T solver.
-  const int sum_spec = DBUF ? (gctrl->pending ? 1 - gctrl->acc : gctrl->acc) : 0;   // the buffer that is accepted if the pending trial is
+  // (readfirstlane: the index is uniform, but it comes from a vector load — as a VGPR it drags every address of the sums into
+  // vector registers and the kernel into 100 spills)
+  const int sum_spec = DBUF ? __builtin_amdgcn_readfirstlane(gctrl->pending ? 1 - gctrl->acc : gctrl->acc) : 0;   // the buffer that is accepted if the pending trial is
   auto sum_partials = [&](int buf, bool use_sums) {
     if constexpr (!LARGE) {
       const int npose_blk = Dp / 6;
@@ -872,7 +874,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     if (tid == 0) *gctrl = c;
     return;
   }
-  const int acc = c.acc;
+  const int acc = __builtin_amdgcn_readfirstlane(c.acc);   // (uniform: keeps the buffer selection in scalar registers)
   const WinPtrs& Wl = *[&]() -> const WinPtrs* {
     if constexpr (LARGE) return &W;
     else return reinterpret_cast<const WinPtrs*>(s_Wd);
