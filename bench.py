@@ -204,11 +204,11 @@ def main():
         #     linearise.  The roofline entry names the kernel that takes most of that chain.
         nst = a.streams if a.streams > 0 else (3 if a.windows >= 56 else 2 if a.windows >= 8 else 1)   # the library's rule (okvis_ba_upload)
         sub = (a.windows + nst - 1) // nst
-        # a batch of `sub` windows on its own would run in fused mode (up to 24 windows); the sub-batches of a
+        # a batch of `sub` windows on its own would run in fused mode (up to 48 windows); the sub-batches of a
         # larger upload do not: profile the kernels the timed loop launches
         import copy
         opt_sub = copy.copy(opt)
-        if a.windows > 24:
+        if a.windows > 48:
             opt_sub.reserved0 = opt_sub.reserved0 | 4
         bs = solver.WindowBatch(wins[:sub], device=local_rank, options=opt_sub)
         bs.begin()

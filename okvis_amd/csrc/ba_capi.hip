@@ -139,7 +139,16 @@ namespace {
 
 size_t solve_smem(int Dpad, bool large);
 
-constexpr int FUSED_MAX_WINDOWS = 24;    // up to here the fused linearise + reduce launch beats the separate Schur launch (tests/gpu_fused_sweep.py)
+constexpr int FUSED_MAX_WINDOWS = 48;   // up to here the fused linearise + reduce launch beats the separate Schur launch (tests/gpu_fused_sweep.py:
+                                        // 48 windows 148.5 vs 151.3 us per step, 64 windows 176 vs 163)
+// (OKVIS_BA_FUSED_MAX_WINDOWS overrides it: diagnostics)
+int fused_max_windows() {
+  static const int v = [] {
+    const char* e = std::getenv("OKVIS_BA_FUSED_MAX_WINDOWS");
+    return e ? std::atoi(e) : FUSED_MAX_WINDOWS;
+  }();
+  return v;
+}
 constexpr int SMALL_BATCH_WINDOWS = 40;   // below: the device is not full - settings that shorten one window's chain win
 
 OptD make_optd(const okvis_ba_options& o, int n_windows) {
@@ -422,7 +431,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // then chunk = group.  options.reserved0 bit 2 keeps the separate launch (A/B switch).
     const int stage = opt.fp32_linearize ? (has_ext ? LinCfg<true, float>::STAGE_DOUBLES : LinCfg<false, float>::STAGE_DOUBLES)
                                          : (has_ext ? LinCfg<true, double>::STAGE_DOUBLES : LinCfg<false, double>::STAGE_DOUBLES);
-    H.group_chunks = !(opt.reserved0 & 4) && opt.schur_lm_per_block == 0 && D <= MAX_D_LDS && Dp <= TILE_DIM && n_windows_total <= FUSED_MAX_WINDOWS && 2 * SCHUR_LM_BATCH * 3 * Dp <= stage &&
+    H.group_chunks = !(opt.reserved0 & 4) && opt.schur_lm_per_block == 0 && D <= MAX_D_LDS && Dp <= TILE_DIM && n_windows_total <= fused_max_windows() && 2 * SCHUR_LM_BATCH * 3 * Dp <= stage &&
                      (opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || opt.gauss_newton);
     if (H.group_chunks) per = 1;
     int g = 0;

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
-for nwin in (1, 2, 4, 8, 12, 16, 24, 32, 64):
+for nwin in [int(x) for x in sys.argv[1:]] or (1, 2, 4, 8, 12, 16, 24, 32, 64):
     ws = [synthetic.config_A(seed=20240923 + i) for i in range(nwin)]
     out = []
     for r0 in (0, 4):
