@@ -338,9 +338,13 @@ def main():
         it_total = slot_total = redo_total = 0
         t_total = 0.0
         term = {}
-        for bi in range(n_batches + 1):   # the first batch warms the graph cache up and is not counted
+        bd = None
+        for bi in range(n_batches + 1):   # the first batch warms the solver up (allocations, launch graphs) and is not counted
             fresh = [synthetic.make_window(a.keyframes, a.landmarks, a.visibility, 7_000_000 + 1000 * bi + i) for i in range(per_batch)]
-            bd = solver.WindowBatch(fresh, device=local_rank, options=dopt)
+            if bd is None:
+                bd = solver.WindowBatch(fresh, device=local_rank, options=dopt)
+            else:
+                bd.upload(fresh)      # one solver serves batch after batch, like a deployment would
             bd.synchronize()
             t0 = time.perf_counter()
             sm = bd.optimize(10)
@@ -353,7 +357,7 @@ def main():
                 redo_total += int(sum(bd.array("IMU_REDO_COUNT", w).sum() for w in range(per_batch)))
                 for x in sm:
                     term[x["termination"]] = term.get(x["termination"], 0) + 1
-            bd.close()
+        bd.close()
         dogleg = {"mode": "DOGLEG, Jacobi scaling, default tolerances (Estimator.cpp:854-873), optimize(10) from the perturbed start",
                   "windows": n_batches * per_batch, "windows_per_call": per_batch,
                   "counted_iterations": it_total, "iterations_per_s": it_total / t_total,

@@ -121,6 +121,10 @@ struct okvis_ba_solver {
   bool uploaded = false, begun = false, any_ext = false;
   bool group_chunks = false;   // every window of the batch has one Schur chunk per linearise group (see fused())
   bool fp32_at_upload = false;
+  std::vector<int64_t> launch_sig;   // what the captured graphs depend on (see okvis_ba_upload)
+  unsigned char* h_ctrl_stage = nullptr;   // pinned / device staging of per-window control data (begin, fetch_ctrl)
+  unsigned char* d_ctrl_stage = nullptr;
+  size_t ctrl_stage_bytes = 0;
   bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0, max_spart_stride = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
@@ -819,6 +823,35 @@ size_t solve_smem(int Dpad, bool large) {
 }
 size_t small_smem() { return (size_t)std::max<int>(std::max<int>(ImuLds::TOTAL, EvalLds::TOTAL), 2 * MAX_MARG_DIM) * sizeof(double); }
 
+// okvis_ba_begin for every window in ONE launch (it used to be three device copies and one upload per window: 1 ms of API calls
+// for 64 windows): the trial buffers start as copies of the accepted ones, the control record starts a new optimisation.
+// `accs[w]` = the accepted buffer as the host knows it (okvis_ba_set_state wrote there).
+__global__ void begin_kernel(const WinPtrs* wins, const int* accs, double initial_radius) {
+  const WinPtrs& W = wins[blockIdx.x];
+  const int acc = accs[blockIdx.x], tr = 1 - acc, tid = threadIdx.x;
+  for (int i = tid; i < 7 * W.n_pose; i += blockDim.x) W.pose[tr][i] = W.pose[acc][i];
+  for (int i = tid; i < 9 * W.n_sb; i += blockDim.x) W.sb[tr][i] = W.sb[acc][i];
+  for (int i = tid; i < 4 * W.n_lm; i += blockDim.x) W.lm[tr][i] = W.lm[acc][i];
+  if (tid == 0) {
+    Ctrl c;
+    for (size_t k = 0; k < sizeof(Ctrl) / 8; ++k) reinterpret_cast<double*>(&c)[k] = 0.0;
+    c.acc = acc;
+    c.pending = 1;
+    c.first = 1;
+    c.radius = initial_radius;
+    c.decrease_factor = 2.0;
+    c.lambda = 1.0 / initial_radius;
+    c.mu = DL_MIN_MU;
+    *W.ctrl = c;
+  }
+}
+// the control records of all windows into one contiguous array (one device-to-host copy instead of one per window)
+__global__ void gather_ctrl_kernel(const WinPtrs* wins, Ctrl* out, int n) {
+  const int w = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+  if (w < n && lane < (int)(sizeof(Ctrl) / 8))
+    reinterpret_cast<double*>(out + w)[lane] = reinterpret_cast<const double*>(wins[w].ctrl)[lane];
+}
+
 // keeps one wave busy for `ticks` of the 100 MHz wall clock (the start stagger of the sub-batch streams)
 __global__ void delay_kernel(long long ticks) {
   const long long t0 = wall_clock64();
@@ -927,11 +960,29 @@ int refresh_acc(okvis_ba_solver* s, int w) {
   return OKVIS_BA_OK;
 }
 
+// grow-only staging for begin_kernel's buffer indices and the gathered control records (pinned host + device)
+hipError_t reserve_ctrl_stage(okvis_ba_solver* s, size_t n_windows) {
+  const size_t bytes = std::max(sizeof(Ctrl), sizeof(int)) * n_windows;
+  if (bytes <= s->ctrl_stage_bytes) return hipSuccess;
+  if (s->h_ctrl_stage) (void)hipHostFree(s->h_ctrl_stage);
+  if (s->d_ctrl_stage) (void)hipFree(s->d_ctrl_stage);
+  s->h_ctrl_stage = s->d_ctrl_stage = nullptr;
+  s->ctrl_stage_bytes = 0;
+  hipError_t e = hipHostMalloc((void**)&s->h_ctrl_stage, bytes, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_ctrl_stage, bytes);
+  if (e == hipSuccess) s->ctrl_stage_bytes = bytes;
+  return e;
+}
+
 int fetch_ctrl(okvis_ba_solver* s, std::vector<Ctrl>& out) {
-  out.resize(s->wins.size());
-  for (size_t i = 0; i < s->wins.size(); ++i)
-    HIP_TRY(hipMemcpyAsync(&out[i], s->wins[i].ptrs.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s->stream));
+  const size_t n = s->wins.size();
+  out.resize(n);
+  HIP_TRY(reserve_ctrl_stage(s, n));
+  hipLaunchKernelGGL(gather_ctrl_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s->stream, s->d_wins, reinterpret_cast<Ctrl*>(s->d_ctrl_stage), (int)n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->h_ctrl_stage, s->d_ctrl_stage, sizeof(Ctrl) * n, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  std::memcpy(out.data(), s->h_ctrl_stage, sizeof(Ctrl) * n);
   return OKVIS_BA_OK;
 }
 
@@ -1053,6 +1104,8 @@ int okvis_ba_destroy(okvis_ba_solver* s) {
   if (s->d_arena) (void)hipFree(s->d_arena);
   if (s->d_wins) (void)hipFree(s->d_wins);
   if (s->d_opt) (void)hipFree(s->d_opt);
+  if (s->h_ctrl_stage) (void)hipHostFree(s->h_ctrl_stage);
+  if (s->d_ctrl_stage) (void)hipFree(s->d_ctrl_stage);
   if (s->marg_scratch) (void)hipFree(s->marg_scratch);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -1091,7 +1144,6 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
   const auto t_synced = std::chrono::steady_clock::now();
-  destroy_graphs(s);
   s->uploaded = false;
   s->begun = false;
   Arena A;
@@ -1196,6 +1248,21 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
       }
     }
   }
+  {
+    // Captured graphs hold grid sizes, LDS sizes, kernel choices and the device addresses of the window / option records —
+    // not the windows themselves.  A re-upload that leaves all of that unchanged (the same number of equally shaped windows:
+    // the per-frame pattern of a batch service, the dogleg record of bench.py) keeps them; anything else drops them.
+    std::vector<int64_t> sig = {n_windows, s->max_group, s->max_imu, s->max_schur_blocks, s->max_lm, s->max_Dpad, s->max_Dp,
+                                s->max_Dpad_small, s->max_Dpad_large, s->max_spart_stride, s->any_ext, s->group_chunks,
+                                s->fp32_at_upload, (int64_t)(intptr_t)s->d_wins, (int64_t)(intptr_t)s->d_opt,
+                                (int64_t)s->sub_streams.size()};
+    for (int b : s->sub_begin) sig.push_back(b);
+    for (auto st : s->sub_streams) sig.push_back((int64_t)(intptr_t)st);
+    if (sig != s->launch_sig) {
+      destroy_graphs(s);
+      s->launch_sig.swap(sig);
+    }
+  }
   s->uploaded = true;
   s->acc_fresh = true;   // Ctrl starts zeroed: accepted buffer 0, like HostWin::acc
   if (dbg_t) {
@@ -1281,21 +1348,15 @@ int okvis_ba_begin(okvis_ba_solver* s) {
   if (!s->uploaded) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
   s->slots = 0;
-  for (auto& H : s->wins) {
-    const int acc = H.acc, tr = 1 - acc;
-    HIP_TRY(hipMemcpyAsync(H.ptrs.pose[tr], H.ptrs.pose[acc], 56 * (size_t)H.n_pose, hipMemcpyDeviceToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(H.ptrs.sb[tr], H.ptrs.sb[acc], 72 * (size_t)H.n_sb, hipMemcpyDeviceToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(H.ptrs.lm[tr], H.ptrs.lm[acc], 32 * (size_t)H.n_lm, hipMemcpyDeviceToDevice, s->stream));
-    Ctrl c;
-    std::memset(&c, 0, sizeof(c));
-    c.acc = acc;
-    c.pending = 1;
-    c.first = 1;
-    c.radius = s->opt.initial_radius;
-    c.decrease_factor = 2.0;
-    c.lambda = 1.0 / s->opt.initial_radius;
-    c.mu = DL_MIN_MU;
-    HIP_TRY(hipMemcpyAsync(H.ptrs.ctrl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
+  {
+    const size_t n = s->wins.size();
+    HIP_TRY(reserve_ctrl_stage(s, n));
+    int* accs = reinterpret_cast<int*>(s->h_ctrl_stage);
+    for (size_t i = 0; i < n; ++i) accs[i] = s->wins[i].acc;
+    HIP_TRY(hipMemcpyAsync(s->d_ctrl_stage, accs, sizeof(int) * n, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(begin_kernel, dim3((unsigned)n), dim3(256), 0, s->stream, s->d_wins, reinterpret_cast<const int*>(s->d_ctrl_stage),
+                       s->opt.initial_radius);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(launch_lin(s, whole(s), 1));
   s->begun = true;
@@ -1404,7 +1465,7 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
       }
       if (need <= 0) break;
       s->slots += need;
-      for (int i = 0; i < need; ++i) HIP_TRY(launch_iteration(s, whole(s)));
+      HIP_TRY(launch_iterations_forked(s, need, 0));   // (on the sub-batch streams like every other iteration; no new budget)
       HIP_TRY(launch_schur(s, whole(s), 1));
       HIP_TRY(launch_solve(s, whole(s), 1));
     }

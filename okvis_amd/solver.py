@@ -45,9 +45,14 @@ class WindowBatch:
         self._L = _lib.lib()
         self._h = C.c_void_p()
         _lib.check(self._L.okvis_ba_create(C.byref(self._h), int(device)), "create")
-        self.windows = list(windows)
         self.options = options or default_options()
         _lib.check(self._L.okvis_ba_set_options(self._h, C.byref(self.options)), "set_options")
+        self.upload(windows)
+
+    def upload(self, windows: Sequence[Window]):
+        """okvis_ba_upload on this solver: replaces the windows.  Device allocations are kept (grow-only) and so are the captured
+        launch graphs when the new windows have the shapes of the old ones."""
+        self.windows = list(windows)
         arr = (WindowC * len(self.windows))()
         keep = []
         for i, w in enumerate(self.windows):
