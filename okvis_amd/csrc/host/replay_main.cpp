@@ -3,7 +3,9 @@
 // The backend-side counterpart of `okvis_app_synchronous <config> <dataset folder>` (reference
 // okvis_apps/src/okvis_app_synchronous.cpp): reads the ASL folder plus the recorded tracks (replay.hpp) and runs the per-frame
 // loop of ThreadedKFVio on okvis_amd::Estimator.  Prints one line per 20 frames and a summary.
+#include <algorithm>
 #include <cstdio>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -53,6 +55,22 @@ int main(int argc, char** argv) {
                 r.frames.size(), r.landmarksRemoved, mo / n, mm / n);
     std::printf("optimize split per frame: flatten %.3f + upload %.3f + iterations %.3f + download %.3f ms\n", t4[0] / n, t4[1] / n, t4[2] / n,
                 t4[3] / n);
+    {   // medians: the means above carry the first frames' device allocations and page-locking
+      auto median = [&](auto get) {
+        std::vector<double> v;
+        for (const okvis_amd::ReplayFrameResult& f : r.frames) v.push_back(get(f));
+        if (v.empty()) return 0.0;
+        std::sort(v.begin(), v.end());
+        return v[v.size() / 2];
+      };
+      std::printf("medians per frame: optimize %.3f (flatten %.3f + upload %.3f + iterations %.3f + download %.3f) + marginalise %.3f ms\n",
+                  median([](const okvis_amd::ReplayFrameResult& f) { return f.msOptimize; }),
+                  median([](const okvis_amd::ReplayFrameResult& f) { return f.msFlatten; }),
+                  median([](const okvis_amd::ReplayFrameResult& f) { return f.msUpload; }),
+                  median([](const okvis_amd::ReplayFrameResult& f) { return f.msIterations; }),
+                  median([](const okvis_amd::ReplayFrameResult& f) { return f.msDownload; }),
+                  median([](const okvis_amd::ReplayFrameResult& f) { return f.msMarginalize; }));
+    }
     if (r.hasGroundTruth)
       std::printf("against the ground truth (first pose aligned): rms position %.4f m, final position %.4f m, final rotation %.5f rad\n",
                   r.rmsPosition, r.finalPosition, r.finalRotation);

@@ -238,3 +238,31 @@ def test_random_coupling_graphs(oracle, seed):
     assert (s1["iterations"], s1["successful_steps"]) == (sr["iterations"], sr["successful_steps"])
     for a, c in zip(x1, ow.get_state()):
         assert np.abs(a - c).max() < 1e-5
+
+
+def test_reupload_on_one_solver_keeps_or_drops_the_launch_graphs_correctly():
+    """okvis_ba_upload on a solver that has already optimised (WindowBatch.upload): the captured launch graphs survive when the
+    new windows have the shapes of the old ones and are dropped otherwise; either way the result is bit-identical to a fresh
+    solver's.  Also the one-launch okvis_ba_begin and the gathered control records behind every optimize()."""
+    def fresh(ws, n):
+        b = _batch(ws)
+        s = b.optimize(n)
+        x = [b.get_state(i) for i in range(len(ws))]
+        b.close()
+        return s, x
+
+    same_a = [synthetic.small_window(seed=300 + i, K=4, L=40) for i in range(3)]
+    same_b = [synthetic.small_window(seed=400 + i, K=4, L=40) for i in range(3)]       # other values, same shapes
+    other = [synthetic.small_window(seed=500 + i, K=5, L=55) for i in range(2)]         # other shapes, other count
+    b = _batch(same_a)
+    for _ in range(3):
+        b.optimize(4)                         # by now iterate(4) replays a captured graph
+    for ws in (same_b, other, same_a):
+        b.upload(ws)
+        got = b.optimize(4)
+        want, states = fresh(ws, 4)
+        assert got == want
+        for i in range(len(ws)):
+            for u, v in zip(b.get_state(i), states[i]):
+                assert np.array_equal(u, v)
+    b.close()
