@@ -701,7 +701,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(ct_rhs, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_y, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_x, put_zero(A, 8 * nT * CT_TB));
-    OFF(ct_flag, put_zero(A, sizeof(int) * (ntile + 3)));
+    OFF(ct_flag, put_zero(A, sizeof(int) * (ntile + 4)));
     OFF(ct_g, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_d2, put_zero(A, 8 * nT * CT_TB));
   }
