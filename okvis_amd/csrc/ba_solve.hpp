@@ -516,12 +516,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
 #pragma unroll
             for (int u = 0; u < 16; ++u) a += v[u];
           }
-          W.spart_sum[i] = a;
+          // device-coherent store (written through): with the plain store the hand-over needed an agent-scope release,
+          // which writes this XCD's whole L2 back (3.5 us, profiles/r03_notes.md) before the counter could be raised
+          __hip_atomic_store(&W.spart_sum[i], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      __threadfence();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's stores have been performed (s_waitcnt)
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(W.sum_sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_fetch_add(W.sum_sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
   }
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           const int i = base + t * NL;
-          if (use_sums) a[t] = i < ntot ? ssum[i] : 0.0;
+          if (use_sums) a[t] = i < ntot ? __hip_atomic_load(&ssum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
           dst[t] = -1;
           if (i < nP) {
             const int q = i / 36, e = i - 36 * q, ii = e / 6, jj = e - 6 * ii;
@@ -840,12 +842,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           __builtin_amdgcn_s_sleep(2);
           ++polls;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(&s_sum_ready, polls >= (1 << 22) ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       if (helped) {
-        while (__hip_atomic_load(&s_sum_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (no agent-scope acquire, which would invalidate the caches: the sums are read with device-coherent loads below)
+        while (__hip_atomic_load(&s_sum_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
       }
       sum_partials(sum_spec, helped);
       for (int i = tid - 64; i < 3 * (Dpad - Dp); i += NL) {   // speed/bias part of the vectors starts from zero

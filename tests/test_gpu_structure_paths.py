@@ -266,3 +266,26 @@ def test_reupload_on_one_solver_keeps_or_drops_the_launch_graphs_correctly():
             for u, v in zip(b.get_state(i), states[i]):
                 assert np.array_equal(u, v)
     b.close()
+
+
+def test_helper_workgroup_hand_over_is_repeatable():
+    """The solve launch of small batches has helper workgroups sum the Schur partials on other CUs and hand the sums over through
+    device-coherent stores and a counter (no cache write-back / invalidate): a stale or torn read would change the iterates.
+    150 repetitions of the same optimisation, fused and with the separate Schur launch: bit-identical every time."""
+    w = synthetic.config_A(seed=99)
+    for r0 in (0, 4):
+        opt = default_options()
+        opt.reserved0 = r0
+        b = solver.WindowBatch([w], options=opt)
+        first = None
+        for rep in range(150):
+            b.upload([w])
+            s = b.optimize(6)[0]
+            x = b.get_state()
+            if first is None:
+                first = (s, x)
+            else:
+                assert s == first[0], (rep, s, first[0])
+                for u, v in zip(x, first[1]):
+                    assert np.array_equal(u, v), rep
+        b.close()
