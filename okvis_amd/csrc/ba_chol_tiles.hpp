@@ -30,6 +30,7 @@ constexpr int CT_TB = 48;            // tile edge
 constexpr int CT_LD = 49;            // LDS row stride (doubles): conflict-free column walks
 constexpr int CT_THREADS = 256;
 constexpr int CT_TILE = CT_TB * CT_TB;
+constexpr int CT_TILE_BYTES = CT_TILE * 8;
 constexpr int CT_SPIN_LIMIT = 1 << 22;
 
 typedef double ct_v4 __attribute__((ext_vector_type(4)));
@@ -48,10 +49,32 @@ struct CholTiles {   // per-window workspace of the tiled solver (device pointer
 
 __device__ __forceinline__ int ct_tile_index(int i, int j) { return i * (i + 1) / 2 + j; }
 
+// Everything one workgroup hands to another inside this launch travels through DEVICE-COHERENT accesses (relaxed agent-scope
+// atomics: written through / read past the XCD's L2) and a flag raised after the writer's stores have been performed
+// (ct_release = s_waitcnt).  The textbook pair — plain stores, agent-scope release, acquire on the reader — writes the writer's
+// whole L2 back and invalidates the reader's at every poll: 3.5 us per hand-over when the chip is quiet, 10 us in the first
+// steps of the factorisation when 130 workgroups poll (profiles/r03_notes.md).
+__device__ __forceinline__ void ct_gst(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ct_gld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// drain: every wave that stored a payload waits for its stores before the workgroup's barrier and the flag behind it
+__device__ __forceinline__ void ct_release() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// 16-byte device-coherent accesses through a buffer descriptor (aux 16 = sc1); `base` must be wave-uniform
+typedef unsigned int ct_v4u __attribute__((ext_vector_type(4)));
+typedef double ct_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ct_v2 ct_gld2(const double* base, int pair) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, CT_TILE_BYTES, 0x00020000);
+  return __builtin_bit_cast(ct_v2, __builtin_amdgcn_raw_buffer_load_b128(rs, pair * 16, 0, 16));
+}
+__device__ __forceinline__ void ct_gst2(double* base, int pair, double a, double b) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, CT_TILE_BYTES, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ct_v4u, ct_v2{a, b}), rs, pair * 16, 0, 16);
+}
+__device__ __forceinline__ void ct_raise(int* f, int v = 1) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // wait until *f != 0 (acquire); returns false on timeout
 __device__ __forceinline__ bool ct_wait(const int* f) {
   for (int it = 0; it < CT_SPIN_LIMIT; ++it) {
-    if (__atomic_load_n(f, __ATOMIC_ACQUIRE) != 0) return true;
+    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
     __builtin_amdgcn_s_sleep(2);
   }
   return false;
@@ -63,7 +86,7 @@ __device__ __forceinline__ bool ct_wait(const int* f) {
 __device__ __forceinline__ bool ct_wait_col(const CholTiles& C, const int* f, int k) {
   if (C.progress) {
     int it = 0;
-    while (__atomic_load_n(C.progress, __ATOMIC_RELAXED) < k && it < CT_SPIN_LIMIT) {
+    while (__hip_atomic_load(C.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k && it < CT_SPIN_LIMIT) {
       __builtin_amdgcn_s_sleep(100);
       ++it;
     }
@@ -73,7 +96,13 @@ __device__ __forceinline__ bool ct_wait_col(const CholTiles& C, const int* f, in
 
 // global tile (row-major 48x48) -> LDS (stride CT_LD)
 __device__ __forceinline__ void ct_load_tile(const double* g, double* l, int tid) {
-  for (int e = tid; e < CT_TILE; e += CT_THREADS) l[(e / CT_TB) * CT_LD + (e % CT_TB)] = g[e];
+  for (int c = tid; c < CT_TILE / 2; c += CT_THREADS) {   // (48 is even: a pair never straddles two rows)
+    const ct_v2 v = ct_gld2(g, c);
+    const int e = 2 * c;
+    double* d = l + (e / CT_TB) * CT_LD + (e % CT_TB);
+    d[0] = v[0];
+    d[1] = v[1];
+  }
 }
 
 // acc(strip r of 16 rows, 3 sub-tiles of 16 columns) += sign * A[16r.., :] * B^T   with A, B 48x48 in LDS.
@@ -106,6 +135,22 @@ __device__ __forceinline__ void ct_load_acc(ct_v4 acc[3], const double* src, int
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[c][i] = src[(16 * strip + r0 + 4 * i) * ld + 16 * c + col];
+}
+
+// the same from / to global memory (device-coherent, see ct_gst)
+__device__ __forceinline__ void ct_store_acc_g(const ct_v4 acc[3], double* dst, int strip, int lane) {
+  const int col = lane & 15, r0 = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ct_gst(dst + (16 * strip + r0 + 4 * i) * CT_TB + 16 * c + col, acc[c][i]);
+}
+__device__ __forceinline__ void ct_load_acc_g(ct_v4 acc[3], const double* src, int strip, int lane) {
+  const int col = lane & 15, r0 = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[c][i] = ct_gld(src + (16 * strip + r0 + 4 * i) * CT_TB + 16 * c + col);
 }
 
 __device__ __forceinline__ double ct_rsqrt(double x) {  // v_rsq_f64 + two Newton steps: full fp64 accuracy
@@ -244,27 +289,26 @@ __device__ void chol_backsub_task(const CholTiles& C, int j, double* lds) {
   }
   __syncthreads();
   if (!s_ok) {
-    if (tid == 0) __atomic_store_n(failflag, 1, __ATOMIC_RELEASE);
+    if (tid == 0) ct_raise(failflag);
     for (int c = tid; c < CT_TB; c += CT_THREADS) C.x[CT_TB * j + c] = 0.0;   // let the rows above run out
     return;
   }
   ct_load_tile(C.Linv + (size_t)j * CT_TILE, sL, tid);
   if (j + 1 < nT) ct_load_tile(C.T + (size_t)ct_tile_index(j + 1, j) * CT_TILE, sNear, tid);
-  if (tid < CT_TB) s_t[tid] = C.y[CT_TB * j + tid];
+  if (tid < CT_TB) s_t[tid] = ct_gld(C.y + CT_TB * j + tid);
   constexpr int PER = CT_TILE / CT_THREADS;   // 9 entries of a tile per work-item
   double pre[PER];
   auto fetch = [&](int i) {
     const double* g = C.T + (size_t)ct_tile_index(i, j) * CT_TILE;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) pre[k] = g[tid + k * CT_THREADS];
+    for (int k = 0; k < PER; ++k) pre[k] = ct_gld(g + tid + k * CT_THREADS);
   };
   const int c = tid % CT_TB, p = tid / CT_TB;   // (component of a 48-vector, part 0..4 of the rows; p = 5: idle)
   if (nT - 1 >= j + 2) {
     // the far tiles of the column are final at the latest when the factorisation is, i.e. when x_(nT-1) appears
     if (tid == 0) (void)poll(CT_TB * (nT - 1));
     __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    fetch(nT - 1);
+    fetch(nT - 1);   // (device-coherent loads: the tiles were performed before their flags, the flags before x_(nT-1))
   }
   for (int i = nT - 1; i > j; --i) {
     const double* cur = (i == j + 1) ? sNear : sFar;
@@ -297,7 +341,7 @@ __device__ void chol_backsub_task(const CholTiles& C, int j, double* lds) {
   if (tid < CT_TB) {
     double v = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid] + s_part[4][tid];
     if (__double_as_longlong(v) == (long long)CT_X_SENTINEL) v = __longlong_as_double(0x7ff8000000000000LL);   // a NaN stays a NaN
-    __threadfence();   // whoever sees x_j may read everything this workgroup has seen
+    // (x_j is all a reader of x_j needs: no fence)
     if (C.tl && tid == 0) C.tl[4 * (nT * (nT + 1) / 2 + nT - 1 - j) + 3] = (double)wall_clock64();
     __atomic_store_n(reinterpret_cast<unsigned long long*>(C.x) + CT_TB * j + tid, (unsigned long long)__double_as_longlong(v),
                      __ATOMIC_RELAXED);
@@ -340,8 +384,8 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
   double* Tij = C.T + (size_t)ct_tile_index(i, j) * CT_TILE;
   double* Tsub = merged ? C.T + (size_t)ct_tile_index(j, j - 1) * CT_TILE : nullptr;
   if (wave < 3) {
-    ct_load_acc(acc, Tij, CT_TB, wave, lane);
-    if (merged) ct_load_acc(acc2, Tsub, CT_TB, wave, lane);
+    ct_load_acc_g(acc, Tij, wave, lane);
+    if (merged) ct_load_acc_g(acc2, Tsub, wave, lane);
   }
   if (diag && tid < CT_TB) s_r[tid] = C.rhs[CT_TB * j + tid];
   __syncthreads();
@@ -366,7 +410,7 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
       const int r = tid - 192;
       const double* yk = C.y + CT_TB * k;
       double s = 0;
-      for (int m = 0; m < CT_TB; ++m) s += sA[r * CT_LD + m] * yk[m];
+      for (int m = 0; m < CT_TB; ++m) s += sA[r * CT_LD + m] * ct_gld(yk + m);
       s_r[r] -= s;
     }
     __syncthreads();
@@ -383,7 +427,7 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc2[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
         ct_gemm_nt(acc2, sA, sB, wave, lane, 1.0);
-        ct_store_acc(acc2, Tsub, CT_TB, wave, lane);   // for the tiles below in column j and the back-substitution (in flight
+        ct_store_acc_g(acc2, Tsub, wave, lane);   // for the tiles below in column j and the back-substitution (in flight
         ct_store_acc(acc2, sC, CT_LD, wave, lane);     // while the update below runs)
       }
       __syncthreads();
@@ -392,19 +436,19 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
         const int r = tid - 192;
         const double* yk = C.y + CT_TB * (j - 1);
         double s = 0;
-        for (int m = 0; m < CT_TB; ++m) s += sC[r * CT_LD + m] * yk[m];
+        for (int m = 0; m < CT_TB; ++m) s += sC[r * CT_LD + m] * ct_gld(yk + m);
         s_r[r] -= s;
       }
-      __threadfence();
+      ct_release();
       __syncthreads();   // (sC is overwritten next)
-      if (tid == 0) __atomic_store_n(C.flag + ct_tile_index(j, j - 1), 1, __ATOMIC_RELEASE);
+      if (tid == 0) ct_raise(C.flag + ct_tile_index(j, j - 1));
     }
   }
   if (!s_ok) {
     if (tid == 0) {
-      __atomic_store_n(failflag, 1, __ATOMIC_RELEASE);
-      __atomic_store_n(C.flag + ct_tile_index(i, j), 1, __ATOMIC_RELEASE);  // let the dependants run out
-      if (merged) __atomic_store_n(C.flag + ct_tile_index(j, j - 1), 1, __ATOMIC_RELEASE);
+      ct_raise(failflag);
+      ct_raise(C.flag + ct_tile_index(i, j));  // let the dependants run out
+      if (merged) ct_raise(C.flag + ct_tile_index(j, j - 1));
     }
     return;
   }
@@ -417,18 +461,22 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
     // publish Linv_j and y_j = Linv_j r_j: what the rest of the solve reads (column j's TRSMs, the next diagonal tile, the
     // back-substitution).  L_jj itself (lower, zeros above) is stored afterwards, off the chain: no task reads it.
     double* Linv = C.Linv + (size_t)j * CT_TILE;
-    for (int e = tid; e < CT_TILE; e += CT_THREADS) Linv[e] = sB[(e / CT_TB) * CT_LD + (e % CT_TB)];
+    for (int c = tid; c < CT_TILE / 2; c += CT_THREADS) {
+      const int e = 2 * c;
+      const double* q = sB + (e / CT_TB) * CT_LD + (e % CT_TB);
+      ct_gst2(Linv, c, q[0], q[1]);
+    }
     if (tid < CT_TB) {
       double s = 0;
       for (int m = 0; m <= tid; ++m) s += sB[tid * CT_LD + m] * s_r[m];
-      C.y[CT_TB * j + tid] = s;
+      ct_gst(C.y + CT_TB * j + tid, s);
     }
-    if (tid == 0 && s_fail) __atomic_store_n(failflag, 1, __ATOMIC_RELEASE);
-    __threadfence();
+    if (tid == 0 && s_fail) ct_raise(failflag);
+    ct_release();
     __syncthreads();
     if (tid == 0) {
-      __atomic_store_n(C.flag + ct_tile_index(i, j), 1, __ATOMIC_RELEASE);
-      if (C.progress) __atomic_store_n(C.progress, j + 1, __ATOMIC_RELAXED);
+      ct_raise(C.flag + ct_tile_index(i, j));
+      if (C.progress) ct_raise(C.progress, j + 1);
     }
     if (C.tl && tid == 0) C.tl[4 * task + 3] = (double)wall_clock64();
     for (int e = tid; e < CT_TILE; e += CT_THREADS) {
@@ -448,13 +496,13 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
       ct_gemm_nt(acc, sA, sB, wave, lane, 1.0);
-      ct_store_acc(acc, Tij, CT_TB, wave, lane);
+      ct_store_acc_g(acc, Tij, wave, lane);
     }
-    if (tid == 0 && !s_ok) __atomic_store_n(failflag, 1, __ATOMIC_RELEASE);
+    if (tid == 0 && !s_ok) ct_raise(failflag);
   }
-  __threadfence();
+  ct_release();
   __syncthreads();
-  if (tid == 0) __atomic_store_n(C.flag + ct_tile_index(i, j), 1, __ATOMIC_RELEASE);
+  if (tid == 0) ct_raise(C.flag + ct_tile_index(i, j));
   if (C.tl && tid == 0) C.tl[4 * task + 3] = (double)wall_clock64();
 }
 

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           __hip_atomic_store(&W.spart_sum[i], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's stores have been performed (s_waitcnt)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have been performed (every storing wave drains)
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(W.sum_sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
