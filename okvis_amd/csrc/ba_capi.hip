@@ -701,7 +701,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(ct_rhs, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_y, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_x, put_zero(A, 8 * nT * CT_TB));
-    OFF(ct_flag, put_zero(A, sizeof(int) * (ntile + 4)));
+    OFF(ct_flag, put_zero(A, sizeof(int) * (ntile + 4 + 2 * nT)));
     OFF(ct_g, put_zero(A, 8 * nT * CT_TB));
     OFF(ct_d2, put_zero(A, 8 * nT * CT_TB));
   }
@@ -1780,7 +1780,7 @@ int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* r
   for (int k = 0; k < n; ++k) r[k] = rhs[k];
   Arena A;
   const size_t oT = A.alloc(8 * tiles.size()), oL = A.alloc(8 * (size_t)nT * CT_TILE), oR = A.alloc(8 * (size_t)np),
-               oY = A.alloc(8 * (size_t)np), oX = A.alloc(8 * (size_t)np), oF = A.alloc(sizeof(int) * (ntiles + 1));
+               oY = A.alloc(8 * (size_t)np), oX = A.alloc(8 * (size_t)np), oF = A.alloc(sizeof(int) * (ntiles + 1 + 2 * nT));
   unsigned char* d = nullptr;
   if (hipMalloc(&d, A.size) != hipSuccess) return OKVIS_BA_HIP_ERROR_BASE + (int)hipGetLastError();
   struct Free { unsigned char* p; ~Free() { if (p) (void)hipFree(p); } } guard{d};
@@ -1788,7 +1788,7 @@ int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* r
   int rc;
   if ((rc = chk(hipMemcpy(d + oT, tiles.data(), 8 * tiles.size(), hipMemcpyHostToDevice)))) return rc;
   if ((rc = chk(hipMemcpy(d + oR, r.data(), 8 * (size_t)np, hipMemcpyHostToDevice)))) return rc;
-  if ((rc = chk(hipMemset(d + oF, 0, sizeof(int) * (ntiles + 1))))) return rc;
+  if ((rc = chk(hipMemset(d + oF, 0, sizeof(int) * (ntiles + 1 + 2 * nT))))) return rc;
   {
     std::vector<unsigned long long> sentinel(np, CT_X_SENTINEL);
     if ((rc = chk(hipMemcpy(d + oX, sentinel.data(), 8 * (size_t)np, hipMemcpyHostToDevice)))) return rc;
@@ -1800,6 +1800,7 @@ int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* r
   C.rhs = reinterpret_cast<double*>(d + oR);
   C.y = reinterpret_cast<double*>(d + oY);
   C.flag = reinterpret_cast<int*>(d + oF);
+  C.pflag = C.flag + ntiles + 1;
   C.x = reinterpret_cast<double*>(d + oX);
   if ((rc = chk(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     CT_SMEM_DOUBLES * 8))))

@@ -42,6 +42,7 @@ struct CholTiles {   // per-window workspace of the tiled solver (device pointer
   double* rhs;       // [48 nT] right-hand side on entry
   double* y;         // [48 nT] L^-1 rhs
   int* flag;         // [nT(nT+1)/2 + 1]: tile done flags; last entry = failure (non-PD pivot / dependency timeout)
+  int* pflag = nullptr;      // [2 nT] "partial ready" flags of the tasks that prepare the chain's inputs: [j] tile (j,j), [nT + j] tile (j+1,j)
   int* progress = nullptr;   // number of diagonal tiles published so far (null: every wait polls its flag from the start)
   double* x = nullptr;   // [48 nT] solution; when set, tasks nT(nT+1)/2 .. + nT - 1 are the back-substitution (below)
   double* tl = nullptr;  // diagnostics: per task 4 wall_clock64() stamps (start, dependencies met, own work done, flag set)
@@ -348,12 +349,116 @@ __device__ void chol_backsub_task(const CholTiles& C, int j, double* lds) {
   }
 }
 
+// ---- the diagonal chain.  ONE workgroup (task 0) walks all diagonal tiles: factor + inverse of tile j in LDS, L_(j+1,j) = C2
+// Linv_j^T and the last update of tile j+1 straight from LDS — the hand-over of Linv_j and L_(j+1,j) between two workgroups
+// through memory is off the serial chain.  What it consumes is prepared by the tasks whose grid slots used to do that work:
+//   task (j,j), j >= 1   publishes  A_jj - sum_(k<j-1) L_jk L_jk^T  (in place) and  rhs_j - sum_(k<j-1) L_jk y_k  (in place)
+//   task (j+1,j)         publishes  A_(j+1,j) - sum_(k<j) L_(j+1,k) L_jk^T  (in place)
+// with "partial ready" flags (C.pflag); the chain overwrites them with L_jj / L_(j+1,j) and raises the ordinary flags.
+__device__ void chol_chain_task(const CholTiles& C, double* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nT = C.nT;
+  double* sA = lds;                       // scratch of the factorisation, then C2_(j+1,j)
+  double* sB = lds + CT_TB * CT_LD;       // Linv_j
+  double* sC = lds + 2 * CT_TB * CT_LD;   // tile j (L_jj after the factorisation)
+  double* sL = lds + 3 * CT_TB * CT_LD;   // L_(j+1,j)
+  __shared__ int s_ok, s_fail;
+  __shared__ double s_r[CT_TB], s_y[CT_TB], s_dinv[CT_TB];
+  int* failflag = C.flag + nT * (nT + 1) / 2;
+  if (tid == 0) {
+    s_ok = 1;
+    s_fail = 0;
+  }
+  ct_v4 acc[3];
+  if (wave < 3) ct_load_acc_g(acc, C.T, wave, lane);
+  if (tid < CT_TB) s_r[tid] = C.rhs[tid];
+  __syncthreads();
+  for (int j = 0; j < nT; ++j) {
+    const int tjj = ct_tile_index(j, j);
+    int task_jj = 0;
+    for (int c = 0; c < j; ++c) task_jj += nT - c;
+    if (C.tl && tid == 0) C.tl[4 * task_jj + 1] = (double)wall_clock64();
+    // ---- factor + inverse of tile j
+    if (wave < 3) ct_store_acc(acc, sC, CT_LD, wave, lane);
+    ct_release();   // (the stores of L_(j,j-1), issued two phases ago, have been performed)
+    __syncthreads();
+    if (tid == 0 && j > 0) ct_raise(C.flag + ct_tile_index(j, j - 1));
+    ct_ldl_inv48(sC, sB, sA, s_dinv, tid, &s_fail);
+    if (C.tl && tid == 0) C.tl[4 * task_jj + 2] = (double)wall_clock64();
+    if (tid < CT_TB) {   // y_j = Linv_j r_j
+      double v = 0;
+      for (int m = 0; m <= tid; ++m) v += sB[tid * CT_LD + m] * s_r[m];
+      s_y[tid] = v;
+    }
+    __syncthreads();
+    const bool more = j + 1 < nT;
+    // ---- wave 3 sends Linv_j and y_j off (write-through stores + drain) while the others wait for / fetch C2_(j+1,j)
+    double* Tsub = C.T + (size_t)ct_tile_index(more ? j + 1 : j, j) * CT_TILE;
+    if (wave == 3) {
+      double* Linv = C.Linv + (size_t)j * CT_TILE;
+      for (int c = lane; c < CT_TILE / 2; c += 64) {
+        const int e = 2 * c;
+        const double* q = sB + (e / CT_TB) * CT_LD + (e % CT_TB);
+        ct_gst2(Linv, c, q[0], q[1]);
+      }
+      if (lane < CT_TB) ct_gst(C.y + CT_TB * j + lane, s_y[lane]);
+      ct_release();
+      if (lane == 0) {
+        if (s_fail) ct_raise(failflag);
+        ct_raise(C.flag + tjj);
+        if (C.progress) ct_raise(C.progress, j + 1);
+        if (C.tl) C.tl[4 * task_jj + 3] = (double)wall_clock64();
+      }
+    } else if (more) {
+      if (tid == 0 && !ct_wait(C.pflag + nT + j)) s_ok = 0;   // C2_(j+1,j) ready (long ago, normally)
+      if (tid == 0) asm volatile("" ::: "memory");
+    }
+    if (!more) break;
+    __syncthreads();
+    if (!s_ok) break;
+    ct_load_tile(Tsub, sA, tid);
+    __syncthreads();
+    // ---- L_(j+1,j) = C2 Linv_j^T: to LDS for the update below, to memory for column j's tiles and the back-substitution
+    //      (its flag is raised at the top of the next round, when the stores have long been performed)
+    if (wave < 3) {
+      ct_v4 l2[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) l2[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
+      ct_gemm_nt(l2, sA, sB, wave, lane, 1.0);
+      ct_store_acc(l2, sL, CT_LD, wave, lane);
+      ct_store_acc_g(l2, Tsub, wave, lane);
+    } else if (tid == 192) {
+      if (!ct_wait(C.pflag + j + 1)) s_ok = 0;   // partial of tile j+1 ready
+    }
+    __syncthreads();
+    if (!s_ok) break;
+    // ---- tile j+1 = its published partial - L L^T;  r_(j+1) = its published partial - L y_j
+    if (wave < 3) {
+      ct_load_acc_g(acc, C.T + (size_t)ct_tile_index(j + 1, j + 1) * CT_TILE, wave, lane);
+      ct_gemm_nt(acc, sL, sL, wave, lane, -1.0);
+    } else if (lane < CT_TB) {
+      double v = ct_gld(C.rhs + CT_TB * (j + 1) + lane);
+      for (int m = 0; m < CT_TB; ++m) v -= sL[lane * CT_LD + m] * s_y[m];
+      s_r[lane] = v;
+    }
+    // (no barrier here: the next round starts with one, after the accumulators have gone to sC)
+  }
+  if (!s_ok && tid == 0) {   // a dependency never came: let everybody run out
+    ct_raise(failflag);
+    for (int t = 0; t < nT * (nT + 1) / 2; ++t) ct_raise(C.flag + t);
+  }
+}
+
 // one workgroup per lower tile, blockIdx.x in column-major task order
 __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nT = C.nT;
   if (task >= nT * (nT + 1) / 2) {   // the back-substitution tasks sit behind the tiles, last tile row first
     chol_backsub_task(C, nT - 1 - (task - nT * (nT + 1) / 2), lds);
+    return;
+  }
+  if (task == 0) {
+    chol_chain_task(C, lds);
     return;
   }
   int j = 0, rem = task;
@@ -364,149 +469,79 @@ __device__ void chol_tile_task(const CholTiles& C, int task, double* lds) {
   const int i = j + rem;
   double* sA = lds;                       // operand / work tiles
   double* sB = lds + CT_TB * CT_LD;
-  double* sC = lds + 2 * CT_TB * CT_LD;
-  __shared__ int s_ok, s_fail;
-  __shared__ double s_r[CT_TB], s_dinv[CT_TB];
+  __shared__ int s_ok;
+  __shared__ double s_r[CT_TB];
   int* failflag = C.flag + nT * (nT + 1) / 2;
-  if (tid == 0) {
-    s_ok = 1;
-    s_fail = 0;
-  }
-  const bool diag = (i == j);
-  // The diagonal task of row j >= 1 also produces the tile left of it, L_(j,j-1): that tile is the last input of the diagonal
-  // tile, so making it here keeps it in LDS and takes one flag + store + load round trip out of the serial chain
-  // diag(j-1) -> L_(j,j-1) -> diag(j).  The grid slot of tile (j, j-1) stays empty.
-  if (i == j + 1) return;
-  const bool merged = diag && j >= 1;
-  const int kend = merged ? j - 1 : j;
+  if (tid == 0) s_ok = 1;
+  const bool diag = (i == j);        // (j >= 1) prepares tile j of the chain: everything but the last update
+  const bool sub = (i == j + 1);     // prepares C2_(j+1,j) for the chain
+  const int kend = diag ? j - 1 : j;
   if (C.tl && tid == 0) C.tl[4 * task] = (double)wall_clock64();
-  ct_v4 acc[3], acc2[3];
+  ct_v4 acc[3];
   double* Tij = C.T + (size_t)ct_tile_index(i, j) * CT_TILE;
-  double* Tsub = merged ? C.T + (size_t)ct_tile_index(j, j - 1) * CT_TILE : nullptr;
-  if (wave < 3) {
-    ct_load_acc_g(acc, Tij, wave, lane);
-    if (merged) ct_load_acc_g(acc2, Tsub, wave, lane);
-  }
+  if (wave < 3) ct_load_acc_g(acc, Tij, wave, lane);
   if (diag && tid < CT_TB) s_r[tid] = C.rhs[CT_TB * j + tid];
   __syncthreads();
   for (int k = 0; k < kend; ++k) {
     if (tid == 0) {
       bool ok = ct_wait_col(C, C.flag + ct_tile_index(i, k), k);
       if (ok && !diag) ok = ct_wait(C.flag + ct_tile_index(j, k));
-      if (ok && merged) ok = ct_wait(C.flag + ct_tile_index(j - 1, k));
       if (!ok) s_ok = 0;
     }
     __syncthreads();
     if (!s_ok) break;
     ct_load_tile(C.T + (size_t)ct_tile_index(i, k) * CT_TILE, sA, tid);
     if (!diag) ct_load_tile(C.T + (size_t)ct_tile_index(j, k) * CT_TILE, sB, tid);
-    if (merged) ct_load_tile(C.T + (size_t)ct_tile_index(j - 1, k) * CT_TILE, sB, tid);
     __syncthreads();
-    if (wave < 3) {
-      ct_gemm_nt(acc, sA, diag ? sA : sB, wave, lane, -1.0);
-      if (merged) ct_gemm_nt(acc2, sA, sB, wave, lane, -1.0);
-    }
+    if (wave < 3) ct_gemm_nt(acc, sA, diag ? sA : sB, wave, lane, -1.0);
     if (diag && tid >= 192 && tid < 192 + CT_TB) {  // forward substitution rides along: r_j -= L_jk y_k
       const int r = tid - 192;
       const double* yk = C.y + CT_TB * k;
-      double s = 0;
-      for (int m = 0; m < CT_TB; ++m) s += sA[r * CT_LD + m] * ct_gld(yk + m);
-      s_r[r] -= s;
+      double v = 0;
+      for (int m = 0; m < CT_TB; ++m) v += sA[r * CT_LD + m] * ct_gld(yk + m);
+      s_r[r] -= v;
     }
     __syncthreads();
-  }
-  if (s_ok && merged) {
-    // L_(j,j-1) = C2 Linv_(j-1)^T as soon as the previous diagonal tile is there, then the last update of this one from LDS
-    if (wave < 3) ct_store_acc(acc2, sA, CT_LD, wave, lane);
-    if (tid == 0 && !ct_wait_col(C, C.flag + ct_tile_index(j - 1, j - 1), j - 1)) s_ok = 0;
-    __syncthreads();
-    if (s_ok) {
-      ct_load_tile(C.Linv + (size_t)(j - 1) * CT_TILE, sB, tid);
-      __syncthreads();
-      if (wave < 3) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc2[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
-        ct_gemm_nt(acc2, sA, sB, wave, lane, 1.0);
-        ct_store_acc_g(acc2, Tsub, wave, lane);   // for the tiles below in column j and the back-substitution (in flight
-        ct_store_acc(acc2, sC, CT_LD, wave, lane);     // while the update below runs)
-      }
-      __syncthreads();
-      if (wave < 3) ct_gemm_nt(acc, sC, sC, wave, lane, -1.0);
-      if (tid >= 192 && tid < 192 + CT_TB) {
-        const int r = tid - 192;
-        const double* yk = C.y + CT_TB * (j - 1);
-        double s = 0;
-        for (int m = 0; m < CT_TB; ++m) s += sC[r * CT_LD + m] * ct_gld(yk + m);
-        s_r[r] -= s;
-      }
-      ct_release();
-      __syncthreads();   // (sC is overwritten next)
-      if (tid == 0) ct_raise(C.flag + ct_tile_index(j, j - 1));
-    }
   }
   if (!s_ok) {
     if (tid == 0) {
       ct_raise(failflag);
-      ct_raise(C.flag + ct_tile_index(i, j));  // let the dependants run out
-      if (merged) ct_raise(C.flag + ct_tile_index(j, j - 1));
+      if (diag) ct_raise(C.pflag + j);          // let the dependants run out
+      else if (sub) ct_raise(C.pflag + nT + j);
+      else ct_raise(C.flag + ct_tile_index(i, j));
     }
     return;
   }
-  if (diag) {
-    if (C.tl && tid == 0) C.tl[4 * task + 1] = (double)wall_clock64();
-    if (wave < 3) ct_store_acc(acc, sC, CT_LD, wave, lane);
-    __syncthreads();
-    ct_ldl_inv48(sC, sB, sA, s_dinv, tid, &s_fail);   // (sA is free here: the tile's inputs have been consumed)
-    if (C.tl && tid == 0) C.tl[4 * task + 2] = (double)wall_clock64();
-    // publish Linv_j and y_j = Linv_j r_j: what the rest of the solve reads (column j's TRSMs, the next diagonal tile, the
-    // back-substitution).  L_jj itself (lower, zeros above) is stored afterwards, off the chain: no task reads it.
-    double* Linv = C.Linv + (size_t)j * CT_TILE;
-    for (int c = tid; c < CT_TILE / 2; c += CT_THREADS) {
-      const int e = 2 * c;
-      const double* q = sB + (e / CT_TB) * CT_LD + (e % CT_TB);
-      ct_gst2(Linv, c, q[0], q[1]);
-    }
-    if (tid < CT_TB) {
-      double s = 0;
-      for (int m = 0; m <= tid; ++m) s += sB[tid * CT_LD + m] * s_r[m];
-      ct_gst(C.y + CT_TB * j + tid, s);
-    }
-    if (tid == 0 && s_fail) ct_raise(failflag);
+  if (diag || sub) {
+    // hand the partial to the chain workgroup (in place)
+    if (wave < 3) ct_store_acc_g(acc, Tij, wave, lane);
+    if (diag && tid < CT_TB) ct_gst(C.rhs + CT_TB * j + tid, s_r[tid]);
     ct_release();
     __syncthreads();
-    if (tid == 0) {
-      ct_raise(C.flag + ct_tile_index(i, j));
-      if (C.progress) ct_raise(C.progress, j + 1);
-    }
-    if (C.tl && tid == 0) C.tl[4 * task + 3] = (double)wall_clock64();
-    for (int e = tid; e < CT_TILE; e += CT_THREADS) {
-      const int r = e / CT_TB, c = e - r * CT_TB;
-      Tij[e] = (c <= r) ? sC[r * CT_LD + c] : 0.0;
-    }
+    if (tid == 0) ct_raise(C.pflag + (diag ? j : nT + j));
     return;
-  } else {
-    // L_ij = C Linv_j^T
-    if (wave < 3) ct_store_acc(acc, sA, CT_LD, wave, lane);
-    if (tid == 0 && !ct_wait_col(C, C.flag + ct_tile_index(j, j), j)) s_ok = 0;
-    if (C.tl && tid == 0) C.tl[4 * task + 1] = (double)wall_clock64();
-    __syncthreads();
-    ct_load_tile(C.Linv + (size_t)j * CT_TILE, sB, tid);
-    __syncthreads();
-    if (wave < 3) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) acc[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
-      ct_gemm_nt(acc, sA, sB, wave, lane, 1.0);
-      ct_store_acc_g(acc, Tij, wave, lane);
-    }
-    if (tid == 0 && !s_ok) ct_raise(failflag);
   }
+  // L_ij = C Linv_j^T
+  if (wave < 3) ct_store_acc(acc, sA, CT_LD, wave, lane);
+  if (tid == 0 && !ct_wait_col(C, C.flag + ct_tile_index(j, j), j)) s_ok = 0;
+  if (C.tl && tid == 0) C.tl[4 * task + 1] = (double)wall_clock64();
+  __syncthreads();
+  ct_load_tile(C.Linv + (size_t)j * CT_TILE, sB, tid);
+  __syncthreads();
+  if (wave < 3) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
+    ct_gemm_nt(acc, sA, sB, wave, lane, 1.0);
+    ct_store_acc_g(acc, Tij, wave, lane);
+  }
+  if (tid == 0 && !s_ok) ct_raise(failflag);
   ct_release();
   __syncthreads();
   if (tid == 0) ct_raise(C.flag + ct_tile_index(i, j));
   if (C.tl && tid == 0) C.tl[4 * task + 3] = (double)wall_clock64();
 }
 
-constexpr int CT_SMEM_DOUBLES = 3 * CT_TB * CT_LD;
+constexpr int CT_SMEM_DOUBLES = 4 * CT_TB * CT_LD;   // (the chain workgroup keeps four tiles)
 
 // stand-alone solve of one dense SPD system (tests / diagnostics): grid.x = number of lower tiles + nT
 __global__ __launch_bounds__(CT_THREADS) void chol_tile_kernel(CholTiles C) {

@@ -1180,6 +1180,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     for (int i = tid; i < ntile + 1; i += SOLVE_THREADS) Wl.ct_flag[i] = 0;
     if (tid == 0) Wl.ct_flag[ntile + 3] = 0;   // progress counter of the tiled factorisation
+    for (int i = tid; i < 2 * nT; i += SOLVE_THREADS) Wl.ct_flag[ntile + 4 + i] = 0;   // "partial ready" flags
     for (int i = tid; i < nT * CT_TB; i += SOLVE_THREADS)
       reinterpret_cast<unsigned long long*>(Wl.ct_x)[i] = CT_X_SENTINEL;   // no value yet (chol_backsub_task polls the values)
     __syncthreads();
@@ -1350,6 +1351,7 @@ __global__ __launch_bounds__(CT_THREADS) void chol_tiles_window_kernel(const Win
   C.y = W.ct_y;
   C.flag = W.ct_flag;
   C.progress = W.ct_flag + ntile + 3;
+  C.pflag = W.ct_flag + ntile + 4;
   C.x = W.ct_x;
   C.tl = (W.prof && blockIdx.y == 0) ? W.prof + 64 : nullptr;   // diagnostics (debug_arrays): task timeline behind the phase stamps
   chol_tile_task(C, blockIdx.x, ct_smem);

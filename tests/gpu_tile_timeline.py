@@ -11,7 +11,7 @@ b = solver.WindowBatch([w], options=opt)
 b.begin(); b.iterate(4); b.synchronize()
 p = b.array("PROF")[64:].reshape(-1, 4) / 100.0   # us
 nT = 16
-t0 = p[0, 0]
+t0 = p[0, 1]
 idx = lambda i, j: sum(nT - c for c in range(j)) + (i - j)
 print("diag tile j: start | deps met (last update applied) | factor+inverse done | published     [us from kernel start]")
 prev = 0
