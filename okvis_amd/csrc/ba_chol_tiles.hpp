@@ -362,12 +362,13 @@ __device__ void chol_chain_task(const CholTiles& C, double* lds) {
   double* sB = lds + CT_TB * CT_LD;       // Linv_j
   double* sC = lds + 2 * CT_TB * CT_LD;   // tile j (L_jj after the factorisation)
   double* sL = lds + 3 * CT_TB * CT_LD;   // L_(j+1,j)
-  __shared__ int s_ok, s_fail;
+  __shared__ int s_ok, s_fail, s_c2;
   __shared__ double s_r[CT_TB], s_y[CT_TB], s_dinv[CT_TB];
   int* failflag = C.flag + nT * (nT + 1) / 2;
   if (tid == 0) {
     s_ok = 1;
     s_fail = 0;
+    s_c2 = 0;
   }
   ct_v4 acc[3];
   if (wave < 3) ct_load_acc_g(acc, C.T, wave, lane);
@@ -410,14 +411,26 @@ __device__ void chol_chain_task(const CholTiles& C, double* lds) {
         if (C.tl) C.tl[4 * task_jj + 3] = (double)wall_clock64();
       }
     } else if (more) {
-      if (tid == 0 && !ct_wait(C.pflag + nT + j)) s_ok = 0;   // C2_(j+1,j) ready (long ago, normally)
-      if (tid == 0) asm volatile("" ::: "memory");
+      // waves 0 - 2 fetch C2_(j+1,j) meanwhile; they follow work-item 0's poll through an LDS word, not through a barrier (which
+      // would wait for the publishing wave)
+      if (tid == 0) {
+        const bool ok = ct_wait(C.pflag + nT + j);   // C2_(j+1,j) ready (long ago, normally)
+        if (!ok) s_ok = 0;
+        __hip_atomic_store(&s_c2, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      while (__hip_atomic_load(&s_c2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1) __builtin_amdgcn_s_sleep(1);
+      if (s_ok)
+        for (int c = tid; c < CT_TILE / 2; c += 192) {
+          const ct_v2 v = ct_gld2(Tsub, c);
+          const int e = 2 * c;
+          double* d = sA + (e / CT_TB) * CT_LD + (e % CT_TB);
+          d[0] = v[0];
+          d[1] = v[1];
+        }
     }
     if (!more) break;
     __syncthreads();
     if (!s_ok) break;
-    ct_load_tile(Tsub, sA, tid);
-    __syncthreads();
     // ---- L_(j+1,j) = C2 Linv_j^T: to LDS for the update below, to memory for column j's tiles and the back-substitution
     //      (its flag is raised at the top of the next round, when the stores have long been performed)
     if (wave < 3) {
