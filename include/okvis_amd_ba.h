@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OKVIS_BA_ABI_VERSION 4
+#define OKVIS_BA_ABI_VERSION 5
 
 /* status codes (0 ok; >0 = hipError_t passthrough + 1000; <0 = argument / state errors) */
 #define OKVIS_BA_OK 0
@@ -257,6 +257,70 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
  * any numeric work.  stats[8] = {D, Dp, n_pair, n_group, n_chunk, n_task, gpart doubles, arena bytes}.
  * opt may be NULL (defaults). */
 int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt, int64_t* stats);
+/* ---- incremental structure updates ---------------------------------------------------------------------
+ * The reference edits its problem in O(1) per block: Map::addParameterBlock / addResidualBlock / removeResidualBlock /
+ * removeParameterBlock (Map.cpp:292-565), driven by Estimator::addStates / addLandmark / addObservation / removeObservation /
+ * applyMarginalizationStrategy (Estimator.cpp:110-365, 368-413, 434-773).  An okvis_ba_patch is one batch of such edits to a
+ * window, applied in this order:
+ *   1. removals, by index into the window as it stands (every list strictly ascending).  Removing a parameter block removes the
+ *      terms attached to it, like Map::removeParameterBlock (Map.cpp:352-379): observations of a removed landmark / pose /
+ *      extrinsics block, IMU terms and pose / speed-bias / relative-pose priors on a removed block.  The dense marginalisation
+ *      prior cannot lose one of its blocks: replace it in the same patch (OKVIS_BA_PATCH_MARG_PRIOR), else OKVIS_BA_ERR_ARG;
+ *   2. what is left is renumbered by stable compaction (relative order kept);
+ *   3. appended blocks take the next indices; appended terms and replaced prior families are given in the NEW numbering;
+ *      observations stay sorted by (lm, pose, cam): appended ones are merged in, behind equal keys;
+ *   4. sparse value updates (new numbering), e.g. re-triangulated landmarks (Estimator::setLandmark).
+ * A patch is checked completely before anything changes: on an error the window is untouched. */
+#define OKVIS_BA_PATCH_POSE_PRIORS 1 /* bits of okvis_ba_patch::replace: the family is replaced wholesale by the patch's arrays */
+#define OKVIS_BA_PATCH_SB_PRIORS 2
+#define OKVIS_BA_PATCH_RELPOSE 4
+#define OKVIS_BA_PATCH_MARG_PRIOR 8
+typedef struct okvis_ba_patch {
+  int32_t n_remove_obs;  const int32_t* remove_obs;
+  int32_t n_remove_lm;   const int32_t* remove_lm;
+  int32_t n_remove_pose; const int32_t* remove_pose;
+  int32_t n_remove_sb;   const int32_t* remove_sb;
+  int32_t n_remove_imu;  const int32_t* remove_imu;
+  int32_t n_add_pose; const double* add_pose; /* [n_add_pose][7] */ const uint8_t* add_pose_fixed;
+  int32_t n_add_sb;   const double* add_sb;   /* [n_add_sb][9]   */ const uint8_t* add_sb_fixed;
+  int32_t n_add_lm;   const double* add_lm;   /* [n_add_lm][4]   */
+  int32_t n_add_obs;  /* arrays as okvis_ba_window::obs_*, any order */
+  const int32_t* add_obs_lm; const int32_t* add_obs_pose; const int32_t* add_obs_ext; const int32_t* add_obs_cam;
+  const double* add_obs_uv; const double* add_obs_sqrtw;
+  int32_t n_add_imu;  /* arrays as okvis_ba_window::imu_*; add_imu_s_begin indexes the patch's own sample arrays */
+  const int32_t* add_imu_pose0; const int32_t* add_imu_sb0; const int32_t* add_imu_pose1; const int32_t* add_imu_sb1;
+  const int64_t* add_imu_t0; const int64_t* add_imu_t1; const int32_t* add_imu_s_begin; const int32_t* add_imu_s_count;
+  int32_t n_add_imu_samples;
+  const int64_t* add_imu_s_t; const double* add_imu_s_gyr; const double* add_imu_s_acc;
+  int32_t replace;    /* OKVIS_BA_PATCH_* bits; the arrays below are read only for the families named here */
+  int32_t n_pprior;  const int32_t* pprior_pose; const double* pprior_meas; const double* pprior_sqrtinfo;
+  int32_t n_sbprior; const int32_t* sbprior_sb;  const double* sbprior_meas; const double* sbprior_sqrtinfo;
+  int32_t n_relpose; const int32_t* rel_pose0; const int32_t* rel_pose1; const double* rel_sqrtinfo;
+  int32_t marg_dim; int32_t marg_nblocks; const int32_t* marg_block_type; const int32_t* marg_block_idx; const int32_t* marg_block_off;
+  const double* marg_J; const double* marg_e0; const double* marg_lin;
+  int32_t n_set_pose; const int32_t* set_pose_idx; const double* set_pose; /* [n_set_pose][7] */
+  int32_t n_set_sb;   const int32_t* set_sb_idx;   const double* set_sb;   /* [n_set_sb][9]   */
+  int32_t n_set_lm;   const int32_t* set_lm_idx;   const double* set_lm;   /* [n_set_lm][4]   */
+} okvis_ba_patch;
+
+/* Host-side window container with these edits (no device needed): create = deep copy of a window, patch = the edit above,
+ * view = the window as okvis_ba_upload takes it (pointers valid until the next patch / destroy of this store). */
+typedef struct okvis_ba_window_store okvis_ba_window_store;
+int okvis_ba_store_create(const okvis_ba_window* w, okvis_ba_window_store** out);
+int okvis_ba_store_patch(okvis_ba_window_store* st, const okvis_ba_patch* p);
+int okvis_ba_store_view(const okvis_ba_window_store* st, okvis_ba_window* out);
+void okvis_ba_store_destroy(okvis_ba_window_store* st);
+
+/* A patchable solver keeps such a container of every window it uploads (set before okvis_ba_upload; default off: no copy).
+ * okvis_ba_patch_window edits window w in place of a re-flatten + re-upload by the caller: the blocks that stay keep the values the
+ * DEVICE holds (the accepted state of the last optimisation, the bias every IMU term's preintegration was last built at), the
+ * index is rebuilt and the arena re-filled from the container.  Results are bit-identical to uploading okvis_ba_store_view of
+ * the same edits with those values.  OKVIS_BA_ERR_STATE: solver not patchable or nothing uploaded. */
+int okvis_ba_set_patchable(okvis_ba_solver* s, int on);
+int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p);
+/* the container of window w of a patchable solver as it stands (pointers valid until the next upload / patch) */
+int okvis_ba_patched_view(okvis_ba_solver* s, int w, okvis_ba_window* out);
+
 /* overwrite only block VALUES of window w (Estimator::set_T_WS/setSpeedAndBias/setLandmark,
  * Estimator.cpp:1205-1302); any pointer may be NULL to keep the device copy. */
 int okvis_ba_set_state(okvis_ba_solver* s, int w, const double* pose, const double* sb, const double* lm);
@@ -331,8 +395,10 @@ int okvis_ba_synchronize(okvis_ba_solver* s);
  * preconditioned pseudo-inverse), then the flagged pose-type / speed-bias blocks (dense path, :686-739), and
  * the remaining system is turned into the error-term form J, e0 (:806-846).  The previous prior enters as
  * (H, b0) over blocks of this window (the reference keeps H_ and b0_ inside the object).  The window itself
- * must not carry a marg_* prior.  Reduced dimension of the window <= OKVIS_BA_MARG_MAX_WINDOW_DIM. */
-#define OKVIS_BA_MARG_MAX_WINDOW_DIM 174
+ * must not carry a marg_* prior.  Reduced dimension of the window <= OKVIS_BA_MARG_MAX_WINDOW_DIM (= okvis_ba_limits::
+ * max_reduced_dim) and previous prior <= okvis_ba_limits::max_marg_dim rows; sub-windows of up to 174 reduced dimensions with
+ * a prior of up to 192 rows take the path whose matrices stay in LDS, larger ones the same arithmetic in an HBM workspace. */
+#define OKVIS_BA_MARG_MAX_WINDOW_DIM 900
 typedef struct okvis_ba_marg_spec {
   const uint8_t* pose_marg;          /* [n_pose] 1 = eliminate this (free) pose-type block */
   const uint8_t* sb_marg;            /* [n_sb]   1 = eliminate this (free) speed/bias block */

@@ -4,7 +4,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .window import LimitsC, MargResultC, MargSpecC, OptionsC, SummaryC, WindowC
+from .window import LimitsC, MargResultC, MargSpecC, OptionsC, PatchC, SummaryC, WindowC
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libokvis_amd_ba.so")
@@ -17,6 +17,8 @@ SYMBOLS = [
     "okvis_ba_evaluate_cost", "okvis_ba_get_state", "okvis_ba_fetch_results", "okvis_ba_array_size", "okvis_ba_download",
     "okvis_ba_reduced_dim", "okvis_ba_pair_count", "okvis_ba_pairs", "okvis_ba_last_iterate_ms",
     "okvis_ba_profile_iterations", "okvis_ba_profile_launches", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize", "okvis_ba_marginalize",
+    "okvis_ba_store_create", "okvis_ba_store_patch", "okvis_ba_store_view", "okvis_ba_store_destroy", "okvis_ba_set_patchable",
+    "okvis_ba_patch_window", "okvis_ba_patched_view",
     "okvis_ba_dense_solve", "okvis_ba_shard", "okvis_ba_batch_run", "okvis_ba_gather_records", "okvis_ba_batch_run_gathered",
 ]
 
@@ -51,6 +53,14 @@ def lib():
     L.okvis_ba_destroy.argtypes = [vp]
     L.okvis_ba_upload.argtypes = [vp, C.c_int, C.POINTER(WindowC)]
     L.okvis_ba_set_state.argtypes = [vp, C.c_int, _dp, _dp, _dp]
+    L.okvis_ba_store_create.argtypes = [C.POINTER(WindowC), C.POINTER(vp)]
+    L.okvis_ba_store_patch.argtypes = [vp, C.POINTER(PatchC)]
+    L.okvis_ba_store_view.argtypes = [vp, C.POINTER(WindowC)]
+    L.okvis_ba_store_destroy.argtypes = [vp]
+    L.okvis_ba_store_destroy.restype = None
+    L.okvis_ba_set_patchable.argtypes = [vp, C.c_int]
+    L.okvis_ba_patch_window.argtypes = [vp, C.c_int, C.POINTER(PatchC)]
+    L.okvis_ba_patched_view.argtypes = [vp, C.c_int, C.POINTER(WindowC)]
     L.okvis_ba_check_window.argtypes = [C.POINTER(WindowC), C.POINTER(OptionsC), C.POINTER(C.c_int64)]
     L.okvis_ba_get_state.argtypes = [vp, C.c_int, _dp, _dp, _dp]
     L.okvis_ba_fetch_results.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _dp]

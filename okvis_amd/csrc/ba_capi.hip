@@ -21,6 +21,7 @@
 #include "ba_marg.hpp"
 #include "ba_schur.hpp"
 #include "ba_solve.hpp"
+#include "ba_store.hpp"
 
 using namespace ba;
 
@@ -125,6 +126,14 @@ struct okvis_ba_solver {
   unsigned char* h_ctrl_stage = nullptr;   // pinned / device staging of per-window control data (begin, fetch_ctrl)
   unsigned char* d_ctrl_stage = nullptr;
   size_t ctrl_stage_bytes = 0;
+  // incremental structure updates (okvis_ba_patch_window): the container of every uploaded window, kept only on request
+  bool patchable = false;
+  std::vector<WindowStore> mirrors;
+  bool evaluated = false;      // okvis_ba_begin ran since the last upload: every IMU term's cache has been (re)built
+  bool mirror_fresh = false;   // the containers hold the values the device holds (nothing optimised / set since)
+  bool res_staged = false;  // stage_res holds window 0's packed results as of the last okvis_ba_finish (single-window solvers)
+  StageVec stage_res;
+  StageVec stage_marg;           // host-written part of okvis_ba_marginalize's scratch block
   bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0, max_spart_stride = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
@@ -1085,8 +1094,11 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_tiles_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             CT_SMEM_DOUBLES * 8);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&marg_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            MARG_LDS_DOUBLES * 8);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&marg_dense_kernel<MAX_D_LDS, MARG_SMALL_PRIOR>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, MARG_LDS_DOUBLES * 8);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&marg_dense_kernel<MAX_D, MAX_MARG_DIM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, MARG_LDS_DOUBLES_LARGE * 8);
 
   if (e != hipSuccess) {
     int code = OKVIS_BA_HIP_ERROR_BASE + (int)e;
@@ -1138,8 +1150,32 @@ int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt) {
   return OKVIS_BA_OK;
 }
 
+static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows);
+
 int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows) {
   if (!s || n_windows <= 0 || !windows) return OKVIS_BA_ERR_ARG;
+  const int rc = upload_impl(s, n_windows, windows);
+  s->mirror_fresh = false;
+  if (rc != OKVIS_BA_OK || !s->patchable) {
+    s->mirrors.clear();
+    return rc;
+  }
+  try {   // a patchable solver keeps what it was given (ba_store.hpp)
+    s->mirrors.resize((size_t)n_windows);
+    for (int i = 0; i < n_windows; ++i)
+      if (int rs = s->mirrors[i].assign(windows[i])) {
+        s->mirrors.clear();
+        return rs;
+      }
+  } catch (const std::bad_alloc&) {
+    s->mirrors.clear();
+    return OKVIS_BA_ERR_ARG;
+  }
+  s->mirror_fresh = true;
+  return OKVIS_BA_OK;
+}
+
+static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows) {
   const auto t_enter = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1264,6 +1300,8 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     }
   }
   s->uploaded = true;
+  s->evaluated = false;
+  s->res_staged = false;
   s->acc_fresh = true;   // Ctrl starts zeroed: accepted buffer 0, like HostWin::acc
   if (dbg_t) {
     const auto t_u2 = std::chrono::steady_clock::now();
@@ -1301,6 +1339,7 @@ int okvis_ba_set_state(okvis_ba_solver* s, int w, const double* pose, const doub
   if (lm) HIP_TRY(hipMemcpyAsync(H.ptrs.lm[H.acc], lm, 32 * (size_t)H.n_lm, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->begun = false;
+  s->res_staged = s->mirror_fresh = false;
   return OKVIS_BA_OK;
 }
 
@@ -1316,11 +1355,81 @@ int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, doub
   return OKVIS_BA_OK;
 }
 
+// the packed results of window w (pose | speed/bias | landmarks | quality | IMU reference biases) in page-locked host memory
+static int stage_results(okvis_ba_solver* s, int w, const unsigned char** rec) {
+  HostWin& H = s->wins[w];
+  *rec = nullptr;
+  const size_t total = 56 * (size_t)H.n_pose + 72 * (size_t)H.n_sb + 40 * (size_t)H.n_lm + 72 * (size_t)H.n_imu;
+  if (total == 0) return OKVIS_BA_OK;
+  if (s->res_staged && w == 0 && s->wins.size() == 1) {   // packed and copied by okvis_ba_finish already
+    *rec = s->stage_res.data();
+    return OKVIS_BA_OK;
+  }
+  if (int rc = refresh_acc(s, w)) return rc;
+  s->stage_dl.resize(total);
+  hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s->stream, s->d_wins + w, H.acc);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->stage_dl.data(), H.ptrs.results, total, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *rec = s->stage_dl.data();
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_set_patchable(okvis_ba_solver* s, int on) {
+  if (!s) return OKVIS_BA_ERR_ARG;
+  s->patchable = on != 0;
+  if (!s->patchable) s->mirrors.clear();
+  return OKVIS_BA_OK;
+}
+
+// the containers take over the values the device holds
+static int refresh_mirrors(okvis_ba_solver* s) {
+  if (s->mirror_fresh) return OKVIS_BA_OK;
+  for (size_t i = 0; i < s->wins.size(); ++i) {
+    const unsigned char* rec = nullptr;
+    if (int rc = stage_results(s, (int)i, &rec)) return rc;
+    if (rec) s->mirrors[i].take_results(rec, s->evaluated);
+  }
+  s->mirror_fresh = true;
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p) {
+  if (!s || !p) return OKVIS_BA_ERR_ARG;
+  if (!s->patchable || !s->uploaded || s->mirrors.size() != s->wins.size()) return OKVIS_BA_ERR_STATE;
+  if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = refresh_mirrors(s)) return rc;
+  try {
+    if (int rc = s->mirrors[w].apply(*p)) return rc;   // (checked completely before anything changes)
+    std::vector<okvis_ba_window> views(s->mirrors.size());
+    for (size_t i = 0; i < views.size(); ++i) s->mirrors[i].view(&views[i]);
+    // same index build and arena fill as okvis_ba_upload.  If the edited window now exceeds a structure limit the status of
+    // that check is returned, the container keeps the edit and the solver is left without an uploaded batch.
+    const int rc = upload_impl(s, (int)views.size(), views.data());
+    s->mirror_fresh = rc == OKVIS_BA_OK;
+    return rc;
+  } catch (const std::bad_alloc&) {
+    return OKVIS_BA_ERR_ARG;
+  }
+}
+
+int okvis_ba_patched_view(okvis_ba_solver* s, int w, okvis_ba_window* out) {
+  if (!s || !out) return OKVIS_BA_ERR_ARG;
+  if (!s->patchable || s->mirrors.size() != s->wins.size() || s->mirrors.empty()) return OKVIS_BA_ERR_STATE;
+  if (w < 0 || w >= (int)s->mirrors.size()) return OKVIS_BA_ERR_ARG;
+  if (s->uploaded) {
+    HIP_TRY(hipSetDevice(s->device));
+    if (int rc = refresh_mirrors(s)) return rc;
+  }
+  s->mirrors[w].view(out);
+  return OKVIS_BA_OK;
+}
+
 int okvis_ba_fetch_results(okvis_ba_solver* s, int w, double* pose, double* sb, double* lm, double* lm_quality,
                            double* imu_sb_ref) {
   if (!s || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return s && !s->uploaded ? OKVIS_BA_ERR_STATE : OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
-  if (int rc = refresh_acc(s, w)) return rc;
   HostWin& H = s->wins[w];
   // everything is gathered on the device into one contiguous record (pose | speed/bias | landmarks | quality | IMU reference
   // biases): one small kernel + ONE copy into page-locked staging instead of five copies (each costs ~15 us of its own)
@@ -1328,12 +1437,8 @@ int okvis_ba_fetch_results(okvis_ba_solver* s, int w, double* pose, double* sb, 
   const size_t b_q = 8 * (size_t)H.n_lm, b_ref = 72 * (size_t)H.n_imu;
   const size_t o_sb = b_pose, o_lm = o_sb + b_sb, o_q = o_lm + b_lm, o_ref = o_q + b_q, total = o_ref + b_ref;
   if (total == 0) return OKVIS_BA_OK;
-  s->stage_dl.resize(total);
-  unsigned char* st = s->stage_dl.data();
-  hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s->stream, s->d_wins + w, H.acc);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(st, H.ptrs.results, total, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  const unsigned char* st = nullptr;
+  if (int rc = stage_results(s, w, &st)) return rc;
   if (pose && b_pose) std::memcpy(pose, st, b_pose);
   if (sb && b_sb) std::memcpy(sb, st + o_sb, b_sb);
   if (lm && b_lm) std::memcpy(lm, st + o_lm, b_lm);
@@ -1343,7 +1448,7 @@ int okvis_ba_fetch_results(okvis_ba_solver* s, int w, double* pose, double* sb, 
 }
 
 int okvis_ba_begin(okvis_ba_solver* s) {
-  if (s) s->acc_fresh = false;
+  if (s) s->acc_fresh = s->res_staged = s->mirror_fresh = false;
   if (!s) return OKVIS_BA_ERR_ARG;
   if (!s->uploaded) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
@@ -1360,6 +1465,7 @@ int okvis_ba_begin(okvis_ba_solver* s) {
   }
   HIP_TRY(launch_lin(s, whole(s), 1));
   s->begun = true;
+  s->evaluated = true;
   return OKVIS_BA_OK;
 }
 
@@ -1474,9 +1580,23 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
     hipLaunchKernelGGL(quality_kernel, dim3((s->max_lm + 255) / 256, (unsigned)s->wins.size()), dim3(256), 0, s->stream, s->d_wins);
     HIP_TRY(hipGetLastError());
   }
+  // a solver with one window (the estimator's case): its packed results ride on the same synchronisation as the control record,
+  // okvis_ba_fetch_results then costs no launch, no copy and no synchronisation of its own
+  size_t res_bytes = 0;
+  if (s->wins.size() == 1) {
+    const HostWin& H0 = s->wins[0];
+    res_bytes = 56 * (size_t)H0.n_pose + 72 * (size_t)H0.n_sb + 40 * (size_t)H0.n_lm + 72 * (size_t)H0.n_imu;
+    if (res_bytes) {
+      s->stage_res.resize(res_bytes);
+      hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s->stream, s->d_wins, -1);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(s->stage_res.data(), H0.ptrs.results, res_bytes, hipMemcpyDeviceToHost, s->stream));
+    }
+  }
   std::vector<Ctrl> cs;
   int rc = fetch_ctrl(s, cs);
   if (rc != OKVIS_BA_OK) return rc;
+  s->res_staged = res_bytes > 0;
   for (size_t i = 0; i < s->wins.size(); ++i) {
     s->wins[i].acc = cs[i].acc;
     if (summaries) {
@@ -1827,7 +1947,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
   HostWin& H = s->wins[w];
   if (H.marg_dim != 0) return OKVIS_BA_ERR_ARG;                    // the previous prior comes in through spec
-  if (H.D > MAX_D_LDS || H.ptrs.Sg != nullptr) return OKVIS_BA_ERR_UNSUPPORTED;
+  const bool large_window = H.ptrs.Sg != nullptr;   // reduced system assembled in HBM (D > MAX_D_LDS)
   if ((H.n_pose > 0 && !spec->pose_marg) || (H.n_sb > 0 && !spec->sb_marg)) return OKVIS_BA_ERR_ARG;
   const int pd = spec->prior_dim, pnb = spec->prior_nblocks;
   if (pd < 0 || pnb < 0 || pd > MAX_MARG_DIM) return pd > MAX_MARG_DIM ? OKVIS_BA_ERR_UNSUPPORTED : OKVIS_BA_ERR_ARG;
@@ -1873,14 +1993,18 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   const size_t o_pt = A.alloc(sizeof(int) * std::max(1, pnb)), o_pi = A.alloc(sizeof(int) * std::max(1, pnb)),
                o_po = A.alloc(sizeof(int) * std::max(1, pnb));
   const size_t o_pH = A.alloc(8 * std::max<size_t>(1, (size_t)pd * pd)), o_pb = A.alloc(8 * std::max(1, pd));
-  const size_t host_part = A.size;
-  const size_t o_work = A.alloc(8 * (3 * std::max<size_t>(1, (size_t)D * D) + 6 * ((size_t)D + 6)));
+  const size_t o_win = A.alloc(sizeof(WinPtrs)), o_opt = A.alloc(sizeof(OptD));
+  const size_t host_part = A.size;   // everything up to here is written by the host: ONE copy
+  const size_t o_work = A.alloc(8 * marg_work_doubles(std::max(1, D)));
   const size_t o_S = A.alloc(8 * std::max<size_t>(1, (size_t)D * D)), o_rhs = A.alloc(8 * std::max(1, D)),
                o_d2 = A.alloc(8 * std::max(1, D));
-  const size_t o_out = A.alloc(8 * (2 * std::max<size_t>(1, (size_t)na * na) + 2 * std::max(1, na)));
-  const size_t o_info = A.alloc(sizeof(int) * (8 + std::max(1, D)));
-  const size_t o_win = A.alloc(sizeof(WinPtrs));
-  std::vector<unsigned char> hb(host_part, 0);
+  // H | J | b0 | e0 | info: contiguous, ONE copy back
+  const size_t nn = std::max<size_t>(1, (size_t)na * na), n1 = std::max(1, na);
+  const size_t out_bytes = 8 * (2 * nn + 2 * n1);
+  const size_t o_out = A.alloc(out_bytes + sizeof(int) * (8 + std::max(1, D)));
+  const size_t o_info = o_out + out_bytes;
+  s->stage_marg.resize(host_part);   // page-locked: the one upload of this call is a true asynchronous copy
+  unsigned char* const hb = s->stage_marg.data();
   if (H.n_pose) std::memcpy(&hb[o_pm], spec->pose_marg, H.n_pose);
   if (H.n_sb) std::memcpy(&hb[o_sm], spec->sb_marg, H.n_sb);
   if (pd > 0) {
@@ -1898,35 +2022,37 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
     s->marg_scratch_bytes = A.size;
   }
   unsigned char* d = s->marg_scratch;
-  HIP_TRY(hipMemcpyAsync(d, hb.data(), host_part, hipMemcpyHostToDevice, s->stream));
   WinPtrs P = H.ptrs;   // this window with the export buffers attached
   P.S = (decltype(P.S))(d + o_S);
   P.rhs = (decltype(P.rhs))(d + o_rhs);
   P.Dp2 = (decltype(P.Dp2))(d + o_d2);
   P.grad = nullptr;
-  HIP_TRY(hipMemcpyAsync(d + o_win, &P, sizeof(P), hipMemcpyHostToDevice, s->stream));
+  std::memcpy(&hb[o_win], &P, sizeof(P));
   const WinPtrs* d_win = reinterpret_cast<const WinPtrs*>(d + o_win);
-
-  // ---- linearise + landmark elimination + export ----
+  // the marginalisation pass has its own option record in the scratch block (no trust region: one linearisation, no damping);
+  // the launches below read it through s->d_opt, which points there for the duration of this call.  The solver's own record is
+  // never touched, so nothing has to be restored on the device and captured launch graphs stay valid.
   OptD od = make_optd(s->opt, (int)s->wins.size());
   od.marg_mode = 1;
-  od.dogleg = 0;   // no trust region in the marginalisation pass: one linearisation, no damping
-  HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
-  struct RestoreOptions {   // whatever happens below, the device copy of the options leaves the marginalisation mode again
+  od.dogleg = 0;
+  std::memcpy(&hb[o_opt], &od, sizeof(od));
+  HIP_TRY(hipMemcpyAsync(d, hb, host_part, hipMemcpyHostToDevice, s->stream));
+  struct SwapOptions {
     okvis_ba_solver* s;
-    bool armed = true;
-    ~RestoreOptions() {
-      if (!armed) return;
-      const OptD o = make_optd(s->opt, (int)s->wins.size());
-      if (hipMemcpyAsync(s->d_opt, &o, sizeof(o), hipMemcpyHostToDevice, s->stream) == hipSuccess) (void)hipStreamSynchronize(s->stream);
-    }
-  } restore_options{s};
+    OptD* saved;
+    ~SwapOptions() { s->d_opt = saved; }
+  } swap_options{s, s->d_opt};
+  s->d_opt = reinterpret_cast<OptD*>(d + o_opt);
+
+  // ---- linearise + landmark elimination + export ----
   int rc = okvis_ba_begin(s);
   if (rc != OKVIS_BA_OK) return rc;
   s->begun = false;
   const Sub one{s->stream, w, 1};
   HIP_TRY(launch_schur(s, one));
-  if (s->group_chunks)
+  if (large_window)
+    hipLaunchKernelGGL((solve_kernel<true, false>), dim3(1), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), s->stream, d_win, s->d_opt, 2);
+  else if (s->group_chunks)
     hipLaunchKernelGGL((solve_kernel<false, true>), dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream,
                        d_win, s->d_opt, 2);
   else
@@ -1945,24 +2071,22 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   ma.prior_b0 = reinterpret_cast<const double*>(d + o_pb);
   ma.work = reinterpret_cast<double*>(d + o_work);
   double* outp = reinterpret_cast<double*>(d + o_out);
-  const size_t nn = std::max<size_t>(1, (size_t)na * na), n1 = std::max(1, na);
   ma.out_H = outp;
   ma.out_J = outp + nn;
   ma.out_b0 = outp + 2 * nn;
   ma.out_e0 = outp + 2 * nn + n1;
   ma.out_info = reinterpret_cast<int*>(d + o_info);
-  hipLaunchKernelGGL(marg_dense_kernel, dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES * 8, s->stream, d_win, 0, ma,
-                     MARG_LDS_DOUBLES);
+  if (large_window || pd > MARG_SMALL_PRIOR)
+    hipLaunchKernelGGL((marg_dense_kernel<MAX_D, MAX_MARG_DIM>), dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES_LARGE * 8, s->stream, d_win, 0,
+                       ma, MARG_LDS_DOUBLES_LARGE);
+  else
+    hipLaunchKernelGGL((marg_dense_kernel<MAX_D_LDS, MARG_SMALL_PRIOR>), dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES * 8, s->stream, d_win, 0,
+                       ma, MARG_LDS_DOUBLES);
   HIP_TRY(hipGetLastError());
-  od = make_optd(s->opt, (int)s->wins.size());
-  HIP_TRY(hipMemcpyAsync(s->d_opt, &od, sizeof(od), hipMemcpyHostToDevice, s->stream));
-  restore_options.armed = false;   // (restored in stream order just above; the guard covers the early returns)
-  // H | J | b0 | e0 are contiguous on the device: one copy into page-locked staging (+ the info record), one sync
+  // H | J | b0 | e0 | info are contiguous on the device: one copy into page-locked staging, one synchronisation
   int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const size_t out_bytes = 8 * (2 * nn + 2 * n1);
   s->stage_dl.resize(out_bytes + sizeof(info));
-  HIP_TRY(hipMemcpyAsync(s->stage_dl.data() + out_bytes, d + o_info, sizeof(info), hipMemcpyDeviceToHost, s->stream));
-  if (na > 0) HIP_TRY(hipMemcpyAsync(s->stage_dl.data(), outp, out_bytes, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->stage_dl.data(), outp, out_bytes + sizeof(info), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   std::memcpy(info, s->stage_dl.data() + out_bytes, sizeof(info));
   if (na > 0) {

@@ -19,6 +19,12 @@ namespace ba {
 constexpr int MARG_THREADS = 1024;
 constexpr int MARG_PC_NMAX = 96;     // largest matrix of the pivoted-Cholesky path (two n x n matrices in LDS)
 constexpr int MARG_LDS_DOUBLES = 18 * 1024;  // 144 KB of dynamic LDS for the eigen-solver buffers
+// Two instantiations of marg_dense_kernel: index lists and vectors of the reduced system are static LDS arrays sized by the
+// template arguments.  The small one serves every sub-window whose reduced system is solved in LDS (D <= MAX_D_LDS) with a
+// previous prior of up to MARG_SMALL_PRIOR rows; the large one takes everything up to MAX_D / MAX_MARG_DIM with less dynamic
+// LDS (its matrices live in the HBM workspace: same code, same arithmetic, slower).
+constexpr int MARG_SMALL_PRIOR = 192;
+constexpr int MARG_LDS_DOUBLES_LARGE = 11 * 1024;
 
 struct MargArgs {
   const unsigned char* pose_marg;  // [n_pose] 1 = eliminate this block in the dense step
@@ -29,13 +35,19 @@ struct MargArgs {
   const int* pb_off;    // [prior_nb] offset inside the prior
   const double* prior_H;   // [prior_dim^2] row-major
   const double* prior_b0;  // [prior_dim]
-  double* work;            // 3 D^2 + 6 (D + 6) doubles
+  double* work;            // marg_work_doubles(D)
   double* out_H;           // [na*na]
   double* out_b0;          // [na]
   double* out_J;           // [na*na]
   double* out_e0;          // [na]
   int* out_info;           // [0] na, [1] nm, [2] rank, [3] Jacobi sweeps (V), [4] Jacobi sweeps (H), [8 + i] kept reduced index i
 };
+
+// workspace of marg_dense_kernel: A | Q | M (D^2 each), the 6-row panel of marg_chol_inverse, and the two padded matrices of the
+// Cholesky fast path when they do not fit into LDS
+__host__ __device__ inline size_t marg_work_doubles(int D) {
+  return 3 * (size_t)D * D + 6 * ((size_t)D + 6) + 2 * ((size_t)D + 6) * ((size_t)D + 6);
+}
 
 // Round-robin pairing of m (even) players: round r in [0, m-1), pair k in [0, m/2) -> (p, q), p < q.
 __device__ __forceinline__ void rr_pair(int m, int r, int k, int* p, int* q) {
@@ -79,9 +91,10 @@ __device__ __forceinline__ bool jacobi_rot(const double* X, int n, int p, int q,
   return true;
 }
 
+template <int MAXD>
 struct JacobiTab {  // the n/2 disjoint rotations of one round
-  int p[MAX_D_LDS / 2 + 1], q[MAX_D_LDS / 2 + 1];
-  double c[MAX_D_LDS / 2 + 1], s[MAX_D_LDS / 2 + 1];
+  int p[MAXD / 2 + 1], q[MAXD / 2 + 1];
+  double c[MAXD / 2 + 1], s[MAXD / 2 + 1];
   int rotated;
   int round_rot[2];  // any rotation in the current round (two slots: rounds alternate, no extra barrier to reset)
   double thr;
@@ -91,7 +104,8 @@ struct JacobiTab {  // the n/2 disjoint rotations of one round
 // compute the disjoint rotations into LDS, (2) the rotations split the matrix into (n/2)^2 independent 2x2
 // blocks B(k1,k2) <- G_k1^T B G_k2 — one work-item each, in place — and Q <- Q G by column pairs.
 // X holds the input and the result (eigenvalues on the diagonal).  X / Q may live in LDS or in global memory.
-__device__ void jacobi_eig(double* X, double* Q, int n, int tid, JacobiTab& jt, int* sweeps) {
+template <class JT>
+__device__ void jacobi_eig(double* X, double* Q, int n, int tid, JT& jt, int* sweeps) {
   for (int k = tid; k < n * n; k += MARG_THREADS) Q[k] = (k / n == k % n) ? 1.0 : 0.0;
   if (tid == 0) {
     double dmax = 0.0;
@@ -592,6 +606,7 @@ __device__ bool marg_chol_inverse(double* M, double* X, int n, int n_true, doubl
   return s_okb != 0;
 }
 
+template <int MAXD, int MAXP>
 __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs* __restrict__ wins, int w, MargArgs a,
                                                                    int lds_doubles) {
   extern __shared__ __attribute__((aligned(16))) double marg_lds[];
@@ -600,12 +615,13 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   const int D = W.D;
   double* H = W.S;     // [D][D]
   double* b = W.rhs;   // [D]
-  __shared__ int s_kidx[MAX_D_LDS], s_midx[MAX_D_LDS], s_ridx[MAX_MARG_DIM];
-  __shared__ double s_p[MAX_D_LDS], s_t[MAX_D_LDS], s_lam[MAX_D_LDS], s_ba[MAX_D_LDS];
+  static_assert(MAXP >= MARG_PC_NMAX && MAXD >= MARG_PC_NMAX, "the pivoted factorisation borrows the index lists");
+  __shared__ int s_kidx[MAXD], s_midx[MAXD], s_ridx[MAXP];
+  __shared__ double s_p[MAXD], s_t[MAXD], s_lam[MAXD], s_ba[MAXD];
   __shared__ int s_na, s_nm, s_cflag;
   __shared__ double s_max;
-  __shared__ JacobiTab jt;
-  __shared__ double s_dinv[MAX_D_LDS + 6], s_red[MARG_THREADS / 64], s_red_big[3 * (MARG_THREADS / 64)];
+  __shared__ JacobiTab<MAXD> jt;
+  __shared__ double s_dinv[MAXD + 6], s_red[MARG_THREADS / 64], s_red_big[3 * (MARG_THREADS / 64)];
   const double EPS = 2.220446049250313e-16;
 #define MSTAMP(k) do { if (W.prof && tid == 0) W.prof[k] = (double)clock64(); } while (0)   // diagnostics (debug_arrays)
   MSTAMP(0);
@@ -662,6 +678,17 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   };
   double *A, *Q;
   int sweeps_v = 0;
+  double* const chol_panel = a.work + 3 * (size_t)D * D;
+  // the two padded matrices of the Cholesky fast path: LDS when they fit, else the HBM workspace
+  auto pick_chol = [&](int np6, double** Mp, double** Xp) {
+    if (2 * np6 * np6 <= lds_doubles) {
+      *Mp = marg_lds;
+      *Xp = marg_lds + np6 * np6;
+    } else {
+      *Mp = chol_panel + 6 * ((size_t)D + 6);
+      *Xp = *Mp + ((size_t)D + 6) * ((size_t)D + 6);
+    }
+  };
 
   if (nm > 0) {
     // ---- dense part of marginalizeOut (:686-736) ----
@@ -670,9 +697,9 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
     bool fast = false;
     {  // Cholesky fast path (see marg_chol_inverse): V^+ = V^-1 proven, "V^(+1/2)" := L^-T
       const int np6 = ((nm + 5) / 6) * 6;
-      if (2 * np6 * np6 <= lds_doubles) {
-        double* Mp = marg_lds;
-        double* Xp = marg_lds + np6 * np6;
+      {
+        double *Mp, *Xp;
+        pick_chol(np6, &Mp, &Xp);
         for (int k = tid; k < np6 * np6; k += MARG_THREADS) {  // V1 = 0.5 (V + V^T) of the scaled system (:725), padded
           const int i = k / np6, j = k - i * np6;
           double v = (i == j) ? 1.0 : 0.0;
@@ -683,7 +710,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
           Mp[k] = v;
         }
         __syncthreads();
-        fast = marg_chol_inverse(Mp, Xp, np6, nm, s_dinv, a.work + 3 * (size_t)D * D, s_red, &s_cflag, tid);
+        fast = marg_chol_inverse(Mp, Xp, np6, nm, s_dinv, chol_panel, s_red, &s_cflag, tid);
         if (fast) {
           Q = a.work + (size_t)D * D;
           for (int k = tid; k < nm * nm; k += MARG_THREADS) {
@@ -770,16 +797,16 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
   {  // Cholesky fast path: full rank proven -> J = L^T P, e0 = -L^-1 P^-1 b0 (J^T J = H, J^T e0 = -b0)
     const int np6 = ((na + 5) / 6) * 6;
     // (with a previous prior the kept block carries its gauge null space: straight to the pivoted factorisation)
-    if (2 * np6 * np6 <= lds_doubles && !(a.prior_dim > 0 && na <= MARG_PC_NMAX)) {
-      double* Mp = marg_lds;
-      double* Xp = marg_lds + np6 * np6;
+    if (!(a.prior_dim > 0 && na <= MARG_PC_NMAX)) {
+      double *Mp, *Xp;
+      pick_chol(np6, &Mp, &Xp);
       for (int k = tid; k < np6 * np6; k += MARG_THREADS) {
         const int i = k / np6, j = k - i * np6;
         Mp[k] = (i < na && j < na) ? 0.5 * (Ha[i * na + j] + Ha[j * na + i]) / (s_p[i] * s_p[j]) : (i == j ? 1.0 : 0.0);
       }
       __syncthreads();
       MSTAMP(4);
-      const bool full = marg_chol_inverse(Mp, Xp, np6, na, s_dinv, a.work + 3 * (size_t)D * D, s_red, &s_cflag, tid);
+      const bool full = marg_chol_inverse(Mp, Xp, np6, na, s_dinv, chol_panel, s_red, &s_cflag, tid);
       MSTAMP(5);
       if (full) {
         for (int k = tid; k < na * na; k += MARG_THREADS) {
@@ -805,7 +832,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
     double* Bp = marg_lds;
     double* Xq = marg_lds + na * na;
     int* perm = s_midx;   // (the eliminated-index list is not needed any more)
-    int* pos = s_ridx;    // (neither is the index map of the previous prior; MAX_MARG_DIM >= MAX_D_LDS)
+    int* pos = s_ridx;    // (neither is the index map of the previous prior; na <= MARG_PC_NMAX entries)
     __syncthreads();
     for (int k = tid; k < na * na; k += MARG_THREADS) {
       const int i = k / na, j = k - i * na;

@@ -1533,6 +1533,7 @@ __global__ void add_budget_kernel(const WinPtrs* __restrict__ wins, int n) {
 // quality[n_lm] | reference bias of every IMU factor [9 n_imu]
 __global__ void pack_results_kernel(const WinPtrs* __restrict__ win, int acc) {
   const WinPtrs& W = *win;
+  if (acc < 0) acc = W.ctrl->acc;   // (okvis_ba_finish: the host has not read the control record yet)
   const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
   double* out = W.results;
   for (int i = t; i < 7 * W.n_pose; i += nt) out[i] = W.pose[acc][i];

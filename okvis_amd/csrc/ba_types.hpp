@@ -25,7 +25,7 @@ constexpr int IMU_THREADS = 256;
 // IMU factor linearisation record: H = J^T J (30x30 lower, packed a(a+1)/2+b) | g = J^T r (30) | r (15) | cost
 constexpr int IMU_H = 0, IMU_G = 465, IMU_R = 495, IMU_COST = 510;
 constexpr int IMU_LIN_STRIDE = 512;
-constexpr int MAX_MARG_DIM = 192;
+constexpr int MAX_MARG_DIM = MAX_D;    // rows of a marginalisation prior (any subset of one window's blocks)
 
 // 32-byte observation record (coalesced 2 x 16 B per lane).  idx0 = landmark | cam << 24.
 struct ObsRec {

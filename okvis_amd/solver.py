@@ -38,16 +38,67 @@ def check_window(window: Window, options: OptionsC | None = None) -> dict:
                 arena_bytes=st[7])
 
 
+class WindowStore:
+    """Host-side window container with O(edit) structure updates (okvis_ba_store_*; no GPU needed)."""
+
+    def __init__(self, window: Window):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        wc, keep = window.as_c()
+        _lib.check(self._L.okvis_ba_store_create(C.byref(wc), C.byref(self._h)), "store_create")
+        del keep
+
+    def patch(self, patch) -> int:
+        """Apply a :class:`okvis_amd.window.Patch`; returns the status (0 = applied, otherwise the window is untouched)."""
+        pc, keep = patch.as_c()
+        rc = self._L.okvis_ba_store_patch(self._h, C.byref(pc))
+        del keep
+        return rc
+
+    def view(self) -> Window:
+        from .window import window_from_c
+        wc = WindowC()
+        _lib.check(self._L.okvis_ba_store_view(self._h, C.byref(wc)), "store_view")
+        return window_from_c(wc)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.okvis_ba_store_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class WindowBatch:
     """A batch of independent sliding windows resident in the HBM of one GPU."""
 
-    def __init__(self, windows: Sequence[Window], device: int = 0, options: OptionsC | None = None):
+    def __init__(self, windows: Sequence[Window], device: int = 0, options: OptionsC | None = None, patchable: bool = False):
         self._L = _lib.lib()
         self._h = C.c_void_p()
         _lib.check(self._L.okvis_ba_create(C.byref(self._h), int(device)), "create")
         self.options = options or default_options()
         _lib.check(self._L.okvis_ba_set_options(self._h, C.byref(self.options)), "set_options")
+        if patchable:   # the solver keeps a container of every uploaded window (okvis_ba_patch_window)
+            _lib.check(self._L.okvis_ba_set_patchable(self._h, 1), "set_patchable")
         self.upload(windows)
+
+    def patch(self, w: int, patch):
+        """okvis_ba_patch_window: edit window w on the solver (blocks that stay keep the device's values)."""
+        pc, keep = patch.as_c()
+        _lib.check(self._L.okvis_ba_patch_window(self._h, int(w), C.byref(pc)), "patch_window")
+        del keep
+        self.windows[w] = self.patched_view(w)
+
+    def patched_view(self, w: int) -> Window:
+        """The solver's container of window w as a :class:`Window` (current device values)."""
+        from .window import window_from_c
+        wc = WindowC()
+        _lib.check(self._L.okvis_ba_patched_view(self._h, int(w), C.byref(wc)), "patched_view")
+        return window_from_c(wc)
 
     def upload(self, windows: Sequence[Window]):
         """okvis_ba_upload on this solver: replaces the windows.  Device allocations are kept (grow-only) and so are the captured

@@ -327,3 +327,167 @@ class Window:
         if k["imu_sb_ref"].shape[0] == w.n_imu and k["imu_sb_ref_valid"].size == w.n_imu and w.n_imu > 0:
             w.imu_sb_ref = p("imu_sb_ref", _dp); w.imu_sb_ref_valid = p("imu_sb_ref_valid", _bp)
         return w, k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# incremental structure updates (okvis_ba_patch, include/okvis_amd_ba.h)
+# ------------------------------------------------------------------------------------------------------------------
+PATCH_POSE_PRIORS, PATCH_SB_PRIORS, PATCH_RELPOSE, PATCH_MARG_PRIOR = 1, 2, 4, 8
+
+
+class PatchC(C.Structure):
+    """ctypes image of ``okvis_ba_patch`` (field order must match the header)."""
+    _fields_ = [
+        ("n_remove_obs", C.c_int32), ("remove_obs", _ip), ("n_remove_lm", C.c_int32), ("remove_lm", _ip),
+        ("n_remove_pose", C.c_int32), ("remove_pose", _ip), ("n_remove_sb", C.c_int32), ("remove_sb", _ip),
+        ("n_remove_imu", C.c_int32), ("remove_imu", _ip),
+        ("n_add_pose", C.c_int32), ("add_pose", _dp), ("add_pose_fixed", _bp),
+        ("n_add_sb", C.c_int32), ("add_sb", _dp), ("add_sb_fixed", _bp),
+        ("n_add_lm", C.c_int32), ("add_lm", _dp),
+        ("n_add_obs", C.c_int32), ("add_obs_lm", _ip), ("add_obs_pose", _ip), ("add_obs_ext", _ip), ("add_obs_cam", _ip),
+        ("add_obs_uv", _dp), ("add_obs_sqrtw", _dp),
+        ("n_add_imu", C.c_int32), ("add_imu_pose0", _ip), ("add_imu_sb0", _ip), ("add_imu_pose1", _ip), ("add_imu_sb1", _ip),
+        ("add_imu_t0", _lp), ("add_imu_t1", _lp), ("add_imu_s_begin", _ip), ("add_imu_s_count", _ip),
+        ("n_add_imu_samples", C.c_int32), ("add_imu_s_t", _lp), ("add_imu_s_gyr", _dp), ("add_imu_s_acc", _dp),
+        ("replace", C.c_int32),
+        ("n_pprior", C.c_int32), ("pprior_pose", _ip), ("pprior_meas", _dp), ("pprior_sqrtinfo", _dp),
+        ("n_sbprior", C.c_int32), ("sbprior_sb", _ip), ("sbprior_meas", _dp), ("sbprior_sqrtinfo", _dp),
+        ("n_relpose", C.c_int32), ("rel_pose0", _ip), ("rel_pose1", _ip), ("rel_sqrtinfo", _dp),
+        ("marg_dim", C.c_int32), ("marg_nblocks", C.c_int32), ("marg_block_type", _ip), ("marg_block_idx", _ip),
+        ("marg_block_off", _ip), ("marg_J", _dp), ("marg_e0", _dp), ("marg_lin", _dp),
+        ("n_set_pose", C.c_int32), ("set_pose_idx", _ip), ("set_pose", _dp),
+        ("n_set_sb", C.c_int32), ("set_sb_idx", _ip), ("set_sb", _dp),
+        ("n_set_lm", C.c_int32), ("set_lm_idx", _ip), ("set_lm", _dp),
+    ]
+
+
+def _e(dtype=np.float64, *shape):
+    return field(default_factory=lambda: np.zeros(shape or (0,), dtype))
+
+
+@dataclass
+class Patch:
+    """One batch of edits to a window (``okvis_ba_patch``): removals by current index, then appended blocks and terms in the
+    new numbering, replaced prior families, sparse value updates."""
+    remove_obs: np.ndarray = _e(np.int32)
+    remove_lm: np.ndarray = _e(np.int32)
+    remove_pose: np.ndarray = _e(np.int32)
+    remove_sb: np.ndarray = _e(np.int32)
+    remove_imu: np.ndarray = _e(np.int32)
+    add_pose: np.ndarray = _e(np.float64, 0, 7)
+    add_pose_fixed: np.ndarray = _e(np.uint8)
+    add_sb: np.ndarray = _e(np.float64, 0, 9)
+    add_sb_fixed: np.ndarray = _e(np.uint8)
+    add_lm: np.ndarray = _e(np.float64, 0, 4)
+    add_obs_lm: np.ndarray = _e(np.int32)
+    add_obs_pose: np.ndarray = _e(np.int32)
+    add_obs_ext: np.ndarray = _e(np.int32)
+    add_obs_cam: np.ndarray = _e(np.int32)
+    add_obs_uv: np.ndarray = _e(np.float64, 0, 2)
+    add_obs_sqrtw: np.ndarray = _e(np.float64)
+    add_imu_pose0: np.ndarray = _e(np.int32)
+    add_imu_sb0: np.ndarray = _e(np.int32)
+    add_imu_pose1: np.ndarray = _e(np.int32)
+    add_imu_sb1: np.ndarray = _e(np.int32)
+    add_imu_t0: np.ndarray = _e(np.int64)
+    add_imu_t1: np.ndarray = _e(np.int64)
+    add_imu_s_begin: np.ndarray = _e(np.int32)
+    add_imu_s_count: np.ndarray = _e(np.int32)
+    add_imu_s_t: np.ndarray = _e(np.int64)
+    add_imu_s_gyr: np.ndarray = _e(np.float64, 0, 3)
+    add_imu_s_acc: np.ndarray = _e(np.float64, 0, 3)
+    replace: int = 0
+    pprior_pose: np.ndarray = _e(np.int32)
+    pprior_meas: np.ndarray = _e(np.float64, 0, 7)
+    pprior_sqrtinfo: np.ndarray = _e(np.float64, 0, 36)
+    sbprior_sb: np.ndarray = _e(np.int32)
+    sbprior_meas: np.ndarray = _e(np.float64, 0, 9)
+    sbprior_sqrtinfo: np.ndarray = _e(np.float64, 0, 81)
+    rel_pose0: np.ndarray = _e(np.int32)
+    rel_pose1: np.ndarray = _e(np.int32)
+    rel_sqrtinfo: np.ndarray = _e(np.float64, 0, 36)
+    marg_block_type: np.ndarray = _e(np.int32)
+    marg_block_idx: np.ndarray = _e(np.int32)
+    marg_block_off: np.ndarray = _e(np.int32)
+    marg_J: np.ndarray = _e(np.float64, 0, 0)
+    marg_e0: np.ndarray = _e(np.float64)
+    marg_lin: np.ndarray = _e(np.float64, 0, 9)
+    set_pose_idx: np.ndarray = _e(np.int32)
+    set_pose: np.ndarray = _e(np.float64, 0, 7)
+    set_sb_idx: np.ndarray = _e(np.int32)
+    set_sb: np.ndarray = _e(np.float64, 0, 9)
+    set_lm_idx: np.ndarray = _e(np.int32)
+    set_lm: np.ndarray = _e(np.float64, 0, 4)
+
+    _I32 = ("remove_obs", "remove_lm", "remove_pose", "remove_sb", "remove_imu", "add_obs_lm", "add_obs_pose", "add_obs_ext",
+            "add_obs_cam", "add_imu_pose0", "add_imu_sb0", "add_imu_pose1", "add_imu_sb1", "add_imu_s_begin", "add_imu_s_count",
+            "pprior_pose", "sbprior_sb", "rel_pose0", "rel_pose1", "marg_block_type", "marg_block_idx", "marg_block_off",
+            "set_pose_idx", "set_sb_idx", "set_lm_idx")
+    _I64 = ("add_imu_t0", "add_imu_t1", "add_imu_s_t")
+    _U8 = ("add_pose_fixed", "add_sb_fixed")
+    _F64 = dict(add_pose=7, add_sb=9, add_lm=4, add_obs_uv=2, add_obs_sqrtw=0, add_imu_s_gyr=3, add_imu_s_acc=3, pprior_meas=7,
+                pprior_sqrtinfo=36, sbprior_meas=9, sbprior_sqrtinfo=81, rel_sqrtinfo=36, marg_e0=0, marg_lin=9, set_pose=7,
+                set_sb=9, set_lm=4)
+
+    def as_c(self):
+        """Return (PatchC, keepalive dict)."""
+        k = {}
+        for n in self._I32:
+            k[n] = _i32(getattr(self, n))
+        for n in self._I64:
+            k[n] = _i64(getattr(self, n))
+        for n in self._U8:
+            k[n] = np.ascontiguousarray(np.asarray(getattr(self, n), np.uint8).reshape(-1))
+        for n, wdt in self._F64.items():
+            k[n] = _f64(getattr(self, n), (-1, wdt) if wdt else (-1,))
+        md = int(k["marg_e0"].size)
+        k["marg_J"] = _f64(self.marg_J, (md, md))
+        typ = {np.dtype(np.int32): _ip, np.dtype(np.int64): _lp, np.dtype(np.uint8): _bp, np.dtype(np.float64): _dp}
+        p = PatchC()
+        for n, a in k.items():
+            setattr(p, n, a.ctypes.data_as(typ[a.dtype]) if a.size else C.cast(None, typ[a.dtype]))
+        p.n_remove_obs, p.n_remove_lm, p.n_remove_pose = k["remove_obs"].size, k["remove_lm"].size, k["remove_pose"].size
+        p.n_remove_sb, p.n_remove_imu = k["remove_sb"].size, k["remove_imu"].size
+        p.n_add_pose, p.n_add_sb, p.n_add_lm = k["add_pose"].shape[0], k["add_sb"].shape[0], k["add_lm"].shape[0]
+        p.n_add_obs, p.n_add_imu, p.n_add_imu_samples = k["add_obs_lm"].size, k["add_imu_pose0"].size, k["add_imu_s_t"].size
+        p.replace = int(self.replace)
+        p.n_pprior, p.n_sbprior, p.n_relpose = k["pprior_pose"].size, k["sbprior_sb"].size, k["rel_pose0"].size
+        p.marg_dim, p.marg_nblocks = md, k["marg_block_type"].size
+        p.n_set_pose, p.n_set_sb, p.n_set_lm = k["set_pose_idx"].size, k["set_sb_idx"].size, k["set_lm_idx"].size
+        return p, k
+
+
+def window_from_c(w: WindowC) -> Window:
+    """Copy an ``okvis_ba_window`` (e.g. okvis_ba_store_view) into a :class:`Window`."""
+    def arr(ptr, n, dtype, shape=None):
+        if n == 0 or not ptr:
+            return np.zeros(shape if shape is not None else (0,), dtype)
+        a = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+        return a.reshape(shape) if shape is not None else a
+    np_, ns, nl, no, ni = w.n_pose, w.n_sb, w.n_lm, w.n_obs, w.n_imu
+    md, nb = w.marg_dim, w.marg_nblocks
+    ip = w.imu_params
+    out = Window(
+        pose=arr(w.pose, 7 * np_, np.float64, (np_, 7)), pose_fixed=arr(w.pose_fixed, np_, np.uint8),
+        sb=arr(w.sb, 9 * ns, np.float64, (ns, 9)), sb_fixed=arr(w.sb_fixed, ns, np.uint8), lm=arr(w.lm, 4 * nl, np.float64, (nl, 4)),
+        cam_intr=arr(w.cam_intr, 12 * w.n_cam, np.float64, (w.n_cam, 12)), cam_model=arr(w.cam_model, w.n_cam, np.int32),
+        obs_lm=arr(w.obs_lm, no, np.int32), obs_pose=arr(w.obs_pose, no, np.int32), obs_ext=arr(w.obs_ext, no, np.int32),
+        obs_cam=arr(w.obs_cam, no, np.int32), obs_uv=arr(w.obs_uv, 2 * no, np.float64, (no, 2)), obs_sqrtw=arr(w.obs_sqrtw, no, np.float64),
+        cauchy_b=float(w.cauchy_b),
+        imu_pose0=arr(w.imu_pose0, ni, np.int32), imu_sb0=arr(w.imu_sb0, ni, np.int32), imu_pose1=arr(w.imu_pose1, ni, np.int32),
+        imu_sb1=arr(w.imu_sb1, ni, np.int32), imu_t0=arr(w.imu_t0, ni, np.int64), imu_t1=arr(w.imu_t1, ni, np.int64),
+        imu_s_begin=arr(w.imu_s_begin, ni, np.int32), imu_s_count=arr(w.imu_s_count, ni, np.int32),
+        imu_s_t=arr(w.imu_s_t, w.n_imu_samples, np.int64), imu_s_gyr=arr(w.imu_s_gyr, 3 * w.n_imu_samples, np.float64, (w.n_imu_samples, 3)),
+        imu_s_acc=arr(w.imu_s_acc, 3 * w.n_imu_samples, np.float64, (w.n_imu_samples, 3)),
+        imu_params=ImuParams(ip.sigma_g_c, ip.sigma_a_c, ip.sigma_gw_c, ip.sigma_aw_c, ip.g, ip.g_max, ip.a_max),
+        pprior_pose=arr(w.pprior_pose, w.n_pprior, np.int32), pprior_meas=arr(w.pprior_meas, 7 * w.n_pprior, np.float64, (w.n_pprior, 7)),
+        pprior_sqrtinfo=arr(w.pprior_sqrtinfo, 36 * w.n_pprior, np.float64, (w.n_pprior, 36)),
+        sbprior_sb=arr(w.sbprior_sb, w.n_sbprior, np.int32), sbprior_meas=arr(w.sbprior_meas, 9 * w.n_sbprior, np.float64, (w.n_sbprior, 9)),
+        sbprior_sqrtinfo=arr(w.sbprior_sqrtinfo, 81 * w.n_sbprior, np.float64, (w.n_sbprior, 81)),
+        rel_pose0=arr(w.rel_pose0, w.n_relpose, np.int32), rel_pose1=arr(w.rel_pose1, w.n_relpose, np.int32),
+        rel_sqrtinfo=arr(w.rel_sqrtinfo, 36 * w.n_relpose, np.float64, (w.n_relpose, 36)),
+        marg_block_type=arr(w.marg_block_type, nb if md else 0, np.int32), marg_block_idx=arr(w.marg_block_idx, nb if md else 0, np.int32),
+        marg_block_off=arr(w.marg_block_off, nb if md else 0, np.int32), marg_J=arr(w.marg_J, md * md, np.float64, (md, md)),
+        marg_e0=arr(w.marg_e0, md, np.float64), marg_lin=arr(w.marg_lin, 9 * (nb if md else 0), np.float64, (nb if md else 0, 9)),
+        imu_sb_ref=arr(w.imu_sb_ref, 9 * ni, np.float64, (ni, 9)), imu_sb_ref_valid=arr(w.imu_sb_ref_valid, ni, np.uint8))
+    return out

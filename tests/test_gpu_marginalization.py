@@ -110,6 +110,56 @@ def test_config_A_size(oracle):
     check(g, r, 1e-8)
 
 
+def test_window_beyond_the_lds_solve_path(oracle):
+    """D = 300 > 174: the reduced system of the sub-window is assembled in HBM (solve_kernel<true>) and the dense tail works in
+    its HBM workspace (marg_dense_kernel<MAX_D, MAX_MARG_DIM>) — MarginalizationError.cpp:507-802 is size-agnostic."""
+    w = synthetic.make_window(20, 30, 1.0, 2, frame_dt=0.1)
+    assert w.reduced_dim() == 300
+    pm, sm = flags(w, [0, 1], [0, 1])
+    g, r = both(oracle, w, pm, sm)
+    assert g["dim"] == 300 - 30
+    check(g, r, 1e-8)
+
+
+def test_previous_prior_of_more_than_192_rows(oracle):
+    """Two stages on a 20-frame window: the first leaves a prior over 291 rows, the second takes it as (H_, b0_) and eliminates a
+    pose; the 291-row prior also re-enters an optimisation as the window's marg_* prior (J, e0)."""
+    from okvis_amd import solver
+    w = synthetic.make_window(20, 30, 1.0, 3, frame_dt=0.1)
+    pm1, sm1 = flags(w, [], [0])
+    g1, r1 = both(oracle, w, pm1, sm1)
+    assert r1["dim"] == 291
+    check(g1, r1, 1e-8)
+    w2 = Window(pose=w.pose, pose_fixed=w.pose_fixed, sb=w.sb, sb_fixed=w.sb_fixed, lm=np.zeros((0, 4)),
+                cam_intr=w.cam_intr, cam_model=w.cam_model, obs_lm=np.zeros(0, np.int32), obs_pose=np.zeros(0, np.int32),
+                obs_ext=np.zeros(0, np.int32), obs_cam=np.zeros(0, np.int32), obs_uv=np.zeros((0, 2)),
+                obs_sqrtw=np.zeros(0), imu_params=w.imu_params)
+    prior = dict(block_type=r1["block_type"], block_idx=r1["block_idx"], H=r1["H"], b0=r1["b0"])
+    pm2, sm2 = flags(w2, [0], [])
+    g2, r2 = both(oracle, w2, pm2, sm2, prior)
+    assert r2["dim"] == 285
+    check(g2, r2, 1e-8)
+    # the same prior as an error term of an optimisation (MarginalizationError::EvaluateWithMinimalJacobians, :893-946)
+    w3 = synthetic.make_window(20, 30, 1.0, 3, frame_dt=0.1)
+    rng = np.random.default_rng(3)
+    w3.marg_J, w3.marg_e0 = r1["J"], r1["e0"]
+    w3.marg_block_type, w3.marg_block_idx = r1["block_type"], r1["block_idx"]
+    w3.marg_block_off = r1["block_off"]
+    lin = np.zeros((len(r1["block_type"]), 9))
+    for k, (t, i) in enumerate(zip(r1["block_type"], r1["block_idx"])):
+        if t == 0:
+            lin[k, :7] = synthetic.pose_oplus(w.pose[i], rng.normal(0, 1e-4, 6))
+        else:
+            lin[k] = w.sb[i] + rng.normal(0, 1e-4, 9)
+    w3.marg_lin = lin
+    b = solver.WindowBatch([w3], options=default_options())
+    sg = b.optimize(6)[0]
+    b.close()
+    sr = oracle.OracleWindow(w3).optimize(6)
+    assert sg["iterations"] == sr["iterations"]
+    assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-8 * sr["final_cost"]
+
+
 def test_optimize_after_marginalize_still_works(oracle):
     """okvis_ba_marginalize leaves the solver usable (device options restored)."""
     from okvis_amd import solver
@@ -150,12 +200,9 @@ def test_argument_and_state_errors():
     res.capacity_dim, res.capacity_blocks = 3, 1
     assert L.okvis_ba_marginalize(b._h, 0, C.byref(spec), C.byref(res)) == -1
     b.close()
-    # a window that already carries a marg_* prior, and one beyond the LDS solve path
-    big = synthetic.make_window(20, 30, 1.0, 2, frame_dt=0.1)    # D = 300
-    b2 = solver.WindowBatch([big], options=default_options())
-    st, _ = marg_call(lambda sp, rs: L.okvis_ba_marginalize(b2._h, 0, sp, rs), big.n_pose, big.n_sb, np.zeros(big.n_pose), np.zeros(big.n_sb))
-    assert st == -3
-    b2.close()
+    # a previous prior beyond the documented limit
+    lim = solver.limits()
+    assert lim["max_marg_dim"] == lim["max_reduced_dim"] == 900
     # dense solve: argument check
     assert L.okvis_ba_dense_solve(0, 0, None, None, None, None) == -1
 
@@ -187,7 +234,7 @@ def test_gauge_deficient_random_sweep(oracle, seed):
     Lm = int(rng.integers(12, 80))
     ext = ["fixed", "shared", "perframe"][int(rng.integers(0, 3))]
     w = synthetic.make_window(K, Lm, float(rng.uniform(0.4, 1.0)), seed=9100 + seed, estimate_extrinsics=ext)
-    if w.reduced_dim() > 174:      # documented limit of the marginalisation sub-window (okvis_ba_get_limits): K = 7 per-frame extrinsics
+    if w.reduced_dim() > 174:      # (keep this sweep on the LDS path; the HBM path has its own tests above): K = 7 per-frame extrinsics
         w = synthetic.make_window(5, Lm, 0.8, seed=9100 + seed, estimate_extrinsics=ext)
         K = 5
     keep = [i for i in range(len(w.pprior_pose)) if w.pprior_pose[i] != 0]      # drop the first-pose prior only

@@ -1,0 +1,123 @@
+"""Host side of okvis_ba_patch (include/okvis_amd_ba.h, "incremental structure updates"; reference semantics: Map::addParameterBlock /
+addResidualBlock / removeResidualBlock / removeParameterBlock, okvis_ceres/src/Map.cpp:292-565): the window container okvis_ba_store_*
+against windows built directly from the same data.  No GPU."""
+import numpy as np
+import pytest
+
+from okvis_amd import solver, synthetic
+from okvis_amd.window import PATCH_MARG_PRIOR, Patch
+from tests.patch_helpers import Carving, make_marg, patch_between, sliding_pair, windows_differ
+
+
+def structure(w):
+    """What the index build of okvis_ba_upload makes of a window (the container keeps one copy of the raw IMU samples per term, a
+    caller may share them between terms: the arena size is not compared)."""
+    st = solver.check_window(w)
+    st.pop("arena_bytes")
+    return st
+
+
+def test_store_holds_the_window_it_was_given():
+    for ext in ("fixed", "shared", "perframe"):
+        w = synthetic.small_window(seed=3, K=5, L=40, estimate_extrinsics=ext)
+        st = solver.WindowStore(w)
+        assert windows_differ(st.view(), w) == []
+        assert structure(st.view()) == structure(w)
+        st.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_one_frame_of_the_sliding_window(seed):
+    """Oldest frame out (its observations, IMU term and priors go with it), landmarks out, single observations out, a frame with its
+    IMU term / observations / landmarks in, priors moved, dense prior replaced: the container equals the window built from scratch."""
+    A, B = sliding_pair(seed=10 + seed, K=4 + seed % 3, L=60 + 10 * seed)
+    st = solver.WindowStore(A.window())
+    p = patch_between(A, B)
+    assert len(p.remove_obs) > 0 and len(p.add_obs_lm) > 0 and len(p.remove_lm) > 0 and len(p.add_imu_pose0) == 1
+    assert st.patch(p) == 0
+    got, want = st.view(), B.window()
+    assert windows_differ(got, want) == []
+    got.validate()                                            # sorted by (lm, pose, cam)
+    assert structure(got) == structure(want)
+    assert np.array_equal(got.imu_sb_ref_valid, np.zeros(got.n_imu, np.uint8))
+    st.close()
+
+
+def test_several_frames_in_a_row():
+    K, L = 5, 70
+    W = synthetic.make_window(K + 3, L, 0.8, seed=31, frame_dt=0.2)
+    ext = [("e", 0), ("e", 1)]
+    lms = list(range(L))
+    cur = Carving(W, [("f", k) for k in range(K)] + ext, list(range(K)), lms[:50])
+    st = solver.WindowStore(cur.window())
+    pose_ids, sb_ids, lm_ids = list(cur.pose_ids), list(cur.sb_ids), list(cur.lm_ids)
+    for step in range(3):
+        pose_ids = [i for i in pose_ids if i != ("f", step)] + [("f", K + step)]
+        sb_ids = [k for k in sb_ids if k != step] + [K + step]
+        lm_ids = [l for l in lm_ids if l % 7 != step] + lms[50 + 5 * step:55 + 5 * step]
+        nxt = Carving(W, pose_ids, sb_ids, lm_ids, pose_prior_on=[("f", step + 1)], sb_prior_on=[step + 1])
+        assert st.patch(patch_between(cur, nxt)) == 0
+        assert windows_differ(st.view(), nxt.window()) == []
+        cur = nxt
+    st.close()
+
+
+def test_sparse_values_and_equal_keys():
+    w = synthetic.small_window(seed=5, K=4, L=30)
+    st = solver.WindowStore(w)
+    # a second keypoint of the same image on the same landmark (legal: implementation/Estimator.hpp:52-56) goes behind the first
+    i = 17
+    p = Patch(add_obs_lm=[w.obs_lm[i]], add_obs_pose=[w.obs_pose[i]], add_obs_ext=[w.obs_ext[i]], add_obs_cam=[w.obs_cam[i]],
+              add_obs_uv=[[1.5, 2.5]], add_obs_sqrtw=[0.5], set_lm_idx=[3, 0], set_lm=[[1, 2, 3, 1], [4, 5, 6, 1]],
+              set_pose_idx=[1], set_pose=[w.pose[2]], set_sb_idx=[2], set_sb=[np.arange(9.0)])
+    assert st.patch(p) == 0
+    v = st.view()
+    assert v.n_obs == w.n_obs + 1 and np.array_equal(v.obs_uv[i + 1], [1.5, 2.5]) and np.array_equal(v.obs_uv[i], w.obs_uv[i])
+    assert np.array_equal(v.lm[3], [1, 2, 3, 1]) and np.array_equal(v.lm[0], [4, 5, 6, 1]) and np.array_equal(v.lm[1], w.lm[1])
+    assert np.array_equal(v.pose[1], w.pose[2]) and np.array_equal(v.sb[2], np.arange(9.0))
+    st.close()
+
+
+def test_rejected_patches_leave_the_window_untouched():
+    rng = np.random.default_rng(8)
+    W = synthetic.make_window(5, 30, 1.0, seed=8, frame_dt=0.2)
+    A = Carving(W, [("f", k) for k in range(5)] + [("e", 0), ("e", 1)], list(range(5)), list(range(30)),
+                marg=make_marg(W, [("p", ("f", 0)), ("s", 0)], rng))
+    w = A.window()
+    st = solver.WindowStore(w)
+    bad = [
+        Patch(remove_obs=[5, 5]), Patch(remove_obs=[9, 3]), Patch(remove_lm=[30]), Patch(remove_pose=[-1]), Patch(remove_sb=[7]),
+        Patch(remove_imu=[4]),
+        Patch(remove_pose=[0]),                                   # the dense prior would lose a block
+        Patch(remove_sb=[0]),
+        Patch(add_obs_lm=[30], add_obs_pose=[0], add_obs_ext=[5], add_obs_cam=[0], add_obs_uv=[[0, 0]], add_obs_sqrtw=[1]),
+        Patch(add_obs_lm=[0], add_obs_pose=[7], add_obs_ext=[5], add_obs_cam=[0], add_obs_uv=[[0, 0]], add_obs_sqrtw=[1]),
+        Patch(add_obs_lm=[0], add_obs_pose=[0], add_obs_ext=[5], add_obs_cam=[2], add_obs_uv=[[0, 0]], add_obs_sqrtw=[1]),
+        Patch(set_lm_idx=[30], set_lm=[[0, 0, 0, 1]]),
+        Patch(add_imu_pose0=[0], add_imu_sb0=[0], add_imu_pose1=[1], add_imu_sb1=[9], add_imu_t0=[0], add_imu_t1=[1],
+              add_imu_s_begin=[0], add_imu_s_count=[2], add_imu_s_t=[0, 1], add_imu_s_gyr=np.zeros((2, 3)), add_imu_s_acc=np.zeros((2, 3))),
+        Patch(add_imu_pose0=[0], add_imu_sb0=[0], add_imu_pose1=[1], add_imu_sb1=[1], add_imu_t0=[0], add_imu_t1=[1],
+              add_imu_s_begin=[1], add_imu_s_count=[2], add_imu_s_t=[0, 1], add_imu_s_gyr=np.zeros((2, 3)), add_imu_s_acc=np.zeros((2, 3))),
+        Patch(replace=1, pprior_pose=[9], pprior_meas=np.zeros((1, 7)), pprior_sqrtinfo=np.zeros((1, 36))),
+    ]
+    for p in bad:
+        assert st.patch(p) == -1
+        assert windows_differ(st.view(), w) == []
+    # the same removal is fine once the prior is replaced (here: dropped) in the same patch
+    assert st.patch(Patch(remove_pose=[0], remove_sb=[0], replace=PATCH_MARG_PRIOR)) == 0
+    v = st.view()
+    assert v.n_pose == w.n_pose - 1 and v.n_sb == 4 and v.n_imu == w.n_imu - 1 and np.asarray(v.marg_e0).size == 0
+    assert len(v.pprior_pose) == 0 and len(v.sbprior_sb) == 0          # W's priors sat on frame 0
+    assert v.n_obs == int((np.asarray(w.obs_pose) != 0).sum()) and v.obs_pose.min() == 0 and v.obs_ext.min() == 4   # renumbered
+    st.close()
+
+
+def test_c_abi_rejects_null_arguments():
+    import ctypes as C
+    from okvis_amd import _lib
+    L = _lib.lib()
+    assert L.okvis_ba_store_create(None, None) == -1
+    assert L.okvis_ba_store_patch(None, None) == -1 and L.okvis_ba_store_view(None, None) == -1
+    L.okvis_ba_store_destroy(None)
+    assert L.okvis_ba_set_patchable(None, 1) == -1 and L.okvis_ba_patch_window(None, 0, None) == -1
+    assert L.okvis_ba_patched_view(None, 0, None) == -1
