@@ -2050,9 +2050,13 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   s->begun = false;
   const Sub one{s->stream, w, 1};
   HIP_TRY(launch_schur(s, one));
-  if (large_window)
+  if (large_window) {
+    // assembly of the undamped system, then the kernel that completes it (Schur partials, IMU terms) and, because this copy of
+    // the window carries an S pointer, writes it out as one full symmetric D x D matrix
     hipLaunchKernelGGL((solve_kernel<true, false>), dim3(1), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), s->stream, d_win, s->d_opt, 2);
-  else if (s->group_chunks)
+    const int nT = (((D + 5) / 6) * 6 + CT_TB - 1) / CT_TB;
+    hipLaunchKernelGGL(large_export_kernel, dim3(nT * (nT + 1) / 2, 1, CT_TILE / CT_THREADS), dim3(CT_THREADS), 0, s->stream, d_win);
+  } else if (s->group_chunks)
     hipLaunchKernelGGL((solve_kernel<false, true>), dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream,
                        d_win, s->d_opt, 2);
   else

@@ -1033,11 +1033,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   if (final_only == 2) {
     // marginalisation pass (okvis_ba_marginalize): export the undamped system left after the landmark
     // elimination, H (D x D, full symmetric) and b0 = -(g - W V^+ b_l)  (MarginalizationError.cpp:682-684)
+    for (int i = tid; i < D; i += SOLVE_THREADS) Wl.rhs[i] = s_rhs[i] - s_g[i];
+    if constexpr (LARGE) {
+      // the matrix of a large window is completed by large_export_kernel (Schur partials of the pose part, IMU terms), which
+      // also writes the full symmetric copy into W.S: ask for it and stop before any damping is added
+      if (tid == 0) {
+        *gctrl = c;
+        Wl.ct_flag[Wl.ct_nT * (Wl.ct_nT + 1) / 2 + 1] = 1;
+      }
+      return;
+    }
     for (int k = tid; k < D * D; k += SOLVE_THREADS) {
       const int i = k / D, j = k - i * D;
       Wl.S[k] = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
     }
-    for (int i = tid; i < D; i += SOLVE_THREADS) Wl.rhs[i] = s_rhs[i] - s_g[i];
     if (tid == 0) *gctrl = c;
     return;
   }

@@ -218,30 +218,36 @@ bool Estimator::initPoseFromImu(const ImuMeasurementDeque& imuMeasurements, Tran
 // addStates (Estimator.cpp:110-343)
 // ---------------------------------------------------------------------------------------------------
 bool Estimator::addStates(MultiFramePtr multiFrame, const ImuMeasurementDeque& imuMeasurements, bool asKeyframe) {
-  if (!multiFrame || imuParametersVec_.empty()) return false;
+  lastRefusal_.clear();
+  if (!multiFrame || imuParametersVec_.empty()) return refuse("addStates: no multiframe or no IMU parameters");
   Transformation T_WS;
   SpeedAndBias speedAndBias{};
   if (states_.empty()) {
-    if (!initPoseFromImu(imuMeasurements, T_WS)) return false;  // :121-125
+    if (!initPoseFromImu(imuMeasurements, T_WS)) return refuse("addStates: initPoseFromImu failed (no IMU measurements)");  // :121-125
     for (int c = 0; c < 3; ++c) speedAndBias[6 + c] = imuParametersVec_.at(0).a0[c];  // :126-127
   } else {
     const State& last = states_.back();
-    if (last.sbBlock < 0) return false;
+    if (last.sbBlock < 0) return refuse("addStates: the previous state has no speed/bias block");
     T_WS.p = poseBlocks_[last.poseBlock].x;
     speedAndBias = sbBlocks_[last.sbBlock].x;
     const int used = propagation(imuMeasurements, imuParametersVec_.at(0), T_WS, speedAndBias, last.t_ns,
                                  multiFrame->t_ns);  // :145-147
-    if (used < 1) return false;                     // :150-153
+    if (used < 1)
+      return refuse("addStates: propagation used " + std::to_string(used) + " of " + std::to_string(imuMeasurements.size()) +
+                    " IMU measurements between " + std::to_string(last.t_ns) + " and " + std::to_string(multiFrame->t_ns) +
+                    (imuMeasurements.empty() ? std::string() : " (measurements " + std::to_string(imuMeasurements.front().t_ns) + " .. " +
+                                                                    std::to_string(imuMeasurements.back().t_ns) + ")"));                    // :150-153
   }
-  if (findState(multiFrame->id)) return false;  // "pose ID was used before" (:161-163)
+  if (findState(multiFrame->id)) return refuse("addStates: pose id " + std::to_string(multiFrame->id) + " was used before");  // "pose ID was used before" (:161-163)
   // the reference orders its states by frame id (statesMap_, std::map) and takes rbegin() as the previous one; ids come from
   // IdProvider and increase.  This class keeps insertion order, which is the same thing only for increasing ids: enforced.
-  if (!states_.empty() && multiFrame->id <= states_.back().id) return false;
+  if (!states_.empty() && multiFrame->id <= states_.back().id)
+    return refuse("addStates: frame id " + std::to_string(multiFrame->id) + " does not follow " + std::to_string(states_.back().id));
   // nothing is changed before every input is known to be usable (extrinsics of the cameras that get a block of their own)
   for (size_t i = 0; i < extrinsicsEstimationParametersVec_.size(); ++i) {
     const ExtrinsicsEstimationParameters& ep = extrinsicsEstimationParametersVec_[i];
     const bool shared = (ep.sigma_c_relative_translation < 1e-12 || ep.sigma_c_relative_orientation < 1e-12) && !states_.empty();
-    if (!shared && i >= multiFrame->T_SC.size()) return false;
+    if (!shared && i >= multiFrame->T_SC.size()) return refuse("addStates: the multiframe has no extrinsics for camera " + std::to_string(i));
   }
 
   State st;
@@ -257,7 +263,7 @@ bool Estimator::addStates(MultiFramePtr multiFrame, const ImuMeasurementDeque& i
     if ((ep.sigma_c_relative_translation < 1e-12 || ep.sigma_c_relative_orientation < 1e-12) && !first) {
       st.extBlocks.push_back(states_.back().extBlocks.at(i));  // use the same block
     } else {
-      if (i >= multiFrame->T_SC.size()) return false;
+      if (i >= multiFrame->T_SC.size()) return refuse("addStates: the multiframe has no extrinsics for camera " + std::to_string(i));
       st.extBlocks.push_back((int)poseBlocks_.size());
       poseBlocks_.push_back(PoseBlock{multiFrame->T_SC[i].p, false, nextId_++});
     }

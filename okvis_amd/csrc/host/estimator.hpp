@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -112,6 +113,7 @@ class Estimator {
   bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks);
   // test hook: the next applyMarginalizationStrategy throws where the GPU call would be (exercises the roll-back)
   void debugFailNextMarginalization() { debugFailMarg_ = true; }
+  const std::string& lastRefusal() const { return lastRefusal_; }
   // diagnostics hook: called by optimize() with the flattened window it is about to upload (stage 0) and again with the
   // same window carrying the optimised pose / sb / lm arrays (stage 1); pointers are valid during the call only.  Lets a
   // test hand the very same problem to another solver and compare in the window's own indexing; not used by the product.
@@ -247,6 +249,12 @@ class Estimator {
 
   const State* findState(uint64_t id) const;
   State* findState(uint64_t id);
+  // why the last addStates returned false (the reference logs the reason and returns false, Estimator.cpp:121-163)
+  bool refuse(const std::string& why) {
+    lastRefusal_ = why;
+    return false;
+  }
+  std::string lastRefusal_;
   WindowSel selectAll() const;
   void flatten(const WindowSel& sel, FlatWindow& fw) const;
 

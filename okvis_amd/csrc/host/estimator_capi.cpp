@@ -93,7 +93,11 @@ int okvis_est_add_states(void* h, void* frame, int n_imu, const int64_t* t, cons
         d[i].acc[c] = acc[3 * i + c];
       }
     }
-    return static_cast<Estimator*>(h)->addStates(*static_cast<MultiFramePtr*>(frame), d, asKeyframe != 0) ? 1 : 0;
+    Estimator* e = static_cast<Estimator*>(h);
+    if (e->addStates(*static_cast<MultiFramePtr*>(frame), d, asKeyframe != 0)) return 1;
+    g_err = e->lastRefusal();   // (okvis_est_last_error)
+    if (g_err.empty()) g_err = "addStates returned false without a reason (" + std::to_string(e->numFrames()) + " frames in the window)";
+    return 0;
   });
 }
 int okvis_est_add_landmark(void* h, uint64_t id, const double hp[4]) {

@@ -158,6 +158,10 @@ class Estimator:
         return bool(self._c(self._api.okvis_est_add_states(self._h, frame._h, int(t.size), t.ctypes.data_as(_lp),
                                                    gyr.ctypes.data_as(_dp), acc.ctypes.data_as(_dp), int(asKeyframe))))
 
+    def last_error(self) -> str:
+        """Text of the last refusal / exception of this thread's calls (okvis_est_last_error)."""
+        return self._api.okvis_est_last_error().decode()
+
     def addLandmark(self, lm_id, hp):
         return bool(self._c(self._api.okvis_est_add_landmark(self._h, C.c_uint64(lm_id), _d(hp).ctypes.data_as(_dp))))
 

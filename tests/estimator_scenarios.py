@@ -27,7 +27,9 @@ def sliding_window(make_estimator, make_frame, n_frames=12, num_keyframes=5, num
     k_intr = synthetic.TEST_INTR_EQUI if model == DIST_EQUIDISTANT else synthetic.TEST_INTR_RADTAN
     intr = np.stack([k_intr, k_intr])
     pts = np.array([[3.0, y, z, 1.0] for y in np.arange(-6.0, DURATION + 6.0, 0.75) for z in np.arange(-6.0, 6.0 + 1e-9, 0.75)])
-    ids = 5000 + np.arange(len(pts))
+    # ids far away from anything the reference's process-wide IdProvider (IdProvider.cpp:46-52, a counter from 1) hands out for its
+    # speed/bias and extrinsics blocks: a frame id it has already used makes okvis::Estimator::addStates refuse the frame
+    ids = 5_000_000 + np.arange(len(pts))
     lm_noise = rng.normal(size=(len(pts), 3)) * 0.05
     px_noise = rng.uniform(-1, 1, (n_frames, 2, len(pts), 2))
 
@@ -40,11 +42,11 @@ def sliding_window(make_estimator, make_frame, n_frames=12, num_keyframes=5, num
     for k in range(n_frames):
         t_k = 1_000_000_000 + int(round(k * FRAME_DT * 1e9))
         r_k = speed * k * FRAME_DT
-        f = make_frame(100 + k, t_k, T_SC, intr, [model] * 2)
+        f = make_frame(1_000_000 + k, t_k, T_SC, intr, [model] * 2)
         frames.append(f)
         lo = np.searchsorted(t_imu, (prev_t if k else t_k) - 20_000_000)
         hi = np.searchsorted(t_imu, t_k + 20_000_000) + 1
-        assert est.addStates(f, t_imu[lo:hi], gyr[lo:hi], acc[lo:hi], k % 3 == 0)
+        assert est.addStates(f, t_imu[lo:hi], gyr[lo:hi], acc[lo:hi], k % 3 == 0), (type(est).__name__, k, est.last_error() if hasattr(est, 'last_error') else None)
         prev_t = t_k
         n_obs = 0
         for i in range(2):
