@@ -414,6 +414,68 @@ def main():
         config_c = {"workload": f"1 window, 50 KF / 2 cam / 2000 landmarks / {wc.n_obs} observations, D = {wc.reduced_dim()}, Gauss-Newton mode",
                     "ms_per_iteration": float(np.median(msc)), "iterations_per_s": 1e3 / float(np.median(msc)),
                     "launch_us": plc, "note": "launch_us.solve = assembly + tile export + tiled fp64-MFMA Cholesky + tail (four launches)"}
+    frame_host = None
+    if rank == 0 and not a.no_extras and not a.pmc_child:
+        # ---- what surrounds the iterations of one frame of the estimator (one window, 8 frames, replay-sized): structure upload,
+        #      the same change as an okvis_ba_patch (newest frame replaced), one marginalisation call
+        try:
+            from okvis_amd.window import Patch
+            wf = synthetic.make_window(8, 430, 0.5, seed=20240924)
+            K, npz = 8, wf.n_pose
+            newest = np.flatnonzero(np.asarray(wf.obs_pose) == K - 1)
+            pf = Patch(remove_pose=[K - 1], remove_sb=[K - 1], add_pose=wf.pose[K - 1:K], add_pose_fixed=[0], add_sb=wf.sb[K - 1:K],
+                       add_sb_fixed=[0], add_obs_lm=wf.obs_lm[newest], add_obs_pose=np.full(newest.size, npz - 1),
+                       add_obs_ext=np.asarray(wf.obs_ext)[newest] - 1, add_obs_cam=wf.obs_cam[newest], add_obs_uv=wf.obs_uv[newest],
+                       add_obs_sqrtw=wf.obs_sqrtw[newest], add_imu_pose0=[K - 2], add_imu_sb0=[K - 2], add_imu_pose1=[npz - 1],
+                       add_imu_sb1=[K - 1], add_imu_t0=wf.imu_t0[-1:], add_imu_t1=wf.imu_t1[-1:], add_imu_s_begin=[0],
+                       add_imu_s_count=wf.imu_s_count[-1:],
+                       add_imu_s_t=wf.imu_s_t[wf.imu_s_begin[-1]:wf.imu_s_begin[-1] + wf.imu_s_count[-1]],
+                       add_imu_s_gyr=wf.imu_s_gyr[wf.imu_s_begin[-1]:wf.imu_s_begin[-1] + wf.imu_s_count[-1]],
+                       add_imu_s_acc=wf.imu_s_acc[wf.imu_s_begin[-1]:wf.imu_s_begin[-1] + wf.imu_s_count[-1]])
+            fopt = default_options()
+            bf = solver.WindowBatch([wf], device=local_rank, options=fopt, patchable=True)
+            bf.optimize(3)
+            t_up, t_patch, t_opt = [], [], []
+            import ctypes as C
+            pc, keep_p = pf.as_c()
+            from okvis_amd.window import WindowC
+            wfc, keep_w = wf.as_c()
+            arr_w = (WindowC * 1)(wfc)
+            for rep in range(12):
+                bf.synchronize()
+                t0 = time.perf_counter()
+                rcu = bf._L.okvis_ba_upload(bf._h, 1, arr_w)   # (the C call itself: no Python marshalling in the timed part)
+                t1 = time.perf_counter()
+                assert rcu == 0, rcu
+                bf.optimize(10)
+                t2 = time.perf_counter()
+                rcp = bf._L.okvis_ba_patch_window(bf._h, 0, C.byref(pc))
+                t3 = time.perf_counter()
+                assert rcp == 0, rcp
+                if rep >= 2:
+                    t_up.append(t1 - t0); t_opt.append(t2 - t1); t_patch.append(t3 - t2)
+            n_obs_after = bf.patched_view(0).n_obs
+            bf.close()
+            wm = synthetic.small_window(seed=9, K=6, L=150, visibility=0.8)
+            pmm = np.zeros(wm.n_pose, np.uint8); smm = np.zeros(wm.n_sb, np.uint8); pmm[0] = 1; smm[[0, 1]] = 1
+            bm = solver.WindowBatch([wm], device=local_rank, options=default_options())
+            t_marg = []
+            for rep in range(14):
+                t0 = time.perf_counter()
+                gm = bm.marginalize(0, pmm, smm)
+                if rep >= 2:
+                    t_marg.append(time.perf_counter() - t0)
+            bm.close()
+            frame_host = {"window": f"8 frames / {wf.n_lm} landmarks / {wf.n_obs} observations (the replay's size), one-window solver",
+                          "upload_ms": float(np.median(t_up)) * 1e3, "optimize10_ms": float(np.median(t_opt)) * 1e3,
+                          "patch_newest_frame_ms": float(np.median(t_patch)) * 1e3, "observations_after_patch": int(n_obs_after),
+                          "marginalize_ms": float(np.median(t_marg)) * 1e3, "marginalize_kept_dim": int(gm["dim"]),
+                          "note": "host wall clock through ctypes; upload = okvis_ba_upload (index build + arena fill), patch = "
+                                  "okvis_ba_patch_window replacing the newest frame with its observations and IMU term (container edit + "
+                                  "the same index build; the blocks that stay keep the device's values), marginalize = one "
+                                  "okvis_ba_marginalize call on a 6-frame sub-window (150 landmarks, one pose and two speed/bias blocks eliminated)"}
+        except Exception as e:   # a diagnostic record must never take the bench line with it
+            frame_host = {"error": repr(e)}
     if not a.no_extras and not a.pmc_child and world > 1 and a.total_windows == 0:
         # ---- BASELINE configs[3] as written: 64 windows IN TOTAL over the ranks (strong scaling), next to the weak line
         tw = 64
@@ -464,7 +526,7 @@ def main():
                                               "max": max(walls) * 1e3 / a.steps}},
             "window_records": {"fields": ["window_id", "iterations", "final_cost", "seconds"], "n": len(records),
                                "first": records[:2], "collective": (f"one all_gather, backend {dist.get_backend()}" + (" (= RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else "none (1 rank)"},
-            "single_window": single, "roofline": roofline, "dogleg": dogleg, "config_C": config_c, "frontend": frontend, "strong_scaling_64_windows": strong,
+            "single_window": single, "roofline": roofline, "dogleg": dogleg, "config_C": config_c, "frontend": frontend, "frame_host": frame_host, "strong_scaling_64_windows": strong,
             "ranks_seen_by_collective": world if dist is None else dist.get_world_size(),
             "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "speedup_vs_cpu": None if cpu is None else {

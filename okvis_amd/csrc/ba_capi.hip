@@ -1553,15 +1553,36 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
   // the final accept/reject needs the Schur partials of the buffer it may accept (gradient test)
   HIP_TRY(launch_schur(s, whole(s), 1));
   HIP_TRY(launch_solve(s, whole(s), 1));
+  // landmark quality, the packed results of a one-window solver (the estimator's case: okvis_ba_fetch_results then costs no
+  // launch, no copy and no synchronisation of its own) and the control records, all behind ONE synchronisation
+  std::vector<Ctrl> cs;
+  size_t res_bytes = 0;
+  auto finalize = [&]() -> int {
+    if (s->max_lm > 0) {
+      hipLaunchKernelGGL(quality_kernel, dim3((s->max_lm + 255) / 256, (unsigned)s->wins.size()), dim3(256), 0, s->stream, s->d_wins);
+      HIP_TRY(hipGetLastError());
+    }
+    if (s->wins.size() == 1) {
+      const HostWin& H0 = s->wins[0];
+      res_bytes = 56 * (size_t)H0.n_pose + 72 * (size_t)H0.n_sb + 40 * (size_t)H0.n_lm + 72 * (size_t)H0.n_imu;
+      if (res_bytes) {
+        s->stage_res.resize(res_bytes);
+        hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s->stream, s->d_wins, -1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(s->stage_res.data(), H0.ptrs.results, res_bytes, hipMemcpyDeviceToHost, s->stream));
+      }
+    }
+    return fetch_ctrl(s, cs);
+  };
+  int rc = finalize();
+  if (rc != OKVIS_BA_OK) return rc;
   if (s->opt.strategy == OKVIS_BA_STRATEGY_DOGLEG && !s->opt.gauss_newton) {
     // Dogleg: a launch slot that had to redo a mis-speculated Gauss-Newton trial as an explicit dogleg step did not
     // finish an iteration, and the decision just taken may itself ask for such a redo.  Windows that still owe
     // iterations of this call's budget get the missing slots (the others are stopped by the budget), then the final
-    // decision is taken again.  Rare: only when the Gauss-Newton point lies outside the trust region.
+    // decision (and what hangs on it) is taken again.  Rare: only when the Gauss-Newton point lies outside the trust region —
+    // the common case pays one synchronisation for the whole finish.
     for (int round = 0; round < 64 && !s->skip_topup; ++round) {
-      std::vector<Ctrl> cs;
-      int rc = fetch_ctrl(s, cs);
-      if (rc != OKVIS_BA_OK) return rc;
       int need = 0;
       for (const Ctrl& c : cs) {
         if (c.done) continue;
@@ -1574,28 +1595,10 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
       HIP_TRY(launch_iterations_forked(s, need, 0));   // (on the sub-batch streams like every other iteration; no new budget)
       HIP_TRY(launch_schur(s, whole(s), 1));
       HIP_TRY(launch_solve(s, whole(s), 1));
+      rc = finalize();
+      if (rc != OKVIS_BA_OK) return rc;
     }
   }
-  if (s->max_lm > 0) {
-    hipLaunchKernelGGL(quality_kernel, dim3((s->max_lm + 255) / 256, (unsigned)s->wins.size()), dim3(256), 0, s->stream, s->d_wins);
-    HIP_TRY(hipGetLastError());
-  }
-  // a solver with one window (the estimator's case): its packed results ride on the same synchronisation as the control record,
-  // okvis_ba_fetch_results then costs no launch, no copy and no synchronisation of its own
-  size_t res_bytes = 0;
-  if (s->wins.size() == 1) {
-    const HostWin& H0 = s->wins[0];
-    res_bytes = 56 * (size_t)H0.n_pose + 72 * (size_t)H0.n_sb + 40 * (size_t)H0.n_lm + 72 * (size_t)H0.n_imu;
-    if (res_bytes) {
-      s->stage_res.resize(res_bytes);
-      hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s->stream, s->d_wins, -1);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(s->stage_res.data(), H0.ptrs.results, res_bytes, hipMemcpyDeviceToHost, s->stream));
-    }
-  }
-  std::vector<Ctrl> cs;
-  int rc = fetch_ctrl(s, cs);
-  if (rc != OKVIS_BA_OK) return rc;
   s->res_staged = res_bytes > 0;
   for (size_t i = 0; i < s->wins.size(); ++i) {
     s->wins[i].acc = cs[i].acc;

@@ -18,6 +18,7 @@ class Carving:
         self.pose_prior_on = pose_prior_on    # list of pose identities that carry an absolute prior (None: W's own, if included)
         self.sb_prior_on = sb_prior_on
         self.marg = marg                      # None or dict(ids=[('p', pose_id) | ('s', frame)], J, e0, lin)
+        self.imu_first = []                   # IMU terms of W that come first, in this order (the ones an edited window already had)
 
     def _pose_block(self, ident):
         K = self.W.meta["K"]
@@ -43,6 +44,7 @@ class Carving:
         w.sort_observations()
         # IMU terms of W whose four blocks are here, in W's order
         fs = [f for f in range(W.n_imu) if W.imu_pose0[f] in pmap and W.imu_pose1[f] in pmap and W.imu_sb0[f] in smap and W.imu_sb1[f] in smap]
+        fs = [f for f in self.imu_first if f in fs] + [f for f in fs if f not in self.imu_first]
         self.imu_terms = fs
         w.imu_pose0 = np.array([pmap[int(W.imu_pose0[f])] for f in fs], np.int32)
         w.imu_pose1 = np.array([pmap[int(W.imu_pose1[f])] for f in fs], np.int32)
@@ -123,7 +125,9 @@ def patch_between(A: Carving, B: Carving) -> Patch:
     p.remove_pose = np.array([n for n, i in enumerate(A.pose_ids) if i not in B.pose_ids], np.int32)
     p.remove_sb = np.array([n for n, k in enumerate(A.sb_ids) if k not in B.sb_ids], np.int32)
     p.remove_lm = np.array([n for n, l in enumerate(A.lm_ids) if l not in B.lm_ids], np.int32)
-    wa, wb = A.window(), B.window()
+    wa = A.window()
+    B.imu_first = list(A.imu_terms)      # appended terms go behind the ones that stay
+    wb = B.window()
     K = W.meta["K"]
     # observations by identity (lm of W, pose block of W, ext block of W, cam, u, v)
     def ident(C, w):

@@ -121,3 +121,40 @@ def test_c_abi_rejects_null_arguments():
     L.okvis_ba_store_destroy(None)
     assert L.okvis_ba_set_patchable(None, 1) == -1 and L.okvis_ba_patch_window(None, 0, None) == -1
     assert L.okvis_ba_patched_view(None, 0, None) == -1
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_edits(seed):
+    """Random subsets of frames / speed-bias blocks / landmarks / observations leave, random ones arrive (blocks in the middle of the
+    window, not only the oldest): the container equals the window built from scratch, and stays a valid upload."""
+    rng = np.random.default_rng(1000 + seed)
+    K, L = int(rng.integers(5, 9)), int(rng.integers(30, 90))
+    W = synthetic.make_window(K, L, float(rng.uniform(0.5, 1.0)), seed=2000 + seed, frame_dt=0.2)
+    ext = [("e", 0), ("e", 1)]
+    frames = list(range(K))
+    a_frames = sorted(rng.choice(frames, int(rng.integers(3, K)), replace=False).tolist())
+    gone = [k for k in a_frames if rng.uniform() < 0.3]
+    arrive = [k for k in frames if k not in a_frames and rng.uniform() < 0.7]
+    b_frames = [k for k in a_frames if k not in gone] + arrive
+    if not b_frames:
+        b_frames = [a_frames[0]]
+    lms = list(range(L))
+    a_lm = sorted(rng.choice(lms, int(rng.integers(L // 3, L)), replace=False).tolist())
+    b_lm = [l for l in a_lm if rng.uniform() > 0.25] + [l for l in lms if l not in a_lm and rng.uniform() < 0.5]
+    A = Carving(W, [("f", k) for k in a_frames] + ext, a_frames, a_lm)
+    cand = [(int(W.obs_lm[i]), int(W.obs_pose[i]), int(W.obs_cam[i])) for i in range(W.n_obs)
+            if W.obs_lm[i] in a_lm and W.obs_lm[i] in b_lm and W.obs_pose[i] in a_frames and W.obs_pose[i] in b_frames]
+    drop = [cand[i] for i in rng.choice(len(cand), min(len(cand), int(rng.integers(0, 12))), replace=False)] if cand else []
+    # speed/bias blocks may leave without their frame (Estimator::applyMarginalizationStrategy drops the speed/bias of old keyframes)
+    b_sb = [k for k in b_frames if k in arrive or rng.uniform() > 0.2]
+    kept_f = [k for k in a_frames if k in b_frames]
+    B = Carving(W, [("f", k) for k in kept_f] + ext + [("f", k) for k in arrive],
+                [k for k in a_frames if k in b_sb] + [k for k in arrive if k in b_sb], b_lm, drop_obs=drop,
+                pose_prior_on=[("f", b_frames[0])], sb_prior_on=b_sb[:1] if b_sb else [],
+                marg=make_marg(W, [("p", ("f", b_frames[0]))] + ([("s", b_sb[0])] if b_sb else []), rng))
+    st = solver.WindowStore(A.window())
+    assert st.patch(patch_between(A, B)) == 0
+    got, want = st.view(), B.window()
+    assert windows_differ(got, want) == []
+    assert structure(got) == structure(want)
+    st.close()
