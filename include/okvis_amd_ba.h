@@ -315,7 +315,9 @@ void okvis_ba_store_destroy(okvis_ba_window_store* st);
  * okvis_ba_patch_window edits window w in place of a re-flatten + re-upload by the caller: the blocks that stay keep the values the
  * DEVICE holds (the accepted state of the last optimisation, the bias every IMU term's preintegration was last built at), the
  * index is rebuilt and the arena re-filled from the container.  Results are bit-identical to uploading okvis_ba_store_view of
- * the same edits with those values.  OKVIS_BA_ERR_STATE: solver not patchable or nothing uploaded. */
+ * the same edits with those values.  All or nothing: a patch that is rejected (OKVIS_BA_ERR_ARG) or whose result exceeds a structure
+ * limit of okvis_ba_upload (that status) leaves the solver with the window it had, values included.
+ * OKVIS_BA_ERR_STATE: solver not patchable or nothing uploaded. */
 int okvis_ba_set_patchable(okvis_ba_solver* s, int on);
 int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p);
 /* the container of window w of a patchable solver as it stands (pointers valid until the next upload / patch) */

@@ -65,3 +65,25 @@ def test_patch_in_a_batch_and_state_errors():
     fresh = solver.WindowBatch([v0, v1], options=default_options())
     assert b.optimize(4) == fresh.optimize(4)
     b.close(); fresh.close()
+
+
+def test_patch_beyond_a_structure_limit_leaves_the_solver_as_it_was():
+    """The edit itself is legal, its result is not (one landmark with more observations than okvis_ba_limits::max_obs_per_lm): the
+    status of the upload check comes back and the solver still holds the old window with its optimised values."""
+    import ctypes as C
+    A, _ = sliding_pair(seed=60, K=5, L=60)
+    w = A.window()
+    b = solver.WindowBatch([w], options=default_options(), patchable=True)
+    b.optimize(3)
+    before = [np.asarray(a).copy() for a in b.get_state(0)]
+    n = solver.limits()["max_obs_per_lm"] + 1
+    too_many = Patch(add_obs_lm=np.zeros(n, np.int32), add_obs_pose=np.zeros(n, np.int32), add_obs_ext=np.full(n, 5, np.int32),
+                     add_obs_cam=np.zeros(n, np.int32), add_obs_uv=np.zeros((n, 2)), add_obs_sqrtw=np.ones(n))
+    pc, keep = too_many.as_c()
+    assert b._L.okvis_ba_patch_window(b._h, 0, C.byref(pc)) == -3
+    assert windows_differ(b.patched_view(0), w) == ["pose", "sb", "lm"]       # structure untouched, values = the device's
+    for a, c in zip(b.get_state(0), before):
+        assert np.array_equal(np.asarray(a), c)
+    s1 = b.optimize(2)[0]
+    assert s1["iterations"] >= 1 and np.isfinite(s1["final_cost"])
+    b.close()
