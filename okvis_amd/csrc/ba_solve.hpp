@@ -509,12 +509,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           const int nch = W.n_chunk;
           auto sp = W.spart + (DBUF ? (size_t)__builtin_amdgcn_readfirstlane(gctrl->pending ? 1 - gctrl->acc : gctrl->acc) * W.spart_buf_stride : (size_t)0) + i;   // (the speculated buffer)
           double a = 0;
-          for (int ch = 0; ch < nch; ch += 16) {
-            double v[16];
+          // (every chunk of a fused window - up to 34 for configs[1] - requested in ONE trip: the helpers' loads come from other
+          // CUs' stores, a trip costs a full memory round trip and there is nothing else to do meanwhile)
+          constexpr int HB = 18;
+          for (int ch = 0; ch < nch; ch += HB) {
+            double v[HB];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride] : 0.0;
+            for (int u = 0; u < HB; ++u) v[u] = (ch + u < nch) ? sp[(size_t)(ch + u) * stride] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a += v[u];
+            for (int u = 0; u < HB; ++u) a += v[u];
           }
           // device-coherent store (written through): with the plain store the hand-over needed an agent-scope release,
           // which writes this XCD's whole L2 back (3.5 us, profiles/r03_notes.md) before the counter could be raised
@@ -667,16 +670,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         if (!use_sums) {
           // large launches: summed here, lanes on consecutive doubles, three items per lane and eight chunks per trip requested
           // together (the loads come from other CUs' stores: what counts is the number of dependent rounds)
-          for (int ch = 0; ch < nch; ch += 8) {
-            double v[3][8];
+          constexpr int CB = 8;   // chunks per trip (a fused window has up to 34 chunks, a separate Schur launch 9)
+          for (int ch = 0; ch < nch; ch += CB) {
+            double v[3][CB];
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-              for (int u = 0; u < 8; ++u) v[t][u] = (ch + u < nch && base + t * NL < ntot) ? sp[(size_t)(ch + u) * stride + base + t * NL] : 0.0;
+              for (int u = 0; u < CB; ++u) v[t][u] = (ch + u < nch && base + t * NL < ntot) ? sp[(size_t)(ch + u) * stride + base + t * NL] : 0.0;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-              for (int u = 0; u < 8; ++u) a[t] += v[t][u];
+              for (int u = 0; u < CB; ++u) a[t] += v[t][u];
           }
         }
 #pragma unroll
