@@ -650,8 +650,15 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       std::vector<int> coloff, color;
       std::vector<int4> table;
     };
-    static thread_local ImuAsmCache asm_cache;
-    const bool asm_hit = asm_cache.D == D && asm_cache.coloff == imu_coloff && asm_cache.color == imu_color;
+    // (four entries, replaced in turn: the estimator alternates between the window it optimises and the sub-window it marginalises)
+    static thread_local ImuAsmCache asm_caches[4];
+    static thread_local int asm_next = 0;
+    int hit = -1;
+    for (int k = 0; k < 4 && hit < 0; ++k)
+      if (asm_caches[k].D == D && asm_caches[k].coloff == imu_coloff && asm_caches[k].color == imu_color) hit = k;
+    const bool asm_hit = hit >= 0;
+    ImuAsmCache& asm_cache = asm_caches[asm_hit ? hit : asm_next];
+    if (!asm_hit) asm_next = (asm_next + 1) & 3;
     std::vector<int4>& imu_asm = asm_cache.table;
     if (!asm_hit) {
       asm_cache.D = D;
