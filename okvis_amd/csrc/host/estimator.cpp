@@ -408,9 +408,14 @@ Estimator::WindowSel Estimator::selectAll() const {
     if (sbBlocks_[i].alive) sel.sb.push_back((int)i);
   // a landmark nobody observes has no residual block: Ceres drops such parameter blocks from the program it solves (they
   // keep their value); optimize() gives them the quality 0 the reference derives from their zero H (Estimator.cpp:890-893)
+  sel.landmarks.reserve(landmarksMap_.size());
+  sel.lmPtr.reserve(landmarksMap_.size());
   for (const auto& kv : landmarksMap_)
-    if (!kv.second.observations.empty()) sel.landmarks.push_back(kv.first);
-  for (const auto& kv : observations_) sel.obs.push_back(kv.first);
+    if (!kv.second.observations.empty()) {
+      sel.landmarks.push_back(kv.first);
+      sel.lmPtr.push_back(&kv.second);
+    }
+  sel.allObservations = true;   // (every observation belongs to a landmark of the map: nothing else to list)
   for (size_t i = 0; i < imuFactors_.size(); ++i) sel.imu.push_back((int)i);
   for (size_t i = 0; i < posePriors_.size(); ++i) sel.pprior.push_back((int)i);
   for (size_t i = 0; i < sbPriors_.size(); ++i) sel.sbprior.push_back((int)i);
@@ -452,15 +457,16 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
     f64[F_SB].insert(f64[F_SB].end(), x, x + 9);
     u8[1].push_back(sbBlocks_[b].fixed ? 1 : 0);
   }
+  const bool walk = sel.allObservations && sel.lmPtr.size() == sel.landmarks.size();
   std::unordered_map<uint64_t, int> lmIndex;
-  lmIndex.reserve(2 * sel.landmarks.size() + 1);
+  if (!walk) lmIndex.reserve(2 * sel.landmarks.size() + 1);
   f64[F_LM].reserve(4 * sel.landmarks.size());
-  for (uint64_t id : sel.landmarks) {
-    const int idx = (int)lmIndex.size();
-    lmIndex[id] = idx;
-    const MapPoint& mp = landmarksMap_.at(id);
+  for (size_t n = 0; n < sel.landmarks.size(); ++n) {
+    if (!walk) lmIndex[sel.landmarks[n]] = (int)n;
+    const MapPoint& mp = walk ? *sel.lmPtr[n] : landmarksMap_.at(sel.landmarks[n]);
     f64[F_LM].insert(f64[F_LM].end(), mp.point.begin(), mp.point.end());
   }
+  const size_t nLandmarks = sel.landmarks.size();
   // cameras: one intrinsics record per camera index of the newest multiframe
   size_t ncam = 0;
   if (!states_.empty()) {
@@ -477,20 +483,41 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
     double u, v, sw;
   };
   std::vector<Rec> recs;
-  recs.reserve(sel.obs.size());
-  for (uint64_t hnd : sel.obs) {
-    const Observation& o = observations_.at(hnd);
-    if (o.camIdx >= ncam) continue;
-    auto li = lmIndex.find(o.landmarkId);
-    if (li == lmIndex.end()) continue;
-    const int ip = fw.poseMap[o.poseBlock], ie = fw.poseMap[o.extBlock];
-    if (ip < 0 || ie < 0) throw Exception("flatten: observation refers to a block outside the window");
-    recs.push_back(Rec{li->second, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw});
+  auto byPoseCam = [](const Rec& a, const Rec& b) {
+    if (a.pose != b.pose) return a.pose < b.pose;
+    return a.cam < b.cam;
+  };
+  if (walk) {
+    // landmark by landmark through its own observation map: the records of one landmark arrive together and in (frame, camera,
+    // keypoint) order, which is (pose index, camera) order because pose blocks are created in frame order
+    recs.reserve(observations_.size());
+    for (size_t n = 0; n < nLandmarks; ++n) {
+      const size_t first = recs.size();
+      for (const auto& ob : sel.lmPtr[n]->observations) {
+        const Observation& o = observations_.at(ob.second);
+        if (o.camIdx >= ncam) continue;
+        const int ip = fw.poseMap[o.poseBlock], ie = fw.poseMap[o.extBlock];
+        if (ip < 0 || ie < 0) throw Exception("flatten: observation refers to a block outside the window");
+        recs.push_back(Rec{(int)n, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw});
+      }
+      if (!std::is_sorted(recs.begin() + first, recs.end(), byPoseCam)) std::stable_sort(recs.begin() + first, recs.end(), byPoseCam);
+    }
+  } else {
+    recs.reserve(sel.obs.size());
+    for (uint64_t hnd : sel.obs) {
+      const Observation& o = observations_.at(hnd);
+      if (o.camIdx >= ncam) continue;
+      auto li = lmIndex.find(o.landmarkId);
+      if (li == lmIndex.end()) continue;
+      const int ip = fw.poseMap[o.poseBlock], ie = fw.poseMap[o.extBlock];
+      if (ip < 0 || ie < 0) throw Exception("flatten: observation refers to a block outside the window");
+      recs.push_back(Rec{li->second, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw});
+    }
   }
-  {
+  if (!walk) {
     // counting sort by landmark (dense indices), then the handful of observations of each landmark by (pose, camera):
     // linear instead of n log n comparisons on the whole list
-    const size_t nl = lmIndex.size();
+    const size_t nl = nLandmarks;
     std::vector<int> start(nl + 1, 0);
     for (const Rec& r : recs) ++start[r.lm + 1];
     for (size_t l = 0; l < nl; ++l) start[l + 1] += start[l];
@@ -498,10 +525,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
     std::vector<int> fill(start.begin(), start.end() - 1);
     for (const Rec& r : recs) sorted[fill[r.lm]++] = r;
     for (size_t l = 0; l < nl; ++l)
-      std::sort(sorted.begin() + start[l], sorted.begin() + start[l + 1], [](const Rec& a, const Rec& b) {
-        if (a.pose != b.pose) return a.pose < b.pose;
-        return a.cam < b.cam;
-      });
+      std::sort(sorted.begin() + start[l], sorted.begin() + start[l + 1], byPoseCam);
     recs.swap(sorted);
   }
   i32[I_OLM].reserve(recs.size());
@@ -561,7 +585,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
   }
   w.n_pose = (int)u8[0].size(); w.pose = f64[F_POSE].data(); w.pose_fixed = u8[0].data();
   w.n_sb = (int)u8[1].size(); w.sb = f64[F_SB].data(); w.sb_fixed = u8[1].data();
-  w.n_lm = (int)lmIndex.size(); w.lm = f64[F_LM].data();
+  w.n_lm = (int)nLandmarks; w.lm = f64[F_LM].data();
   w.n_cam = (int)ncam; w.cam_intr = f64[F_INTR].data(); w.cam_model = i32[I_MODEL].data();
   w.n_obs = (int)recs.size();
   w.obs_lm = i32[I_OLM].data(); w.obs_pose = i32[I_OPOSE].data(); w.obs_ext = i32[I_OEXT].data(); w.obs_cam = i32[I_OCAM].data();
@@ -805,6 +829,8 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
   const uint64_t currentKfId = allLinearizedFrames.at(0);
   std::vector<uint64_t> selObs;
   std::unordered_set<uint64_t> selObsSet;  // membership test of selObs
+  std::unordered_set<uint64_t> margLandmarkSet;   // membership test of margLandmarks (only consulted for a second removed frame)
+  std::vector<uint64_t> residuals;               // (one buffer for every landmark of the loop below)
   for (size_t rf = 0; rf < removeFrames.size(); ++rf) {
     size_t k = 0;
     while (states_[k].id != removeFrames[rf]) ++k;
@@ -823,11 +849,11 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
     // now finally we treat all the observations (:620-725)
     for (auto pit = landmarksMap_.begin(); pit != landmarksMap_.end();) {
       MapPoint& mp = pit->second;
-      if (std::find(margLandmarks.begin(), margLandmarks.end(), pit->first) != margLandmarks.end()) {
+      if (rf > 0 && margLandmarkSet.count(pit->first)) {
         ++pit;  // already scheduled (the reference erased it from landmarksMap_ at that point, :715-719)
         continue;
       }
-      std::vector<uint64_t> residuals;  // reprojection residuals still in the map
+      residuals.clear();  // reprojection residuals still in the map
       for (const auto& ob : mp.observations)
         if (!selObsSet.count(ob.second)) residuals.push_back(ob.second);
       bool skipLandmark = true, hasNewObservations = false, justDelete = false, marginalize = true, errorTermAdded = false;
@@ -885,6 +911,7 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
       }
       if (marginalize && errorTermAdded) {
         margLandmarks.push_back(pit->first);
+        margLandmarkSet.insert(pit->first);
         removedLandmarks.push_back(mp);
         ++pit;  // the block itself is erased after the numerics below (its value is the linearisation point)
         continue;

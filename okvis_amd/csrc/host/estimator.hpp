@@ -234,6 +234,10 @@ class Estimator {
     std::vector<int> pose, sb;                  // block indices, window order
     std::vector<uint64_t> landmarks;            // ids, window order
     std::vector<uint64_t> obs;                  // observation handles
+    // selectAll(): every observation of the listed landmarks is part of the window; flatten() then walks each landmark's own
+    // observation map (already in (frame, camera, keypoint) order) instead of looking every observation's landmark up
+    bool allObservations = false;
+    std::vector<const MapPoint*> lmPtr;         // the listed landmarks (valid until the maps change)
     std::vector<int> imu, pprior, sbprior, rel; // indices into the factor vectors
     bool withPrior = false;                     // attach prior_ as marg_* (optimize) or not (marginalisation)
     bool atLinearizationPoint = false;          // values of prior-connected blocks = their linearisation point
