@@ -830,7 +830,12 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
   std::vector<uint64_t> selObs;
   std::unordered_set<uint64_t> selObsSet;  // membership test of selObs
   std::unordered_set<uint64_t> margLandmarkSet;   // membership test of margLandmarks (only consulted for a second removed frame)
-  std::vector<uint64_t> residuals;               // (one buffer for every landmark of the loop below)
+  // (one buffer for every landmark of the loop below; the frame id of an observation is part of its key in the landmark's own
+  // observation map, so the loop needs no look-up in observations_)
+  struct Residual {
+    uint64_t handle, poseId;
+  };
+  std::vector<Residual> residuals;
   for (size_t rf = 0; rf < removeFrames.size(); ++rf) {
     size_t k = 0;
     while (states_[k].id != removeFrames[rf]) ++k;
@@ -855,11 +860,11 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
       }
       residuals.clear();  // reprojection residuals still in the map
       for (const auto& ob : mp.observations)
-        if (!selObsSet.count(ob.second)) residuals.push_back(ob.second);
+        if (selObsSet.empty() || !selObsSet.count(ob.second)) residuals.push_back(Residual{ob.second, ob.first.frameId});
       bool skipLandmark = true, hasNewObservations = false, justDelete = false, marginalize = true, errorTermAdded = false;
       size_t obsCount = 0;
-      for (uint64_t hnd : residuals) {
-        const uint64_t poseId = observations_.at(hnd).poseId;
+      for (const Residual& res : residuals) {
+        const uint64_t poseId = res.poseId;
         if (contains(removeFrames, poseId)) skipLandmark = false;
         if (poseId >= currentKfId) {
           marginalize = false;
@@ -879,8 +884,8 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
         continue;
       }
       for (size_t r = 0; r < residuals.size(); ++r) {
-        const uint64_t hnd = residuals[r];
-        const uint64_t poseId = observations_.at(hnd).poseId;
+        const uint64_t hnd = residuals[r].handle;
+        const uint64_t poseId = residuals[r].poseId;
         if ((contains(removeFrames, poseId) && hasNewObservations) ||
             (!contains(allLinearizedFrames, poseId) && marginalize)) {
           removeObservationLogged(hnd);  // ok, let's ignore the observation
