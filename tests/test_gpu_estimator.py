@@ -190,3 +190,29 @@ def test_failed_marginalization_is_rolled_back():
             assert np.array_equal(a["sbs"][fid], b["sbs"][fid])
         for lid in a["landmarks"]:
             assert np.array_equal(a["landmarks"][lid], b["landmarks"][lid])
+
+
+def test_add_states_says_why_it_refuses():
+    """okvis::Estimator::addStates logs a reason and returns false (Estimator.cpp:121-163); the drop-in returns false and keeps the
+    reason for okvis_est_last_error."""
+    prm = ImuParams()
+    T_SC = np.array([[0, 0, 0, 0, 0, 0, 1.0], [0, 0.1, 0, 0, 0, 0, 1.0]])
+    intr = np.stack([synthetic.TEST_INTR_EQUI, synthetic.TEST_INTR_EQUI])
+    t = (np.arange(60) * 10_000_000).astype(np.int64) + 1_000_000_000
+    gyr = np.zeros((60, 3)); acc = np.tile([0.0, 0.0, prm.g], (60, 1))
+    est = estimator.Estimator(0)
+    f0 = estimator.Frame(7, int(t[5]), T_SC, intr, [DIST_EQUIDISTANT] * 2)
+    assert not est.addStates(f0, t[:10], gyr[:10], acc[:10], True) and "IMU parameters" in est.last_error()
+    est.addCamera(0, 0, 0, 0); est.addCamera(0, 0, 0, 0)
+    est.addImu(estimator.imu_param_vector(prm))
+    assert not est.addStates(f0, t[:0], gyr[:0], acc[:0], True) and "initPoseFromImu" in est.last_error()
+    assert est.addStates(f0, t[:10], gyr[:10], acc[:10], True)
+    f1 = estimator.Frame(8, int(t[40]), T_SC, intr, [DIST_EQUIDISTANT] * 2)
+    assert not est.addStates(f1, t[:20], gyr[:20], acc[:20], False)          # measurements end before the frame
+    assert "propagation used -1 of 20" in est.last_error()
+    again = estimator.Frame(7, int(t[40]), T_SC, intr, [DIST_EQUIDISTANT] * 2)
+    assert not est.addStates(again, t[:50], gyr[:50], acc[:50], False) and "was used before" in est.last_error()
+    older = estimator.Frame(3, int(t[40]), T_SC, intr, [DIST_EQUIDISTANT] * 2)
+    assert not est.addStates(older, t[:50], gyr[:50], acc[:50], False) and "does not follow" in est.last_error()
+    assert est.addStates(f1, t[:50], gyr[:50], acc[:50], False) and est.numFrames() == 2
+    est.close()
