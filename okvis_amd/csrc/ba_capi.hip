@@ -355,7 +355,11 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   pair_list.reserve(2 * (size_t)nobs);
   task_list.reserve(3 * (size_t)nobs);
   std::vector<int> blk_slot(npose, -1);                 // scratch: block -> pair of the current landmark / task of the group
-  std::vector<std::vector<uint16_t>> blk_obs(npose);    // scratch: block -> observations of the current group (own role)
+  // scratch: block -> observations of the current group (own role).  Kept between calls (every list is left empty): the lists
+  // grow to a few hundred entries each, once, instead of through ten reallocations per block in every upload
+  static thread_local std::vector<std::vector<uint16_t>> blk_obs;
+  if ((int)blk_obs.size() < npose) blk_obs.resize(npose);
+  for (auto& v : blk_obs) v.clear();   // (whatever an interrupted call may have left)
   std::vector<int> touched;
   for (int g = 0; g < ngroup; ++g) {
     Group& G = groups[g];
