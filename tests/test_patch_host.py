@@ -158,3 +158,33 @@ def test_random_edits(seed):
     assert windows_differ(got, want) == []
     assert structure(got) == structure(want)
     st.close()
+
+
+def test_per_frame_extrinsics_leave_with_their_relative_pose_terms():
+    """A window with one extrinsics block per frame and camera, chained by RelativePoseError terms (TestEstimator.cpp case c = 3):
+    removing frame 0 and its two extrinsics blocks takes its observations, its IMU term, the priors on those blocks and the two
+    relative-pose terms that touch them along; everything else is renumbered in place."""
+    K, NC = 5, 2
+    w = synthetic.small_window(seed=21, K=K, L=40, estimate_extrinsics="perframe")
+    gone = [0, K + 0, K + 1]                                   # T_WS of frame 0, T_SC0 and T_SC1 of frame 0
+    st = solver.WindowStore(w)
+    assert st.patch(Patch(remove_pose=gone, remove_sb=[0])) == 0
+    v = st.view()
+    new = -np.ones(w.n_pose, np.int64)
+    new[[i for i in range(w.n_pose) if i not in gone]] = np.arange(w.n_pose - 3)
+    keep_o = ~np.isin(w.obs_pose, gone) & ~np.isin(w.obs_ext, gone)
+    assert not keep_o.all() and v.n_obs == int(keep_o.sum())
+    assert np.array_equal(v.obs_pose, new[w.obs_pose[keep_o]]) and np.array_equal(v.obs_ext, new[w.obs_ext[keep_o]])
+    assert np.array_equal(v.obs_uv, w.obs_uv[keep_o]) and np.array_equal(v.obs_lm, w.obs_lm[keep_o])
+    keep_r = ~np.isin(w.rel_pose0, gone) & ~np.isin(w.rel_pose1, gone)
+    assert int((~keep_r).sum()) == NC
+    assert np.array_equal(v.rel_pose0, new[w.rel_pose0[keep_r]]) and np.array_equal(v.rel_pose1, new[w.rel_pose1[keep_r]])
+    assert np.array_equal(v.rel_sqrtinfo, w.rel_sqrtinfo[keep_r])
+    keep_p = ~np.isin(w.pprior_pose, gone)
+    assert np.array_equal(v.pprior_pose, new[w.pprior_pose[keep_p]]) and len(v.sbprior_sb) == 0
+    assert v.n_imu == w.n_imu - 1 and np.array_equal(v.imu_pose0, new[w.imu_pose0[1:]]) and np.array_equal(v.imu_sb0, w.imu_sb0[1:] - 1)
+    assert np.array_equal(v.pose, np.delete(w.pose, gone, axis=0)) and np.array_equal(v.sb, w.sb[1:])
+    assert np.array_equal(v.lm, w.lm)                          # landmarks stay, observed or not
+    v.validate()
+    assert solver.check_window(v)["D"] == solver.check_window(w)["D"] - 6 * 3 - 9
+    st.close()
