@@ -18,6 +18,7 @@
 #include "ba_imu.hpp"
 #include "ba_chol_tiles.hpp"
 #include "ba_linearize.hpp"
+#include "ba_linearize2.hpp"
 #include "ba_marg.hpp"
 #include "ba_schur.hpp"
 #include "ba_solve.hpp"
@@ -120,6 +121,8 @@ struct okvis_ba_solver {
   StageVec stage, stage_small;   // pinned staging of the arena's data part / of the WinPtrs + OptD records (kept across uploads)
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
+  bool lin2 = false;          // the batch's index lists are those of the piece path (ba_linearize2.hpp)
+  bool split_small = false;   // piece path: IMU / prior factors in a launch of their own (small_kernel), four linearise workgroups per CU
   bool group_chunks = false;   // every window of the batch has one Schur chunk per linearise group (see fused())
   bool fp32_at_upload = false;
   std::vector<int64_t> launch_sig;   // what the captured graphs depend on (see okvis_ba_upload)
@@ -226,7 +229,26 @@ struct BuildTimes {
 };
 BuildTimes g_build_times;
 
-int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A, HostWin& H, int n_windows_total = 1) {
+// Internal status of build_window(lin2 = true): the window does not fit the piece path of the linearise launch
+// (ba_linearize2.hpp: free extrinsics, or one landmark with more than LIN2_PIECES pieces); the caller rebuilds the batch
+// for ba_linearize.hpp.
+constexpr int BW_LIN2_UNFIT = -1000;
+
+// number of pieces of the observations [o0, o1) of one landmark placed at lanes lane0... of a workgroup (a piece = one or two
+// adjacent observations of the same pose inside one row of 16 lanes, greedy from the start of the run: the rule of
+// linearize2_kernel's phase B)
+inline int count_pieces(const okvis_ba_window& w, int o0, int o1, int lane0) {
+  int n = 0, o = o0;
+  while (o < o1) {
+    int e = o + 1;
+    while (e < o1 && w.obs_pose[e] == w.obs_pose[o] && ((lane0 + (e - o0)) & 15) != 0) ++e;
+    n += (e - o + 1) / 2;
+    o = e;
+  }
+  return n;
+}
+
+int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A, HostWin& H, int n_windows_total = 1, bool lin2 = false) {
   auto bw_t0 = std::chrono::steady_clock::now();
   if (g_build_times.on) g_build_times.calls++;
 #define BW_T(name)                                                                                       \
@@ -286,6 +308,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (lm_obs_begin[l + 1] > GROUP_OBS) return OKVIS_BA_ERR_UNSUPPORTED;
     lm_obs_begin[l + 1] += lm_obs_begin[l];
   }
+  if (lin2 && has_ext) return BW_LIN2_UNFIT;
   BW_T("validate");
   // ---- (landmark, free block) pairs ----
   std::vector<int> pair_lm, pair_block, pair_off, pair_role, lm_pair_begin(nlm + 1, 0);
@@ -328,12 +351,19 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       G.lm_begin = l;
       G.obs_begin = lm_obs_begin[l];
       G.pair_begin = lm_pair_begin[l];
-      int no = 0, np = 0, nl = 0;
+      int no = 0, np = 0, nl = 0, npc = 0;
       while (l < nlm) {
         const int lo = lm_obs_begin[l + 1] - lm_obs_begin[l], lp = lm_pair_begin[l + 1] - lm_pair_begin[l];
+        int lpc = 0;
+        if (lin2) {   // piece path: at most LIN2_PIECES pieces per group (a pair has at least one piece)
+          lpc = count_pieces(w, lm_obs_begin[l], lm_obs_begin[l + 1], no);
+          if (nl == 0 && lpc > LIN2_PIECES) return BW_LIN2_UNFIT;
+          if (nl > 0 && npc + lpc > LIN2_PIECES) break;
+        }
         if (nl > 0 && (no + lo > GROUP_OBS || np + lp > GROUP_PAIRS || nl + 1 > GROUP_LM)) break;
         no += lo;
         np += lp;
+        npc += lpc;
         ++nl;
         ++l;
       }
@@ -341,6 +371,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       G.obs_end = lm_obs_begin[l];
       G.pair_end = lm_pair_begin[l];
       G.task_begin = G.task_end = 0;
+      G.plist_begin = G.plist_end = G.tlist_begin = G.tlist_end = 0;
+      G.piece_begin = G.pw1 = G.pw2 = G.pw3 = 0;
       groups.push_back(G);
     }
   }
@@ -361,7 +393,76 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   if ((int)blk_obs.size() < npose) blk_obs.resize(npose);
   for (auto& v : blk_obs) v.clear();   // (whatever an interrupted call may have left)
   std::vector<int> touched;
-  for (int g = 0; g < ngroup; ++g) {
+  // piece path (ba_linearize2.hpp): pieces instead of per-observation lists
+  std::vector<int> lm_piece_begin, pair_piece;
+  if (lin2) {
+    lm_piece_begin.assign(nlm + 1, 0);
+    pair_piece.assign(npair, 0);
+    static thread_local std::vector<std::vector<uint16_t>> blk_pairs;
+    if ((int)blk_pairs.size() < npose) blk_pairs.resize(npose);
+    for (auto& v : blk_pairs) v.clear();
+    int piece_total = 0;
+    for (int g = 0; g < ngroup; ++g) {
+      Group& G = groups[g];
+      G.piece_begin = piece_total;
+      G.tlist_begin = (int)task_list.size();
+      int wave_count[4] = {0, 0, 0, 0};
+      int local = 0;   // pieces of this group so far
+      for (int l = G.lm_begin; l < G.lm_end; ++l) {
+        lm_piece_begin[l] = piece_total + local;
+        int p = lm_pair_begin[l];   // pairs of a landmark are sorted by block, observations by pose: one forward walk
+        const int p1 = lm_pair_begin[l + 1];
+        int o = lm_obs_begin[l];
+        const int o1 = lm_obs_begin[l + 1];
+        while (o < o1) {
+          const int lane0 = o - G.obs_begin;
+          int e = o + 1;
+          while (e < o1 && w.obs_pose[e] == w.obs_pose[o] && ((e - G.obs_begin) & 15) != 0) ++e;
+          const int npc = (e - o + 1) / 2;
+          for (int k = 0; k < npc; ++k) wave_count[(lane0 + 2 * k) >> 6]++;
+          const int blk = w.obs_pose[o];
+          if (pose_off[blk] >= 0) {
+            while (p < p1 && pair_block[p] < blk) ++p;
+            // (p < p1 && pair_block[p] == blk by construction of the pairs)
+            if ((pair_piece[p] >> 16) == 0) pair_piece[p] = local;
+            pair_piece[p] += npc << 16;
+          }
+          local += npc;
+          o = e;
+        }
+      }
+      G.pw1 = wave_count[0];
+      G.pw2 = wave_count[0] + wave_count[1];
+      G.pw3 = wave_count[0] + wave_count[1] + wave_count[2];
+      piece_total += local;
+      // tasks: one per free block seen by the group, ascending; its list = the group-local pairs of that block
+      G.task_begin = (int)tasks.size();
+      touched.clear();
+      for (int p = G.pair_begin; p < G.pair_end; ++p) {
+        const int b = pair_block[p];
+        if (blk_pairs[b].empty()) touched.push_back(b);
+        blk_pairs[b].push_back((uint16_t)(p - G.pair_begin));
+      }
+      std::sort(touched.begin(), touched.end());
+      for (int b : touched) {
+        Task T;
+        T.type = 0;
+        T.off_a = pose_off[b];
+        T.off_b = -1;
+        T.list_begin = (int)task_list.size();
+        task_list.insert(task_list.end(), blk_pairs[b].begin(), blk_pairs[b].end());
+        T.list_end = (int)task_list.size();
+        T.out = gpart_size;
+        gpart_size += 27;
+        tasks.push_back(T);
+        blk_pairs[b].clear();
+      }
+      G.task_end = (int)tasks.size();
+      G.tlist_end = (int)task_list.size();
+    }
+    lm_piece_begin[nlm] = piece_total;
+  }
+  for (int g = 0; g < ngroup && !lin2; ++g) {
     Group& G = groups[g];
     G.plist_begin = (int)pair_list.size();
     G.tlist_begin = (int)task_list.size();
@@ -590,6 +691,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.marg_dim = Dm; P.marg_nb = nmb;
   P.D = D; P.Dp = Dp; P.n_pair = npair; P.n_group = ngroup; P.n_chunk = nchunk; P.n_task = (int)tasks.size();
   P.has_ext = has_ext ? 1 : 0;
+  P.lin2 = lin2 ? 1 : 0;
   P.gpart_size = gpart_size;
   P.n_tile = ntile;
   P.n_imu_color = n_imu_color;
@@ -602,7 +704,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       max_pairs = std::max(max_pairs, Gq.pair_end - Gq.pair_begin);
     }
     const int stage = opt.fp32_linearize ? LinCfg<false, float>::STAGE_DOUBLES : LinCfg<false, double>::STAGE_DOUBLES;
-    P.fuse_fast = H.group_chunks && !has_ext && max_tasks <= FUSE_MAX_TASKS && 6 * max_pairs <= FUSE_WIT * LIN_THREADS &&
+    P.fuse_fast = H.group_chunks && !has_ext && max_tasks <= FUSE_MAX_TASKS && (lin2 || 6 * max_pairs <= FUSE_WIT * LIN_THREADS) &&
                   fuse_nlb(Dp, stage) >= 4;
   }
   P.cauchy_b = w.cauchy_b;
@@ -633,6 +735,9 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(pair_list, put(A, pair_list));
   OFF(lm_pair_begin, put(A, lm_pair_begin));
   OFF(lm_obs_begin, put(A, lm_obs_begin));
+  OFF(lm_piece_begin, put(A, lm_piece_begin));
+  OFF(pair_piece, put(A, pair_piece));
+  OFF(pair_block, put(A, lin2 ? pair_block : std::vector<int>()));
   OFF(tasks, put(A, tasks));
   OFF(task_list, put(A, task_list));
   OFF(chunks, put(A, chunks));
@@ -864,6 +969,16 @@ size_t solve_smem(int Dpad, bool large) {
   // LDS-resident: the matrix area of the LDL^T solver (ba_ldl16.hpp; Dpad >= D bounds it) + four vectors
   return ((large ? 0 : (size_t)ldl16_area_doubles(Dpad)) + 4 * (size_t)Dpad) * sizeof(double) + 16;
 }
+// dynamic LDS of linearize2_kernel: fixed part + the pose part of the step (fused: the aux area of the group reduction)
+int lin2_step_doubles(int max_Dp, bool fuse, bool f32) {
+  const int m = fuse ? (f32 ? Lin2Cfg<float, true>::MIN_STEP_DOUBLES : Lin2Cfg<double, true>::MIN_STEP_DOUBLES) : Lin2Cfg<double, false>::MIN_STEP_DOUBLES;
+  return std::max(m, ((max_Dp + 1) / 2) * 2);
+}
+size_t lin2_smem(int max_Dp, bool fuse, bool f32) {
+  const int fixed = f32 ? (fuse ? Lin2Cfg<float, true>::FIXED_DOUBLES : Lin2Cfg<float, false>::FIXED_DOUBLES)
+                        : (fuse ? Lin2Cfg<double, true>::FIXED_DOUBLES : Lin2Cfg<double, false>::FIXED_DOUBLES);
+  return (size_t)(fixed + lin2_step_doubles(max_Dp, fuse, f32)) * sizeof(double);
+}
 size_t small_smem() { return (size_t)std::max<int>(std::max<int>(ImuLds::TOTAL, EvalLds::TOTAL), 2 * MAX_MARG_DIM) * sizeof(double); }
 
 // okvis_ba_begin for every window in ONE launch (it used to be three device copies and one upload per window: 1 ms of API calls
@@ -947,10 +1062,30 @@ hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
 // workgroups) and the reprojection groups
 hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
   const int n_small = s->max_imu + 1;
-  const dim3 grid(n_small + s->max_group, (unsigned)b.nw), blk(LIN_THREADS);
   const bool f32 = s->opt.fp32_linearize != 0;
-  const size_t smem = std::max(lin_smem(s->any_ext, f32), small_smem());
   const bool fuse = fused(s);
+  if (s->lin2) {   // piece path (ba_linearize2.hpp)
+    const int sd = lin2_step_doubles(s->max_Dp, fuse, f32);
+    const size_t smem2 = lin2_smem(s->max_Dp, fuse, f32);
+    if (s->split_small) {
+      hipLaunchKernelGGL(small_kernel, dim3(n_small, (unsigned)b.nw), dim3(LIN_THREADS), small_smem(), b.st, s->d_wins + b.w0, init);
+      const dim3 grid2(s->max_group, (unsigned)b.nw);
+      auto go2 = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid2, dim3(LIN_THREADS), smem2, b.st, s->d_wins + b.w0, s->d_opt, init, 0, sd); };
+      // (registers: 4 workgroups per CU = 128 per work-item, 3 = 168; OKVIS_BA_LIN2_OCC picks, diagnostics)
+      static const int occ = [] { const char* e = std::getenv("OKVIS_BA_LIN2_OCC"); return e ? std::atoi(e) : 3; }();
+      if (f32) fuse ? go2(linearize2_kernel<float, true, false>) : (occ >= 4 ? go2(linearize2_kernel<float, false, false, 4>) : go2(linearize2_kernel<float, false, false, 3>));
+      else fuse ? go2(linearize2_kernel<double, true, false>) : (occ >= 4 ? go2(linearize2_kernel<double, false, false, 4>) : go2(linearize2_kernel<double, false, false, 3>));
+    } else {
+      const dim3 grid2(n_small + s->max_group, (unsigned)b.nw);
+      const size_t sm = std::max(smem2, small_smem());
+      auto go2 = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid2, dim3(LIN_THREADS), sm, b.st, s->d_wins + b.w0, s->d_opt, init, n_small, sd); };
+      if (f32) fuse ? go2(linearize2_kernel<float, true, true>) : go2(linearize2_kernel<float, false, true>);
+      else fuse ? go2(linearize2_kernel<double, true, true>) : go2(linearize2_kernel<double, false, true>);
+    }
+    return hipGetLastError();
+  }
+  const dim3 grid(n_small + s->max_group, (unsigned)b.nw), blk(LIN_THREADS);
+  const size_t smem = std::max(lin_smem(s->any_ext, f32), small_smem());
   auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, blk, smem, b.st, s->d_wins + b.w0, s->d_opt, init, n_small); };
   if (s->any_ext) {
     if (f32) fuse ? go(linearize_kernel<true, float, true>) : go(linearize_kernel<true, float, false>);
@@ -1112,6 +1247,20 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   lds(reinterpret_cast<const void*>(&linearize_kernel<false, float, true>), std::max(lin_smem(false, true), small_smem()));
   lds(reinterpret_cast<const void*>(&linearize_kernel<false, double, false>), std::max(lin_smem(false), small_smem()));
   lds(reinterpret_cast<const void*>(&linearize_kernel<false, double, true>), std::max(lin_smem(false), small_smem()));
+  {
+    const size_t l2d = std::max(lin2_smem(MAX_D, true, false), small_smem()), l2f = std::max(lin2_smem(MAX_D, true, true), small_smem());
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<double, false, false, 3>), l2d);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<double, false, false, 4>), l2d);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<double, false, true>), l2d);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<double, true, false>), l2d);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<double, true, true>), l2d);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<float, false, false, 3>), l2f);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<float, false, false, 4>), l2f);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<float, false, true>), l2f);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<float, true, false>), l2f);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<float, true, true>), l2f);
+    lds(reinterpret_cast<const void*>(&small_kernel), small_smem());
+  }
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * SCHUR_LM_BATCH * TILE_DIM * 3 * sizeof(double)));
@@ -1226,9 +1375,27 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   std::vector<HostWin> wins(n_windows);
   const bool dbg_t = std::getenv("OKVIS_BA_DEBUG_UPLOAD") != nullptr;
   const auto t_u0 = std::chrono::steady_clock::now();
+  // the piece path of the linearise launch (ba_linearize2.hpp) unless a window of the batch does not fit it (free extrinsics,
+  // a landmark with more than LIN2_PIECES pieces) or options.reserved0 bit 3 / OKVIS_BA_NO_LIN2 asks for the staged kernel
+  static const bool no_lin2_env = std::getenv("OKVIS_BA_NO_LIN2") != nullptr;
+  bool lin2 = !(s->opt.reserved0 & 8) && !no_lin2_env;
   for (int i = 0; i < n_windows; ++i) {
-    int rc = build_window(windows[i], s->opt, A, wins[i], n_windows);
+    int rc = build_window(windows[i], s->opt, A, wins[i], n_windows, lin2);
+    if (rc == BW_LIN2_UNFIT) {   // start over with the staged kernel's lists for every window
+      lin2 = false;
+      A.size = 0;
+      A.zsize = 0;
+      i = -1;
+      continue;
+    }
     if (rc != OKVIS_BA_OK) return rc;
+  }
+  s->lin2 = lin2;
+  {
+    // IMU / prior factors in a launch of their own when the batch fills the device (then four linearise workgroups share a
+    // CU); one launch for everything when a few windows wait for one another's latency
+    static const int split_min = [] { const char* e = std::getenv("OKVIS_BA_SPLIT_SMALL_MIN"); return e ? std::atoi(e) : SMALL_BATCH_WINDOWS; }();
+    s->split_small = lin2 && n_windows >= split_min;
   }
   const auto t_u1 = std::chrono::steady_clock::now();
   // grow-only device allocations: the per-frame re-upload of okvis_amd::Estimator must not pay hipFree/hipMalloc
@@ -1322,7 +1489,7 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     // not the windows themselves.  A re-upload that leaves all of that unchanged (the same number of equally shaped windows:
     // the per-frame pattern of a batch service, the dogleg record of bench.py) keeps them; anything else drops them.
     std::vector<int64_t> sig = {n_windows, s->max_group, s->max_imu, s->max_schur_blocks, s->max_lm, s->max_Dpad, s->max_Dp,
-                                s->max_Dpad_small, s->max_Dpad_large, s->max_spart_stride, s->any_ext, s->group_chunks,
+                                s->max_Dpad_small, s->max_Dpad_large, s->max_spart_stride, s->any_ext, s->group_chunks, s->lin2, s->split_small,
                                 s->fp32_at_upload, (int64_t)(intptr_t)s->d_wins, (int64_t)(intptr_t)s->d_opt,
                                 (int64_t)s->sub_streams.size()};
     for (int b : s->sub_begin) sig.push_back(b);

@@ -57,15 +57,17 @@ __host__ __device__ constexpr int fuse_rows(int Dp) { return ((Dp + 1 + 15) / 16
 // landmarks per batch so that two [rows][3 nlb + 1] tiles fit `stage` doubles (a multiple of 4: 3 nlb is a multiple of 4)
 __host__ __device__ constexpr int fuse_nlb(int Dp, int stage) { return 4 * (((stage / (2 * fuse_rows(Dp))) - 1) / 12); }
 
-struct FuseItems {      // what phase C(b) hands over: W rows in registers
-  double w[FUSE_WIT][3];
-  int row[FUSE_WIT];    // reduced offset of the row (pose part), -1 = none
-  int lm[FUSE_WIT];     // landmark of the row, group-local
+template <int NQ>
+struct FuseItemsT {     // what phase C(b) hands over: W rows in registers
+  double w[NQ][3];
+  int row[NQ];          // reduced offset of the row (pose part), -1 = none
+  int lm[NQ];           // landmark of the row, group-local
 };
+typedef FuseItemsT<FUSE_WIT> FuseItems;
 
-template <int STAGE_DOUBLES>
+template <int STAGE_DOUBLES, int NQ>
 __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& opt, int g, int buf, double lam, int nlm, bool init,
-                                                  const double (&pf_sc)[3], const FuseItems& it, double* tiles,
+                                                  const double (&pf_sc)[3], const FuseItemsT<NQ>& it, double* tiles,
                                                   const double* s_lmres, double* aux) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define FSTAMP(k) do { if (W.prof && tid == 0 && g == 0 && blockIdx.y == 0) W.prof[k] = (double)clock64(); } while (0)
@@ -122,7 +124,7 @@ __device__ __forceinline__ void fused_reduce_fast(const WinPtrs& W, const OptD& 
     __syncthreads();
     if (l0 == 0) FSTAMP(19);
 #pragma unroll
-    for (int q = 0; q < FUSE_WIT; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int lb = it.lm[q] - l0;
       if (it.row[q] >= 0 && lb >= 0 && lb < nlb) {
         const double w0 = it.w[q][0], w1 = it.w[q][1], w2 = it.w[q][2];
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void linearize_kernel(const WinPtrs
     // the scalars first, by wave 0; the landmark work of the fast reduction belongs to wave 1, so the two overlap
     group_scalars();
     if (fast)
-      fused_reduce_fast<LinCfg<EXT, REAL>::STAGE_DOUBLES>(W, opt, g, trial, lam_next, nlm, init != 0, pf_sc, fit, smem, s_lmres, s_step);
+      fused_reduce_fast<LinCfg<EXT, REAL>::STAGE_DOUBLES, FUSE_WIT>(W, opt, g, trial, lam_next, nlm, init != 0, pf_sc, fit, smem, s_lmres, s_step);
     else
       reduce_own_group(trial, lam_next);
   }

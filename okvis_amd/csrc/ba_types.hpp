@@ -12,6 +12,7 @@ constexpr int GROUP_OBS = 256;       // observations handled by one linearise wo
 constexpr int GROUP_LM = 64;         // max landmarks per group
 constexpr int GROUP_PAIRS = 512;     // max (landmark, block) pairs per group
 constexpr int LIN_THREADS = 256;
+constexpr int LIN2_PIECES = 128;     // pieces (<= 2 adjacent observations of one (landmark, pose)) per group on the piece path
 constexpr int SCHUR_THREADS = 256;
 constexpr int SCHUR_TILE_BLOCKS = 16;  // 16 x 16 blocks of 6x6 = 96 x 96 tile, one 6x6 block per thread
 constexpr int SCHUR_LM_BATCH = 16;     // landmarks staged per LDS pass in the Schur kernel
@@ -43,7 +44,10 @@ struct Group {  // one linearise workgroup: whole landmarks, <= GROUP_OBS observ
   int task_begin, task_end;
   int plist_begin, plist_end;  // the group's slice of pair_list (= pair_list_begin[pair_begin .. pair_end])
   int tlist_begin, tlist_end;  // the group's slice of task_list
+  // piece path (ba_linearize2.hpp): pieces before this group in the window, and before waves 1..3 inside the group
+  int piece_begin, pw1, pw2, pw3;
 };
+static_assert(sizeof(Group) == 64, "Group is fetched as 16 dwords");
 
 // reduction task of a group: accumulate over a list of the group's observations
 //   type 0: block Hessian/gradient of a pose-role block   out = 27 doubles (21 upper-tri A + 6 g)
@@ -53,7 +57,7 @@ struct Task {
   int type;
   int off_a;       // reduced offset of the (first) block
   int off_b;       // reduced offset of the second block (type 2)
-  int list_begin;  // into task_list (group-local observation indices)
+  int list_begin;  // into task_list (group-local observation indices; piece path: group-local pair indices)
   int list_end;
   int out;         // offset (doubles) into the lin buffer's gpart array
 };
@@ -157,6 +161,7 @@ struct WinPtrs {
   int spart_stride;       // doubles per chunk partial: (Dp/6)(Dp/6+1)/2*36 + 3*Dp  (S | Y b | g | diag U)
   int fuse_fast;          // fused mode: the groups of this window qualify for the matrix-core reduction (ba_linearize.hpp)
   int spart_buf_stride;   // doubles between the partials of linearisation buffer 0 and 1 (fused mode: one set per buffer); 0 = one set
+  int lin2;               // the index lists are those of the piece path (ba_linearize2.hpp)
   double cauchy_b;
   ImuParamsD imu;
 
@@ -179,6 +184,10 @@ struct WinPtrs {
   const BA_G uint16_t* pair_list;   // group-local observation indices
   const BA_G int* lm_pair_begin;    // [n_lm+1]
   const BA_G int* lm_obs_begin;     // [n_lm+1] observation range of each landmark (sorted order)
+  // piece path (ba_linearize2.hpp)
+  const BA_G int* lm_piece_begin;   // [n_lm+1] window-wide piece index of each landmark's first piece
+  const BA_G int* pair_piece;       // [n_pair] group-local first piece | piece count << 16
+  const BA_G int* pair_block;       // [n_pair] pose index of the pair's block
   const BA_G Task* tasks;
   const BA_G uint16_t* task_list;
   const BA_G Chunk* chunks;
