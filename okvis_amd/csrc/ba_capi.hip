@@ -122,7 +122,7 @@ struct okvis_ba_solver {
   std::vector<HostWin> wins;
   bool uploaded = false, begun = false, any_ext = false;
   bool lin2 = false;          // the batch's index lists are those of the piece path (ba_linearize2.hpp)
-  bool split_small = false;   // piece path: IMU / prior factors in a launch of their own (small_kernel), four linearise workgroups per CU
+  bool split_small = false;   // piece path: IMU / prior factors in a launch of their own (small_kernel), three linearise workgroups per CU
   bool group_chunks = false;   // every window of the batch has one Schur chunk per linearise group (see fused())
   bool fp32_at_upload = false;
   std::vector<int64_t> launch_sig;   // what the captured graphs depend on (see okvis_ba_upload)
@@ -444,14 +444,18 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
         blk_pairs[b].push_back((uint16_t)(p - G.pair_begin));
       }
       std::sort(touched.begin(), touched.end());
+      task_list.resize(task_list.size() + (size_t)(G.pair_end - G.pair_begin));
+      int slot = 0;
       for (int b : touched) {
         Task T;
         T.type = 0;
         T.off_a = pose_off[b];
         T.off_b = -1;
-        T.list_begin = (int)task_list.size();
-        task_list.insert(task_list.end(), blk_pairs[b].begin(), blk_pairs[b].end());
-        T.list_end = (int)task_list.size();
+        // task_list holds, per group-local pair, the SLOT of its block record: the records of one block are contiguous
+        // [list_begin, list_end) in slot order (pairs ascending), which is the order they are summed in
+        T.list_begin = G.tlist_begin + slot;
+        for (uint16_t pl : blk_pairs[b]) task_list[(size_t)G.tlist_begin + pl] = (uint16_t)slot++;
+        T.list_end = G.tlist_begin + slot;
         T.out = gpart_size;
         gpart_size += 27;
         tasks.push_back(T);
@@ -971,8 +975,8 @@ size_t solve_smem(int Dpad, bool large) {
 }
 // dynamic LDS of linearize2_kernel: fixed part + the pose part of the step (fused: the aux area of the group reduction)
 int lin2_step_doubles(int max_Dp, bool fuse, bool f32) {
-  const int m = fuse ? (f32 ? Lin2Cfg<float, true>::MIN_STEP_DOUBLES : Lin2Cfg<double, true>::MIN_STEP_DOUBLES) : Lin2Cfg<double, false>::MIN_STEP_DOUBLES;
-  return std::max(m, ((max_Dp + 1) / 2) * 2);
+  const int aux = fuse ? (f32 ? Lin2Cfg<float, true>::MIN_STEP_DOUBLES : Lin2Cfg<double, true>::MIN_STEP_DOUBLES) : Lin2Cfg<double, false>::MIN_STEP_DOUBLES;
+  return ((max_Dp + 1) / 2) * 2 + 8 + aux;   // pose part of the step, then the aux area of the fused reduction
 }
 size_t lin2_smem(int max_Dp, bool fuse, bool f32) {
   const int fixed = f32 ? (fuse ? Lin2Cfg<float, true>::FIXED_DOUBLES : Lin2Cfg<float, false>::FIXED_DOUBLES)
