@@ -19,6 +19,7 @@
 #include "ba_chol_tiles.hpp"
 #include "ba_linearize.hpp"
 #include "ba_linearize2.hpp"
+#include "ba_schur2.hpp"
 #include "ba_marg.hpp"
 #include "ba_schur.hpp"
 #include "ba_solve.hpp"
@@ -599,6 +600,15 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   }
   chunk_diag_begin[(size_t)nchunk * npose_blk_c] = (int)chunk_diag_out.size();
   chunk_cross_begin[nchunk] = (int)chunk_cross.size() / 3;
+  // chunk descriptors of the matrix-core Schur kernel: one record instead of the chain chunks -> groups -> lm_pair_begin
+  std::vector<int> chunk_desc((size_t)nchunk * SCHUR_DESC_INTS, 0);
+  for (int c = 0; c < nchunk; ++c) {
+    int* d = chunk_desc.data() + (size_t)c * SCHUR_DESC_INTS;
+    const int lb = groups[chunks[c].group_begin].lm_begin, le = groups[chunks[c].group_end - 1].lm_end;
+    d[0] = lb;
+    d[1] = le;
+    for (int i = 0; i <= SCHUR_CHUNK_LM_MAX / 4; ++i) d[2 + i] = lm_pair_begin[std::min(lb + 4 * i, le)];
+  }
   BW_T("chunks");
   // ---- greedy colouring of the IMU factors: factors of one colour share no parameter block ----
   std::vector<int> imu_color(w.n_imu, 0);
@@ -749,6 +759,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(chunk_diag_out, put(A, chunk_diag_out));
   OFF(chunk_cross_begin, put(A, chunk_cross_begin));
   OFF(chunk_cross, put(A, chunk_cross));
+  OFF(chunk_desc, put(A, chunk_desc));
   OFF(imu_order, put(A, imu_order));
   OFF(imu_color_begin, put(A, imu_color_begin));
   OFF(imu_coloff, put(A, imu_coloff));
@@ -1035,6 +1046,22 @@ bool fused(const okvis_ba_solver* s) {
 hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
   if (s->max_schur_blocks == 0 || fused(s)) return hipSuccess;
   const int trows = std::min(TILE_DIM, s->max_Dp);
+  static const bool no_mfma = std::getenv("OKVIS_BA_NO_SCHUR2") != nullptr;
+  // no pose x extrinsics cross blocks: the reduction as a GEMM on the fp64 matrix core (ba_schur2.hpp).  Pose parts beyond 63 rows
+  // (several 96-row tile pairs per chunk) keep schur_kernel unless OKVIS_BA_SCHUR2_LARGE is set: every tile pair of a chunk
+  // scans all its (landmark, block) rows to fill its tiles, and at configs[2] that makes the matrix-core kernel the slower one
+  // (111 against 100 us per launch)
+  static const bool mfma_large = std::getenv("OKVIS_BA_SCHUR2_LARGE") != nullptr;
+  if (!s->any_ext && !no_mfma && (trows + 1 <= SCH2_MAXT_SMALL_ROWS || mfma_large)) {
+    int nlb = sch2_nlb(trows, 5120);              // 40 KB of tiles: three workgroups per CU
+    if (nlb < 12) nlb = sch2_nlb(trows, 9216);    // wide tiles: 72 KB, two per CU
+    const size_t sm = (size_t)sch2_tile_doubles(trows, nlb) * sizeof(double);
+    if (trows + 1 <= SCH2_MAXT_SMALL_ROWS)
+      hipLaunchKernelGGL(schur_mfma_kernel<3>, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), sm, b.st, s->d_wins + b.w0, s->d_opt, trows, final_call, nlb);
+    else
+      hipLaunchKernelGGL(schur_mfma_kernel<9>, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), sm, b.st, s->d_wins + b.w0, s->d_opt, trows, final_call, nlb);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(schur_kernel, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS),
                      (size_t)2 * SCHUR_LM_BATCH * trows * 3 * sizeof(double), b.st, s->d_wins + b.w0, s->d_opt, trows,
                      final_call);
@@ -1265,6 +1292,8 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
     lds(reinterpret_cast<const void*>(&linearize2_kernel<float, true, true>), l2f);
     lds(reinterpret_cast<const void*>(&small_kernel), small_smem());
   }
+  lds(reinterpret_cast<const void*>(&schur_mfma_kernel<3>), (size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double));
+  lds(reinterpret_cast<const void*>(&schur_mfma_kernel<9>), (size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * SCHUR_LM_BATCH * TILE_DIM * 3 * sizeof(double)));

@@ -122,7 +122,9 @@ __device__ __forceinline__ double wave_max_full(double v) {
 // in a fixed order (lane-strided accumulation + wave_sum_full) so that the Schur kernel and the solve
 // kernel obtain bit-identical values.  out: cost, g.delta (landmarks), delta^T D^2 delta, |delta|^2,
 // |x|^2, max|g_l|.
-__device__ __forceinline__ void wave_trial_sums(const WinPtrs& W, int buf, int lane, double out[6]) {
+// (two halves: the lane-strided partial sums, which only need memory, and the wave reductions; the Schur kernels request the
+// partials of BOTH buffers before the control record has arrived and reduce the one the record names)
+__device__ __forceinline__ void wave_trial_partials(const WinPtrs& W, int buf, int lane, double part[6]) {
   double cost = 0, gd = 0, ddd = 0, s2 = 0, x2 = 0, gm = 0;
   const double* gs = W.gscal[buf];
   for (int g = lane; g < W.n_group; g += 64) {
@@ -136,12 +138,20 @@ __device__ __forceinline__ void wave_trial_sums(const WinPtrs& W, int buf, int l
   }
   for (int f = lane; f < W.n_imu; f += 64) cost += W.imu_lin[buf][(size_t)f * IMU_LIN_STRIDE + IMU_COST];
   if (lane == 0) cost += W.small_cost[buf][0];
-  out[0] = wave_sum_full(cost);
-  out[1] = wave_sum_full(gd);
-  out[2] = wave_sum_full(ddd);
-  out[3] = wave_sum_full(s2);
-  out[4] = wave_sum_full(x2);
-  out[5] = wave_max_full(gm);
+  part[0] = cost, part[1] = gd, part[2] = ddd, part[3] = s2, part[4] = x2, part[5] = gm;
+}
+__device__ __forceinline__ void wave_trial_reduce(const double part[6], double out[6]) {
+  out[0] = wave_sum_full(part[0]);
+  out[1] = wave_sum_full(part[1]);
+  out[2] = wave_sum_full(part[2]);
+  out[3] = wave_sum_full(part[3]);
+  out[4] = wave_sum_full(part[4]);
+  out[5] = wave_max_full(part[5]);
+}
+__device__ __forceinline__ void wave_trial_sums(const WinPtrs& W, int buf, int lane, double out[6]) {
+  double part[6];
+  wave_trial_partials(W, buf, lane, part);
+  wave_trial_reduce(part, out);
 }
 
 struct Decision {
@@ -153,8 +163,11 @@ struct Decision {
 
 // Accept/reject + trust-region radius update for the pending trial (Ceres LevenbergMarquardtStrategy
 // StepAccepted/StepRejected + TrustRegionMinimizer step evaluation, restated; DESIGN.md "solver policy").
-// Not inlined and contraction-free so that every kernel evaluating it gets the same bits.
-__device__ __noinline__ void decide(const Ctrl* c, const OptD* o, const double sums[6], Decision* d) {
+// Contraction-free so that every kernel evaluating it gets the same bits (no fast-math anywhere: without contraction the
+// operations are plain IEEE whatever they are inlined into).  The Schur kernels inline it (as a real call it cost them ~1 us
+// of scratch traffic for the callee-saved registers); the solve kernel, which has no registers to spare, calls it (decide /
+// decide_dl below).
+__device__ __forceinline__ void decide_inl(const Ctrl* c, const OptD* o, const double sums[6], Decision* d) {
 #pragma clang fp contract(off)
   d->accept = 0;
   d->term = 0;
@@ -211,7 +224,7 @@ struct DecisionDL {
   int invalid_steps, have_tot;
   double radius, mu, rho, model_change, tot_C, tot_E;
 };
-__device__ __noinline__ void decide_dl(const Ctrl* c, const OptD* o, const double sums[6], int final_call, DecisionDL* d) {
+__device__ __forceinline__ void decide_dl_inl(const Ctrl* c, const OptD* o, const double sums[6], int final_call, DecisionDL* d) {
 #pragma clang fp contract(off)
   d->accept = 0;
   d->term = 0;
@@ -283,6 +296,11 @@ __device__ __noinline__ void decide_dl(const Ctrl* c, const OptD* o, const doubl
   }
   // a NEW iteration would start now (anything but the redo of a mis-speculated trial): is there budget left?
   if (!final_call && !d->term && !(d->explicit_next && !d->judged) && c->iter >= c->max_iter) d->term = 6;
+}
+
+__device__ __noinline__ void decide(const Ctrl* c, const OptD* o, const double sums[6], Decision* d) { decide_inl(c, o, sums, d); }
+__device__ __noinline__ void decide_dl(const Ctrl* c, const OptD* o, const double sums[6], int final_call, DecisionDL* d) {
+  decide_dl_inl(c, o, sums, final_call, d);
 }
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -289,6 +289,101 @@ __device__ __forceinline__ void schur_reduce_chunk(const WinPtrs& W, const OptD&
   SSTAMP(23);
 }
 
+// The accept / reject decision for the pending trial, recomputed by wave 0 of every Schur workgroup (bit-identical to the
+// solve kernel, ba_device.hpp): which linearisation buffer to reduce, whether anything is to be reduced at all, and the
+// regulariser.  s_ctrl / s_dec / s_lambda are LDS; the caller synchronises the workgroup afterwards.
+// What wave 0 requests for the decision: the control record (one double per lane) and the per-lane partial sums of BOTH
+// linearisation buffers (the record names the one of the pending trial): one memory round trip, issued as early as the caller
+// likes (schur_decision_issue) and consumed by schur_decision_finish.
+struct SchurDecisionLoads {
+  double part0[6], part1[6], cval;
+};
+__device__ __forceinline__ void schur_decision_issue(const WinPtrs& W, const Ctrl* ctrl, int tid, SchurDecisionLoads& L) {
+  L.cval = 0.0;
+  if (tid < 64) {
+    wave_trial_partials(W, 0, tid, L.part0);
+    wave_trial_partials(W, 1, tid, L.part1);
+    if (tid < (int)(sizeof(Ctrl) / 8)) L.cval = reinterpret_cast<const double*>(ctrl)[tid];
+  }
+}
+__device__ __forceinline__ void schur_decision_finish(const WinPtrs& W, const OptD& opt, const SchurDecisionLoads& L, int final_call, int bx, int tid,
+                                                      Ctrl& s_ctrl, int* s_dec, double& s_lambda) {
+  if (tid < 64) {
+    const double (&part0)[6] = L.part0;
+    const double (&part1)[6] = L.part1;
+    if (tid < (int)(sizeof(Ctrl) / 8)) reinterpret_cast<double*>(&s_ctrl)[tid] = L.cval;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("" ::: "memory");
+    int acc = s_ctrl.acc, term = 0;
+    auto trial_sums = [&](int buf, double sums[6]) {
+      double part[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) part[k] = buf ? part1[k] : part0[k];
+      wave_trial_reduce(part, sums);
+    };
+    double lam;
+    if (opt.dogleg) {
+      // dogleg: the regulariser of the Gauss-Newton solve is mu * diagonal^2; a decision that asks for an explicit
+      // dogleg step (rejected step / mis-speculated Gauss-Newton trial) needs no new reduction at all
+      double mu = s_ctrl.mu;
+      int expl = s_ctrl.explicit_next;
+      if (s_ctrl.pending) {
+        double sums[6];
+        trial_sums(1 - acc, sums);
+        DecisionDL d;
+        decide_dl_inl(&s_ctrl, &opt, sums, final_call, &d);
+        if (bx == 0 && tid == 0) {   // published for the solve kernel (it would compute exactly this)
+          auto o = W.dec;
+          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
+          o[DEC_DL + 0] = d.accept; o[DEC_DL + 1] = d.term; o[DEC_DL + 2] = d.explicit_next; o[DEC_DL + 3] = d.judged;
+          o[DEC_DL + 4] = d.invalid_steps; o[DEC_DL + 5] = d.have_tot; o[DEC_DL + 6] = d.radius; o[DEC_DL + 7] = d.mu;
+          o[DEC_DL + 8] = d.rho; o[DEC_DL + 9] = d.model_change; o[DEC_DL + 10] = d.tot_C; o[DEC_DL + 11] = d.tot_E;
+          o[DEC_VALID] = 1.0;
+        }
+        if (d.accept) acc = 1 - acc;
+        term = d.term;
+        mu = d.mu;
+        expl = d.explicit_next ? (d.judged ? 1 : 2) : 0;
+      } else if (!final_call && expl != 2 && s_ctrl.iter >= s_ctrl.max_iter) {
+        term = 6;
+      }
+      if (expl) term = 7;   // nothing to reduce in this slot
+      lam = mu;
+    } else {
+      double radius = s_ctrl.radius;
+      if (s_ctrl.pending) {
+        double sums[6];
+        trial_sums(1 - acc, sums);
+        Decision d;
+        decide_inl(&s_ctrl, &opt, sums, &d);
+        if (bx == 0 && tid == 0) {
+          auto o = W.dec;
+          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
+          o[DEC_LM + 0] = d.accept; o[DEC_LM + 1] = d.term; o[DEC_LM + 2] = d.radius; o[DEC_LM + 3] = d.decrease_factor;
+          o[DEC_LM + 4] = d.rho; o[DEC_LM + 5] = d.model_change;
+          o[DEC_VALID] = 1.0;
+        }
+        if (d.accept) acc = 1 - acc;
+        radius = d.radius;
+        term = d.term;
+      }
+      lam = 1.0 / radius;
+    }
+    if (tid == 0) {
+      s_dec[0] = acc;
+      s_dec[1] = term;
+      s_lambda = lam;
+    }
+  }
+}
+
+__device__ __forceinline__ void schur_decision(const WinPtrs& W, const OptD& opt, const Ctrl* ctrl, int final_call, int bx, int tid,
+                                               Ctrl& s_ctrl, int* s_dec, double& s_lambda) {
+  SchurDecisionLoads L;
+  schur_decision_issue(W, ctrl, tid, L);
+  schur_decision_finish(W, opt, L, final_call, bx, tid, s_ctrl, s_dec, s_lambda);
+}
+
 __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __restrict__ wins,
                                                               const OptD* __restrict__ optp, int tile_rows, int final_call) {
   const WinPtrs& W = wins[blockIdx.y];
@@ -325,65 +420,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void schur_kernel(const WinPtrs* __r
     pb.v[i] = (i <= nbatch) ? W.lm_pair_begin[min(lm_begin + i * SCHUR_LM_BATCH, lm_end)] : 0;
   // ---- decision (wave 0) ----
   __shared__ Ctrl s_ctrl;   // the control record is fetched with ONE coalesced load; decide() then reads the LDS copy
-  if (tid < 64) {
-    if (tid < (int)(sizeof(Ctrl) / 8)) reinterpret_cast<double*>(&s_ctrl)[tid] = reinterpret_cast<const double*>(ctrl)[tid];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    asm volatile("" ::: "memory");
-    int acc = s_ctrl.acc, term = 0;
-    double lam;
-    if (opt.dogleg) {
-      // dogleg: the regulariser of the Gauss-Newton solve is mu * diagonal^2; a decision that asks for an explicit
-      // dogleg step (rejected step / mis-speculated Gauss-Newton trial) needs no new reduction at all
-      double mu = s_ctrl.mu;
-      int expl = s_ctrl.explicit_next;
-      if (s_ctrl.pending) {
-        double sums[6];
-        wave_trial_sums(W, 1 - acc, tid, sums);
-        DecisionDL d;
-        decide_dl(&s_ctrl, &opt, sums, final_call, &d);
-        if (bx == 0 && tid == 0) {   // published for the solve kernel (it would compute exactly this)
-          auto o = W.dec;
-          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
-          o[DEC_DL + 0] = d.accept; o[DEC_DL + 1] = d.term; o[DEC_DL + 2] = d.explicit_next; o[DEC_DL + 3] = d.judged;
-          o[DEC_DL + 4] = d.invalid_steps; o[DEC_DL + 5] = d.have_tot; o[DEC_DL + 6] = d.radius; o[DEC_DL + 7] = d.mu;
-          o[DEC_DL + 8] = d.rho; o[DEC_DL + 9] = d.model_change; o[DEC_DL + 10] = d.tot_C; o[DEC_DL + 11] = d.tot_E;
-          o[DEC_VALID] = 1.0;
-        }
-        if (d.accept) acc = 1 - acc;
-        term = d.term;
-        mu = d.mu;
-        expl = d.explicit_next ? (d.judged ? 1 : 2) : 0;
-      } else if (!final_call && expl != 2 && s_ctrl.iter >= s_ctrl.max_iter) {
-        term = 6;
-      }
-      if (expl) term = 7;   // nothing to reduce in this slot
-      lam = mu;
-    } else {
-      double radius = s_ctrl.radius;
-      if (s_ctrl.pending) {
-        double sums[6];
-        wave_trial_sums(W, 1 - acc, tid, sums);
-        Decision d;
-        decide(&s_ctrl, &opt, sums, &d);
-        if (bx == 0 && tid == 0) {
-          auto o = W.dec;
-          for (int k = 0; k < 6; ++k) o[DEC_SUMS + k] = sums[k];
-          o[DEC_LM + 0] = d.accept; o[DEC_LM + 1] = d.term; o[DEC_LM + 2] = d.radius; o[DEC_LM + 3] = d.decrease_factor;
-          o[DEC_LM + 4] = d.rho; o[DEC_LM + 5] = d.model_change;
-          o[DEC_VALID] = 1.0;
-        }
-        if (d.accept) acc = 1 - acc;
-        radius = d.radius;
-        term = d.term;
-      }
-      lam = 1.0 / radius;
-    }
-    if (tid == 0) {
-      s_dec[0] = acc;
-      s_dec[1] = term;
-      s_lambda = lam;
-    }
-  }
+  schur_decision(W, opt, ctrl, final_call, bx, tid, s_ctrl, s_dec, s_lambda);
   __syncthreads();
   SSTAMP(17);
   if (s_dec[1]) return;  // terminated by the decision; the solve kernel records it

@@ -18,6 +18,7 @@ constexpr int SCHUR_TILE_BLOCKS = 16;  // 16 x 16 blocks of 6x6 = 96 x 96 tile, 
 constexpr int SCHUR_LM_BATCH = 16;     // landmarks staged per LDS pass in the Schur kernel
 constexpr int SCHUR_CHUNK_LM_MAX = 64;   // landmarks of one Schur workgroup (chunk) = GROUP_LM: a chunk is at least one group;
                                         // more would push the kernel past 80 KB of LDS at 96-row tiles (one workgroup per CU)
+constexpr int SCHUR_DESC_INTS = 2 + SCHUR_CHUNK_LM_MAX / 4 + 1 + 1;   // chunk descriptor of the matrix-core Schur kernel (20 ints)
 constexpr int SOLVE_THREADS = 1024;
 constexpr int MAX_D_LDS = 174;         // reduced systems up to this size are factorised in LDS (block-packed)
 constexpr int MAX_D = 900;             // larger ones (up to this) keep the block matrix in HBM/L2 (slower path)
@@ -196,6 +197,7 @@ struct WinPtrs {
   const BA_G int* chunk_diag_out;
   const BA_G int* chunk_cross_begin;  // [n_chunk + 1] into chunk_cross (triples off_a, off_b, out)
   const BA_G int* chunk_cross;
+  const BA_G int* chunk_desc;         // [n_chunk][SCHUR_DESC_INTS]: lm_begin, lm_end, then lm_pair_begin at every 4th landmark of the chunk (ba_schur2.hpp)
   const BA_G int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
   const BA_G int* imu_color_begin;    // [n_imu_color+1]
   const BA_G int* imu_coloff;         // [n_imu][30] reduced index of each local column (or -1)

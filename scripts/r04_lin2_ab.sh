@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round 4: parity of the piece path (full GPU suite), then A/B of the linearise variants.
+# Round 4: parity (full GPU suite), then A/B of the kernel variants.
 cd "$(dirname "$0")/.." || exit 1
 OUT=gpurun_out/r04_ab
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1
 echo "pytest rc $?" >> $OUT/pytest.log
-tail -12 $OUT/pytest.log
+grep -E "passed|failed|FAILED|rc " $OUT/pytest.log | tail -12
 B="python bench.py --no-pmc --no-extras --no-cpu-baseline --repeats 12"
 run() { name=$1; shift; ( "$@" ) > $OUT/$name.json 2> $OUT/$name.err; python - <<PY
 import json
@@ -18,25 +18,16 @@ except Exception as e:
     print("$name failed", e)
 PY
 }
-run old64         env OKVIS_BA_NO_LIN2=1 $B
-run lin2_gpw1     env OKVIS_BA_LIN2_GPW=1 $B
-run lin2_gpw1_occ4 env OKVIS_BA_LIN2_GPW=1 OKVIS_BA_LIN2_OCC=4 $B
-run lin2_gpw2     env OKVIS_BA_LIN2_GPW=2 $B
-run lin2_gpw3     env OKVIS_BA_LIN2_GPW=3 $B
-run lin2_auto     $B
-run lin2_fork     env OKVIS_BA_LIN2_GPW=1 OKVIS_BA_SMALL_FORK=1 $B
-run lin2_comb     env OKVIS_BA_SPLIT_SMALL_MIN=100000 $B
-run lin2_fused64  env OKVIS_BA_FUSED_MAX_WINDOWS=64 OKVIS_BA_SPLIT_SMALL_MIN=100000 $B
-run old256        env OKVIS_BA_NO_LIN2=1 $B --windows 256
-run lin2_256_gpw1 env OKVIS_BA_LIN2_GPW=1 $B --windows 256
-run lin2_256_gpw4 env OKVIS_BA_LIN2_GPW=4 $B --windows 256
-run lin2_256_auto $B --windows 256
-run old1          env OKVIS_BA_NO_LIN2=1 $B --windows 1
-run lin2_1        $B --windows 1
-run lin2_8        $B --windows 8
-run old8          env OKVIS_BA_NO_LIN2=1 $B --windows 8
-for nw in 1 64 256; do
-  OKVIS_BA_LIN2_GPW=1 python tests/gpu_lin_stamps.py $nw 4 > $OUT/stamps_lin2_$nw.txt 2>&1
-done
-python tests/gpu_lin_stamps.py 1 0 > $OUT/stamps_lin2_fused_1.txt 2>&1
-cat $OUT/stamps_lin2_1.txt $OUT/stamps_lin2_64.txt $OUT/stamps_lin2_256.txt $OUT/stamps_lin2_fused_1.txt
+run vschur_64     env OKVIS_BA_NO_SCHUR2=1 $B
+run mfma_64       $B
+run mfma_256      $B --windows 256
+run vschur_256    env OKVIS_BA_NO_SCHUR2=1 $B --windows 256
+run mfma_128      $B --windows 128
+run mfma_32_sep   env OKVIS_BA_FUSED_MAX_WINDOWS=0 $B --windows 32
+run mfma_32       $B --windows 32
+run mfma_8_sep    env OKVIS_BA_FUSED_MAX_WINDOWS=0 $B --windows 8
+run mfma_8        $B --windows 8
+run mfma_1_sep    env OKVIS_BA_FUSED_MAX_WINDOWS=0 $B --windows 1
+run mfma_1        $B --windows 1
+python scripts/bench_config_c.py > $OUT/config_c.json 2> $OUT/config_c.err; tail -3 $OUT/config_c.json | cut -c1-600
+OKVIS_BA_NO_SCHUR2=1 python scripts/bench_config_c.py > $OUT/config_c_vschur.json 2> $OUT/config_c_vschur.err; tail -3 $OUT/config_c_vschur.json | cut -c1-600
