@@ -55,7 +55,7 @@ def parse():
     return p.parse_args()
 
 
-KERNEL_SYMBOL = {"schur": "schur_kernel", "solve": "solve_kernel", "linearize": "linearize_kernel"}
+KERNEL_SYMBOL = {"schur": "schur_", "solve": "solve_kernel", "linearize": "linearize"}   # (schur_kernel | schur_mfma_kernel, linearize_kernel | linearize2_kernel)
 
 
 def pmc_traffic(a, kernel):
@@ -170,7 +170,7 @@ def main():
     if rank == 0 and a.profile_steps > 0:
         st = solver.check_window(wins[0])
         D_red = int(st["D"])
-        n_cu, wg_per_cu = 256, 2
+        n_cu, wg_per_cu = 256, 3
 
         def flops_per_launch(nw):
             # ~1.5 kflop per observation (residual + 2x15 Jacobian + J^T J / J^T r + cost) in the linearise

@@ -451,7 +451,10 @@ int okvis_ba_batch_run(int device, int32_t rank, int32_t world, int32_t n_total,
  * OKVIS_BA_RCCL_LIB names another file), one communicator per call.  Every rank passes n_per_rank records (ranks with
  * fewer windows pad with window_id = 0xffffffff); all [world][n_per_rank].  The ncclUniqueId goes from rank 0 to the others
  * through `id_file` (a path every rank sees; written with an atomic rename, polled for up to timeout_s; not needed for
- * world = 1).  OKVIS_BA_ERR_UNSUPPORTED: no RCCL library found; OKVIS_BA_ERR_STATE: id file timeout or an RCCL error. */
+ * world = 1).  The path belongs to ONE gather: rank 0 removes a left-over file before it publishes and removes its own as soon as
+ * the communicator stands (or it fails); two jobs must not share a path, and ranks > 0 must not be started against the file of an
+ * earlier job that rank 0 has not yet replaced.  OKVIS_BA_ERR_UNSUPPORTED: no RCCL library found (checked on every rank before an
+ * id changes hands); OKVIS_BA_ERR_STATE: id file timeout or an RCCL error. */
 int okvis_ba_gather_records(int32_t rank, int32_t world, int device, const char* id_file, double timeout_s,
                             const okvis_ba_window_record* mine, int32_t n_per_rank, okvis_ba_window_record* all);
 /* okvis_ba_batch_run + okvis_ba_gather_records: every rank returns the records of ALL n_total windows in window order */

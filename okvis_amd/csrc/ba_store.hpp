@@ -84,6 +84,34 @@ struct WindowStore {
     if (w.marg_dim && (!w.marg_block_type || !w.marg_block_idx || !w.marg_block_off || !w.marg_J || !w.marg_e0 || !w.marg_lin ||
                        w.marg_nblocks <= 0))
       return OKVIS_BA_ERR_ARG;
+    // every index array is range-checked before anything is copied: the container is usable without a device, so
+    // okvis_ba_upload's validation never sees these windows, and apply() indexes its remap tables with them
+    for (int o = 0; o < w.n_obs; ++o)
+      if (w.obs_lm[o] < 0 || w.obs_lm[o] >= w.n_lm || w.obs_pose[o] < 0 || w.obs_pose[o] >= w.n_pose || w.obs_ext[o] < 0 ||
+          w.obs_ext[o] >= w.n_pose || w.obs_cam[o] < 0 || w.obs_cam[o] >= w.n_cam)
+        return OKVIS_BA_ERR_ARG;
+    for (int f = 0; f < w.n_imu; ++f) {
+      if (w.imu_pose0[f] < 0 || w.imu_pose0[f] >= w.n_pose || w.imu_pose1[f] < 0 || w.imu_pose1[f] >= w.n_pose || w.imu_sb0[f] < 0 ||
+          w.imu_sb0[f] >= w.n_sb || w.imu_sb1[f] < 0 || w.imu_sb1[f] >= w.n_sb)
+        return OKVIS_BA_ERR_ARG;
+      const int64_t b = w.imu_s_begin[f], c = w.imu_s_count[f];   // (64-bit: b + c must not wrap)
+      if (b < 0 || c < 0 || b + c > (int64_t)w.n_imu_samples) return OKVIS_BA_ERR_ARG;
+    }
+    for (int i = 0; i < w.n_pprior; ++i)
+      if (w.pprior_pose[i] < 0 || w.pprior_pose[i] >= w.n_pose) return OKVIS_BA_ERR_ARG;
+    for (int i = 0; i < w.n_sbprior; ++i)
+      if (w.sbprior_sb[i] < 0 || w.sbprior_sb[i] >= w.n_sb) return OKVIS_BA_ERR_ARG;
+    for (int i = 0; i < w.n_relpose; ++i)
+      if (w.rel_pose0[i] < 0 || w.rel_pose0[i] >= w.n_pose || w.rel_pose1[i] < 0 || w.rel_pose1[i] >= w.n_pose) return OKVIS_BA_ERR_ARG;
+    if (w.marg_dim > 0)
+      for (int b = 0; b < w.marg_nblocks; ++b) {
+        const int t = w.marg_block_type[b];
+        if (t != OKVIS_BA_BLOCK_POSE && t != OKVIS_BA_BLOCK_SPEEDBIAS) return OKVIS_BA_ERR_ARG;
+        const int lim = t == OKVIS_BA_BLOCK_POSE ? w.n_pose : w.n_sb, dim = t == OKVIS_BA_BLOCK_POSE ? 6 : 9;
+        if (w.marg_block_idx[b] < 0 || w.marg_block_idx[b] >= lim || w.marg_block_off[b] < 0 ||
+            (int64_t)w.marg_block_off[b] + dim > (int64_t)w.marg_dim)
+          return OKVIS_BA_ERR_ARG;
+      }
     put(pose, w.pose, 7 * (size_t)w.n_pose); put(pose_fixed, w.pose_fixed, (size_t)w.n_pose);
     put(sb, w.sb, 9 * (size_t)w.n_sb); put(sb_fixed, w.sb_fixed, (size_t)w.n_sb);
     put(lm, w.lm, 4 * (size_t)w.n_lm);

@@ -67,9 +67,17 @@ int okvis_ba_gather_records(int32_t rank, int32_t world, int device, const char*
   Rccl R;
   UniqueId id;
   std::memset(&id, 0, sizeof(id));
-  // ---- the id: rank 0 makes it and publishes it with an atomic rename, the others wait for the file ----
+  // every rank loads RCCL BEFORE an id changes hands: a rank that cannot (OKVIS_BA_ERR_UNSUPPORTED) then fails without having
+  // made the others wait inside ncclCommInitRank for it
+  if (!R.load()) return OKVIS_BA_ERR_UNSUPPORTED;   // no librccl.so to be found
+  // ---- the id: rank 0 makes it and publishes it with an atomic rename, the others wait for the file.  The path belongs to
+  //      ONE gather: rank 0 clears whatever an earlier (crashed) job left there before it makes the id, and removes the file
+  //      again as soon as the communicator stands (every rank has read it by then) ----
   if (rank == 0) {
-    if (!R.load()) return OKVIS_BA_ERR_UNSUPPORTED;   // no librccl.so to be found
+    if (world > 1) {
+      (void)std::remove(id_file);
+      (void)std::remove((std::string(id_file) + ".tmp").c_str());
+    }
     if (R.GetUniqueId(&id) != 0) return OKVIS_BA_ERR_STATE;
     if (world > 1) {
       const std::string tmp = std::string(id_file) + ".tmp";
@@ -85,8 +93,11 @@ int okvis_ba_gather_records(int32_t rank, int32_t world, int device, const char*
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return OKVIS_BA_ERR_STATE;
       std::this_thread::sleep_for(std::chrono::milliseconds(2));
     }
-    if (!R.load()) return OKVIS_BA_ERR_UNSUPPORTED;
   }
+  struct RemoveIdFile {   // rank 0, on every way out from here on (a failed rank 0 must not leave an id nobody will honour)
+    const char* f;
+    ~RemoveIdFile() { if (f) (void)std::remove(f); }
+  } remove_id{(rank == 0 && world > 1) ? id_file : nullptr};
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return OKVIS_BA_ERR_NO_DEVICE;
   if (device < 0 || device >= n_dev) return OKVIS_BA_ERR_ARG;
@@ -94,6 +105,10 @@ int okvis_ba_gather_records(int32_t rank, int32_t world, int device, const char*
   if (e != hipSuccess) return OKVIS_BA_HIP_ERROR_BASE + (int)e;
   Comm comm = nullptr;
   if (R.CommInitRank(&comm, world, id, rank) != 0) return OKVIS_BA_ERR_STATE;
+  if (remove_id.f) {   // the communicator stands: every rank has the id
+    (void)std::remove(remove_id.f);
+    remove_id.f = nullptr;
+  }
   unsigned char *d_send = nullptr, *d_recv = nullptr;
   hipStream_t st = nullptr;
   int rc = OKVIS_BA_OK;

@@ -177,3 +177,32 @@ def test_record_gather_checks_its_arguments_and_times_out_without_an_id_file(tmp
     t = time.time()
     assert L.okvis_ba_gather_records(1, 2, 0, os.fsencode(str(tmp_path / "never")), 0.2, mine, 2, out) == -2
     assert 0.15 < time.time() - t < 5.0
+
+
+def test_record_gather_id_file_belongs_to_one_gather(tmp_path):
+    """Two ranks without a device (this container): rank 0 replaces a stale id file left by an earlier job before it publishes
+    its own, rank 1 picks the id up within its time-out, both then fail alike at the first device call (OKVIS_BA_ERR_NO_DEVICE,
+    not a hang in ncclCommInitRank), and rank 0 leaves no file behind."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a host without a GPU: with one, two ranks on the same device cannot form a communicator")
+    idf = tmp_path / "nccl_id"
+    idf.write_bytes(b"\x55" * 128)   # a crashed job's left-over
+    code = (
+        "import ctypes as C, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from okvis_amd import _lib\n"
+        "from okvis_amd.dist import WindowRecordC\n"
+        "L = _lib.lib()\n"
+        "L.okvis_ba_gather_records.argtypes = [C.c_int32, C.c_int32, C.c_int, C.c_char_p, C.c_double, C.c_void_p, C.c_int32, C.c_void_p]\n"
+        "mine, out = (WindowRecordC * 1)(), (WindowRecordC * 2)()\n"
+        "print(L.okvis_ba_gather_records(int(sys.argv[1]), 2, 0, os.fsencode(sys.argv[2]), 20.0, mine, 1, out))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p0 = subprocess.Popen([sys.executable, "-c", code, "0", str(idf)], stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p0.communicate(timeout=120)[0].strip().splitlines() if ln.strip().lstrip("-").isdigit()]
+    # rank 0 fails for want of a device (in ncclGetUniqueId: OKVIS_BA_ERR_STATE, or at the first HIP call: _NO_DEVICE; without a
+    # librccl.so: _UNSUPPORTED) — and the stale id is gone: a rank 1 started now times out instead of joining a dead communicator
+    assert lines and int(lines[-1]) in (-2, -3, -4), lines
+    assert not idf.exists()

@@ -188,3 +188,29 @@ def test_per_frame_extrinsics_leave_with_their_relative_pose_terms():
     v.validate()
     assert solver.check_window(v)["D"] == solver.check_window(w)["D"] - 6 * 3 - 9
     st.close()
+
+
+def test_store_rejects_out_of_range_indices():
+    """okvis_ba_store_create checks every index array (the container is usable without a device: okvis_ba_upload's validation
+    never sees these windows, and apply() indexes its remap tables with the values)."""
+    import copy
+    from okvis_amd._lib import BackendError
+    base = synthetic.small_window(seed=5, K=4, L=30)
+
+    def broken(field, idx, value):
+        w = copy.deepcopy(base)
+        a = np.array(getattr(w, field)).copy()
+        a[idx] = value
+        setattr(w, field, a)
+        return w
+
+    cases = [("obs_lm", 0, base.n_lm), ("obs_lm", 3, -1), ("obs_pose", 1, base.n_pose), ("obs_ext", 2, -2), ("obs_cam", 0, len(base.cam_model)),
+             ("imu_pose0", 0, base.n_pose), ("imu_sb1", 0, base.n_sb), ("imu_s_count", 0, 2 ** 31 - 1), ("imu_s_begin", 0, -1)]
+    if len(base.pprior_pose):
+        cases.append(("pprior_pose", 0, base.n_pose))
+    if len(base.sbprior_sb):
+        cases.append(("sbprior_sb", 0, -1))
+    for field, idx, value in cases:
+        with pytest.raises(BackendError):
+            solver.WindowStore(broken(field, idx, value))
+    solver.WindowStore(base).close()   # the untouched window is still accepted
