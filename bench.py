@@ -414,6 +414,45 @@ def main():
         config_c = {"workload": f"1 window, 50 KF / 2 cam / 2000 landmarks / {wc.n_obs} observations, D = {wc.reduced_dim()}, Gauss-Newton mode",
                     "ms_per_iteration": float(np.median(msc)), "iterations_per_s": 1e3 / float(np.median(msc)),
                     "launch_us": plc, "note": "launch_us.solve = assembly + tile export + tiled fp64-MFMA Cholesky + tail (four launches)"}
+    fp32 = None
+    if rank == 0 and not a.no_extras and not a.pmc_child and not a.fp32:
+        # ---- BASELINE configs[4]: fp32 Jacobian / Hessian build, fp64 Schur complement and reduced solve (okvis_ba_options.
+        #      fp32_linearize), on the windows and in the mode of the headline line; and what it does to the result in the
+        #      reference's mode (DOGLEG, default tolerances, optimize(10) from the perturbed start) on window 0
+        import copy
+        o32 = copy.copy(opt)
+        o32.fp32_linearize = 1
+        b32 = solver.WindowBatch(wins, device=local_rank, options=o32)
+        b32.begin()
+        b32.iterate(a.warmup)
+        b32.synchronize()
+        ms32 = []
+        for _ in range(9):
+            b32.iterate(a.steps)
+            b32.synchronize()
+            ms32.append(b32.last_iterate_ms() / a.steps)
+        pl32 = {k: float(np.median(v)) * 1e3 for k, v in b32.profile_launches(20).items()}
+        b32.finish()
+        b32.close()
+        dev = {}
+        for name, f32 in (("fp64", 0), ("mixed", 1)):
+            od = default_options()
+            od.fp32_linearize = f32
+            bdv = solver.WindowBatch([wins[0]], device=local_rank, options=od)
+            dev[name] = (bdv.optimize(10)[0], bdv.get_state(0))
+            bdv.close()
+        s64, s32 = dev["fp64"][0], dev["mixed"][0]
+        fp32 = {"mode": "fp32_linearize = 1: residual, Jacobians and the J^T J / J^T r products of the linearise launch in fp32; landmark "
+                        "Schur complement, IMU / prior factors and reduced solve in fp64",
+                "iterations_per_s": len(wins) / (float(np.median(ms32)) * 1e-3), "ms_per_step": float(np.median(ms32)),
+                "fp64_iterations_per_s": len(wins) * a.steps / wall, "speedup_over_fp64": (wall / a.steps * 1e3) / float(np.median(ms32)),
+                "launch_us": pl32,
+                "dogleg_window_0": {"final_cost_fp64": s64["final_cost"], "final_cost_mixed": s32["final_cost"],
+                                    "final_cost_rel_dev": abs(s32["final_cost"] - s64["final_cost"]) / s64["final_cost"],
+                                    "iterations_fp64": s64["iterations"], "iterations_mixed": s32["iterations"],
+                                    "max_position_dev_m": float(np.abs(dev["mixed"][1][0][:, :3] - dev["fp64"][1][0][:, :3]).max()),
+                                    "max_landmark_dev_m": float(np.abs(dev["mixed"][1][2][:, :3] - dev["fp64"][1][2][:, :3]).max())},
+                "study": "profiles/r04_mixed_precision.json (8 seeds, 10 and 30 iterations)"}
     frame_host = None
     if rank == 0 and not a.no_extras and not a.pmc_child:
         # ---- what surrounds the iterations of one frame of the estimator (one window, 8 frames, replay-sized): structure upload,
@@ -526,7 +565,7 @@ def main():
                                               "max": max(walls) * 1e3 / a.steps}},
             "window_records": {"fields": ["window_id", "iterations", "final_cost", "seconds"], "n": len(records),
                                "first": records[:2], "collective": (f"one all_gather, backend {dist.get_backend()}" + (" (= RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else "none (1 rank)"},
-            "single_window": single, "roofline": roofline, "dogleg": dogleg, "config_C": config_c, "frontend": frontend, "frame_host": frame_host, "strong_scaling_64_windows": strong,
+            "single_window": single, "roofline": roofline, "dogleg": dogleg, "config_C": config_c, "fp32": fp32, "frontend": frontend, "frame_host": frame_host, "strong_scaling_64_windows": strong,
             "ranks_seen_by_collective": world if dist is None else dist.get_world_size(),
             "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "speedup_vs_cpu": None if cpu is None else {

@@ -638,7 +638,8 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
   flatten(sel, fw);
   const auto t1 = clk::now();
   if (windowObserver_) windowObserver_(&fw.w, 0, windowObserverUser_);
-  if (std::getenv("OKVIS_AMD_TRACE"))
+  static const bool trace = std::getenv("OKVIS_AMD_TRACE") != nullptr;   // (read once: optimize() is the per-frame hot path)
+  if (trace)
     for (size_t a = 0; a < fw.f64.size(); ++a) {
       size_t bad = 0;
       for (double v : fw.f64[a]) bad += !std::isfinite(v);
@@ -648,13 +649,13 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
   const auto t1b = clk::now();
   check(okvis_ba_upload(solver_, 1, &fw.w), "upload");
   const auto t2 = clk::now();
-  if (std::getenv("OKVIS_AMD_TRACE")) std::printf("set_options %.4f ms, upload %.4f ms\n", ms(t1, t1b), ms(t1b, t2));
+  if (trace) std::printf("set_options %.4f ms, upload %.4f ms\n", ms(t1, t1b), ms(t1b, t2));
   if (hasTimeLimit_)  // CeresIterationCallback semantics (CeresIterationCallback.hpp:77-86)
     check(okvis_ba_optimize_timed(solver_, (int)numIter, minIterations_, timeLimit_, &summary_), "optimize");
   else
     check(okvis_ba_optimize(solver_, (int)numIter, &summary_), "optimize");
   const auto t3 = clk::now();
-  if (verbose || std::getenv("OKVIS_AMD_TRACE"))  // the reference prints summary.FullReport() when verbose (Estimator.cpp:870-872)
+  if (verbose || trace)  // the reference prints summary.FullReport() when verbose (Estimator.cpp:870-872)
     std::printf("okvis_amd::Estimator::optimize: %d poses, %d speed/bias, %d landmarks, %d observations, %d IMU terms, prior %d | "
                 "iterations %d (%d successful), cost %.9g -> %.9g, termination %d, radius %.3g\n",
                 fw.w.n_pose, fw.w.n_sb, fw.w.n_lm, fw.w.n_obs, fw.w.n_imu, fw.w.marg_dim, summary_.iterations,
@@ -687,17 +688,20 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
     std::lock_guard<std::mutex> l(statesMutex_);
     // sel.landmarks was filled by walking landmarksMap_ (selectAll): same order, so the map is walked again instead of
     // nl lookups (nothing was inserted or erased in between: optimize() runs under the caller's estimator mutex)
+    // (the qualities of unobserved landmarks — not part of the problem — are zeroed in a pass of their own: a shared iterator
+    //  would skip or revisit some of them whenever the walk has to fall back on a lookup)
+    for (auto& kv : landmarksMap_)
+      if (kv.second.observations.empty()) kv.second.quality = 0.0;
     auto it = landmarksMap_.begin();
-    for (size_t i = 0; i < nl; ++i, ++it) {
-      for (; it != landmarksMap_.end() && it->first != sel.landmarks[i] && it->second.observations.empty(); ++it)
-        it->second.quality = 0.0;  // unobserved, not part of the problem
+    for (size_t i = 0; i < nl; ++i) {
+      while (it != landmarksMap_.end() && it->first != sel.landmarks[i] && it->second.observations.empty()) ++it;
       if (it == landmarksMap_.end() || it->first != sel.landmarks[i]) it = landmarksMap_.find(sel.landmarks[i]);
+      if (it == landmarksMap_.end()) continue;   // (cannot happen: nothing is erased between selectAll and here)
       MapPoint& mp = it->second;
       mp.quality = q[i];
       std::copy(lm.begin() + 4 * i, lm.begin() + 4 * i + 4, mp.point.begin());
+      ++it;
     }
-    for (; it != landmarksMap_.end(); ++it)
-      if (it->second.observations.empty()) it->second.quality = 0.0;
   }
   timings_ = {ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, clk::now())};
 }

@@ -44,14 +44,14 @@ def throughput(ws, fp32, steps=100):
 def main():
     seeds = [20240923 + i for i in range(8)]
     ws = [synthetic.config_A(seed=s) for s in seeds]
-    out = {"config": "BASELINE configs[4] on configs[1] windows (10 KF / 2 cam / 400 landmarks / 8000 obs), 8 seeds"}
+    out = {"config": "BASELINE configs[4] on configs[1] windows (10 KF / 2 cam / 400 landmarks / 8000 obs), 8 seeds; DOGLEG (the default strategy), round-4 kernels (piece path of the linearise launch)"}
     for iters in (10, 30):
         s64, st64 = run(ws, False, iters)
         s32, st32 = run(ws, True, iters)
         dev = [abs(a["final_cost"] - b["final_cost"]) / b["final_cost"] for a, b in zip(s32, s64)]
         dpos = max(np.abs(a[0][:, :3] - b[0][:, :3]).max() for a, b in zip(st32, st64))
         dlm = max(np.abs(a[2][:, :3] - b[2][:, :3]).max() for a, b in zip(st32, st64))
-        out[f"lm_{iters}_iterations"] = {
+        out[f"dogleg_{iters}_iterations"] = {
             "final_cost_rel_dev_max": max(dev), "final_cost_rel_dev_median": float(np.median(dev)),
             "iterations_fp64": [x["iterations"] for x in s64], "iterations_mixed": [x["iterations"] for x in s32],
             "termination_fp64": [x["termination"] for x in s64], "termination_mixed": [x["termination"] for x in s32],
