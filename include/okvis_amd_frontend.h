@@ -73,6 +73,13 @@ int okvis_fe_stereo_triangulate(okvis_fe_context* ctx, const okvis_fe_camera* ca
                                 const double* T_AB, const double* UOplus, int32_t n_a, const float* kp_a, int32_t n_b,
                                 const float* kp_b, int32_t n_pairs, const int32_t* pairs, const double* sigma_ray,
                                 int32_t want_uncertainty, double* hp_a, double* cov, uint8_t* flags);
+/* The same call with one more output: gn [n_pairs][81] = the 9x9 Gauss-Newton matrix H of getUncertainty (:286-345; rows /
+ * columns 0..5 the relative pose, 6..8 the point), row-major, zeros where getUncertainty does not run.  For referees of the
+ * point covariance (tests/test_gpu_frontend.py inverts it in extended precision); NULL = okvis_fe_stereo_triangulate. */
+int okvis_fe_stereo_triangulate_gn(okvis_fe_context* ctx, const okvis_fe_camera* cam_a, const okvis_fe_camera* cam_b,
+                                const double* T_AB, const double* UOplus, int32_t n_a, const float* kp_a, int32_t n_b,
+                                const float* kp_b, int32_t n_pairs, const int32_t* pairs, const double* sigma_ray,
+                                int32_t want_uncertainty, double* hp_a, double* cov, uint8_t* flags, double* gn);
 
 /* hp_W [n][4] through T_CbW [7] into camera B: uv [n][2] (written unless INVALID), U [n][4] = J P_C J^T row-major 2x2 with
  * P_C = P3 [9] (row-major 3x3, the top-left block of the relative pose uncertainty, :197-203), status [n]. */

@@ -689,6 +689,7 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
   if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[62] = (double)clock64();   // diagnostics: length of one IMU workgroup
   imu_maybe_redo(W, f, trial, lds, tid);  // rarely taken; updates the HBM cache in place
   __syncthreads();
+  if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[36] = (double)clock64();
   double* ca = lds + EvalLds::CA;
   const double* p0 = W.pose[trial] + 7 * (size_t)W.imu_pose0[f];
   const double* p1 = W.pose[trial] + 7 * (size_t)W.imu_pose1[f];
@@ -715,6 +716,7 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
   }
   if (tid < 225) ca[CA_SI + tid] = cg->sqrt_info[tid];
   __syncthreads();
+  if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[37] = (double)clock64();
   // ---- F = [F0 | F1] and the error vector by one work-item (ImuError.cpp:561-601)
   double* F = lds + EvalLds::FM;
   double* ev = lds + EvalLds::EV;
@@ -838,6 +840,7 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
     for (int i = 0; i < 6; ++i) ev[9 + i] = sb0[3 + i] - b1[3 + i];
   }
   __syncthreads();
+  if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[39] = (double)clock64();
   // ---- J = sqrtInfo (upper) * F (kept in LDS), r = sqrtInfo * e, then H = J^T J and g = J^T r
   double* out = W.imu_lin[trial] + (size_t)f * IMU_LIN_STRIDE;
   const double* SI = ca + CA_SI;
@@ -856,6 +859,7 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
     s_r[tid] = s;
   }
   __syncthreads();
+  if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[59] = (double)clock64();
   for (int wi = tid; wi < 465 + 30; wi += IMU_THREADS) {
     if (wi < 465) {
       int a = (int)((sqrtf(8.0f * wi + 1.0f) - 1.0f) * 0.5f);

@@ -127,6 +127,14 @@ int okvis_fe_stereo_triangulate(okvis_fe_context* c, const okvis_fe_camera* cam_
                                 const double* T_AB, const double* UOplus, int32_t n_a, const float* kp_a, int32_t n_b,
                                 const float* kp_b, int32_t n_pairs, const int32_t* pairs, const double* sigma_ray,
                                 int32_t want_uncertainty, double* hp_a, double* cov, uint8_t* flags) {
+  return okvis_fe_stereo_triangulate_gn(c, cam_a, cam_b, T_AB, UOplus, n_a, kp_a, n_b, kp_b, n_pairs, pairs, sigma_ray, want_uncertainty, hp_a,
+                                        cov, flags, nullptr);
+}
+
+int okvis_fe_stereo_triangulate_gn(okvis_fe_context* c, const okvis_fe_camera* cam_a, const okvis_fe_camera* cam_b,
+                                   const double* T_AB, const double* UOplus, int32_t n_a, const float* kp_a, int32_t n_b,
+                                   const float* kp_b, int32_t n_pairs, const int32_t* pairs, const double* sigma_ray,
+                                   int32_t want_uncertainty, double* hp_a, double* cov, uint8_t* flags, double* gn) {
   if (!c || !camera_ok(cam_a) || !camera_ok(cam_b) || !T_AB || !UOplus || n_a < 0 || n_b < 0 || n_pairs < 0) return OKVIS_BA_ERR_ARG;
   if (n_pairs == 0) return OKVIS_BA_OK;
   if (!kp_a || !kp_b || !pairs || n_a == 0 || n_b == 0) return OKVIS_BA_ERR_ARG;
@@ -145,6 +153,7 @@ int okvis_fe_stereo_triangulate(okvis_fe_context* c, const okvis_fe_camera* cam_
   all = in;
   const size_t o_hp = all.add(sizeof(double) * 4 * n_pairs), o_cov = all.add(sizeof(double) * 9 * n_pairs);
   const size_t o_fl = all.add(n_pairs);
+  const size_t o_gn = gn ? all.add(sizeof(double) * 81 * n_pairs) : 0;
   if (int rc = reserve(c, all.size)) return rc;
   std::memcpy(c->h_stage + o_ka, kp_a, sizeof(float) * 3 * n_a);
   std::memcpy(c->h_stage + o_kb, kp_b, sizeof(float) * 3 * n_b);
@@ -152,6 +161,8 @@ int okvis_fe_stereo_triangulate(okvis_fe_context* c, const okvis_fe_camera* cam_
   if (sigma_ray) std::memcpy(c->h_stage + o_sig, sigma_ray, sizeof(double) * n_pairs);
   FE_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, in.size, hipMemcpyHostToDevice, c->stream));
   if (cov) FE_TRY(hipMemsetAsync(c->d_stage + o_cov, 0, sizeof(double) * 9 * n_pairs, c->stream));
+  if (gn) FE_TRY(hipMemsetAsync(c->d_stage + o_gn, 0, sizeof(double) * 81 * n_pairs, c->stream));
+  P.gn = gn ? (double*)(c->d_stage + o_gn) : nullptr;
   P.kp_a = (const float*)(c->d_stage + o_ka), P.kp_b = (const float*)(c->d_stage + o_kb);
   P.pairs = (const int32_t*)(c->d_stage + o_pairs);
   P.sigma_ray = sigma_ray ? (const double*)(c->d_stage + o_sig) : nullptr;
@@ -164,6 +175,7 @@ int okvis_fe_stereo_triangulate(okvis_fe_context* c, const okvis_fe_camera* cam_
   if (hp_a) std::memcpy(hp_a, c->h_stage + o_hp, sizeof(double) * 4 * n_pairs);
   if (cov) std::memcpy(cov, c->h_stage + o_cov, sizeof(double) * 9 * n_pairs);
   if (flags) std::memcpy(flags, c->h_stage + o_fl, n_pairs);
+  if (gn) std::memcpy(gn, c->h_stage + o_gn, sizeof(double) * 81 * n_pairs);
   return OKVIS_BA_OK;
 }
 

@@ -38,6 +38,7 @@ struct TriParams {
   double* hp;             // [n_pairs][4]
   double* cov;            // [n_pairs][9]
   uint8_t* flags;
+  double* gn;             // [n_pairs][81] the 9x9 Gauss-Newton matrix of getUncertainty (row-major), or null
 };
 
 // D::undistort(pointDistorted, &pointUndistorted): Gauss-Newton on distort(), at most 5 iterations
@@ -350,6 +351,8 @@ __global__ void __launch_bounds__(TRI_THREADS) stereo_triangulate_kernel(const T
         if (r >= 6 && c >= 6) v += la.Jl[r - 6] * la.Jl[c - 6] + la.Jl[3 + r - 6] * la.Jl[3 + c - 6];
         H[9 * r + c] = v;
       }
+    if (P.gn)
+      for (int k = 0; k < 81; ++k) P.gn[81 * (size_t)i + k] = H[k];
     double* M = sH + threadIdx.x;
 #pragma unroll
     for (int r = 0; r < 9; ++r)

@@ -11,7 +11,8 @@ from . import _lib
 TRI_VALID, TRI_NOT_PARALLEL, TRI_CAN_INIT, TRI_RANK_DEFICIENT = 1, 2, 4, 8
 PROJ_SUCCESSFUL, PROJ_OUTSIDE_IMAGE, PROJ_MASKED, PROJ_BEHIND, PROJ_INVALID = range(5)
 GATE_VERIFIED, GATE_ACCEPTED, GATE_UNCERTAIN = 1, 2, 4
-SYMBOLS = ["okvis_fe_create", "okvis_fe_destroy", "okvis_fe_stereo_triangulate", "okvis_fe_project_landmarks", "okvis_fe_gate_3d2d"]
+SYMBOLS = ["okvis_fe_create", "okvis_fe_destroy", "okvis_fe_stereo_triangulate", "okvis_fe_stereo_triangulate_gn", "okvis_fe_project_landmarks",
+           "okvis_fe_gate_3d2d"]
 
 
 class CameraC(C.Structure):
@@ -45,6 +46,9 @@ def declare(L, prefix="okvis_fe_", with_context=True):
     cam = C.POINTER(CameraC)
     getattr(L, prefix + "stereo_triangulate").argtypes = ctx + [cam, cam, vp, vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, vp,
                                                                 C.c_int32, vp, vp, vp]
+    if with_context and hasattr(L, prefix + "stereo_triangulate_gn"):
+        getattr(L, prefix + "stereo_triangulate_gn").argtypes = ctx + [cam, cam, vp, vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, vp, vp,
+                                                                       C.c_int32, vp, vp, vp, vp]
     getattr(L, prefix + "project_landmarks").argtypes = ctx + [cam, vp, vp, C.c_int32, vp, vp, vp, vp]
     getattr(L, prefix + "gate_3d2d").argtypes = ctx + [C.c_int32, vp, vp, C.c_int32, vp, C.c_int32, vp, vp, vp]
 
@@ -95,6 +99,19 @@ class Frontend:
                    kp_a.ctypes.data, len(kp_b), kp_b.ctypes.data, n, pairs.ctypes.data, None if sig is None else sig.ctypes.data,
                    int(bool(want_uncertainty)), hp.ctypes.data, cov.ctypes.data, flags.ctypes.data)
         return hp, cov, flags
+
+    def stereo_triangulate_gn(self, cam_a: CameraC, cam_b: CameraC, T_AB, UOplus, kp_a, kp_b, pairs, sigma_ray=None):
+        """okvis_fe_stereo_triangulate_gn -> hp_A, cov, flags, gn [n][9][9] (the Gauss-Newton matrix getUncertainty inverts)"""
+        kp_a, kp_b = _f32(kp_a, 3), _f32(kp_b, 3)
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        n = len(pairs)
+        T_AB, UOplus = _f64(T_AB, 7), _f64(UOplus, (6, 6))
+        sig = None if sigma_ray is None else _f64(sigma_ray, n)
+        hp, cov, flags, gn = np.zeros((n, 4)), np.zeros((n, 3, 3)), np.zeros(n, np.uint8), np.zeros((n, 9, 9))
+        self._call("stereo_triangulate_gn", C.byref(cam_a), C.byref(cam_b), T_AB.ctypes.data, UOplus.ctypes.data, len(kp_a),
+                   kp_a.ctypes.data, len(kp_b), kp_b.ctypes.data, n, pairs.ctypes.data, None if sig is None else sig.ctypes.data,
+                   1, hp.ctypes.data, cov.ctypes.data, flags.ctypes.data, gn.ctypes.data)
+        return hp, cov, flags, gn
 
     def project_landmarks(self, cam_b: CameraC, T_CbW, P3, hp_W):
         """-> uv [n][2], U [n][2][2], status [n] (PROJ_*)"""

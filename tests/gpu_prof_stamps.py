@@ -35,3 +35,4 @@ for k in range(41, 50):
     d = p[k] - p[k - 1]; print(f"  {ln[k]:36s} {d:10.0f} cyc {d/2100:8.2f} us")
 print("  total", (p[49] - p[40]) / 2100, "us")
 print("one IMU workgroup (factor 0, no re-preintegration):", (p[63] - p[62]) / 2100, "us")
+print("IMU workgroup (us): entry + bias check", (p[36]-p[62])/2100, " cache -> LDS", (p[37]-p[36])/2100, " F + error (one work-item)", (p[39]-p[37])/2100, " J = sqrtInfo F", (p[59]-p[39])/2100, " H, g", (p[63]-p[59])/2100)
