@@ -551,7 +551,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // landmarks per Schur workgroup: 48 (three staged batches of 16) keeps the workgroup count low when many windows share
     // the device; a few windows have the device to themselves and finish sooner with 32 (measured, tests/gpu_chunk_diag.py:
     // one window 114.7 vs 119.7 us per iteration, 64 windows 239 vs 217)
-    int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : (n_windows_total <= 8 ? 16 : n_windows_total < SMALL_BATCH_WINDOWS ? 32 : 48), SCHUR_CHUNK_LM_MAX);
+    static const int per_env = [] { const char* e = std::getenv("OKVIS_BA_SCHUR_LM"); return e ? std::atoi(e) : 0; }();   // (diagnostics: chunk sweep)
+    int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : per_env > 0 ? per_env : (n_windows_total <= 8 ? 16 : n_windows_total < SMALL_BATCH_WINDOWS ? 32 : n_windows_total < 128 ? 48 : 64), SCHUR_CHUNK_LM_MAX);   // (round 4 sweep with the matrix-core kernel, 64 windows: 12: 382 k, 24: 436 k, 48: 448 k, 64: 448 k it/s; 256 windows: 48: 585 k, 64: 597 k)
     // fused mode (the linearise workgroup reduces its own group, no Schur launch: DOGLEG and fixed-radius runs): possible when
     // the reduced system is solved in LDS, the pose part is one Schur tile and the reduction's landmark tables fit the observation stage of the linearise kernel;
     // then chunk = group.  options.reserved0 bit 2 keeps the separate launch (A/B switch).
