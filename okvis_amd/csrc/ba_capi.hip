@@ -990,9 +990,10 @@ int lin2_step_doubles(int max_Dp, bool fuse, bool f32) {
   const int aux = fuse ? (f32 ? Lin2Cfg<float, true>::MIN_STEP_DOUBLES : Lin2Cfg<double, true>::MIN_STEP_DOUBLES) : Lin2Cfg<double, false>::MIN_STEP_DOUBLES;
   return ((max_Dp + 1) / 2) * 2 + 8 + aux;   // pose part of the step, then the aux area of the fused reduction
 }
-size_t lin2_smem(int max_Dp, bool fuse, bool f32) {
-  const int fixed = f32 ? (fuse ? Lin2Cfg<float, true>::FIXED_DOUBLES : Lin2Cfg<float, false>::FIXED_DOUBLES)
-                        : (fuse ? Lin2Cfg<double, true>::FIXED_DOUBLES : Lin2Cfg<double, false>::FIXED_DOUBLES);
+size_t lin2_smem(int max_Dp, bool fuse, bool f32, bool two_rounds = false) {
+  const int fixed = two_rounds ? (f32 ? Lin2Cfg<float, false, 14>::FIXED_DOUBLES : Lin2Cfg<double, false, 14>::FIXED_DOUBLES)
+                    : f32 ? (fuse ? Lin2Cfg<float, true>::FIXED_DOUBLES : Lin2Cfg<float, false>::FIXED_DOUBLES)
+                          : (fuse ? Lin2Cfg<double, true>::FIXED_DOUBLES : Lin2Cfg<double, false>::FIXED_DOUBLES);
   return (size_t)(fixed + lin2_step_doubles(max_Dp, fuse, f32)) * sizeof(double);
 }
 size_t small_smem() { return (size_t)std::max<int>(std::max<int>(ImuLds::TOTAL, EvalLds::TOTAL), 2 * MAX_MARG_DIM) * sizeof(double); }
@@ -1102,11 +1103,13 @@ hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
     if (s->split_small) {
       hipLaunchKernelGGL(small_kernel, dim3(n_small, (unsigned)b.nw), dim3(LIN_THREADS), small_smem(), b.st, s->d_wins + b.w0, init);
       const dim3 grid2(s->max_group, (unsigned)b.nw);
-      auto go2 = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid2, dim3(LIN_THREADS), smem2, b.st, s->d_wins + b.w0, s->d_opt, init, 0, sd); };
-      // (registers: 4 workgroups per CU = 128 per work-item, 3 = 168; OKVIS_BA_LIN2_OCC picks, diagnostics)
-      static const int occ = [] { const char* e = std::getenv("OKVIS_BA_LIN2_OCC"); return e ? std::atoi(e) : 3; }();
-      if (f32) fuse ? go2(linearize2_kernel<float, true, false>) : (occ >= 4 ? go2(linearize2_kernel<float, false, false, 4>) : go2(linearize2_kernel<float, false, false, 3>));
-      else fuse ? go2(linearize2_kernel<double, true, false>) : (occ >= 4 ? go2(linearize2_kernel<double, false, false, 4>) : go2(linearize2_kernel<double, false, false, 3>));
+      static const int occ_env = [] { const char* e = std::getenv("OKVIS_BA_LIN2_OCC"); return e ? std::atoi(e) : 4; }();
+      const bool two_rounds = !fuse && occ_env >= 4;   // block records in two rounds: 37 KB of LDS, four workgroups per CU
+      const size_t smem2v = two_rounds ? lin2_smem(s->max_Dp, false, f32, true) : smem2;
+      auto go2 = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid2, dim3(LIN_THREADS), smem2v, b.st, s->d_wins + b.w0, s->d_opt, init, 0, sd); };
+      const int occ = occ_env;
+      if (f32) fuse ? go2(linearize2_kernel<float, true, false>) : (occ >= 4 ? go2(linearize2_kernel<float, false, false, 4, 14>) : go2(linearize2_kernel<float, false, false, 3>));
+      else fuse ? go2(linearize2_kernel<double, true, false>) : (occ >= 4 ? go2(linearize2_kernel<double, false, false, 4, 14>) : go2(linearize2_kernel<double, false, false, 3>));
     } else {
       const dim3 grid2(n_small + s->max_group, (unsigned)b.nw);
       const size_t sm = std::max(smem2, small_smem());
@@ -1282,12 +1285,12 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   {
     const size_t l2d = std::max(lin2_smem(MAX_D, true, false), small_smem()), l2f = std::max(lin2_smem(MAX_D, true, true), small_smem());
     lds(reinterpret_cast<const void*>(&linearize2_kernel<double, false, false, 3>), l2d);
-    lds(reinterpret_cast<const void*>(&linearize2_kernel<double, false, false, 4>), l2d);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<double, false, false, 4, 14>), l2d);
     lds(reinterpret_cast<const void*>(&linearize2_kernel<double, false, true>), l2d);
     lds(reinterpret_cast<const void*>(&linearize2_kernel<double, true, false>), l2d);
     lds(reinterpret_cast<const void*>(&linearize2_kernel<double, true, true>), l2d);
     lds(reinterpret_cast<const void*>(&linearize2_kernel<float, false, false, 3>), l2f);
-    lds(reinterpret_cast<const void*>(&linearize2_kernel<float, false, false, 4>), l2f);
+    lds(reinterpret_cast<const void*>(&linearize2_kernel<float, false, false, 4, 14>), l2f);
     lds(reinterpret_cast<const void*>(&linearize2_kernel<float, false, true>), l2f);
     lds(reinterpret_cast<const void*>(&linearize2_kernel<float, true, false>), l2f);
     lds(reinterpret_cast<const void*>(&linearize2_kernel<float, true, true>), l2f);

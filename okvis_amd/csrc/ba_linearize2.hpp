@@ -36,17 +36,19 @@ constexpr int LIN2_POSES = 64;   // poses of a window staged in LDS (more: phase
 constexpr int LIN2_CAMS = 8;     // cameras staged in LDS
 constexpr int LIN2_IDX_INTS = 2 * (((GROUP_LM + 1) + 2 * LIN2_PIECES + LIN_TASK_CACHE * 6 + LIN2_PIECES / 2 + LIN2_PIECES / 4 + LIN2_CAMS + 1) / 2);
 
-template <class REAL, bool FUSE>
+// UB: entries of the block records that go through LDS per round: all 27 (one round), or 14 (two rounds: the record area then
+// is the 16 KB of the piece records, and four workgroups instead of three fit a CU)
+template <class REAL, bool FUSE, int UB = LIN2_REC>
 struct Lin2Cfg {
   // piece records [pieces][16], then block records [pairs][27]; the fused launch puts the tiles / tables of the group
   // reduction here afterwards (at least the observation stage of ba_linearize.hpp, which the host checked them against)
-  static constexpr int PAIR_REC_DOUBLES = (LIN2_PIECES * LIN2_REC * (int)sizeof(REAL) + 7) / 8;
+  static constexpr int PAIR_REC_DOUBLES = (LIN2_PIECES * (UB > 16 ? UB : 16) * (int)sizeof(REAL) + 7) / 8;
   static constexpr int STAGE = LinCfg<false, REAL>::STAGE_DOUBLES;
   static constexpr int REC_DOUBLES = FUSE ? (STAGE > PAIR_REC_DOUBLES ? STAGE : PAIR_REC_DOUBLES) : PAIR_REC_DOUBLES;
   static constexpr int FIXED_DOUBLES = REC_DOUBLES + GROUP_LM * 4 + GROUP_LM * 16 + 4 * 64 + LIN2_POSES * 7 + LIN2_CAMS * 12 + LIN2_IDX_INTS / 2;
   static constexpr int MIN_STEP_DOUBLES = FUSE ? 1024 : 0;   // aux area behind the step (fused: inverse landmark blocks, J^T J blocks, offsets)
 };
-static_assert(LIN2_PIECES * 16 <= LIN2_PIECES * LIN2_REC && LIN2_PIECES * 3 * 2 <= LIN2_PIECES * LIN2_REC, "aliases of the record area");
+static_assert(LIN2_PIECES * 3 * 2 <= LIN2_PIECES * 16, "phase A's pair sums alias the record area");
 static_assert(LIN2_PIECES <= LIN_THREADS, "one pair per work-item");
 
 // value of lane + 1 of the same DPP row (0 for the last lane of a row): row_shl:1
@@ -70,7 +72,7 @@ struct Lin2Heavy {   // operands of the back-substitution (54 registers)
 // SMALL: the first n_small workgroups evaluate the IMU / prior factors (as in ba_linearize.hpp: one launch, one window's
 // latency); without it the small factors have their own launch (small_kernel) and this kernel's register budget is its
 // own.  OCC: workgroups per CU the kernel is compiled for (512 / OCC registers per work-item).
-template <class REAL, bool FUSE, bool SMALL, int OCC = 2>
+template <class REAL, bool FUSE, bool SMALL, int OCC = 2, int UB = LIN2_REC>
 __global__ __launch_bounds__(LIN_THREADS, OCC) void linearize2_kernel(const WinPtrs* __restrict__ wins, const OptD* __restrict__ optp, int init,
                                                                       int n_small, int step_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(LIN_THREADS, OCC) void linearize2_kernel(const WinP
   const Ctrl* ctrl = W.ctrl;
   if (ctrl->done) return;
   const OptD opt = *optp;
-  constexpr int RECD = Lin2Cfg<REAL, FUSE>::REC_DOUBLES;
+  constexpr int RECD = Lin2Cfg<REAL, FUSE, UB>::REC_DOUBLES;
   REAL* s_rec = reinterpret_cast<REAL*>(smem);   // [pieces][16] piece records; then [pairs][27] block records in slot order
   double* s_pair = smem;                         // phase A: [pairs][3]
   double* s_lm = smem + RECD;                    // [GROUP_LM][4] trial landmarks
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(LIN_THREADS, OCC) void linearize2_kernel(const WinP
   uint16_t* s_slot = reinterpret_cast<uint16_t*>(s_cmodel + LIN2_CAMS);   // [LIN2_PIECES] pair -> slot of its block record
   uint8_t* s_plm = reinterpret_cast<uint8_t*>(s_slot + LIN2_PIECES);      // [LIN2_PIECES] group-local landmark of a pair
   double* s_step = reinterpret_cast<double*>(s_lpb + LIN2_IDX_INTS);      // [step_doubles]: pose part of the step | fused: aux area
-  double* s_aux = s_step + (step_doubles - Lin2Cfg<REAL, FUSE>::MIN_STEP_DOUBLES);   // (fused: inverse landmark blocks, J^T J blocks, offsets)
+  double* s_aux = s_step + (step_doubles - Lin2Cfg<REAL, FUSE, UB>::MIN_STEP_DOUBLES);   // (fused: inverse landmark blocks, J^T J blocks, offsets)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // ---- fused mode: see ba_linearize.hpp ----
@@ -524,43 +526,56 @@ __global__ __launch_bounds__(LIN_THREADS, OCC) void linearize2_kernel(const WinP
       double* Wt = W.W[trial] + (size_t)(G.pair_begin + tid) * 18;
 #pragma unroll
       for (int i = 0; i < 18; ++i) Wt[i] = Wm[i];
-      // entry k of the pair's block record: k < 21: U[ra][b] = sum_c W[ra][c] M[c][b] at k = ut6(ra, b); 21 + a: g[a] (ra == 6)
-      auto urec = [&](int ra, int b) -> REAL {
-        const REAL w0 = ra < 6 ? Wm[3 * (ra < 6 ? ra : 0)] : bp[0], w1 = ra < 6 ? Wm[3 * (ra < 6 ? ra : 0) + 1] : bp[1],
-                   w2 = ra < 6 ? Wm[3 * (ra < 6 ? ra : 0) + 2] : bp[2];
-        return b == 0 ? -hw * w0 : b == 1 ? -hw * w1 : b == 2 ? -hw * w2 : b == 3 ? w1 * d2 - w2 * d1 : b == 4 ? w2 * d0 - w0 * d2 : w0 * d1 - w1 * d0;
-      };
-      // the record goes to the pair's SLOT: the records of one block (task) are contiguous there
-      REAL* ur = s_rec + LIN2_REC * my_slot;
+    }
+    // (c) per-block J^T J / J^T r partials.  The pair's record goes to its SLOT — the records of one block (task) are contiguous
+    //     there — UB entries per round, and every (block, entry) is one contiguous sum in slot (= list) order
+    auto urec_k = [&](int kk) -> REAL {   // entry kk of this pair's block record: k < 21: U[ra][b] at k = ut6(ra, b); 21 + a: g[a]
+      REAL v = 0;
       int k = 0;
 #pragma unroll
       for (int ra = 0; ra < 7; ++ra)
 #pragma unroll
-        for (int b = (ra < 6 ? ra : 0); b < 6; ++b, ++k) ur[k] = urec(ra, b);
-    }
-    __syncthreads();
-    LSTAMP(47);
-    // (c) per-block J^T J / J^T r partials: contiguous sums over the block's records, in slot (= list) order
-    for (int wi = tid; wi < ntask * LIN2_REC; wi += LIN_THREADS) {
-      const int tt = wi / LIN2_REC, k = wi - tt * LIN2_REC;
-      int lb, le, out;
-      if (tasks_cached) {
-        const int* t = s_task + 6 * tt;
-        lb = t[3], le = t[4], out = t[5];
-      } else {
-        const Task T = W.tasks[G.task_begin + tt];
-        lb = T.list_begin - G.tlist_begin, le = T.list_end - G.tlist_begin, out = T.out;
+        for (int b = (ra < 6 ? ra : 0); b < 6; ++b, ++k)
+          if (k == kk) {
+            const REAL w0 = ra < 6 ? Wm[3 * (ra < 6 ? ra : 0)] : bp[0], w1 = ra < 6 ? Wm[3 * (ra < 6 ? ra : 0) + 1] : bp[1],
+                       w2 = ra < 6 ? Wm[3 * (ra < 6 ? ra : 0) + 2] : bp[2];
+            v = b == 0 ? -hw * w0 : b == 1 ? -hw * w1 : b == 2 ? -hw * w2 : b == 3 ? w1 * d2 - w2 * d1 : b == 4 ? w2 * d0 - w0 * d2 : w0 * d1 - w1 * d0;
+          }
+      return v;
+    };
+#pragma unroll
+    for (int r0 = 0; r0 < LIN2_REC; r0 += UB) {
+      const int ne = (LIN2_REC - r0 < UB) ? LIN2_REC - r0 : UB;
+      if (r0 > 0) __syncthreads();   // the previous round's sums are done with the records
+      if (has_pair) {
+        REAL* ur = s_rec + UB * my_slot;
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+          if (k < ne) ur[k] = urec_k(r0 + k);
       }
-      REAL s0 = 0, s1 = 0;
-      int j = lb;
-      for (; j + 1 < le; j += 2) {
-        s0 += s_rec[j * LIN2_REC + k];
-        s1 += s_rec[(j + 1) * LIN2_REC + k];
+      __syncthreads();
+      if (r0 == 0) LSTAMP(47);
+      for (int wi = tid; wi < ntask * ne; wi += LIN_THREADS) {
+        const int tt = wi / ne, k = wi - tt * ne;
+        int lb, le, out;
+        if (tasks_cached) {
+          const int* t = s_task + 6 * tt;
+          lb = t[3], le = t[4], out = t[5];
+        } else {
+          const Task T = W.tasks[G.task_begin + tt];
+          lb = T.list_begin - G.tlist_begin, le = T.list_end - G.tlist_begin, out = T.out;
+        }
+        REAL s0 = 0, s1 = 0;
+        int j = lb;
+        for (; j + 1 < le; j += 2) {
+          s0 += s_rec[j * UB + k];
+          s1 += s_rec[(j + 1) * UB + k];
+        }
+        if (j < le) s0 += s_rec[j * UB + k];
+        const REAL sum = s0 + s1;
+        W.gpart[trial][out + r0 + k] = sum;
+        if (fast) s_aux[GROUP_LM * 9 + tt * 36 + r0 + k] = sum;   // the group's own J^T J / J^T r blocks for the reduction below
       }
-      if (j < le) s0 += s_rec[j * LIN2_REC + k];
-      const REAL sum = s0 + s1;
-      W.gpart[trial][out + k] = sum;
-      if (fast) s_aux[GROUP_LM * 9 + tt * 36 + k] = sum;   // the group's own J^T J / J^T r blocks for the reduction below
     }
     LSTAMP(48);
     LSTAMP(49);
