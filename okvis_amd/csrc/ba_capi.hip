@@ -761,6 +761,22 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(chunk_cross_begin, put(A, chunk_cross_begin));
   OFF(chunk_cross, put(A, chunk_cross));
   OFF(chunk_desc, put(A, chunk_desc));
+  {
+    // several Schur tiles per dimension (pose part beyond 96 rows): where the (landmark, block) pairs of every tile start, so that
+    // a tile pair's workgroup touches its own pairs only (the pairs of a landmark are sorted by block)
+    std::vector<int> lm_tile_begin;
+    if (ntile > 1) {
+      lm_tile_begin.resize((size_t)nlm * (ntile + 1));
+      for (int l = 0; l < nlm; ++l) {
+        int p = lm_pair_begin[l];
+        for (int t = 0; t <= ntile; ++t) {
+          while (p < lm_pair_begin[l + 1] && pair_off[p] < t * SCHUR_TILE_BLOCKS * 6) ++p;
+          lm_tile_begin[(size_t)l * (ntile + 1) + t] = p;
+        }
+      }
+    }
+    OFF(lm_tile_begin, put(A, lm_tile_begin));
+  }
   OFF(imu_order, put(A, imu_order));
   OFF(imu_color_begin, put(A, imu_color_begin));
   OFF(imu_coloff, put(A, imu_coloff));

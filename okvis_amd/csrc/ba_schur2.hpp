@@ -50,6 +50,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
   __shared__ int s_dec[2];
   __shared__ double s_lambda;
   __shared__ Ctrl s_ctrl;
+  __shared__ int2 s_tb[SCH2_MAXT > 3 ? 2 * SCHUR_CHUNK_LM_MAX : 2];   // several tiles per dimension: pair range of (landmark, row | column tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #undef SSTAMP
@@ -117,6 +118,13 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
     for (int q = 0; q < SCH2_LL; ++q)
       if (q < r_n) r_out[q] = W.chunk_diag_out[r_q0 + q];
   }
+  const bool tiled = SCH2_MAXT > 3 && W.n_tile > 1;
+  if constexpr (SCH2_MAXT > 3) {
+    if (tiled && tid < 2 * nl) {   // (visible behind the barrier of the decision)
+      const int* tb = W.lm_tile_begin + (size_t)(lm_begin + (tid >> 1)) * (W.n_tile + 1) + ((tid & 1) ? tj : ti);
+      s_tb[tid] = make_int2(tb[0], tb[1]);
+    }
+  }
   // pair ranges of the landmark batches (uniform)
   constexpr int SCH2_NB = SCHUR_CHUNK_LM_MAX / 4;   // batches of >= 4 landmarks
   int pbv[SCH2_NB + 1];
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
   auto load_batch = [&](int ib) {   // one work-item per (landmark, block) pair of batch ib
     const int pp = pb_at(ib) + tid;
     f_slot = -1;
-    if (pp < pb_at(ib + 1)) {
+    if (!tiled && pp < pb_at(ib + 1)) {
       const double* Wp = Wb + (size_t)pp * 18;
 #pragma unroll
       for (int i = 0; i < 18; ++i) wp[i] = Wp[i];
@@ -280,7 +288,25 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
       }
     };
     if (f_slot >= 0) fill(wp, f_slot, f_lb);
-    for (int q = p0 + tid + SCHUR_THREADS; q < p1; q += SCHUR_THREADS) {   // more than 256 pairs in the batch
+    if constexpr (SCH2_MAXT > 3) {
+      if (tiled) {
+        // only the pairs of this tile pair: item = (landmark of the batch, row | column tile, block of the tile)
+        for (int it = tid; it < nb * 32; it += SCHUR_THREADS) {
+          const int lb = it >> 5, side = (it >> 4) & 1;
+          if (diag && side) continue;   // (row tile = column tile: the row side fills both operands)
+          const int2 r = s_tb[2 * (l0 - lm_begin + lb) + side];
+          const int q = r.x + (it & 15);
+          if (q < r.y) {
+            const double* Wp = Wb + (size_t)q * 18;
+            double w2[18];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) w2[i] = Wp[i];
+            fill(w2, W.pair_off[q] / 6, lb);
+          }
+        }
+      }
+    }
+    for (int q = p0 + tid + SCHUR_THREADS; !tiled && q < p1; q += SCHUR_THREADS) {   // more than 256 pairs in the batch
       const double* Wp = Wb + (size_t)q * 18;
       double w2[18];
 #pragma unroll

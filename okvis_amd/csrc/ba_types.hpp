@@ -197,6 +197,7 @@ struct WinPtrs {
   const BA_G int* chunk_diag_out;
   const BA_G int* chunk_cross_begin;  // [n_chunk + 1] into chunk_cross (triples off_a, off_b, out)
   const BA_G int* chunk_cross;
+  const BA_G int* lm_tile_begin;      // [n_lm][n_tile + 1] (only with n_tile > 1): first pair of landmark l whose block lies in Schur tile t or beyond
   const BA_G int* chunk_desc;         // [n_chunk][SCHUR_DESC_INTS]: lm_begin, lm_end, then lm_pair_begin at every 4th landmark of the chunk (ba_schur2.hpp)
   const BA_G int* imu_order;          // [n_imu] factor indices sorted by colour (one colour shares no parameter block)
   const BA_G int* imu_color_begin;    // [n_imu_color+1]
