@@ -108,3 +108,15 @@ def test_piece_path_and_staged_kernel_agree(oracle):
     assert abs(a[0]["final_cost"] - s[0]["final_cost"]) <= 1e-11 * s[0]["final_cost"]
     assert (a[0]["iterations"], a[0]["successful_steps"]) == (s[0]["iterations"], s[0]["successful_steps"])
     assert np.abs(a[1][0] - s[1][0]).max() < 1e-9 and np.abs(a[1][2] - s[1][2]).max() < 1e-8
+
+
+def test_more_poses_than_the_kernel_stages_in_lds(oracle):
+    """70 keyframes, two cameras (72 pose blocks > LIN2_POSES = 64): phase B and the pair lanes read the poses from global memory
+    instead of the LDS copy; 140 observations = 70 pieces per landmark keep the batch on the piece path"""
+    w = synthetic.make_window(70, 10, 1.0, seed=68, with_imu=False, frame_dt=0.05)
+    w.pose_fixed = np.asarray(w.pose_fixed).copy()
+    w.pose_fixed[:62] = 1
+    w.sb_fixed = np.asarray(w.sb_fixed).copy()
+    w.sb_fixed[:] = 1
+    assert w.pose.shape[0] > 64 and np.bincount(np.asarray(w.obs_lm)).max() == 140
+    _check(oracle, w, n=4)
