@@ -1649,30 +1649,45 @@ static int refresh_mirrors(okvis_ba_solver* s) {
 
 int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p) {
   if (!s || !p) return OKVIS_BA_ERR_ARG;
-  if (!s->patchable || !s->uploaded || s->mirrors.size() != s->wins.size()) return OKVIS_BA_ERR_STATE;
+  if (!s->uploaded || !s->patchable || s->mirrors.size() != s->wins.size()) return OKVIS_BA_ERR_STATE;
   if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = refresh_mirrors(s)) return rc;
+  // All or nothing.  The edit is applied to a COPY of window w's container; the solver's own container only changes (one swap,
+  // which cannot throw) after the edited window has been indexed and uploaded.  Whatever fails before that — a rejected patch, a
+  // structure limit, an allocation, the device — leaves the containers as they were; if the device no longer holds the old
+  // windows (a failed upload has dropped them), they are uploaded again from the untouched containers.
+  WindowStore after;
+  bool upload_started = false;
+  int rc = OKVIS_BA_OK;
   try {
-    WindowStore before = s->mirrors[w];                  // (a few hundred KB: 5 us; what makes the call all-or-nothing)
-    if (int rc = s->mirrors[w].apply(*p)) return rc;   // (checked completely before anything changes)
-    std::vector<okvis_ba_window> views(s->mirrors.size());
-    for (size_t i = 0; i < views.size(); ++i) s->mirrors[i].view(&views[i]);
-    // same index build and arena fill as okvis_ba_upload
-    int rc = upload_impl(s, (int)views.size(), views.data());
-    if (rc != OKVIS_BA_OK) {
-      // the edited window exceeds a structure limit (or the device refused): the status of that check is returned and the
-      // solver goes back to the window it had
-      s->mirrors[w] = std::move(before);
-      for (size_t i = 0; i < views.size(); ++i) s->mirrors[i].view(&views[i]);
-      s->mirror_fresh = upload_impl(s, (int)views.size(), views.data()) == OKVIS_BA_OK;
-      return rc;
+    after = s->mirrors[w];
+    rc = after.apply(*p);   // (checks the whole patch before it touches `after`; `after` is discarded on failure anyway)
+    if (rc == OKVIS_BA_OK) {
+      std::vector<okvis_ba_window> views(s->mirrors.size());
+      for (size_t i = 0; i < s->mirrors.size(); ++i) ((int)i == w ? after : s->mirrors[i]).view(&views[i]);
+      upload_started = true;
+      rc = upload_impl(s, (int)views.size(), views.data());
     }
-    s->mirror_fresh = true;
-    return rc;
   } catch (const std::bad_alloc&) {
-    return OKVIS_BA_ERR_ARG;
+    rc = OKVIS_BA_ERR_ARG;
   }
+  if (rc != OKVIS_BA_OK) {
+    if (upload_started && !s->uploaded) {   // the old windows back on the device (the containers still hold them)
+      try {
+        std::vector<okvis_ba_window> views(s->mirrors.size());
+        for (size_t i = 0; i < s->mirrors.size(); ++i) s->mirrors[i].view(&views[i]);
+        (void)upload_impl(s, (int)views.size(), views.data());
+      } catch (const std::bad_alloc&) {
+      }
+    }
+    // (after a successful re-upload the device holds exactly what the containers hold)
+    s->mirror_fresh = s->uploaded;
+    return rc;
+  }
+  std::swap(s->mirrors[w], after);   // (moves of vectors: cannot throw)
+  s->mirror_fresh = true;   // the device holds exactly what the containers hold
+  return OKVIS_BA_OK;
 }
 
 int okvis_ba_patched_view(okvis_ba_solver* s, int w, okvis_ba_window* out) {
