@@ -270,8 +270,9 @@ def main():
         b1.iterate(a.steps)
         ms1 = b1.last_iterate_ms()
         b1.finish()
+        late = b1.helper_timeouts()   # solve launches whose helper workgroups were late (summed in the solving workgroup then)
         b1.close()
-        single = {"iterations_per_s": a.steps / (ms1 * 1e-3), "ms_per_iteration": ms1 / a.steps}
+        single = {"iterations_per_s": a.steps / (ms1 * 1e-3), "ms_per_iteration": ms1 / a.steps, "helper_timeouts": late}
 
     cpu = cpu_mt = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:   # reported at N=1 only

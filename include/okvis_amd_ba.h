@@ -191,7 +191,9 @@ typedef struct okvis_ba_options {
   int32_t max_consecutive_invalid_steps; /* 5 (Ceres max_num_consecutive_invalid_steps): then termination 5     */
   int32_t reserved0;            /* diagnostics.  Bit 2 (value 4): keep the landmark Schur reduction in its own launch
                                    (default: DOGLEG / fixed-radius runs whose windows fit reduce each group inside the
-                                   linearise launch).  Bits 0-1: not read any more              */
+                                   linearise launch).  Bit 3 (8): the staged linearise kernel instead
+                                   of the piece path.  Bit 4 (16): solving workgroups do not wait for their helper
+                                   workgroups (exercises the time-out route).  Bits 0-1: not read any more           */
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */
@@ -386,6 +388,10 @@ int okvis_ba_profile_launches(okvis_ba_solver* s, int n, float* ms /* [n][4] */)
 int okvis_ba_algorithmic_bytes(okvis_ba_solver* s, int64_t* linearize_bytes, int64_t* schur_bytes,
                                int64_t* solve_bytes, int64_t* small_bytes);
 int okvis_ba_synchronize(okvis_ba_solver* s);
+/* Launches of few windows sum the Schur partials on helper workgroups next to the solving one.  A solving
+ * workgroup whose helpers are late (not co-scheduled) sums the partials itself, with the same result, and counts it:
+ * count = such time-outs over all windows since the upload.  0 in a healthy run; tests and bench.py report it. */
+int okvis_ba_helper_timeouts(okvis_ba_solver* s, int64_t* count);
 
 /* ---- marginalisation -------------------------------------------------------
  * Numeric core of okvis::Estimator::applyMarginalizationStrategy (Estimator.cpp:434-773), i.e. what the

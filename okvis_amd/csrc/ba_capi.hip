@@ -184,6 +184,7 @@ OptD make_optd(const okvis_ba_options& o, int n_windows) {
   d.dogleg = o.strategy == OKVIS_BA_STRATEGY_DOGLEG;
   d.jacobi_scaling = o.jacobi_scaling != 0;
   d.max_invalid = o.max_consecutive_invalid_steps > 0 ? o.max_consecutive_invalid_steps : 5;
+  d.helper_polls = (o.reserved0 & 16) ? 0 : 1 << 22;   // (bit 4: the test of the time-out route gives up at once)
   return d;
 }
 
@@ -1951,6 +1952,19 @@ int okvis_ba_evaluate_cost(okvis_ba_solver* s, double* costs) {
 int okvis_ba_reduced_dim(okvis_ba_solver* s, int w, int32_t* dim) {
   if (!s || !dim || w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
   *dim = s->wins[w].D;
+  return OKVIS_BA_OK;
+}
+int okvis_ba_helper_timeouts(okvis_ba_solver* s, int64_t* count) {
+  if (!s || !count) return OKVIS_BA_ERR_ARG;
+  if (!s->uploaded) return OKVIS_BA_ERR_STATE;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *count = 0;
+  for (const HostWin& H : s->wins) {
+    int n = 0;
+    HIP_TRY(hipMemcpy(&n, H.ptrs.sum_sync + 2, sizeof(int), hipMemcpyDeviceToHost));
+    *count += n;
+  }
   return OKVIS_BA_OK;
 }
 int okvis_ba_pair_count(okvis_ba_solver* s, int w, int32_t* n_pair) {

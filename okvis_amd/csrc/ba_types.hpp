@@ -100,6 +100,7 @@ struct OptD {
   int dogleg;        // 1 = Ceres' DOGLEG strategy (the reference's configuration), 0 = Levenberg-Marquardt
   int jacobi_scaling;
   int max_invalid;   // max_num_consecutive_invalid_steps
+  int helper_polls;  // how long a solving workgroup waits for its helper workgroups before it sums the partials itself
 };
 
 // DoglegStrategy constants (Ceres: kMinMu, kMaxMu, mu_increase_factor_)

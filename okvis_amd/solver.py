@@ -236,6 +236,12 @@ class WindowBatch:
         a = np.array(ms[:], dtype=np.float64).reshape(int(n), 4)
         return dict(schur=a[:, 0], solve=a[:, 1], linearize=a[:, 2] + a[:, 3])
 
+    def helper_timeouts(self) -> int:
+        """okvis_ba_helper_timeouts: solve launches whose helper workgroups were late (0 in a healthy run)"""
+        n = C.c_int64()
+        _lib.check(self._L.okvis_ba_helper_timeouts(self._h, C.byref(n)))
+        return n.value
+
     def algorithmic_bytes(self):
         v = [C.c_int64() for _ in range(4)]
         _lib.check(self._L.okvis_ba_algorithmic_bytes(self._h, *[C.byref(x) for x in v]))

@@ -288,4 +288,25 @@ def test_helper_workgroup_hand_over_is_repeatable():
                 assert s == first[0], (rep, s, first[0])
                 for u, v in zip(x, first[1]):
                     assert np.array_equal(u, v), rep
+        assert b.helper_timeouts() == 0   # (a healthy run never falls back)
         b.close()
+
+
+def test_late_helper_workgroups_do_not_stop_the_window():
+    """options.reserved0 bit 4: the solving workgroup does not wait for its helpers and sums the chunk partials itself (what a
+    time-out does).  Same chunk order, so the same iterates bit for bit, and the time-outs are counted."""
+    w = synthetic.config_A(seed=98)
+    out = []
+    for r0 in (0, 16, 4, 20):
+        opt = default_options()
+        opt.reserved0 = r0
+        b = solver.WindowBatch([w], options=opt)
+        s = b.optimize(6)[0]
+        out.append((s, b.get_state(), b.helper_timeouts()))
+        b.close()
+    for healthy, late in ((out[0], out[1]), (out[2], out[3])):
+        assert healthy[2] == 0 and late[2] >= 6, (healthy[2], late[2])
+        assert healthy[0] == late[0], (healthy[0], late[0])
+        assert healthy[0]["termination"] != 6
+        for u, v in zip(healthy[1], late[1]):
+            assert np.array_equal(u, v)
