@@ -133,6 +133,7 @@ struct okvis_ba_solver {
   // incremental structure updates (okvis_ba_patch_window): the container of every uploaded window, kept only on request
   bool patchable = false;
   std::vector<WindowStore> mirrors;
+  WindowStore mirror_edit;   // okvis_ba_patch_window edits a copy: this one
   bool evaluated = false;      // okvis_ba_begin ran since the last upload: every IMU term's cache has been (re)built
   bool mirror_fresh = false;   // the containers hold the values the device holds (nothing optimised / set since)
   bool res_staged = false;  // stage_res holds window 0's packed results as of the last okvis_ba_finish (single-window solvers)
@@ -1658,7 +1659,7 @@ int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p) {
   // which cannot throw) after the edited window has been indexed and uploaded.  Whatever fails before that — a rejected patch, a
   // structure limit, an allocation, the device — leaves the containers as they were; if the device no longer holds the old
   // windows (a failed upload has dropped them), they are uploaded again from the untouched containers.
-  WindowStore after;
+  WindowStore& after = s->mirror_edit;   // (kept between calls: the copy reuses its storage)
   bool upload_started = false;
   int rc = OKVIS_BA_OK;
   try {

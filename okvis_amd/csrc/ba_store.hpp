@@ -49,11 +49,23 @@ struct WindowStore {
   int32_t marg_dim = 0;
   std::vector<int32_t> marg_block_type, marg_block_idx, marg_block_off;
   std::vector<double> marg_J, marg_e0, marg_lin;
-  // flat IMU arrays handed out by view()
-  mutable std::vector<int32_t> f_ip0, f_is0, f_ip1, f_is1, f_sbegin, f_scount;
-  mutable std::vector<int64_t> f_t0, f_t1, f_st;
-  mutable std::vector<double> f_gyr, f_acc, f_ref;
-  mutable std::vector<uint8_t> f_refv;
+  // Not part of the window's value: the flat IMU arrays view() hands out and the scratch of apply().  A copy of the container
+  // starts with its own (empty) ones; a container that is copied INTO keeps its buffers, so that editing a copy
+  // (okvis_ba_patch_window) allocates nothing in the steady state.
+  struct Buffers {
+    std::vector<int32_t> f_ip0, f_is0, f_ip1, f_is1, f_sbegin, f_scount;
+    std::vector<int64_t> f_t0, f_t1, f_st;
+    std::vector<double> f_gyr, f_acc, f_ref;
+    std::vector<uint8_t> f_refv;
+    std::vector<int32_t> x_mp, x_ms, x_ml, x_mo, x_ord, x_lm, x_pose, x_ext, x_cam;
+    std::vector<double> x_uv, x_sw;
+    Buffers() = default;
+    Buffers(const Buffers&) {}
+    Buffers& operator=(const Buffers&) { return *this; }
+    Buffers(Buffers&&) = default;
+    Buffers& operator=(Buffers&&) = default;
+  };
+  mutable Buffers buf;
 
   int n_pose() const { return (int)pose_fixed.size(); }
   int n_sb() const { return (int)sb_fixed.size(); }
@@ -156,6 +168,10 @@ struct WindowStore {
   void view(okvis_ba_window* out) const {
     okvis_ba_window& w = *out;
     std::memset(&w, 0, sizeof(w));
+    auto &f_ip0 = buf.f_ip0, &f_is0 = buf.f_is0, &f_ip1 = buf.f_ip1, &f_is1 = buf.f_is1, &f_sbegin = buf.f_sbegin, &f_scount = buf.f_scount;
+    auto &f_t0 = buf.f_t0, &f_t1 = buf.f_t1, &f_st = buf.f_st;
+    auto &f_gyr = buf.f_gyr, &f_acc = buf.f_acc, &f_ref = buf.f_ref;
+    auto& f_refv = buf.f_refv;
     const size_t nf = imu.size();
     f_ip0.resize(nf); f_is0.resize(nf); f_ip1.resize(nf); f_is1.resize(nf); f_sbegin.resize(nf); f_scount.resize(nf);
     f_t0.resize(nf); f_t1.resize(nf); f_ref.resize(9 * nf); f_refv.resize(nf);
@@ -256,7 +272,10 @@ struct WindowStore {
     if (rep_marg && p.marg_dim > 0 &&
         (!p.marg_block_type || !p.marg_block_idx || !p.marg_block_off || !p.marg_J || !p.marg_e0 || !p.marg_lin || p.marg_nblocks <= 0))
       return OKVIS_BA_ERR_ARG;
-    std::vector<int32_t> mp, ms, ml, mo;
+    // (scratch kept between calls: an edit of a frame's worth of observations allocates nothing in the steady state)
+    std::vector<int32_t>&mp = buf.x_mp, &ms = buf.x_ms, &ml = buf.x_ml, &mo = buf.x_mo;
+    auto &x_ord = buf.x_ord, &x_lm = buf.x_lm, &x_pose = buf.x_pose, &x_ext = buf.x_ext, &x_cam = buf.x_cam;
+    auto &x_uv = buf.x_uv, &x_sw = buf.x_sw;
     const int np1 = remap(np0, p.remove_pose, p.n_remove_pose, mp) + p.n_add_pose;
     const int ns1 = remap(ns0, p.remove_sb, p.n_remove_sb, ms) + p.n_add_sb;
     const int nl1 = remap(nl0, p.remove_lm, p.n_remove_lm, ml) + p.n_add_lm;
@@ -285,21 +304,9 @@ struct WindowStore {
         if (!in(p.marg_block_idx[b], p.marg_block_type[b] == OKVIS_BA_BLOCK_POSE ? np1 : ns1)) return OKVIS_BA_ERR_ARG;
 
     // ---- 1 + 2: removals, stable compaction ----
-    for (int i = 0; i < no0; ++i)   // observations of a removed landmark / pose / extrinsics block go with it
-      if (mo[i] >= 0 && (ml[obs_lm[i]] < 0 || mp[obs_pose[i]] < 0 || mp[obs_ext[i]] < 0)) mo[i] = -1;
     compact(pose, mp, 7); compact(pose_fixed, mp, 1);
     compact(sb, ms, 9); compact(sb_fixed, ms, 1);
     compact(lm, ml, 4);
-    {
-      size_t o = 0;
-      for (int i = 0; i < no0; ++i) {
-        if (mo[i] < 0) continue;
-        obs_lm[o] = ml[obs_lm[i]]; obs_pose[o] = mp[obs_pose[i]]; obs_ext[o] = mp[obs_ext[i]]; obs_cam[o] = obs_cam[i];
-        obs_uv[2 * o] = obs_uv[2 * (size_t)i]; obs_uv[2 * o + 1] = obs_uv[2 * (size_t)i + 1]; obs_sqrtw[o] = obs_sqrtw[i];
-        ++o;
-      }
-      obs_lm.resize(o); obs_pose.resize(o); obs_ext.resize(o); obs_cam.resize(o); obs_uv.resize(2 * o); obs_sqrtw.resize(o);
-    }
     {
       std::vector<int32_t> mi;
       remap(ni0, p.remove_imu, p.n_remove_imu, mi);
@@ -376,40 +383,42 @@ struct WindowStore {
       std::memset(m.sb_ref, 0, sizeof(m.sb_ref));
       imu.push_back(std::move(m));
     }
-    // ---- 4: appended observations, merged into the (landmark, pose, camera) order ----
-    if (p.n_add_obs) {
-      std::vector<int32_t> ord((size_t)p.n_add_obs);
+    // ---- 2 + 4: observations in ONE pass: what stays is renumbered (its order is unchanged by the compaction of the blocks),
+    //      what comes is merged into the (landmark, pose, camera) order behind equal keys ----
+    if (p.n_add_obs || (size_t)no0 != 0) {
+      std::vector<int32_t>& ord = x_ord;
+      ord.resize((size_t)p.n_add_obs);
       for (int i = 0; i < p.n_add_obs; ++i) ord[i] = i;
       auto key_less = [](int l0, int p0, int c0, int l1, int p1, int c1) {
         if (l0 != l1) return l0 < l1;
         if (p0 != p1) return p0 < p1;
         return c0 < c1;
       };
-      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+      auto new_less = [&](int a, int b) {
         return key_less(p.add_obs_lm[a], p.add_obs_pose[a], p.add_obs_cam[a], p.add_obs_lm[b], p.add_obs_pose[b], p.add_obs_cam[b]);
-      });
-      const size_t nk = obs_lm.size(), nt = nk + (size_t)p.n_add_obs;
-      std::vector<int32_t> o_lm(nt), o_pose(nt), o_ext(nt), o_cam(nt);
-      std::vector<double> o_uv(2 * nt), o_sw(nt);
-      size_t i = 0, j = 0, o = 0;
-      while (i < nk || j < (size_t)p.n_add_obs) {
-        bool take_new = i == nk;
-        if (!take_new && j < (size_t)p.n_add_obs) {
-          const int a = ord[j];
-          take_new = key_less(p.add_obs_lm[a], p.add_obs_pose[a], p.add_obs_cam[a], obs_lm[i], obs_pose[i], obs_cam[i]);
-        }
-        if (take_new) {
-          const int a = ord[j++];
-          o_lm[o] = p.add_obs_lm[a]; o_pose[o] = p.add_obs_pose[a]; o_ext[o] = p.add_obs_ext[a]; o_cam[o] = p.add_obs_cam[a];
-          o_uv[2 * o] = p.add_obs_uv[2 * (size_t)a]; o_uv[2 * o + 1] = p.add_obs_uv[2 * (size_t)a + 1]; o_sw[o] = p.add_obs_sqrtw[a];
-        } else {
-          o_lm[o] = obs_lm[i]; o_pose[o] = obs_pose[i]; o_ext[o] = obs_ext[i]; o_cam[o] = obs_cam[i];
-          o_uv[2 * o] = obs_uv[2 * i]; o_uv[2 * o + 1] = obs_uv[2 * i + 1]; o_sw[o] = obs_sqrtw[i];
-          ++i;
-        }
+      };
+      if (!std::is_sorted(ord.begin(), ord.end(), new_less)) std::stable_sort(ord.begin(), ord.end(), new_less);
+      const size_t cap = (size_t)no0 + (size_t)p.n_add_obs;
+      x_lm.resize(cap); x_pose.resize(cap); x_ext.resize(cap); x_cam.resize(cap); x_uv.resize(2 * cap); x_sw.resize(cap);
+      size_t o = 0;
+      int j = 0;
+      auto put_new = [&](int a) {
+        x_lm[o] = p.add_obs_lm[a]; x_pose[o] = p.add_obs_pose[a]; x_ext[o] = p.add_obs_ext[a]; x_cam[o] = p.add_obs_cam[a];
+        x_uv[2 * o] = p.add_obs_uv[2 * (size_t)a]; x_uv[2 * o + 1] = p.add_obs_uv[2 * (size_t)a + 1]; x_sw[o] = p.add_obs_sqrtw[a];
+        ++o;
+      };
+      for (int i = 0; i < no0; ++i) {
+        if (mo[i] < 0) continue;
+        const int l = ml[obs_lm[i]], ip = mp[obs_pose[i]], ie = mp[obs_ext[i]], c = obs_cam[i];
+        if (l < 0 || ip < 0 || ie < 0) continue;   // observations of a removed landmark / pose / extrinsics block go with it
+        while (j < p.n_add_obs && key_less(p.add_obs_lm[ord[j]], p.add_obs_pose[ord[j]], p.add_obs_cam[ord[j]], l, ip, c)) put_new(ord[j++]);
+        x_lm[o] = l; x_pose[o] = ip; x_ext[o] = ie; x_cam[o] = c;
+        x_uv[2 * o] = obs_uv[2 * (size_t)i]; x_uv[2 * o + 1] = obs_uv[2 * (size_t)i + 1]; x_sw[o] = obs_sqrtw[i];
         ++o;
       }
-      obs_lm.swap(o_lm); obs_pose.swap(o_pose); obs_ext.swap(o_ext); obs_cam.swap(o_cam); obs_uv.swap(o_uv); obs_sqrtw.swap(o_sw);
+      while (j < p.n_add_obs) put_new(ord[j++]);
+      x_lm.resize(o); x_pose.resize(o); x_ext.resize(o); x_cam.resize(o); x_uv.resize(2 * o); x_sw.resize(o);
+      obs_lm.swap(x_lm); obs_pose.swap(x_pose); obs_ext.swap(x_ext); obs_cam.swap(x_cam); obs_uv.swap(x_uv); obs_sqrtw.swap(x_sw);
     }
     // ---- 5: sparse values ----
     for (int i = 0; i < p.n_set_pose; ++i) std::memcpy(&pose[7 * (size_t)p.set_pose_idx[i]], p.set_pose + 7 * (size_t)i, 56);

@@ -66,12 +66,20 @@ Estimator::Estimator(int device) : device_(device) {
   // ~10 x 3 plain kernel launches that overlap with the GPU work anyway): eager launches by default here.
   options_.use_graph = 0;
   std::memset(&summary_, 0, sizeof(summary_));
+  if (std::getenv("OKVIS_AMD_NO_PATCH")) usePatch_ = false;
+  if (device < 0) {   // book-keeping only (estimator.hpp): nothing below this class computes
+    dry_ = true;
+    return;
+  }
   // no GPU => hard failure: there is no CPU optimisation path behind this class
   check(okvis_ba_create(&solver_, device), "okvis_ba_create");
+  check(okvis_ba_set_patchable(solver_, 1), "okvis_ba_set_patchable");   // the solver keeps the window between optimize() calls
 }
 
 Estimator::~Estimator() {
   if (solver_) okvis_ba_destroy(solver_);
+  if (margSolver_) okvis_ba_destroy(margSolver_);
+  if (dryStore_) okvis_ba_store_destroy(dryStore_);
 }
 
 int Estimator::addCamera(const ExtrinsicsEstimationParameters& p) {
@@ -278,6 +286,7 @@ bool Estimator::addStates(MultiFramePtr multiFrame, const ImuMeasurementDeque& i
     info[35] = 1.0e8;
     sqrtInformation(info, 6, si);
     posePriors_.push_back(PosePrior{st.poseBlock, T_WS.p, si});
+    familiesChanged_ |= OKVIS_BA_PATCH_POSE_PRIORS | OKVIS_BA_PATCH_SB_PRIORS;
     for (size_t i = 0; i < extrinsicsEstimationParametersVec_.size(); ++i) {  // :247-268
       const ExtrinsicsEstimationParameters& ep = extrinsicsEstimationParametersVec_[i];
       const double tv = ep.sigma_absolute_translation * ep.sigma_absolute_translation;
@@ -300,12 +309,13 @@ bool Estimator::addStates(MultiFramePtr multiFrame, const ImuMeasurementDeque& i
     }
   } else {
     const State& last = states_.back();
-    imuFactors_.push_back(ImuFactor{last.poseBlock, last.sbBlock, st.poseBlock, st.sbBlock, last.t_ns, st.t_ns,
+    imuFactors_.push_back(ImuFactor{nextImuUid_++, last.poseBlock, last.sbBlock, st.poseBlock, st.sbBlock, last.t_ns, st.t_ns,
                                     imuMeasurements, {}, false});  // :288-307
     for (size_t i = 0; i < extrinsicsEstimationParametersVec_.size(); ++i) {           // :310-336
       if (last.extBlocks[i] != st.extBlocks[i]) {
         const ExtrinsicsEstimationParameters& ep = extrinsicsEstimationParametersVec_[i];
         const double dt = ba::ns_to_sec(st.t_ns - last.t_ns);
+        familiesChanged_ |= OKVIS_BA_PATCH_RELPOSE;
         relPoses_.push_back(RelPose{last.extBlocks[i], st.extBlocks[i],
                                     poseSqrtInfo(ep.sigma_c_relative_translation * ep.sigma_c_relative_translation * dt,
                                                  ep.sigma_c_relative_orientation * ep.sigma_c_relative_orientation * dt)});
@@ -362,6 +372,11 @@ uint64_t Estimator::addObservation(uint64_t landmarkId, uint64_t poseId, size_t 
   }
   observations_[o.handle] = o;
   lit->second.observations[kid] = o.handle;
+  touch(lit->second);
+  if (synced_.valid) {
+    obsAdded_.push_back(PendingObs{&lit->second, o.handle, o.poseBlock, o.extBlock, (int)camIdx, o.u, o.v, o.sqrtw});
+    lit->second.pendingAdds++;
+  }
   return o.handle;
 }
 
@@ -376,6 +391,7 @@ bool Estimator::removeObservation(uint64_t handle) {
     else
       ++oit;
   }
+  noteObservationRemoved(mp, handle);
   observations_.erase(it);
   return true;
 }
@@ -384,6 +400,7 @@ bool Estimator::removeObservation(uint64_t landmarkId, uint64_t poseId, size_t c
   if (lit == landmarksMap_.end()) throw Exception("landmark not added");
   auto oit = lit->second.observations.find(KeypointIdentifier{poseId, camIdx, keypointIdx});
   if (oit == lit->second.observations.end()) return false;  // observation not present
+  noteObservationRemoved(lit->second, oit->second);
   observations_.erase(oit->second);
   lit->second.observations.erase(oit);
   return true;
@@ -481,6 +498,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
   struct Rec {
     int lm, pose, ext, cam;
     double u, v, sw;
+    uint64_t handle;
   };
   std::vector<Rec> recs;
   auto byPoseCam = [](const Rec& a, const Rec& b) {
@@ -498,7 +516,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
         if (o.camIdx >= ncam) continue;
         const int ip = fw.poseMap[o.poseBlock], ie = fw.poseMap[o.extBlock];
         if (ip < 0 || ie < 0) throw Exception("flatten: observation refers to a block outside the window");
-        recs.push_back(Rec{(int)n, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw});
+        recs.push_back(Rec{(int)n, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw, o.handle});
       }
       if (!std::is_sorted(recs.begin() + first, recs.end(), byPoseCam)) std::stable_sort(recs.begin() + first, recs.end(), byPoseCam);
     }
@@ -511,7 +529,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
       if (li == lmIndex.end()) continue;
       const int ip = fw.poseMap[o.poseBlock], ie = fw.poseMap[o.extBlock];
       if (ip < 0 || ie < 0) throw Exception("flatten: observation refers to a block outside the window");
-      recs.push_back(Rec{li->second, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw});
+      recs.push_back(Rec{li->second, ip, ie, (int)o.camIdx, o.u, o.v, o.sqrtw, o.handle});
     }
   }
   if (!walk) {
@@ -534,7 +552,10 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
   i32[I_OCAM].reserve(recs.size());
   f64[F_UV].reserve(2 * recs.size());
   f64[F_SW].reserve(recs.size());
+  fw.obsHandle.clear();
+  fw.obsHandle.reserve(recs.size());
   for (const Rec& r : recs) {
+    fw.obsHandle.push_back(r.handle);
     i32[I_OLM].push_back(r.lm);
     i32[I_OPOSE].push_back(r.pose);
     i32[I_OEXT].push_back(r.ext);
@@ -632,24 +653,37 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
   if (states_.empty()) return;
   typedef std::chrono::steady_clock clk;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  const auto t0 = clk::now();
-  const WindowSel sel = selectAll();
-  FlatWindow fw;
-  flatten(sel, fw);
-  const auto t1 = clk::now();
-  if (windowObserver_) windowObserver_(&fw.w, 0, windowObserverUser_);
   static const bool trace = std::getenv("OKVIS_AMD_TRACE") != nullptr;   // (read once: optimize() is the per-frame hot path)
-  if (trace)
-    for (size_t a = 0; a < fw.f64.size(); ++a) {
-      size_t bad = 0;
-      for (double v : fw.f64[a]) bad += !std::isfinite(v);
-      if (bad) std::printf("okvis_amd::Estimator::optimize: input array %zu holds %zu non-finite values of %zu\n", a, bad, fw.f64[a].size());
-    }
-  check(okvis_ba_set_options(solver_, &options_), "set_options");
-  const auto t1b = clk::now();
-  check(okvis_ba_upload(solver_, 1, &fw.w), "upload");
+  static const bool checkPatch = std::getenv("OKVIS_AMD_CHECK_PATCH") != nullptr;
+  const auto t0 = clk::now();
+  if (!dry_) check(okvis_ba_set_options(solver_, &options_), "set_options");
+  // ---- the window: the edits since the last call as one patch of the window the solver holds, else flatten + upload ----
+  patchSplit_ = {0.0, 0.0};
+  lastWasPatch_ = usePatch_ && patchWindow();
+  if (!lastWasPatch_) {
+    FlatWindow fw;
+    uploadWindow(fw);
+    if (trace)
+      for (size_t a = 0; a < fw.f64.size(); ++a) {
+        size_t bad = 0;
+        for (double v : fw.f64[a]) bad += !std::isfinite(v);
+        if (bad) std::printf("okvis_amd::Estimator::optimize: input array %zu holds %zu non-finite values of %zu\n", a, bad, fw.f64[a].size());
+      }
+  }
   const auto t2 = clk::now();
-  if (trace) std::printf("set_options %.4f ms, upload %.4f ms\n", ms(t1, t1b), ms(t1b, t2));
+  const SyncedWindow& S = synced_;
+  if (checkPatch || dry_) {
+    const std::string diff = debugCheckWindow();
+    if (!diff.empty()) throw Exception("okvis_amd::Estimator::optimize: the window the solver holds differs from the estimator's: " + diff);
+  }
+  if (dry_) {   // book-keeping only: nothing is computed (estimator.hpp)
+    timings_ = {patchSplit_[0], patchSplit_[1], 0.0, 0.0};
+    return;
+  }
+  okvis_ba_window view;
+  if (windowObserver_ || verbose || trace) currentWindowView(&view);
+  if (windowObserver_) windowObserver_(&view, 0, windowObserverUser_);
+  if (trace) std::printf("window %s: describe %.4f ms, hand-over %.4f ms\n", lastWasPatch_ ? "patched" : "uploaded", patchSplit_[0], patchSplit_[1]);
   if (hasTimeLimit_)  // CeresIterationCallback semantics (CeresIterationCallback.hpp:77-86)
     check(okvis_ba_optimize_timed(solver_, (int)numIter, minIterations_, timeLimit_, &summary_), "optimize");
   else
@@ -658,52 +692,545 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
   if (verbose || trace)  // the reference prints summary.FullReport() when verbose (Estimator.cpp:870-872)
     std::printf("okvis_amd::Estimator::optimize: %d poses, %d speed/bias, %d landmarks, %d observations, %d IMU terms, prior %d | "
                 "iterations %d (%d successful), cost %.9g -> %.9g, termination %d, radius %.3g\n",
-                fw.w.n_pose, fw.w.n_sb, fw.w.n_lm, fw.w.n_obs, fw.w.n_imu, fw.w.marg_dim, summary_.iterations,
+                view.n_pose, view.n_sb, view.n_lm, view.n_obs, view.n_imu, view.marg_dim, summary_.iterations,
                 summary_.successful_steps, summary_.initial_cost, summary_.final_cost, summary_.termination, summary_.final_radius);
   // copy the estimates back (the reference's parameter blocks are updated in place by Ceres)
-  const size_t nl = sel.landmarks.size();
-  std::vector<double> pose(7 * sel.pose.size()), sb(9 * sel.sb.size()), lm(4 * nl), q(nl);
-  std::vector<double> ref(9 * sel.imu.size());
+  const size_t nl = S.lm.size();
+  std::vector<double>& pose = resPose_; std::vector<double>& sb = resSb_; std::vector<double>& lm = resLm_; std::vector<double>& q = resQ_; std::vector<double>& ref = resRef_;
+  pose.resize(7 * S.pose.size()), sb.resize(9 * S.sb.size()), lm.resize(4 * nl), q.resize(nl), ref.resize(9 * S.imu.size());
   check(okvis_ba_fetch_results(solver_, 0, pose.data(), sb.data(), lm.data(), q.empty() ? nullptr : q.data(),
                                ref.empty() ? nullptr : ref.data()), "fetch_results");
   if (windowObserver_) {
-    okvis_ba_window after = fw.w;
+    currentWindowView(&view);   // (the container has taken the results over meanwhile; the arrays below are the same numbers)
+    okvis_ba_window after = view;
     after.pose = pose.data(), after.sb = sb.data(), after.lm = lm.data();
     windowObserver_(&after, 1, windowObserverUser_);
   }
-  for (size_t i = 0; i < sel.pose.size(); ++i)
-    std::copy(pose.begin() + 7 * i, pose.begin() + 7 * i + 7, poseBlocks_[sel.pose[i]].x.begin());
-  for (size_t i = 0; i < sel.sb.size(); ++i)
-    std::copy(sb.begin() + 9 * i, sb.begin() + 9 * i + 9, sbBlocks_[sel.sb[i]].x.begin());
-  if (!sel.imu.empty()) {  // the ImuError caches live on: remember the bias each one was (re)built at
-    for (size_t i = 0; i < sel.imu.size(); ++i) {
-      ImuFactor& f = imuFactors_[sel.imu[i]];
-      std::copy(ref.begin() + 9 * i, ref.begin() + 9 * i + 9, f.sbRef.begin());
-      f.hasRef = true;
-    }
+  for (size_t i = 0; i < S.pose.size(); ++i)
+    std::copy(pose.begin() + 7 * i, pose.begin() + 7 * i + 7, poseBlocks_[S.pose[i]].x.begin());
+  for (size_t i = 0; i < S.sb.size(); ++i)
+    std::copy(sb.begin() + 9 * i, sb.begin() + 9 * i + 9, sbBlocks_[S.sb[i]].x.begin());
+  // the ImuError caches live on: remember the bias each one was (re)built at (window order = order of imuFactors_)
+  for (size_t i = 0; i < S.imu.size(); ++i) {
+    ImuFactor& f = imuFactors_[i];
+    std::copy(ref.begin() + 9 * i, ref.begin() + 9 * i + 9, f.sbRef.begin());
+    f.hasRef = true;
   }
   {
     // update landmarks: quality = sqrt(lambda_min)/sqrt(lambda_max) of the un-robustified H_l and the
-    // estimate (Estimator.cpp:880-900)
+    // estimate (Estimator.cpp:880-900); a landmark nobody observes is not part of the problem and gets the quality 0 the
+    // reference derives from its zero H (Estimator.cpp:890-893)
     std::lock_guard<std::mutex> l(statesMutex_);
-    // sel.landmarks was filled by walking landmarksMap_ (selectAll): same order, so the map is walked again instead of
-    // nl lookups (nothing was inserted or erased in between: optimize() runs under the caller's estimator mutex)
-    // (the qualities of unobserved landmarks — not part of the problem — are zeroed in a pass of their own: a shared iterator
-    //  would skip or revisit some of them whenever the walk has to fall back on a lookup)
     for (auto& kv : landmarksMap_)
       if (kv.second.observations.empty()) kv.second.quality = 0.0;
-    auto it = landmarksMap_.begin();
     for (size_t i = 0; i < nl; ++i) {
-      while (it != landmarksMap_.end() && it->first != sel.landmarks[i] && it->second.observations.empty()) ++it;
-      if (it == landmarksMap_.end() || it->first != sel.landmarks[i]) it = landmarksMap_.find(sel.landmarks[i]);
-      if (it == landmarksMap_.end()) continue;   // (cannot happen: nothing is erased between selectAll and here)
-      MapPoint& mp = it->second;
+      MapPoint& mp = *S.lm[i];
       mp.quality = q[i];
       std::copy(lm.begin() + 4 * i, lm.begin() + 4 * i + 4, mp.point.begin());
-      ++it;
     }
   }
-  timings_ = {ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, clk::now())};
+  timings_ = {patchSplit_[0], patchSplit_[1] + ms(t0, t2) - patchSplit_[0] - patchSplit_[1], ms(t2, t3), ms(t3, clk::now())};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the window between two optimize() calls (Map.cpp:292-565 as edits of the window the solver holds)
+// ---------------------------------------------------------------------------------------------------
+void Estimator::forgetLandmark(MapPoint& mp) {
+  if (mp.winIdx >= 0 && synced_.valid && (size_t)mp.winIdx < synced_.lm.size() && synced_.lm[mp.winIdx] == &mp) {
+    synced_.lm[mp.winIdx] = nullptr;
+    erasedWinLm_.push_back(mp.winIdx);
+  }
+  if (mp.touched)
+    for (MapPoint*& t : touchedLm_)
+      if (t == &mp) t = nullptr;
+  if (mp.pendingAdds > 0)
+    for (PendingObs& a : obsAdded_)
+      if (a.lm == &mp) a.lm = nullptr;
+}
+
+// an observation leaves: one that the window holds is logged with its landmark's window index, one that was added since the last
+// hand-over just disappears from the log of additions (handles are handed out in increasing order)
+void Estimator::noteObservationRemoved(MapPoint& mp, uint64_t handle) {
+  touch(mp);
+  if (!synced_.valid) return;
+  if (handle >= firstPendingHandle_) {
+    for (size_t k = obsAdded_.size(); k-- > 0;)
+      if (obsAdded_[k].handle == handle) {
+        obsAdded_[k].lm = nullptr;
+        mp.pendingAdds--;
+        break;
+      }
+  } else if (mp.winIdx >= 0) {
+    obsRemoved_.push_back(RemovedObs{mp.winIdx, handle});
+  }
+}
+
+void Estimator::invalidateSynced() {
+  synced_.valid = false;
+  touchedLm_.clear();
+  erasedWinLm_.clear();
+  obsAdded_.clear();
+  obsRemoved_.clear();
+}
+
+void Estimator::currentWindowView(okvis_ba_window* out) {
+  if (dry_) {
+    if (!dryStore_) throw Exception("no window yet");
+    check(okvis_ba_store_view(dryStore_, out), "okvis_ba_store_view");
+  } else {
+    check(okvis_ba_patched_view(solver_, 0, out), "okvis_ba_patched_view");
+  }
+}
+
+void Estimator::uploadWindow(FlatWindow& fw) {
+  typedef std::chrono::steady_clock clk;
+  auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = clk::now();
+  invalidateSynced();
+  const WindowSel sel = selectAll();
+  flatten(sel, fw);
+  const auto t1 = clk::now();
+  if (dry_) {
+    if (dryStore_) okvis_ba_store_destroy(dryStore_);
+    dryStore_ = nullptr;
+    check(okvis_ba_store_create(&fw.w, &dryStore_), "okvis_ba_store_create");
+  } else {
+    check(okvis_ba_upload(solver_, 1, &fw.w), "upload");
+  }
+  // ---- what the solver holds now, in the estimator's terms ----
+  SyncedWindow& S = synced_;
+  S.pose = sel.pose;
+  S.sb = sel.sb;
+  S.poseWin = fw.poseMap;
+  S.sbWin = fw.sbMap;
+  S.poseFixed.assign(fw.u8[0].begin(), fw.u8[0].end());
+  S.sbFixed.assign(fw.u8[1].begin(), fw.u8[1].end());
+  for (auto& kv : landmarksMap_) kv.second.winIdx = -1, kv.second.touched = kv.second.valueSet = false, kv.second.pendingAdds = 0;
+  firstPendingHandle_ = nextHandle_;
+  const size_t nl = sel.landmarks.size();
+  S.lm.assign(nl, nullptr);
+  S.lmObs.assign(nl, {});
+  for (size_t n = 0; n < nl; ++n) {
+    MapPoint* mp = const_cast<MapPoint*>(sel.lmPtr[n]);
+    mp->winIdx = (int)n;
+    S.lm[n] = mp;
+  }
+  for (int o = 0; o < fw.w.n_obs; ++o)
+    S.lmObs[fw.w.obs_lm[o]].push_back(SyncedObs{fw.obsHandle[o], S.pose[fw.w.obs_pose[o]], fw.w.obs_cam[o]});
+  S.imu.clear();
+  for (const ImuFactor& f : imuFactors_) S.imu.push_back(f.uid);
+  S.camIntr.assign(fw.w.cam_intr, fw.w.cam_intr + 12 * (size_t)fw.w.n_cam);
+  S.camModel.assign(fw.w.cam_model, fw.w.cam_model + fw.w.n_cam);
+  S.nPoseBlocks = poseBlocks_.size();
+  S.nSbBlocks = sbBlocks_.size();
+  S.nObs = (size_t)fw.w.n_obs;
+  S.valid = true;
+  poseValueSet_.clear();
+  sbValueSet_.clear();
+  familiesChanged_ = 0;
+  patchSplit_ = {ms(t0, t1), ms(t1, clk::now())};
+}
+
+bool Estimator::patchWindow() {
+  typedef std::chrono::steady_clock clk;
+  auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = clk::now();
+  SyncedWindow& S = synced_;
+  if (!S.valid || states_.empty()) return false;
+  if (dry_ ? dryStore_ == nullptr : false) return false;
+  {  // the cameras are part of the window description: new intrinsics start the window over
+    const MultiFramePtr& mf = multiFramePtrMap_.at(states_.back().id);
+    if (mf->geometry.size() != S.camModel.size()) return false;
+    for (size_t c = 0; c < mf->geometry.size(); ++c)
+      if (mf->geometry[c].model != S.camModel[c] || std::memcmp(mf->geometry[c].intr.data(), &S.camIntr[12 * c], 12 * sizeof(double)) != 0)
+        return false;
+  }
+  PatchBuffers& B = patchBuf_;
+  B.clear();
+  // ---- parameter blocks: the marginalised ones leave, the ones created since the last hand-over are appended ----
+  std::vector<int>& pose2 = B.pose2;
+  std::vector<int>& sb2 = B.sb2;
+  std::vector<int>& poseWin2 = B.poseWin2;
+  std::vector<int>& sbWin2 = B.sbWin2;
+  poseWin2.assign(poseBlocks_.size(), -1);
+  sbWin2.assign(sbBlocks_.size(), -1);
+  for (size_t wi = 0; wi < S.pose.size(); ++wi) {
+    const int b = S.pose[wi];
+    if (!poseBlocks_[b].alive) {
+      B.remPose.push_back((int32_t)wi);
+      continue;
+    }
+    if ((poseBlocks_[b].fixed ? 1 : 0) != S.poseFixed[wi]) return false;
+    poseWin2[b] = (int)pose2.size();
+    pose2.push_back(b);
+    B.poseFixed2.push_back(S.poseFixed[wi]);
+  }
+  for (size_t b = S.nPoseBlocks; b < poseBlocks_.size(); ++b)
+    if (poseBlocks_[b].alive) {
+      poseWin2[b] = (int)pose2.size();
+      pose2.push_back((int)b);
+      B.poseFixed2.push_back(poseBlocks_[b].fixed ? 1 : 0);
+      B.addPose.insert(B.addPose.end(), poseBlocks_[b].x.begin(), poseBlocks_[b].x.end());
+      B.addPoseFixed.push_back(poseBlocks_[b].fixed ? 1 : 0);
+    }
+  for (size_t wi = 0; wi < S.sb.size(); ++wi) {
+    const int b = S.sb[wi];
+    if (!sbBlocks_[b].alive) {
+      B.remSb.push_back((int32_t)wi);
+      continue;
+    }
+    if ((sbBlocks_[b].fixed ? 1 : 0) != S.sbFixed[wi]) return false;
+    sbWin2[b] = (int)sb2.size();
+    sb2.push_back(b);
+    B.sbFixed2.push_back(S.sbFixed[wi]);
+  }
+  for (size_t b = S.nSbBlocks; b < sbBlocks_.size(); ++b)
+    if (sbBlocks_[b].alive) {
+      sbWin2[b] = (int)sb2.size();
+      sb2.push_back((int)b);
+      B.sbFixed2.push_back(sbBlocks_[b].fixed ? 1 : 0);
+      B.addSb.insert(B.addSb.end(), sbBlocks_[b].x.begin(), sbBlocks_[b].x.end());
+      B.addSbFixed.push_back(sbBlocks_[b].fixed ? 1 : 0);
+    }
+  // ---- landmarks: erased ones and the ones that lost their last observation leave; observed ones that are not part of the
+  //      window yet are appended (by id, the order flatten() would give them among themselves) ----
+  std::vector<MapPoint*>& added = B.addedLm;
+  for (int wi : erasedWinLm_) B.remLm.push_back(wi);
+  for (MapPoint* mp : touchedLm_) {
+    if (!mp) continue;
+    if (mp->winIdx >= 0 && mp->observations.empty()) B.remLm.push_back(mp->winIdx);
+    if (mp->winIdx < 0 && !mp->observations.empty()) added.push_back(mp);
+  }
+  std::sort(B.remLm.begin(), B.remLm.end());
+  std::sort(added.begin(), added.end(), [](const MapPoint* a, const MapPoint* b) { return a->id < b->id; });
+  std::vector<int>& lmWin2 = B.lmWin2;   // old window index -> new
+  lmWin2.assign(S.lm.size(), 0);
+  for (int wi : B.remLm) lmWin2[wi] = -1;
+  int nl2 = 0;
+  for (size_t wi = 0; wi < S.lm.size(); ++wi)
+    if (lmWin2[wi] == 0) lmWin2[wi] = nl2++;
+  const int nKeptLm = nl2;
+  for (MapPoint* mp : added) {
+    B.addLm.insert(B.addLm.end(), mp->point.begin(), mp->point.end());
+    ++nl2;
+  }
+  // ---- observations: what left and what came since the last hand-over, from the two logs (no look-up, no comparison of lists) ----
+  // From here on the description is edited in place.  Whenever this function gives up (return false) optimize() describes the
+  // window from scratch (uploadWindow), so a half-edited description is never used.
+  std::vector<size_t>& obsBegin = B.obsBegin;   // first observation of each landmark in the window as it stands
+  obsBegin.assign(S.lm.size() + 1, 0);
+  for (size_t wi = 0; wi < S.lm.size(); ++wi) obsBegin[wi + 1] = obsBegin[wi] + S.lmObs[wi].size();
+  size_t nObs2 = S.nObs;
+  for (int wi : B.remLm) nObs2 -= S.lmObs[wi].size();
+  std::vector<int>& edited = B.editedLm;   // old window indices of the landmarks whose list changes
+  for (const RemovedObs& r : obsRemoved_) {
+    if (lmWin2[r.lmWin] < 0) continue;   // (the landmark leaves with everything it has)
+    std::vector<SyncedObs>& list = S.lmObs[r.lmWin];
+    size_t k = 0;
+    while (k < list.size() && list[k].handle != r.handle) ++k;
+    if (k == list.size()) continue;      // (an observation of a camera the window does not have)
+    list[k].handle = 0;                  // (handles start at 1) taken out below, once every index has been computed
+    B.remObs.push_back((int32_t)(obsBegin[r.lmWin] + k));
+    edited.push_back(r.lmWin);
+    --nObs2;
+  }
+  std::sort(B.remObs.begin(), B.remObs.end());
+  for (int wi : edited) {
+    std::vector<SyncedObs>& list = S.lmObs[wi];
+    list.erase(std::remove_if(list.begin(), list.end(), [](const SyncedObs& o) { return o.handle == 0; }), list.end());
+  }
+  edited.clear();
+  for (size_t a = 0; a < added.size(); ++a) added[a]->winIdx = -2 - (int)a;   // (their final index: nKeptLm + a)
+  B.addedLists.resize(added.size());
+  for (const PendingObs& o : obsAdded_) {
+    if (!o.lm) continue;                               // removed again, or its landmark erased, before it ever reached the window
+    if ((size_t)o.cam >= S.camModel.size()) continue;  // (flatten() skips the observations of cameras the window does not have)
+    MapPoint& mp = *o.lm;
+    const int ip = poseWin2[o.poseBlock], ie = poseWin2[o.extBlock];
+    if (ip < 0 || ie < 0) return false;                // (an observation of a block outside the window: flatten() reports it)
+    int lmNew;
+    std::vector<SyncedObs>* list;
+    if (mp.winIdx >= 0) {
+      lmNew = lmWin2[mp.winIdx];
+      list = &S.lmObs[mp.winIdx];
+      edited.push_back(mp.winIdx);
+    } else if (mp.winIdx <= -2) {
+      lmNew = nKeptLm + (-2 - mp.winIdx);
+      list = &B.addedLists[-2 - mp.winIdx];
+    } else {
+      return false;   // (cannot happen: a landmark with an observation is part of the new window)
+    }
+    if (lmNew < 0) return false;
+    B.aoLm.push_back(lmNew), B.aoPose.push_back(ip), B.aoExt.push_back(ie), B.aoCam.push_back(o.cam);
+    B.aoUv.push_back(o.u), B.aoUv.push_back(o.v), B.aoSw.push_back(o.sqrtw);
+    list->push_back(SyncedObs{o.handle, o.poseBlock, o.cam});
+    ++nObs2;
+  }
+  // the lists stay sorted by (pose, camera), what came behind what was there among equal keys (WindowStore::apply, ba_store.hpp).
+  // The usual edit, observations of the newest frame, lands at the end and in order already.
+  auto restore = [&](std::vector<SyncedObs>& list) {
+    auto less = [&](const SyncedObs& a, const SyncedObs& b) {
+      const int pa = poseWin2[a.poseBlock], pb = poseWin2[b.poseBlock];
+      return pa != pb ? pa < pb : a.cam < b.cam;
+    };
+    if (!std::is_sorted(list.begin(), list.end(), less)) std::stable_sort(list.begin(), list.end(), less);
+  };
+  for (int wi : edited) restore(S.lmObs[wi]);
+  for (auto& list : B.addedLists) restore(list);
+  for (MapPoint* mp : touchedLm_)
+    if (mp && mp->valueSet && mp->winIdx >= 0 && lmWin2[mp->winIdx] >= 0) {
+      B.setLmIdx.push_back(lmWin2[mp->winIdx]);
+      B.setLm.insert(B.setLm.end(), mp->point.begin(), mp->point.end());
+    }
+  // ---- IMU terms (both lists are in time order) ----
+  {
+    size_t j = 0;
+    for (size_t i = 0; i < S.imu.size(); ++i) {
+      if (j < imuFactors_.size() && imuFactors_[j].uid == S.imu[i]) {
+        ++j;
+      } else {
+        B.remImu.push_back((int32_t)i);
+      }
+    }
+    for (size_t i = 0, k = 0; i < S.imu.size(); ++i) {   // (what stays must be the front of imuFactors_, in order)
+      if (!B.remImu.empty() && std::binary_search(B.remImu.begin(), B.remImu.end(), (int32_t)i)) continue;
+      if (k >= imuFactors_.size() || imuFactors_[k].uid != S.imu[i]) return false;
+      ++k;
+    }
+    for (; j < imuFactors_.size(); ++j) {
+      const ImuFactor& f = imuFactors_[j];
+      const int p0 = poseWin2[f.pose0Block], s0 = sbWin2[f.sb0Block], p1 = poseWin2[f.pose1Block], s1 = sbWin2[f.sb1Block];
+      if (p0 < 0 || s0 < 0 || p1 < 0 || s1 < 0) return false;
+      B.aiP0.push_back(p0), B.aiS0.push_back(s0), B.aiP1.push_back(p1), B.aiS1.push_back(s1);
+      B.aiT0.push_back(f.t0), B.aiT1.push_back(f.t1);
+      B.aiBegin.push_back((int32_t)B.aiSt.size()), B.aiCount.push_back((int32_t)f.meas.size());
+      for (const ImuMeasurement& m : f.meas) {
+        B.aiSt.push_back(m.t_ns);
+        B.aiGyr.insert(B.aiGyr.end(), m.gyr.begin(), m.gyr.end());
+        B.aiAcc.insert(B.aiAcc.end(), m.acc.begin(), m.acc.end());
+      }
+    }
+  }
+  // ---- the patch ----
+  okvis_ba_patch P;
+  std::memset(&P, 0, sizeof(P));
+  P.n_remove_obs = (int32_t)B.remObs.size(), P.remove_obs = B.remObs.data();
+  P.n_remove_lm = (int32_t)B.remLm.size(), P.remove_lm = B.remLm.data();
+  P.n_remove_pose = (int32_t)B.remPose.size(), P.remove_pose = B.remPose.data();
+  P.n_remove_sb = (int32_t)B.remSb.size(), P.remove_sb = B.remSb.data();
+  P.n_remove_imu = (int32_t)B.remImu.size(), P.remove_imu = B.remImu.data();
+  P.n_add_pose = (int32_t)B.addPoseFixed.size(), P.add_pose = B.addPose.data(), P.add_pose_fixed = B.addPoseFixed.data();
+  P.n_add_sb = (int32_t)B.addSbFixed.size(), P.add_sb = B.addSb.data(), P.add_sb_fixed = B.addSbFixed.data();
+  P.n_add_lm = (int32_t)added.size(), P.add_lm = B.addLm.data();
+  P.n_add_obs = (int32_t)B.aoLm.size();
+  P.add_obs_lm = B.aoLm.data(), P.add_obs_pose = B.aoPose.data(), P.add_obs_ext = B.aoExt.data(), P.add_obs_cam = B.aoCam.data();
+  P.add_obs_uv = B.aoUv.data(), P.add_obs_sqrtw = B.aoSw.data();
+  P.n_add_imu = (int32_t)B.aiP0.size();
+  P.add_imu_pose0 = B.aiP0.data(), P.add_imu_sb0 = B.aiS0.data(), P.add_imu_pose1 = B.aiP1.data(), P.add_imu_sb1 = B.aiS1.data();
+  P.add_imu_t0 = B.aiT0.data(), P.add_imu_t1 = B.aiT1.data(), P.add_imu_s_begin = B.aiBegin.data(), P.add_imu_s_count = B.aiCount.data();
+  P.n_add_imu_samples = (int32_t)B.aiSt.size();
+  P.add_imu_s_t = B.aiSt.data(), P.add_imu_s_gyr = B.aiGyr.data(), P.add_imu_s_acc = B.aiAcc.data();
+  P.replace = familiesChanged_;
+  if (familiesChanged_ & OKVIS_BA_PATCH_POSE_PRIORS)
+    for (const PosePrior& pp : posePriors_) {
+      if (poseWin2[pp.block] < 0) return false;
+      B.ppPose.push_back(poseWin2[pp.block]);
+      B.ppMeas.insert(B.ppMeas.end(), pp.meas.begin(), pp.meas.end());
+      B.ppSi.insert(B.ppSi.end(), pp.sqrtInfo.begin(), pp.sqrtInfo.end());
+    }
+  if (familiesChanged_ & OKVIS_BA_PATCH_SB_PRIORS)
+    for (const SbPrior& sp : sbPriors_) {
+      if (sbWin2[sp.block] < 0) return false;
+      B.spSb.push_back(sbWin2[sp.block]);
+      B.spMeas.insert(B.spMeas.end(), sp.meas.begin(), sp.meas.end());
+      B.spSi.insert(B.spSi.end(), sp.sqrtInfo.begin(), sp.sqrtInfo.end());
+    }
+  if (familiesChanged_ & OKVIS_BA_PATCH_RELPOSE)
+    for (const RelPose& r : relPoses_) {
+      if (poseWin2[r.block0] < 0 || poseWin2[r.block1] < 0) return false;
+      B.rp0.push_back(poseWin2[r.block0]), B.rp1.push_back(poseWin2[r.block1]);
+      B.rpSi.insert(B.rpSi.end(), r.sqrtInfo.begin(), r.sqrtInfo.end());
+    }
+  P.n_pprior = (int32_t)B.ppPose.size(), P.pprior_pose = B.ppPose.data(), P.pprior_meas = B.ppMeas.data(), P.pprior_sqrtinfo = B.ppSi.data();
+  P.n_sbprior = (int32_t)B.spSb.size(), P.sbprior_sb = B.spSb.data(), P.sbprior_meas = B.spMeas.data(), P.sbprior_sqrtinfo = B.spSi.data();
+  P.n_relpose = (int32_t)B.rp0.size(), P.rel_pose0 = B.rp0.data(), P.rel_pose1 = B.rp1.data(), P.rel_sqrtinfo = B.rpSi.data();
+  if ((familiesChanged_ & OKVIS_BA_PATCH_MARG_PRIOR) && prior_.dim > 0) {   // the MarginalizationError residual block (Estimator.cpp:750-759)
+    int off = 0;
+    for (size_t k = 0; k < prior_.block.size(); ++k) {
+      const bool isPose = prior_.type[k] == OKVIS_BA_BLOCK_POSE;
+      const int wi = isPose ? poseWin2[prior_.block[k]] : sbWin2[prior_.block[k]];
+      if (wi < 0) return false;
+      B.mType.push_back(prior_.type[k]), B.mIdx.push_back(wi), B.mOff.push_back(off);
+      off += isPose ? 6 : 9;
+      B.mLin.insert(B.mLin.end(), prior_.lin[k].begin(), prior_.lin[k].end());
+    }
+    P.marg_dim = prior_.dim;
+    P.marg_nblocks = (int32_t)prior_.block.size();
+    P.marg_block_type = B.mType.data(), P.marg_block_idx = B.mIdx.data(), P.marg_block_off = B.mOff.data();
+    P.marg_J = prior_.J.data(), P.marg_e0 = prior_.e0.data(), P.marg_lin = B.mLin.data();
+  }
+  // values the caller has set since (blocks that were part of the window already; new ones carry theirs)
+  for (int b : poseValueSet_)
+    if ((size_t)b < S.nPoseBlocks && poseWin2[b] >= 0) {
+      B.setPoseIdx.push_back(poseWin2[b]);
+      B.setPose.insert(B.setPose.end(), poseBlocks_[b].x.begin(), poseBlocks_[b].x.end());
+    }
+  for (int b : sbValueSet_)
+    if ((size_t)b < S.nSbBlocks && sbWin2[b] >= 0) {
+      B.setSbIdx.push_back(sbWin2[b]);
+      B.setSb.insert(B.setSb.end(), sbBlocks_[b].x.begin(), sbBlocks_[b].x.end());
+    }
+  P.n_set_pose = (int32_t)B.setPoseIdx.size(), P.set_pose_idx = B.setPoseIdx.data(), P.set_pose = B.setPose.data();
+  P.n_set_sb = (int32_t)B.setSbIdx.size(), P.set_sb_idx = B.setSbIdx.data(), P.set_sb = B.setSb.data();
+  P.n_set_lm = (int32_t)B.setLmIdx.size(), P.set_lm_idx = B.setLmIdx.data(), P.set_lm = B.setLm.data();
+  const auto t1 = clk::now();
+  const int rc = dry_ ? okvis_ba_store_patch(dryStore_, &P) : okvis_ba_patch_window(solver_, 0, &P);
+  if (rc != OKVIS_BA_OK) {
+    // (all or nothing on the solver's side: the old window is still there; optimize() describes the new one from scratch)
+    static const bool trace = std::getenv("OKVIS_AMD_TRACE") != nullptr;
+    if (trace) std::printf("okvis_amd::Estimator: patch refused (%s), uploading the window instead\n", okvis_ba_error_string(rc));
+    return false;
+  }
+  // ---- the description follows the container ----
+  for (MapPoint* mp : touchedLm_)
+    if (mp) mp->touched = mp->valueSet = false, mp->pendingAdds = 0;
+  {
+    std::vector<MapPoint*> lm2((size_t)nl2, nullptr);
+    std::vector<std::vector<SyncedObs>> obs2((size_t)nl2);
+    for (size_t wi = 0; wi < S.lm.size(); ++wi) {
+      if (lmWin2[wi] < 0) {
+        if (S.lm[wi]) S.lm[wi]->winIdx = -1;
+        continue;
+      }
+      lm2[lmWin2[wi]] = S.lm[wi];
+      S.lm[wi]->winIdx = lmWin2[wi];
+      obs2[lmWin2[wi]] = std::move(S.lmObs[wi]);
+    }
+    for (size_t a = 0; a < added.size(); ++a) {
+      lm2[nKeptLm + a] = added[a];
+      added[a]->winIdx = nKeptLm + (int)a;
+      obs2[nKeptLm + a] = std::move(B.addedLists[a]);
+    }
+    S.lm.swap(lm2);
+    S.lmObs.swap(obs2);
+  }
+  S.pose.swap(pose2);
+  S.sb.swap(sb2);
+  S.poseWin.swap(poseWin2);
+  S.sbWin.swap(sbWin2);
+  S.poseFixed.swap(B.poseFixed2);
+  S.sbFixed.swap(B.sbFixed2);
+  S.imu.clear();
+  for (const ImuFactor& f : imuFactors_) S.imu.push_back(f.uid);
+  S.nPoseBlocks = poseBlocks_.size();
+  S.nSbBlocks = sbBlocks_.size();
+  S.nObs = nObs2;
+  touchedLm_.clear();
+  erasedWinLm_.clear();
+  obsAdded_.clear();
+  obsRemoved_.clear();
+  firstPendingHandle_ = nextHandle_;
+  poseValueSet_.clear();
+  sbValueSet_.clear();
+  familiesChanged_ = 0;
+  patchSplit_ = {ms(t0, t1), ms(t1, clk::now())};
+  return true;
+}
+
+std::string Estimator::debugCheckWindow() {
+  okvis_ba_window v;
+  currentWindowView(&v);
+  const WindowSel sel = selectAll();
+  FlatWindow fw;
+  flatten(sel, fw);
+  const okvis_ba_window& f = fw.w;
+  const SyncedWindow& S = synced_;
+  auto num = [](const char* what, long a, long b) { return std::string(what) + " " + std::to_string(a) + " vs " + std::to_string(b); };
+  if (!S.valid) return "no window description";
+  if (v.n_pose != f.n_pose) return num("n_pose", v.n_pose, f.n_pose);
+  if (v.n_sb != f.n_sb) return num("n_sb", v.n_sb, f.n_sb);
+  if (v.n_lm != f.n_lm) return num("n_lm", v.n_lm, f.n_lm);
+  if (v.n_obs != f.n_obs) return num("n_obs", v.n_obs, f.n_obs);
+  if (v.n_imu != f.n_imu) return num("n_imu", v.n_imu, f.n_imu);
+  if (v.n_cam != f.n_cam) return num("n_cam", v.n_cam, f.n_cam);
+  if (v.n_pprior != f.n_pprior || v.n_sbprior != f.n_sbprior || v.n_relpose != f.n_relpose) return "prior counts";
+  if (v.marg_dim != f.marg_dim || (v.marg_dim > 0 && v.marg_nblocks != f.marg_nblocks)) return num("marg_dim", v.marg_dim, f.marg_dim);
+  if ((size_t)v.n_pose != S.pose.size() || (size_t)v.n_sb != S.sb.size() || (size_t)v.n_lm != S.lm.size() || (size_t)v.n_obs != S.nObs ||
+      (size_t)v.n_imu != S.imu.size())
+    return "the description's sizes differ from the container's";
+  auto same = [](const void* a, const void* b, size_t n) { return n == 0 || std::memcmp(a, b, n) == 0; };
+  // blocks: same order in both (blocks are created in time order and appended)
+  if (!same(v.pose_fixed, f.pose_fixed, (size_t)v.n_pose) || !same(v.sb_fixed, f.sb_fixed, (size_t)v.n_sb)) return "fixed flags";
+  if (!dry_) {
+    // (with a device the container carries what the DEVICE holds: the estimator wrote the same numbers back)
+  }
+  if (!same(v.pose, f.pose, 56 * (size_t)v.n_pose)) return "pose values";
+  if (!same(v.sb, f.sb, 72 * (size_t)v.n_sb)) return "speed/bias values";
+  for (int i = 0; i < v.n_pose; ++i)
+    if (S.pose[i] != sel.pose[i]) return "pose order";
+  for (int i = 0; i < v.n_sb; ++i)
+    if (S.sb[i] != sel.sb[i]) return "speed/bias order";
+  if (!same(v.cam_intr, f.cam_intr, 96 * (size_t)v.n_cam) || !same(v.cam_model, f.cam_model, 4 * (size_t)v.n_cam)) return "cameras";
+  // landmarks: any order; observation lists per landmark as sorted tuples
+  std::vector<int> fBegin((size_t)f.n_lm + 1, 0), vBegin((size_t)v.n_lm + 1, 0);
+  for (int o = 0; o < f.n_obs; ++o) fBegin[f.obs_lm[o] + 1]++;
+  for (int o = 0; o < v.n_obs; ++o) vBegin[v.obs_lm[o] + 1]++;
+  for (int l = 0; l < f.n_lm; ++l) fBegin[l + 1] += fBegin[l], vBegin[l + 1] += vBegin[l];
+  for (int o = 1; o < v.n_obs; ++o) {
+    if (v.obs_lm[o - 1] > v.obs_lm[o] || (v.obs_lm[o - 1] == v.obs_lm[o] && (v.obs_pose[o - 1] > v.obs_pose[o] ||
+        (v.obs_pose[o - 1] == v.obs_pose[o] && v.obs_cam[o - 1] > v.obs_cam[o]))))
+      return num("container observations unsorted at", o, v.n_obs);
+  }
+  typedef std::array<double, 6> Tup;
+  std::vector<Tup> a, b;
+  for (int l = 0; l < f.n_lm; ++l) {
+    const MapPoint* mp = sel.lmPtr[l];
+    const int wi = mp->winIdx;
+    if (wi < 0 || wi >= v.n_lm || S.lm[wi] != mp) return num("landmark not in the description:", (long)mp->id, wi);
+    if (!same(v.lm + 4 * (size_t)wi, f.lm + 4 * (size_t)l, 32)) return num("landmark value", (long)mp->id, wi);
+    a.clear(), b.clear();
+    for (int o = fBegin[l]; o < fBegin[l + 1]; ++o)
+      a.push_back(Tup{(double)f.obs_pose[o], (double)f.obs_ext[o], (double)f.obs_cam[o], f.obs_uv[2 * o], f.obs_uv[2 * o + 1], f.obs_sqrtw[o]});
+    for (int o = vBegin[wi]; o < vBegin[wi + 1]; ++o)
+      b.push_back(Tup{(double)v.obs_pose[o], (double)v.obs_ext[o], (double)v.obs_cam[o], v.obs_uv[2 * o], v.obs_uv[2 * o + 1], v.obs_sqrtw[o]});
+    std::sort(a.begin(), a.end()), std::sort(b.begin(), b.end());
+    if (a != b) return num("observations of landmark", (long)mp->id, (long)a.size() * 1000 + (long)b.size());
+    // the description's own list (what the next patch computes its removal indices from) is the container's, entry by entry
+    if (S.lmObs[wi].size() != b.size()) return num("described observation count of landmark", (long)mp->id, (long)S.lmObs[wi].size());
+    for (size_t k = 0; k < S.lmObs[wi].size(); ++k) {
+      const int o = vBegin[wi] + (int)k;
+      const auto it = observations_.find(S.lmObs[wi][k].handle);
+      if (it == observations_.end()) return num("described observation gone, landmark", (long)mp->id, (long)k);
+      if (S.poseWin[it->second.poseBlock] != v.obs_pose[o] || (int)it->second.camIdx != v.obs_cam[o] || it->second.u != v.obs_uv[2 * o] ||
+          it->second.v != v.obs_uv[2 * o + 1])
+        return num("described observation order, landmark", (long)mp->id, (long)k);
+    }
+  }
+  // IMU terms, priors: same order
+  if (!same(v.imu_pose0, f.imu_pose0, 4 * (size_t)v.n_imu) || !same(v.imu_sb0, f.imu_sb0, 4 * (size_t)v.n_imu) ||
+      !same(v.imu_pose1, f.imu_pose1, 4 * (size_t)v.n_imu) || !same(v.imu_sb1, f.imu_sb1, 4 * (size_t)v.n_imu) ||
+      !same(v.imu_t0, f.imu_t0, 8 * (size_t)v.n_imu) || !same(v.imu_t1, f.imu_t1, 8 * (size_t)v.n_imu) ||
+      !same(v.imu_s_count, f.imu_s_count, 4 * (size_t)v.n_imu) || v.n_imu_samples != f.n_imu_samples ||
+      !same(v.imu_s_t, f.imu_s_t, 8 * (size_t)v.n_imu_samples) || !same(v.imu_s_gyr, f.imu_s_gyr, 24 * (size_t)v.n_imu_samples) ||
+      !same(v.imu_s_acc, f.imu_s_acc, 24 * (size_t)v.n_imu_samples))
+    return "IMU terms";
+  if (!same(v.pprior_pose, f.pprior_pose, 4 * (size_t)v.n_pprior) || !same(v.pprior_meas, f.pprior_meas, 56 * (size_t)v.n_pprior) ||
+      !same(v.pprior_sqrtinfo, f.pprior_sqrtinfo, 288 * (size_t)v.n_pprior))
+    return "pose priors";
+  if (!same(v.sbprior_sb, f.sbprior_sb, 4 * (size_t)v.n_sbprior) || !same(v.sbprior_meas, f.sbprior_meas, 72 * (size_t)v.n_sbprior) ||
+      !same(v.sbprior_sqrtinfo, f.sbprior_sqrtinfo, 648 * (size_t)v.n_sbprior))
+    return "speed/bias priors";
+  if (!same(v.rel_pose0, f.rel_pose0, 4 * (size_t)v.n_relpose) || !same(v.rel_pose1, f.rel_pose1, 4 * (size_t)v.n_relpose) ||
+      !same(v.rel_sqrtinfo, f.rel_sqrtinfo, 288 * (size_t)v.n_relpose))
+    return "relative-pose terms";
+  if (v.marg_dim > 0) {
+    const size_t d = (size_t)v.marg_dim, nb = (size_t)v.marg_nblocks;
+    if (!same(v.marg_block_type, f.marg_block_type, 4 * nb) || !same(v.marg_block_idx, f.marg_block_idx, 4 * nb) ||
+        !same(v.marg_block_off, f.marg_block_off, 4 * nb) || !same(v.marg_J, f.marg_J, 8 * d * d) || !same(v.marg_e0, f.marg_e0, 8 * d) ||
+        !same(v.marg_lin, f.marg_lin, 72 * nb))
+      return "marginalisation prior";
+  }
+  return std::string();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -735,6 +1262,7 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
     return applyMarginalizationStrategyImpl(numKeyframes, numImuFrames, removedLandmarks, undo);
   } catch (...) {
     std::lock_guard<std::mutex> l(statesMutex_);
+    invalidateSynced();   // (landmarks come back as new map nodes: the next optimize() describes the window from scratch)
     for (size_t k = undo.ops.size(); k-- > 0;) {
       MargUndo::Op& op = undo.ops[k];
       if (op.kind == MargUndo::Op::SB_CLEARED) {
@@ -880,6 +1408,7 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
         removedLandmarks.push_back(mp);
         logLandmarkErase(mp);
         landmarkInitialized_.erase(pit->first);
+        forgetLandmark(mp);
         pit = landmarksMap_.erase(pit);
         continue;
       }
@@ -915,6 +1444,7 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
         removedLandmarks.push_back(mp);
         logLandmarkErase(mp);
         landmarkInitialized_.erase(pit->first);
+        forgetLandmark(mp);
         pit = landmarksMap_.erase(pit);
         continue;
       }
@@ -1017,10 +1547,31 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
       debugFailMarg_ = false;
       throw Exception("applyMarginalizationStrategy: injected failure (debugFailNextMarginalization)");
     }
-    check(okvis_ba_set_options(solver_, &options_), "set_options");
-    check(okvis_ba_upload(solver_, 1, &fw.w), "upload (marginalisation window)");
-    const auto tm2 = clk::now();
-    check(okvis_ba_marginalize(solver_, 0, &spec, &res), "marginalize");
+    auto tm2 = clk::now();
+    if (dry_) {
+      // book-keeping only: the blocks the prior will connect are known without the numbers (every free block of the
+      // sub-window that is not eliminated); a unit prior at the current values stands in
+      int nb = 0, off = 0;
+      auto keep = [&](int type, int wi, int dim) {
+        bt[nb] = type, bi[nb] = wi, bo[nb] = off;
+        ++nb;
+        off += dim;
+      };
+      for (size_t i = 0; i < sel.pose.size(); ++i)
+        if (!pm[i] && !poseBlocks_[sel.pose[i]].fixed) keep(OKVIS_BA_BLOCK_POSE, (int)i, 6);
+      for (size_t i = 0; i < sel.sb.size(); ++i)
+        if (!sm[i] && !sbBlocks_[sel.sb[i]].fixed) keep(OKVIS_BA_BLOCK_SPEEDBIAS, (int)i, 9);
+      res.dim = off;
+      res.nblocks = nb;
+      for (int i = 0; i < off; ++i) Hn[(size_t)i * off + i] = Jn[(size_t)i * off + i] = 1.0;
+    } else {
+      // the sub-window has a solver of its own: solver_ keeps the window optimize() works on between the calls
+      if (!margSolver_) check(okvis_ba_create(&margSolver_, device_), "okvis_ba_create (marginalisation)");
+      check(okvis_ba_set_options(margSolver_, &options_), "set_options");
+      check(okvis_ba_upload(margSolver_, 1, &fw.w), "upload (marginalisation window)");
+      tm2 = clk::now();
+      check(okvis_ba_marginalize(margSolver_, 0, &spec, &res), "marginalize");
+    }
     margInfo_ = {msf(tm0, tm1), msf(tm1, tm2), msf(tm2, clk::now()), (double)res.sweeps[0], (double)res.sweeps[1],
                  (double)(6 * sel.pose.size() + 9 * sel.sb.size())};
 
@@ -1045,6 +1596,7 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
     np.e0.assign(en.begin(), en.begin() + n);
     if (np.dim == 0) np = MargPrior();  // "if(marginalizationErrorPtr_->num_residuals()==0) reset" (:747-749)
     prior_ = np;
+    familiesChanged_ |= OKVIS_BA_PATCH_MARG_PRIOR;
   }
 
   // ---- remove what was linearised / marginalised from the graph (Map::removeResidualBlock / removeParameterBlock)
@@ -1059,6 +1611,10 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
   };
   compact(imuFactors_, imuSel);
   for (size_t i = 0; i < posePriors_.size(); ++i) ppSel[i] = ppSel[i] || ppDrop[i];
+  auto any = [](const std::vector<char>& v) { return std::find(v.begin(), v.end(), (char)1) != v.end(); };
+  if (any(ppSel)) familiesChanged_ |= OKVIS_BA_PATCH_POSE_PRIORS;
+  if (any(sbpSel)) familiesChanged_ |= OKVIS_BA_PATCH_SB_PRIORS;
+  if (any(relSel)) familiesChanged_ |= OKVIS_BA_PATCH_RELPOSE;
   compact(posePriors_, ppSel);
   compact(sbPriors_, sbpSel);
   compact(relPoses_, relSel);
@@ -1066,7 +1622,11 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
   {
     std::lock_guard<std::mutex> l(statesMutex_);
     for (uint64_t id : margLandmarks) {
-      landmarksMap_.erase(id);
+      auto it = landmarksMap_.find(id);
+      if (it != landmarksMap_.end()) {
+        forgetLandmark(it->second);
+        landmarksMap_.erase(it);
+      }
       landmarkInitialized_.erase(id);
     }
   }
@@ -1089,6 +1649,7 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
     sqrtInformation(info, 6, si);
     const int b = states_.front().poseBlock;
     posePriors_.push_back(PosePrior{b, poseBlocks_[b].x, si});
+    familiesChanged_ |= OKVIS_BA_PATCH_POSE_PRIORS;
   }
   return true;
 }
@@ -1192,24 +1753,29 @@ bool Estimator::set_T_WS(uint64_t poseId, const Transformation& T_WS) {
   State* s = findState(poseId);
   if (!s) return false;
   poseBlocks_[s->poseBlock].x = T_WS.p;
+  poseValueSet_.push_back(s->poseBlock);
   return true;
 }
 bool Estimator::setSpeedAndBias(uint64_t poseId, size_t, const SpeedAndBias& sb) {
   State* s = findState(poseId);
   if (!s || s->sbBlock < 0) return false;
   sbBlocks_[s->sbBlock].x = sb;
+  sbValueSet_.push_back(s->sbBlock);
   return true;
 }
 bool Estimator::setCameraSensorStates(uint64_t poseId, size_t cameraIdx, const Transformation& T_SCi) {
   State* s = findState(poseId);
   if (!s || cameraIdx >= s->extBlocks.size()) return false;
   poseBlocks_[s->extBlocks[cameraIdx]].x = T_SCi.p;
+  poseValueSet_.push_back(s->extBlocks[cameraIdx]);
   return true;
 }
 bool Estimator::setLandmark(uint64_t landmarkId, const std::array<double, 4>& landmark) {
   auto it = landmarksMap_.find(landmarkId);
   if (it == landmarksMap_.end()) return false;
   it->second.point = landmark;
+  it->second.valueSet = true;
+  touch(it->second);
   return true;
 }
 void Estimator::setLandmarkInitialized(uint64_t landmarkId, bool initialized) {

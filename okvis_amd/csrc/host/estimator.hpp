@@ -79,6 +79,11 @@ struct MapPoint {  // okvis::MapPoint (FrameTypedefs.hpp)
   std::array<double, 4> point{{0, 0, 0, 1}};
   double quality = 0, distance = 0;
   std::map<KeypointIdentifier, uint64_t> observations;  // value: opaque residual handle
+  // book-keeping of okvis_amd::Estimator (not part of okvis::MapPoint): the landmark's index in the window the solver holds
+  // (-1 = not part of it), and whether its observations / its value changed since that window was brought up to date
+  int winIdx = -1;
+  bool touched = false, valueSet = false;
+  int pendingAdds = 0;   // observations added since then
 };
 typedef std::vector<MapPoint> MapPointVector;
 typedef std::map<uint64_t, MapPoint> PointMap;
@@ -87,6 +92,9 @@ class Estimator {
  public:
   typedef std::runtime_error Exception;  // OKVIS_DEFINE_EXCEPTION(Exception, std::runtime_error), Estimator.hpp:80
 
+  // device < 0: book-keeping only (no solver is created; optimize() brings the window description up to date, checks it against a
+  // freshly flattened one and computes NOTHING, applyMarginalizationStrategy() keeps the structure decisions and leaves a unit prior):
+  // what the CPU tests drive the window edits with.  Every numeric result needs a device.
   explicit Estimator(int device = 0);
   ~Estimator();
   Estimator(const Estimator&) = delete;
@@ -151,8 +159,18 @@ class Estimator {
   void setLandmarkInitialized(uint64_t landmarkId, bool initialized);
   void setKeyframe(uint64_t frameId, bool isKeyframe);
 
-  // wall-clock split of the last optimize() in ms: flatten, okvis_ba_upload, iterations, downloads
+  // wall-clock split of the last optimize() in ms: window description (edits since the last call, or a full flatten), hand-over
+  // to the solver (okvis_ba_patch_window, or okvis_ba_upload), iterations, downloads
   const std::array<double, 4>& lastOptimizeTimings() const { return timings_; }
+  // The solver keeps the window between calls (okvis_ba_set_patchable): optimize() sends it the edits since the last call
+  // (addStates, addObservation, removeObservation, applyMarginalizationStrategy, the setters) as one okvis_ba_patch instead of
+  // flattening and uploading everything again.  false = flatten + upload every time (the round-3 route; A/B switch, also
+  // OKVIS_AMD_NO_PATCH in the environment).
+  void setUsePatch(bool on) { usePatch_ = on; }
+  bool lastOptimizeWasPatch() const { return lastWasPatch_; }
+  // diagnostics: compares the window the solver holds with a freshly flattened one (landmark by landmark, any landmark order);
+  // returns an empty string when they agree.  optimize() runs it after every hand-over when OKVIS_AMD_CHECK_PATCH is set.
+  std::string debugCheckWindow();
 
   // last applyMarginalizationStrategy(): ms flatten / upload / okvis_ba_marginalize, Jacobi sweeps of the two
   // decompositions (0 = Cholesky fast path), reduced dimension of the marginalisation window
@@ -199,6 +217,7 @@ class Estimator {
     int poseBlock, extBlock;  // T_WS and T_SCi blocks of the observing frame (cached at addObservation)
   };
   struct ImuFactor {
+    uint64_t uid;  // identity of the term between windows (the vector is compacted when terms are marginalised)
     int pose0Block, sb0Block, pose1Block, sb1Block;  // indices into poseBlocks_ / sbBlocks_
     int64_t t0, t1;
     ImuMeasurementDeque meas;  // the deque is COPIED into the factor (ImuError.hpp:151-153)
@@ -248,8 +267,89 @@ class Estimator {
     std::vector<std::vector<int64_t>> i64;
     std::vector<std::vector<uint8_t>> u8;
     std::vector<int> poseMap, sbMap;            // block index -> window index (-1 = not in the window)
+    std::vector<uint64_t> obsHandle;            // per observation of the window: its handle
     okvis_ba_window w;
   };
+  // ---- the window the solver holds (Map::addParameterBlock / addResidualBlock / remove*, Map.cpp:292-565, as edits of it) ----
+  struct SyncedObs {
+    uint64_t handle;
+    int poseBlock, cam;
+  };
+  struct SyncedWindow {
+    bool valid = false;
+    std::vector<int> pose, sb;                    // window index -> block
+    std::vector<int> poseWin, sbWin;              // block -> window index (-1 = not in the window)
+    std::vector<uint8_t> poseFixed, sbFixed;      // (a block that changes this flag makes the window start over)
+    std::vector<MapPoint*> lm;                    // window index -> landmark (nodes of landmarksMap_ do not move); nullptr = erased
+    std::vector<std::vector<SyncedObs>> lmObs;    // per window landmark: its observations in window order
+    std::vector<uint64_t> imu;                    // window index -> ImuFactor::uid
+    std::vector<double> camIntr;
+    std::vector<int32_t> camModel;
+    size_t nPoseBlocks = 0, nSbBlocks = 0;        // poseBlocks_.size() / sbBlocks_.size() at that time: later blocks are new
+    size_t nObs = 0;
+  };
+  SyncedWindow synced_;
+  // scratch of patchWindow(), kept between calls (no allocation in the steady state)
+  struct PatchBuffers {
+    std::vector<int32_t> remObs, remLm, remPose, remSb, remImu;
+    std::vector<double> addPose, addSb, addLm, aoUv, aoSw, aiGyr, aiAcc, ppMeas, ppSi, spMeas, spSi, rpSi, mLin, setPose, setSb, setLm;
+    std::vector<uint8_t> addPoseFixed, addSbFixed, poseFixed2, sbFixed2;
+    std::vector<int32_t> aoLm, aoPose, aoExt, aoCam, aiP0, aiS0, aiP1, aiS1, aiBegin, aiCount, ppPose, spSb, rp0, rp1, mType, mIdx, mOff,
+        setPoseIdx, setSbIdx, setLmIdx;
+    std::vector<int64_t> aiT0, aiT1, aiSt;
+    std::vector<int> pose2, sb2, poseWin2, sbWin2, lmWin2;
+    std::vector<size_t> obsBegin;
+    std::vector<char> found;
+    std::vector<uint64_t> fresh;
+    std::vector<MapPoint*> addedLm;
+    std::vector<int> editedLm;
+    std::vector<std::vector<SyncedObs>> addedLists;
+    void clear() {
+      for (auto* v : {&remObs, &remLm, &remPose, &remSb, &remImu, &aoLm, &aoPose, &aoExt, &aoCam, &aiP0, &aiS0, &aiP1, &aiS1, &aiBegin, &aiCount,
+                      &ppPose, &spSb, &rp0, &rp1, &mType, &mIdx, &mOff, &setPoseIdx, &setSbIdx, &setLmIdx})
+        v->clear();
+      for (auto* v : {&addPose, &addSb, &addLm, &aoUv, &aoSw, &aiGyr, &aiAcc, &ppMeas, &ppSi, &spMeas, &spSi, &rpSi, &mLin, &setPose, &setSb, &setLm})
+        v->clear();
+      for (auto* v : {&addPoseFixed, &addSbFixed, &poseFixed2, &sbFixed2}) v->clear();
+      for (auto* v : {&aiT0, &aiT1, &aiSt}) v->clear();
+      for (auto* v : {&pose2, &sb2, &poseWin2, &sbWin2, &lmWin2}) v->clear();
+      obsBegin.clear(), found.clear(), fresh.clear(), addedLm.clear(), editedLm.clear(), addedLists.clear();
+    }
+  };
+  PatchBuffers patchBuf_;
+  std::array<double, 2> patchSplit_{};            // ms: describing the window (patch or flatten), handing it over
+  std::vector<double> resPose_, resSb_, resLm_, resQ_, resRef_;   // results of the last optimize() (kept: no allocation per frame)
+  std::vector<MapPoint*> touchedLm_;              // landmarks with MapPoint::touched (nullptr = erased meanwhile)
+  std::vector<int> erasedWinLm_;                  // window indices of landmarks erased from the map
+  // the two logs of observation edits since the last hand-over (addObservation / removeObservation write them)
+  struct PendingObs {
+    MapPoint* lm;                                 // nullptr = removed again (or its landmark erased) before it reached the window
+    uint64_t handle;
+    int poseBlock, extBlock, cam;
+    double u, v, sqrtw;
+  };
+  struct RemovedObs {
+    int lmWin;                                    // window index of its landmark
+    uint64_t handle;
+  };
+  std::vector<PendingObs> obsAdded_;
+  std::vector<RemovedObs> obsRemoved_;
+  uint64_t firstPendingHandle_ = 1;               // handles from here on were handed out after the last hand-over
+  void noteObservationRemoved(MapPoint& mp, uint64_t handle);
+  std::vector<int> poseValueSet_, sbValueSet_;    // blocks whose value the caller has set
+  int familiesChanged_ = 0;                       // OKVIS_BA_PATCH_* bits: prior families edited since the last hand-over
+  bool usePatch_ = true, lastWasPatch_ = false;
+  void touch(MapPoint& mp) {
+    if (!mp.touched) {
+      mp.touched = true;
+      touchedLm_.push_back(&mp);
+    }
+  }
+  void forgetLandmark(MapPoint& mp);              // before the landmark is erased from landmarksMap_
+  void invalidateSynced();                        // the next optimize() flattens and uploads
+  bool patchWindow();                             // edits since the last hand-over -> okvis_ba_patch_window; false = not possible
+  void uploadWindow(FlatWindow& fw);              // flatten + okvis_ba_upload, synced_ rebuilt
+  void currentWindowView(okvis_ba_window* out);   // the container the solver (or the book-keeping-only store) holds
 
   const State* findState(uint64_t id) const;
   State* findState(uint64_t id);
@@ -264,6 +364,9 @@ class Estimator {
 
   int device_;
   okvis_ba_solver* solver_ = nullptr;
+  okvis_ba_solver* margSolver_ = nullptr;          // the marginalisation sub-window has a solver of its own: solver_ keeps its window
+  okvis_ba_window_store* dryStore_ = nullptr;      // book-keeping-only instance (device < 0): the container, no solver
+  bool dry_ = false;
   okvis_ba_options options_;
   okvis_ba_summary summary_;
   double timeLimit_ = -1.0;
@@ -293,6 +396,7 @@ class Estimator {
   std::array<double, 6> margInfo_{};  // last marginalisation: ms flatten, upload, marginalize; Jacobi sweeps (2); sub-window D
   uint64_t nextId_ = 1ULL << 40;    // IdProvider::instance().newId() stand-in for internal blocks
   uint64_t nextHandle_ = 1;
+  uint64_t nextImuUid_ = 1;
   mutable std::mutex statesMutex_;  // guards getLandmark(s) like Estimator.cpp:936,956,965
 };
 

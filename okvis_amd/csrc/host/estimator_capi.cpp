@@ -236,6 +236,52 @@ int okvis_est_set_use_graph(void* h, int use_graph) {
     return 1;
   });
 }
+// setters (Estimator.hpp:366-411): 1 = done, 0 = unknown id
+int okvis_est_set_T_WS(void* h, uint64_t id, const double T[7]) {
+  return guarded([&] {
+    Transformation t;
+    std::copy(T, T + 7, t.p.begin());
+    return static_cast<Estimator*>(h)->set_T_WS(id, t) ? 1 : 0;
+  });
+}
+int okvis_est_set_speed_and_bias(void* h, uint64_t id, const double sb[9]) {
+  return guarded([&] {
+    SpeedAndBias v;
+    std::copy(sb, sb + 9, v.begin());
+    return static_cast<Estimator*>(h)->setSpeedAndBias(id, 0, v) ? 1 : 0;
+  });
+}
+int okvis_est_set_extrinsics(void* h, uint64_t id, int cam, const double T[7]) {
+  return guarded([&] {
+    Transformation t;
+    std::copy(T, T + 7, t.p.begin());
+    return static_cast<Estimator*>(h)->setCameraSensorStates(id, (size_t)cam, t) ? 1 : 0;
+  });
+}
+int okvis_est_set_landmark(void* h, uint64_t id, const double hp[4]) {
+  return guarded([&] {
+    std::array<double, 4> p{{hp[0], hp[1], hp[2], hp[3]}};
+    return static_cast<Estimator*>(h)->setLandmark(id, p) ? 1 : 0;
+  });
+}
+// 1 = optimize() sends the edits since the last call as a patch of the window the solver holds (default), 0 = flatten + upload
+int okvis_est_set_use_patch(void* h, int on) {
+  return guarded([&] {
+    static_cast<Estimator*>(h)->setUsePatch(on != 0);
+    return 1;
+  });
+}
+int okvis_est_last_was_patch(void* h) {
+  return guarded([&] { return static_cast<Estimator*>(h)->lastOptimizeWasPatch() ? 1 : 0; });
+}
+// 1 = the window the solver holds equals a freshly flattened one; 0 = it differs (what: okvis_est_last_error)
+int okvis_est_debug_check_window(void* h) {
+  return guarded([&] {
+    const std::string d = static_cast<Estimator*>(h)->debugCheckWindow();
+    if (!d.empty()) g_err = d;
+    return d.empty() ? 1 : 0;
+  });
+}
 int okvis_est_num_frames(void* h) { return (int)static_cast<Estimator*>(h)->numFrames(); }
 int okvis_est_num_landmarks(void* h) { return (int)static_cast<Estimator*>(h)->numLandmarks(); }
 int okvis_est_current_frame_id(void* h, uint64_t* id) {

@@ -1,4 +1,6 @@
-// okvis_amd_replay <dataset folder> [trajectory.csv] [--keyframes N] [--imu-frames N] [--iterations N] [--max-frames N]
+// okvis_amd_replay <dataset folder> [trajectory.csv] [--keyframes N] [--imu-frames N] [--iterations N] [--max-frames N] [--no-patch]
+//
+// --no-patch: every optimize() flattens and uploads its window (the round-3 route) instead of patching the window the solver holds.
 //
 // The backend-side counterpart of `okvis_app_synchronous <config> <dataset folder>` (reference
 // okvis_apps/src/okvis_app_synchronous.cpp): reads the ASL folder plus the recorded tracks (replay.hpp) and runs the per-frame
@@ -19,6 +21,7 @@ int main(int argc, char** argv) {
   }
   okvis_amd::ReplayOptions opt;
   std::string out;
+  bool usePatch = true;
   for (int i = 2; i < argc; ++i) {
     auto val = [&](int& dst) {
       if (i + 1 >= argc) {
@@ -31,6 +34,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--imu-frames")) val(opt.numImuFrames);
     else if (!std::strcmp(argv[i], "--iterations")) val(opt.numIterations);
     else if (!std::strcmp(argv[i], "--max-frames")) val(opt.maxFrames);
+    else if (!std::strcmp(argv[i], "--no-patch")) usePatch = false;
     else out = argv[i];
   }
   try {
@@ -39,6 +43,7 @@ int main(int argc, char** argv) {
     std::printf("No. frames: %zu, cameras: %zu, recorded observations: %zu, landmarks: %zu\n", rec.frames.size(), rec.cameras.size(),
                 rec.observations.size(), rec.landmarks.size());
     okvis_amd::Estimator estimator(0);
+    if (!usePatch) estimator.setUsePatch(false);
     const okvis_amd::ReplayResult r = okvis_amd::replay(rec, opt, estimator);
     double mo = 0, mm = 0, t4[4] = {0, 0, 0, 0};
     for (size_t k = 0; k < r.frames.size(); ++k) {
@@ -53,7 +58,10 @@ int main(int argc, char** argv) {
     const double n = r.frames.empty() ? 1.0 : (double)r.frames.size();
     std::printf("Finished: %zu frames, %zu landmarks marginalised or dropped, optimize %.3f ms + marginalise %.3f ms per frame\n",
                 r.frames.size(), r.landmarksRemoved, mo / n, mm / n);
-    std::printf("optimize split per frame: flatten %.3f + upload %.3f + iterations %.3f + download %.3f ms\n", t4[0] / n, t4[1] / n, t4[2] / n,
+    // window = describing it (the edits since the last frame as one patch; --no-patch: a full flatten), hand-over = giving it to the
+    // solver (okvis_ba_patch_window; --no-patch: okvis_ba_upload)
+    std::printf("window route: %s\n", usePatch ? "patch (edits of the window the solver holds)" : "flatten + upload");
+    std::printf("optimize split per frame: window %.3f + hand-over %.3f + iterations %.3f + download %.3f ms\n", t4[0] / n, t4[1] / n, t4[2] / n,
                 t4[3] / n);
     {   // medians: the means above carry the first frames' device allocations and page-locking
       auto median = [&](auto get) {
@@ -63,7 +71,7 @@ int main(int argc, char** argv) {
         std::sort(v.begin(), v.end());
         return v[v.size() / 2];
       };
-      std::printf("medians per frame: optimize %.3f (flatten %.3f + upload %.3f + iterations %.3f + download %.3f) + marginalise %.3f ms\n",
+      std::printf("medians per frame: optimize %.3f (window %.3f + hand-over %.3f + iterations %.3f + download %.3f) + marginalise %.3f ms\n",
                   median([](const okvis_amd::ReplayFrameResult& f) { return f.msOptimize; }),
                   median([](const okvis_amd::ReplayFrameResult& f) { return f.msFlatten; }),
                   median([](const okvis_amd::ReplayFrameResult& f) { return f.msUpload; }),

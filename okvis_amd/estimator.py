@@ -209,6 +209,44 @@ class Estimator:
         self._c(self._api.okvis_est_last_marg_info(self._h, out.ctypes.data_as(_dp)))
         return out
 
+    def set_T_WS(self, pose_id, T):
+        fn = self._api.okvis_est_set_T_WS
+        fn.argtypes = [C.c_void_p, C.c_uint64, _dp]
+        return bool(self._c(fn(self._h, int(pose_id), _d(T).ctypes.data_as(_dp))))
+
+    def setSpeedAndBias(self, pose_id, sb):
+        fn = self._api.okvis_est_set_speed_and_bias
+        fn.argtypes = [C.c_void_p, C.c_uint64, _dp]
+        return bool(self._c(fn(self._h, int(pose_id), _d(sb).ctypes.data_as(_dp))))
+
+    def setCameraSensorStates(self, pose_id, cam, T):
+        fn = self._api.okvis_est_set_extrinsics
+        fn.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _dp]
+        return bool(self._c(fn(self._h, int(pose_id), int(cam), _d(T).ctypes.data_as(_dp))))
+
+    def setLandmark(self, lm_id, hp):
+        fn = self._api.okvis_est_set_landmark
+        fn.argtypes = [C.c_void_p, C.c_uint64, _dp]
+        return bool(self._c(fn(self._h, int(lm_id), _d(hp).ctypes.data_as(_dp))))
+
+    def setUsePatch(self, on):
+        """True (default): optimize() patches the window the solver holds with the edits since the last call; False: flatten +
+        upload every time."""
+        fn = self._api.okvis_est_set_use_patch
+        fn.argtypes = [C.c_void_p, C.c_int]
+        self._c(fn(self._h, int(bool(on))))
+
+    def lastOptimizeWasPatch(self):
+        fn = self._api.okvis_est_last_was_patch
+        fn.argtypes = [C.c_void_p]
+        return bool(self._c(fn(self._h)))
+
+    def debugCheckWindow(self):
+        """'' when the window the solver holds equals a freshly flattened one, else what differs"""
+        fn = self._api.okvis_est_debug_check_window
+        fn.argtypes = [C.c_void_p]
+        return "" if self._c(fn(self._h)) else self._api.okvis_est_last_error().decode()
+
     def setUseGraph(self, use_graph):
         self._c(self._api.okvis_est_set_use_graph(self._h, int(use_graph)))
 
