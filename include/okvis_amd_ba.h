@@ -269,7 +269,8 @@ int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt,
  *      extrinsics block, IMU terms and pose / speed-bias / relative-pose priors on a removed block.  The dense marginalisation
  *      prior cannot lose one of its blocks: replace it in the same patch (OKVIS_BA_PATCH_MARG_PRIOR), else OKVIS_BA_ERR_ARG;
  *   2. what is left is renumbered by stable compaction (relative order kept);
- *   3. appended blocks take the next indices; appended terms and replaced prior families are given in the NEW numbering;
+ *   3. appended blocks take the next indices (landmarks: or the places add_lm_before names); appended terms and replaced
+ *      prior families are given in the NEW numbering;
  *      observations stay sorted by (lm, pose, cam): appended ones are merged in, behind equal keys;
  *   4. sparse value updates (new numbering), e.g. re-triangulated landmarks (Estimator::setLandmark).
  * A patch is checked completely before anything changes: on an error the window is untouched. */
@@ -303,6 +304,11 @@ typedef struct okvis_ba_patch {
   int32_t n_set_pose; const int32_t* set_pose_idx; const double* set_pose; /* [n_set_pose][7] */
   int32_t n_set_sb;   const int32_t* set_sb_idx;   const double* set_sb;   /* [n_set_sb][9]   */
   int32_t n_set_lm;   const int32_t* set_lm_idx;   const double* set_lm;   /* [n_set_lm][4]   */
+  /* optional (NULL = every appended landmark takes the next index): add_lm_before[k] = how many of the landmarks that STAY come
+   * in front of appended landmark k, ascending (0 .. number that stay).  Landmark k is then inserted there instead of at the
+   * end, e.g. to keep the landmarks in the order of their ids like a flattened okvis::PointMap; landmark indices of the
+   * appended observations and of set_lm_idx are the resulting ones. */
+  const int32_t* add_lm_before;
 } okvis_ba_patch;
 
 /* Host-side window container with these edits (no device needed): create = deep copy of a window, patch = the edit above,

@@ -1398,6 +1398,13 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
     s->mirrors.clear();
     return rc;
   }
+  const auto t_c0 = std::chrono::steady_clock::now();
+  struct Note {
+    std::chrono::steady_clock::time_point t0;
+    ~Note() {
+      if (g_build_times.on) g_build_times.ms["upload: copy into the container"] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+  } note{t_c0};
   try {   // a patchable solver keeps what it was given (ba_store.hpp)
     s->mirrors.resize((size_t)n_windows);
     for (int i = 0; i < n_windows; ++i)
@@ -1558,6 +1565,14 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   s->evaluated = false;
   s->res_staged = false;
   s->acc_fresh = true;   // Ctrl starts zeroed: accepted buffer 0, like HostWin::acc
+  if (g_build_times.on) {
+    const auto t_u2 = std::chrono::steady_clock::now();
+    auto d = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    g_build_times.ms["upload_impl: wait for the stream"] += d(t_enter, t_synced);
+    g_build_times.ms["upload_impl: index build (sum of the sections)"] += d(t_u0, t_u1);
+    g_build_times.ms["upload_impl: staging + enqueue"] += d(t_u1, t_u2);
+    g_build_times.ms["upload_impl calls"] += 1.0;
+  }
   if (dbg_t) {
     const auto t_u2 = std::chrono::steady_clock::now();
     std::fprintf(stderr, "upload: sync %.3f ms, graphs %.3f ms, index build %.3f ms, staging + enqueue %.3f ms, arena %zu bytes data + %zu zero\n",
@@ -1654,7 +1669,16 @@ int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p) {
   if (!s->uploaded || !s->patchable || s->mirrors.size() != s->wins.size()) return OKVIS_BA_ERR_STATE;
   if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
+  auto pt_prev = std::chrono::steady_clock::now();
+  auto PT = [&](const char* name) {   // (OKVIS_BA_DEBUG_BUILD: mean host time per section, printed at exit with build_window's)
+    if (g_build_times.on) {
+      const auto t_ = std::chrono::steady_clock::now();
+      g_build_times.ms[name] += std::chrono::duration<double, std::milli>(t_ - pt_prev).count();
+      pt_prev = t_;
+    }
+  };
   if (int rc = refresh_mirrors(s)) return rc;
+  PT("patch: values from the device");
   // All or nothing.  The edit is applied to a COPY of window w's container; the solver's own container only changes (one swap,
   // which cannot throw) after the edited window has been indexed and uploaded.  Whatever fails before that — a rejected patch, a
   // structure limit, an allocation, the device — leaves the containers as they were; if the device no longer holds the old
@@ -1664,12 +1688,15 @@ int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p) {
   int rc = OKVIS_BA_OK;
   try {
     after = s->mirrors[w];
+    PT("patch: copy of the container");
     rc = after.apply(*p);   // (checks the whole patch before it touches `after`; `after` is discarded on failure anyway)
+    PT("patch: edit");
     if (rc == OKVIS_BA_OK) {
       std::vector<okvis_ba_window> views(s->mirrors.size());
       for (size_t i = 0; i < s->mirrors.size(); ++i) ((int)i == w ? after : s->mirrors[i]).view(&views[i]);
       upload_started = true;
       rc = upload_impl(s, (int)views.size(), views.data());
+      PT("patch: index + upload");
     }
   } catch (const std::bad_alloc&) {
     rc = OKVIS_BA_ERR_ARG;

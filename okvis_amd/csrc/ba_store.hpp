@@ -278,7 +278,10 @@ struct WindowStore {
     auto &x_uv = buf.x_uv, &x_sw = buf.x_sw;
     const int np1 = remap(np0, p.remove_pose, p.n_remove_pose, mp) + p.n_add_pose;
     const int ns1 = remap(ns0, p.remove_sb, p.n_remove_sb, ms) + p.n_add_sb;
-    const int nl1 = remap(nl0, p.remove_lm, p.n_remove_lm, ml) + p.n_add_lm;
+    const int nlk = remap(nl0, p.remove_lm, p.n_remove_lm, ml), nl1 = nlk + p.n_add_lm;
+    if (p.add_lm_before)   // places of the appended landmarks among the ones that stay: ascending, 0 .. nlk
+      for (int k = 0; k < p.n_add_lm; ++k)
+        if (p.add_lm_before[k] < 0 || p.add_lm_before[k] > nlk || (k > 0 && p.add_lm_before[k] < p.add_lm_before[k - 1])) return OKVIS_BA_ERR_ARG;
     remap(no0, p.remove_obs, p.n_remove_obs, mo);
     if (!rep_marg)
       for (size_t b = 0; b < marg_block_type.size(); ++b)
@@ -307,6 +310,28 @@ struct WindowStore {
     compact(pose, mp, 7); compact(pose_fixed, mp, 1);
     compact(sb, ms, 9); compact(sb_fixed, ms, 1);
     compact(lm, ml, 4);
+    if (p.add_lm_before && p.n_add_lm) {
+      // the appended landmarks take their places: a landmark that stays moves back by the number of new ones in front of it
+      std::vector<double>& out = buf.x_uv;   // (free until the observations are merged below)
+      out.resize(4 * (size_t)nl1);
+      int k = 0;
+      for (int j = 0; j <= nlk; ++j) {
+        while (k < p.n_add_lm && p.add_lm_before[k] == j) {
+          std::memcpy(&out[4 * (size_t)(j + k)], p.add_lm + 4 * (size_t)k, 32);
+          ++k;
+        }
+        if (j < nlk) std::memcpy(&out[4 * (size_t)(j + k)], &lm[4 * (size_t)j], 32);
+      }
+      lm.assign(out.begin(), out.end());
+      k = 0;
+      int j = 0;   // (ml is ascending over the landmarks that stay)
+      for (int l = 0; l < nl0; ++l) {
+        if (ml[l] < 0) continue;
+        while (k < p.n_add_lm && p.add_lm_before[k] <= j) ++k;
+        ml[l] = j + k;
+        ++j;
+      }
+    }
     {
       std::vector<int32_t> mi;
       remap(ni0, p.remove_imu, p.n_remove_imu, mi);
@@ -370,7 +395,7 @@ struct WindowStore {
     pose_fixed.insert(pose_fixed.end(), p.add_pose_fixed, p.add_pose_fixed + p.n_add_pose);
     sb.insert(sb.end(), p.add_sb, p.add_sb + 9 * (size_t)p.n_add_sb);
     sb_fixed.insert(sb_fixed.end(), p.add_sb_fixed, p.add_sb_fixed + p.n_add_sb);
-    lm.insert(lm.end(), p.add_lm, p.add_lm + 4 * (size_t)p.n_add_lm);
+    if (!(p.add_lm_before && p.n_add_lm)) lm.insert(lm.end(), p.add_lm, p.add_lm + 4 * (size_t)p.n_add_lm);
     for (int f = 0; f < p.n_add_imu; ++f) {
       Imu m;
       m.pose0 = p.add_imu_pose0[f]; m.sb0 = p.add_imu_sb0[f]; m.pose1 = p.add_imu_pose1[f]; m.sb1 = p.add_imu_sb1[f];
@@ -400,23 +425,41 @@ struct WindowStore {
       if (!std::is_sorted(ord.begin(), ord.end(), new_less)) std::stable_sort(ord.begin(), ord.end(), new_less);
       const size_t cap = (size_t)no0 + (size_t)p.n_add_obs;
       x_lm.resize(cap); x_pose.resize(cap); x_ext.resize(cap); x_cam.resize(cap); x_uv.resize(2 * cap); x_sw.resize(cap);
+      // (plain pointers: the loop below is the bulk of an edit's time — a frame's worth of records moved once)
+      int32_t* __restrict o_lm = x_lm.data(); int32_t* __restrict o_pose = x_pose.data(); int32_t* __restrict o_ext = x_ext.data();
+      int32_t* __restrict o_cam = x_cam.data(); double* __restrict o_uv = x_uv.data(); double* __restrict o_sw = x_sw.data();
+      const int32_t* __restrict i_lm = obs_lm.data(); const int32_t* __restrict i_pose = obs_pose.data();
+      const int32_t* __restrict i_ext = obs_ext.data(); const int32_t* __restrict i_cam = obs_cam.data();
+      const double* __restrict i_uv = obs_uv.data(); const double* __restrict i_sw = obs_sqrtw.data();
+      const int32_t* __restrict r_ml = ml.data(); const int32_t* __restrict r_mp = mp.data(); const int32_t* __restrict r_mo = mo.data();
       size_t o = 0;
       int j = 0;
+      const int nadd = p.n_add_obs;
       auto put_new = [&](int a) {
-        x_lm[o] = p.add_obs_lm[a]; x_pose[o] = p.add_obs_pose[a]; x_ext[o] = p.add_obs_ext[a]; x_cam[o] = p.add_obs_cam[a];
-        x_uv[2 * o] = p.add_obs_uv[2 * (size_t)a]; x_uv[2 * o + 1] = p.add_obs_uv[2 * (size_t)a + 1]; x_sw[o] = p.add_obs_sqrtw[a];
+        o_lm[o] = p.add_obs_lm[a]; o_pose[o] = p.add_obs_pose[a]; o_ext[o] = p.add_obs_ext[a]; o_cam[o] = p.add_obs_cam[a];
+        o_uv[2 * o] = p.add_obs_uv[2 * (size_t)a]; o_uv[2 * o + 1] = p.add_obs_uv[2 * (size_t)a + 1]; o_sw[o] = p.add_obs_sqrtw[a];
         ++o;
       };
+      // key of the next record that comes (INT_MAX landmark once there is none: nothing is in front of it any more)
+      int nl = 0x7fffffff, np_ = 0, nc = 0;
+      auto next_key = [&] {
+        if (j < nadd) nl = p.add_obs_lm[ord[j]], np_ = p.add_obs_pose[ord[j]], nc = p.add_obs_cam[ord[j]];
+        else nl = 0x7fffffff;
+      };
+      next_key();
       for (int i = 0; i < no0; ++i) {
-        if (mo[i] < 0) continue;
-        const int l = ml[obs_lm[i]], ip = mp[obs_pose[i]], ie = mp[obs_ext[i]], c = obs_cam[i];
-        if (l < 0 || ip < 0 || ie < 0) continue;   // observations of a removed landmark / pose / extrinsics block go with it
-        while (j < p.n_add_obs && key_less(p.add_obs_lm[ord[j]], p.add_obs_pose[ord[j]], p.add_obs_cam[ord[j]], l, ip, c)) put_new(ord[j++]);
-        x_lm[o] = l; x_pose[o] = ip; x_ext[o] = ie; x_cam[o] = c;
-        x_uv[2 * o] = obs_uv[2 * (size_t)i]; x_uv[2 * o + 1] = obs_uv[2 * (size_t)i + 1]; x_sw[o] = obs_sqrtw[i];
+        if (r_mo[i] < 0) continue;
+        const int l = r_ml[i_lm[i]], ip = r_mp[i_pose[i]], ie = r_mp[i_ext[i]], c = i_cam[i];
+        if ((l | ip | ie) < 0) continue;   // observations of a removed landmark / pose / extrinsics block go with it
+        while (nl < l || (nl == l && (np_ < ip || (np_ == ip && nc < c)))) {
+          put_new(ord[j++]);
+          next_key();
+        }
+        o_lm[o] = l; o_pose[o] = ip; o_ext[o] = ie; o_cam[o] = c;
+        o_uv[2 * o] = i_uv[2 * (size_t)i]; o_uv[2 * o + 1] = i_uv[2 * (size_t)i + 1]; o_sw[o] = i_sw[i];
         ++o;
       }
-      while (j < p.n_add_obs) put_new(ord[j++]);
+      while (j < nadd) put_new(ord[j++]);
       x_lm.resize(o); x_pose.resize(o); x_ext.resize(o); x_cam.resize(o); x_uv.resize(2 * o); x_sw.resize(o);
       obs_lm.swap(x_lm); obs_pose.swap(x_pose); obs_ext.swap(x_ext); obs_cam.swap(x_cam); obs_uv.swap(x_uv); obs_sqrtw.swap(x_sw);
     }

@@ -893,7 +893,8 @@ bool Estimator::patchWindow() {
       B.addSbFixed.push_back(sbBlocks_[b].fixed ? 1 : 0);
     }
   // ---- landmarks: erased ones and the ones that lost their last observation leave; observed ones that are not part of the
-  //      window yet are appended (by id, the order flatten() would give them among themselves) ----
+  //      window yet take their places by id among the ones that stay (add_lm_before): the window keeps the order of
+  //      landmarksMap_, the order flatten() gives it ----
   std::vector<MapPoint*>& added = B.addedLm;
   for (int wi : erasedWinLm_) B.remLm.push_back(wi);
   for (MapPoint* mp : touchedLm_) {
@@ -907,13 +908,26 @@ bool Estimator::patchWindow() {
   lmWin2.assign(S.lm.size(), 0);
   for (int wi : B.remLm) lmWin2[wi] = -1;
   int nl2 = 0;
-  for (size_t wi = 0; wi < S.lm.size(); ++wi)
-    if (lmWin2[wi] == 0) lmWin2[wi] = nl2++;
-  const int nKeptLm = nl2;
-  for (MapPoint* mp : added) {
-    B.addLm.insert(B.addLm.end(), mp->point.begin(), mp->point.end());
-    ++nl2;
+  {
+    size_t a = 0;   // new landmarks placed so far
+    int kept = 0;
+    for (size_t wi = 0; wi < S.lm.size(); ++wi) {
+      if (lmWin2[wi] < 0) continue;
+      while (a < added.size() && added[a]->id < S.lm[wi]->id) {
+        B.addLmBefore.push_back(kept);
+        B.addLmIdx.push_back(kept + (int)a);
+        ++a;
+      }
+      lmWin2[wi] = kept + (int)a;
+      ++kept;
+    }
+    for (; a < added.size(); ++a) {
+      B.addLmBefore.push_back(kept);
+      B.addLmIdx.push_back(kept + (int)a);
+    }
+    nl2 = kept + (int)added.size();
   }
+  for (MapPoint* mp : added) B.addLm.insert(B.addLm.end(), mp->point.begin(), mp->point.end());
   // ---- observations: what left and what came since the last hand-over, from the two logs (no look-up, no comparison of lists) ----
   // From here on the description is edited in place.  Whenever this function gives up (return false) optimize() describes the
   // window from scratch (uploadWindow), so a half-edited description is never used.
@@ -940,7 +954,7 @@ bool Estimator::patchWindow() {
     list.erase(std::remove_if(list.begin(), list.end(), [](const SyncedObs& o) { return o.handle == 0; }), list.end());
   }
   edited.clear();
-  for (size_t a = 0; a < added.size(); ++a) added[a]->winIdx = -2 - (int)a;   // (their final index: nKeptLm + a)
+  for (size_t a = 0; a < added.size(); ++a) added[a]->winIdx = -2 - (int)a;   // (their final index: B.addLmIdx[a])
   B.addedLists.resize(added.size());
   for (const PendingObs& o : obsAdded_) {
     if (!o.lm) continue;                               // removed again, or its landmark erased, before it ever reached the window
@@ -955,7 +969,7 @@ bool Estimator::patchWindow() {
       list = &S.lmObs[mp.winIdx];
       edited.push_back(mp.winIdx);
     } else if (mp.winIdx <= -2) {
-      lmNew = nKeptLm + (-2 - mp.winIdx);
+      lmNew = B.addLmIdx[-2 - mp.winIdx];
       list = &B.addedLists[-2 - mp.winIdx];
     } else {
       return false;   // (cannot happen: a landmark with an observation is part of the new window)
@@ -1021,7 +1035,7 @@ bool Estimator::patchWindow() {
   P.n_remove_imu = (int32_t)B.remImu.size(), P.remove_imu = B.remImu.data();
   P.n_add_pose = (int32_t)B.addPoseFixed.size(), P.add_pose = B.addPose.data(), P.add_pose_fixed = B.addPoseFixed.data();
   P.n_add_sb = (int32_t)B.addSbFixed.size(), P.add_sb = B.addSb.data(), P.add_sb_fixed = B.addSbFixed.data();
-  P.n_add_lm = (int32_t)added.size(), P.add_lm = B.addLm.data();
+  P.n_add_lm = (int32_t)added.size(), P.add_lm = B.addLm.data(), P.add_lm_before = B.addLmBefore.data();
   P.n_add_obs = (int32_t)B.aoLm.size();
   P.add_obs_lm = B.aoLm.data(), P.add_obs_pose = B.aoPose.data(), P.add_obs_ext = B.aoExt.data(), P.add_obs_cam = B.aoCam.data();
   P.add_obs_uv = B.aoUv.data(), P.add_obs_sqrtw = B.aoSw.data();
@@ -1107,9 +1121,9 @@ bool Estimator::patchWindow() {
       obs2[lmWin2[wi]] = std::move(S.lmObs[wi]);
     }
     for (size_t a = 0; a < added.size(); ++a) {
-      lm2[nKeptLm + a] = added[a];
-      added[a]->winIdx = nKeptLm + (int)a;
-      obs2[nKeptLm + a] = std::move(B.addedLists[a]);
+      lm2[B.addLmIdx[a]] = added[a];
+      added[a]->winIdx = B.addLmIdx[a];
+      obs2[B.addLmIdx[a]] = std::move(B.addedLists[a]);
     }
     S.lm.swap(lm2);
     S.lmObs.swap(obs2);
@@ -1186,6 +1200,7 @@ std::string Estimator::debugCheckWindow() {
   for (int l = 0; l < f.n_lm; ++l) {
     const MapPoint* mp = sel.lmPtr[l];
     const int wi = mp->winIdx;
+    if (wi != l) return num("landmark order: window index vs place in the map,", wi, l);
     if (wi < 0 || wi >= v.n_lm || S.lm[wi] != mp) return num("landmark not in the description:", (long)mp->id, wi);
     if (!same(v.lm + 4 * (size_t)wi, f.lm + 4 * (size_t)l, 32)) return num("landmark value", (long)mp->id, wi);
     a.clear(), b.clear();
@@ -1258,11 +1273,20 @@ struct Estimator::MargUndo {
 bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks) {
   MargUndo undo;
   undo.removedSize = removedLandmarks.size();
+  // the logs of window edits as they stand: a failed call takes its entries back (possible unless it may have dropped entries of
+  // the log of additions, which cannot be brought back; then the next optimize() describes the window from scratch)
+  const size_t nRemovedLog = obsRemoved_.size(), nErasedLog = erasedWinLm_.size();
+  const bool logsRestorable = synced_.valid && obsAdded_.empty();
   try {
     return applyMarginalizationStrategyImpl(numKeyframes, numImuFrames, removedLandmarks, undo);
   } catch (...) {
     std::lock_guard<std::mutex> l(statesMutex_);
-    invalidateSynced();   // (landmarks come back as new map nodes: the next optimize() describes the window from scratch)
+    if (logsRestorable) {
+      obsRemoved_.resize(nRemovedLog);
+      erasedWinLm_.resize(nErasedLog);
+    } else {
+      invalidateSynced();
+    }
     for (size_t k = undo.ops.size(); k-- > 0;) {
       MargUndo::Op& op = undo.ops[k];
       if (op.kind == MargUndo::Op::SB_CLEARED) {
@@ -1273,7 +1297,17 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
             op.obs.handle;
       } else {
         landmarkInitialized_[op.landmark.id] = op.initialized;
-        landmarksMap_[op.landmark.id] = std::move(op.landmark);
+        const uint64_t id = op.landmark.id;
+        MapPoint& node = landmarksMap_[id];
+        node = std::move(op.landmark);
+        if (synced_.valid) {   // the landmark is back as a new map node: the window description points at it again
+          if (node.winIdx >= 0 && (size_t)node.winIdx < synced_.lm.size()) synced_.lm[node.winIdx] = &node;
+          if (node.touched) touchedLm_.push_back(&node);
+        } else {
+          node.winIdx = -1;
+          node.touched = node.valueSet = false;
+          node.pendingAdds = 0;
+        }
       }
     }
     removedLandmarks.resize(undo.removedSize);

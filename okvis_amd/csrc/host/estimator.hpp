@@ -297,7 +297,8 @@ class Estimator {
     std::vector<int32_t> aoLm, aoPose, aoExt, aoCam, aiP0, aiS0, aiP1, aiS1, aiBegin, aiCount, ppPose, spSb, rp0, rp1, mType, mIdx, mOff,
         setPoseIdx, setSbIdx, setLmIdx;
     std::vector<int64_t> aiT0, aiT1, aiSt;
-    std::vector<int> pose2, sb2, poseWin2, sbWin2, lmWin2;
+    std::vector<int> pose2, sb2, poseWin2, sbWin2, lmWin2, addLmIdx;
+    std::vector<int32_t> addLmBefore;
     std::vector<size_t> obsBegin;
     std::vector<char> found;
     std::vector<uint64_t> fresh;
@@ -312,7 +313,7 @@ class Estimator {
         v->clear();
       for (auto* v : {&addPoseFixed, &addSbFixed, &poseFixed2, &sbFixed2}) v->clear();
       for (auto* v : {&aiT0, &aiT1, &aiSt}) v->clear();
-      for (auto* v : {&pose2, &sb2, &poseWin2, &sbWin2, &lmWin2}) v->clear();
+      for (auto* v : {&pose2, &sb2, &poseWin2, &sbWin2, &lmWin2, &addLmIdx, &addLmBefore}) v->clear();
       obsBegin.clear(), found.clear(), fresh.clear(), addedLm.clear(), editedLm.clear(), addedLists.clear();
     }
   };

@@ -358,6 +358,7 @@ class PatchC(C.Structure):
         ("n_set_pose", C.c_int32), ("set_pose_idx", _ip), ("set_pose", _dp),
         ("n_set_sb", C.c_int32), ("set_sb_idx", _ip), ("set_sb", _dp),
         ("n_set_lm", C.c_int32), ("set_lm_idx", _ip), ("set_lm", _dp),
+        ("add_lm_before", _ip),
     ]
 
 
@@ -418,11 +419,12 @@ class Patch:
     set_sb: np.ndarray = _e(np.float64, 0, 9)
     set_lm_idx: np.ndarray = _e(np.int32)
     set_lm: np.ndarray = _e(np.float64, 0, 4)
+    add_lm_before: np.ndarray = _e(np.int32)   # empty = appended at the end
 
     _I32 = ("remove_obs", "remove_lm", "remove_pose", "remove_sb", "remove_imu", "add_obs_lm", "add_obs_pose", "add_obs_ext",
             "add_obs_cam", "add_imu_pose0", "add_imu_sb0", "add_imu_pose1", "add_imu_sb1", "add_imu_s_begin", "add_imu_s_count",
             "pprior_pose", "sbprior_sb", "rel_pose0", "rel_pose1", "marg_block_type", "marg_block_idx", "marg_block_off",
-            "set_pose_idx", "set_sb_idx", "set_lm_idx")
+            "set_pose_idx", "set_sb_idx", "set_lm_idx", "add_lm_before")
     _I64 = ("add_imu_t0", "add_imu_t1", "add_imu_s_t")
     _U8 = ("add_pose_fixed", "add_sb_fixed")
     _F64 = dict(add_pose=7, add_sb=9, add_lm=4, add_obs_uv=2, add_obs_sqrtw=0, add_imu_s_gyr=3, add_imu_s_acc=3, pprior_meas=7,

@@ -1,10 +1,13 @@
-"""diagnostics (not a test): per-frame timing split of the C++ replay on a synthetic recording"""
+"""diagnostics (not a test): per-frame timing split of the C++ replay on a synthetic recording, with the window patched between
+frames (default) and flattened + uploaded every frame (--no-patch).  OKVIS_BA_DEBUG_BUILD=1 in the environment adds the mean host
+time of the solver's sections (index build, container edit, enqueue) to stderr."""
 import os, sys, subprocess, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from okvis_amd import recording
 d = tempfile.mkdtemp()
 recording.write_synthetic_recording(d, duration_s=8.0)
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "okvis_amd", "lib", "okvis_amd_replay")
-p = subprocess.run([exe, d], capture_output=True, text=True)
-print(p.stdout[-500:])
-print("\n".join(p.stderr.splitlines()[10:40]))
+for extra in ([], ["--no-patch"], [], ["--no-patch"]):
+    p = subprocess.run([exe, d] + extra, capture_output=True, text=True)
+    print("\n".join(p.stdout.splitlines()[-9:]))
+    print("\n".join(l for l in p.stderr.splitlines() if "build_window" in l).replace("  ", "\n    "))

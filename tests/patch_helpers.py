@@ -112,7 +112,8 @@ def make_marg(W, ids, rng):
 
 
 def patch_between(A: Carving, B: Carving) -> Patch:
-    """The okvis_ba_patch that turns carving A into carving B.  Requires B's kept blocks in A's relative order, new ones behind."""
+    """The okvis_ba_patch that turns carving A into carving B.  Requires B's kept blocks in A's relative order, new ones behind;
+    new landmarks may sit anywhere among the kept ones (add_lm_before then says where)."""
     W = A.W
     p = Patch()
     keep_pose = [i for i in A.pose_ids if i in B.pose_ids]
@@ -121,7 +122,9 @@ def patch_between(A: Carving, B: Carving) -> Patch:
     new_pose = [i for i in B.pose_ids if i not in A.pose_ids]
     new_sb = [k for k in B.sb_ids if k not in A.sb_ids]
     new_lm = [l for l in B.lm_ids if l not in A.lm_ids]
-    assert B.pose_ids == keep_pose + new_pose and B.sb_ids == keep_sb + new_sb and B.lm_ids == keep_lm + new_lm
+    assert B.pose_ids == keep_pose + new_pose and B.sb_ids == keep_sb + new_sb
+    assert [l for l in B.lm_ids if l in A.lm_ids] == keep_lm
+    lm_in_place = B.lm_ids != keep_lm + new_lm
     p.remove_pose = np.array([n for n, i in enumerate(A.pose_ids) if i not in B.pose_ids], np.int32)
     p.remove_sb = np.array([n for n, k in enumerate(A.sb_ids) if k not in B.sb_ids], np.int32)
     p.remove_lm = np.array([n for n, l in enumerate(A.lm_ids) if l not in B.lm_ids], np.int32)
@@ -151,6 +154,10 @@ def patch_between(A: Carving, B: Carving) -> Patch:
     p.add_pose, p.add_pose_fixed = wb.pose[nkp:].reshape(-1, 7), wb.pose_fixed[nkp:]
     p.add_sb, p.add_sb_fixed = wb.sb[nks:].reshape(-1, 9), wb.sb_fixed[nks:]
     p.add_lm = wb.lm[nkl:].reshape(-1, 4)
+    if lm_in_place:
+        pos = [n for n, l in enumerate(B.lm_ids) if l not in A.lm_ids]
+        p.add_lm = wb.lm[pos].reshape(-1, 4)
+        p.add_lm_before = np.array([n - k for k, n in enumerate(pos)], np.int32)   # kept landmarks in front of each new one
     # IMU terms: B's terms that A does not have, with their own sample arrays
     new_terms = [n for n, f in enumerate(B.imu_terms) if f not in A.imu_terms]
     assert [f for f in B.imu_terms if f in A.imu_terms] + [B.imu_terms[n] for n in new_terms] == B.imu_terms

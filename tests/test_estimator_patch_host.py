@@ -161,7 +161,7 @@ def test_random_edits_between_frames(folder, seed):
     est.applyMarginalizationStrategy = marg
     _frame_loop(rng, est, rec, 30, hook)
     assert len(failed) == 2
-    assert est.patched[0] is False and sum(est.patched) >= 25, est.patched   # (the two roll-backs start the window over)
+    assert est.patched[0] is False and all(est.patched[1:]), est.patched   # (a roll-back takes its entries of the edit logs back)
     assert est.debugCheckWindow() != ""          # (the last marginalisation's edits are still to be handed over)
     est.optimize(1, 1, False)
     assert est.debugCheckWindow() == ""

@@ -43,6 +43,37 @@ def test_one_frame_of_the_sliding_window(seed):
     st.close()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_new_landmarks_inserted_in_id_order(seed):
+    """add_lm_before: the new landmarks take their places among the ones that stay (a flattened okvis::PointMap is ordered by id)
+    instead of the end; observations and sparse values use the resulting indices"""
+    A, B = sliding_pair(seed=30 + seed, K=5, L=70, n_new_lm=15)
+    A.lm_ids, B.lm_ids = sorted(A.lm_ids), sorted(B.lm_ids)
+    assert B.lm_ids != [l for l in B.lm_ids if l in A.lm_ids] + [l for l in B.lm_ids if l not in A.lm_ids]   # (really interleaved)
+    st = solver.WindowStore(A.window())
+    p = patch_between(A, B)
+    assert len(p.add_lm_before) == len(p.add_lm) > 0
+    want = B.window()
+    p.set_lm_idx = np.array([0, want.n_lm - 1], np.int32)
+    p.set_lm = want.lm[[0, want.n_lm - 1]] + 0.25
+    want.lm[[0, want.n_lm - 1]] += 0.25
+    assert st.patch(p) == 0
+    got = st.view()
+    assert windows_differ(got, want) == []
+    got.validate()
+    assert structure(got) == structure(want)
+    # places that are not ascending, or beyond the landmarks that stay, are refused and change nothing
+    for bad in (p.add_lm_before[::-1].copy(), p.add_lm_before + want.n_lm):
+        q = patch_between(A, B)
+        q.add_lm_before = bad
+        st2 = solver.WindowStore(A.window())
+        if not np.array_equal(bad, p.add_lm_before):
+            assert st2.patch(q) != 0
+            assert windows_differ(st2.view(), A.window()) == []
+        st2.close()
+    st.close()
+
+
 def test_several_frames_in_a_row():
     K, L = 5, 70
     W = synthetic.make_window(K + 3, L, 0.8, seed=31, frame_dt=0.2)
