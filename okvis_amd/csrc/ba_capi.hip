@@ -221,12 +221,24 @@ std::vector<T> vec(const T* p, size_t n) {
 // diagnostics: OKVIS_BA_DEBUG_BUILD=1 accumulates the host time of build_window's sections and prints them at exit
 struct BuildTimes {
   bool on = std::getenv("OKVIS_BA_DEBUG_BUILD") != nullptr;
-  std::map<std::string, double> ms;
+  struct Acc {   // (`+=` keeps the call sites of the mean-only version)
+    std::vector<double> v;
+    Acc& operator+=(double x) {
+      v.push_back(x);
+      return *this;
+    }
+  };
+  std::map<std::string, Acc> ms;
   long calls = 0;
   ~BuildTimes() {
     if (!on || !calls) return;
-    std::fprintf(stderr, "build_window: %ld calls, mean ms per section:", calls);
-    for (const auto& kv : ms) std::fprintf(stderr, "  %s %.4f", kv.first.c_str(), kv.second / calls);
+    std::fprintf(stderr, "build_window: %ld calls, median ms per section (number of samples):", calls);
+    for (auto& kv : ms) {
+      std::vector<double>& v = kv.second.v;
+      if (v.empty()) continue;
+      std::sort(v.begin(), v.end());
+      std::fprintf(stderr, "  %s %.4f (%zu)", kv.first.c_str(), v[v.size() / 2], v.size());
+    }
     std::fprintf(stderr, "\n");
   }
 };

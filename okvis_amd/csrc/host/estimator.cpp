@@ -670,6 +670,8 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
         if (bad) std::printf("okvis_amd::Estimator::optimize: input array %zu holds %zu non-finite values of %zu\n", a, bad, fw.f64[a].size());
       }
   }
+  static const bool syncAfter = std::getenv("OKVIS_AMD_SYNC_AFTER_HANDOVER") != nullptr;   // (diagnostics: the enqueued copies are charged to the hand-over)
+  if (syncAfter && !dry_) check(okvis_ba_synchronize(solver_), "synchronize");
   const auto t2 = clk::now();
   const SyncedWindow& S = synced_;
   if (checkPatch || dry_) {
