@@ -21,6 +21,7 @@
 #include "ba_linearize2.hpp"
 #include "ba_schur2.hpp"
 #include "ba_marg.hpp"
+#include "ba_marg_tiles.hpp"
 #include "ba_schur.hpp"
 #include "ba_solve.hpp"
 #include "ba_store.hpp"
@@ -134,6 +135,7 @@ struct okvis_ba_solver {
   bool patchable = false;
   std::vector<WindowStore> mirrors;
   WindowStore mirror_edit;   // okvis_ba_patch_window edits a copy: this one
+  long marg_tiles_fallbacks = 0;   // okvis_ba_marginalize calls whose tiled tail gave way to the single workgroup (diagnostics)
   bool evaluated = false;      // okvis_ba_begin ran since the last upload: every IMU term's cache has been (re)built
   bool mirror_fresh = false;   // the containers hold the values the device holds (nothing optimised / set since)
   bool res_staged = false;  // stage_res holds window 0's packed results as of the last okvis_ba_finish (single-window solvers)
@@ -2336,6 +2338,15 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   const size_t out_bytes = 8 * (2 * nn + 2 * n1);
   const size_t o_out = A.alloc(out_bytes + sizeof(int) * (8 + std::max(1, D)));
   const size_t o_info = o_out + out_bytes;
+  // kept blocks beyond the single-workgroup LDS paths: the tail on many workgroups (ba_marg_tiles.hpp)
+  const bool no_tiles = std::getenv("OKVIS_BA_NO_MARG_TILES") != nullptr;   // (A/B switch, read per call)
+  const bool tiles = na > MARG_PC_NMAX && !no_tiles;
+  const int mt_nT = tiles ? (na + CT_TB - 1) / CT_TB : 0, mt_ntiles = mt_nT * (mt_nT + 1) / 2;
+  const size_t o_mtT = A.alloc(8 * (size_t)std::max(1, mt_ntiles) * CT_TILE), o_mtZ = A.alloc(8 * (size_t)std::max(1, mt_ntiles) * CT_TILE),
+               o_mtL = A.alloc(8 * (size_t)std::max(1, mt_nT) * CT_TILE), o_mtR = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)),
+               o_mtY = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)), o_mtP = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)),
+               o_mtF = A.alloc(8 * (size_t)std::max(1, mt_nT)), o_mtp = A.alloc(8 * (size_t)std::max(1, D)),
+               o_mtf = A.alloc(sizeof(int) * (size_t)(mt_ntiles + 1 + 2 * mt_nT + 1));
   s->stage_marg.resize(host_part);   // page-locked: the one upload of this call is a true asynchronous copy
   unsigned char* const hb = s->stage_marg.data();
   if (H.n_pose) std::memcpy(&hb[o_pm], spec->pose_marg, H.n_pose);
@@ -2413,18 +2424,75 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   ma.out_b0 = outp + 2 * nn;
   ma.out_e0 = outp + 2 * nn + n1;
   ma.out_info = reinterpret_cast<int*>(d + o_info);
-  if (large_window || pd > MARG_SMALL_PRIOR)
-    hipLaunchKernelGGL((marg_dense_kernel<MAX_D, MAX_MARG_DIM>), dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES_LARGE * 8, s->stream, d_win, 0,
-                       ma, MARG_LDS_DOUBLES_LARGE);
-  else
-    hipLaunchKernelGGL((marg_dense_kernel<MAX_D_LDS, MARG_SMALL_PRIOR>), dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES * 8, s->stream, d_win, 0,
-                       ma, MARG_LDS_DOUBLES);
+  ma.p_out = reinterpret_cast<double*>(d + o_mtp);
+  auto dense = [&](const MargArgs& args, int stage) {
+    if (large_window || pd > MARG_SMALL_PRIOR)
+      hipLaunchKernelGGL((marg_dense_kernel<MAX_D, MAX_MARG_DIM>), dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES_LARGE * 8, s->stream, d_win, 0,
+                         args, MARG_LDS_DOUBLES_LARGE, stage);
+    else
+      hipLaunchKernelGGL((marg_dense_kernel<MAX_D_LDS, MARG_SMALL_PRIOR>), dim3(1), dim3(MARG_THREADS), MARG_LDS_DOUBLES * 8, s->stream, d_win, 0,
+                         args, MARG_LDS_DOUBLES, stage);
+  };
+  MargTiles mt{};
+  if (tiles) {
+    // the single workgroup stops after M and b0; Schur complement, scaling, tiled factorisation (matrix core), L^-1 for the proof
+    // of full rank, J and e0 on many workgroups
+    mt.C.nT = mt_nT;
+    mt.C.T = reinterpret_cast<double*>(d + o_mtT);
+    mt.C.Linv = reinterpret_cast<double*>(d + o_mtL);
+    mt.C.rhs = reinterpret_cast<double*>(d + o_mtR);
+    mt.C.y = reinterpret_cast<double*>(d + o_mtY);
+    mt.C.flag = reinterpret_cast<int*>(d + o_mtf);
+    mt.C.pflag = mt.C.flag + mt_ntiles + 1;
+    mt.Z = reinterpret_cast<double*>(d + o_mtZ);
+    mt.fro = reinterpret_cast<double*>(d + o_mtF);
+    mt.p2 = reinterpret_cast<double*>(d + o_mtP);
+    mt.ok = mt.C.flag + mt_ntiles + 1 + 2 * mt_nT;
+    static const bool attrs = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM_DOUBLES * 8);
+      return true;
+    }();
+    (void)attrs;
+    dense(ma, 1);
+    const unsigned nb2 = (unsigned)(((size_t)na * na + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS);
+    hipLaunchKernelGGL(marg_schur_kernel, dim3(nb2), dim3(MARG_TILES_THREADS), 0, s->stream, d_win, ma);
+    hipLaunchKernelGGL(marg_tiles_scale_kernel, dim3((CT_TB * mt_nT + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS), dim3(MARG_TILES_THREADS), 0,
+                       s->stream, ma, mt);
+    hipLaunchKernelGGL(marg_tiles_fill_kernel, dim3(mt_ntiles), dim3(MARG_TILES_THREADS), 0, s->stream, ma, mt);
+    hipLaunchKernelGGL(chol_tile_kernel, dim3(mt_ntiles), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8, s->stream, mt.C);
+    hipLaunchKernelGGL(marg_tiles_inverse_kernel, dim3(mt_nT), dim3(CT_THREADS), 2 * CT_TB * CT_LD * 8, s->stream, ma, mt);
+    hipLaunchKernelGGL(marg_tiles_out_kernel, dim3(mt_ntiles), dim3(MARG_TILES_THREADS), 0, s->stream, ma, mt);
+    hipLaunchKernelGGL(marg_tiles_decide_kernel, dim3(1), dim3(MARG_THREADS), 0, s->stream, ma, mt);
+  } else {
+    dense(ma, 0);
+  }
   HIP_TRY(hipGetLastError());
   // H | J | b0 | e0 | info are contiguous on the device: one copy into page-locked staging, one synchronisation
   int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  s->stage_dl.resize(out_bytes + sizeof(info));
-  HIP_TRY(hipMemcpyAsync(s->stage_dl.data(), outp, out_bytes + sizeof(info), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->stage_dl.resize(out_bytes + sizeof(info) + sizeof(int));
+  int* const tiles_ok = reinterpret_cast<int*>(s->stage_dl.data() + out_bytes + sizeof(info));
+  auto fetch = [&]() -> hipError_t {
+    hipError_t e = hipMemcpyAsync(s->stage_dl.data(), outp, out_bytes + sizeof(info), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && tiles) e = hipMemcpyAsync(tiles_ok, mt.ok, sizeof(int), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    return e;
+  };
+  *tiles_ok = 1;
+  HIP_TRY(fetch());
+  if (tiles && !*tiles_ok) {
+    // no proof of full rank (a rank-deficient kept block, a pivot that is not positive): the single workgroup takes over — the
+    // previous prior is part of H already, everything else is done again — and goes on to the eigen-decomposition
+    MargArgs again = ma;
+    again.prior_dim = 0;
+    again.prior_nb = 0;
+    dense(again, 0);
+    HIP_TRY(hipGetLastError());
+    *tiles_ok = 1;
+    hipError_t e = hipMemcpyAsync(s->stage_dl.data(), outp, out_bytes + sizeof(info), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    HIP_TRY(e);
+    s->marg_tiles_fallbacks++;
+  }
   std::memcpy(info, s->stage_dl.data() + out_bytes, sizeof(info));
   if (na > 0) {
     const double* h = reinterpret_cast<const double*>(s->stage_dl.data());

@@ -41,6 +41,8 @@ struct MargArgs {
   double* out_J;           // [na*na]
   double* out_e0;          // [na]
   int* out_info;           // [0] na, [1] nm, [2] rank, [3] Jacobi sweeps (V), [4] Jacobi sweeps (H), [8 + i] kept reduced index i
+  // tiled route (ba_marg_tiles.hpp): the kernel stops after M and b0 (stage = 1) and leaves the scaling of the elimination here
+  double* p_out = nullptr; // [D]
 };
 
 // workspace of marg_dense_kernel: A | Q | M (D^2 each), the 6-row panel of marg_chol_inverse, and the two padded matrices of the
@@ -608,7 +610,7 @@ __device__ bool marg_chol_inverse(double* M, double* X, int n, int n_true, doubl
 
 template <int MAXD, int MAXP>
 __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs* __restrict__ wins, int w, MargArgs a,
-                                                                   int lds_doubles) {
+                                                                   int lds_doubles, int stage) {
   extern __shared__ __attribute__((aligned(16))) double marg_lds[];
   const WinPtrs& W = wins[w];
   const int tid = threadIdx.x;
@@ -768,6 +770,11 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
       a.out_b0[i] = v;
       s_ba[i] = v;
     }
+    if (stage == 1) {   // the rest on many workgroups (marg_schur_kernel ...): they need the scaling
+      for (int i = tid; i < D; i += MARG_THREADS) a.p_out[i] = s_p[i];
+      if (tid == 0) a.out_info[3] = sweeps_v;
+      return;
+    }
     for (int k = tid; k < na * na; k += MARG_THREADS) {  // H = P_a (U - M M^T) P_a (:736-738)
       const int i = k / na, j = k - i * na;
       const int ki = s_kidx[i], kj = s_kidx[j];
@@ -779,6 +786,10 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
     for (int i = tid; i < na; i += MARG_THREADS) {
       a.out_b0[i] = b[s_kidx[i]];
       s_ba[i] = b[s_kidx[i]];
+    }
+    if (stage == 1) {
+      if (tid == 0) a.out_info[3] = 0;
+      return;
     }
     for (int k = tid; k < na * na; k += MARG_THREADS) a.out_H[k] = H[s_kidx[k / na] * D + s_kidx[k % na]];
   }

@@ -1,0 +1,239 @@
+// The dense tail of the marginalisation (ba_marg.hpp) on MANY workgroups, for kept blocks that do not fit the single-workgroup
+// LDS paths (more than MARG_PC_NMAX = 96 rows: a window of 20 or 50 frames, BASELINE configs[2]).  Same algebra, same proofs:
+//
+//   marginalizeOut, dense part      okvis_ceres/src/MarginalizationError.cpp:686-736
+//   updateErrorComputation          okvis_ceres/src/MarginalizationError.cpp:806-846
+//
+//   marg_dense_kernel(stage 1)   one workgroup: previous prior into H, the eliminated block's V^(+1/2) (small: one frame's pose and
+//                                speed/bias), M = W V^(+1/2), b0 — and stops
+//   marg_schur_kernel            H_a = P (U - M M^T) P, one entry per work-item                       (:736-738)
+//   marg_tiles_fill_kernel       the pre-scaled, symmetrised kept block as 48 x 48 lower tiles (identity padded), rhs = P^-1 b0
+//   chol_tile_kernel             ba_chol_tiles.hpp: L (fp64 matrix core), the inverses of the diagonal tiles, y = L^-1 rhs
+//   marg_tiles_inverse_kernel    L^-T tile column by tile column (one workgroup each, matrix core): ||L^-1||_F^2
+//   marg_tiles_out_kernel        J = L^T P, e0 = -y
+//   marg_tiles_decide_kernel     the proof of full rank, as in marg_chol_inverse:  1 / ||L^-1||_F^2 > 4 eps n max_i sum_j |A_ij|
+//
+// When the proof fails (a rank-deficient kept block, a non-positive pivot) nothing of this is used: the caller runs the
+// single-workgroup kernel, which goes on to the eigen-decomposition.
+#pragma once
+#include "ba_chol_tiles.hpp"
+#include "ba_marg.hpp"
+
+namespace ba {
+
+constexpr int MARG_TILES_THREADS = 256;
+
+struct MargTiles {
+  CholTiles C;          // tiles, diagonal inverses, rhs, y, flags (x = nullptr: no back-substitution)
+  double* Z;            // [ntiles] tiles of L^-T: tile column j of L^-1, transposed, at ct_tile_index(i, j)
+  double* fro;          // [nT] ||tile column j of L^-1||_F^2 over the true rows / columns
+  double* p2;           // [48 nT] scaling of the kept block
+  int* ok;              // [0] 1 = the factor and the proof hold: J, e0 are final
+};
+
+// H_a = P_a (U - M M^T) P_a : the expression of marg_dense_kernel, entry by entry
+__global__ __launch_bounds__(MARG_TILES_THREADS) void marg_schur_kernel(const WinPtrs* __restrict__ wins, MargArgs a) {
+  const WinPtrs& W = wins[0];
+  const int D = W.D, na = a.out_info[0], nm = a.out_info[1];
+  const double* H = W.S;
+  const double* M = a.work + 2 * (size_t)D * D;
+  const int* kidx = a.out_info + 8;
+  const size_t k = (size_t)blockIdx.x * MARG_TILES_THREADS + threadIdx.x;
+  if (k >= (size_t)na * na) return;
+  const int i = (int)(k / na), j = (int)(k - (size_t)i * na);
+  const int ki = kidx[i], kj = kidx[j];
+  if (nm == 0) {
+    a.out_H[k] = H[(size_t)ki * D + kj];
+    return;
+  }
+  const double pp = a.p_out[ki] * a.p_out[kj];
+  double s = H[(size_t)ki * D + kj] / pp;
+  for (int c = 0; c < nm; ++c) s -= M[(size_t)i * nm + c] * M[(size_t)j * nm + c];
+  a.out_H[k] = s * pp;
+}
+
+// scaling of updateErrorComputation (:812-815) — needs the finished diagonal of H_a, hence a launch of its own
+__global__ __launch_bounds__(MARG_TILES_THREADS) void marg_tiles_scale_kernel(MargArgs a, MargTiles T) {
+  const int na = a.out_info[0];
+  const int i = blockIdx.x * MARG_TILES_THREADS + threadIdx.x;
+  if (i >= CT_TB * T.C.nT) return;
+  double p = 1.0;
+  if (i < na) {
+    const double d = a.out_H[(size_t)i * na + i];
+    p = d > 1.0e-9 ? sqrt(d) : 1.0e-3;
+  }
+  T.p2[i] = p;
+  T.C.rhs[i] = i < na ? a.out_b0[i] / p : 0.0;
+}
+
+// one workgroup per lower tile: A = 0.5 (H_a + H_a^T) pre-scaled, identity outside the true part; the flags of the factorisation start at zero
+__global__ __launch_bounds__(MARG_TILES_THREADS) void marg_tiles_fill_kernel(MargArgs a, MargTiles T) {
+  const int na = a.out_info[0], nT = T.C.nT;
+  int j = 0, rem = blockIdx.x;   // column-major task order, like chol_tile_task
+  while (rem >= nT - j) {
+    rem -= nT - j;
+    ++j;
+  }
+  const int i = j + rem;
+  double* t = T.C.T + (size_t)ct_tile_index(i, j) * CT_TILE;
+  const double* Ha = a.out_H;
+  for (int e = threadIdx.x; e < CT_TILE; e += MARG_TILES_THREADS) {
+    const int r = CT_TB * i + e / CT_TB, c = CT_TB * j + e % CT_TB;
+    double v = r == c ? 1.0 : 0.0;
+    if (r < na && c < na) v = 0.5 * (Ha[(size_t)r * na + c] + Ha[(size_t)c * na + r]) / (T.p2[r] * T.p2[c]);
+    t[e] = v;
+  }
+  if (blockIdx.x == 0) {
+    const int nflag = nT * (nT + 1) / 2 + 1 + 2 * nT;
+    for (int e = threadIdx.x; e < nflag; e += MARG_TILES_THREADS) T.C.flag[e] = 0;
+    if (threadIdx.x == 0) T.ok[0] = 0;
+  }
+}
+
+// Tile column j of L^-1 by forward substitution over tiles, kept TRANSPOSED (Z_ji = (L^-1)_ij^T) so that every product is the
+// A B^T form of the factorisation (ct_gemm_nt):
+//   Z_jj = Linv_j^T,     Z_ji = - (sum_(k = j .. i-1) Z_jk L_ik^T) Linv_i^T        (from  sum_k L_ik X_kj = delta_ij)
+// One workgroup per tile column; the column's tiles go to memory as they are finished and come back through the cache for the
+// sums below them.  fro[j] = sum of the squares over the true part (the identity padding contributes nothing to the bound).
+__global__ __launch_bounds__(CT_THREADS) void marg_tiles_inverse_kernel(MargArgs a, MargTiles T) {
+  extern __shared__ __attribute__((aligned(16))) double mt_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int na = a.out_info[0], nT = T.C.nT, j = blockIdx.x;
+  double* sA = mt_smem;                      // Z_jk, then the sum
+  double* sB = mt_smem + CT_TB * CT_LD;      // L_ik, then Linv_i
+  __shared__ double s_part[CT_THREADS / 64];
+  double fs = 0.0;
+  auto square_sum = [&](const ct_v4 acc[3], int ti) {   // accumulator of Z_(j, ti): rows 48 j + .., columns 48 ti + ..
+    const int col = lane & 15, r0 = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gr = CT_TB * j + 16 * wave + r0 + 4 * q, gc = CT_TB * ti + 16 * c + col;
+        if (gr < na && gc < na) fs += acc[c][q] * acc[c][q];
+      }
+  };
+  // Z_jj = Linv_j^T
+  {
+    const double* Lj = T.C.Linv + (size_t)j * CT_TILE;
+    double* Zjj = T.Z + (size_t)ct_tile_index(j, j) * CT_TILE;
+    for (int e = tid; e < CT_TILE; e += CT_THREADS) {
+      const int r = e / CT_TB, c = e - r * CT_TB;
+      const double v = ct_gld(Lj + c * CT_TB + r);
+      ct_gst(Zjj + e, v);
+      if (CT_TB * j + r < na && CT_TB * j + c < na) fs += v * v;
+    }
+    ct_release();
+    __syncthreads();
+  }
+  for (int i = j + 1; i < nT; ++i) {
+    ct_v4 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
+    for (int k = j; k < i; ++k) {
+      ct_load_tile(T.Z + (size_t)ct_tile_index(k, j) * CT_TILE, sA, tid);      // Z_jk is stored at the place of tile (k, j)
+      ct_load_tile(T.C.T + (size_t)ct_tile_index(i, k) * CT_TILE, sB, tid);    // L_ik
+      __syncthreads();
+      if (wave < 3) ct_gemm_nt(acc, sA, sB, wave, lane, 1.0);
+      __syncthreads();
+    }
+    if (wave < 3) ct_store_acc(acc, sA, CT_LD, wave, lane);
+    ct_load_tile(T.C.Linv + (size_t)i * CT_TILE, sB, tid);
+    __syncthreads();
+    if (wave < 3) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
+      ct_gemm_nt(acc, sA, sB, wave, lane, -1.0);
+      square_sum(acc, i);
+      ct_store_acc_g(acc, T.Z + (size_t)ct_tile_index(i, j) * CT_TILE, wave, lane);
+    }
+    ct_release();
+    __syncthreads();
+  }
+  fs = wave_sum(fs);
+  if (lane == 0) s_part[wave] = fs;
+  __syncthreads();
+  if (tid == 0) {
+    double f = 0.0;
+    for (int q = 0; q < CT_THREADS / 64; ++q) f += s_part[q];
+    T.fro[j] = f;
+  }
+}
+
+// J = L^T P (upper triangular), e0 = -L^-1 P^-1 b0 = -y.  The diagonal tiles of L are not kept by the factorisation (it keeps
+// their inverses): L_jj = (Linv_j)^-1 by substitution, one column per work-item.
+__global__ __launch_bounds__(MARG_TILES_THREADS) void marg_tiles_out_kernel(MargArgs a, MargTiles T) {
+  const int na = a.out_info[0], nT = T.C.nT;
+  int j = 0, rem = blockIdx.x;
+  while (rem >= nT - j) {
+    rem -= nT - j;
+    ++j;
+  }
+  const int i = j + rem;   // tile (i, j) of L, i >= j  ->  block (j, i) of J
+  __shared__ double s_L[CT_TB * CT_LD];
+  const int tid = threadIdx.x;
+  if (i == j) {
+    __shared__ double s_X[CT_TB * CT_LD];
+    const double* Lj = T.C.Linv + (size_t)j * CT_TILE;
+    for (int e = tid; e < CT_TILE; e += MARG_TILES_THREADS) s_X[(e / CT_TB) * CT_LD + e % CT_TB] = ct_gld(Lj + e);
+    __syncthreads();
+    if (tid < CT_TB) {   // column c of L = X^-1:  L_cc = 1 / X_cc,  L_rc = -(sum_(m = c .. r-1) X_rm L_mc) / X_rr
+      const int c = tid;
+      for (int r = 0; r < CT_TB; ++r) {
+        double v = 0.0;
+        if (r == c) {
+          v = 1.0 / s_X[r * CT_LD + r];
+        } else if (r > c) {
+          double sacc = 0.0;
+          for (int m = c; m < r; ++m) sacc += s_X[r * CT_LD + m] * s_L[m * CT_LD + c];
+          v = -sacc / s_X[r * CT_LD + r];
+        }
+        s_L[r * CT_LD + c] = v;
+      }
+    }
+    __syncthreads();
+    if (tid < CT_TB && CT_TB * j + tid < na) a.out_e0[CT_TB * j + tid] = -ct_gld(T.C.y + CT_TB * j + tid);
+  } else {
+    const double* Lij = T.C.T + (size_t)ct_tile_index(i, j) * CT_TILE;
+    for (int e = tid; e < CT_TILE; e += MARG_TILES_THREADS) s_L[(e / CT_TB) * CT_LD + e % CT_TB] = ct_gld(Lij + e);
+    __syncthreads();
+  }
+  // J[r][c] = L[c][r] p_c for c >= r; this tile supplies rows 48 j + .. and columns 48 i + ..; the strictly lower part of J is zero
+  for (int e = tid; e < CT_TILE; e += MARG_TILES_THREADS) {
+    const int rr = e / CT_TB, cc = e - rr * CT_TB;       // J row 48 j + rr, column 48 i + cc  <-  L[48 i + cc][48 j + rr]
+    const int gr = CT_TB * j + rr, gc = CT_TB * i + cc;
+    if (gr < na && gc < na) a.out_J[(size_t)gr * na + gc] = gc >= gr ? s_L[cc * CT_LD + rr] * T.p2[gc] : 0.0;
+    if (i != j && gr < na && gc < na) a.out_J[(size_t)gc * na + gr] = 0.0;   // the mirrored block, below the diagonal
+  }
+}
+
+// lambda_max bound (max absolute row sum of the pre-scaled matrix) and the decision
+__global__ __launch_bounds__(MARG_THREADS) void marg_tiles_decide_kernel(MargArgs a, MargTiles T) {
+  const int tid = threadIdx.x;
+  const int na = a.out_info[0], nT = T.C.nT;
+  __shared__ double s_red[MARG_THREADS / 64];
+  double rs = 0.0;
+  for (int r = tid; r < na; r += MARG_THREADS) {
+    double v = 0.0;
+    for (int c = 0; c < na; ++c)
+      v += fabs(0.5 * (a.out_H[(size_t)r * na + c] + a.out_H[(size_t)c * na + r]) / (T.p2[r] * T.p2[c]));
+    rs = fmax(rs, v);
+  }
+  rs = wave_max(rs);
+  if ((tid & 63) == 0) s_red[tid >> 6] = rs;
+  __syncthreads();
+  if (tid == 0) {
+    double rowmax = 0.0, f = 0.0;
+    for (int q = 0; q < MARG_THREADS / 64; ++q) rowmax = fmax(rowmax, s_red[q]);
+    for (int j = 0; j < nT; ++j) f += T.fro[j];
+    const int failed = T.C.flag[nT * (nT + 1) / 2];
+    const bool ok = !failed && f > 0.0 && 1.0 / f > 4.0 * 2.220446049250313e-16 * na * rowmax;
+    T.ok[0] = ok ? 1 : 0;
+    if (ok) {
+      a.out_info[2] = na;
+      a.out_info[4] = 0;
+    }
+  }
+}
+
+}  // namespace ba

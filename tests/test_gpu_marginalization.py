@@ -121,6 +121,32 @@ def test_window_beyond_the_lds_solve_path(oracle):
     check(g, r, 1e-8)
 
 
+def test_tiled_tail_equals_the_single_workgroup(monkeypatch):
+    """kept blocks of more than 96 rows: Schur complement, factorisation (matrix core, 48 x 48 tiles), proof of full rank and
+    J, e0 on many workgroups (ba_marg_tiles.hpp) — the same numbers as the single workgroup working in HBM
+    (OKVIS_BA_NO_MARG_TILES), which is the Cholesky factor of the same matrix"""
+    from okvis_amd import solver
+    for K, seed, poses, sbs in ((20, 2, [0, 1], [0, 1]), (12, 5, [0], [0, 1, 2]), (20, 7, [], [0])):
+        w = synthetic.make_window(K, 30, 1.0, seed, frame_dt=0.1)
+        pm, sm = flags(w, poses, sbs)
+        out = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("OKVIS_BA_NO_MARG_TILES", "1")
+            else:
+                monkeypatch.delenv("OKVIS_BA_NO_MARG_TILES", raising=False)
+            b = solver.WindowBatch([w], options=default_options())
+            out.append(b.marginalize(0, pm, sm))
+            b.close()
+        t, o = out
+        assert t["dim"] == o["dim"] > 96 and t["rank"] == o["rank"] == t["dim"]
+        assert np.array_equal(t["H"], o["H"]) and np.array_equal(t["b0"], o["b0"])     # (the same expressions, entry by entry)
+        assert rel(t["J"], o["J"]) < 1e-10 and rel(t["e0"], o["e0"]) < 1e-9
+        assert np.abs(np.tril(t["J"], -1)).max() == 0.0
+        assert rel(t["J"].T @ t["J"], t["H"]) < 1e-12
+    monkeypatch.delenv("OKVIS_BA_NO_MARG_TILES", raising=False)
+
+
 def test_previous_prior_of_more_than_192_rows(oracle):
     """Two stages on a 20-frame window: the first leaves a prior over 291 rows, the second takes it as (H_, b0_) and eliminates a
     pose; the 291-row prior also re-enters an optimisation as the window's marg_* prior (J, e0)."""
