@@ -44,6 +44,7 @@ struct HostWin {  // host copy of what the queries and downloads need
   std::vector<int> pair_lm, pair_block;
   std::vector<int> pose_off, sb_off;  // reduced ordering (host copy)
   int marg_dim = 0;
+  bool h0_on_device = false;   // H0 = J^T J of a large prior is formed by marg_h0_kernel after the upload, not by build_window
   bool group_chunks = false;   // one Schur chunk per linearise group (what the fused linearise + reduce launch needs)
   WinPtrs ptrs;  // device pointers
   int acc = 0;
@@ -245,6 +246,29 @@ struct BuildTimes {
   }
 };
 BuildTimes g_build_times;
+
+constexpr int H0_DEVICE_MIN = 128;   // rows of a marginalisation prior from which H0 = J^T J is formed on the device
+
+// H0 = J^T J of window blockIdx.y's prior, one entry per work-item, the terms of an entry added in row order and without
+// contraction into fused multiply-adds: bit for bit what build_window computes on the host for the small priors
+__global__ __launch_bounds__(256) void marg_h0_kernel(const WinPtrs* __restrict__ wins, int w0) {
+  const WinPtrs& W = wins[w0 + blockIdx.y];
+  const int Dm = W.marg_dim;
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (Dm <= H0_DEVICE_MIN || k >= (size_t)Dm * Dm) return;
+  const int i = (int)(k / Dm), j = (int)(k - (size_t)i * Dm);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;   // (the host fills the upper triangle and mirrors it)
+  const BA_G double* J = W.marg_J;
+  double sacc = 0.0;
+  {
+#pragma clang fp contract(off)   // (the host's index build has no fused multiply-add: product and sum are rounded separately)
+    for (int r = 0; r < Dm; ++r) {
+      const double pr = J[(size_t)r * Dm + lo] * J[(size_t)r * Dm + hi];
+      sacc = sacc + pr;
+    }
+  }
+  const_cast<BA_G double*>(W.marg_H0)[k] = sacc;
+}
 
 // Internal status of build_window(lin2 = true): the window does not fit the piece path of the linearise launch
 // (ba_linearize2.hpp: free extrinsics, or one landmark with more than LIN2_PIECES pieces); the caller rebuilds the batch
@@ -700,9 +724,12 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
         return OKVIS_BA_ERR_ARG;
       if (b > 0 && w.marg_block_off[b] <= w.marg_block_off[b - 1]) return OKVIS_BA_ERR_ARG;
     }
+    // a prior of more than H0_DEVICE_MIN rows: the O(Dm^3) product is left to the device (marg_h0_kernel, launched behind the
+    // upload: the same sums in the same order)
+    H.h0_on_device = Dm > H0_DEVICE_MIN && !std::getenv("OKVIS_BA_H0_ON_HOST");   // (the switch: A/B test of the two)
     // upper triangle as a sum of row outer products: every entry still adds its terms in row order (same value as the
     // column-by-column dot products), but the inner loop runs along a row of J (contiguous: 10 us -> 3 us at 45 rows)
-    for (int r = 0; r < Dm; ++r) {
+    for (int r = 0; r < Dm && !H.h0_on_device; ++r) {
       const double* Jr = w.marg_J + (size_t)r * Dm;
       for (int i = 0; i < Dm; ++i) {
         const double a = Jr[i];
@@ -1530,6 +1557,12 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     HIP_TRY(hipMemcpyAsync(s->d_wins, s->stage_small.data(), wb, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->d_opt, s->stage_small.data() + wb, sizeof(OptD), hipMemcpyHostToDevice, s->stream));
   }
+  for (int i = 0; i < n_windows; ++i)
+    if (wins[i].h0_on_device) {
+      const int Dm = wins[i].marg_dim;
+      hipLaunchKernelGGL(marg_h0_kernel, dim3((unsigned)(((size_t)Dm * Dm + 255) / 256), 1), dim3(256), 0, s->stream, s->d_wins, i);
+      HIP_TRY(hipGetLastError());
+    }
   s->wins.swap(wins);
   // ---- sub-batches: opt.n_streams (0 = auto).  Measured at 64 windows (scripts/sweep_streams.sh, r02): 1 stream 272 k,
   //      2: 300 k, 3: 325 k, 4: 198 k window-iterations/s — the main stream and the sub-streams together must not

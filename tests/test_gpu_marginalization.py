@@ -188,6 +188,41 @@ def test_previous_prior_of_more_than_192_rows(oracle):
     assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-6 * sr["final_cost"]
 
 
+def test_large_prior_product_on_the_device_is_the_hosts(monkeypatch, oracle):
+    """H0 = J^T J of a prior of more than 128 rows is formed by a kernel behind the upload (the same sums in the same order,
+    no fused multiply-add) instead of by the host's index build: the optimisation does not change by a bit"""
+    from okvis_amd import solver
+    w = synthetic.make_window(20, 30, 1.0, 3, frame_dt=0.1)
+    pm1, sm1 = flags(w, [], [0])
+    r1 = oracle.OracleWindow(w).marginalize(pm1, sm1)
+    assert r1["dim"] == 291
+    rng = np.random.default_rng(4)
+    w.marg_J, w.marg_e0 = r1["J"], r1["e0"]
+    w.marg_block_type, w.marg_block_idx, w.marg_block_off = r1["block_type"], r1["block_idx"], r1["block_off"]
+    lin = np.zeros((len(r1["block_type"]), 9))
+    for k, (t, i) in enumerate(zip(r1["block_type"], r1["block_idx"])):
+        if t == 0:
+            lin[k, :7] = synthetic.pose_oplus(w.pose[i], rng.normal(0, 1e-4, 6))
+        else:
+            lin[k] = w.sb[i] + rng.normal(0, 1e-4, 9)
+    w.marg_lin = lin
+    out = []
+    for host in (False, True, False, True):
+        if host:
+            monkeypatch.setenv("OKVIS_BA_H0_ON_HOST", "1")
+        else:
+            monkeypatch.delenv("OKVIS_BA_H0_ON_HOST", raising=False)
+        b = solver.WindowBatch([w], options=default_options())
+        s = b.optimize(5)[0]
+        out.append((s, b.get_state()))
+        b.close()
+    monkeypatch.delenv("OKVIS_BA_H0_ON_HOST", raising=False)
+    assert out[0][0] == out[2][0] and out[1][0] == out[3][0], "the optimisation itself is not repeatable"
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for u, v in zip(out[0][1], out[1][1]):
+        assert np.array_equal(u, v)
+
+
 def test_optimize_after_marginalize_still_works(oracle):
     """okvis_ba_marginalize leaves the solver usable (device options restored)."""
     from okvis_amd import solver
