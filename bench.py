@@ -514,6 +514,29 @@ def main():
                                   "okvis_ba_patch_window replacing the newest frame with its observations and IMU term (container edit + "
                                   "the same index build; the blocks that stay keep the device's values), marginalize = one "
                                   "okvis_ba_marginalize call on a 6-frame sub-window (150 landmarks, one pose and two speed/bias blocks eliminated)"}
+            # the same frame inside okvis_amd::Estimator: the C++ replay of a synthetic ASL recording (80 frames, windows of 8 frames),
+            # once with the window patched between frames (the default) and once flattened + uploaded every frame
+            try:
+                import re, subprocess, tempfile
+                from okvis_amd import recording
+                exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "okvis_amd", "lib", "okvis_amd_replay")
+                with tempfile.TemporaryDirectory() as dsyn:
+                    recording.write_synthetic_recording(dsyn, duration_s=8.0)
+                    rep = {}
+                    for name, extra in (("patch", []), ("flatten_upload", ["--no-patch"])):
+                        out = subprocess.run([exe, dsyn] + extra, capture_output=True, text=True, timeout=120).stdout
+                        m = re.search(r"medians per frame: optimize ([\d.]+) \(window ([\d.]+) \+ hand-over ([\d.]+) \+ iterations ([\d.]+) \+ "
+                                      r"download ([\d.]+)\) \+ marginalise ([\d.]+) ms", out)
+                        if m:
+                            v = [float(x) for x in m.groups()]
+                            rep[name] = {"optimize_ms": v[0], "window_description_ms": v[1], "hand_over_ms": v[2], "iterations_ms": v[3],
+                                         "download_ms": v[4], "marginalise_ms": v[5]}
+                    frame_host["estimator_replay"] = dict(rep, note="medians per frame of okvis_amd_replay (okvis_amd::Estimator, optimize(10) + "
+                                                                   "applyMarginalizationStrategy per frame): window description = the edits since "
+                                                                   "the last frame as one okvis_ba_patch, or a full flatten; hand-over = "
+                                                                   "okvis_ba_patch_window, or okvis_ba_upload")
+            except Exception as e:
+                frame_host["estimator_replay"] = {"error": repr(e)}
         except Exception as e:   # a diagnostic record must never take the bench line with it
             frame_host = {"error": repr(e)}
     if not a.no_extras and not a.pmc_child and world > 1 and a.total_windows == 0:
