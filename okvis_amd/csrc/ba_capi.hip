@@ -2379,6 +2379,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
                o_mtL = A.alloc(8 * (size_t)std::max(1, mt_nT) * CT_TILE), o_mtR = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)),
                o_mtY = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)), o_mtP = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)),
                o_mtF = A.alloc(8 * (size_t)std::max(1, mt_nT)), o_mtp = A.alloc(8 * (size_t)std::max(1, D)),
+               o_mtS = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)),
                o_mtf = A.alloc(sizeof(int) * (size_t)(mt_ntiles + 1 + 2 * mt_nT + 1));
   s->stage_marg.resize(host_part);   // page-locked: the one upload of this call is a true asynchronous copy
   unsigned char* const hb = s->stage_marg.data();
@@ -2480,6 +2481,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
     mt.Z = reinterpret_cast<double*>(d + o_mtZ);
     mt.fro = reinterpret_cast<double*>(d + o_mtF);
     mt.p2 = reinterpret_cast<double*>(d + o_mtP);
+    mt.rowsum = reinterpret_cast<double*>(d + o_mtS);
     mt.ok = mt.C.flag + mt_ntiles + 1 + 2 * mt_nT;
     static const bool attrs = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM_DOUBLES * 8);
@@ -2495,6 +2497,8 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
     hipLaunchKernelGGL(chol_tile_kernel, dim3(mt_ntiles), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8, s->stream, mt.C);
     hipLaunchKernelGGL(marg_tiles_inverse_kernel, dim3(mt_nT), dim3(CT_THREADS), 2 * CT_TB * CT_LD * 8, s->stream, ma, mt);
     hipLaunchKernelGGL(marg_tiles_out_kernel, dim3(mt_ntiles), dim3(MARG_TILES_THREADS), 0, s->stream, ma, mt);
+    hipLaunchKernelGGL(marg_tiles_rowsum_kernel, dim3((na + MARG_TILES_THREADS / 64 - 1) / (MARG_TILES_THREADS / 64)), dim3(MARG_TILES_THREADS), 0,
+                       s->stream, ma, mt);
     hipLaunchKernelGGL(marg_tiles_decide_kernel, dim3(1), dim3(MARG_THREADS), 0, s->stream, ma, mt);
   } else {
     dense(ma, 0);

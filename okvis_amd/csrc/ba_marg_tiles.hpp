@@ -11,6 +11,7 @@
 //   chol_tile_kernel             ba_chol_tiles.hpp: L (fp64 matrix core), the inverses of the diagonal tiles, y = L^-1 rhs
 //   marg_tiles_inverse_kernel    L^-T tile column by tile column (one workgroup each, matrix core): ||L^-1||_F^2
 //   marg_tiles_out_kernel        J = L^T P, e0 = -y
+//   marg_tiles_rowsum_kernel     sum_j |A_ij|, one wave per row
 //   marg_tiles_decide_kernel     the proof of full rank, as in marg_chol_inverse:  1 / ||L^-1||_F^2 > 4 eps n max_i sum_j |A_ij|
 //
 // When the proof fails (a rank-deficient kept block, a non-positive pivot) nothing of this is used: the caller runs the
@@ -28,6 +29,7 @@ struct MargTiles {
   double* Z;            // [ntiles] tiles of L^-T: tile column j of L^-1, transposed, at ct_tile_index(i, j)
   double* fro;          // [nT] ||tile column j of L^-1||_F^2 over the true rows / columns
   double* p2;           // [48 nT] scaling of the kept block
+  double* rowsum;       // [48 nT] sum_j |A_ij| of the pre-scaled matrix
   int* ok;              // [0] 1 = the factor and the proof hold: J, e0 are final
 };
 
@@ -207,18 +209,25 @@ __global__ __launch_bounds__(MARG_TILES_THREADS) void marg_tiles_out_kernel(Marg
   }
 }
 
+// absolute row sums of the pre-scaled matrix, one wave per row (for the lambda_max bound)
+__global__ __launch_bounds__(MARG_TILES_THREADS) void marg_tiles_rowsum_kernel(MargArgs a, MargTiles T) {
+  const int na = a.out_info[0];
+  const int lane = threadIdx.x & 63, r = blockIdx.x * (MARG_TILES_THREADS / 64) + (threadIdx.x >> 6);
+  if (r >= na) return;
+  double v = 0.0;
+  for (int c = lane; c < na; c += 64)
+    v += fabs(0.5 * (a.out_H[(size_t)r * na + c] + a.out_H[(size_t)c * na + r]) / (T.p2[r] * T.p2[c]));
+  v = wave_sum(v);
+  if (lane == 0) T.rowsum[r] = v;
+}
+
 // lambda_max bound (max absolute row sum of the pre-scaled matrix) and the decision
 __global__ __launch_bounds__(MARG_THREADS) void marg_tiles_decide_kernel(MargArgs a, MargTiles T) {
   const int tid = threadIdx.x;
   const int na = a.out_info[0], nT = T.C.nT;
   __shared__ double s_red[MARG_THREADS / 64];
   double rs = 0.0;
-  for (int r = tid; r < na; r += MARG_THREADS) {
-    double v = 0.0;
-    for (int c = 0; c < na; ++c)
-      v += fabs(0.5 * (a.out_H[(size_t)r * na + c] + a.out_H[(size_t)c * na + r]) / (T.p2[r] * T.p2[c]));
-    rs = fmax(rs, v);
-  }
+  for (int r = tid; r < na; r += MARG_THREADS) rs = fmax(rs, T.rowsum[r]);
   rs = wave_max(rs);
   if ((tid & 63) == 0) s_red[tid >> 6] = rs;
   __syncthreads();
