@@ -2488,7 +2488,10 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
       return true;
     }();
     (void)attrs;
-    dense(ma, 1);
+    if (pd > 0)
+      hipLaunchKernelGGL(marg_prior_add_kernel, dim3((unsigned)(((size_t)pd * pd + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS)),
+                         dim3(MARG_TILES_THREADS), 0, s->stream, d_win, ma);
+    dense(ma, 1 | 2);
     const unsigned nb2 = (unsigned)(((size_t)na * na + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS);
     hipLaunchKernelGGL(marg_schur_kernel, dim3(nb2), dim3(MARG_TILES_THREADS), 0, s->stream, d_win, ma);
     hipLaunchKernelGGL(marg_tiles_scale_kernel, dim3((CT_TB * mt_nT + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS), dim3(MARG_TILES_THREADS), 0,

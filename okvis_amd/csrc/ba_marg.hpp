@@ -661,13 +661,15 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
     for (int i = 0; i < na; ++i) a.out_info[8 + i] = s_kidx[i];
   }
   __syncthreads();
-  for (int k = tid; k < a.prior_dim * a.prior_dim; k += MARG_THREADS) {
-    const int rr = k / a.prior_dim, cc = k - rr * a.prior_dim;
-    const int ri = s_ridx[rr], ci = s_ridx[cc];
-    if (ri >= 0 && ci >= 0) H[ri * D + ci] += a.prior_H[k];
+  if (!(stage & 2)) {   // (stage bit 1: marg_prior_add_kernel has done this on many workgroups)
+    for (int k = tid; k < a.prior_dim * a.prior_dim; k += MARG_THREADS) {
+      const int rr = k / a.prior_dim, cc = k - rr * a.prior_dim;
+      const int ri = s_ridx[rr], ci = s_ridx[cc];
+      if (ri >= 0 && ci >= 0) H[ri * D + ci] += a.prior_H[k];
+    }
+    for (int rr = tid; rr < a.prior_dim; rr += MARG_THREADS)
+      if (s_ridx[rr] >= 0) b[s_ridx[rr]] += a.prior_b0[rr];
   }
-  for (int rr = tid; rr < a.prior_dim; rr += MARG_THREADS)
-    if (s_ridx[rr] >= 0) b[s_ridx[rr]] += a.prior_b0[rr];
   __syncthreads();
   const int na = s_na, nm = s_nm;
   MSTAMP(1);
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
       a.out_b0[i] = v;
       s_ba[i] = v;
     }
-    if (stage == 1) {   // the rest on many workgroups (marg_schur_kernel ...): they need the scaling
+    if (stage & 1) {   // the rest on many workgroups (marg_schur_kernel ...): they need the scaling
       for (int i = tid; i < D; i += MARG_THREADS) a.p_out[i] = s_p[i];
       if (tid == 0) a.out_info[3] = sweeps_v;
       return;
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
       a.out_b0[i] = b[s_kidx[i]];
       s_ba[i] = b[s_kidx[i]];
     }
-    if (stage == 1) {
+    if (stage & 1) {
       if (tid == 0) a.out_info[3] = 0;
       return;
     }

@@ -4,8 +4,9 @@
 //   marginalizeOut, dense part      okvis_ceres/src/MarginalizationError.cpp:686-736
 //   updateErrorComputation          okvis_ceres/src/MarginalizationError.cpp:806-846
 //
-//   marg_dense_kernel(stage 1)   one workgroup: previous prior into H, the eliminated block's V^(+1/2) (small: one frame's pose and
-//                                speed/bias), M = W V^(+1/2), b0 — and stops
+//   marg_prior_add_kernel        previous prior into H and b, one entry per work-item
+//   marg_dense_kernel(stage 3)   one workgroup: the eliminated block's V^(+1/2) (small: one frame's pose and speed/bias),
+//                                M = W V^(+1/2), b0 — and stops
 //   marg_schur_kernel            H_a = P (U - M M^T) P, one entry per work-item                       (:736-738)
 //   marg_tiles_fill_kernel       the pre-scaled, symmetrised kept block as 48 x 48 lower tiles (identity padded), rhs = P^-1 b0
 //   chol_tile_kernel             ba_chol_tiles.hpp: L (fp64 matrix core), the inverses of the diagonal tiles, y = L^-1 rhs
@@ -32,6 +33,25 @@ struct MargTiles {
   double* rowsum;       // [48 nT] sum_j |A_ij| of the pre-scaled matrix
   int* ok;              // [0] 1 = the factor and the proof hold: J, e0 are final
 };
+
+// previous prior into the exported system (H_, b0_ of the reference's MarginalizationError): one entry per work-item
+__global__ __launch_bounds__(MARG_TILES_THREADS) void marg_prior_add_kernel(const WinPtrs* __restrict__ wins, MargArgs a) {
+  const WinPtrs& W = wins[0];
+  const int D = W.D, pd = a.prior_dim;
+  const size_t k = (size_t)blockIdx.x * MARG_TILES_THREADS + threadIdx.x;
+  if (k >= (size_t)pd * pd) return;
+  const int rr = (int)(k / pd), cc = (int)(k - (size_t)rr * pd);
+  auto reduced = [&](int row) {   // row of the prior -> index in the reduced system (-1: a fixed block)
+    int bi = 0;
+    for (int q = 0; q < a.prior_nb; ++q)
+      if (a.pb_off[q] <= row) bi = q;
+    const int base = a.pb_type[bi] == 0 ? W.pose_off[a.pb_idx[bi]] : W.sb_off[a.pb_idx[bi]];
+    return base < 0 ? -1 : base + (row - a.pb_off[bi]);
+  };
+  const int ri = reduced(rr), ci = reduced(cc);
+  if (ri >= 0 && ci >= 0) W.S[(size_t)ri * D + ci] += a.prior_H[k];
+  if (cc == 0 && ri >= 0) W.rhs[ri] += a.prior_b0[rr];
+}
 
 // H_a = P_a (U - M M^T) P_a : the expression of marg_dense_kernel, entry by entry
 __global__ __launch_bounds__(MARG_TILES_THREADS) void marg_schur_kernel(const WinPtrs* __restrict__ wins, MargArgs a) {
