@@ -44,6 +44,31 @@ def test_patched_solver_equals_fresh_upload_bitwise(oracle, seed):
     pa.close(); fresh.close()
 
 
+def test_new_landmarks_in_place_equal_a_fresh_upload_bitwise():
+    """add_lm_before (what okvis_amd::Estimator sends: new landmarks take their places by id among the ones that stay): the
+    landmarks that stay keep the device's values at their new indices; the patched solver and a fresh upload of its container
+    iterate bit for bit alike"""
+    A, B = sliding_pair(seed=70, K=6, L=90, n_new_lm=14)
+    A.lm_ids, B.lm_ids = sorted(A.lm_ids), sorted(B.lm_ids)
+    pa = solver.WindowBatch([A.window()], options=default_options(), patchable=True)
+    pa.optimize(4)
+    lm_a = _state(pa)[2]
+    p = patch_between(A, B)
+    assert len(p.add_lm_before) == len(p.add_lm) > 0 and p.add_lm_before[0] < len(B.lm_ids) - len(p.add_lm)
+    pa.patch(0, p)
+    v = pa.patched_view(0)
+    want = B.window()
+    assert windows_differ(v, want) == ["pose", "sb", "lm"]
+    ia = {l: n for n, l in enumerate(A.lm_ids)}
+    for n, l in enumerate(B.lm_ids):
+        assert np.array_equal(v.lm[n], lm_a[ia[l]] if l in ia else want.lm[n])
+    fresh = solver.WindowBatch([v], options=default_options())
+    assert pa.optimize(5)[0] == fresh.optimize(5)[0]
+    for a, b in zip(_state(pa), _state(fresh)):
+        assert np.array_equal(a, b)
+    pa.close(); fresh.close()
+
+
 def test_patch_in_a_batch_and_state_errors():
     A, B = sliding_pair(seed=50, K=5, L=60)
     A2, _ = sliding_pair(seed=51, K=5, L=60)
