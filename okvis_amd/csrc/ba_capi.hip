@@ -2491,7 +2491,18 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
     if (pd > 0)
       hipLaunchKernelGGL(marg_prior_add_kernel, dim3((unsigned)(((size_t)pd * pd + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS)),
                          dim3(MARG_TILES_THREADS), 0, s->stream, d_win, ma);
-    dense(ma, 1 | 2);
+    int nm = 0;   // rows of the eliminated block
+    for (int i = 0; i < H.n_pose; ++i) nm += (H.pose_off[i] >= 0 && spec->pose_marg[i]) ? 6 : 0;
+    for (int i = 0; i < H.n_sb; ++i) nm += (H.sb_off[i] >= 0 && spec->sb_marg[i]) ? 9 : 0;
+    if (nm > 0) {
+      dense(ma, 1 | 2 | 4);
+      hipLaunchKernelGGL(marg_M_kernel, dim3((unsigned)(((size_t)na * nm + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS)), dim3(MARG_TILES_THREADS), 0,
+                         s->stream, d_win, ma);
+      hipLaunchKernelGGL(marg_b0_kernel, dim3((unsigned)((na + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS)), dim3(MARG_TILES_THREADS), 0, s->stream,
+                         d_win, ma);
+    } else {
+      dense(ma, 1 | 2);   // (nothing to eliminate densely: b0 is a gather)
+    }
     const unsigned nb2 = (unsigned)(((size_t)na * na + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS);
     hipLaunchKernelGGL(marg_schur_kernel, dim3(nb2), dim3(MARG_TILES_THREADS), 0, s->stream, d_win, ma);
     hipLaunchKernelGGL(marg_tiles_scale_kernel, dim3((CT_TB * mt_nT + MARG_TILES_THREADS - 1) / MARG_TILES_THREADS), dim3(MARG_TILES_THREADS), 0,

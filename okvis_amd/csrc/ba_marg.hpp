@@ -751,6 +751,15 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_dense_kernel(const WinPtrs*
       __syncthreads();
     }
     MSTAMP(2);
+    if (stage & 4) {   // M, b0 and everything behind them on many workgroups (ba_marg_tiles.hpp): they need V^(+1/2), the scaling, the lists
+      double* Qg = a.work + (size_t)D * D;
+      if (Q != Qg)
+        for (int k = tid; k < nm * nm; k += MARG_THREADS) Qg[k] = Q[k];
+      for (int i = tid; i < D; i += MARG_THREADS) a.p_out[i] = s_p[i];
+      for (int c = tid; c < nm; c += MARG_THREADS) a.out_info[8 + na + c] = s_midx[c];
+      if (tid == 0) a.out_info[3] = sweeps_v;
+      return;
+    }
     for (int k = tid; k < na * nm; k += MARG_THREADS) {  // M = W V^(+1/2) (:729)
       const int i = k / nm, j = k - i * nm;
       const int ki = s_kidx[i];

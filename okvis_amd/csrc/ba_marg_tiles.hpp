@@ -5,8 +5,9 @@
 //   updateErrorComputation          okvis_ceres/src/MarginalizationError.cpp:806-846
 //
 //   marg_prior_add_kernel        previous prior into H and b, one entry per work-item
-//   marg_dense_kernel(stage 3)   one workgroup: the eliminated block's V^(+1/2) (small: one frame's pose and speed/bias),
-//                                M = W V^(+1/2), b0 — and stops
+//   marg_dense_kernel(stage 7)   one workgroup: index lists, the eliminated block's V^(+1/2) (small: one frame's pose and
+//                                speed/bias) — and stops
+//   marg_M_kernel, marg_b0_kernel   M = W V^(+1/2), b0 = P (b_a - M V^(+1/2)^T b_b), one entry per work-item
 //   marg_schur_kernel            H_a = P (U - M M^T) P, one entry per work-item                       (:736-738)
 //   marg_tiles_fill_kernel       the pre-scaled, symmetrised kept block as 48 x 48 lower tiles (identity padded), rhs = P^-1 b0
 //   chol_tile_kernel             ba_chol_tiles.hpp: L (fp64 matrix core), the inverses of the diagonal tiles, y = L^-1 rhs
@@ -51,6 +52,49 @@ __global__ __launch_bounds__(MARG_TILES_THREADS) void marg_prior_add_kernel(cons
   const int ri = reduced(rr), ci = reduced(cc);
   if (ri >= 0 && ci >= 0) W.S[(size_t)ri * D + ci] += a.prior_H[k];
   if (cc == 0 && ri >= 0) W.rhs[ri] += a.prior_b0[rr];
+}
+
+// M = W V^(+1/2)  (:729), one entry per work-item: the expression of marg_dense_kernel (its column gathers from H are what made the
+// single workgroup slow)
+__global__ __launch_bounds__(MARG_TILES_THREADS) void marg_M_kernel(const WinPtrs* __restrict__ wins, MargArgs a) {
+  const WinPtrs& W = wins[0];
+  const int D = W.D, na = a.out_info[0], nm = a.out_info[1];
+  const double* H = W.S;
+  const double* Q = a.work + (size_t)D * D;
+  double* M = a.work + 2 * (size_t)D * D;
+  const int* kidx = a.out_info + 8;
+  const int* midx = a.out_info + 8 + na;
+  const size_t k = (size_t)blockIdx.x * MARG_TILES_THREADS + threadIdx.x;
+  if (k >= (size_t)na * nm) return;
+  const int i = (int)(k / nm), j = (int)(k - (size_t)i * nm);
+  const int ki = kidx[i];
+  double s = 0;
+  for (int c = 0; c < nm; ++c) s += H[(size_t)ki * D + midx[c]] / (a.p_out[ki] * a.p_out[midx[c]]) * Q[(size_t)c * nm + j];
+  M[k] = s;
+}
+
+// b0 = P_a (b_a - M V^(+1/2)^T b_b)  (:732, :739); every workgroup forms V^(+1/2)^T b_b for itself
+__global__ __launch_bounds__(MARG_TILES_THREADS) void marg_b0_kernel(const WinPtrs* __restrict__ wins, MargArgs a) {
+  const WinPtrs& W = wins[0];
+  const int D = W.D, na = a.out_info[0], nm = a.out_info[1];
+  const double* Q = a.work + (size_t)D * D;
+  const double* M = a.work + 2 * (size_t)D * D;
+  const double* b = W.rhs;
+  const int* kidx = a.out_info + 8;
+  const int* midx = a.out_info + 8 + na;
+  __shared__ double s_t[MAX_D];
+  for (int j = threadIdx.x; j < nm; j += MARG_TILES_THREADS) {
+    double s = 0;
+    for (int c = 0; c < nm; ++c) s += Q[(size_t)c * nm + j] * (b[midx[c]] / a.p_out[midx[c]]);
+    s_t[j] = s;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * MARG_TILES_THREADS + threadIdx.x;
+  if (i >= na) return;
+  const int ki = kidx[i];
+  double s = b[ki] / a.p_out[ki];
+  for (int c = 0; c < nm; ++c) s -= M[(size_t)i * nm + c] * s_t[c];
+  a.out_b0[i] = s * a.p_out[ki];
 }
 
 // H_a = P_a (U - M M^T) P_a : the expression of marg_dense_kernel, entry by entry
