@@ -2378,9 +2378,9 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   const size_t o_mtT = A.alloc(8 * (size_t)std::max(1, mt_ntiles) * CT_TILE), o_mtZ = A.alloc(8 * (size_t)std::max(1, mt_ntiles) * CT_TILE),
                o_mtL = A.alloc(8 * (size_t)std::max(1, mt_nT) * CT_TILE), o_mtR = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)),
                o_mtY = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)), o_mtP = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)),
-               o_mtF = A.alloc(8 * (size_t)std::max(1, mt_nT)), o_mtp = A.alloc(8 * (size_t)std::max(1, D)),
+               o_mtF = A.alloc(8 * (size_t)std::max(1, mt_ntiles)), o_mtp = A.alloc(8 * (size_t)std::max(1, D)),
                o_mtS = A.alloc(8 * (size_t)std::max(1, CT_TB * mt_nT)),
-               o_mtf = A.alloc(sizeof(int) * (size_t)(mt_ntiles + 1 + 2 * mt_nT + 1));
+               o_mtf = A.alloc(sizeof(int) * (size_t)(mt_ntiles + 1 + 2 * mt_nT + 1 + mt_ntiles));
   s->stage_marg.resize(host_part);   // page-locked: the one upload of this call is a true asynchronous copy
   unsigned char* const hb = s->stage_marg.data();
   if (H.n_pose) std::memcpy(&hb[o_pm], spec->pose_marg, H.n_pose);
@@ -2483,6 +2483,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
     mt.p2 = reinterpret_cast<double*>(d + o_mtP);
     mt.rowsum = reinterpret_cast<double*>(d + o_mtS);
     mt.ok = mt.C.flag + mt_ntiles + 1 + 2 * mt_nT;
+    mt.zflag = mt.ok + 1;
     static const bool attrs = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM_DOUBLES * 8);
       return true;
@@ -2509,7 +2510,7 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
                        s->stream, ma, mt);
     hipLaunchKernelGGL(marg_tiles_fill_kernel, dim3(mt_ntiles), dim3(MARG_TILES_THREADS), 0, s->stream, ma, mt);
     hipLaunchKernelGGL(chol_tile_kernel, dim3(mt_ntiles), dim3(CT_THREADS), CT_SMEM_DOUBLES * 8, s->stream, mt.C);
-    hipLaunchKernelGGL(marg_tiles_inverse_kernel, dim3(mt_nT), dim3(CT_THREADS), 2 * CT_TB * CT_LD * 8, s->stream, ma, mt);
+    hipLaunchKernelGGL(marg_tiles_inverse_kernel, dim3(mt_ntiles), dim3(CT_THREADS), 2 * CT_TB * CT_LD * 8, s->stream, ma, mt);
     hipLaunchKernelGGL(marg_tiles_out_kernel, dim3(mt_ntiles), dim3(MARG_TILES_THREADS), 0, s->stream, ma, mt);
     hipLaunchKernelGGL(marg_tiles_rowsum_kernel, dim3((na + MARG_TILES_THREADS / 64 - 1) / (MARG_TILES_THREADS / 64)), dim3(MARG_TILES_THREADS), 0,
                        s->stream, ma, mt);

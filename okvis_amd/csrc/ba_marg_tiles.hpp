@@ -11,7 +11,7 @@
 //   marg_schur_kernel            H_a = P (U - M M^T) P, one entry per work-item                       (:736-738)
 //   marg_tiles_fill_kernel       the pre-scaled, symmetrised kept block as 48 x 48 lower tiles (identity padded), rhs = P^-1 b0
 //   chol_tile_kernel             ba_chol_tiles.hpp: L (fp64 matrix core), the inverses of the diagonal tiles, y = L^-1 rhs
-//   marg_tiles_inverse_kernel    L^-T tile column by tile column (one workgroup each, matrix core): ||L^-1||_F^2
+//   marg_tiles_inverse_kernel    L^-T tile by tile (one workgroup each, the task graph of the factorisation, matrix core): ||L^-1||_F^2
 //   marg_tiles_out_kernel        J = L^T P, e0 = -y
 //   marg_tiles_rowsum_kernel     sum_j |A_ij|, one wave per row
 //   marg_tiles_decide_kernel     the proof of full rank, as in marg_chol_inverse:  1 / ||L^-1||_F^2 > 4 eps n max_i sum_j |A_ij|
@@ -28,8 +28,9 @@ constexpr int MARG_TILES_THREADS = 256;
 
 struct MargTiles {
   CholTiles C;          // tiles, diagonal inverses, rhs, y, flags (x = nullptr: no back-substitution)
-  double* Z;            // [ntiles] tiles of L^-T: tile column j of L^-1, transposed, at ct_tile_index(i, j)
-  double* fro;          // [nT] ||tile column j of L^-1||_F^2 over the true rows / columns
+  double* Z;            // [ntiles] tiles of L^-T: tile (i, j) of L^-1, transposed, at ct_tile_index(i, j)
+  int* zflag;           // [ntiles] tile of Z published
+  double* fro;          // [ntiles] sum of the squares of each tile of L^-1 over the true rows / columns
   double* p2;           // [48 nT] scaling of the kept block
   double* rowsum;       // [48 nT] sum_j |A_ij| of the pre-scaled matrix
   int* ok;              // [0] 1 = the factor and the proof hold: J, e0 are final
@@ -152,35 +153,36 @@ __global__ __launch_bounds__(MARG_TILES_THREADS) void marg_tiles_fill_kernel(Mar
   if (blockIdx.x == 0) {
     const int nflag = nT * (nT + 1) / 2 + 1 + 2 * nT;
     for (int e = threadIdx.x; e < nflag; e += MARG_TILES_THREADS) T.C.flag[e] = 0;
+    for (int e = threadIdx.x; e < nT * (nT + 1) / 2; e += MARG_TILES_THREADS) T.zflag[e] = 0;
     if (threadIdx.x == 0) T.ok[0] = 0;
   }
 }
 
-// Tile column j of L^-1 by forward substitution over tiles, kept TRANSPOSED (Z_ji = (L^-1)_ij^T) so that every product is the
-// A B^T form of the factorisation (ct_gemm_nt):
+// L^-1 by forward substitution over tiles, kept TRANSPOSED (Z_ji = (L^-1)_ij^T) so that every product is the A B^T form of the
+// factorisation (ct_gemm_nt):
 //   Z_jj = Linv_j^T,     Z_ji = - (sum_(k = j .. i-1) Z_jk L_ik^T) Linv_i^T        (from  sum_k L_ik X_kj = delta_ij)
-// One workgroup per tile column; the column's tiles go to memory as they are finished and come back through the cache for the
-// sums below them.  fro[j] = sum of the squares over the true part (the identity padding contributes nothing to the bound).
+// One workgroup per tile (i, j), i >= j, in the column-major task order of the factorisation: tile (i, j) adds the products in
+// the order k = j, j + 1, ... as the tiles Z_jk above it are published (flags; every dependency has a smaller task index, so it
+// is resident or finished when a workgroup starts to wait) — the chain of a tile column is one product + one hand-over per tile
+// instead of i - j products (a workgroup per column: 305 us at nT = 15).  fro[task] = the sum of the squares over the true part
+// (the identity padding contributes nothing to the bound).
 __global__ __launch_bounds__(CT_THREADS) void marg_tiles_inverse_kernel(MargArgs a, MargTiles T) {
   extern __shared__ __attribute__((aligned(16))) double mt_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int na = a.out_info[0], nT = T.C.nT, j = blockIdx.x;
+  const int na = a.out_info[0], nT = T.C.nT;
+  int j = 0, rem = blockIdx.x;
+  while (rem >= nT - j) {
+    rem -= nT - j;
+    ++j;
+  }
+  const int i = j + rem;
   double* sA = mt_smem;                      // Z_jk, then the sum
   double* sB = mt_smem + CT_TB * CT_LD;      // L_ik, then Linv_i
   __shared__ double s_part[CT_THREADS / 64];
+  __shared__ int s_ok;
+  int* failflag = T.C.flag + nT * (nT + 1) / 2;
   double fs = 0.0;
-  auto square_sum = [&](const ct_v4 acc[3], int ti) {   // accumulator of Z_(j, ti): rows 48 j + .., columns 48 ti + ..
-    const int col = lane & 15, r0 = lane >> 4;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int gr = CT_TB * j + 16 * wave + r0 + 4 * q, gc = CT_TB * ti + 16 * c + col;
-        if (gr < na && gc < na) fs += acc[c][q] * acc[c][q];
-      }
-  };
-  // Z_jj = Linv_j^T
-  {
+  if (i == j) {   // Z_jj = Linv_j^T
     const double* Lj = T.C.Linv + (size_t)j * CT_TILE;
     double* Zjj = T.Z + (size_t)ct_tile_index(j, j) * CT_TILE;
     for (int e = tid; e < CT_TILE; e += CT_THREADS) {
@@ -189,40 +191,52 @@ __global__ __launch_bounds__(CT_THREADS) void marg_tiles_inverse_kernel(MargArgs
       ct_gst(Zjj + e, v);
       if (CT_TB * j + r < na && CT_TB * j + c < na) fs += v * v;
     }
-    ct_release();
-    __syncthreads();
-  }
-  for (int i = j + 1; i < nT; ++i) {
+  } else {
+    if (tid == 0) s_ok = 1;
     ct_v4 acc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
     for (int k = j; k < i; ++k) {
-      ct_load_tile(T.Z + (size_t)ct_tile_index(k, j) * CT_TILE, sA, tid);      // Z_jk is stored at the place of tile (k, j)
-      ct_load_tile(T.C.T + (size_t)ct_tile_index(i, k) * CT_TILE, sB, tid);    // L_ik
+      ct_load_tile(T.C.T + (size_t)ct_tile_index(i, k) * CT_TILE, sB, tid);    // L_ik: there since the factorisation
+      if (tid == 0 && !ct_wait(T.zflag + ct_tile_index(k, j))) s_ok = 0;        // Z_jk (stored at the place of tile (k, j))
+      __syncthreads();
+      if (!s_ok) break;
+      ct_load_tile(T.Z + (size_t)ct_tile_index(k, j) * CT_TILE, sA, tid);
       __syncthreads();
       if (wave < 3) ct_gemm_nt(acc, sA, sB, wave, lane, 1.0);
       __syncthreads();
     }
-    if (wave < 3) ct_store_acc(acc, sA, CT_LD, wave, lane);
-    ct_load_tile(T.C.Linv + (size_t)i * CT_TILE, sB, tid);
-    __syncthreads();
-    if (wave < 3) {
+    if (s_ok) {
+      if (wave < 3) ct_store_acc(acc, sA, CT_LD, wave, lane);
+      ct_load_tile(T.C.Linv + (size_t)i * CT_TILE, sB, tid);
+      __syncthreads();
+      if (wave < 3) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) acc[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
-      ct_gemm_nt(acc, sA, sB, wave, lane, -1.0);
-      square_sum(acc, i);
-      ct_store_acc_g(acc, T.Z + (size_t)ct_tile_index(i, j) * CT_TILE, wave, lane);
+        for (int c = 0; c < 3; ++c) acc[c] = ct_v4{0.0, 0.0, 0.0, 0.0};
+        ct_gemm_nt(acc, sA, sB, wave, lane, -1.0);
+        const int col = lane & 15, r0 = lane >> 4;   // accumulator of Z_(j, i): rows 48 j + .., columns 48 i + ..
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int gr = CT_TB * j + 16 * wave + r0 + 4 * q, gc = CT_TB * i + 16 * c + col;
+            if (gr < na && gc < na) fs += acc[c][q] * acc[c][q];
+          }
+        ct_store_acc_g(acc, T.Z + (size_t)ct_tile_index(i, j) * CT_TILE, wave, lane);
+      }
+    } else if (tid == 0) {
+      ct_raise(failflag);   // a tile above never came: no proof (the dependants below run out through their own waits)
     }
-    ct_release();
-    __syncthreads();
   }
+  ct_release();
   fs = wave_sum(fs);
   if (lane == 0) s_part[wave] = fs;
   __syncthreads();
   if (tid == 0) {
     double f = 0.0;
     for (int q = 0; q < CT_THREADS / 64; ++q) f += s_part[q];
-    T.fro[j] = f;
+    T.fro[blockIdx.x] = f;
+    ct_raise(T.zflag + ct_tile_index(i, j));
   }
 }
 
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(MARG_THREADS) void marg_tiles_decide_kernel(MargArg
   if (tid == 0) {
     double rowmax = 0.0, f = 0.0;
     for (int q = 0; q < MARG_THREADS / 64; ++q) rowmax = fmax(rowmax, s_red[q]);
-    for (int j = 0; j < nT; ++j) f += T.fro[j];
+    for (int t = 0; t < nT * (nT + 1) / 2; ++t) f += T.fro[t];
     const int failed = T.C.flag[nT * (nT + 1) / 2];
     const bool ok = !failed && f > 0.0 && 1.0 / f > 4.0 * 2.220446049250313e-16 * na * rowmax;
     T.ok[0] = ok ? 1 : 0;
