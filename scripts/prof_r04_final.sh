@@ -17,7 +17,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/graph -o p -- \
 f=$(find $O/graph -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_graph.csv
 t=$(find $O/graph -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python $R/scripts/kernel_trace_by_shape.py $t > $O/kernel_by_shape_graph.csv
 rm -rf $O/graph
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/marg -o p -- python $R/scripts/bench_marginalize.py --config-c > $O/bench_marginalize.json 2> $O/bench_marginalize.err
+timeout 200 python $R/scripts/bench_marginalize.py --config-c > $O/bench_marginalize.json 2> $O/bench_marginalize.err
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/marg -o p -- python $R/scripts/bench_marginalize.py --config-c > $O/bench_marginalize_under_rocprof.json 2>> $O/bench_marginalize.err
 f=$(find $O/marg -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_marginalize.csv
 rm -rf $O/marg
 cd $R
