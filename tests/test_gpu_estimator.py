@@ -192,6 +192,55 @@ def test_failed_marginalization_is_rolled_back():
             assert np.array_equal(a["landmarks"][lid], b["landmarks"][lid])
 
 
+@pytest.mark.parametrize("sigmas", [(0, 0, 0, 0), (0.01, 0.01, 1e-3, 1e-3)])
+def test_patched_windows_iterate_like_flattened_ones(sigmas):
+    """optimize() patches the window the solver holds with the edits since the last call; a second estimator flattens and uploads
+    every frame (setUsePatch(False), the round-3 route).  The two hold the same window landmark for landmark — the blocks that
+    stay carry the device's values, which are the values the other one uploads — so every state of every frame agrees bit for
+    bit.  With relative extrinsics noise every frame has extrinsics blocks and relative-pose terms of its own."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import estimator_scenarios as S
+    made = {}
+
+    def make(patch):
+        def f():
+            e = estimator.Estimator(0)
+            e.setUsePatch(patch)
+            made[patch] = e
+            return e
+        return f
+
+    routes = {}
+    orig = estimator.Estimator.optimize
+
+    def traced(self, *a, **k):
+        r = orig(self, *a, **k)
+        routes.setdefault(id(self), []).append(self.lastOptimizeWasPatch())
+        return r
+
+    estimator.Estimator.optimize = traced
+    try:
+        kw = dict(n_frames=14, num_keyframes=3, num_imu_frames=2, iters=5, seed=23, extrinsics_sigmas=sigmas)
+        a, _ = S.sliding_window(make(True), estimator.Frame, **kw)
+        b, _ = S.sliding_window(make(False), estimator.Frame, **kw)
+    finally:
+        estimator.Estimator.optimize = orig
+    ra, rb = routes[id(made[True])], routes[id(made[False])]
+    assert ra[0] is False and all(ra[1:]) and not any(rb), (ra, rb)
+    assert any(x["removed"] for x in a)
+    for x, y in zip(a, b):
+        assert (x["removed"], x["n_frames"], x["n_landmarks"], x["prior"]) == (y["removed"], y["n_frames"], y["n_landmarks"], y["prior"])
+        assert x["summary"] == y["summary"], (x["summary"], y["summary"])
+        for fid in x["poses"]:
+            assert np.array_equal(x["poses"][fid], y["poses"][fid])
+        for fid in x["sbs"]:
+            assert np.array_equal(x["sbs"][fid], y["sbs"][fid])
+        for lid in x["landmarks"]:
+            assert np.array_equal(x["landmarks"][lid], y["landmarks"][lid])
+
+
 def test_add_states_says_why_it_refuses():
     """okvis::Estimator::addStates logs a reason and returns false (Estimator.cpp:121-163); the drop-in returns false and keeps the
     reason for okvis_est_last_error."""
