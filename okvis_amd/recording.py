@@ -28,8 +28,10 @@ def _yaml_list(v):
 
 def write_synthetic_recording(path, duration_s=10.0, frame_rate_hz=10.0, imu_rate_hz=200.0, n_points=1100, seed=3,
                               detect_prob=0.85, max_keypoints=220, pixel_noise=0.7, keyframe_every=4,
-                              gyro_bias=(0.003, -0.002, 0.001), acc_bias=(0.02, -0.015, 0.01), start_s=0.25):
-    """Returns a dict with the truth (frame times, poses) and counts.  Deterministic in `seed`."""
+                              gyro_bias=(0.003, -0.002, 0.001), acc_bias=(0.02, -0.015, 0.01), start_s=0.25,
+                              ids_by_first_sighting=False):
+    """Returns a dict with the truth (frame times, poses) and counts.  Deterministic in `seed`.  ids_by_first_sighting: landmark ids
+    grow with the time a track starts (what OKVIS' IdProvider does) instead of following the point cloud."""
     rng = np.random.default_rng(seed)
     prm = ImuParams()
     for d in ("imu0", "cam0", "cam1", "state_groundtruth_estimate0", "okvis_amd_tracks"):
@@ -104,6 +106,8 @@ def write_synthetic_recording(path, duration_s=10.0, frame_rate_hz=10.0, imu_rat
             vis[:, k, c] = ok & (rng.uniform(size=n_points) < detect_prob)
             uvs[:, k, c] = uv
     started = np.zeros(n_points, bool)
+    lid_of = 5000 + np.arange(n_points)
+    n_started = 0
     obs_rows, lm_rows = [], []
     n_obs_frame = []
     for k in range(n_frames):
@@ -111,7 +115,10 @@ def write_synthetic_recording(path, duration_s=10.0, frame_rate_hz=10.0, imu_rat
         for l in np.flatnonzero(new):
             p_S = R_frames[k].T @ (pts[l] - poses[k, :3])                   # in the sensor frame of the triangulating frame
             depth = np.linalg.norm(p_S)
-            lm_rows.append((5000 + l, t_frame_ns[k], p_S + p_S / depth * rng.standard_normal() * 0.004 * depth ** 2
+            if ids_by_first_sighting:
+                lid_of[l] = 5000 + n_started
+                n_started += 1
+            lm_rows.append((lid_of[l], t_frame_ns[k], p_S + p_S / depth * rng.standard_normal() * 0.004 * depth ** 2
                             + rng.standard_normal(3) * 0.002 * depth))
         started |= new
         cnt = 0
@@ -121,7 +128,7 @@ def write_synthetic_recording(path, duration_s=10.0, frame_rate_hz=10.0, imu_rat
                 cand = np.sort(rng.choice(cand, max_keypoints, replace=False))
             for l in rng.permutation(cand):                    # any order inside a frame
                 m = (uvs[l, k, c] + rng.standard_normal(2) * pixel_noise).astype(np.float32)
-                obs_rows.append((t_frame_ns[k], c, m[0], m[1], 8.0 if l % 3 else 12.0, 5000 + l))
+                obs_rows.append((t_frame_ns[k], c, m[0], m[1], 8.0 if l % 3 else 12.0, lid_of[l]))
                 cnt += 1
         n_obs_frame.append(cnt)
     with open(os.path.join(path, "okvis_amd_tracks", "frames.csv"), "w") as f:

@@ -5,7 +5,8 @@ import os, sys, subprocess, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from okvis_amd import recording
 d = tempfile.mkdtemp()
-recording.write_synthetic_recording(d, duration_s=8.0)
+# OKVIS_AMD_REPLAY_AGE_IDS=1: landmark ids grow with the time their tracks start (a real run's ids) instead of following the point cloud
+recording.write_synthetic_recording(d, duration_s=8.0, ids_by_first_sighting=bool(os.environ.get("OKVIS_AMD_REPLAY_AGE_IDS")))
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "okvis_amd", "lib", "okvis_amd_replay")
 for extra in ([], ["--no-patch"], [], ["--no-patch"]):
     p = subprocess.run([exe, d] + extra, capture_output=True, text=True)
