@@ -385,6 +385,13 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   BW_T("pairs");
   // ---- groups ----
   std::vector<Group> groups;
+  // OKVIS_BA_GROUP_WORK (sweeps): a group also closes when the block products of its landmark elimination, sum of
+  // pairs (pairs + 1) / 2, reach this number.  Measured (profiles/r04_notes.md): a window that has the device to itself finishes
+  // sooner with more, lighter groups (cap 250: replay 0.833 -> 0.805 ms per frame for the ten iterations, one configs[1] window
+  // 73.1 -> 72.2 us per iteration), with more windows the additional workgroups cost more than they bring (4 windows: 74 -> 78 us per
+  // step, 64: 451 k -> 358 k it/s).  Not the default: the other grouping moves the rounding of every single-window run, and one
+  // of the ill-conditioned DOGLEG cases that sit at the 1e-6 bound (test_dogleg_rejected_steps) lands at 1.25e-6.
+  static const long group_work_cap = [] { const char* e = std::getenv("OKVIS_BA_GROUP_WORK"); return e ? std::atol(e) : 0L; }();
   {
     int l = 0;
     while (l < nlm) {
@@ -393,8 +400,11 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       G.obs_begin = lm_obs_begin[l];
       G.pair_begin = lm_pair_begin[l];
       int no = 0, np = 0, nl = 0, npc = 0;
+      long work = 0;   // block products of the group's landmark elimination: sum of pairs (pairs + 1) / 2
       while (l < nlm) {
         const int lo = lm_obs_begin[l + 1] - lm_obs_begin[l], lp = lm_pair_begin[l + 1] - lm_pair_begin[l];
+        if (group_work_cap > 0 && nl > 0 && work + (long)lp * (lp + 1) / 2 > group_work_cap) break;
+        work += (long)lp * (lp + 1) / 2;
         int lpc = 0;
         if (lin2) {   // piece path: at most LIN2_PIECES pieces per group (a pair has at least one piece)
           lpc = count_pieces(w, lm_obs_begin[l], lm_obs_begin[l + 1], no);
