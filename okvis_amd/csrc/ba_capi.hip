@@ -247,6 +247,7 @@ struct BuildTimes {
 };
 BuildTimes g_build_times;
 
+constexpr int GROUP_LM_DEFAULT = 32;   // landmarks the index build puts into one linearise group (see build_window)
 constexpr int H0_DEVICE_MIN = 128;   // rows of a marginalisation prior from which H0 = J^T J is formed on the device
 
 // H0 = J^T J of window blockIdx.y's prior, one entry per work-item, the terms of an entry added in row order and without
@@ -392,6 +393,14 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   // step, 64: 451 k -> 358 k it/s).  Not the default: the other grouping moves the rounding of every single-window run, and one
   // of the ill-conditioned DOGLEG cases that sit at the 1e-6 bound (test_dogleg_rejected_steps) lands at 1.25e-6.
   static const long group_work_cap = [] { const char* e = std::getenv("OKVIS_BA_GROUP_WORK"); return e ? std::atol(e) : 0L; }();
+  // Landmarks per group: GROUP_LM (64) is what the kernels hold, GROUP_LM_DEFAULT (32) what the index build fills.  A group of 64
+  // short tracks (landmarks that entered the window with the last frame or two: 2 - 4 observations each) is the slowest workgroup
+  // of its launch — the landmark elimination loops over the landmarks of the group — and OKVIS hands its landmark ids out in
+  // increasing order, so a real window has its short tracks side by side at the end.  Measured (tests/gpu_age_order.py, one
+  // 8-frame window, 5520 observations): landmarks in age order 77.3 us per iteration with 64, 71.8 with 40, 69.0 with 28 = what
+  // the same window takes in random order; windows whose groups close at 256 observations first (configs[1]: 12 landmarks per
+  // group) are not touched.  OKVIS_BA_GROUP_LM overrides (sweeps).
+  const int group_lm_cap = [] { const char* e = std::getenv("OKVIS_BA_GROUP_LM"); return std::max(1, std::min(e ? std::atoi(e) : GROUP_LM_DEFAULT, GROUP_LM)); }();   // (read per call: the tests switch it)
   {
     int l = 0;
     while (l < nlm) {
@@ -411,7 +420,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
           if (nl == 0 && lpc > LIN2_PIECES) return BW_LIN2_UNFIT;
           if (nl > 0 && npc + lpc > LIN2_PIECES) break;
         }
-        if (nl > 0 && (no + lo > GROUP_OBS || np + lp > GROUP_PAIRS || nl + 1 > GROUP_LM)) break;
+        if (nl > 0 && (no + lo > GROUP_OBS || np + lp > GROUP_PAIRS || nl + 1 > group_lm_cap)) break;
         no += lo;
         np += lp;
         npc += lpc;

@@ -6,7 +6,8 @@ fallback; configs[1] alone would never run them):
   * more than PRI_STAGE pose priors / speed-bias priors (records not staged in LDS),
   * more IMU factors than the solve kernel prefetches (n_imu * 512 > 6 * 960) on the LDS-resident solve,
   * more than LIN_TASK_CACHE reduction tasks in one linearise group (per-frame extrinsics, many frames),
-  * groups of 64 landmarks / chunks larger than the default 48 landmarks (low visibility).
+  * groups of 64 landmarks (what the kernels hold; the index build fills 32 by default) / chunks larger than the default 48
+    landmarks (low visibility).
 
 Everything is compared with the CPU oracle through the C-ABI, like tests/test_gpu_parity.py."""
 import copy
@@ -90,10 +91,24 @@ def test_many_reduction_tasks_per_group(oracle):
     _compare(oracle, w, 6, tol=1e-8)
 
 
-def test_low_visibility_large_groups_and_custom_chunks(oracle):
+@pytest.mark.parametrize("group_lm", [None, 64])
+def test_low_visibility_large_groups_and_custom_chunks(oracle, monkeypatch, group_lm):
+    """short tracks: the groups close at the landmark limit, not at 256 observations — 32 landmarks by default, 64 (the kernels'
+    capacity, OKVIS_BA_GROUP_LM) on request"""
+    if group_lm:
+        monkeypatch.setenv("OKVIS_BA_GROUP_LM", str(group_lm))
     w = synthetic.make_window(6, 300, 0.3, seed=48)
     for per in (0, 16, 100, 1000):                          # Schur workgroup size: default, small, > 64, clamped
         _compare(oracle, w, 6, schur_lm_per_block=per)
+    b = _batch([w])
+    import ctypes as C
+    from okvis_amd.window import default_options as _do
+    st = (C.c_int64 * 8)()
+    wc, keep = w.as_c()
+    o = _do()
+    assert b._L.okvis_ba_check_window(C.byref(wc), C.byref(o), st) == 0
+    b.close()
+    assert st[3] == (6 if group_lm else 10), (st[3], w.n_lm)      # groups of 300 landmarks / 1504 observations: 6 x <= 64 or 10 x <= 32
 
 
 @pytest.mark.parametrize("K,ext,expect_lds", [(11, "fixed", True), (10, "shared", True), (11, "shared", False)])
