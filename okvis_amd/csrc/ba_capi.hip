@@ -247,7 +247,8 @@ struct BuildTimes {
 };
 BuildTimes g_build_times;
 
-constexpr int GROUP_LM_DEFAULT = 32;   // landmarks the index build puts into one linearise group (see build_window)
+constexpr int GROUP_LM_DEFAULT = 32;   // landmarks the index build puts into one linearise group (see build_window) ...
+constexpr int GROUP_LM_FEW = 16, GROUP_LM_FEW_WINDOWS = 8;   // ... and when at most this many windows share the device
 constexpr int H0_DEVICE_MIN = 128;   // rows of a marginalisation prior from which H0 = J^T J is formed on the device
 
 // H0 = J^T J of window blockIdx.y's prior, one entry per work-item, the terms of an entry added in row order and without
@@ -393,14 +394,19 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   // step, 64: 451 k -> 358 k it/s).  Not the default: the other grouping moves the rounding of every single-window run, and one
   // of the ill-conditioned DOGLEG cases that sit at the 1e-6 bound (test_dogleg_rejected_steps) lands at 1.25e-6.
   static const long group_work_cap = [] { const char* e = std::getenv("OKVIS_BA_GROUP_WORK"); return e ? std::atol(e) : 0L; }();
-  // Landmarks per group: GROUP_LM (64) is what the kernels hold, GROUP_LM_DEFAULT (32) what the index build fills.  A group of 64
-  // short tracks (landmarks that entered the window with the last frame or two: 2 - 4 observations each) is the slowest workgroup
-  // of its launch — the landmark elimination loops over the landmarks of the group — and OKVIS hands its landmark ids out in
-  // increasing order, so a real window has its short tracks side by side at the end.  Measured (tests/gpu_age_order.py, one
-  // 8-frame window, 5520 observations): landmarks in age order 77.3 us per iteration with 64, 71.8 with 40, 69.0 with 28 = what
-  // the same window takes in random order; windows whose groups close at 256 observations first (configs[1]: 12 landmarks per
-  // group) are not touched.  OKVIS_BA_GROUP_LM overrides (sweeps).
-  const int group_lm_cap = [] { const char* e = std::getenv("OKVIS_BA_GROUP_LM"); return std::max(1, std::min(e ? std::atoi(e) : GROUP_LM_DEFAULT, GROUP_LM)); }();   // (read per call: the tests switch it)
+  // Landmarks per group: GROUP_LM (64) is what the kernels hold; the index build fills 32, and 16 when at most GROUP_LM_FEW_WINDOWS
+  // windows share the device.  A group of 64 short tracks (landmarks that entered the window with the last frame or two: 2 - 4
+  // observations each) is the slowest workgroup of its launch — the landmark elimination loops over the landmarks of the group —
+  // and OKVIS hands its landmark ids out in increasing order, so a real window has its short tracks side by side at the end.
+  // Measured (profiles/r04_notes.md; windows whose groups close at 256 observations first — configs[1]: 12 landmarks per group —
+  // are not touched): one 8-frame window in age order 77.3 us per iteration with 64, 69.0 with 32 (= random order); batches of
+  // short-track windows (8 frames, 430 landmarks, 8 observations each), us per step with 64 / 32 / 24 / 16 landmarks per group:
+  // 1 window 68.7 / 68.9 / 65.5 / 64.3, 8: 72.1 / 72.3 / 69.0 / 68.6, 64: 124.8 / 125.5 / 115.1 / 121.1, 256: 302 / 304 / 304 / 331;
+  // the replay's ten iterations per frame 0.830 (ids by first sighting) / 0.817 / 0.785 / 0.783 ms.  OKVIS_BA_GROUP_LM overrides.
+  const int group_lm_cap = [&] {   // (the environment is read per call: the tests switch it)
+    const char* e = std::getenv("OKVIS_BA_GROUP_LM");
+    return std::max(1, std::min(e ? std::atoi(e) : (n_windows_total <= GROUP_LM_FEW_WINDOWS ? GROUP_LM_FEW : GROUP_LM_DEFAULT), GROUP_LM));
+  }();
   {
     int l = 0;
     while (l < nlm) {

@@ -6,7 +6,7 @@ fallback; configs[1] alone would never run them):
   * more than PRI_STAGE pose priors / speed-bias priors (records not staged in LDS),
   * more IMU factors than the solve kernel prefetches (n_imu * 512 > 6 * 960) on the LDS-resident solve,
   * more than LIN_TASK_CACHE reduction tasks in one linearise group (per-frame extrinsics, many frames),
-  * groups of 64 landmarks (what the kernels hold; the index build fills 32 by default) / chunks larger than the default 48
+  * groups of 64 landmarks (what the kernels hold; the index build fills 16 or 32) / chunks larger than the default 48
     landmarks (low visibility).
 
 Everything is compared with the CPU oracle through the C-ABI, like tests/test_gpu_parity.py."""
@@ -91,10 +91,10 @@ def test_many_reduction_tasks_per_group(oracle):
     _compare(oracle, w, 6, tol=1e-8)
 
 
-@pytest.mark.parametrize("group_lm", [None, 64])
+@pytest.mark.parametrize("group_lm", [None, 32, 64])
 def test_low_visibility_large_groups_and_custom_chunks(oracle, monkeypatch, group_lm):
-    """short tracks: the groups close at the landmark limit, not at 256 observations — 32 landmarks by default, 64 (the kernels'
-    capacity, OKVIS_BA_GROUP_LM) on request"""
+    """short tracks: the groups close at the landmark limit, not at 256 observations — 16 landmarks for a solver of few windows,
+    32 for batches, 64 (the kernels' capacity) on request (OKVIS_BA_GROUP_LM)"""
     if group_lm:
         monkeypatch.setenv("OKVIS_BA_GROUP_LM", str(group_lm))
     w = synthetic.make_window(6, 300, 0.3, seed=48)
@@ -108,7 +108,7 @@ def test_low_visibility_large_groups_and_custom_chunks(oracle, monkeypatch, grou
     o = _do()
     assert b._L.okvis_ba_check_window(C.byref(wc), C.byref(o), st) == 0
     b.close()
-    assert st[3] == (6 if group_lm else 10), (st[3], w.n_lm)      # groups of 300 landmarks / 1504 observations: 6 x <= 64 or 10 x <= 32
+    assert st[3] == {None: 19, 32: 10, 64: 6}[group_lm], (st[3], w.n_lm)      # groups of 300 landmarks / 1504 observations
 
 
 @pytest.mark.parametrize("K,ext,expect_lds", [(11, "fixed", True), (10, "shared", True), (11, "shared", False)])
