@@ -370,7 +370,7 @@ uint64_t Estimator::addObservation(uint64_t landmarkId, uint64_t poseId, size_t 
     o.poseBlock = st->poseBlock;
     o.extBlock = st->extBlocks[camIdx];
   }
-  observations_[o.handle] = o;
+  observations_.insert(o);
   lit->second.observations[kid] = o.handle;
   touch(lit->second);
   if (synced_.valid) {
@@ -382,9 +382,9 @@ uint64_t Estimator::addObservation(uint64_t landmarkId, uint64_t poseId, size_t 
 
 // Estimator.cpp:368-413
 bool Estimator::removeObservation(uint64_t handle) {
-  auto it = observations_.find(handle);
-  if (it == observations_.end()) return false;
-  MapPoint& mp = landmarksMap_.at(it->second.landmarkId);
+  const Observation* found = observations_.find(handle);
+  if (!found) return false;
+  MapPoint& mp = landmarksMap_.at(found->landmarkId);
   for (auto oit = mp.observations.begin(); oit != mp.observations.end();) {
     if (oit->second == handle)
       oit = mp.observations.erase(oit);
@@ -392,7 +392,7 @@ bool Estimator::removeObservation(uint64_t handle) {
       ++oit;
   }
   noteObservationRemoved(mp, handle);
-  observations_.erase(it);
+  observations_.erase(handle);
   return true;
 }
 bool Estimator::removeObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx) {
@@ -1216,10 +1216,10 @@ std::string Estimator::debugCheckWindow() {
     if (S.lmObs[wi].size() != b.size()) return num("described observation count of landmark", (long)mp->id, (long)S.lmObs[wi].size());
     for (size_t k = 0; k < S.lmObs[wi].size(); ++k) {
       const int o = vBegin[wi] + (int)k;
-      const auto it = observations_.find(S.lmObs[wi][k].handle);
-      if (it == observations_.end()) return num("described observation gone, landmark", (long)mp->id, (long)k);
-      if (S.poseWin[it->second.poseBlock] != v.obs_pose[o] || (int)it->second.camIdx != v.obs_cam[o] || it->second.u != v.obs_uv[2 * o] ||
-          it->second.v != v.obs_uv[2 * o + 1])
+      const Observation* it = observations_.find(S.lmObs[wi][k].handle);
+      if (!it) return num("described observation gone, landmark", (long)mp->id, (long)k);
+      if (S.poseWin[it->poseBlock] != v.obs_pose[o] || (int)it->camIdx != v.obs_cam[o] || it->u != v.obs_uv[2 * o] ||
+          it->v != v.obs_uv[2 * o + 1])
         return num("described observation order, landmark", (long)mp->id, (long)k);
     }
   }
@@ -1260,15 +1260,17 @@ std::string Estimator::debugCheckWindow() {
 struct Estimator::MargUndo {
   // decisions and deletions of Estimator.cpp:485-725 are interleaved, so they are applied as the reference applies them and
   // logged; the log is replayed backwards if the numerics (upload / okvis_ba_marginalize) throw
+  // (the removed observations have a list of their own — a frame's worth per call, and an Op carries a whole MapPoint; on the way
+  //  back the landmarks return first, then the observations, whose landmarks are all there again by then)
   struct Op {
-    enum Kind { SB_CLEARED, OBSERVATION_REMOVED, LANDMARK_ERASED } kind;
+    enum Kind { SB_CLEARED, LANDMARK_ERASED } kind;
     size_t stateIdx = 0;
     int sbBlock = -1;
-    Observation obs{};
     MapPoint landmark;
     bool initialized = false;
   };
   std::vector<Op> ops;
+  std::vector<Observation> removedObs;
   size_t removedSize = 0;
 };
 
@@ -1293,10 +1295,6 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
       MargUndo::Op& op = undo.ops[k];
       if (op.kind == MargUndo::Op::SB_CLEARED) {
         states_[op.stateIdx].sbBlock = op.sbBlock;
-      } else if (op.kind == MargUndo::Op::OBSERVATION_REMOVED) {
-        observations_[op.obs.handle] = op.obs;
-        landmarksMap_.at(op.obs.landmarkId).observations[KeypointIdentifier{op.obs.poseId, op.obs.camIdx, op.obs.keypointIdx}] =
-            op.obs.handle;
       } else {
         landmarkInitialized_[op.landmark.id] = op.initialized;
         const uint64_t id = op.landmark.id;
@@ -1311,6 +1309,11 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
           node.pendingAdds = 0;
         }
       }
+    }
+    for (size_t k = undo.removedObs.size(); k-- > 0;) {
+      const Observation& o = undo.removedObs[k];
+      observations_.insert(o);
+      landmarksMap_.at(o.landmarkId).observations[KeypointIdentifier{o.poseId, o.camIdx, o.keypointIdx}] = o.handle;
     }
     removedLandmarks.resize(undo.removedSize);
     throw;
@@ -1327,12 +1330,15 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
     op.initialized = it != landmarkInitialized_.end() && it->second;
     undo.ops.push_back(std::move(op));
   };
-  auto removeObservationLogged = [&](uint64_t hnd) {
-    MargUndo::Op op;
-    op.kind = MargUndo::Op::OBSERVATION_REMOVED;
-    op.obs = observations_.at(hnd);
-    undo.ops.push_back(std::move(op));
-    removeObservation(hnd);
+  // (the caller holds the landmark and the observation's key: one look-up in observations_, one erase by key in the landmark's own
+  //  map — removeObservation(handle) would find the landmark in landmarksMap_ and scan its observations for the handle)
+  auto removeObservationLogged = [&](MapPoint& mp, uint64_t hnd, const KeypointIdentifier& kid) {
+    const Observation* it = observations_.find(hnd);
+    if (!it) return;
+    undo.removedObs.push_back(*it);
+    mp.observations.erase(kid);
+    noteObservationRemoved(mp, hnd);
+    observations_.erase(hnd);
   };
   // keep the newest numImuFrames (:439-446)
   if (states_.size() <= numImuFrames) return true;
@@ -1402,7 +1408,10 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
   // observation map, so the loop needs no look-up in observations_)
   struct Residual {
     uint64_t handle, poseId;
+    size_t cam, kp;
   };
+  uint64_t newestRemoved = 0;
+  for (uint64_t id : removeFrames) newestRemoved = std::max(newestRemoved, id);
   std::vector<Residual> residuals;
   for (size_t rf = 0; rf < removeFrames.size(); ++rf) {
     size_t k = 0;
@@ -1426,9 +1435,26 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
         ++pit;  // already scheduled (the reference erased it from landmarksMap_ at that point, :715-719)
         continue;
       }
+      if (selObsSet.empty() && !mp.observations.empty()) {
+        // most landmarks have nothing to do with the frames that leave: their observations are ordered by frame, so the ones of
+        // the removed frames, if any, come first (the same outcome as the full pass below: skipLandmark)
+        bool touchesRemoved = false;
+        for (const auto& ob : mp.observations) {
+          if (ob.first.frameId > newestRemoved) break;
+          if (contains(removeFrames, ob.first.frameId)) {
+            touchesRemoved = true;
+            break;
+          }
+        }
+        if (!touchesRemoved) {
+          ++pit;
+          continue;
+        }
+      }
       residuals.clear();  // reprojection residuals still in the map
       for (const auto& ob : mp.observations)
-        if (selObsSet.empty() || !selObsSet.count(ob.second)) residuals.push_back(Residual{ob.second, ob.first.frameId});
+        if (selObsSet.empty() || !selObsSet.count(ob.second))
+          residuals.push_back(Residual{ob.second, ob.first.frameId, ob.first.cameraIndex, ob.first.keypointIndex});
       bool skipLandmark = true, hasNewObservations = false, justDelete = false, marginalize = true, errorTermAdded = false;
       size_t obsCount = 0;
       for (const Residual& res : residuals) {
@@ -1457,12 +1483,12 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
         const uint64_t poseId = residuals[r].poseId;
         if ((contains(removeFrames, poseId) && hasNewObservations) ||
             (!contains(allLinearizedFrames, poseId) && marginalize)) {
-          removeObservationLogged(hnd);  // ok, let's ignore the observation
+          removeObservationLogged(mp, hnd, KeypointIdentifier{poseId, residuals[r].cam, residuals[r].kp});  // ok, let's ignore the observation
           residuals.erase(residuals.begin() + r);
           r--;
         } else if (marginalize && contains(allLinearizedFrames, poseId)) {
           if (obsCount < 2) {
-            removeObservationLogged(hnd);
+            removeObservationLogged(mp, hnd, KeypointIdentifier{poseId, residuals[r].cam, residuals[r].kp});
             residuals.erase(residuals.begin() + r);
             r--;
           } else {

@@ -12,6 +12,7 @@
 // numeric part of optimize() runs on the CPU.
 #pragma once
 #include <array>
+#include <deque>
 #include <cstdint>
 #include <map>
 #include <ostream>
@@ -211,7 +212,7 @@ class Estimator {
     bool alive = true;
   };
   struct Observation {
-    uint64_t handle, landmarkId, poseId;
+    uint64_t handle = 0, landmarkId = 0, poseId = 0;
     size_t camIdx, keypointIdx;
     double u, v, sqrtw;
     int poseBlock, extBlock;  // T_WS and T_SCi blocks of the observing frame (cached at addObservation)
@@ -382,7 +383,52 @@ class Estimator {
   std::vector<SbBlock> sbBlocks_;
   PointMap landmarksMap_;
   std::map<uint64_t, bool> landmarkInitialized_;
-  std::unordered_map<uint64_t, Observation> observations_;  // by handle
+  // Observations by handle.  Handles are handed out in increasing order and observations leave roughly in that order too (the
+  // oldest frames go first), so the table is a deque indexed by handle - base with dead slots in between: no hashing on the paths
+  // that touch every observation of a frame (addObservation, the marginalisation's removals, flatten).
+  class ObsTable {
+   public:
+    Observation* find(uint64_t h) {
+      if (h < base_ || h - base_ >= slots_.size()) return nullptr;
+      Observation& o = slots_[h - base_];
+      return o.handle == h ? &o : nullptr;
+    }
+    const Observation* find(uint64_t h) const { return const_cast<ObsTable*>(this)->find(h); }
+    const Observation& at(uint64_t h) const {
+      const Observation* o = find(h);
+      if (!o) throw std::out_of_range("observation handle");
+      return *o;
+    }
+    void insert(const Observation& o) {   // (a handle below the range comes back in a roll-back: the range grows downwards)
+      if (slots_.empty()) base_ = o.handle;
+      while (o.handle < base_) {
+        slots_.push_front(Observation{});
+        --base_;
+      }
+      while (o.handle - base_ >= slots_.size()) slots_.push_back(Observation{});
+      Observation& slot = slots_[o.handle - base_];
+      if (slot.handle != o.handle) ++live_;
+      slot = o;
+    }
+    bool erase(uint64_t h) {
+      Observation* o = find(h);
+      if (!o) return false;
+      o->handle = 0;   // (handles start at 1)
+      --live_;
+      while (!slots_.empty() && slots_.front().handle == 0) {
+        slots_.pop_front();
+        ++base_;
+      }
+      return true;
+    }
+    size_t size() const { return live_; }
+
+   private:
+    std::deque<Observation> slots_;
+    uint64_t base_ = 1;
+    size_t live_ = 0;
+  };
+  ObsTable observations_;
   std::vector<ImuFactor> imuFactors_;
   std::vector<PosePrior> posePriors_;
   std::vector<SbPrior> sbPriors_;

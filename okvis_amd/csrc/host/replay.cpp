@@ -413,6 +413,10 @@ ReplayResult replay(const Recording& rec, const ReplayOptions& opt, Estimator& e
     r.msOptimize = ms(a, b);
     r.msMarginalize = ms(b, c);
     r.msFlatten = optT[0], r.msUpload = optT[1], r.msIterations = optT[2], r.msDownload = optT[3];
+    {
+      const std::array<double, 6>& mi = est.lastMarginalizationInfo();
+      r.msMargFlatten = mi[0], r.msMargUpload = mi[1], r.msMargCall = mi[2];
+    }
     out.frames.push_back(r);
   }
 

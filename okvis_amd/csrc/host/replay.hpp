@@ -91,6 +91,7 @@ struct ReplayFrameResult {
   int observations, landmarksInWindow, framesInWindow, iterations;
   double initialCost, finalCost, msOptimize, msMarginalize;
   double msFlatten, msUpload, msIterations, msDownload;   // split of msOptimize (Estimator::lastOptimizeTimings)
+  double msMargFlatten = 0, msMargUpload = 0, msMargCall = 0;   // part of msMarginalize (Estimator::lastMarginalizationInfo)
 };
 struct ReplayResult {
   std::vector<ReplayFrameResult> frames;

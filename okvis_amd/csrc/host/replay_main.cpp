@@ -79,6 +79,19 @@ int main(int argc, char** argv) {
                   median([](const okvis_amd::ReplayFrameResult& f) { return f.msDownload; }),
                   median([](const okvis_amd::ReplayFrameResult& f) { return f.msMarginalize; }));
     }
+    {
+      auto median = [&](auto get) {
+        std::vector<double> v;
+        for (const okvis_amd::ReplayFrameResult& f : r.frames) v.push_back(get(f));
+        if (v.empty()) return 0.0;
+        std::sort(v.begin(), v.end());
+        return v[v.size() / 2];
+      };
+      std::printf("marginalise, medians per frame: sub-window flatten %.3f + upload %.3f + okvis_ba_marginalize %.3f ms (the rest: the decisions and deletions of applyMarginalizationStrategy)\n",
+                  median([](const okvis_amd::ReplayFrameResult& f) { return f.msMargFlatten; }),
+                  median([](const okvis_amd::ReplayFrameResult& f) { return f.msMargUpload; }),
+                  median([](const okvis_amd::ReplayFrameResult& f) { return f.msMargCall; }));
+    }
     if (r.hasGroundTruth)
       std::printf("against the ground truth (first pose aligned): rms position %.4f m, final position %.4f m, final rotation %.5f rad\n",
                   r.rmsPosition, r.finalPosition, r.finalRotation);

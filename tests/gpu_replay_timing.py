@@ -10,5 +10,5 @@ recording.write_synthetic_recording(d, duration_s=8.0, ids_by_first_sighting=boo
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "okvis_amd", "lib", "okvis_amd_replay")
 for extra in ([], ["--no-patch"], [], ["--no-patch"]):
     p = subprocess.run([exe, d] + extra, capture_output=True, text=True)
-    print("\n".join(p.stdout.splitlines()[-9:]))
+    print("\n".join(p.stdout.splitlines()[-10:]))
     print("\n".join(l for l in p.stderr.splitlines() if "build_window" in l).replace("  ", "\n    "))
