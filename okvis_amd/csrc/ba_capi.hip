@@ -214,9 +214,15 @@ size_t put(Arena& A, const std::vector<T>& v) {
   return off;
 }
 size_t put_zero(Arena& A, size_t bytes) { return A.zalloc(std::max<size_t>(bytes, 8)); }
+// a caller's array straight into the arena (n elements; a null pointer or n = 0 leaves one zeroed element, like an empty vector)
 template <class T>
-std::vector<T> vec(const T* p, size_t n) {
-  return (p && n) ? std::vector<T>(p, p + n) : std::vector<T>();
+size_t put_n(Arena& A, const T* p, size_t n) {
+  if (!p) n = 0;
+  size_t off = A.alloc(std::max<size_t>(n, 1) * sizeof(T));
+  if (A.host.size() < A.size) A.host.resize(A.size + A.size / 2, 0);
+  if (n) std::memcpy(A.host.data() + off, p, n * sizeof(T));
+  else std::memset(A.host.data() + off, 0, sizeof(T));
+  return off;
 }
 
 #define OFF(field, off) P.field = reinterpret_cast<std::remove_reference<decltype(P.field)>::type>(off)
@@ -272,6 +278,21 @@ __global__ __launch_bounds__(256) void marg_h0_kernel(const WinPtrs* __restrict_
   const_cast<BA_G double*>(W.marg_H0)[k] = sacc;
 }
 
+// Work vectors of build_window, one set per host thread, kept between calls (capacity only: every call assigns what it reads)
+struct BuildScratch {
+  std::vector<int> pose_off, sb_off, role, lm_obs_begin, pair_lm, pair_block, pair_off, pair_role, lm_pair_begin, blocks, seen;
+  std::vector<int> chunk_diag_begin, chunk_diag_out, chunk_cross_begin, chunk_cross, chunk_desc, blk_cursor;
+  std::vector<int> pair_list_begin, blk_slot, touched, lm_piece_begin, pair_piece, blk_cnt;
+  std::vector<uint16_t> pair_list, task_list;
+  std::vector<Group> groups;
+  std::vector<Task> tasks;
+  std::vector<Chunk> chunks;
+};
+BuildScratch& build_scratch() {
+  static thread_local BuildScratch S;
+  return S;
+}
+
 // Internal status of build_window(lin2 = true): the window does not fit the piece path of the linearise launch
 // (ba_linearize2.hpp: free extrinsics, or one landmark with more than LIN2_PIECES pieces); the caller rebuilds the batch
 // for ba_linearize.hpp.
@@ -309,11 +330,13 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
                   !w.cam_model))
     return OKVIS_BA_ERR_ARG;
   if (w.n_pose > 65535 || w.n_lm >= (1 << 24) || w.n_cam > 255) return OKVIS_BA_ERR_UNSUPPORTED;
-  WinPtrs& P = H.ptrs;
-  std::memset(&P, 0, sizeof(P));
   const int npose = w.n_pose, nsb = w.n_sb, nlm = w.n_lm, nobs = w.n_obs;
+  // (the index lists live in one set of vectors per host thread: a frame's upload allocates nothing once they have grown)
+  BuildScratch& S = build_scratch();
   // ---- reduced ordering: free pose blocks (6 each) then free speed/bias blocks (9 each) ----
-  std::vector<int> pose_off(npose, -1), sb_off(nsb, -1);
+  std::vector<int>&pose_off = S.pose_off, &sb_off = S.sb_off;
+  pose_off.assign(npose, -1);
+  sb_off.assign(nsb, -1);
   int off = 0;
   for (int i = 0; i < npose; ++i)
     if (!w.pose_fixed[i]) {
@@ -328,65 +351,118 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     }
   const int D = off;
   if (D > MAX_D || D == 0) return OKVIS_BA_ERR_UNSUPPORTED;
-  // ---- validate observations, roles ----
-  std::vector<int> role(npose, -1);  // 0 pose role, 1 extrinsics role
-  std::vector<int> lm_obs_begin(nlm + 1, 0);
+  // ---- one pass over the observations, landmark by landmark: validation, roles, observation records and the
+  //      (landmark, free block) pairs ----
+  std::vector<int>&role = S.role, &lm_obs_begin = S.lm_obs_begin;   // role: 0 pose role, 1 extrinsics role
+  role.assign(npose, -1);
+  lm_obs_begin.resize((size_t)nlm + 1);
+  // The arena's first arrays have sizes known by now, so the observation records are written where they stay (the arena is not
+  // touched again before the pass below ends; a failed or unfit window's bytes are discarded by the caller).
+  WinPtrs& P = H.ptrs;
+  std::memset(&P, 0, sizeof(P));
+  for (int b = 0; b < 2; ++b) {
+    OFF(pose[b], put_n(A, w.pose, 7 * (size_t)npose));
+    OFF(sb[b], put_n(A, w.sb, 9 * (size_t)nsb));
+    OFF(lm[b], put_n(A, w.lm, 4 * (size_t)nlm));
+  }
+  OFF(pose_off, put(A, pose_off));
+  OFF(sb_off, put(A, sb_off));
+  OFF(cam_intr, put_n(A, w.cam_intr, 12 * (size_t)w.n_cam));
+  OFF(cam_model, put_n(A, w.cam_model, (size_t)w.n_cam));
+  const size_t recs_off = put_n(A, (const ObsRec*)nullptr, 0);   // (an empty array's single zeroed element ...)
+  if (nobs > 1) {                                                // (... grown to n_obs records)
+    A.size = recs_off + (size_t)nobs * sizeof(ObsRec);
+    if (A.host.size() < A.size) A.host.resize(A.size + A.size / 2, 0);
+  }
+  OFF(obs, recs_off);
+  ObsRec* const recs = reinterpret_cast<ObsRec*>(A.host.data() + recs_off);
+  std::vector<int>&pair_lm = S.pair_lm, &pair_block = S.pair_block, &pair_off = S.pair_off, &pair_role = S.pair_role, &lm_pair_begin = S.lm_pair_begin;
+  int npair_run = 0;   // (the pair vectors are work space of at least 2 n_obs entries: the first npair_run are this window's)
+  lm_pair_begin.resize((size_t)nlm + 1);
   bool has_ext = false;
-  for (int o = 0; o < nobs; ++o) {
-    const int l = w.obs_lm[o], ip = w.obs_pose[o], ie = w.obs_ext[o], c = w.obs_cam[o];
-    if (l < 0 || l >= nlm || ip < 0 || ip >= npose || ie < 0 || ie >= npose || c < 0 || c >= w.n_cam) return OKVIS_BA_ERR_ARG;
-    if (o > 0) {
-      const int pl = w.obs_lm[o - 1], pp = w.obs_pose[o - 1], pc = w.obs_cam[o - 1];
-      // sorted by (landmark, pose, cam); REPEATED (landmark, pose, cam) entries are legal: the reference adds one residual
-      // block per matched keypoint (implementation/Estimator.hpp:52-56 only rejects an identical KeypointIdentifier)
-      if (pl > l || (pl == l && (pp > ip || (pp == ip && pc > c)))) return OKVIS_BA_ERR_ARG;  // unsorted
-    }
-    if (role[ip] == 1 || role[ie] == 0 || ip == ie) return OKVIS_BA_ERR_UNSUPPORTED;
-    role[ip] = 0;
-    role[ie] = 1;
-    if (pose_off[ie] >= 0) has_ext = true;
-    lm_obs_begin[l + 1]++;
-  }
-  for (int l = 0; l < nlm; ++l) {
-    if (lm_obs_begin[l + 1] > GROUP_OBS) return OKVIS_BA_ERR_UNSUPPORTED;
-    lm_obs_begin[l + 1] += lm_obs_begin[l];
-  }
-  if (lin2 && has_ext) return BW_LIN2_UNFIT;
-  BW_T("validate");
-  // ---- (landmark, free block) pairs ----
-  std::vector<int> pair_lm, pair_block, pair_off, pair_role, lm_pair_begin(nlm + 1, 0);
   {
-    // (one scratch list and a "seen for this landmark" stamp per block instead of a fresh vector + std::find per landmark:
-    // this loop runs once per frame in the host class)
     const size_t guess = 2 * (size_t)nobs;
-    pair_lm.reserve(guess), pair_block.reserve(guess), pair_off.reserve(guess), pair_role.reserve(guess);
-    std::vector<int> blocks, seen(npose, -1);
+    if (pair_lm.size() < guess) pair_lm.resize(guess), pair_block.resize(guess), pair_off.resize(guess), pair_role.resize(guess);
+    int *const pl = pair_lm.data(), *const pb = pair_block.data(), *const po = pair_off.data(), *const pr = pair_role.data();
+    std::vector<int>&blocks = S.blocks, &seen = S.seen;   // a "seen for this landmark" stamp per block
+    seen.assign(npose, -1);
+    if ((int)blocks.size() < npose + 2) blocks.resize((size_t)npose + 2);   // (a landmark's blocks are distinct; one slot for the store below)
+    int* const bl = blocks.data();
+    // what the separate passes of the earlier versions reported after the whole observation list had been checked
+    bool obs_over = false, pairs_over = false;
+    const unsigned unpose = (unsigned)npose, uncam = (unsigned)w.n_cam;
+    int o = 0;
     for (int l = 0; l < nlm; ++l) {
-      blocks.clear();
-      for (int o = lm_obs_begin[l]; o < lm_obs_begin[l + 1]; ++o) {
-        const int cand[2] = {w.obs_pose[o], w.obs_ext[o]};
-        for (int c = 0; c < 2; ++c)
-          if (pose_off[cand[c]] >= 0 && seen[cand[c]] != l) {
-            seen[cand[c]] = l;
-            blocks.push_back(cand[c]);
+      const int o0 = o;
+      lm_obs_begin[l] = o0;
+      int nb = 0, last = -1;         // blocks of this landmark so far, the last one taken
+      bool ascending = true;
+      int prev_ip = -1, prev_c = -1;
+      // (the tests that depend on the data — same pose as the observation before? a block not seen yet? — are arithmetic, not
+      // branches: they fail to predict about once per observation)
+      for (; o < nobs && w.obs_lm[o] == l; ++o) {
+        const int ip = w.obs_pose[o], ie = w.obs_ext[o], c = w.obs_cam[o];
+        if (((unsigned)ip >= unpose) | ((unsigned)ie >= unpose) | ((unsigned)c >= uncam)) return OKVIS_BA_ERR_ARG;
+        // sorted by (landmark, pose, cam); REPEATED (landmark, pose, cam) entries are legal: the reference adds one residual
+        // block per matched keypoint (implementation/Estimator.hpp:52-56 only rejects an identical KeypointIdentifier)
+        if ((prev_ip > ip) | ((prev_ip == ip) & (prev_c > c))) return OKVIS_BA_ERR_ARG;  // unsorted
+        if ((role[ip] == 1) | (role[ie] == 0) | (ip == ie)) return OKVIS_BA_ERR_UNSUPPORTED;
+        role[ip] = 0;
+        role[ie] = 1;
+        ObsRec& R = recs[o];
+        R.lm_cam = (uint32_t)l | ((uint32_t)c << 24);
+        R.pose = (uint16_t)ip;
+        R.ext = (uint16_t)ie;
+        R.u = w.obs_uv[2 * o];
+        R.v = w.obs_uv[2 * o + 1];
+        R.sw = w.obs_sqrtw[o];
+        // a landmark's observations are sorted by pose and no block has both roles: a pose-role block is new exactly when the
+        // pose index changes; an extrinsics block needs the stamp
+        const int newp = (int)(ip != prev_ip) & (int)(pose_off[ip] >= 0);
+        ascending &= !(newp & (int)(ip < last));
+        bl[nb] = ip;
+        nb += newp;
+        last = newp ? ip : last;
+        prev_ip = ip;
+        prev_c = c;
+        if (pose_off[ie] >= 0) {
+          has_ext = true;
+          if (seen[ie] != l) {
+            seen[ie] = l;
+            if (ie < last) ascending = false;
+            bl[nb++] = ie;
+            last = ie;
           }
+        }
       }
-      std::sort(blocks.begin(), blocks.end());
-      lm_pair_begin[l] = (int)pair_lm.size();
-      for (int b : blocks) {
-        pair_lm.push_back(l);
-        pair_block.push_back(b);
-        pair_off.push_back(pose_off[b]);
-        pair_role.push_back(role[b]);
+      if (o - o0 > GROUP_OBS) obs_over = true;
+      if (!ascending) std::sort(bl, bl + nb);   // (only extrinsics blocks can come out of order)
+      lm_pair_begin[l] = npair_run;
+      for (int k = 0; k < nb; ++k) {
+        const int b = bl[k];
+        pl[npair_run] = l;
+        pb[npair_run] = b;
+        po[npair_run] = pose_off[b];
+        pr[npair_run] = role[b];
+        ++npair_run;
       }
-      if ((int)blocks.size() > GROUP_PAIRS) return OKVIS_BA_ERR_UNSUPPORTED;
+      // (the earlier version stopped at the first landmark with too many blocks; an unsorted or out-of-range observation
+      // further on still comes first, see below)
+      if (nb > GROUP_PAIRS) pairs_over = true;
     }
+    lm_obs_begin[nlm] = o;
+    // an observation the walk did not consume names a landmark out of range or before its predecessor's
+    if (o < nobs) return OKVIS_BA_ERR_ARG;
+    if (obs_over) return OKVIS_BA_ERR_UNSUPPORTED;
+    if (lin2 && has_ext) return BW_LIN2_UNFIT;
+    if (pairs_over) return OKVIS_BA_ERR_UNSUPPORTED;
   }
-  lm_pair_begin[nlm] = (int)pair_lm.size();
-  const int npair = (int)pair_lm.size();
-  BW_T("pairs");
+  lm_pair_begin[nlm] = npair_run;
+  const int npair = npair_run;
+  BW_T("observations + pairs");
   // ---- groups ----
-  std::vector<Group> groups;
+  std::vector<Group>& groups = S.groups;
+  groups.clear();
   // OKVIS_BA_GROUP_WORK (sweeps): a group also closes when the block products of its landmark elimination, sum of
   // pairs (pairs + 1) / 2, reach this number.  Measured (profiles/r04_notes.md): a window that has the device to itself finishes
   // sooner with more, lighter groups (cap 250: replay 0.833 -> 0.805 ms per frame for the ten iterations, one configs[1] window
@@ -407,26 +483,62 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     const char* e = std::getenv("OKVIS_BA_GROUP_LM");
     return std::max(1, std::min(e ? std::atoi(e) : (n_windows_total <= GROUP_LM_FEW_WINDOWS ? GROUP_LM_FEW : GROUP_LM_DEFAULT), GROUP_LM));
   }();
+  // piece path (ba_linearize2.hpp): pieces instead of per-observation lists.  A piece = one or two adjacent observations of the same
+  // pose inside one row of 16 lanes, greedy from the start of the run (the rule of linearize2_kernel's phase B).  The pieces of a
+  // landmark depend on the lane its first observation takes, i.e. on the group it joins, so they are laid out while the groups
+  // are formed: lm_piece_begin[l] = the landmark's first piece in the window, pair_piece[p] = the pair's first piece in its group
+  // | its number of pieces << 16, per group the pieces before waves 1..3.
+  std::vector<int>&lm_piece_begin = S.lm_piece_begin, &pair_piece = S.pair_piece;
+  if (lin2) {
+    lm_piece_begin.resize((size_t)nlm + 1);
+    pair_piece.resize((size_t)npair + 1);   // (one more: where the pieces of fixed poses count)
+  }
   {
     int l = 0;
+    int piece_total = 0;
+    int* const ppc = pair_piece.data();
     while (l < nlm) {
       Group G;
       G.lm_begin = l;
       G.obs_begin = lm_obs_begin[l];
       G.pair_begin = lm_pair_begin[l];
       int no = 0, np = 0, nl = 0, npc = 0;
+      int wave_count[4] = {0, 0, 0, 0};
       long work = 0;   // block products of the group's landmark elimination: sum of pairs (pairs + 1) / 2
       while (l < nlm) {
-        const int lo = lm_obs_begin[l + 1] - lm_obs_begin[l], lp = lm_pair_begin[l + 1] - lm_pair_begin[l];
+        const int o0 = lm_obs_begin[l], o1 = lm_obs_begin[l + 1], p0 = lm_pair_begin[l], p1 = lm_pair_begin[l + 1];
+        const int lo = o1 - o0, lp = p1 - p0;
         if (group_work_cap > 0 && nl > 0 && work + (long)lp * (lp + 1) / 2 > group_work_cap) break;
-        work += (long)lp * (lp + 1) / 2;
-        int lpc = 0;
-        if (lin2) {   // piece path: at most LIN2_PIECES pieces per group (a pair has at least one piece)
-          lpc = count_pieces(w, lm_obs_begin[l], lm_obs_begin[l + 1], no);
-          if (nl == 0 && lpc > LIN2_PIECES) return BW_LIN2_UNFIT;
-          if (nl > 0 && npc + lpc > LIN2_PIECES) break;
-        }
         if (nl > 0 && (no + lo > GROUP_OBS || np + lp > GROUP_PAIRS || nl + 1 > group_lm_cap)) break;
+        int lpc = 0;
+        int wc[4] = {0, 0, 0, 0};
+        if (lin2) {   // piece path: at most LIN2_PIECES pieces per group (a pair has at least one piece)
+          // One walk over the landmark's observations; the tests that depend on the data are arithmetic.  An observation opens a
+          // piece when it opens a run (new pose, or first lane of a row) or sits at an even place of its run.
+          for (int p = p0; p < p1; ++p) ppc[p] = 0;
+          int pnext = p0, cur = npair, prev = -1, par = 0, local = npc;
+          for (int o = o0; o < o1; ++o) {
+            const int lane = no + (o - o0), pose = w.obs_pose[o];
+            const int changed = pose != prev, freeb = pose_off[pose] >= 0;
+            cur = changed ? (freeb ? pnext : npair) : cur;   // (the pairs of a landmark are its free poses in this order)
+            pnext += changed & freeb;
+            const int start = changed | (int)((lane & 15) == 0);
+            par = start ? 0 : par ^ 1;
+            const int newp = par == 0;
+            int v = ppc[cur];
+            v = (newp & (int)((v >> 16) == 0)) ? local : v;
+            ppc[cur] = v + (newp << 16);
+            wc[lane >> 6] += newp;
+            local += newp;
+            prev = pose;
+          }
+          lpc = local - npc;
+          if (nl == 0 && lpc > LIN2_PIECES) return BW_LIN2_UNFIT;
+          if (nl > 0 && npc + lpc > LIN2_PIECES) break;   // (the landmark opens the next group and is laid out again from lane 0)
+          lm_piece_begin[l] = piece_total + npc;
+          for (int k = 0; k < 4; ++k) wave_count[k] += wc[k];
+        }
+        work += (long)lp * (lp + 1) / 2;
         no += lo;
         np += lp;
         npc += lpc;
@@ -438,76 +550,49 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       G.pair_end = lm_pair_begin[l];
       G.task_begin = G.task_end = 0;
       G.plist_begin = G.plist_end = G.tlist_begin = G.tlist_end = 0;
-      G.piece_begin = G.pw1 = G.pw2 = G.pw3 = 0;
+      G.piece_begin = piece_total;
+      G.pw1 = wave_count[0];
+      G.pw2 = wave_count[0] + wave_count[1];
+      G.pw3 = wave_count[0] + wave_count[1] + wave_count[2];
+      if (!lin2) G.piece_begin = 0;
+      piece_total += npc;
       groups.push_back(G);
     }
+    if (lin2) lm_piece_begin[nlm] = piece_total;
   }
   const int ngroup = (int)groups.size();
   BW_T("groups");
   // ---- per-pair observation lists, per-group tasks ----
-  std::vector<int> pair_list_begin(npair + 1, 0);
-  std::vector<uint16_t> pair_list;
-  std::vector<Task> tasks;
-  std::vector<uint16_t> task_list;
+  std::vector<int>& pair_list_begin = S.pair_list_begin;
+  pair_list_begin.assign((size_t)npair + 1, 0);
+  std::vector<uint16_t>&pair_list = S.pair_list, &task_list = S.task_list;
+  std::vector<Task>& tasks = S.tasks;
+  pair_list.clear(), task_list.clear(), tasks.clear();
   int gpart_size = 0;
   pair_list.reserve(2 * (size_t)nobs);
   task_list.reserve(3 * (size_t)nobs);
-  std::vector<int> blk_slot(npose, -1);                 // scratch: block -> pair of the current landmark / task of the group
+  std::vector<int>& blk_slot = S.blk_slot;              // scratch: block -> pair of the current landmark / task of the group
+  blk_slot.assign(npose, -1);
   // scratch: block -> observations of the current group (own role).  Kept between calls (every list is left empty): the lists
   // grow to a few hundred entries each, once, instead of through ten reallocations per block in every upload
   static thread_local std::vector<std::vector<uint16_t>> blk_obs;
   if ((int)blk_obs.size() < npose) blk_obs.resize(npose);
   for (auto& v : blk_obs) v.clear();   // (whatever an interrupted call may have left)
-  std::vector<int> touched;
+  std::vector<int>& touched = S.touched;
+  touched.clear();
   // piece path (ba_linearize2.hpp): pieces instead of per-observation lists
-  std::vector<int> lm_piece_begin, pair_piece;
   if (lin2) {
-    lm_piece_begin.assign(nlm + 1, 0);
-    pair_piece.assign(npair, 0);
-    static thread_local std::vector<std::vector<uint16_t>> blk_pairs;
-    if ((int)blk_pairs.size() < npose) blk_pairs.resize(npose);
-    for (auto& v : blk_pairs) v.clear();
-    int piece_total = 0;
+    std::vector<int>& blk_cnt = S.blk_cnt;   // pairs of the current group per block, then the next slot of the block
+    blk_cnt.assign(npose, 0);
     for (int g = 0; g < ngroup; ++g) {
       Group& G = groups[g];
-      G.piece_begin = piece_total;
       G.tlist_begin = (int)task_list.size();
-      int wave_count[4] = {0, 0, 0, 0};
-      int local = 0;   // pieces of this group so far
-      for (int l = G.lm_begin; l < G.lm_end; ++l) {
-        lm_piece_begin[l] = piece_total + local;
-        int p = lm_pair_begin[l];   // pairs of a landmark are sorted by block, observations by pose: one forward walk
-        const int p1 = lm_pair_begin[l + 1];
-        int o = lm_obs_begin[l];
-        const int o1 = lm_obs_begin[l + 1];
-        while (o < o1) {
-          const int lane0 = o - G.obs_begin;
-          int e = o + 1;
-          while (e < o1 && w.obs_pose[e] == w.obs_pose[o] && ((e - G.obs_begin) & 15) != 0) ++e;
-          const int npc = (e - o + 1) / 2;
-          for (int k = 0; k < npc; ++k) wave_count[(lane0 + 2 * k) >> 6]++;
-          const int blk = w.obs_pose[o];
-          if (pose_off[blk] >= 0) {
-            while (p < p1 && pair_block[p] < blk) ++p;
-            // (p < p1 && pair_block[p] == blk by construction of the pairs)
-            if ((pair_piece[p] >> 16) == 0) pair_piece[p] = local;
-            pair_piece[p] += npc << 16;
-          }
-          local += npc;
-          o = e;
-        }
-      }
-      G.pw1 = wave_count[0];
-      G.pw2 = wave_count[0] + wave_count[1];
-      G.pw3 = wave_count[0] + wave_count[1] + wave_count[2];
-      piece_total += local;
       // tasks: one per free block seen by the group, ascending; its list = the group-local pairs of that block
       G.task_begin = (int)tasks.size();
       touched.clear();
       for (int p = G.pair_begin; p < G.pair_end; ++p) {
         const int b = pair_block[p];
-        if (blk_pairs[b].empty()) touched.push_back(b);
-        blk_pairs[b].push_back((uint16_t)(p - G.pair_begin));
+        if (blk_cnt[b]++ == 0) touched.push_back(b);
       }
       std::sort(touched.begin(), touched.end());
       task_list.resize(task_list.size() + (size_t)(G.pair_end - G.pair_begin));
@@ -520,17 +605,19 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
         // task_list holds, per group-local pair, the SLOT of its block record: the records of one block are contiguous
         // [list_begin, list_end) in slot order (pairs ascending), which is the order they are summed in
         T.list_begin = G.tlist_begin + slot;
-        for (uint16_t pl : blk_pairs[b]) task_list[(size_t)G.tlist_begin + pl] = (uint16_t)slot++;
+        const int n = blk_cnt[b];
+        blk_cnt[b] = slot;   // from here on: the slot the block's next pair takes
+        slot += n;
         T.list_end = G.tlist_begin + slot;
         T.out = gpart_size;
         gpart_size += 27;
         tasks.push_back(T);
-        blk_pairs[b].clear();
       }
+      for (int p = G.pair_begin; p < G.pair_end; ++p) task_list[(size_t)G.tlist_begin + (p - G.pair_begin)] = (uint16_t)blk_cnt[pair_block[p]]++;
+      for (int b : touched) blk_cnt[b] = 0;
       G.task_end = (int)tasks.size();
       G.tlist_end = (int)task_list.size();
     }
-    lm_piece_begin[nlm] = piece_total;
   }
   for (int g = 0; g < ngroup && !lin2; ++g) {
     Group& G = groups[g];
@@ -611,7 +698,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   pair_list_begin[npair] = (int)pair_list.size();
   BW_T("lists+tasks");
   // ---- chunks (Schur workgroups) ----
-  std::vector<Chunk> chunks;
+  std::vector<Chunk>& chunks = S.chunks;
+  chunks.clear();
   {
     // landmarks per Schur workgroup: 48 (three staged batches of 16) keeps the workgroup count low when many windows share
     // the device; a few windows have the device to themselves and finish sooner with 32 (measured, tests/gpu_chunk_diag.py:
@@ -644,30 +732,49 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   const int nchunk = (int)chunks.size();
   // ---- per-chunk lists: which per-group partials sum into which pose block / cross block ----
   const int npose_blk_c = Dp / 6;
-  std::vector<int> chunk_diag_begin((size_t)nchunk * npose_blk_c + 1, 0), chunk_diag_out, chunk_cross_begin(nchunk + 1, 0), chunk_cross;
-  for (int c = 0; c < nchunk; ++c) {
-    std::vector<std::vector<int>> per_blk(npose_blk_c);
-    chunk_cross_begin[c] = (int)chunk_cross.size() / 3;
-    for (int g = chunks[c].group_begin; g < chunks[c].group_end; ++g)
-      for (int t = groups[g].task_begin; t < groups[g].task_end; ++t) {
+  std::vector<int>&chunk_diag_begin = S.chunk_diag_begin, &chunk_diag_out = S.chunk_diag_out, &chunk_cross_begin = S.chunk_cross_begin,
+                   &chunk_cross = S.chunk_cross;
+  chunk_diag_begin.assign((size_t)nchunk * npose_blk_c + 1, 0);
+  chunk_cross_begin.assign((size_t)nchunk + 1, 0);
+  chunk_cross.clear();
+  {
+    // per chunk and pose block: the partials (Task::out) of that block in (group, task) order — counted, then placed
+    int n_diag = 0;
+    for (const Task& T : tasks) n_diag += T.type < 2;
+    chunk_diag_out.resize((size_t)n_diag);
+    std::vector<int>& cur = S.blk_cursor;
+    cur.resize((size_t)npose_blk_c + 1);
+    int run = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      chunk_cross_begin[c] = (int)chunk_cross.size() / 3;
+      int* const begin = chunk_diag_begin.data() + (size_t)c * npose_blk_c;   // (zeroed above: counts first)
+      const int t0 = groups[chunks[c].group_begin].task_begin, t1 = groups[chunks[c].group_end - 1].task_end;   // (tasks are laid out group by group)
+      for (int t = t0; t < t1; ++t) {
         const Task& T = tasks[t];
         if (T.type < 2) {
-          per_blk[T.off_a / 6].push_back(T.out);
+          ++begin[T.off_a / 6];
         } else {
           chunk_cross.push_back(T.off_a);
           chunk_cross.push_back(T.off_b);
           chunk_cross.push_back(T.out);
         }
       }
-    for (int bkk = 0; bkk < npose_blk_c; ++bkk) {
-      chunk_diag_begin[(size_t)c * npose_blk_c + bkk] = (int)chunk_diag_out.size();
-      chunk_diag_out.insert(chunk_diag_out.end(), per_blk[bkk].begin(), per_blk[bkk].end());
+      for (int bkk = 0; bkk < npose_blk_c; ++bkk) {
+        const int n = begin[bkk];
+        begin[bkk] = cur[bkk] = run;
+        run += n;
+      }
+      for (int t = t0; t < t1; ++t) {
+        const Task& T = tasks[t];
+        if (T.type < 2) chunk_diag_out[(size_t)cur[T.off_a / 6]++] = T.out;
+      }
     }
   }
   chunk_diag_begin[(size_t)nchunk * npose_blk_c] = (int)chunk_diag_out.size();
   chunk_cross_begin[nchunk] = (int)chunk_cross.size() / 3;
   // chunk descriptors of the matrix-core Schur kernel: one record instead of the chain chunks -> groups -> lm_pair_begin
-  std::vector<int> chunk_desc((size_t)nchunk * SCHUR_DESC_INTS, 0);
+  std::vector<int>& chunk_desc = S.chunk_desc;
+  chunk_desc.assign((size_t)nchunk * SCHUR_DESC_INTS, 0);
   for (int c = 0; c < nchunk; ++c) {
     int* d = chunk_desc.data() + (size_t)c * SCHUR_DESC_INTS;
     const int lb = groups[chunks[c].group_begin].lm_begin, le = groups[chunks[c].group_end - 1].lm_end;
@@ -712,16 +819,6 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   const int npose_blk = Dp / 6;
   const int spart_stride = npose_blk * (npose_blk + 1) / 2 * 36 + 3 * Dp;
   const int ntile = std::max(1, (Dp / 6 + SCHUR_TILE_BLOCKS - 1) / SCHUR_TILE_BLOCKS);
-  // ---- observation records ----
-  std::vector<ObsRec> recs(nobs);
-  for (int o = 0; o < nobs; ++o) {
-    recs[o].lm_cam = (uint32_t)w.obs_lm[o] | ((uint32_t)w.obs_cam[o] << 24);
-    recs[o].pose = (uint16_t)w.obs_pose[o];
-    recs[o].ext = (uint16_t)w.obs_ext[o];
-    recs[o].u = w.obs_uv[2 * o];
-    recs[o].v = w.obs_uv[2 * o + 1];
-    recs[o].sw = w.obs_sqrtw[o];
-  }
   // ---- IMU ----
   for (int f = 0; f < w.n_imu; ++f) {
     if (w.imu_pose0[f] < 0 || w.imu_pose0[f] >= npose || w.imu_pose1[f] < 0 || w.imu_pose1[f] >= npose ||
@@ -733,7 +830,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // ImuError::redoPreintegration returns -1 when the samples do not cover [t0,t1] (ImuError.cpp:87-89)
     if (!(w.imu_s_t[w.imu_s_begin[f] + w.imu_s_count[f] - 1] >= w.imu_t1[f])) return OKVIS_BA_ERR_ARG;
   }
-  BW_T("obs records + imu");
+  BW_T("imu checks");
   // ---- marginalisation prior: H0 = J^T J ----
   const int Dm = w.marg_dim;
   if (Dm < 0 || Dm > MAX_MARG_DIM) return OKVIS_BA_ERR_UNSUPPORTED;
@@ -796,31 +893,18 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.imu.g = w.imu_params.g; P.imu.g_max = w.imu_params.g_max; P.imu.a_max = w.imu_params.a_max;
 
   BW_T("prior + sizes");
-  // ---- arena: state ----
-  auto poses = vec(w.pose, 7 * (size_t)npose);
-  auto sbs = vec(w.sb, 9 * (size_t)nsb);
-  auto lms = vec(w.lm, 4 * (size_t)nlm);
-  for (int b = 0; b < 2; ++b) {
-    OFF(pose[b], put(A, poses));
-    OFF(sb[b], put(A, sbs));
-    OFF(lm[b], put(A, lms));
-  }
-  OFF(pose_off, put(A, pose_off));
-  OFF(sb_off, put(A, sb_off));
-  OFF(cam_intr, put(A, vec(w.cam_intr, 12 * (size_t)w.n_cam)));
-  OFF(cam_model, put(A, vec(w.cam_model, (size_t)w.n_cam)));
-  OFF(obs, put(A, recs));
+  // ---- arena: index lists (the state arrays and the observation records are in place, see above) ----
   OFF(groups, put(A, groups));
-  OFF(pair_lm, put(A, pair_lm));
-  OFF(pair_off, put(A, pair_off));
-  OFF(pair_role, put(A, pair_role));
+  OFF(pair_lm, put_n(A, pair_lm.data(), (size_t)npair));
+  OFF(pair_off, put_n(A, pair_off.data(), (size_t)npair));
+  OFF(pair_role, put_n(A, pair_role.data(), (size_t)npair));
   OFF(pair_list_begin, put(A, pair_list_begin));
   OFF(pair_list, put(A, pair_list));
   OFF(lm_pair_begin, put(A, lm_pair_begin));
   OFF(lm_obs_begin, put(A, lm_obs_begin));
-  OFF(lm_piece_begin, put(A, lm_piece_begin));
-  OFF(pair_piece, put(A, pair_piece));
-  OFF(pair_block, put(A, lin2 ? pair_block : std::vector<int>()));
+  OFF(lm_piece_begin, put_n(A, lm_piece_begin.data(), lin2 ? (size_t)nlm + 1 : 0));
+  OFF(pair_piece, put_n(A, pair_piece.data(), lin2 ? (size_t)npair : 0));
+  OFF(pair_block, put_n(A, pair_block.data(), lin2 ? (size_t)npair : 0));
   OFF(tasks, put(A, tasks));
   OFF(task_list, put(A, task_list));
   OFF(chunks, put(A, chunks));
@@ -961,10 +1045,10 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(results, put_zero(A, 8 * (7 * (size_t)npose + 9 * (size_t)nsb + 5 * (size_t)nlm + 9 * (size_t)std::max(w.n_imu, 0)) + 8));
   if (opt.debug_arrays) OFF(prof, put_zero(A, 8 * (64 + 4 * 160)));   // clock64() phase stamps + tile task timeline: diagnostics only
   OFF(ctrl, put_zero(A, sizeof(Ctrl)));
-  OFF(imu_pose0, put(A, vec(w.imu_pose0, (size_t)w.n_imu)));
-  OFF(imu_sb0, put(A, vec(w.imu_sb0, (size_t)w.n_imu)));
-  OFF(imu_pose1, put(A, vec(w.imu_pose1, (size_t)w.n_imu)));
-  OFF(imu_sb1, put(A, vec(w.imu_sb1, (size_t)w.n_imu)));
+  OFF(imu_pose0, put_n(A, w.imu_pose0, (size_t)w.n_imu));
+  OFF(imu_sb0, put_n(A, w.imu_sb0, (size_t)w.n_imu));
+  OFF(imu_pose1, put_n(A, w.imu_pose1, (size_t)w.n_imu));
+  OFF(imu_sb1, put_n(A, w.imu_sb1, (size_t)w.n_imu));
   {
     std::vector<long long> t0(w.n_imu), t1(w.n_imu), st(w.n_imu ? w.n_imu_samples : 0);
     for (int f = 0; f < w.n_imu; ++f) {
@@ -976,10 +1060,10 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(imu_t1, put(A, t1));
     OFF(imu_s_t, put(A, st));
   }
-  OFF(imu_s_begin, put(A, vec(w.imu_s_begin, (size_t)w.n_imu)));
-  OFF(imu_s_count, put(A, vec(w.imu_s_count, (size_t)w.n_imu)));
-  OFF(imu_s_gyr, put(A, vec(w.imu_s_gyr, w.n_imu ? 3 * (size_t)w.n_imu_samples : 0)));
-  OFF(imu_s_acc, put(A, vec(w.imu_s_acc, w.n_imu ? 3 * (size_t)w.n_imu_samples : 0)));
+  OFF(imu_s_begin, put_n(A, w.imu_s_begin, (size_t)w.n_imu));
+  OFF(imu_s_count, put_n(A, w.imu_s_count, (size_t)w.n_imu));
+  OFF(imu_s_gyr, put_n(A, w.imu_s_gyr, w.n_imu ? 3 * (size_t)w.n_imu_samples : 0));
+  OFF(imu_s_acc, put_n(A, w.imu_s_acc, w.n_imu ? 3 * (size_t)w.n_imu_samples : 0));
   {
     std::vector<ImuCacheD> caches((size_t)w.n_imu);
     std::memset(caches.data(), 0, sizeof(ImuCacheD) * caches.size());
@@ -991,22 +1075,22 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
         }
     OFF(imu_cache, put(A, caches));
   }
-  OFF(pprior_pose, put(A, vec(w.pprior_pose, (size_t)w.n_pprior)));
-  OFF(pprior_meas, put(A, vec(w.pprior_meas, 7 * (size_t)w.n_pprior)));
-  OFF(pprior_sqrtinfo, put(A, vec(w.pprior_sqrtinfo, 36 * (size_t)w.n_pprior)));
-  OFF(sbprior_sb, put(A, vec(w.sbprior_sb, (size_t)w.n_sbprior)));
-  OFF(sbprior_meas, put(A, vec(w.sbprior_meas, 9 * (size_t)w.n_sbprior)));
-  OFF(sbprior_sqrtinfo, put(A, vec(w.sbprior_sqrtinfo, 81 * (size_t)w.n_sbprior)));
-  OFF(rel_pose0, put(A, vec(w.rel_pose0, (size_t)w.n_relpose)));
-  OFF(rel_pose1, put(A, vec(w.rel_pose1, (size_t)w.n_relpose)));
-  OFF(rel_sqrtinfo, put(A, vec(w.rel_sqrtinfo, 36 * (size_t)w.n_relpose)));
-  OFF(marg_block_type, put(A, vec(w.marg_block_type, (size_t)nmb)));
-  OFF(marg_block_idx, put(A, vec(w.marg_block_idx, (size_t)nmb)));
-  OFF(marg_block_off, put(A, vec(w.marg_block_off, (size_t)nmb)));
-  OFF(marg_J, put(A, vec(w.marg_J, (size_t)Dm * Dm)));
+  OFF(pprior_pose, put_n(A, w.pprior_pose, (size_t)w.n_pprior));
+  OFF(pprior_meas, put_n(A, w.pprior_meas, 7 * (size_t)w.n_pprior));
+  OFF(pprior_sqrtinfo, put_n(A, w.pprior_sqrtinfo, 36 * (size_t)w.n_pprior));
+  OFF(sbprior_sb, put_n(A, w.sbprior_sb, (size_t)w.n_sbprior));
+  OFF(sbprior_meas, put_n(A, w.sbprior_meas, 9 * (size_t)w.n_sbprior));
+  OFF(sbprior_sqrtinfo, put_n(A, w.sbprior_sqrtinfo, 81 * (size_t)w.n_sbprior));
+  OFF(rel_pose0, put_n(A, w.rel_pose0, (size_t)w.n_relpose));
+  OFF(rel_pose1, put_n(A, w.rel_pose1, (size_t)w.n_relpose));
+  OFF(rel_sqrtinfo, put_n(A, w.rel_sqrtinfo, 36 * (size_t)w.n_relpose));
+  OFF(marg_block_type, put_n(A, w.marg_block_type, (size_t)nmb));
+  OFF(marg_block_idx, put_n(A, w.marg_block_idx, (size_t)nmb));
+  OFF(marg_block_off, put_n(A, w.marg_block_off, (size_t)nmb));
+  OFF(marg_J, put_n(A, w.marg_J, (size_t)Dm * Dm));
   OFF(marg_H0, put(A, H0));
-  OFF(marg_e0, put(A, vec(w.marg_e0, (size_t)Dm)));
-  OFF(marg_lin, put(A, vec(w.marg_lin, 9 * (size_t)nmb)));
+  OFF(marg_e0, put_n(A, w.marg_e0, (size_t)Dm));
+  OFF(marg_lin, put_n(A, w.marg_lin, 9 * (size_t)nmb));
   for (int i = 0; i < w.n_pprior; ++i)
     if (w.pprior_pose[i] < 0 || w.pprior_pose[i] >= npose) return OKVIS_BA_ERR_ARG;
   for (int i = 0; i < w.n_sbprior; ++i)
@@ -1017,8 +1101,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   H.n_pose = npose; H.n_sb = nsb; H.n_lm = nlm; H.n_obs = nobs; H.n_imu = w.n_imu; H.D = D; H.Dp = Dp;
   H.pose_off = pose_off; H.sb_off = sb_off; H.marg_dim = Dm;
   H.n_pair = npair; H.n_group = ngroup; H.n_chunk = nchunk;
-  H.pair_lm = pair_lm;
-  H.pair_block = pair_block;
+  H.pair_lm.assign(pair_lm.data(), pair_lm.data() + npair);
+  H.pair_block.assign(pair_block.data(), pair_block.data() + npair);
   H.acc = 0;
   BW_T("arena");
   // ---- algorithmic (compulsory) bytes per iteration, DESIGN.md §4 ----
@@ -1662,8 +1746,34 @@ int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt,
   if (opt) o = *opt; else okvis_ba_default_options(&o);
   Arena A;
   HostWin H;
-  int rc = build_window(*w, o, A, H);
+  // (the staging bytes are kept between calls like a solver keeps them between uploads — except for a dump, whose alignment
+  // gaps must be zero)
+  static thread_local StageVec kept;
+  const bool dumping = std::getenv("OKVIS_BA_DUMP_ARENA") != nullptr;
+  if (!dumping) A.host.swap(kept);
+  struct GiveBack {
+    StageVec& a;
+    StageVec& b;
+    bool on;
+    ~GiveBack() {
+      if (on) a.swap(b);
+    }
+  } give_back{A.host, kept, !dumping};
+  // the route okvis_ba_upload takes for a one-window batch: the piece path's lists unless the window does not fit them
+  int rc = (o.reserved0 & 8) || std::getenv("OKVIS_BA_NO_LIN2") ? BW_LIN2_UNFIT : build_window(*w, o, A, H, 1, true);
+  if (rc == BW_LIN2_UNFIT) {
+    A.size = 0;
+    A.zsize = 0;
+    rc = build_window(*w, o, A, H);
+  }
   if (rc != OKVIS_BA_OK) return rc;
+  if (const char* dump = std::getenv("OKVIS_BA_DUMP_ARENA")) {   // diagnostics: the index build's output, byte for byte
+    if (FILE* f = std::fopen(dump, "wb")) {
+      std::fwrite(A.host.data(), 1, A.size, f);
+      std::fwrite(&H.ptrs, 1, sizeof(H.ptrs), f);
+      std::fclose(f);
+    }
+  }
   if (stats) {
     stats[0] = H.D; stats[1] = H.Dp; stats[2] = H.n_pair; stats[3] = H.n_group; stats[4] = H.n_chunk;
     stats[5] = H.ptrs.n_task; stats[6] = H.ptrs.gpart_size; stats[7] = (int64_t)A.total();

@@ -95,6 +95,32 @@ def test_upload_validation_errors():
     assert status(rep) == 0
     bad = copy.deepcopy(w); bad.imu_s_count = bad.imu_s_count.copy(); bad.imu_s_count[0] = 5   # samples do not reach t1
     assert status(bad) == -1
+    # the observation pass is one walk, landmark by landmark: the first offending observation decides, in list order
+    first = int(np.flatnonzero(w.obs_lm == w.obs_lm[0]).size)              # observations of landmark 0
+    assert first >= 2
+    bad = copy.deepcopy(w); bad.obs_pose = bad.obs_pose.copy(); bad.obs_pose[[0, first - 1]] = bad.obs_pose[[first - 1, 0]]
+    assert status(bad) == -1                                               # poses of one landmark out of order
+    same = np.flatnonzero((w.obs_lm[1:] == w.obs_lm[:-1]) & (w.obs_pose[1:] == w.obs_pose[:-1]))
+    if same.size:                                                          # cameras of one (landmark, pose) out of order
+        bad = copy.deepcopy(w); bad.obs_cam = bad.obs_cam.copy(); i = int(same[0]); bad.obs_cam[[i, i + 1]] = bad.obs_cam[[i + 1, i]]
+        assert status(bad) == -1
+    bad = copy.deepcopy(w); bad.obs_lm = bad.obs_lm.copy(); bad.obs_lm[-1] = w.n_lm   # landmark out of range
+    assert status(bad) == -1
+    bad = copy.deepcopy(w); bad.obs_lm = bad.obs_lm.copy(); bad.obs_lm[-1] = -1
+    assert status(bad) == -1
+    bad = copy.deepcopy(w); bad.obs_cam = bad.obs_cam.copy(); bad.obs_cam[3] = len(w.cam_model)
+    assert status(bad) == -1
+    bad = copy.deepcopy(w); bad.obs_ext = bad.obs_ext.copy(); bad.obs_ext[-1] = bad.obs_pose[0]   # a block in both roles
+    assert status(bad) == -3
+    bad = copy.deepcopy(w); bad.obs_ext = bad.obs_ext.copy(); bad.obs_ext[2] = bad.obs_pose[2]   # pose = extrinsics
+    assert status(bad) == -3
+    # a role conflict early in the list is reported although a later observation is out of range (and the other way round)
+    bad = copy.deepcopy(w); bad.obs_ext = bad.obs_ext.copy(); bad.obs_pose = bad.obs_pose.copy()
+    bad.obs_ext[1] = bad.obs_pose[0]; bad.obs_pose[-1] = 99
+    assert status(bad) == -3
+    bad = copy.deepcopy(w); bad.obs_ext = bad.obs_ext.copy(); bad.obs_pose = bad.obs_pose.copy()
+    bad.obs_pose[0] = 99; bad.obs_ext[-1] = w.obs_pose[-1]
+    assert status(bad) == -1
     big = synthetic.make_window(3, 5, 1.0, 1)
     big.obs_lm = np.zeros(300, np.int32)                                   # > 256 observations of one landmark
     big.obs_pose = np.arange(300, dtype=np.int32) % 3
