@@ -259,6 +259,32 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
  * any numeric work.  stats[8] = {D, Dp, n_pair, n_group, n_chunk, n_task, gpart doubles, arena bytes}.
  * opt may be NULL (defaults). */
 int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt, int64_t* stats);
+/* The index lists that build would hand to the device, for a window that is one of n_windows sharing it (the batch size sets
+ * the landmarks per linearise group and per Schur chunk): host only, diagnostics and tests.  `which` names a list
+ * (OKVIS_BA_LIST_*); its entries are written to out as int32 (16-bit lists widened, records as consecutive ints: a group is
+ * 16 ints {lm, obs, pair, task, pair-list, task-list begin/end, first piece, pieces before waves 1..3}, a task 6 {type,
+ * offset a, offset b, list begin, list end, output}, a chunk 2 {group begin, end}).  *n = number of ints of the list;
+ * nothing is written when capacity < *n (returns OKVIS_BA_ERR_ARG then, with *n set: ask with capacity 0 first). */
+#define OKVIS_BA_LIST_GROUPS 0
+#define OKVIS_BA_LIST_LM_OBS_BEGIN 1
+#define OKVIS_BA_LIST_LM_PAIR_BEGIN 2
+#define OKVIS_BA_LIST_PAIR_LM 3
+#define OKVIS_BA_LIST_PAIR_BLOCK 4      /* piece path only */
+#define OKVIS_BA_LIST_PAIR_OFF 5
+#define OKVIS_BA_LIST_PAIR_ROLE 6
+#define OKVIS_BA_LIST_LM_PIECE_BEGIN 7  /* piece path only */
+#define OKVIS_BA_LIST_PAIR_PIECE 8      /* piece path only */
+#define OKVIS_BA_LIST_PAIR_LIST_BEGIN 9
+#define OKVIS_BA_LIST_PAIR_LIST 10      /* staged path only */
+#define OKVIS_BA_LIST_TASKS 11
+#define OKVIS_BA_LIST_TASK_LIST 12
+#define OKVIS_BA_LIST_CHUNKS 13
+#define OKVIS_BA_LIST_CHUNK_DIAG_BEGIN 14
+#define OKVIS_BA_LIST_CHUNK_DIAG_OUT 15
+#define OKVIS_BA_LIST_CHUNK_DESC 16
+#define OKVIS_BA_LIST_PIECE_PATH 17     /* one int: 1 = the lists are those of the piece path (ba_linearize2.hpp) */
+int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options* opt, int32_t n_windows, int32_t which,
+                                int32_t* out, int64_t capacity, int64_t* n);
 /* ---- incremental structure updates ---------------------------------------------------------------------
  * The reference edits its problem in O(1) per block: Map::addParameterBlock / addResidualBlock / removeResidualBlock /
  * removeParameterBlock (Map.cpp:292-565), driven by Estimator::addStates / addLandmark / addObservation / removeObservation /

@@ -7,12 +7,13 @@ import os
 from .window import LimitsC, MargResultC, MargSpecC, OptionsC, PatchC, SummaryC, WindowC
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libokvis_amd_ba.so")
+# (OKVIS_AMD_LIB_DIR: a directory holding an instrumented build of the same sources — scripts/host_sanitize.sh)
+LIB_PATH = os.path.join(os.environ.get("OKVIS_AMD_LIB_DIR") or os.path.join(_HERE, "lib"), "libokvis_amd_ba.so")
 
 # every symbol include/okvis_amd_ba.h declares
 SYMBOLS = [
     "okvis_ba_abi_version", "okvis_ba_get_limits", "okvis_ba_default_options", "okvis_ba_error_string",
-    "okvis_ba_create", "okvis_ba_destroy", "okvis_ba_upload", "okvis_ba_check_window", "okvis_ba_set_state", "okvis_ba_set_options",
+    "okvis_ba_create", "okvis_ba_destroy", "okvis_ba_upload", "okvis_ba_check_window", "okvis_ba_check_window_lists", "okvis_ba_set_state", "okvis_ba_set_options",
     "okvis_ba_optimize", "okvis_ba_optimize_timed", "okvis_ba_begin", "okvis_ba_iterate", "okvis_ba_finish",
     "okvis_ba_evaluate_cost", "okvis_ba_get_state", "okvis_ba_fetch_results", "okvis_ba_array_size", "okvis_ba_download",
     "okvis_ba_reduced_dim", "okvis_ba_pair_count", "okvis_ba_pairs", "okvis_ba_last_iterate_ms",
@@ -63,6 +64,8 @@ def lib():
     L.okvis_ba_patch_window.argtypes = [vp, C.c_int, C.POINTER(PatchC)]
     L.okvis_ba_patched_view.argtypes = [vp, C.c_int, C.POINTER(WindowC)]
     L.okvis_ba_check_window.argtypes = [C.POINTER(WindowC), C.POINTER(OptionsC), C.POINTER(C.c_int64)]
+    L.okvis_ba_check_window_lists.argtypes = [C.POINTER(WindowC), C.POINTER(OptionsC), C.c_int32, C.c_int32, _ip, C.c_int64,
+                                              C.POINTER(C.c_int64)]
     L.okvis_ba_get_state.argtypes = [vp, C.c_int, _dp, _dp, _dp]
     L.okvis_ba_fetch_results.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _dp]
     L.okvis_ba_set_options.argtypes = [vp, C.POINTER(OptionsC)]

@@ -1066,7 +1066,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(imu_s_acc, put_n(A, w.imu_s_acc, w.n_imu ? 3 * (size_t)w.n_imu_samples : 0));
   {
     std::vector<ImuCacheD> caches((size_t)w.n_imu);
-    std::memset(caches.data(), 0, sizeof(ImuCacheD) * caches.size());
+    if (!caches.empty()) std::memset(caches.data(), 0, sizeof(ImuCacheD) * caches.size());
     if (w.imu_sb_ref && w.imu_sb_ref_valid)
       for (int f = 0; f < w.n_imu; ++f)
         if (w.imu_sb_ref_valid[f]) {
@@ -1777,6 +1777,72 @@ int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt,
   if (stats) {
     stats[0] = H.D; stats[1] = H.Dp; stats[2] = H.n_pair; stats[3] = H.n_group; stats[4] = H.n_chunk;
     stats[5] = H.ptrs.n_task; stats[6] = H.ptrs.gpart_size; stats[7] = (int64_t)A.total();
+  }
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options* opt, int32_t n_windows, int32_t which,
+                                int32_t* out, int64_t capacity, int64_t* n) {
+  if (!w || !n || n_windows <= 0 || capacity < 0 || (capacity > 0 && !out)) return OKVIS_BA_ERR_ARG;
+  okvis_ba_options o;
+  if (opt) o = *opt; else okvis_ba_default_options(&o);
+  Arena A;
+  HostWin H;
+  int rc = (o.reserved0 & 8) || std::getenv("OKVIS_BA_NO_LIN2") ? BW_LIN2_UNFIT : build_window(*w, o, A, H, n_windows, true);
+  if (rc == BW_LIN2_UNFIT) {
+    A.size = 0;
+    A.zsize = 0;
+    rc = build_window(*w, o, A, H, n_windows, false);
+  }
+  if (rc != OKVIS_BA_OK) return rc;
+  const WinPtrs& P = H.ptrs;   // (the pointer members still hold offsets into the arena's data part)
+  const unsigned char* base = A.host.data();
+  auto at = [&](const void* field) { return base + reinterpret_cast<size_t>(field); };
+  const int nb = P.Dp / 6;
+  const void* src = nullptr;
+  int64_t count = 0;
+  int width = 4;   // bytes per entry
+  switch (which) {
+    case OKVIS_BA_LIST_GROUPS: src = at((const void*)P.groups), count = 16 * (int64_t)P.n_group; break;
+    case OKVIS_BA_LIST_LM_OBS_BEGIN: src = at((const void*)P.lm_obs_begin), count = P.n_lm + 1; break;
+    case OKVIS_BA_LIST_LM_PAIR_BEGIN: src = at((const void*)P.lm_pair_begin), count = P.n_lm + 1; break;
+    case OKVIS_BA_LIST_PAIR_LM: src = at((const void*)P.pair_lm), count = P.n_pair; break;
+    case OKVIS_BA_LIST_PAIR_BLOCK: src = at((const void*)P.pair_block), count = P.lin2 ? P.n_pair : 0; break;
+    case OKVIS_BA_LIST_PAIR_OFF: src = at((const void*)P.pair_off), count = P.n_pair; break;
+    case OKVIS_BA_LIST_PAIR_ROLE: src = at((const void*)P.pair_role), count = P.n_pair; break;
+    case OKVIS_BA_LIST_LM_PIECE_BEGIN: src = at((const void*)P.lm_piece_begin), count = P.lin2 ? P.n_lm + 1 : 0; break;
+    case OKVIS_BA_LIST_PAIR_PIECE: src = at((const void*)P.pair_piece), count = P.lin2 ? P.n_pair : 0; break;
+    case OKVIS_BA_LIST_PAIR_LIST_BEGIN: src = at((const void*)P.pair_list_begin), count = P.n_pair + 1; break;
+    case OKVIS_BA_LIST_PAIR_LIST:
+      src = at((const void*)P.pair_list), width = 2;
+      count = reinterpret_cast<const int*>(at((const void*)P.pair_list_begin))[P.n_pair];
+      break;
+    case OKVIS_BA_LIST_TASKS: src = at((const void*)P.tasks), count = 6 * (int64_t)P.n_task; break;
+    case OKVIS_BA_LIST_TASK_LIST: {
+      src = at((const void*)P.task_list), width = 2;
+      const Group* g = reinterpret_cast<const Group*>(at((const void*)P.groups));
+      count = P.n_group ? g[P.n_group - 1].tlist_end : 0;
+      break;
+    }
+    case OKVIS_BA_LIST_CHUNKS: src = at((const void*)P.chunks), count = 2 * (int64_t)P.n_chunk; break;
+    case OKVIS_BA_LIST_CHUNK_DIAG_BEGIN: src = at((const void*)P.chunk_diag_begin), count = (int64_t)P.n_chunk * nb + 1; break;
+    case OKVIS_BA_LIST_CHUNK_DIAG_OUT:
+      src = at((const void*)P.chunk_diag_out);
+      count = reinterpret_cast<const int*>(at((const void*)P.chunk_diag_begin))[(size_t)P.n_chunk * nb];
+      break;
+    case OKVIS_BA_LIST_CHUNK_DESC: src = at((const void*)P.chunk_desc), count = (int64_t)P.n_chunk * SCHUR_DESC_INTS; break;
+    case OKVIS_BA_LIST_PIECE_PATH: count = 1; break;
+    default: return OKVIS_BA_ERR_ARG;
+  }
+  *n = count;
+  if (capacity < count) return OKVIS_BA_ERR_ARG;
+  if (which == OKVIS_BA_LIST_PIECE_PATH) {
+    out[0] = P.lin2;
+  } else if (width == 4) {
+    if (count) std::memcpy(out, src, 4 * (size_t)count);
+  } else {
+    const uint16_t* s16 = static_cast<const uint16_t*>(src);
+    for (int64_t i = 0; i < count; ++i) out[i] = s16[i];
   }
   return OKVIS_BA_OK;
 }

@@ -321,14 +321,6 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const LYT LY, double* S
 
 }
 
-// ---- speed/bias blocks of the reduced system, eliminated FIRST and in parallel by levels -------------------------
-// The 9x9 speed/bias diagonal blocks couple only through ImuError (sb_k - sb_k+1) and the marginalisation prior, never
-// through landmarks: the reduced matrix is [pose-pose dense | banded pose-sb | block-tridiagonal sb-sb].  Instead of
-// walking through them as part of 25 sequential 6x6 block columns, blocks that are mutually uncoupled (host-built levels:
-// for an IMU chain of n states ceil(log2 n) of them, e.g. {0,2,4,6,8} {1,5,9} {3} {7}) are factorised at the same time by
-// different work-items and eliminated with one symmetric update; the dense blocked Cholesky then only sees the pose part.
-// The rows Y = C L^-T of every level stay in an LDS stage for the recovery after the dense back-substitution.
-
 // trial poses / speed-biases  x (+) delta  of buffer 1-acc (PoseLocalParameterization::plus, PoseLocalParameterization.cpp:60-87).
 // Adds |x|^2 over the free blocks to *x2 and, when `ambient`, |x - x(+)delta|^2 to *s2.
 // pre (LDS, may be null): the accepted values of the first PRE_BLOCKS pose blocks [b][7] and speed/bias blocks

@@ -11,7 +11,8 @@ import numpy as np
 from .window import SummaryC
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libokvis_amd_estimator.so")
+# (OKVIS_AMD_LIB_DIR: a directory holding an instrumented build of the same sources — scripts/host_sanitize.sh)
+LIB_PATH = os.path.join(os.environ.get("OKVIS_AMD_LIB_DIR") or os.path.join(_HERE, "lib"), "libokvis_amd_estimator.so")
 _dp = C.POINTER(C.c_double)
 _lp = C.POINTER(C.c_int64)
 _lib = None

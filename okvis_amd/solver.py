@@ -38,6 +38,35 @@ def check_window(window: Window, options: OptionsC | None = None) -> dict:
                 arena_bytes=st[7])
 
 
+INDEX_LISTS = ("groups", "lm_obs_begin", "lm_pair_begin", "pair_lm", "pair_block", "pair_off", "pair_role", "lm_piece_begin",
+               "pair_piece", "pair_list_begin", "pair_list", "tasks", "task_list", "chunks", "chunk_diag_begin", "chunk_diag_out",
+               "chunk_desc", "piece_path")   # OKVIS_BA_LIST_* in this order
+
+
+def index_lists(window: Window, options: OptionsC | None = None, n_windows: int = 1) -> dict:
+    """The index lists okvis_ba_upload would build for `window` as one of `n_windows` (host only; okvis_ba_check_window_lists)."""
+    wc, keep = window.as_c()
+    L = _lib.lib()
+    po = C.byref(options) if options is not None else None
+    out = {}
+    for which, name in enumerate(INDEX_LISTS):
+        n = C.c_int64()
+        rc = L.okvis_ba_check_window_lists(C.byref(wc), po, n_windows, which, None, 0, C.byref(n))
+        if rc != 0 and not (rc == -1 and n.value > 0):
+            _lib.check(rc, "check_window_lists")
+        a = np.zeros(max(n.value, 1), np.int32)
+        if n.value:
+            _lib.check(L.okvis_ba_check_window_lists(C.byref(wc), po, n_windows, which, a.ctypes.data_as(C.POINTER(C.c_int32)), n.value,
+                                                     C.byref(n)), "check_window_lists")
+        out[name] = a[:n.value]
+    del keep
+    out["groups"] = out["groups"].reshape(-1, 16)
+    out["tasks"] = out["tasks"].reshape(-1, 6)
+    out["chunks"] = out["chunks"].reshape(-1, 2)
+    out["piece_path"] = int(out["piece_path"][0])
+    return out
+
+
 class WindowStore:
     """Host-side window container with O(edit) structure updates (okvis_ba_store_*; no GPU needed)."""
 
