@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OKVIS_BA_ABI_VERSION 5
+#define OKVIS_BA_ABI_VERSION 6
 
 /* status codes (0 ok; >0 = hipError_t passthrough + 1000; <0 = argument / state errors) */
 #define OKVIS_BA_OK 0
@@ -47,6 +47,10 @@ extern "C" {
 #define OKVIS_BA_DIST_RADTAN8 3      /* RadialTangentialDistortion8 k1 k2 p1 p2 k3 k4 k5 k6 */
 
 /* block types inside the marginalisation prior */
+/* one ImuError preintegration as the device keeps it (Delta_q, the integrals, their bias Jacobians, the square-root information,
+ * the reference bias), opaque to the caller: okvis_ba_fetch_imu_caches hands it out, okvis_ba_window::imu_cache takes it back */
+#define OKVIS_BA_IMU_CACHE_DOUBLES 290
+
 #define OKVIS_BA_BLOCK_POSE 0
 #define OKVIS_BA_BLOCK_SPEEDBIAS 1
 
@@ -146,9 +150,15 @@ typedef struct okvis_ba_window {
   /* ImuError keeps a mutable preintegration cache whose reference bias (speedAndBiases_ref_, ImuError.hpp) is
    * the bias of its last redoPreintegration and survives optimize() calls.  Optional: the reference bias each
    * factor's cache starts from (download it after optimize with OKVIS_BA_ARR_IMU_SB_REF).  NULL / flag 0 = a
-   * brand-new factor: the first evaluation re-preintegrates at the current bias (redo_ = true, ImuError.cpp:62) */
+   * brand-new factor: the first evaluation re-preintegrates at the current bias (redo_ = true, ImuError.cpp:62).
+   * Flag 1 = the reference bias only: the cache is rebuilt AT that reference on first use (what the reference's object would
+   * still hold).  Flag 2 = the preintegration itself travels too — the record okvis_ba_fetch_imu_caches handed out for the same
+   * term (same samples, same interval) sits in imu_cache: nothing is rebuilt unless the bias has moved past the threshold
+   * (ImuError.cpp:549), exactly like the reference's ImuError object that lives on between optimize() calls.  The values are
+   * the same either way (the rebuild is deterministic); flag 2 saves the 0.1 ms a re-preintegration takes. */
   const double* imu_sb_ref;        /* [n_imu][9] or NULL */
-  const uint8_t* imu_sb_ref_valid; /* [n_imu] or NULL */
+  const uint8_t* imu_sb_ref_valid; /* [n_imu] or NULL: 0 / 1 / 2, see above */
+  const double* imu_cache;         /* [n_imu][OKVIS_BA_IMU_CACHE_DOUBLES] or NULL (opaque records, read where the flag is 2) */
 } okvis_ba_window;
 
 /*
@@ -397,6 +407,11 @@ int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, doub
  * imu_sb_ref [n_imu][9] (OKVIS_BA_ARR_IMU_SB_REF); any pointer may be NULL. */
 int okvis_ba_fetch_results(okvis_ba_solver* s, int w, double* pose, double* sb, double* lm, double* lm_quality,
                            double* imu_sb_ref);
+/* The preintegration records of window w's IMU terms, caches [n_imu][OKVIS_BA_IMU_CACHE_DOUBLES], from the same packed record
+ * as okvis_ba_fetch_results (no further synchronisation after it): what okvis_ba_window::imu_cache takes back with flag 2.  A term
+ * that has not been evaluated since the upload has nothing to hand out: its record's flag word is 0 and it must travel with
+ * flag 0 or 1. */
+int okvis_ba_fetch_imu_caches(okvis_ba_solver* s, int w, double* caches);
 /* size (in doubles) and contents of an intermediate array of window w (parity tests) */
 int okvis_ba_array_size(okvis_ba_solver* s, int w, int which, int64_t* n_doubles);
 int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t n_doubles);

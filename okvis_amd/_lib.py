@@ -15,7 +15,7 @@ SYMBOLS = [
     "okvis_ba_abi_version", "okvis_ba_get_limits", "okvis_ba_default_options", "okvis_ba_error_string",
     "okvis_ba_create", "okvis_ba_destroy", "okvis_ba_upload", "okvis_ba_check_window", "okvis_ba_check_window_lists", "okvis_ba_set_state", "okvis_ba_set_options",
     "okvis_ba_optimize", "okvis_ba_optimize_timed", "okvis_ba_begin", "okvis_ba_iterate", "okvis_ba_finish",
-    "okvis_ba_evaluate_cost", "okvis_ba_get_state", "okvis_ba_fetch_results", "okvis_ba_array_size", "okvis_ba_download",
+    "okvis_ba_evaluate_cost", "okvis_ba_get_state", "okvis_ba_fetch_results", "okvis_ba_fetch_imu_caches", "okvis_ba_array_size", "okvis_ba_download",
     "okvis_ba_reduced_dim", "okvis_ba_pair_count", "okvis_ba_pairs", "okvis_ba_last_iterate_ms",
     "okvis_ba_profile_iterations", "okvis_ba_profile_launches", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize",
     "okvis_ba_helper_timeouts", "okvis_ba_marginalize",
@@ -68,6 +68,7 @@ def lib():
                                               C.POINTER(C.c_int64)]
     L.okvis_ba_get_state.argtypes = [vp, C.c_int, _dp, _dp, _dp]
     L.okvis_ba_fetch_results.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _dp]
+    L.okvis_ba_fetch_imu_caches.argtypes = [vp, C.c_int, _dp]
     L.okvis_ba_set_options.argtypes = [vp, C.POINTER(OptionsC)]
     L.okvis_ba_optimize.argtypes = [vp, C.c_int, C.POINTER(SummaryC)]
     L.okvis_ba_optimize_timed.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.POINTER(SummaryC)]

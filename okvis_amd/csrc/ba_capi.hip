@@ -402,11 +402,11 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       // branches: they fail to predict about once per observation)
       for (; o < nobs && w.obs_lm[o] == l; ++o) {
         const int ip = w.obs_pose[o], ie = w.obs_ext[o], c = w.obs_cam[o];
-        if (((unsigned)ip >= unpose) | ((unsigned)ie >= unpose) | ((unsigned)c >= uncam)) return OKVIS_BA_ERR_ARG;
+        if ((int)((unsigned)ip >= unpose) | (int)((unsigned)ie >= unpose) | (int)((unsigned)c >= uncam)) return OKVIS_BA_ERR_ARG;
         // sorted by (landmark, pose, cam); REPEATED (landmark, pose, cam) entries are legal: the reference adds one residual
         // block per matched keypoint (implementation/Estimator.hpp:52-56 only rejects an identical KeypointIdentifier)
-        if ((prev_ip > ip) | ((prev_ip == ip) & (prev_c > c))) return OKVIS_BA_ERR_ARG;  // unsorted
-        if ((role[ip] == 1) | (role[ie] == 0) | (ip == ie)) return OKVIS_BA_ERR_UNSUPPORTED;
+        if ((int)(prev_ip > ip) | ((int)(prev_ip == ip) & (int)(prev_c > c))) return OKVIS_BA_ERR_ARG;  // unsorted
+        if ((int)(role[ip] == 1) | (int)(role[ie] == 0) | (int)(ip == ie)) return OKVIS_BA_ERR_UNSUPPORTED;
         role[ip] = 0;
         role[ie] = 1;
         ObsRec& R = recs[o];
@@ -1042,7 +1042,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   OFF(lm_scale, put_zero(A, 24 * (size_t)nlm));
   OFF(grad, put_zero(A, 8 * (size_t)D));
   OFF(quality, put_zero(A, 8 * (size_t)nlm));
-  OFF(results, put_zero(A, 8 * (7 * (size_t)npose + 9 * (size_t)nsb + 5 * (size_t)nlm + 9 * (size_t)std::max(w.n_imu, 0)) + 8));
+  OFF(results, put_zero(A, results_bytes(npose, nsb, nlm, w.n_imu) + 8));
   if (opt.debug_arrays) OFF(prof, put_zero(A, 8 * (64 + 4 * 160)));   // clock64() phase stamps + tile task timeline: diagnostics only
   OFF(ctrl, put_zero(A, sizeof(Ctrl)));
   OFF(imu_pose0, put_n(A, w.imu_pose0, (size_t)w.n_imu));
@@ -1067,12 +1067,19 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   {
     std::vector<ImuCacheD> caches((size_t)w.n_imu);
     if (!caches.empty()) std::memset(caches.data(), 0, sizeof(ImuCacheD) * caches.size());
-    if (w.imu_sb_ref && w.imu_sb_ref_valid)
-      for (int f = 0; f < w.n_imu; ++f)
-        if (w.imu_sb_ref_valid[f]) {
+    if (w.imu_sb_ref && w.imu_sb_ref_valid) {
+      for (int f = 0; f < w.n_imu; ++f) {
+        if (w.imu_sb_ref_valid[f] == 2 && w.imu_cache) {
+          // the preintegration itself (okvis_ba_fetch_imu_caches): valid as it stands, nothing is rebuilt on first use
+          std::memcpy(&caches[f], w.imu_cache + (size_t)OKVIS_BA_IMU_CACHE_DOUBLES * f, sizeof(ImuCacheD));
+          if (caches[f].valid != 1) return OKVIS_BA_ERR_ARG;   // (a record of a term that was never evaluated)
+          caches[f].redo_count = 0;
+        } else if (w.imu_sb_ref_valid[f]) {
           caches[f].valid = 2;
           for (int k = 0; k < 9; ++k) caches[f].sb_ref[k] = w.imu_sb_ref[9 * (size_t)f + k];
         }
+      }
+    }
     OFF(imu_cache, put(A, caches));
   }
   OFF(pprior_pose, put_n(A, w.pprior_pose, (size_t)w.n_pprior));
@@ -1877,7 +1884,7 @@ int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, doub
 static int stage_results(okvis_ba_solver* s, int w, const unsigned char** rec) {
   HostWin& H = s->wins[w];
   *rec = nullptr;
-  const size_t total = 56 * (size_t)H.n_pose + 72 * (size_t)H.n_sb + 40 * (size_t)H.n_lm + 72 * (size_t)H.n_imu;
+  const size_t total = results_bytes(H.n_pose, H.n_sb, H.n_lm, H.n_imu);
   if (total == 0) return OKVIS_BA_OK;
   if (s->res_staged && w == 0 && s->wins.size() == 1) {   // packed and copied by okvis_ba_finish already
     *rec = s->stage_res.data();
@@ -2000,6 +2007,18 @@ int okvis_ba_fetch_results(okvis_ba_solver* s, int w, double* pose, double* sb, 
   return OKVIS_BA_OK;
 }
 
+int okvis_ba_fetch_imu_caches(okvis_ba_solver* s, int w, double* caches) {
+  if (!s || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return s && !s->uploaded ? OKVIS_BA_ERR_STATE : OKVIS_BA_ERR_ARG;
+  if (!caches) return OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  HostWin& H = s->wins[w];
+  if (H.n_imu == 0) return OKVIS_BA_OK;
+  const unsigned char* st = nullptr;
+  if (int rc = stage_results(s, w, &st)) return rc;
+  std::memcpy(caches, st + results_bytes(H.n_pose, H.n_sb, H.n_lm, 0) + 72 * (size_t)H.n_imu, sizeof(ImuCacheD) * (size_t)H.n_imu);
+  return OKVIS_BA_OK;
+}
+
 int okvis_ba_begin(okvis_ba_solver* s) {
   if (s) s->acc_fresh = s->res_staged = s->mirror_fresh = false;
   if (!s) return OKVIS_BA_ERR_ARG;
@@ -2117,7 +2136,7 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
     }
     if (s->wins.size() == 1) {
       const HostWin& H0 = s->wins[0];
-      res_bytes = 56 * (size_t)H0.n_pose + 72 * (size_t)H0.n_sb + 40 * (size_t)H0.n_lm + 72 * (size_t)H0.n_imu;
+      res_bytes = results_bytes(H0.n_pose, H0.n_sb, H0.n_lm, H0.n_imu);
       if (res_bytes) {
         s->stage_res.resize(res_bytes);
         hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s->stream, s->d_wins, -1);

@@ -1546,6 +1546,12 @@ __global__ void pack_results_kernel(const WinPtrs* __restrict__ win, int acc) {
   for (int i = t; i < W.n_lm; i += nt) out[i] = W.quality[i];
   out += W.n_lm;
   for (int i = t; i < 9 * W.n_imu; i += nt) out[i] = W.imu_cache[i / 9].sb_ref[i % 9];
+  out += 9 * (size_t)W.n_imu;
+  {   // the preintegrations themselves (the records are whole doubles: Delta_q .. sb_ref, then the two flag words as one)
+    constexpr int CD = (int)(sizeof(ImuCacheD) / 8);
+    const double* src = reinterpret_cast<const double*>(W.imu_cache);
+    for (int i = t; i < CD * W.n_imu; i += nt) out[i] = src[i];
+  }
 }
 
 // landmark quality (Estimator.cpp:880-896): 3x3 eigenvalues of the un-robustified H_l of the accepted

@@ -39,7 +39,8 @@ struct WindowStore {
     std::vector<int64_t> s_t;
     std::vector<double> s_gyr, s_acc;
     double sb_ref[9];
-    uint8_t ref_valid;
+    uint8_t ref_valid;   // 0 none / 1 the reference bias / 2 the whole preintegration record (okvis_ba_window::imu_sb_ref_valid)
+    std::vector<double> cache;   // OKVIS_BA_IMU_CACHE_DOUBLES when ref_valid == 2 (kept allocated once it has been)
   };
   std::vector<Imu> imu;
   okvis_ba_imu_params imu_params{};
@@ -55,7 +56,7 @@ struct WindowStore {
   struct Buffers {
     std::vector<int32_t> f_ip0, f_is0, f_ip1, f_is1, f_sbegin, f_scount;
     std::vector<int64_t> f_t0, f_t1, f_st;
-    std::vector<double> f_gyr, f_acc, f_ref;
+    std::vector<double> f_gyr, f_acc, f_ref, f_cache;
     std::vector<uint8_t> f_refv;
     std::vector<int32_t> x_mp, x_ms, x_ml, x_mo, x_ord, x_lm, x_pose, x_ext, x_cam;
     std::vector<double> x_uv, x_sw;
@@ -143,7 +144,9 @@ struct WindowStore {
       put(m.s_gyr, w.imu_s_gyr + 3 * (size_t)b, 3 * (size_t)c);
       put(m.s_acc, w.imu_s_acc + 3 * (size_t)b, 3 * (size_t)c);
       m.ref_valid = (w.imu_sb_ref && w.imu_sb_ref_valid) ? w.imu_sb_ref_valid[f] : 0;
+      if (m.ref_valid > 2 || (m.ref_valid == 2 && !w.imu_cache)) return OKVIS_BA_ERR_ARG;
       for (int k = 0; k < 9; ++k) m.sb_ref[k] = (m.ref_valid && w.imu_sb_ref) ? w.imu_sb_ref[9 * (size_t)f + k] : 0.0;
+      if (m.ref_valid == 2) m.cache.assign(w.imu_cache + (size_t)OKVIS_BA_IMU_CACHE_DOUBLES * f, w.imu_cache + (size_t)OKVIS_BA_IMU_CACHE_DOUBLES * (f + 1));
     }
     imu_params = w.imu_params;
     put(pprior_pose, w.pprior_pose, (size_t)w.n_pprior); put(pprior_meas, w.pprior_meas, 7 * (size_t)w.n_pprior);
@@ -175,6 +178,10 @@ struct WindowStore {
     const size_t nf = imu.size();
     f_ip0.resize(nf); f_is0.resize(nf); f_ip1.resize(nf); f_is1.resize(nf); f_sbegin.resize(nf); f_scount.resize(nf);
     f_t0.resize(nf); f_t1.resize(nf); f_ref.resize(9 * nf); f_refv.resize(nf);
+    auto& f_cache = buf.f_cache;
+    bool any_cache = false;
+    for (size_t f = 0; f < nf; ++f) any_cache = any_cache || imu[f].ref_valid == 2;
+    f_cache.resize(any_cache ? (size_t)OKVIS_BA_IMU_CACHE_DOUBLES * nf : 0);
     f_st.clear(); f_gyr.clear(); f_acc.clear();
     for (size_t f = 0; f < nf; ++f) {
       const Imu& m = imu[f];
@@ -187,6 +194,7 @@ struct WindowStore {
       f_acc.insert(f_acc.end(), m.s_acc.begin(), m.s_acc.end());
       std::memcpy(&f_ref[9 * f], m.sb_ref, sizeof(m.sb_ref));
       f_refv[f] = m.ref_valid;
+      if (m.ref_valid == 2) std::memcpy(&f_cache[(size_t)OKVIS_BA_IMU_CACHE_DOUBLES * f], m.cache.data(), 8 * (size_t)OKVIS_BA_IMU_CACHE_DOUBLES);
     }
     w.n_pose = n_pose(); w.pose = pose.data(); w.pose_fixed = pose_fixed.data();
     w.n_sb = n_sb(); w.sb = sb.data(); w.sb_fixed = sb_fixed.data();
@@ -202,6 +210,7 @@ struct WindowStore {
     w.n_imu_samples = (int32_t)f_st.size(); w.imu_s_t = f_st.data(); w.imu_s_gyr = f_gyr.data(); w.imu_s_acc = f_acc.data();
     w.imu_params = imu_params;
     w.imu_sb_ref = f_ref.data(); w.imu_sb_ref_valid = f_refv.data();
+    w.imu_cache = any_cache ? f_cache.data() : nullptr;
     w.n_pprior = (int32_t)pprior_pose.size(); w.pprior_pose = pprior_pose.data(); w.pprior_meas = pprior_meas.data();
     w.pprior_sqrtinfo = pprior_sqrtinfo.data();
     w.n_sbprior = (int32_t)sbprior_sb.size(); w.sbprior_sb = sbprior_sb.data(); w.sbprior_meas = sbprior_meas.data();
@@ -478,9 +487,17 @@ struct WindowStore {
     if (b_sb) std::memcpy(sb.data(), rec + b_pose, b_sb);
     if (b_lm) std::memcpy(lm.data(), rec + b_pose + b_sb, b_lm);
     const unsigned char* r = rec + b_pose + b_sb + b_lm + b_q;
+    const unsigned char* rc = r + 72 * imu.size();   // the preintegration records behind the reference biases
     for (size_t f = 0; take_refs && f < imu.size(); ++f) {
       std::memcpy(imu[f].sb_ref, r + 72 * f, 72);
       imu[f].ref_valid = 1;
+      const unsigned char* c = rc + 8 * (size_t)OKVIS_BA_IMU_CACHE_DOUBLES * f;
+      int32_t valid;
+      std::memcpy(&valid, c + 8 * (size_t)(OKVIS_BA_IMU_CACHE_DOUBLES - 1), 4);   // (the record's last double holds its two flag words)
+      if (valid == 1) {
+        imu[f].cache.assign(reinterpret_cast<const double*>(c), reinterpret_cast<const double*>(c) + OKVIS_BA_IMU_CACHE_DOUBLES);
+        imu[f].ref_valid = 2;
+      }
     }
   }
 };

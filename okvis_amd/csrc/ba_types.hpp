@@ -85,6 +85,12 @@ struct ImuCacheD {
   int redo_count;
 };
 
+static_assert(sizeof(ImuCacheD) == 8 * OKVIS_BA_IMU_CACHE_DOUBLES, "the record okvis_ba_fetch_imu_caches hands out");
+// bytes of the packed results record (pack_results_kernel): pose | speed/bias | landmarks | quality | IMU reference biases | IMU caches
+__host__ __device__ inline size_t results_bytes(int n_pose, int n_sb, int n_lm, int n_imu) {
+  return 56 * (size_t)n_pose + 72 * (size_t)n_sb + 40 * (size_t)n_lm + (72 + sizeof(ImuCacheD)) * (size_t)(n_imu > 0 ? n_imu : 0);
+}
+
 // layout of WinPtrs::dec (doubles)
 enum { DEC_VALID = 0, DEC_SUMS = 1, DEC_DL = 7, DEC_LM = 19, DEC_COUNT = 32 };
 

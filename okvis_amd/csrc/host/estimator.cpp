@@ -452,7 +452,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
   i32.assign(24, {});
   i64.assign(4, {});
   u8.assign(3, {});
-  enum { F_POSE, F_SB, F_LM, F_INTR, F_UV, F_SW, F_GYR, F_ACC, F_PPM, F_PPS, F_SBM, F_SBS, F_RELS, F_MJ, F_ME, F_ML, F_SBREF };
+  enum { F_POSE, F_SB, F_LM, F_INTR, F_UV, F_SW, F_GYR, F_ACC, F_PPM, F_PPS, F_SBM, F_SBS, F_RELS, F_MJ, F_ME, F_ML, F_SBREF, F_ICACHE };
   enum { I_MODEL, I_OLM, I_OPOSE, I_OEXT, I_OCAM, I_IP0, I_IS0, I_IP1, I_IS1, I_SB, I_SC, I_PPP, I_SBP, I_R0, I_R1,
          I_MT, I_MI, I_MO };
   // parameter blocks (values: estimate, or the linearisation point of prior-connected blocks)
@@ -579,7 +579,9 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
     i32[I_SB].push_back((int)i64[2].size());
     i32[I_SC].push_back((int)f.meas.size());
     f64[F_SBREF].insert(f64[F_SBREF].end(), f.sbRef.begin(), f.sbRef.end());
-    u8[2].push_back(f.hasRef ? 1 : 0);
+    u8[2].push_back(f.hasRef ? (f.hasCache ? 2 : 1) : 0);
+    if (f.hasCache) f64[F_ICACHE].insert(f64[F_ICACHE].end(), f.cache.begin(), f.cache.end());
+    else f64[F_ICACHE].resize(f64[F_ICACHE].size() + OKVIS_BA_IMU_CACHE_DOUBLES, 0.0);
     for (const ImuMeasurement& m : f.meas) {
       i64[2].push_back(m.t_ns);
       f64[F_GYR].insert(f64[F_GYR].end(), m.gyr.begin(), m.gyr.end());
@@ -616,7 +618,7 @@ void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
   w.imu_pose0 = i32[I_IP0].data(); w.imu_sb0 = i32[I_IS0].data(); w.imu_pose1 = i32[I_IP1].data(); w.imu_sb1 = i32[I_IS1].data();
   w.imu_t0 = i64[0].data(); w.imu_t1 = i64[1].data(); w.imu_s_begin = i32[I_SB].data(); w.imu_s_count = i32[I_SC].data();
   w.n_imu_samples = (int)i64[2].size(); w.imu_s_t = i64[2].data(); w.imu_s_gyr = f64[F_GYR].data(); w.imu_s_acc = f64[F_ACC].data();
-  w.imu_sb_ref = f64[F_SBREF].data(); w.imu_sb_ref_valid = u8[2].data();
+  w.imu_sb_ref = f64[F_SBREF].data(); w.imu_sb_ref_valid = u8[2].data(); w.imu_cache = f64[F_ICACHE].data();
   if (!imuParametersVec_.empty()) {
     const ImuParameters& ip = imuParametersVec_[0];
     w.imu_params = okvis_ba_imu_params{ip.sigma_g_c, ip.sigma_a_c, ip.sigma_gw_c, ip.sigma_aw_c, ip.g, ip.g_max, ip.a_max};
@@ -713,10 +715,17 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
   for (size_t i = 0; i < S.sb.size(); ++i)
     std::copy(sb.begin() + 9 * i, sb.begin() + 9 * i + 9, sbBlocks_[S.sb[i]].x.begin());
   // the ImuError caches live on: remember the bias each one was (re)built at (window order = order of imuFactors_)
+  resCache_.resize((size_t)OKVIS_BA_IMU_CACHE_DOUBLES * S.imu.size());
+  if (!S.imu.empty()) check(okvis_ba_fetch_imu_caches(solver_, 0, resCache_.data()), "fetch_imu_caches");
   for (size_t i = 0; i < S.imu.size(); ++i) {
     ImuFactor& f = imuFactors_[i];
     std::copy(ref.begin() + 9 * i, ref.begin() + 9 * i + 9, f.sbRef.begin());
     f.hasRef = true;
+    const double* c = resCache_.data() + (size_t)OKVIS_BA_IMU_CACHE_DOUBLES * i;
+    int32_t valid;
+    std::memcpy(&valid, c + OKVIS_BA_IMU_CACHE_DOUBLES - 1, 4);   // (the record's flag word: 1 = evaluated since the upload)
+    f.hasCache = valid == 1;
+    if (f.hasCache) f.cache.assign(c, c + OKVIS_BA_IMU_CACHE_DOUBLES);
   }
   {
     // update landmarks: quality = sqrt(lambda_min)/sqrt(lambda_max) of the un-robustified H_l and the
@@ -1231,6 +1240,15 @@ std::string Estimator::debugCheckWindow() {
       !same(v.imu_s_t, f.imu_s_t, 8 * (size_t)v.n_imu_samples) || !same(v.imu_s_gyr, f.imu_s_gyr, 24 * (size_t)v.n_imu_samples) ||
       !same(v.imu_s_acc, f.imu_s_acc, 24 * (size_t)v.n_imu_samples))
     return "IMU terms";
+  // what the terms carry from the last optimisation: the flag, the reference bias and (flag 2) the preintegration record
+  for (int i = 0; i < v.n_imu; ++i) {
+    const int fv = v.imu_sb_ref_valid ? v.imu_sb_ref_valid[i] : 0, ff = f.imu_sb_ref_valid ? f.imu_sb_ref_valid[i] : 0;
+    if (fv != ff) return num("flag of an IMU term's preintegration", fv, ff);
+    if (fv && !same(v.imu_sb_ref + 9 * (size_t)i, f.imu_sb_ref + 9 * (size_t)i, 72)) return "reference bias of an IMU term";
+    if (fv == 2 && !same(v.imu_cache + (size_t)OKVIS_BA_IMU_CACHE_DOUBLES * i, f.imu_cache + (size_t)OKVIS_BA_IMU_CACHE_DOUBLES * i,
+                         8 * (size_t)OKVIS_BA_IMU_CACHE_DOUBLES))
+      return "preintegration record of an IMU term";
+  }
   if (!same(v.pprior_pose, f.pprior_pose, 4 * (size_t)v.n_pprior) || !same(v.pprior_meas, f.pprior_meas, 56 * (size_t)v.n_pprior) ||
       !same(v.pprior_sqrtinfo, f.pprior_sqrtinfo, 288 * (size_t)v.n_pprior))
     return "pose priors";

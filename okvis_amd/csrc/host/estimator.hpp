@@ -225,6 +225,11 @@ class Estimator {
     // reference bias of the factor's preintegration cache after the last optimize() (speedAndBiases_ref_)
     std::array<double, 9> sbRef{};
     bool hasRef = false;
+    // ... and the preintegration itself (okvis_ba_fetch_imu_caches): like the reference's ImuError object, the term keeps it between
+    // optimize() calls and hands it to every window it is part of (the optimised one and the marginalisation sub-window), so that
+    // nothing is re-preintegrated unless the bias moves past the threshold (ImuError.cpp:549)
+    std::vector<double> cache;
+    bool hasCache = false;
   };
   struct PosePrior {
     int block;
@@ -320,7 +325,7 @@ class Estimator {
   };
   PatchBuffers patchBuf_;
   std::array<double, 2> patchSplit_{};            // ms: describing the window (patch or flatten), handing it over
-  std::vector<double> resPose_, resSb_, resLm_, resQ_, resRef_;   // results of the last optimize() (kept: no allocation per frame)
+  std::vector<double> resPose_, resSb_, resLm_, resQ_, resRef_, resCache_;   // results of the last optimize() (kept: no allocation per frame)
   std::vector<MapPoint*> touchedLm_;              // landmarks with MapPoint::touched (nullptr = erased meanwhile)
   std::vector<int> erasedWinLm_;                  // window indices of landmarks erased from the map
   // the two logs of observation edits since the last hand-over (addObservation / removeObservation write them)

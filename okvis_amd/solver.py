@@ -219,6 +219,13 @@ class WindowBatch:
                                                   q.ctypes.data_as(_dp), ref.ctypes.data_as(_dp)), "fetch_results")
         return dict(pose=pose, sb=sb, lm=lm, quality=q, imu_sb_ref=ref)
 
+    def fetch_imu_caches(self, w: int = 0):
+        """okvis_ba_fetch_imu_caches: the preintegration records of window w's IMU terms, [n_imu, 290] (Window.imu_cache, flag 2)."""
+        from .window import IMU_CACHE_DOUBLES
+        out = np.zeros((self.windows[w].n_imu, IMU_CACHE_DOUBLES))
+        _lib.check(self._L.okvis_ba_fetch_imu_caches(self._h, w, out.ctypes.data_as(_dp)), "fetch_imu_caches")
+        return out
+
     def set_state(self, w: int, pose=None, sb=None, lm=None):
         def p(a):
             return None if a is None else np.ascontiguousarray(a, np.float64)

@@ -15,6 +15,7 @@ import numpy as np
 DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT, DIST_RADTAN8 = 0, 1, 2, 3
 BLOCK_POSE, BLOCK_SPEEDBIAS = 0, 1
 
+IMU_CACHE_DOUBLES = 290   # OKVIS_BA_IMU_CACHE_DOUBLES
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)
@@ -45,7 +46,7 @@ class WindowC(C.Structure):
         ("marg_dim", C.c_int32), ("marg_nblocks", C.c_int32), ("marg_block_type", _ip),
         ("marg_block_idx", _ip), ("marg_block_off", _ip), ("marg_J", _dp), ("marg_e0", _dp),
         ("marg_lin", _dp),
-        ("imu_sb_ref", _dp), ("imu_sb_ref_valid", _bp),
+        ("imu_sb_ref", _dp), ("imu_sb_ref_valid", _bp), ("imu_cache", _dp),
     ]
 
 
@@ -225,7 +226,8 @@ class Window:
     marg_e0: np.ndarray = field(default_factory=lambda: np.zeros(0))
     marg_lin: np.ndarray = field(default_factory=lambda: np.zeros((0, 9)))
     imu_sb_ref: np.ndarray = field(default_factory=lambda: np.zeros((0, 9)))       # [n_imu,9] or empty
-    imu_sb_ref_valid: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint8))
+    imu_sb_ref_valid: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint8))   # 0 / 1 (reference bias) / 2 (+ imu_cache)
+    imu_cache: np.ndarray = field(default_factory=lambda: np.zeros((0, IMU_CACHE_DOUBLES)))   # [n_imu, 290] or empty (WindowBatch.fetch_imu_caches)
     meta: dict = field(default_factory=dict)   # generator bookkeeping (truth etc.); never uploaded
 
     # ------------------------------------------------------------------------------------------
@@ -293,6 +295,7 @@ class Window:
         k["marg_lin"] = _f64(self.marg_lin, (-1, 9))
         k["imu_sb_ref"] = _f64(self.imu_sb_ref, (-1, 9))
         k["imu_sb_ref_valid"] = np.ascontiguousarray(self.imu_sb_ref_valid, np.uint8)
+        k["imu_cache"] = _f64(self.imu_cache, (-1, IMU_CACHE_DOUBLES))
 
         def p(name, typ):
             a = k[name]
@@ -326,6 +329,8 @@ class Window:
         w.marg_J = p("marg_J", _dp); w.marg_e0 = p("marg_e0", _dp); w.marg_lin = p("marg_lin", _dp)
         if k["imu_sb_ref"].shape[0] == w.n_imu and k["imu_sb_ref_valid"].size == w.n_imu and w.n_imu > 0:
             w.imu_sb_ref = p("imu_sb_ref", _dp); w.imu_sb_ref_valid = p("imu_sb_ref_valid", _bp)
+            if k["imu_cache"].shape[0] == w.n_imu:
+                w.imu_cache = p("imu_cache", _dp)
         return w, k
 
 
@@ -491,5 +496,6 @@ def window_from_c(w: WindowC) -> Window:
         marg_block_type=arr(w.marg_block_type, nb if md else 0, np.int32), marg_block_idx=arr(w.marg_block_idx, nb if md else 0, np.int32),
         marg_block_off=arr(w.marg_block_off, nb if md else 0, np.int32), marg_J=arr(w.marg_J, md * md, np.float64, (md, md)),
         marg_e0=arr(w.marg_e0, md, np.float64), marg_lin=arr(w.marg_lin, 9 * (nb if md else 0), np.float64, (nb if md else 0, 9)),
-        imu_sb_ref=arr(w.imu_sb_ref, 9 * ni, np.float64, (ni, 9)), imu_sb_ref_valid=arr(w.imu_sb_ref_valid, ni, np.uint8))
+        imu_sb_ref=arr(w.imu_sb_ref, 9 * ni, np.float64, (ni, 9)), imu_sb_ref_valid=arr(w.imu_sb_ref_valid, ni, np.uint8),
+        imu_cache=arr(w.imu_cache, IMU_CACHE_DOUBLES * ni, np.float64, (ni, IMU_CACHE_DOUBLES)))
     return out

@@ -282,6 +282,57 @@ def test_config_C_full_size(oracle):
     b.close(); bb.close()
 
 
+def test_imu_preintegration_travels_with_the_term():
+    """The reference's ImuError object keeps its preintegration between optimize() calls.  A window can hand over the record
+    okvis_ba_fetch_imu_caches gave out for the same term (flag 2): nothing is re-preintegrated on first use, and the numbers are the
+    ones the rebuild at the reference bias (flag 1) produces — bit for bit, through a whole optimisation; a bias beyond the threshold
+    still re-preintegrates (ImuError.cpp:549); a record of a term that was never evaluated is refused."""
+    w = synthetic.small_window(seed=62, K=5, L=60)
+    n = w.n_imu
+    b0 = _batch([w], debug_arrays=1)
+    b0.optimize(5)
+    res = b0.fetch_results(0)
+    caches = b0.fetch_imu_caches(0)
+    assert caches.shape == (n, 290) and np.array_equal(caches[:, 280:289], res["imu_sb_ref"])   # (the record ends with its reference bias)
+    b0.close()
+    import copy
+    nxt = copy.deepcopy(w)
+    nxt.pose, nxt.sb, nxt.lm = res["pose"], res["sb"], res["lm"]
+    nxt.imu_sb_ref = res["imu_sb_ref"]
+    runs = {}
+    for flag in (1, 2):
+        wi = copy.deepcopy(nxt)
+        wi.imu_sb_ref_valid = np.full(n, flag, np.uint8)
+        if flag == 2:
+            wi.imu_cache = caches
+        b = _batch([wi], debug_arrays=1)
+        b.begin()
+        redo_first = b.array("IMU_REDO_COUNT").copy()
+        lin = b.array("IMU_RESIDUAL").copy()
+        b.finish()
+        s = b.optimize(6)[0]
+        runs[flag] = (redo_first, lin, s, b.get_state(0), b.fetch_imu_caches(0))
+        b.close()
+    assert np.array_equal(runs[1][0], np.ones(n)) and np.array_equal(runs[2][0], np.zeros(n))   # rebuilt at the reference | kept
+    assert np.array_equal(runs[1][1], runs[2][1]) and runs[1][2] == runs[2][2]
+    for a, c in zip(runs[1][3], runs[2][3]):
+        assert np.array_equal(a, c)
+    assert np.array_equal(runs[1][4][:, :289], runs[2][4][:, :289])       # (the last double holds the flag word and the redo counter)
+    # a gyro bias beyond the threshold re-preintegrates although the record is there
+    far = copy.deepcopy(nxt)
+    far.imu_sb_ref_valid = np.full(n, 2, np.uint8); far.imu_cache = caches
+    far.sb = far.sb.copy(); far.sb[:, 3:6] += 5e-3
+    b = _batch([far], debug_arrays=1)
+    b.begin()
+    assert np.array_equal(b.array("IMU_REDO_COUNT"), np.ones(n))
+    b.finish(); b.close()
+    # a record that was never filled (flag word 0) must not travel with flag 2
+    bad = copy.deepcopy(nxt)
+    bad.imu_sb_ref_valid = np.full(n, 2, np.uint8); bad.imu_cache = np.zeros((n, 290))
+    with pytest.raises(Exception):
+        _batch([bad])
+
+
 def test_inherited_imu_reference_bias(oracle):
     """ImuError's preintegration cache survives optimize() calls in the reference (speedAndBiases_ref_): a window
     can hand over the reference bias of every factor.  Within the 1e-4 threshold the factor is evaluated with the

@@ -31,7 +31,7 @@ def test_patched_solver_equals_fresh_upload_bitwise(oracle, seed):
     assert np.array_equal(v.pose[:len(keep_pose)], pose_a[keep_pose])      # ... optimised values of what stayed ...
     assert np.array_equal(v.sb[:len(keep_sb)], sb_a[keep_sb]) and np.array_equal(v.lm[:len(keep_lm)], lm_a[keep_lm])
     assert np.array_equal(v.pose[len(keep_pose):], want.pose[len(keep_pose):])     # ... the given values of what arrived
-    assert np.array_equal(v.imu_sb_ref_valid, [1] * (v.n_imu - 1) + [0])           # kept IMU terms keep their reference bias
+    assert np.array_equal(v.imu_sb_ref_valid, [2] * (v.n_imu - 1) + [0])           # kept IMU terms keep their preintegration (flag 2)
     fresh = solver.WindowBatch([v], options=default_options())
     s1, s2 = pa.optimize(5)[0], fresh.optimize(5)[0]
     assert s1 == s2 and s1["iterations"] > 0 and s1["initial_cost"] != s0["final_cost"]

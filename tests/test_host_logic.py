@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), name
     assert set(_lib.SYMBOLS) == declared
-    assert L.okvis_ba_abi_version() == 5
+    assert L.okvis_ba_abi_version() == 6
 
 
 def test_struct_layout_matches_header():
@@ -155,7 +155,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
                            "-o", str(exe), "-L", libdir, "-lokvis_amd_ba", "-Wl,-rpath," + libdir])
     out = subprocess.check_output([str(exe)]).decode().split(None, 3)
-    assert int(out[0]) == 5 and int(out[1]) == 900
+    assert int(out[0]) == 6 and int(out[1]) == 900
     import torch
     if not torch.cuda.is_available():
         assert int(out[2]) == -4 and "no CPU path" in out[3]      # fails loudly without a GPU
