@@ -142,6 +142,9 @@ struct okvis_ba_solver {
   bool res_staged = false;  // stage_res holds window 0's packed results as of the last okvis_ba_finish (single-window solvers)
   StageVec stage_res;
   StageVec stage_marg;           // host-written part of okvis_ba_marginalize's scratch block
+  StageVec stage_pre;            // first preintegrations started at upload (imu_pre_kernel): the staged block and its device copy
+  unsigned char* d_pre = nullptr;
+  size_t pre_capacity = 0;
   bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0, max_spart_stride = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
@@ -1509,6 +1512,7 @@ int okvis_ba_destroy(okvis_ba_solver* s) {
   (void)hipSetDevice(s->device);
   destroy_graphs(s);
   if (s->d_arena) (void)hipFree(s->d_arena);
+  if (s->d_pre) (void)hipFree(s->d_pre);
   if (s->d_wins) (void)hipFree(s->d_wins);
   if (s->d_opt) (void)hipFree(s->d_opt);
   if (s->h_ctrl_stage) (void)hipHostFree(s->h_ctrl_stage);
@@ -1577,6 +1581,100 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
   return OKVIS_BA_OK;
 }
 
+// IMU terms that arrive without a preintegration (flag 0) get theirs started now, at the bias their first evaluation will see (the
+// uploaded value of their first speed/bias block), so that it runs while the host builds the index lists (imu_pre_kernel,
+// ba_linearize2.hpp).  A handful of terms only — the new term of a sliding window; a batch of fresh windows re-preintegrates inside
+// its first linearise launch as before (hundreds of terms fill the device either way).  Returns the number started; where[k] =
+// (window, term) and the device records wait at *src for imu_pre_place_kernel.  OKVIS_BA_NO_PRE switches it off (A/B).
+constexpr int PRE_MAX_TERMS = 8;
+static int pre_launch(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows, const int2** where_dev, const ImuCacheD** src_dev) {
+  static const bool off = std::getenv("OKVIS_BA_NO_PRE") != nullptr;
+  if (off) return 0;
+  struct Item {
+    int w, f;
+  };
+  Item items[PRE_MAX_TERMS];
+  int K = 0;
+  size_t samples = 0;
+  for (int i = 0; i < n_windows; ++i) {
+    const okvis_ba_window& w = windows[i];
+    if (w.n_imu <= 0) continue;
+    if (!w.imu_pose0 || !w.imu_sb0 || !w.imu_t0 || !w.imu_t1 || !w.imu_s_begin || !w.imu_s_count || !w.imu_s_t || !w.imu_s_gyr || !w.imu_s_acc || !w.sb)
+      return 0;   // (the index build reports it)
+    for (int f = 0; f < w.n_imu; ++f) {
+      if (w.imu_sb_ref && w.imu_sb_ref_valid && w.imu_sb_ref_valid[f]) continue;
+      const int64_t b = w.imu_s_begin[f], c = w.imu_s_count[f];
+      if (w.imu_sb0[f] < 0 || w.imu_sb0[f] >= w.n_sb || b < 0 || c < 2 || c > MAX_IMU_SAMPLES || b + c > (int64_t)w.n_imu_samples) return 0;
+      if (!(w.imu_s_t[b + c - 1] >= w.imu_t1[f])) return 0;   // (ImuError::redoPreintegration's -1: the upload refuses the window)
+      if (K == PRE_MAX_TERMS) return 0;
+      items[K++] = Item{i, f};
+      samples += (size_t)c;
+    }
+  }
+  if (K == 0) return 0;
+  // the staged block: stand-in window records | biases | (window, term) | t0 | t1 | sample begin (0) | sample count | samples | records
+  auto up8 = [](size_t x) { return (x + 7) & ~size_t(7); };
+  const size_t o_mini = 0, o_sb = o_mini + sizeof(WinPtrs) * K, o_where = o_sb + 72 * (size_t)K, o_t0 = o_where + sizeof(int2) * K,
+               o_t1 = o_t0 + 8 * (size_t)K, o_beg = o_t1 + 8 * (size_t)K, o_cnt = up8(o_beg + 4 * (size_t)K), o_st = up8(o_cnt + 4 * (size_t)K),
+               o_gyr = o_st + 8 * samples, o_acc = o_gyr + 24 * samples, o_rec = o_acc + 24 * samples, total = o_rec + sizeof(ImuCacheD) * K;
+  if (total > s->pre_capacity) {
+    if (s->d_pre) (void)hipFree(s->d_pre);
+    s->d_pre = nullptr;
+    s->pre_capacity = 0;
+    if (hipMalloc(&s->d_pre, 2 * total) != hipSuccess) return 0;
+    s->pre_capacity = 2 * total;
+  }
+  s->stage_pre.resize(total);
+  unsigned char* h = s->stage_pre.data();
+  unsigned char* d = s->d_pre;
+  std::memset(h, 0, total);
+  size_t at = 0;   // samples placed so far
+  for (int k = 0; k < K; ++k) {
+    const okvis_ba_window& w = windows[items[k].w];
+    const int f = items[k].f, b = w.imu_s_begin[f], c = w.imu_s_count[f];
+    WinPtrs P;
+    std::memset(&P, 0, sizeof(P));
+    P.n_imu = 1;
+    P.imu.sigma_g_c = w.imu_params.sigma_g_c; P.imu.sigma_a_c = w.imu_params.sigma_a_c;
+    P.imu.sigma_gw_c = w.imu_params.sigma_gw_c; P.imu.sigma_aw_c = w.imu_params.sigma_aw_c;
+    P.imu.g = w.imu_params.g; P.imu.g_max = w.imu_params.g_max; P.imu.a_max = w.imu_params.a_max;
+    OFF(imu_t0, (size_t)(uintptr_t)(d + o_t0 + 8 * (size_t)k));
+    OFF(imu_t1, (size_t)(uintptr_t)(d + o_t1 + 8 * (size_t)k));
+    OFF(imu_s_begin, (size_t)(uintptr_t)(d + o_beg + 4 * (size_t)k));
+    OFF(imu_s_count, (size_t)(uintptr_t)(d + o_cnt + 4 * (size_t)k));
+    OFF(imu_s_t, (size_t)(uintptr_t)(d + o_st + 8 * at));
+    OFF(imu_s_gyr, (size_t)(uintptr_t)(d + o_gyr + 24 * at));
+    OFF(imu_s_acc, (size_t)(uintptr_t)(d + o_acc + 24 * at));
+    OFF(imu_cache, (size_t)(uintptr_t)(d + o_rec + sizeof(ImuCacheD) * (size_t)k));
+    std::memcpy(h + o_mini + sizeof(WinPtrs) * (size_t)k, &P, sizeof(P));
+    std::memcpy(h + o_sb + 72 * (size_t)k, w.sb + 9 * (size_t)w.imu_sb0[f], 72);
+    const int2 wf = make_int2(items[k].w, f);
+    std::memcpy(h + o_where + sizeof(int2) * (size_t)k, &wf, sizeof(wf));
+    const long long t0 = w.imu_t0[f], t1 = w.imu_t1[f];
+    std::memcpy(h + o_t0 + 8 * (size_t)k, &t0, 8);
+    std::memcpy(h + o_t1 + 8 * (size_t)k, &t1, 8);
+    const int32_t cnt = c;
+    std::memcpy(h + o_cnt + 4 * (size_t)k, &cnt, 4);
+    for (int j = 0; j < c; ++j) {
+      const long long t = w.imu_s_t[b + j];
+      std::memcpy(h + o_st + 8 * (at + j), &t, 8);
+    }
+    std::memcpy(h + o_gyr + 24 * at, w.imu_s_gyr + 3 * (size_t)b, 24 * (size_t)c);
+    std::memcpy(h + o_acc + 24 * at, w.imu_s_acc + 3 * (size_t)b, 24 * (size_t)c);
+    at += (size_t)c;
+  }
+  // On the solver's own stream (idle here: upload_impl has waited for it, so the block of the previous call is no longer read).
+  // A stream of their own with an event in front of imu_pre_place_kernel was measured too: the arena copy then no longer
+  // queues up behind the recursion, but the cross-stream wait costs what that buys (replay optimize() 0.91 against 0.89 ms).
+  if (hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s->stream) != hipSuccess) return 0;
+  hipLaunchKernelGGL(imu_pre_kernel, dim3((unsigned)K), dim3(IMU_THREADS), small_smem(), s->stream, reinterpret_cast<const WinPtrs*>(d + o_mini),
+                     reinterpret_cast<const double*>(d + o_sb));
+  if (hipGetLastError() != hipSuccess) return 0;
+  *where_dev = reinterpret_cast<const int2*>(d + o_where);
+  *src_dev = reinterpret_cast<const ImuCacheD*>(d + o_rec);
+  return K;
+}
+
 static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows) {
   const auto t_enter = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
@@ -1592,6 +1690,9 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     ~GiveBack() { a.swap(b); }
   } give_back{A.host, s->stage};
   std::vector<HostWin> wins(n_windows);
+  const int2* pre_where = nullptr;
+  const ImuCacheD* pre_src = nullptr;
+  const int n_pre = pre_launch(s, n_windows, windows, &pre_where, &pre_src);   // (runs on the device while the lists are built)
   const bool dbg_t = std::getenv("OKVIS_BA_DEBUG_UPLOAD") != nullptr;
   const auto t_u0 = std::chrono::steady_clock::now();
   // the piece path of the linearise launch (ba_linearize2.hpp) unless a window of the batch does not fit it (free extrinsics,
@@ -1672,6 +1773,10 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     std::memcpy(s->stage_small.data() + wb, &d, sizeof(d));
     HIP_TRY(hipMemcpyAsync(s->d_wins, s->stage_small.data(), wb, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->d_opt, s->stage_small.data() + wb, sizeof(OptD), hipMemcpyHostToDevice, s->stream));
+  }
+  if (n_pre > 0) {   // the records started before the index build take their places in the window
+    hipLaunchKernelGGL(imu_pre_place_kernel, dim3((unsigned)n_pre), dim3(64), 0, s->stream, s->d_wins, pre_where, pre_src);
+    HIP_TRY(hipGetLastError());
   }
   for (int i = 0; i < n_windows; ++i)
     if (wins[i].h0_on_device) {

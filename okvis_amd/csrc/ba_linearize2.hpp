@@ -606,4 +606,21 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void small_kernel(const WinPtrs* __
   small_body(wins[blockIdx.y], init, blockIdx.x, smem);
 }
 
+// First preintegration of IMU terms that arrive without one (okvis_ba_window::imu_sb_ref_valid = 0), started by okvis_ba_upload /
+// okvis_ba_patch_window BEFORE the host builds the window's index lists, so that the 0.1 ms recursion runs while the host works
+// instead of stretching the first linearise launch of the next optimisation.  Workgroup k integrates the one term of the
+// stand-in window record mini[k] (its IMU arrays, noise parameters and cache pointer; everything else unset) at the bias sb0s[9 k ..]
+// — imu_redo itself, so the record is the one the first evaluation would have built at that bias; imu_pre_place_kernel then
+// copies it over the term's (empty) record in the uploaded window, behind the arena copy on the same stream.
+__global__ __launch_bounds__(IMU_THREADS, 2) void imu_pre_kernel(const WinPtrs* __restrict__ mini, const double* __restrict__ sb0s) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  imu_redo(mini[blockIdx.x], 0, sb0s + 9 * (size_t)blockIdx.x, smem, threadIdx.x);
+}
+__global__ void imu_pre_place_kernel(const WinPtrs* __restrict__ wins, const int2* __restrict__ where, const ImuCacheD* __restrict__ src) {
+  const int2 wf = where[blockIdx.x];
+  const double* s = reinterpret_cast<const double*>(src + blockIdx.x);
+  auto d = reinterpret_cast<BA_G double*>(wins[wf.x].imu_cache + wf.y);
+  for (int i = threadIdx.x; i < (int)(sizeof(ImuCacheD) / 8); i += blockDim.x) d[i] = s[i];
+}
+
 }  // namespace ba

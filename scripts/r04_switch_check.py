@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A batch of windows through optimize() in both trust-region modes; the final states and summaries go to an .npz so that two
-runs (OKVIS_BA_NO_MERGE_SMALL set / not set) can be compared bit for bit:  r04_merge_check.py run out.npz | cmp a.npz b.npz"""
+"""A batch of windows (CHECK_WINDOWS, default 48) through optimize() in both trust-region modes; the final states and summaries go to
+an .npz so that two runs with a switch of the solver set / not set (an environment variable read once per process, e.g.
+OKVIS_BA_NO_PRE) can be compared bit for bit:  r04_merge_check.py run out.npz | cmp a.npz b.npz"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +13,8 @@ def run(out):
     from okvis_amd.window import default_options
     res = {}
     n = int(os.environ.get("CHECK_WINDOWS", "48"))
-    wins = [synthetic.make_window(10, 400, 1.0, 9_100_000 + i) for i in range(n - 8)] + \
-           [synthetic.make_window(6 + i % 3, 150 + 20 * i, 0.6, 9_200_000 + i) for i in range(8)]
+    wins = ([synthetic.make_window(10, 400, 1.0, 9_100_000 + i) for i in range(max(0, n - 8))] +
+            [synthetic.make_window(6 + i % 3, 150 + 20 * i, 0.6, 9_200_000 + i) for i in range(8)])[-n:]
     for mode in ("dogleg", "gn"):
         o = default_options()
         if mode == "gn":
