@@ -245,3 +245,50 @@ def test_store_rejects_out_of_range_indices():
         with pytest.raises(BackendError):
             solver.WindowStore(broken(field, idx, value))
     solver.WindowStore(base).close()   # the untouched window is still accepted
+
+
+def test_preintegration_records_stay_with_their_terms():
+    """okvis_ba_window::imu_cache (flag 2): the container keeps a term's preintegration record and its reference bias through edits —
+    the term that leaves takes its record with it, the one that arrives has none — and refuses flags it cannot honour."""
+    A, B = sliding_pair(seed=77, K=5, L=60)
+    w = A.window()
+    n = w.n_imu
+    rng = np.random.default_rng(5)
+    w.imu_sb_ref = rng.standard_normal((n, 9))
+    w.imu_cache = rng.standard_normal((n, 290))
+    w.imu_sb_ref_valid = np.array([2, 1, 0, 2][:n] + [2] * max(0, n - 4), np.uint8)
+    st = solver.WindowStore(w)
+    v = st.view()
+    assert np.array_equal(v.imu_sb_ref_valid, w.imu_sb_ref_valid)
+    for f in range(n):
+        if w.imu_sb_ref_valid[f]:
+            assert np.array_equal(v.imu_sb_ref[f], w.imu_sb_ref[f])
+        if w.imu_sb_ref_valid[f] == 2:
+            assert np.array_equal(v.imu_cache[f], w.imu_cache[f])
+    assert st.patch(patch_between(A, B)) == 0
+    got = st.view()
+    kept = [f for f in range(n) if imu_term_key(w, f) in {imu_term_key(got, g) for g in range(got.n_imu)}]
+    assert 0 < len(kept) < n and got.n_imu == len(kept) + 1
+    for g in range(got.n_imu):
+        src = [f for f in kept if imu_term_key(w, f) == imu_term_key(got, g)]
+        if not src:
+            assert got.imu_sb_ref_valid[g] == 0                       # the new term: its first evaluation integrates
+            continue
+        f = src[0]
+        assert got.imu_sb_ref_valid[g] == w.imu_sb_ref_valid[f]
+        if w.imu_sb_ref_valid[f]:
+            assert np.array_equal(got.imu_sb_ref[g], w.imu_sb_ref[f])
+        if w.imu_sb_ref_valid[f] == 2:
+            assert np.array_equal(got.imu_cache[g], w.imu_cache[f])
+    st.close()
+    bad = A.window()
+    bad.imu_sb_ref = np.zeros((n, 9)); bad.imu_sb_ref_valid = np.full(n, 2, np.uint8)    # flag 2 without the records
+    with pytest.raises(Exception):
+        solver.WindowStore(bad)
+    bad.imu_cache = np.zeros((n, 290)); bad.imu_sb_ref_valid = np.full(n, 3, np.uint8)   # no such flag
+    with pytest.raises(Exception):
+        solver.WindowStore(bad)
+
+
+def imu_term_key(w, f):
+    return (int(w.imu_t0[f]), int(w.imu_t1[f]))
