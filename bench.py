@@ -475,6 +475,9 @@ def main():
             fopt = default_options()
             bf = solver.WindowBatch([wf], device=local_rank, options=fopt, patchable=True)
             bf.optimize(3)
+            # (like okvis_amd::Estimator, the caller hands every IMU term's preintegration back with the window: okvis_ba_fetch_imu_caches)
+            res0 = bf.fetch_results(0)
+            wf.imu_sb_ref, wf.imu_cache, wf.imu_sb_ref_valid = res0["imu_sb_ref"], bf.fetch_imu_caches(0), np.full(wf.n_imu, 2, np.uint8)
             t_up, t_patch, t_opt = [], [], []
             import ctypes as C
             pc, keep_p = pf.as_c()
@@ -510,7 +513,7 @@ def main():
                           "upload_ms": float(np.median(t_up)) * 1e3, "optimize10_ms": float(np.median(t_opt)) * 1e3,
                           "patch_newest_frame_ms": float(np.median(t_patch)) * 1e3, "observations_after_patch": int(n_obs_after),
                           "marginalize_ms": float(np.median(t_marg)) * 1e3, "marginalize_kept_dim": int(gm["dim"]),
-                          "note": "host wall clock through ctypes; upload = okvis_ba_upload (index build + arena fill), patch = "
+                          "note": "host wall clock through ctypes; upload = okvis_ba_upload (index build + arena fill; the IMU terms carry their preintegration records), patch = "
                                   "okvis_ba_patch_window replacing the newest frame with its observations and IMU term (container edit + "
                                   "the same index build; the blocks that stay keep the device's values), marginalize = one "
                                   "okvis_ba_marginalize call on a 6-frame sub-window (150 landmarks, one pose and two speed/bias blocks eliminated)"}

@@ -1616,18 +1616,19 @@ static int pre_launch(okvis_ba_solver* s, int n_windows, const okvis_ba_window* 
   auto up8 = [](size_t x) { return (x + 7) & ~size_t(7); };
   const size_t o_mini = 0, o_sb = o_mini + sizeof(WinPtrs) * K, o_where = o_sb + 72 * (size_t)K, o_t0 = o_where + sizeof(int2) * K,
                o_t1 = o_t0 + 8 * (size_t)K, o_beg = o_t1 + 8 * (size_t)K, o_cnt = up8(o_beg + 4 * (size_t)K), o_st = up8(o_cnt + 4 * (size_t)K),
-               o_gyr = o_st + 8 * samples, o_acc = o_gyr + 24 * samples, o_rec = o_acc + 24 * samples, total = o_rec + sizeof(ImuCacheD) * K;
-  if (total > s->pre_capacity) {
-    if (s->d_pre) (void)hipFree(s->d_pre);
-    s->d_pre = nullptr;
-    s->pre_capacity = 0;
-    if (hipMalloc(&s->d_pre, 2 * total) != hipSuccess) return 0;
-    s->pre_capacity = 2 * total;
+               o_gyr = o_st + 8 * samples, o_acc = o_gyr + 24 * samples, total = o_acc + 24 * samples;
+  // The device reads the block where the host writes it: page-locked host memory is mapped into the device's address space, the
+  // few KB cross PCIe once, coalesced, and the host saves the copy call.  Only the records live in device memory (imu_redo writes
+  // every field but the counter of re-preintegrations, which it counts up: imu_pre_place_kernel sets that to 1).
+  if (!s->d_pre) {
+    if (hipMalloc(&s->d_pre, sizeof(ImuCacheD) * PRE_MAX_TERMS) != hipSuccess) return 0;
+    s->pre_capacity = sizeof(ImuCacheD) * PRE_MAX_TERMS;
   }
-  s->stage_pre.resize(total);
+  if (s->stage_pre.size() < total) s->stage_pre.resize(total + total / 2);
   unsigned char* h = s->stage_pre.data();
-  unsigned char* d = s->d_pre;
-  std::memset(h, 0, total);
+  unsigned char* d = h;                // (inputs: the staging block itself)
+  unsigned char* rec = s->d_pre;       // (outputs)
+  std::memset(h, 0, o_st);             // (the fixed-size head; the samples are written in full below)
   size_t at = 0;   // samples placed so far
   for (int k = 0; k < K; ++k) {
     const okvis_ba_window& w = windows[items[k].w];
@@ -1645,7 +1646,7 @@ static int pre_launch(okvis_ba_solver* s, int n_windows, const okvis_ba_window* 
     OFF(imu_s_t, (size_t)(uintptr_t)(d + o_st + 8 * at));
     OFF(imu_s_gyr, (size_t)(uintptr_t)(d + o_gyr + 24 * at));
     OFF(imu_s_acc, (size_t)(uintptr_t)(d + o_acc + 24 * at));
-    OFF(imu_cache, (size_t)(uintptr_t)(d + o_rec + sizeof(ImuCacheD) * (size_t)k));
+    OFF(imu_cache, (size_t)(uintptr_t)(rec + sizeof(ImuCacheD) * (size_t)k));
     std::memcpy(h + o_mini + sizeof(WinPtrs) * (size_t)k, &P, sizeof(P));
     std::memcpy(h + o_sb + 72 * (size_t)k, w.sb + 9 * (size_t)w.imu_sb0[f], 72);
     const int2 wf = make_int2(items[k].w, f);
@@ -1666,12 +1667,11 @@ static int pre_launch(okvis_ba_solver* s, int n_windows, const okvis_ba_window* 
   // On the solver's own stream (idle here: upload_impl has waited for it, so the block of the previous call is no longer read).
   // A stream of their own with an event in front of imu_pre_place_kernel was measured too: the arena copy then no longer
   // queues up behind the recursion, but the cross-stream wait costs what that buys (replay optimize() 0.91 against 0.89 ms).
-  if (hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s->stream) != hipSuccess) return 0;
   hipLaunchKernelGGL(imu_pre_kernel, dim3((unsigned)K), dim3(IMU_THREADS), small_smem(), s->stream, reinterpret_cast<const WinPtrs*>(d + o_mini),
                      reinterpret_cast<const double*>(d + o_sb));
   if (hipGetLastError() != hipSuccess) return 0;
   *where_dev = reinterpret_cast<const int2*>(d + o_where);
-  *src_dev = reinterpret_cast<const ImuCacheD*>(d + o_rec);
+  *src_dev = reinterpret_cast<const ImuCacheD*>(rec);
   return K;
 }
 

@@ -620,7 +620,11 @@ __global__ void imu_pre_place_kernel(const WinPtrs* __restrict__ wins, const int
   const int2 wf = where[blockIdx.x];
   const double* s = reinterpret_cast<const double*>(src + blockIdx.x);
   auto d = reinterpret_cast<BA_G double*>(wins[wf.x].imu_cache + wf.y);
-  for (int i = threadIdx.x; i < (int)(sizeof(ImuCacheD) / 8); i += blockDim.x) d[i] = s[i];
+  for (int i = threadIdx.x; i < (int)(sizeof(ImuCacheD) / 8) - 1; i += blockDim.x) d[i] = s[i];
+  if (threadIdx.x == 0) {   // (the last double holds the two counters: valid since its first preintegration, which was one)
+    wins[wf.x].imu_cache[wf.y].valid = 1;
+    wins[wf.x].imu_cache[wf.y].redo_count = 1;
+  }
 }
 
 }  // namespace ba
