@@ -482,6 +482,15 @@ typedef struct okvis_ba_marg_result {
 } okvis_ba_marg_result;
 
 int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* result);
+/* The same call in two halves, for a caller that has work of its own to do while the device computes (the reference's
+ * applyMarginalizationStrategy goes on to delete what was marginalised, Estimator.cpp:694-745, and the frontend adds the next frame
+ * before the prior is read again).  _begin checks the arguments, copies what it needs of `spec`, enqueues everything and returns
+ * with the blocks the new prior connects (result->dim, nblocks, block_type / block_idx / block_off: known without the numbers);
+ * _end waits and fills H, b0, J, e0, rank, sweeps of a result with the same capacities (it may be the same struct).  Between
+ * the two the solver accepts no upload and hands out no results (OKVIS_BA_ERR_STATE); sizes beyond the LDS route are waited for
+ * in _begin (their fall-back needs the call's arguments).  A numeric failure is reported by _end (OKVIS_BA_ERR_NUMERIC). */
+int okvis_ba_marginalize_begin(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* result);
+int okvis_ba_marginalize_end(okvis_ba_solver* s, okvis_ba_marg_result* result);
 
 /* ---- multi-GPU driver --------------------------------------------------------------
  * Windows are independent units: window i of a job runs on rank i mod world, one process per GPU, no data-path

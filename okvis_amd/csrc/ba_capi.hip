@@ -142,6 +142,13 @@ struct okvis_ba_solver {
   bool res_staged = false;  // stage_res holds window 0's packed results as of the last okvis_ba_finish (single-window solvers)
   StageVec stage_res;
   StageVec stage_marg;           // host-written part of okvis_ba_marginalize's scratch block
+  // okvis_ba_marginalize_begin without its _end yet: what _end needs to hand the numbers over (the kept blocks are known at begin)
+  struct MargPending {
+    bool active = false, synced = false;
+    int w = 0, na = 0;
+    size_t nn = 0, n1 = 0, out_bytes = 0;
+    std::vector<int> bt, bi, bo;
+  } marg_pending;
   StageVec stage_pre;            // first preintegrations started at upload (imu_pre_kernel): the staged block and its device copy
   unsigned char* d_pre = nullptr;
   size_t pre_capacity = 0;
@@ -1676,6 +1683,7 @@ static int pre_launch(okvis_ba_solver* s, int n_windows, const okvis_ba_window* 
 }
 
 static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows) {
+  if (s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first)
   const auto t_enter = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1989,6 +1997,7 @@ int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, doub
 static int stage_results(okvis_ba_solver* s, int w, const unsigned char** rec) {
   HostWin& H = s->wins[w];
   *rec = nullptr;
+  if (s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: its numbers wait in the same staging)
   const size_t total = results_bytes(H.n_pose, H.n_sb, H.n_lm, H.n_imu);
   if (total == 0) return OKVIS_BA_OK;
   if (s->res_staged && w == 0 && s->wins.size() == 1) {   // packed and copied by okvis_ba_finish already
@@ -2634,9 +2643,14 @@ int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* r
 // the landmarks (schur_kernel in marg_mode), export the dense system (solve_kernel final_only = 2), then the
 // dense elimination + eigen-decomposition (marg_dense_kernel).
 int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* res) {
+  if (int rc = okvis_ba_marginalize_begin(s, w, spec, res)) return rc;
+  return okvis_ba_marginalize_end(s, res);
+}
+
+int okvis_ba_marginalize_begin(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* res) {
   if (s) s->acc_fresh = false;
   if (!s || !spec || !res) return OKVIS_BA_ERR_ARG;
-  if (!s->uploaded) return OKVIS_BA_ERR_STATE;
+  if (!s->uploaded || s->marg_pending.active) return OKVIS_BA_ERR_STATE;
   if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
   HostWin& H = s->wins[w];
   if (H.marg_dim != 0) return OKVIS_BA_ERR_ARG;                    // the previous prior comes in through spec
@@ -2848,10 +2862,12 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
   int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   s->stage_dl.resize(out_bytes + sizeof(info) + sizeof(int));
   int* const tiles_ok = reinterpret_cast<int*>(s->stage_dl.data() + out_bytes + sizeof(info));
+  // (the tiled route may have to fall back on the single workgroup, which needs this call's arguments: it is waited for here;
+  //  the route of the pipeline's sizes only enqueues the copy and leaves the wait to okvis_ba_marginalize_end)
   auto fetch = [&]() -> hipError_t {
     hipError_t e = hipMemcpyAsync(s->stage_dl.data(), outp, out_bytes + sizeof(info), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess && tiles) e = hipMemcpyAsync(tiles_ok, mt.ok, sizeof(int), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess && tiles) e = hipStreamSynchronize(s->stream);
     return e;
   };
   *tiles_ok = 1;
@@ -2870,6 +2886,36 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
     HIP_TRY(e);
     s->marg_tiles_fallbacks++;
   }
+  // what is known without the numbers: the blocks the new prior connects
+  res->dim = na;
+  res->nblocks = (int)bt.size();
+  for (size_t k = 0; k < bt.size(); ++k) {
+    res->block_type[k] = bt[k];
+    res->block_idx[k] = bi[k];
+    res->block_off[k] = bo[k];
+  }
+  okvis_ba_solver::MargPending& mp = s->marg_pending;
+  mp.active = true;
+  mp.synced = tiles;
+  mp.w = w, mp.na = na, mp.nn = nn, mp.n1 = n1, mp.out_bytes = out_bytes;
+  mp.bt.swap(bt), mp.bi.swap(bi), mp.bo.swap(bo);
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_marginalize_end(okvis_ba_solver* s, okvis_ba_marg_result* res) {
+  if (!s || !res) return OKVIS_BA_ERR_ARG;
+  okvis_ba_solver::MargPending& mp = s->marg_pending;
+  if (!mp.active) return OKVIS_BA_ERR_STATE;
+  mp.active = false;   // (whatever happens below, the call is over)
+  HIP_TRY(hipSetDevice(s->device));
+  if (!mp.synced) HIP_TRY(hipStreamSynchronize(s->stream));
+  const int na = mp.na;
+  const size_t nn = mp.nn, n1 = mp.n1, out_bytes = mp.out_bytes;
+  const std::vector<int>&bt = mp.bt, &bi = mp.bi, &bo = mp.bo;
+  HostWin& H = s->wins[mp.w];
+  if (na > res->capacity_dim || (int)bt.size() > res->capacity_blocks) return OKVIS_BA_ERR_ARG;
+  if (na > 0 && (!res->H || !res->b0 || !res->J || !res->e0 || !res->block_type || !res->block_idx || !res->block_off)) return OKVIS_BA_ERR_ARG;
+  int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::memcpy(info, s->stage_dl.data() + out_bytes, sizeof(info));
   if (na > 0) {
     const double* h = reinterpret_cast<const double*>(s->stage_dl.data());

@@ -77,6 +77,7 @@ Estimator::Estimator(int device) : device_(device) {
 }
 
 Estimator::~Estimator() {
+  if (priorPending_ && margSolver_) (void)okvis_ba_marginalize_end(margSolver_, &margRes_);   // (nobody reads the numbers any more)
   if (solver_) okvis_ba_destroy(solver_);
   if (margSolver_) okvis_ba_destroy(margSolver_);
   if (dryStore_) okvis_ba_store_destroy(dryStore_);
@@ -441,7 +442,28 @@ Estimator::WindowSel Estimator::selectAll() const {
   return sel;
 }
 
+void Estimator::resolvePrior() const {
+  if (!priorPending_) return;
+  priorPending_ = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = okvis_ba_marginalize_end(margSolver_, &margRes_);
+  if (rc != OKVIS_BA_OK)
+    throw Exception(std::string("okvis_amd::Estimator: the marginalisation enqueued by applyMarginalizationStrategy failed (") +
+                    okvis_ba_error_string(rc) + "); its deletions cannot be taken back");
+  const size_t n = (size_t)margRes_.dim;
+  if (prior_.dim > 0) {   // (a prior without residuals was dropped at once, Estimator.cpp:747-749)
+    prior_.H.assign(margH_.begin(), margH_.begin() + n * n);
+    prior_.b0.assign(margB_.begin(), margB_.begin() + n);
+    prior_.J.assign(margJ_.begin(), margJ_.begin() + n * n);
+    prior_.e0.assign(margE_.begin(), margE_.begin() + n);
+  }
+  margInfo_[2] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  margInfo_[3] = (double)margRes_.sweeps[0];
+  margInfo_[4] = (double)margRes_.sweeps[1];
+}
+
 void Estimator::flatten(const WindowSel& sel, FlatWindow& fw) const {
+  if (sel.withPrior) resolvePrior();
   okvis_ba_window& w = fw.w;
   std::memset(&w, 0, sizeof(w));
   auto& f64 = fw.f64;
@@ -1079,6 +1101,7 @@ bool Estimator::patchWindow() {
   P.n_pprior = (int32_t)B.ppPose.size(), P.pprior_pose = B.ppPose.data(), P.pprior_meas = B.ppMeas.data(), P.pprior_sqrtinfo = B.ppSi.data();
   P.n_sbprior = (int32_t)B.spSb.size(), P.sbprior_sb = B.spSb.data(), P.sbprior_meas = B.spMeas.data(), P.sbprior_sqrtinfo = B.spSi.data();
   P.n_relpose = (int32_t)B.rp0.size(), P.rel_pose0 = B.rp0.data(), P.rel_pose1 = B.rp1.data(), P.rel_sqrtinfo = B.rpSi.data();
+  if (familiesChanged_ & OKVIS_BA_PATCH_MARG_PRIOR) resolvePrior();
   if ((familiesChanged_ & OKVIS_BA_PATCH_MARG_PRIOR) && prior_.dim > 0) {   // the MarginalizationError residual block (Estimator.cpp:750-759)
     int off = 0;
     for (size_t k = 0; k < prior_.block.size(); ++k) {
@@ -1293,6 +1316,7 @@ struct Estimator::MargUndo {
 };
 
 bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks) {
+  resolvePrior();   // (the previous prior's numbers go into this marginalisation)
   MargUndo undo;
   undo.removedSize = removedLandmarks.size();
   // the logs of window edits as they stand: a failed call takes its entries back (possible unless it may have dropped entries of
@@ -1302,6 +1326,10 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
   try {
     return applyMarginalizationStrategyImpl(numKeyframes, numImuFrames, removedLandmarks, undo);
   } catch (...) {
+    if (priorPending_) {   // (something threw behind okvis_ba_marginalize_begin: its numbers are not wanted any more)
+      priorPending_ = false;
+      (void)okvis_ba_marginalize_end(margSolver_, &margRes_);
+    }
     std::lock_guard<std::mutex> l(statesMutex_);
     if (logsRestorable) {
       obsRemoved_.resize(nRemovedLog);
@@ -1615,9 +1643,15 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
       spec.prior_b0 = prior_.b0.data();
     }
     const int cap = 6 * (int)sel.pose.size() + 9 * (int)sel.sb.size(), capb = (int)(sel.pose.size() + sel.sb.size());
-    std::vector<int32_t> bt(std::max(1, capb)), bi(std::max(1, capb)), bo(std::max(1, capb));
-    std::vector<double> Hn(std::max(1, cap * cap)), bn(std::max(1, cap)), Jn(std::max(1, cap * cap)), en(std::max(1, cap));
-    okvis_ba_marg_result res;
+    // (the result's arrays outlive this call — the numbers arrive in resolvePrior() — and keep their size from frame to frame)
+    std::vector<int32_t>&bt = margBt_, &bi = margBi_, &bo = margBo_;
+    std::vector<double>&Hn = margH_, &bn = margB_, &Jn = margJ_, &en = margE_;
+    auto grow = [](auto& v, size_t n) {
+      if (v.size() < n) v.resize(n);
+    };
+    grow(bt, (size_t)std::max(1, capb)), grow(bi, (size_t)std::max(1, capb)), grow(bo, (size_t)std::max(1, capb));
+    grow(Hn, (size_t)std::max(1, cap * cap)), grow(bn, (size_t)std::max(1, cap)), grow(Jn, (size_t)std::max(1, cap * cap)), grow(en, (size_t)std::max(1, cap));
+    okvis_ba_marg_result& res = margRes_;
     std::memset(&res, 0, sizeof(res));
     res.capacity_dim = cap;
     res.capacity_blocks = capb;
@@ -1643,6 +1677,10 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
         if (!sm[i] && !sbBlocks_[sel.sb[i]].fixed) keep(OKVIS_BA_BLOCK_SPEEDBIAS, (int)i, 9);
       res.dim = off;
       res.nblocks = nb;
+      std::fill(Hn.begin(), Hn.begin() + (size_t)off * off, 0.0);
+      std::fill(Jn.begin(), Jn.begin() + (size_t)off * off, 0.0);
+      std::fill(bn.begin(), bn.begin() + off, 0.0);
+      std::fill(en.begin(), en.begin() + off, 0.0);
       for (int i = 0; i < off; ++i) Hn[(size_t)i * off + i] = Jn[(size_t)i * off + i] = 1.0;
     } else {
       // the sub-window has a solver of its own: solver_ keeps the window optimize() works on between the calls
@@ -1650,7 +1688,9 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
       check(okvis_ba_set_options(margSolver_, &options_), "set_options");
       check(okvis_ba_upload(margSolver_, 1, &fw.w), "upload (marginalisation window)");
       tm2 = clk::now();
-      check(okvis_ba_marginalize(margSolver_, 0, &spec, &res), "marginalize");
+      // everything is enqueued; the numbers are waited for where they are read next (resolvePrior)
+      check(okvis_ba_marginalize_begin(margSolver_, 0, &spec, &res), "marginalize");
+      priorPending_ = true;
     }
     margInfo_ = {msf(tm0, tm1), msf(tm1, tm2), msf(tm2, clk::now()), (double)res.sweeps[0], (double)res.sweeps[1],
                  (double)(6 * sel.pose.size() + 9 * sel.sb.size())};
@@ -1670,10 +1710,12 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
       np.lin.push_back(lin);
     }
     const size_t n = (size_t)res.dim;
-    np.H.assign(Hn.begin(), Hn.begin() + n * n);
-    np.b0.assign(bn.begin(), bn.begin() + n);
-    np.J.assign(Jn.begin(), Jn.begin() + n * n);
-    np.e0.assign(en.begin(), en.begin() + n);
+    if (!priorPending_) {   // (book-keeping only: the stand-in numbers are there already)
+      np.H.assign(Hn.begin(), Hn.begin() + n * n);
+      np.b0.assign(bn.begin(), bn.begin() + n);
+      np.J.assign(Jn.begin(), Jn.begin() + n * n);
+      np.e0.assign(en.begin(), en.begin() + n);
+    }
     if (np.dim == 0) np = MargPrior();  // "if(marginalizationErrorPtr_->num_residuals()==0) reset" (:747-749)
     prior_ = np;
     familiesChanged_ |= OKVIS_BA_PATCH_MARG_PRIOR;

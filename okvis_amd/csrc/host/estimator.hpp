@@ -438,14 +438,26 @@ class Estimator {
   std::vector<PosePrior> posePriors_;
   std::vector<SbPrior> sbPriors_;
   std::vector<RelPose> relPoses_;
-  MargPrior prior_;
+  mutable MargPrior prior_;   // (mutable: resolvePrior() fills in the numbers of a pending marginalisation)
   std::array<double, 4> timings_{};
   bool debugFailMarg_ = false;
   WindowObserver windowObserver_ = nullptr;
   void* windowObserverUser_ = nullptr;
   struct MargUndo;  // what applyMarginalizationStrategy changed before its GPU call (estimator.cpp)
   bool applyMarginalizationStrategyImpl(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks, MargUndo& undo);
-  std::array<double, 6> margInfo_{};  // last marginalisation: ms flatten, upload, marginalize; Jacobi sweeps (2); sub-window D
+  // last marginalisation: ms flatten, upload, marginalize (the call that enqueues it + the wait for its numbers, wherever that
+  // wait took place); Jacobi sweeps (2); sub-window D
+  mutable std::array<double, 6> margInfo_{};
+  // A marginalisation whose numbers are still on their way (okvis_ba_marginalize_begin): prior_ already has its blocks and
+  // linearisation points — all the deletions and the book-keeping need — and resolvePrior() waits for H, b0, J, e0 where they are
+  // read next: the next window description / flatten, the next marginalisation, the destructor.  The device computes while
+  // applyMarginalizationStrategy deletes what was marginalised and the caller adds the next frame.  A numeric failure then
+  // surfaces at that later point and cannot be rolled back any more (the reference's marginalisation has no way back either).
+  mutable bool priorPending_ = false;
+  mutable std::vector<int32_t> margBt_, margBi_, margBo_;
+  mutable std::vector<double> margH_, margB_, margJ_, margE_;
+  mutable okvis_ba_marg_result margRes_{};
+  void resolvePrior() const;
   uint64_t nextId_ = 1ULL << 40;    // IdProvider::instance().newId() stand-in for internal blocks
   uint64_t nextHandle_ = 1;
   uint64_t nextImuUid_ = 1;

@@ -87,7 +87,8 @@ int main(int argc, char** argv) {
         std::sort(v.begin(), v.end());
         return v[v.size() / 2];
       };
-      std::printf("marginalise, medians per frame: sub-window flatten %.3f + upload %.3f + okvis_ba_marginalize %.3f ms (the rest: the decisions and deletions of applyMarginalizationStrategy)\n",
+      std::printf("marginalise, medians per frame: sub-window flatten %.3f + upload %.3f + okvis_ba_marginalize_begin %.3f ms (the rest: the decisions and deletions of "
+                  "applyMarginalizationStrategy; the device computes meanwhile and the numbers are waited for in the next frame's window description)\n",
                   median([](const okvis_amd::ReplayFrameResult& f) { return f.msMargFlatten; }),
                   median([](const okvis_amd::ReplayFrameResult& f) { return f.msMargUpload; }),
                   median([](const okvis_amd::ReplayFrameResult& f) { return f.msMargCall; }));

@@ -333,3 +333,40 @@ def test_gauge_deficient_random_sweep(oracle, seed):
             assert rel(g2["H"], r2["H"]) < 1e-9 and abs(g2["rank"] - r2["rank"]) <= 1
             return
         check(g2, r2)
+
+
+@pytest.mark.gpu
+def test_marginalize_in_two_halves():
+    """okvis_ba_marginalize_begin / _end: the kept blocks are known when _begin returns, the numbers when _end does — the same
+    numbers as the single call, bit for bit; between the two the solver takes no upload and hands out no results; an _end without
+    a _begin is a state error.  Also beyond the LDS route (waited for in _begin)."""
+    import ctypes as C
+    from okvis_amd import solver
+    from okvis_amd.window import marg_call
+    for w, K in ((synthetic.small_window(seed=33, K=6, L=120, visibility=0.8), 6), (synthetic.make_window(20, 60, 1.0, 5, frame_dt=0.1), 20)):
+        pm = np.zeros(w.n_pose, np.uint8); sm = np.zeros(w.n_sb, np.uint8)
+        pm[0] = 1; sm[[0, 1]] = 1
+        b = solver.WindowBatch([w], options=default_options())
+        one = b.marginalize(0, pm, sm)
+        L, h = b._L, b._h
+        seen = {}
+
+        def halves(sp, rs):
+            rc = L.okvis_ba_marginalize_begin(h, 0, sp, rs)
+            if rc:
+                return rc
+            wc, keep = w.as_c()
+            from okvis_amd.window import WindowC
+            seen["upload"] = L.okvis_ba_upload(h, 1, (WindowC * 1)(wc))
+            pose = np.zeros((w.n_pose, 7))
+            seen["fetch"] = L.okvis_ba_fetch_results(h, 0, pose.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, None)
+            seen["begin_again"] = L.okvis_ba_marginalize_begin(h, 0, sp, rs)
+            return L.okvis_ba_marginalize_end(h, rs)
+        st, two = marg_call(halves, w.n_pose, w.n_sb, pm, sm, None)
+        assert st == 0 and seen["upload"] == -2 and seen["fetch"] == -2 and seen["begin_again"] == -2     # OKVIS_BA_ERR_STATE
+        for k in ("dim", "rank", "block_type", "block_idx", "block_off", "H", "b0", "J", "e0"):
+            assert np.array_equal(np.asarray(one[k]), np.asarray(two[k])), k
+        st, _ = marg_call(lambda sp, rs: L.okvis_ba_marginalize_end(h, rs), w.n_pose, w.n_sb, pm, sm, None)
+        assert st == -2
+        b.optimize(2)   # the solver is usable again
+        b.close()
