@@ -180,6 +180,7 @@ int fused_max_windows() {
   }();
   return v;
 }
+constexpr size_t OPT_PAD = (sizeof(OptD) + 255) & ~size_t(255);   // the option record in front of the window records (one allocation, one copy)
 constexpr int SMALL_BATCH_WINDOWS = 40;   // below: the device is not full - settings that shorten one window's chain win
 
 OptD make_optd(const okvis_ba_options& o, int n_windows) {
@@ -1454,7 +1455,13 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   if (e == hipSuccess) e = hipEventCreate(&s->ev0);
   if (e == hipSuccess) e = hipEventCreate(&s->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipMalloc(&s->d_opt, sizeof(OptD));
+  // the option record and the window records share one allocation — [OptD, padded | WinPtrs x capacity] — so that an upload
+  // refreshes both with ONE copy
+  if (e == hipSuccess) e = hipMalloc(&s->d_opt, OPT_PAD + sizeof(WinPtrs));
+  if (e == hipSuccess) {
+    s->d_wins = reinterpret_cast<WinPtrs*>(reinterpret_cast<unsigned char*>(s->d_opt) + OPT_PAD);
+    s->wins_capacity = 1;
+  }
   // kernels may use more than the default 64 KB of dynamic LDS
   auto lds = [&](const void* f, size_t bytes) {
     if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1520,8 +1527,7 @@ int okvis_ba_destroy(okvis_ba_solver* s) {
   destroy_graphs(s);
   if (s->d_arena) (void)hipFree(s->d_arena);
   if (s->d_pre) (void)hipFree(s->d_pre);
-  if (s->d_wins) (void)hipFree(s->d_wins);
-  if (s->d_opt) (void)hipFree(s->d_opt);
+  if (s->d_opt) (void)hipFree(s->d_opt);   // (d_wins lives in the same allocation)
   if (s->h_ctrl_stage) (void)hipHostFree(s->h_ctrl_stage);
   if (s->d_ctrl_stage) (void)hipFree(s->d_ctrl_stage);
   if (s->marg_scratch) (void)hipFree(s->marg_scratch);
@@ -1766,21 +1772,22 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   }
   if (!s->group_chunks)   // a batch is fused as a whole or not at all: one set of partials for everybody
     for (int i = 0; i < n_windows; ++i) ptrs[i].spart_buf_stride = 0, ptrs[i].fuse_fast = 0;
-  if ((size_t)n_windows > s->wins_capacity) {
-    if (s->d_wins) HIP_TRY(hipFree(s->d_wins));
+  if ((size_t)n_windows > s->wins_capacity) {   // [OptD, padded | WinPtrs x capacity], see okvis_ba_create
+    if (s->d_opt) HIP_TRY(hipFree(s->d_opt));
+    s->d_opt = nullptr;
     s->d_wins = nullptr;
     s->wins_capacity = 0;
-    HIP_TRY(hipMalloc(&s->d_wins, sizeof(WinPtrs) * n_windows));
+    HIP_TRY(hipMalloc(&s->d_opt, OPT_PAD + sizeof(WinPtrs) * n_windows));
+    s->d_wins = reinterpret_cast<WinPtrs*>(reinterpret_cast<unsigned char*>(s->d_opt) + OPT_PAD);
     s->wins_capacity = (size_t)n_windows;
   }
   {
     const size_t wb = sizeof(WinPtrs) * (size_t)n_windows;
-    s->stage_small.resize(wb + sizeof(OptD));
-    std::memcpy(s->stage_small.data(), ptrs.data(), wb);
+    s->stage_small.resize(OPT_PAD + wb);
     const OptD d = make_optd(s->opt, n_windows);
-    std::memcpy(s->stage_small.data() + wb, &d, sizeof(d));
-    HIP_TRY(hipMemcpyAsync(s->d_wins, s->stage_small.data(), wb, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->d_opt, s->stage_small.data() + wb, sizeof(OptD), hipMemcpyHostToDevice, s->stream));
+    std::memcpy(s->stage_small.data(), &d, sizeof(d));
+    std::memcpy(s->stage_small.data() + OPT_PAD, ptrs.data(), wb);
+    HIP_TRY(hipMemcpyAsync(s->d_opt, s->stage_small.data(), OPT_PAD + wb, hipMemcpyHostToDevice, s->stream));
   }
   if (n_pre > 0) {   // the records started before the index build take their places in the window
     hipLaunchKernelGGL(imu_pre_place_kernel, dim3((unsigned)n_pre), dim3(64), 0, s->stream, s->d_wins, pre_where, pre_src);
