@@ -536,7 +536,8 @@ def main():
                                          "download_ms": v[4], "marginalise_ms": v[5]}
                     frame_host["estimator_replay"] = dict(rep, note="medians per frame of okvis_amd_replay (okvis_amd::Estimator, optimize(10) + "
                                                                    "applyMarginalizationStrategy per frame): window description = the edits since "
-                                                                   "the last frame as one okvis_ba_patch, or a full flatten; hand-over = "
+                                                                   "the last frame as one okvis_ba_patch, or a full flatten, plus the wait for the numbers of the marginalisation the previous "
+                                                                   "frame enqueued (okvis_ba_marginalize_begin / _end); hand-over = "
                                                                    "okvis_ba_patch_window, or okvis_ba_upload")
             except Exception as e:
                 frame_host["estimator_replay"] = {"error": repr(e)}
