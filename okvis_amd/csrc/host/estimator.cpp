@@ -447,9 +447,12 @@ void Estimator::resolvePrior() const {
   priorPending_ = false;
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = okvis_ba_marginalize_end(margSolver_, &margRes_);
-  if (rc != OKVIS_BA_OK)
+  if (rc != OKVIS_BA_OK) {
+    // (the prior has its blocks but will never have its numbers: without it the estimator stays usable, if poorer)
+    prior_ = MargPrior();   // (the family is still flagged as changed: applyMarginalizationStrategy did that when it set the blocks)
     throw Exception(std::string("okvis_amd::Estimator: the marginalisation enqueued by applyMarginalizationStrategy failed (") +
-                    okvis_ba_error_string(rc) + "); its deletions cannot be taken back");
+                    okvis_ba_error_string(rc) + "); its deletions cannot be taken back, the prior is dropped");
+  }
   const size_t n = (size_t)margRes_.dim;
   if (prior_.dim > 0) {   // (a prior without residuals was dropped at once, Estimator.cpp:747-749)
     prior_.H.assign(margH_.begin(), margH_.begin() + n * n);
