@@ -446,7 +446,11 @@ void Estimator::resolvePrior() const {
   if (!priorPending_) return;
   priorPending_ = false;
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = okvis_ba_marginalize_end(margSolver_, &margRes_);
+  int rc = okvis_ba_marginalize_end(margSolver_, &margRes_);
+  if (debugFailPending_) {
+    debugFailPending_ = false;
+    rc = OKVIS_BA_ERR_NUMERIC;
+  }
   if (rc != OKVIS_BA_OK) {
     // (the prior has its blocks but will never have its numbers: without it the estimator stays usable, if poorer)
     prior_ = MargPrior();   // (the family is still flagged as changed: applyMarginalizationStrategy did that when it set the blocks)
@@ -686,7 +690,14 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
   if (!dry_) check(okvis_ba_set_options(solver_, &options_), "set_options");
   // ---- the window: the edits since the last call as one patch of the window the solver holds, else flatten + upload ----
   patchSplit_ = {0.0, 0.0};
-  lastWasPatch_ = usePatch_ && patchWindow();
+  try {
+    lastWasPatch_ = usePatch_ && patchWindow();
+  } catch (...) {
+    // (the description of the edits may have been half consumed — e.g. the numbers of a pending marginalisation failed to
+    //  arrive in the middle of it: the next call describes the window from scratch)
+    invalidateSynced();
+    throw;
+  }
   if (!lastWasPatch_) {
     FlatWindow fw;
     uploadWindow(fw);

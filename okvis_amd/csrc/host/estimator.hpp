@@ -122,6 +122,9 @@ class Estimator {
   bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks);
   // test hook: the next applyMarginalizationStrategy throws where the GPU call would be (exercises the roll-back)
   void debugFailNextMarginalization() { debugFailMarg_ = true; }
+  // test hook: the numbers of the marginalisation that is on its way are treated as failed where they are waited for
+  // (exercises the late failure path of resolvePrior: the prior is dropped, the estimator stays usable)
+  void debugFailPendingMarginalization() { debugFailPending_ = true; }
   const std::string& lastRefusal() const { return lastRefusal_; }
   // diagnostics hook: called by optimize() with the flattened window it is about to upload (stage 0) and again with the
   // same window carrying the optimised pose / sb / lm arrays (stage 1); pointers are valid during the call only.  Lets a
@@ -441,6 +444,7 @@ class Estimator {
   mutable MargPrior prior_;   // (mutable: resolvePrior() fills in the numbers of a pending marginalisation)
   std::array<double, 4> timings_{};
   bool debugFailMarg_ = false;
+  mutable bool debugFailPending_ = false;
   WindowObserver windowObserver_ = nullptr;
   void* windowObserverUser_ = nullptr;
   struct MargUndo;  // what applyMarginalizationStrategy changed before its GPU call (estimator.cpp)

@@ -138,6 +138,13 @@ int okvis_est_debug_fail_next_marginalization(void* h) {
     return 1;
   });
 }
+// test hook: the marginalisation that is on its way fails where its numbers are waited for
+int okvis_est_debug_fail_pending_marginalization(void* h) {
+  return guarded([&] {
+    static_cast<Estimator*>(h)->debugFailPendingMarginalization();
+    return 1;
+  });
+}
 // diagnostics hook (Estimator::setWindowObserver): cb(window, user) sees each window optimize() flattens
 int okvis_est_set_window_observer(void* h, void (*cb)(const okvis_ba_window*, int, void*), void* user) {
   return guarded([&] {

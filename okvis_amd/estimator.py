@@ -192,6 +192,12 @@ class Estimator:
             removed.extend(int(ids[i]) for i in range(min(n.value, cap)))
         return ok
 
+    def debugFailPendingMarginalization(self):
+        """test hook: the marginalisation that is on its way fails where its numbers are waited for (late failure path)"""
+        fn = self._api.okvis_est_debug_fail_pending_marginalization
+        fn.argtypes = [C.c_void_p]
+        self._c(fn(self._h))
+
     def debugFailNextMarginalization(self):
         """test hook: the next applyMarginalizationStrategy raises where its GPU call would be (roll-back test)"""
         fn = self._api.okvis_est_debug_fail_next_marginalization

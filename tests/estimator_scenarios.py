@@ -8,7 +8,8 @@ from okvis_amd.window import DIST_EQUIDISTANT, DIST_RADTAN, ImuParams
 
 
 def sliding_window(make_estimator, make_frame, n_frames=12, num_keyframes=5, num_imu_frames=3, iters=5, seed=7,
-                   model=DIST_EQUIDISTANT, extrinsics_sigmas=(0, 0, 0, 0), marginalize=True, fail_marginalization_at=()):
+                   model=DIST_EQUIDISTANT, extrinsics_sigmas=(0, 0, 0, 0), marginalize=True, fail_marginalization_at=(),
+                   fail_pending_marginalization_at=()):
     """What ThreadedKFVio does per frame (ThreadedKFVio.cpp:736-765): addStates, addLandmark / addObservation for the
     visible wall points, optimize(iters), applyMarginalizationStrategy(numKeyframes, numImuFrames).  Returns a trace:
     one dict per frame with the states of every frame in the window, a sample of landmarks, counts and removed ids."""
@@ -68,6 +69,16 @@ def sliding_window(make_estimator, make_frame, n_frames=12, num_keyframes=5, num
                 kp = f.add_keypoint(i, m[0], m[1], 8.0)
                 assert est.addObservation(lid, f.id, i, kp) != 0
                 n_obs += 1
+        if k in fail_pending_marginalization_at:
+            # the numbers of the marginalisation the previous frame enqueued never arrive (injected): the call that waits for them
+            # throws once, the prior is dropped, and the estimator goes on
+            est.debugFailPendingMarginalization()
+            late = False
+            try:
+                est.optimize(iters, 2, False)
+            except Exception:
+                late = True
+            assert late and est.priorInfo()[0] == 0
         s = est.optimize(iters, 2, False)
         removed = []
         if marginalize and k in fail_marginalization_at:

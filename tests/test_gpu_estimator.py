@@ -192,6 +192,29 @@ def test_failed_marginalization_is_rolled_back():
             assert np.array_equal(a["landmarks"][lid], b["landmarks"][lid])
 
 
+def test_a_marginalisation_that_fails_late_drops_the_prior():
+    """applyMarginalizationStrategy enqueues the marginalisation and returns; its numbers are waited for where they are read next
+    (okvis_ba_marginalize_begin / _end).  When they never arrive (injected at two frames) the waiting call throws once, the prior
+    is dropped — blocks without numbers must not reach a window — and the estimator carries on: every later frame optimises, the
+    next marginalisation builds a new prior."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import estimator_scenarios as S
+    kw = dict(n_frames=14, num_keyframes=3, num_imu_frames=2, iters=4, seed=11)
+    clean, _ = S.sliding_window(lambda: estimator.Estimator(0), estimator.Frame, **kw)
+    rough, _ = S.sliding_window(lambda: estimator.Estimator(0), estimator.Frame, fail_pending_marginalization_at=(6, 10), **kw)
+    assert clean[5]["prior"][0] > 0 and clean[9]["prior"][0] > 0, "no prior at the frames whose numbers fail to arrive"
+    for k, (a, b) in enumerate(zip(clean, rough)):
+        assert (a["removed"], a["n_frames"], a["n_landmarks"]) == (b["removed"], b["n_frames"], b["n_landmarks"])   # the book-keeping is the same
+        assert b["summary"]["iterations"] > 0 and np.isfinite(b["summary"]["final_cost"])
+        if k < 6:
+            assert a["prior"] == b["prior"]
+            for fid in a["poses"]:
+                assert np.array_equal(a["poses"][fid], b["poses"][fid])
+    assert rough[-1]["prior"][0] > 0   # a new prior has been built since
+
+
 @pytest.mark.parametrize("sigmas", [(0, 0, 0, 0), (0.01, 0.01, 1e-3, 1e-3)])
 def test_patched_windows_iterate_like_flattened_ones(sigmas):
     """optimize() patches the window the solver holds with the edits since the last call; a second estimator flattens and uploads
