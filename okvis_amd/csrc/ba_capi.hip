@@ -150,8 +150,7 @@ struct okvis_ba_solver {
     std::vector<int> bt, bi, bo;
   } marg_pending;
   StageVec stage_pre;            // first preintegrations started at upload (imu_pre_kernel): the staged block and its device copy
-  unsigned char* d_pre = nullptr;
-  size_t pre_capacity = 0;
+  unsigned char* d_pre = nullptr;   // (PRE_MAX_TERMS records)
   bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0, max_spart_stride = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
@@ -308,20 +307,6 @@ BuildScratch& build_scratch() {
 // (ba_linearize2.hpp: free extrinsics, or one landmark with more than LIN2_PIECES pieces); the caller rebuilds the batch
 // for ba_linearize.hpp.
 constexpr int BW_LIN2_UNFIT = -1000;
-
-// number of pieces of the observations [o0, o1) of one landmark placed at lanes lane0... of a workgroup (a piece = one or two
-// adjacent observations of the same pose inside one row of 16 lanes, greedy from the start of the run: the rule of
-// linearize2_kernel's phase B)
-inline int count_pieces(const okvis_ba_window& w, int o0, int o1, int lane0) {
-  int n = 0, o = o0;
-  while (o < o1) {
-    int e = o + 1;
-    while (e < o1 && w.obs_pose[e] == w.obs_pose[o] && ((lane0 + (e - o0)) & 15) != 0) ++e;
-    n += (e - o + 1) / 2;
-    o = e;
-  }
-  return n;
-}
 
 int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A, HostWin& H, int n_windows_total = 1, bool lin2 = false) {
   auto bw_t0 = std::chrono::steady_clock::now();
@@ -1635,7 +1620,6 @@ static int pre_launch(okvis_ba_solver* s, int n_windows, const okvis_ba_window* 
   // every field but the counter of re-preintegrations, which it counts up: imu_pre_place_kernel sets that to 1).
   if (!s->d_pre) {
     if (hipMalloc(&s->d_pre, sizeof(ImuCacheD) * PRE_MAX_TERMS) != hipSuccess) return 0;
-    s->pre_capacity = sizeof(ImuCacheD) * PRE_MAX_TERMS;
   }
   if (s->stage_pre.size() < total) s->stage_pre.resize(total + total / 2);
   unsigned char* h = s->stage_pre.data();

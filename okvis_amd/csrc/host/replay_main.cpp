@@ -1,4 +1,4 @@
-// okvis_amd_replay <dataset folder> [trajectory.csv] [--keyframes N] [--imu-frames N] [--iterations N] [--max-frames N] [--no-patch]
+// okvis_amd_replay <dataset folder> [trajectory.csv] [--keyframes N] [--imu-frames N] [--iterations N] [--max-frames N] [--no-patch] [--device N]
 //
 // --no-patch: every optimize() flattens and uploads its window (the round-3 route) instead of patching the window the solver holds.
 //
@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
   okvis_amd::ReplayOptions opt;
   std::string out;
   bool usePatch = true;
+  int device = 0;
   for (int i = 2; i < argc; ++i) {
     auto val = [&](int& dst) {
       if (i + 1 >= argc) {
@@ -35,6 +36,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--iterations")) val(opt.numIterations);
     else if (!std::strcmp(argv[i], "--max-frames")) val(opt.maxFrames);
     else if (!std::strcmp(argv[i], "--no-patch")) usePatch = false;
+    else if (!std::strcmp(argv[i], "--device")) val(device);   // (-1: book-keeping only, nothing is computed: host timings without a GPU)
     else out = argv[i];
   }
   try {
@@ -42,7 +44,7 @@ int main(int argc, char** argv) {
     std::printf("No. IMU measurements: %zu\n", rec.imu.size());  // okvis_app_synchronous.cpp:249
     std::printf("No. frames: %zu, cameras: %zu, recorded observations: %zu, landmarks: %zu\n", rec.frames.size(), rec.cameras.size(),
                 rec.observations.size(), rec.landmarks.size());
-    okvis_amd::Estimator estimator(0);
+    okvis_amd::Estimator estimator(device);
     if (!usePatch) estimator.setUsePatch(false);
     const okvis_amd::ReplayResult r = okvis_amd::replay(rec, opt, estimator);
     double mo = 0, mm = 0, t4[4] = {0, 0, 0, 0};
