@@ -86,6 +86,8 @@ struct StageAlloc {
   bool operator!=(const StageAlloc<U>&) const { return false; }
 };
 typedef std::vector<unsigned char, StageAlloc<unsigned char>> StageVec;
+// page-locked (and so readable by the device in place) or the plain-malloc fall-back?  (the tag StageAlloc keeps in front of the block)
+inline bool stage_is_pinned(const StageVec& v) { return !v.empty() && (v.data() - 16)[0] == 1; }
 struct Arena {
   StageVec host;   // data part
   size_t size = 0;                   // bytes of the data part
@@ -1622,6 +1624,7 @@ static int pre_launch(okvis_ba_solver* s, int n_windows, const okvis_ba_window* 
     if (hipMalloc(&s->d_pre, sizeof(ImuCacheD) * PRE_MAX_TERMS) != hipSuccess) return 0;
   }
   if (s->stage_pre.size() < total) s->stage_pre.resize(total + total / 2);
+  if (!stage_is_pinned(s->stage_pre)) return 0;   // (pageable memory: the device cannot read it in place)
   unsigned char* h = s->stage_pre.data();
   unsigned char* d = h;                // (inputs: the staging block itself)
   unsigned char* rec = s->d_pre;       // (outputs)

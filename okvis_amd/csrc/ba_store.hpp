@@ -58,7 +58,7 @@ struct WindowStore {
     std::vector<int64_t> f_t0, f_t1, f_st;
     std::vector<double> f_gyr, f_acc, f_ref, f_cache;
     std::vector<uint8_t> f_refv;
-    std::vector<int32_t> x_mp, x_ms, x_ml, x_mo, x_ord, x_lm, x_pose, x_ext, x_cam;
+    std::vector<int32_t> x_mp, x_ms, x_ml, x_ord, x_lm, x_pose, x_ext, x_cam;
     std::vector<double> x_uv, x_sw;
     Buffers() = default;
     Buffers(const Buffers&) {}
@@ -282,7 +282,7 @@ struct WindowStore {
         (!p.marg_block_type || !p.marg_block_idx || !p.marg_block_off || !p.marg_J || !p.marg_e0 || !p.marg_lin || p.marg_nblocks <= 0))
       return OKVIS_BA_ERR_ARG;
     // (scratch kept between calls: an edit of a frame's worth of observations allocates nothing in the steady state)
-    std::vector<int32_t>&mp = buf.x_mp, &ms = buf.x_ms, &ml = buf.x_ml, &mo = buf.x_mo;
+    std::vector<int32_t>&mp = buf.x_mp, &ms = buf.x_ms, &ml = buf.x_ml;
     auto &x_ord = buf.x_ord, &x_lm = buf.x_lm, &x_pose = buf.x_pose, &x_ext = buf.x_ext, &x_cam = buf.x_cam;
     auto &x_uv = buf.x_uv, &x_sw = buf.x_sw;
     const int np1 = remap(np0, p.remove_pose, p.n_remove_pose, mp) + p.n_add_pose;
@@ -291,7 +291,6 @@ struct WindowStore {
     if (p.add_lm_before)   // places of the appended landmarks among the ones that stay: ascending, 0 .. nlk
       for (int k = 0; k < p.n_add_lm; ++k)
         if (p.add_lm_before[k] < 0 || p.add_lm_before[k] > nlk || (k > 0 && p.add_lm_before[k] < p.add_lm_before[k - 1])) return OKVIS_BA_ERR_ARG;
-    remap(no0, p.remove_obs, p.n_remove_obs, mo);
     if (!rep_marg)
       for (size_t b = 0; b < marg_block_type.size(); ++b)
         if ((marg_block_type[b] == OKVIS_BA_BLOCK_POSE ? mp : ms)[marg_block_idx[b]] < 0) return OKVIS_BA_ERR_ARG;
@@ -440,7 +439,10 @@ struct WindowStore {
       const int32_t* __restrict i_lm = obs_lm.data(); const int32_t* __restrict i_pose = obs_pose.data();
       const int32_t* __restrict i_ext = obs_ext.data(); const int32_t* __restrict i_cam = obs_cam.data();
       const double* __restrict i_uv = obs_uv.data(); const double* __restrict i_sw = obs_sqrtw.data();
-      const int32_t* __restrict r_ml = ml.data(); const int32_t* __restrict r_mp = mp.data(); const int32_t* __restrict r_mo = mo.data();
+      const int32_t* __restrict r_ml = ml.data(); const int32_t* __restrict r_mp = mp.data();
+      const int32_t* __restrict rem = p.remove_obs;   // (ascending: a cursor instead of a map over all observations)
+      int ro = 0;
+      const int nrem = p.n_remove_obs;
       size_t o = 0;
       int j = 0;
       const int nadd = p.n_add_obs;
@@ -457,7 +459,10 @@ struct WindowStore {
       };
       next_key();
       for (int i = 0; i < no0; ++i) {
-        if (r_mo[i] < 0) continue;
+        if (ro < nrem && rem[ro] == i) {
+          ++ro;
+          continue;
+        }
         const int l = r_ml[i_lm[i]], ip = r_mp[i_pose[i]], ie = r_mp[i_ext[i]], c = i_cam[i];
         if ((l | ip | ie) < 0) continue;   // observations of a removed landmark / pose / extrinsics block go with it
         while (nl < l || (nl == l && (np_ < ip || (np_ == ip && nc < c)))) {
