@@ -127,10 +127,12 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Xout) {
   return ok;
 }
 
-constexpr int SOLVE_LDS_LIMIT = 150 * 1024;   // dynamic LDS of the solve kernel (160 KB per workgroup minus its static arrays, about 8.5 KB)
+constexpr int SOLVE_LDS_LIMIT = 148 * 1024;   // dynamic LDS of the solve kernel (160 KB per workgroup minus its static arrays, about 11 KB;
+                                              // the largest LDS-resident system, D = 174, takes 137.5 KB)
 constexpr int PRI_STAGE = 2;  // pose / speed-bias priors whose records the solve kernel stages in LDS ahead of time
 constexpr int SOLVE_HELPERS = 4;   // workgroups per window (blockIdx.y < SOLVE_HELPERS) that sum the Schur chunk partials for the solving one
 constexpr int SOLVE_HELPED_MAX_WINDOWS = 8;   // launches of more windows sum inside the solving workgroup (a helper takes a whole CU)
+constexpr int MARG_BLOCKS_MAX = MAX_MARG_DIM / 6;   // blocks of a marginalisation prior (staged in LDS by assemble_base)
 constexpr int PRE_BLOCKS = 32;  // pose / speed-bias blocks whose accepted values the solve kernel stages in LDS ahead of time
 
 // IMU Hessian blocks, priors and the marginalisation prior of linearisation buffer `acc`, accumulated into S
@@ -265,56 +267,77 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const LYT LY, double* S
     __syncthreads();
   }
   // ---- marginalisation prior: H = B^T (J^T J) B, g = B^T J^T e ----
+  // (B: identity except the 3x3 rotation blocks M of the pose blocks' orientation parts.)  The block table — offset in the prior,
+  // type, reduced offset in the system — is staged in LDS first: looked up per entry in global memory it cost every entry four
+  // dependent round trips (offsets -> type / index -> reduced offset -> H0), three passes of them for a 45-row prior.  Now an
+  // entry's H0 / M operands are its only global loads, requested together.
   if (W.marg_dim > 0) {
     const int Dm = W.marg_dim, nb = W.marg_nb;
+    __shared__ int s_moff[MARG_BLOCKS_MAX], s_mR[MARG_BLOCKS_MAX];
+    __shared__ unsigned char s_mpose[MARG_BLOCKS_MAX];
+    for (int b = tid; b < nb; b += nthreads) {
+      const int type = W.marg_block_type[b], idx = W.marg_block_idx[b];
+      s_moff[b] = W.marg_block_off[b];
+      s_mpose[b] = type == 0;
+      s_mR[b] = type == 0 ? W.pose_off[idx] : W.sb_off[idx];
+    }
+    __syncthreads();
     const double* M = W.marg_lin_M[acc];
     const double* JTe = W.marg_lin_e[acc] + Dm;  // [e | J^T e]
+    const double* H0 = W.marg_H0;
+    // (the operands of an entry are named scalars, not arrays: with 128 registers per lane the compiler keeps small private
+    //  arrays in scratch memory)
     for (int wi = tid; wi < Dm * Dm; wi += nthreads) {
       const int rr = wi / Dm, cc = wi - rr * Dm;
       int bi = 0, bj = 0;
       for (int b = 0; b < nb; ++b) {
-        if (W.marg_block_off[b] <= rr) bi = b;
-        if (W.marg_block_off[b] <= cc) bj = b;
+        if (s_moff[b] <= rr) bi = b;
+        if (s_moff[b] <= cc) bj = b;
       }
-      const int oi = W.marg_block_off[bi], oj = W.marg_block_off[bj];
+      const int oi = s_moff[bi], oj = s_moff[bj];
       const int li = rr - oi, lj = cc - oj;
-      const int Ri = W.marg_block_type[bi] == 0 ? W.pose_off[W.marg_block_idx[bi]] : W.sb_off[W.marg_block_idx[bi]];
-      const int Rj = W.marg_block_type[bj] == 0 ? W.pose_off[W.marg_block_idx[bj]] : W.sb_off[W.marg_block_idx[bj]];
+      const int Ri = s_mR[bi], Rj = s_mR[bj];
       if (Ri < 0 || Rj < 0 || Ri + li < Rj + lj) continue;
-      const bool roti = (W.marg_block_type[bi] == 0) && li >= 3;
-      const bool rotj = (W.marg_block_type[bj] == 0) && lj >= 3;
-      double s = 0;
+      const bool roti = s_mpose[bi] && li >= 3;
+      const bool rotj = s_mpose[bj] && lj >= 3;
+      double sacc = 0;
       if (!roti && !rotj) {
-        s = W.marg_H0[(size_t)rr * Dm + cc];
+        sacc = H0[(size_t)rr * Dm + cc];
       } else {
-        for (int a = 0; a < (roti ? 3 : 1); ++a) {
-          const int r2 = roti ? oi + 3 + a : rr;
-          const double wa = roti ? M[9 * bi + 3 * a + (li - 3)] : 1.0;
-          for (int b = 0; b < (rotj ? 3 : 1); ++b) {
-            const int c2 = rotj ? oj + 3 + b : cc;
-            const double wb = rotj ? M[9 * bj + 3 * b + (lj - 3)] : 1.0;
-            s += wa * W.marg_H0[(size_t)r2 * Dm + c2] * wb;
-          }
-        }
+        const int na = roti ? 3 : 1, nbk = rotj ? 3 : 1;
+        // rows r2(a) = oi + 3 + a | rr, columns c2(b) = oj + 3 + b | cc; weights M(bi)[a][li - 3] | 1, M(bj)[b][lj - 3] | 1
+#define MP_W(v, rot, blk, k, l) const double v = (rot) ? M[9 * (blk) + 3 * (k) + ((l) - 3)] : 1.0;
+        MP_W(wa0, roti, bi, 0, li) MP_W(wa1, roti && 1 < na, bi, 1, li) MP_W(wa2, roti && 2 < na, bi, 2, li)
+        MP_W(wb0, rotj, bj, 0, lj) MP_W(wb1, rotj && 1 < nbk, bj, 1, lj) MP_W(wb2, rotj && 2 < nbk, bj, 2, lj)
+#undef MP_W
+#define MP_H(v, a2, b2) const double v = ((a2) < na && (b2) < nbk) ? H0[(size_t)(roti ? oi + 3 + (a2) : rr) * Dm + (rotj ? oj + 3 + (b2) : cc)] : 0.0;
+        MP_H(h00, 0, 0) MP_H(h01, 0, 1) MP_H(h02, 0, 2) MP_H(h10, 1, 0) MP_H(h11, 1, 1) MP_H(h12, 1, 2) MP_H(h20, 2, 0) MP_H(h21, 2, 1) MP_H(h22, 2, 2)
+#undef MP_H
+        // (the terms in the order of the loops over a and b, every product as wa * H0 * wb)
+#define MP_T(a2, b2, w1, h, w2) if ((a2) < na && (b2) < nbk) sacc += (w1) * (h) * (w2);
+        MP_T(0, 0, wa0, h00, wb0) MP_T(0, 1, wa0, h01, wb1) MP_T(0, 2, wa0, h02, wb2)
+        MP_T(1, 0, wa1, h10, wb0) MP_T(1, 1, wa1, h11, wb1) MP_T(1, 2, wa1, h12, wb2)
+        MP_T(2, 0, wa2, h20, wb0) MP_T(2, 1, wa2, h21, wb1) MP_T(2, 2, wa2, h22, wb2)
+#undef MP_T
       }
-      S[LY.at(Ri + li, Rj + lj)] += s;
-      if (Ri + li == Rj + lj) d2[Ri + li] += s;
+      S[LY.at(Ri + li, Rj + lj)] += sacc;
+      if (Ri + li == Rj + lj) d2[Ri + li] += sacc;
     }
     for (int rr = tid; rr < Dm; rr += nthreads) {
       int bi = 0;
       for (int b = 0; b < nb; ++b)
-        if (W.marg_block_off[b] <= rr) bi = b;
-      const int oi = W.marg_block_off[bi], li = rr - oi;
-      const int Ri = W.marg_block_type[bi] == 0 ? W.pose_off[W.marg_block_idx[bi]] : W.sb_off[W.marg_block_idx[bi]];
+        if (s_moff[b] <= rr) bi = b;
+      const int oi = s_moff[bi], li = rr - oi;
+      const int Ri = s_mR[bi];
       if (Ri < 0) continue;
-      double s;
-      if (W.marg_block_type[bi] == 0 && li >= 3) {
-        s = 0;
-        for (int a = 0; a < 3; ++a) s += M[9 * bi + 3 * a + (li - 3)] * JTe[oi + 3 + a];
+      double sacc;
+      if (s_mpose[bi] && li >= 3) {
+        sacc = 0;
+        for (int a2 = 0; a2 < 3; ++a2) sacc += M[9 * bi + 3 * a2 + (li - 3)] * JTe[oi + 3 + a2];
       } else {
-        s = JTe[rr];
+        sacc = JTe[rr];
       }
-      g[Ri + li] += s;
+      g[Ri + li] += sacc;
     }
     __syncthreads();
   }
