@@ -170,6 +170,11 @@ def test_null_solver_is_an_argument_error_everywhere():
     assert L.okvis_ba_iterate(None, 1) == -1
     assert L.okvis_ba_finish(None, None) == -1
     assert L.okvis_ba_marginalize(None, 0, None, None) == -1
+    assert L.okvis_ba_marginalize_begin(None, 0, None, None) == -1 and L.okvis_ba_marginalize_end(None, None) == -1
+    assert L.okvis_ba_fetch_imu_caches(None, 0, None) == -1
+    import ctypes as C
+    n = C.c_int64()
+    assert L.okvis_ba_check_window_lists(None, None, 1, 0, None, 0, C.byref(n)) == -1
 
 
 def test_okvis_adapter_compiles_against_the_interface():
