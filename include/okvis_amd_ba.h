@@ -366,6 +366,13 @@ int okvis_ba_set_patchable(okvis_ba_solver* s, int on);
 int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p);
 /* the container of window w of a patchable solver as it stands (pointers valid until the next upload / patch) */
 int okvis_ba_patched_view(okvis_ba_solver* s, int w, okvis_ba_window* out);
+/* The NUMBERS of window w's marginalisation prior once more — J [marg_dim][marg_dim] row-major, e0 [marg_dim] — for the blocks,
+ * offsets and linearisation points the window was uploaded or patched with (they stay as they are).  For a caller whose prior
+ * is still being computed when the window is handed over (okvis_ba_marginalize_begin on another solver): it uploads / patches with
+ * the block structure and stand-in numbers, waits for the numbers meanwhile, and sets them here — before the next
+ * okvis_ba_begin / optimize.  One copy; a patchable solver's container is updated too.  OKVIS_BA_ERR_ARG if the window has no
+ * prior. */
+int okvis_ba_set_marg_prior_values(okvis_ba_solver* s, int w, const double* J, const double* e0);
 
 /* overwrite only block VALUES of window w (Estimator::set_T_WS/setSpeedAndBias/setLandmark,
  * Estimator.cpp:1205-1302); any pointer may be NULL to keep the device copy. */

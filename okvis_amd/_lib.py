@@ -20,7 +20,7 @@ SYMBOLS = [
     "okvis_ba_profile_iterations", "okvis_ba_profile_launches", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize",
     "okvis_ba_helper_timeouts", "okvis_ba_marginalize", "okvis_ba_marginalize_begin", "okvis_ba_marginalize_end",
     "okvis_ba_store_create", "okvis_ba_store_patch", "okvis_ba_store_view", "okvis_ba_store_destroy", "okvis_ba_set_patchable",
-    "okvis_ba_patch_window", "okvis_ba_patched_view",
+    "okvis_ba_patch_window", "okvis_ba_patched_view", "okvis_ba_set_marg_prior_values",
     "okvis_ba_dense_solve", "okvis_ba_shard", "okvis_ba_batch_run", "okvis_ba_gather_records", "okvis_ba_batch_run_gathered",
 ]
 
@@ -63,6 +63,7 @@ def lib():
     L.okvis_ba_set_patchable.argtypes = [vp, C.c_int]
     L.okvis_ba_patch_window.argtypes = [vp, C.c_int, C.POINTER(PatchC)]
     L.okvis_ba_patched_view.argtypes = [vp, C.c_int, C.POINTER(WindowC)]
+    L.okvis_ba_set_marg_prior_values.argtypes = [vp, C.c_int, _dp, _dp]
     L.okvis_ba_check_window.argtypes = [C.POINTER(WindowC), C.POINTER(OptionsC), C.POINTER(C.c_int64)]
     L.okvis_ba_check_window_lists.argtypes = [C.POINTER(WindowC), C.POINTER(OptionsC), C.c_int32, C.c_int32, _ip, C.c_int64,
                                               C.POINTER(C.c_int64)]

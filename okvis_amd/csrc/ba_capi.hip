@@ -144,6 +144,8 @@ struct okvis_ba_solver {
   bool res_staged = false;  // stage_res holds window 0's packed results as of the last okvis_ba_finish (single-window solvers)
   StageVec stage_res;
   StageVec stage_marg;           // host-written part of okvis_ba_marginalize's scratch block
+  StageVec stage_marg_vals;      // okvis_ba_set_marg_prior_values: the staged J | H0 | e0 span ...
+  hipEvent_t ev_marg_vals = nullptr;   // ... and the event behind its copy
   // okvis_ba_marginalize_begin without its _end yet: what _end needs to hand the numbers over (the kept blocks are known at begin)
   struct MargPending {
     bool active = false, synced = false;
@@ -303,6 +305,21 @@ struct BuildScratch {
 BuildScratch& build_scratch() {
   static thread_local BuildScratch S;
   return S;
+}
+
+// H0 = J^T J on the host (H0 zeroed by the caller): the upper triangle as a sum of row outer products, then mirrored
+inline void marg_h0_host(const double* J, int Dm, double* H0) {
+  for (int r = 0; r < Dm; ++r) {
+    const double* Jr = J + (size_t)r * Dm;
+    for (int i = 0; i < Dm; ++i) {
+      const double a = Jr[i];
+      if (a == 0.0) continue;   // (J of the reference's prior is upper triangular up to the rank: 0 * x adds nothing)
+      double* Hi = H0 + (size_t)i * Dm;
+      for (int j = i; j < Dm; ++j) Hi[j] += a * Jr[j];
+    }
+  }
+  for (int i = 0; i < Dm; ++i)
+    for (int j = i + 1; j < Dm; ++j) H0[(size_t)j * Dm + i] = H0[(size_t)i * Dm + j];
 }
 
 // Internal status of build_window(lin2 = true): the window does not fit the piece path of the linearise launch
@@ -849,17 +866,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     H.h0_on_device = Dm > H0_DEVICE_MIN && !std::getenv("OKVIS_BA_H0_ON_HOST");   // (the switch: A/B test of the two)
     // upper triangle as a sum of row outer products: every entry still adds its terms in row order (same value as the
     // column-by-column dot products), but the inner loop runs along a row of J (contiguous: 10 us -> 3 us at 45 rows)
-    for (int r = 0; r < Dm && !H.h0_on_device; ++r) {
-      const double* Jr = w.marg_J + (size_t)r * Dm;
-      for (int i = 0; i < Dm; ++i) {
-        const double a = Jr[i];
-        if (a == 0.0) continue;   // (J of the reference's prior is upper triangular up to the rank: 0 * x adds nothing)
-        double* Hi = H0.data() + (size_t)i * Dm;
-        for (int j = i; j < Dm; ++j) Hi[j] += a * Jr[j];
-      }
-    }
-    for (int i = 0; i < Dm; ++i)
-      for (int j = i + 1; j < Dm; ++j) H0[(size_t)j * Dm + i] = H0[(size_t)i * Dm + j];
+    if (!H.h0_on_device) marg_h0_host(w.marg_J, Dm, H0.data());
   }
   const int nmb = Dm > 0 ? w.marg_nblocks : 0;
 
@@ -1514,6 +1521,7 @@ int okvis_ba_destroy(okvis_ba_solver* s) {
   destroy_graphs(s);
   if (s->d_arena) (void)hipFree(s->d_arena);
   if (s->d_pre) (void)hipFree(s->d_pre);
+  if (s->ev_marg_vals) (void)hipEventDestroy(s->ev_marg_vals);
   if (s->d_opt) (void)hipFree(s->d_opt);   // (d_wins lives in the same allocation)
   if (s->h_ctrl_stage) (void)hipHostFree(s->h_ctrl_stage);
   if (s->d_ctrl_stage) (void)hipFree(s->d_ctrl_stage);
@@ -2079,6 +2087,52 @@ int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p) {
   }
   std::swap(s->mirrors[w], after);   // (moves of vectors: cannot throw)
   s->mirror_fresh = true;   // the device holds exactly what the containers hold
+  return OKVIS_BA_OK;
+}
+
+int okvis_ba_set_marg_prior_values(okvis_ba_solver* s, int w, const double* J, const double* e0) {
+  if (!s || !J || !e0) return OKVIS_BA_ERR_ARG;
+  if (!s->uploaded || s->marg_pending.active) return OKVIS_BA_ERR_STATE;
+  if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
+  HostWin& H = s->wins[w];
+  const int Dm = H.marg_dim;
+  if (Dm <= 0) return OKVIS_BA_ERR_ARG;
+  HIP_TRY(hipSetDevice(s->device));
+  // J | H0 | e0 sit behind one another in the arena (each on its 256-byte boundary): one staged image of that span, one copy
+  const uintptr_t aJ = reinterpret_cast<uintptr_t>(H.ptrs.marg_J), aH0 = reinterpret_cast<uintptr_t>(H.ptrs.marg_H0),
+                  ae0 = reinterpret_cast<uintptr_t>(H.ptrs.marg_e0);
+  unsigned char* const dJ = reinterpret_cast<unsigned char*>(aJ);
+  const size_t o_H0 = (size_t)(aH0 - aJ), o_e0 = (size_t)(ae0 - aJ);
+  const size_t nJ = 8 * (size_t)Dm * Dm, span = o_e0 + 8 * (size_t)Dm;
+  if (!(nJ <= o_H0 && o_H0 + nJ <= o_e0)) return OKVIS_BA_ERR_STATE;   // (the layout build_window gives them)
+  if (s->stage_marg_vals.size() < span) s->stage_marg_vals.resize(span);
+  unsigned char* h = s->stage_marg_vals.data();
+  // (the staging of the previous call must have been read: an event behind its copy, long reached in the steady state)
+  if (!s->ev_marg_vals) HIP_TRY(hipEventCreateWithFlags(&s->ev_marg_vals, hipEventDisableTiming));
+  else HIP_TRY(hipEventSynchronize(s->ev_marg_vals));
+  std::memcpy(h, J, nJ);
+  if (!H.h0_on_device) {
+    double* H0 = reinterpret_cast<double*>(h + o_H0);
+    std::memset(H0, 0, nJ);
+    marg_h0_host(J, Dm, H0);
+  }
+  std::memcpy(h + o_e0, e0, 8 * (size_t)Dm);
+  if (H.h0_on_device) {   // (H0 stays where it is and is formed again on the device behind the copy)
+    HIP_TRY(hipMemcpyAsync(dJ, h, nJ, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(dJ + o_e0, h + o_e0, 8 * (size_t)Dm, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(marg_h0_kernel, dim3((unsigned)(((size_t)Dm * Dm + 255) / 256), 1), dim3(256), 0, s->stream, s->d_wins, w);
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemcpyAsync(dJ, h, span, hipMemcpyHostToDevice, s->stream));
+  }
+  HIP_TRY(hipEventRecord(s->ev_marg_vals, s->stream));
+  if (s->patchable && (size_t)w < s->mirrors.size()) {   // the container holds what the device holds
+    s->mirrors[w].marg_J.assign(J, J + (size_t)Dm * Dm);
+    s->mirrors[w].marg_e0.assign(e0, e0 + Dm);
+  }
+  s->begun = false;
+  s->evaluated = false;
+  s->res_staged = false;
   return OKVIS_BA_OK;
 }
 

@@ -1115,7 +1115,12 @@ bool Estimator::patchWindow() {
   P.n_pprior = (int32_t)B.ppPose.size(), P.pprior_pose = B.ppPose.data(), P.pprior_meas = B.ppMeas.data(), P.pprior_sqrtinfo = B.ppSi.data();
   P.n_sbprior = (int32_t)B.spSb.size(), P.sbprior_sb = B.spSb.data(), P.sbprior_meas = B.spMeas.data(), P.sbprior_sqrtinfo = B.spSi.data();
   P.n_relpose = (int32_t)B.rp0.size(), P.rel_pose0 = B.rp0.data(), P.rel_pose1 = B.rp1.data(), P.rel_sqrtinfo = B.rpSi.data();
-  if (familiesChanged_ & OKVIS_BA_PATCH_MARG_PRIOR) resolvePrior();
+  // The numbers of a prior that is still being computed (okvis_ba_marginalize_begin) are not waited for here: the patch carries the
+  // prior's blocks and linearisation points with stand-in numbers (the result buffers as they are), the solver edits its container
+  // and builds its index lists meanwhile, and the numbers follow through okvis_ba_set_marg_prior_values at the end of this function.
+  const bool lateNumbers = priorPending_ && !dry_ && (familiesChanged_ & OKVIS_BA_PATCH_MARG_PRIOR) && prior_.dim > 0 &&
+                           margJ_.size() >= (size_t)prior_.dim * prior_.dim && margE_.size() >= (size_t)prior_.dim;
+  if ((familiesChanged_ & OKVIS_BA_PATCH_MARG_PRIOR) && !lateNumbers) resolvePrior();
   if ((familiesChanged_ & OKVIS_BA_PATCH_MARG_PRIOR) && prior_.dim > 0) {   // the MarginalizationError residual block (Estimator.cpp:750-759)
     int off = 0;
     for (size_t k = 0; k < prior_.block.size(); ++k) {
@@ -1129,7 +1134,9 @@ bool Estimator::patchWindow() {
     P.marg_dim = prior_.dim;
     P.marg_nblocks = (int32_t)prior_.block.size();
     P.marg_block_type = B.mType.data(), P.marg_block_idx = B.mIdx.data(), P.marg_block_off = B.mOff.data();
-    P.marg_J = prior_.J.data(), P.marg_e0 = prior_.e0.data(), P.marg_lin = B.mLin.data();
+    P.marg_J = lateNumbers ? margJ_.data() : prior_.J.data();
+    P.marg_e0 = lateNumbers ? margE_.data() : prior_.e0.data();
+    P.marg_lin = B.mLin.data();
   }
   // values the caller has set since (blocks that were part of the window already; new ones carry theirs)
   for (int b : poseValueSet_)
@@ -1195,6 +1202,12 @@ bool Estimator::patchWindow() {
   poseValueSet_.clear();
   sbValueSet_.clear();
   familiesChanged_ = 0;
+  if (lateNumbers) {
+    // the solver holds the window with stand-in numbers in its prior: wait for the real ones (the device has had the
+    // container edit, the index build and the copies of the hand-over to finish them) and set them before anything is computed
+    resolvePrior();
+    check(okvis_ba_set_marg_prior_values(solver_, 0, prior_.J.data(), prior_.e0.data()), "okvis_ba_set_marg_prior_values");
+  }
   patchSplit_ = {ms(t0, t1), ms(t1, clk::now())};
   return true;
 }

@@ -282,6 +282,45 @@ def test_config_C_full_size(oracle):
     b.close(); bb.close()
 
 
+def test_prior_numbers_set_after_the_hand_over():
+    """okvis_ba_set_marg_prior_values: a window uploaded with the blocks of its marginalisation prior and stand-in numbers, the
+    real J and e0 set afterwards, is the window uploaded with them — same optimisation bit for bit, same container — also for a
+    prior whose H0 = J^T J is formed on the device (more than 128 rows); a window without a prior refuses the call."""
+    import copy
+    import ctypes as C
+    from okvis_amd import solver
+    dp = C.POINTER(C.c_double)
+    for K, nposeb, nsbb in ((6, 4, 2), (26, 16, 10)):     # 42 rows | 186 rows
+        w = synthetic.make_window(K, 120, 0.8, seed=70 + K, frame_dt=0.25)
+        rng = np.random.default_rng(K)
+        bt = [0] * nposeb + [1] * nsbb
+        bi = list(range(nposeb)) + list(range(nsbb))
+        off, bo = 0, []
+        for t in bt:
+            bo.append(off); off += 6 if t == 0 else 9
+        w.marg_block_type, w.marg_block_idx, w.marg_block_off = (np.array(a, np.int32) for a in (bt, bi, bo))
+        w.marg_J = np.triu(rng.standard_normal((off, off))) * 3.0
+        w.marg_e0 = rng.standard_normal(off) * 0.01
+        w.marg_lin = np.array([np.r_[w.pose[i], 0, 0] if t == 0 else w.sb[i] for t, i in zip(bt, bi)])
+        a = solver.WindowBatch([w], options=default_options(), patchable=True)
+        standin = copy.deepcopy(w)
+        standin.marg_J = np.zeros_like(w.marg_J); standin.marg_e0 = np.zeros_like(w.marg_e0)
+        b = solver.WindowBatch([standin], options=default_options(), patchable=True)
+        J, e0 = np.ascontiguousarray(w.marg_J), np.ascontiguousarray(w.marg_e0)
+        assert b._L.okvis_ba_set_marg_prior_values(b._h, 0, J.ctypes.data_as(dp), e0.ctypes.data_as(dp)) == 0
+        sa, sb_ = a.optimize(5)[0], b.optimize(5)[0]
+        assert sa == sb_ and sa["iterations"] > 0
+        for x, y in zip(a.get_state(0), b.get_state(0)):
+            assert np.array_equal(x, y)
+        v = b.patched_view(0)
+        assert np.array_equal(v.marg_J, w.marg_J) and np.array_equal(v.marg_e0, w.marg_e0)
+        a.close(); b.close()
+    plain = solver.WindowBatch([synthetic.small_window(seed=3)], options=default_options())
+    z = np.zeros(4)
+    assert plain._L.okvis_ba_set_marg_prior_values(plain._h, 0, z.ctypes.data_as(dp), z.ctypes.data_as(dp)) == -1
+    plain.close()
+
+
 def test_imu_preintegration_travels_with_the_term():
     """The reference's ImuError object keeps its preintegration between optimize() calls.  A window can hand over the record
     okvis_ba_fetch_imu_caches gave out for the same term (flag 2): nothing is re-preintegrated on first use, and the numbers are the
