@@ -15,6 +15,8 @@ def run(out):
     n = int(os.environ.get("CHECK_WINDOWS", "48"))
     wins = ([synthetic.make_window(10, 400, 1.0, 9_100_000 + i) for i in range(max(0, n - 8))] +
             [synthetic.make_window(6 + i % 3, 150 + 20 * i, 0.6, 9_200_000 + i) for i in range(8)])[-n:]
+    if os.environ.get("CHECK_K"):   # windows of CHECK_K frames (CHECK_K - 1 IMU terms each)
+        wins = [synthetic.make_window(int(os.environ["CHECK_K"]), 120 + 10 * i, 0.7, 9_300_000 + i) for i in range(n)]
     for mode in ("dogleg", "gn"):
         o = default_options()
         if mode == "gn":
