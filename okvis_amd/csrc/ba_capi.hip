@@ -530,8 +530,9 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
         if (lin2) {   // piece path: at most LIN2_PIECES pieces per group (a pair has at least one piece)
           // One walk over the landmark's observations; the tests that depend on the data are arithmetic.  An observation opens a
           // piece when it opens a run (new pose, or first lane of a row) or sits at an even place of its run.
-          for (int p = p0; p < p1; ++p) ppc[p] = 0;
           int pnext = p0, cur = npair, prev = -1, par = 0, local = npc;
+          int v = 0;   // first piece | pieces << 16 of the pair the walk is in: kept in a register, stored (never re-read) every step
+          int w0 = 0, w1 = 0, w2 = 0, w3 = 0;
           for (int o = o0; o < o1; ++o) {
             const int lane = no + (o - o0), pose = w.obs_pose[o];
             const int changed = pose != prev, freeb = pose_off[pose] >= 0;
@@ -540,13 +541,16 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
             const int start = changed | (int)((lane & 15) == 0);
             par = start ? 0 : par ^ 1;
             const int newp = par == 0;
-            int v = ppc[cur];
+            v = changed ? 0 : v;   // (every pair is entered once: it starts empty)
             v = (newp & (int)((v >> 16) == 0)) ? local : v;
-            ppc[cur] = v + (newp << 16);
-            wc[lane >> 6] += newp;
+            v += newp << 16;
+            ppc[cur] = v;
+            const int wv = lane >> 6;
+            w0 += newp & (int)(wv == 0), w1 += newp & (int)(wv == 1), w2 += newp & (int)(wv == 2), w3 += newp & (int)(wv == 3);
             local += newp;
             prev = pose;
           }
+          wc[0] = w0, wc[1] = w1, wc[2] = w2, wc[3] = w3;
           lpc = local - npc;
           if (nl == 0 && lpc > LIN2_PIECES) return BW_LIN2_UNFIT;
           if (nl > 0 && npc + lpc > LIN2_PIECES) break;   // (the landmark opens the next group and is laid out again from lane 0)
