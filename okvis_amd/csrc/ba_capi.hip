@@ -2109,7 +2109,11 @@ int okvis_ba_set_marg_prior_values(okvis_ba_solver* s, int w, const double* J, c
   const size_t o_H0 = (size_t)(aH0 - aJ), o_e0 = (size_t)(ae0 - aJ);
   const size_t nJ = 8 * (size_t)Dm * Dm, span = o_e0 + 8 * (size_t)Dm;
   if (!(nJ <= o_H0 && o_H0 + nJ <= o_e0)) return OKVIS_BA_ERR_STATE;   // (the layout build_window gives them)
-  if (s->stage_marg_vals.size() < span) s->stage_marg_vals.resize(span);
+  try {
+    if (s->stage_marg_vals.size() < span) s->stage_marg_vals.resize(span);
+  } catch (const std::bad_alloc&) {
+    return OKVIS_BA_ERR_ARG;
+  }
   unsigned char* h = s->stage_marg_vals.data();
   // (the staging of the previous call must have been read: an event behind its copy, long reached in the steady state)
   if (!s->ev_marg_vals) HIP_TRY(hipEventCreateWithFlags(&s->ev_marg_vals, hipEventDisableTiming));
@@ -2131,8 +2135,13 @@ int okvis_ba_set_marg_prior_values(okvis_ba_solver* s, int w, const double* J, c
   }
   HIP_TRY(hipEventRecord(s->ev_marg_vals, s->stream));
   if (s->patchable && (size_t)w < s->mirrors.size()) {   // the container holds what the device holds
-    s->mirrors[w].marg_J.assign(J, J + (size_t)Dm * Dm);
-    s->mirrors[w].marg_e0.assign(e0, e0 + Dm);
+    try {
+      s->mirrors[w].marg_J.assign(J, J + (size_t)Dm * Dm);
+      s->mirrors[w].marg_e0.assign(e0, e0 + Dm);
+    } catch (const std::bad_alloc&) {
+      s->mirrors.clear();   // (no container any more: the next patch is refused and the caller uploads)
+      s->mirror_fresh = false;
+    }
   }
   s->begun = false;
   s->evaluated = false;
