@@ -24,8 +24,20 @@ ARR = dict(POSE=0, SB=1, LM=2, OBS_RESIDUAL=3, LM_V=4, LM_B=5, LM_HQ=6, PAIR_W=7
            REDUCED_RHS=9, STEP=10, LM_QUALITY=11, GRADIENT=12, IMU_RESIDUAL=13, HPP=14, IMU_SB_REF=16)
 
 
+def locked_make(args, lock_dir):
+    """`make` under an exclusive lock file in lock_dir: parallel test workers (pytest -n) that find the same target stale must not
+    build it into each other's half-written objects."""
+    import fcntl
+    with open(os.path.join(lock_dir, ".make.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make", "-s"] + args, stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def build_oracle():
-    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR], stdout=subprocess.DEVNULL)
+    locked_make(["-C", _ORACLE_DIR], _ORACLE_DIR)
     return os.path.join(_ORACLE_DIR, "liboracle.so")
 
 

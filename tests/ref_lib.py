@@ -33,7 +33,11 @@ def available() -> bool:
 def build() -> str:
     """make -C oracle/ref (needs the reference tree; on the GPU box the prebuilt .so travels with the snapshot)."""
     if os.path.isdir(os.path.join(REFERENCE, "okvis_ceres")):
-        subprocess.check_call(["make", "-s", "-C", _REF_BUILD, f"REF={REFERENCE}"], stdout=subprocess.DEVNULL)
+        try:
+            from tests.oracle_lib import locked_make
+        except ImportError:   # (imported with tests/ itself on the path, e.g. by tests/golden/make_golden.py)
+            from oracle_lib import locked_make
+        locked_make(["-C", _REF_BUILD, f"REF={REFERENCE}"], _REF_BUILD)
     return _REF_SO
 
 
