@@ -122,6 +122,7 @@ struct okvis_ba_solver {
   unsigned char* d_arena = nullptr;
   size_t arena_bytes = 0, arena_capacity = 0, wins_capacity = 0;
   WinPtrs* d_wins = nullptr;
+  CtrlSlot* d_ctrl = nullptr;    // the control records of the uploaded windows (same allocation, behind the window records)
   StageVec stage_dl;             // pinned staging of result downloads (okvis_ba_marginalize)
   StageVec stage, stage_small;   // pinned staging of the arena's data part / of the WinPtrs + OptD records (kept across uploads)
   std::vector<HostWin> wins;
@@ -184,6 +185,9 @@ int fused_max_windows() {
   return v;
 }
 constexpr size_t OPT_PAD = (sizeof(OptD) + 255) & ~size_t(255);   // the option record in front of the window records (one allocation, one copy)
+// [OptD, padded | WinPtrs x n | (padded) CtrlSlot x n]: where the control records of n windows start / how long the block is
+constexpr size_t ctrl_off(size_t n) { return (OPT_PAD + sizeof(WinPtrs) * n + 255) & ~size_t(255); }
+constexpr size_t records_bytes(size_t n) { return ctrl_off(n) + sizeof(CtrlSlot) * n; }
 constexpr int SMALL_BATCH_WINDOWS = 40;   // below: the device is not full - settings that shorten one window's chain win
 
 OptD make_optd(const okvis_ba_options& o, int n_windows) {
@@ -951,6 +955,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       int D = -1;
       std::vector<int> coloff, color;
       std::vector<int4> table;
+      std::vector<int> fastw;
     };
     // (four entries, replaced in turn: the estimator alternates between the window it optimises and the sub-window it marginalises)
     static thread_local ImuAsmCache asm_caches[4];
@@ -962,6 +967,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     ImuAsmCache& asm_cache = asm_caches[asm_hit ? hit : asm_next];
     if (!asm_hit) asm_next = (asm_next + 1) & 3;
     std::vector<int4>& imu_asm = asm_cache.table;
+    std::vector<int>& imu_fastw = asm_cache.fastw;
     if (!asm_hit) {
       asm_cache.D = D;
       asm_cache.coloff = imu_coloff;
@@ -971,7 +977,17 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
         const int bi = i / 6, bj = j / 6;
         return (bj * nbk - (bj * (bj - 1)) / 2 + (bi - bj)) * SBS + (i - 6 * bi) * 6 + (j - 6 * bj);
       };
+      // the same entry in the LDS layout of the LDL^T solver (L16::at, ba_ldl16.hpp): i >= j, stored at the mirrored position
+      const int nb16 = ldl16_nb(D);
+      auto at16 = [&](int i, int j) {
+        const int I = j >> 4, J = i >> 4, r = j & 15, c = i & 15;
+        return (I * nb16 - (I * (I - 1)) / 2 + (J - I)) * 256 + (r >> 2) * 64 + (r & 3) * 16 + c;
+      };
       imu_asm.assign(512 * (size_t)w.n_imu, make_int4(-1, -1, 0, 0));
+      imu_fastw.assign(512 * (size_t)w.n_imu, -1);
+      // (the solve kernel's dynamic LDS: matrix area, then rhs, gradient, diagonal, solution — Dpad doubles each, ba_solve.hpp)
+      const bool lds_system = D <= MAX_D_LDS;
+      const int goff16 = lds_system ? ldl16_area_doubles(D) + ((D + 5) / 6) * 6 : 0;
       for (int f = 0; f < w.n_imu; ++f) {
         const int* co = imu_coloff.data() + 30 * (size_t)f;
         int e = 0;
@@ -980,14 +996,22 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
             const int ra = co[a], rb = co[b];
             if (ra < 0 || rb < 0) continue;
             imu_asm[512 * (size_t)f + e] = make_int4((ra >= rb ? at(ra, rb) : at(rb, ra)) | (imu_color[f] << 24), a == b ? ra : -1,
-                                                     ra >= rb ? (ra << 16 | rb) : (rb << 16 | ra), 0);   // z: the reduced indices (LDS layout of ba_ldl16.hpp)
+                                                     ra >= rb ? (ra << 16 | rb) : (rb << 16 | ra),   // z: the reduced indices
+                                                     0);
+            if (lds_system && imu_color[f] < 16)
+              imu_fastw[512 * (size_t)f + e] = (ra >= rb ? at16(ra, rb) : at16(rb, ra)) | ((a == b ? ra + 1 : 0) << 16) | (imu_color[f] << 24);
           }
         for (int a = 0; a < 30; ++a)
-          if (co[a] >= 0) imu_asm[512 * (size_t)f + 465 + a] = make_int4(co[a] | (1 << 20) | (imu_color[f] << 24), -1, 0, 0);
+          if (co[a] >= 0) {
+            imu_asm[512 * (size_t)f + 465 + a] = make_int4(co[a] | (1 << 20) | (imu_color[f] << 24), -1, 0, 0);
+            if (lds_system && imu_color[f] < 16) imu_fastw[512 * (size_t)f + 465 + a] = (goff16 + co[a]) | (imu_color[f] << 24);
+          }
       }
     }
     if (imu_asm.empty()) OFF(imu_asm, put(A, std::vector<int4>(1, make_int4(-1, -1, 0, 0))));
     else OFF(imu_asm, put(A, imu_asm));
+    if (imu_fastw.empty()) OFF(imu_fastw, put(A, std::vector<int>(1, -1)));
+    else OFF(imu_fastw, put(A, imu_fastw));
     // large windows: the reverse map, so that the tile export (many workgroups) gathers the IMU contributions instead of one
     // workgroup scattering them into HBM.  At most two factors meet in one entry (the chain couples consecutive states).
     std::vector<int2> imu_rev;
@@ -1113,6 +1137,20 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (w.sbprior_sb[i] < 0 || w.sbprior_sb[i] >= nsb) return OKVIS_BA_ERR_ARG;
   for (int i = 0; i < w.n_relpose; ++i)
     if (w.rel_pose0[i] < 0 || w.rel_pose0[i] >= npose || w.rel_pose1[i] < 0 || w.rel_pose1[i] >= npose) return OKVIS_BA_ERR_ARG;
+  {
+    // where the columns of the pose / speed-bias priors sit in the reduced system (the solve kernel used to look this up
+    // through two dependent loads per column)
+    std::vector<int> prior_col(6 * (size_t)w.n_pprior + 9 * (size_t)w.n_sbprior + 1, -1);
+    for (int i = 0; i < w.n_pprior; ++i) {
+      const int off = pose_off[w.pprior_pose[i]];
+      for (int k = 0; k < 6; ++k) prior_col[6 * (size_t)i + k] = off < 0 ? -1 : off + k;
+    }
+    for (int i = 0; i < w.n_sbprior; ++i) {
+      const int off = sb_off[w.sbprior_sb[i]];
+      for (int k = 0; k < 9; ++k) prior_col[6 * (size_t)w.n_pprior + 9 * (size_t)i + k] = off < 0 ? -1 : off + k;
+    }
+    OFF(prior_col, put(A, prior_col));
+  }
 
   H.n_pose = npose; H.n_sb = nsb; H.n_lm = nlm; H.n_obs = nobs; H.n_imu = w.n_imu; H.D = D; H.Dp = Dp;
   H.pose_off = pose_off; H.sb_off = sb_off; H.marg_dim = Dm;
@@ -1139,7 +1177,7 @@ void relocate(WinPtrs& P, unsigned char* base, unsigned char* zbase, int debug) 
   // all pointer members are laid out contiguously from pose[0] to marg_lin; relocate by scanning the
   // struct region as an array of pointers (sizes/scalars precede pose[0])
   const size_t first = offsetof(WinPtrs, pose);
-  const size_t n = (sizeof(WinPtrs) - first) / sizeof(void*);
+  const size_t n = (offsetof(WinPtrs, marg_lin) + sizeof(void*) - first) / sizeof(void*);   // (the record ends with alignment padding)
   for (size_t i = 0; i < n; ++i) {
     const size_t off = reinterpret_cast<size_t>(fields[i]);
     fields[i] = (off & ARENA_ZFLAG) ? zbase + (off & ~ARENA_ZFLAG) : base + off;
@@ -1256,14 +1294,14 @@ hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
 hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
   if (s->max_Dpad_small > 0 && s->group_chunks)   // (one set of partials per linearisation buffer)
     hipLaunchKernelGGL((solve_kernel<false, true>), dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), b.st,
-                       s->d_wins + b.w0, s->d_opt, final_only);
+                       s->d_wins + b.w0, s->d_opt, final_only, s->d_ctrl + b.w0);
   else if (s->max_Dpad_small > 0)
     hipLaunchKernelGGL((solve_kernel<false, false>), dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), b.st,
-                       s->d_wins + b.w0, s->d_opt, final_only);
+                       s->d_wins + b.w0, s->d_opt, final_only, s->d_ctrl + b.w0);
   if (s->max_Dpad_large > 0) {
     // large windows: assemble + export, tiled multi-workgroup Cholesky (fp64 MFMA), back-substitution + finish
     hipLaunchKernelGGL((solve_kernel<true, false>), dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), b.st,
-                       s->d_wins + b.w0, s->d_opt, final_only);
+                       s->d_wins + b.w0, s->d_opt, final_only, s->d_ctrl + b.w0);
     if (!final_only) {
       const int nT = (s->max_Dpad_large + CT_TB - 1) / CT_TB;
       hipLaunchKernelGGL(large_export_kernel, dim3(nT * (nT + 1) / 2, (unsigned)b.nw, CT_TILE / CT_THREADS), dim3(CT_THREADS), 0, b.st,
@@ -1455,9 +1493,10 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
   // the option record and the window records share one allocation — [OptD, padded | WinPtrs x capacity] — so that an upload
   // refreshes both with ONE copy
-  if (e == hipSuccess) e = hipMalloc(&s->d_opt, OPT_PAD + sizeof(WinPtrs));
+  if (e == hipSuccess) e = hipMalloc(&s->d_opt, records_bytes(1));
   if (e == hipSuccess) {
     s->d_wins = reinterpret_cast<WinPtrs*>(reinterpret_cast<unsigned char*>(s->d_opt) + OPT_PAD);
+    s->d_ctrl = reinterpret_cast<CtrlSlot*>(reinterpret_cast<unsigned char*>(s->d_opt) + ctrl_off(1));
     s->wins_capacity = 1;
   }
   // kernels may use more than the default 64 KB of dynamic LDS
@@ -1745,6 +1784,18 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   unsigned char* zbase = s->d_arena + A.data_bytes();
   if (A.zsize) HIP_TRY(hipMemsetAsync(zbase, 0, A.zsize, s->stream));   // overlaps with the copy below
   HIP_TRY(hipMemcpyAsync(s->d_arena, A.host.data(), A.size, hipMemcpyHostToDevice, s->stream));
+  if ((size_t)n_windows > s->wins_capacity) {   // [OptD, padded | WinPtrs x n | CtrlSlot x n], see okvis_ba_create
+    if (s->d_opt) HIP_TRY(hipFree(s->d_opt));
+    s->d_opt = nullptr;
+    s->d_wins = nullptr;
+    s->d_ctrl = nullptr;
+    s->wins_capacity = 0;
+    HIP_TRY(hipMalloc(&s->d_opt, records_bytes((size_t)n_windows)));
+    s->d_wins = reinterpret_cast<WinPtrs*>(reinterpret_cast<unsigned char*>(s->d_opt) + OPT_PAD);
+    s->wins_capacity = (size_t)n_windows;
+  }
+  // (the control records follow the records of the windows that are there: n_windows of them, not the capacity)
+  s->d_ctrl = reinterpret_cast<CtrlSlot*>(reinterpret_cast<unsigned char*>(s->d_opt) + ctrl_off((size_t)n_windows));
   std::vector<WinPtrs> ptrs(n_windows);
   s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = s->max_spart_stride = 0;
   s->max_Dpad_small = s->max_Dpad_large = 0;
@@ -1753,6 +1804,7 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   s->fp32_at_upload = s->opt.fp32_linearize != 0;
   for (int i = 0; i < n_windows; ++i) {
     relocate(wins[i].ptrs, s->d_arena, zbase, s->opt.debug_arrays);
+    wins[i].ptrs.ctrl = (decltype(wins[i].ptrs.ctrl))(&s->d_ctrl[i].c);   // (not the arena's slot: see CtrlSlot)
     ptrs[i] = wins[i].ptrs;
     const WinPtrs& P = ptrs[i];
     s->max_group = std::max(s->max_group, P.n_group);
@@ -1771,22 +1823,15 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   }
   if (!s->group_chunks)   // a batch is fused as a whole or not at all: one set of partials for everybody
     for (int i = 0; i < n_windows; ++i) ptrs[i].spart_buf_stride = 0, ptrs[i].fuse_fast = 0;
-  if ((size_t)n_windows > s->wins_capacity) {   // [OptD, padded | WinPtrs x capacity], see okvis_ba_create
-    if (s->d_opt) HIP_TRY(hipFree(s->d_opt));
-    s->d_opt = nullptr;
-    s->d_wins = nullptr;
-    s->wins_capacity = 0;
-    HIP_TRY(hipMalloc(&s->d_opt, OPT_PAD + sizeof(WinPtrs) * n_windows));
-    s->d_wins = reinterpret_cast<WinPtrs*>(reinterpret_cast<unsigned char*>(s->d_opt) + OPT_PAD);
-    s->wins_capacity = (size_t)n_windows;
-  }
   {
-    const size_t wb = sizeof(WinPtrs) * (size_t)n_windows;
-    s->stage_small.resize(OPT_PAD + wb);
+    // one copy: option record, window records and the (zeroed) control records behind them
+    const size_t wb = sizeof(WinPtrs) * (size_t)n_windows, all = records_bytes((size_t)n_windows);
+    s->stage_small.resize(all);
+    std::memset(s->stage_small.data(), 0, all);
     const OptD d = make_optd(s->opt, n_windows);
     std::memcpy(s->stage_small.data(), &d, sizeof(d));
     std::memcpy(s->stage_small.data() + OPT_PAD, ptrs.data(), wb);
-    HIP_TRY(hipMemcpyAsync(s->d_opt, s->stage_small.data(), OPT_PAD + wb, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_opt, s->stage_small.data(), all, hipMemcpyHostToDevice, s->stream));
   }
   if (n_pre > 0) {   // the records started before the index build take their places in the window
     hipLaunchKernelGGL(imu_pre_place_kernel, dim3((unsigned)n_pre), dim3(64), 0, s->stream, s->d_wins, pre_where, pre_src);
@@ -2831,15 +2876,15 @@ int okvis_ba_marginalize_begin(okvis_ba_solver* s, int w, const okvis_ba_marg_sp
   if (large_window) {
     // assembly of the undamped system, then the kernel that completes it (Schur partials, IMU terms) and, because this copy of
     // the window carries an S pointer, writes it out as one full symmetric D x D matrix
-    hipLaunchKernelGGL((solve_kernel<true, false>), dim3(1), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), s->stream, d_win, s->d_opt, 2);
+    hipLaunchKernelGGL((solve_kernel<true, false>), dim3(1), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), s->stream, d_win, s->d_opt, 2, s->d_ctrl + w);
     const int nT = (((D + 5) / 6) * 6 + CT_TB - 1) / CT_TB;
     hipLaunchKernelGGL(large_export_kernel, dim3(nT * (nT + 1) / 2, 1, CT_TILE / CT_THREADS), dim3(CT_THREADS), 0, s->stream, d_win);
   } else if (s->group_chunks)
     hipLaunchKernelGGL((solve_kernel<false, true>), dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream,
-                       d_win, s->d_opt, 2);
+                       d_win, s->d_opt, 2, s->d_ctrl + w);
   else
     hipLaunchKernelGGL((solve_kernel<false, false>), dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream,
-                       d_win, s->d_opt, 2);
+                       d_win, s->d_opt, 2, s->d_ctrl + w);
   HIP_TRY(hipGetLastError());
   MargArgs ma;
   ma.pose_marg = d + o_pm;

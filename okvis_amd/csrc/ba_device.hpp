@@ -127,6 +127,22 @@ __device__ __forceinline__ double wave_max_full(double v) {
 __device__ __forceinline__ void wave_trial_partials(const WinPtrs& W, int buf, int lane, double part[6]) {
   double cost = 0, gd = 0, ddd = 0, s2 = 0, x2 = 0, gm = 0;
   const double* gs = W.gscal[buf];
+  if (W.n_group <= 64 && W.n_imu <= 64) {
+    // one group and one IMU factor per lane at most (every window up to configs[1]'s size): all loads leave together — as three
+    // loops they were three dependent memory round trips at the head of the solve kernel and of every Schur workgroup.  The
+    // same sums in the same order as the loops below (an absent term adds +0.0).
+    double v[6] = {0, 0, 0, 0, 0, 0}, ic = 0, sc = 0;
+    if (lane < W.n_group) {
+      const double* p = gs + (size_t)lane * GS_COUNT;
+      v[0] = p[GS_COST], v[1] = p[GS_GD], v[2] = p[GS_DDD], v[3] = p[GS_STEP2], v[4] = p[GS_X2], v[5] = p[GS_GMAX];
+    }
+    if (lane < W.n_imu) ic = W.imu_lin[buf][(size_t)lane * IMU_LIN_STRIDE + IMU_COST];
+    if (lane == 0) sc = W.small_cost[buf][0];
+    cost = (0.0 + v[0]) + ic;
+    if (lane == 0) cost += sc;
+    part[0] = cost, part[1] = 0.0 + v[1], part[2] = 0.0 + v[2], part[3] = 0.0 + v[3], part[4] = 0.0 + v[4], part[5] = fmax(0.0, v[5]);
+    return;
+  }
   for (int g = lane; g < W.n_group; g += 64) {
     const double* p = gs + (size_t)g * GS_COUNT;
     cost += p[GS_COST];

@@ -141,7 +141,7 @@ template <class LYT>
 __device__ void assemble_base(const WinPtrs& W, int acc, const LYT LY, double* S, double* g, double* d2,
                               int* coloff, int tid, int nthreads, bool skip_imu,
                               const double* pri = nullptr, const int* pricol = nullptr, int n_pri = 0,
-                              bool imu_matrix_elsewhere = false) {
+                              bool imu_matrix_elsewhere = false, bool skip_priors = false) {
   // pri / pricol: LDS copies of the first n_pri (<= PRI_STAGE) pose priors [f][42], speed/bias priors r [f][9] and
   // sqrtInfo [f][81] of buffer `acc` and their reduced column offsets [f][6] | [f][9], staged by the caller
   // ---- IMU factors: precomputed H (30x30 lower) | g (30); factors of one colour touch disjoint blocks ----
@@ -207,9 +207,8 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const LYT LY, double* S
       __syncthreads();
     }
   }
-  if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[58] = (double)clock64();   // diagnostics: end of the IMU part
-  // ---- pose priors: J 6x6 | r 6 ----
-  for (int f = 0; f < W.n_pprior; ++f) {
+  // ---- pose priors: J 6x6 | r 6 ----  (skip_priors: the caller has added the pose and speed/bias priors itself)
+  for (int f = 0; f < (skip_priors ? 0 : W.n_pprior); ++f) {
     if (f < n_pri) {
       const double* L = pri + 42 * f;
       add_small_factor(S, LY, g, d2, L, L + 36, 6, 6, pricol + 6 * f, tid, nthreads);
@@ -226,7 +225,7 @@ __device__ void assemble_base(const WinPtrs& W, int acc, const LYT LY, double* S
     __syncthreads();
   }
   // ---- speed/bias priors: J = -sqrtInfo (9x9 const) | r 9 ----
-  for (int f = 0; f < W.n_sbprior; ++f) {
+  for (int f = 0; f < (skip_priors ? 0 : W.n_sbprior); ++f) {
     const bool st = f < n_pri;
     if (!st) {
       if (tid < 9) {
@@ -500,12 +499,32 @@ __device__ __forceinline__ void solve_failed_dl(Ctrl* c, const OptD& opt) {
 // are taken from the buffer that is accepted if the pending trial is, and taken again when it was not.
 template <bool LARGE, bool DBUF>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __restrict__ wins,
-                                                              const OptD* __restrict__ optp, int final_only) {
+                                                              const OptD* __restrict__ optp, int final_only, CtrlSlot* ctrls) {
   static_assert(!(LARGE && DBUF), "windows solved in HBM are never fused");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const WinPtrs& W = wins[blockIdx.x];
+  // The control record: its address comes from the kernel arguments (CtrlSlot, ba_types.hpp; == W.ctrl), so its first words —
+  // accepted buffer, pending, first, done — are requested together with the window record.  Every speculative load below
+  // (Schur partials, IMU / prior records, states, the trial's scalar partials) takes its buffer index from them: they all
+  // leave one memory round trip earlier than when the record's address had to be read from the window record first.
+  Ctrl* gctrl = &ctrls[blockIdx.x].c;
+  typedef int ctrl_v4 __attribute__((ext_vector_type(4)));
+  const ctrl_v4 chead = *as_global(reinterpret_cast<const ctrl_v4*>(gctrl));   // acc, pending, first, done
+  // The window record is 18 lines of the scalar cache, and the compiler fetches a field where it is first used: line after
+  // line, each miss a memory round trip of its own in front of whatever needed the field.  One dword of every line is
+  // requested here, next to the control words; the fields then come from the cache.  (Plain loads whose combination feeds a
+  // branch that is never taken: any inline assembly in this kernel makes the compiler read the whole record with vector loads.)
+  int warm = 0;
+  {
+    static_assert(sizeof(WinPtrs) <= 18 * 64, "lines touched below");
+    const int* wi = reinterpret_cast<const int*>(&W);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) warm |= wi[16 * k];
+  }
+  // the buffer that is accepted if the pending trial is (uniform: a scalar register, so are the addresses derived from it)
+  const int spec0 = __builtin_amdgcn_readfirstlane(chead.y ? 1 - chead.x : chead.x);
+  if (final_only == 0x7ffffff1 && warm == 0x5a5a5a5a) return;   // (never: keeps the loads above)
   if (LARGE != (W.Sg != nullptr)) return;  // each window is handled by the instantiation that fits it
-  Ctrl* gctrl = W.ctrl;
   const int tid = threadIdx.x;
   if constexpr (!LARGE) {
     // ---- helper workgroups (blockIdx.y < gridDim.y - 1; dispatched before the solving workgroup of their window): the sum
@@ -517,16 +536,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       const int nh = (int)gridDim.y - 1;
       const int ntot = W.spart_stride, per = (ntot + nh - 1) / nh;
       if (W.n_chunk > 0) {   // (also for a finished window: the sums are not used then, but nothing has to be read to find out)
+        const size_t stride = (size_t)__builtin_amdgcn_readfirstlane(W.spart_stride);   // (uniform: the chunk offsets are scalar arithmetic)
+        const int nch = __builtin_amdgcn_readfirstlane(W.n_chunk);
+        auto sp0 = W.spart + (DBUF ? (size_t)spec0 * W.spart_buf_stride : (size_t)0);   // (the speculated buffer)
         for (int k = tid; k < per; k += SOLVE_THREADS) {
           const int i = blockIdx.y * per + k;
           if (i >= ntot) break;
-          const size_t stride = W.spart_stride;
-          const int nch = W.n_chunk;
-          auto sp = W.spart + (DBUF ? (size_t)__builtin_amdgcn_readfirstlane(gctrl->pending ? 1 - gctrl->acc : gctrl->acc) * W.spart_buf_stride : (size_t)0) + i;   // (the speculated buffer)
+          auto sp = sp0 + i;
           double a = 0;
-          // (every chunk of a fused window - up to 34 for configs[1] - requested in ONE trip: the helpers' loads come from other
+          // (every chunk of a fused window - 34 for configs[1] - requested in ONE trip: the helpers' loads come from other
           // CUs' stores, a trip costs a full memory round trip and there is nothing else to do meanwhile)
-          constexpr int HB = 18;
+          constexpr int HB = 36;
           for (int ch = 0; ch < nch; ch += HB) {
             double v[HB];
 #pragma unroll
@@ -545,25 +565,34 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       return;
     }
   }
-  // (solving workgroup) helpers delivered so far must reach SOLVE_HELPERS x the number of solve launches of this window
-  // (work-item 64 alone keeps this book and polls; the other waves follow its LDS flag)
-  int sum_expected = 0;
-  __shared__ int s_sum_ready;   // 1 = the helpers' sums are there, 2 = they are late: summed here
+  // ------------------------------------------------------------------ 0. every request that needs no decision, in one go
+  // The prologue is straight-line code: every load below is issued before the first of them is waited for (one memory round
+  // trip for all of them), indices are clamped instead of guarded (a lane without an element requests element 0 along), and
+  // what goes to LDS is stored further down, in the shadow of wave 0's decision.  (As guarded load-store pairs — `if (t < n)
+  // s_x[t] = W.x[t]` — every pair waited for its own load: eight memory round trips in a row before the IMU records and the
+  // Schur sums were even requested.)
   const bool helped = !LARGE && gridDim.y > 1;   // small launches only: a helper occupies a whole CU (the kernel's LDS footprint)
-  if (!LARGE && tid == 64) {
-    sum_expected = W.sum_sync[1] + ((int)gridDim.y - 1);   // helper arrivals this window must have seen after this launch
-    W.sum_sync[1] = sum_expected;
-    s_sum_ready = helped ? 0 : 1;
-  }
-
-  // The window record (sizes and ~140 pointers, 1.3 KB in HBM) is copied to LDS once: every later W.field is an LDS read
+  __shared__ int s_sum_ready;   // 1 = the helpers' sums are there, 2 = they are late: summed here
+  const int t64 = tid - 64;                 // work-item index among the waves 1 .. 15
+  const int tl = t64 < 0 ? 0 : t64;
+  // helpers delivered so far must reach SOLVE_HELPERS x the number of solve launches of this window (work-item 64 alone keeps
+  // this book and polls; the other waves follow its LDS flag)
+  const int sum_launches = LARGE ? 0 : as_global(W.sum_sync)[1];
+  // The window record (sizes and ~140 pointers, 1.1 KB in HBM) is copied to LDS once: every later W.field is an LDS read
   // instead of a scalar load that misses its cache line by line (measured: 3 us of the 4.6 us tail were such misses)
   __shared__ double s_Wd[(sizeof(WinPtrs) + 7) / 8];
   static_assert(sizeof(WinPtrs) % 8 == 0, "copied as doubles");
-  if (!LARGE && tid >= 64 && tid < 64 + (int)(sizeof(WinPtrs) / 8)) s_Wd[tid - 64] = reinterpret_cast<const double*>(&W)[tid - 64];
+  constexpr int WD_N = (int)(sizeof(WinPtrs) / 8);
+  const double wd_v = LARGE ? 0.0 : reinterpret_cast<const double*>(&W)[tl < WD_N ? tl : 0];
   if (LARGE && tid == 0) W.ct_flag[W.ct_nT * (W.ct_nT + 1) / 2 + 1] = 0;  // no system exported (yet) this launch
-  if (gctrl->done) return;
-  const OptD opt = *optp;
+  if (chead.w) {   // done (the launch still counts: the helpers of this window have arrived, or will)
+    if (helped && tid == 64) as_global(W.sum_sync)[1] = sum_launches + ((int)gridDim.y - 1);
+    return;
+  }
+  // (a reference, not a copy: the fields are scalar loads from the option record where they are used.  As a local copy the
+  //  record lived in scratch memory — its address is handed to the decision functions — and every opt.field was a scratch
+  //  load whose wait also waited for every prefetch in flight)
+  const OptD& opt = *optp;
   const int D = W.D, Dp = W.Dp;
   const int Dpad = ((D + 5) / 6) * 6, nbk = Dpad / 6;
   // LDS-resident: the matrix area of the LDL^T solver (upper 16x16 blocks incl. the rhs column D, or its work area)
@@ -584,83 +613,64 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
 
 #define STAMP(k) do { if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[k] = (double)clock64(); } while (0)
   STAMP(0);
-  // IMU factor records (H | g, 495 doubles each): value and destination (host-built imu_asm) of up to IMU_NPF entries
-  // per lane are requested now, from the buffer that is accepted if the pending step is (the common case), and
-  // scattered after the decision without any further global round trip.
-  constexpr int IMU_NPF = 6, IMU_NL = SOLVE_THREADS - 64;
-  const int imu_items = W.n_imu * 512;
-  const bool imu_fast = !LARGE && imu_items <= IMU_NPF * IMU_NL;
-  double imu_v[IMU_NPF];
-  int imu_dst[IMU_NPF], imu_d2[IMU_NPF], imu_rc[IMU_NPF];
-  int imu_spec = 0;
-#pragma unroll
-  for (int j = 0; j < IMU_NPF; ++j) {
-    imu_v[j] = 0;
-    imu_dst[j] = -1;
-    imu_d2[j] = -1;
-    imu_rc[j] = 0;
-  }
-  const double dec_pref = (!LARGE && tid < DEC_COUNT) ? W.dec[tid] : 0.0;   // the Schur kernel's decision record (wave 0 reads it below)
+  const double dec_pref = LARGE ? 0.0 : W.dec[tid < DEC_COUNT ? tid : 0];   // the Schur kernel's decision record (wave 0 reads it below)
   // the Jacobi scale of this lane's column (used by the damping, section 4): requested now, the value is only wrong in the
   // launch that estimates it
-  const double scale_pref = (tid < D && opt.dogleg) ? W.scale_p[tid] : 1.0;
+  const double scale_pref = opt.dogleg ? W.scale_p[tid < D ? tid : 0] : 1.0;
+  // pose / speed-bias prior records of the speculated buffer and their columns in the reduced system (host-built) -> LDS
   __shared__ double s_pri[PRI_STAGE * (42 + 9 + 81)];
   __shared__ int s_pricol[PRI_STAGE * (6 + 9)];
   const int n_pri = (!LARGE && W.n_pprior <= PRI_STAGE && W.n_sbprior <= PRI_STAGE) ? PRI_STAGE : 0;
-  if (n_pri && tid >= 64) {   // prior records of the speculated buffer and their column offsets -> LDS
-    const int spec = gctrl->pending ? 1 - gctrl->acc : gctrl->acc;
-    const int t = tid - 64;
-    if (t < W.n_pprior * 42) s_pri[t] = W.pp_lin[spec][t];
-    if (t < W.n_sbprior * 9) s_pri[PRI_STAGE * 42 + t] = W.sbp_lin[spec][t];
-    if (t < W.n_sbprior * 81) s_pri[PRI_STAGE * 51 + t] = W.sbprior_sqrtinfo[t];
-    if (t < W.n_pprior * 6) {
-      const int off = W.pose_off[W.pprior_pose[t / 6]];
-      s_pricol[t] = off < 0 ? -1 : off + t % 6;
-    }
-    if (t < W.n_sbprior * 9) {
-      const int off = W.sb_off[W.sbprior_sb[t / 9]];
-      s_pricol[PRI_STAGE * 6 + t] = off < 0 ? -1 : off + t % 9;
-    }
+  double pri_a = 0, pri_b = 0, pri_c = 0;
+  int pri_col = -1;
+  if (n_pri) {   // (uniform)
+    const int npp = W.n_pprior, nsp = W.n_sbprior;
+    pri_a = W.pp_lin[spec0][(tl < npp * 42 && npp > 0) ? tl : 0];
+    pri_b = W.sbp_lin[spec0][(tl < nsp * 9 && nsp > 0) ? tl : 0];
+    pri_c = W.sbprior_sqrtinfo[(tl < nsp * 81 && nsp > 0) ? tl : 0];
+    pri_col = W.prior_col[tl < npp * 6 + nsp * 9 ? tl : 0];
   }
   // accepted pose / speed-bias values of the speculated buffer -> LDS (the convergence test and the trial states read them;
   // one memory round trip here instead of two on the critical path later)
   __shared__ double s_pre[PRE_BLOCKS * 16];
   __shared__ int s_preoff[2 * PRE_BLOCKS];   // reduced offsets of the first PRE_BLOCKS pose blocks | speed/bias blocks
-  const bool pre_on = !LARGE;
-  double pre_v[2] = {0, 0};
-  int pre_o = -1;
-  if (pre_on && tid >= 64 + PRE_BLOCKS * 8 && tid < 64 + PRE_BLOCKS * 10) {
-    const int t = tid - 64 - PRE_BLOCKS * 8;
-    if (t < PRE_BLOCKS) pre_o = t < W.n_pose ? W.pose_off[t] : -1;
-    else pre_o = t - PRE_BLOCKS < W.n_sb ? W.sb_off[t - PRE_BLOCKS] : -1;
+  constexpr bool pre_on = !LARGE;
+  // (what is loaded is only selected where it is stored: a select in front of the other requests makes the compiler wait for
+  //  the load — and with it for every request issued so far — right here)
+  double pre_a0 = 0, pre_b0 = 0, pre_a1 = 0, pre_b1 = 0;
+  int pre_po = -1, pre_so = -1;
+  if constexpr (pre_on) {
+    // two doubles per work-item 64 .. 64 + 8 PRE_BLOCKS - 1: element i = 2 t + u of [pose values (7 per block) | speed/bias values (9)]
+    const int np7 = 7 * W.n_pose, ns9 = 9 * W.n_sb;
+    const int i0 = 2 * tl, i1 = 2 * tl + 1;
+    const int kp0 = i0 < np7 ? i0 : 0, kp1 = i1 < np7 ? i1 : 0;
+    const int ks0 = (i0 >= PRE_BLOCKS * 7 && i0 - PRE_BLOCKS * 7 < ns9) ? i0 - PRE_BLOCKS * 7 : 0;
+    const int ks1 = (i1 >= PRE_BLOCKS * 7 && i1 - PRE_BLOCKS * 7 < ns9) ? i1 - PRE_BLOCKS * 7 : 0;
+    auto pp = W.pose[spec0];
+    auto sp = W.sb[spec0];
+    pre_a0 = pp[kp0], pre_b0 = sp[ks0], pre_a1 = pp[kp1], pre_b1 = sp[ks1];
+    // the reduced offsets: work-items 64 + 8 PRE_BLOCKS .. + 10 PRE_BLOCKS - 1
+    const int to = tl - PRE_BLOCKS * 8;
+    pre_po = W.pose_off[(to >= 0 && to < PRE_BLOCKS && to < W.n_pose) ? to : 0];
+    pre_so = W.sb_off[(to >= PRE_BLOCKS && to < 2 * PRE_BLOCKS && to - PRE_BLOCKS < W.n_sb) ? to - PRE_BLOCKS : 0];
   }
-  if (pre_on && tid >= 64 && tid < 64 + PRE_BLOCKS * 8) {
-    const int spec = gctrl->pending ? 1 - gctrl->acc : gctrl->acc;
-    const int t = tid - 64;   // two doubles per lane
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = 2 * t + u;
-      if (i < PRE_BLOCKS * 7) {
-        if (i < 7 * W.n_pose) pre_v[u] = W.pose[spec][i];
-      } else if (i - PRE_BLOCKS * 7 < 9 * W.n_sb) {
-        pre_v[u] = W.sb[spec][i - PRE_BLOCKS * 7];
-      }
-    }
-  }
-  if (imu_fast && tid >= 64) {
-    imu_spec = gctrl->pending ? 1 - gctrl->acc : gctrl->acc;
-    const double* src = W.imu_lin[imu_spec];
-#pragma unroll
-    for (int j = 0; j < IMU_NPF; ++j) {
-      const int idx = tid - 64 + j * IMU_NL;
-      if (idx < imu_items) {
-        const int4 d = W.imu_asm[idx];
-        imu_dst[j] = d.x;
-        imu_d2[j] = d.y;
-        imu_rc[j] = d.z;
-        imu_v[j] = src[idx];
-      }
-    }
+  // IMU factor records (H | g, 495 doubles each): value and destination (host-built imu_fastw: one word per entry) of up to
+  // IMU_NPF entries per lane are requested now, from the buffer that is accepted if the pending step is (the common case),
+  // and scattered after the decision without any further global round trip.
+  constexpr int IMU_NPF = 6, IMU_NL = SOLVE_THREADS - 64;
+  const int imu_items = W.n_imu * 512;
+  const bool imu_fast = !LARGE && imu_items <= IMU_NPF * IMU_NL && W.n_imu_color < 16;
+  const int imu_spec = spec0;
+  // (named scalars, not arrays: with 128 registers per lane the compiler parks small private arrays in scratch memory)
+  double imu_v0 = 0, imu_v1 = 0, imu_v2 = 0, imu_v3 = 0, imu_v4 = 0, imu_v5 = 0;
+  int imu_w0 = -1, imu_w1 = -1, imu_w2 = -1, imu_w3 = -1, imu_w4 = -1, imu_w5 = -1;
+  if (imu_fast && imu_items > 0) {   // (uniform)
+    auto src = W.imu_lin[imu_spec];
+    auto dst = W.imu_fastw;
+#define BA_IMU_REQ(j) { const int idx = tl + (j) * IMU_NL; const bool on = t64 >= 0 && idx < imu_items; imu_w##j = dst[on ? idx : 0]; \
+                        imu_v##j = src[on ? idx : 0]; }   /* (a lane without an entry: masked behind the barrier, see BA_IMU_MASK) */
+    BA_IMU_REQ(0) BA_IMU_REQ(1) BA_IMU_REQ(2) BA_IMU_REQ(3) BA_IMU_REQ(4) BA_IMU_REQ(5)
+#undef BA_IMU_REQ
   }
   // The chunk partials of linearisation buffer `buf` -> S and the pose part of the three vectors (waves 1 .. 15).  use_sums:
   // the helper workgroups have summed them (into W.spart_sum).  One item = one double of the partials' record (lower triangle
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // dependent rounds), scattered into the 16x16 accumulator-layout blocks of the LDL^T solver.
   // (readfirstlane: the index is uniform, but it comes from a vector load — as a VGPR it drags every address of the sums into
   // vector registers and the kernel into 100 spills)
-  const int sum_spec = DBUF ? __builtin_amdgcn_readfirstlane(gctrl->pending ? 1 - gctrl->acc : gctrl->acc) : 0;   // the buffer that is accepted if the pending trial is
+  const int sum_spec = DBUF ? spec0 : 0;   // the buffer that is accepted if the pending trial is
   auto sum_partials = [&](int buf, bool use_sums) {
     if constexpr (!LARGE) {
       const int npose_blk = Dp / 6;
@@ -730,8 +740,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     double sums[6] = {0, 0, 0, 0, 0, 0};
     Decision d;
     d.accept = 0; d.term = 0;
-    // the control record: one coalesced load into the LDS copy, which decide() reads and lane 0 then updates
-    if (tid < (int)(sizeof(Ctrl) / 8)) reinterpret_cast<double*>(&c)[tid] = reinterpret_cast<const double*>(gctrl)[tid];
+    // the scalar partials of the trial (per group, per IMU factor, priors): requested now, with the decision record of the Schur
+    // kernel, and reduced below only when no Schur launch has decided (fused mode)
+    // (the control record itself: one coalesced load, requested first, into the LDS copy that decide() reads and lane 0 updates)
+    double cword = 0;
+    if (tid < (int)(sizeof(Ctrl) / 8)) cword = as_global(reinterpret_cast<const double*>(gctrl))[tid];
+    double tpart[6] = {0, 0, 0, 0, 0, 0};
+    if (chead.y) wave_trial_partials(W, 1 - chead.x, tid, tpart);
+    if (tid < (int)(sizeof(Ctrl) / 8)) reinterpret_cast<double*>(&c)[tid] = cword;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     asm volatile("" ::: "memory");
     const int pending = c.pending;
@@ -757,9 +773,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         }
         if (tid == 0) W.dec[DEC_VALID] = 0.0;   // consumed
       } else {
-        wave_trial_sums(W, 1 - c.acc, tid, sums);
-        if (opt.dogleg) decide_dl(&c, &opt, sums, final_only != 0, &dl);
-        else decide(&c, &opt, sums, &d);
+        wave_trial_reduce(tpart, sums);
+        if (opt.dogleg) decide_dl_inl(&c, &opt, sums, final_only != 0, &dl);
+        else decide_inl(&c, &opt, sums, &d);
       }
     }
     if (tid == 0) {
@@ -857,31 +873,57 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       // (not co-scheduled: other streams or processes hold the CUs) do not stop the window, this workgroup then sums the chunk
       // partials itself as a launch without helpers does (same chunk order: the same sums), and the time-out is counted
       // (sum_sync[2]; okvis_ba_helper_timeouts) so that it shows in tests and in bench.py.
+      // what the prologue requested for LDS: stored here, where the helpers' sums (or this workgroup's own loads of the chunk
+      // partials) are the longer wait
+      auto stage_stores = [&]() {
+        if (t64 < WD_N) s_Wd[t64] = wd_v;
+        if (n_pri) {
+          const int npp = W.n_pprior, nsp = W.n_sbprior;
+          if (t64 < npp * 42) s_pri[t64] = pri_a;
+          if (t64 < nsp * 9) s_pri[PRI_STAGE * 42 + t64] = pri_b;
+          if (t64 < nsp * 81) s_pri[PRI_STAGE * 51 + t64] = pri_c;
+          if (t64 < npp * 6) s_pricol[t64] = pri_col;
+          else if (t64 < npp * 6 + nsp * 9) s_pricol[PRI_STAGE * 6 + t64 - npp * 6] = pri_col;
+        }
+        if (pre_on && t64 < PRE_BLOCKS * 8) {
+          const int np7 = 7 * W.n_pose, ns9 = 9 * W.n_sb;
+          const int i0 = 2 * t64, i1 = 2 * t64 + 1;
+          s_pre[i0] = i0 < PRE_BLOCKS * 7 ? (i0 < np7 ? pre_a0 : 0.0) : (i0 - PRE_BLOCKS * 7 < ns9 ? pre_b0 : 0.0);
+          s_pre[i1] = i1 < PRE_BLOCKS * 7 ? (i1 < np7 ? pre_a1 : 0.0) : (i1 - PRE_BLOCKS * 7 < ns9 ? pre_b1 : 0.0);
+        } else if (pre_on && t64 < PRE_BLOCKS * 10) {
+          const int to = t64 - PRE_BLOCKS * 8;
+          s_preoff[to] = to < PRE_BLOCKS ? (to < W.n_pose ? pre_po : -1) : (to - PRE_BLOCKS < W.n_sb ? pre_so : -1);
+        }
+      };
+      // The flag the other waves follow carries this launch's count (a stale word of an earlier workgroup on this CU cannot
+      // be mistaken for it): count << 2 | 1 = the helpers' sums are there, | 2 = they are late: summed here.
+      const int sum_expected = sum_launches + ((int)gridDim.y - 1);   // helper arrivals this window must have seen after this launch
+      if (helped) stage_stores();
       if (helped && tid == 64) {
+        as_global(W.sum_sync)[1] = sum_expected;
         int polls = 0;
         while (__hip_atomic_load(W.sum_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sum_expected && polls < opt.helper_polls) {
           __builtin_amdgcn_s_sleep(2);
           ++polls;
         }
         if (polls >= opt.helper_polls) W.sum_sync[2] += 1;
-        __hip_atomic_store(&s_sum_ready, polls >= opt.helper_polls ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&s_sum_ready, (sum_expected << 2) | (polls >= opt.helper_polls ? 2 : 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+      bool use_sums = false;
       if (helped) {
         // (no agent-scope acquire, which would invalidate the caches: the sums are read with device-coherent loads below)
-        while (__hip_atomic_load(&s_sum_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+        int v;
+        while (((v = __hip_atomic_load(&s_sum_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) != sum_expected || (v & 3) == 0)
+          __builtin_amdgcn_s_sleep(1);
+        use_sums = (v & 3) == 1;
       }
-      sum_partials(sum_spec, helped && __hip_atomic_load(&s_sum_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1);
+      sum_partials(sum_spec, use_sums);
+      if (!helped) stage_stores();
       for (int i = tid - 64; i < 3 * (Dpad - Dp); i += NL) {   // speed/bias part of the vectors starts from zero
         const int which = i / (Dpad - Dp), j = Dp + i - which * (Dpad - Dp);
         (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = 0.0;
       }
       for (int i = tid - 64; i < Dpad; i += SOLVE_THREADS - 64) s_x[i] = 0.0;
-    }
-    if (pre_on && tid < 64 + PRE_BLOCKS * 8) {
-      s_pre[2 * (tid - 64)] = pre_v[0];
-      s_pre[2 * (tid - 64) + 1] = pre_v[1];
-    } else if (pre_on && tid < 64 + PRE_BLOCKS * 10) {
-      s_preoff[tid - 64 - PRE_BLOCKS * 8] = pre_o;
     }
     if (W.prof && tid == 64 && blockIdx.x == 0) W.prof[4] = (double)clock64();
   }
@@ -921,33 +963,125 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       (which == 0 ? s_rhs : (which == 1 ? s_g : s_d2))[j] = a;
     }
     for (int i = tid; i < Dpad; i += SOLVE_THREADS) s_x[i] = 0.0;
+    __syncthreads();
   }
-  __syncthreads();
   STAMP(2);
-  if (imu_fast) {
-    if (tid >= 64 && acc != imu_spec) {   // the step was rejected: the records of the other buffer are needed
-      const double* src = Wl.imu_lin[acc];
-#pragma unroll
-      for (int j = 0; j < IMU_NPF; ++j)
-        if (imu_dst[j] >= 0) imu_v[j] = src[tid - 64 + j * IMU_NL];
-    }
-    for (int col = 0; col < Wl.n_imu_color; ++col) {   // factors of one colour touch disjoint blocks
-#pragma unroll
-      for (int j = 0; j < IMU_NPF; ++j) {
-        const int d = imu_dst[j];
-        if (d >= 0 && (d >> 24) == col) {
-          if (d & (1 << 20)) {
-            s_g[d & 0xFFFFF] += imu_v[j];
-          } else {
-            S[imu_dst_off(LY, make_int4(d, 0, imu_rc[j], 0))] += imu_v[j];
-            if (imu_d2[j] >= 0) s_d2[imu_d2[j]] += imu_v[j];
+  // The staged pose / speed-bias priors (the stock configuration has one of each) belong to wave 0, which holds no IMU entries
+  // and idles through the colour passes: it forms their J^T J / J^T r entries (the expressions of add_small_factor, same bits)
+  // from the LDS copies of the records during the first pass and adds them in ONE pass behind the IMU colours — pose prior p
+  // and speed/bias prior p never share a block.  Two tasks per lane and pass: 21 + 6 entries of the pose prior, 45 + 9 of the
+  // speed/bias prior.
+  const int goff = (int)(s_g - smem);   // the gradient as an offset into the dynamic LDS, like the matrix entries
+  const bool w0pri = !LARGE && n_pri > 0 && (Wl.n_pprior > 0 || Wl.n_sbprior > 0);
+  const bool rejected = s_was_pending && !s_accepted;   // the speculated buffer was the wrong one (rare): records are restaged below
+  // (named scalars, not arrays: with 128 registers per lane the compiler parks small private arrays in scratch memory)
+  static_assert(PRI_STAGE == 2, "the four tasks below");
+  double pr_v00 = 0, pr_v01 = 0, pr_v10 = 0, pr_v11 = 0;
+  int pr_o00 = -1, pr_o01 = -1, pr_o10 = -1, pr_o11 = -1, pr_d00 = -1, pr_d01 = -1, pr_d10 = -1, pr_d11 = -1;
+  auto prior_task = [&](int p, int t, double& val, int& off, int& d2i) {   // task t of pass p (wave 0 only)
+    if (t < 27) {
+      if (p < Wl.n_pprior) {
+        const double* L = s_pri + 42 * p;
+        const int* co = s_pricol + 6 * p;
+        if (t < 21) {
+          int a = 0;
+          while ((a + 1) * (a + 2) / 2 <= t) ++a;
+          const int b = t - a * (a + 1) / 2;
+          const int ra = co[a], rb = co[b];
+          if (ra >= 0 && rb >= 0) {
+            double sacc = 0;
+            for (int k = 0; k < 6; ++k) sacc += L[k * 6 + a] * L[k * 6 + b];
+            val = sacc;
+            off = LY.at(ra, rb);
+            d2i = a == b ? ra : -1;
+          }
+        } else {
+          const int a = t - 21, ra = co[a];
+          if (ra >= 0) {
+            double sacc = 0;
+            for (int k = 0; k < 6; ++k) sacc += L[k * 6 + a] * L[36 + k];
+            val = sacc;
+            off = goff + ra;
           }
         }
       }
+    } else if (t < 81) {
+      if (p < Wl.n_sbprior) {
+        // J^T J and J^T r are sign-invariant / sign-flipped: +sqrtInfo with -r
+        const double* Jc = s_pri + PRI_STAGE * 51 + 81 * p;
+        const double* r = s_pri + PRI_STAGE * 42 + 9 * p;
+        const int* co = s_pricol + PRI_STAGE * 6 + 9 * p;
+        if (t < 72) {
+          const int e = t - 27;
+          int a = 0;
+          while ((a + 1) * (a + 2) / 2 <= e) ++a;
+          const int b = e - a * (a + 1) / 2;
+          const int ra = co[a], rb = co[b];
+          if (ra >= 0 && rb >= 0) {
+            double sacc = 0;
+            for (int k = 0; k < 9; ++k) sacc += Jc[k * 9 + a] * Jc[k * 9 + b];
+            val = sacc;
+            off = LY.at(ra, rb);
+            d2i = a == b ? ra : -1;
+          }
+        } else {
+          const int a = t - 72, ra = co[a];
+          if (ra >= 0) {
+            double sacc = 0;
+            for (int k = 0; k < 9; ++k) sacc -= Jc[k * 9 + a] * r[k];
+            val = sacc;
+            off = goff + ra;
+          }
+        }
+      }
+    }
+  };
+  auto prior_tasks = [&]() {
+    prior_task(0, tid, pr_v00, pr_o00, pr_d00);
+    prior_task(0, tid + 64, pr_v01, pr_o01, pr_d01);
+    prior_task(1, tid, pr_v10, pr_o10, pr_d10);
+    prior_task(1, tid + 64, pr_v11, pr_o11, pr_d11);
+  };
+  // one pass: every read of the wave leaves before its first write (the entries of a pass are disjoint)
+  auto prior_apply = [&](double va, int oa, int da, double vb, int ob, int db) {
+    const double a0 = oa >= 0 ? smem[oa] : 0.0, a1 = da >= 0 ? s_d2[da] : 0.0;
+    const double b0 = ob >= 0 ? smem[ob] : 0.0, b1 = db >= 0 ? s_d2[db] : 0.0;
+    if (oa >= 0) smem[oa] = a0 + va;
+    if (da >= 0) s_d2[da] = a1 + va;
+    if (ob >= 0) smem[ob] = b0 + vb;
+    if (db >= 0) s_d2[db] = b1 + vb;
+  };
+  bool pri_formed = false;
+  if (imu_fast) {
+    if (imu_items > 0) {
+#define BA_IMU_MASK(j) if (!(t64 >= 0 && t64 + (j) * IMU_NL < imu_items)) imu_w##j = -1;
+      BA_IMU_MASK(0) BA_IMU_MASK(1) BA_IMU_MASK(2) BA_IMU_MASK(3) BA_IMU_MASK(4) BA_IMU_MASK(5)
+#undef BA_IMU_MASK
+    }
+    if (t64 >= 0 && acc != imu_spec) {   // the step was rejected: the records of the other buffer are needed
+      auto src = Wl.imu_lin[acc];
+#define BA_IMU_RELOAD(j) if (imu_w##j >= 0) imu_v##j = src[t64 + (j) * IMU_NL];
+      BA_IMU_RELOAD(0) BA_IMU_RELOAD(1) BA_IMU_RELOAD(2) BA_IMU_RELOAD(3) BA_IMU_RELOAD(4) BA_IMU_RELOAD(5)
+#undef BA_IMU_RELOAD
+    }
+    for (int col = 0; col < Wl.n_imu_color; ++col) {   // factors of one colour touch disjoint blocks
+      // (the entries of one colour are disjoint, a work-item's own included: all of its reads leave before the first write —
+      // two LDS round trips per colour instead of one per entry.  A word of imu_fastw: offset in the dynamic LDS | (index in the
+      // diagonal + 1) << 16 | colour << 24.)
+#define BA_IMU_RD(j) const bool on##j = imu_w##j >= 0 && (imu_w##j >> 24) == col; const int d##j = ((imu_w##j >> 16) & 0xFF) - 1; \
+                     const double o##j = on##j ? smem[imu_w##j & 0xFFFF] : 0.0; const double q##j = (on##j && d##j >= 0) ? s_d2[d##j] : 0.0;
+      BA_IMU_RD(0) BA_IMU_RD(1) BA_IMU_RD(2) BA_IMU_RD(3) BA_IMU_RD(4) BA_IMU_RD(5)
+#undef BA_IMU_RD
+#define BA_IMU_WR(j) if (on##j) { smem[imu_w##j & 0xFFFF] = o##j + imu_v##j; if (d##j >= 0) s_d2[d##j] = q##j + imu_v##j; }
+      BA_IMU_WR(0) BA_IMU_WR(1) BA_IMU_WR(2) BA_IMU_WR(3) BA_IMU_WR(4) BA_IMU_WR(5)
+#undef BA_IMU_WR
+      if (col == 0 && w0pri && !rejected && tid < 64) prior_tasks();
       __syncthreads();
     }
+    pri_formed = Wl.n_imu_color > 0 && !rejected;
   }
-  if (pre_on && s_was_pending && !s_accepted) {   // rejected step: the other buffer stays accepted
+  if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[58] = (double)clock64();   // diagnostics: end of the IMU part
+  if (pre_on && rejected) {   // rejected step: the other buffer stays accepted
     for (int i = tid; i < PRE_BLOCKS * 16; i += SOLVE_THREADS) {
       double v = 0;
       if (i < PRE_BLOCKS * 7) {
@@ -963,7 +1097,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     // one set of Schur partials per linearisation buffer (fused mode): the sums in S and in the three vectors were taken from the
     // buffer of the trial; it was rejected (or replaced by an explicit dogleg step), so they are corrected by the difference of
     // the two sets — here, where the registers of the speculative prefetches are free again, and only in this rare case
-    if (s_was_pending && !s_accepted && Wl.spart_buf_stride) {
+    if (rejected && Wl.spart_buf_stride) {
       const int npose_blk = Dp / 6;
       const int nP = npose_blk * (npose_blk + 1) / 2 * 36, ntot = nP + 3 * Dp;
       const size_t stride = Wl.spart_stride;
@@ -989,17 +1123,29 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
   }
   if (n_pri) {
-    if (s_was_pending && !s_accepted) {   // rejected step: restage the records of the buffer that stays accepted
+    if (rejected) {   // rejected step: restage the records of the buffer that stays accepted
       if (tid < Wl.n_pprior * 42) s_pri[tid] = Wl.pp_lin[acc][tid];
       if (tid < Wl.n_sbprior * 9) s_pri[PRI_STAGE * 42 + tid] = Wl.sbp_lin[acc][tid];
       __syncthreads();
     }
   }
-  assemble_base(Wl, acc, LY, S, s_g, s_d2, s_coloff, tid, SOLVE_THREADS, imu_fast, s_pri, s_pricol, n_pri, LARGE);
-  __syncthreads();
+  if (w0pri) {
+    if (!pri_formed && tid < 64) prior_tasks();
+    if (tid < 64) prior_apply(pr_v00, pr_o00, pr_d00, pr_v01, pr_o01, pr_d01);
+    __syncthreads();
+    if (Wl.n_pprior > 1 || Wl.n_sbprior > 1) {
+      if (tid < 64) prior_apply(pr_v10, pr_o10, pr_d10, pr_v11, pr_o11, pr_d11);
+      __syncthreads();
+    }
+  }
+  // what is left: factors the fast paths above do not cover (more IMU entries than the prefetch holds, more priors than are
+  // staged, relative pose factors, the marginalisation prior); every part ends with its own barrier
+  assemble_base(Wl, acc, LY, S, s_g, s_d2, s_coloff, tid, SOLVE_THREADS, imu_fast, s_pri, s_pricol, n_pri, LARGE, w0pri);
   STAMP(5);
-  // ------------------------------------------------------------------ 3. convergence of the accepted step
-  {
+  const double lambda = opt.dogleg ? c.mu : 1.0 / c.radius;
+  const bool est_scale = s_was_first && s_accepted;   // first linearisation of this call: estimate the Jacobi scale
+  // convergence measure of the accepted step: partial maxima per wave
+  auto conv_partial = [&]() {
     double m = 0;
     if (opt.dogleg) {
       // Ceres 1.9: gradient_max_norm = || x - Plus(x, -g) ||_inf over the ambient coordinates: the gradient itself for
@@ -1021,6 +1167,52 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     m = wave_max_full(m);
     if ((tid & 63) == 0) s_red[tid >> 6] = m;
+  };
+  // the decision every work-item derives from the partial maxima (the same inputs, the same expressions: uniform); work-item 0
+  // records it.  Returns the termination code (0 = go on).
+  auto conv_decide = [&]() -> int {
+    double gm = s_lm_gmax;
+    for (int i = 0; i < SOLVE_THREADS / 64; ++i) gm = fmax(gm, s_red[i]);
+    int done_now = 0;
+    if (s_accepted) {
+      const double tol = s_was_first ? (opt.dogleg ? opt.gradient_tolerance : opt.gradient_tolerance * fmax(gm, 2.220446049250313e-16))
+                                     : c.abs_grad_tol;
+      if (opt.gradient_tolerance > 0 && gm <= tol) {
+        done_now = 2 + 1;
+      } else if (!opt.dogleg && !s_was_first && opt.function_tolerance > 0 &&
+                 fabs(s_cost_change) < opt.function_tolerance * s_old_cost) {
+        done_now = 1 + 1;   // (dogleg: tested before the step is taken, in decide_dl)
+      }
+    }
+    return done_now;
+  };
+  auto damping = [&]() {
+    for (int i = tid; i < Dpad; i += SOLVE_THREADS) {
+      if (i < D) {
+        double sc = 1.0;
+        if (opt.dogleg) {
+          if (est_scale) {
+            sc = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(s_d2[i])) : 1.0;
+            Wl.scale_p[i] = sc;
+          } else {
+            sc = i == tid ? scale_pref : Wl.scale_p[i];
+          }
+        }
+        const double d2 = damp_diag(s_d2[i], sc, opt);
+        s_d2[i] = d2;
+        S[LY.at(i, i)] += lambda * d2;
+        const double rh = s_rhs[i] - s_g[i];
+        s_rhs[i] = rh;
+        if constexpr (!LARGE) S[LY.at(D, i)] = rh;   // the right-hand side rides along as column D of the matrix (ba_ldl16.hpp)
+      } else {
+        if constexpr (LARGE) S[LY.at(i, i)] = 1.0;  // identity padding up to a multiple of 6
+        s_rhs[i] = 0.0;
+      }
+    }
+  };
+  if (final_only) {
+    // cost / gradient evaluation and the marginalisation pass: nothing is damped or solved
+    conv_partial();
     __syncthreads();
     if (tid == 0) {
       double gm = s_lm_gmax;
@@ -1041,59 +1233,57 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       }
     }
     __syncthreads();
+    if (Wl.grad)
+      for (int i = tid; i < D; i += SOLVE_THREADS) Wl.grad[i] = s_g[i];
+    if (final_only == 2) {
+      // marginalisation pass (okvis_ba_marginalize): export the undamped system left after the landmark
+      // elimination, H (D x D, full symmetric) and b0 = -(g - W V^+ b_l)  (MarginalizationError.cpp:682-684)
+      for (int i = tid; i < D; i += SOLVE_THREADS) Wl.rhs[i] = s_rhs[i] - s_g[i];
+      if constexpr (LARGE) {
+        // the matrix of a large window is completed by large_export_kernel (Schur partials of the pose part, IMU terms), which
+        // also writes the full symmetric copy into W.S: ask for it and stop before any damping is added
+        if (tid == 0) {
+          *gctrl = c;
+          Wl.ct_flag[Wl.ct_nT * (Wl.ct_nT + 1) / 2 + 1] = 1;
+        }
+        return;
+      }
+      for (int k = tid; k < D * D; k += SOLVE_THREADS) {
+        const int i = k / D, j = k - i * D;
+        Wl.S[k] = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
+      }
+    }
+    if (tid == 0) *gctrl = c;
+    return;
   }
-  STAMP(30);
+  // ------------------------------------------------------------------ 3 + 4. convergence of the accepted step, damping
+  // One phase: the partial maxima of the convergence test, the damping of the diagonal (it does not depend on the test: a
+  // window that stops here simply does not use it) and the right-hand side column; behind ONE barrier every work-item derives
+  // the same verdict from the partial maxima, work-item 0 records it.
+  conv_partial();
+  damping();
   if (Wl.grad)
     for (int i = tid; i < D; i += SOLVE_THREADS) Wl.grad[i] = s_g[i];
-  if (final_only == 2) {
-    // marginalisation pass (okvis_ba_marginalize): export the undamped system left after the landmark
-    // elimination, H (D x D, full symmetric) and b0 = -(g - W V^+ b_l)  (MarginalizationError.cpp:682-684)
-    for (int i = tid; i < D; i += SOLVE_THREADS) Wl.rhs[i] = s_rhs[i] - s_g[i];
-    if constexpr (LARGE) {
-      // the matrix of a large window is completed by large_export_kernel (Schur partials of the pose part, IMU terms), which
-      // also writes the full symmetric copy into W.S: ask for it and stop before any damping is added
-      if (tid == 0) {
-        *gctrl = c;
-        Wl.ct_flag[Wl.ct_nT * (Wl.ct_nT + 1) / 2 + 1] = 1;
+  if (tid == 0 && opt.dogleg && c.mu >= DL_MAX_MU) s_fail = 1;   // DoglegStrategy: no solve is attempted once mu has reached max_mu
+  __syncthreads();
+  {
+    const int verdict = conv_decide();
+    if (tid == 0 && s_accepted) {
+      double gm = s_lm_gmax;
+      for (int i = 0; i < SOLVE_THREADS / 64; ++i) gm = fmax(gm, s_red[i]);
+      c.grad_max = gm;
+      if (s_was_first) {
+        c.initial_cost = c.cost;
+        c.abs_grad_tol = opt.dogleg ? opt.gradient_tolerance : opt.gradient_tolerance * fmax(gm, 2.220446049250313e-16);
       }
+      if (verdict & 3) c.done = verdict & 3;
+      c.first = 0;
+    }
+    if (verdict & 3) {
+      if (tid == 0) *gctrl = c;
       return;
     }
-    for (int k = tid; k < D * D; k += SOLVE_THREADS) {
-      const int i = k / D, j = k - i * D;
-      Wl.S[k] = (i >= j) ? S[LY.at(i, j)] : S[LY.at(j, i)];
-    }
-    if (tid == 0) *gctrl = c;
-    return;
   }
-  if (c.done || final_only) {
-    if (tid == 0) *gctrl = c;
-    return;
-  }
-
-  // ------------------------------------------------------------------ 4. damping + Cholesky
-  const double lambda = opt.dogleg ? c.mu : 1.0 / c.radius;
-  const bool est_scale = s_was_first && s_accepted;   // first linearisation of this call: estimate the Jacobi scale
-  for (int i = tid; i < Dpad; i += SOLVE_THREADS) {
-    if (i < D) {
-      double sc = 1.0;
-      if (opt.dogleg) {
-        if (est_scale) {
-          sc = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(s_d2[i])) : 1.0;
-          Wl.scale_p[i] = sc;
-        } else {
-          sc = i == tid ? scale_pref : Wl.scale_p[i];
-        }
-      }
-      const double d2 = damp_diag(s_d2[i], sc, opt);
-      s_d2[i] = d2;
-      S[LY.at(i, i)] += lambda * d2;
-      s_rhs[i] = s_rhs[i] - s_g[i];
-    } else {
-      if constexpr (LARGE) S[LY.at(i, i)] = 1.0;  // identity padding up to a multiple of 6
-      s_rhs[i] = 0.0;
-    }
-  }
-  __syncthreads();
   if (Wl.S) {  // parity/debug copy of the damped system
     for (int k = tid; k < D * D; k += SOLVE_THREADS) {
       const int i = k / D, j = k - i * D;
@@ -1216,10 +1406,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   }
   // ------------------------------------------------------------------ 4b. blocked LDL^T on the matrix core (ba_ldl16.hpp)
   // The right-hand side rides along as column D of the matrix: the elimination turns it into L^-1 b.
+  // (column D and the max_mu verdict were written in the damping phase, in front of the barrier every work-item has passed)
   if constexpr (!LARGE) {
-    for (int i = tid; i < D; i += SOLVE_THREADS) S[LY.at(D, i)] = s_rhs[i];
-    if (tid == 0 && opt.dogleg && c.mu >= DL_MAX_MU) s_fail = 1;   // DoglegStrategy: no solve is attempted once mu has reached max_mu
-    __syncthreads();
     STAMP(10);
     ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail);
   }

@@ -147,6 +147,14 @@ struct Ctrl {
   int have_tot, pad2;
 };
 static_assert(sizeof(Ctrl) % 8 == 0 && sizeof(Ctrl) / 8 <= 64, "Ctrl is fetched by one wave, one double per lane");
+// The control records of a solver's windows sit in ONE array behind its window records (okvis_ba_upload), one 256-byte slot
+// each (no two workgroups write the same lines): the solve kernel computes the address of its record from a kernel argument
+// and blockIdx.x, so the record — and with it the index of the linearisation buffer every speculative load depends on —
+// arrives together with the window record instead of one memory round trip behind it.  WinPtrs::ctrl points to the same slot.
+struct alignas(256) CtrlSlot {
+  Ctrl c;
+};
+static_assert(sizeof(CtrlSlot) == 256, "one slot per window");
 
 // On the device every pointer of the record refers to HBM: typed as global-address-space pointers, their accesses are
 // global_load / global_store (tracked by the vector-memory counter only) instead of FLAT instructions.
@@ -155,7 +163,8 @@ static_assert(sizeof(Ctrl) % 8 == 0 && sizeof(Ctrl) / 8 <= 64, "Ctrl is fetched 
 #else
 #define BA_G
 #endif
-struct WinPtrs {
+// (64-byte aligned: a record is exactly 18 lines of the scalar cache, which the solve kernel requests in one go)
+struct alignas(64) WinPtrs {
   // ---- sizes ----
   int n_pose, n_sb, n_lm, n_cam, n_obs, n_imu, n_pprior, n_sbprior, n_rel;
   int marg_dim, marg_nb;
@@ -213,6 +222,11 @@ struct WinPtrs {
                                  // entries f * 512 + e that land there, or -1: gathered by large_export_kernel
   const BA_G int4* imu_asm;           // [n_imu][512] where entry e of factor f's H|g record lands in the solve kernel's LDS
                                  // system: x = offset | is_g << 20 | colour << 24 (or -1), y = d2 index or -1 (D <= MAX_D_LDS)
+  const BA_G int* imu_fastw;          // [n_imu][512] the same for the solve kernel's prefetch (D <= MAX_D_LDS), one word per entry:
+                                 // offset in the kernel's dynamic LDS (doubles: the matrix in the layout of ba_ldl16.hpp, the gradient
+                                 // behind it) | (d2 index + 1) << 16 | colour << 24, or -1
+  const BA_G int* prior_col;          // [6 n_pprior | 9 n_sbprior] reduced index of every column of the pose priors, then of the
+                                 // speed/bias priors, or -1 (fixed block)
 
   // ---- linearisation (index = buffer 0/1) ----
   BA_G double* V[2];           // [n_lm][6]
