@@ -39,6 +39,15 @@ namespace ba {
 typedef double ldl_v4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDL_MAX_NB = 11;   // D + 1 <= 176
+// A/B switches of the diagonal chain (tests/micro/ldl16.hip builds the variants): LDL_PIVOT 0 = reciprocal first, then the
+// multiplier; 1 = the multiplier and the reciprocal side by side (default)
+#ifndef LDL_PIVOT
+#define LDL_PIVOT 1
+#endif
+// LDL_W0_REORDER 1 = wave 0 reads its own operands back in front of the flag's release (default)
+#ifndef LDL_W0_REORDER
+#define LDL_W0_REORDER 1
+#endif
 
 struct L16 {
   int nb;
@@ -134,10 +143,30 @@ __device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool ac
     *bad = *bad || neg;
     d = neg ? 1.0 : d;
   }
+#if LDL_PIVOT == 0
   double rd = rcp_nr(d);
   if (!FULL) rd = act ? rd : 0.0;
   const bool me = (j == K);
   double v = -r[K] * rd;
+#else
+  // 1/d = y0 (1 + e)(1 + e^2), y0 the hardware estimate and e = 1 - d y0 (the two Newton steps of rcp_nr written out): the
+  // multiplier -r[K] / d takes the same three factors one by one, so that it is ready four dependent instructions behind d
+  // (estimate, e | -r[K] y0, two fused multiply-adds) instead of seven (estimate, two Newton steps, product).  The reciprocal
+  // itself (kept by lane K) is off the chain.
+  const double y0 = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, y0, 1.0);
+  const double u0 = -r[K] * y0;
+  const double e2 = e * e;
+  const double u1 = fma(u0, e, u0);
+  double v = fma(u1, e2, u1);
+  const double y1 = fma(y0, e, y0);
+  double rd = fma(y1, e2, y1);
+  if (!FULL) {
+    rd = act ? rd : 0.0;
+    v = act ? v : 0.0;
+  }
+  const bool me = (j == K);
+#endif
   v = me ? ((FULL || act) ? -2.0 : 0.0) : v;
   mine = me ? rd : mine;
   double dn = 1.0;
@@ -470,10 +499,30 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
           for (int i = 0; i < 16; ++i) xv[kb * 16 + i] = c[i];
         }
       }
+#if LDL_W0_REORDER
+      // this wave's own operand reads (L_kk^-1 in the A-operand layout) leave right behind the writes they read back — the LDS
+      // serves a wave's requests in order — so their latency hides under the release of the flag instead of following it
+      double a[4], dq[4], xh_[4];
+      if (kb + 1 < nb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ak = (lane >> 4) + 4 * q;
+          dq[q] = -dinv[kb * 16 + ak];
+          xh_[q] = Xs[kb * LDL_XB + ak * LDL_RS + j];
+        }
+      }
+#endif
       ldl_signal(&f_xready, kb + 1, lane);
       if (stamps && tid == 0 && kb < 12) stamps[17 + 4 * kb] = clock64();
       if (kb + 1 >= nb) break;
       // ---- R = L_kk^-1 A_(k,k+1) privately, then the last update of the next diagonal block
+#if LDL_W0_REORDER
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ak = (lane >> 4) + 4 * q;
+        a[q] = j > ak ? xh_[q] * -dq[q] : (j == ak ? 1.0 : 0.0);
+      }
+#else
       double a[4], dq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -482,6 +531,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
         const double xh = Xs[kb * LDL_XB + ak * LDL_RS + j];
         a[q] = j > ak ? xh * -dq[q] : (j == ak ? 1.0 : 0.0);
       }
+#endif
       LDL_EV(0x600 | kb);   // wave 0: X_kb published, waiting for Q_kb and P_(kb+1)
       for (;;) {
         const int fq = __hip_atomic_load(&f_hq[kb & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

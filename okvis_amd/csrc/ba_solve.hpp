@@ -502,6 +502,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
                                                               const OptD* __restrict__ optp, int final_only, CtrlSlot* ctrls) {
   static_assert(!(LARGE && DBUF), "windows solved in HBM are never fused");
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  const long long t_start = clock64();   // (diagnostics: stamp 43)
   const WinPtrs& W = wins[blockIdx.x];
   // The control record: its address comes from the kernel arguments (CtrlSlot, ba_types.hpp; == W.ctrl), so its first words —
   // accepted buffer, pending, first, done — are requested together with the window record.  Every speculative load below
@@ -526,6 +527,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   if (final_only == 0x7ffffff1 && warm == 0x5a5a5a5a) return;   // (never: keeps the loads above)
   if (LARGE != (W.Sg != nullptr)) return;  // each window is handled by the instantiation that fits it
   const int tid = threadIdx.x;
+  if (W.prof && tid == 0 && blockIdx.x == 0 && blockIdx.y + 1 == gridDim.y) {   // diagnostics: first instruction | control words + window record are there
+    W.prof[43] = (double)t_start;
+    W.prof[40] = (double)clock64();
+  }
   if constexpr (!LARGE) {
     // ---- helper workgroups (blockIdx.y < gridDim.y - 1; dispatched before the solving workgroup of their window): the sum
     // of the Schur chunk partials, one item (double of the partials' record) per work-item, every chunk requested at once and
@@ -680,6 +685,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // (readfirstlane: the index is uniform, but it comes from a vector load — as a VGPR it drags every address of the sums into
   // vector registers and the kernel into 100 spills)
   const int sum_spec = DBUF ? spec0 : 0;   // the buffer that is accepted if the pending trial is
+  STAMP(41);   // (every request of the prologue has been issued)
   auto sum_partials = [&](int buf, bool use_sums) {
     if constexpr (!LARGE) {
       const int npose_blk = Dp / 6;
@@ -748,6 +754,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     double tpart[6] = {0, 0, 0, 0, 0, 0};
     if (chead.y) wave_trial_partials(W, 1 - chead.x, tid, tpart);
     if (tid < (int)(sizeof(Ctrl) / 8)) reinterpret_cast<double*>(&c)[tid] = cword;
+    STAMP(42);   // (control record and scalar partials of the trial have arrived)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     asm volatile("" ::: "memory");
     const int pending = c.pending;

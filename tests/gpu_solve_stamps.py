@@ -9,13 +9,12 @@ b = solver.WindowBatch([synthetic.config_A(seed=20240923 + i) for i in range(NW)
 b.begin(); b.iterate(12); b.synchronize()
 p = b.array("PROF")
 T = 2380.0
-print("wave 0 decision done at %.2f us; shadow assembly (Schur partials) done at %.2f us" % ((p[3] - p[0]) / T, (p[4] - p[0]) / T))
-names = [(1, "decision + Schur partial sums"), (2, "(barrier)"), (58, "IMU records"), (5, "priors + marginalisation prior"), (6, "convergence + damping"),
-         (10, "rhs column + barrier"), (7, "LDL^T + back-substitution"), (9, "scalars, trial states, ctrl")]
+print("head (us after the first instruction): control words + window record %.2f, (stamp 0 %.2f), prologue requests issued %.2f, control record + trial partials %.2f, "
+      "wave 0 decision done %.2f, Schur sums in LDS %.2f" % tuple((p[k] - p[43]) / T for k in (40, 0, 41, 42, 3, 4)))
+names = [(1, "decision + Schur partial sums"), (58, "IMU records"), (5, "priors + marginalisation prior"), (6, "convergence + damping + rhs column"),
+         (7, "LDL^T + back-substitution"), (9, "scalars, trial states, ctrl")]
 prev = 0
 for k, n in names:
-    print("  %-34s %8.0f ticks %7.2f us" % (n, p[k] - p[prev], (p[k] - p[prev]) / T)); prev = k
-print("  total %.2f us" % ((p[9] - p[0]) / T))
-print("  convergence test %.2f us, damping (+ debug copies) %.2f us" % ((p[30] - p[5]) / T, (p[6] - p[30]) / T))
+    print("  %-36s %8.0f ticks %7.2f us" % (n, p[k] - p[prev], (p[k] - p[prev]) / T)); prev = k
+print("  total %.2f us from stamp 0, %.2f us from the first instruction" % ((p[9] - p[0]) / T, (p[9] - p[43]) / T))
 print("  tail: step vector %.2f, trial states %.2f, sums + barrier %.2f, ctrl %.2f us" % ((p[31] - p[7]) / T, (p[32] - p[31]) / T, (p[33] - p[32]) / T, (p[9] - p[33]) / T))
-print("  trial states: poses %.2f us, speed/bias %.2f us" % ((p[34] - p[31]) / T, (p[32] - p[34]) / T))

@@ -9,6 +9,7 @@
 #include <vector>
 #include <algorithm>
 
+#include "../../include/okvis_amd_ba.h"   // (ba_types.hpp sizes a record by one of its constants)
 // #define LDL_TRACE   // (per-wave event log: perturbs the timing by a few hundred cycles per event)
 #include "ba_ldl16.hpp"
 
