@@ -952,24 +952,26 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // (the table only depends on where the terms' blocks sit in the reduced system: a window that slides keeps it from frame to
     // frame, so the last one is kept — 9 us of a 70 us upload)
     struct ImuAsmCache {
-      int D = -1;
+      int D = -1, Dp = -1;
       std::vector<int> coloff, color;
       std::vector<int4> table;
-      std::vector<int> fastw;
+      std::vector<int> fastw, pos;
     };
     // (four entries, replaced in turn: the estimator alternates between the window it optimises and the sub-window it marginalises)
     static thread_local ImuAsmCache asm_caches[4];
     static thread_local int asm_next = 0;
     int hit = -1;
     for (int k = 0; k < 4 && hit < 0; ++k)
-      if (asm_caches[k].D == D && asm_caches[k].coloff == imu_coloff && asm_caches[k].color == imu_color) hit = k;
+      if (asm_caches[k].D == D && asm_caches[k].Dp == Dp && asm_caches[k].coloff == imu_coloff && asm_caches[k].color == imu_color) hit = k;
     const bool asm_hit = hit >= 0;
     ImuAsmCache& asm_cache = asm_caches[asm_hit ? hit : asm_next];
     if (!asm_hit) asm_next = (asm_next + 1) & 3;
     std::vector<int4>& imu_asm = asm_cache.table;
     std::vector<int>& imu_fastw = asm_cache.fastw;
+    std::vector<int>& imu_pos = asm_cache.pos;
     if (!asm_hit) {
       asm_cache.D = D;
+      asm_cache.Dp = Dp;
       asm_cache.coloff = imu_coloff;
       asm_cache.color = imu_color;
       const int nbk = (D + 5) / 6;   // (the HBM matrix of the large windows has the same block layout)
@@ -978,33 +980,49 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
         return (bj * nbk - (bj * (bj - 1)) / 2 + (bi - bj)) * SBS + (i - 6 * bi) * 6 + (j - 6 * bj);
       };
       // the same entry in the LDS layout of the LDL^T solver (L16::at, ba_ldl16.hpp): i >= j, stored at the mirrored position
-      const int nb16 = ldl16_nb(D);
-      auto at16 = [&](int i, int j) {
-        const int I = j >> 4, J = i >> 4, r = j & 15, c = i & 15;
-        return (I * nb16 - (I * (I - 1)) / 2 + (J - I)) * 256 + (r >> 2) * 64 + (r & 3) * 16 + c;
-      };
+      const L16 ly16{ldl16_nb(D), D - Dp, D};   // (the solver's ordering: speed/bias part first)
+      auto at16 = [&](int i, int j) { return ly16.at(i, j); };
       imu_asm.assign(512 * (size_t)w.n_imu, make_int4(-1, -1, 0, 0));
       imu_fastw.assign(512 * (size_t)w.n_imu, -1);
       // (the solve kernel's dynamic LDS: matrix area, then rhs, gradient, diagonal, solution — Dpad doubles each, ba_solve.hpp)
       const bool lds_system = D <= MAX_D_LDS;
       const int goff16 = lds_system ? ldl16_area_doubles(D) + ((D + 5) / 6) * 6 : 0;
+      // Where the entries of a factor's H | g record sit in the record (imu_pos, read by the factor workgroup that writes it): for a
+      // system solved in LDS in the order of their places there, so that the lanes of a wave of the solve kernel — consecutive
+      // record entries — add to ascending, mostly consecutive LDS addresses.  (In the packed order of the triangle the 64 entries
+      // of a wave landed on one bank pair — a row of a 16x16 block lies 128 bytes behind the previous one — and the scatter
+      // took 4 us.)  Windows solved in HBM keep the packed order.
+      imu_pos.assign(512 * (size_t)w.n_imu, 0);
+      std::vector<std::pair<int, int>> keys(495);
       for (int f = 0; f < w.n_imu; ++f) {
         const int* co = imu_coloff.data() + 30 * (size_t)f;
         int e = 0;
         for (int a = 0; a < 30; ++a)
           for (int b = 0; b <= a; ++b, ++e) {
             const int ra = co[a], rb = co[b];
+            keys[e] = {(ra < 0 || rb < 0) ? INT_MAX : (lds_system ? at16(ra, rb) : e), e};
+          }
+        for (int a = 0; a < 30; ++a) keys[465 + a] = {co[a] < 0 ? INT_MAX : (lds_system ? goff16 + co[a] : 465 + a), 465 + a};
+        if (lds_system) std::sort(keys.begin(), keys.end());
+        int* pos = imu_pos.data() + 512 * (size_t)f;
+        for (int rank = 0; rank < 495; ++rank) pos[keys[rank].second] = rank;
+        for (int k = 495; k < 512; ++k) pos[k] = k;
+        e = 0;
+        for (int a = 0; a < 30; ++a)
+          for (int b = 0; b <= a; ++b, ++e) {
+            const int ra = co[a], rb = co[b];
             if (ra < 0 || rb < 0) continue;
-            imu_asm[512 * (size_t)f + e] = make_int4((ra >= rb ? at(ra, rb) : at(rb, ra)) | (imu_color[f] << 24), a == b ? ra : -1,
-                                                     ra >= rb ? (ra << 16 | rb) : (rb << 16 | ra),   // z: the reduced indices
-                                                     0);
-            if (lds_system && imu_color[f] < 16)
-              imu_fastw[512 * (size_t)f + e] = (ra >= rb ? at16(ra, rb) : at16(rb, ra)) | ((a == b ? ra + 1 : 0) << 16) | (imu_color[f] << 24);
+            const size_t at_rec = 512 * (size_t)f + pos[e];
+            imu_asm[at_rec] = make_int4((ra >= rb ? at(ra, rb) : at(rb, ra)) | (imu_color[f] << 24), a == b ? ra : -1,
+                                        ra >= rb ? (ra << 16 | rb) : (rb << 16 | ra),   // z: the reduced indices
+                                        0);
+            if (lds_system && imu_color[f] < 16) imu_fastw[at_rec] = at16(ra, rb) | ((a == b ? ra + 1 : 0) << 16) | (imu_color[f] << 24);
           }
         for (int a = 0; a < 30; ++a)
           if (co[a] >= 0) {
-            imu_asm[512 * (size_t)f + 465 + a] = make_int4(co[a] | (1 << 20) | (imu_color[f] << 24), -1, 0, 0);
-            if (lds_system && imu_color[f] < 16) imu_fastw[512 * (size_t)f + 465 + a] = (goff16 + co[a]) | (imu_color[f] << 24);
+            const size_t at_rec = 512 * (size_t)f + pos[465 + a];
+            imu_asm[at_rec] = make_int4(co[a] | (1 << 20) | (imu_color[f] << 24), -1, 0, 0);
+            if (lds_system && imu_color[f] < 16) imu_fastw[at_rec] = (goff16 + co[a]) | (imu_color[f] << 24);
           }
       }
     }
@@ -1012,6 +1030,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     else OFF(imu_asm, put(A, imu_asm));
     if (imu_fastw.empty()) OFF(imu_fastw, put(A, std::vector<int>(1, -1)));
     else OFF(imu_fastw, put(A, imu_fastw));
+    if (imu_pos.empty()) OFF(imu_pos, put(A, std::vector<int>(1, 0)));
+    else OFF(imu_pos, put(A, imu_pos));
     // large windows: the reverse map, so that the tile export (many workgroups) gathers the IMU contributions instead of one
     // workgroup scattering them into HBM.  At most two factors meet in one entry (the chain couples consecutive states).
     std::vector<int2> imu_rev;

@@ -860,7 +860,10 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
   }
   __syncthreads();
   if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[59] = (double)clock64();
+  // (an entry's place in the record: host-built, W.imu_pos — the order in which the solve kernel adds the record to its system)
+  const BA_G int* pos = W.imu_pos + (size_t)f * IMU_LIN_STRIDE;
   for (int wi = tid; wi < 465 + 30; wi += IMU_THREADS) {
+    const int at_rec = pos[wi];
     if (wi < 465) {
       int a = (int)((sqrtf(8.0f * wi + 1.0f) - 1.0f) * 0.5f);
       while ((a + 1) * (a + 2) / 2 <= wi) ++a;
@@ -869,13 +872,13 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
       double s = 0;
 #pragma unroll
       for (int k = 0; k < 15; ++k) s += Jl[30 * k + a] * Jl[30 * k + b];
-      out[IMU_H + wi] = s;
+      out[at_rec] = s;
     } else {
       const int a = wi - 465;
       double s = 0;
 #pragma unroll
       for (int k = 0; k < 15; ++k) s += Jl[30 * k + a] * s_r[k];
-      out[IMU_G + a] = s;
+      out[at_rec] = s;
     }
   }
   if (tid == 0) {

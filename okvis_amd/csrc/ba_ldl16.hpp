@@ -40,25 +40,39 @@ typedef double ldl_v4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDL_MAX_NB = 11;   // D + 1 <= 176
 // A/B switches of the diagonal chain (tests/micro/ldl16.hip builds the variants): LDL_PIVOT 0 = reciprocal first, then the
-// multiplier; 1 = the multiplier and the reciprocal side by side (default)
+// multiplier (default); 1 = the multiplier and the reciprocal side by side (measured slower, 2055 against 2006 cycles per block: the
+// elimination is bound by instruction issue, not by the chain)
 #ifndef LDL_PIVOT
-#define LDL_PIVOT 1
+#define LDL_PIVOT 0
 #endif
-// LDL_W0_REORDER 1 = wave 0 reads its own operands back in front of the flag's release (default)
+// LDL_W0_REORDER 1 = wave 0 reads its own operands back in front of the flag's release (measured: no gain; default 0)
 #ifndef LDL_W0_REORDER
-#define LDL_W0_REORDER 1
+#define LDL_W0_REORDER 0
 #endif
 
 struct L16 {
   int nb;
-  __device__ __forceinline__ int blk(int I, int J) const { return (I * nb - (I * (I - 1)) / 2 + (J - I)) * 256; }   // I <= J
-  // scalar index of entry (i, j) with i >= j (the lower-triangle convention of the assembly code): stored at the mirrored
-  // position (j, i) of the upper block triangle
-  __device__ __forceinline__ int at(int i, int j) const {
-    const int I = j >> 4, J = i >> 4, r = j & 15, c = i & 15;
+  // Solver ordering.  The reduced system numbers the pose-type blocks first (Dp rows), then the speed/bias blocks; the solver
+  // eliminates the speed/bias part first: their block-tridiagonal coupling leaves whole 16x16 blocks of the first panel rows
+  // zero (the matrix core, 64 cycles per 16x16x4 product on three SIMDs, is what the first block steps wait for when every
+  // block is treated as dense), and the solver skips zero blocks.  Reduced index i < Dp sits at solver row i + Ds, i >= Dp at
+  // i - Dp (Ds = Dn - Dp); index Dn — the right-hand side column — and beyond keep their places.  Ds = 0: no reordering.
+  int Ds = 0;
+  int Dn = INT_MAX;
+  __host__ __device__ __forceinline__ int perm(int i) const { return i >= Dn ? i : (i < Dn - Ds ? i + Ds : i - (Dn - Ds)); }
+  __host__ __device__ __forceinline__ int unperm(int p) const { return p >= Dn ? p : (p < Ds ? p + (Dn - Ds) : p - Ds); }
+  __host__ __device__ __forceinline__ int blk(int I, int J) const { return (I * nb - (I * (I - 1)) / 2 + (J - I)) * 256; }   // I <= J
+  // scalar index of solver entry (p, q), p >= q: stored at the mirrored position (q, p) of the upper block triangle
+  __host__ __device__ __forceinline__ int at_solver(int p, int q) const {
+    const int I = q >> 4, J = p >> 4, r = q & 15, c = p & 15;
     return blk(I, J) + (r >> 2) * 64 + (r & 3) * 16 + c;
   }
-  __device__ __forceinline__ int sym(int i, int j) const { return i >= j ? at(i, j) : at(j, i); }
+  // scalar index of entry (i, j) in REDUCED coordinates (the assembly code's; either order)
+  __host__ __device__ __forceinline__ int at(int i, int j) const {
+    const int p = perm(i), q = perm(j);
+    return p >= q ? at_solver(p, q) : at_solver(q, p);
+  }
+  __host__ __device__ __forceinline__ int sym(int i, int j) const { return at(i, j); }
   __host__ __device__ static int blocks(int nb) { return nb * (nb + 1) / 2; }
 };
 
@@ -116,6 +130,13 @@ __device__ __forceinline__ void ldl_wait_eq(const int* flag, int need) {
 __device__ __forceinline__ unsigned long long ldl_ready_mask(const int* flags, int n, int need, int lane) {
   const int v = lane < n ? __hip_atomic_load(&flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : INT_MAX;
   return __ballot(v >= need);
+}
+// the same for flags that carry a property of what they announce in bit 0 (value = count << 1 | bit): *bits receives bit 0 of
+// every flag (meaningful where the flag is ready)
+__device__ __forceinline__ unsigned long long ldl_ready_mask_bit(const int* flags, int n, int need2, int lane, unsigned long long* bits) {
+  const int v = lane < n ? __hip_atomic_load(&flags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : INT_MAX - 1;
+  *bits = __ballot((v & 1) != 0);
+  return __ballot(v >= need2);
 }
 // the calling wave's LDS writes become visible before the flag does
 __device__ __forceinline__ void ldl_signal(int* flag, int v, int lane) {
@@ -204,7 +225,7 @@ __device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, doubl
 // solution.  *s_fail (LDS int, zeroed by the caller before a barrier) is set when a pivot is not positive.
 // Ends with a barrier: x_out and *s_fail are visible to every thread on return.
 template <int NW>
-__device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x_out, int* s_fail, long long* stamps = nullptr) {
+__device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x_out, int* s_fail, long long* stamps = nullptr, int Ds = 0) {
   // Wave 0 carries the diagonal chain at raised priority and wants its SIMD for itself: the waves that share it (4, 8, 12:
   // waves w, w+4, w+8, w+12 of a workgroup sit on one SIMD, tests/micro/hwid.hip) would be starved exactly when the chain
   // needs their hand-offs (measured: a flag seen 5500 cycles late), so they own nothing and go straight to the last barrier.
@@ -212,7 +233,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
   constexpr int NREG = 12;                                            // waves that own blocks: (wave & 3) != 0
   constexpr int SLOTS = (LDL_MAX_NB * (LDL_MAX_NB + 1) / 2 + NREG - 1) / NREG;
   const int nb = ldl16_nb(D);
-  const L16 LY{nb};
+  const L16 LY{nb, Ds, D};   // (S is assembled in the solver's ordering, L16::perm; x_out is written in the caller's)
   const int nblk = L16::blocks(nb);
   const int npl = D - 16 * (nb - 1);                                  // pivots of the last block (its column npl is the rhs)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -233,7 +254,9 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
   // One flag per buffer, not one counter: the hand-offs of consecutive steps come from different waves and may complete
   // out of order (the hand-off for step m + 1 does not depend on wave 0 having consumed the one for step m).
   __shared__ int f_hq[2], f_hp[2];
-  __shared__ int f_prdy[LDL_MAX_NB];       // [J] k + 1: R_J of step k published in Rp[k & 1]
+  // [k & 1][J] (k + 1) << 1 | z: R_J of step k published in Rp[k & 1]; z = 1: the block is zero and nothing was written (the
+  // consumers skip their products with it).  One set of flags per buffer: a flag keeps its step's z until the buffer is reused.
+  __shared__ int f_prdy[2][LDL_MAX_NB];
   __shared__ int f_tdn[16];                // [wave] k + 1: the wave has finished its trailing updates of step k
   __shared__ int f_x;                      // back-substitution: number of solved blocks (from the last one)
   __shared__ int f_tc[LDL_MAX_NB];         // [K] number of slots tcon[K][.] written
@@ -254,7 +277,8 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
     f_x = 0;
   }
   if (tid < LDL_MAX_NB) {
-    f_prdy[tid] = 0;
+    f_prdy[0][tid] = 0;
+    f_prdy[1][tid] = 0;
     f_tc[tid] = 0;
     f_xb[tid] = 0;
   }
@@ -352,11 +376,15 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
             // chain is waiting for)
             if (pJ <= kb + 2) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(1);
-            ldl_v4 R{0, 0, 0, 0};
+            // a block that is still exactly zero (no coupling, no fill so far) stays zero: no product, nothing written
+            const bool nz = __any(acc[s][0] != 0.0 || acc[s][1] != 0.0 || acc[s][2] != 0.0 || acc[s][3] != 0.0) != 0;
+            if (nz) {
+              ldl_v4 R{0, 0, 0, 0};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], acc[s][q], R, 0, 0, 0);
-            acc[s] = R;
-            if (!waited) {   // the buffer still holds the panel row of step kb - 2: every wave must be through with it
+              for (int q = 0; q < 4; ++q) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], acc[s][q], R, 0, 0, 0);
+              acc[s] = R;
+            }
+            if (!waited) {   // the buffer (and its flags) still belong to the panel row of step kb - 2: every wave must be through with it
               for (;;) {
                 const int v = (lane < NW && (lane & 3) != 0) ? __hip_atomic_load(&f_tdn[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : INT_MAX;
                 if (__all(v >= kb - 1)) break;
@@ -365,10 +393,12 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
               waited = true;
             }
-            double* rp = Rk + pJ * 256 + lane;
+            if (nz) {
+              double* rp = Rk + pJ * 256 + lane;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rp[64 * r] = R[r];
-            ldl_signal(&f_prdy[pJ], kb + 1, lane);
+              for (int r = 0; r < 4; ++r) rp[64 * r] = acc[s][r];
+            }
+            ldl_signal(&f_prdy[kb & 1][pJ], ((kb + 1) << 1) | (nz ? 0 : 1), lane);
             LDL_EV(0x200 | (kb << 4) | pJ);   // panel block (kb, J) published
             __builtin_amdgcn_s_setprio(0);
           }
@@ -377,7 +407,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
         // with this update, and the diagonal block kb + 2.  The diagonal block kb + 1 is completed by wave 0 itself.
         // (a wave's slots are in row-major order, which is the order in which the chain needs them)
         {
-          unsigned long long ready = 0;
+          unsigned long long ready = 0, zeros = 0;
 #pragma unroll
           for (int s = 0; s < SLOTS; ++s) {
             int I = sI[s], J = sJ[s];
@@ -388,21 +418,23 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
             {   // the panel blocks R_I and R_J of this step (one poll fetches the state of the whole panel row)
               const unsigned long long nd = (1ull << I) | (1ull << J);
               while ((ready & nd) != nd) {
-                ready = ldl_ready_mask(f_prdy, nb, kb + 1, lane);
+                ready = ldl_ready_mask_bit(f_prdy[kb & 1], nb, (kb + 1) << 1, lane, &zeros);
                 if ((ready & nd) != nd) __builtin_amdgcn_s_sleep(1);
               }
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            const double* rp = Rk + I * 256 + lane;
-            const double* rn = Rk + J * 256 + lane;
-            double ra[4], rb[4];
+            if (!(zeros & ((1ull << I) | (1ull << J)))) {   // (a zero panel block: R_I^T D^-1 R_J is zero)
+              const double* rp = Rk + I * 256 + lane;
+              const double* rn = Rk + J * 256 + lane;
+              double ra[4], rb[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              ra[q] = rp[64 * q];
-              rb[q] = rn[64 * q] * dq[q];
+              for (int q = 0; q < 4; ++q) {
+                ra[q] = rp[64 * q];
+                rb[q] = rn[64 * q] * dq[q];
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[q], rb[q], acc[s], 0, 0, 0);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[q], rb[q], acc[s], 0, 0, 0);
             if (hq) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) qbuf[(I & 1) * 256 + 64 * r + lane] = acc[s][r];
@@ -611,7 +643,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
       if (K == nb - 1) x = j == npl ? -1.0 : (j < npl ? x : 0.0);
       if (lane < 16) {
         xv[K * 16 + lane] = x;
-        if (K * 16 + lane < D) x_out[K * 16 + lane] = x;
+        if (K * 16 + lane < D) x_out[LY.unperm(K * 16 + lane)] = x;
       }
       ldl_signal(&f_x, nb - K, lane);
       if (K > 0) {

@@ -603,7 +603,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // LDS-resident: the matrix area of the LDL^T solver (upper 16x16 blocks incl. the rhs column D, or its work area)
   const int nS = LARGE ? nbk * (nbk + 1) / 2 * SBS : ldl16_area_doubles(D);
   typedef typename SolveLayout<LARGE>::type LYT;
-  const LYT LY{LARGE ? nbk : ldl16_nb(D)};
+  // (LDS-resident: the solver eliminates the speed/bias part first, L16::perm; every LY.at() below takes reduced coordinates)
+  const LYT LY = [&]() {
+    if constexpr (LARGE) return LYT{nbk};
+    else return LYT{ldl16_nb(D), D - Dp, D};
+  }();
 
   double* S = LARGE ? W.Sg : smem;            // block-packed lower triangle
   double* s_rhs = LARGE ? smem : smem + nS;   // Dpad: rhs, then y = L^-1 rhs in place
@@ -859,8 +863,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       const int nP = npose_blk * (npose_blk + 1) / 2 * 36, ntot = nP + 3 * Dp;
       constexpr int NL = SOLVE_THREADS - 64;
       {
+        // (solver coordinates: the pose part sits behind the speed/bias part, rows / columns Ds .. D - 1; an item lands on every
+        // entry (r, c) of the upper triangle with Ds <= r <= c < D)
         const int nb16 = LY.nb, nblk16 = L16::blocks(nb16);
-        const int nbp = (Dp + 15) >> 4;   // block rows / columns that hold pose entries
+        const int Ds = D - Dp;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6) - 1, l = tid & 63;
         int I = 0, rem = wv;   // block wv, wv + 15, ... of the row-major upper triangle -> (I, I + rem)
         for (int b = wv; b < nblk16; b += SOLVE_THREADS / 64 - 1) {
@@ -869,9 +875,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
             ++I;
           }
           const int J = I + rem;
-          if (J >= nbp || 16 * J + (l & 15) >= Dp) {   // not a pose column: no item lands here
+          const int cc = 16 * J + (l & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S[b * 256 + 64 * r + l] = 0.0;
+          for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * I + 4 * r + (l >> 4);
+            if (!(rr >= Ds && cc >= rr && cc < D)) S[b * 256 + 64 * r + l] = 0.0;   // no item lands here
           }
           rem += SOLVE_THREADS / 64 - 1;
         }
@@ -1416,7 +1424,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // (column D and the max_mu verdict were written in the damping phase, in front of the barrier every work-item has passed)
   if constexpr (!LARGE) {
     STAMP(10);
-    ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail);
+    ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail, nullptr, D - Dp);
   }
   STAMP(7);
   if (s_fail) {  // not positive definite: invalid step (handled like a rejection)

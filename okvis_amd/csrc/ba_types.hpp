@@ -225,6 +225,8 @@ struct alignas(64) WinPtrs {
   const BA_G int* imu_fastw;          // [n_imu][512] the same for the solve kernel's prefetch (D <= MAX_D_LDS), one word per entry:
                                  // offset in the kernel's dynamic LDS (doubles: the matrix in the layout of ba_ldl16.hpp, the gradient
                                  // behind it) | (d2 index + 1) << 16 | colour << 24, or -1
+  const BA_G int* imu_pos;            // [n_imu][512] where logical entry e of a factor's H | g part (H 30x30 lower packed a(a+1)/2+b, then g) sits in
+                                 // its record: the order of the entries' places in the solve kernel's LDS system (identity for D > MAX_D_LDS)
   const BA_G int* prior_col;          // [6 n_pprior | 9 n_sbprior] reduced index of every column of the pose priors, then of the
                                  // speed/bias priors, or -1 (fixed block)
 

@@ -16,7 +16,7 @@
 constexpr int NW = 16;
 
 __global__ __launch_bounds__(NW * 64) void k_solve(const double* __restrict__ Sg, int D, double* xg, long long* stamps, int* fail,
-                                                     int reps) {
+                                                     int reps, int Ds) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int area = ba::ldl16_area_doubles(D);
   const size_t off = (size_t)blockIdx.x * area;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(NW * 64) void k_solve(const double* __restrict__ Sg
     for (int i = threadIdx.x; i < area; i += blockDim.x) S[i] = Sg[off + i];
     if (threadIdx.x == 0) s_fail = 0;
     __syncthreads();
-    ba::ldl16_solve<NW>(S, D, threadIdx.x, x, &s_fail, (blockIdx.x == 0 && rep == reps - 1) ? stamps : nullptr);
+    ba::ldl16_solve<NW>(S, D, threadIdx.x, x, &s_fail, (blockIdx.x == 0 && rep == reps - 1) ? stamps : nullptr, Ds);
     __syncthreads();
   }
   for (int i = threadIdx.x; i < D; i += blockDim.x) xg[(size_t)blockIdx.x * 192 + i] = x[i];
@@ -96,26 +96,50 @@ static int at_host(int nb, int i, int j) {   // i >= j
 }
 
 int main(int argc, char** argv) {
-  const int dims[] = {150, 162, 174, 175, 160, 144, 90, 31, 16, 15, 6};
+  // D > 0: dense random SPD system.  D < 0: a system with the structure of a window's reduced system, K = -D / 15 frames: pose
+  // blocks (6) first, dense among themselves, then speed/bias blocks (9), block-tridiagonal, pose k coupled to speed/bias
+  // k - 1 .. k + 1 — solved in the solver's ordering (speed/bias part first, L16::perm) with its zero blocks skipped.
+  const int dims[] = {150, -150, -120, -165, 162, 174, 175, 160, 144, 90, 31, 16, 15, 6};
   const int nwg = argc > 1 ? atoi(argv[1]) : 1;
   run_elim();
-  for (int D : dims) {
+  for (int Dsigned : dims) {
+    const int D = abs(Dsigned);
+    const bool structured = Dsigned < 0;
+    const int K = D / 15, Dp = structured ? 6 * K : D, Ds = D - Dp;
     const int nb = ba::ldl16_nb(D), area = ba::ldl16_area_doubles(D);
+    const ba::L16 LYh{nb, Ds, D};
     std::vector<double> A((size_t)D * D), b(D), G((size_t)D * D);
     srand(D);
-    for (auto& v : G) v = rand() / (double)RAND_MAX - 0.5;
-    for (int i = 0; i < D; ++i)
-      for (int j = 0; j < D; ++j) {
+    if (!structured) {
+      for (auto& v : G) v = rand() / (double)RAND_MAX - 0.5;
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+          double s = 0;
+          for (int k = 0; k < D; ++k) s += G[(size_t)i * D + k] * G[(size_t)j * D + k];
+          A[(size_t)i * D + j] = s + (i == j ? 0.05 * D : 0.0);
+        }
+    } else {
+      auto frame_of = [&](int i) { return i < Dp ? i / 6 : (i - Dp) / 9; };
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j <= i; ++j) {
+          const bool pi = i < Dp, pj = j < Dp;
+          const int d = abs(frame_of(i) - frame_of(j));
+          const bool on = (pi && pj) || d <= 1;
+          const double v = on ? rand() / (double)RAND_MAX - 0.5 : 0.0;
+          A[(size_t)i * D + j] = A[(size_t)j * D + i] = v;
+        }
+      for (int i = 0; i < D; ++i) {   // diagonally dominant: positive definite
         double s = 0;
-        for (int k = 0; k < D; ++k) s += G[(size_t)i * D + k] * G[(size_t)j * D + k];
-        A[(size_t)i * D + j] = s + (i == j ? 0.05 * D : 0.0);
+        for (int j = 0; j < D; ++j) s += j == i ? 0.0 : fabs(A[(size_t)i * D + j]);
+        A[(size_t)i * D + i] = s + 1.0;
       }
+    }
     for (auto& v : b) v = rand() / (double)RAND_MAX - 0.5;
     std::vector<double> S((size_t)area * nwg, 0.0);
     for (int w = 0; w < nwg; ++w) {
       for (int i = 0; i < D; ++i)
-        for (int j = 0; j <= i; ++j) S[(size_t)w * area + at_host(nb, i, j)] = A[(size_t)i * D + j];
-      for (int i = 0; i < D; ++i) S[(size_t)w * area + at_host(nb, D, i)] = b[i];
+        for (int j = 0; j <= i; ++j) S[(size_t)w * area + LYh.at(i, j)] = A[(size_t)i * D + j];
+      for (int i = 0; i < D; ++i) S[(size_t)w * area + LYh.at(D, i)] = b[i];
     }
     // host Cholesky
     std::vector<double> L(A), y(b), x(D);
@@ -146,7 +170,7 @@ int main(int argc, char** argv) {
     hipMemset(dst, 0, 2048 * 8);
     const size_t shmem = (size_t)(area + 192) * 8;
     hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 3);
+    k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 3, Ds);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) {
       printf("D=%d: %s\n", D, hipGetErrorString(e));
@@ -157,13 +181,13 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     hipEventRecord(e0);
-    k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 23);
+    k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 23, Ds);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventRecord(e0);
-    k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 3);
+    k_solve<<<nwg, NW * 64, shmem>>>(dS, D, dx, dst, dfail, 3, Ds);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms3 = 0;
@@ -180,8 +204,8 @@ int main(int argc, char** argv) {
         err = fmax(err, fabs(xg[(size_t)w * 192 + i] - x[i]));
         nrm = fmax(nrm, fabs(x[i]));
       }
-    printf("D=%3d nb=%2d  rel err %.2e  fail %d  | cycles: load %lld  factor %lld  backsub %lld  total %lld | %.2f us per solve (incl. LDS fill)\n",
-           D, nb, err / nrm, fl[0], st[1] - st[0], st[2] - st[1], st[3] - st[2], st[3] - st[0], (ms - ms3) * 1000.0 / 20.0);
+    printf("D=%4d nb=%2d  rel err %.2e  fail %d  | cycles: load %lld  factor %lld  backsub %lld  total %lld | %.2f us per solve (incl. LDS fill)\n",
+           Dsigned, nb, err / nrm, fl[0], st[1] - st[0], st[2] - st[1], st[3] - st[2], st[3] - st[0], (ms - ms3) * 1000.0 / 20.0);
     if (D == 150) {
       for (int kb = 0; kb < nb; ++kb)
         printf("   step %2d: eliminate %5lld  publish %5lld  wait+R+P (8 MFMA) %5lld  convert %5lld\n", kb,
