@@ -49,6 +49,10 @@ constexpr int LDL_MAX_NB = 11;   // D + 1 <= 176
 #ifndef LDL_W0_REORDER
 #define LDL_W0_REORDER 0
 #endif
+// LDL_ELIM16 1 = the elimination of a diagonal block runs with lanes 16 .. 63 masked off
+#ifndef LDL_ELIM16
+#define LDL_ELIM16 0
+#endif
 
 struct L16 {
   int nb;
@@ -514,8 +518,15 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
     for (int kb = 0; kb < nb; ++kb) {
       const int npiv = (kb == nb - 1) ? npl : 16;
       mine = 0.0;
+#if LDL_ELIM16
+      if (lane < 16) {   // (only DPP row 0 holds the block: the other three quarter-waves are masked off)
+        if (kb < nb - 1) ldl16_eliminate<true>(c, 16, mine, j);
+        else ldl16_eliminate<false>(c, npiv, mine, j);
+      }
+#else
       if (kb < nb - 1) ldl16_eliminate<true>(c, 16, mine, j);
       else ldl16_eliminate<false>(c, npiv, mine, j);
+#endif
       bad = bad || (j < npiv && !(mine > 0.0 && mine < 1.0e300));   // a pivot was not positive
       if (stamps && tid == 0 && kb < 12) stamps[16 + 4 * kb] = clock64();
       // publish Bh (column `lane` as it is: the consumers mask the dead entries above the diagonal) and 1/d

@@ -381,7 +381,8 @@ __device__ __forceinline__ void trial_states(const WinPtrs& W, int acc, const do
       for (int k = 0; k < 7; ++k) xt[k] = xin[k];
     }
   }
-  for (int b = tid; b < W.n_sb; b += SOLVE_THREADS) {
+  // (the speed/bias blocks on wave 2's lanes: the pose blocks keep wave 0's busy)
+  for (int b = (tid + SOLVE_THREADS - 128) % SOLVE_THREADS; b < W.n_sb; b += SOLVE_THREADS) {
     auto xt = as_global(W.sb[trial] + 9 * (size_t)b);
     double v[9], d[9];
     int off;
@@ -626,18 +627,27 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // the Jacobi scale of this lane's column (used by the damping, section 4): requested now, the value is only wrong in the
   // launch that estimates it
   const double scale_pref = opt.dogleg ? W.scale_p[tid < D ? tid : 0] : 1.0;
-  // pose / speed-bias prior records of the speculated buffer and their columns in the reduced system (host-built) -> LDS
+  // Pose / speed-bias priors (the stock window has one of each): wave 0's business from the first request to the last sum.  Its
+  // lanes request the records of the speculated buffer and the priors' columns in the reduced system (host-built) here, park
+  // them in LDS behind the decision (its own writes, read back by itself: no other wave is involved), form the J^T J / J^T r
+  // entries while the other waves still wait for the Schur sums, and add them behind the IMU records.
   __shared__ double s_pri[PRI_STAGE * (42 + 9 + 81)];
   __shared__ int s_pricol[PRI_STAGE * (6 + 9)];
   const int n_pri = (!LARGE && W.n_pprior <= PRI_STAGE && W.n_sbprior <= PRI_STAGE) ? PRI_STAGE : 0;
-  double pri_a = 0, pri_b = 0, pri_c = 0;
+  double pri_a0 = 0, pri_a1 = 0, pri_b = 0, pri_c0 = 0, pri_c1 = 0, pri_c2 = 0;
   int pri_col = -1;
   if (n_pri) {   // (uniform)
     const int npp = W.n_pprior, nsp = W.n_sbprior;
-    pri_a = W.pp_lin[spec0][(tl < npp * 42 && npp > 0) ? tl : 0];
-    pri_b = W.sbp_lin[spec0][(tl < nsp * 9 && nsp > 0) ? tl : 0];
-    pri_c = W.sbprior_sqrtinfo[(tl < nsp * 81 && nsp > 0) ? tl : 0];
-    pri_col = W.prior_col[tl < npp * 6 + nsp * 9 ? tl : 0];
+    const int l = tid & 63;
+    auto pa = W.pp_lin[spec0];
+    auto pc = W.sbprior_sqrtinfo;
+    pri_a0 = pa[l < npp * 42 ? l : 0];
+    pri_a1 = pa[l + 64 < npp * 42 ? l + 64 : 0];
+    pri_b = W.sbp_lin[spec0][l < nsp * 9 ? l : 0];
+    pri_c0 = pc[l < nsp * 81 ? l : 0];
+    pri_c1 = pc[l + 64 < nsp * 81 ? l + 64 : 0];
+    pri_c2 = pc[l + 128 < nsp * 81 ? l + 128 : 0];
+    pri_col = W.prior_col[l < npp * 6 + nsp * 9 ? l : 0];
   }
   // accepted pose / speed-bias values of the speculated buffer -> LDS (the convergence test and the trial states read them;
   // one memory round trip here instead of two on the critical path later)
@@ -681,6 +691,88 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     BA_IMU_REQ(0) BA_IMU_REQ(1) BA_IMU_REQ(2) BA_IMU_REQ(3) BA_IMU_REQ(4) BA_IMU_REQ(5)
 #undef BA_IMU_REQ
   }
+  // ---- the entries of the staged priors (formed by wave 0 behind its decision, added behind the IMU records): J^T J / J^T r
+  // with the expressions of add_small_factor (same bits).  Pose prior p and speed/bias prior p never share a block, so they go
+  // in one pass: two tasks per lane and pass — 21 + 6 entries of the pose prior, 45 + 9 of the speed/bias prior.
+  const int goff = (int)(s_g - smem);   // the gradient as an offset into the dynamic LDS, like the matrix entries
+  const bool w0pri = !LARGE && n_pri > 0 && (W.n_pprior > 0 || W.n_sbprior > 0);
+  // (named scalars, not arrays: with 128 registers per lane the compiler parks small private arrays in scratch memory)
+  static_assert(PRI_STAGE == 2, "the four tasks below");
+  double pr_v00 = 0, pr_v01 = 0, pr_v10 = 0, pr_v11 = 0;
+  int pr_o00 = -1, pr_o01 = -1, pr_o10 = -1, pr_o11 = -1, pr_d00 = -1, pr_d01 = -1, pr_d10 = -1, pr_d11 = -1;
+  auto prior_task = [&](int p, int t, double& val, int& off, int& d2i) {   // task t of pass p (wave 0 only)
+    if (t < 27) {
+      if (p < W.n_pprior) {
+        const double* L = s_pri + 42 * p;
+        const int* co = s_pricol + 6 * p;
+        if (t < 21) {
+          int a = 0;
+          while ((a + 1) * (a + 2) / 2 <= t) ++a;
+          const int b = t - a * (a + 1) / 2;
+          const int ra = co[a], rb = co[b];
+          if (ra >= 0 && rb >= 0) {
+            double sacc = 0;
+            for (int k = 0; k < 6; ++k) sacc += L[k * 6 + a] * L[k * 6 + b];
+            val = sacc;
+            off = LY.at(ra, rb);
+            d2i = a == b ? ra : -1;
+          }
+        } else {
+          const int a = t - 21, ra = co[a];
+          if (ra >= 0) {
+            double sacc = 0;
+            for (int k = 0; k < 6; ++k) sacc += L[k * 6 + a] * L[36 + k];
+            val = sacc;
+            off = goff + ra;
+          }
+        }
+      }
+    } else if (t < 81) {
+      if (p < W.n_sbprior) {
+        // J^T J and J^T r are sign-invariant / sign-flipped: +sqrtInfo with -r
+        const double* Jc = s_pri + PRI_STAGE * 51 + 81 * p;
+        const double* r = s_pri + PRI_STAGE * 42 + 9 * p;
+        const int* co = s_pricol + PRI_STAGE * 6 + 9 * p;
+        if (t < 72) {
+          const int e = t - 27;
+          int a = 0;
+          while ((a + 1) * (a + 2) / 2 <= e) ++a;
+          const int b = e - a * (a + 1) / 2;
+          const int ra = co[a], rb = co[b];
+          if (ra >= 0 && rb >= 0) {
+            double sacc = 0;
+            for (int k = 0; k < 9; ++k) sacc += Jc[k * 9 + a] * Jc[k * 9 + b];
+            val = sacc;
+            off = LY.at(ra, rb);
+            d2i = a == b ? ra : -1;
+          }
+        } else {
+          const int a = t - 72, ra = co[a];
+          if (ra >= 0) {
+            double sacc = 0;
+            for (int k = 0; k < 9; ++k) sacc -= Jc[k * 9 + a] * r[k];
+            val = sacc;
+            off = goff + ra;
+          }
+        }
+      }
+    }
+  };
+  auto prior_tasks = [&]() {
+    prior_task(0, tid, pr_v00, pr_o00, pr_d00);
+    prior_task(0, tid + 64, pr_v01, pr_o01, pr_d01);
+    prior_task(1, tid, pr_v10, pr_o10, pr_d10);
+    prior_task(1, tid + 64, pr_v11, pr_o11, pr_d11);
+  };
+  // one pass: every read of the wave leaves before its first write (the entries of a pass are disjoint)
+  auto prior_apply = [&](double va, int oa, int da, double vb, int ob, int db) {
+    const double a0 = oa >= 0 ? smem[oa] : 0.0, a1 = da >= 0 ? s_d2[da] : 0.0;
+    const double b0 = ob >= 0 ? smem[ob] : 0.0, b1 = db >= 0 ? s_d2[db] : 0.0;
+    if (oa >= 0) smem[oa] = a0 + va;
+    if (da >= 0) s_d2[da] = a1 + va;
+    if (ob >= 0) smem[ob] = b0 + vb;
+    if (db >= 0) s_d2[db] = b1 + vb;
+  };
   // The chunk partials of linearisation buffer `buf` -> S and the pose part of the three vectors (waves 1 .. 15).  use_sums:
   // the helper workgroups have summed them (into W.spart_sum).  One item = one double of the partials' record (lower triangle
   // of the pose part in 6x6 blocks, then  Y b | g | diag U): lanes on consecutive doubles (coalesced; three items per lane
@@ -705,7 +797,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         if (!use_sums) {
           // large launches: summed here, lanes on consecutive doubles, three items per lane and eight chunks per trip requested
           // together (the loads come from other CUs' stores: what counts is the number of dependent rounds)
-          constexpr int CB = 8;   // chunks per trip (a fused window has up to 34 chunks, a separate Schur launch 9)
+          constexpr int CB = 9;   // chunks per trip (a separate Schur launch leaves 9 chunks at configs[1]: ONE trip; a fused window has up to 34)
           for (int ch = 0; ch < nch; ch += CB) {
             double v[3][CB];
 #pragma unroll
@@ -845,6 +937,32 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       }
       if (W.prof && blockIdx.x == 0) W.prof[3] = (double)clock64();
     }
+    if (w0pri) {
+      // the prior records into LDS (this wave's own writes, read back by itself) and their entries into registers — with the
+      // records of the buffer the decision has just named (a rejected trial: the other buffer's, requested again)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      asm volatile("" ::: "memory");
+      const int accn = __builtin_amdgcn_readfirstlane(c.acc);
+      const int npp = W.n_pprior, nsp = W.n_sbprior;
+      if (accn != spec0) {
+        auto pa = W.pp_lin[accn];
+        pri_a0 = pa[tid < npp * 42 ? tid : 0];
+        pri_a1 = pa[tid + 64 < npp * 42 ? tid + 64 : 0];
+        pri_b = W.sbp_lin[accn][tid < nsp * 9 ? tid : 0];
+      }
+      if (tid < npp * 42) s_pri[tid] = pri_a0;
+      if (tid + 64 < npp * 42) s_pri[tid + 64] = pri_a1;
+      if (tid < nsp * 9) s_pri[PRI_STAGE * 42 + tid] = pri_b;
+      if (tid < nsp * 81) s_pri[PRI_STAGE * 51 + tid] = pri_c0;
+      if (tid + 64 < nsp * 81) s_pri[PRI_STAGE * 51 + tid + 64] = pri_c1;
+      if (tid + 128 < nsp * 81) s_pri[PRI_STAGE * 51 + tid + 128] = pri_c2;
+      if (tid < npp * 6) s_pricol[tid] = pri_col;
+      else if (tid < npp * 6 + nsp * 9) s_pricol[PRI_STAGE * 6 + tid - npp * 6] = pri_col;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      asm volatile("" ::: "memory");
+      prior_tasks();
+      if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[44] = (double)clock64();   // diagnostics: prior entries formed
+    }
   } else {
     // meanwhile the other waves prepare what does not depend on the decision
     if constexpr (LARGE) {
@@ -892,14 +1010,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       // partials) are the longer wait
       auto stage_stores = [&]() {
         if (t64 < WD_N) s_Wd[t64] = wd_v;
-        if (n_pri) {
-          const int npp = W.n_pprior, nsp = W.n_sbprior;
-          if (t64 < npp * 42) s_pri[t64] = pri_a;
-          if (t64 < nsp * 9) s_pri[PRI_STAGE * 42 + t64] = pri_b;
-          if (t64 < nsp * 81) s_pri[PRI_STAGE * 51 + t64] = pri_c;
-          if (t64 < npp * 6) s_pricol[t64] = pri_col;
-          else if (t64 < npp * 6 + nsp * 9) s_pricol[PRI_STAGE * 6 + t64 - npp * 6] = pri_col;
-        }
         if (pre_on && t64 < PRE_BLOCKS * 8) {
           const int np7 = 7 * W.n_pose, ns9 = 9 * W.n_sb;
           const int i0 = 2 * t64, i1 = 2 * t64 + 1;
@@ -981,92 +1091,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     __syncthreads();
   }
   STAMP(2);
-  // The staged pose / speed-bias priors (the stock configuration has one of each) belong to wave 0, which holds no IMU entries
-  // and idles through the colour passes: it forms their J^T J / J^T r entries (the expressions of add_small_factor, same bits)
-  // from the LDS copies of the records during the first pass and adds them in ONE pass behind the IMU colours — pose prior p
-  // and speed/bias prior p never share a block.  Two tasks per lane and pass: 21 + 6 entries of the pose prior, 45 + 9 of the
-  // speed/bias prior.
-  const int goff = (int)(s_g - smem);   // the gradient as an offset into the dynamic LDS, like the matrix entries
-  const bool w0pri = !LARGE && n_pri > 0 && (Wl.n_pprior > 0 || Wl.n_sbprior > 0);
-  const bool rejected = s_was_pending && !s_accepted;   // the speculated buffer was the wrong one (rare): records are restaged below
-  // (named scalars, not arrays: with 128 registers per lane the compiler parks small private arrays in scratch memory)
-  static_assert(PRI_STAGE == 2, "the four tasks below");
-  double pr_v00 = 0, pr_v01 = 0, pr_v10 = 0, pr_v11 = 0;
-  int pr_o00 = -1, pr_o01 = -1, pr_o10 = -1, pr_o11 = -1, pr_d00 = -1, pr_d01 = -1, pr_d10 = -1, pr_d11 = -1;
-  auto prior_task = [&](int p, int t, double& val, int& off, int& d2i) {   // task t of pass p (wave 0 only)
-    if (t < 27) {
-      if (p < Wl.n_pprior) {
-        const double* L = s_pri + 42 * p;
-        const int* co = s_pricol + 6 * p;
-        if (t < 21) {
-          int a = 0;
-          while ((a + 1) * (a + 2) / 2 <= t) ++a;
-          const int b = t - a * (a + 1) / 2;
-          const int ra = co[a], rb = co[b];
-          if (ra >= 0 && rb >= 0) {
-            double sacc = 0;
-            for (int k = 0; k < 6; ++k) sacc += L[k * 6 + a] * L[k * 6 + b];
-            val = sacc;
-            off = LY.at(ra, rb);
-            d2i = a == b ? ra : -1;
-          }
-        } else {
-          const int a = t - 21, ra = co[a];
-          if (ra >= 0) {
-            double sacc = 0;
-            for (int k = 0; k < 6; ++k) sacc += L[k * 6 + a] * L[36 + k];
-            val = sacc;
-            off = goff + ra;
-          }
-        }
-      }
-    } else if (t < 81) {
-      if (p < Wl.n_sbprior) {
-        // J^T J and J^T r are sign-invariant / sign-flipped: +sqrtInfo with -r
-        const double* Jc = s_pri + PRI_STAGE * 51 + 81 * p;
-        const double* r = s_pri + PRI_STAGE * 42 + 9 * p;
-        const int* co = s_pricol + PRI_STAGE * 6 + 9 * p;
-        if (t < 72) {
-          const int e = t - 27;
-          int a = 0;
-          while ((a + 1) * (a + 2) / 2 <= e) ++a;
-          const int b = e - a * (a + 1) / 2;
-          const int ra = co[a], rb = co[b];
-          if (ra >= 0 && rb >= 0) {
-            double sacc = 0;
-            for (int k = 0; k < 9; ++k) sacc += Jc[k * 9 + a] * Jc[k * 9 + b];
-            val = sacc;
-            off = LY.at(ra, rb);
-            d2i = a == b ? ra : -1;
-          }
-        } else {
-          const int a = t - 72, ra = co[a];
-          if (ra >= 0) {
-            double sacc = 0;
-            for (int k = 0; k < 9; ++k) sacc -= Jc[k * 9 + a] * r[k];
-            val = sacc;
-            off = goff + ra;
-          }
-        }
-      }
-    }
-  };
-  auto prior_tasks = [&]() {
-    prior_task(0, tid, pr_v00, pr_o00, pr_d00);
-    prior_task(0, tid + 64, pr_v01, pr_o01, pr_d01);
-    prior_task(1, tid, pr_v10, pr_o10, pr_d10);
-    prior_task(1, tid + 64, pr_v11, pr_o11, pr_d11);
-  };
-  // one pass: every read of the wave leaves before its first write (the entries of a pass are disjoint)
-  auto prior_apply = [&](double va, int oa, int da, double vb, int ob, int db) {
-    const double a0 = oa >= 0 ? smem[oa] : 0.0, a1 = da >= 0 ? s_d2[da] : 0.0;
-    const double b0 = ob >= 0 ? smem[ob] : 0.0, b1 = db >= 0 ? s_d2[db] : 0.0;
-    if (oa >= 0) smem[oa] = a0 + va;
-    if (da >= 0) s_d2[da] = a1 + va;
-    if (ob >= 0) smem[ob] = b0 + vb;
-    if (db >= 0) s_d2[db] = b1 + vb;
-  };
-  bool pri_formed = false;
+  const bool rejected = s_was_pending && !s_accepted;   // the speculated buffer was the wrong one (rare): records are reloaded below
   if (imu_fast) {
     if (imu_items > 0) {
 #define BA_IMU_MASK(j) if (!(t64 >= 0 && t64 + (j) * IMU_NL < imu_items)) imu_w##j = -1;
@@ -1090,10 +1115,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
 #define BA_IMU_WR(j) if (on##j) { smem[imu_w##j & 0xFFFF] = o##j + imu_v##j; if (d##j >= 0) s_d2[d##j] = q##j + imu_v##j; }
       BA_IMU_WR(0) BA_IMU_WR(1) BA_IMU_WR(2) BA_IMU_WR(3) BA_IMU_WR(4) BA_IMU_WR(5)
 #undef BA_IMU_WR
-      if (col == 0 && w0pri && !rejected && tid < 64) prior_tasks();
+      if (W.prof && tid == 64 && blockIdx.x == 0) W.prof[45 + (col > 0)] = (double)clock64();   // diagnostics: a wave's colour pass is through
       __syncthreads();
     }
-    pri_formed = Wl.n_imu_color > 0 && !rejected;
   }
   if (W.prof && tid == 0 && blockIdx.x == 0) W.prof[58] = (double)clock64();   // diagnostics: end of the IMU part
   if (pre_on && rejected) {   // rejected step: the other buffer stays accepted
@@ -1137,15 +1161,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       __syncthreads();
     }
   }
-  if (n_pri) {
-    if (rejected) {   // rejected step: restage the records of the buffer that stays accepted
-      if (tid < Wl.n_pprior * 42) s_pri[tid] = Wl.pp_lin[acc][tid];
-      if (tid < Wl.n_sbprior * 9) s_pri[PRI_STAGE * 42 + tid] = Wl.sbp_lin[acc][tid];
-      __syncthreads();
-    }
-  }
-  if (w0pri) {
-    if (!pri_formed && tid < 64) prior_tasks();
+  if (w0pri) {   // (formed by wave 0 in front of the barrier)
     if (tid < 64) prior_apply(pr_v00, pr_o00, pr_d00, pr_v01, pr_o01, pr_d01);
     __syncthreads();
     if (Wl.n_pprior > 1 || Wl.n_sbprior > 1) {
@@ -1165,7 +1181,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     if (opt.dogleg) {
       // Ceres 1.9: gradient_max_norm = || x - Plus(x, -g) ||_inf over the ambient coordinates: the gradient itself for
       // Euclidean blocks, the change of the quaternion coefficients for the rotation part of a pose
-      for (int b = tid; b < Wl.n_pose; b += SOLVE_THREADS) {
+      // (the pose blocks on wave 4's lanes: waves 0 .. 2 carry the damping of the same phase)
+      for (int b = (tid + SOLVE_THREADS - 256) % SOLVE_THREADS; b < Wl.n_pose; b += SOLVE_THREADS) {
         const int off = (pre_on && b < PRE_BLOCKS) ? s_preoff[b] : Wl.pose_off[b];
         if (off < 0) continue;
         const double* xp = (pre_on && b < PRE_BLOCKS) ? s_pre + 7 * b : Wl.pose[acc] + 7 * (size_t)b;

@@ -18,6 +18,6 @@ for k, n in names:
     print("  %-36s %8.0f ticks %7.2f us" % (n, p[k] - p[prev], (p[k] - p[prev]) / T)); prev = k
 print("  total %.2f us from stamp 0, %.2f us from the first instruction" % ((p[9] - p[0]) / T, (p[9] - p[43]) / T))
 print("  tail: step vector %.2f, trial states %.2f, sums + barrier %.2f, ctrl %.2f us" % ((p[31] - p[7]) / T, (p[32] - p[31]) / T, (p[33] - p[32]) / T, (p[9] - p[33]) / T))
-ids = [43, 40, 0, 41, 42, 3, 4, 1, 2, 58, 5, 6, 10, 7, 8, 31, 32, 33, 9]
+ids = [43, 40, 0, 41, 42, 3, 44, 4, 1, 2, 45, 46, 58, 5, 6, 10, 7, 8, 31, 32, 33, 9]
 base = min(p[k] for k in ids if p[k] > 0)
 print("  raw stamps (us after the earliest): " + "  ".join("%d:%.2f" % (k, (p[k] - base) / T) for k in ids if p[k] > 0))

@@ -60,6 +60,9 @@ __global__ __launch_bounds__(NW * 64) void k_elim(const double* __restrict__ A, 
     }
 
     double mine = 0.0;
+#if LDL_ELIM16
+    if (lane < 16)
+#endif
     ba::ldl16_eliminate<true>(c, 16, mine, j);
     acc += mine + c[15];
   }
