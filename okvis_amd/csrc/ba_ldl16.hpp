@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <type_traits>
 
 #include "ba_device.hpp"
 
@@ -52,6 +53,9 @@ constexpr int LDL_MAX_NB = 11;   // D + 1 <= 176
 // LDL_ELIM16 1 = the elimination of a diagonal block runs with lanes 16 .. 63 masked off
 #ifndef LDL_ELIM16
 #define LDL_ELIM16 0
+#endif
+#ifndef LDL_ASSIGN_COLUMNS
+#define LDL_ASSIGN_COLUMNS 0
 #endif
 
 struct L16 {
@@ -84,7 +88,7 @@ constexpr int LDL_RS = 18;   // stride of the 16-vectors that one lane reads or 
 constexpr int LDL_XB = 16 * LDL_RS;
 // doubles of LDS the solver needs from the start of the assembly buffer (it overwrites the assembled matrix)
 __host__ __device__ inline int ldl16_work_doubles(int nb) {
-  return 2 * nb * 256 /* Rp */ + 3 * nb * LDL_XB /* Xs, XB, Rsup */ + 4 * 256 /* qbuf, dpart */ + 2 * nb * 16 /* dinv, xv */;
+  return 2 * nb * 256 /* Rp */ + 3 * nb * LDL_XB /* Xs, XB, Rsup */ + 4 * 256 /* qbuf, dpart */ + 2 * nb * 16 /* dinv, xv */ + LDL_XB /* Pt */;
 }
 __host__ __device__ inline int ldl16_nb(int D) { return (D + 1 + 15) / 16; }
 // size of the matrix area (doubles): the assembled blocks or the work area, whichever is larger
@@ -142,10 +146,36 @@ __device__ __forceinline__ unsigned long long ldl_ready_mask_bit(const int* flag
   *bits = __ballot((v & 1) != 0);
   return __ballot(v >= need2);
 }
-// the calling wave's LDS writes become visible before the flag does
+// The calling wave's LDS writes become visible before the flag does.  No wait in between: the LDS executes the requests of one
+// wave in the order they were issued (their answers return in that order), so a flag written behind the data is performed
+// behind the data; a workgroup-scope release fence would have the wave sit through the round trip of its own writes (~100
+// cycles in every hand-over).  The asm statement keeps the compiler from moving the flag's store in front of the data's.
 __device__ __forceinline__ void ldl_signal(int* flag, int v, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("" ::: "memory");
   if (lane == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+
+// The A operand of the panel products of step k,  L_kk^-1 = Bh D^-1  (unit diagonal, exact zeros above it), and -1/d, for the
+// rows (lane >> 4) + 4 q of the product's inner dimension.  Every value is requested before the first is used: written as
+// `a[q] = am > ak ? Xs[..] * dinv[..] : ..` the compiler put each load inside its own branch, four LDS round trips in a row
+// in every wave that forms a panel block (and in wave 0's chain).
+__device__ __forceinline__ void ldl_operand(const double* Xk, const double* dk, int lane, double (&a)[4], double (&dq)[4]) {
+  const int am = lane & 15;
+  double xh[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ak = (lane >> 4) + 4 * q;
+    dq[q] = -dk[ak];
+    xh[q] = Xk[ak * LDL_RS + am];
+  }
+  asm volatile("" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(dq[0]), "+v"(dq[1]), "+v"(dq[2]), "+v"(dq[3]));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ak = (lane >> 4) + 4 * q;
+    const double v = xh[q] * -dq[q];
+    a[q] = am > ak ? v : (am == ak ? 1.0 : 0.0);
+  }
 }
 
 // One elimination step of the 16x16 diagonal block held column per lane, r[i] = entry (i, lane & 15), A and the inverse
@@ -203,8 +233,11 @@ __device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool ac
   for (int i = K + 2; i < 16; ++i) fmac_bcast<K>(r[i], r[i], v);
   return dn;
 }
-template <bool FULL, bool GUARD = false>
-__device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, double& mine, int j, bool* bad = nullptr) {
+struct LdlNoHook { __device__ __forceinline__ void operator()() const {} };
+// (mid: called between the pivots 9 and 10 — wave 0 issues the requests for the hand-overs of its step there, late enough for
+// them to have arrived in the common case and early enough for the answers to be there when the elimination ends)
+template <bool FULL, bool GUARD = false, class HOOK = LdlNoHook>
+__device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, double& mine, int j, bool* bad = nullptr, HOOK mid = HOOK()) {
   double d = bcast_nop<0>(r[0]);
   d = ldl16_pivot<0, FULL, GUARD>(r, d, 0 < npiv, mine, j, bad);
   d = ldl16_pivot<1, FULL, GUARD>(r, d, 1 < npiv, mine, j, bad);
@@ -216,6 +249,7 @@ __device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, doubl
   d = ldl16_pivot<7, FULL, GUARD>(r, d, 7 < npiv, mine, j, bad);
   d = ldl16_pivot<8, FULL, GUARD>(r, d, 8 < npiv, mine, j, bad);
   d = ldl16_pivot<9, FULL, GUARD>(r, d, 9 < npiv, mine, j, bad);
+  mid();
   d = ldl16_pivot<10, FULL, GUARD>(r, d, 10 < npiv, mine, j, bad);
   d = ldl16_pivot<11, FULL, GUARD>(r, d, 11 < npiv, mine, j, bad);
   d = ldl16_pivot<12, FULL, GUARD>(r, d, 12 < npiv, mine, j, bad);
@@ -234,6 +268,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
   // waves w, w+4, w+8, w+12 of a workgroup sit on one SIMD, tests/micro/hwid.hip) would be starved exactly when the chain
   // needs their hand-offs (measured: a flag seen 5500 cycles late), so they own nothing and go straight to the last barrier.
   static_assert(NW == 16, "wave roles below assume 16 waves");
+  static_assert(LDL_MAX_NB <= 12, "two block columns per near-diagonal wave");
   constexpr int NREG = 12;                                            // waves that own blocks: (wave & 3) != 0
   constexpr int SLOTS = (LDL_MAX_NB * (LDL_MAX_NB + 1) / 2 + NREG - 1) / NREG;
   const int nb = ldl16_nb(D);
@@ -241,6 +276,11 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
   const int nblk = L16::blocks(nb);
   const int npl = D - 16 * (nb - 1);                                  // pivots of the last block (its column npl is the rhs)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // Inside the step loops the lane index is taken through an empty asm statement once per iteration: what is derived from it
+  // (LDS addresses, the sixteen `lane == K` masks of the elimination) is then recomputed per step — a few VALU instructions —
+  // instead of being hoisted in front of the loops, kept live across them and spilled (every reload of a spilled address
+  // inside a step is a scratch-memory round trip on the chain).
+#define LDL_LANE() [&]() { int l_ = tid & 63; asm volatile("" : "+v"(l_)); return l_; }()
   const int ridx = (wave >> 2) * 3 + (wave & 3) - 1;                  // 0..11 for the block-owning waves
   // work area (aliases the assembled matrix once every block sits in registers)
   double* Rp = S;                          // [2][nb][256] panel row R_J of step kb in buffer kb & 1, accumulator layout
@@ -251,7 +291,9 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
   double* dpart = qbuf + 512;              // [2][256] diagonal block I with the updates k <= I - 2, accumulator layout
   double* dinv = dpart + 512;              // [nb][16]
   double* xv = dinv + nb * 16;             // [nb][16] solution incl. x[D] = -1
+  double* Pt = xv + nb * 16;               // [16][LDL_RS] wave 0's own: the next diagonal block on its way from the accumulator layout to column per lane
   double* tcon = Rp;                       // [nb][nb][16] back-substitution: R_KJ x_J, one slot per block (the panel rows are dead by then)
+  double* tsv = tcon + nb * nb * 16;       // [nb][16] minus the sum of the slots of a block row, in the fixed order (by wave 4)
   // flags (outside the matrix area: they are zeroed before the assembled matrix is dead)
   __shared__ int f_xready;                 // k + 1: Bh_k and 1/d_k published
   // [m & 1] = m + 1: block (m, m+1) complete in qbuf[m & 1] / diagonal block m with the updates <= m - 2 in dpart[m & 1].
@@ -265,7 +307,28 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
   __shared__ int f_x;                      // back-substitution: number of solved blocks (from the last one)
   __shared__ int f_tc[LDL_MAX_NB];         // [K] number of slots tcon[K][.] written
   __shared__ int f_xb[LDL_MAX_NB];         // [K] 1: XB[K] prepared
+  __shared__ int f_ts[LDL_MAX_NB];         // [K] 1: the slots of block row K summed (tsv[K])
 #define LDL_STAMP(k) do { if (stamps && tid == 0) stamps[k] = clock64(); } while (0)
+  // diagnostics (tests/micro/ldl16.hip -DLDL_TS_STEP=k): time stamps of wave 0's step k, kept in scalar registers and stored
+  // behind the factorisation (a stamp written where it is taken costs ~150 cycles and delays the chain it measures)
+#ifdef LDL_TS_ALL   // loop top | hand-overs requested again .. both there, every step, through LDS (costs ~250 cycles per step)
+  __shared__ long long ts_all[3][16];
+#define LDL_TSA(i) do { if (lane == 0) ts_all[i][kb] = clock64(); } while (0)
+#else
+#define LDL_TSA(i) do { } while (0)
+#endif
+#ifdef LDL_OTS_WAVE   // the same for an owner wave (LDL_OTS_WAVE) in step LDL_TS_STEP; stamps 0..15, a stamp index used twice keeps the later time
+  long long ots_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define LDL_OTS(i) do { if (kb == LDL_TS_STEP && wave == LDL_OTS_WAVE) ots_[i] = clock64(); } while (0)
+#else
+#define LDL_OTS(i) do { } while (0)
+#endif
+#ifdef LDL_TS_STEP
+  long long ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LDL_TS(i) do { if (kb == LDL_TS_STEP) ts_[i] = clock64(); } while (0)
+#else
+#define LDL_TS(i) do { } while (0)
+#endif
 #ifdef LDL_TRACE   // diagnostics (tests/micro/ldl16.hip): per-wave event log {clock, code} in LDS, dumped behind the stamps
   __shared__ long long tr_log[16][64];
   int tr_n = 0;
@@ -285,58 +348,124 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
     f_prdy[1][tid] = 0;
     f_tc[tid] = 0;
     f_xb[tid] = 0;
+    f_ts[tid] = 0;
   }
   if (tid < 16) f_tdn[tid] = 0;
 
   if (wave > 0 && (wave & 3) == 0) {
     __syncthreads();   // (the barrier after the initial loads)
+    if (wave == 4 && nb >= 3) {
+      // Back-substitution, off the chain: minus the sum of the slots of block row K (the products R_KJ x_J, J >= K + 2, of the
+      // block-owning waves) in the fixed order J = nb-1, nb-2, ..., for wave 0 to start its t_K from.  Wave 0 used to do this
+      // itself: a poll of the slot counter, nine loads and nine selected subtractions per step, in front of its chain.
+      // (The wave shares wave 0's SIMD: it sleeps until the back-substitution has started.)
+      while (__hip_atomic_load(&f_x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 1) __builtin_amdgcn_s_sleep(8);
+      const int j = lane & 15;
+      for (int K = nb - 3; K >= 0; --K) {
+        ldl_wait_ge(&f_tc[K], nb - K - 2);
+        double tc[LDL_MAX_NB - 2];
+#pragma unroll
+        for (int u = 0; u < LDL_MAX_NB - 2; ++u) {
+          const int J = nb - 1 - u;
+          const int Jc = J >= K + 2 ? J : K + 2;   // (clamped: a load, not a branch; the copy is not added)
+          tc[u] = tcon[(K * nb + Jc) * 16 + j];
+        }
+        double ts = 0.0;
+#pragma unroll
+        for (int u = 0; u < LDL_MAX_NB - 2; ++u) ts -= (nb - 1 - u >= K + 2) ? tc[u] : 0.0;
+        if (lane < 16) tsv[K * 16 + lane] = ts;
+        ldl_signal(&f_ts[K], 1, lane);
+      }
+    }
   } else if (wave > 0) {
     // =============================================================================== the twelve block-owning waves
     ldl_v4 acc[SLOTS];
-    int sI[SLOTS], sJ[SLOTS];
+    // the block coordinates of the slots, four bits each (15 = no block): two scalar registers instead of twelve (which spilled)
+    static_assert(LDL_MAX_NB < 15 && SLOTS <= 8, "four bits per coordinate");
+    unsigned pkI = 0xFFFFFFFFu, pkJ = 0xFFFFFFFFu;
     int lastStep = -1;   // last step in which this wave has panel or trailing work
-    // block number -> (I, J) of the row-major upper triangle: lane s works out slot s, the results travel by v_readlane
-    int uI = 0, uR = lane * NREG + ridx;
-    while (uR >= nb - uI && uI < nb) {
-      uR -= nb - uI;
-      ++uI;
-    }
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      const int b = s * NREG + ridx;
-      sI[s] = nb;                          // inactive
-      sJ[s] = nb;
-      acc[s] = ldl_v4{0, 0, 0, 0};
-      if (b < nblk) {
-        const int I = __builtin_amdgcn_readlane(uI, s), rem = __builtin_amdgcn_readlane(uR, s);
-        sI[s] = I;
-        sJ[s] = I + rem;
-        lastStep = max(lastStep, rem > 0 ? I : I - 2);
-        const double* p = S + LY.blk(I, I + rem);
-        if (rem > 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[s][r] = p[64 * r + lane];
-        } else {   // a diagonal block: only its upper triangle is assembled, the accumulators hold the full symmetric block
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = (lane >> 4) + 4 * r, col = lane & 15;
-            const int lo = row < col ? row : col, hi = row < col ? col : row;
-            acc[s][r] = p[(lo >> 2) * 64 + (lo & 3) * 16 + hi];
-          }
-        }
+    // Which blocks a wave owns: lane s works out slot s, the results travel by v_readlane.
+    int uI, uJ;
+#if LDL_ASSIGN_COLUMNS
+    // (variant, measured slower: the six waves 1-3, 5-7 own the blocks next to the diagonal by block COLUMN — wave ridx the columns
+    // c = ridx and ridx + 6, of each the blocks (c-2, c), (c-1, c), (c, c), so that what the chain waits for in step k is the
+    // business of one wave — and the other six share the blocks (I, J >= I + 3).  The column that carries the right-hand side is
+    // dense in every step: its wave falls behind the chain.)
+    if (ridx < NREG / 2) {
+      const int c = ridx + (NREG / 2) * (lane / 3), d = 2 - lane % 3;
+      uI = (c < nb && c - d >= 0 && lane < SLOTS) ? c - d : nb;
+      uJ = c;
+    } else {
+      int r = lane * (NREG / 2) + (ridx - NREG / 2);
+      uI = 0;
+      while (uI < nb && r >= max(0, nb - uI - 3)) {
+        r -= max(0, nb - uI - 3);
+        ++uI;
       }
+      uJ = uI + 3 + r;
+    }
+#else
+    // block number b = lane * NREG + ridx of the row-major upper triangle: row I starts at first(I) = I nb - I (I - 1) / 2, so
+    // I = floor((2 nb + 1 - sqrt((2 nb + 1)^2 - 8 b)) / 2) — in single precision, put right by at most one either way.  (As a
+    // loop over the rows, every lane subtracting row lengths until its number fits: 11 divergent iterations, 180 instructions
+    // in front of the first load of every solve.)
+    {
+      const int b = lane * NREG + ridx;
+      const float t = (float)(2 * nb + 1);
+      int I = (int)((t - sqrtf(fmaxf(t * t - 8.0f * (float)b, 0.0f))) * 0.5f);
+      I = max(0, min(I, nb - 1));
+      if (I * nb - (I * (I - 1)) / 2 > b) --I;
+      if ((I + 1) * nb - ((I + 1) * I) / 2 <= b) ++I;
+      uI = b < nblk ? I : nb;
+      uJ = I + (b - (I * nb - (I * (I - 1)) / 2));
+    }
+#endif
+    const int u_lane = lane;
+    // the steps in which slot `lane` has trailing work: kb < u_tl (a diagonal block takes its last update, that of step I - 1,
+    // inside wave 0)
+    const int u_tl = uI < nb ? (uJ > uI ? uI : uI - 1) : -1;
+    // The blocks into the accumulator registers.  Every slot is loaded, without a branch: a slot without a block reads block
+    // (0, 0) (its registers are never used), and the element a lane reads of a diagonal block — only the upper triangle is
+    // assembled, the accumulators hold the full symmetric block — is a select between two offsets that depend on the lane
+    // alone.  All 24 loads are in flight together.  (With `if (slot has a block) { if (diagonal) .. else .. }` the compiler
+    // loaded every slot into temporaries and waited for them slot by slot.)
+    {
+      const int ln = LDL_LANE();
+      int dofs[4];   // offset of element (row (ln >> 4) + 4 r, column ln & 15) of a diagonal block, read at its mirror image above the diagonal
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (ln >> 4) + 4 * r, col = ln & 15;
+        const int lo = row < col ? row : col, hi = row < col ? col : row;
+        dofs[r] = (lo >> 2) * 64 + (lo & 3) * 16 + hi;
+      }
+      int ls = -1;
+#pragma unroll
+      for (int s = SLOTS - 1; s >= 0; --s) {
+        const int I = __builtin_amdgcn_readlane(uI, s), J = __builtin_amdgcn_readlane(uJ, s);
+        const bool on = I < nb;
+        pkI = (pkI << 4) | (unsigned)(on ? I : 15);
+        pkJ = (pkJ << 4) | (unsigned)(on ? J : 15);
+        ls = max(ls, on ? (J > I ? I : I - 2) : -1);
+        const int Ic = on ? I : 0, Jc = on ? J : 0;
+        const double* p = S + LY.blk(Ic, Jc);
+        const bool diag = Ic == Jc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = p[diag ? dofs[r] : 64 * r + ln];
+      }
+      lastStep = ls;
     }
     __syncthreads();   // every block is in registers: the matrix area is free
     LDL_EV(0xB00);
     // the copies wave 0 needs first: block (0, 1) and the diagonal block 1
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-      if (sI[s] == 0 && sJ[s] == 1) {
+      const int sI_s = (pkI >> (4 * s)) & 15, sJ_s = (pkJ >> (4 * s)) & 15;
+      if (sI_s == 0 && sJ_s == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) qbuf[64 * r + lane] = acc[s][r];
         ldl_signal(&f_hq[0], 1, lane);
       }
-      if (sI[s] == 1 && sJ[s] == 1) {
+      if (sI_s == 1 && sJ_s == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) dpart[256 + 64 * r + lane] = acc[s][r];
         ldl_signal(&f_hp[1], 2, lane);
@@ -346,6 +475,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
     for (int k = ridx; k < nb; k += NREG) lastHelp = k;
     bool tdn_final = false;
     for (int kb = 0; kb < nb; ++kb) {
+      const int lane = LDL_LANE();
       const bool helper = (kb % NREG == ridx);
       if (kb > lastStep && !tdn_final) {   // no panel or trailing work any more: the wave never reads a panel row again
         ldl_signal(&f_tdn[wave], INT_MAX, lane);
@@ -358,102 +488,127 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
       LDL_EV(0xA00 | kb);   // at the wait for X_kb
       ldl_wait_ge(&f_xready, kb + 1);
       LDL_EV(0x100 | kb);   // X_kb seen
-      const int am = lane & 15;
+      LDL_OTS(0);
       double a[4], dq[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ak = (lane >> 4) + 4 * q;
-        dq[q] = -dinv[kb * 16 + ak];
-        const double xh = Xs[kb * LDL_XB + ak * LDL_RS + am];
-        a[q] = am > ak ? xh * -dq[q] : (am == ak ? 1.0 : 0.0);   // L^-1 = Bh D^-1, unit diagonal, exact zeros above it
-      }
+      ldl_operand(Xs + kb * LDL_XB, dinv + kb * 16, lane, a, dq);
+      LDL_OTS(1);
       if (kb <= lastStep) {
         double* Rk = Rp + (kb & 1) * nb * 256;
+        // Which of the wave's slots have work in this step: one ballot each over the lanes that worked the slots out (lane s =
+        // slot s); a slot without work costs a bit test and a branch.  (As a chain of `if (I == kb && J > kb)` over the slots the
+        // bookkeeping was ~25 scalar instructions per slot and loop — coordinates read back from spilled registers, compares,
+        // selects — some 300 per step and wave whatever the wave had to do; a wave issues one instruction every 4-8 cycles.
+        // A loop over the set bits with a jump to the slot's code was slower still: the compiler moves what the six bodies
+        // compute from the step number in front of the loop, for all six.)
+        const unsigned pmask = (unsigned)__ballot(u_lane < SLOTS && uI == kb && uJ > kb);
+        const unsigned tmask = (unsigned)__ballot(u_lane < SLOTS && kb < u_tl);
+        unsigned cI = pkI, cJ = pkJ;
+        asm volatile("" : "+s"(cI), "+s"(cJ));   // (what is derived from the slot coordinates is recomputed, not hoisted and spilled)
+#define LDL_DISPATCH(mask, F)                                                             \
+  {                                                                                       \
+    if ((mask) & 1u) F(std::integral_constant<int, 0>{});                                 \
+    if ((mask) & 2u) F(std::integral_constant<int, 1>{});                                 \
+    if ((mask) & 4u) F(std::integral_constant<int, 2>{});                                 \
+    if ((mask) & 8u) F(std::integral_constant<int, 3>{});                                 \
+    if ((mask) & 16u) F(std::integral_constant<int, 4>{});                                \
+    if ((mask) & 32u) F(std::integral_constant<int, 5>{});                                \
+  }
+        static_assert(SLOTS == 6, "the cases of LDL_DISPATCH");
         // ---- panel row: R_J = L_kk^-1 A_kJ for the owned blocks (kb, J > kb)
         bool waited = kb < 2;
+        LDL_OTS(2);
+        auto panel_slot = [&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          const int pJ = (cJ >> (4 * s)) & 15;
+          LDL_OTS(3);
+          // (the SIMD issues oldest-wave-first: without a priority the youngest of its four waves publishes last, whatever the
+          // chain is waiting for)
+          if (pJ <= kb + 2) __builtin_amdgcn_s_setprio(3);
+          else __builtin_amdgcn_s_setprio(1);
+          // a block that is still exactly zero (no coupling, no fill so far) stays zero: no product, nothing written
+          const bool nz = __any(acc[s][0] != 0.0 || acc[s][1] != 0.0 || acc[s][2] != 0.0 || acc[s][3] != 0.0) != 0;
+          if (nz) {
+            ldl_v4 R{0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-          int pI = sI[s], pJ = sJ[s];
-          asm volatile("" : "+s"(pI), "+s"(pJ));   // (what is derived from the slot coordinates is recomputed, not hoisted and spilled)
-          if (pI == kb && pJ > kb) {
-            // (the SIMD issues oldest-wave-first: without a priority the youngest of its four waves publishes last, whatever the
-            // chain is waiting for)
-            if (pJ <= kb + 2) __builtin_amdgcn_s_setprio(3);
-            else __builtin_amdgcn_s_setprio(1);
-            // a block that is still exactly zero (no coupling, no fill so far) stays zero: no product, nothing written
-            const bool nz = __any(acc[s][0] != 0.0 || acc[s][1] != 0.0 || acc[s][2] != 0.0 || acc[s][3] != 0.0) != 0;
-            if (nz) {
-              ldl_v4 R{0, 0, 0, 0};
-#pragma unroll
-              for (int q = 0; q < 4; ++q) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], acc[s][q], R, 0, 0, 0);
-              acc[s] = R;
-            }
-            if (!waited) {   // the buffer (and its flags) still belong to the panel row of step kb - 2: every wave must be through with it
-              for (;;) {
-                const int v = (lane < NW && (lane & 3) != 0) ? __hip_atomic_load(&f_tdn[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : INT_MAX;
-                if (__all(v >= kb - 1)) break;
-                __builtin_amdgcn_s_sleep(1);
-              }
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-              waited = true;
-            }
-            if (nz) {
-              double* rp = Rk + pJ * 256 + lane;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) rp[64 * r] = acc[s][r];
-            }
-            ldl_signal(&f_prdy[kb & 1][pJ], ((kb + 1) << 1) | (nz ? 0 : 1), lane);
-            LDL_EV(0x200 | (kb << 4) | pJ);   // panel block (kb, J) published
-            __builtin_amdgcn_s_setprio(0);
+            for (int q = 0; q < 4; ++q) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], acc[s][q], R, 0, 0, 0);
+            acc[s] = R;
           }
-        }
+          LDL_OTS(4);
+          if (!waited) {   // the buffer (and its flags) still belong to the panel row of step kb - 2: every wave must be through with it
+            for (;;) {
+              const int v = (lane < NW && (lane & 3) != 0) ? __hip_atomic_load(&f_tdn[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : INT_MAX;
+              if (__all(v >= kb - 1)) break;
+              __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            waited = true;
+          }
+          LDL_OTS(5);
+          if (nz) {
+            double* rp = Rk + pJ * 256 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rp[64 * r] = acc[s][r];
+          }
+          ldl_signal(&f_prdy[kb & 1][pJ], ((kb + 1) << 1) | (nz ? 0 : 1), lane);
+          LDL_EV(0x200 | (kb << 4) | pJ);   // panel block (kb, J) published
+          __builtin_amdgcn_s_setprio(0);
+          LDL_OTS(6);
+        };
+        LDL_DISPATCH(pmask, panel_slot)
         // ---- trailing update of the owned blocks (I > kb).  Two of them are handed to wave 0 afterwards: (kb+1, kb+2), complete
         // with this update, and the diagonal block kb + 2.  The diagonal block kb + 1 is completed by wave 0 itself.
         // (a wave's slots are in row-major order, which is the order in which the chain needs them)
-        {
-          unsigned long long ready = 0, zeros = 0;
-#pragma unroll
-          for (int s = 0; s < SLOTS; ++s) {
-            int I = sI[s], J = sJ[s];
-            asm volatile("" : "+s"(I), "+s"(J));
-            const bool hq = (I == kb + 1 && J == kb + 2), hp = (I == kb + 2 && J == kb + 2);
-            if (I <= kb || I >= nb || (I == kb + 1 && J == kb + 1)) continue;
-            if (hq || hp) __builtin_amdgcn_s_setprio(3);
-            {   // the panel blocks R_I and R_J of this step (one poll fetches the state of the whole panel row)
-              const unsigned long long nd = (1ull << I) | (1ull << J);
-              while ((ready & nd) != nd) {
-                ready = ldl_ready_mask_bit(f_prdy[kb & 1], nb, (kb + 1) << 1, lane, &zeros);
-                if ((ready & nd) != nd) __builtin_amdgcn_s_sleep(1);
-              }
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            if (!(zeros & ((1ull << I) | (1ull << J)))) {   // (a zero panel block: R_I^T D^-1 R_J is zero)
-              const double* rp = Rk + I * 256 + lane;
-              const double* rn = Rk + J * 256 + lane;
-              double ra[4], rb[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                ra[q] = rp[64 * q];
-                rb[q] = rn[64 * q] * dq[q];
-              }
-#pragma unroll
-              for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[q], rb[q], acc[s], 0, 0, 0);
-            }
-            if (hq) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) qbuf[(I & 1) * 256 + 64 * r + lane] = acc[s][r];
-              ldl_signal(&f_hq[I & 1], I + 1, lane);
-              LDL_EV(0x400 | I);   // Q_I handed over
-            }
-            if (hp) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) dpart[(I & 1) * 256 + 64 * r + lane] = acc[s][r];
-              ldl_signal(&f_hp[I & 1], I + 1, lane);
-              LDL_EV(0x500 | I);   // P_I handed over
-            }
-            if (hq || hp) __builtin_amdgcn_s_setprio(0);
+        // (Tried: the panel blocks of slot s + 1 requested before the products of slot s are issued, with a look at the flags that
+        // does not wait.  Slower — the hand-overs arrive 2000 to 6000 cycles later: the extra looks at flags that are not up yet
+        // cost more instructions than the hidden round trips give.)
+        unsigned long long ready = 0, zeros = 0;
+        auto trail_slot = [&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          const int I = (cI >> (4 * s)) & 15, J = (cJ >> (4 * s)) & 15;
+          const bool hq = (I == kb + 1 && J == kb + 2), hp = (I == kb + 2 && J == kb + 2);
+          if (hq) LDL_OTS(7);
+          if (hp) LDL_OTS(11);
+          if (hq || hp) __builtin_amdgcn_s_setprio(3);
+          const unsigned long long nd = (1ull << I) | (1ull << J);
+          while ((ready & nd) != nd) {   // the panel blocks R_I and R_J of this step (one poll fetches the state of the whole panel row)
+            ready = ldl_ready_mask_bit(f_prdy[kb & 1], nb, (kb + 1) << 1, lane, &zeros);
+            if ((ready & nd) != nd) __builtin_amdgcn_s_sleep(1);
           }
-        }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if (hq) LDL_OTS(8);
+          if (hp) LDL_OTS(12);
+          if (!(zeros & nd)) {   // (a zero panel block: R_I^T D^-1 R_J is zero)
+            const double* rp = Rk + I * 256 + lane;
+            const double* rn = Rk + J * 256 + lane;
+            double ra[4], rb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              ra[q] = rp[64 * q];
+              rb[q] = rn[64 * q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[q], rb[q] * dq[q], acc[s], 0, 0, 0);
+          }
+          if (hq) {
+            LDL_OTS(9);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qbuf[(I & 1) * 256 + 64 * r + lane] = acc[s][r];
+            ldl_signal(&f_hq[I & 1], I + 1, lane);
+            LDL_EV(0x400 | I);   // Q_I handed over
+            LDL_OTS(10);
+          }
+          if (hp) {
+            LDL_OTS(13);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dpart[(I & 1) * 256 + 64 * r + lane] = acc[s][r];
+            ldl_signal(&f_hp[I & 1], I + 1, lane);
+            LDL_EV(0x500 | I);   // P_I handed over
+            LDL_OTS(14);
+          }
+          if (hq || hp) __builtin_amdgcn_s_setprio(0);
+        };
+        LDL_DISPATCH(tmask, trail_slot)
+#undef LDL_DISPATCH
         ldl_signal(&f_tdn[wave], kb + 1, lane);
         LDL_EV(0x300 | kb);   // trailing updates of step kb done
       }
@@ -471,19 +626,25 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
         ldl_signal(&f_xb[kb], 1, lane);
       }
     }
+#ifdef LDL_OTS_WAVE
+    if (stamps && wave == LDL_OTS_WAVE && lane == 0)
+      for (int i = 0; i < 16; ++i) stamps[80 + i] = ots_[i];
+#endif
     // ---- back-substitution: R_KJ x_J of the owned blocks with K <= J - 2, block column by block column, each into its own
     // slot (wave 0 adds the slots of a block row in a fixed order, so the result does not depend on who finishes first)
     for (int J = nb - 1; J >= 2; --J) {
+      const int lane = LDL_LANE();
       bool any = false;
+      unsigned cI = pkI, cJ = pkJ;
+      asm volatile("" : "+s"(cI), "+s"(cJ));
 #pragma unroll
-      for (int s = 0; s < SLOTS; ++s) any = any || (sJ[s] == J && sI[s] + 2 <= J);
+      for (int s = 0; s < SLOTS; ++s) any = any || ((int)((cJ >> (4 * s)) & 15) == J && (int)((cI >> (4 * s)) & 15) + 2 <= J);
       if (!any) continue;
       ldl_wait_ge(&f_x, nb - J);
       const double xj = xv[J * 16 + (lane & 15)];
 #pragma unroll
       for (int s = SLOTS - 1; s >= 0; --s) {   // (the block row closest to J first: wave 0 asks for it first)
-        int K = sI[s], sj = sJ[s];
-        asm volatile("" : "+s"(K), "+s"(sj));
+        const int K = (cI >> (4 * s)) & 15, sj = (cJ >> (4 * s)) & 15;
         if (sj == J && K + 2 <= J) {
           if (K + 2 == J) __builtin_amdgcn_s_setprio(3);   // the slot wave 0 asks for next
           double p[4];
@@ -493,7 +654,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
 #pragma unroll
             for (int r = 0; r < 4; ++r) tcon[(K * nb + J) * 16 + (lane >> 4) + 4 * r] = p[r];
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          asm volatile("" ::: "memory");   // (in-order LDS: see ldl_signal)
           if (lane == 0) __hip_atomic_fetch_add(&f_tc[K], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           LDL_EV(0xF00 | (K << 4) | J);   // slot (K, J) written
           __builtin_amdgcn_s_setprio(0);
@@ -504,31 +665,51 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
     // =============================================================================== wave 0: the diagonal chain
     // Lanes 0..15 carry the chain (column j = lane); the other three DPP rows execute along on data that is never stored.
     double c[16];
-    const int j = lane & 15;
+    const int j = LDL_LANE() & 15;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       c[i] = S[(lo >> 2) * 64 + (lo & 3) * 16 + hi];   // block (0, 0) sits at offset 0
     }
+    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+    asm volatile("" : "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]));
     __syncthreads();
     __builtin_amdgcn_s_setprio(3);
     LDL_STAMP(1);
     bool bad = false;
     double mine = 0.0;
+    // The hand-overs of step kb — block (kb, kb+1) with all its updates (qbuf) and the diagonal block kb + 1 with the updates
+    // <= kb - 1 (dpart) — normally arrive while the block kb is being eliminated.  They are requested BEFORE the elimination,
+    // flags first (the LDS serves a wave's requests in order and the producers write data, wait, then flag: data requested behind
+    // a flag that reads as set is the data the flag announces), and looked at behind it: the poll, the acquire and the data round
+    // trip leave the chain.  Only when a flag was not set yet are they requested again, as before.
+    // (inline assembly: the compiler would wait for the loads right where they are issued, in front of the elimination)
+    int hq_f = 0, hp_f = 0;
+    double q0, q1, q2, q3, p0, p1, p2, p3;
+    auto request_handover = [&](int kb, int lane) {
+      const unsigned fqa = (unsigned)(size_t)&f_hq[kb & 1], fpa = (unsigned)(size_t)&f_hp[(kb + 1) & 1];
+      const unsigned qa = (unsigned)(size_t)(qbuf + (kb & 1) * 256 + lane), pa = (unsigned)(size_t)(dpart + ((kb + 1) & 1) * 256 + lane);
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(hq_f), "=&v"(hp_f) : "v"(fqa), "v"(fpa) : "memory");
+      asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1536"
+                   : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(qa) : "memory");
+      asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1536"
+                   : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(pa) : "memory");
+    };
+    auto complete_handover = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hq_f), "+v"(hp_f), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : : "memory");
+    };
     for (int kb = 0; kb < nb; ++kb) {
+      const int lane = LDL_LANE();
+      const int j = lane & 15;
       const int npiv = (kb == nb - 1) ? npl : 16;
       mine = 0.0;
-#if LDL_ELIM16
-      if (lane < 16) {   // (only DPP row 0 holds the block: the other three quarter-waves are masked off)
-        if (kb < nb - 1) ldl16_eliminate<true>(c, 16, mine, j);
-        else ldl16_eliminate<false>(c, npiv, mine, j);
-      }
-#else
-      if (kb < nb - 1) ldl16_eliminate<true>(c, 16, mine, j);
+      LDL_TSA(0);
+      LDL_TS(0);
+      LDL_TS(7);
+      if (kb < nb - 1) ldl16_eliminate<true>(c, 16, mine, j, nullptr, [&]() { request_handover(kb, lane); });
       else ldl16_eliminate<false>(c, npiv, mine, j);
-#endif
       bad = bad || (j < npiv && !(mine > 0.0 && mine < 1.0e300));   // a pivot was not positive
-      if (stamps && tid == 0 && kb < 12) stamps[16 + 4 * kb] = clock64();
+      LDL_TS(1);
       // publish Bh (column `lane` as it is: the consumers mask the dead entries above the diagonal) and 1/d
       if (lane < 16) {
         ldl_v4* xo = reinterpret_cast<ldl_v4*>(Xs + kb * LDL_XB + lane * LDL_RS);
@@ -542,93 +723,82 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
           for (int i = 0; i < 16; ++i) xv[kb * 16 + i] = c[i];
         }
       }
-#if LDL_W0_REORDER
       // this wave's own operand reads (L_kk^-1 in the A-operand layout) leave right behind the writes they read back — the LDS
-      // serves a wave's requests in order — so their latency hides under the release of the flag instead of following it
-      double a[4], dq[4], xh_[4];
-      if (kb + 1 < nb) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ak = (lane >> 4) + 4 * q;
-          dq[q] = -dinv[kb * 16 + ak];
-          xh_[q] = Xs[kb * LDL_XB + ak * LDL_RS + j];
-        }
-      }
-#endif
+      // serves a wave's requests in order — so their round trip runs under the release of the flag instead of behind it
+      double a[4], dq[4];
+      if (kb + 1 < nb) ldl_operand(Xs + kb * LDL_XB, dinv + kb * 16, lane, a, dq);
       ldl_signal(&f_xready, kb + 1, lane);
-      if (stamps && tid == 0 && kb < 12) stamps[17 + 4 * kb] = clock64();
+      LDL_TS(2);
       if (kb + 1 >= nb) break;
       // ---- R = L_kk^-1 A_(k,k+1) privately, then the last update of the next diagonal block
-#if LDL_W0_REORDER
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ak = (lane >> 4) + 4 * q;
-        a[q] = j > ak ? xh_[q] * -dq[q] : (j == ak ? 1.0 : 0.0);
-      }
-#else
-      double a[4], dq[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ak = (lane >> 4) + 4 * q;
-        dq[q] = -dinv[kb * 16 + ak];
-        const double xh = Xs[kb * LDL_XB + ak * LDL_RS + j];
-        a[q] = j > ak ? xh * -dq[q] : (j == ak ? 1.0 : 0.0);
-      }
-#endif
       LDL_EV(0x600 | kb);   // wave 0: X_kb published, waiting for Q_kb and P_(kb+1)
-      for (;;) {
-        const int fq = __hip_atomic_load(&f_hq[kb & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int fp = __hip_atomic_load(&f_hp[(kb + 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (fq >= kb + 1 && fp >= kb + 2) break;
+      complete_handover();
+      LDL_TSA(1);
+      while (!(__builtin_amdgcn_readfirstlane(hq_f) >= kb + 1 && __builtin_amdgcn_readfirstlane(hp_f) >= kb + 2)) {
         __builtin_amdgcn_s_sleep(1);
+        request_handover(kb, lane);
+        complete_handover();
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       LDL_EV(0x700 | kb);   // both there
-      ldl_v4 Q, R{0, 0, 0, 0}, P;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        Q[q] = qbuf[(kb & 1) * 256 + 64 * q + lane];
-        P[q] = dpart[((kb + 1) & 1) * 256 + 64 * q + lane];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], Q[q], R, 0, 0, 0);
+      LDL_TSA(2);
+      LDL_TS(3);
+      ldl_v4 R{0, 0, 0, 0}, P{p0, p1, p2, p3};
+      R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], q0, R, 0, 0, 0);
+      R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], q1, R, 0, 0, 0);
+      R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], q2, R, 0, 0, 0);
+      R = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], q3, R, 0, 0, 0);
+      LDL_TS(4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) P = __builtin_amdgcn_mfma_f64_16x16x4f64(R[q], R[q] * dq[q], P, 0, 0, 0);
-      if (stamps && tid == 0 && kb < 12) stamps[18 + 4 * kb] = clock64();
+      LDL_TS(5);
 #pragma unroll
       for (int r = 0; r < 4; ++r) Rsup[kb * LDL_XB + ((lane >> 4) + 4 * r) * LDL_RS + j] = R[r];   // for the back-substitution
-      // accumulator layout -> column per lane: P[r] of DPP row p is entry (p + 4 r, j); rows 1..3 travel to row 0 with
-      // v_permlane16_swap (odd rows of the first operand <-> even rows of the second) and v_permlane32_swap (upper half of
-      // the first <-> lower half of the second)
+      // accumulator layout -> column per lane through LDS: P[r] of DPP row p is entry (p + 4 r, j) = (j, p + 4 r) (the block is
+      // symmetric); column j lands contiguous at j * LDL_RS and lane j reads it back as eight 16-byte words (one round trip;
+      // the v_permlane16/32_swap network it replaces took 24 dependent cross-lane moves)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned lo = (unsigned)__double2loint(P[r]), hi = (unsigned)__double2hiint(P[r]);
-        const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [0] = rows (0,0,2,2), [1] = rows (1,1,3,3)
-        const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        const auto l2 = __builtin_amdgcn_permlane32_swap(l16[0], l16[0], false, false);   // [1] = rows (2,2,..)
-        const auto h2 = __builtin_amdgcn_permlane32_swap(h16[0], h16[0], false, false);
-        const auto l3 = __builtin_amdgcn_permlane32_swap(l16[1], l16[1], false, false);   // [1] = rows (3,3,..)
-        const auto h3 = __builtin_amdgcn_permlane32_swap(h16[1], h16[1], false, false);
-        c[4 * r] = P[r];
-        c[4 * r + 1] = __hiloint2double((int)h16[1], (int)l16[1]);
-        c[4 * r + 2] = __hiloint2double((int)h2[1], (int)l2[1]);
-        c[4 * r + 3] = __hiloint2double((int)h3[1], (int)l3[1]);
+      for (int r = 0; r < 4; ++r) Pt[j * LDL_RS + (lane >> 4) + 4 * r] = P[r];
+      if (lane < 16) {
+        typedef double ldl_v2 __attribute__((ext_vector_type(2)));
+        const ldl_v2* pi = reinterpret_cast<const ldl_v2*>(Pt + lane * LDL_RS);
+        ldl_v2 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = pi[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          c[2 * i] = t[i][0];
+          c[2 * i + 1] = t[i][1];
+        }
       }
-      if (stamps && tid == 0 && kb < 12) stamps[19 + 4 * kb] = clock64();
+      LDL_TS(6);
     }
     if (__any(bad && lane < 16) && lane == 0) *s_fail = 1;
     LDL_STAMP(2);
+#ifdef LDL_TS_STEP
+    if (stamps && tid == 0)
+      for (int i = 0; i < 8; ++i) stamps[16 + i] = ts_[i];
+#endif
+#ifdef LDL_TS_ALL
+    if (stamps && tid == 0)
+      for (int i = 0; i < 48; ++i) stamps[32 + i] = ts_all[i / 16][i % 16];
+#endif
     // ---- back-substitution, block by block from the last one.  Lane i holds entry i of the 16-vectors.
     //   t_K = -(slots of the block columns >= K+2, by the other waves) - R_(K,K+1) x_(K+1) ;  x_K = L_KK^-T D_K^-1 t_K = (D^-1 Bh D^-1)^T t_K
     double x = 0.0, tsum = 0.0;
     double rrow[16], xcol[16];   // row j of R_(K,K+1) and column j of XB[K]: fetched one step ahead (they are final long before)
     ldl_wait_ge(&f_xb[nb - 1], 1);
+    {
+      const int j = LDL_LANE() & 15;
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
-      xcol[n] = XB[(nb - 1) * LDL_XB + j * LDL_RS + n];
-      rrow[n] = 0.0;
+      for (int n = 0; n < 16; ++n) {
+        xcol[n] = XB[(nb - 1) * LDL_XB + j * LDL_RS + n];
+        rrow[n] = 0.0;
+      }
     }
+    int fxb_next = nb >= 2 ? __hip_atomic_load(&f_xb[nb - 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 1;   // (looked at one step ahead)
     for (int K = nb - 1; K >= 0; --K) {
+      const int lane = LDL_LANE();
+      const int j = lane & 15;
       // the chain: t_K = tsum_K - R_(K,K+1) x_(K+1), x_K = XB_K^T t_K, publish
       double t;
       if (K == nb - 1) {
@@ -644,6 +814,12 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
         t = s0 + s1;
       }
       LDL_EV(0xE00 | K);   // t_K complete
+      // (the operands of the next step are requested as soon as their registers are free: R_(K-1,K)'s rows here, under the second
+      // product — wave 0 wrote them itself during the factorisation — and XB[K-1] with the sum of the slots behind it)
+      if (K > 0) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) rrow[n] = Rsup[(K - 1) * LDL_XB + j * LDL_RS + n];
+      }
       double s0 = 0.0, s1 = 0.0;
       fmac_bcast_nop<0>(s0, t, xcol[0]);
       fmac_bcast<1>(s1, t, xcol[1]);
@@ -658,29 +834,27 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
       }
       ldl_signal(&f_x, nb - K, lane);
       if (K > 0) {
-        // off the chain: the operands of the next step; its slots (block columns >= K+1: none of them needs x_K) summed
-        // in the fixed order nb-1, nb-2, ...
-        ldl_wait_ge(&f_xb[K - 1], 1);
+        // what wave 4 has summed of the next step's slots (block columns >= K + 1: none of them needs x_K): the flag of the sum
+        // in front of the sum (a sum requested behind a flag that reads as set is the sum the flag announces)
+        if (fxb_next < 1) ldl_wait_ge(&f_xb[K - 1], 1);
+        int ts_f = 1;
+        double ts_v = 0.0;
+        const bool summed = K + 1 < nb;
+        const unsigned fa = (unsigned)(size_t)&f_ts[K - 1], va = (unsigned)(size_t)(tsv + (K - 1) * 16 + j);
+        if (summed) asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3" : "=&v"(ts_f), "=&v"(ts_v) : "v"(fa), "v"(va) : "memory");
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-          rrow[n] = Rsup[(K - 1) * LDL_XB + j * LDL_RS + n];
-          xcol[n] = XB[(K - 1) * LDL_XB + j * LDL_RS + n];
-        }
-        tsum = 0.0;
-        if (K + 1 < nb) {
+        for (int n = 0; n < 16; ++n) xcol[n] = XB[(K - 1) * LDL_XB + j * LDL_RS + n];
+        fxb_next = K >= 2 ? __hip_atomic_load(&f_xb[K - 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 1;
+        if (summed) {
           LDL_EV(0xC00 | (K - 1));
-          ldl_wait_ge(&f_tc[K - 1], nb - K - 1);
-          LDL_EV(0xD00 | (K - 1));
-          double tc[LDL_MAX_NB - 2];
-#pragma unroll
-          for (int u = 0; u < LDL_MAX_NB - 2; ++u) {
-            const int J = nb - 1 - u;
-            const int Jc = J >= K + 1 ? J : K + 1;   // (clamped: a load, not a branch; the copy is not added)
-            tc[u] = tcon[((K - 1) * nb + Jc) * 16 + j];
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ts_f), "+v"(ts_v) : : "memory");
+          while (__builtin_amdgcn_readfirstlane(ts_f) < 1) {
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ts_f), "=&v"(ts_v) : "v"(fa), "v"(va) : "memory");
           }
-#pragma unroll
-          for (int u = 0; u < LDL_MAX_NB - 2; ++u) tsum -= (nb - 1 - u >= K + 1) ? tc[u] : 0.0;
+          LDL_EV(0xD00 | (K - 1));
         }
+        tsum = ts_v;
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -694,6 +868,10 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
   }
 #endif
 #undef LDL_STAMP
+#undef LDL_LANE
+#undef LDL_TS
+#undef LDL_TSA
+#undef LDL_OTS
 #undef LDL_EV
 }
 

@@ -1441,7 +1441,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // (column D and the max_mu verdict were written in the damping phase, in front of the barrier every work-item has passed)
   if constexpr (!LARGE) {
     STAMP(10);
-    ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail, nullptr, D - Dp);
+    // (diagnostics: the solver's own stamps — load | factor | back-substitution, and with -DLDL_TS_ALL wave 0's steps — as 64-bit
+    // integers behind the phase stamps)
+    ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail, (W.prof && blockIdx.x == 0) ? reinterpret_cast<long long*>(W.prof + 64) : nullptr, D - Dp);
   }
   STAMP(7);
   if (s_fail) {  // not positive definite: invalid step (handled like a rejection)

@@ -21,3 +21,9 @@ print("  tail: step vector %.2f, trial states %.2f, sums + barrier %.2f, ctrl %.
 ids = [43, 40, 0, 41, 42, 3, 44, 4, 1, 2, 45, 46, 58, 5, 6, 10, 7, 8, 31, 32, 33, 9]
 base = min(p[k] for k in ids if p[k] > 0)
 print("  raw stamps (us after the earliest): " + "  ".join("%d:%.2f" % (k, (p[k] - base) / T) for k in ids if p[k] > 0))
+import numpy as np
+q = np.asarray(p[64:64 + 96]).view(np.int64)
+print("  LDL^T solver: load %.2f, factor %.2f, back-substitution %.2f us" % ((q[1] - q[0]) / T, (q[2] - q[1]) / T, (q[3] - q[2]) / T))
+if q[32] > 0 and q[33] > q[32]:
+    nbk = int(np.count_nonzero(q[32:48]))
+    print("  wave 0's steps (cycles; hand-overs requested again .. both there in brackets): " + " ".join("%d (%d)" % (q[33 + k] - q[32 + k], q[64 + k] - q[48 + k]) for k in range(nbk - 1)))

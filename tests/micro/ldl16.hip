@@ -209,12 +209,27 @@ int main(int argc, char** argv) {
       }
     printf("D=%4d nb=%2d  rel err %.2e  fail %d  | cycles: load %lld  factor %lld  backsub %lld  total %lld | %.2f us per solve (incl. LDS fill)\n",
            Dsigned, nb, err / nrm, fl[0], st[1] - st[0], st[2] - st[1], st[3] - st[2], st[3] - st[0], (ms - ms3) * 1000.0 / 20.0);
+#ifdef LDL_TS_ALL
     if (D == 150) {
-      for (int kb = 0; kb < nb; ++kb)
-        printf("   step %2d: eliminate %5lld  publish %5lld  wait+R+P (8 MFMA) %5lld  convert %5lld\n", kb,
-               st[16 + 4 * kb] - (kb ? st[19 + 4 * (kb - 1)] : st[1]), kb + 1 < nb ? st[17 + 4 * kb] - st[16 + 4 * kb] : 0LL,
-               kb + 1 < nb ? st[18 + 4 * kb] - st[17 + 4 * kb] : 0LL, kb + 1 < nb ? st[19 + 4 * kb] - st[18 + 4 * kb] : 0LL);
+      printf("   steps of wave 0 (cycles; waiting for the hand-overs in brackets):");
+      for (int kb = 0; kb + 1 < nb; ++kb) printf(" %lld (%lld)", st[32 + kb + 1] - st[32 + kb], st[32 + 32 + kb] - st[32 + 16 + kb]);
+      printf("\n");
     }
+#endif
+#ifdef LDL_OTS_WAVE
+    if (D == 150) {
+      printf("   wave %d in step %d (cycles after it saw X): operand %lld  dispatch %lld | panel: in %lld  product %lld  buffer free %lld  published %lld | Q: in %lld  flags %lld  product %lld  handed %lld | P: in %lld  flags %lld  product %lld  handed %lld\n",
+             LDL_OTS_WAVE, LDL_TS_STEP, st[81] - st[80], st[82] - st[80], st[83] - st[80], st[84] - st[80], st[85] - st[80], st[86] - st[80], st[87] - st[80], st[88] - st[80], st[89] - st[80],
+             st[90] - st[80], st[91] - st[80], st[92] - st[80], st[93] - st[80], st[94] - st[80]);
+      printf("      X published by wave 0 at %lld, seen at %lld (absolute)\n", st[16 + 2], st[80]);
+    }
+#endif
+#ifdef LDL_TS_STEP
+    if (LDL_TS_STEP + 1 < nb)
+      printf("   step %d of wave 0: request %lld  eliminate %lld  publish %lld  operands + hand-over %lld  R %lld  P %lld  transpose %lld | %lld\n", LDL_TS_STEP,
+             st[16 + 7] - st[16 + 0], st[16 + 1] - st[16 + 7], st[16 + 2] - st[16 + 1], st[16 + 3] - st[16 + 2], st[16 + 4] - st[16 + 3], st[16 + 5] - st[16 + 4],
+             st[16 + 6] - st[16 + 5], st[16 + 6] - st[16 + 0]);
+#endif
     if (D == 150 && argc > 2) {   // timeline of all waves, merged and sorted
       std::vector<std::pair<long long, int>> ev;
       for (int w = 0; w < 16; ++w)
