@@ -494,8 +494,13 @@ int okvis_ba_marginalize(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* sp
  * before the prior is read again).  _begin checks the arguments, copies what it needs of `spec`, enqueues everything and returns
  * with the blocks the new prior connects (result->dim, nblocks, block_type / block_idx / block_off: known without the numbers);
  * _end waits and fills H, b0, J, e0, rank, sweeps of a result with the same capacities (it may be the same struct).  Between
- * the two the solver accepts no upload and hands out no results (OKVIS_BA_ERR_STATE); sizes beyond the LDS route are waited for
- * in _begin (their fall-back needs the call's arguments).  A numeric failure is reported by _end (OKVIS_BA_ERR_NUMERIC). */
+ * the two the solver takes no edits and hands out no results: okvis_ba_upload, _patch_window, _set_state, _get_state,
+ * _set_marg_prior_values, _begin, _iterate, _finish (and with them _optimize / _optimize_timed / _evaluate_cost), _fetch_results,
+ * _fetch_imu_caches, _download and another _marginalize / _marginalize_begin all return OKVIS_BA_ERR_STATE; only the queries that
+ * touch neither the device nor the window (_reduced_dim, _pair_count, _get_limits, ...) and _synchronize are served.  Sizes beyond
+ * the LDS route are waited for in _begin (their fall-back needs the call's arguments).  _end looks at the result structure before
+ * it ends the call: with too little room (OKVIS_BA_ERR_ARG) nothing is lost and _end can be called again with more.  A numeric
+ * failure is reported by _end (OKVIS_BA_ERR_NUMERIC). */
 int okvis_ba_marginalize_begin(okvis_ba_solver* s, int w, const okvis_ba_marg_spec* spec, okvis_ba_marg_result* result);
 int okvis_ba_marginalize_end(okvis_ba_solver* s, okvis_ba_marg_result* result);
 

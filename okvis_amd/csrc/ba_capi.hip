@@ -1122,10 +1122,16 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (!caches.empty()) std::memset(caches.data(), 0, sizeof(ImuCacheD) * caches.size());
     if (w.imu_sb_ref && w.imu_sb_ref_valid) {
       for (int f = 0; f < w.n_imu; ++f) {
+        // (the rule of WindowStore::assign: a window a patchable solver refuses is refused here as well)
+        if (w.imu_sb_ref_valid[f] > 2 || (w.imu_sb_ref_valid[f] == 2 && !w.imu_cache)) return OKVIS_BA_ERR_ARG;
         if (w.imu_sb_ref_valid[f] == 2 && w.imu_cache) {
           // the preintegration itself (okvis_ba_fetch_imu_caches): valid as it stands, nothing is rebuilt on first use
           std::memcpy(&caches[f], w.imu_cache + (size_t)OKVIS_BA_IMU_CACHE_DOUBLES * f, sizeof(ImuCacheD));
           if (caches[f].valid != 1) return OKVIS_BA_ERR_ARG;   // (a record of a term that was never evaluated)
+          for (int k = 0; k < 225; ++k)
+            if (!std::isfinite(caches[f].sqrt_info[k])) return OKVIS_BA_ERR_ARG;
+          for (int k = 0; k < 4; ++k)
+            if (!std::isfinite(caches[f].Delta_q[k])) return OKVIS_BA_ERR_ARG;
           caches[f].redo_count = 0;
         } else if (w.imu_sb_ref_valid[f]) {
           caches[f].valid = 2;
@@ -2039,6 +2045,7 @@ int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options
 }
 
 int okvis_ba_set_state(okvis_ba_solver* s, int w, const double* pose, const double* sb, const double* lm) {
+  if (s && s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: between the two halves the solver takes no edits and hands out no results)
   if (!s || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return s && !s->uploaded ? OKVIS_BA_ERR_STATE : OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = refresh_acc(s, w)) return rc;
@@ -2053,6 +2060,7 @@ int okvis_ba_set_state(okvis_ba_solver* s, int w, const double* pose, const doub
 }
 
 int okvis_ba_get_state(okvis_ba_solver* s, int w, double* pose, double* sb, double* lm) {
+  if (s && s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: between the two halves the solver takes no edits and hands out no results)
   if (!s || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return s && !s->uploaded ? OKVIS_BA_ERR_STATE : OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = refresh_acc(s, w)) return rc;
@@ -2105,6 +2113,7 @@ static int refresh_mirrors(okvis_ba_solver* s) {
 }
 
 int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p) {
+  if (s && s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: between the two halves the solver takes no edits and hands out no results)
   if (!s || !p) return OKVIS_BA_ERR_ARG;
   if (!s->uploaded || !s->patchable || s->mirrors.size() != s->wins.size()) return OKVIS_BA_ERR_STATE;
   if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
@@ -2228,6 +2237,7 @@ int okvis_ba_patched_view(okvis_ba_solver* s, int w, okvis_ba_window* out) {
 
 int okvis_ba_fetch_results(okvis_ba_solver* s, int w, double* pose, double* sb, double* lm, double* lm_quality,
                            double* imu_sb_ref) {
+  if (s && s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: between the two halves the solver takes no edits and hands out no results)
   if (!s || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return s && !s->uploaded ? OKVIS_BA_ERR_STATE : OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
   HostWin& H = s->wins[w];
@@ -2248,6 +2258,7 @@ int okvis_ba_fetch_results(okvis_ba_solver* s, int w, double* pose, double* sb, 
 }
 
 int okvis_ba_fetch_imu_caches(okvis_ba_solver* s, int w, double* caches) {
+  if (s && s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: between the two halves the solver takes no edits and hands out no results)
   if (!s || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return s && !s->uploaded ? OKVIS_BA_ERR_STATE : OKVIS_BA_ERR_ARG;
   if (!caches) return OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
@@ -2260,6 +2271,7 @@ int okvis_ba_fetch_imu_caches(okvis_ba_solver* s, int w, double* caches) {
 }
 
 int okvis_ba_begin(okvis_ba_solver* s) {
+  if (s && s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: between the two halves the solver takes no edits and hands out no results)
   if (s) s->acc_fresh = s->res_staged = s->mirror_fresh = false;
   if (!s) return OKVIS_BA_ERR_ARG;
   if (!s->uploaded) return OKVIS_BA_ERR_STATE;
@@ -2282,6 +2294,7 @@ int okvis_ba_begin(okvis_ba_solver* s) {
 }
 
 int okvis_ba_iterate(okvis_ba_solver* s, int n) {
+  if (s && s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: between the two halves the solver takes no edits and hands out no results)
   if (s) s->acc_fresh = false;
   if (!s || n < 0) return OKVIS_BA_ERR_ARG;
   if (!s->begun) return OKVIS_BA_ERR_STATE;
@@ -2359,6 +2372,7 @@ int okvis_ba_last_iterate_ms(okvis_ba_solver* s, float* total_ms) {
 }
 
 int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
+  if (s && s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: between the two halves the solver takes no edits and hands out no results)
   if (!s) return OKVIS_BA_ERR_ARG;
   if (!s->begun) return OKVIS_BA_ERR_STATE;
   HIP_TRY(hipSetDevice(s->device));
@@ -2553,6 +2567,7 @@ int okvis_ba_array_size(okvis_ba_solver* s, int w, int which, int64_t* n_doubles
 }
 
 int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t n_doubles) {
+  if (s && s->marg_pending.active) return OKVIS_BA_ERR_STATE;   // (okvis_ba_marginalize_end first: between the two halves the solver takes no edits and hands out no results)
   if (!s || !out || !s->uploaded || w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
   const double* p = nullptr;
@@ -3032,6 +3047,9 @@ int okvis_ba_marginalize_end(okvis_ba_solver* s, okvis_ba_marg_result* res) {
   if (!s || !res) return OKVIS_BA_ERR_ARG;
   okvis_ba_solver::MargPending& mp = s->marg_pending;
   if (!mp.active) return OKVIS_BA_ERR_STATE;
+  // the result structure is looked at first: a call with too little room changes nothing and can be repeated with more
+  if (mp.na > res->capacity_dim || (int)mp.bt.size() > res->capacity_blocks) return OKVIS_BA_ERR_ARG;
+  if (mp.na > 0 && (!res->H || !res->b0 || !res->J || !res->e0 || !res->block_type || !res->block_idx || !res->block_off)) return OKVIS_BA_ERR_ARG;
   mp.active = false;   // (whatever happens below, the call is over)
   HIP_TRY(hipSetDevice(s->device));
   if (!mp.synced) HIP_TRY(hipStreamSynchronize(s->stream));

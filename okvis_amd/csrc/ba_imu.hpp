@@ -664,15 +664,26 @@ __device__ void imu_maybe_redo(const WinPtrs& W, int f, int trial, double* lds, 
   double sb0[9];
   for (int i = 0; i < 9; ++i) sb0[i] = b0[i];
   const double Dt = ns_to_sec(W.imu_t1[f] - W.imu_t0[f]);
-  const ImuCacheD* cg = W.imu_cache + f;
+  ImuCacheD* cg = W.imu_cache + f;
   if (tid == 0) {
     double db[3];
     for (int i = 0; i < 3; ++i) db[i] = sb0[3 + i] - cg->sb_ref[3 + i];
     const double nbg = sqrt(db[0] * db[0] + db[1] * db[1] + db[2] * db[2]);
-    s_redo = (!cg->valid) || (nbg * Dt > 0.0001);  // ImuError.cpp:549
+    // valid == 3: the record was built ahead of time at the bias of the uploaded window (imu_pre_kernel).  It stands for the
+    // preintegration of the first evaluation (redo_ = true, ImuError.cpp:62) only if that evaluation sees the very same bias;
+    // okvis_ba_set_state may have changed it since: then the term is integrated again, at the bias it is evaluated at, and the
+    // early integration does not count.
+    const int v = cg->valid;
+    bool pre_stale = false;
+    if (v == 3) {
+      for (int i = 0; i < 9; ++i) pre_stale = pre_stale || !(sb0[i] == cg->sb_ref[i]);
+      if (pre_stale) cg->redo_count = 0;
+      else cg->valid = 1;
+    }
+    s_redo = (!v) || pre_stale || (nbg * Dt > 0.0001);  // ImuError.cpp:549
     // a cache inherited from a previous optimize() call (only its reference bias travels): rebuild it at that
     // reference unless the bias moved past the threshold anyway
-    s_redo_ref = (!s_redo && cg->valid == 2) ? 1 : 0;
+    s_redo_ref = (!s_redo && v == 2) ? 1 : 0;
   }
   __syncthreads();
   if (s_redo_ref) {

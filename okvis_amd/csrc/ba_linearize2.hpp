@@ -621,8 +621,9 @@ __global__ void imu_pre_place_kernel(const WinPtrs* __restrict__ wins, const int
   const double* s = reinterpret_cast<const double*>(src + blockIdx.x);
   auto d = reinterpret_cast<BA_G double*>(wins[wf.x].imu_cache + wf.y);
   for (int i = threadIdx.x; i < (int)(sizeof(ImuCacheD) / 8) - 1; i += blockDim.x) d[i] = s[i];
-  if (threadIdx.x == 0) {   // (the last double holds the two counters: valid since its first preintegration, which was one)
-    wins[wf.x].imu_cache[wf.y].valid = 1;
+  if (threadIdx.x == 0) {   // (the last double holds the two counters: one preintegration so far, valid at the bias it was built at —
+                            // 3: imu_maybe_redo takes it for the first evaluation's only if that evaluation sees the same bias)
+    wins[wf.x].imu_cache[wf.y].valid = 3;
     wins[wf.x].imu_cache[wf.y].redo_count = 1;
   }
 }

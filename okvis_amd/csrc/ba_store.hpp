@@ -138,8 +138,8 @@ struct WindowStore {
       Imu& m = imu[f];
       m.pose0 = w.imu_pose0[f]; m.sb0 = w.imu_sb0[f]; m.pose1 = w.imu_pose1[f]; m.sb1 = w.imu_sb1[f];
       m.t0 = w.imu_t0[f]; m.t1 = w.imu_t1[f];
-      const int b = w.imu_s_begin[f], c = w.imu_s_count[f];
-      if (b < 0 || c < 0 || b + c > w.n_imu_samples) return OKVIS_BA_ERR_ARG;
+      const int64_t b = w.imu_s_begin[f], c = w.imu_s_count[f];   // (64-bit: b + c must not wrap)
+      if (b < 0 || c < 0 || b + c > (int64_t)w.n_imu_samples) return OKVIS_BA_ERR_ARG;
       put(m.s_t, w.imu_s_t + b, (size_t)c);
       put(m.s_gyr, w.imu_s_gyr + 3 * (size_t)b, 3 * (size_t)c);
       put(m.s_acc, w.imu_s_acc + 3 * (size_t)b, 3 * (size_t)c);

@@ -81,7 +81,8 @@ struct ImuCacheD {
   double sqrt_info[225];   // upper-triangular L^T
   double sb_ref[9];
   int valid;               // 0 until the first preintegration (redo_ = true initially); 2 = sb_ref was handed
-                           // over by the host (cache of a previous optimize call), integrals not computed yet
+                           // over by the host (cache of a previous optimize call), integrals not computed yet;
+                           // 3 = integrated ahead of the first evaluation at the uploaded bias (imu_pre_place_kernel)
   int redo_count;
 };
 

@@ -1340,6 +1340,11 @@ struct Estimator::MargUndo {
   std::vector<Op> ops;
   std::vector<Observation> removedObs;
   size_t removedSize = 0;
+  // the prior as it stood before the call replaced it (with its numbers: whatever throws behind the replacement — an allocation in
+  // the compactions, say — must not leave a prior with blocks but without J / e0, which every later optimize() would be refused)
+  bool priorSaved = false;
+  MargPrior prior;
+  uint32_t familiesChanged = 0;
 };
 
 bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, MapPointVector& removedLandmarks) {
@@ -1358,6 +1363,10 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
       (void)okvis_ba_marginalize_end(margSolver_, &margRes_);
     }
     std::lock_guard<std::mutex> l(statesMutex_);
+    if (undo.priorSaved) {   // the old prior, numbers included, is the window's prior again
+      prior_ = std::move(undo.prior);
+      familiesChanged_ = undo.familiesChanged | OKVIS_BA_PATCH_MARG_PRIOR;   // (the solver may have seen the replacement's blocks)
+    }
     if (logsRestorable) {
       obsRemoved_.resize(nRemovedLog);
       erasedWinLm_.resize(nErasedLog);
@@ -1744,6 +1753,9 @@ bool Estimator::applyMarginalizationStrategyImpl(size_t numKeyframes, size_t num
       np.e0.assign(en.begin(), en.begin() + n);
     }
     if (np.dim == 0) np = MargPrior();  // "if(marginalizationErrorPtr_->num_residuals()==0) reset" (:747-749)
+    undo.prior = std::move(prior_);
+    undo.familiesChanged = familiesChanged_;
+    undo.priorSaved = true;
     prior_ = np;
     familiesChanged_ |= OKVIS_BA_PATCH_MARG_PRIOR;
   }

@@ -148,6 +148,7 @@ class Estimator {
   bool getCameraSensorStates(uint64_t poseId, size_t cameraIdx, Transformation& T_SCi) const;
   size_t numFrames() const { return states_.size(); }
   size_t numLandmarks() const { return landmarksMap_.size(); }
+  size_t debugObservationSlots() const { return observations_.slots(); }   // entries of memory the observation table holds (tests)
   uint64_t currentKeyframeId() const;
   uint64_t frameIdByAge(size_t age) const;
   uint64_t currentFrameId() const;
@@ -397,9 +398,15 @@ class Estimator {
   class ObsTable {
    public:
     Observation* find(uint64_t h) {
-      if (h < base_ || h - base_ >= slots_.size()) return nullptr;
-      Observation& o = slots_[h - base_];
-      return o.handle == h ? &o : nullptr;
+      if (h >= base_ && h - base_ < slots_.size()) {
+        Observation& o = slots_[h - base_];
+        return o.handle == h ? &o : nullptr;
+      }
+      if (!aged_.empty() && h < base_) {
+        auto it = aged_.find(h);
+        return it == aged_.end() ? nullptr : &it->second;
+      }
+      return nullptr;
     }
     const Observation* find(uint64_t h) const { return const_cast<ObsTable*>(this)->find(h); }
     const Observation& at(uint64_t h) const {
@@ -408,6 +415,11 @@ class Estimator {
       return *o;
     }
     void insert(const Observation& o) {   // (a handle below the range comes back in a roll-back: the range grows downwards)
+      if (o.handle < base_ && (!aged_.empty() || (!slots_.empty() && base_ - o.handle > kAgedGap))) {
+        if (aged_.emplace(o.handle, o).second) ++live_;   // (far below the dense range, or the range has shed old entries: the side map)
+        else aged_[o.handle] = o;
+        return;
+      }
       if (slots_.empty()) base_ = o.handle;
       while (o.handle < base_) {
         slots_.push_front(Observation{});
@@ -415,26 +427,61 @@ class Estimator {
       }
       while (o.handle - base_ >= slots_.size()) slots_.push_back(Observation{});
       Observation& slot = slots_[o.handle - base_];
-      if (slot.handle != o.handle) ++live_;
+      if (slot.handle != o.handle) {
+        ++live_;
+        ++dense_live_;
+      }
       slot = o;
     }
     bool erase(uint64_t h) {
-      Observation* o = find(h);
-      if (!o) return false;
-      o->handle = 0;   // (handles start at 1)
-      --live_;
+      if (h >= base_ && h - base_ < slots_.size()) {
+        Observation& o = slots_[h - base_];
+        if (o.handle != h) return false;
+        o.handle = 0;   // (handles start at 1)
+        --live_;
+        --dense_live_;
+        while (!slots_.empty() && slots_.front().handle == 0) {
+          slots_.pop_front();
+          ++base_;
+        }
+        shed();
+        return true;
+      }
+      if (!aged_.empty() && aged_.erase(h)) {
+        --live_;
+        return true;
+      }
+      return false;
+    }
+    size_t size() const { return live_; }
+    size_t slots() const { return slots_.size() + aged_.size(); }   // memory held, in entries (tests)
+
+   private:
+    // Handles grow with time and the dead slots are only dropped at the front: a few long-lived observations (a camera standing
+    // still keeps its old keyframes, and their observations, while those of every passing frame come and go) would pin an ever
+    // longer range of dead slots.  When the live entries are few in a long range, the oldest part of the range is dropped and
+    // its live entries move to a side map — the range stays within a constant factor of what is alive.
+    static constexpr size_t kShedMin = 4096, kAgedGap = 1u << 20;
+    void shed() {
+      if (slots_.size() < kShedMin || dense_live_ * 8 >= slots_.size()) return;
+      while (slots_.size() > kShedMin / 4 && dense_live_ * 2 < slots_.size()) {
+        Observation& f = slots_.front();
+        if (f.handle != 0) {
+          aged_.emplace(f.handle, f);
+          --dense_live_;
+        }
+        slots_.pop_front();
+        ++base_;
+      }
       while (!slots_.empty() && slots_.front().handle == 0) {
         slots_.pop_front();
         ++base_;
       }
-      return true;
     }
-    size_t size() const { return live_; }
-
-   private:
     std::deque<Observation> slots_;
+    std::unordered_map<uint64_t, Observation> aged_;
     uint64_t base_ = 1;
-    size_t live_ = 0;
+    size_t live_ = 0, dense_live_ = 0;
   };
   ObsTable observations_;
   std::vector<ImuFactor> imuFactors_;

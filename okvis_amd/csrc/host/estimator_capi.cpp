@@ -291,6 +291,7 @@ int okvis_est_debug_check_window(void* h) {
 }
 int okvis_est_num_frames(void* h) { return (int)static_cast<Estimator*>(h)->numFrames(); }
 int okvis_est_num_landmarks(void* h) { return (int)static_cast<Estimator*>(h)->numLandmarks(); }
+long long okvis_est_debug_obs_slots(void* h) { return (long long)static_cast<Estimator*>(h)->debugObservationSlots(); }
 int okvis_est_current_frame_id(void* h, uint64_t* id) {
   return guarded([&] {
     *id = static_cast<Estimator*>(h)->currentFrameId();

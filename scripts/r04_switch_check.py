@@ -22,6 +22,12 @@ def run(out):
         if mode == "gn":
             o.gauss_newton = 1
         b = solver.WindowBatch(wins, device=0, options=o)
+        if os.environ.get("CHECK_SET_STATE"):   # the biases change between the upload and the first evaluation
+            for w in range(n):
+                sb = b.get_state(w)[1].copy()
+                sb[:, 3:6] += 2.0e-3 * (1 + w % 3)
+                sb[:, 6:9] -= 1.0e-2
+                b.set_state(w, sb=sb)
         sm = b.optimize(12)
         st = [b.get_state(w) for w in range(n)]
         res[mode + "_cost"] = np.array([x["final_cost"] for x in sm])
@@ -30,6 +36,8 @@ def run(out):
         res[mode + "_pose"] = np.concatenate([x[0].reshape(-1) for x in st])
         res[mode + "_sb"] = np.concatenate([x[1].reshape(-1) for x in st])
         res[mode + "_lm"] = np.concatenate([x[2].reshape(-1) for x in st])
+        if os.environ.get("CHECK_SET_STATE"):
+            res[mode + "_redo"] = np.concatenate([np.asarray(b.array("IMU_REDO_COUNT", w)).reshape(-1) for w in range(n)])
         res[mode + "_timeouts"] = np.array([b.helper_timeouts() if hasattr(b, "helper_timeouts") else -1])
         b.close()
     np.savez(out, **res)

@@ -180,3 +180,44 @@ def test_per_frame_extrinsics_and_their_terms(folder):
     _frame_loop(np.random.default_rng(0), est, rec, 20, lambda *a: None)
     assert est.patched[0] is False and all(est.patched[1:])
     est.close()
+
+
+def test_observation_table_stays_bounded_under_a_long_lived_observation():
+    """A camera standing still: the old keyframes (and their observations) stay while the observations of every passing frame
+    come and go.  The handle-indexed table drops dead slots only at its front; it must not grow with the number of observations
+    ever made (~72 bytes per dead slot, 300 KB/s at 10 Hz stereo)."""
+    from okvis_amd import synthetic
+    from okvis_amd.window import DIST_EQUIDISTANT, ImuParams
+    prm = ImuParams(sigma_g_c=6.0e-4, sigma_a_c=2.0e-3, sigma_gw_c=3.0e-6, sigma_aw_c=2.0e-5, g=9.81, g_max=1000.0, a_max=1000.0)
+    est = _Dry()
+    est.addCamera(0, 0, 0, 0)
+    est.addImu(E.imu_param_vector(prm))
+    T_SC = np.array([[0, 0, 0, 0, 0, 0, 1.0]])
+    intr = np.stack([synthetic.TEST_INTR_EQUI])
+    t = (np.arange(120) * 10_000_000).astype(np.int64) + 1_000_000_000
+    gyr = np.zeros((120, 3)); acc = np.tile([0, 0, 9.81], (120, 1))
+    frames = []
+    for k in range(2):
+        f = E.Frame(1_000_000 + k, 1_000_000_000 + k * 500_000_000, T_SC, intr, [DIST_EQUIDISTANT])
+        for i in range(8):
+            f.add_keypoint(0, 100.0 + 10 * i, 120.0, 8.0)
+        frames.append(f)
+        lo, hi = (0, 4) if k == 0 else (0, 56)
+        assert est.addStates(f, t[lo:hi], gyr[lo:hi], acc[lo:hi], True), est.last_error()
+    assert est.addLandmark(7_000_001, [3.0, 0.0, 0.0, 1.0]) and est.addLandmark(7_000_002, [3.0, 0.5, 0.0, 1.0])
+    first = est.addObservation(7_000_001, frames[0].id, 0, 0)      # stays for good
+    assert first
+    api = est._api
+    api.okvis_est_debug_obs_slots.restype = __import__("ctypes").c_longlong
+    api.okvis_est_debug_obs_slots.argtypes = [__import__("ctypes").c_void_p]
+    n = 40_000
+    for i in range(n):
+        h = est.addObservation(7_000_002, frames[1].id, 0, 1 + i % 7)
+        assert h > first
+        assert est.removeObservation(7_000_002, frames[1].id, 0, 1 + i % 7)
+    slots = api.okvis_est_debug_obs_slots(est._h)
+    assert slots < 5000, slots                                    # not ~n
+    # the old observation is still there and can be removed; a new one still lands
+    h = est.addObservation(7_000_002, frames[1].id, 0, 3)
+    assert h and est.removeObservation(7_000_001, frames[0].id, 0, 0) and est.removeObservation(7_000_002, frames[1].id, 0, 3)
+    assert api.okvis_est_debug_obs_slots(est._h) < 5000

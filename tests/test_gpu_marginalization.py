@@ -361,9 +361,24 @@ def test_marginalize_in_two_halves():
             pose = np.zeros((w.n_pose, 7))
             seen["fetch"] = L.okvis_ba_fetch_results(h, 0, pose.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, None)
             seen["begin_again"] = L.okvis_ba_marginalize_begin(h, 0, sp, rs)
+            # every call that edits the window or hands out results is refused the same way
+            dp = C.POINTER(C.c_double)
+            seen["get_state"] = L.okvis_ba_get_state(h, 0, pose.ctypes.data_as(dp), None, None)
+            seen["set_state"] = L.okvis_ba_set_state(h, 0, pose.ctypes.data_as(dp), None, None)
+            seen["begin"] = L.okvis_ba_begin(h)
+            seen["iterate"] = L.okvis_ba_iterate(h, 1)
+            one_d = np.zeros(1)
+            seen["download"] = L.okvis_ba_download(h, 0, 12, one_d.ctypes.data_as(dp), 1)
+            # an _end with too little room changes nothing: it can be repeated with the full structure
+            cap_dim, cap_blocks = rs._obj.capacity_dim, rs._obj.capacity_blocks
+            rs._obj.capacity_dim = 1
+            seen["end_small"] = L.okvis_ba_marginalize_end(h, rs)
+            rs._obj.capacity_dim, rs._obj.capacity_blocks = cap_dim, cap_blocks
             return L.okvis_ba_marginalize_end(h, rs)
         st, two = marg_call(halves, w.n_pose, w.n_sb, pm, sm, None)
         assert st == 0 and seen["upload"] == -2 and seen["fetch"] == -2 and seen["begin_again"] == -2     # OKVIS_BA_ERR_STATE
+        assert all(seen[k] == -2 for k in ("get_state", "set_state", "begin", "iterate", "download")), seen
+        assert seen["end_small"] == -1, seen                                                              # OKVIS_BA_ERR_ARG, then the retry worked
         for k in ("dim", "rank", "block_type", "block_idx", "block_off", "H", "b0", "J", "e0"):
             assert np.array_equal(np.asarray(one[k]), np.asarray(two[k])), k
         st, _ = marg_call(lambda sp, rs: L.okvis_ba_marginalize_end(h, rs), w.n_pose, w.n_sb, pm, sm, None)

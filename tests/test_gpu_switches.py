@@ -30,3 +30,17 @@ def test_first_preintegration_started_at_upload_changes_nothing(tmp_path, window
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
     assert a["dogleg_iter"].min() > 0
+
+
+@pytest.mark.parametrize("windows,frames", [(1, 6), (3, 4)])
+def test_bias_set_between_upload_and_first_evaluation(tmp_path, windows, frames):
+    """okvis_ba_set_state(sb) between okvis_ba_upload and the first evaluation: the preintegration started at upload was built
+    at the uploaded bias and must not stand for the one of the first evaluation (redo_ = true, ImuError.cpp:62, integrates at the
+    bias it is evaluated at).  Every state, every summary and every count of preintegrations equals the run that leaves the
+    first preintegration to the first linearise launch, bit for bit."""
+    a = _run(tmp_path, "pre_set", CHECK_WINDOWS=windows, CHECK_K=frames, CHECK_SET_STATE=1)
+    b = _run(tmp_path, "nopre_set", CHECK_WINDOWS=windows, CHECK_K=frames, CHECK_SET_STATE=1, OKVIS_BA_NO_PRE=1)
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["dogleg_iter"].min() > 0 and a["dogleg_redo"].min() >= 1
