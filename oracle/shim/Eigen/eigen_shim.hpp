@@ -783,6 +783,14 @@ class Matrix : public MatrixBase<Matrix<S, R, C, O, MR, MC>> {
   operator S() const {
     return st_.data()[0];
   }
+  // ... and to an integral type in one step, as Eigen's (non-template) conversion followed by a standard conversion does
+  // (a conversion function TEMPLATE must hit the target type exactly; VioKeyframeWindowMatchingAlgorithm.cpp:332:
+  // `const int chi2 = err.transpose() * U.inverse() * err;`)
+  template <class T, int RR = R, int CC = C,
+            class = typename std::enable_if<RR == 1 && CC == 1 && std::is_integral<T>::value && !std::is_same<T, S>::value>::type>
+  operator T() const {
+    return (T)st_.data()[0];
+  }
 
  private:
   internal::Storage<S, R, C> st_;

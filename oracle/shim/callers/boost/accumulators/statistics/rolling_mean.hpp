@@ -1,0 +1,2 @@
+#pragma once
+#include <boost/accumulators/accumulators.hpp>
