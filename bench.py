@@ -52,14 +52,15 @@ def parse():
     p.add_argument("--no-extras", action="store_true", help="skip the dogleg / configs[2] / strong-scaling sub-records")
     p.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE/WRITE_SIZE passes (roofline.traffic = null)")
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("--pmc-separate", action="store_true", help=argparse.SUPPRESS)   # (child: the kernels of a sub-batch of a larger upload — not fused)
     return p.parse_args()
 
 
 KERNEL_SYMBOL = {"schur": "schur_", "solve": "solve_kernel", "linearize": "linearize"}   # (schur_kernel | schur_mfma_kernel, linearize_kernel | linearize2_kernel)
 
 
-def pmc_traffic(a, kernel):
-    """HBM bytes per launch of `kernel` from the TCC counters, collected the way MI355X_MICROARCH.md
+def pmc_traffic(a, kernel, windows=None, separate=False):
+    """HBM bytes per launch of `kernel` (launches of `windows` windows; default: all of the GPU's) from the TCC counters, collected the way MI355X_MICROARCH.md
     prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (they do not fit one pass) over
     an eager re-run of the same workload in a child process; FETCH_SIZE (KB) is doubled (gfx950 tallies
     128-B requests at 64 B), WRITE_SIZE (KB) is taken as reported (uncalibrated).  Returns None when
@@ -76,9 +77,9 @@ def pmc_traffic(a, kernel):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="okvis_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-               sys.executable, os.path.abspath(__file__), "--pmc-child", "--windows", str(a.windows),
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--windows", str(windows or a.windows),
                "--keyframes", str(a.keyframes), "--landmarks", str(a.landmarks), "--visibility", str(a.visibility),
-               "--steps", "12", "--warmup", "4", "--no-graph"] + (["--fp32"] if a.fp32 else [])
+               "--steps", "12", "--warmup", "4", "--no-graph"] + (["--fp32"] if a.fp32 else []) + (["--pmc-separate"] if separate else [])
         try:
             subprocess.run(cmd, timeout=120, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
@@ -127,6 +128,8 @@ def main():
     opt.n_streams = a.streams
     opt.fp32_linearize = 1 if a.fp32 else 0
     opt.gauss_newton = 1  # every timed iteration does identical full work (no trust-region collapse at the optimum)
+    if a.pmc_separate:
+        opt.reserved0 = opt.reserved0 | 4
     batch = solver.WindowBatch(wins, device=local_rank, options=opt)
 
     def barrier():
@@ -219,7 +222,9 @@ def main():
         dom = max(loop_tab, key=lambda k: loop_tab[k]["launch_us"])
         # (b) all windows of the GPU in one launch (the launch that fills the device: the linearise kernel)
         full_tab, redo = kernel_table(batch, a.windows)
-        pmc = None if (a.no_pmc or world > 1) else pmc_traffic(a, dom)
+        # HBM traffic of the dominant kernel at the SAME launch shape as its algorithmic bytes (a sub-batch of the timed loop),
+        # and of the device-filling kernel at its own (all windows in one launch)
+        pmc = None if (a.no_pmc or world > 1) else pmc_traffic(a, dom, windows=sub, separate=a.windows > 48)
         pmc_lin = None if (a.no_pmc or world > 1 or dom == "linearize") else pmc_traffic(a, "linearize")
         d = loop_tab[dom]
         roofline = {
@@ -229,7 +234,8 @@ def main():
             "bound": "latency", "kernel": dom, "launch_shape": {"streams": nst, "windows_per_launch": sub},
             "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["hbm_frac"],
             "traffic": None if pmc is None else pmc["bytes"], "traffic_detail": pmc,
-            "traffic_note": "PMC pass runs all windows in one launch (eager): bytes per launch of that shape" if pmc else None,
+            "traffic_note": f"PMC passes over eager launches of {sub} windows: the launch shape of algorithmic_bytes_per_launch" if pmc else None,
+            "traffic_over_algorithmic": None if pmc is None else pmc["bytes"] / d["algorithmic_bytes"],
             "avg_launch_us": d["launch_us"], "algorithmic_bytes_per_launch": d["algorithmic_bytes"],
             "fp64": {"kernel": dom, "flops_per_launch": d["flops"], "achieved_tflops": d["achieved_tflops"],
                      "peak_tflops": FP64_PEAK_TFLOPS, "frac": d["fp64_frac"]},
@@ -248,6 +254,39 @@ def main():
                     "blocked LDL^T on the fp64 matrix core with a one-wave diagonal chain, back-substitution, trial states); the "
                     "linearise launch is the one that fills all CUs (device_filling_kernel).  Algorithmic bytes / flops per "
                     "SURVEY.md section 8d; W / V / b round trips between launches are served by L2 / Infinity Cache"}
+    if roofline is not None:
+        # the WHOLE step against the roofs (algorithmic bytes and flops of one iteration of one window x the
+        # windows, over the measured time of a step) — the number that describes the headline, next to its longest link above
+        def step_record(nw, ms_per_step, nbytes, fl):
+            B, F = float(sum(nbytes.values())), float(sum(fl.values()))
+            return {"windows": nw, "ms_per_step": ms_per_step, "algorithmic_bytes_per_step": B, "flops_per_step": F,
+                    "bytes_per_window_iteration": B / nw, "flops_per_window_iteration": F / nw,
+                    "achieved_GBps": B / (ms_per_step * 1e-3) / 1e9, "hbm_frac": B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "achieved_tflops": F / (ms_per_step * 1e-3) / 1e12, "fp64_frac": F / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        nb_all = batch.algorithmic_bytes()
+        roofline["step"] = step_record(a.windows, wall * 1e3 / a.steps, nb_all, flops_per_launch(a.windows))
+        roofline["step"]["bound"] = "latency"
+        roofline["step"]["chain"] = ("one iteration of a sub-batch = " + ("4" if sub >= 40 else "3") +
+                                     " dependent launches on its stream (Schur, solve, linearise" + (", IMU / prior factors" if sub >= 40 else "") +
+                                     f"), {nst} sub-batches side by side; the solve launch occupies {sub} of 256 CUs")
+        if not a.no_extras and world == 1:
+            # the saturated shape: 256 windows per GPU (4 x the headline's batch), same windows repeated with fresh seeds
+            nsat = 256
+            wsat = wins + [synthetic.make_window(a.keyframes, a.landmarks, a.visibility, 20250000 + i) for i in range(nsat - len(wins))]
+            bsat = solver.WindowBatch(wsat[:nsat], device=local_rank, options=opt)
+            bsat.begin()
+            bsat.iterate(a.warmup)
+            bsat.iterate(a.steps)
+            bsat.synchronize()
+            bsat.iterate(a.steps)
+            ms_sat = bsat.last_iterate_ms() / a.steps
+            nb_sat = bsat.algorithmic_bytes()
+            bsat.finish()
+            bsat.close()
+            obs_s, lm_s = sum(w.n_obs for w in wsat[:nsat]), sum(w.n_lm for w in wsat[:nsat])
+            fl_sat = {"linearize": 1.5e3 * obs_s, "schur": 3.0 * (6.0 * a.keyframes) ** 2 * lm_s, "solve": nsat * (D_red ** 3 / 3.0 + 2.0 * D_red ** 2)}
+            roofline["step_saturated"] = step_record(nsat, ms_sat, nb_sat, fl_sat)
+            roofline["step_saturated"]["iterations_per_s"] = nsat / (ms_sat * 1e-3)
     summaries = batch.finish()
     n_rec = (a.total_windows + world - 1) // world if a.total_windows > 0 else a.windows
     rec = []
