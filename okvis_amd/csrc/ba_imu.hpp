@@ -656,84 +656,97 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
 }
 #undef RSTAMP
 
-// bias check of ImuError::EvaluateWithMinimalJacobians (ImuError.cpp:541-558): re-preintegrate on first use
-// or when |b_g - b_g,ref| * dt > 1e-4 (rarely taken).
-__device__ void imu_maybe_redo(const WinPtrs& W, int f, int trial, double* lds, int tid) {
-  __shared__ int s_redo, s_redo_ref;
-  const double* b0 = W.sb[trial] + 9 * (size_t)W.imu_sb0[f];
-  double sb0[9];
-  for (int i = 0; i < 9; ++i) sb0[i] = b0[i];
-  const double Dt = ns_to_sec(W.imu_t1[f] - W.imu_t0[f]);
-  ImuCacheD* cg = W.imu_cache + f;
-  if (tid == 0) {
-    double db[3];
-    for (int i = 0; i < 3; ++i) db[i] = sb0[3 + i] - cg->sb_ref[3 + i];
-    const double nbg = sqrt(db[0] * db[0] + db[1] * db[1] + db[2] * db[2]);
-    // valid == 3: the record was built ahead of time at the bias of the uploaded window (imu_pre_kernel).  It stands for the
-    // preintegration of the first evaluation (redo_ = true, ImuError.cpp:62) only if that evaluation sees the very same bias;
-    // okvis_ba_set_state may have changed it since: then the term is integrated again, at the bias it is evaluated at, and the
-    // early integration does not count.
-    const int v = cg->valid;
-    bool pre_stale = false;
-    if (v == 3) {
-      for (int i = 0; i < 9; ++i) pre_stale = pre_stale || !(sb0[i] == cg->sb_ref[i]);
-      if (pre_stale) cg->redo_count = 0;
-      else cg->valid = 1;
-    }
-    s_redo = (!v) || pre_stale || (nbg * Dt > 0.0001);  // ImuError.cpp:549
-    // a cache inherited from a previous optimize() call (only its reference bias travels): rebuild it at that
-    // reference unless the bias moved past the threshold anyway
-    s_redo_ref = (!s_redo && v == 2) ? 1 : 0;
-  }
-  __syncthreads();
-  if (s_redo_ref) {
-    double sbr[9];
-    for (int i = 0; i < 9; ++i) sbr[i] = cg->sb_ref[i];
-    imu_redo(W, f, sbr, lds, tid);
-  } else if (s_redo) {
-    imu_redo(W, f, sb0, lds, tid);
-  }
-}
-
 __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int tid) {
   __shared__ double s_db[6];
+  // the trial states p0[7] | p1[7] | b0[9] | b1[9] and the cache's reference bias [9]
+  __shared__ double s_st[32 + 9];
+  __shared__ int s_valid;
   if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[62] = (double)clock64();   // diagnostics: length of one IMU workgroup
-  imu_maybe_redo(W, f, trial, lds, tid);  // rarely taken; updates the HBM cache in place
-  __syncthreads();
-  if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[36] = (double)clock64();
   double* ca = lds + EvalLds::CA;
   const double* p0 = W.pose[trial] + 7 * (size_t)W.imu_pose0[f];
   const double* p1 = W.pose[trial] + 7 * (size_t)W.imu_pose1[f];
   const double* b0 = W.sb[trial] + 9 * (size_t)W.imu_sb0[f];
   const double* b1 = W.sb[trial] + 9 * (size_t)W.imu_sb1[f];
-  double sb0[9];
-  for (int i = 0; i < 9; ++i) sb0[i] = b0[i];
   const double Dt = ns_to_sec(W.imu_t1[f] - W.imu_t0[f]);
-  const ImuCacheD* cg = W.imu_cache + f;
+  ImuCacheD* cg = W.imu_cache + f;
+  // Everything the factor reads from HBM — the preintegration record, the four state blocks, the record's reference bias and its
+  // state word — is requested in one go, every work-item its share, and waits at ONE barrier.  (Before: work-item 0 fetched the
+  // bias and the reference for the bias check, barrier, then the record came in, barrier, then work-item 0 fetched the poses
+  // inside its serial part: three dependent round trips to memory in every IMU workgroup.)
+  auto stage = [&]() {
+    if (tid < 4) ca[CA_DQ + tid] = cg->Delta_q[tid];
+    if (tid < 9) {
+      ca[CA_CI + tid] = cg->C_integral[tid];
+      ca[CA_CD + tid] = cg->C_doubleintegral[tid];
+      ca[CA_DA + tid] = cg->dalpha_db_g[tid];
+      ca[CA_DV + tid] = cg->dv_db_g[tid];
+      ca[CA_DP + tid] = cg->dp_db_g[tid];
+    }
+    if (tid < 3) {
+      ca[CA_AI + tid] = cg->acc_integral[tid];
+      ca[CA_AD + tid] = cg->acc_doubleintegral[tid];
+    }
+    if (tid < 225) ca[CA_SI + tid] = cg->sqrt_info[tid];
+    const int u = tid - 192;   // (the last wave has the fewest of the loads above)
+    if (u >= 0 && u < 7) s_st[u] = p0[u];
+    else if (u >= 7 && u < 14) s_st[u] = p1[u - 7];
+    else if (u >= 14 && u < 23) s_st[u] = b0[u - 14];
+    else if (u >= 23 && u < 32) s_st[u] = b1[u - 23];
+    else if (u >= 32 && u < 41) s_st[u] = cg->sb_ref[u - 32];
+    else if (u == 41) s_valid = cg->valid;
+  };
+  stage();
+  __syncthreads();
+  // ---- bias check of ImuError::EvaluateWithMinimalJacobians (ImuError.cpp:541-558), by every work-item from the staged values
+  // (a uniform verdict, no second barrier): re-preintegrate on first use or when |b_g - b_g,ref| * dt > 1e-4 (rarely taken)
+  {
+    const int v = s_valid;
+    double db[3];
+    for (int i = 0; i < 3; ++i) db[i] = s_st[14 + 3 + i] - s_st[32 + 3 + i];
+    const double nbg = sqrt(db[0] * db[0] + db[1] * db[1] + db[2] * db[2]);
+    // valid == 3: the record was built ahead of time at the bias of the uploaded window (imu_pre_kernel).  It stands for the
+    // preintegration of the first evaluation (redo_ = true, ImuError.cpp:62) only if that evaluation sees the very same bias;
+    // okvis_ba_set_state may have changed it since: then the term is integrated again, at the bias it is evaluated at, and the
+    // early integration does not count.
+    bool pre_stale = false;
+    if (v == 3) {
+      for (int i = 0; i < 9; ++i) pre_stale = pre_stale || !(s_st[14 + i] == s_st[32 + i]);
+      if (tid == 0) {
+        if (pre_stale) cg->redo_count = 0;
+        else cg->valid = 1;
+      }
+    }
+    const bool redo = (!v) || pre_stale || (nbg * Dt > 0.0001);  // ImuError.cpp:549
+    // a cache inherited from a previous optimize() call (only its reference bias travels): rebuild it at that
+    // reference unless the bias moved past the threshold anyway
+    const bool redo_ref = !redo && v == 2;
+    if (redo || redo_ref) {
+      double sbx[9];
+      for (int i = 0; i < 9; ++i) sbx[i] = redo_ref ? s_st[32 + i] : s_st[14 + i];
+      __syncthreads();   // (every work-item has read what it needs of the staged values: the re-preintegration reuses the LDS)
+      imu_redo(W, f, sbx, lds, tid);   // updates the HBM cache in place; ends with a barrier
+      stage();
+      __syncthreads();
+    }
+  }
+  if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[36] = (double)clock64();
   // the cache is valid now and, if it was just redone, its reference equals sb0 so that Delta_b is
   // exactly zero (ImuError.cpp:553)
-  if (tid < 6) s_db[tid] = sb0[3 + tid] - cg->sb_ref[3 + tid];
-  if (tid < 4) ca[CA_DQ + tid] = cg->Delta_q[tid];
-  if (tid < 9) {
-    ca[CA_CI + tid] = cg->C_integral[tid];
-    ca[CA_CD + tid] = cg->C_doubleintegral[tid];
-    ca[CA_DA + tid] = cg->dalpha_db_g[tid];
-    ca[CA_DV + tid] = cg->dv_db_g[tid];
-    ca[CA_DP + tid] = cg->dp_db_g[tid];
-  }
-  if (tid < 3) {
-    ca[CA_AI + tid] = cg->acc_integral[tid];
-    ca[CA_AD + tid] = cg->acc_doubleintegral[tid];
-  }
-  if (tid < 225) ca[CA_SI + tid] = cg->sqrt_info[tid];
-  __syncthreads();
+  if (tid < 6) s_db[tid] = s_st[14 + 3 + tid] - s_st[32 + 3 + tid];
   if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[37] = (double)clock64();
-  // ---- F = [F0 | F1] and the error vector by one work-item (ImuError.cpp:561-601)
+  // ---- F = [F0 | F1] and the error vector (ImuError.cpp:561-601), by the first work-item of each of the four waves: every one
+  // of them forms the common quantities (normalised quaternions, C0, the position / velocity differences, Delta_q corrected for
+  // the bias change) with the same expressions — the same bits — and then its share of the blocks; every entry is computed by
+  // the expression one work-item used to compute it with.  (One work-item alone spent 4.4 of the workgroup's 11 us here: some
+  // 1300 instructions at one instruction every 4-8 cycles.)
   double* F = lds + EvalLds::FM;
   double* ev = lds + EvalLds::EV;
   for (int i = tid; i < 450; i += IMU_THREADS) F[i] = 0.0;
   __syncthreads();
-  if (tid == 0) {
+  static_assert(IMU_THREADS == 256, "four waves, four shares");
+  if ((tid & 63) == 0) {
+    const int part = tid >> 6;
+    const double *p0 = s_st, *p1 = s_st + 7, *sb0 = s_st + 14, *b1 = s_st + 23;   // (the staged states)
     double q0[4] = {p0[3], p0[4], p0[5], p0[6]}, q1[4] = {p1[3], p1[4], p1[5], p1[6]};
     qnormalize(q0);
     qnormalize(q1);
@@ -765,52 +778,8 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
     double C0T[9], t9[9], cx[9];
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) C0T[3 * i + j] = C0[3 * j + i];
-    // F0 = I with blocks
-    for (int i = 0; i < 15; ++i) F[30 * i + i] = 1.0;
-    Fset(0, 0, C0T, 1.0);
-    cross_mx(dp, cx);
-    mat3_mul(C0T, cx, t9);
-    Fset(0, 3, t9, 1.0);
-    for (int c = 0; c < 9; ++c) t9[c] = C0T[c] * Dt;
-    Fset(0, 6, t9, 1.0);
-    Fset(0, 9, ca + CA_DP, 1.0);
-    Fset(0, 12, ca + CA_CD, -1.0);
-    {
-      double qa[4], A[16], B[16];
-      qmul(Dq, q1i, qa);
-      qplus44(qa, A);
-      qoplus44(q0, B);
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-          double s = 0;
-          for (int m = 0; m < 4; ++m) s += A[4 * i + m] * B[4 * m + j];
-          t9[3 * i + j] = s;
-        }
-      Fset(3, 3, t9, 1.0);
-      double qb[4], M3[9];
-      qmul(q1i, q0, qb);
-      qoplus44(qb, A);
-      qoplus44(Dq, B);
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-          double s = 0;
-          for (int m = 0; m < 4; ++m) s += A[4 * i + m] * B[4 * m + j];
-          M3[3 * i + j] = s;
-        }
-      mat3_mul(M3, da, t9);
-      Fset(3, 9, t9, -1.0);
-    }
-    cross_mx(dv, cx);
-    mat3_mul(C0T, cx, t9);
-    Fset(6, 3, t9, 1.0);
-    Fset(6, 6, C0T, 1.0);
-    Fset(6, 9, ca + CA_DV, 1.0);
-    Fset(6, 12, ca + CA_CI, -1.0);
-    // F1 = -I with blocks (columns 15..29)
-    for (int i = 0; i < 15; ++i) F[30 * i + 15 + i] = -1.0;
-    Fset(0, 15, C0T, -1.0);
-    Fset(6, 21, C0T, -1.0);
-    {
+    if (part == 0) {
+      // d e_q / d q1 (columns 18..20 of rows 3..5)
       double A[16], B[16], Cq[16], AB[16];
       qplus44(Dq, A);
       qoplus44(q0, B);
@@ -828,27 +797,79 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
           t9[3 * i + j] = s;
         }
       Fset(3, 18, t9, -1.0);
-    }
-    // error vector (:597-601)
-    double e0[3], e2[3];
-    mat3_vec(C0T, dp, e0);
-    mat3_vec(C0T, dv, e2);
-    for (int i = 0; i < 3; ++i) {
-      double s0 = e0[i] + ca[CA_AD + i], s2 = e2[i] + ca[CA_AI + i];
-      for (int m = 0; m < 6; ++m) {
-        s0 += F[30 * i + 9 + m] * s_db[m];
-        s2 += F[30 * (6 + i) + 9 + m] * s_db[m];
+    } else if (part == 1) {
+      // d e_q / d b_g (rows 3..5, columns 9..11) and d e_p / d q0 (rows 0..2, columns 3..5)
+      double A[16], B[16], qb[4], M3[9];
+      qmul(q1i, q0, qb);
+      qoplus44(qb, A);
+      qoplus44(Dq, B);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double s = 0;
+          for (int m = 0; m < 4; ++m) s += A[4 * i + m] * B[4 * m + j];
+          M3[3 * i + j] = s;
+        }
+      mat3_mul(M3, da, t9);
+      Fset(3, 9, t9, -1.0);
+      cross_mx(dp, cx);
+      mat3_mul(C0T, cx, t9);
+      Fset(0, 3, t9, 1.0);
+    } else if (part == 2) {
+      // d e_q / d q0 (rows 3..5, columns 3..5), d e_v / d q0 (rows 6..8, columns 3..5) and the copies of C0^T
+      double qa[4], A[16], B[16];
+      qmul(Dq, q1i, qa);
+      qplus44(qa, A);
+      qoplus44(q0, B);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double s = 0;
+          for (int m = 0; m < 4; ++m) s += A[4 * i + m] * B[4 * m + j];
+          t9[3 * i + j] = s;
+        }
+      Fset(3, 3, t9, 1.0);
+      cross_mx(dv, cx);
+      mat3_mul(C0T, cx, t9);
+      Fset(6, 3, t9, 1.0);
+      Fset(0, 0, C0T, 1.0);
+      for (int c = 0; c < 9; ++c) t9[c] = C0T[c] * Dt;
+      Fset(0, 6, t9, 1.0);
+      Fset(6, 6, C0T, 1.0);
+      Fset(0, 15, C0T, -1.0);
+      Fset(6, 21, C0T, -1.0);
+    } else {
+      // the blocks that are copies of the preintegration's Jacobians, the identity parts that no block covers (rows 9..14)
+      // and the error vector (:597-601)
+      Fset(0, 9, ca + CA_DP, 1.0);
+      Fset(0, 12, ca + CA_CD, -1.0);
+      Fset(6, 9, ca + CA_DV, 1.0);
+      Fset(6, 12, ca + CA_CI, -1.0);
+      for (int i = 9; i < 15; ++i) {
+        F[30 * i + i] = 1.0;
+        F[30 * i + 15 + i] = -1.0;
       }
-      ev[i] = s0;
-      ev[6 + i] = s2;
+      double e0[3], e2[3];
+      mat3_vec(C0T, dp, e0);
+      mat3_vec(C0T, dv, e2);
+      for (int i = 0; i < 3; ++i) {
+        double s0 = e0[i] + ca[CA_AD + i], s2 = e2[i] + ca[CA_AI + i];
+        for (int m = 0; m < 6; ++m) {
+          // (F[30 i + 9 + m] and F[30 (6 + i) + 9 + m]: the copies this work-item has just written, read from where they came from)
+          const double f0 = m < 3 ? 1.0 * ca[CA_DP + 3 * i + m] : -1.0 * ca[CA_CD + 3 * i + (m - 3)];
+          const double f2 = m < 3 ? 1.0 * ca[CA_DV + 3 * i + m] : -1.0 * ca[CA_CI + 3 * i + (m - 3)];
+          s0 += f0 * s_db[m];
+          s2 += f2 * s_db[m];
+        }
+        ev[i] = s0;
+        ev[6 + i] = s2;
+      }
+      double qe[4], qt[4];
+      qmul(q1i, q0, qt);
+      qmul(Dq, qt, qe);
+      ev[3] = 2 * qe[0];
+      ev[4] = 2 * qe[1];
+      ev[5] = 2 * qe[2];
+      for (int i = 0; i < 6; ++i) ev[9 + i] = sb0[3 + i] - b1[3 + i];
     }
-    double qe[4], qt[4];
-    qmul(q1i, q0, qt);
-    qmul(Dq, qt, qe);
-    ev[3] = 2 * qe[0];
-    ev[4] = 2 * qe[1];
-    ev[5] = 2 * qe[2];
-    for (int i = 0; i < 6; ++i) ev[9 + i] = sb0[3 + i] - b1[3 + i];
   }
   __syncthreads();
   if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[39] = (double)clock64();
