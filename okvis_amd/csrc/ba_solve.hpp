@@ -782,7 +782,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // vector registers and the kernel into 100 spills)
   const int sum_spec = DBUF ? spec0 : 0;   // the buffer that is accepted if the pending trial is
   STAMP(41);   // (every request of the prologue has been issued)
-  auto sum_partials = [&](int buf, bool use_sums) {
+  // (pre: the three sums of a lane's items, formed by the caller from loads it requested earlier — launches without helpers ask
+  // for the chunk partials BEFORE they clear the matrix area, so that the clearing runs under the loads' round trip)
+  auto sum_partials = [&](int buf, bool use_sums, const double* pre = nullptr) {
     if constexpr (!LARGE) {
       const int npose_blk = Dp / 6;
       const int nP = npose_blk * (npose_blk + 1) / 2 * 36, ntot = nP + 3 * Dp;
@@ -794,7 +796,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       for (int base = tid - 64; base < ntot; base += 3 * NL) {
         double a[3] = {0, 0, 0};
         int dst[3];
-        if (!use_sums) {
+        if (pre) {
+          a[0] = pre[0], a[1] = pre[1], a[2] = pre[2];
+        } else if (!use_sums) {
           // large launches: summed here, lanes on consecutive doubles, three items per lane and eight chunks per trip requested
           // together (the loads come from other CUs' stores: what counts is the number of dependent rounds)
           constexpr int CB = 9;   // chunks per trip (a separate Schur launch leaves 9 chunks at configs[1]: ONE trip; a fused window has up to 34)
@@ -980,6 +984,23 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       const int npose_blk = Dp / 6;
       const int nP = npose_blk * (npose_blk + 1) / 2 * 36, ntot = nP + 3 * Dp;
       constexpr int NL = SOLVE_THREADS - 64;
+      // launches without helpers whose partials fit one trip (at most 9 chunks, at most three items per lane — configs[1] behind
+      // a separate Schur launch): the loads leave here, in front of the clearing of the matrix area
+      constexpr int PCB = 9;
+      const bool early = !helped && W.n_chunk <= PCB && ntot <= 3 * NL;
+      double pv0[PCB], pv1[PCB], pv2[PCB];
+      if (early) {
+        const size_t stride = W.spart_stride;
+        const int nch = W.n_chunk;
+        auto sp = W.spart + (DBUF ? (size_t)sum_spec * W.spart_buf_stride : (size_t)0);
+        const int i0 = tid - 64;
+#pragma unroll
+        for (int u = 0; u < PCB; ++u) {
+          pv0[u] = (u < nch && i0 < ntot) ? sp[(size_t)u * stride + i0] : 0.0;
+          pv1[u] = (u < nch && i0 + NL < ntot) ? sp[(size_t)u * stride + i0 + NL] : 0.0;
+          pv2[u] = (u < nch && i0 + 2 * NL < ntot) ? sp[(size_t)u * stride + i0 + 2 * NL] : 0.0;
+        }
+      }
       {
         // (solver coordinates: the pose part sits behind the speed/bias part, rows / columns Ds .. D - 1; an item lands on every
         // entry (r, c) of the upper triangle with Ds <= r <= c < D)
@@ -1042,7 +1063,18 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
           __builtin_amdgcn_s_sleep(1);
         use_sums = (v & 3) == 1;
       }
-      sum_partials(sum_spec, use_sums);
+      if (early) {
+        double pre[3] = {0, 0, 0};   // (the chunks in their order: the sums of a launch that asks later, bit for bit)
+#pragma unroll
+        for (int u = 0; u < PCB; ++u) pre[0] += pv0[u];
+#pragma unroll
+        for (int u = 0; u < PCB; ++u) pre[1] += pv1[u];
+#pragma unroll
+        for (int u = 0; u < PCB; ++u) pre[2] += pv2[u];
+        sum_partials(sum_spec, false, pre);
+      } else {
+        sum_partials(sum_spec, use_sums);
+      }
       if (!helped) stage_stores();
       for (int i = tid - 64; i < 3 * (Dpad - Dp); i += NL) {   // speed/bias part of the vectors starts from zero
         const int which = i / (Dpad - Dp), j = Dp + i - which * (Dpad - Dp);
@@ -1052,6 +1084,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     }
     if (W.prof && tid == 64 && blockIdx.x == 0) W.prof[4] = (double)clock64();
   }
+  if (W.prof && (tid & 63) == 0 && blockIdx.x == 0) W.prof[170 + (tid >> 6)] = (double)clock64();   // diagnostics: when each wave reaches the barrier of the head
   __syncthreads();
   if (c.done) {
     if (tid == 0) *gctrl = c;

@@ -27,3 +27,4 @@ print("  LDL^T solver: load %.2f, factor %.2f, back-substitution %.2f us" % ((q[
 if q[32] > 0 and q[33] > q[32]:
     nbk = int(np.count_nonzero(q[32:48]))
     print("  wave 0's steps (cycles; hand-overs requested again .. both there in brackets): " + " ".join("%d (%d)" % (q[33 + k] - q[32 + k], q[64 + k] - q[48 + k]) for k in range(nbk - 1)))
+print("  waves at the barrier of the head (us after stamp 0): " + " ".join("%d:%.2f" % (w, (p[170 + w] - p[0]) / T) for w in range(16)))
