@@ -46,6 +46,7 @@ struct HostWin {  // host copy of what the queries and downloads need
   int marg_dim = 0;
   bool h0_on_device = false;   // H0 = J^T J of a large prior is formed by marg_h0_kernel after the upload, not by build_window
   bool group_chunks = false;   // one Schur chunk per linearise group (what the fused linearise + reduce launch needs)
+  bool spec_ok = false;        // the window can take a decision-free Schur launch (one set of partials per linearisation buffer, see spec_schur)
   WinPtrs ptrs;  // device pointers
   int acc = 0;
   int64_t bytes_lin = 0, bytes_schur = 0, bytes_solve = 0, bytes_small = 0;
@@ -130,6 +131,10 @@ struct okvis_ba_solver {
   bool lin2 = false;          // the batch's index lists are those of the piece path (ba_linearize2.hpp)
   bool split_small = false;   // piece path: IMU / prior factors in a launch of their own (small_kernel), three linearise workgroups per CU
   bool group_chunks = false;   // every window of the batch has one Schur chunk per linearise group (see fused())
+  // Batches that are not fused but run DOGLEG or fixed-radius iterations on windows the matrix-core Schur kernel serves: the Schur
+  // launch takes no decision (schur_mfma_kernel, nodec) and reduces the trial buffer into that buffer's own set of partials, the
+  // solve kernel decides (its DBUF instantiation, as in fused mode).  OKVIS_BA_NO_SPEC_SCHUR keeps the decision in the Schur launch.
+  bool spec_schur = false;
   bool fp32_at_upload = false;
   std::vector<int64_t> launch_sig;   // what the captured graphs depend on (see okvis_ba_upload)
   unsigned char* h_ctrl_stage = nullptr;   // pinned / device staging of per-window control data (begin, fetch_ctrl)
@@ -737,6 +742,11 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     H.group_chunks = !(opt.reserved0 & 4) && opt.schur_lm_per_block == 0 && D <= MAX_D_LDS && Dp <= TILE_DIM && n_windows_total <= fused_max_windows() && 2 * SCHUR_LM_BATCH * 3 * Dp <= stage &&
                      (opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || opt.gauss_newton);
     if (H.group_chunks) per = 1;
+    {
+      static const bool no_spec = std::getenv("OKVIS_BA_NO_SPEC_SCHUR") != nullptr, no_mfma = std::getenv("OKVIS_BA_NO_SCHUR2") != nullptr;
+      H.spec_ok = !no_spec && !no_mfma && opt.schur_lm_per_block == 0 && D <= MAX_D_LDS && !has_ext && std::min(TILE_DIM, Dp) + 1 <= SCH2_MAXT_SMALL_ROWS &&
+                  (opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || opt.gauss_newton);
+    }
     int g = 0;
     while (g < ngroup) {
       Chunk C;
@@ -889,7 +899,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.n_tile = ntile;
   P.n_imu_color = n_imu_color;
   P.spart_stride = spart_stride;
-  P.spart_buf_stride = H.group_chunks ? std::max(nchunk, 1) * spart_stride : 0;
+  P.spart_buf_stride = (H.group_chunks || H.spec_ok) ? std::max(nchunk, 1) * spart_stride : 0;
   {
     int max_tasks = 0, max_pairs = 0;
     for (const Group& Gq : groups) {
@@ -1067,7 +1077,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     OFF(small_cost[b], put_zero(A, 16));
     if (opt.debug_arrays) OFF(obs_r[b], put_zero(A, 16 * (size_t)nobs));
   }
-  OFF(spart, put_zero(A, 8 * (size_t)std::max(nchunk, 1) * (size_t)spart_stride * (H.group_chunks ? 2 : 1)));
+  OFF(spart, put_zero(A, 8 * (size_t)std::max(nchunk, 1) * (size_t)spart_stride * ((H.group_chunks || H.spec_ok) ? 2 : 1)));
   OFF(spart_sum, put_zero(A, 8 * (size_t)std::max(spart_stride, 1)));
   OFF(sum_sync, put_zero(A, 16));
   OFF(dec, put_zero(A, 8 * (size_t)DEC_COUNT));
@@ -1293,6 +1303,21 @@ bool fused(const okvis_ba_solver* s) {
   return s->group_chunks && (s->opt.fp32_linearize != 0) == s->fp32_at_upload &&
          (s->opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || s->opt.gauss_newton);
 }
+// decision-free Schur launch (okvis_ba_solver::spec_schur): the batch was laid out for it and the options still ask for a mode
+// whose damping does not depend on the decision
+bool spec_schur_now(const okvis_ba_solver* s) {
+  return s->spec_schur && !fused(s) && (s->opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || s->opt.gauss_newton);
+}
+// ... and the IMU / prior factors CAN ride in that launch instead of one of their own in front of the linearise launch
+// (schur_small_kernel; where they have a launch of their own today: piece path, batches of 40 windows and more).  Built,
+// bit-identical, OFF by default (OKVIS_BA_SMALL_MERGE=1 switches it on): the kernel time of a sub-batch's chain drops by 12.5 us
+// (26.7 us for the joint launch against 24.9 + 14.3 at 21 windows, profiles/r05_notes.md) but the 64-window bench line falls from
+// 497 k to 465 k it/s — the joint launch runs at the factor workgroups' two workgroups per CU (255 registers, 73 KB of LDS) and
+// takes 30 % more CU-time than the two launches, and with three sub-batch streams the device is short of exactly that.
+bool small_rides_with_schur(const okvis_ba_solver* s) {
+  static const bool on = std::getenv("OKVIS_BA_SMALL_MERGE") != nullptr;
+  return on && spec_schur_now(s) && s->lin2 && s->split_small && s->max_schur_blocks > 0 && std::min(TILE_DIM, s->max_Dp) + 1 <= SCH2_MAXT_SMALL_ROWS;
+}
 hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
   if (s->max_schur_blocks == 0 || fused(s)) return hipSuccess;
   const int trows = std::min(TILE_DIM, s->max_Dp);
@@ -1306,10 +1331,14 @@ hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
     int nlb = sch2_nlb(trows, 5120);              // 40 KB of tiles: three workgroups per CU
     if (nlb < 12) nlb = sch2_nlb(trows, 9216);    // wide tiles: 72 KB, two per CU
     const size_t sm = (size_t)sch2_tile_doubles(trows, nlb) * sizeof(double);
-    if (trows + 1 <= SCH2_MAXT_SMALL_ROWS)
-      hipLaunchKernelGGL(schur_mfma_kernel<3>, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), sm, b.st, s->d_wins + b.w0, s->d_opt, trows, final_call, nlb);
+    if (small_rides_with_schur(s)) {   // the IMU / prior factors of the trial in the same launch (schur_small_kernel)
+      const int n_small = s->max_imu + 1;
+      hipLaunchKernelGGL(schur_small_kernel<3>, dim3(n_small + s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), std::max(sm, small_smem()), b.st, s->d_wins + b.w0,
+                         s->d_opt, trows, final_call, nlb, s->d_ctrl + b.w0, 1, n_small);
+    } else if (trows + 1 <= SCH2_MAXT_SMALL_ROWS)
+      hipLaunchKernelGGL(schur_mfma_kernel<3>, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), sm, b.st, s->d_wins + b.w0, s->d_opt, trows, final_call, nlb, s->d_ctrl + b.w0, spec_schur_now(s) ? 1 : 0);
     else
-      hipLaunchKernelGGL(schur_mfma_kernel<9>, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), sm, b.st, s->d_wins + b.w0, s->d_opt, trows, final_call, nlb);
+      hipLaunchKernelGGL(schur_mfma_kernel<9>, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), sm, b.st, s->d_wins + b.w0, s->d_opt, trows, final_call, nlb, s->d_ctrl + b.w0, 0);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(schur_kernel, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS),
@@ -1318,7 +1347,7 @@ hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
   return hipGetLastError();
 }
 hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
-  if (s->max_Dpad_small > 0 && s->group_chunks)   // (one set of partials per linearisation buffer)
+  if (s->max_Dpad_small > 0 && (s->group_chunks || s->spec_schur))   // (one set of partials per linearisation buffer)
     hipLaunchKernelGGL((solve_kernel<false, true>), dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), b.st,
                        s->d_wins + b.w0, s->d_opt, final_only, s->d_ctrl + b.w0);
   else if (s->max_Dpad_small > 0)
@@ -1349,7 +1378,10 @@ hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
     const int sd = lin2_step_doubles(s->max_Dp, fuse, f32);
     const size_t smem2 = lin2_smem(s->max_Dp, fuse, f32);
     if (s->split_small) {
-      hipLaunchKernelGGL(small_kernel, dim3(n_small, (unsigned)b.nw), dim3(LIN_THREADS), small_smem(), b.st, s->d_wins + b.w0, init);
+      // (the factors of a trial ride with the next Schur launch where that launch takes no decision; the initial evaluation keeps
+      // its own launch: okvis_ba_begin is followed by a Schur launch too, whose factor workgroups then evaluate the same states again)
+      if (init || !small_rides_with_schur(s))
+        hipLaunchKernelGGL(small_kernel, dim3(n_small, (unsigned)b.nw), dim3(LIN_THREADS), small_smem(), b.st, s->d_wins + b.w0, init);
       const dim3 grid2(s->max_group, (unsigned)b.nw);
       static const int occ_env = [] { const char* e = std::getenv("OKVIS_BA_LIN2_OCC"); return e ? std::atoi(e) : 4; }();
       const bool two_rounds = !fuse && occ_env >= 4;   // block records in two rounds: 37 KB of LDS, four workgroups per CU
@@ -1552,6 +1584,7 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
     lds(reinterpret_cast<const void*>(&small_kernel), small_smem());
   }
   lds(reinterpret_cast<const void*>(&schur_mfma_kernel<3>), (size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double));
+  lds(reinterpret_cast<const void*>(&schur_small_kernel<3>), std::max((size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double), small_smem()));
   lds(reinterpret_cast<const void*>(&schur_mfma_kernel<9>), (size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1827,6 +1860,7 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   s->max_Dpad_small = s->max_Dpad_large = 0;
   s->any_ext = false;
   s->group_chunks = true;
+  s->spec_schur = true;
   s->fp32_at_upload = s->opt.fp32_linearize != 0;
   for (int i = 0; i < n_windows; ++i) {
     relocate(wins[i].ptrs, s->d_arena, zbase, s->opt.debug_arrays);
@@ -1846,9 +1880,15 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
       s->max_Dpad_large = std::max(s->max_Dpad_large, ((P.D + 5) / 6) * 6);
     s->any_ext = s->any_ext || P.has_ext;
     s->group_chunks = s->group_chunks && wins[i].group_chunks;
+    s->spec_schur = s->spec_schur && wins[i].spec_ok;
   }
-  if (!s->group_chunks)   // a batch is fused as a whole or not at all: one set of partials for everybody
-    for (int i = 0; i < n_windows; ++i) ptrs[i].spart_buf_stride = 0, ptrs[i].fuse_fast = 0;
+  // a batch is fused as a whole or not at all; a batch that is not takes the decision-free Schur launch as a whole or not at all;
+  // otherwise one set of partials for everybody
+  if (s->group_chunks) s->spec_schur = false;
+  if (!s->group_chunks)
+    for (int i = 0; i < n_windows; ++i) ptrs[i].fuse_fast = 0;
+  if (!s->group_chunks && !s->spec_schur)
+    for (int i = 0; i < n_windows; ++i) ptrs[i].spart_buf_stride = 0;
   {
     // one copy: option record, window records and the (zeroed) control records behind them
     const size_t wb = sizeof(WinPtrs) * (size_t)n_windows, all = records_bytes((size_t)n_windows);
@@ -1904,7 +1944,7 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     // not the windows themselves.  A re-upload that leaves all of that unchanged (the same number of equally shaped windows:
     // the per-frame pattern of a batch service, the dogleg record of bench.py) keeps them; anything else drops them.
     std::vector<int64_t> sig = {n_windows, s->max_group, s->max_imu, s->max_schur_blocks, s->max_lm, s->max_Dpad, s->max_Dp,
-                                s->max_Dpad_small, s->max_Dpad_large, s->max_spart_stride, s->any_ext, s->group_chunks, s->lin2, s->split_small,
+                                s->max_Dpad_small, s->max_Dpad_large, s->max_spart_stride, s->any_ext, s->group_chunks, s->spec_schur, s->lin2, s->split_small,
                                 s->fp32_at_upload, (int64_t)(intptr_t)s->d_wins, (int64_t)(intptr_t)s->d_opt,
                                 (int64_t)s->sub_streams.size()};
     for (int b : s->sub_begin) sig.push_back(b);
@@ -2914,7 +2954,7 @@ int okvis_ba_marginalize_begin(okvis_ba_solver* s, int w, const okvis_ba_marg_sp
     hipLaunchKernelGGL((solve_kernel<true, false>), dim3(1), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), s->stream, d_win, s->d_opt, 2, s->d_ctrl + w);
     const int nT = (((D + 5) / 6) * 6 + CT_TB - 1) / CT_TB;
     hipLaunchKernelGGL(large_export_kernel, dim3(nT * (nT + 1) / 2, 1, CT_TILE / CT_THREADS), dim3(CT_THREADS), 0, s->stream, d_win);
-  } else if (s->group_chunks)
+  } else if (s->group_chunks || s->spec_schur)
     hipLaunchKernelGGL((solve_kernel<false, true>), dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream,
                        d_win, s->d_opt, 2, s->d_ctrl + w);
   else

@@ -249,13 +249,18 @@ __device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, doubl
   d = ldl16_pivot<7, FULL, GUARD>(r, d, 7 < npiv, mine, j, bad);
   d = ldl16_pivot<8, FULL, GUARD>(r, d, 8 < npiv, mine, j, bad);
   d = ldl16_pivot<9, FULL, GUARD>(r, d, 9 < npiv, mine, j, bad);
-  mid();
+#ifndef LDL_HOOK_AT
+#define LDL_HOOK_AT 9
+#endif
+  if (LDL_HOOK_AT == 9) mid();
   d = ldl16_pivot<10, FULL, GUARD>(r, d, 10 < npiv, mine, j, bad);
   d = ldl16_pivot<11, FULL, GUARD>(r, d, 11 < npiv, mine, j, bad);
   d = ldl16_pivot<12, FULL, GUARD>(r, d, 12 < npiv, mine, j, bad);
+  if (LDL_HOOK_AT == 12) mid();
   d = ldl16_pivot<13, FULL, GUARD>(r, d, 13 < npiv, mine, j, bad);
   d = ldl16_pivot<14, FULL, GUARD>(r, d, 14 < npiv, mine, j, bad);
   d = ldl16_pivot<15, FULL, GUARD>(r, d, 15 < npiv, mine, j, bad);
+  if (LDL_HOOK_AT == 15) mid();
 }
 
 // NW waves (NW * 64 threads), all of which must call.  S: the assembled system (see above) for an nb = ldl16_nb(D)

@@ -34,13 +34,20 @@ __host__ __device__ constexpr int sch2_nlb(int trows, int budget) {
 __host__ __device__ constexpr int sch2_tile_doubles(int trows, int nlb) { return (sch2_pad16(trows + 1) + sch2_pad16(trows)) * (3 * nlb + 1); }
 
 template <int SCH2_MAXT>
-__global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_mfma_kernel(const WinPtrs* __restrict__ wins, const OptD* __restrict__ optp,
-                                                                      int tile_rows, int final_call, int nlb) {
+__device__ __forceinline__ void schur_mfma_body(const WinPtrs* __restrict__ wins, const OptD* __restrict__ optp, int tile_rows, int final_call, int nlb,
+                                                const CtrlSlot* __restrict__ ctrls, int nodec, const int bx) {
   const WinPtrs& W = wins[blockIdx.y];
+  // The control record's address comes from the kernel arguments (CtrlSlot, ba_types.hpp; == W.ctrl): its first words — accepted
+  // buffer, pending, first, done — arrive together with the window record, and with them the index of the linearisation buffer
+  // that is reduced if the pending trial is accepted (the common case).  Everything the reduction reads first from that buffer
+  // — the (landmark, block) rows of the first batch, the landmark blocks V | b — is requested from the speculated buffer next
+  // to the decision's own loads instead of one memory round trip behind the decision (round 5; the solve kernel does the same).
+  const Ctrl* ctrl = &ctrls[blockIdx.y].c;
+  typedef int sch2_i4 __attribute__((ext_vector_type(4)));
+  const sch2_i4 chead = *reinterpret_cast<const sch2_i4*>(ctrl);   // acc, pending, first, done
+  const int spec = __builtin_amdgcn_readfirstlane(chead.y ? 1 - chead.x : chead.x);
   const int n_tp = W.n_tile * (W.n_tile + 1) / 2;
-  const int bx = blockIdx.x;
   if (bx >= W.n_chunk * n_tp) return;
-  const Ctrl* ctrl = W.ctrl;   // (whether the window is done is read from the LDS copy of the record, behind the decision)
 
   extern __shared__ __attribute__((aligned(16))) double sch_smem[];   // tY [pad16(tile_rows + 1)][3 nlb + 1] | tW [pad16(tile_rows)][3 nlb + 1]
   __shared__ double s_vinv[SCHUR_CHUNK_LM_MAX][6];   // (V_l + lambda D_l^2)^-1 of every landmark of the chunk
@@ -57,8 +64,16 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
 #define SSTAMP(k) do { if (W.prof && tid == 0 && bx == 0 && blockIdx.y == 0) W.prof[k] = (double)clock64(); } while (0)
   SSTAMP(16);
   // wave 0's loads for the decision go out first; the static structure below is fetched while they are in flight
+  // nodec (batches that keep one set of partials per linearisation buffer, okvis_ba_upload: DOGLEG and fixed-radius runs behind a
+  // separate Schur launch): no decision at the head.  The launch reduces what the fused linearise launch would reduce — the trial
+  // buffer if a trial is pending, with the damping the next solve will use if the trial is accepted (it does not depend on the
+  // costs in these modes), else the accepted buffer — into that buffer's own set of partials; the solve kernel takes the
+  // decision, sums the set of the buffer it accepts and, after a rejection, has the other set from the launch that reduced it.
+  // The trust-region decision with its two dependent loads and its barrier (5.7 of a workgroup's 29 us, in every workgroup)
+  // leaves the chain, and nothing in this launch waits for the costs of the IMU / prior factors any more.
   SchurDecisionLoads dl;
-  schur_decision_issue(W, ctrl, tid, dl);
+  if (!nodec) schur_decision_issue(W, ctrl, tid, dl);
+  const double c_mu = nodec ? ctrl->mu : 0.0, c_radius = nodec ? ctrl->radius : 1.0;
   const OptD opt = *optp;
   const int chunk = bx / n_tp;
   const int* cd = W.chunk_desc + (size_t)chunk * SCHUR_DESC_INTS;   // lm_begin, lm_end, pair ranges: one record
@@ -138,16 +153,9 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
     return r;
   };
 
-  schur_decision_finish(W, opt, dl, final_call, bx, tid, s_ctrl, s_dec, s_lambda);
-  __syncthreads();
-  SSTAMP(17);
-  if (s_ctrl.done || s_dec[1]) return;   // finished earlier / terminated by the decision (the solve kernel records it)
-  const int acc = s_dec[0];
-  const double lambda = s_lambda;
-
-  // ---- everything that needed the decision (which buffer) is requested in one go: the (landmark, block) rows of the first
-  //      batch, the landmark blocks, the partials of the diagonal-block lists ----
-  const double* Wb = W.W[acc];
+  // ---- what the reduction reads first, from the speculated buffer: the (landmark, block) rows of the first batch and the
+  //      landmark blocks (one landmark per work-item: a chunk has at most SCHUR_CHUNK_LM_MAX <= SCHUR_THREADS of them) ----
+  const double* Wb = W.W[spec];
   double wp[18];
   int f_slot = -1, f_lb = 0;
   auto load_batch = [&](int ib) {   // one work-item per (landmark, block) pair of batch ib
@@ -161,7 +169,32 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
       f_lb = W.pair_lm[pp] - (lm_begin + ib * nlb);
     }
   };
+  static_assert(SCHUR_CHUNK_LM_MAX <= SCHUR_THREADS, "one landmark per work-item");
+  double lv[6] = {1, 0, 0, 1, 0, 1}, lb3[3] = {0, 0, 0};
+  auto load_landmark = [&](int buf) {
+    if (tid < nl) {
+      const double* Vl = W.V[buf] + 6 * (size_t)(lm_begin + tid);
+      const double* bl = W.bl[buf] + 3 * (size_t)(lm_begin + tid);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) lv[e] = Vl[e];
+      lb3[0] = bl[0], lb3[1] = bl[1], lb3[2] = bl[2];
+    }
+  };
   load_batch(0);
+  load_landmark(spec);
+  if (!nodec) schur_decision_finish(W, opt, dl, final_call, bx, tid, s_ctrl, s_dec, s_lambda);
+  __syncthreads();
+  SSTAMP(17);
+  if (nodec ? chead.w != 0 : (s_ctrl.done || s_dec[1])) return;   // finished earlier / terminated by the decision (the solve kernel records it)
+  const int acc = nodec ? spec : __builtin_amdgcn_readfirstlane(s_dec[0]);
+  // (nodec: the rule of the fused linearise launch, ba_linearize2.hpp — the damping of the solve that follows an accepted trial)
+  const double lam_next = opt.dogleg ? ((chead.z || opt.gauss_newton) ? c_mu : fmax(DL_MIN_MU, 2.0 * c_mu / DL_MU_INCREASE)) : 1.0 / c_radius;
+  const double lambda = nodec ? (chead.y ? lam_next : (opt.dogleg ? c_mu : 1.0 / c_radius)) : s_lambda;
+  if (acc != spec) {   // (a rejected trial: the other buffer is the one to reduce — requested again)
+    Wb = W.W[acc];
+    load_batch(0);
+    load_landmark(acc);
+  }
   const double* gp = W.gpart[acc];
   double d_u[SCH2_DI], r_g = 0.0, r_du = 0.0;
   if (diag) {
@@ -199,13 +232,12 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
       }
     }
   }
-  // (V_l + lambda D_l^2)^-1 and V^-1 b of every landmark of the chunk
-  for (int i = tid; i < nl; i += SCHUR_THREADS) {
+  // (V_l + lambda D_l^2)^-1 and V^-1 b of every landmark of the chunk (work-item i: landmark i, its blocks are in registers)
+  if (tid < nl) {
+    const int i = tid;
     const int l = lm_begin + i;
-    const double* Vl = W.V[acc] + 6 * (size_t)l;
-    const double* bl = W.bl[acc] + 3 * (size_t)l;
-    double v[6] = {Vl[0], Vl[1], Vl[2], Vl[3], Vl[4], Vl[5]};
-    const double b0 = bl[0], b1 = bl[1], b2 = bl[2];
+    double v[6] = {lv[0], lv[1], lv[2], lv[3], lv[4], lv[5]};
+    const double b0 = lb3[0], b1 = lb3[1], b2 = lb3[2];
     double vi[6];
     if (opt.marg_mode) {
       pinv3sym_precond(v, vi);   // MarginalizationError::marginalizeOut landmark path (no damping)
@@ -451,6 +483,30 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
   }
   SSTAMP(23);
 #undef SSTAMP
+}
+
+
+template <int SCH2_MAXT>
+__global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_mfma_kernel(const WinPtrs* __restrict__ wins, const OptD* __restrict__ optp,
+                                                                      int tile_rows, int final_call, int nlb, const CtrlSlot* __restrict__ ctrls, int nodec) {
+  schur_mfma_body<SCH2_MAXT>(wins, optp, tile_rows, final_call, nlb, ctrls, nodec, (int)blockIdx.x);
+}
+
+// The decision-free Schur launch and the IMU / prior factors of the same trial in ONE launch (round 5): workgroups 0 .. n_small - 1
+// of a window are the factor workgroups of small_kernel (ba_imu.hpp), the others the Schur workgroups.  Neither waits for the
+// other — the reduction does not need the factors' costs when it takes no decision — and both only have to be through before the
+// solve launch: the factor launch (14 us at 21 windows) leaves the chain of a sub-batch.  Two workgroups per CU (the factor
+// workgroups' registers and LDS), which the 9 + 10 workgroups per window of configs[1] fit in one round at the timed loop's shape.
+template <int SCH2_MAXT>
+__global__ __launch_bounds__(SCHUR_THREADS, 2) void schur_small_kernel(const WinPtrs* __restrict__ wins, const OptD* __restrict__ optp, int tile_rows,
+                                                                       int final_call, int nlb, const CtrlSlot* __restrict__ ctrls, int nodec, int n_small) {
+  static_assert(SCHUR_THREADS == IMU_THREADS && SCHUR_THREADS == LIN_THREADS, "one block size for both kinds of workgroup");
+  if ((int)blockIdx.x < n_small) {
+    extern __shared__ __attribute__((aligned(16))) double sch_smem[];
+    small_body(wins[blockIdx.y], 0, (int)blockIdx.x, sch_smem);
+    return;
+  }
+  schur_mfma_body<SCH2_MAXT>(wins, optp, tile_rows, final_call, nlb, ctrls, nodec, (int)blockIdx.x - n_small);
 }
 
 }  // namespace ba
