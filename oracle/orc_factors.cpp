@@ -9,8 +9,8 @@ namespace orc {
 // ===================================================================================================
 // Distortion models
 // ===================================================================================================
-bool distort(const Camera& c, const double u[2], double out[2], double J[4]) {
-  const double u0 = u[0], u1 = u[1];
+bool distort(const Camera& c, const real u[2], real out[2], real J[4]) {
+  const real u0 = u[0], u1 = u[1];
   switch (c.model) {
     case DIST_NONE: {  // NoDistortion: identity
       out[0] = u0;
@@ -22,10 +22,10 @@ bool distort(const Camera& c, const double u[2], double out[2], double J[4]) {
     }
     case DIST_RADTAN: {
       // okvis_cv/include/okvis/cameras/implementation/RadialTangentialDistortion.hpp:105-151
-      const double k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3];
-      const double mx_u = u0 * u0, my_u = u1 * u1, mxy_u = u0 * u1;
-      const double rho_u = mx_u + my_u;
-      const double rad_dist_u = k1 * rho_u + k2 * rho_u * rho_u;
+      const real k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3];
+      const real mx_u = u0 * u0, my_u = u1 * u1, mxy_u = u0 * u1;
+      const real rho_u = mx_u + my_u;
+      const real rad_dist_u = k1 * rho_u + k2 * rho_u * rho_u;
       out[0] = u0 + u0 * rad_dist_u + 2.0 * p1 * mxy_u + p2 * (rho_u + 2.0 * mx_u);
       out[1] = u1 + u1 * rad_dist_u + 2.0 * p2 * mxy_u + p1 * (rho_u + 2.0 * my_u);
       if (J) {
@@ -38,18 +38,18 @@ bool distort(const Camera& c, const double u[2], double out[2], double J[4]) {
     }
     case DIST_EQUI: {
       // okvis_cv/include/okvis/cameras/implementation/EquidistantDistortion.hpp:105-206
-      const double k1 = c.d[0], k2 = c.d[1], k3 = c.d[2], k4 = c.d[3];
-      const double r = std::sqrt(u0 * u0 + u1 * u1);
-      const double theta = std::atan(r);
-      const double theta2 = theta * theta, theta4 = theta2 * theta2;
-      const double theta6 = theta4 * theta2, theta8 = theta4 * theta4;
-      const double thetad = theta * (1 + k1 * theta2 + k2 * theta4 + k3 * theta6 + k4 * theta8);
-      const double scaling = (r > 1e-8) ? thetad / r : 1.0;
+      const real k1 = c.d[0], k2 = c.d[1], k3 = c.d[2], k4 = c.d[3];
+      const real r = std::sqrt(u0 * u0 + u1 * u1);
+      const real theta = std::atan(r);
+      const real theta2 = theta * theta, theta4 = theta2 * theta2;
+      const real theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+      const real thetad = theta * (1 + k1 * theta2 + k2 * theta4 + k3 * theta6 + k4 * theta8);
+      const real scaling = (r > 1e-8) ? thetad / r : 1.0;
       out[0] = scaling * u0;
       out[1] = scaling * u1;
       if (J) {
         if (r > 1e-8) {
-          double t2, t3, t4, t6, t7, t8, t9, t11, t17, t18, t19, t20, t25;
+          real t2, t3, t4, t6, t7, t8, t9, t11, t17, t18, t19, t20, t25;
           t2 = u0 * u0;
           t3 = u1 * u1;
           t4 = t2 + t3;
@@ -81,28 +81,28 @@ bool distort(const Camera& c, const double u[2], double out[2], double J[4]) {
     }
     case DIST_RADTAN8: {
       // okvis_cv/include/okvis/cameras/implementation/RadialTangentialDistortion8.hpp:125-150
-      const double k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3];
-      const double k3 = c.d[4], k4 = c.d[5], k5 = c.d[6], k6 = c.d[7];
-      const double mx_u = u0 * u0, my_u = u1 * u1, mxy_u = u0 * u1;
-      const double rho_u = mx_u + my_u;
+      const real k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3];
+      const real k3 = c.d[4], k4 = c.d[5], k5 = c.d[6], k6 = c.d[7];
+      const real mx_u = u0 * u0, my_u = u1 * u1, mxy_u = u0 * u1;
+      const real rho_u = mx_u + my_u;
       if (rho_u > 9.0) return false;  // reference returns false with outputs unset
-      const double cc = rho_u * (k4 + rho_u * (k5 + k6 * rho_u)) + 1.0;
-      const double c2 = cc * cc;
-      const double rad_dist_u = (1.0 + ((k3 * rho_u + k2) * rho_u + k1) * rho_u) /
+      const real cc = rho_u * (k4 + rho_u * (k5 + k6 * rho_u)) + 1.0;
+      const real c2 = cc * cc;
+      const real rad_dist_u = (1.0 + ((k3 * rho_u + k2) * rho_u + k1) * rho_u) /
                                 (1.0 + ((k6 * rho_u + k5) * rho_u + k4) * rho_u);
       out[0] = u0 * rad_dist_u + 2.0 * p1 * mxy_u + p2 * (rho_u + 2.0 * mx_u);
       out[1] = u1 * rad_dist_u + 2.0 * p2 * mxy_u + p1 * (rho_u + 2.0 * my_u);
       if (J) {
-        const double num = rho_u * (k1 + rho_u * (k2 + k3 * rho_u)) + 1.0;
-        const double den = rho_u * (k4 + rho_u * (k5 + k6 * rho_u)) + 1.0;
+        const real num = rho_u * (k1 + rho_u * (k2 + k3 * rho_u)) + 1.0;
+        const real den = rho_u * (k4 + rho_u * (k5 + k6 * rho_u)) + 1.0;
         // d(num)/du_a and d(den)/du_a as written (expanded) in the reference
-        const double dnum0 = rho_u * (u0 * (k2 + k3 * rho_u) * 2.0 + k3 * u0 * rho_u * 2.0) +
+        const real dnum0 = rho_u * (u0 * (k2 + k3 * rho_u) * 2.0 + k3 * u0 * rho_u * 2.0) +
                              u0 * (k1 + rho_u * (k2 + k3 * rho_u)) * 2.0;
-        const double dnum1 = rho_u * (u1 * (k2 + k3 * rho_u) * 2.0 + k3 * u1 * rho_u * 2.0) +
+        const real dnum1 = rho_u * (u1 * (k2 + k3 * rho_u) * 2.0 + k3 * u1 * rho_u * 2.0) +
                              u1 * (k1 + rho_u * (k2 + k3 * rho_u)) * 2.0;
-        const double dden0 = rho_u * (u0 * (k5 + k6 * rho_u) * 2.0 + k6 * u0 * rho_u * 2.0) +
+        const real dden0 = rho_u * (u0 * (k5 + k6 * rho_u) * 2.0 + k6 * u0 * rho_u * 2.0) +
                              u0 * (k4 + rho_u * (k5 + k6 * rho_u)) * 2.0;
-        const double dden1 = rho_u * (u1 * (k5 + k6 * rho_u) * 2.0 + k6 * u1 * rho_u * 2.0) +
+        const real dden1 = rho_u * (u1 * (k5 + k6 * rho_u) * 2.0 + k6 * u1 * rho_u * 2.0) +
                              u1 * (k4 + rho_u * (k5 + k6 * rho_u)) * 2.0;
         J[0] = p1 * u1 * 2.0 + p2 * u0 * 6.0 + num / den + (u0 * dnum0) / den - u0 * dden0 * num * 1.0 / c2;
         J[1] = p1 * u0 * 2.0 + p2 * u1 * 2.0 + (u0 * dnum1) / den - u0 * dden1 * num * 1.0 / c2;
@@ -116,12 +116,12 @@ bool distort(const Camera& c, const double u[2], double out[2], double J[4]) {
 }
 
 // PinholeCamera<D>::project with point Jacobian (implementation/PinholeCamera.hpp:148-226)
-bool project(const Camera& c, const V3& point, double kp[2], Mat<2, 3>* Jout) {
+bool project(const Camera& c, const V3& point, real kp[2], Mat<2, 3>* Jout) {
   if (std::fabs(point[2]) < 1.0e-12) return false;  // :155-157 ProjectionStatus::Invalid, outputs unset
-  const double rz = 1.0 / point[2];
-  const double rz2 = rz * rz;
-  double u[2] = {point[0] * rz, point[1] * rz};
-  double d[2], Jd[4];
+  const real rz = 1.0 / point[2];
+  const real rz2 = rz * rz;
+  real u[2] = {point[0] * rz, point[1] * rz};
+  real d[2], Jd[4];
   if (!distort(c, u, d, Jd)) return false;
   if (Jout) {
     Mat<2, 3>& J = *Jout;  // :196-206
@@ -138,7 +138,7 @@ bool project(const Camera& c, const V3& point, double kp[2], Mat<2, 3>* Jout) {
 }
 
 // PinholeCamera<D>::projectHomogeneous (implementation/PinholeCamera.hpp:357-378)
-bool projectHomogeneous(const Camera& c, const V4& hp, double kp[2], Mat<2, 4>* J) {
+bool projectHomogeneous(const Camera& c, const V4& hp, real kp[2], Mat<2, 4>* J) {
   V3 head = vec3(hp[0], hp[1], hp[2]);
   Mat<2, 3> J3;
   bool ok;
@@ -160,12 +160,12 @@ bool projectHomogeneous(const Camera& c, const V4& hp, double kp[2], Mat<2, 4>* 
 // ===================================================================================================
 // PoseLocalParameterization
 // ===================================================================================================
-void pose_plus(const double x[7], const double delta[6], double out[7]) {
+void pose_plus(const real x[7], const real delta[6], real out[7]) {
   Transformation T = Transformation::fromParams(x);  // PoseLocalParameterization.cpp:66-69
   T.oplus(delta);                                    // :72 -> Transformation::oplus
   T.toParams(out);
 }
-void pose_minus(const double x[7], const double xp[7], double delta[6]) {
+void pose_minus(const real x[7], const real xp[7], real delta[6]) {
   delta[0] = xp[0] - x[0];
   delta[1] = xp[1] - x[1];
   delta[2] = xp[2] - x[2];
@@ -176,7 +176,7 @@ void pose_minus(const double x[7], const double xp[7], double delta[6]) {
   delta[4] = 2 * d.y;
   delta[5] = 2 * d.z;
 }
-void pose_lift_jacobian(const double x[7], double J[42]) {
+void pose_lift_jacobian(const real x[7], real J[42]) {
   // PoseLocalParameterization.cpp:131-145
   for (int i = 0; i < 42; ++i) J[i] = 0;
   J[0 * 7 + 0] = 1;
@@ -187,7 +187,7 @@ void pose_lift_jacobian(const double x[7], double J[42]) {
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 4; ++j) J[(3 + i) * 7 + 3 + j] = 2.0 * Qp(i, j);
 }
-void pose_plus_jacobian(const double x[7], double J[42]) {
+void pose_plus_jacobian(const real x[7], real J[42]) {
   // Transformation::oplusJacobian (implementation/Transformation.hpp:273-286): 7x6
   for (int i = 0; i < 42; ++i) J[i] = 0;
   J[0 * 6 + 0] = 1;
@@ -202,8 +202,8 @@ void pose_plus_jacobian(const double x[7], double J[42]) {
 // ===================================================================================================
 // ReprojectionError
 // ===================================================================================================
-void reprojection_error(const double pose[7], const double point[4], const double extr[7],
-                        const Camera& cam, const double uv[2], const double sqrtInfo[4], bool jac,
+void reprojection_error(const real pose[7], const real point[4], const real extr[7],
+                        const Camera& cam, const real uv[2], const real sqrtInfo[4], bool jac,
                         ReprojOut* out) {
   // implementation/ReprojectionError.hpp:95-121
   const V3 t_WS_W = vec3(pose[0], pose[1], pose[2]);
@@ -227,7 +227,7 @@ void reprojection_error(const double pose[7], const double point[4], const doubl
   const V4 hp_C = T_CS * hp_S;
 
   // :124-141
-  double kp[2];
+  real kp[2];
   Mat<2, 4> Jh;
   Mat<2, 2> sqrtI;
   for (int i = 0; i < 4; ++i) sqrtI[i] = sqrtInfo[i];
@@ -291,14 +291,14 @@ struct PreintState {
   V3 acc_integral, acc_doubleintegral;
   M3 cross, dalpha_db_g, dv_db_g, dp_db_g;
   Mat<15, 15> P_delta;
-  double Delta_t;
+  real Delta_t;
 };
 
 // The integration loop shared (textually duplicated in the reference) by redoPreintegration
 // (ImuError.cpp:113-261) and propagation (:327-468).  `staticVariant` selects the two places where the
 // copies differ: dalpha_db_g (quirk b, :200 vs :412) and sigma2_v (quirk c, :234 vs :438).
 int integrate(const ImuSamples& s, const ImuParams& prm, int64_t t_start, int64_t t_end,
-              const double sb[9], bool staticVariant, bool withCov, PreintState* st) {
+              const real sb[9], bool staticVariant, bool withCov, PreintState* st) {
   int64_t time = t_start;
   const int64_t end = t_end;
   st->Delta_q = Quat{0, 0, 0, 1};
@@ -326,12 +326,12 @@ int integrate(const ImuSamples& s, const ImuParams& prm, int64_t t_start, int64_
     V3 acc_S_1 = vec3(s.acc[3 * nx], s.acc[3 * nx + 1], s.acc[3 * nx + 2]);
 
     int64_t nexttime = (it + 1 == s.n) ? t_end : s.t[it + 1];
-    double dt = nsToSec(nexttime - time);
+    real dt = nsToSec(nexttime - time);
     if (end < nexttime) {
-      double interval = nsToSec(nexttime - s.t[it]);
+      real interval = nsToSec(nexttime - s.t[it]);
       nexttime = t_end;
       dt = nsToSec(nexttime - time);
-      const double r = dt / interval;
+      const real r = dt / interval;
       omega_S_1 = (1.0 - r) * omega_S_0 + r * omega_S_1;
       acc_S_1 = (1.0 - r) * acc_S_0 + r * acc_S_1;
     }
@@ -339,13 +339,13 @@ int integrate(const ImuSamples& s, const ImuParams& prm, int64_t t_start, int64_
     st->Delta_t += dt;
     if (!hasStarted) {
       hasStarted = true;
-      const double r = dt / nsToSec(nexttime - s.t[it]);
+      const real r = dt / nsToSec(nexttime - s.t[it]);
       omega_S_0 = r * omega_S_0 + (1.0 - r) * omega_S_1;
       acc_S_0 = r * acc_S_0 + (1.0 - r) * acc_S_1;
     }
     // saturation (:153-173)
-    double sigma_g_c = prm.sigma_g_c;
-    double sigma_a_c = prm.sigma_a_c;
+    real sigma_g_c = prm.sigma_g_c;
+    real sigma_a_c = prm.sigma_a_c;
     bool gsat = false, asat = false;
     for (int k = 0; k < 3; ++k) {
       if (std::fabs(omega_S_0[k]) > prm.g_max || std::fabs(omega_S_1[k]) > prm.g_max) gsat = true;
@@ -356,9 +356,9 @@ int integrate(const ImuSamples& s, const ImuParams& prm, int64_t t_start, int64_
 
     // orientation (:177-185)
     const V3 omega_S_true = 0.5 * (omega_S_0 + omega_S_1) - bg;
-    const double theta_half = omega_S_true.norm() * 0.5 * dt;
-    const double sinc_theta_half = sinc(theta_half);
-    const double cos_theta_half = std::cos(theta_half);
+    const real theta_half = omega_S_true.norm() * 0.5 * dt;
+    const real sinc_theta_half = sinc(theta_half);
+    const real cos_theta_half = std::cos(theta_half);
     Quat dq;
     dq.x = sinc_theta_half * omega_S_true[0] * 0.5 * dt;
     dq.y = sinc_theta_half * omega_S_true[1] * 0.5 * dt;
@@ -400,11 +400,11 @@ int integrate(const ImuSamples& s, const ImuParams& prm, int64_t t_start, int64_
       F.setBlock(6, 9, (0.5 * dt) * G);
       F.setBlock(6, 12, (-0.5 * CC) * dt);
       st->P_delta = F * st->P_delta * F.t();
-      const double sigma2_dalpha = dt * sigma_g_c * sigma_g_c;
-      const double sigma2_v = staticVariant ? dt * sigma_a_c * prm.sigma_a_c : dt * sigma_a_c * sigma_a_c;
-      const double sigma2_p = 0.5 * dt * dt * sigma2_v;
-      const double sigma2_b_g = dt * prm.sigma_gw_c * prm.sigma_gw_c;
-      const double sigma2_b_a = dt * prm.sigma_aw_c * prm.sigma_aw_c;
+      const real sigma2_dalpha = dt * sigma_g_c * sigma_g_c;
+      const real sigma2_v = staticVariant ? dt * sigma_a_c * prm.sigma_a_c : dt * sigma_a_c * sigma_a_c;
+      const real sigma2_p = 0.5 * dt * dt * sigma2_v;
+      const real sigma2_b_g = dt * prm.sigma_gw_c * prm.sigma_gw_c;
+      const real sigma2_b_a = dt * prm.sigma_aw_c * prm.sigma_aw_c;
       for (int k = 0; k < 3; ++k) {
         st->P_delta(3 + k, 3 + k) += sigma2_dalpha;
         st->P_delta(6 + k, 6 + k) += sigma2_v;
@@ -428,7 +428,7 @@ int integrate(const ImuSamples& s, const ImuParams& prm, int64_t t_start, int64_
 }  // namespace
 
 int imu_redo_preintegration(const ImuSamples& s, const ImuParams& p, int64_t t0, int64_t t1,
-                            const double sb[9], ImuCache* c) {
+                            const real sb[9], ImuCache* c) {
   if (s.n == 0 || !(s.t[s.n - 1] >= t1)) return -1;  // :87-89
   PreintState st;
   int i = integrate(s, p, t0, t1, sb, /*static*/ false, /*cov*/ true, &st);
@@ -451,18 +451,18 @@ int imu_redo_preintegration(const ImuSamples& s, const ImuParams& p, int64_t t0,
 }
 
 void imu_evaluate(const ImuSamples& s, const ImuParams& p, int64_t t0, int64_t t1, ImuCache* c,
-                  const double pose0[7], const double sb0[9], const double pose1[7], const double sb1[9],
-                  double r[15], double* J0, double* J1, double* J2, double* J3) {
+                  const real pose0[7], const real sb0[9], const real pose1[7], const real sb1[9],
+                  real r[15], real* J0, real* J1, real* J2, real* J3) {
   // ImuError.cpp:520-539
   const Transformation T_WS_0 = Transformation::fromParams(pose0);
   const Transformation T_WS_1 = Transformation::fromParams(pose1);
   const M3 C_WS_0 = T_WS_0.C;
   const M3 C_S0_W = C_WS_0.t();
   // :541-558
-  const double Delta_t = nsToSec(t1 - t0);
+  const real Delta_t = nsToSec(t1 - t0);
   Mat<6, 1> Delta_b;
   for (int k = 0; k < 6; ++k) Delta_b[k] = sb0[3 + k] - c->sb_ref[3 + k];
-  const double nbg = std::sqrt(Delta_b[0] * Delta_b[0] + Delta_b[1] * Delta_b[1] + Delta_b[2] * Delta_b[2]);
+  const real nbg = std::sqrt(Delta_b[0] * Delta_b[0] + Delta_b[1] * Delta_b[1] + Delta_b[2] * Delta_b[2]);
   c->redo = c->redo || (nbg * Delta_t > 0.0001);
   if (c->redo) {
     imu_redo_preintegration(s, p, t0, t1, sb0, c);
@@ -534,8 +534,8 @@ void imu_evaluate(const ImuSamples& s, const ImuParams& p, int64_t t0, int64_t t
   }
 }
 
-int imu_propagation(const ImuSamples& s, const ImuParams& p, double T_WS_io[7], double sb[9],
-                    int64_t t_start, int64_t t_end, double* cov, double* jac) {
+int imu_propagation(const ImuSamples& s, const ImuParams& p, real T_WS_io[7], real sb[9],
+                    int64_t t_start, int64_t t_end, real* cov, real* jac) {
   if (s.n == 0 || !(s.t[s.n - 1] >= t_end)) return -1;  // ImuError.cpp:301-302
   const Transformation T_WS = Transformation::fromParams(T_WS_io);
   const V3 r_0 = T_WS.r;
@@ -546,7 +546,7 @@ int imu_propagation(const ImuSamples& s, const ImuParams& p, double T_WS_io[7], 
   // :470-477
   const V3 g_W = vec3(0, 0, p.g);
   const V3 v = vec3(sb[0], sb[1], sb[2]);
-  const double Dt = st.Delta_t;
+  const real Dt = st.Delta_t;
   Transformation Tn(r_0 + v * Dt + C_WS_0 * st.acc_doubleintegral - (0.5 * Dt * Dt) * g_W,
                     qmul(q_WS_0, st.Delta_q));
   Tn.toParams(T_WS_io);
@@ -580,8 +580,8 @@ int imu_propagation(const ImuSamples& s, const ImuParams& p, double T_WS_io[7], 
 // ===================================================================================================
 // Priors
 // ===================================================================================================
-void pose_error(const double pose[7], const double meas[7], const double sqrtInfo[36], double r[6],
-                double* Jmin) {
+void pose_error(const real pose[7], const real meas[7], const real sqrtInfo[36], real r[6],
+                real* Jmin) {
   // PoseError.cpp:91-104
   const Transformation T_WS = Transformation::fromParams(pose);
   const Transformation T_m = Transformation::fromParams(meas);
@@ -603,8 +603,8 @@ void pose_error(const double pose[7], const double meas[7], const double sqrtInf
   }
 }
 
-void speedbias_error(const double sb[9], const double meas[9], const double sqrtInfo[81], double r[9],
-                     double* Jmin) {
+void speedbias_error(const real sb[9], const real meas[9], const real sqrtInfo[81], real r[9],
+                     real* Jmin) {
   // SpeedAndBiasError.cpp:93-114
   Mat<9, 9> S;
   std::memcpy(S.a, sqrtInfo, sizeof(S.a));
@@ -618,8 +618,8 @@ void speedbias_error(const double sb[9], const double meas[9], const double sqrt
   }
 }
 
-void relative_pose_error(const double pose0[7], const double pose1[7], const double sqrtInfo[36],
-                         double r[6], double* J0min, double* J1min) {
+void relative_pose_error(const real pose0[7], const real pose1[7], const real sqrtInfo[36],
+                         real r[6], real* J0min, real* J1min) {
   // RelativePoseError.cpp:88-107
   const Transformation T0 = Transformation::fromParams(pose0);
   const Transformation T1 = Transformation::fromParams(pose1);

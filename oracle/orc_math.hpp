@@ -1,7 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under okvis_amd/ may include, link or call this.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
 //
-// Tiny fixed-size double-precision matrix helpers for the CPU restatement of the okvis_ceres hot path.
+// Tiny fixed-size matrix helpers for the CPU restatement of the okvis_ceres hot path, in the scalar type `orc::real`:
+// double for liboracle.so (the checker), long double (x87 extended, 64-bit mantissa) for liboracle_ld.so — the same sources
+// built with -DORC_LONG_DOUBLE, the referee that says which side of a 1e-6 disagreement between the GPU and the fp64 oracle
+// drifted (tests/test_oracle_referee.py).  The C entry points take and return double in both builds.
 // Eigen is not available in this environment, so the handful of operations the reference uses are
 // re-stated here (row-major storage, plain loops).
 #pragma once
@@ -12,13 +15,19 @@
 
 namespace orc {
 
+#ifdef ORC_LONG_DOUBLE
+typedef long double real;
+#else
+typedef double real;
+#endif
+
 template <int R, int C>
 struct Mat {
-  double a[R * C];
-  double& operator()(int i, int j) { return a[i * C + j]; }
-  double operator()(int i, int j) const { return a[i * C + j]; }
-  double& operator[](int i) { return a[i]; }
-  double operator[](int i) const { return a[i]; }
+  real a[R * C];
+  real& operator()(int i, int j) { return a[i * C + j]; }
+  real operator()(int i, int j) const { return a[i * C + j]; }
+  real& operator[](int i) { return a[i]; }
+  real operator[](int i) const { return a[i]; }
   static Mat Zero() {
     Mat m;
     for (int i = 0; i < R * C; ++i) m.a[i] = 0.0;
@@ -47,12 +56,12 @@ struct Mat {
     for (int i = 0; i < R2; ++i)
       for (int j = 0; j < C2; ++j) (*this)(r0 + i, c0 + j) = b(i, j);
   }
-  double squaredNorm() const {
-    double s = 0;
+  real squaredNorm() const {
+    real s = 0;
     for (int i = 0; i < R * C; ++i) s += a[i] * a[i];
     return s;
   }
-  double norm() const { return std::sqrt(squaredNorm()); }
+  real norm() const { return std::sqrt(squaredNorm()); }
 };
 
 template <int R, int K, int C>
@@ -60,7 +69,7 @@ inline Mat<R, C> operator*(const Mat<R, K>& A, const Mat<K, C>& B) {
   Mat<R, C> m;
   for (int i = 0; i < R; ++i)
     for (int j = 0; j < C; ++j) {
-      double s = 0;
+      real s = 0;
       for (int k = 0; k < K; ++k) s += A(i, k) * B(k, j);
       m(i, j) = s;
     }
@@ -85,13 +94,13 @@ inline Mat<R, C> operator-(const Mat<R, C>& A) {
   return m;
 }
 template <int R, int C>
-inline Mat<R, C> operator*(double s, const Mat<R, C>& A) {
+inline Mat<R, C> operator*(real s, const Mat<R, C>& A) {
   Mat<R, C> m;
   for (int i = 0; i < R * C; ++i) m.a[i] = s * A.a[i];
   return m;
 }
 template <int R, int C>
-inline Mat<R, C> operator*(const Mat<R, C>& A, double s) {
+inline Mat<R, C> operator*(const Mat<R, C>& A, real s) {
   return s * A;
 }
 
@@ -100,7 +109,7 @@ typedef Mat<4, 1> V4;
 typedef Mat<3, 3> M3;
 typedef Mat<4, 4> M4;
 
-inline V3 vec3(double x, double y, double z) {
+inline V3 vec3(real x, real y, real z) {
   V3 v;
   v[0] = x;
   v[1] = y;
@@ -119,7 +128,7 @@ inline M3 crossMx(const V3& v) {
 
 // Quaternion, Eigen coefficient order (x,y,z,w), Hamilton product (reference README.md:23-25).
 struct Quat {
-  double x, y, z, w;
+  real x, y, z, w;
 };
 inline Quat qmul(const Quat& a, const Quat& b) {
   Quat r;
@@ -130,24 +139,24 @@ inline Quat qmul(const Quat& a, const Quat& b) {
   return r;
 }
 inline Quat qconj(const Quat& q) { return Quat{-q.x, -q.y, -q.z, q.w}; }
-inline double qnorm2(const Quat& q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
+inline real qnorm2(const Quat& q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
 // Eigen::Quaternion::inverse(): conjugate / squaredNorm
 inline Quat qinv(const Quat& q) {
-  double n2 = qnorm2(q);
+  real n2 = qnorm2(q);
   Quat c = qconj(q);
   return Quat{c.x / n2, c.y / n2, c.z / n2, c.w / n2};
 }
 inline Quat qnormalized(const Quat& q) {
-  double n = std::sqrt(qnorm2(q));
+  real n = std::sqrt(qnorm2(q));
   return Quat{q.x / n, q.y / n, q.z / n, q.w / n};
 }
 // Eigen::QuaternionBase::toRotationMatrix() — NOT normalising (matters: ReprojectionError uses the raw
 // parameter quaternion, implementation/ReprojectionError.hpp:95-114).
 inline M3 qrot(const Quat& q) {
-  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
-  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
-  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
-  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  const real tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const real twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const real txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const real tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
   M3 R;
   R(0, 0) = 1 - (tyy + tzz); R(0, 1) = txy - twz;       R(0, 2) = txz + twy;
   R(1, 0) = txy + twz;       R(1, 1) = 1 - (txx + tzz); R(1, 2) = tyz - twx;
@@ -173,28 +182,28 @@ inline M4 qoplusMat(const Quat& q) {
 }
 
 // okvis::kinematics::sinc (implementation/Transformation.hpp:45-57) == ode::sinc (ode/ode.hpp:58-70)
-inline double sinc(double x) {
+inline real sinc(real x) {
   if (std::fabs(x) > 1e-6) return std::sin(x) / x;
-  const double c_2 = 1.0 / 6.0, c_4 = 1.0 / 120.0, c_6 = 1.0 / 5040.0;
-  const double x_2 = x * x, x_4 = x_2 * x_2, x_6 = x_2 * x_2 * x_2;
+  const real c_2 = 1.0 / 6.0, c_4 = 1.0 / 120.0, c_6 = 1.0 / 5040.0;
+  const real x_2 = x * x, x_4 = x_2 * x_2, x_6 = x_2 * x_2 * x_2;
   return 1.0 - c_2 * x_2 + c_4 * x_4 - c_6 * x_6;
 }
 // okvis::kinematics::deltaQ (implementation/Transformation.hpp:59-66)
 inline Quat deltaQ(const V3& dAlpha) {
-  double halfnorm = 0.5 * dAlpha.norm();
-  double s = sinc(halfnorm) * 0.5;
+  real halfnorm = 0.5 * dAlpha.norm();
+  real s = sinc(halfnorm) * 0.5;
   return Quat{s * dAlpha[0], s * dAlpha[1], s * dAlpha[2], std::cos(halfnorm)};
 }
 // okvis::kinematics::rightJacobian (implementation/Transformation.hpp:69-82)
 inline M3 rightJacobian(const V3& PhiVec) {
-  const double Phi = PhiVec.norm();
+  const real Phi = PhiVec.norm();
   M3 ret = M3::Identity();
   const M3 Phi_x = crossMx(PhiVec);
   const M3 Phi_x2 = Phi_x * Phi_x;
   if (Phi < 1.0e-4) {
     ret = ret + (-0.5) * Phi_x + (1.0 / 6.0) * Phi_x2;
   } else {
-    const double Phi2 = Phi * Phi, Phi3 = Phi2 * Phi;
+    const real Phi2 = Phi * Phi, Phi3 = Phi2 * Phi;
     ret = ret + (-(1.0 - std::cos(Phi)) / Phi2) * Phi_x + ((Phi - std::sin(Phi)) / Phi3) * Phi_x2;
   }
   return ret;
@@ -215,7 +224,7 @@ struct Transformation {
     q = qnormalized(q_AB);
     C = qrot(q);
   }
-  static Transformation fromParams(const double* p) {  // x,y,z,qx,qy,qz,qw
+  static Transformation fromParams(const real* p) {  // x,y,z,qx,qy,qz,qw
     return Transformation(vec3(p[0], p[1], p[2]), Quat{p[3], p[4], p[5], p[6]});
   }
   Transformation inverse() const {  // (:170-173)
@@ -224,16 +233,16 @@ struct Transformation {
   Transformation operator*(const Transformation& rhs) const {  // (:216-220)
     return Transformation(C * rhs.r + r, qmul(q, rhs.q));
   }
-  void toParams(double* p) const {
+  void toParams(real* p) const {
     p[0] = r[0]; p[1] = r[1]; p[2] = r[2];
     p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w;
   }
   // Transformation::oplus (:246-258)
-  void oplus(const double* delta) {
+  void oplus(const real* delta) {
     r[0] += delta[0]; r[1] += delta[1]; r[2] += delta[2];
     V3 da = vec3(delta[3], delta[4], delta[5]);
-    double halfnorm = 0.5 * da.norm();
-    double s = sinc(halfnorm) * 0.5;
+    real halfnorm = 0.5 * da.norm();
+    real s = sinc(halfnorm) * 0.5;
     Quat dq{s * da[0], s * da[1], s * da[2], std::cos(halfnorm)};
     q = qnormalized(qmul(dq, q));
     C = qrot(q);
@@ -245,15 +254,15 @@ struct Transformation {
 // first-pose information diag(1e8,1e8,1e8,0,0,1e8) (Estimator.cpp:240-242, PoseError.cpp:70-76):
 // matrixL() = diag(1e4,1e4,1e4,0,0,1e8).  Returns -1 on success or the failing column index.
 // A (n x n row-major) is overwritten: lower triangle = L.
-inline int llt_eigen_inplace(double* A, int n) {
+inline int llt_eigen_inplace(real* A, int n) {
   for (int k = 0; k < n; ++k) {
-    double x = A[k * n + k];
+    real x = A[k * n + k];
     for (int j = 0; j < k; ++j) x -= A[k * n + j] * A[k * n + j];
     if (x <= 0.0) return k;
     x = std::sqrt(x);
     A[k * n + k] = x;
     for (int i = k + 1; i < n; ++i) {
-      double s = A[i * n + k];
+      real s = A[i * n + k];
       for (int j = 0; j < k; ++j) s -= A[i * n + j] * A[k * n + j];
       A[i * n + k] = s / x;
     }
@@ -262,8 +271,8 @@ inline int llt_eigen_inplace(double* A, int n) {
 }
 // squareRootInformation_ = lltOfInformation.matrixL().transpose()  (e.g. PoseError.cpp:74-75):
 // upper-triangular U with U^T U = information; out row-major n x n.
-inline void sqrt_information_upper(const double* info, int n, double* out) {
-  std::vector<double> L(info, info + n * n);
+inline void sqrt_information_upper(const real* info, int n, real* out) {
+  std::vector<real> L(info, info + n * n);
   llt_eigen_inplace(L.data(), n);
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) out[i * n + j] = (j >= i) ? L[j * n + i] : 0.0;
@@ -271,13 +280,13 @@ inline void sqrt_information_upper(const double* info, int n, double* out) {
 
 // General dense inverse by LU with partial pivoting (what Eigen's .inverse() does for n>4).
 // A row-major n x n -> Ainv. Returns false if singular.
-inline bool inverse_lu(const double* A, int n, double* Ainv) {
-  std::vector<double> M(A, A + n * n);
+inline bool inverse_lu(const real* A, int n, real* Ainv) {
+  std::vector<real> M(A, A + n * n);
   std::vector<int> piv(n);
   for (int i = 0; i < n; ++i) piv[i] = i;
   for (int k = 0; k < n; ++k) {
     int p = k;
-    double best = std::fabs(M[k * n + k]);
+    real best = std::fabs(M[k * n + k]);
     for (int i = k + 1; i < n; ++i)
       if (std::fabs(M[i * n + k]) > best) {
         best = std::fabs(M[i * n + k]);
@@ -289,21 +298,21 @@ inline bool inverse_lu(const double* A, int n, double* Ainv) {
       std::swap(piv[k], piv[p]);
     }
     for (int i = k + 1; i < n; ++i) {
-      double f = M[i * n + k] / M[k * n + k];
+      real f = M[i * n + k] / M[k * n + k];
       M[i * n + k] = f;
       for (int j = k + 1; j < n; ++j) M[i * n + j] -= f * M[k * n + j];
     }
   }
   // solve for each unit vector
   for (int c = 0; c < n; ++c) {
-    std::vector<double> y(n);
+    std::vector<real> y(n);
     for (int i = 0; i < n; ++i) {
-      double s = (piv[i] == c) ? 1.0 : 0.0;
+      real s = (piv[i] == c) ? 1.0 : 0.0;
       for (int j = 0; j < i; ++j) s -= M[i * n + j] * y[j];
       y[i] = s;
     }
     for (int i = n - 1; i >= 0; --i) {
-      double s = y[i];
+      real s = y[i];
       for (int j = i + 1; j < n; ++j) s -= M[i * n + j] * Ainv[j * n + c];
       Ainv[i * n + c] = s / M[i * n + i];
     }
@@ -311,16 +320,16 @@ inline bool inverse_lu(const double* A, int n, double* Ainv) {
   return true;
 }
 
-// okvis::Duration::toSec() of a signed nanosecond difference: (double)sec + 1e-9*(double)nsec with
+// okvis::Duration::toSec() of a signed nanosecond difference: (real)sec + 1e-9*(real)nsec with
 // nsec normalised into [0,1e9) (okvis_time/include/okvis/Duration.hpp:111-113, src/Duration.cpp:55-73).
-inline double nsToSec(int64_t ns) {
+inline real nsToSec(int64_t ns) {
   int64_t sec = ns / 1000000000LL;
   int64_t nsec = ns % 1000000000LL;
   if (nsec < 0) {
     nsec += 1000000000LL;
     --sec;
   }
-  return (double)sec + 1e-9 * (double)nsec;
+  return (real)sec + 1e-9 * (real)nsec;
 }
 
 }  // namespace orc

@@ -26,22 +26,22 @@ static int g_threads = 1;  // > 1: OpenMP CPU-baseline mode (bench.py only), see
 struct orc_window {
   // ---- copied structure ----
   int n_pose, n_sb, n_lm, n_cam, n_obs, n_imu, n_pprior, n_sbprior, n_relpose;
-  std::vector<double> pose, sb, lm;
+  std::vector<real> pose, sb, lm;
   std::vector<uint8_t> pose_fixed, sb_fixed;
   std::vector<Camera> cams;
   std::vector<int> obs_lm, obs_pose, obs_ext, obs_cam;
-  std::vector<double> obs_uv, obs_sqrtw;
-  double cauchy_b;
+  std::vector<real> obs_uv, obs_sqrtw;
+  real cauchy_b;
   std::vector<int> imu_pose0, imu_sb0, imu_pose1, imu_sb1, imu_s_begin, imu_s_count;
   std::vector<int64_t> imu_t0, imu_t1, imu_s_t;
-  std::vector<double> imu_s_gyr, imu_s_acc;
+  std::vector<real> imu_s_gyr, imu_s_acc;
   ImuParams imu_params;
   std::vector<ImuCache> imu_cache;
   std::vector<int> pprior_pose, sbprior_sb, rel_pose0, rel_pose1;
-  std::vector<double> pprior_meas, pprior_sqrtinfo, sbprior_meas, sbprior_sqrtinfo, rel_sqrtinfo;
+  std::vector<real> pprior_meas, pprior_sqrtinfo, sbprior_meas, sbprior_sqrtinfo, rel_sqrtinfo;
   int marg_dim, marg_nblocks;
   std::vector<int> marg_block_type, marg_block_idx, marg_block_off;
-  std::vector<double> marg_J, marg_e0, marg_lin;
+  std::vector<real> marg_J, marg_e0, marg_lin;
   bool marg_exact = true;
 
   // ---- derived ordering ----
@@ -51,11 +51,11 @@ struct orc_window {
   int n_pair = 0;
 
   // ---- linearisation at the accepted state ----
-  std::vector<double> V, b, Hq, W, U, g, obs_r, imu_r, quality;
-  double cost = 0;
+  std::vector<real> V, b, Hq, W, U, g, obs_r, imu_r, quality;
+  real cost = 0;
   // ---- last solve ----
-  std::vector<double> S, rhs, step_p, step_l, Dp2, Dl2;
-  double lambda = 0;
+  std::vector<real> S, rhs, step_p, step_l, Dp2, Dl2;
+  real lambda = 0;
 
   ImuSamples samples(int f) const {
     ImuSamples s;
@@ -73,6 +73,7 @@ template <class T>
 std::vector<T> copyv(const T* p, size_t n) {
   return p ? std::vector<T>(p, p + n) : std::vector<T>(n);
 }
+std::vector<real> copyr(const double* p, size_t n) { return p ? std::vector<real>(p, p + n) : std::vector<real>(n); }
 
 void build_ordering(orc_window* h) {
   h->pose_off.assign(h->n_pose, -1);
@@ -127,18 +128,18 @@ void build_ordering(orc_window* h) {
 }
 
 // accumulate a factor's J^T J and J^T r into the dense pose-side system
-void add_factor_to(double* U, double* g, int D, int nres, const double* r, int nb, const int* off, const int* dim,
-                   const double* const* J);
-void add_factor(orc_window* h, int nres, const double* r, int nb, const int* off, const int* dim,
-                const double* const* J) {
+void add_factor_to(real* U, real* g, int D, int nres, const real* r, int nb, const int* off, const int* dim,
+                   const real* const* J);
+void add_factor(orc_window* h, int nres, const real* r, int nb, const int* off, const int* dim,
+                const real* const* J) {
   add_factor_to(h->U.data(), h->g.data(), h->D, nres, r, nb, off, dim, J);
 }
-void add_factor_to(double* U, double* g, int D, int nres, const double* r, int nb, const int* off, const int* dim,
-                   const double* const* J) {
+void add_factor_to(real* U, real* g, int D, int nres, const real* r, int nb, const int* off, const int* dim,
+                   const real* const* J) {
   for (int a = 0; a < nb; ++a) {
     if (off[a] < 0) continue;
     for (int i = 0; i < dim[a]; ++i) {
-      double s = 0;
+      real s = 0;
       for (int k = 0; k < nres; ++k) s += J[a][k * dim[a] + i] * r[k];
       g[off[a] + i] += s;
     }
@@ -146,7 +147,7 @@ void add_factor_to(double* U, double* g, int D, int nres, const double* r, int n
       if (off[bb] < 0) continue;
       for (int i = 0; i < dim[a]; ++i)
         for (int j = 0; j < dim[bb]; ++j) {
-          double s = 0;
+          real s = 0;
           for (int k = 0; k < nres; ++k) s += J[a][k * dim[a] + i] * J[bb][k * dim[bb] + j];
           U[(size_t)(off[a] + i) * D + off[bb] + j] += s;
         }
@@ -157,19 +158,19 @@ void add_factor_to(double* U, double* g, int D, int nres, const double* r, int n
 // reprojection residuals o0 <= o < o1 (ReprojectionError + CauchyLoss, implementation/Estimator.hpp:68-82); the
 // landmark-side sums (V, b, Hq, W) go to the window (observations are sorted by landmark: ranges cut at landmark
 // boundaries never share an entry), the pose-side sums to U / g of the caller (per thread in the OpenMP baseline)
-static void reprojection_range(orc_window* h, bool lin, int o0, int o1, double* U, double* g, double* cost) {
+static void reprojection_range(orc_window* h, bool lin, int o0, int o1, real* U, real* g, real* cost) {
   static const int ut[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
   for (int o = o0; o < o1; ++o) {
     const int l = h->obs_lm[o], ip = h->obs_pose[o], ie = h->obs_ext[o];
-    const double w = h->obs_sqrtw[o];
-    const double sqrtInfo[4] = {w, 0, 0, w};
+    const real w = h->obs_sqrtw[o];
+    const real sqrtInfo[4] = {w, 0, 0, w};
     ReprojOut out;
     reprojection_error(&h->pose[7 * ip], &h->lm[4 * l], &h->pose[7 * ie], h->cams[h->obs_cam[o]],
                        &h->obs_uv[2 * o], sqrtInfo, lin, &out);
-    const double s = out.r[0] * out.r[0] + out.r[1] * out.r[1];
-    double sr = 1.0;
+    const real s = out.r[0] * out.r[0] + out.r[1] * out.r[1];
+    real sr = 1.0;
     if (h->cauchy_b > 0) {
-      double rho[3];
+      real rho[3];
       cauchy_loss(h->cauchy_b, s, rho);
       *cost += 0.5 * rho[0];
       sr = std::sqrt(rho[1]);  // Corrector: rho'' <= 0 -> residual_scaling = sqrt(rho'), alpha = 0
@@ -182,7 +183,7 @@ static void reprojection_range(orc_window* h, bool lin, int o0, int o1, double* 
     // un-robustified landmark Hessian (Map::getLhs, Map.cpp:101-156)
     for (int e = 0; e < 6; ++e)
       h->Hq[6 * l + e] += out.Jl(0, ut[e][0]) * out.Jl(0, ut[e][1]) + out.Jl(1, ut[e][0]) * out.Jl(1, ut[e][1]);
-    const double rt[2] = {sr * out.r[0], sr * out.r[1]};
+    const real rt[2] = {sr * out.r[0], sr * out.r[1]};
     Mat<2, 6> Jp = sr * out.Jp;
     Mat<2, 3> Jl = sr * out.Jl;
     Mat<2, 6> Je = sr * out.Je;
@@ -198,13 +199,13 @@ static void reprojection_range(orc_window* h, bool lin, int o0, int o1, double* 
         for (int j = 0; j < 3; ++j) h->W[18 * pe + 3 * i + j] += Je(0, i) * Jl(0, j) + Je(1, i) * Jl(1, j);
     const int off[2] = {h->pose_off[ip], h->pose_off[ie]};
     const int dim[2] = {6, 6};
-    const double* J[2] = {Jp.a, Je.a};
+    const real* J[2] = {Jp.a, Je.a};
     add_factor_to(U, g, h->D, 2, rt, 2, off, dim, J);
   }
 }
 
 // Evaluate all error terms at the current state.  lin=true additionally fills the linearisation.
-double evaluate(orc_window* h, bool lin) {
+real evaluate(orc_window* h, bool lin) {
   const int D = h->D;
   if (lin) {
     h->V.assign(6 * (size_t)h->n_lm, 0.0);
@@ -216,7 +217,7 @@ double evaluate(orc_window* h, bool lin) {
     h->obs_r.assign(2 * (size_t)h->n_obs, 0.0);
     h->imu_r.assign(15 * (size_t)h->n_imu, 0.0);
   }
-  double cost = 0;
+  real cost = 0;
   // ---- reprojection ----
   if (g_threads <= 1 || h->n_lm < 2 * g_threads) {
     reprojection_range(h, lin, 0, h->n_obs, h->U.data(), h->g.data(), &cost);
@@ -225,8 +226,8 @@ double evaluate(orc_window* h, bool lin) {
     // CPU-baseline mode (orc_set_threads): landmark ranges per thread, private pose-side accumulators summed in thread
     // order.  Same arithmetic per observation; the order of the pose-side sums differs from the serial path.
     const int T = g_threads;
-    std::vector<std::vector<double>> Ut(T), gt(T);
-    std::vector<double> ct(T, 0.0);
+    std::vector<std::vector<real>> Ut(T), gt(T);
+    std::vector<real> ct(T, 0.0);
 #pragma omp parallel num_threads(T)
     {
       const int t = omp_get_thread_num();
@@ -248,12 +249,12 @@ double evaluate(orc_window* h, bool lin) {
   }
   // ---- IMU ----
   for (int f = 0; f < h->n_imu; ++f) {
-    double r[15], J0[90], J1[135], J2[90], J3[135];
+    real r[15], J0[90], J1[135], J2[90], J3[135];
     imu_evaluate(h->samples(f), h->imu_params, h->imu_t0[f], h->imu_t1[f], &h->imu_cache[f],
                  &h->pose[7 * h->imu_pose0[f]], &h->sb[9 * h->imu_sb0[f]], &h->pose[7 * h->imu_pose1[f]],
                  &h->sb[9 * h->imu_sb1[f]], r, lin ? J0 : nullptr, lin ? J1 : nullptr,
                  lin ? J2 : nullptr, lin ? J3 : nullptr);
-    double s = 0;
+    real s = 0;
     for (int k = 0; k < 15; ++k) s += r[k] * r[k];
     cost += 0.5 * s;
     if (!lin) continue;
@@ -261,59 +262,59 @@ double evaluate(orc_window* h, bool lin) {
     const int off[4] = {h->pose_off[h->imu_pose0[f]], h->sb_off[h->imu_sb0[f]],
                         h->pose_off[h->imu_pose1[f]], h->sb_off[h->imu_sb1[f]]};
     const int dim[4] = {6, 9, 6, 9};
-    const double* J[4] = {J0, J1, J2, J3};
+    const real* J[4] = {J0, J1, J2, J3};
     add_factor(h, 15, r, 4, off, dim, J);
   }
   // ---- pose priors ----
   for (int f = 0; f < h->n_pprior; ++f) {
-    double r[6], J[36];
+    real r[6], J[36];
     const int ip = h->pprior_pose[f];
     pose_error(&h->pose[7 * ip], &h->pprior_meas[7 * f], &h->pprior_sqrtinfo[36 * f], r, lin ? J : nullptr);
-    double s = 0;
+    real s = 0;
     for (int k = 0; k < 6; ++k) s += r[k] * r[k];
     cost += 0.5 * s;
     if (!lin) continue;
     const int off[1] = {h->pose_off[ip]};
     const int dim[1] = {6};
-    const double* Jp[1] = {J};
+    const real* Jp[1] = {J};
     add_factor(h, 6, r, 1, off, dim, Jp);
   }
   // ---- speed/bias priors ----
   for (int f = 0; f < h->n_sbprior; ++f) {
-    double r[9], J[81];
+    real r[9], J[81];
     const int is = h->sbprior_sb[f];
     speedbias_error(&h->sb[9 * is], &h->sbprior_meas[9 * f], &h->sbprior_sqrtinfo[81 * f], r, lin ? J : nullptr);
-    double s = 0;
+    real s = 0;
     for (int k = 0; k < 9; ++k) s += r[k] * r[k];
     cost += 0.5 * s;
     if (!lin) continue;
     const int off[1] = {h->sb_off[is]};
     const int dim[1] = {9};
-    const double* Jp[1] = {J};
+    const real* Jp[1] = {J};
     add_factor(h, 9, r, 1, off, dim, Jp);
   }
   // ---- relative pose ----
   for (int f = 0; f < h->n_relpose; ++f) {
-    double r[6], J0[36], J1[36];
+    real r[6], J0[36], J1[36];
     const int i0 = h->rel_pose0[f], i1 = h->rel_pose1[f];
     relative_pose_error(&h->pose[7 * i0], &h->pose[7 * i1], &h->rel_sqrtinfo[36 * f], r, lin ? J0 : nullptr,
                         lin ? J1 : nullptr);
-    double s = 0;
+    real s = 0;
     for (int k = 0; k < 6; ++k) s += r[k] * r[k];
     cost += 0.5 * s;
     if (!lin) continue;
     const int off[2] = {h->pose_off[i0], h->pose_off[i1]};
     const int dim[2] = {6, 6};
-    const double* Jp[2] = {J0, J1};
+    const real* Jp[2] = {J0, J1};
     add_factor(h, 6, r, 2, off, dim, Jp);
   }
   // ---- marginalisation prior (MarginalizationError.cpp:867-946) ----
   if (h->marg_dim > 0) {
     const int Dm = h->marg_dim, nb = h->marg_nblocks;
-    std::vector<double> dchi(Dm, 0.0), e(h->marg_e0);
-    std::vector<std::vector<double>> Jb(nb);
+    std::vector<real> dchi(Dm, 0.0), e(h->marg_e0);
+    std::vector<std::vector<real>> Jb(nb);
     std::vector<int> off(nb), dim(nb);
-    std::vector<const double*> Jp(nb);
+    std::vector<const real*> Jp(nb);
     for (int i = 0; i < nb; ++i) {
       const int idx = h->marg_block_idx[i], o = h->marg_block_off[i];
       M3 Mrot = M3::Identity();
@@ -326,7 +327,7 @@ double evaluate(orc_window* h, bool lin) {
             // what Ceres multiplies together: J_min * lift(x_lin) (:931-938) * plusJacobian(x)
             // = J_min * blkdiag(I, oplus(q (x) q_lin^-1)[0:3,0:3])
             Quat q{h->pose[7 * idx + 3], h->pose[7 * idx + 4], h->pose[7 * idx + 5], h->pose[7 * idx + 6]};
-            const double* xl = &h->marg_lin[9 * i];
+            const real* xl = &h->marg_lin[9 * i];
             Quat ql_inv{-xl[3], -xl[4], -xl[5], xl[6]};
             Mrot = qoplusMat(qmul(q, ql_inv)).block<3, 3>(0, 0);
           }
@@ -340,7 +341,7 @@ double evaluate(orc_window* h, bool lin) {
       if (lin) {
         Jb[i].assign((size_t)Dm * dim[i], 0.0);
         for (int r = 0; r < Dm; ++r) {
-          const double* Jr = &h->marg_J[(size_t)r * Dm + o];
+          const real* Jr = &h->marg_J[(size_t)r * Dm + o];
           if (dim[i] == 6) {
             for (int k = 0; k < 3; ++k) Jb[i][r * 6 + k] = Jr[k];
             for (int k = 0; k < 3; ++k)
@@ -352,9 +353,9 @@ double evaluate(orc_window* h, bool lin) {
         Jp[i] = Jb[i].data();
       }
     }
-    double s = 0;
+    real s = 0;
     for (int r = 0; r < Dm; ++r) {
-      double acc = 0;
+      real acc = 0;
       for (int c = 0; c < Dm; ++c) acc += h->marg_J[(size_t)r * Dm + c] * dchi[c];
       e[r] += acc;
       s += e[r] * e[r];
@@ -366,14 +367,14 @@ double evaluate(orc_window* h, bool lin) {
   return cost;
 }
 
-inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+inline real clampd(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // inverse of a symmetric 3x3 given upper-tri (00,01,02,11,12,22) via cofactors
-void inv3sym(const double v[6], double out[6]) {
-  const double a = v[0], b = v[1], c = v[2], d = v[3], e = v[4], f = v[5];
-  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-  const double det = a * c00 + b * c01 + c * c02;
-  const double id = 1.0 / det;
+void inv3sym(const real v[6], real out[6]) {
+  const real a = v[0], b = v[1], c = v[2], d = v[3], e = v[4], f = v[5];
+  const real c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const real det = a * c00 + b * c01 + c * c02;
+  const real id = 1.0 / det;
   out[0] = c00 * id;
   out[1] = c01 * id;
   out[2] = c02 * id;
@@ -383,28 +384,28 @@ void inv3sym(const double v[6], double out[6]) {
 }
 
 // dense Cholesky solve A x = b (A row-major n x n, SPD). returns false if not PD.
-bool chol_solve(std::vector<double> A, int n, const std::vector<double>& b, std::vector<double>* x) {
+bool chol_solve(std::vector<real> A, int n, const std::vector<real>& b, std::vector<real>* x) {
   for (int k = 0; k < n; ++k) {
-    double d = A[(size_t)k * n + k];
+    real d = A[(size_t)k * n + k];
     for (int j = 0; j < k; ++j) d -= A[(size_t)k * n + j] * A[(size_t)k * n + j];
     if (!(d > 0.0)) return false;
     d = std::sqrt(d);
     A[(size_t)k * n + k] = d;
     for (int i = k + 1; i < n; ++i) {
-      double s = A[(size_t)i * n + k];
+      real s = A[(size_t)i * n + k];
       for (int j = 0; j < k; ++j) s -= A[(size_t)i * n + j] * A[(size_t)k * n + j];
       A[(size_t)i * n + k] = s / d;
     }
   }
-  std::vector<double> y(n);
+  std::vector<real> y(n);
   for (int i = 0; i < n; ++i) {
-    double s = b[i];
+    real s = b[i];
     for (int j = 0; j < i; ++j) s -= A[(size_t)i * n + j] * y[j];
     y[i] = s / A[(size_t)i * n + i];
   }
   x->assign(n, 0.0);
   for (int i = n - 1; i >= 0; --i) {
-    double s = y[i];
+    real s = y[i];
     for (int j = i + 1; j < n; ++j) s -= A[(size_t)j * n + i] * (*x)[j];
     (*x)[i] = s / A[(size_t)i * n + i];
   }
@@ -413,7 +414,7 @@ bool chol_solve(std::vector<double> A, int n, const std::vector<double>& b, std:
 
 // (H + lambda Dd) delta = -g via landmark Schur complement, Dd = diag(h->Dp2, h->Dl2) given by the caller.
 // Returns false if S is not PD.
-bool solve_damped(orc_window* h, double lambda) {
+bool solve_damped(orc_window* h, real lambda) {
   const int D = h->D;
   h->lambda = lambda;
   h->S = h->U;
@@ -422,21 +423,21 @@ bool solve_damped(orc_window* h, double lambda) {
     h->S[(size_t)i * D + i] += lambda * h->Dp2[i];
     h->rhs[i] = -h->g[i];
   }
-  std::vector<double> Vinv(6 * (size_t)h->n_lm);
-  auto reduce_range = [&](int l0, int l1, double* S_, double* rhs_) {
+  std::vector<real> Vinv(6 * (size_t)h->n_lm);
+  auto reduce_range = [&](int l0, int l1, real* S_, real* rhs_) {
     for (int l = l0; l < l1; ++l) {
-    double v[6];
+    real v[6];
     for (int e = 0; e < 6; ++e) v[e] = h->V[6 * l + e];
     v[0] += lambda * h->Dl2[3 * l + 0];
     v[3] += lambda * h->Dl2[3 * l + 1];
     v[5] += lambda * h->Dl2[3 * l + 2];
-    double* vi = &Vinv[6 * l];
+    real* vi = &Vinv[6 * l];
     inv3sym(v, vi);
-    const double Vi[3][3] = {{vi[0], vi[1], vi[2]}, {vi[1], vi[3], vi[4]}, {vi[2], vi[4], vi[5]}};
+    const real Vi[3][3] = {{vi[0], vi[1], vi[2]}, {vi[1], vi[3], vi[4]}, {vi[2], vi[4], vi[5]}};
     const int p0 = h->lm_pair_begin[l], p1 = h->lm_pair_begin[l + 1];
     for (int pa = p0; pa < p1; ++pa) {
-      double Y[18];
-      const double* Wa = &h->W[18 * pa];
+      real Y[18];
+      const real* Wa = &h->W[18 * pa];
       for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 3; ++j)
           Y[3 * i + j] = Wa[3 * i + 0] * Vi[0][j] + Wa[3 * i + 1] * Vi[1][j] + Wa[3 * i + 2] * Vi[2][j];
@@ -444,7 +445,7 @@ bool solve_damped(orc_window* h, double lambda) {
       for (int i = 0; i < 6; ++i)
         rhs_[oa + i] += Y[3 * i] * h->b[3 * l] + Y[3 * i + 1] * h->b[3 * l + 1] + Y[3 * i + 2] * h->b[3 * l + 2];
       for (int pb = p0; pb < p1; ++pb) {
-        const double* Wb = &h->W[18 * pb];
+        const real* Wb = &h->W[18 * pb];
         const int ob = h->pose_off[h->pair_block[pb]];
         for (int i = 0; i < 6; ++i)
           for (int j = 0; j < 6; ++j)
@@ -459,7 +460,7 @@ bool solve_damped(orc_window* h, double lambda) {
   } else {
 #ifdef _OPENMP
     const int T = g_threads;   // CPU-baseline mode: private partial reduced systems, summed in thread order
-    std::vector<std::vector<double>> St(T), rt(T);
+    std::vector<std::vector<real>> St(T), rt(T);
 #pragma omp parallel num_threads(T)
     {
       const int t = omp_get_thread_num();
@@ -477,14 +478,14 @@ bool solve_damped(orc_window* h, double lambda) {
   // back-substitution: delta_l = -Vinv (g_l + W^T delta_p)
   h->step_l.assign(3 * (size_t)h->n_lm, 0.0);
   for (int l = 0; l < h->n_lm; ++l) {
-    double t[3] = {h->b[3 * l], h->b[3 * l + 1], h->b[3 * l + 2]};
+    real t[3] = {h->b[3 * l], h->b[3 * l + 1], h->b[3 * l + 2]};
     for (int p = h->lm_pair_begin[l]; p < h->lm_pair_begin[l + 1]; ++p) {
-      const double* Wp = &h->W[18 * p];
-      const double* dp = &h->step_p[h->pose_off[h->pair_block[p]]];
+      const real* Wp = &h->W[18 * p];
+      const real* dp = &h->step_p[h->pose_off[h->pair_block[p]]];
       for (int j = 0; j < 3; ++j)
         for (int i = 0; i < 6; ++i) t[j] += Wp[3 * i + j] * dp[i];
     }
-    const double* vi = &Vinv[6 * l];
+    const real* vi = &Vinv[6 * l];
     h->step_l[3 * l + 0] = -(vi[0] * t[0] + vi[1] * t[1] + vi[2] * t[2]);
     h->step_l[3 * l + 1] = -(vi[1] * t[0] + vi[3] * t[1] + vi[4] * t[2]);
     h->step_l[3 * l + 2] = -(vi[2] * t[0] + vi[4] * t[1] + vi[5] * t[2]);
@@ -493,7 +494,7 @@ bool solve_damped(orc_window* h, double lambda) {
 }
 
 // LevenbergMarquardtStrategy: D^2 = clamp(diag J^T J, min_lm_diagonal, max_lm_diagonal), damping D^2 / radius
-bool solve(orc_window* h, double radius, const okvis_ba_options& opt) {
+bool solve(orc_window* h, real radius, const okvis_ba_options& opt) {
   h->Dp2.assign(h->D, 0.0);
   h->Dl2.assign(3 * (size_t)h->n_lm, 0.0);
   for (int i = 0; i < h->D; ++i) h->Dp2[i] = clampd(h->U[(size_t)i * h->D + i], opt.min_lm_diagonal, opt.max_lm_diagonal);
@@ -503,7 +504,7 @@ bool solve(orc_window* h, double radius, const okvis_ba_options& opt) {
   return solve_damped(h, 1.0 / radius);
 }
 
-void apply_step(orc_window* h, std::vector<double>* pose, std::vector<double>* sb, std::vector<double>* lm) {
+void apply_step(orc_window* h, std::vector<real>* pose, std::vector<real>* sb, std::vector<real>* lm) {
   *pose = h->pose;
   *sb = h->sb;
   *lm = h->lm;
@@ -516,32 +517,32 @@ void apply_step(orc_window* h, std::vector<double>* pose, std::vector<double>* s
     for (int k = 0; k < 3; ++k) (*lm)[4 * l + k] = h->lm[4 * l + k] + h->step_l[3 * l + k];
 }
 
-double gradient_max_norm(const orc_window* h) {
-  double m = 0;
-  for (double v : h->g) m = std::max(m, std::fabs(v));
-  for (double v : h->b) m = std::max(m, std::fabs(v));
+real gradient_max_norm(const orc_window* h) {
+  real m = 0;
+  for (real v : h->g) m = std::max(m, std::fabs(v));
+  for (real v : h->b) m = std::max(m, std::fabs(v));
   return m;
 }
 
 // 3x3 symmetric eigenvalues by cyclic Jacobi (replaces Eigen::SelfAdjointEigenSolver<Matrix3d>)
-void eig3sym(const double v[6], double ev[3]) {
-  double A[3][3] = {{v[0], v[1], v[2]}, {v[1], v[3], v[4]}, {v[2], v[4], v[5]}};
+void eig3sym(const real v[6], real ev[3]) {
+  real A[3][3] = {{v[0], v[1], v[2]}, {v[1], v[3], v[4]}, {v[2], v[4], v[5]}};
   for (int sweep = 0; sweep < 30; ++sweep) {
-    double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    real off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
     if (off < 1e-300) break;
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
         if (A[p][q] == 0.0) continue;
-        double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        real theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        real t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        real c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
         for (int k = 0; k < 3; ++k) {
-          double akp = A[k][p], akq = A[k][q];
+          real akp = A[k][p], akq = A[k][q];
           A[k][p] = c * akp - s * akq;
           A[k][q] = s * akp + c * akq;
         }
         for (int k = 0; k < 3; ++k) {
-          double apk = A[p][k], aqk = A[q][k];
+          real apk = A[p][k], aqk = A[q][k];
           A[p][k] = c * apk - s * aqk;
           A[q][k] = s * apk + c * aqk;
         }
@@ -557,7 +558,7 @@ void landmark_quality(orc_window* h) {
   // Estimator.cpp:880-896
   h->quality.assign(h->n_lm, 0.0);
   for (int l = 0; l < h->n_lm; ++l) {
-    double ev[3];
+    real ev[3];
     eig3sym(&h->Hq[6 * l], ev);
     if (ev[0] < 1.0e-12)
       h->quality[l] = 0.0;
@@ -567,14 +568,14 @@ void landmark_quality(orc_window* h) {
 }
 
 void lm_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis_ba_summary* sum) {
-  double radius = opt.initial_radius, decrease_factor = 2.0;
+  real radius = opt.initial_radius, decrease_factor = 2.0;
   evaluate(h, true);
   okvis_ba_summary s;
   std::memset(&s, 0, sizeof(s));
   s.initial_cost = h->cost;
-  const double g0 = gradient_max_norm(h);
+  const real g0 = gradient_max_norm(h);
   s.gradient_max_norm = g0;
-  const double abs_grad_tol = opt.gradient_tolerance * std::max(g0, 2.220446049250313e-16);
+  const real abs_grad_tol = opt.gradient_tolerance * std::max(g0, real(2.220446049250313e-16));
   s.termination = 0;
   bool done = false;
   if (opt.gradient_tolerance > 0 && g0 <= abs_grad_tol) {
@@ -584,9 +585,9 @@ void lm_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis_ba_
   for (int it = 1; it <= num_iter && !done; ++it) {
     s.iterations = it;
     bool ok = solve(h, radius, opt);
-    double model_change = 0;
+    real model_change = 0;
     if (ok) {
-      double gd = 0, dDd = 0;
+      real gd = 0, dDd = 0;
       for (int i = 0; i < h->D; ++i) {
         gd += h->g[i] * h->step_p[i];
         dDd += h->Dp2[i] * h->step_p[i] * h->step_p[i];
@@ -608,40 +609,40 @@ void lm_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis_ba_
       continue;
     }
     // parameter tolerance (checked before the trial evaluation)
-    double step2 = 0, x2 = 0;
-    for (double v : h->step_p) step2 += v * v;
-    for (double v : h->step_l) step2 += v * v;
+    real step2 = 0, x2 = 0;
+    for (real v : h->step_p) step2 += v * v;
+    for (real v : h->step_l) step2 += v * v;
     for (int i = 0; i < h->n_pose; ++i)
       if (h->pose_off[i] >= 0)
         for (int k = 0; k < 7; ++k) x2 += h->pose[7 * i + k] * h->pose[7 * i + k];
     for (int i = 0; i < h->n_sb; ++i)
       if (h->sb_off[i] >= 0)
         for (int k = 0; k < 9; ++k) x2 += h->sb[9 * i + k] * h->sb[9 * i + k];
-    for (double v : h->lm) x2 += v * v;
+    for (real v : h->lm) x2 += v * v;
     if (opt.parameter_tolerance > 0 &&
         std::sqrt(step2) <= opt.parameter_tolerance * (std::sqrt(x2) + opt.parameter_tolerance)) {
       s.termination = 3;
       done = true;
       continue;
     }
-    std::vector<double> pose_t, sb_t, lm_t, pose_s = h->pose, sb_s = h->sb, lm_s = h->lm;
+    std::vector<real> pose_t, sb_t, lm_t, pose_s = h->pose, sb_s = h->sb, lm_s = h->lm;
     apply_step(h, &pose_t, &sb_t, &lm_t);
     h->pose = pose_t;
     h->sb = sb_t;
     h->lm = lm_t;
-    const double old_cost = h->cost;
-    const double new_cost = evaluate(h, false);
-    const double rho = (old_cost - new_cost) / model_change;
+    const real old_cost = h->cost;
+    const real new_cost = evaluate(h, false);
+    const real rho = (old_cost - new_cost) / model_change;
     if (opt.gauss_newton || rho > opt.min_relative_decrease) {
       evaluate(h, true);  // Ceres re-evaluates residuals + Jacobians at the accepted point
       s.successful_steps++;
       if (!opt.gauss_newton) {
-        const double t = 2.0 * rho - 1.0;
-        radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
-        radius = std::min(opt.max_radius, radius);
+        const real t = 2.0 * rho - 1.0;
+        radius = radius / std::max(real(1.0 / 3.0), 1.0 - t * t * t);
+        radius = std::min(real(opt.max_radius), radius);
         decrease_factor = 2.0;
       }
-      const double gm = gradient_max_norm(h);
+      const real gm = gradient_max_norm(h);
       s.gradient_max_norm = gm;
       if (opt.gradient_tolerance > 0 && gm <= abs_grad_tol) {
         s.termination = 2;
@@ -683,10 +684,10 @@ void lm_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis_ba_
 //   step                                  delta = -cA xv + beta dGN  (dogleg interpolation in the hat space)
 // ---------------------------------------------------------------------------------------------------
 struct Full {  // a vector over [reduced pose/speed-bias part | 3 per landmark]
-  std::vector<double> p, l;
+  std::vector<real> p, l;
 };
-static double dotf(const Full& a, const Full& b) {
-  double s = 0;
+static real dotf(const Full& a, const Full& b) {
+  real s = 0;
   for (size_t i = 0; i < a.p.size(); ++i) s += a.p[i] * b.p[i];
   for (size_t i = 0; i < a.l.size(); ++i) s += a.l[i] * b.l[i];
   return s;
@@ -697,18 +698,18 @@ static void hessian_times(const orc_window* h, const Full& x, Full* y) {
   y->p.assign(D, 0.0);
   y->l.assign(3 * (size_t)h->n_lm, 0.0);
   for (int i = 0; i < D; ++i) {
-    double s = 0;
+    real s = 0;
     for (int j = 0; j < D; ++j) s += h->U[(size_t)i * D + j] * x.p[j];
     y->p[i] = s;
   }
   for (int l = 0; l < h->n_lm; ++l) {
-    const double* v = &h->V[6 * l];
-    const double* xl = &x.l[3 * l];
+    const real* v = &h->V[6 * l];
+    const real* xl = &x.l[3 * l];
     y->l[3 * l + 0] = v[0] * xl[0] + v[1] * xl[1] + v[2] * xl[2];
     y->l[3 * l + 1] = v[1] * xl[0] + v[3] * xl[1] + v[4] * xl[2];
     y->l[3 * l + 2] = v[2] * xl[0] + v[4] * xl[1] + v[5] * xl[2];
     for (int pr = h->lm_pair_begin[l]; pr < h->lm_pair_begin[l + 1]; ++pr) {
-      const double* Wp = &h->W[18 * pr];  // 6x3 row-major block (pose block rows, landmark columns)
+      const real* Wp = &h->W[18 * pr];  // 6x3 row-major block (pose block rows, landmark columns)
       const int o = h->pose_off[h->pair_block[pr]];
       for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 3; ++j) {
@@ -719,11 +720,11 @@ static void hessian_times(const orc_window* h, const Full& x, Full* y) {
   }
 }
 // Ceres 1.9: gradient_max_norm = || x - Plus(x, -g) ||_inf over the ambient coordinates
-static double projected_gradient_max_norm(const orc_window* h) {
-  double m = 0;
+static real projected_gradient_max_norm(const orc_window* h) {
+  real m = 0;
   for (int i = 0; i < h->n_pose; ++i)
     if (h->pose_off[i] >= 0) {
-      double d[6], xp[7];
+      real d[6], xp[7];
       for (int k = 0; k < 6; ++k) d[k] = -h->g[h->pose_off[i] + k];
       pose_plus(&h->pose[7 * i], d, xp);
       for (int k = 0; k < 7; ++k) m = std::max(m, std::fabs(h->pose[7 * i + k] - xp[k]));
@@ -731,28 +732,28 @@ static double projected_gradient_max_norm(const orc_window* h) {
   for (int i = 0; i < h->n_sb; ++i)
     if (h->sb_off[i] >= 0)
       for (int k = 0; k < 9; ++k) m = std::max(m, std::fabs(h->g[h->sb_off[i] + k]));
-  for (double v : h->b) m = std::max(m, std::fabs(v));
+  for (real v : h->b) m = std::max(m, std::fabs(v));
   return m;
 }
-static double free_x_norm(const orc_window* h) {
-  double x2 = 0;
+static real free_x_norm(const orc_window* h) {
+  real x2 = 0;
   for (int i = 0; i < h->n_pose; ++i)
     if (h->pose_off[i] >= 0)
       for (int k = 0; k < 7; ++k) x2 += h->pose[7 * i + k] * h->pose[7 * i + k];
   for (int i = 0; i < h->n_sb; ++i)
     if (h->sb_off[i] >= 0)
       for (int k = 0; k < 9; ++k) x2 += h->sb[9 * i + k] * h->sb[9 * i + k];
-  for (double v : h->lm) x2 += v * v;
+  for (real v : h->lm) x2 += v * v;
   return std::sqrt(x2);
 }
 
 void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis_ba_summary* sum) {
-  const double kMinMu = 1e-8, kMaxMu = 1.0, kMuIncrease = 10.0;  // DoglegStrategy constants
+  const real kMinMu = 1e-8, kMaxMu = 1.0, kMuIncrease = 10.0;  // DoglegStrategy constants
   const int D = h->D, NL = 3 * h->n_lm;
   static const int dg[3] = {0, 3, 5};
-  double radius = opt.initial_radius, mu = kMinMu;
+  real radius = opt.initial_radius, mu = kMinMu;
   bool reuse = false, gn_ok = false;
-  double alpha = 0, dogleg_step_norm = 0;
+  real alpha = 0, dogleg_step_norm = 0;
   int invalid_steps = 0;
   evaluate(h, true);
   okvis_ba_summary s;
@@ -773,7 +774,7 @@ void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis
     s.termination = 2;
     done = true;
   }
-  double x_norm = free_x_norm(h);
+  real x_norm = free_x_norm(h);
   for (int it = 1; it <= num_iter && !done; ++it) {
     s.iterations = it;
     // ---------------- DoglegStrategy::ComputeStep ----------------
@@ -808,8 +809,8 @@ void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis
       while (mu < kMaxMu) {
         bool ok = solve_damped(h, mu);
         if (ok) {
-          for (double v : h->step_p) ok = ok && std::isfinite(v);
-          for (double v : h->step_l) ok = ok && std::isfinite(v);
+          for (real v : h->step_p) ok = ok && std::isfinite(v);
+          for (real v : h->step_l) ok = ok && std::isfinite(v);
         }
         if (!ok) {
           mu *= kMuIncrease;
@@ -826,11 +827,11 @@ void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis
       }
     }
     bool valid = gn_ok;
-    double model_change = 0;
+    real model_change = 0;
     if (gn_ok) {
       // ---------------- ComputeTraditionalDoglegStep ----------------
-      double cA = 0, beta = 1;
-      const double gradient_norm = std::sqrt(dotf(ghat, ghat)), gn_norm = std::sqrt(dotf(gnhat, gnhat));
+      real cA = 0, beta = 1;
+      const real gradient_norm = std::sqrt(dotf(ghat, ghat)), gn_norm = std::sqrt(dotf(gnhat, gnhat));
       if (opt.gauss_newton || gn_norm <= radius) {  // case 1: the Gauss-Newton point lies inside the trust region
         cA = 0, beta = 1;
         dogleg_step_norm = gn_norm;
@@ -838,11 +839,11 @@ void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis
         cA = radius / gradient_norm, beta = 0;
         dogleg_step_norm = radius;
       } else {  // case 3: on the segment Cauchy point -> Gauss-Newton point
-        const double b_dot_a = -alpha * dotf(ghat, gnhat);
-        const double a2 = (alpha * gradient_norm) * (alpha * gradient_norm);
-        const double bma2 = a2 - 2 * b_dot_a + gn_norm * gn_norm;
-        const double c = b_dot_a - a2;
-        const double dsc = std::sqrt(c * c + bma2 * (radius * radius - a2));
+        const real b_dot_a = -alpha * dotf(ghat, gnhat);
+        const real a2 = (alpha * gradient_norm) * (alpha * gradient_norm);
+        const real bma2 = a2 - 2 * b_dot_a + gn_norm * gn_norm;
+        const real c = b_dot_a - a2;
+        const real dsc = std::sqrt(c * c + bma2 * (radius * radius - a2));
         beta = (c <= 0) ? (dsc - c) / bma2 : (radius * radius - a2) / (dsc + c);
         cA = alpha * (1.0 - beta);
         Full t = gnhat;
@@ -875,15 +876,15 @@ void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis
     }
     invalid_steps = 0;
     h->step_p = step.p, h->step_l = step.l;
-    std::vector<double> pose_t, sb_t, lm_t, pose_s = h->pose, sb_s = h->sb, lm_s = h->lm;
+    std::vector<real> pose_t, sb_t, lm_t, pose_s = h->pose, sb_s = h->sb, lm_s = h->lm;
     apply_step(h, &pose_t, &sb_t, &lm_t);
-    double dx2 = 0;
+    real dx2 = 0;
     for (size_t i = 0; i < pose_t.size(); ++i) dx2 += (pose_t[i] - pose_s[i]) * (pose_t[i] - pose_s[i]);
     for (size_t i = 0; i < sb_t.size(); ++i) dx2 += (sb_t[i] - sb_s[i]) * (sb_t[i] - sb_s[i]);
     for (size_t i = 0; i < lm_t.size(); ++i) dx2 += (lm_t[i] - lm_s[i]) * (lm_t[i] - lm_s[i]);
     h->pose = pose_t, h->sb = sb_t, h->lm = lm_t;
-    const double old_cost = h->cost;
-    const double new_cost = evaluate(h, false);
+    const real old_cost = h->cost;
+    const real new_cost = evaluate(h, false);
     h->pose = pose_s, h->sb = sb_s, h->lm = lm_s;
     if (!opt.gauss_newton) {
       if (opt.parameter_tolerance > 0 && std::sqrt(dx2) <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) {
@@ -897,7 +898,7 @@ void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis
         continue;
       }
     }
-    const double rho = (old_cost - new_cost) / model_change;
+    const real rho = (old_cost - new_cost) / model_change;
     if (opt.gauss_newton || rho > opt.min_relative_decrease) {
       s.successful_steps++;
       if (!opt.gauss_newton) {  // StepAccepted
@@ -934,12 +935,47 @@ void dogleg_loop(orc_window* h, const okvis_ba_options& opt, int num_iter, okvis
 // ===================================================================================================
 // C API
 // ===================================================================================================
+// The entry points take and return double whatever `real` is: arguments are copied into `real` arrays, results copied back
+// (exact in the fp64 build; the long double build rounds its results to double on the way out).
+namespace {
+struct In {
+  std::vector<real> v;
+  bool has;
+  In(const double* p, size_t n) : has(p != nullptr) {
+    if (p) v.assign(p, p + n);
+  }
+  operator const real*() const { return has ? v.data() : nullptr; }
+};
+struct Out {  // written back when the object goes out of scope; `init` for arguments that are read and written
+  double* dst;
+  std::vector<real> v;
+  Out(double* p, size_t n, bool init = false) : dst(p), v(p ? n : 0) {
+    if (p && init) v.assign(p, p + n);
+  }
+  Out(const Out&) = delete;
+  operator real*() { return dst ? v.data() : nullptr; }
+  ~Out() {
+    if (dst)
+      for (size_t i = 0; i < v.size(); ++i) dst[i] = (double)v[i];
+  }
+};
+template <class M>
+void put(double* dst, const M& m) {
+  if (dst)
+    for (size_t i = 0; i < sizeof(m.a) / sizeof(m.a[0]); ++i) dst[i] = (double)m.a[i];
+}
+void put(double* dst, const std::vector<real>& v) {
+  if (dst)
+    for (size_t i = 0; i < v.size(); ++i) dst[i] = (double)v[i];
+}
+}  // namespace
+
 extern "C" {
 
-void orc_pose_plus(const double x[7], const double d[6], double out[7]) { pose_plus(x, d, out); }
-void orc_pose_minus(const double x[7], const double xpd[7], double d[6]) { pose_minus(x, xpd, d); }
-void orc_pose_lift_jacobian(const double x[7], double J[42]) { pose_lift_jacobian(x, J); }
-void orc_pose_plus_jacobian(const double x[7], double J[42]) { pose_plus_jacobian(x, J); }
+void orc_pose_plus(const double x[7], const double d[6], double out[7]) { pose_plus(In(x, 7), In(d, 6), Out(out, 7)); }
+void orc_pose_minus(const double x[7], const double xpd[7], double d[6]) { pose_minus(In(x, 7), In(xpd, 7), Out(d, 6)); }
+void orc_pose_lift_jacobian(const double x[7], double J[42]) { pose_lift_jacobian(In(x, 7), Out(J, 42)); }
+void orc_pose_plus_jacobian(const double x[7], double J[42]) { pose_plus_jacobian(In(x, 7), Out(J, 42)); }
 
 static Camera make_cam(const double intr[12], int model) {
   Camera c;
@@ -956,19 +992,20 @@ int orc_reprojection(const double pose[7], const double point[4], const double e
                      const double intr[12], int model, const double uv[2], const double sqrtInfo[4],
                      double r[2], double* Jp, double* Jl, double* Je) {
   ReprojOut out;
-  reprojection_error(pose, point, extr, make_cam(intr, model), uv, sqrtInfo, Jp || Jl || Je, &out);
-  r[0] = out.r[0];
-  r[1] = out.r[1];
-  if (Jp) std::memcpy(Jp, out.Jp.a, sizeof(out.Jp.a));
-  if (Jl) std::memcpy(Jl, out.Jl.a, sizeof(out.Jl.a));
-  if (Je) std::memcpy(Je, out.Je.a, sizeof(out.Je.a));
+  reprojection_error(In(pose, 7), In(point, 4), In(extr, 7), make_cam(intr, model), In(uv, 2), In(sqrtInfo, 4), Jp || Jl || Je,
+                     &out);
+  r[0] = (double)out.r[0];
+  r[1] = (double)out.r[1];
+  put(Jp, out.Jp);
+  put(Jl, out.Jl);
+  put(Je, out.Je);
   return (out.valid ? 1 : 0) | (out.defined ? 2 : 0);
 }
 
 int orc_project(const double intr[12], int model, const double point[3], double kp[2], double* J) {
   Mat<2, 3> Jm;
-  bool ok = project(make_cam(intr, model), vec3(point[0], point[1], point[2]), kp, J ? &Jm : nullptr);
-  if (ok && J) std::memcpy(J, Jm.a, sizeof(Jm.a));
+  bool ok = project(make_cam(intr, model), vec3(point[0], point[1], point[2]), Out(kp, 2), J ? &Jm : nullptr);
+  if (ok) put(J, Jm);
   return ok ? 1 : 0;
 }
 
@@ -988,10 +1025,12 @@ int orc_imu_evaluate_fresh(int n, const int64_t* t, const double* gyr, const dou
                            const okvis_ba_imu_params* p, int64_t t0, int64_t t1, const double pose0[7],
                            const double sb0[9], const double pose1[7], const double sb1[9], double r[15],
                            double* J0, double* J1, double* J2, double* J3, double* sqrtInfo) {
-  ImuSamples s{n, t, gyr, acc};
+  In g(gyr, 3 * (size_t)n), a(acc, 3 * (size_t)n);
+  ImuSamples s{n, t, g, a};
   ImuCache c;
-  imu_evaluate(s, make_params(p), t0, t1, &c, pose0, sb0, pose1, sb1, r, J0, J1, J2, J3);
-  if (sqrtInfo) std::memcpy(sqrtInfo, c.sqrtInfo.a, sizeof(c.sqrtInfo.a));
+  imu_evaluate(s, make_params(p), t0, t1, &c, In(pose0, 7), In(sb0, 9), In(pose1, 7), In(sb1, 9), Out(r, 15), Out(J0, 90),
+               Out(J1, 135), Out(J2, 90), Out(J3, 135));
+  put(sqrtInfo, c.sqrtInfo);
   return c.redoCounter;
 }
 
@@ -1000,36 +1039,41 @@ int orc_imu_evaluate_at_ref(int n, const int64_t* t, const double* gyr, const do
                             const double pose0[7], const double sb0[9], const double pose1[7],
                             const double sb1[9], double r[15], double* J0, double* J1, double* J2,
                             double* J3) {
-  ImuSamples s{n, t, gyr, acc};
+  In g(gyr, 3 * (size_t)n), a(acc, 3 * (size_t)n);
+  ImuSamples s{n, t, g, a};
   ImuCache c;
   ImuParams prm = make_params(p);
-  imu_redo_preintegration(s, prm, t0, t1, sb_ref, &c);
+  imu_redo_preintegration(s, prm, t0, t1, In(sb_ref, 9), &c);
   c.redo = false;
   // evaluate with the redo threshold effectively disabled: temporarily fake a huge threshold by
   // evaluating through a copy whose reference equals sb_ref; the reference's own threshold
   // (|dbg|*dt > 1e-4, ImuError.cpp:549) applies — callers keep |dbg| below it.
-  imu_evaluate(s, prm, t0, t1, &c, pose0, sb0, pose1, sb1, r, J0, J1, J2, J3);
+  imu_evaluate(s, prm, t0, t1, &c, In(pose0, 7), In(sb0, 9), In(pose1, 7), In(sb1, 9), Out(r, 15), Out(J0, 90), Out(J1, 135),
+               Out(J2, 90), Out(J3, 135));
   return c.redoCounter;
 }
 
 int orc_imu_propagation(int n, const int64_t* t, const double* gyr, const double* acc,
                         const okvis_ba_imu_params* p, double T_WS[7], double sb[9], int64_t t_start,
                         int64_t t_end, double* cov, double* jac) {
-  ImuSamples s{n, t, gyr, acc};
-  return imu_propagation(s, make_params(p), T_WS, sb, t_start, t_end, cov, jac);
+  In g(gyr, 3 * (size_t)n), a(acc, 3 * (size_t)n);
+  ImuSamples s{n, t, g, a};
+  return imu_propagation(s, make_params(p), Out(T_WS, 7, true), Out(sb, 9, true), t_start, t_end, Out(cov, 225), Out(jac, 225));
 }
 
 void orc_pose_error(const double pose[7], const double meas[7], const double si[36], double r[6], double* J) {
-  pose_error(pose, meas, si, r, J);
+  pose_error(In(pose, 7), In(meas, 7), In(si, 36), Out(r, 6), Out(J, 36));
 }
 void orc_speedbias_error(const double sb[9], const double meas[9], const double si[81], double r[9], double* J) {
-  speedbias_error(sb, meas, si, r, J);
+  speedbias_error(In(sb, 9), In(meas, 9), In(si, 81), Out(r, 9), Out(J, 81));
 }
 void orc_relative_pose_error(const double p0[7], const double p1[7], const double si[36], double r[6],
                              double* J0, double* J1) {
-  relative_pose_error(p0, p1, si, r, J0, J1);
+  relative_pose_error(In(p0, 7), In(p1, 7), In(si, 36), Out(r, 6), Out(J0, 36), Out(J1, 36));
 }
-void orc_sqrt_information(const double* info, int n, double* out) { sqrt_information_upper(info, n, out); }
+void orc_sqrt_information(const double* info, int n, double* out) {
+  sqrt_information_upper(In(info, (size_t)n * n), n, Out(out, (size_t)n * n));
+}
 
 orc_window* orc_window_create(const okvis_ba_window* w) {
   orc_window* h = new orc_window();
@@ -1042,9 +1086,9 @@ orc_window* orc_window_create(const okvis_ba_window* w) {
   h->n_pprior = w->n_pprior;
   h->n_sbprior = w->n_sbprior;
   h->n_relpose = w->n_relpose;
-  h->pose = copyv(w->pose, 7 * (size_t)w->n_pose);
-  h->sb = copyv(w->sb, 9 * (size_t)w->n_sb);
-  h->lm = copyv(w->lm, 4 * (size_t)w->n_lm);
+  h->pose = copyr(w->pose, 7 * (size_t)w->n_pose);
+  h->sb = copyr(w->sb, 9 * (size_t)w->n_sb);
+  h->lm = copyr(w->lm, 4 * (size_t)w->n_lm);
   h->pose_fixed = copyv(w->pose_fixed, (size_t)w->n_pose);
   h->sb_fixed = copyv(w->sb_fixed, (size_t)w->n_sb);
   for (int i = 0; i < w->n_cam; ++i) h->cams.push_back(make_cam(w->cam_intr + 12 * i, w->cam_model[i]));
@@ -1052,8 +1096,8 @@ orc_window* orc_window_create(const okvis_ba_window* w) {
   h->obs_pose = copyv(w->obs_pose, (size_t)w->n_obs);
   h->obs_ext = copyv(w->obs_ext, (size_t)w->n_obs);
   h->obs_cam = copyv(w->obs_cam, (size_t)w->n_obs);
-  h->obs_uv = copyv(w->obs_uv, 2 * (size_t)w->n_obs);
-  h->obs_sqrtw = copyv(w->obs_sqrtw, (size_t)w->n_obs);
+  h->obs_uv = copyr(w->obs_uv, 2 * (size_t)w->n_obs);
+  h->obs_sqrtw = copyr(w->obs_sqrtw, (size_t)w->n_obs);
   h->cauchy_b = w->cauchy_b;
   h->imu_pose0 = copyv(w->imu_pose0, (size_t)w->n_imu);
   h->imu_sb0 = copyv(w->imu_sb0, (size_t)w->n_imu);
@@ -1064,37 +1108,35 @@ orc_window* orc_window_create(const okvis_ba_window* w) {
   h->imu_s_begin = copyv(w->imu_s_begin, (size_t)w->n_imu);
   h->imu_s_count = copyv(w->imu_s_count, (size_t)w->n_imu);
   h->imu_s_t = copyv(w->imu_s_t, (size_t)w->n_imu_samples);
-  h->imu_s_gyr = copyv(w->imu_s_gyr, 3 * (size_t)w->n_imu_samples);
-  h->imu_s_acc = copyv(w->imu_s_acc, 3 * (size_t)w->n_imu_samples);
+  h->imu_s_gyr = copyr(w->imu_s_gyr, 3 * (size_t)w->n_imu_samples);
+  h->imu_s_acc = copyr(w->imu_s_acc, 3 * (size_t)w->n_imu_samples);
   h->imu_params = make_params(&w->imu_params);
   h->imu_cache.assign(w->n_imu, ImuCache());
   // an ImuError object that lived through earlier optimize() calls: its cache was built at sb_ref
   if (w->imu_sb_ref && w->imu_sb_ref_valid)
     for (int f = 0; f < w->n_imu; ++f)
       if (w->imu_sb_ref_valid[f]) {
-        ImuSamples smp{w->imu_s_count[f], w->imu_s_t + w->imu_s_begin[f], w->imu_s_gyr + 3 * (size_t)w->imu_s_begin[f],
-                       w->imu_s_acc + 3 * (size_t)w->imu_s_begin[f]};
-        imu_redo_preintegration(smp, h->imu_params, w->imu_t0[f], w->imu_t1[f], w->imu_sb_ref + 9 * (size_t)f,
+        imu_redo_preintegration(h->samples(f), h->imu_params, w->imu_t0[f], w->imu_t1[f], In(w->imu_sb_ref + 9 * (size_t)f, 9),
                                 &h->imu_cache[f]);
         h->imu_cache[f].redo = false;
       }
   h->pprior_pose = copyv(w->pprior_pose, (size_t)w->n_pprior);
-  h->pprior_meas = copyv(w->pprior_meas, 7 * (size_t)w->n_pprior);
-  h->pprior_sqrtinfo = copyv(w->pprior_sqrtinfo, 36 * (size_t)w->n_pprior);
+  h->pprior_meas = copyr(w->pprior_meas, 7 * (size_t)w->n_pprior);
+  h->pprior_sqrtinfo = copyr(w->pprior_sqrtinfo, 36 * (size_t)w->n_pprior);
   h->sbprior_sb = copyv(w->sbprior_sb, (size_t)w->n_sbprior);
-  h->sbprior_meas = copyv(w->sbprior_meas, 9 * (size_t)w->n_sbprior);
-  h->sbprior_sqrtinfo = copyv(w->sbprior_sqrtinfo, 81 * (size_t)w->n_sbprior);
+  h->sbprior_meas = copyr(w->sbprior_meas, 9 * (size_t)w->n_sbprior);
+  h->sbprior_sqrtinfo = copyr(w->sbprior_sqrtinfo, 81 * (size_t)w->n_sbprior);
   h->rel_pose0 = copyv(w->rel_pose0, (size_t)w->n_relpose);
   h->rel_pose1 = copyv(w->rel_pose1, (size_t)w->n_relpose);
-  h->rel_sqrtinfo = copyv(w->rel_sqrtinfo, 36 * (size_t)w->n_relpose);
+  h->rel_sqrtinfo = copyr(w->rel_sqrtinfo, 36 * (size_t)w->n_relpose);
   h->marg_dim = w->marg_dim;
   h->marg_nblocks = w->marg_dim > 0 ? w->marg_nblocks : 0;
   h->marg_block_type = copyv(w->marg_block_type, (size_t)h->marg_nblocks);
   h->marg_block_idx = copyv(w->marg_block_idx, (size_t)h->marg_nblocks);
   h->marg_block_off = copyv(w->marg_block_off, (size_t)h->marg_nblocks);
-  h->marg_J = copyv(w->marg_J, (size_t)w->marg_dim * w->marg_dim);
-  h->marg_e0 = copyv(w->marg_e0, (size_t)w->marg_dim);
-  h->marg_lin = copyv(w->marg_lin, 9 * (size_t)h->marg_nblocks);
+  h->marg_J = copyr(w->marg_J, (size_t)w->marg_dim * w->marg_dim);
+  h->marg_e0 = copyr(w->marg_e0, (size_t)w->marg_dim);
+  h->marg_lin = copyr(w->marg_lin, 9 * (size_t)h->marg_nblocks);
   build_ordering(h);
   return h;
 }
@@ -1142,14 +1184,14 @@ int orc_window_solve(orc_window* h, double radius, const okvis_ba_options* opt) 
     h->Dp2.assign(D, 0.0);
     h->Dl2.assign(3 * (size_t)h->n_lm, 0.0);
     for (int i = 0; i < D; ++i) {
-      const double hh = h->U[(size_t)i * D + i];
-      const double sc = opt->jacobi_scaling ? 1.0 / (1.0 + std::sqrt(hh)) : 1.0;
+      const real hh = h->U[(size_t)i * D + i];
+      const real sc = opt->jacobi_scaling ? 1.0 / (1.0 + std::sqrt(hh)) : 1.0;
       h->Dp2[i] = clampd(sc * sc * hh, opt->min_lm_diagonal, opt->max_lm_diagonal) / (sc * sc);
     }
     for (int l = 0; l < h->n_lm; ++l)
       for (int k = 0; k < 3; ++k) {
-        const double hh = h->V[6 * l + dg[k]];
-        const double sc = opt->jacobi_scaling ? 1.0 / (1.0 + std::sqrt(hh)) : 1.0;
+        const real hh = h->V[6 * l + dg[k]];
+        const real sc = opt->jacobi_scaling ? 1.0 / (1.0 + std::sqrt(hh)) : 1.0;
         h->Dl2[3 * l + k] = clampd(sc * sc * hh, opt->min_lm_diagonal, opt->max_lm_diagonal) / (sc * sc);
       }
     return solve_damped(h, 1e-8) ? 0 : 1;
@@ -1175,17 +1217,17 @@ double orc_window_time_iterations(orc_window* h, const okvis_ba_options* opt, in
   return std::chrono::duration<double>(t1 - t0).count();
 }
 void orc_window_get_state(orc_window* h, double* pose, double* sb, double* lm) {
-  if (pose) std::memcpy(pose, h->pose.data(), h->pose.size() * 8);
-  if (sb) std::memcpy(sb, h->sb.data(), h->sb.size() * 8);
-  if (lm) std::memcpy(lm, h->lm.data(), h->lm.size() * 8);
+  put(pose, h->pose);
+  put(sb, h->sb);
+  put(lm, h->lm);
 }
 void orc_window_set_state(orc_window* h, const double* pose, const double* sb, const double* lm) {
-  if (pose) std::memcpy(h->pose.data(), pose, h->pose.size() * 8);
-  if (sb) std::memcpy(h->sb.data(), sb, h->sb.size() * 8);
-  if (lm) std::memcpy(h->lm.data(), lm, h->lm.size() * 8);
+  if (pose) h->pose.assign(pose, pose + h->pose.size());
+  if (sb) h->sb.assign(sb, sb + h->sb.size());
+  if (lm) h->lm.assign(lm, lm + h->lm.size());
 }
 
-static const std::vector<double>* pick(orc_window* h, int which) {
+static const std::vector<real>* pick(orc_window* h, int which) {
   switch (which) {
     case OKVIS_BA_ARR_POSE: return &h->pose;
     case OKVIS_BA_ARR_SB: return &h->sb;
@@ -1207,24 +1249,24 @@ static const std::vector<double>* pick(orc_window* h, int which) {
 }
 int64_t orc_window_array_size(orc_window* h, int which) {
   if (which == OKVIS_BA_ARR_IMU_SB_REF) return 9 * (int64_t)h->n_imu;
-  const std::vector<double>* v = pick(h, which);
+  const std::vector<real>* v = pick(h, which);
   return v ? (int64_t)v->size() : -1;
 }
 int orc_window_download(orc_window* h, int which, double* out, int64_t n) {
   if (which == OKVIS_BA_ARR_IMU_SB_REF) {
     if (n != 9 * (int64_t)h->n_imu) return -1;
     for (int f = 0; f < h->n_imu; ++f)
-      for (int k = 0; k < 9; ++k) out[9 * f + k] = h->imu_cache[f].sb_ref[k];
+      for (int k = 0; k < 9; ++k) out[9 * f + k] = (double)h->imu_cache[f].sb_ref[k];
     return 0;
   }
-  const std::vector<double>* v = pick(h, which);
+  const std::vector<real>* v = pick(h, which);
   if (!v || (int64_t)v->size() != n) return -1;
-  std::memcpy(out, v->data(), n * 8);
+  put(out, *v);
   return 0;
 }
 void orc_window_full_gradient(orc_window* h, double* g_full) {
-  for (int i = 0; i < h->D; ++i) g_full[i] = h->g[i];
-  for (size_t i = 0; i < h->b.size(); ++i) g_full[h->D + i] = h->b[i];
+  for (int i = 0; i < h->D; ++i) g_full[i] = (double)h->g[i];
+  for (size_t i = 0; i < h->b.size(); ++i) g_full[h->D + i] = (double)h->b[i];
 }
 
 }  // extern "C"
@@ -1233,36 +1275,36 @@ void orc_window_full_gradient(orc_window* h, double* g_full) {
 // Marginalisation (MarginalizationError.cpp), literal restatement on dense matrices
 // ===================================================================================================
 namespace {
-typedef std::vector<double> Vec;
+typedef std::vector<real> Vec;
 
 // Eigen::SelfAdjointEigenSolver stand-in: classical cyclic-by-row Jacobi; ascending eigenvalues like Eigen.
 void sym_eig(const Vec& Ain, int n, Vec* ev, Vec* Qout) {
   Vec A(Ain), Q((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i) Q[(size_t)i * n + i] = 1.0;
-  const double eps = std::numeric_limits<double>::epsilon();
-  double dmax = 0.0;
+  const real eps = std::numeric_limits<double>::epsilon();
+  real dmax = 0.0;
   for (int i = 0; i < n; ++i) dmax = std::max(dmax, std::fabs(A[(size_t)i * n + i]));
-  const double thr = std::max(eps * dmax, 1e-300);  // absolute accuracy of a backward-stable solver
+  const real thr = std::max(eps * dmax, real(1e-300));  // absolute accuracy of a backward-stable solver
   for (int sweep = 0; sweep < 100; ++sweep) {
     bool rotated = false;
     for (int p = 0; p < n - 1; ++p)
       for (int q = p + 1; q < n; ++q) {
-        const double apq = A[(size_t)p * n + q], app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+        const real apq = A[(size_t)p * n + q], app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
         if (std::fabs(apq) <= thr || std::fabs(apq) <= eps * std::sqrt(std::fabs(app * aqq))) continue;
         rotated = true;
-        const double theta = (aqq - app) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        const real theta = (aqq - app) / (2.0 * apq);
+        const real t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const real c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
         for (int k = 0; k < n; ++k) {
-          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          const real akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
           A[(size_t)k * n + p] = c * akp - s * akq;
           A[(size_t)k * n + q] = s * akp + c * akq;
-          const double qkp = Q[(size_t)k * n + p], qkq = Q[(size_t)k * n + q];
+          const real qkp = Q[(size_t)k * n + p], qkq = Q[(size_t)k * n + q];
           Q[(size_t)k * n + p] = c * qkp - s * qkq;
           Q[(size_t)k * n + q] = s * qkp + c * qkq;
         }
         for (int k = 0; k < n; ++k) {
-          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          const real apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
           A[(size_t)p * n + k] = c * apk - s * aqk;
           A[(size_t)q * n + k] = s * apk + c * aqk;
         }
@@ -1284,12 +1326,12 @@ void sym_eig(const Vec& Ain, int n, Vec* ev, Vec* Qout) {
 void pinv_symm_sqrt(const Vec& a, int n, Vec* result) {
   Vec ev, Q;
   sym_eig(a, n, &ev, &Q);
-  double mx = ev[0];
+  real mx = ev[0];
   for (int i = 1; i < n; ++i) mx = std::max(mx, ev[i]);
-  const double tol = std::numeric_limits<double>::epsilon() * n * mx;
+  const real tol = std::numeric_limits<double>::epsilon() * n * mx;
   result->assign((size_t)n * n, 0.0);
   for (int k = 0; k < n; ++k) {
-    const double s = ev[k] > tol ? std::sqrt(1.0 / ev[k]) : 0.0;
+    const real s = ev[k] > tol ? std::sqrt(1.0 / ev[k]) : 0.0;
     for (int i = 0; i < n; ++i) (*result)[(size_t)i * n + k] = Q[(size_t)i * n + k] * s;
   }
 }
@@ -1334,23 +1376,23 @@ void marginalize_out(Vec* Hp, Vec* bp, int n, const std::vector<int>& mb, bool l
       Vec M((size_t)na * 3), M1((size_t)na * 3);
       for (int r = 0; r < na; ++r)
         for (int c = 0; c < 3; ++c) {
-          double s = 0;
+          real s = 0;
           for (int k = 0; k < 3; ++k) s += W[(size_t)r * nm + i + k] * Vis[3 * k + c];
           M[3 * r + c] = s;
         }
       for (int r = 0; r < na; ++r)
         for (int c = 0; c < 3; ++c) {
-          double s = 0;
+          real s = 0;
           for (int k = 0; k < 3; ++k) s += M[3 * r + k] * Vis[3 * c + k];  // M * Vis^T
           M1[3 * r + c] = s;
         }
       for (int r = 0; r < na; ++r) {
         for (int c = 0; c < na; ++c) {
-          double s = 0;
+          real s = 0;
           for (int k = 0; k < 3; ++k) s += M[3 * r + k] * M[3 * c + k];
           dH[(size_t)r * na + c] += s;
         }
-        double s = 0;
+        real s = 0;
         for (int k = 0; k < 3; ++k) s += M1[3 * r + k] * b_b[i + k];
         db[r] += s;
       }
@@ -1363,21 +1405,21 @@ void marginalize_out(Vec* Hp, Vec* bp, int n, const std::vector<int>& mb, bool l
     Vec M((size_t)na * nm), t(nm);
     for (int r = 0; r < na; ++r)
       for (int c = 0; c < nm; ++c) {
-        double s = 0;
+        real s = 0;
         for (int k = 0; k < nm; ++k) s += W[(size_t)r * nm + k] * Vis[(size_t)k * nm + c];
         M[(size_t)r * nm + c] = s;
       }
     for (int c = 0; c < nm; ++c) {
-      double s = 0;
+      real s = 0;
       for (int k = 0; k < nm; ++k) s += Vis[(size_t)k * nm + c] * b_b[k];
       t[c] = s;
     }
     for (int r = 0; r < na; ++r) {
-      double s = 0;
+      real s = 0;
       for (int k = 0; k < nm; ++k) s += M[(size_t)r * nm + k] * t[k];
       db[r] = s;
       for (int c = 0; c < na; ++c) {
-        double q = 0;
+        real q = 0;
         for (int k = 0; k < nm; ++k) q += M[(size_t)r * nm + k] * M[(size_t)c * nm + k];
         dH[(size_t)r * na + c] = q;
       }
@@ -1491,13 +1533,13 @@ int orc_window_marginalize(orc_window* h, const okvis_ba_marg_spec* spec, okvis_
     for (int j = 0; j < na; ++j)
       A[(size_t)i * na + j] = 0.5 * (1.0 / p[i]) * (H[(size_t)i * na + j] + H[(size_t)j * na + i]) * (1.0 / p[j]);
   sym_eig(A, na, &ev, &Q);
-  double mx = ev[0];
+  real mx = ev[0];
   for (int i = 1; i < na; ++i) mx = std::max(mx, ev[i]);
-  const double tol = std::numeric_limits<double>::epsilon() * na * mx;
+  const real tol = std::numeric_limits<double>::epsilon() * na * mx;
   for (int r = 0; r < na; ++r) {
-    const double S = ev[r] > tol ? ev[r] : 0.0, Sp = ev[r] > tol ? 1.0 / ev[r] : 0.0;
+    const real S = ev[r] > tol ? ev[r] : 0.0, Sp = ev[r] > tol ? 1.0 / ev[r] : 0.0;
     if (ev[r] > tol) res->rank++;
-    double s = 0;
+    real s = 0;
     for (int c = 0; c < na; ++c) {
       res->J[(size_t)r * na + c] = p[c] * Q[(size_t)c * na + r] * std::sqrt(S);
       s += std::sqrt(Sp) * Q[(size_t)c * na + r] * (1.0 / p[c]) * b0[c];

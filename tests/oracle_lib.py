@@ -42,6 +42,7 @@ def build_oracle():
 
 
 _lib = None
+_lib_ld = None
 
 
 def lib():
@@ -51,7 +52,24 @@ def lib():
     path = os.path.join(_ORACLE_DIR, "liboracle.so")
     if not os.path.exists(path) or os.path.exists(os.path.join(_ORACLE_DIR, "Makefile")) and _stale(path):
         path = build_oracle()
-    L = C.CDLL(path)
+    _lib = _bind(C.CDLL(path))
+    return _lib
+
+
+def lib_ld():
+    """The same sources built with `real = long double` (x87 extended precision, 64-bit mantissa): the referee of
+    tests/test_oracle_referee.py.  Same entry points, double in and out."""
+    global _lib_ld
+    if _lib_ld is not None:
+        return _lib_ld
+    path = os.path.join(_ORACLE_DIR, "liboracle_ld.so")
+    if not os.path.exists(path) or os.path.exists(os.path.join(_ORACLE_DIR, "Makefile")) and _stale(path):
+        locked_make(["-C", _ORACLE_DIR, "liboracle_ld.so"], _ORACLE_DIR)
+    _lib_ld = _bind(C.CDLL(path))
+    return _lib_ld
+
+
+def _bind(L):
     L.orc_window_create.restype = C.c_void_p
     L.orc_window_create.argtypes = [C.POINTER(WindowC)]
     L.orc_window_destroy.argtypes = [C.c_void_p]
@@ -78,7 +96,6 @@ def lib():
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_imu_propagation.argtypes = [C.c_int, _lp, _dp, _dp, C.POINTER(ImuParamsC), _dp, _dp, C.c_int64,
                                       C.c_int64, _dp, _dp]
-    _lib = L
     return L
 
 
@@ -209,12 +226,13 @@ def sqrt_information(info):
 # window-level wrapper
 # ---------------------------------------------------------------------------------------------------
 class OracleWindow:
-    def __init__(self, window: Window):
+    def __init__(self, window: Window, extended=False):
         self.window = window
+        self._L = lib_ld() if extended else lib()
         self._wc, self._keep = window.as_c()
-        self._h = lib().orc_window_create(C.byref(self._wc))
-        self.D = lib().orc_window_reduced_dim(self._h)
-        self.n_pair = lib().orc_window_pair_count(self._h)
+        self._h = self._L.orc_window_create(C.byref(self._wc))
+        self.D = self._L.orc_window_reduced_dim(self._h)
+        self.n_pair = self._L.orc_window_pair_count(self._h)
 
     @classmethod
     def from_c(cls, wc_ptr):
@@ -223,70 +241,71 @@ class OracleWindow:
         self = cls.__new__(cls)
         wc = wc_ptr.contents
         self.window = types.SimpleNamespace(n_pose=wc.n_pose, n_sb=wc.n_sb, n_lm=wc.n_lm)
-        self._h = lib().orc_window_create(wc_ptr)
-        self.D = lib().orc_window_reduced_dim(self._h)
-        self.n_pair = lib().orc_window_pair_count(self._h)
+        self._L = lib()
+        self._h = self._L.orc_window_create(wc_ptr)
+        self.D = self._L.orc_window_reduced_dim(self._h)
+        self.n_pair = self._L.orc_window_pair_count(self._h)
         return self
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_window_destroy(self._h)
+            self._L.orc_window_destroy(self._h)
             self._h = None
 
     def set_marg_exact(self, exact):
-        lib().orc_window_set_marg_exact(self._h, int(exact))
+        self._L.orc_window_set_marg_exact(self._h, int(exact))
 
     def pairs(self):
         a = np.zeros(self.n_pair, np.int32)
         b = np.zeros(self.n_pair, np.int32)
-        lib().orc_window_pairs(self._h, a.ctypes.data_as(_ip), b.ctypes.data_as(_ip))
+        self._L.orc_window_pairs(self._h, a.ctypes.data_as(_ip), b.ctypes.data_as(_ip))
         return a, b
 
     def linearize(self):
-        return lib().orc_window_linearize(self._h)
+        return self._L.orc_window_linearize(self._h)
 
     def cost(self):
-        return lib().orc_window_cost(self._h)
+        return self._L.orc_window_cost(self._h)
 
     def solve(self, radius, opt=None):
         opt = opt or default_options()
-        return lib().orc_window_solve(self._h, float(radius), C.byref(opt))
+        return self._L.orc_window_solve(self._h, float(radius), C.byref(opt))
 
     def optimize(self, num_iter, opt=None):
         opt = opt or default_options()
         s = SummaryC()
-        lib().orc_window_optimize(self._h, C.byref(opt), int(num_iter), C.byref(s))
+        self._L.orc_window_optimize(self._h, C.byref(opt), int(num_iter), C.byref(s))
         return s.as_dict()
 
     def time_iterations(self, n, opt=None):
         opt = opt or default_options()
-        return lib().orc_window_time_iterations(self._h, C.byref(opt), int(n))
+        return self._L.orc_window_time_iterations(self._h, C.byref(opt), int(n))
 
     def get_state(self):
         w = self.window
         pose, sb, lm = np.zeros((w.n_pose, 7)), np.zeros((w.n_sb, 9)), np.zeros((w.n_lm, 4))
-        lib().orc_window_get_state(self._h, _p(pose), _p(sb), _p(lm))
+        self._L.orc_window_get_state(self._h, _p(pose), _p(sb), _p(lm))
         return pose, sb, lm
 
     def set_state(self, pose=None, sb=None, lm=None):
-        lib().orc_window_set_state(self._h, _p(None if pose is None else _arr(pose)),
+        self._L.orc_window_set_state(self._h, _p(None if pose is None else _arr(pose)),
                                    _p(None if sb is None else _arr(sb)), _p(None if lm is None else _arr(lm)))
 
     def array(self, name):
         which = ARR[name]
-        n = lib().orc_window_array_size(self._h, which)
+        n = self._L.orc_window_array_size(self._h, which)
         out = np.zeros(max(n, 0))
         if n > 0:
-            assert lib().orc_window_download(self._h, which, _p(out), n) == 0
+            assert self._L.orc_window_download(self._h, which, _p(out), n) == 0
         return out
 
     def marginalize(self, pose_marg, sb_marg, prior=None):
-        st, out = marg_call(lambda sp, rs: lib().orc_window_marginalize(self._h, sp, rs), self.window.n_pose,
+        st, out = marg_call(lambda sp, rs: self._L.orc_window_marginalize(self._h, sp, rs), self.window.n_pose,
                             self.window.n_sb, pose_marg, sb_marg, prior)
         assert st == 0, st
         return out
 
     def full_gradient(self):
         g = np.zeros(self.D + 3 * self.window.n_lm)
-        lib().orc_window_full_gradient(self._h, _p(g))
+        self._L.orc_window_full_gradient(self._h, _p(g))
         return g
