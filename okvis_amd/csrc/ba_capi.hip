@@ -895,6 +895,25 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.D = D; P.Dp = Dp; P.n_pair = npair; P.n_group = ngroup; P.n_chunk = nchunk; P.n_task = (int)tasks.size();
   P.has_ext = has_ext ? 1 : 0;
   P.lin2 = lin2 ? 1 : 0;
+  {
+    // Diagonal blocks of the dense solver that carry a pose prior or the marginalisation prior: information of a few directions
+    // that is orders of magnitude above everything else in the block (the yaw prior of the first pose: 1e16 n n^T across three
+    // rotation rows), whose elimination cancels the leading digits of the block.  ba_ldl16.hpp eliminates them with compensated
+    // products (profiles/r05_notes.md, "the referee").  The solver numbers the speed/bias part first (L16::perm).
+    unsigned m = 0;
+    if (D <= MAX_D_LDS && !std::getenv("OKVIS_BA_NO_LDL_COMP")) {
+      const L16 LY{ldl16_nb(D), D - Dp, D};
+      auto mark = [&](int off, int n) { if (off >= 0) for (int k = 0; k < n; ++k) m |= 1u << (LY.perm(off + k) >> 4); };
+      for (int i = 0; i < w.n_pprior; ++i) mark(pose_off[w.pprior_pose[i]], 6);
+      for (int b = 0; b < nmb; ++b) {
+        const bool pose = w.marg_block_type[b] == OKVIS_BA_BLOCK_POSE;
+        mark(pose ? pose_off[w.marg_block_idx[b]] : sb_off[w.marg_block_idx[b]], pose ? 6 : 9);
+      }
+      if (std::getenv("OKVIS_BA_LDL_COMP_ALL")) m = ~0u;
+    }
+    P.ldl_comp = m;
+    P.pad0_ = 0;
+  }
   P.gpart_size = gpart_size;
   P.n_tile = ntile;
   P.n_imu_color = n_imu_color;

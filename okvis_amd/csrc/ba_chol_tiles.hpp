@@ -186,7 +186,7 @@ __device__ void ct_ldl_inv48(double* M, double* X, double* R, double* dinv, int 
       if (lane < 16) {
         dinv[16 * b + j] = mine;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) X[(16 * b + i) * CT_LD + 16 * b + j] = i > j ? c[i] * mine : (i == j ? 1.0 : 0.0);
+        for (int i = 0; i < 16; ++i) X[(16 * b + i) * CT_LD + 16 * b + j] = i > j ? -c[i] * mine : (i == j ? 1.0 : 0.0);   // (c: -L^-1 D below the diagonal)
       }
     }
   };

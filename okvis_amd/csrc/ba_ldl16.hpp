@@ -173,25 +173,39 @@ __device__ __forceinline__ void ldl_operand(const double* Xk, const double* dk, 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int ak = (lane >> 4) + 4 * q;
-    const double v = xh[q] * -dq[q];
+    const double v = xh[q] * dq[q];   // (the published column holds -Bh below the diagonal)
     a[q] = am > ak ? v : (am == ak ? 1.0 : 0.0);
   }
 }
 
 // One elimination step of the 16x16 diagonal block held column per lane, r[i] = entry (i, lane & 15), A and the inverse
 // of its unit-lower factor IN THE SAME REGISTERS: before step K the lanes j >= K hold the columns of the partially
-// eliminated A, the lanes j < K the columns of  Bh = L^-1 D  (L^-1 so far, every column scaled by its pivot; the diagonal
-// entry r[j] of lane j stays d_j).  With m_i = A[i][K] (lane K) and 1/d:
-//   lanes j > K:  A[i][j]  -= m_i A[K][j] / d          (Schur complement)
-//   lanes j < K:  Bh[i][j] -= m_i Bh[K][j] / d         (row operation on the inverse: the same formula, r[K] is Bh[K][j])
-//   lane  j = K:  Bh[i][K]  = -m_i = r[i] + m_i (-2)    (exact: no reciprocal involved)
+// eliminated A, the lanes j < K the columns of  G = -L^-1 D  below the diagonal (L^-1 so far, every column scaled by its pivot,
+// sign flipped: the consumers fold the sign into the masks they apply anyway; the diagonal entry r[j] of lane j stays d_j).
+// With m_i = A[i][K] (lane K) and 1/d:
+//   lanes j > K:  A[i][j] -= m_i A[K][j] / d          (Schur complement)
+//   lanes j < K:  G[i][j] -= m_i G[K][j] / d          (row operation on the inverse: the same formula, r[K] is G[K][j])
+//   lane  j = K:  G[i][K]  = m_i                       (the lane keeps its registers: v = 0)
 // i.e. ONE v_fmac_f64_dpp per row for the factorisation and the inverse together.  What is left above the diagonal of
 // lane j (rows i < j: entries of D L^T) is dead and masked when the block is published.
+// COMP (compensated products, for the blocks the window record marks: ldl_comp).  Row i's multiplier comes from the pivot
+// COLUMN (lane K's r[i]) while the row factor v = -A[K][j] / d comes from the pivot ROW (lane j's r[K]): column and row agree in
+// exact arithmetic only — entry (i, j) takes fl(a_iK fl(a_Kj / d)), its mirror image fl(a_jK fl(a_Ki / d)), one ulp of the
+// PRODUCT apart.  Behind a pivot that cancels many digits — the yaw prior of the first pose, 1e16 n n^T across the three
+// rotation rows, leaves pivots 7.5e13, 2.9e6, 4.1e8 — that is 1e-9 of what is left, the elimination turns into the LU
+// factorisation of a matrix that is not symmetric any more, and the panel rows (L^-1 from the columns) stop matching the
+// trailing updates (which assume D L^T from the rows).  Measured against the oracle built in long double: the Gauss-Newton step
+// of the far-start DOGLEG case of test_dogleg_rejected_steps 1e-7 from the extended-precision solution of the same system
+// (an unblocked Cholesky: 4e-9), the cost after 20 iterations 3e-7 (tests/gpu_referee_*.py, profiles/r05_notes.md).  With
+// v = vh + vl, vl = fma(-A[K][j], 1/d, -vh) the part of the product that vh rounded away, and a second fmac per row,
+// entry and mirror image receive a_iK a_Kj / d to twice the working precision — the first fmac cancels exactly, the second
+// restores what vh had lost — and agree to an ulp of the RESULT: 1.2e-9 on the same case (the fp64 oracle: 3.5e-9).
+// 16 -> 31 instructions per pivot on the rows, +370 cycles per block.
 // d = r[K] of lane K (already broadcast).  FULL: all 16 pivots exist; otherwise act = (K < npiv) and an inactive step
 // changes nothing.  Lane K keeps 1 / d_K (0 when inactive) in `mine`.  Returns the next pivot, broadcast as soon as its
 // entry is final so that its reciprocal (the dependent chain) overlaps the remaining updates of this step.
 // GUARD: a pivot that is not positive is replaced by 1 (everything stays finite; the caller reports the failure).
-template <int K, bool FULL, bool GUARD = false>
+template <int K, bool FULL, bool GUARD = false, bool COMP = false>
 __device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool act, double& mine, int j, bool* bad = nullptr) {
   if constexpr (GUARD) {
     const bool neg = !(d > 0.0);
@@ -203,7 +217,11 @@ __device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool ac
   if (!FULL) rd = act ? rd : 0.0;
   const bool me = (j == K);
   double v = -r[K] * rd;
+  double vl = 0.0;
+  if constexpr (COMP) vl = fma(-r[K], rd, -v);   // what the product above rounded away (exact)
 #else
+  static_assert(!COMP, "the compensated elimination is written for LDL_PIVOT 0");
+  double vl = 0.0;
   // 1/d = y0 (1 + e)(1 + e^2), y0 the hardware estimate and e = 1 - d y0 (the two Newton steps of rcp_nr written out): the
   // multiplier -r[K] / d takes the same three factors one by one, so that it is ready four dependent instructions behind d
   // (estimate, e | -r[K] y0, two fused multiply-adds) instead of seven (estimate, two Newton steps, product).  The reciprocal
@@ -222,44 +240,51 @@ __device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool ac
   }
   const bool me = (j == K);
 #endif
-  v = me ? ((FULL || act) ? -2.0 : 0.0) : v;
+  v = me ? 0.0 : v;
+  if constexpr (COMP) vl = me ? 0.0 : vl;
   mine = me ? rd : mine;
   double dn = 1.0;
   if constexpr (K < 15) {
     fmac_bcast<K>(r[K + 1], r[K + 1], v);
+    if constexpr (COMP) fmac_bcast_nop<K>(r[K + 1], r[K + 1], vl);
     dn = bcast_nop<K + 1>(r[K + 1]);
   }
 #pragma unroll
   for (int i = K + 2; i < 16; ++i) fmac_bcast<K>(r[i], r[i], v);
+  if constexpr (COMP) {
+    if constexpr (K >= 11) asm volatile("s_nop 1");   // (fewer than three rows left: keep the DPP distance to the writes above)
+#pragma unroll
+    for (int i = K + 2; i < 16; ++i) fmac_bcast<K>(r[i], r[i], vl);
+  }
   return dn;
 }
 struct LdlNoHook { __device__ __forceinline__ void operator()() const {} };
 // (mid: called between the pivots 9 and 10 — wave 0 issues the requests for the hand-overs of its step there, late enough for
 // them to have arrived in the common case and early enough for the answers to be there when the elimination ends)
-template <bool FULL, bool GUARD = false, class HOOK = LdlNoHook>
+template <bool FULL, bool GUARD = false, class HOOK = LdlNoHook, bool COMP = false>
 __device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, double& mine, int j, bool* bad = nullptr, HOOK mid = HOOK()) {
   double d = bcast_nop<0>(r[0]);
-  d = ldl16_pivot<0, FULL, GUARD>(r, d, 0 < npiv, mine, j, bad);
-  d = ldl16_pivot<1, FULL, GUARD>(r, d, 1 < npiv, mine, j, bad);
-  d = ldl16_pivot<2, FULL, GUARD>(r, d, 2 < npiv, mine, j, bad);
-  d = ldl16_pivot<3, FULL, GUARD>(r, d, 3 < npiv, mine, j, bad);
-  d = ldl16_pivot<4, FULL, GUARD>(r, d, 4 < npiv, mine, j, bad);
-  d = ldl16_pivot<5, FULL, GUARD>(r, d, 5 < npiv, mine, j, bad);
-  d = ldl16_pivot<6, FULL, GUARD>(r, d, 6 < npiv, mine, j, bad);
-  d = ldl16_pivot<7, FULL, GUARD>(r, d, 7 < npiv, mine, j, bad);
-  d = ldl16_pivot<8, FULL, GUARD>(r, d, 8 < npiv, mine, j, bad);
-  d = ldl16_pivot<9, FULL, GUARD>(r, d, 9 < npiv, mine, j, bad);
+  d = ldl16_pivot<0, FULL, GUARD, COMP>(r, d, 0 < npiv, mine, j, bad);
+  d = ldl16_pivot<1, FULL, GUARD, COMP>(r, d, 1 < npiv, mine, j, bad);
+  d = ldl16_pivot<2, FULL, GUARD, COMP>(r, d, 2 < npiv, mine, j, bad);
+  d = ldl16_pivot<3, FULL, GUARD, COMP>(r, d, 3 < npiv, mine, j, bad);
+  d = ldl16_pivot<4, FULL, GUARD, COMP>(r, d, 4 < npiv, mine, j, bad);
+  d = ldl16_pivot<5, FULL, GUARD, COMP>(r, d, 5 < npiv, mine, j, bad);
+  d = ldl16_pivot<6, FULL, GUARD, COMP>(r, d, 6 < npiv, mine, j, bad);
+  d = ldl16_pivot<7, FULL, GUARD, COMP>(r, d, 7 < npiv, mine, j, bad);
+  d = ldl16_pivot<8, FULL, GUARD, COMP>(r, d, 8 < npiv, mine, j, bad);
+  d = ldl16_pivot<9, FULL, GUARD, COMP>(r, d, 9 < npiv, mine, j, bad);
 #ifndef LDL_HOOK_AT
 #define LDL_HOOK_AT 9
 #endif
   if (LDL_HOOK_AT == 9) mid();
-  d = ldl16_pivot<10, FULL, GUARD>(r, d, 10 < npiv, mine, j, bad);
-  d = ldl16_pivot<11, FULL, GUARD>(r, d, 11 < npiv, mine, j, bad);
-  d = ldl16_pivot<12, FULL, GUARD>(r, d, 12 < npiv, mine, j, bad);
+  d = ldl16_pivot<10, FULL, GUARD, COMP>(r, d, 10 < npiv, mine, j, bad);
+  d = ldl16_pivot<11, FULL, GUARD, COMP>(r, d, 11 < npiv, mine, j, bad);
+  d = ldl16_pivot<12, FULL, GUARD, COMP>(r, d, 12 < npiv, mine, j, bad);
   if (LDL_HOOK_AT == 12) mid();
-  d = ldl16_pivot<13, FULL, GUARD>(r, d, 13 < npiv, mine, j, bad);
-  d = ldl16_pivot<14, FULL, GUARD>(r, d, 14 < npiv, mine, j, bad);
-  d = ldl16_pivot<15, FULL, GUARD>(r, d, 15 < npiv, mine, j, bad);
+  d = ldl16_pivot<13, FULL, GUARD, COMP>(r, d, 13 < npiv, mine, j, bad);
+  d = ldl16_pivot<14, FULL, GUARD, COMP>(r, d, 14 < npiv, mine, j, bad);
+  d = ldl16_pivot<15, FULL, GUARD, COMP>(r, d, 15 < npiv, mine, j, bad);
   if (LDL_HOOK_AT == 15) mid();
 }
 
@@ -267,8 +292,10 @@ __device__ __forceinline__ void ldl16_eliminate(double (&r)[16], int npiv, doubl
 // block matrix whose column D holds the right-hand side.  x_out (LDS, >= D doubles, outside the matrix area) receives the
 // solution.  *s_fail (LDS int, zeroed by the caller before a barrier) is set when a pivot is not positive.
 // Ends with a barrier: x_out and *s_fail are visible to every thread on return.
+// comp_mask: bit b set = diagonal block b is eliminated with compensated products (ldl16_pivot<.., COMP>: +370 cycles per block).
 template <int NW>
-__device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x_out, int* s_fail, long long* stamps = nullptr, int Ds = 0) {
+__device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x_out, int* s_fail, long long* stamps = nullptr, int Ds = 0,
+                                            unsigned comp_mask = 0) {
   // Wave 0 carries the diagonal chain at raised priority and wants its SIMD for itself: the waves that share it (4, 8, 12:
   // waves w, w+4, w+8, w+12 of a workgroup sit on one SIMD, tests/micro/hwid.hip) would be starved exactly when the chain
   // needs their hand-offs (measured: a flag seen 5500 cycles late), so they own nothing and go straight to the last barrier.
@@ -289,7 +316,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
   const int ridx = (wave >> 2) * 3 + (wave & 3) - 1;                  // 0..11 for the block-owning waves
   // work area (aliases the assembled matrix once every block sits in registers)
   double* Rp = S;                          // [2][nb][256] panel row R_J of step kb in buffer kb & 1, accumulator layout
-  double* Xs = Rp + 2 * nb * 256;          // [nb][16][LDL_RS] Bh = L_II^-1 D_I as wave 0 leaves it: column j at j * LDL_RS (rows < j: dead)
+  double* Xs = Rp + 2 * nb * 256;          // [nb][16][LDL_RS] -Bh = -L_II^-1 D_I below the diagonal, d_j on it, as wave 0 leaves it: column j at j * LDL_RS (rows < j: dead)
   double* XB = Xs + nb * LDL_XB;           // [nb][16][LDL_RS] D^-1 Bh^T ... for the back-substitution: entry (i, j) of D^-1 Bh D^-1 masked, at j * LDL_RS + i
   double* Rsup = XB + nb * LDL_XB;         // [nb][16][LDL_RS] wave 0's copies of R_(K,K+1), row-major
   double* qbuf = Rsup + nb * LDL_XB;       // [2][256] block (I, I+1) with all its updates, accumulator layout
@@ -626,7 +653,7 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * (lane >> 4) + e;
           const double v = Xs[kb * LDL_XB + j * LDL_RS + i] * dinv[kb * 16 + i] * dj;
-          XB[kb * LDL_XB + j * LDL_RS + i] = i > j ? v : (i == j ? dj : 0.0);
+          XB[kb * LDL_XB + j * LDL_RS + i] = i > j ? -v : (i == j ? dj : 0.0);   // (Xs holds -Bh below the diagonal)
         }
         ldl_signal(&f_xb[kb], 1, lane);
       }
@@ -711,8 +738,21 @@ __device__ __forceinline__ void ldl16_solve(double* S, int D, int tid, double* x
       LDL_TSA(0);
       LDL_TS(0);
       LDL_TS(7);
-      if (kb < nb - 1) ldl16_eliminate<true>(c, 16, mine, j, nullptr, [&]() { request_handover(kb, lane); });
-      else ldl16_eliminate<false>(c, npiv, mine, j);
+      {
+        auto hook = [&]() { request_handover(kb, lane); };
+#ifdef LDL_COMP_ALL
+        const bool careful = true;
+#else
+        const bool careful = (comp_mask >> kb) & 1u;   // (uniform: the mask comes from the window record)
+#endif
+        if (kb < nb - 1) {
+          if (careful) ldl16_eliminate<true, false, decltype(hook), true>(c, 16, mine, j, nullptr, hook);
+          else ldl16_eliminate<true, false, decltype(hook), false>(c, 16, mine, j, nullptr, hook);
+        } else {
+          if (careful) ldl16_eliminate<false, false, LdlNoHook, true>(c, npiv, mine, j);
+          else ldl16_eliminate<false>(c, npiv, mine, j);
+        }
+      }
       bad = bad || (j < npiv && !(mine > 0.0 && mine < 1.0e300));   // a pivot was not positive
       LDL_TS(1);
       // publish Bh (column `lane` as it is: the consumers mask the dead entries above the diagonal) and 1/d

@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     STAMP(10);
     // (diagnostics: the solver's own stamps — load | factor | back-substitution, and with -DLDL_TS_ALL wave 0's steps — as 64-bit
     // integers behind the phase stamps)
-    ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail, (W.prof && blockIdx.x == 0) ? reinterpret_cast<long long*>(W.prof + 64) : nullptr, D - Dp);
+    ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail, (W.prof && blockIdx.x == 0) ? reinterpret_cast<long long*>(W.prof + 64) : nullptr, D - Dp, W.ldl_comp);
   }
   STAMP(7);
   if (s_fail) {  // not positive definite: invalid step (handled like a rejection)

@@ -63,14 +63,15 @@ def test_dogleg_matches_oracle(oracle, case, radius):
 
 
 def test_dogleg_rejected_steps(oracle):
-    """Far starts with rejected steps.  Seed 41 crawls along a flat valley (466.0026 after 20 iterations, 465.70 after 80) and its
-    cost there depends on the rounding at the 1e-6 level for as long as it crawls: against the oracle 9.7e-7 / 5.6e-7 / 1.7e-6 /
-    5.7e-8 / 1.7e-6 with 64 / 32 / 24 / 16 / 8 landmarks per linearise group (tests/gpu_dogleg_rejected_diag.py; the same accepted and
-    rejected steps every time); the other seeds agree to 1e-9 and better.  The index build's default for one window is 16."""
+    """Far starts with rejected steps.  Seed 41 crawls along a flat valley (466.0026 after 20 iterations, 465.70 after 80).  Until
+    round 5 its cost sat 6e-7 ... 1.7e-6 from the oracle depending on the landmarks per linearise group (rounding-level differences
+    in the reduced matrix) and this test ran at 1e-6.  The oracle built in long double (tests/test_oracle_referee.py) settled which
+    side moved: the fp64 oracle is 3.5e-9 from the extended-precision run, the GPU was 3e-7 — the elimination of the diagonal
+    block that carries the first pose's yaw prior (ba_ldl16.hpp).  With compensated products there: 1.2e-9; bound 1e-7."""
     found = False
     for seed in (41, 42, 43, 44):
         w = synthetic.small_window(seed=seed, K=5, L=60, pose_noise=(0.4, np.deg2rad(6.0)), landmark_noise=0.8)
-        s = _compare(oracle, w, 20, tol=1e-6, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+        s = _compare(oracle, w, 20, tol=1e-7, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
         found = found or s["successful_steps"] < s["iterations"]
     assert found
 
