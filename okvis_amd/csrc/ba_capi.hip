@@ -901,17 +901,9 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // rotation rows), whose elimination cancels the leading digits of the block.  ba_ldl16.hpp eliminates them with compensated
     // products (profiles/r05_notes.md, "the referee").  The solver numbers the speed/bias part first (L16::perm).
     unsigned m = 0;
-    if (!std::getenv("OKVIS_BA_NO_LDL_COMP")) {
-      // (larger systems: the tiled solver keeps the caller's numbering, 48 x 48 tiles of three 16-blocks; blocks from 32 on stay unmarked)
-      const bool lds = D <= MAX_D_LDS;
-      const L16 LY{ldl16_nb(D), lds ? D - Dp : 0, D};
-      auto mark = [&](int off, int n) {
-        if (off >= 0)
-          for (int k = 0; k < n; ++k) {
-            const int b = LY.perm(off + k) >> 4;
-            if (b < 32) m |= 1u << b;
-          }
-      };
+    if (D <= MAX_D_LDS && !std::getenv("OKVIS_BA_NO_LDL_COMP")) {   // (the tiled solver of larger systems: not compensated, ba_chol_tiles.hpp)
+      const L16 LY{ldl16_nb(D), D - Dp, D};
+      auto mark = [&](int off, int n) { if (off >= 0) for (int k = 0; k < n; ++k) m |= 1u << (LY.perm(off + k) >> 4); };
       for (int i = 0; i < w.n_pprior; ++i) mark(pose_off[w.pprior_pose[i]], 6);
       for (int b = 0; b < nmb; ++b) {
         const bool pose = w.marg_block_type[b] == OKVIS_BA_BLOCK_POSE;

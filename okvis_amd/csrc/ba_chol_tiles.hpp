@@ -46,7 +46,6 @@ struct CholTiles {   // per-window workspace of the tiled solver (device pointer
   int* progress = nullptr;   // number of diagonal tiles published so far (null: every wait polls its flag from the start)
   double* x = nullptr;   // [48 nT] solution; when set, tasks nT(nT+1)/2 .. + nT - 1 are the back-substitution (below)
   double* tl = nullptr;  // diagnostics: per task 4 wall_clock64() stamps (start, dependencies met, own work done, flag set)
-  unsigned comp = 0;     // bit b: the 16 rows / columns from 16 b are eliminated with compensated products (WinPtrs::ldl_comp)
 };
 
 __device__ __forceinline__ int ct_tile_index(int i, int j) { return i * (i + 1) / 2 + j; }
@@ -169,7 +168,7 @@ __device__ __forceinline__ double ct_rsqrt(double x) {  // v_rsq_f64 + two Newto
 // right-looking factorisation with 6-wide block columns, the diagonal block factored and inverted by one work-item, 20.5 us).
 //   M: 48x48 SPD in LDS (stride CT_LD, lower triangle referenced; overwritten).  X: L^-1 with A = L L^T (full square, zeros
 //   above the diagonal) = D^-1/2 Lt^-1 for A = Lt D Lt^T.  R: 48 x CT_LD scratch.  dinv: 48 doubles scratch.
-__device__ void ct_ldl_inv48(double* M, double* X, double* R, double* dinv, int tid, int* s_fail, unsigned comp3 = 0) {
+__device__ void ct_ldl_inv48(double* M, double* X, double* R, double* dinv, int tid, int* s_fail) {
   const int lane = tid & 63, wave = tid >> 6, j = lane & 15;
   // ---- one elimination step of the chain: diagonal block b (rows / columns 16 b ..) of M -> unit-lower inverse into X
   auto eliminate = [&](int b) {
@@ -182,9 +181,10 @@ __device__ void ct_ldl_inv48(double* M, double* X, double* R, double* dinv, int 
         c[i] = M[(16 * b + hi) * CT_LD + 16 * b + lo];
       }
       bool bad = false;
-      // (guarded: a pivot that is not positive becomes 1, the tile reports failure; comp3: ba_ldl16.hpp, ldl16_pivot<.., COMP>)
-      if ((comp3 >> b) & 1u) ldl16_eliminate<true, true, LdlNoHook, true>(c, 16, mine, j, &bad);
-      else ldl16_eliminate<true, true>(c, 16, mine, j, &bad);
+      // (guarded: a pivot that is not positive becomes 1, the tile reports failure.  Not compensated — ba_ldl16.hpp, ldl16_pivot<.., COMP>:
+      //  a second instantiation in this kernel costs 41 registers, scratch and half the occupancy, configs[2] 327 -> 398 us per solve,
+      //  and two D = 300 windows showed nothing to gain against the long double referee, profiles/r05_referee_large.txt)
+      ldl16_eliminate<true, true>(c, 16, mine, j, &bad);
       if (bad && lane == 0) *s_fail = 1;
       if (lane < 16) {
         dinv[16 * b + j] = mine;
@@ -387,7 +387,7 @@ __device__ void chol_chain_task(const CholTiles& C, double* lds) {
     ct_release();   // (the stores of L_(j,j-1), issued two phases ago, have been performed)
     __syncthreads();
     if (tid == 0 && j > 0) ct_raise(C.flag + ct_tile_index(j, j - 1));
-    ct_ldl_inv48(sC, sB, sA, s_dinv, tid, &s_fail, 3 * j < 32 ? (C.comp >> (3 * j)) & 7u : 0u);
+    ct_ldl_inv48(sC, sB, sA, s_dinv, tid, &s_fail);
     if (C.tl && tid == 0) C.tl[4 * task_jj + 2] = (double)wall_clock64();
     if (tid < CT_TB) {   // y_j = Linv_j r_j
       double v = 0;

@@ -1632,7 +1632,6 @@ __global__ __launch_bounds__(CT_THREADS) void chol_tiles_window_kernel(const Win
   C.progress = W.ct_flag + ntile + 3;
   C.pflag = W.ct_flag + ntile + 4;
   C.x = W.ct_x;
-  C.comp = W.ldl_comp;
   C.tl = (W.prof && blockIdx.y == 0) ? W.prof + 64 : nullptr;   // diagnostics (debug_arrays): task timeline behind the phase stamps
   chol_tile_task(C, blockIdx.x, ct_smem);
 }

@@ -180,8 +180,8 @@ struct alignas(64) WinPtrs {
   int fuse_fast;          // fused mode: the groups of this window qualify for the matrix-core reduction (ba_linearize.hpp)
   int spart_buf_stride;   // doubles between the partials of linearisation buffer 0 and 1 (fused mode: one set per buffer); 0 = one set
   int lin2;               // the index lists are those of the piece path (ba_linearize2.hpp)
-  unsigned ldl_comp;      // bit b: diagonal 16-block b of the dense solver's ordering (ba_ldl16.hpp; the tiled solver: the caller's)
-                          // holds columns of a pose prior or of the marginalisation prior and is eliminated with compensated products
+  unsigned ldl_comp;      // bit b: diagonal block b of the solver's ordering (ba_ldl16.hpp) holds columns of a pose prior or of the
+                          // marginalisation prior and is eliminated with compensated products (D <= MAX_D_LDS; 0 otherwise)
   int pad0_;
   double cauchy_b;
   ImuParamsD imu;

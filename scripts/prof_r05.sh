@@ -58,6 +58,10 @@ timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c_trace -
 f=$(find $O/c_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_config_C.csv
 rm -rf $O/c_trace
 cd $R
+# the long double referee: spread of the far-start DOGLEG case, the random sweep's seeds, two D = 300 windows
+timeout 300 python tests/gpu_referee_spread.py > $O/referee_spread41.txt 2>&1
+timeout 300 python tests/gpu_sweep_gaps.py > $O/referee_sweep_gaps.txt 2>&1
+timeout 300 python tests/gpu_referee_large.py > $O/referee_large.txt 2>&1
 timeout 200 python tests/gpu_replay_timing.py > $O/replay_timing.txt 2>&1
 grep -E "medians|route" $O/replay_timing.txt | head
 timeout 200 python scripts/bench_marginalize.py --config-c > $O/bench_marginalize.json 2> $O/bench_marginalize.err
