@@ -1169,6 +1169,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       }
     }
     OFF(imu_cache, put(A, caches));
+    OFF(imu_cache_prev, put_zero(A, sizeof(ImuCacheD) * (size_t)w.n_imu));
   }
   OFF(pprior_pose, put_n(A, w.pprior_pose, (size_t)w.n_pprior));
   OFF(pprior_meas, put_n(A, w.pprior_meas, 7 * (size_t)w.n_pprior));

@@ -656,11 +656,11 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
 }
 #undef RSTAMP
 
-__device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int tid) {
+__device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int tid, int spec_discard = 0) {
   __shared__ double s_db[6];
   // the trial states p0[7] | p1[7] | b0[9] | b1[9] and the cache's reference bias [9]
   __shared__ double s_st[32 + 9];
-  __shared__ int s_valid;
+  __shared__ int s_valid, s_prev;
   if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[62] = (double)clock64();   // diagnostics: length of one IMU workgroup
   double* ca = lds + EvalLds::CA;
   const double* p0 = W.pose[trial] + 7 * (size_t)W.imu_pose0[f];
@@ -669,6 +669,7 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
   const double* b1 = W.sb[trial] + 9 * (size_t)W.imu_sb1[f];
   const double Dt = ns_to_sec(W.imu_t1[f] - W.imu_t0[f]);
   ImuCacheD* cg = W.imu_cache + f;
+  ImuCacheD* cp = W.imu_cache_prev + f;
   // Everything the factor reads from HBM — the preintegration record, the four state blocks, the record's reference bias and its
   // state word — is requested in one go, every work-item its share, and waits at ONE barrier.  (Before: work-item 0 fetched the
   // bias and the reference for the bias check, barrier, then the record came in, barrier, then work-item 0 fetched the poses
@@ -694,9 +695,32 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
     else if (u >= 23 && u < 32) s_st[u] = b1[u - 23];
     else if (u >= 32 && u < 41) s_st[u] = cg->sb_ref[u - 32];
     else if (u == 41) s_valid = cg->valid;
+    else if (u == 42) s_prev = cp->valid;
   };
   stage();
   __syncthreads();
+  // ---- the record follows the reference's sequence of evaluations.  ImuError's preintegration members are `mutable`: every
+  // Evaluate call may redo them and what it leaves stays, whether the step is accepted or not (ImuError.cpp:541-558).  This
+  // backend makes one kind of evaluation Ceres never makes: the Gauss-Newton point, tried speculatively before its length is
+  // known, when it turns out to lie outside the trust region (Ctrl::spec_discard; the explicit dogleg step replaces it).  If
+  // that evaluation re-preintegrated — a Gauss-Newton point far away moves the gyro bias past the threshold — the record it
+  // overwrote comes back here, before this evaluation looks at its own bias.  (Until round 5 it stayed: the explicit trial then
+  // saw a reference bias further away than the threshold and integrated once more, at ITS bias, where the reference still
+  // has the preintegration of the last real evaluation — costs 1e-9 ... 1e-5 apart in the middle of radius-limited runs,
+  // two re-preintegrations of 104 us for none.  Found with the long double referee, tests/gpu_cost_consistency.py.)
+  if (s_prev) {   // (uniform; rare: the previous evaluation of this term re-preintegrated)
+    if (spec_discard) {
+      const double* src = reinterpret_cast<const double*>(cp);
+      double* dst = reinterpret_cast<double*>(cg);
+      for (int i = tid; i < (int)(sizeof(ImuCacheD) / 8); i += IMU_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tid == 0) cp->valid = 0;
+    if (spec_discard) {
+      stage();
+      __syncthreads();
+    }
+  }
   // ---- bias check of ImuError::EvaluateWithMinimalJacobians (ImuError.cpp:541-558), by every work-item from the staged values
   // (a uniform verdict, no second barrier): re-preintegrate on first use or when |b_g - b_g,ref| * dt > 1e-4 (rarely taken)
   {
@@ -724,6 +748,11 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
       double sbx[9];
       for (int i = 0; i < 9; ++i) sbx[i] = redo_ref ? s_st[32 + i] : s_st[14 + i];
       __syncthreads();   // (every work-item has read what it needs of the staged values: the re-preintegration reuses the LDS)
+      if (v == 1 || v == 2) {   // keep what is about to be overwritten: the next evaluation may have to take it back (see above)
+        const double* src = reinterpret_cast<const double*>(cg);
+        double* dst = reinterpret_cast<double*>(cp);
+        for (int i = tid; i < (int)(sizeof(ImuCacheD) / 8); i += IMU_THREADS) dst[i] = src[i];
+      }
       imu_redo(W, f, sbx, lds, tid);   // updates the HBM cache in place; ends with a barrier
       stage();
       __syncthreads();
@@ -932,13 +961,14 @@ __device__ void small_factors(const WinPtrs& W, int trial, double* lds, int tid)
     const double* m = W.pprior_meas + 7 * (size_t)f;
     const double* SI = W.pprior_sqrtinfo + 36 * (size_t)f;
     double q[4] = {x[3], x[4], x[5], x[6]}, qm[4] = {m[3], m[4], m[5], m[6]};
-    qnormalize(q);
-    qnormalize(qm);
+    // (the *_strict forms: a pose at its prior gives dq.xyz = 0 exactly, as the reference's arithmetic does — ba_math.hpp)
+    qnormalize_strict(q);
+    qnormalize_strict(qm);
     double qi[4], dq[4];
-    qinv(q, qi);
-    qnormalize(qi);
-    qmul(qm, qi, dq);
-    qnormalize(dq);
+    qinv_strict(q, qi);
+    qnormalize_strict(qi);
+    qmul_strict(qm, qi, dq);
+    qnormalize_strict(dq);
     const double e[6] = {m[0] - x[0], m[1] - x[1], m[2] - x[2], 2 * dq[0], 2 * dq[1], 2 * dq[2]};
     double J0[36];
     for (int i = 0; i < 36; ++i) J0[i] = 0;
@@ -979,13 +1009,13 @@ __device__ void small_factors(const WinPtrs& W, int trial, double* lds, int tid)
     const double* x1 = W.pose[trial] + 7 * (size_t)W.rel_pose1[f];
     const double* SI = W.rel_sqrtinfo + 36 * (size_t)f;
     double q0[4] = {x0[3], x0[4], x0[5], x0[6]}, q1[4] = {x1[3], x1[4], x1[5], x1[6]};
-    qnormalize(q0);
-    qnormalize(q1);
+    qnormalize_strict(q0);
+    qnormalize_strict(q1);
     double qi[4], dq[4];
-    qinv(q0, qi);
-    qnormalize(qi);
-    qmul(q1, qi, dq);
-    qnormalize(dq);
+    qinv_strict(q0, qi);
+    qnormalize_strict(qi);
+    qmul_strict(q1, qi, dq);
+    qnormalize_strict(dq);
     const double e[6] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2], 2 * dq[0], 2 * dq[1], 2 * dq[2]};
     double P3[9], O3[9];
     qplus33(dq, P3);
@@ -1080,7 +1110,7 @@ __device__ __forceinline__ void small_body(const WinPtrs& W, int init, int bx, d
   if (!init && !ctrl->pending) return;
   const int trial = 1 - ctrl->acc;
   if (bx < W.n_imu)
-    imu_factor(W, bx, trial, smem, threadIdx.x);
+    imu_factor(W, bx, trial, smem, threadIdx.x, init ? 0 : ctrl->spec_discard);
   else
     small_factors(W, trial, smem, threadIdx.x);
 }

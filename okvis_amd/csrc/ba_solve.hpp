@@ -1438,6 +1438,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
         c.step2_p = a0;
         c.x2_p = a1;
         c.tr_kind = 1;
+        c.spec_discard = c.explicit_next == 2;   // (the IMU terms take back what the discarded evaluation did to them: ba_imu.hpp)
         if (c.explicit_next == 1) c.iter++;   // a new iteration (after a rejection); 2 = same iteration redone
         c.explicit_next = 0;
         c.lambda = mu;
@@ -1539,6 +1540,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       c.x2_p = a3;
       c.lambda = lambda;
       c.tr_kind = 0;         // dogleg: the Gauss-Newton point, launched speculatively
+      c.spec_discard = 0;
       c.explicit_next = 0;
       c.have_tot = 0;
       c.iter++;
@@ -1727,6 +1729,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
       c.step2_p = a0;
       c.x2_p = a1;
       c.tr_kind = 1;
+      c.spec_discard = c.explicit_next == 2;
       if (c.explicit_next == 1) c.iter++;
       c.explicit_next = 0;
       c.lambda = mu;
@@ -1794,6 +1797,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
     c.x2_p = a3;
     c.lambda = lambda;
     c.tr_kind = 0;
+    c.spec_discard = 0;
     c.explicit_next = 0;
     c.have_tot = 0;
     c.iter++;

@@ -145,7 +145,10 @@ struct Ctrl {
   double pend_model;  // model cost change of the pending explicit trial
   double tot_C, tot_E;  // g.dGN and |gnhat|^2 of the accepted point (pose + landmark parts), valid when have_tot
   double tot_A;       // (diagnostic) |ghat|^2 of the last explicit step
-  int have_tot, pad2;
+  int have_tot;
+  int spec_discard;   // 1 = the pending (explicit) trial replaces a speculative Gauss-Newton trial that was evaluated and turned out to lie
+                      // outside the trust region: an evaluation the reference never makes.  The IMU terms take back what that
+                      // evaluation did to their preintegration (ba_imu.hpp, imu_factor) before they look at the new trial
 };
 static_assert(sizeof(Ctrl) % 8 == 0 && sizeof(Ctrl) / 8 <= 64, "Ctrl is fetched by one wave, one double per lane");
 // The control records of a solver's windows sit in ONE array behind its window records (okvis_ba_upload), one 256-byte slot
@@ -286,6 +289,7 @@ struct alignas(64) WinPtrs {
   const BA_G int* imu_s_begin; const BA_G int* imu_s_count;
   const long long* imu_s_t; const BA_G double* imu_s_gyr; const BA_G double* imu_s_acc;
   BA_G ImuCacheD* imu_cache;
+  BA_G ImuCacheD* imu_cache_prev;   // [n_imu] the record as it was before the last evaluation re-preintegrated it (valid = 0: it did not)
 
   // ---- priors ----
   const BA_G int* pprior_pose; const BA_G double* pprior_meas; const BA_G double* pprior_sqrtinfo;

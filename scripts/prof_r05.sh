@@ -62,6 +62,9 @@ cd $R
 timeout 300 python tests/gpu_referee_spread.py > $O/referee_spread41.txt 2>&1
 timeout 300 python tests/gpu_sweep_gaps.py > $O/referee_sweep_gaps.txt 2>&1
 timeout 300 python tests/gpu_referee_large.py > $O/referee_large.txt 2>&1
+timeout 300 python tests/gpu_referee_marg.py > $O/referee_marg.txt 2>&1
+timeout 300 python tests/gpu_tolerance_audit.py > $O/tolerance_audit.txt 2>&1
+timeout 200 python tests/gpu_referee_dogleg_iters.py 2 30 > $O/referee_dogleg_iters.txt 2>&1
 timeout 200 python tests/gpu_replay_timing.py > $O/replay_timing.txt 2>&1
 grep -E "medians|route" $O/replay_timing.txt | head
 timeout 200 python scripts/bench_marginalize.py --config-c > $O/bench_marginalize.json 2> $O/bench_marginalize.err

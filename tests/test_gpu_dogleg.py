@@ -52,14 +52,35 @@ def _compare(oracle, w, n, tol=1e-9, **kw):
 @pytest.mark.parametrize("radius", [1e4, 30.0, 1.0])
 def test_dogleg_matches_oracle(oracle, case, radius):
     w = synthetic.small_window(**G.SMALL[case])
-    # Interpolated steps depend on |gnhat|, the D-normalised length of the Gauss-Newton point, which weights the weakly
-    # constrained directions: with mu = 1e-8 the reduced system of these windows has condition ~1e15 (first-pose prior
-    # 1e16 next to 1e6 entries) and two correct factorisations differ by 1e-8 in that length (plain fp64 Cholesky vs
-    # extended precision: 4e-10; tests/micro note in DESIGN.md).  Pure Gauss-Newton iterations (radius 1e4) are not
-    # affected; the north_star tolerance on the final cost is 1e-6.
-    s = _compare(oracle, w, 10, tol=1e-9 if radius == 1e4 else 1e-6, initial_radius=radius)
+    # (Until round 5 the radius-limited runs — 30: interpolated steps, 1: scaled Cauchy steps — were compared at 1e-6 and explained
+    # with the conditioning of |gnhat|.  The long double referee showed the oracle at 1e-11 and the GPU at 1e-8 ... 2e-7 in those runs,
+    # 1e-5 in their middle: a Gauss-Newton point evaluated speculatively and then replaced by an explicit step had re-preintegrated
+    # IMU terms, an evaluation the reference never makes; its trace is now taken back (ba_imu.hpp, Ctrl::spec_discard).  Measured
+    # now against the oracle: <= 3e-11, tests/gpu_tolerance_audit.py.)
+    s = _compare(oracle, w, 10, tol=1e-9, initial_radius=radius)
     if radius == 1.0:
         assert s["final_radius"] > 1e3
+
+
+@pytest.mark.parametrize("case,radius", [(2, 30.0), (1, 1.0)])
+def test_radius_limited_runs_iteration_by_iteration(oracle, case, radius):
+    """The middle of a radius-limited run, not only its end: after every iteration the cost agrees with the oracle's and every IMU
+    term holds the preintegration of the reference's sequence of evaluations — the same reference bias as the oracle's ImuError
+    restatement.  (Round 5: a speculative Gauss-Newton evaluation that was replaced by an explicit step left its
+    re-preintegration behind; the costs of iterations 3 - 5 of the first case were 1e-5 from the oracle's, at 1e-7 by the end.)"""
+    w = synthetic.small_window(**G.SMALL[case])
+    kw = dict(initial_radius=radius, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    for n in range(1, 7):
+        b = solver.WindowBatch([w], options=_opts(**kw))
+        sg = b.optimize(n)[0]
+        ref_g = b.array("IMU_SB_REF")
+        b.close()
+        o = oracle.OracleWindow(w)
+        sr = o.optimize(n, _opts(**kw))
+        assert (sg["iterations"], sg["successful_steps"]) == (sr["iterations"], sr["successful_steps"])
+        # (1e-8: in the middle of the descent the fp64 oracle itself is 1e-9 from the long double run, the GPU 1e-10 — tests/gpu_referee_dogleg_iters.py)
+        assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-8 * sr["final_cost"], (n, sg["final_cost"], sr["final_cost"])
+        assert np.abs(ref_g - o.array("IMU_SB_REF")).max() <= 1e-9, n   # (a re-preintegration at a state 1e-12 apart; a stale reference would be 1e-3 off)
 
 
 def test_dogleg_rejected_steps(oracle):
@@ -84,20 +105,20 @@ def test_dogleg_function_tolerance_returns_without_the_step(oracle):
 
 def test_dogleg_without_jacobi_scaling(oracle):
     w = synthetic.small_window(**G.SMALL[1])
-    _compare(oracle, w, 8, tol=1e-6, jacobi_scaling=0, initial_radius=100.0)
+    _compare(oracle, w, 8, tol=1e-9, jacobi_scaling=0, initial_radius=100.0)
 
 
 def test_dogleg_config_A(oracle):
     w = synthetic.config_A()
     _compare(oracle, w, 10)
-    _compare(oracle, w, 6, tol=1e-6, initial_radius=50.0)
+    _compare(oracle, w, 6, tol=1e-9, initial_radius=50.0)
 
 
 def test_dogleg_large_window_tiled_solver(oracle):
     w = synthetic.make_window(20, 200, 1.0, seed=33, frame_dt=0.1)   # D = 300 > 174
     assert w.reduced_dim() == 300
     _compare(oracle, w, 6, tol=1e-8)
-    _compare(oracle, w, 6, tol=1e-6, initial_radius=40.0)
+    _compare(oracle, w, 6, tol=1e-8, initial_radius=40.0)
 
 
 def test_dogleg_batch_with_different_slot_counts(oracle):

@@ -30,11 +30,13 @@ def check(g, r, tol=1e-9):
     assert np.array_equal(g["block_type"], r["block_type"]) and np.array_equal(g["block_idx"], r["block_idx"])
     assert np.array_equal(g["block_off"], r["block_off"])
     assert rel(g["H"], r["H"]) < tol
-    # b0 = -(g - W V^+ b_l) cancels terms weighted with the 1e8 / 1e16 prior information (same effect as
-    # REDUCED_RHS in test_gpu_parity.py): compare at 1e-6 relative, measured 1e-8 .. 1e-15
-    assert rel(g["b0"], r["b0"]) < 1e-6
+    # (until round 5: 1e-6, "b0 cancels terms weighted with the prior information".  It was not cancellation: the first pose sits
+    #  at its prior, the reference's quaternion arithmetic gives a residual of exactly zero there and the kernel's contracted
+    #  products gave 1e-17, times 1e16 — ba_math.hpp, qmul_strict; against the long double oracle now 3e-15 ... 4e-14,
+    #  tests/gpu_referee_marg.py)
+    assert rel(g["b0"], r["b0"]) < max(tol, 1e-9)
     assert rel(g["J"].T @ g["J"], r["J"].T @ r["J"]) < tol
-    assert rel(g["J"].T @ g["e0"], r["J"].T @ r["e0"]) < 1e-6
+    assert rel(g["J"].T @ g["e0"], r["J"].T @ r["e0"]) < max(tol, 1e-9)
     assert rel(g["J"].T @ g["J"], g["H"]) < 1e-9
 
 

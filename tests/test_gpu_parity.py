@@ -46,7 +46,7 @@ def test_linearisation_arrays_match_oracle(oracle, ext, model):
     assert o.solve(opt.initial_radius, opt) == 0
     S_g, S_r = b.array("REDUCED_S"), o.array("REDUCED_S")
     _close(S_g, S_r, 1e-12)
-    _close(b.array("REDUCED_RHS"), o.array("REDUCED_RHS"), 1e-6)   # rhs = -g + Yb cancels 1e16-weighted terms
+    _close(b.array("REDUCED_RHS"), o.array("REDUCED_RHS"), 1e-9)   # (1e-6 until round 5: the pose prior's residual, ba_math.hpp qmul_strict)
     _close(b.array("STEP"), o.array("STEP"), 1e-8)
     b.close()
 
