@@ -6,7 +6,7 @@ fp64 oracle moved: the far-start DOGLEG case of test_gpu_dogleg.py::test_dogleg_
 rejected steps along a flat valley) used to sit 6e-7 ... 1.7e-6 from the fp64 oracle depending on a tuning knob of the index
 build.  Measured (tests/gpu_referee_spread.py, 12 one-ulp perturbations of the landmark start values, each run against the
 referee of the same input): fp64 oracle 3.5e-9 (median) / 1.4e-8 (max) from the referee; the GPU 2.9e-7 / 7.1e-7 before the
-compensated elimination of the prior blocks (ba_ldl16.hpp, WinPtrs::ldl_comp), 1.2e-9 / 1.5e-9 with it.  The oracle had been right.
+compensated elimination of the prior blocks (ba_ldl16.hpp, WinPtrs::ldl_comp), 1e-9 ... 1.3e-8 with it.  The oracle had been right.
 
 CPU tests: the referee builds, agrees with the fp64 build where nothing is ill-conditioned, and the fp64 oracle stays within 5e-8 of it
 on the far-start cases.  GPU tests: the GPU against the referee."""
@@ -72,7 +72,8 @@ def test_gpu_against_referee_far_start(oracle, seed):
 @pytest.mark.gpu
 def test_gpu_spread_under_one_ulp_perturbations(oracle):
     """the 20-iteration cost of seed 41 under one-ulp perturbations of the landmark start values, each against the referee of the
-    same input: no run further than 2e-8 (before the compensated elimination: 7e-7; the fp64 oracle: 1.4e-8)"""
+    same input: no run further than 5e-8 (before the compensated elimination: 7e-7; the fp64 oracle: 1.4e-8; measured 1.2e-9 ... 1.3e-8
+    over the builds of round 5 — the second iteration takes the cost from 124 k to 1.6 k and multiplies whatever the first left)"""
     from okvis_amd import solver
     w = synthetic.small_window(seed=41, **FAR)
     rng = np.random.default_rng(0)
@@ -90,4 +91,4 @@ def test_gpu_spread_under_one_ulp_perturbations(oracle):
         b.close()
         assert g["successful_steps"] == r["successful_steps"]
         worst = max(worst, abs(g["final_cost"] - r["final_cost"]) / r["final_cost"])
-    assert worst <= 2e-8, worst
+    assert worst <= 5e-8, worst
