@@ -53,8 +53,9 @@ def test_rejected_steps_take_the_reload_path(oracle):
     for seed in (41, 42, 43, 44):
         w = synthetic.small_window(seed=seed, K=5, L=60, pose_noise=(0.4, np.deg2rad(6.0)), landmark_noise=0.8)
         # tolerance: with a radius of 1e8 the first systems are almost undamped and ill-conditioned; GPU and oracle
-        # differ by 1e-11 after ONE iteration and that grows to 6e-8 over the 25 (north_star asks 1e-6)
-        s = _compare(oracle, w, 25, tol=1e-6, initial_radius=1e8, function_tolerance=0.0, gradient_tolerance=0.0,
+        # differ by 1e-11 after ONE iteration and that grows to 6e-8 over the 25 (north_star asks 1e-6; against the long double
+        # oracle the GPU is at 2.7e-8 and the fp64 oracle at 3.2e-8 on seed 41, 1e-11 ... 1e-13 on the others: tests/gpu_tolerance_audit.py)
+        s = _compare(oracle, w, 25, tol=5e-7, initial_radius=1e8, function_tolerance=0.0, gradient_tolerance=0.0,
                      parameter_tolerance=0.0)
         found = found or s["successful_steps"] < s["iterations"]
     assert found, "no rejected step in any of the seeds: the scenario does not exercise the path"
@@ -189,8 +190,8 @@ def test_speed_bias_coupling_structures(oracle, maker):
         lin[2, :7] = synthetic.pose_oplus(w.pose[1], rng.normal(0, 0.02, 6))
         lin[3] = w.sb[2] + rng.normal(0, 0.01, 9)
         w.marg_lin = lin
-    _compare(oracle, w, 6, tol=1e-6)
-    _compare(oracle, w, 6, tol=1e-6, strategy=1)   # Levenberg-Marquardt damping
+    _compare(oracle, w, 6, tol=1e-9)   # (1e-6 until round 5; measured <= 7e-12 after the fixes the long double referee led to)
+    _compare(oracle, w, 6, tol=1e-9, strategy=1)   # Levenberg-Marquardt damping
 
 
 def _random_structure(seed):
@@ -249,7 +250,7 @@ def test_random_coupling_graphs(oracle, seed):
     op.function_tolerance = op.gradient_tolerance = op.parameter_tolerance = 0.0
     ow = oracle.OracleWindow(w)
     sr = ow.optimize(4, op)
-    assert abs(s1["final_cost"] - sr["final_cost"]) <= 1e-6 * sr["final_cost"], (s1, sr)
+    assert abs(s1["final_cost"] - sr["final_cost"]) <= 1e-9 * sr["final_cost"], (s1, sr)   # (1e-6 until round 5)
     assert (s1["iterations"], s1["successful_steps"]) == (sr["iterations"], sr["successful_steps"])
     for a, c in zip(x1, ow.get_state()):
         assert np.abs(a - c).max() < 1e-5
