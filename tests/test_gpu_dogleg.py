@@ -84,6 +84,25 @@ def test_radius_limited_runs_iteration_by_iteration(oracle, case, radius):
         assert np.abs(ref_g - o.array("IMU_SB_REF")).max() <= 1e-9, n   # (a re-preintegration at a state 1e-12 apart; a stale reference would be 1e-3 off)
 
 
+def test_imu_reference_biases_follow_the_oracle_in_a_batch(oracle):
+    """Six far starts in one batch, ten DOGLEG iterations with the default tolerances: every IMU term ends with the reference bias
+    the oracle's ImuError restatement ends with — the preintegrations were redone at the same evaluations, no more and no less
+    (speculative evaluations that are discarded leave no trace: Ctrl::spec_discard) — and some of them did move."""
+    ws = [synthetic.small_window(seed=s, K=5, L=60, pose_noise=(0.4, np.deg2rad(6.0)), landmark_noise=0.8) for s in range(41, 47)]
+    b = solver.WindowBatch(ws, options=_opts())
+    sg = b.optimize(10)
+    moved = 0
+    for i, w in enumerate(ws):
+        o = oracle.OracleWindow(w)
+        sr = o.optimize(10, _opts())
+        assert (sg[i]["iterations"], sg[i]["successful_steps"], sg[i]["termination"]) == (sr["iterations"], sr["successful_steps"], sr["termination"]), i
+        ref_o = o.array("IMU_SB_REF").reshape(-1, 9)
+        assert np.abs(b.array("IMU_SB_REF", i).reshape(-1, 9) - ref_o).max() <= 1e-8, i
+        moved += int((np.abs(ref_o - w.sb[:-1]).max(axis=1) > 0).sum())
+    b.close()
+    assert moved > 0, "no term was re-preintegrated: the scenario does not exercise the path"
+
+
 def test_dogleg_rejected_steps(oracle):
     """Far starts with rejected steps.  Seed 41 crawls along a flat valley (466.0026 after 20 iterations, 465.70 after 80).  Until
     round 5 its cost sat 6e-7 ... 1.7e-6 from the oracle depending on the landmarks per linearise group (rounding-level differences
