@@ -122,7 +122,10 @@ struct Ctrl {
   int iter;         // iterations started (excluding iteration 0)
   int successful;
   int chol_fail;    // diagnostics: number of non-PD factorisations
-  int pad;
+  int spec_discard; // 1 = the pending (explicit) trial replaces a speculative Gauss-Newton trial that was evaluated and turned out to lie
+                    // outside the trust region: an evaluation the reference never makes.  The IMU terms take back what that
+                    // evaluation did to their preintegration (ba_imu.hpp, imu_factor) before they look at the new trial.  (Here, in
+                    // the line of the record that every small-factor workgroup reads anyway.)
   double radius, decrease_factor;
   double cost;          // cost at the accepted state
   double lambda;        // 1/radius used for the pending step
@@ -145,10 +148,7 @@ struct Ctrl {
   double pend_model;  // model cost change of the pending explicit trial
   double tot_C, tot_E;  // g.dGN and |gnhat|^2 of the accepted point (pose + landmark parts), valid when have_tot
   double tot_A;       // (diagnostic) |ghat|^2 of the last explicit step
-  int have_tot;
-  int spec_discard;   // 1 = the pending (explicit) trial replaces a speculative Gauss-Newton trial that was evaluated and turned out to lie
-                      // outside the trust region: an evaluation the reference never makes.  The IMU terms take back what that
-                      // evaluation did to their preintegration (ba_imu.hpp, imu_factor) before they look at the new trial
+  int have_tot, pad2;
 };
 static_assert(sizeof(Ctrl) % 8 == 0 && sizeof(Ctrl) / 8 <= 64, "Ctrl is fetched by one wave, one double per lane");
 // The control records of a solver's windows sit in ONE array behind its window records (okvis_ba_upload), one 256-byte slot
