@@ -92,3 +92,36 @@ def test_gpu_spread_under_one_ulp_perturbations(oracle):
         assert g["successful_steps"] == r["successful_steps"]
         worst = max(worst, abs(g["final_cost"] - r["final_cost"]) / r["final_cost"])
     assert worst <= 5e-8, worst
+
+
+@pytest.mark.gpu
+def test_switching_the_compensated_elimination_off_brings_the_distance_back(oracle, monkeypatch):
+    """OKVIS_BA_NO_LDL_COMP=1 (read when a window is uploaded): the same inputs, the plain elimination of the prior blocks — the
+    20-iteration cost of seed 41 is several 1e-7 from the referee again on at least one of four inputs one ulp apart (measured
+    6e-7), and within 5e-8 on all of them with the default.  Keeps the switch honest and the defect on record."""
+    from okvis_amd import solver
+    w = synthetic.small_window(seed=41, **FAR)
+    rng = np.random.default_rng(0)
+    inputs = [w.lm.copy()]
+    for _ in range(4):
+        lm2 = w.lm.copy()
+        lm2[:, :3] = np.nextafter(w.lm[:, :3], w.lm[:, :3] + rng.choice([-1.0, 1.0], size=w.lm[:, :3].shape))
+        inputs.append(lm2)
+    worst = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("OKVIS_BA_NO_LDL_COMP", "1")
+        else:
+            monkeypatch.delenv("OKVIS_BA_NO_LDL_COMP", raising=False)
+        worst[off] = 0.0
+        for lm2 in inputs:
+            ref = oracle.OracleWindow(w, extended=True)
+            ref.set_state(lm=lm2)
+            r = ref.optimize(20, _opts())
+            b = solver.WindowBatch([w], options=_opts())
+            b.set_state(0, lm=lm2)
+            g = b.optimize(20)[0]
+            b.close()
+            worst[off] = max(worst[off], abs(g["final_cost"] - r["final_cost"]) / r["final_cost"])
+    assert worst[False] <= 5e-8, worst
+    assert worst[True] >= 1e-7, worst
