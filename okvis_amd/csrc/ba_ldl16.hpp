@@ -104,6 +104,13 @@ __device__ __forceinline__ double rcp_nr(double d) {   // 1/d: hardware estimate
   y = fma(y, fma(-d, y, 1.0), y);
   return y;
 }
+// (experiment, -DLDL_NR1: one Newton step — <= 11 ulp, tests/micro/rcp_acc.hip — in the blocks that are not compensated; two
+//  instructions fewer per pivot.  Measured against the long double referee: profiles/r05_notes.md.  Not the default.)
+__device__ __forceinline__ double rcp_nr1(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(y, fma(-d, y, 1.0), y);
+  return y;
+}
 
 // DPP row_newbcast (gfx90a+): lane K of the caller's row of 16 lanes, as the first source of a 64-bit VALU operation.
 // Written as volatile inline assembly (one instruction per element instead of v_mov_b64_dpp + copy + v_fmac), which the
@@ -213,7 +220,11 @@ __device__ __forceinline__ double ldl16_pivot(double (&r)[16], double d, bool ac
     d = neg ? 1.0 : d;
   }
 #if LDL_PIVOT == 0
+#ifdef LDL_NR1
+  double rd = (COMP || GUARD) ? rcp_nr(d) : rcp_nr1(d);   // (GUARD: the tiled solver keeps two steps)
+#else
   double rd = rcp_nr(d);
+#endif
   if (!FULL) rd = act ? rd : 0.0;
   const bool me = (j == K);
   double v = -r[K] * rd;
