@@ -293,6 +293,8 @@ int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt,
 #define OKVIS_BA_LIST_CHUNK_DIAG_OUT 15
 #define OKVIS_BA_LIST_CHUNK_DESC 16
 #define OKVIS_BA_LIST_PIECE_PATH 17     /* one int: 1 = the lists are those of the piece path (ba_linearize2.hpp) */
+#define OKVIS_BA_LIST_LDL_COMP 18       /* one int: bit b = diagonal block b of the dense solver is eliminated with compensated products (it holds
+                                           columns of a pose prior or of the marginalisation prior; 0 for windows above the LDS solver's size) */
 int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options* opt, int32_t n_windows, int32_t which,
                                 int32_t* out, int64_t capacity, int64_t* n);
 /* ---- incremental structure updates ---------------------------------------------------------------------

@@ -2089,12 +2089,15 @@ int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options
       break;
     case OKVIS_BA_LIST_CHUNK_DESC: src = at((const void*)P.chunk_desc), count = (int64_t)P.n_chunk * SCHUR_DESC_INTS; break;
     case OKVIS_BA_LIST_PIECE_PATH: count = 1; break;
+    case OKVIS_BA_LIST_LDL_COMP: count = 1; break;
     default: return OKVIS_BA_ERR_ARG;
   }
   *n = count;
   if (capacity < count) return OKVIS_BA_ERR_ARG;
   if (which == OKVIS_BA_LIST_PIECE_PATH) {
     out[0] = P.lin2;
+  } else if (which == OKVIS_BA_LIST_LDL_COMP) {
+    out[0] = (int32_t)P.ldl_comp;
   } else if (width == 4) {
     if (count) std::memcpy(out, src, 4 * (size_t)count);
   } else {

@@ -208,3 +208,49 @@ def test_index_lists_report_their_size_before_they_write():
     assert L.okvis_ba_check_window_lists(C.byref(wc), None, 1, 99, buf, n.value, C.byref(n)) == -1
     assert L.okvis_ba_check_window_lists(C.byref(wc), None, 0, 3, buf, n.value, C.byref(n)) == -1
     assert L.okvis_ba_check_window_lists(None, None, 1, 3, buf, n.value, C.byref(n)) == -1
+
+
+def _expected_ldl_comp(w, blocks):
+    """blocks: (type, index) of the blocks that carry a pose prior or the marginalisation prior; the solver numbers the speed/bias
+    part first (L16::perm) and cuts the system into 16-wide diagonal blocks"""
+    free_p = [i for i in range(w.n_pose) if not w.pose_fixed[i]]
+    free_s = [i for i in range(w.n_sb) if not w.sb_fixed[i]]
+    Dp, Ds = 6 * len(free_p), 9 * len(free_s)
+    m = 0
+    for t, i in blocks:
+        if t == 0 and i in free_p:
+            rows = range(Ds + 6 * free_p.index(i), Ds + 6 * free_p.index(i) + 6)
+        elif t == 1 and i in free_s:
+            rows = range(9 * free_s.index(i), 9 * free_s.index(i) + 9)
+        else:
+            continue
+        for r in rows:
+            m |= 1 << (r >> 4)
+    return m
+
+
+def test_blocks_with_a_prior_are_marked_for_the_compensated_elimination(monkeypatch):
+    """WinPtrs::ldl_comp (ba_ldl16.hpp): the diagonal blocks of the dense solver that hold columns of a pose prior or of the
+    marginalisation prior, in the solver's ordering; nothing for windows above the LDS solver's size; OKVIS_BA_NO_LDL_COMP clears it"""
+    wA = synthetic.config_A()
+    assert solver.index_lists(wA)["ldl_comp"] == _expected_ldl_comp(wA, [(0, int(p)) for p in wA.pprior_pose]) == 1 << 5
+    w = synthetic.small_window(seed=41, K=5, L=60)
+    assert solver.index_lists(w)["ldl_comp"] == _expected_ldl_comp(w, [(0, int(p)) for p in w.pprior_pose]) == 0b1100
+    # a dense prior over two poses and two speed/bias blocks
+    rng = np.random.default_rng(6)
+    wm = synthetic.small_window(seed=6, K=5, L=70)
+    Dm = 6 + 9 + 6 + 9
+    wm.marg_J = np.triu(rng.standard_normal((Dm, Dm))) * 3.0
+    wm.marg_e0 = rng.standard_normal(Dm) * 0.1
+    wm.marg_block_type = np.array([0, 1, 0, 1], np.int32)
+    wm.marg_block_idx = np.array([0, 0, 1, 2], np.int32)
+    wm.marg_block_off = np.array([0, 6, 15, 21], np.int32)
+    lin = np.zeros((4, 9))
+    lin[0, :7] = wm.pose[0]; lin[1] = wm.sb[0]; lin[2, :7] = wm.pose[1]; lin[3] = wm.sb[2]
+    wm.marg_lin = lin
+    want = _expected_ldl_comp(wm, [(0, int(p)) for p in wm.pprior_pose] + [(0, 0), (1, 0), (0, 1), (1, 2)])
+    assert solver.index_lists(wm)["ldl_comp"] == want and bin(want).count("1") >= 3
+    wl = synthetic.make_window(20, 30, 1.0, 2, frame_dt=0.1)
+    assert wl.reduced_dim() == 300 and solver.index_lists(wl)["ldl_comp"] == 0
+    monkeypatch.setenv("OKVIS_BA_NO_LDL_COMP", "1")
+    assert solver.index_lists(wA)["ldl_comp"] == 0
