@@ -39,7 +39,10 @@ def parse():
     p.add_argument("--total-windows", type=int, default=0,
                    help="BASELINE configs[3]: this many windows IN TOTAL, window i on rank i mod N (strong scaling); "
                         "overrides --windows")
-    p.add_argument("--repeats", type=int, default=50, help="timed regions of --steps iterations each (median / p10 / p90)")
+    p.add_argument("--repeats", type=int, default=50, help="timed regions of --steps iterations each (median / p10 / p90); at least this many")
+    p.add_argument("--min-timed-s", type=float, default=3.0,
+                   help="the timed regions together cover at least this much wall time (more regions of EXACTLY --steps iterations each are "
+                        "added: a 20-step region of the default batch is 3 ms, too short for a 1 Hz utilisation sampler to see)")
     p.add_argument("--streams", type=int, default=0, help="sub-batch streams (0 = auto)")
     p.add_argument("--keyframes", type=int, default=10)
     p.add_argument("--landmarks", type=int, default=400)
@@ -154,7 +157,9 @@ def main():
     # R timed regions of EXACTLY --steps iterations each, every one bracketed by barrier + synchronize on both sides
     # and MAX-reduced over the ranks; the reported value is the MEDIAN region (median + p10/p90)
     walls, evs = [], []
-    for _ in range(max(1, a.repeats)):
+    n_regions = max(1, a.repeats)
+    k = 0
+    while k < n_regions:
         barrier()
         t0 = time.perf_counter()
         batch.iterate(a.steps)
@@ -162,6 +167,9 @@ def main():
         t1 = time.perf_counter()
         walls.append(D.max_over_ranks(dist, t1 - t0))
         evs.append(batch.last_iterate_ms())
+        k += 1
+        if k == 5 and a.min_timed_s > 0:   # (every rank computes the same count from the max-reduced times)
+            n_regions = max(n_regions, min(20000, int(np.ceil(a.min_timed_s / max(float(np.median(walls)), 1e-6)))))
     wall = float(np.median(walls))
     ev_ms = float(np.median(evs))
     # the one collective of the design: all-gather of the timing records, one record per window
@@ -254,17 +262,46 @@ def main():
                     "blocked LDL^T on the fp64 matrix core with a one-wave diagonal chain, back-substitution, trial states); the "
                     "linearise launch is the one that fills all CUs (device_filling_kernel).  Algorithmic bytes / flops per "
                     "SURVEY.md section 8d; W / V / b round trips between launches are served by L2 / Infinity Cache"}
+    def bytes_8d(w):
+        """SURVEY.md section 8(d), "ALGORITHMIC bytes per iteration" (compulsory traffic: states in LDS / registers, W NOT materialised),
+        from the actual O, K, C, L, M, D, D_m of window w: three observation sweeps 3*32*O; states 8*(7K + 9K + 7C + 4L) read three
+        times and written once; reduced system 8*D^2 written + read; per-landmark V^-1, b_l 8*9*L written + read; IMU summaries
+        8*290*M twice; prior 8*D_m^2 + 8*D_m.  Returns the total and the share this implementation's solve stage owns (reduced system
+        + IMU summaries + prior + the pose / speed-bias states it writes)."""
+        O, K, L, M = w.n_obs, w.n_sb, w.n_lm, w.n_imu           # (one speed/bias block per keyframe; n_pose also counts the
+        Cc = w.n_pose - K                                       #  camera extrinsics blocks)
+        Dr, Dm = w.reduced_dim(), int(np.asarray(w.marg_e0).size)
+        obs, states = 3 * 32 * O, 4 * 8 * (7 * K + 9 * K + 7 * Cc + 4 * L)
+        red, lmk, imu, prior = 2 * 8 * Dr * Dr, 2 * 8 * 9 * L, 2 * 8 * 290 * M, 8 * Dm * Dm + 8 * Dm
+        return {"total": obs + states + red + lmk + imu + prior, "solve": red + imu + prior + 8 * (7 * K + 9 * K),
+                "terms": {"observation_sweeps": obs, "states": states, "reduced_system": red, "landmark_blocks": lmk, "imu": imu, "prior": prior}}
+
     if roofline is not None:
         # the WHOLE step against the roofs (SURVEY.md section 8d: algorithmic bytes and flops of one iteration of one window x the
         # windows, over the measured time of a step) — the number that describes the headline, next to its longest link above
-        def step_record(nw, ms_per_step, nbytes, fl):
+        def step_record(nw, ms_per_step, nbytes, fl, ws):
             B, F = float(sum(nbytes.values())), float(sum(fl.values()))
-            return {"windows": nw, "ms_per_step": ms_per_step, "algorithmic_bytes_per_step": B, "flops_per_step": F,
-                    "bytes_per_window_iteration": B / nw, "flops_per_window_iteration": F / nw,
+            B8 = float(sum(bytes_8d(w)["total"] for w in ws))
+            return {"windows": nw, "ms_per_step": ms_per_step, "flops_per_step": F, "flops_per_window_iteration": F / nw,
+                    # two byte counts, both per window-iteration.  bytes_8d: SURVEY.md section 8(d)'s compulsory traffic (W not
+                    # materialised).  bytes_impl: what THIS implementation's launches exchange through HBM by design — it
+                    # materialises W (144 B per (landmark, block) pair, written once by the linearise launch and read by the Schur
+                    # launch and by the next linearise launch's back-substitution) and the per-chunk Schur partials.
+                    "bytes_8d_per_window_iteration": B8 / nw, "bytes_impl_per_window_iteration": B / nw,
+                    "impl_over_8d": B / B8,
+                    "achieved_GBps_8d": B8 / (ms_per_step * 1e-3) / 1e9, "frac_8d": B8 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_step": B, "bytes_per_window_iteration": B / nw,
                     "achieved_GBps": B / (ms_per_step * 1e-3) / 1e9, "hbm_frac": B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "achieved_tflops": F / (ms_per_step * 1e-3) / 1e12, "fp64_frac": F / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
         nb_all = batch.algorithmic_bytes()
-        roofline["step"] = step_record(a.windows, wall * 1e3 / a.steps, nb_all, flops_per_launch(a.windows))
+        roofline["step"] = step_record(a.windows, wall * 1e3 / a.steps, nb_all, flops_per_launch(a.windows), wins)
+        roofline["step"]["note"] = ("frac_8d = SURVEY.md section 8(d) bytes / measured step time / 8 TB/s; hbm_frac = the same with bytes_impl, "
+                                    "which adds the materialised W and the Schur partials (impl_over_8d x the compulsory traffic)")
+        # the dominant kernel against section 8(d)'s bytes of ITS stage (reduced system written + read, IMU summaries, prior, states written)
+        d8 = float(sum(bytes_8d(w)["solve" if dom == "solve" else "total"] for w in wins[:sub]))
+        roofline["bytes_8d_per_launch"] = d8
+        roofline["achieved_8d"] = d8 / (d["launch_us"] * 1e-6) / 1e9
+        roofline["frac_8d"] = roofline["achieved_8d"] / HBM_PEAK_GBS
         roofline["step"]["bound"] = "latency"
         roofline["step"]["chain"] = ("one iteration of a sub-batch = " + ("4" if sub >= 40 else "3") +
                                      " dependent launches on its stream (Schur, solve, linearise" + (", IMU / prior factors" if sub >= 40 else "") +
@@ -285,9 +322,40 @@ def main():
             bsat.close()
             obs_s, lm_s = sum(w.n_obs for w in wsat[:nsat]), sum(w.n_lm for w in wsat[:nsat])
             fl_sat = {"linearize": 1.5e3 * obs_s, "schur": 3.0 * (6.0 * a.keyframes) ** 2 * lm_s, "solve": nsat * (D_red ** 3 / 3.0 + 2.0 * D_red ** 2)}
-            roofline["step_saturated"] = step_record(nsat, ms_sat, nb_sat, fl_sat)
+            roofline["step_saturated"] = step_record(nsat, ms_sat, nb_sat, fl_sat, wsat[:nsat])
             roofline["step_saturated"]["iterations_per_s"] = nsat / (ms_sat * 1e-3)
     summaries = batch.finish()
+    # ---- the timed batch against the oracle, AFTER the timed region (the checker, never the thing measured).  (i) the states the
+    #      timed iterations ended in: thousands of Gauss-Newton iterations sit at the fixed point, which the oracle reaches from the
+    #      same start (it iterates until its cost is stationary to 1e-14); (ii) the same solver, the same options, the same windows
+    #      uploaded again (shapes unchanged: the captured graphs of the timed region are replayed) for optimize(10) from the start —
+    #      an iteration-for-iteration comparison.  Four windows sampled over the three sub-batches.
+    oracle_check = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.pmc_child and a.total_windows == 0:
+        from tests import oracle_lib as _ol
+        sample = sorted({0, a.windows // 3, (2 * a.windows) // 3, a.windows - 1})
+        dev_fix = 0.0
+        for i in sample:
+            ow = _ol.OracleWindow(wins[i])
+            prev = None
+            for _ in range(40):
+                r = ow.optimize(5, opt)
+                if prev is not None and abs(r["final_cost"] - prev) <= 1e-14 * prev:
+                    break
+                prev = r["final_cost"]
+            dev_fix = max(dev_fix, abs(summaries[i]["final_cost"] - r["final_cost"]) / r["final_cost"])
+        batch.upload(wins)
+        s10 = batch.optimize(10)
+        dev_10, same_book = 0.0, True
+        for i in sample:
+            r = _ol.OracleWindow(wins[i]).optimize(10, opt)
+            dev_10 = max(dev_10, abs(s10[i]["final_cost"] - r["final_cost"]) / r["final_cost"])
+            same_book = same_book and (s10[i]["iterations"], s10[i]["successful_steps"]) == (r["iterations"], r["successful_steps"])
+        oracle_check = {"windows_checked": sample, "max_rel_cost_dev_vs_oracle": max(dev_fix, dev_10),
+                        "after_timed_region_fixed_point": dev_fix, "optimize_10_from_the_start": dev_10,
+                        "identical_iteration_bookkeeping": bool(same_book), "route": batch.launch_route(),
+                        "note": "the timed solver object after the timed region, bench options, against oracle/ (CPU restatement pinned "
+                                "to the reference's sources, DESIGN.md section 3); tests/test_gpu_batch64.py checks all 64 windows"}
     n_rec = (a.total_windows + world - 1) // world if a.total_windows > 0 else a.windows
     rec = []
     for k in range(n_rec):
@@ -313,7 +381,7 @@ def main():
         b1.close()
         single = {"iterations_per_s": a.steps / (ms1 * 1e-3), "ms_per_iteration": ms1 / a.steps, "helper_timeouts": late}
 
-    cpu = cpu_mt = None
+    cpu = cpu_mt = cpu_2t = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:   # reported at N=1 only
         # CPU restatement (oracle/: same algorithm, same policy, g++ -O3), bounded sample of the same workload, on this
         # box's host cores: one thread, and OpenMP over the observation sweep + landmark Schur reduction at all cores.
@@ -334,9 +402,14 @@ def main():
             return n / tc, n, tc
 
         v1, n1, t1 = cpu_rate(1, 8.0)
+        v2, n2, t2 = cpu_rate(2, 4.0)
         cpu = {"value": v1, "unit": "iterations/s", "cores": 1, "kind": "port",
                "sample": f"1 window (configs[1] shape) x {n1} iterations of the CPU restatement (oracle/, g++ -O3 -fopenmp, "
                          f"same DOGLEG/Gauss-Newton mode as the GPU run; not Ceres), {t1:.1f} s"}
+        cpu_2t = {"value": v2, "unit": "iterations/s", "cores": 2, "kind": "port",
+                  "sample": f"the same window x {n2} iterations with 2 OpenMP threads over the observation sweep and the landmark Schur "
+                            f"reduction — the thread count the application hands to Ceres (ThreadedKFVio.cpp:736: optimize(..., 2, false)); {t2:.1f} s",
+                  "speedup_over_1_core": v2 / v1}
         # all cores: the windows of a batch are independent, so a CPU deployment runs one window per thread (OpenMP inside
         # one small window does not pay: measured 0.2x at 64 threads).  C threads, one window of the batch each.
         import threading
@@ -634,7 +707,9 @@ def main():
                                "first": records[:2], "collective": (f"one all_gather, backend {dist.get_backend()}" + (" (= RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else "none (1 rank)"},
             "single_window": single, "roofline": roofline, "dogleg": dogleg, "config_C": config_c, "fp32": fp32, "frontend": frontend, "frame_host": frame_host, "strong_scaling_64_windows": strong,
             "ranks_seen_by_collective": world if dist is None else dist.get_world_size(),
-            "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
+            "cpu_baseline": cpu, "cpu_baseline_2_threads": cpu_2t, "cpu_baseline_all_cores": cpu_mt,
+            "oracle_check": oracle_check,
+            "max_rel_cost_dev_vs_oracle": None if oracle_check is None else oracle_check["max_rel_cost_dev_vs_oracle"],
             "speedup_vs_cpu": None if cpu is None else {
                 "single_window_vs_1_core": single["iterations_per_s"] / cpu["value"],
                 "batch_vs_all_cores": None if cpu_mt is None else value / cpu_mt["value"],

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OKVIS_BA_ABI_VERSION 6
+#define OKVIS_BA_ABI_VERSION 7
 
 /* status codes (0 ok; >0 = hipError_t passthrough + 1000; <0 = argument / state errors) */
 #define OKVIS_BA_OK 0
@@ -171,6 +171,36 @@ typedef struct okvis_ba_window {
  */
 #define OKVIS_BA_STRATEGY_DOGLEG 0
 #define OKVIS_BA_STRATEGY_LM 1
+/*
+ * Launch shapes and A/B switches (ABI 7).  Up to ABI 6 these were some twenty environment variables read inside the library: a
+ * linked-in backend must not change its behaviour with its host process's environment, so they are fields now, set per solver
+ * with okvis_ba_set_options BEFORE the upload they are meant for (okvis_ba_check_window[_lists] take them through their options
+ * argument).  All zero = the defaults.  None of them changes what is computed; a different grouping of a sum moves its rounding.
+ * Every field is driven against the oracle by tests/test_gpu_tuning.py.  The library reads ONE environment variable, OKVIS_BA_DEBUG
+ * (a comma-separated list of print-only diagnostics: "build", "upload", "marg", "arena=<file>"); it never changes a result.
+ */
+#define OKVIS_BA_TUNE_SCHUR_DECIDES 0x1u      /* the separate Schur launch takes the trust-region decision itself (rounds 1-4) instead of
+                                                 reducing the trial buffer decision-free (DESIGN.md section 5, row 1')                    */
+#define OKVIS_BA_TUNE_SCHUR_VALU 0x2u         /* schur_kernel (fp64 FMA) also where the matrix-core kernel would run                      */
+#define OKVIS_BA_TUNE_SCHUR_MFMA_LARGE 0x4u   /* the matrix-core Schur kernel also for pose parts of several 96-row tiles (configs[2])    */
+#define OKVIS_BA_TUNE_NO_LDL_COMP 0x8u        /* no compensated elimination in the dense solver's prior-carrying diagonal blocks          */
+#define OKVIS_BA_TUNE_LDL_COMP_ALL 0x10u      /* compensated elimination in every diagonal block                                          */
+#define OKVIS_BA_TUNE_H0_ON_HOST 0x20u        /* H0 = J^T J of a large marginalisation prior on the host instead of marg_h0_kernel        */
+#define OKVIS_BA_TUNE_NO_EARLY_PREINTEGRATION 0x40u /* a new IMU term's first preintegration inside the first linearise launch, not at upload */
+#define OKVIS_BA_TUNE_NO_MARG_TILES 0x80u     /* okvis_ba_marginalize: kept blocks > 96 rows on the single workgroup, not on the tiled tail */
+#define OKVIS_BA_SOLVE_AUTO 0                  /* the library picks (OKVIS_BA_ROUTE_SOLVE_MODE reports what it picked)                     */
+#define OKVIS_BA_SOLVE_DENSE 1                /* blocked LDL^T of the whole D x D reduced system in LDS (rounds 3-5)                      */
+#define OKVIS_BA_SOLVE_CHAIN 2                /* speed/bias blocks eliminated along the IMU chain first, dense pose system behind it      */
+typedef struct okvis_ba_tuning {
+  uint32_t flags;               /* OKVIS_BA_TUNE_* */
+  int32_t fused_max_windows;    /* batches up to this many windows use the fused linearise + reduce launch; 0 = 48, < 0 = never  */
+  int32_t group_lm;             /* landmarks per linearise group; 0 = auto (16 for <= 8 windows, else 32), at most 64            */
+  int32_t group_work;           /* > 0: close a linearise group at this many observations x blocks (work-balanced groups); 0 = off */
+  int32_t split_small_min;      /* batches from this many windows on run the IMU / prior factors in a launch of their own; 0 = 40 */
+  int32_t lin2_occupancy;       /* piece-path linearise kernel built for 4 (default, 0) or 3 workgroups per CU                   */
+  int32_t stagger_us;           /* start offset between the sub-batch streams; 0 = 20 us, < 0 = none                              */
+  int32_t solve_mode;           /* reduced solve: 0 = auto, see OKVIS_BA_SOLVE_*                                                  */
+} okvis_ba_tuning;
 typedef struct okvis_ba_options {
   double initial_radius;        /* 1e4   */
   double max_radius;            /* 1e16  */
@@ -204,6 +234,7 @@ typedef struct okvis_ba_options {
                                    linearise launch).  Bit 3 (8): the staged linearise kernel instead
                                    of the piece path.  Bit 4 (16): solving workgroups do not wait for their helper
                                    workgroups (exercises the time-out route).  Bits 0-1: not read any more           */
+  okvis_ba_tuning tuning;       /* launch shapes and A/B switches; all zero = the defaults (see above)              */
 } okvis_ba_options;
 
 /* per-window result of okvis_ba_optimize (what ::ceres::Solver::Summary gives Estimator::optimize) */
@@ -448,6 +479,25 @@ int okvis_ba_synchronize(okvis_ba_solver* s);
  * workgroup whose helpers are late (not co-scheduled) sums the partials itself, with the same result, and counts it:
  * count = such time-outs over all windows since the upload.  0 in a healthy run; tests and bench.py report it. */
 int okvis_ba_helper_timeouts(okvis_ba_solver* s, int64_t* count);
+/* Which launches the uploaded batch takes under the solver's current options (read-only, nothing is launched): the parity tests of
+ * the headline configuration assert the route they mean to test (tests/test_gpu_batch64.py).  route[OKVIS_BA_ROUTE_COUNT]. */
+#define OKVIS_BA_ROUTE_WINDOWS 0
+#define OKVIS_BA_ROUTE_FUSED 1                  /* 1 = linearise + landmark reduction in one launch, no Schur launch                */
+#define OKVIS_BA_ROUTE_DECISION_FREE_SCHUR 2    /* 1 = the Schur launch reduces the trial buffer, the solve kernel decides          */
+#define OKVIS_BA_ROUTE_PIECE_PATH 3             /* 1 = linearize2_kernel                                                            */
+#define OKVIS_BA_ROUTE_SPLIT_SMALL 4            /* 1 = IMU / prior factors in small_kernel, a launch of their own                   */
+#define OKVIS_BA_ROUTE_SUB_BATCHES 5            /* streams the batch is spread over                                                 */
+#define OKVIS_BA_ROUTE_SUB_BATCH_MAX_WINDOWS 6
+#define OKVIS_BA_ROUTE_SCHUR_KERNEL 7           /* 0 none, 1 schur_kernel, 2 schur_mfma_kernel<3>, 3 schur_mfma_kernel<9>           */
+#define OKVIS_BA_ROUTE_SOLVE_DBUF 8             /* 1 = solve_kernel<false, true> (one set of Schur partials per linearisation buffer) */
+#define OKVIS_BA_ROUTE_SOLVE_TILED 9            /* 1 = at least one window above the LDS solver's size (chol_tiles_window_kernel)    */
+#define OKVIS_BA_ROUTE_SOLVE_HELPERS 10         /* helper workgroups per solving workgroup (0 above 8 windows per launch)           */
+#define OKVIS_BA_ROUTE_GRAPH 11
+#define OKVIS_BA_ROUTE_MAX_CHUNKS 12            /* Schur chunks of the window that has most                                         */
+#define OKVIS_BA_ROUTE_SLOTS 13                 /* launch slots since okvis_ba_begin                                                */
+#define OKVIS_BA_ROUTE_SOLVE_MODE 14            /* OKVIS_BA_SOLVE_* the LDS-resident windows are solved with                         */
+#define OKVIS_BA_ROUTE_COUNT 16
+int okvis_ba_launch_route(okvis_ba_solver* s, int32_t* route);
 
 /* ---- marginalisation -------------------------------------------------------
  * Numeric core of okvis::Estimator::applyMarginalizationStrategy (Estimator.cpp:434-773), i.e. what the

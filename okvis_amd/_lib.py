@@ -18,7 +18,7 @@ SYMBOLS = [
     "okvis_ba_evaluate_cost", "okvis_ba_get_state", "okvis_ba_fetch_results", "okvis_ba_fetch_imu_caches", "okvis_ba_array_size", "okvis_ba_download",
     "okvis_ba_reduced_dim", "okvis_ba_pair_count", "okvis_ba_pairs", "okvis_ba_last_iterate_ms",
     "okvis_ba_profile_iterations", "okvis_ba_profile_launches", "okvis_ba_algorithmic_bytes", "okvis_ba_synchronize",
-    "okvis_ba_helper_timeouts", "okvis_ba_marginalize", "okvis_ba_marginalize_begin", "okvis_ba_marginalize_end",
+    "okvis_ba_helper_timeouts", "okvis_ba_launch_route", "okvis_ba_marginalize", "okvis_ba_marginalize_begin", "okvis_ba_marginalize_end",
     "okvis_ba_store_create", "okvis_ba_store_patch", "okvis_ba_store_view", "okvis_ba_store_destroy", "okvis_ba_set_patchable",
     "okvis_ba_patch_window", "okvis_ba_patched_view", "okvis_ba_set_marg_prior_values",
     "okvis_ba_dense_solve", "okvis_ba_shard", "okvis_ba_batch_run", "okvis_ba_gather_records", "okvis_ba_batch_run_gathered",
@@ -89,6 +89,7 @@ def lib():
     L.okvis_ba_reduced_dim.argtypes = [vp, C.c_int, _ip]
     L.okvis_ba_pair_count.argtypes = [vp, C.c_int, _ip]
     L.okvis_ba_helper_timeouts.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.okvis_ba_launch_route.argtypes = [vp, _ip]
     L.okvis_ba_pairs.argtypes = [vp, C.c_int, _ip, _ip]
     L.okvis_ba_last_iterate_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.okvis_ba_profile_iterations.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]

@@ -133,7 +133,7 @@ struct okvis_ba_solver {
   bool group_chunks = false;   // every window of the batch has one Schur chunk per linearise group (see fused())
   // Batches that are not fused but run DOGLEG or fixed-radius iterations on windows the matrix-core Schur kernel serves: the Schur
   // launch takes no decision (schur_mfma_kernel, nodec) and reduces the trial buffer into that buffer's own set of partials, the
-  // solve kernel decides (its DBUF instantiation, as in fused mode).  OKVIS_BA_NO_SPEC_SCHUR keeps the decision in the Schur launch.
+  // solve kernel decides (its DBUF instantiation, as in fused mode).  OKVIS_BA_TUNE_SCHUR_DECIDES keeps the decision in the Schur launch.
   bool spec_schur = false;
   bool fp32_at_upload = false;
   std::vector<int64_t> launch_sig;   // what the captured graphs depend on (see okvis_ba_upload)
@@ -164,7 +164,7 @@ struct okvis_ba_solver {
   bool acc_fresh = false;   // HostWin::acc mirrors the device's accepted-buffer index (no kernel launched since it was read)
   int max_group = 0, max_imu = 0, max_schur_blocks = 0, max_lm = 0, max_Dpad = 0, max_Dp = 0, max_spart_stride = 0;
   int max_Dpad_small = 0, max_Dpad_large = 0;
-  long long stagger_ticks = 0;   // start offset between consecutive sub-batch streams (wall_clock64 ticks, 100 MHz); OKVIS_BA_STAGGER_US
+  long long stagger_ticks = 0;   // start offset between consecutive sub-batch streams (wall_clock64 ticks, 100 MHz); okvis_ba_tuning::stagger_us
   bool skip_topup = false;   // okvis_ba_optimize_timed ran out of time: finish() must not grant the slots mis-speculated steps still owe
   long long slots = 0;   // launch slots (schur + solve + linearise triples) since okvis_ba_begin: diagnostics (array 96)
   std::map<int, hipGraphExec_t> graphs;
@@ -179,15 +179,39 @@ namespace {
 
 size_t solve_smem(int Dpad, bool large);
 
-constexpr int FUSED_MAX_WINDOWS = 48;   // up to here the fused linearise + reduce launch beats the separate Schur launch (tests/gpu_fused_sweep.py:
+constexpr int FUSED_MAX_WINDOWS = 48;   // up to here the fused linearise + reduce launch beats the separate Schur launch (tools/gpu_fused_sweep.py:
                                         // 48 windows 148.5 vs 151.3 us per step, 64 windows 176 vs 163)
-// (OKVIS_BA_FUSED_MAX_WINDOWS overrides it: diagnostics)
-int fused_max_windows() {
-  static const int v = [] {
-    const char* e = std::getenv("OKVIS_BA_FUSED_MAX_WINDOWS");
-    return e ? std::atoi(e) : FUSED_MAX_WINDOWS;
-  }();
-  return v;
+// (okvis_ba_tuning::fused_max_windows overrides it: A/B sweeps)
+int fused_max_windows(const okvis_ba_options& o) {
+  return o.tuning.fused_max_windows > 0 ? o.tuning.fused_max_windows : o.tuning.fused_max_windows < 0 ? 0 : FUSED_MAX_WINDOWS;
+}
+// Print-only diagnostics: the ONE environment variable the library reads, once per process.  OKVIS_BA_DEBUG is a comma-separated
+// list of "build" (host time of build_window's sections, printed at exit), "upload" (sections of every upload), "marg" (ranks and
+// bounds of every marginalisation), "arena=<file>" (okvis_ba_check_window dumps the index build's output).  Nothing here changes a
+// result; everything that does is a field of okvis_ba_options::tuning.
+struct DebugWord {
+  bool build = false, upload = false, marg = false;
+  std::string arena;
+  DebugWord() {
+    const char* e = std::getenv("OKVIS_BA_DEBUG");
+    if (!e) return;
+    std::string w(e);
+    size_t at = 0;
+    while (at <= w.size()) {
+      size_t c = w.find(',', at);
+      if (c == std::string::npos) c = w.size();
+      const std::string tok = w.substr(at, c - at);
+      if (tok == "build") build = true;
+      else if (tok == "upload") upload = true;
+      else if (tok == "marg") marg = true;
+      else if (tok.rfind("arena=", 0) == 0) arena = tok.substr(6);
+      at = c + 1;
+    }
+  }
+};
+const DebugWord& debug_word() {
+  static const DebugWord w;
+  return w;
 }
 constexpr size_t OPT_PAD = (sizeof(OptD) + 255) & ~size_t(255);   // the option record in front of the window records (one allocation, one copy)
 // [OptD, padded | WinPtrs x n | (padded) CtrlSlot x n]: where the control records of n windows start / how long the block is
@@ -250,9 +274,9 @@ size_t put_n(Arena& A, const T* p, size_t n) {
 
 #define OFF(field, off) P.field = reinterpret_cast<std::remove_reference<decltype(P.field)>::type>(off)
 
-// diagnostics: OKVIS_BA_DEBUG_BUILD=1 accumulates the host time of build_window's sections and prints them at exit
+// diagnostics: OKVIS_BA_DEBUG=build accumulates the host time of build_window's sections and prints them at exit
 struct BuildTimes {
-  bool on = std::getenv("OKVIS_BA_DEBUG_BUILD") != nullptr;
+  bool on = debug_word().build;
   struct Acc {   // (`+=` keeps the call sites of the mean-only version)
     std::vector<double> v;
     Acc& operator+=(double x) {
@@ -487,13 +511,13 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   // ---- groups ----
   std::vector<Group>& groups = S.groups;
   groups.clear();
-  // OKVIS_BA_GROUP_WORK (sweeps): a group also closes when the block products of its landmark elimination, sum of
+  // okvis_ba_tuning::group_work (sweeps): a group also closes when the block products of its landmark elimination, sum of
   // pairs (pairs + 1) / 2, reach this number.  Measured (profiles/r04_notes.md): a window that has the device to itself finishes
   // sooner with more, lighter groups (cap 250: replay 0.833 -> 0.805 ms per frame for the ten iterations, one configs[1] window
   // 73.1 -> 72.2 us per iteration), with more windows the additional workgroups cost more than they bring (4 windows: 74 -> 78 us per
   // step, 64: 451 k -> 358 k it/s).  Not the default: the other grouping moves the rounding of every single-window run, and one
   // of the ill-conditioned DOGLEG cases that sit at the 1e-6 bound (test_dogleg_rejected_steps) lands at 1.25e-6.
-  static const long group_work_cap = [] { const char* e = std::getenv("OKVIS_BA_GROUP_WORK"); return e ? std::atol(e) : 0L; }();
+  const long group_work_cap = opt.tuning.group_work > 0 ? opt.tuning.group_work : 0L;
   // Landmarks per group: GROUP_LM (64) is what the kernels hold; the index build fills 32, and 16 when at most GROUP_LM_FEW_WINDOWS
   // windows share the device.  A group of 64 short tracks (landmarks that entered the window with the last frame or two: 2 - 4
   // observations each) is the slowest workgroup of its launch — the landmark elimination loops over the landmarks of the group —
@@ -502,11 +526,8 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   // are not touched): one 8-frame window in age order 77.3 us per iteration with 64, 69.0 with 32 (= random order); batches of
   // short-track windows (8 frames, 430 landmarks, 8 observations each), us per step with 64 / 32 / 24 / 16 landmarks per group:
   // 1 window 68.7 / 68.9 / 65.5 / 64.3, 8: 72.1 / 72.3 / 69.0 / 68.6, 64: 124.8 / 125.5 / 115.1 / 121.1, 256: 302 / 304 / 304 / 331;
-  // the replay's ten iterations per frame 0.830 (ids by first sighting) / 0.817 / 0.785 / 0.783 ms.  OKVIS_BA_GROUP_LM overrides.
-  const int group_lm_cap = [&] {   // (the environment is read per call: the tests switch it)
-    const char* e = std::getenv("OKVIS_BA_GROUP_LM");
-    return std::max(1, std::min(e ? std::atoi(e) : (n_windows_total <= GROUP_LM_FEW_WINDOWS ? GROUP_LM_FEW : GROUP_LM_DEFAULT), GROUP_LM));
-  }();
+  // the replay's ten iterations per frame 0.830 (ids by first sighting) / 0.817 / 0.785 / 0.783 ms.  okvis_ba_tuning::group_lm overrides.
+  const int group_lm_cap = std::max(1, std::min(opt.tuning.group_lm > 0 ? opt.tuning.group_lm : (n_windows_total <= GROUP_LM_FEW_WINDOWS ? GROUP_LM_FEW : GROUP_LM_DEFAULT), GROUP_LM));
   // piece path (ba_linearize2.hpp): pieces instead of per-observation lists.  A piece = one or two adjacent observations of the same
   // pose inside one row of 16 lanes, greedy from the start of the run (the rule of linearize2_kernel's phase B).  The pieces of a
   // landmark depend on the lane its first observation takes, i.e. on the group it joins, so they are laid out while the groups
@@ -730,20 +751,19 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   chunks.clear();
   {
     // landmarks per Schur workgroup: 48 (three staged batches of 16) keeps the workgroup count low when many windows share
-    // the device; a few windows have the device to themselves and finish sooner with 32 (measured, tests/gpu_chunk_diag.py:
+    // the device; a few windows have the device to themselves and finish sooner with 32 (measured, tools/gpu_chunk_diag.py:
     // one window 114.7 vs 119.7 us per iteration, 64 windows 239 vs 217)
-    static const int per_env = [] { const char* e = std::getenv("OKVIS_BA_SCHUR_LM"); return e ? std::atoi(e) : 0; }();   // (diagnostics: chunk sweep)
-    int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : per_env > 0 ? per_env : (n_windows_total <= 8 ? 16 : n_windows_total < SMALL_BATCH_WINDOWS ? 32 : n_windows_total < 128 ? 48 : 64), SCHUR_CHUNK_LM_MAX);   // (round 4 sweep with the matrix-core kernel, 64 windows: 12: 382 k, 24: 436 k, 48: 448 k, 64: 448 k it/s; 256 windows: 48: 585 k, 64: 597 k)
+    int per = std::min(opt.schur_lm_per_block > 0 ? opt.schur_lm_per_block : (n_windows_total <= 8 ? 16 : n_windows_total < SMALL_BATCH_WINDOWS ? 32 : n_windows_total < 128 ? 48 : 64), SCHUR_CHUNK_LM_MAX);   // (round 4 sweep with the matrix-core kernel, 64 windows: 12: 382 k, 24: 436 k, 48: 448 k, 64: 448 k it/s; 256 windows: 48: 585 k, 64: 597 k)
     // fused mode (the linearise workgroup reduces its own group, no Schur launch: DOGLEG and fixed-radius runs): possible when
     // the reduced system is solved in LDS, the pose part is one Schur tile and the reduction's landmark tables fit the observation stage of the linearise kernel;
     // then chunk = group.  options.reserved0 bit 2 keeps the separate launch (A/B switch).
     const int stage = opt.fp32_linearize ? (has_ext ? LinCfg<true, float>::STAGE_DOUBLES : LinCfg<false, float>::STAGE_DOUBLES)
                                          : (has_ext ? LinCfg<true, double>::STAGE_DOUBLES : LinCfg<false, double>::STAGE_DOUBLES);
-    H.group_chunks = !(opt.reserved0 & 4) && opt.schur_lm_per_block == 0 && D <= MAX_D_LDS && Dp <= TILE_DIM && n_windows_total <= fused_max_windows() && 2 * SCHUR_LM_BATCH * 3 * Dp <= stage &&
+    H.group_chunks = !(opt.reserved0 & 4) && opt.schur_lm_per_block == 0 && D <= MAX_D_LDS && Dp <= TILE_DIM && n_windows_total <= fused_max_windows(opt) && 2 * SCHUR_LM_BATCH * 3 * Dp <= stage &&
                      (opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || opt.gauss_newton);
     if (H.group_chunks) per = 1;
     {
-      static const bool no_spec = std::getenv("OKVIS_BA_NO_SPEC_SCHUR") != nullptr, no_mfma = std::getenv("OKVIS_BA_NO_SCHUR2") != nullptr;
+      const bool no_spec = (opt.tuning.flags & OKVIS_BA_TUNE_SCHUR_DECIDES) != 0, no_mfma = (opt.tuning.flags & OKVIS_BA_TUNE_SCHUR_VALU) != 0;
       H.spec_ok = !no_spec && !no_mfma && opt.schur_lm_per_block == 0 && D <= MAX_D_LDS && !has_ext && std::min(TILE_DIM, Dp) + 1 <= SCH2_MAXT_SMALL_ROWS &&
                   (opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || opt.gauss_newton);
     }
@@ -881,7 +901,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     }
     // a prior of more than H0_DEVICE_MIN rows: the O(Dm^3) product is left to the device (marg_h0_kernel, launched behind the
     // upload: the same sums in the same order)
-    H.h0_on_device = Dm > H0_DEVICE_MIN && !std::getenv("OKVIS_BA_H0_ON_HOST");   // (the switch: A/B test of the two)
+    H.h0_on_device = Dm > H0_DEVICE_MIN && !(opt.tuning.flags & OKVIS_BA_TUNE_H0_ON_HOST);   // (the switch: A/B test of the two)
     // upper triangle as a sum of row outer products: every entry still adds its terms in row order (same value as the
     // column-by-column dot products), but the inner loop runs along a row of J (contiguous: 10 us -> 3 us at 45 rows)
     if (!H.h0_on_device) marg_h0_host(w.marg_J, Dm, H0.data());
@@ -901,7 +921,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // rotation rows), whose elimination cancels the leading digits of the block.  ba_ldl16.hpp eliminates them with compensated
     // products (profiles/r05_notes.md, "the referee").  The solver numbers the speed/bias part first (L16::perm).
     unsigned m = 0;
-    if (D <= MAX_D_LDS && !std::getenv("OKVIS_BA_NO_LDL_COMP")) {   // (the tiled solver of larger systems: not compensated, ba_chol_tiles.hpp)
+    if (D <= MAX_D_LDS && !(opt.tuning.flags & OKVIS_BA_TUNE_NO_LDL_COMP)) {   // (the tiled solver of larger systems: not compensated, ba_chol_tiles.hpp)
       const L16 LY{ldl16_nb(D), D - Dp, D};
       auto mark = [&](int off, int n) { if (off >= 0) for (int k = 0; k < n; ++k) m |= 1u << (LY.perm(off + k) >> 4); };
       for (int i = 0; i < w.n_pprior; ++i) mark(pose_off[w.pprior_pose[i]], 6);
@@ -909,7 +929,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
         const bool pose = w.marg_block_type[b] == OKVIS_BA_BLOCK_POSE;
         mark(pose ? pose_off[w.marg_block_idx[b]] : sb_off[w.marg_block_idx[b]], pose ? 6 : 9);
       }
-      if (std::getenv("OKVIS_BA_LDL_COMP_ALL")) m = ~0u;
+      if (opt.tuning.flags & OKVIS_BA_TUNE_LDL_COMP_ALL) m = ~0u;
     }
     P.ldl_comp = m;
     P.pad0_ = 0;
@@ -1328,34 +1348,20 @@ bool fused(const okvis_ba_solver* s) {
 bool spec_schur_now(const okvis_ba_solver* s) {
   return s->spec_schur && !fused(s) && (s->opt.strategy == OKVIS_BA_STRATEGY_DOGLEG || s->opt.gauss_newton);
 }
-// ... and the IMU / prior factors CAN ride in that launch instead of one of their own in front of the linearise launch
-// (schur_small_kernel; where they have a launch of their own today: piece path, batches of 40 windows and more).  Built,
-// bit-identical, OFF by default (OKVIS_BA_SMALL_MERGE=1 switches it on): the kernel time of a sub-batch's chain drops by 12.5 us
-// (26.7 us for the joint launch against 24.9 + 14.3 at 21 windows, profiles/r05_notes.md) but the 64-window bench line falls from
-// 497 k to 465 k it/s — the joint launch runs at the factor workgroups' two workgroups per CU (255 registers, 73 KB of LDS) and
-// takes 30 % more CU-time than the two launches, and with three sub-batch streams the device is short of exactly that.
-bool small_rides_with_schur(const okvis_ba_solver* s) {
-  static const bool on = std::getenv("OKVIS_BA_SMALL_MERGE") != nullptr;
-  return on && spec_schur_now(s) && s->lin2 && s->split_small && s->max_schur_blocks > 0 && std::min(TILE_DIM, s->max_Dp) + 1 <= SCH2_MAXT_SMALL_ROWS;
-}
 hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
   if (s->max_schur_blocks == 0 || fused(s)) return hipSuccess;
   const int trows = std::min(TILE_DIM, s->max_Dp);
-  static const bool no_mfma = std::getenv("OKVIS_BA_NO_SCHUR2") != nullptr;
+  const bool no_mfma = (s->opt.tuning.flags & OKVIS_BA_TUNE_SCHUR_VALU) != 0;
   // no pose x extrinsics cross blocks: the reduction as a GEMM on the fp64 matrix core (ba_schur2.hpp).  Pose parts beyond 63 rows
-  // (several 96-row tile pairs per chunk) keep schur_kernel unless OKVIS_BA_SCHUR2_LARGE is set: every tile pair of a chunk
+  // (several 96-row tile pairs per chunk) keep schur_kernel unless OKVIS_BA_TUNE_SCHUR_MFMA_LARGE is set: every tile pair of a chunk
   // scans all its (landmark, block) rows to fill its tiles, and at configs[2] that makes the matrix-core kernel the slower one
   // (111 against 100 us per launch)
-  static const bool mfma_large = std::getenv("OKVIS_BA_SCHUR2_LARGE") != nullptr;
+  const bool mfma_large = (s->opt.tuning.flags & OKVIS_BA_TUNE_SCHUR_MFMA_LARGE) != 0;
   if (!s->any_ext && !no_mfma && (trows + 1 <= SCH2_MAXT_SMALL_ROWS || mfma_large)) {
     int nlb = sch2_nlb(trows, 5120);              // 40 KB of tiles: three workgroups per CU
     if (nlb < 12) nlb = sch2_nlb(trows, 9216);    // wide tiles: 72 KB, two per CU
     const size_t sm = (size_t)sch2_tile_doubles(trows, nlb) * sizeof(double);
-    if (small_rides_with_schur(s)) {   // the IMU / prior factors of the trial in the same launch (schur_small_kernel)
-      const int n_small = s->max_imu + 1;
-      hipLaunchKernelGGL(schur_small_kernel<3>, dim3(n_small + s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), std::max(sm, small_smem()), b.st, s->d_wins + b.w0,
-                         s->d_opt, trows, final_call, nlb, s->d_ctrl + b.w0, 1, n_small);
-    } else if (trows + 1 <= SCH2_MAXT_SMALL_ROWS)
+    if (trows + 1 <= SCH2_MAXT_SMALL_ROWS)
       hipLaunchKernelGGL(schur_mfma_kernel<3>, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), sm, b.st, s->d_wins + b.w0, s->d_opt, trows, final_call, nlb, s->d_ctrl + b.w0, spec_schur_now(s) ? 1 : 0);
     else
       hipLaunchKernelGGL(schur_mfma_kernel<9>, dim3(s->max_schur_blocks, (unsigned)b.nw), dim3(SCHUR_THREADS), sm, b.st, s->d_wins + b.w0, s->d_opt, trows, final_call, nlb, s->d_ctrl + b.w0, 0);
@@ -1398,12 +1404,9 @@ hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
     const int sd = lin2_step_doubles(s->max_Dp, fuse, f32);
     const size_t smem2 = lin2_smem(s->max_Dp, fuse, f32);
     if (s->split_small) {
-      // (the factors of a trial ride with the next Schur launch where that launch takes no decision; the initial evaluation keeps
-      // its own launch: okvis_ba_begin is followed by a Schur launch too, whose factor workgroups then evaluate the same states again)
-      if (init || !small_rides_with_schur(s))
-        hipLaunchKernelGGL(small_kernel, dim3(n_small, (unsigned)b.nw), dim3(LIN_THREADS), small_smem(), b.st, s->d_wins + b.w0, init);
+      hipLaunchKernelGGL(small_kernel, dim3(n_small, (unsigned)b.nw), dim3(LIN_THREADS), small_smem(), b.st, s->d_wins + b.w0, init);
       const dim3 grid2(s->max_group, (unsigned)b.nw);
-      static const int occ_env = [] { const char* e = std::getenv("OKVIS_BA_LIN2_OCC"); return e ? std::atoi(e) : 4; }();
+      const int occ_env = s->opt.tuning.lin2_occupancy > 0 ? s->opt.tuning.lin2_occupancy : 4;
       const bool two_rounds = !fuse && occ_env >= 4;   // block records in two rounds: 37 KB of LDS, four workgroups per CU
       const size_t smem2v = two_rounds ? lin2_smem(s->max_Dp, false, f32, true) : smem2;
       auto go2 = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid2, dim3(LIN_THREADS), smem2v, b.st, s->d_wins + b.w0, s->d_opt, init, 0, sd); };
@@ -1536,6 +1539,7 @@ void okvis_ba_default_options(okvis_ba_options* o) {
   o->jacobi_scaling = 1;
   o->max_consecutive_invalid_steps = 5;
   o->reserved0 = 0;
+  std::memset(&o->tuning, 0, sizeof(o->tuning));
 }
 
 const char* okvis_ba_error_string(int status) {
@@ -1560,10 +1564,7 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   okvis_ba_solver* s = new okvis_ba_solver();
   s->device = device;
   okvis_ba_default_options(&s->opt);
-  {   // start offset of the sub-batch streams (us; default 20: measured 20 / 45 / 70 us all lock the fast interleaving; 0 = none)
-    const char* e = std::getenv("OKVIS_BA_STAGGER_US");
-    s->stagger_ticks = (long long)((e ? std::atof(e) : 20.0) * 100.0);
-  }
+  s->stagger_ticks = 20 * 100;   // start offset of the sub-batch streams (us; default 20: measured 20 / 45 / 70 us all lock the fast interleaving; okvis_ba_tuning::stagger_us)
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&s->ev0);
@@ -1604,7 +1605,6 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
     lds(reinterpret_cast<const void*>(&small_kernel), small_smem());
   }
   lds(reinterpret_cast<const void*>(&schur_mfma_kernel<3>), (size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double));
-  lds(reinterpret_cast<const void*>(&schur_small_kernel<3>), std::max((size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double), small_smem()));
   lds(reinterpret_cast<const void*>(&schur_mfma_kernel<9>), (size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double));
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1664,7 +1664,14 @@ int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt) {
     return OKVIS_BA_ERR_ARG;
   if (s->uploaded && (opt->debug_arrays != s->opt.debug_arrays || opt->schur_lm_per_block != s->opt.schur_lm_per_block ||
                       opt->n_streams != s->opt.n_streams))
-    return OKVIS_BA_ERR_STATE;  // these two shape the arena: set them before upload
+    return OKVIS_BA_ERR_STATE;  // these shape the arena: set them before upload
+  if (s->uploaded) {   // ... and so does the tuning record, but for the switches that are read per call and the stream stagger
+    const uint32_t per_call = OKVIS_BA_TUNE_NO_MARG_TILES | OKVIS_BA_TUNE_NO_EARLY_PREINTEGRATION | OKVIS_BA_TUNE_H0_ON_HOST;
+    okvis_ba_tuning a = opt->tuning, b = s->opt.tuning;
+    a.flags &= ~per_call; b.flags &= ~per_call;
+    a.stagger_us = b.stagger_us = 0;
+    if (std::memcmp(&a, &b, sizeof(a)) != 0) return OKVIS_BA_ERR_STATE;
+  }
   // unchanged options (the host class sets them before every upload): nothing to do - every upload writes the device copy
   if (std::memcmp(opt, &s->opt, sizeof(*opt)) == 0) return OKVIS_BA_OK;
   // captured graphs name the kernels and the launch sequence of the options they were captured under: another linearise
@@ -1672,6 +1679,7 @@ int okvis_ba_set_options(okvis_ba_solver* s, const okvis_ba_options* opt) {
   if (opt->fp32_linearize != s->opt.fp32_linearize || opt->strategy != s->opt.strategy || opt->gauss_newton != s->opt.gauss_newton)
     destroy_graphs(s);
   s->opt = *opt;
+  s->stagger_ticks = (long long)(opt->tuning.stagger_us > 0 ? opt->tuning.stagger_us : opt->tuning.stagger_us < 0 ? 0 : 20) * 100;
   HIP_TRY(hipSetDevice(s->device));
   OptD d = make_optd(s->opt, (int)s->wins.size());
   HIP_TRY(hipMemcpyAsync(s->d_opt, &d, sizeof(d), hipMemcpyHostToDevice, s->stream));
@@ -1715,11 +1723,10 @@ int okvis_ba_upload(okvis_ba_solver* s, int n_windows, const okvis_ba_window* wi
 // uploaded value of their first speed/bias block), so that it runs while the host builds the index lists (imu_pre_kernel,
 // ba_linearize2.hpp).  A handful of terms only — the new term of a sliding window; a batch of fresh windows re-preintegrates inside
 // its first linearise launch as before (hundreds of terms fill the device either way).  Returns the number started; where[k] =
-// (window, term) and the device records wait at *src for imu_pre_place_kernel.  OKVIS_BA_NO_PRE switches it off (A/B).
+// (window, term) and the device records wait at *src for imu_pre_place_kernel.  OKVIS_BA_TUNE_NO_EARLY_PREINTEGRATION switches it off (A/B).
 constexpr int PRE_MAX_TERMS = 8;
 static int pre_launch(okvis_ba_solver* s, int n_windows, const okvis_ba_window* windows, const int2** where_dev, const ImuCacheD** src_dev) {
-  static const bool off = std::getenv("OKVIS_BA_NO_PRE") != nullptr;
-  if (off) return 0;
+  if (s->opt.tuning.flags & OKVIS_BA_TUNE_NO_EARLY_PREINTEGRATION) return 0;
   struct Item {
     int w, f;
   };
@@ -1824,12 +1831,11 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   const int2* pre_where = nullptr;
   const ImuCacheD* pre_src = nullptr;
   const int n_pre = pre_launch(s, n_windows, windows, &pre_where, &pre_src);   // (runs on the device while the lists are built)
-  const bool dbg_t = std::getenv("OKVIS_BA_DEBUG_UPLOAD") != nullptr;
+  const bool dbg_t = debug_word().upload;
   const auto t_u0 = std::chrono::steady_clock::now();
   // the piece path of the linearise launch (ba_linearize2.hpp) unless a window of the batch does not fit it (free extrinsics,
-  // a landmark with more than LIN2_PIECES pieces) or options.reserved0 bit 3 / OKVIS_BA_NO_LIN2 asks for the staged kernel
-  static const bool no_lin2_env = std::getenv("OKVIS_BA_NO_LIN2") != nullptr;
-  bool lin2 = !(s->opt.reserved0 & 8) && !no_lin2_env;
+  // a landmark with more than LIN2_PIECES pieces) or options.reserved0 bit 3 asks for the staged kernel
+  bool lin2 = !(s->opt.reserved0 & 8);
   for (int i = 0; i < n_windows; ++i) {
     int rc = build_window(windows[i], s->opt, A, wins[i], n_windows, lin2);
     if (rc == BW_LIN2_UNFIT) {   // start over with the staged kernel's lists for every window
@@ -1845,7 +1851,7 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   {
     // IMU / prior factors in a launch of their own when the batch fills the device (then four linearise workgroups share a
     // CU); one launch for everything when a few windows wait for one another's latency
-    static const int split_min = [] { const char* e = std::getenv("OKVIS_BA_SPLIT_SMALL_MIN"); return e ? std::atoi(e) : SMALL_BATCH_WINDOWS; }();
+    const int split_min = s->opt.tuning.split_small_min > 0 ? s->opt.tuning.split_small_min : SMALL_BATCH_WINDOWS;
     s->split_small = lin2 && n_windows >= split_min;
   }
   const auto t_u1 = std::chrono::steady_clock::now();
@@ -2006,7 +2012,7 @@ int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt,
   // (the staging bytes are kept between calls like a solver keeps them between uploads — except for a dump, whose alignment
   // gaps must be zero)
   static thread_local StageVec kept;
-  const bool dumping = std::getenv("OKVIS_BA_DUMP_ARENA") != nullptr;
+  const bool dumping = !debug_word().arena.empty();
   if (!dumping) A.host.swap(kept);
   struct GiveBack {
     StageVec& a;
@@ -2017,15 +2023,15 @@ int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt,
     }
   } give_back{A.host, kept, !dumping};
   // the route okvis_ba_upload takes for a one-window batch: the piece path's lists unless the window does not fit them
-  int rc = (o.reserved0 & 8) || std::getenv("OKVIS_BA_NO_LIN2") ? BW_LIN2_UNFIT : build_window(*w, o, A, H, 1, true);
+  int rc = (o.reserved0 & 8) ? BW_LIN2_UNFIT : build_window(*w, o, A, H, 1, true);
   if (rc == BW_LIN2_UNFIT) {
     A.size = 0;
     A.zsize = 0;
     rc = build_window(*w, o, A, H);
   }
   if (rc != OKVIS_BA_OK) return rc;
-  if (const char* dump = std::getenv("OKVIS_BA_DUMP_ARENA")) {   // diagnostics: the index build's output, byte for byte
-    if (FILE* f = std::fopen(dump, "wb")) {
+  if (dumping) {   // diagnostics (OKVIS_BA_DEBUG=arena=<file>): the index build's output, byte for byte
+    if (FILE* f = std::fopen(debug_word().arena.c_str(), "wb")) {
       std::fwrite(A.host.data(), 1, A.size, f);
       std::fwrite(&H.ptrs, 1, sizeof(H.ptrs), f);
       std::fclose(f);
@@ -2045,7 +2051,7 @@ int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options
   if (opt) o = *opt; else okvis_ba_default_options(&o);
   Arena A;
   HostWin H;
-  int rc = (o.reserved0 & 8) || std::getenv("OKVIS_BA_NO_LIN2") ? BW_LIN2_UNFIT : build_window(*w, o, A, H, n_windows, true);
+  int rc = (o.reserved0 & 8) ? BW_LIN2_UNFIT : build_window(*w, o, A, H, n_windows, true);
   if (rc == BW_LIN2_UNFIT) {
     A.size = 0;
     A.zsize = 0;
@@ -2182,7 +2188,7 @@ int okvis_ba_patch_window(okvis_ba_solver* s, int w, const okvis_ba_patch* p) {
   if (w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
   HIP_TRY(hipSetDevice(s->device));
   auto pt_prev = std::chrono::steady_clock::now();
-  auto PT = [&](const char* name) {   // (OKVIS_BA_DEBUG_BUILD: mean host time per section, printed at exit with build_window's)
+  auto PT = [&](const char* name) {   // (OKVIS_BA_DEBUG=build: mean host time per section, printed at exit with build_window's)
     if (g_build_times.on) {
       const auto t_ = std::chrono::steady_clock::now();
       g_build_times.ms[name] += std::chrono::duration<double, std::milli>(t_ - pt_prev).count();
@@ -2579,6 +2585,46 @@ int okvis_ba_helper_timeouts(okvis_ba_solver* s, int64_t* count) {
   }
   return OKVIS_BA_OK;
 }
+int okvis_ba_launch_route(okvis_ba_solver* s, int32_t* route) {
+  if (!s || !route) return OKVIS_BA_ERR_ARG;
+  if (!s->uploaded) return OKVIS_BA_ERR_STATE;
+  for (int i = 0; i < OKVIS_BA_ROUTE_COUNT; ++i) route[i] = 0;
+  const int n = (int)s->wins.size(), nsub = std::max<int>(1, (int)s->sub_streams.size());
+  int sub_max = n;
+  if (s->sub_streams.size() > 1) {
+    sub_max = 0;
+    for (size_t k = 0; k + 1 < s->sub_begin.size(); ++k) sub_max = std::max(sub_max, s->sub_begin[k + 1] - s->sub_begin[k]);
+  }
+  route[OKVIS_BA_ROUTE_WINDOWS] = n;
+  route[OKVIS_BA_ROUTE_FUSED] = fused(s) ? 1 : 0;
+  route[OKVIS_BA_ROUTE_DECISION_FREE_SCHUR] = spec_schur_now(s) ? 1 : 0;
+  route[OKVIS_BA_ROUTE_PIECE_PATH] = s->lin2 ? 1 : 0;
+  route[OKVIS_BA_ROUTE_SPLIT_SMALL] = s->split_small ? 1 : 0;
+  route[OKVIS_BA_ROUTE_SUB_BATCHES] = nsub;
+  route[OKVIS_BA_ROUTE_SUB_BATCH_MAX_WINDOWS] = sub_max;
+  {   // the kernel launch_schur picks (same conditions, nothing launched)
+    const int trows = std::min(TILE_DIM, s->max_Dp);
+    int k = 0;
+    if (s->max_schur_blocks > 0 && !fused(s)) {
+      if (!s->any_ext && !(s->opt.tuning.flags & OKVIS_BA_TUNE_SCHUR_VALU) &&
+          (trows + 1 <= SCH2_MAXT_SMALL_ROWS || (s->opt.tuning.flags & OKVIS_BA_TUNE_SCHUR_MFMA_LARGE)))
+        k = trows + 1 <= SCH2_MAXT_SMALL_ROWS ? 2 : 3;
+      else
+        k = 1;
+    }
+    route[OKVIS_BA_ROUTE_SCHUR_KERNEL] = k;
+  }
+  route[OKVIS_BA_ROUTE_SOLVE_DBUF] = (s->max_Dpad_small > 0 && (s->group_chunks || s->spec_schur)) ? 1 : 0;
+  route[OKVIS_BA_ROUTE_SOLVE_TILED] = s->max_Dpad_large > 0 ? 1 : 0;
+  route[OKVIS_BA_ROUTE_SOLVE_HELPERS] = sub_max <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0;
+  route[OKVIS_BA_ROUTE_GRAPH] = s->opt.use_graph ? 1 : 0;
+  int ch = 0;
+  for (const HostWin& H : s->wins) ch = std::max(ch, H.n_chunk);
+  route[OKVIS_BA_ROUTE_MAX_CHUNKS] = ch;
+  route[OKVIS_BA_ROUTE_SLOTS] = (int32_t)std::min<long long>(s->slots, 0x7fffffff);
+  route[OKVIS_BA_ROUTE_SOLVE_MODE] = s->max_Dpad_small > 0 ? OKVIS_BA_SOLVE_DENSE : 0;
+  return OKVIS_BA_OK;
+}
 int okvis_ba_pair_count(okvis_ba_solver* s, int w, int32_t* n_pair) {
   if (!s || !n_pair || w < 0 || w >= (int)s->wins.size()) return OKVIS_BA_ERR_ARG;
   *n_pair = s->wins[w].n_pair;
@@ -2915,7 +2961,7 @@ int okvis_ba_marginalize_begin(okvis_ba_solver* s, int w, const okvis_ba_marg_sp
   const size_t o_out = A.alloc(out_bytes + sizeof(int) * (8 + std::max(1, D)));
   const size_t o_info = o_out + out_bytes;
   // kept blocks beyond the single-workgroup LDS paths: the tail on many workgroups (ba_marg_tiles.hpp)
-  const bool no_tiles = std::getenv("OKVIS_BA_NO_MARG_TILES") != nullptr;   // (A/B switch, read per call)
+  const bool no_tiles = (s->opt.tuning.flags & OKVIS_BA_TUNE_NO_MARG_TILES) != 0;   // (A/B switch)
   const bool tiles = na > MARG_PC_NMAX && !no_tiles;
   const int mt_nT = tiles ? (na + CT_TB - 1) / CT_TB : 0, mt_ntiles = mt_nT * (mt_nT + 1) / 2;
   const size_t o_mtT = A.alloc(8 * (size_t)std::max(1, mt_ntiles) * CT_TILE), o_mtZ = A.alloc(8 * (size_t)std::max(1, mt_ntiles) * CT_TILE),
@@ -3137,7 +3183,7 @@ int okvis_ba_marginalize_end(okvis_ba_solver* s, okvis_ba_marg_result* res) {
   res->rank = info[2];
   res->sweeps[0] = info[3];
   res->sweeps[1] = info[4];
-  if (std::getenv("OKVIS_BA_DEBUG_MARG"))
+  if (debug_word().marg)
     std::fprintf(stderr, "marginalize: kept dim %d rank %d sweeps %d %d  pivoted-Cholesky bounds: dropped %.3f tau_hi, kept %d tau_hi\n", info[0],
                  info[2], info[3], info[4], info[6] * 1e-3, info[7]);
   for (size_t k = 0; k < bt.size(); ++k) {

@@ -707,7 +707,7 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
   // overwrote comes back here, before this evaluation looks at its own bias.  (Until round 5 it stayed: the explicit trial then
   // saw a reference bias further away than the threshold and integrated once more, at ITS bias, where the reference still
   // has the preintegration of the last real evaluation — costs 1e-9 ... 1e-5 apart in the middle of radius-limited runs,
-  // two re-preintegrations of 104 us for none.  Found with the long double referee, tests/gpu_cost_consistency.py.)
+  // two re-preintegrations of 104 us for none.  Found with the long double referee, tools/gpu_cost_consistency.py.)
   if (s_prev) {   // (uniform; rare: the previous evaluation of this term re-preintegrated)
     if (spec_discard) {
       const double* src = reinterpret_cast<const double*>(cp);

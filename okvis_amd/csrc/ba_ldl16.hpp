@@ -203,7 +203,7 @@ __device__ __forceinline__ void ldl_operand(const double* Xk, const double* dk, 
 // factorisation of a matrix that is not symmetric any more, and the panel rows (L^-1 from the columns) stop matching the
 // trailing updates (which assume D L^T from the rows).  Measured against the oracle built in long double: the Gauss-Newton step
 // of the far-start DOGLEG case of test_dogleg_rejected_steps 1e-7 from the extended-precision solution of the same system
-// (an unblocked Cholesky: 4e-9), the cost after 20 iterations 3e-7 (tests/gpu_referee_*.py, profiles/r05_notes.md).  With
+// (an unblocked Cholesky: 4e-9), the cost after 20 iterations 3e-7 (tools/gpu_referee_*.py, profiles/r05_notes.md).  With
 // v = vh + vl, vl = fma(-A[K][j], 1/d, -vh) the part of the product that vh rounded away, and a second fmac per row,
 // entry and mirror image receive a_iK a_Kj / d to twice the working precision — the first fmac cancels exactly, the second
 // restores what vh had lost — and agree to an ulp of the RESULT: 1.2e-9 on the same case (the fp64 oracle: 3.5e-9).

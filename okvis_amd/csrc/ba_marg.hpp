@@ -239,7 +239,7 @@ __device__ __forceinline__ double marg_rsqrt(double x) {  // v_rsq_f64 + two New
 // The kept eigenvalues are PROVEN to lie above every possible threshold (> 4 tau_hi).  The remainder R of a
 // rank-deficient matrix is rounding noise, so "below tau" cannot be proven for the dropped ones; required instead: the
 // UPPER bound of the dropped eigenvalues is below 1e3 tau_hi AND there is a gap of at least 100 to the smallest kept one.
-// Measured (OKVIS_BA_DEBUG_MARG=1 prints the bounds; tests/gpu_marg_bounds.py): after ONE marginalisation of a gauge-deficient
+// Measured (OKVIS_BA_DEBUG=marg prints the bounds; tools/gpu_marg_bounds.py): after ONE marginalisation of a gauge-deficient
 // window the bound is 0.02 .. 0.44 tau_hi; in the running pipeline, where every prior is built on the previous one, it is
 // 2 .. 360 tau_hi (80-frame replay) - there the reference's own eigen decision flips between consecutive frames (rank 42 / 43
 // of 45), i.e. the disputed direction sits at the cut itself.  A limit of 4 tau_hi was tried: every frame of the replay then

@@ -492,21 +492,4 @@ __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_m
   schur_mfma_body<SCH2_MAXT>(wins, optp, tile_rows, final_call, nlb, ctrls, nodec, (int)blockIdx.x);
 }
 
-// The decision-free Schur launch and the IMU / prior factors of the same trial in ONE launch (round 5): workgroups 0 .. n_small - 1
-// of a window are the factor workgroups of small_kernel (ba_imu.hpp), the others the Schur workgroups.  Neither waits for the
-// other — the reduction does not need the factors' costs when it takes no decision — and both only have to be through before the
-// solve launch: the factor launch (14 us at 21 windows) leaves the chain of a sub-batch.  Two workgroups per CU (the factor
-// workgroups' registers and LDS), which the 9 + 10 workgroups per window of configs[1] fit in one round at the timed loop's shape.
-template <int SCH2_MAXT>
-__global__ __launch_bounds__(SCHUR_THREADS, 2) void schur_small_kernel(const WinPtrs* __restrict__ wins, const OptD* __restrict__ optp, int tile_rows,
-                                                                       int final_call, int nlb, const CtrlSlot* __restrict__ ctrls, int nodec, int n_small) {
-  static_assert(SCHUR_THREADS == IMU_THREADS && SCHUR_THREADS == LIN_THREADS, "one block size for both kinds of workgroup");
-  if ((int)blockIdx.x < n_small) {
-    extern __shared__ __attribute__((aligned(16))) double sch_smem[];
-    small_body(wins[blockIdx.y], 0, (int)blockIdx.x, sch_smem);
-    return;
-  }
-  schur_mfma_body<SCH2_MAXT>(wins, optp, tile_rows, final_call, nlb, ctrls, nodec, (int)blockIdx.x - n_small);
-}
-
 }  // namespace ba

@@ -66,7 +66,12 @@ Estimator::Estimator(int device) : device_(device) {
   // ~10 x 3 plain kernel launches that overlap with the GPU work anyway): eager launches by default here.
   options_.use_graph = 0;
   std::memset(&summary_, 0, sizeof(summary_));
-  if (std::getenv("OKVIS_AMD_NO_PATCH")) usePatch_ = false;
+  if (const char* e = std::getenv("OKVIS_AMD_DEBUG")) {   // print / cross-check diagnostics only (estimator.hpp, Diagnostics)
+    const std::string w = std::string(",") + e + ",";
+    diag_.trace = w.find(",trace,") != std::string::npos;
+    diag_.checkPatch = w.find(",check_patch,") != std::string::npos;
+    diag_.syncAfterHandover = w.find(",sync_after_handover,") != std::string::npos;
+  }
   if (device < 0) {   // book-keeping only (estimator.hpp): nothing below this class computes
     dry_ = true;
     return;
@@ -684,8 +689,7 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
   if (states_.empty()) return;
   typedef std::chrono::steady_clock clk;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  static const bool trace = std::getenv("OKVIS_AMD_TRACE") != nullptr;   // (read once: optimize() is the per-frame hot path)
-  static const bool checkPatch = std::getenv("OKVIS_AMD_CHECK_PATCH") != nullptr;
+  const bool trace = diag_.trace, checkPatch = diag_.checkPatch;
   const auto t0 = clk::now();
   if (!dry_) check(okvis_ba_set_options(solver_, &options_), "set_options");
   // ---- the window: the edits since the last call as one patch of the window the solver holds, else flatten + upload ----
@@ -708,7 +712,7 @@ void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
         if (bad) std::printf("okvis_amd::Estimator::optimize: input array %zu holds %zu non-finite values of %zu\n", a, bad, fw.f64[a].size());
       }
   }
-  static const bool syncAfter = std::getenv("OKVIS_AMD_SYNC_AFTER_HANDOVER") != nullptr;   // (diagnostics: the enqueued copies are charged to the hand-over)
+  const bool syncAfter = diag_.syncAfterHandover;   // (diagnostics: the enqueued copies are charged to the hand-over)
   if (syncAfter && !dry_) check(okvis_ba_synchronize(solver_), "synchronize");
   const auto t2 = clk::now();
   const SyncedWindow& S = synced_;
@@ -1156,8 +1160,7 @@ bool Estimator::patchWindow() {
   const int rc = dry_ ? okvis_ba_store_patch(dryStore_, &P) : okvis_ba_patch_window(solver_, 0, &P);
   if (rc != OKVIS_BA_OK) {
     // (all or nothing on the solver's side: the old window is still there; optimize() describes the new one from scratch)
-    static const bool trace = std::getenv("OKVIS_AMD_TRACE") != nullptr;
-    if (trace) std::printf("okvis_amd::Estimator: patch refused (%s), uploading the window instead\n", okvis_ba_error_string(rc));
+    if (diag_.trace) std::printf("okvis_amd::Estimator: patch refused (%s), uploading the window instead\n", okvis_ba_error_string(rc));
     return false;
   }
   // ---- the description follows the container ----

@@ -169,12 +169,21 @@ class Estimator {
   const std::array<double, 4>& lastOptimizeTimings() const { return timings_; }
   // The solver keeps the window between calls (okvis_ba_set_patchable): optimize() sends it the edits since the last call
   // (addStates, addObservation, removeObservation, applyMarginalizationStrategy, the setters) as one okvis_ba_patch instead of
-  // flattening and uploading everything again.  false = flatten + upload every time (the round-3 route; A/B switch, also
-  // OKVIS_AMD_NO_PATCH in the environment).
+  // flattening and uploading everything again.  false = flatten + upload every time (the round-3 route; A/B switch).
   void setUsePatch(bool on) { usePatch_ = on; }
+  // Print / cross-check diagnostics; none changes a result.  trace: non-finite inputs and refused patches are printed;
+  // checkPatch: every hand-over is compared with a freshly flattened window (debugCheckWindow(), throws on a difference);
+  // syncAfterHandover: optimize() waits for the enqueued copies before it starts the iterations' clock.  The constructor also
+  // takes them from the ONE environment variable this class reads, OKVIS_AMD_DEBUG, a comma-separated list of
+  // "trace", "check_patch", "sync_after_handover" (so that a whole test run can be cross-checked: scripts/).
+  struct Diagnostics {
+    bool trace = false, checkPatch = false, syncAfterHandover = false;
+  };
+  void setDiagnostics(const Diagnostics& d) { diag_ = d; }
+  const Diagnostics& diagnostics() const { return diag_; }
   bool lastOptimizeWasPatch() const { return lastWasPatch_; }
   // diagnostics: compares the window the solver holds with a freshly flattened one (landmark by landmark, any landmark order);
-  // returns an empty string when they agree.  optimize() runs it after every hand-over when OKVIS_AMD_CHECK_PATCH is set.
+  // returns an empty string when they agree.  optimize() runs it after every hand-over when Diagnostics::checkPatch is set.
   std::string debugCheckWindow();
 
   // last applyMarginalizationStrategy(): ms flatten / upload / okvis_ba_marginalize, Jacobi sweeps of the two
@@ -350,6 +359,7 @@ class Estimator {
   std::vector<int> poseValueSet_, sbValueSet_;    // blocks whose value the caller has set
   int familiesChanged_ = 0;                       // OKVIS_BA_PATCH_* bits: prior families edited since the last hand-over
   bool usePatch_ = true, lastWasPatch_ = false;
+  Diagnostics diag_;
   void touch(MapPoint& mp) {
     if (!mp.touched) {
       mp.touched = true;

@@ -279,6 +279,15 @@ class WindowBatch:
         _lib.check(self._L.okvis_ba_helper_timeouts(self._h, C.byref(n)))
         return n.value
 
+    ROUTE = ("windows", "fused", "decision_free_schur", "piece_path", "split_small", "sub_batches", "sub_batch_max_windows",
+             "schur_kernel", "solve_dbuf", "solve_tiled", "solve_helpers", "graph", "max_chunks", "slots", "solve_mode")
+
+    def launch_route(self) -> dict:
+        """okvis_ba_launch_route: which launches this batch takes under the current options (read-only)"""
+        r = (C.c_int32 * 16)()
+        _lib.check(self._L.okvis_ba_launch_route(self._h, r), "launch_route")
+        return {n: int(r[i]) for i, n in enumerate(self.ROUTE)}
+
     def algorithmic_bytes(self):
         v = [C.c_int64() for _ in range(4)]
         _lib.check(self._L.okvis_ba_algorithmic_bytes(self._h, *[C.byref(x) for x in v]))

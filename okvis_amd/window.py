@@ -50,6 +50,19 @@ class WindowC(C.Structure):
     ]
 
 
+# okvis_ba_tuning.flags (include/okvis_amd_ba.h, OKVIS_BA_TUNE_*) and okvis_ba_tuning.solve_mode (OKVIS_BA_SOLVE_*)
+TUNE_SCHUR_DECIDES, TUNE_SCHUR_VALU, TUNE_SCHUR_MFMA_LARGE, TUNE_NO_LDL_COMP, TUNE_LDL_COMP_ALL = 0x1, 0x2, 0x4, 0x8, 0x10
+TUNE_H0_ON_HOST, TUNE_NO_EARLY_PREINTEGRATION, TUNE_NO_MARG_TILES = 0x20, 0x40, 0x80
+SOLVE_AUTO, SOLVE_DENSE, SOLVE_CHAIN = 0, 1, 2
+
+
+class TuningC(C.Structure):
+    _fields_ = [
+        ("flags", C.c_uint32), ("fused_max_windows", C.c_int32), ("group_lm", C.c_int32), ("group_work", C.c_int32),
+        ("split_small_min", C.c_int32), ("lin2_occupancy", C.c_int32), ("stagger_us", C.c_int32), ("solve_mode", C.c_int32),
+    ]
+
+
 class OptionsC(C.Structure):
     _fields_ = [
         ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
@@ -60,7 +73,7 @@ class OptionsC(C.Structure):
         ("debug_arrays", C.c_int32), ("gauss_newton", C.c_int32),
         ("n_streams", C.c_int32), ("fp32_linearize", C.c_int32),
         ("strategy", C.c_int32), ("jacobi_scaling", C.c_int32), ("max_consecutive_invalid_steps", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("reserved0", C.c_int32), ("tuning", TuningC),
     ]
 
 
@@ -148,6 +161,16 @@ def default_options(strategy=None) -> OptionsC:
     """Ceres 1.9 defaults restated from its documentation (not in the reference tree)."""
     return OptionsC(1e4, 1e16, 1e-32, 1e-6, 1e32, 1e-3, 1e-6, 1e-10, 1e-8, 1, 0, 0, 0, 0, 0,
                     DEFAULT_STRATEGY if strategy is None else strategy, 1, 5, 0)
+
+
+def set_options(o: OptionsC, **kw) -> OptionsC:
+    """o.<name> = value; names starting with `tuning_` address okvis_ba_options::tuning (tuning_group_lm=64, tuning_flags=...)."""
+    for k, v in kw.items():
+        if k.startswith("tuning_"):
+            setattr(o.tuning, k[7:], v)
+        else:
+            setattr(o, k, v)
+    return o
 
 
 def _f64(a, shape):

@@ -59,8 +59,8 @@ c=$(find $O/c_pmc -name "*counter_collection.csv" | head -1); [ -n "$c" ] && sum
 rm -rf $O/c_pmc
 cd $R
 timeout 150 python scripts/bench_marginalize.py --config-c > $O/bench_marginalize.json 2> $O/bench_marginalize.err
-timeout 60 python tests/gpu_replay_timing.py > $O/replay_timing.txt 2>&1
+timeout 60 python tools/gpu_replay_timing.py > $O/replay_timing.txt 2>&1
 timeout 200 python scripts/mixed_precision_study.py > $O/mixed_precision.json 2> $O/mixed_precision.err
-for nw in 1 64; do OKVIS_BA_FUSED_MAX_WINDOWS=0 python tests/gpu_lin_stamps.py $nw 4 > $O/lin_stamps_$nw.txt 2>&1; python tests/gpu_prof_stamps.py $nw 4 > $O/stamps_$nw.txt 2>&1; done
-python tests/gpu_solve_stamps.py > $O/solve_stamps.txt 2>&1
+for nw in 1 64; do OKVIS_BA_FUSED_MAX_WINDOWS=0 python tools/gpu_lin_stamps.py $nw 4 > $O/lin_stamps_$nw.txt 2>&1; python tools/gpu_prof_stamps.py $nw 4 > $O/stamps_$nw.txt 2>&1; done
+python tools/gpu_solve_stamps.py > $O/solve_stamps.txt 2>&1
 head -c 300 $O/bench_default.json; echo; head -8 $O/kernel_stats_graph.csv | cut -c1-150; cat $O/batch_sweep.jsonl; cat $O/pmc_sq_64windows.txt | head -40

@@ -22,6 +22,6 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/marg -o p
 f=$(find $O/marg -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_marginalize.csv
 rm -rf $O/marg
 cd $R
-timeout 200 python tests/gpu_replay_timing.py > $O/replay_timing.txt 2>&1
+timeout 200 python tools/gpu_replay_timing.py > $O/replay_timing.txt 2>&1
 timeout 120 python scripts/bench_config_c.py > $O/bench_config_C.json 2> $O/bench_config_C.err
 grep -E "medians|route" $O/replay_timing.txt; head -12 $O/kernel_stats_marginalize.csv | cut -c1-160; tail -c 300 $O/bench_config_C.json

@@ -17,8 +17,8 @@ for n in 1 2 4 8 16 32 64 128 256; do
   python bench.py --windows $n --no-pmc --no-cpu-baseline --no-extras --profile-steps 0 --repeats 15 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'windows': $n, 'iterations_per_s': d['value'], 'us_per_step': d['ms_per_step']*1e3}))"
 done > $O/batch_sweep.jsonl
 cat $O/batch_sweep.jsonl
-for n in 1 8 22 64; do timeout 120 python tests/gpu_solve_stamps.py $n > $O/solve_stamps_$n.txt 2>&1; done
-timeout 120 python tests/gpu_prof_stamps.py > $O/linearize_stamps.txt 2>&1
+for n in 1 8 22 64; do timeout 120 python tools/gpu_solve_stamps.py $n > $O/solve_stamps_$n.txt 2>&1; done
+timeout 120 python tools/gpu_prof_stamps.py > $O/linearize_stamps.txt 2>&1
 timeout 60 tests/micro/bin/ldl16 > $O/ldl16_micro.txt 2>&1
 for b in branch_lat lds_lat icache rcp_acc mfma_lat; do echo "== $b"; timeout 60 tests/micro/bin/$b; done > $O/micro_costs.txt 2>&1
 cd /tmp
@@ -59,13 +59,13 @@ f=$(find $O/c_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f"
 rm -rf $O/c_trace
 cd $R
 # the long double referee: spread of the far-start DOGLEG case, the random sweep's seeds, two D = 300 windows
-timeout 300 python tests/gpu_referee_spread.py > $O/referee_spread41.txt 2>&1
-timeout 300 python tests/gpu_sweep_gaps.py > $O/referee_sweep_gaps.txt 2>&1
-timeout 300 python tests/gpu_referee_large.py > $O/referee_large.txt 2>&1
-timeout 300 python tests/gpu_referee_marg.py > $O/referee_marg.txt 2>&1
-timeout 300 python tests/gpu_tolerance_audit.py > $O/tolerance_audit.txt 2>&1
-timeout 200 python tests/gpu_referee_dogleg_iters.py 2 30 > $O/referee_dogleg_iters.txt 2>&1
-timeout 200 python tests/gpu_replay_timing.py > $O/replay_timing.txt 2>&1
+timeout 300 python tools/gpu_referee_spread.py > $O/referee_spread41.txt 2>&1
+timeout 300 python tools/gpu_sweep_gaps.py > $O/referee_sweep_gaps.txt 2>&1
+timeout 300 python tools/gpu_referee_large.py > $O/referee_large.txt 2>&1
+timeout 300 python tools/gpu_referee_marg.py > $O/referee_marg.txt 2>&1
+timeout 300 python tools/gpu_tolerance_audit.py > $O/tolerance_audit.txt 2>&1
+timeout 200 python tools/gpu_referee_dogleg_iters.py 2 30 > $O/referee_dogleg_iters.txt 2>&1
+timeout 200 python tools/gpu_replay_timing.py > $O/replay_timing.txt 2>&1
 grep -E "medians|route" $O/replay_timing.txt | head
 timeout 200 python scripts/bench_marginalize.py --config-c > $O/bench_marginalize.json 2> $O/bench_marginalize.err
 echo done

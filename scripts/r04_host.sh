@@ -18,7 +18,7 @@ print({k: fh.get(k) for k in ("upload_ms", "optimize10_ms", "patch_newest_frame_
 print(fh.get("estimator_replay"))
 print("single", d.get("single_window"))
 PY
-timeout 200 python tests/gpu_replay_timing.py > $OUT/replay_timing.txt 2>&1
+timeout 200 python tools/gpu_replay_timing.py > $OUT/replay_timing.txt 2>&1
 grep -E "medians|route" $OUT/replay_timing.txt
-OKVIS_BA_DEBUG_BUILD=1 timeout 200 python tests/gpu_replay_timing.py > $OUT/replay_sections.txt 2>&1
+OKVIS_BA_DEBUG_BUILD=1 timeout 200 python tools/gpu_replay_timing.py > $OUT/replay_sections.txt 2>&1
 grep -E "route|patch:|index build|staging|observations|groups|lists" $OUT/replay_sections.txt | head -24

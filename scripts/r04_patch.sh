@@ -9,7 +9,7 @@ OKVIS_AMD_CHECK_PATCH=1 timeout 1500 python -m pytest tests/test_gpu_patch.py te
 grep -E "passed|failed|FAILED|Error" $OUT/pytest_estimator.log | tail -8
 timeout 600 python -m pytest tests/test_gpu_structure_paths.py -m gpu -q -x -k "helper" > $OUT/pytest_helpers.log 2>&1
 grep -E "passed|failed|FAILED|Error" $OUT/pytest_helpers.log | tail -4
-timeout 200 python tests/gpu_replay_timing.py > $OUT/replay_timing.txt 2>&1
+timeout 200 python tools/gpu_replay_timing.py > $OUT/replay_timing.txt 2>&1
 grep -E "medians|route" $OUT/replay_timing.txt
-OKVIS_BA_DEBUG_BUILD=1 timeout 200 python tests/gpu_replay_timing.py > $OUT/replay_sections.txt 2>&1
+OKVIS_BA_DEBUG_BUILD=1 timeout 200 python tools/gpu_replay_timing.py > $OUT/replay_sections.txt 2>&1
 grep -E "build_window|route" $OUT/replay_sections.txt | head -4

@@ -13,7 +13,7 @@ grep -E "passed|failed" $O/pytest_gpu.log | tail -3; grep -E "^FAILED|^ERROR" $O
 for v in r4 new; do
   d=$R/okvis_amd/lib_variants/$v; [ $v = new ] && d=$R/okvis_amd/lib
   for n in 1 8 22; do
-    OKVIS_AMD_LIB_DIR=$d timeout 120 python tests/gpu_solve_stamps.py $n > $O/stamps_${v}_$n.txt 2>&1
+    OKVIS_AMD_LIB_DIR=$d timeout 120 python tools/gpu_solve_stamps.py $n > $O/stamps_${v}_$n.txt 2>&1
   done
 done
 echo "== new, 1 window"; cat $O/stamps_new_1.txt; echo "== new, 22 windows"; cat $O/stamps_new_22.txt

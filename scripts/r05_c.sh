@@ -10,7 +10,7 @@ timeout 30 tests/micro/bin/mfma_lat > $O/mfma_lat.txt 2>&1; cat $O/mfma_lat.txt
 for b in ldl16_z ldl16_z_e16; do echo "== $b"; timeout 60 tests/micro/bin/$b > $O/$b.txt 2>&1; grep -E "elimination|D= *-?150|step" $O/$b.txt | head -26; done
 timeout 900 python -m pytest tests -m gpu -q --timeout=240 > $O/pytest_gpu.log 2>&1
 grep -E "passed|failed" $O/pytest_gpu.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head -20
-for n in 1 8 22; do timeout 120 python tests/gpu_solve_stamps.py $n > $O/stamps_new_$n.txt 2>&1; done
+for n in 1 8 22; do timeout 120 python tools/gpu_solve_stamps.py $n > $O/stamps_new_$n.txt 2>&1; done
 echo "== new, 1 window"; cat $O/stamps_new_1.txt; echo "== new, 22 windows"; cat $O/stamps_new_22.txt
 B="python bench.py --no-pmc --no-extras --no-cpu-baseline --repeats 12"
 for v in new; do

@@ -10,7 +10,7 @@ grep -E "passed|failed" $O/pytest_gpu.log | tail -3; grep -E "^FAILED|^ERROR" $O
 for v in r4 new; do
   d=$R/okvis_amd/lib_variants/$v; [ $v = new ] && d=$R/okvis_amd/lib
   for n in 1 8 22; do
-    OKVIS_AMD_LIB_DIR=$d timeout 120 python tests/gpu_solve_stamps.py $n > $O/stamps_${v}_$n.txt 2>&1
+    OKVIS_AMD_LIB_DIR=$d timeout 120 python tools/gpu_solve_stamps.py $n > $O/stamps_${v}_$n.txt 2>&1
   done
   echo "== $v, 1 window"; cat $O/stamps_${v}_1.txt
 done

@@ -7,9 +7,9 @@ cd $R
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q --timeout=240 -x > $O/pytest_gpu.log 2>&1
 grep -E "passed|failed" $O/pytest_gpu.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head -20
-for n in 1 22; do timeout 120 python tests/gpu_solve_stamps.py $n > $O/stamps_new_$n.txt 2>&1; done
+for n in 1 22; do timeout 120 python tools/gpu_solve_stamps.py $n > $O/stamps_new_$n.txt 2>&1; done
 grep -E "total|LDL" $O/stamps_new_1.txt $O/stamps_new_22.txt
-timeout 120 python tests/gpu_prof_stamps.py > $O/prof_stamps.txt 2>&1; tail -12 $O/prof_stamps.txt
+timeout 120 python tools/gpu_prof_stamps.py > $O/prof_stamps.txt 2>&1; tail -12 $O/prof_stamps.txt
 B="python bench.py --no-pmc --no-extras --no-cpu-baseline --repeats 12"
 timeout 300 $B > $O/bench_new.json 2> $O/bench_new.err
 python - <<PY

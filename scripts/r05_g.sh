@@ -18,5 +18,5 @@ done
 cd $R
 for v in comp nocomp; do
   if [ $v = nocomp ]; then export OKVIS_BA_NO_LDL_COMP=1; else unset OKVIS_BA_NO_LDL_COMP; fi
-  for n in 1 64; do timeout 100 python tests/gpu_solve_stamps.py $n 2>&1 | grep -E "total|LDL\^T solver" | sed "s/^/$v $n: /"; done
+  for n in 1 64; do timeout 100 python tools/gpu_solve_stamps.py $n 2>&1 | grep -E "total|LDL\^T solver" | sed "s/^/$v $n: /"; done
 done

@@ -7,8 +7,8 @@ mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 export OKVIS_AMD_LIB_DIR=okvis_amd/lib_variants/nr1
-timeout 200 python tests/gpu_referee_spread.py > $O/spread41_nr1.txt 2>&1; cat $O/spread41_nr1.txt
-timeout 200 python tests/gpu_sweep_gaps.py > $O/sweep_gaps_nr1.txt 2>&1
+timeout 200 python tools/gpu_referee_spread.py > $O/spread41_nr1.txt 2>&1; cat $O/spread41_nr1.txt
+timeout 200 python tools/gpu_sweep_gaps.py > $O/sweep_gaps_nr1.txt 2>&1
 python - <<PY
 import re
 g=[]; o=[]

@@ -1,0 +1,139 @@
+"""GPU parity of the HEADLINE configuration: the very windows bench.py times — 64 windows of BASELINE
+configs[1] built by synthetic.make_window(10, 400, visibility, 20240923 + i), i.e. configs[3]'s job on one GPU — through the DEFAULT
+route of a batch of that size, which no smaller batch takes: IMU / prior factors in a launch of their own (split_small, from 40
+windows), three sub-batches on three streams (from 56 windows), Schur chunks of 48 landmarks, the decision-free matrix-core Schur
+launch and the solve kernel's DBUF instantiation, replayed from a hipGraph.  Every window's result is compared with the oracle
+(okvis::Estimator::optimize, okvis_ceres/src/Estimator.cpp:843-906: the same number of trust-region iterations on every window),
+and the route is asserted through okvis_ba_launch_route / okvis_ba_check_window_lists so that the test cannot silently fall back
+to the small-batch path it was written to complement.  The 256-window shape is bench.py's `step_saturated` record."""
+import numpy as np
+import pytest
+
+from okvis_amd import solver, synthetic
+from okvis_amd.window import default_options
+
+pytestmark = pytest.mark.gpu
+
+N_HEAD = 64
+N_SAT = 256
+
+
+def bench_windows(n):
+    """the windows of bench.py: seeds 20240923 + i for the headline batch, 20250000 + i for the ones that fill it up to 256"""
+    return [synthetic.make_window(10, 400, 1.0, 20240923 + i) for i in range(min(n, N_HEAD))] + \
+           [synthetic.make_window(10, 400, 1.0, 20250000 + i) for i in range(max(0, n - N_HEAD))]
+
+
+def bench_options():
+    """bench.py's options for the timed region"""
+    o = default_options()
+    o.function_tolerance = o.gradient_tolerance = o.parameter_tolerance = 0.0
+    o.use_graph = 1
+    o.gauss_newton = 1
+    return o
+
+
+@pytest.fixture(scope="module")
+def windows():
+    return bench_windows(N_SAT)
+
+
+def _landmarks_per_chunk(w, opt, n_windows):
+    il = solver.index_lists(w, opt, n_windows)
+    g, ch = il["groups"], il["chunks"]
+    return [int(g[e - 1, 1] - g[b, 0]) for b, e in ch]
+
+
+def _assert_headline_route(b, n, opt, w0):
+    r = b.launch_route()
+    assert r["windows"] == n
+    assert r["fused"] == 0, r                       # (> 48 windows: no fused linearise + reduce launch)
+    assert r["decision_free_schur"] == 1, r         # schur_mfma_kernel<3>, nodec
+    assert r["schur_kernel"] == 2, r
+    assert r["piece_path"] == 1 and r["split_small"] == 1, r     # linearize2_kernel + small_kernel
+    assert r["sub_batches"] == 3 and r["sub_batch_max_windows"] == (n + 2) // 3, r
+    assert r["solve_dbuf"] == 1 and r["solve_tiled"] == 0 and r["solve_helpers"] == 0, r
+    assert r["graph"] == 1, r
+    per = _landmarks_per_chunk(w0, opt, n)
+    want = 48 if n < 128 else 64
+    assert max(per) == want and r["max_chunks"] == len(per) == -(-400 // want), (per, r)
+    return r
+
+
+def _check(sg, ws, idx, oracle, opt, n_iter, tol, states=None):
+    worst = 0.0
+    for i in idx:
+        o = oracle.OracleWindow(ws[i])
+        ref = o.optimize(n_iter, opt)
+        dev = abs(sg[i]["final_cost"] - ref["final_cost"]) / ref["final_cost"]
+        worst = max(worst, dev)
+        assert dev <= tol, (i, dev, sg[i], ref)
+        assert abs(sg[i]["initial_cost"] - ref["initial_cost"]) <= 1e-12 * ref["initial_cost"], (i, sg[i], ref)
+        assert (sg[i]["iterations"], sg[i]["successful_steps"], sg[i]["termination"]) == \
+               (ref["iterations"], ref["successful_steps"], ref["termination"]), (i, sg[i], ref)
+        if states is not None:
+            pg, sbg, lg = states(i)
+            pr, sbr, lr = o.get_state()
+            assert np.abs(pg - pr).max() < 1e-8 and np.abs(sbg - sbr).max() < 1e-8 and np.abs(lg - lr).max() < 1e-7, i
+    return worst
+
+
+@pytest.mark.parametrize("mode", ["bench", "default"])
+def test_64_windows_of_the_bench_through_the_default_route(oracle, windows, mode):
+    """(a) bench.py's options (Gauss-Newton mode, tolerances off, graph replay), (b) the library's defaults (DOGLEG, what
+    Estimator.cpp:858 configures): optimize(10) on all 64 windows, EVERY window against the oracle at 1e-9 on the cost, states at
+    1e-8, identical iteration book-keeping."""
+    ws = windows[:N_HEAD]
+    opt = bench_options() if mode == "bench" else default_options()
+    b = solver.WindowBatch(ws, options=opt)
+    _assert_headline_route(b, N_HEAD, opt, ws[0])
+    sg = b.optimize(10)
+    assert b.launch_route()["slots"] >= 10
+    worst = _check(sg, ws, range(N_HEAD), oracle, opt, 10, 1e-9, states=b.get_state)
+    print(f"64 windows, {mode}: max rel cost deviation from the oracle {worst:.2e}")
+    # the timed loop of bench.py is begin() + iterate(n) repeated on the same solver: a second call continues from the states of the
+    # first (graph of another length), and the oracle repeats the calls
+    sg2 = b.optimize(5)
+    for i in (0, 21, 22, 42, 43, 63):                  # first and last window of every sub-batch
+        o = oracle.OracleWindow(ws[i])
+        o.optimize(10, opt)
+        ref = o.optimize(5, opt)
+        assert abs(sg2[i]["final_cost"] - ref["final_cost"]) <= 1e-9 * ref["final_cost"], (i, sg2[i], ref)
+        assert (sg2[i]["iterations"], sg2[i]["successful_steps"]) == (ref["iterations"], ref["successful_steps"])
+    b.close()
+
+
+def test_64_windows_begin_iterate_finish_like_the_timed_loop(oracle, windows):
+    """bench.py's call sequence itself: begin(), iterate(warmup), iterate(steps) several times, finish() — the graphs of both lengths
+    replayed back to back — against the oracle run for the same total number of iterations."""
+    ws = windows[:N_HEAD]
+    opt = bench_options()
+    b = solver.WindowBatch(ws, options=opt)
+    b.begin()
+    b.iterate(3)
+    for _ in range(3):
+        b.iterate(4)
+    sg = b.finish()
+    _check(sg, ws, range(0, N_HEAD, 3), oracle, opt, 15, 1e-9)
+    b.close()
+
+
+@pytest.mark.parametrize("mode", ["bench", "default"])
+def test_256_windows_saturated_shape(oracle, windows, mode):
+    """bench.py's `step_saturated` record: 256 windows in one upload (three sub-batches of 85 / 86 windows, chunks of 64 landmarks);
+    every 8th window against the oracle, and every window's cost against its own 64-window run where the two batches share windows
+    (another chunking: the Schur partials are summed in another grouping, so this is a rounding-level comparison, not bit-identity)."""
+    opt = bench_options() if mode == "bench" else default_options()
+    b = solver.WindowBatch(windows, options=opt)
+    _assert_headline_route(b, N_SAT, opt, windows[0])
+    sg = b.optimize(10)
+    worst = _check(sg, windows, range(0, N_SAT, 8), oracle, opt, 10, 1e-9, states=b.get_state)
+    print(f"256 windows, {mode}: max rel cost deviation from the oracle {worst:.2e}")
+    costs = np.array([s["final_cost"] for s in sg])
+    assert np.all(np.isfinite(costs)) and np.all([s["iterations"] == 10 for s in sg])
+    b.close()
+    b64 = solver.WindowBatch(windows[:N_HEAD], options=opt)
+    s64 = b64.optimize(10)
+    b64.close()
+    c64 = np.array([s["final_cost"] for s in s64])
+    assert np.abs(costs[:N_HEAD] - c64).max() <= 1e-10 * c64.max()

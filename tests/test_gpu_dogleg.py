@@ -56,7 +56,7 @@ def test_dogleg_matches_oracle(oracle, case, radius):
     # with the conditioning of |gnhat|.  The long double referee showed the oracle at 1e-11 and the GPU at 1e-8 ... 2e-7 in those runs,
     # 1e-5 in their middle: a Gauss-Newton point evaluated speculatively and then replaced by an explicit step had re-preintegrated
     # IMU terms, an evaluation the reference never makes; its trace is now taken back (ba_imu.hpp, Ctrl::spec_discard).  Measured
-    # now against the oracle: <= 3e-11, tests/gpu_tolerance_audit.py.)
+    # now against the oracle: <= 3e-11, tools/gpu_tolerance_audit.py.)
     s = _compare(oracle, w, 10, tol=1e-9, initial_radius=radius)
     if radius == 1.0:
         assert s["final_radius"] > 1e3
@@ -76,7 +76,7 @@ def test_radius_limited_runs_iteration_by_iteration(oracle, case, radius):
         ref_g = b.array("IMU_SB_REF")
         b.close()
         # (against the oracle in long double: in the middle of the descent the fp64 oracle itself is 1e-8 from it, the GPU 1e-9 —
-        #  tests/gpu_referee_dogleg_iters.py)
+        #  tools/gpu_referee_dogleg_iters.py)
         o = oracle.OracleWindow(w, extended=True)
         sr = o.optimize(n, _opts(**kw))
         assert (sg["iterations"], sg["successful_steps"]) == (sr["iterations"], sr["successful_steps"])

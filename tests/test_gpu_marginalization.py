@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from okvis_amd import synthetic
-from okvis_amd.window import Window, default_options
+from okvis_amd.window import TUNE_H0_ON_HOST, TUNE_NO_MARG_TILES, Window, default_options
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,7 @@ def check(g, r, tol=1e-9):
     # (until round 5: 1e-6, "b0 cancels terms weighted with the prior information".  It was not cancellation: the first pose sits
     #  at its prior, the reference's quaternion arithmetic gives a residual of exactly zero there and the kernel's contracted
     #  products gave 1e-17, times 1e16 — ba_math.hpp, qmul_strict; against the long double oracle now 3e-15 ... 4e-14,
-    #  tests/gpu_referee_marg.py)
+    #  tools/gpu_referee_marg.py)
     assert rel(g["b0"], r["b0"]) < max(tol, 1e-9)
     assert rel(g["J"].T @ g["J"], r["J"].T @ r["J"]) < tol
     assert rel(g["J"].T @ g["e0"], r["J"].T @ r["e0"]) < max(tol, 1e-9)
@@ -123,21 +123,19 @@ def test_window_beyond_the_lds_solve_path(oracle):
     check(g, r, 1e-8)
 
 
-def test_tiled_tail_equals_the_single_workgroup(monkeypatch):
+def test_tiled_tail_equals_the_single_workgroup():
     """kept blocks of more than 96 rows: Schur complement, factorisation (matrix core, 48 x 48 tiles), proof of full rank and
     J, e0 on many workgroups (ba_marg_tiles.hpp) — the same numbers as the single workgroup working in HBM
-    (OKVIS_BA_NO_MARG_TILES), which is the Cholesky factor of the same matrix"""
+    (okvis_ba_tuning flag OKVIS_BA_TUNE_NO_MARG_TILES), which is the Cholesky factor of the same matrix"""
     from okvis_amd import solver
     for K, seed, poses, sbs in ((20, 2, [0, 1], [0, 1]), (12, 5, [0], [0, 1, 2]), (20, 7, [], [0])):
         w = synthetic.make_window(K, 30, 1.0, seed, frame_dt=0.1)
         pm, sm = flags(w, poses, sbs)
         out = []
         for off in (False, True):
-            if off:
-                monkeypatch.setenv("OKVIS_BA_NO_MARG_TILES", "1")
-            else:
-                monkeypatch.delenv("OKVIS_BA_NO_MARG_TILES", raising=False)
-            b = solver.WindowBatch([w], options=default_options())
+            o = default_options()
+            o.tuning.flags = TUNE_NO_MARG_TILES if off else 0
+            b = solver.WindowBatch([w], options=o)
             out.append(b.marginalize(0, pm, sm))
             b.close()
         t, o = out
@@ -146,7 +144,6 @@ def test_tiled_tail_equals_the_single_workgroup(monkeypatch):
         assert rel(t["J"], o["J"]) < 1e-10 and rel(t["e0"], o["e0"]) < 1e-9
         assert np.abs(np.tril(t["J"], -1)).max() == 0.0
         assert rel(t["J"].T @ t["J"], t["H"]) < 1e-12
-    monkeypatch.delenv("OKVIS_BA_NO_MARG_TILES", raising=False)
 
 
 def test_previous_prior_of_more_than_192_rows(oracle):
@@ -190,7 +187,7 @@ def test_previous_prior_of_more_than_192_rows(oracle):
     assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-8 * sr["final_cost"]
 
 
-def test_large_prior_product_on_the_device_is_the_hosts(monkeypatch, oracle):
+def test_large_prior_product_on_the_device_is_the_hosts(oracle):
     """H0 = J^T J of a prior of more than 128 rows is formed by a kernel behind the upload (the same sums in the same order,
     no fused multiply-add) instead of by the host's index build: the optimisation does not change by a bit"""
     from okvis_amd import solver
@@ -210,15 +207,12 @@ def test_large_prior_product_on_the_device_is_the_hosts(monkeypatch, oracle):
     w.marg_lin = lin
     out = []
     for host in (False, True, False, True):
-        if host:
-            monkeypatch.setenv("OKVIS_BA_H0_ON_HOST", "1")
-        else:
-            monkeypatch.delenv("OKVIS_BA_H0_ON_HOST", raising=False)
-        b = solver.WindowBatch([w], options=default_options())
+        o = default_options()
+        o.tuning.flags = TUNE_H0_ON_HOST if host else 0
+        b = solver.WindowBatch([w], options=o)
         s = b.optimize(5)[0]
         out.append((s, b.get_state()))
         b.close()
-    monkeypatch.delenv("OKVIS_BA_H0_ON_HOST", raising=False)
     assert out[0][0] == out[2][0] and out[1][0] == out[3][0], "the optimisation itself is not repeatable"
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     for u, v in zip(out[0][1], out[1][1]):

@@ -7,7 +7,7 @@ Four seeds are checked against the oracle built in long double instead (REFEREE;
 reference's DOGLEG policy the Gauss-Newton systems are regularised by mu = 1e-8 only, and those windows (two frames / a handful
 of landmarks / 15 % visibility, or a snapshot in mid-descent) have weakly constrained directions that make the step uncertain at
 1e-8 in fp64 (condition of the reduced matrix up to 1e15).  Until round 5 they ran against the fp64 oracle at north_star's 1e-6.
-Measured with tests/gpu_sweep_gaps.py (round 5, profiles/r05_referee_sweep_gaps.txt), cost against the referee, GPU | fp64 oracle:
+Measured with tools/gpu_sweep_gaps.py (round 5, profiles/r05_referee_sweep_gaps.txt), cost against the referee, GPU | fp64 oracle:
 seed 0: 9.8e-10 | 3.1e-9, seed 7: 7.5e-8 | 3.1e-7, seed 8: 6.6e-11 | 9.3e-10, seed 21: 1.2e-10 | 2.2e-9 — the distance these seeds
 had shown was the oracle's.  The other 28 seeds: GPU <= 5.5e-10 from the referee, <= 2.7e-10 from the fp64 oracle."""
 import numpy as np

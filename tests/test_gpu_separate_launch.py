@@ -2,18 +2,16 @@
 small batches (options.reserved0 bit 2 keeps the separate launch where the fused linearise + reduce launch would be chosen).
 
 Round 5: in DOGLEG and fixed-radius runs that launch takes no trust-region decision any more (schur_mfma_kernel, nodec): it reduces
-the trial buffer into that buffer's own set of partials and the solve kernel decides, as in fused mode.  OKVIS_BA_NO_SPEC_SCHUR=1
-(read once per process) keeps the decision at the head of the Schur launch; both routes are compared with the oracle here, and with
-each other in two processes."""
+the trial buffer into that buffer's own set of partials and the solve kernel decides, as in fused mode.  The tuning flag
+OKVIS_BA_TUNE_SCHUR_DECIDES keeps the decision at the head of the Schur launch; both routes are compared with the oracle here, and with
+each other."""
 import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
 
 from okvis_amd import solver, synthetic
-from okvis_amd.window import default_options
+from okvis_amd.window import TUNE_SCHUR_DECIDES, default_options
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,37 +57,30 @@ def test_separate_launch_matches_oracle(oracle, mode):
     b.close()
 
 
-_CHILD = r'''
-import os, sys
-sys.path.insert(0, sys.argv[2])
-import numpy as np
-from okvis_amd import solver
-sys.path.insert(0, os.path.join(sys.argv[2], "tests"))
-import test_gpu_separate_launch as T
-res = {}
-for mode in ("dogleg", "gn"):
-    ws = T._windows()
-    b = solver.WindowBatch(ws, options=T._opts(mode))
-    sm = b.optimize(10)
-    res[mode + "_cost"] = np.array([x["final_cost"] for x in sm])
-    res[mode + "_iter"] = np.array([x["iterations"] for x in sm])
-    res[mode + "_succ"] = np.array([x["successful_steps"] for x in sm])
-    res[mode + "_pose"] = np.concatenate([b.get_state(i)[0].reshape(-1) for i in range(len(ws))])
-    b.close()
-np.savez(sys.argv[1], **res)
-'''
+def _both_modes(flags):
+    res = {}
+    for mode in ("dogleg", "gn"):
+        ws = _windows()
+        o = _opts(mode)
+        o.tuning.flags = flags
+        b = solver.WindowBatch(ws, options=o)
+        route = b.launch_route()
+        assert route["fused"] == 0 and route["decision_free_schur"] == (0 if flags & TUNE_SCHUR_DECIDES else 1), route
+        sm = b.optimize(10)
+        res[mode + "_cost"] = np.array([x["final_cost"] for x in sm])
+        res[mode + "_iter"] = np.array([x["iterations"] for x in sm])
+        res[mode + "_succ"] = np.array([x["successful_steps"] for x in sm])
+        res[mode + "_pose"] = np.concatenate([b.get_state(i)[0].reshape(-1) for i in range(len(ws))])
+        b.close()
+    return res
 
 
-def test_decision_free_schur_launch_against_the_deciding_one(tmp_path):
-    """The two routes in two processes: the same accepted / rejected steps; fixed-radius runs (every step accepted: the same
+def test_decision_free_schur_launch_against_the_deciding_one():
+    """The two routes: the same accepted / rejected steps; fixed-radius runs (every step accepted: the same
     partials summed in the same order) agree bit for bit, and so do DOGLEG runs without a rejected step; after a rejection the solve
     kernel corrects the sums it took from the trial's set by the difference of the two sets where the deciding launch reduces
     the accepted buffer again: the far-start windows then differ by rounding (measured 4e-12 on the cost)."""
-    out = {}
-    for name, env in (("spec", {}), ("dec", {"OKVIS_BA_NO_SPEC_SCHUR": "1"})):
-        f = str(tmp_path / (name + ".npz"))
-        subprocess.run([sys.executable, "-c", _CHILD, f, ROOT], check=True, env=dict(os.environ, **env), timeout=300)
-        out[name] = np.load(f)
+    out = {"spec": _both_modes(0), "dec": _both_modes(TUNE_SCHUR_DECIDES)}
     a, b = out["spec"], out["dec"]
     for k in ("dogleg_iter", "dogleg_succ", "gn_iter", "gn_succ"):
         assert np.array_equal(a[k], b[k]), k

@@ -16,26 +16,20 @@ import numpy as np
 import pytest
 
 from okvis_amd import solver, synthetic
-from okvis_amd.window import default_options
+from okvis_amd.window import default_options, set_options
 
 pytestmark = pytest.mark.gpu
 
 
 def _batch(ws, **opt):
-    o = default_options()
-    for k, v in opt.items():
-        setattr(o, k, v)
-    return solver.WindowBatch(ws, options=o)
+    return solver.WindowBatch(ws, options=set_options(default_options(), **opt))
 
 
 def _compare(oracle, w, n, tol=1e-9, **opt):
     b = _batch([w], **opt)
     sg = b.optimize(n)[0]
     o = oracle.OracleWindow(w)
-    op = default_options()
-    for k, v in opt.items():
-        setattr(op, k, v)
-    sr = o.optimize(n, op)
+    sr = o.optimize(n, set_options(default_options(), **opt))
     assert abs(sg["final_cost"] - sr["final_cost"]) <= tol * sr["final_cost"], (sg, sr)
     assert (sg["iterations"], sg["successful_steps"], sg["termination"]) == \
            (sr["iterations"], sr["successful_steps"], sr["termination"]), (sg, sr)
@@ -54,7 +48,7 @@ def test_rejected_steps_take_the_reload_path(oracle):
         w = synthetic.small_window(seed=seed, K=5, L=60, pose_noise=(0.4, np.deg2rad(6.0)), landmark_noise=0.8)
         # tolerance: with a radius of 1e8 the first systems are almost undamped and ill-conditioned; GPU and oracle
         # differ by 1e-11 after ONE iteration and that grows to 6e-8 over the 25 (north_star asks 1e-6; against the long double
-        # oracle the GPU is at 2.7e-8 and the fp64 oracle at 3.2e-8 on seed 41, 1e-11 ... 1e-13 on the others: tests/gpu_tolerance_audit.py)
+        # oracle the GPU is at 2.7e-8 and the fp64 oracle at 3.2e-8 on seed 41, 1e-11 ... 1e-13 on the others: tools/gpu_tolerance_audit.py)
         s = _compare(oracle, w, 25, tol=5e-7, initial_radius=1e8, function_tolerance=0.0, gradient_tolerance=0.0,
                      parameter_tolerance=0.0)
         found = found or s["successful_steps"] < s["iterations"]
@@ -93,22 +87,17 @@ def test_many_reduction_tasks_per_group(oracle):
 
 
 @pytest.mark.parametrize("group_lm", [None, 32, 64])
-def test_low_visibility_large_groups_and_custom_chunks(oracle, monkeypatch, group_lm):
+def test_low_visibility_large_groups_and_custom_chunks(oracle, group_lm):
     """short tracks: the groups close at the landmark limit, not at 256 observations — 16 landmarks for a solver of few windows,
-    32 for batches, 64 (the kernels' capacity) on request (OKVIS_BA_GROUP_LM)"""
-    if group_lm:
-        monkeypatch.setenv("OKVIS_BA_GROUP_LM", str(group_lm))
+    32 for batches, 64 (the kernels' capacity) on request (okvis_ba_tuning::group_lm)"""
     w = synthetic.make_window(6, 300, 0.3, seed=48)
     for per in (0, 16, 100, 1000):                          # Schur workgroup size: default, small, > 64, clamped
-        _compare(oracle, w, 6, schur_lm_per_block=per)
-    b = _batch([w])
+        _compare(oracle, w, 6, schur_lm_per_block=per, tuning_group_lm=group_lm or 0)
     import ctypes as C
-    from okvis_amd.window import default_options as _do
     st = (C.c_int64 * 8)()
     wc, keep = w.as_c()
-    o = _do()
-    assert b._L.okvis_ba_check_window(C.byref(wc), C.byref(o), st) == 0
-    b.close()
+    o = set_options(default_options(), tuning_group_lm=group_lm or 0)
+    assert solver._lib.lib().okvis_ba_check_window(C.byref(wc), C.byref(o), st) == 0
     assert st[3] == {None: 19, 32: 10, 64: 6}[group_lm], (st[3], w.n_lm)      # groups of 300 landmarks / 1504 observations
 
 

@@ -229,9 +229,9 @@ def _expected_ldl_comp(w, blocks):
     return m
 
 
-def test_blocks_with_a_prior_are_marked_for_the_compensated_elimination(monkeypatch):
+def test_blocks_with_a_prior_are_marked_for_the_compensated_elimination():
     """WinPtrs::ldl_comp (ba_ldl16.hpp): the diagonal blocks of the dense solver that hold columns of a pose prior or of the
-    marginalisation prior, in the solver's ordering; nothing for windows above the LDS solver's size; OKVIS_BA_NO_LDL_COMP clears it"""
+    marginalisation prior, in the solver's ordering; nothing for windows above the LDS solver's size; the tuning flag OKVIS_BA_TUNE_NO_LDL_COMP clears it"""
     wA = synthetic.config_A()
     assert solver.index_lists(wA)["ldl_comp"] == _expected_ldl_comp(wA, [(0, int(p)) for p in wA.pprior_pose]) == 1 << 5
     w = synthetic.small_window(seed=41, K=5, L=60)
@@ -252,5 +252,6 @@ def test_blocks_with_a_prior_are_marked_for_the_compensated_elimination(monkeypa
     assert solver.index_lists(wm)["ldl_comp"] == want and bin(want).count("1") >= 3
     wl = synthetic.make_window(20, 30, 1.0, 2, frame_dt=0.1)
     assert wl.reduced_dim() == 300 and solver.index_lists(wl)["ldl_comp"] == 0
-    monkeypatch.setenv("OKVIS_BA_NO_LDL_COMP", "1")
-    assert solver.index_lists(wA)["ldl_comp"] == 0
+    from okvis_amd.window import TUNE_LDL_COMP_ALL, TUNE_NO_LDL_COMP, default_options, set_options
+    assert solver.index_lists(wA, set_options(default_options(), tuning_flags=TUNE_NO_LDL_COMP))["ldl_comp"] == 0
+    assert solver.index_lists(wA, set_options(default_options(), tuning_flags=TUNE_LDL_COMP_ALL))["ldl_comp"] == 0xFFFFFFFF

@@ -4,7 +4,7 @@ oracle/liboracle_ld.so is oracle/liboracle.so's sources built with orc::real = l
 than fp64); the C entry points take and return double in both.  It answers which side of a disagreement between the GPU and the
 fp64 oracle moved: the far-start DOGLEG case of test_gpu_dogleg.py::test_dogleg_rejected_steps (seed 41: ten accepted and ten
 rejected steps along a flat valley) used to sit 6e-7 ... 1.7e-6 from the fp64 oracle depending on a tuning knob of the index
-build.  Measured (tests/gpu_referee_spread.py, 12 one-ulp perturbations of the landmark start values, each run against the
+build.  Measured (tools/gpu_referee_spread.py, 12 one-ulp perturbations of the landmark start values, each run against the
 referee of the same input): fp64 oracle 3.5e-9 (median) / 1.4e-8 (max) from the referee; the GPU 2.9e-7 / 7.1e-7 before the
 compensated elimination of the prior blocks (ba_ldl16.hpp, WinPtrs::ldl_comp), 1e-9 ... 1.3e-8 with it.  The oracle had been right.
 
@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from okvis_amd import synthetic
-from okvis_amd.window import STRATEGY_DOGLEG, default_options
+from okvis_amd.window import SOLVE_DENSE, STRATEGY_DOGLEG, TUNE_NO_LDL_COMP, default_options
 
 FAR = dict(K=5, L=60, pose_noise=(0.4, np.deg2rad(6.0)), landmark_noise=0.8)
 
@@ -95,8 +95,8 @@ def test_gpu_spread_under_one_ulp_perturbations(oracle):
 
 
 @pytest.mark.gpu
-def test_switching_the_compensated_elimination_off_brings_the_distance_back(oracle, monkeypatch):
-    """OKVIS_BA_NO_LDL_COMP=1 (read when a window is uploaded): the same inputs, the plain elimination of the prior blocks — the
+def test_switching_the_compensated_elimination_off_brings_the_distance_back(oracle):
+    """OKVIS_BA_TUNE_NO_LDL_COMP (okvis_ba_options::tuning, read when a window is uploaded): the same inputs, the plain elimination of the prior blocks — the
     20-iteration cost of seed 41 is several 1e-7 from the referee again on at least one of four inputs one ulp apart (measured
     6e-7), and within 5e-8 on all of them with the default.  Keeps the switch honest and the defect on record."""
     from okvis_amd import solver
@@ -109,16 +109,15 @@ def test_switching_the_compensated_elimination_off_brings_the_distance_back(orac
         inputs.append(lm2)
     worst = {}
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("OKVIS_BA_NO_LDL_COMP", "1")
-        else:
-            monkeypatch.delenv("OKVIS_BA_NO_LDL_COMP", raising=False)
+        og = _opts()
+        og.tuning.flags = TUNE_NO_LDL_COMP if off else 0
+        og.tuning.solve_mode = SOLVE_DENSE      # (the switch belongs to the dense blocked LDL^T)
         worst[off] = 0.0
         for lm2 in inputs:
             ref = oracle.OracleWindow(w, extended=True)
             ref.set_state(lm=lm2)
             r = ref.optimize(20, _opts())
-            b = solver.WindowBatch([w], options=_opts())
+            b = solver.WindowBatch([w], options=og)
             b.set_state(0, lm=lm2)
             g = b.optimize(20)[0]
             b.close()

@@ -1,4 +1,4 @@
-"""Stage-by-stage GPU-vs-oracle diagnostic (run on the GPU box: python tests/gpu_diag.py).
+"""Stage-by-stage GPU-vs-oracle diagnostic (run on the GPU box: python tools/gpu_diag.py).
 
 Not a pytest module: prints the relative difference of every intermediate array so that one gpurun call
 localises a bug to a kernel.  The pytest parity tests are in tests/test_gpu_parity.py.

@@ -1,5 +1,5 @@
 """diagnostics (not a test): the far-start DOGLEG cases of test_dogleg_rejected_steps against the oracle, after 20 iterations
-(not converged) and at convergence, for several landmark-per-group limits of the index build (OKVIS_BA_GROUP_LM)"""
+(not converged) and at convergence, for several landmark-per-group limits of the index build (okvis_ba_tuning::group_lm)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ for seed in (41, 42, 43, 44):
         sr = oracle_lib.OracleWindow(w).optimize(n, o)
         row = []
         for cap in (64, 32, 24, 16, 8):
-            os.environ["OKVIS_BA_GROUP_LM"] = str(cap)
+            o.tuning.group_lm = cap
             b = solver.WindowBatch([w], options=o)
             sg = b.optimize(n)[0]
             b.close()

@@ -1,5 +1,5 @@
 """Diagnostic (not a test): clock64() phase stamps of linearise group 0 of window 0, alone and under load.
-usage: python tests/gpu_lin_stamps.py [n_windows] [reserved0]   (reserved0 bit 3 = staged kernel, bit 2 = no fused launch)"""
+usage: python tools/gpu_lin_stamps.py [n_windows] [reserved0]   (reserved0 bit 3 = staged kernel, bit 2 = no fused launch)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from okvis_amd import solver, synthetic

@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["OKVIS_BA_DEBUG_MARG"] = "1"
+os.environ["OKVIS_BA_DEBUG"] = "marg"
 from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
 from tests import oracle_lib

@@ -3,7 +3,7 @@ oracle?  The referee is the oracle built in long double (oracle/liboracle_ld.so)
 fp64 oracle and the GPU each linearise and solve the first DOGLEG system (mu = 1e-8); every intermediate array is compared with the
 referee's, error relative to the array's largest entry.  Then the 20-iteration run itself: per-iteration cost of the three sides.
 
-    python tests/gpu_referee_diag.py [--cpu] [seed]
+    python tools/gpu_referee_diag.py [--cpu] [seed]
 """
 import os, sys
 import numpy as np

@@ -1,5 +1,5 @@
 """diagnostics (not a test): the far-start DOGLEG case iteration by iteration — cost, radius and the IMU terms' reference biases of
-the GPU and the fp64 oracle against the long double referee.    python tests/gpu_referee_iters.py [seed]"""
+the GPU and the fp64 oracle against the long double referee.    python tools/gpu_referee_iters.py [seed]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

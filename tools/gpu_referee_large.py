@@ -1,6 +1,6 @@
 """diagnostics (not a test): windows above the LDS solver's size (tiled solver, D = 300) against the long double referee.  The tiled
 solver is not compensated (ba_chol_tiles.hpp says why; an experiment with it changed the last digits only), so the two GPU columns —
-with and without OKVIS_BA_NO_LDL_COMP — agree by construction."""
+with and without OKVIS_BA_TUNE_NO_LDL_COMP — agree by construction."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,11 +23,10 @@ for name, w in cases:
         a = oracle_lib.OracleWindow(w).optimize(8, o)
         row = "%-24s %-12s D %d  cost %.6f (%d acc)  oracle %.1e" % (name, sname, w.reduced_dim(), r["final_cost"], r["successful_steps"], abs(a["final_cost"] - r["final_cost"]) / r["final_cost"])
         for off in (0, 1):
-            if off: os.environ["OKVIS_BA_NO_LDL_COMP"] = "1"
-            else: os.environ.pop("OKVIS_BA_NO_LDL_COMP", None)
+            o.tuning.flags = 0x8 if off else 0   # OKVIS_BA_TUNE_NO_LDL_COMP
             b = solver.WindowBatch([w], options=o)
             g = b.optimize(8)[0]
             b.close()
             row += "   GPU%s %.1e%s" % (" (no comp)" if off else "", abs(g["final_cost"] - r["final_cost"]) / r["final_cost"], "" if g["successful_steps"] == r["successful_steps"] else " (steps differ)")
-        os.environ.pop("OKVIS_BA_NO_LDL_COMP", None)
+        o.tuning.flags = 0
         print(row, " [%.0f s]" % (time.time() - t0), flush=True)

@@ -1,5 +1,5 @@
 """diagnostics (not a test): okvis_ba_marginalize and the fp64 oracle's MarginalizationError against the oracle in long double:
-H, b0, J^T J, J^T e0 relative to the largest entry.    python tests/gpu_referee_marg.py [--cpu]"""
+H, b0, J^T J, J^T e0 relative to the largest entry.    python tools/gpu_referee_marg.py [--cpu]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -26,8 +26,9 @@ for t in range(12):
     o = oracle_lib.OracleWindow(w); o.set_state(lm=lm2)
     rows["oracle fp64"].append((o.optimize(n_it, opts())["final_cost"] - ref["final_cost"]) / ref["final_cost"])
     for cap in (16, 64, 8):
-        os.environ["OKVIS_BA_GROUP_LM"] = str(cap)
-        b = solver.WindowBatch([w], options=opts())
+        og = opts()
+        og.tuning.group_lm = cap
+        b = solver.WindowBatch([w], options=og)
         b.set_state(0, lm=lm2)
         s = b.optimize(n_it)[0]
         b.close()

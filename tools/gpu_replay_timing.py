@@ -1,5 +1,5 @@
 """diagnostics (not a test): per-frame timing split of the C++ replay on a synthetic recording, with the window patched between
-frames (default) and flattened + uploaded every frame (--no-patch).  OKVIS_BA_DEBUG_BUILD=1 in the environment adds the mean host
+frames (default) and flattened + uploaded every frame (--no-patch).  OKVIS_BA_DEBUG=build in the environment adds the mean host
 time of the solver's sections (index build, container edit, enqueue) to stderr."""
 import os, sys, subprocess, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""Diagnostics (not a test): phase stamps of the solve kernel of window 0 (clock64 ticks and us at 2.38 GHz).  python tests/gpu_solve_stamps.py [n_windows]"""
+"""Diagnostics (not a test): phase stamps of the solve kernel of window 0 (clock64 ticks and us at 2.38 GHz).  python tools/gpu_solve_stamps.py [n_windows]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from okvis_amd import solver, synthetic

@@ -1,8 +1,8 @@
-"""diagnostics (not a test): host time of okvis_ba_upload by section for a replay-sized window (OKVIS_BA_DEBUG_BUILD / _UPLOAD)"""
+"""diagnostics (not a test): host time of okvis_ba_upload by section for a replay-sized window (OKVIS_BA_DEBUG=build,upload)"""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["OKVIS_BA_DEBUG_BUILD"] = "1"
+os.environ["OKVIS_BA_DEBUG"] = "build,upload"
 from okvis_amd import solver, synthetic
 from okvis_amd.window import WindowC, default_options
 w = synthetic.make_window(8, 430, 0.5, seed=20240924)
