@@ -303,8 +303,9 @@ def main():
         roofline["achieved_8d"] = d8 / (d["launch_us"] * 1e-6) / 1e9
         roofline["frac_8d"] = roofline["achieved_8d"] / HBM_PEAK_GBS
         roofline["step"]["bound"] = "latency"
-        roofline["step"]["chain"] = ("one iteration of a sub-batch = " + ("4" if sub >= 40 else "3") +
-                                     " dependent launches on its stream (Schur, solve, linearise" + (", IMU / prior factors" if sub >= 40 else "") +
+        split_small = bool(batch.launch_route()["split_small"])
+        roofline["step"]["chain"] = ("one iteration of a sub-batch = " + ("4" if split_small else "3") +
+                                     " dependent launches on its stream (Schur, solve, linearise" + (", IMU / prior factors" if split_small else "") +
                                      f"), {nst} sub-batches side by side; the solve launch occupies {sub} of 256 CUs")
         if not a.no_extras and world == 1:
             # the saturated shape: 256 windows per GPU (4 x the headline's batch), same windows repeated with fresh seeds

@@ -55,8 +55,8 @@ def _assert_headline_route(b, n, opt, w0):
     assert r["solve_dbuf"] == 1 and r["solve_tiled"] == 0 and r["solve_helpers"] == 0, r
     assert r["graph"] == 1, r
     per = _landmarks_per_chunk(w0, opt, n)
-    want = 48 if n < 128 else 64
-    assert max(per) == want and r["max_chunks"] == len(per) == -(-400 // want), (per, r)
+    want = 48 if n < 128 else 64                    # (whole groups of 12 landmarks: 48, and 60 under the limit of 64)
+    assert want - 12 < max(per) <= want and r["max_chunks"] == len(per) == -(-400 // max(per)), (per, r)
     return r
 
 
