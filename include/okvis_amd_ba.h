@@ -326,6 +326,9 @@ int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt,
 #define OKVIS_BA_LIST_PIECE_PATH 17     /* one int: 1 = the lists are those of the piece path (ba_linearize2.hpp) */
 #define OKVIS_BA_LIST_LDL_COMP 18       /* one int: bit b = diagonal block b of the dense solver is eliminated with compensated products (it holds
                                            columns of a pose prior or of the marginalisation prior; 0 for windows above the LDS solver's size) */
+#define OKVIS_BA_LIST_CHAIN 19          /* one int: > 0 = the window (as a batch of its own) is laid out for the chain solver (okvis_ba_tuning::
+                                           solve_mode, ba_chain.hpp), the value is the number of speed/bias blocks; 0 = dense LDL^T.  The mask of
+                                           OKVIS_BA_LIST_LDL_COMP then counts the 16-blocks of the POSE system                         */
 int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options* opt, int32_t n_windows, int32_t which,
                                 int32_t* out, int64_t capacity, int64_t* n);
 /* ---- incremental structure updates ---------------------------------------------------------------------
@@ -595,6 +598,15 @@ int okvis_ba_batch_run_gathered(int device, int32_t rank, int32_t world, int32_t
  * symmetric positive definite S [n][n] (row-major, full storage).  *info = 0 ok, 1 = not positive definite /
  * dependency timeout. */
 int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* rhs, double* x, int32_t* info);
+/* One reduced camera system through the LDS-resident solvers of the solve kernel, on its own (unit tests and A/B timing of the
+ * two solvers; D <= the LDS solver's limit, (D - Dp) a multiple of 9).  S: D x D symmetric, row-major; Dp: rows of the pose part
+ * (pose-type blocks first, then 9-row speed/bias blocks).  mode: OKVIS_BA_SOLVE_DENSE = blocked LDL^T of the whole system,
+ * OKVIS_BA_SOLVE_CHAIN = speed/bias blocks eliminated along the chain first — S must then have the chain structure (a speed/bias
+ * block couples only to its two neighbours and to poses).  comp_mask: diagonal 16-blocks eliminated with compensated products (of
+ * the whole system / of the pose system).  ticks: device clock ticks of one solve (mean over `repeats`); info: 1 = a pivot was not
+ * positive.  lds_dump (NULL or lds_capacity doubles, at most 20 000 are needed): the solver's LDS image after the solve. */
+int okvis_ba_reduced_solve(int device, int32_t D, int32_t Dp, int32_t mode, uint32_t comp_mask, const double* S, const double* rhs,
+                           double* x, int64_t* ticks, int32_t* info, int32_t repeats, double* lds_dump, int64_t lds_capacity);
 
 #ifdef __cplusplus
 }

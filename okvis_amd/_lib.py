@@ -21,7 +21,7 @@ SYMBOLS = [
     "okvis_ba_helper_timeouts", "okvis_ba_launch_route", "okvis_ba_marginalize", "okvis_ba_marginalize_begin", "okvis_ba_marginalize_end",
     "okvis_ba_store_create", "okvis_ba_store_patch", "okvis_ba_store_view", "okvis_ba_store_destroy", "okvis_ba_set_patchable",
     "okvis_ba_patch_window", "okvis_ba_patched_view", "okvis_ba_set_marg_prior_values",
-    "okvis_ba_dense_solve", "okvis_ba_shard", "okvis_ba_batch_run", "okvis_ba_gather_records", "okvis_ba_batch_run_gathered",
+    "okvis_ba_dense_solve", "okvis_ba_reduced_solve", "okvis_ba_shard", "okvis_ba_batch_run", "okvis_ba_gather_records", "okvis_ba_batch_run_gathered",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -77,6 +77,8 @@ def lib():
     L.okvis_ba_iterate.argtypes = [vp, C.c_int]
     L.okvis_ba_finish.argtypes = [vp, C.POINTER(SummaryC)]
     L.okvis_ba_dense_solve.argtypes = [C.c_int, C.c_int32, _dp, _dp, _dp, C.POINTER(C.c_int32)]
+    L.okvis_ba_reduced_solve.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, _dp, _dp, _dp, C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int32), C.c_int32, _dp, C.c_int64]
     L.okvis_ba_shard.argtypes = [C.c_int32, C.c_int32, C.c_int32, _ip, C.POINTER(C.c_int32)]
     L.okvis_ba_batch_run.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.POINTER(WindowC), C.POINTER(OptionsC), C.c_int,
                                      C.c_void_p, C.POINTER(C.c_int32)]

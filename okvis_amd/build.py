@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libokvis_amd_ba.so")
 OBJ_DIR = os.path.join(HERE, "lib", "obj")
 # translation units of the HIP library and the headers each one is rebuilt for
-BA_HEADERS = ["ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_linearize2.hpp", "ba_schur.hpp", "ba_schur2.hpp", "ba_solve.hpp", "ba_imu.hpp",
+BA_HEADERS = ["ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_linearize2.hpp", "ba_schur.hpp", "ba_schur2.hpp", "ba_solve.hpp", "ba_chain.hpp", "ba_imu.hpp",
               "ba_marg.hpp", "ba_marg_tiles.hpp", "ba_chol_tiles.hpp", "ba_ldl16.hpp", "ba_store.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
 UNITS = {
     "ba_capi.hip": BA_HEADERS,                                     # the bundle-adjustment path (include/okvis_amd_ba.h)

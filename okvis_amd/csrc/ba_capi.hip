@@ -47,6 +47,7 @@ struct HostWin {  // host copy of what the queries and downloads need
   bool h0_on_device = false;   // H0 = J^T J of a large prior is formed by marg_h0_kernel after the upload, not by build_window
   bool group_chunks = false;   // one Schur chunk per linearise group (what the fused linearise + reduce launch needs)
   bool spec_ok = false;        // the window can take a decision-free Schur launch (one set of partials per linearisation buffer, see spec_schur)
+  bool chain = false;          // laid out for the chain solver (ba_chain.hpp): WinPtrs::chain > 0
   WinPtrs ptrs;  // device pointers
   int acc = 0;
   int64_t bytes_lin = 0, bytes_schur = 0, bytes_solve = 0, bytes_small = 0;
@@ -135,6 +136,8 @@ struct okvis_ba_solver {
   // launch takes no decision (schur_mfma_kernel, nodec) and reduces the trial buffer into that buffer's own set of partials, the
   // solve kernel decides (its DBUF instantiation, as in fused mode).  OKVIS_BA_TUNE_SCHUR_DECIDES keeps the decision in the Schur launch.
   bool spec_schur = false;
+  bool chain = false;          // the LDS-resident windows of the batch are laid out for the chain solver (ba_chain.hpp): solve_kernel<.., CHAIN>
+  int max_chain_doubles = 0;   // its matrix area (LChain::total), largest window
   bool fp32_at_upload = false;
   std::vector<int64_t> launch_sig;   // what the captured graphs depend on (see okvis_ba_upload)
   unsigned char* h_ctrl_stage = nullptr;   // pinned / device staging of per-window control data (begin, fetch_ctrl)
@@ -178,6 +181,7 @@ struct okvis_ba_solver {
 namespace {
 
 size_t solve_smem(int Dpad, bool large);
+size_t solve_smem_chain(int chain_doubles, int Dpad);
 
 constexpr int FUSED_MAX_WINDOWS = 48;   // up to here the fused linearise + reduce launch beats the separate Schur launch (tools/gpu_fused_sweep.py:
                                         // 48 windows 148.5 vs 151.3 us per step, 64 windows 176 vs 163)
@@ -359,8 +363,22 @@ inline void marg_h0_host(const double* J, int Dm, double* H0) {
 // (ba_linearize2.hpp: free extrinsics, or one landmark with more than LIN2_PIECES pieces); the caller rebuilds the batch
 // for ba_linearize.hpp.
 constexpr int BW_LIN2_UNFIT = -1000;
+// ... (chain = true): the window's speed/bias blocks do not form a chain in the order of the reduced system, or the chain solver
+// does not pay for it (okvis_ba_upload then lays the whole batch out for the dense LDL^T)
+constexpr int BW_CHAIN_UNFIT = -1001;
+// OKVIS_BA_SOLVE_AUTO: the chain solver from this many speed/bias blocks on.  Measured (tools/gpu_chain_shapes.py, device ticks of
+// one solve, chain / dense): 10 poses + 10 blocks 0.92, 12 + 10: 0.93, 10 + 8: 0.96, 10 + 6: 0.97, 10 + 5: 1.06, 10 + 3: 1.12,
+// 8 + 3 (the sliding window of the replay): 1.32 — two sweeps, the pose system's update and the back-substitution are fixed costs
+// that a short chain does not earn back.
+constexpr int CHAIN_AUTO_MIN_BLOCKS = 8;
+// the reduced solve the options ask for: 0 = dense, 1 = chain where every window has at least `*min_blocks` blocks in a chain
+inline bool want_chain(const okvis_ba_options& o, int* min_blocks) {
+  *min_blocks = o.tuning.solve_mode == OKVIS_BA_SOLVE_CHAIN ? 1 : CHAIN_AUTO_MIN_BLOCKS;
+  return o.tuning.solve_mode != OKVIS_BA_SOLVE_DENSE;
+}
 
-int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A, HostWin& H, int n_windows_total = 1, bool lin2 = false) {
+int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A, HostWin& H, int n_windows_total = 1, bool lin2 = false,
+                 bool chain = false) {
   auto bw_t0 = std::chrono::steady_clock::now();
   if (g_build_times.on) g_build_times.calls++;
 #define BW_T(name)                                                                                       \
@@ -915,6 +933,33 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
   P.D = D; P.Dp = Dp; P.n_pair = npair; P.n_group = ngroup; P.n_chunk = nchunk; P.n_task = (int)tasks.size();
   P.has_ext = has_ext ? 1 : 0;
   P.lin2 = lin2 ? 1 : 0;
+  // ---- chain solver (ba_chain.hpp): the speed/bias blocks must couple only to their neighbours in the order of the reduced
+  //      system (an IMU term links consecutive blocks; a marginalisation prior may span two adjacent ones) — what a sliding
+  //      window's blocks do, in time order.  Windows solved in HBM (D > MAX_D_LDS) are not concerned.
+  bool use_chain = false;
+  if (D <= MAX_D_LDS) {
+    int min_blocks = 1;
+    (void)want_chain(opt, &min_blocks);
+    const int Ks = (D - Dp) / 9;
+    bool fits = Dp >= 6 && Ks >= min_blocks && Ks <= CH_MAX_KS && LChain::tiles_fit(Dp) &&
+                (int)solve_smem_chain(LChain::make(D, Dp).total, ((D + 5) / 6) * 6) <= SOLVE_LDS_LIMIT_CHAIN;
+    auto rank = [&](int b) { return sb_off[b] < 0 ? -1 : (sb_off[b] - Dp) / 9; };
+    for (int f = 0; f < w.n_imu && fits; ++f) {
+      const int r0 = rank(w.imu_sb0[f]), r1 = rank(w.imu_sb1[f]);
+      if (r0 >= 0 && r1 >= 0 && r0 != r1 + 1 && r1 != r0 + 1) fits = false;
+    }
+    int lo = INT_MAX, hi = -1;
+    for (int b = 0; b < nmb && fits; ++b)
+      if (w.marg_block_type[b] != OKVIS_BA_BLOCK_POSE) {
+        const int r = rank(w.marg_block_idx[b]);
+        if (r >= 0) lo = std::min(lo, r), hi = std::max(hi, r);
+      }
+    if (hi - lo > 1) fits = false;
+    if (chain && !fits) return BW_CHAIN_UNFIT;
+    use_chain = chain;
+  }
+  H.chain = use_chain;
+  P.chain = use_chain ? (D - Dp) / 9 : 0;
   {
     // Diagonal blocks of the dense solver that carry a pose prior or the marginalisation prior: information of a few directions
     // that is orders of magnitude above everything else in the block (the yaw prior of the first pose: 1e16 n n^T across three
@@ -922,8 +967,13 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // products (profiles/r05_notes.md, "the referee").  The solver numbers the speed/bias part first (L16::perm).
     unsigned m = 0;
     if (D <= MAX_D_LDS && !(opt.tuning.flags & OKVIS_BA_TUNE_NO_LDL_COMP)) {   // (the tiled solver of larger systems: not compensated, ba_chol_tiles.hpp)
-      const L16 LY{ldl16_nb(D), D - Dp, D};
-      auto mark = [&](int off, int n) { if (off >= 0) for (int k = 0; k < n; ++k) m |= 1u << (LY.perm(off + k) >> 4); };
+      // (chain solver: the blocks of the POSE system, which ldl16_solve factorises on its own; the speed/bias blocks are
+      // eliminated 9 x 9, in the order of their rows, without the blocked solver's row / column asymmetry)
+      const L16 LY = use_chain ? L16{ldl16_nb(Dp), 0, Dp} : L16{ldl16_nb(D), D - Dp, D};
+      auto mark = [&](int off, int n) {
+        if (off >= 0 && !(use_chain && off >= Dp))
+          for (int k = 0; k < n; ++k) m |= 1u << (LY.perm(off + k) >> 4);
+      };
       for (int i = 0; i < w.n_pprior; ++i) mark(pose_off[w.pprior_pose[i]], 6);
       for (int b = 0; b < nmb; ++b) {
         const bool pose = w.marg_block_type[b] == OKVIS_BA_BLOCK_POSE;
@@ -932,7 +982,6 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       if (opt.tuning.flags & OKVIS_BA_TUNE_LDL_COMP_ALL) m = ~0u;
     }
     P.ldl_comp = m;
-    P.pad0_ = 0;
   }
   P.gpart_size = gpart_size;
   P.n_tile = ntile;
@@ -1001,7 +1050,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     // (the table only depends on where the terms' blocks sit in the reduced system: a window that slides keeps it from frame to
     // frame, so the last one is kept — 9 us of a 70 us upload)
     struct ImuAsmCache {
-      int D = -1, Dp = -1;
+      int D = -1, Dp = -1, chain = -1;
       std::vector<int> coloff, color;
       std::vector<int4> table;
       std::vector<int> fastw, pos;
@@ -1011,7 +1060,9 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     static thread_local int asm_next = 0;
     int hit = -1;
     for (int k = 0; k < 4 && hit < 0; ++k)
-      if (asm_caches[k].D == D && asm_caches[k].Dp == Dp && asm_caches[k].coloff == imu_coloff && asm_caches[k].color == imu_color) hit = k;
+      if (asm_caches[k].D == D && asm_caches[k].Dp == Dp && asm_caches[k].chain == (int)use_chain && asm_caches[k].coloff == imu_coloff &&
+          asm_caches[k].color == imu_color)
+        hit = k;
     const bool asm_hit = hit >= 0;
     ImuAsmCache& asm_cache = asm_caches[asm_hit ? hit : asm_next];
     if (!asm_hit) asm_next = (asm_next + 1) & 3;
@@ -1021,6 +1072,7 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
     if (!asm_hit) {
       asm_cache.D = D;
       asm_cache.Dp = Dp;
+      asm_cache.chain = (int)use_chain;
       asm_cache.coloff = imu_coloff;
       asm_cache.color = imu_color;
       const int nbk = (D + 5) / 6;   // (the HBM matrix of the large windows has the same block layout)
@@ -1030,12 +1082,13 @@ int build_window(const okvis_ba_window& w, const okvis_ba_options& opt, Arena& A
       };
       // the same entry in the LDS layout of the LDL^T solver (L16::at, ba_ldl16.hpp): i >= j, stored at the mirrored position
       const L16 ly16{ldl16_nb(D), D - Dp, D};   // (the solver's ordering: speed/bias part first)
-      auto at16 = [&](int i, int j) { return ly16.at(i, j); };
+      const LChain lych = LChain::make(D, Dp);  // (chain solver: ba_chain.hpp)
+      auto at16 = [&](int i, int j) { return use_chain ? lych.at(i, j) : ly16.at(i, j); };
       imu_asm.assign(512 * (size_t)w.n_imu, make_int4(-1, -1, 0, 0));
       imu_fastw.assign(512 * (size_t)w.n_imu, -1);
       // (the solve kernel's dynamic LDS: matrix area, then rhs, gradient, diagonal, solution — Dpad doubles each, ba_solve.hpp)
       const bool lds_system = D <= MAX_D_LDS;
-      const int goff16 = lds_system ? ldl16_area_doubles(D) + ((D + 5) / 6) * 6 : 0;
+      const int goff16 = lds_system ? (use_chain ? lych.total : ldl16_area_doubles(D)) + ((D + 5) / 6) * 6 : 0;
       // Where the entries of a factor's H | g record sit in the record (imu_pos, read by the factor workgroup that writes it): for a
       // system solved in LDS in the order of their places there, so that the lanes of a wave of the solve kernel — consecutive
       // record entries — add to ascending, mostly consecutive LDS addresses.  (In the packed order of the triangle the 64 entries
@@ -1283,6 +1336,21 @@ size_t solve_smem(int Dpad, bool large) {
   // LDS-resident: the matrix area of the LDL^T solver (ba_ldl16.hpp; Dpad >= D bounds it) + four vectors
   return ((large ? 0 : (size_t)ldl16_area_doubles(Dpad)) + 4 * (size_t)Dpad) * sizeof(double) + 16;
 }
+// chain solver (ba_chain.hpp): its matrix area (LChain::total of the batch's largest window) + the four vectors
+size_t solve_smem_chain(int chain_doubles, int Dpad) { return ((size_t)chain_doubles + 4 * (size_t)Dpad) * sizeof(double) + 16; }
+// the solve launch of the LDS-resident windows: the instantiation the batch was laid out for
+void launch_solve_small(okvis_ba_solver* s, dim3 grid, hipStream_t st, const WinPtrs* wins, int final_only, CtrlSlot* ctrls) {
+  const bool dbuf = s->group_chunks || s->spec_schur;   // (one set of partials per linearisation buffer)
+  if (s->chain) {
+    const size_t sm = solve_smem_chain(s->max_chain_doubles, s->max_Dpad_small);
+    if (dbuf) hipLaunchKernelGGL((solve_kernel<false, true, true>), grid, dim3(SOLVE_THREADS), sm, st, wins, s->d_opt, final_only, ctrls);
+    else hipLaunchKernelGGL((solve_kernel<false, false, true>), grid, dim3(SOLVE_THREADS), sm, st, wins, s->d_opt, final_only, ctrls);
+  } else {
+    const size_t sm = solve_smem(s->max_Dpad_small, false);
+    if (dbuf) hipLaunchKernelGGL((solve_kernel<false, true>), grid, dim3(SOLVE_THREADS), sm, st, wins, s->d_opt, final_only, ctrls);
+    else hipLaunchKernelGGL((solve_kernel<false, false>), grid, dim3(SOLVE_THREADS), sm, st, wins, s->d_opt, final_only, ctrls);
+  }
+}
 // dynamic LDS of linearize2_kernel: fixed part + the pose part of the step (fused: the aux area of the group reduction)
 int lin2_step_doubles(int max_Dp, bool fuse, bool f32) {
   const int aux = fuse ? (f32 ? Lin2Cfg<float, true>::MIN_STEP_DOUBLES : Lin2Cfg<double, true>::MIN_STEP_DOUBLES) : Lin2Cfg<double, false>::MIN_STEP_DOUBLES;
@@ -1373,12 +1441,8 @@ hipError_t launch_schur(okvis_ba_solver* s, Sub b, int final_call = 0) {
   return hipGetLastError();
 }
 hipError_t launch_solve(okvis_ba_solver* s, Sub b, int final_only) {
-  if (s->max_Dpad_small > 0 && (s->group_chunks || s->spec_schur))   // (one set of partials per linearisation buffer)
-    hipLaunchKernelGGL((solve_kernel<false, true>), dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), b.st,
-                       s->d_wins + b.w0, s->d_opt, final_only, s->d_ctrl + b.w0);
-  else if (s->max_Dpad_small > 0)
-    hipLaunchKernelGGL((solve_kernel<false, false>), dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), b.st,
-                       s->d_wins + b.w0, s->d_opt, final_only, s->d_ctrl + b.w0);
+  if (s->max_Dpad_small > 0)
+    launch_solve_small(s, dim3((unsigned)b.nw, 1 + (b.nw <= SOLVE_HELPED_MAX_WINDOWS ? SOLVE_HELPERS : 0)), b.st, s->d_wins + b.w0, final_only, s->d_ctrl + b.w0);
   if (s->max_Dpad_large > 0) {
     // large windows: assemble + export, tiled multi-workgroup Cholesky (fp64 MFMA), back-substitution + finish
     hipLaunchKernelGGL((solve_kernel<true, false>), dim3((unsigned)b.nw), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), b.st,
@@ -1432,6 +1496,12 @@ hipError_t launch_lin(okvis_ba_solver* s, Sub b, int init) {
     if (f32) fuse ? go(linearize_kernel<false, float, true>) : go(linearize_kernel<false, float, false>);
     else fuse ? go(linearize_kernel<false, double, true>) : go(linearize_kernel<false, double, false>);
   }
+  return hipGetLastError();
+}
+// the preintegrations a discarded speculative evaluation left behind, taken back before results leave the device (ba_solve.hpp)
+hipError_t launch_imu_take_back(okvis_ba_solver* s, int w0, int nw) {
+  if (s->max_imu == 0 || s->opt.strategy != OKVIS_BA_STRATEGY_DOGLEG || s->opt.gauss_newton) return hipSuccess;
+  hipLaunchKernelGGL(imu_take_back_kernel, dim3((unsigned)s->max_imu, (unsigned)nw), dim3(64), 0, s->stream, s->d_wins + w0);
   return hipGetLastError();
 }
 hipError_t launch_iteration(okvis_ba_solver* s, Sub b) {
@@ -1615,6 +1685,10 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             std::max((int)solve_smem(((MAX_D_LDS + 5) / 6) * 6, false), SOLVE_LDS_LIMIT));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_LDS_LIMIT_CHAIN);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SOLVE_LDS_LIMIT_CHAIN);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)solve_smem(((MAX_D + 5) / 6) * 6, true));
@@ -1836,10 +1910,15 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   // the piece path of the linearise launch (ba_linearize2.hpp) unless a window of the batch does not fit it (free extrinsics,
   // a landmark with more than LIN2_PIECES pieces) or options.reserved0 bit 3 asks for the staged kernel
   bool lin2 = !(s->opt.reserved0 & 8);
+  // the reduced solve of the LDS-resident windows: the chain solver (ba_chain.hpp) when the options allow it and EVERY such
+  // window of the batch fits it, else the dense LDL^T for all of them (one kernel instantiation per launch)
+  int chain_min = 1;
+  bool chain = want_chain(s->opt, &chain_min);
   for (int i = 0; i < n_windows; ++i) {
-    int rc = build_window(windows[i], s->opt, A, wins[i], n_windows, lin2);
-    if (rc == BW_LIN2_UNFIT) {   // start over with the staged kernel's lists for every window
-      lin2 = false;
+    int rc = build_window(windows[i], s->opt, A, wins[i], n_windows, lin2, chain);
+    if (rc == BW_LIN2_UNFIT || rc == BW_CHAIN_UNFIT) {   // start over with the staged kernel's lists / the dense solver's layout for every window
+      if (rc == BW_LIN2_UNFIT) lin2 = false;
+      else chain = false;
       A.size = 0;
       A.zsize = 0;
       i = -1;
@@ -1884,6 +1963,8 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
   std::vector<WinPtrs> ptrs(n_windows);
   s->max_group = s->max_imu = s->max_schur_blocks = s->max_lm = s->max_Dpad = s->max_Dp = s->max_spart_stride = 0;
   s->max_Dpad_small = s->max_Dpad_large = 0;
+  s->max_chain_doubles = 0;
+  s->chain = false;
   s->any_ext = false;
   s->group_chunks = true;
   s->spec_schur = true;
@@ -1902,6 +1983,10 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     s->max_Dp = std::max(s->max_Dp, P.Dp);
     if (P.D <= MAX_D_LDS) {
       s->max_Dpad_small = std::max(s->max_Dpad_small, ((P.D + 5) / 6) * 6);
+      if (P.chain) {
+        s->chain = true;
+        s->max_chain_doubles = std::max(s->max_chain_doubles, LChain::make(P.D, P.Dp).total);
+      }
     } else
       s->max_Dpad_large = std::max(s->max_Dpad_large, ((P.D + 5) / 6) * 6);
     s->any_ext = s->any_ext || P.has_ext;
@@ -1970,7 +2055,7 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     // not the windows themselves.  A re-upload that leaves all of that unchanged (the same number of equally shaped windows:
     // the per-frame pattern of a batch service, the dogleg record of bench.py) keeps them; anything else drops them.
     std::vector<int64_t> sig = {n_windows, s->max_group, s->max_imu, s->max_schur_blocks, s->max_lm, s->max_Dpad, s->max_Dp,
-                                s->max_Dpad_small, s->max_Dpad_large, s->max_spart_stride, s->any_ext, s->group_chunks, s->spec_schur, s->lin2, s->split_small,
+                                s->max_Dpad_small, s->max_Dpad_large, s->max_spart_stride, s->any_ext, s->group_chunks, s->spec_schur, s->lin2, s->split_small, s->chain, s->max_chain_doubles,
                                 s->fp32_at_upload, (int64_t)(intptr_t)s->d_wins, (int64_t)(intptr_t)s->d_opt,
                                 (int64_t)s->sub_streams.size()};
     for (int b : s->sub_begin) sig.push_back(b);
@@ -2023,11 +2108,16 @@ int okvis_ba_check_window(const okvis_ba_window* w, const okvis_ba_options* opt,
     }
   } give_back{A.host, kept, !dumping};
   // the route okvis_ba_upload takes for a one-window batch: the piece path's lists unless the window does not fit them
-  int rc = (o.reserved0 & 8) ? BW_LIN2_UNFIT : build_window(*w, o, A, H, 1, true);
-  if (rc == BW_LIN2_UNFIT) {
+  int chain_min = 1;
+  bool chain = want_chain(o, &chain_min), lin2 = !(o.reserved0 & 8);
+  int rc;
+  for (;;) {   // (the route okvis_ba_upload takes for a one-window batch)
     A.size = 0;
     A.zsize = 0;
-    rc = build_window(*w, o, A, H);
+    rc = build_window(*w, o, A, H, 1, lin2, chain);
+    if (rc == BW_LIN2_UNFIT) lin2 = false;
+    else if (rc == BW_CHAIN_UNFIT) chain = false;
+    else break;
   }
   if (rc != OKVIS_BA_OK) return rc;
   if (dumping) {   // diagnostics (OKVIS_BA_DEBUG=arena=<file>): the index build's output, byte for byte
@@ -2051,11 +2141,16 @@ int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options
   if (opt) o = *opt; else okvis_ba_default_options(&o);
   Arena A;
   HostWin H;
-  int rc = (o.reserved0 & 8) ? BW_LIN2_UNFIT : build_window(*w, o, A, H, n_windows, true);
-  if (rc == BW_LIN2_UNFIT) {
+  int chain_min = 1;
+  bool chain = want_chain(o, &chain_min), lin2 = !(o.reserved0 & 8);
+  int rc;
+  for (;;) {
     A.size = 0;
     A.zsize = 0;
-    rc = build_window(*w, o, A, H, n_windows, false);
+    rc = build_window(*w, o, A, H, n_windows, lin2, chain);
+    if (rc == BW_LIN2_UNFIT) lin2 = false;
+    else if (rc == BW_CHAIN_UNFIT) chain = false;
+    else break;
   }
   if (rc != OKVIS_BA_OK) return rc;
   const WinPtrs& P = H.ptrs;   // (the pointer members still hold offsets into the arena's data part)
@@ -2096,6 +2191,7 @@ int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options
     case OKVIS_BA_LIST_CHUNK_DESC: src = at((const void*)P.chunk_desc), count = (int64_t)P.n_chunk * SCHUR_DESC_INTS; break;
     case OKVIS_BA_LIST_PIECE_PATH: count = 1; break;
     case OKVIS_BA_LIST_LDL_COMP: count = 1; break;
+    case OKVIS_BA_LIST_CHAIN: count = 1; break;
     default: return OKVIS_BA_ERR_ARG;
   }
   *n = count;
@@ -2104,6 +2200,8 @@ int okvis_ba_check_window_lists(const okvis_ba_window* w, const okvis_ba_options
     out[0] = P.lin2;
   } else if (which == OKVIS_BA_LIST_LDL_COMP) {
     out[0] = (int32_t)P.ldl_comp;
+  } else if (which == OKVIS_BA_LIST_CHAIN) {
+    out[0] = P.chain;
   } else if (width == 4) {
     if (count) std::memcpy(out, src, 4 * (size_t)count);
   } else {
@@ -2154,6 +2252,7 @@ static int stage_results(okvis_ba_solver* s, int w, const unsigned char** rec) {
   }
   if (int rc = refresh_acc(s, w)) return rc;
   s->stage_dl.resize(total);
+  HIP_TRY(launch_imu_take_back(s, w, 1));
   hipLaunchKernelGGL(pack_results_kernel, dim3(8), dim3(256), 0, s->stream, s->d_wins + w, H.acc);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(s->stage_dl.data(), H.ptrs.results, total, hipMemcpyDeviceToHost, s->stream));
@@ -2453,6 +2552,7 @@ int okvis_ba_finish(okvis_ba_solver* s, okvis_ba_summary* summaries) {
   std::vector<Ctrl> cs;
   size_t res_bytes = 0;
   auto finalize = [&]() -> int {
+    HIP_TRY(launch_imu_take_back(s, 0, (int)s->wins.size()));
     if (s->max_lm > 0) {
       hipLaunchKernelGGL(quality_kernel, dim3((s->max_lm + 255) / 256, (unsigned)s->wins.size()), dim3(256), 0, s->stream, s->d_wins);
       HIP_TRY(hipGetLastError());
@@ -2622,7 +2722,7 @@ int okvis_ba_launch_route(okvis_ba_solver* s, int32_t* route) {
   for (const HostWin& H : s->wins) ch = std::max(ch, H.n_chunk);
   route[OKVIS_BA_ROUTE_MAX_CHUNKS] = ch;
   route[OKVIS_BA_ROUTE_SLOTS] = (int32_t)std::min<long long>(s->slots, 0x7fffffff);
-  route[OKVIS_BA_ROUTE_SOLVE_MODE] = s->max_Dpad_small > 0 ? OKVIS_BA_SOLVE_DENSE : 0;
+  route[OKVIS_BA_ROUTE_SOLVE_MODE] = s->max_Dpad_small > 0 ? (s->chain ? OKVIS_BA_SOLVE_CHAIN : OKVIS_BA_SOLVE_DENSE) : 0;
   return OKVIS_BA_OK;
 }
 int okvis_ba_pair_count(okvis_ba_solver* s, int w, int32_t* n_pair) {
@@ -2687,6 +2787,8 @@ int okvis_ba_download(okvis_ba_solver* s, int w, int which, double* out, int64_t
   if (n != n_doubles) return OKVIS_BA_ERR_ARG;
   if (which == OKVIS_BA_ARR_IMU_SB_REF) {
     const HostWin& H = s->wins[w];
+    HIP_TRY(launch_imu_take_back(s, w, 1));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     // one strided copy gathers the reference biases out of the per-factor cache records
     if (H.n_imu > 0)
       HIP_TRY(hipMemcpy2D(out, 9 * sizeof(double), reinterpret_cast<const unsigned char*>(H.ptrs.imu_cache) + offsetof(ImuCacheD, sb_ref),
@@ -2889,6 +2991,49 @@ int okvis_ba_dense_solve(int device, int32_t n, const double* S, const double* r
   return OKVIS_BA_OK;
 }
 
+int okvis_ba_reduced_solve(int device, int32_t D, int32_t Dp, int32_t mode, uint32_t comp_mask, const double* S, const double* rhs,
+                           double* x, int64_t* ticks, int32_t* info, int32_t repeats, double* lds_dump, int64_t lds_capacity) {
+  if (D <= 0 || D > MAX_D_LDS || Dp < 0 || Dp > D || (D - Dp) % 9 != 0 || !S || !rhs || !x || !info) return OKVIS_BA_ERR_ARG;
+  const bool chain = mode == OKVIS_BA_SOLVE_CHAIN;
+  if (chain && (Dp < 6 || D == Dp || !LChain::tiles_fit(Dp))) return OKVIS_BA_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return OKVIS_BA_ERR_NO_DEVICE;
+  if (repeats < 1) repeats = 1;
+  auto chk = [](hipError_t err) { return err == hipSuccess ? OKVIS_BA_OK : OKVIS_BA_HIP_ERROR_BASE + (int)err; };
+  unsigned char* d = nullptr;
+  const size_t n_lds = chain ? (size_t)LChain::make(D, Dp).total : (size_t)ldl16_area_doubles(D);
+  const bool dumping = lds_dump && lds_capacity >= (int64_t)n_lds;
+  const size_t nS = 8 * (size_t)D * D, total = nS + 16 * (size_t)D + 64 + (dumping ? 8 * n_lds : 0);
+  if (hipMalloc(&d, total) != hipSuccess) return OKVIS_BA_HIP_ERROR_BASE + (int)hipGetLastError();
+  struct Free { unsigned char* p; ~Free() { if (p) (void)hipFree(p); } } guard{d};
+  int rc;
+  if ((rc = chk(hipMemcpy(d, S, nS, hipMemcpyHostToDevice)))) return rc;
+  if ((rc = chk(hipMemcpy(d + nS, rhs, 8 * (size_t)D, hipMemcpyHostToDevice)))) return rc;
+  double* dx = reinterpret_cast<double*>(d + nS + 8 * (size_t)D);
+  long long* dt = reinterpret_cast<long long*>(d + nS + 16 * (size_t)D);
+  int* di = reinterpret_cast<int*>(dt + 1);
+  double* dd = dumping ? reinterpret_cast<double*>(d + nS + 16 * (size_t)D + 64) : nullptr;
+  const size_t smem = ((chain ? (size_t)LChain::make(D, Dp).total : (size_t)ldl16_area_doubles(D)) + (size_t)D + 8) * sizeof(double);
+  const void* fn = chain ? reinterpret_cast<const void*>(&reduced_solve_kernel<true>) : reinterpret_cast<const void*>(&reduced_solve_kernel<false>);
+  if ((rc = chk(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 65536))))) return rc;
+  if (chain)
+    hipLaunchKernelGGL(reduced_solve_kernel<true>, dim3(1), dim3(SOLVE_THREADS), smem, 0, reinterpret_cast<const double*>(d),
+                       reinterpret_cast<const double*>(d + nS), D, Dp, comp_mask, dx, dt, di, repeats, dd);
+  else
+    hipLaunchKernelGGL(reduced_solve_kernel<false>, dim3(1), dim3(SOLVE_THREADS), smem, 0, reinterpret_cast<const double*>(d),
+                       reinterpret_cast<const double*>(d + nS), D, Dp, comp_mask, dx, dt, di, repeats, dd);
+  if ((rc = chk(hipGetLastError()))) return rc;
+  if ((rc = chk(hipDeviceSynchronize()))) return rc;
+  if ((rc = chk(hipMemcpy(x, dx, 8 * (size_t)D, hipMemcpyDeviceToHost)))) return rc;
+  long long t = 0;
+  int f = 0;
+  if ((rc = chk(hipMemcpy(&t, dt, sizeof(t), hipMemcpyDeviceToHost)))) return rc;
+  if ((rc = chk(hipMemcpy(&f, di, sizeof(f), hipMemcpyDeviceToHost)))) return rc;
+  if (ticks) *ticks = t;
+  *info = f;
+  if (dumping && (rc = chk(hipMemcpy(lds_dump, dd, 8 * n_lds, hipMemcpyDeviceToHost)))) return rc;
+  return OKVIS_BA_OK;
+}
+
 // MarginalizationError numerics (see include/okvis_amd_ba.h): linearise at the uploaded values, eliminate
 // the landmarks (schur_kernel in marg_mode), export the dense system (solve_kernel final_only = 2), then the
 // dense elimination + eigen-decomposition (marg_dense_kernel).
@@ -3023,12 +3168,8 @@ int okvis_ba_marginalize_begin(okvis_ba_solver* s, int w, const okvis_ba_marg_sp
     hipLaunchKernelGGL((solve_kernel<true, false>), dim3(1), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_large, true), s->stream, d_win, s->d_opt, 2, s->d_ctrl + w);
     const int nT = (((D + 5) / 6) * 6 + CT_TB - 1) / CT_TB;
     hipLaunchKernelGGL(large_export_kernel, dim3(nT * (nT + 1) / 2, 1, CT_TILE / CT_THREADS), dim3(CT_THREADS), 0, s->stream, d_win);
-  } else if (s->group_chunks || s->spec_schur)
-    hipLaunchKernelGGL((solve_kernel<false, true>), dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream,
-                       d_win, s->d_opt, 2, s->d_ctrl + w);
-  else
-    hipLaunchKernelGGL((solve_kernel<false, false>), dim3(1, 1 + SOLVE_HELPERS), dim3(SOLVE_THREADS), solve_smem(s->max_Dpad_small, false), s->stream,
-                       d_win, s->d_opt, 2, s->d_ctrl + w);
+  } else
+    launch_solve_small(s, dim3(1, 1 + SOLVE_HELPERS), s->stream, d_win, 2, s->d_ctrl + w);
   HIP_TRY(hipGetLastError());
   MargArgs ma;
   ma.pose_marg = d + o_pm;

@@ -20,6 +20,7 @@
 #include "ba_chol_tiles.hpp"
 #include "ba_device.hpp"
 #include "ba_ldl16.hpp"
+#include "ba_chain.hpp"
 
 namespace ba {
 
@@ -45,6 +46,7 @@ template <> struct SolveLayout<false> { typedef L16 type; };
 // where entry d of the host-built IMU destination table lands: x carries the SLayout offset, z the reduced indices (i << 16 | j)
 __device__ __forceinline__ int imu_dst_off(const SLayout&, const int4& d) { return d.x & 0xFFFFF; }
 __device__ __forceinline__ int imu_dst_off(const L16& LY, const int4& d) { return LY.at(d.z >> 16, d.z & 0xFFFF); }
+__device__ __forceinline__ int imu_dst_off(const LChain& LY, const int4& d) { return LY.at(d.z >> 16, d.z & 0xFFFF); }
 
 // accumulate J^T J (lower triangle, reduced coordinates) and J^T r of one small factor.
 // J: nres x ncol row-major (ncol = sum of dims), col_off[c] = reduced index of local column c or -1.
@@ -127,6 +129,7 @@ __device__ __forceinline__ bool factor_diag(const double* dblk, double* Xout) {
   return ok;
 }
 
+constexpr int SOLVE_LDS_LIMIT_CHAIN = 144 * 1024;   // the same for the chain instantiations (15 KB of static arrays)
 constexpr int SOLVE_LDS_LIMIT = 148 * 1024;   // dynamic LDS of the solve kernel (160 KB per workgroup minus its static arrays, about 11 KB;
                                               // the largest LDS-resident system, D = 174, takes 137.5 KB)
 constexpr int PRI_STAGE = 2;  // pose / speed-bias priors whose records the solve kernel stages in LDS ahead of time
@@ -498,10 +501,13 @@ __device__ __forceinline__ void solve_failed_dl(Ctrl* c, const OptD& opt) {
 // workspace (L2-resident; same algorithm, one workgroup) — the functional path for BASELINE configs[2].
 // DBUF: the batch keeps one set of Schur partials per linearisation buffer (fused mode, WinPtrs::spart_buf_stride): the sums
 // are taken from the buffer that is accepted if the pending trial is, and taken again when it was not.
-template <bool LARGE, bool DBUF>
+// CHAIN (LDS-resident windows of a batch laid out for it, WinPtrs::chain): the system is assembled in the layout of ba_chain.hpp
+// and solved by chain_solve — speed/bias blocks eliminated along the IMU chain, then the dense pose system.
+template <bool LARGE, bool DBUF, bool CHAIN = false>
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __restrict__ wins,
                                                               const OptD* __restrict__ optp, int final_only, CtrlSlot* ctrls) {
   static_assert(!(LARGE && DBUF), "windows solved in HBM are never fused");
+  static_assert(!(LARGE && CHAIN), "the chain solver is an LDS solver");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const long long t_start = clock64();   // (diagnostics: stamp 43)
   const WinPtrs& W = wins[blockIdx.x];
@@ -527,6 +533,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   const int spec0 = __builtin_amdgcn_readfirstlane(chead.y ? 1 - chead.x : chead.x);
   if (final_only == 0x7ffffff1 && warm == 0x5a5a5a5a) return;   // (never: keeps the loads above)
   if (LARGE != (W.Sg != nullptr)) return;  // each window is handled by the instantiation that fits it
+  if (!LARGE && CHAIN != (W.chain != 0)) return;
   const int tid = threadIdx.x;
   if (W.prof && tid == 0 && blockIdx.x == 0 && blockIdx.y + 1 == gridDim.y) {   // diagnostics: first instruction | control words + window record are there
     W.prof[43] = (double)t_start;
@@ -602,12 +609,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   const int D = W.D, Dp = W.Dp;
   const int Dpad = ((D + 5) / 6) * 6, nbk = Dpad / 6;
   // LDS-resident: the matrix area of the LDL^T solver (upper 16x16 blocks incl. the rhs column D, or its work area)
-  const int nS = LARGE ? nbk * (nbk + 1) / 2 * SBS : ldl16_area_doubles(D);
-  typedef typename SolveLayout<LARGE>::type LYT;
+  typedef typename std::conditional<CHAIN, LChain, typename SolveLayout<LARGE>::type>::type LYT;
   // (LDS-resident: the solver eliminates the speed/bias part first, L16::perm; every LY.at() below takes reduced coordinates)
   const LYT LY = [&]() {
-    if constexpr (LARGE) return LYT{nbk};
+    if constexpr (CHAIN) return LChain::make(D, Dp);
+    else if constexpr (LARGE) return LYT{nbk};
     else return LYT{ldl16_nb(D), D - Dp, D};
+  }();
+  const int nS = [&]() {
+    if constexpr (CHAIN) return LY.total;
+    else return LARGE ? nbk * (nbk + 1) / 2 * SBS : ldl16_area_doubles(D);
   }();
 
   double* S = LARGE ? W.Sg : smem;            // block-packed lower triangle
@@ -1004,8 +1015,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
       {
         // (solver coordinates: the pose part sits behind the speed/bias part, rows / columns Ds .. D - 1; an item lands on every
         // entry (r, c) of the upper triangle with Ds <= r <= c < D)
-        const int nb16 = LY.nb, nblk16 = L16::blocks(nb16);
-        const int Ds = D - Dp;
+        // (chain mode: the pose system alone has this layout — no speed/bias part in front of it, Dp rows — and the chain's
+        // arrays behind it start from zero as a whole)
+        const L16& PL = [&]() -> const L16& {
+          if constexpr (CHAIN) return LY.P;
+          else return LY;
+        }();
+        const int nb16 = PL.nb, nblk16 = L16::blocks(nb16);
+        const int Ds = CHAIN ? 0 : D - Dp;
+        const int Dz = CHAIN ? Dp : D;
+        if constexpr (CHAIN)
+          for (int i = LY.oA + tid - 64; i < LY.total; i += NL) S[i] = 0.0;   // (oA = the end of the pose system's blocks)
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6) - 1, l = tid & 63;
         int I = 0, rem = wv;   // block wv, wv + 15, ... of the row-major upper triangle -> (I, I + rem)
         for (int b = wv; b < nblk16; b += SOLVE_THREADS / 64 - 1) {
@@ -1018,7 +1038,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int rr = 16 * I + 4 * r + (l >> 4);
-            if (!(rr >= Ds && cc >= rr && cc < D)) S[b * 256 + 64 * r + l] = 0.0;   // no item lands here
+            if (!(rr >= Ds && cc >= rr && cc < Dz)) S[b * 256 + 64 * r + l] = 0.0;   // no item lands here
           }
           rem += SOLVE_THREADS / 64 - 1;
         }
@@ -1477,7 +1497,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
     STAMP(10);
     // (diagnostics: the solver's own stamps — load | factor | back-substitution, and with -DLDL_TS_ALL wave 0's steps — as 64-bit
     // integers behind the phase stamps)
-    ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail, (W.prof && blockIdx.x == 0) ? reinterpret_cast<long long*>(W.prof + 64) : nullptr, D - Dp, W.ldl_comp);
+    long long* const stamps = (W.prof && blockIdx.x == 0) ? reinterpret_cast<long long*>(W.prof + 64) : nullptr;
+    if constexpr (CHAIN) chain_solve<SOLVE_THREADS / 64>(S, LY, tid, s_x, &s_fail, stamps, W.ldl_comp);
+    else ldl16_solve<SOLVE_THREADS / 64>(S, D, tid, s_x, &s_fail, stamps, D - Dp, W.ldl_comp);
   }
   STAMP(7);
   if (s_fail) {  // not positive definite: invalid step (handled like a rejection)
@@ -1550,6 +1572,53 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   }
   STAMP(9);
 #undef STAMP
+}
+
+// One reduced system through the LDS-resident solvers of solve_kernel, on its own (okvis_ba_reduced_solve: unit tests and the
+// A/B timing of the two solvers): Sd = the dense D x D symmetric matrix (row-major), scattered into the solver's LDS layout the
+// way the assembly does (LY.at on the lower triangle, the right-hand side as "row D"), then ldl16_solve (CHAIN = false) or
+// chain_solve.  out: x[D], then ticks[0] = clock64 ticks of the solve, info[0] = 1 when a pivot was not positive.
+template <bool CHAIN>
+__global__ __launch_bounds__(SOLVE_THREADS) void reduced_solve_kernel(const double* __restrict__ Sd, const double* __restrict__ rhs, int D, int Dp,
+                                                                      unsigned comp_mask, double* __restrict__ x, long long* __restrict__ ticks,
+                                                                      int* __restrict__ info, int repeats, double* __restrict__ dump) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  typedef typename std::conditional<CHAIN, LChain, L16>::type LYT;
+  const LYT LY = [&]() {
+    if constexpr (CHAIN) return LChain::make(D, Dp);
+    else return L16{ldl16_nb(D), D - Dp, D};
+  }();
+  const int nS = CHAIN ? LChain::make(D, Dp).total : ldl16_area_doubles(D);
+  double* s_x = smem + nS;
+  __shared__ int s_fail;
+  long long total = 0;
+  for (int rep = 0; rep < repeats; ++rep) {
+    for (int i = tid; i < nS; i += SOLVE_THREADS) smem[i] = 0.0;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int k = tid; k < D * D; k += SOLVE_THREADS) {
+      const int i = k / D, j = k - i * D;
+      if (i >= j) {
+        const double v = Sd[k];
+        if (v != 0.0 || i == j) smem[LY.at(i, j)] = v;
+      }
+    }
+    for (int i = tid; i < D; i += SOLVE_THREADS) smem[LY.at(D, i)] = rhs[i];
+    __syncthreads();
+    const long long t0 = clock64();
+    if constexpr (CHAIN) chain_solve<SOLVE_THREADS / 64>(smem, LY, tid, s_x, &s_fail, nullptr, comp_mask);
+    else ldl16_solve<SOLVE_THREADS / 64>(smem, D, tid, s_x, &s_fail, nullptr, D - Dp, comp_mask);
+    total += clock64() - t0;
+    __syncthreads();
+  }
+  for (int i = tid; i < D; i += SOLVE_THREADS) x[i] = s_x[i];
+  if (dump)   // (diagnostics: the solver's LDS image as the solve left it)
+    for (int i = tid; i < nS; i += SOLVE_THREADS) dump[i] = smem[i];
+  if (tid == 0) {
+    ticks[0] = total / repeats;
+    info[0] = s_fail;
+  }
 }
 
 // ---- large windows (D > MAX_D_LDS): solve_kernel<true> assembles and exports the damped system, the tile
@@ -1810,6 +1879,26 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_large_tail_kernel(const W
 // of a mis-speculated Gauss-Newton trial do not count as iterations, so slots and iterations can differ)
 __global__ void add_budget_kernel(const WinPtrs* __restrict__ wins, int n) {
   if (threadIdx.x == 0) wins[blockIdx.x].ctrl->max_iter += n;
+}
+
+// A run that stops right behind a decision which discarded a speculative Gauss-Newton evaluation (Ctrl::explicit_next == 2:
+// okvis_ba_optimize_timed out of time, or the caller fetches between two okvis_ba_iterate calls) has no further evaluation to take
+// the IMU terms' preintegrations back (ba_imu.hpp, imu_factor): the record the speculative evaluation re-preintegrated would travel
+// to the next frame with okvis_ba_fetch_imu_caches, one the reference never had.  This kernel does what that evaluation would have
+// done — record and reference bias of every such term back from imu_cache_prev — before results are handed out.  Idempotent: a
+// later evaluation finds nothing left to take back.  grid (max_imu, windows).
+__global__ void imu_take_back_kernel(const WinPtrs* __restrict__ wins) {
+  const WinPtrs& W = wins[blockIdx.y];
+  const int f = blockIdx.x;
+  if (f >= W.n_imu || W.ctrl->explicit_next != 2) return;
+  auto cg = W.imu_cache + f;
+  auto cp = W.imu_cache_prev + f;
+  if (!cp->valid) return;
+  auto src = reinterpret_cast<const BA_G double*>(cp);
+  auto dst = reinterpret_cast<BA_G double*>(cg);
+  for (int i = threadIdx.x; i < (int)(sizeof(ImuCacheD) / 8); i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  if (threadIdx.x == 0) cp->valid = 0;
 }
 
 // the results of one window in one contiguous record for okvis_ba_fetch_results: pose[7 n_pose] | sb[9 n_sb] | lm[4 n_lm] |

@@ -185,7 +185,8 @@ struct alignas(64) WinPtrs {
   int lin2;               // the index lists are those of the piece path (ba_linearize2.hpp)
   unsigned ldl_comp;      // bit b: diagonal block b of the solver's ordering (ba_ldl16.hpp) holds columns of a pose prior or of the
                           // marginalisation prior and is eliminated with compensated products (D <= MAX_D_LDS; 0 otherwise)
-  int pad0_;
+  int chain;              // > 0: the reduced system is laid out for and solved by ba_chain.hpp (speed/bias blocks eliminated along the
+                          // IMU chain first); the value is the number of speed/bias blocks.  0: the dense blocked LDL^T (ba_ldl16.hpp)
   double cauchy_b;
   ImuParamsD imu;
 

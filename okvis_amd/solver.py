@@ -40,7 +40,7 @@ def check_window(window: Window, options: OptionsC | None = None) -> dict:
 
 INDEX_LISTS = ("groups", "lm_obs_begin", "lm_pair_begin", "pair_lm", "pair_block", "pair_off", "pair_role", "lm_piece_begin",
                "pair_piece", "pair_list_begin", "pair_list", "tasks", "task_list", "chunks", "chunk_diag_begin", "chunk_diag_out",
-               "chunk_desc", "piece_path", "ldl_comp")   # OKVIS_BA_LIST_* in this order
+               "chunk_desc", "piece_path", "ldl_comp", "chain")   # OKVIS_BA_LIST_* in this order
 
 
 def index_lists(window: Window, options: OptionsC | None = None, n_windows: int = 1) -> dict:
@@ -65,6 +65,7 @@ def index_lists(window: Window, options: OptionsC | None = None, n_windows: int 
     out["chunks"] = out["chunks"].reshape(-1, 2)
     out["piece_path"] = int(out["piece_path"][0])
     out["ldl_comp"] = int(out["ldl_comp"][0]) & 0xFFFFFFFF
+    out["chain"] = int(out["chain"][0])
     return out
 
 

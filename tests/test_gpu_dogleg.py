@@ -84,6 +84,41 @@ def test_radius_limited_runs_iteration_by_iteration(oracle, case, radius):
         assert np.abs(ref_g - o.array("IMU_SB_REF")).max() <= 1e-9, n   # (a re-preintegration at a state 1e-12 apart; a stale reference would be 1e-3 off)
 
 
+@pytest.mark.parametrize("case,radius", [(2, 30.0), (1, 20.0)])
+def test_a_run_that_stops_behind_a_discarded_speculative_evaluation_hands_out_the_references_record(oracle, case, radius):
+    """okvis_ba_optimize_timed out of time: it has launched its slots, the last decision may have found the Gauss-Newton point it
+    evaluated speculatively outside the trust region (Ctrl::explicit_next == 2), and no slot follows in which the IMU terms could
+    take back what that evaluation did to their preintegration (finish() grants no top-up when the time is up).  What
+    okvis_ba_fetch_imu_caches / OKVIS_BA_ARR_IMU_SB_REF hand out — and the next frame starts from — must still be the record of
+    the reference's sequence of evaluations (imu_take_back_kernel): the oracle's after the iterations that completed."""
+    w = synthetic.small_window(**G.SMALL[case])
+    kw = dict(initial_radius=radius, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    pending_seen = 0
+    for n in range(1, 8):
+        b = solver.WindowBatch([w], options=_opts(**kw))
+        sg = b.optimize_timed(n + 5, n, 0.0)[0]      # n slots (min_iter), then the time is up: no top-up slots
+        ref_g = b.array("IMU_SB_REF").reshape(-1, 9)
+        caches = b.fetch_imu_caches(0)
+        # Ctrl::explicit_next (ba_types.hpp: the int behind eight ints, thirteen doubles and tr_kind): 2 = the last slot's
+        # Gauss-Newton point was found outside the trust region and nothing followed — that iteration was started, not completed
+        pending = int(b.array("CTRL").view(np.int32)[35]) == 2
+        pending_seen += int(pending)
+        done = sg["iterations"] - int(pending)
+        b.close()
+        o = oracle.OracleWindow(w, extended=True)
+        sr = o.optimize(done, _opts(**kw)) if done > 0 else None
+        ref_o = o.array("IMU_SB_REF").reshape(-1, 9) if sr is not None else None
+        if sr is not None:
+            assert sg["successful_steps"] == sr["successful_steps"]
+            assert abs(sg["final_cost"] - sr["final_cost"]) <= 1e-8 * sr["final_cost"], (n, sg, sr)
+            assert np.abs(ref_g - ref_o).max() <= 1e-9, n
+            from okvis_amd.window import IMU_CACHE_DOUBLES
+            assert caches.shape == (w.n_imu, IMU_CACHE_DOUBLES)
+            # (the record's reference bias are the nine doubles in front of its two flag words)
+            assert np.abs(caches[:, IMU_CACHE_DOUBLES - 10:IMU_CACHE_DOUBLES - 1] - ref_o).max() <= 1e-9, n
+    assert pending_seen > 0, "no run stopped behind a mis-speculated Gauss-Newton trial: the scenario does not exercise the path"
+
+
 def test_imu_reference_biases_follow_the_oracle_in_a_batch(oracle):
     """Six far starts in one batch, ten DOGLEG iterations with the default tolerances: every IMU term ends with the reference bias
     the oracle's ImuError restatement ends with — the preintegrations were redone at the same evaluations, no more and no less

@@ -210,17 +210,20 @@ def test_index_lists_report_their_size_before_they_write():
     assert L.okvis_ba_check_window_lists(None, None, 1, 3, buf, n.value, C.byref(n)) == -1
 
 
-def _expected_ldl_comp(w, blocks):
-    """blocks: (type, index) of the blocks that carry a pose prior or the marginalisation prior; the solver numbers the speed/bias
-    part first (L16::perm) and cuts the system into 16-wide diagonal blocks"""
+def _expected_ldl_comp(w, blocks, chain=False):
+    """blocks: (type, index) of the blocks that carry a pose prior or the marginalisation prior; the dense solver numbers the
+    speed/bias part first (L16::perm) and cuts the system into 16-wide diagonal blocks; the chain solver (ba_chain.hpp) hands
+    ldl16_solve the pose system alone: its 16-blocks, pose blocks only"""
     free_p = [i for i in range(w.n_pose) if not w.pose_fixed[i]]
     free_s = [i for i in range(w.n_sb) if not w.sb_fixed[i]]
     Dp, Ds = 6 * len(free_p), 9 * len(free_s)
+    if chain:
+        Ds = 0
     m = 0
     for t, i in blocks:
         if t == 0 and i in free_p:
             rows = range(Ds + 6 * free_p.index(i), Ds + 6 * free_p.index(i) + 6)
-        elif t == 1 and i in free_s:
+        elif t == 1 and i in free_s and not chain:
             rows = range(9 * free_s.index(i), 9 * free_s.index(i) + 9)
         else:
             continue
@@ -232,11 +235,20 @@ def _expected_ldl_comp(w, blocks):
 def test_blocks_with_a_prior_are_marked_for_the_compensated_elimination():
     """WinPtrs::ldl_comp (ba_ldl16.hpp): the diagonal blocks of the dense solver that hold columns of a pose prior or of the
     marginalisation prior, in the solver's ordering; nothing for windows above the LDS solver's size; the tuning flag OKVIS_BA_TUNE_NO_LDL_COMP clears it"""
+    from okvis_amd.window import SOLVE_CHAIN, SOLVE_DENSE, TUNE_LDL_COMP_ALL, TUNE_NO_LDL_COMP, default_options, set_options
+    dense = set_options(default_options(), tuning_solve_mode=SOLVE_DENSE)
+    chain = set_options(default_options(), tuning_solve_mode=SOLVE_CHAIN)
     wA = synthetic.config_A()
-    assert solver.index_lists(wA)["ldl_comp"] == _expected_ldl_comp(wA, [(0, int(p)) for p in wA.pprior_pose]) == 1 << 5
+    assert solver.index_lists(wA, dense)["ldl_comp"] == _expected_ldl_comp(wA, [(0, int(p)) for p in wA.pprior_pose]) == 1 << 5
+    assert solver.index_lists(wA, dense)["chain"] == 0
+    # the chain solver (the default for a window whose speed/bias blocks form a chain): ten blocks, and the pose system's own block 0
+    for o in (None, chain):
+        il = solver.index_lists(wA, o)
+        assert il["chain"] == 10 and il["ldl_comp"] == _expected_ldl_comp(wA, [(0, int(p)) for p in wA.pprior_pose], chain=True) == 1
     w = synthetic.small_window(seed=41, K=5, L=60)
-    assert solver.index_lists(w)["ldl_comp"] == _expected_ldl_comp(w, [(0, int(p)) for p in w.pprior_pose]) == 0b1100
-    # a dense prior over two poses and two speed/bias blocks
+    assert solver.index_lists(w, dense)["ldl_comp"] == _expected_ldl_comp(w, [(0, int(p)) for p in w.pprior_pose]) == 0b1100
+    assert solver.index_lists(w)["chain"] == 0 and solver.index_lists(w, chain)["chain"] == 5 and solver.index_lists(w, chain)["ldl_comp"] == 1   # (auto: from 8 blocks on)
+    # a dense prior over two poses and two speed/bias blocks that are NOT neighbours: no chain, whatever the options ask for
     rng = np.random.default_rng(6)
     wm = synthetic.small_window(seed=6, K=5, L=70)
     Dm = 6 + 9 + 6 + 9
@@ -249,9 +261,20 @@ def test_blocks_with_a_prior_are_marked_for_the_compensated_elimination():
     lin[0, :7] = wm.pose[0]; lin[1] = wm.sb[0]; lin[2, :7] = wm.pose[1]; lin[3] = wm.sb[2]
     wm.marg_lin = lin
     want = _expected_ldl_comp(wm, [(0, int(p)) for p in wm.pprior_pose] + [(0, 0), (1, 0), (0, 1), (1, 2)])
-    assert solver.index_lists(wm)["ldl_comp"] == want and bin(want).count("1") >= 3
+    for o in (None, dense, chain):
+        il = solver.index_lists(wm, o)
+        assert il["chain"] == 0 and il["ldl_comp"] == want and bin(want).count("1") >= 3
+    # ... over two NEIGHBOURS it is one: the prior's pose columns are marked in the pose system, its speed/bias columns nowhere
+    wm.marg_block_idx = np.array([0, 0, 1, 1], np.int32)
+    lin[3] = wm.sb[1]
+    wm.marg_lin = lin
+    il = solver.index_lists(wm, chain)
+    assert il["chain"] == 5 and il["ldl_comp"] == _expected_ldl_comp(wm, [(0, int(p)) for p in wm.pprior_pose] + [(0, 0), (0, 1)], chain=True)
     wl = synthetic.make_window(20, 30, 1.0, 2, frame_dt=0.1)
-    assert wl.reduced_dim() == 300 and solver.index_lists(wl)["ldl_comp"] == 0
-    from okvis_amd.window import TUNE_LDL_COMP_ALL, TUNE_NO_LDL_COMP, default_options, set_options
+    assert wl.reduced_dim() == 300 and solver.index_lists(wl)["ldl_comp"] == 0 and solver.index_lists(wl)["chain"] == 0
+    # one speed/bias block: the chain solver on request only
+    w1 = synthetic.small_window(seed=3, K=4, L=30)
+    w1.sb_fixed = np.array([0, 1, 1, 1], np.uint8)
+    assert solver.index_lists(w1)["chain"] == 0 and solver.index_lists(w1, chain)["chain"] == 1
     assert solver.index_lists(wA, set_options(default_options(), tuning_flags=TUNE_NO_LDL_COMP))["ldl_comp"] == 0
     assert solver.index_lists(wA, set_options(default_options(), tuning_flags=TUNE_LDL_COMP_ALL))["ldl_comp"] == 0xFFFFFFFF

@@ -5,6 +5,7 @@ from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
 opt = default_options(); opt.gauss_newton = 1; opt.function_tolerance = 0; opt.gradient_tolerance = 0; opt.parameter_tolerance = 0; opt.use_graph = 0; opt.debug_arrays = 2
 NW = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+opt.tuning.solve_mode = {"dense": 1, "chain": 2}.get(sys.argv[2] if len(sys.argv) > 2 else "", 0)   # okvis_ba_tuning::solve_mode (default: auto)
 b = solver.WindowBatch([synthetic.config_A(seed=20240923 + i) for i in range(NW)], options=opt)
 b.begin(); b.iterate(12); b.synchronize()
 p = b.array("PROF")
@@ -22,8 +23,16 @@ ids = [43, 40, 0, 41, 42, 3, 44, 4, 1, 2, 45, 46, 58, 5, 6, 10, 7, 8, 31, 32, 33
 base = min(p[k] for k in ids if p[k] > 0)
 print("  raw stamps (us after the earliest): " + "  ".join("%d:%.2f" % (k, (p[k] - base) / T) for k in ids if p[k] > 0))
 import numpy as np
-q = np.asarray(p[64:64 + 96]).view(np.int64)
+q = np.asarray(p[64:64 + 128]).view(np.int64)
 print("  LDL^T solver: load %.2f, factor %.2f, back-substitution %.2f us" % ((q[1] - q[0]) / T, (q[2] - q[1]) / T, (q[3] - q[2]) / T))
+if q[16] > 0 and q[20] > q[16]:   # chain solver (ba_chain.hpp): its own phases around the pose system's LDL^T
+    print("  chain solver: sweeps %.2f, pose update %.2f, pose LDL^T %.2f, speed/bias back-substitution %.2f us  (route: %s)" %
+          ((q[17] - q[16]) / T, (q[18] - q[17]) / T, (q[19] - q[18]) / T, (q[20] - q[19]) / T, b.launch_route()))
+    print("    sweeps (us after their start): chain wave left %.2f right %.2f, column wave left %.2f right %.2f;  pose update: matrix-core waves %.2f, G %.2f;  "
+          "back-substitution: u %.2f" % (tuple((q[i] - q[16]) / T for i in (21, 22, 23, 24)) + tuple((q[i] - q[17]) / T for i in (25, 26)) + ((q[27] - q[19]) / T,)))
+    print("    pose update, waves through after (us): " + " ".join("%.2f" % ((q[40 + w] - q[17]) / T) for w in range(16)))
+    print("    u of the back-substitution, waves through after (us): " + " ".join("%.2f" % ((q[56 + w] - q[19]) / T) for w in range(16)))
+    print("    chain wave left, per step (ticks): " + " ".join("%d" % (q[33 + i] - q[32 + i]) for i in range(8) if q[33 + i] > 0 and q[32 + i] > 0))
 if q[32] > 0 and q[33] > q[32]:
     nbk = int(np.count_nonzero(q[32:48]))
     print("  wave 0's steps (cycles; hand-overs requested again .. both there in brackets): " + " ".join("%d (%d)" % (q[33 + k] - q[32 + k], q[64 + k] - q[48 + k]) for k in range(nbk - 1)))
