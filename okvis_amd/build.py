@@ -23,7 +23,7 @@ UNITS = {
                     os.path.join("..", "..", "include", "okvis_amd_ba.h")],   # frontend pieces (include/okvis_amd_frontend.h)
 }
 SOURCES = list(UNITS)
-HOST_SOURCES = [os.path.join("host", f) for f in ("estimator.hpp", "estimator.cpp", "replay.hpp", "replay.cpp", "replay_main.cpp",
+HOST_SOURCES = [os.path.join("host", f) for f in ("estimator.hpp", "estimator.cpp", "replay.hpp", "replay.cpp", "replay_main.cpp", "okvis_config.hpp", "okvis_config.cpp",
                                                    "estimator_capi.cpp", "okvis_estimator_adapter.hpp")]
 HEADERS = sorted({h for hs in UNITS.values() for h in hs} | set(HOST_SOURCES))
 
@@ -75,7 +75,7 @@ def build_host(verbose: bool = False) -> str:
     """C++ host layer (okvis_amd::Estimator + flat C wrapper), linked against the HIP library."""
     host = os.path.join(CSRC, "host")
     cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", os.path.join(host, "estimator.cpp"),
-           os.path.join(host, "estimator_capi.cpp"), os.path.join(host, "replay.cpp"), "-o", HOST_LIB, "-L" + os.path.dirname(LIB), "-lokvis_amd_ba",
+           os.path.join(host, "estimator_capi.cpp"), os.path.join(host, "replay.cpp"), os.path.join(host, "okvis_config.cpp"), "-o", HOST_LIB, "-L" + os.path.dirname(LIB), "-lokvis_amd_ba",
            "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "estimator.hpp"
+#include "okvis_config.hpp"
 #include "replay.hpp"
 
 using namespace okvis_amd;
@@ -375,6 +376,144 @@ extern "C" int okvis_replay_probe(const char* path, int imuAsFloat, long long* c
     *cam0_model = rec.cameras[0].geometry.model;
     imu_params4[0] = rec.imuParameters.sigma_g_c, imu_params4[1] = rec.imuParameters.sigma_gw_c;
     imu_params4[2] = rec.imuParameters.sigma_a_c, imu_params4[3] = rec.imuParameters.sigma_aw_c;
+    return 1;
+  });
+}
+// ---- the reference's configuration file (okvis_config.hpp), for the CPU tests -------------------------------------------------
+// the parsed document as JSON text (scalars as strings with their cv::FileNode type: {"i": "5"}, {"r": "0.035"}, {"s": "abc"}),
+// so that a test can hold the parser against another YAML implementation.  Returns the length needed (without the 0).
+static void yamlToJson(const okvis_amd::YamlNode& n, std::string& o) {
+  auto esc = [&](const std::string& t) {
+    o += '"';
+    for (char ch : t) {
+      if (ch == '"' || ch == '\\') o += '\\';
+      o += ch;
+    }
+    o += '"';
+  };
+  switch (n.kind) {
+    case okvis_amd::YamlNode::NONE: o += "null"; break;
+    case okvis_amd::YamlNode::SCALAR:
+      o += n.isInt() ? "{\"i\": " : n.isReal() ? "{\"r\": " : "{\"s\": ";
+      esc(n.scalar);
+      o += "}";
+      break;
+    case okvis_amd::YamlNode::SEQ:
+      o += "[";
+      for (size_t k = 0; k < n.seq.size(); ++k) {
+        if (k) o += ", ";
+        yamlToJson(n.seq[k], o);
+      }
+      o += "]";
+      break;
+    case okvis_amd::YamlNode::MAP:
+      o += "{\"m\": {";
+      for (size_t k = 0; k < n.map.size(); ++k) {
+        if (k) o += ", ";
+        esc(n.map[k].first);
+        o += ": ";
+        yamlToJson(n.map[k].second, o);
+      }
+      o += "}}";
+      break;
+  }
+}
+extern "C" int okvis_yaml_to_json(const char* text, char* out, int capacity) {
+  return guarded([&] {
+    std::string o;
+    yamlToJson(okvis_amd::parseYaml(text, "<text>"), o);
+    if (out && capacity > 0) {
+      const size_t n = std::min<size_t>(o.size(), (size_t)capacity - 1);
+      std::memcpy(out, o.data(), n);
+      out[n] = 0;
+    }
+    return (int)o.size();
+  });
+}
+// ints[8 + 3 * cameras]: numKeyframes, numImuFrames, minIterations, maxIterations, cameraRate, imu rate, cameras, 0, then per camera
+// width, height, model.  reals[36 + 19 * cameras]: timeLimit, imageDelay, timestampTolerance, the 4 extrinsics sigmas, the 13 IMU
+// parameters (order of okvis_est_add_imu), T_BS (16), then per camera T_SC as r, q(xyzw) (7) and the 12 intrinsics.
+// Returns the number of cameras (at most max_cameras are written).
+extern "C" int okvis_config_read(const char* file, int max_cameras, int* ints, double* reals) {
+  return guarded([&] {
+    const okvis_amd::OkvisConfig c = okvis_amd::readOkvisConfig(file);
+    ints[0] = c.numKeyframes, ints[1] = c.numImuFrames, ints[2] = c.minIterations, ints[3] = c.maxIterations, ints[4] = c.cameraRate;
+    ints[5] = c.imu.rate, ints[6] = (int)c.cameras.size(), ints[7] = 0;
+    const ImuParameters& p = c.imu;
+    const double head[20] = {c.timeLimit, c.imageDelay, c.timestampTolerance, c.extrinsics.sigma_absolute_translation,
+                             c.extrinsics.sigma_absolute_orientation, c.extrinsics.sigma_c_relative_translation,
+                             c.extrinsics.sigma_c_relative_orientation, p.a_max, p.g_max, p.sigma_g_c, p.sigma_a_c, p.sigma_bg, p.sigma_ba,
+                             p.sigma_gw_c, p.sigma_aw_c, p.tau, p.g, p.a0[0], p.a0[1], p.a0[2]};
+    std::memcpy(reals, head, sizeof(head));
+    std::memcpy(reals + 20, c.T_BS, sizeof(c.T_BS));
+    for (size_t k = 0; k < c.cameras.size() && (int)k < max_cameras; ++k) {
+      ints[8 + 3 * k] = c.cameras[k].width, ints[9 + 3 * k] = c.cameras[k].height, ints[10 + 3 * k] = c.cameras[k].geometry.model;
+      const okvis_amd::Transformation T = c.cameras[k].T_SC();
+      for (int e = 0; e < 7; ++e) reals[36 + 19 * k + e] = T.p[e];
+      for (int e = 0; e < 12; ++e) reals[36 + 19 * k + 7 + e] = c.cameras[k].geometry.intr[e];
+    }
+    return (int)c.cameras.size();
+  });
+}
+// cam<i>/data of an ASL folder as okvis_app_synchronous enumerates it; returns the number of images (t_ns: the first `capacity`)
+extern "C" int okvis_asl_list_images(const char* path, int cam, long long* t_ns, int capacity) {
+  return guarded([&] {
+    const std::vector<okvis_amd::AslImage> v = okvis_amd::listAslImages(path, cam);
+    for (size_t k = 0; k < v.size() && (int)k < capacity; ++k) t_ns[k] = v[k].t_ns;
+    return (int)v.size();
+  });
+}
+extern "C" int okvis_asl_read_image_csv(const char* file, long long* t_ns, int capacity) {
+  return guarded([&] {
+    const std::vector<okvis_amd::AslImage> v = okvis_amd::readAslImageCsv(file);
+    for (size_t k = 0; k < v.size() && (int)k < capacity; ++k) t_ns[k] = v[k].t_ns;
+    return (int)v.size();
+  });
+}
+// okvis_replay_probe / okvis_replay_run with the calibration and the estimator parameters of a configuration file
+// (`okvis_app_synchronous <config> <dataset folder>`); opts as okvis_replay_run, entries < 0 keep the file's value;
+// use_time_limit: the file's ceres_options timeLimit / minIterations bound every optimize() (the non-blocking mode of ThreadedKFVio)
+extern "C" int okvis_replay_probe_config(const char* path, const char* config, int imuAsFloat, long long* counts, double* cam0_T_SC7,
+                                         double* cam0_intr12, int* cam0_model, double* imu_params13, double* extrinsics4) {
+  return guarded([&] {
+    const okvis_amd::OkvisConfig c = okvis_amd::readOkvisConfig(config);
+    const okvis_amd::Recording rec = okvis_amd::readRecording(path, c, imuAsFloat != 0);
+    counts[0] = (long long)rec.imu.size(), counts[1] = (long long)rec.cameras.size(), counts[2] = (long long)rec.groundTruth.size();
+    counts[3] = (long long)rec.frames.size(), counts[4] = (long long)rec.observations.size(), counts[5] = (long long)rec.landmarks.size();
+    const okvis_amd::Transformation T = rec.cameras[0].T_SC();
+    for (int k = 0; k < 7; ++k) cam0_T_SC7[k] = T.p[k];
+    for (int k = 0; k < 12; ++k) cam0_intr12[k] = rec.cameras[0].geometry.intr[k];
+    *cam0_model = rec.cameras[0].geometry.model;
+    const ImuParameters& p = rec.imuParameters;
+    const double prm[13] = {p.a_max, p.g_max, p.sigma_g_c, p.sigma_a_c, p.sigma_bg, p.sigma_ba, p.sigma_gw_c, p.sigma_aw_c,
+                            p.tau, p.g, p.a0[0], p.a0[1], p.a0[2]};
+    std::memcpy(imu_params13, prm, sizeof(prm));
+    extrinsics4[0] = rec.extrinsics.sigma_absolute_translation, extrinsics4[1] = rec.extrinsics.sigma_absolute_orientation;
+    extrinsics4[2] = rec.extrinsics.sigma_c_relative_translation, extrinsics4[3] = rec.extrinsics.sigma_c_relative_orientation;
+    return 1;
+  });
+}
+extern "C" int okvis_replay_run_config(const char* path, const char* config, int device, const int* opts, double imuOverlap,
+                                       int use_time_limit, const char* trajectory_csv, double* stats) {
+  return guarded([&] {
+    const okvis_amd::OkvisConfig c = okvis_amd::readOkvisConfig(config);
+    okvis_amd::ReplayOptions o = okvis_amd::replayOptionsFrom(c);
+    if (opts[0] >= 0) o.numKeyframes = opts[0];
+    if (opts[1] >= 0) o.numImuFrames = opts[1];
+    if (opts[2] >= 0) o.numIterations = opts[2];
+    if (opts[3] >= 0) o.numThreads = opts[3];
+    o.maxFrames = std::max(0, opts[4]), o.minObservationsPerLandmark = std::max(0, opts[5]);
+    o.imuOverlap = imuOverlap;
+    if (use_time_limit) o.timeLimit = c.timeLimit;
+    const okvis_amd::Recording rec = okvis_amd::readRecording(path, c, opts[6] != 0);
+    Estimator est(device);
+    const okvis_amd::ReplayResult r = okvis_amd::replay(rec, o, est);
+    if (trajectory_csv && trajectory_csv[0]) okvis_amd::writeTrajectoryCsv(trajectory_csv, r);
+    double mo = 0, mm = 0;
+    for (const auto& f : r.frames) mo += f.msOptimize, mm += f.msMarginalize;
+    const double n = r.frames.empty() ? 1.0 : (double)r.frames.size();
+    stats[0] = (double)r.frames.size(), stats[1] = (double)r.landmarksRemoved, stats[2] = r.hasGroundTruth ? 1 : 0;
+    stats[3] = r.rmsPosition, stats[4] = r.finalPosition, stats[5] = r.finalRotation, stats[6] = mo / n, stats[7] = mm / n;
     return 1;
   });
 }

@@ -282,6 +282,12 @@ Recording readRecording(const std::string& path, bool imu_as_float) {
     std::ifstream probe(f);
     if (probe.good()) rec.groundTruth = readAslGroundTruthCsv(f);
   }
+  readRecordedTracks(path, rec);
+  return rec;
+}
+
+void readRecordedTracks(const std::string& path, Recording& rec) {
+  if (rec.cameras.empty()) fail(path, 0, "readRecordedTracks: the recording has no cameras yet");
   {
     const std::string f = path + "/okvis_amd_tracks/frames.csv";
     const Csv c = readCsv(f, 3);
@@ -331,13 +337,12 @@ Recording readRecording(const std::string& path, bool imu_as_float) {
     std::stable_sort(rec.observations.begin(), rec.observations.end(),
                      [](const RecordedObservation& a, const RecordedObservation& b) { return a.t_ns < b.t_ns; });
   }
-  return rec;
 }
 
 ReplayResult replay(const Recording& rec, const ReplayOptions& opt, Estimator& est) {
   typedef std::chrono::steady_clock clk;
   auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  for (size_t i = 0; i < rec.cameras.size(); ++i) est.addCamera(ExtrinsicsEstimationParameters());  // fixed extrinsics (EuRoC config)
+  for (size_t i = 0; i < rec.cameras.size(); ++i) est.addCamera(rec.extrinsics);  // all zero = fixed extrinsics (EuRoC config)
   est.addImu(rec.imuParameters);
   std::map<uint64_t, const RecordedLandmark*> landmarkOf;
   for (const RecordedLandmark& l : rec.landmarks) landmarkOf[l.id] = &l;
@@ -390,6 +395,8 @@ ReplayResult replay(const Recording& rec, const ReplayOptions& opt, Estimator& e
       kps.push_back(Keypoint{o.u, o.v, o.size});
       if (est.addObservation(o.landmark, fr.id, (size_t)o.cam, kps.size() - 1) != 0) ++nObs;
     }
+    // ThreadedKFVio.cpp:313-318 (blocking: no limit, max_iterations as the minimum) / :526-530 (the budget left of timeLimit)
+    if (opt.timeLimit >= 0) est.setOptimizationTimeLimit(opt.timeLimit, opt.minIterations);
     const auto a = clk::now();
     est.optimize((size_t)opt.numIterations, (size_t)opt.numThreads, false);
     const auto b = clk::now();

@@ -69,16 +69,21 @@ struct Recording {
   std::vector<ImuMeasurement> imu;
   std::vector<AslCamera> cameras;
   ImuParameters imuParameters;
+  ExtrinsicsEstimationParameters extrinsics;  // camera_params sigma_* of the configuration file (all 0: fixed extrinsics)
   std::vector<AslGroundTruth> groundTruth;  // may be empty
   std::vector<RecordedFrame> frames;        // by time
   std::vector<RecordedObservation> observations;  // sorted by frame time (stable)
   std::vector<RecordedLandmark> landmarks;
 };
 Recording readRecording(const std::string& path, bool imu_as_float = true);
+// the okvis_amd_tracks/ part alone, into a recording whose cameras are already there (okvis_config.hpp uses it)
+void readRecordedTracks(const std::string& path, Recording& rec);
 
 struct ReplayOptions {
   int numKeyframes = 5, numImuFrames = 3;  // config_fpga_p2_euroc.yaml
   int numIterations = 10, numThreads = 2;  // max_iterations / ThreadedKFVio.cpp:736
+  int minIterations = 1;                   // ceres_options minIterations, used with timeLimit
+  double timeLimit = -1.0;                 // [s] per optimize(); negative: none (okvis_app_synchronous runs blocking, ThreadedKFVio.cpp:313-318)
   double imuOverlap = 0.02;                // temporal_imu_data_overlap
   int maxFrames = 0;                       // 0 = all
   int minObservationsPerLandmark = 0;      // landmarks with fewer recorded observations are never added (0 = keep all)

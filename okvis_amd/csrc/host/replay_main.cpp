@@ -1,4 +1,11 @@
-// okvis_amd_replay <dataset folder> [trajectory.csv] [--keyframes N] [--imu-frames N] [--iterations N] [--max-frames N] [--no-patch] [--device N]
+// okvis_amd_replay <dataset folder> [trajectory.csv] [--config <okvis config.yaml>] [--time-limit] [--keyframes N] [--imu-frames N]
+//                  [--iterations N] [--max-frames N] [--no-patch] [--device N]
+// okvis_amd_replay <okvis config.yaml> <dataset folder> [trajectory.csv] [...]        (the argument order of okvis_app_synchronous)
+//
+// --config: cameras, IMU parameters, extrinsics uncertainty, numKeyframes, numImuFrames and ceres_options of the reference's
+// configuration file (config/config_fpga_p2_euroc.yaml; okvis_config.hpp) instead of the ASL sensor.yaml files and the defaults;
+// options given after it override single values.  --time-limit: every optimize() is bound by the file's ceres_options timeLimit /
+// minIterations (the non-blocking mode of ThreadedKFVio.cpp:526-530) instead of running maxIterations (okvis_app_synchronous).
 //
 // --no-patch: every optimize() flattens and uploads its window (the round-3 route) instead of patching the window the solver holds.
 //
@@ -10,8 +17,10 @@
 #include <vector>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 
+#include "okvis_config.hpp"
 #include "replay.hpp"
 
 int main(int argc, char** argv) {
@@ -20,27 +29,53 @@ int main(int argc, char** argv) {
     return -1;  // okvis_app_synchronous.cpp:208-212
   }
   okvis_amd::ReplayOptions opt;
-  std::string out;
-  bool usePatch = true;
-  int device = 0;
-  for (int i = 2; i < argc; ++i) {
-    auto val = [&](int& dst) {
-      if (i + 1 >= argc) {
-        std::fprintf(stderr, "%s needs a value\n", argv[i]);
-        std::exit(-1);
-      }
-      dst = std::atoi(argv[++i]);
-    };
-    if (!std::strcmp(argv[i], "--keyframes")) val(opt.numKeyframes);
-    else if (!std::strcmp(argv[i], "--imu-frames")) val(opt.numImuFrames);
-    else if (!std::strcmp(argv[i], "--iterations")) val(opt.numIterations);
-    else if (!std::strcmp(argv[i], "--max-frames")) val(opt.maxFrames);
-    else if (!std::strcmp(argv[i], "--no-patch")) usePatch = false;
-    else if (!std::strcmp(argv[i], "--device")) val(device);   // (-1: book-keeping only, nothing is computed: host timings without a GPU)
-    else out = argv[i];
+  std::string out, config, dataset = argv[1];
+  bool usePatch = true, useTimeLimit = false;
+  int device = 0, first = 2;
+  auto endsWith = [](const std::string& s, const char* e) { return s.size() >= std::strlen(e) && s.compare(s.size() - std::strlen(e), std::string::npos, e) == 0; };
+  if (endsWith(dataset, ".yaml") || endsWith(dataset, ".yml")) {   // okvis_app_synchronous <config> <dataset folder>
+    if (argc < 3) {
+      std::fprintf(stderr, "usage: %s <okvis config.yaml> <dataset folder> [trajectory.csv] [...]\n", argv[0]);
+      return -1;
+    }
+    config = dataset, dataset = argv[2], first = 3;
   }
+  // first pass: the configuration file, so that the options after it override its values whatever their order
+  for (int i = first; i + 1 < argc; ++i)
+    if (!std::strcmp(argv[i], "--config")) config = argv[i + 1];
   try {
-    const okvis_amd::Recording rec = okvis_amd::readRecording(argv[1]);
+    okvis_amd::OkvisConfig cfg;
+    if (!config.empty()) {
+      cfg = okvis_amd::readOkvisConfig(config);
+      opt = okvis_amd::replayOptionsFrom(cfg);
+    }
+    for (int i = first; i < argc; ++i) {
+      auto val = [&](int& dst) {
+        if (i + 1 >= argc) {
+          std::fprintf(stderr, "%s needs a value\n", argv[i]);
+          std::exit(-1);
+        }
+        dst = std::atoi(argv[++i]);
+      };
+      if (!std::strcmp(argv[i], "--keyframes")) val(opt.numKeyframes);
+      else if (!std::strcmp(argv[i], "--imu-frames")) val(opt.numImuFrames);
+      else if (!std::strcmp(argv[i], "--iterations")) val(opt.numIterations);
+      else if (!std::strcmp(argv[i], "--max-frames")) val(opt.maxFrames);
+      else if (!std::strcmp(argv[i], "--no-patch")) usePatch = false;
+      else if (!std::strcmp(argv[i], "--time-limit")) useTimeLimit = true;
+      else if (!std::strcmp(argv[i], "--config")) ++i;
+      else if (!std::strcmp(argv[i], "--device")) val(device);   // (-1: book-keeping only, nothing is computed: host timings without a GPU)
+      else out = argv[i];
+    }
+    if (useTimeLimit) {
+      if (config.empty()) throw std::runtime_error("--time-limit needs --config (ceres_options timeLimit, minIterations)");
+      opt.timeLimit = cfg.timeLimit;
+    }
+    const okvis_amd::Recording rec = config.empty() ? okvis_amd::readRecording(dataset) : okvis_amd::readRecording(dataset, cfg);
+    if (!config.empty())
+      std::printf("configuration %s: %zu cameras, numKeyframes %d, numImuFrames %d, iterations %d..%d, timeLimit %g s (%s)\n", config.c_str(),
+                  cfg.cameras.size(), opt.numKeyframes, opt.numImuFrames, opt.minIterations, opt.numIterations, cfg.timeLimit,
+                  opt.timeLimit >= 0 ? "applied" : "not applied: blocking");
     std::printf("No. IMU measurements: %zu\n", rec.imu.size());  // okvis_app_synchronous.cpp:249
     std::printf("No. frames: %zu, cameras: %zu, recorded observations: %zu, landmarks: %zu\n", rec.frames.size(), rec.cameras.size(),
                 rec.observations.size(), rec.landmarks.size());

@@ -22,6 +22,13 @@ from .window import DIST_RADTAN, ImuParams
 _DP = C.POINTER(C.c_double)
 
 
+def _real(x):
+    """repr with a '.' in the mantissa ("4.0e-06"): a real for cv::FileStorage either way, and for YAML 1.1 readers only so"""
+    t = repr(float(x))
+    m, _, e = t.partition("e")
+    return (m if "." in m else m + ".0") + ("e" + e if e else "")
+
+
 def _yaml_list(v):
     return "[" + ", ".join(repr(float(x)) for x in v) + "]"
 
@@ -148,6 +155,69 @@ def write_synthetic_recording(path, duration_s=10.0, frame_rate_hz=10.0, imu_rat
                 first_imu=np.r_[float(t_imu_ns[0]), gyr[0], acc[0]])
 
 
+def write_okvis_config(file, frame_rate_hz=10.0, imu_rate_hz=200.0, num_keyframes=5, num_imu_frames=3, min_iterations=3,
+                       max_iterations=10, time_limit=0.035, sigma_absolute_translation=0.0, sigma_absolute_orientation=0.0,
+                       prm=None, distortion_type="radialtangential"):
+    """A configuration file in the format of the reference's applications (`okvis_app_synchronous <config> <dataset>`; the keys of
+    reference config/config_fpga_p2_euroc.yaml) for the synthetic rig of `write_synthetic_recording`: OpenCV-FileStorage YAML 1.0,
+    the cameras as a block sequence of flow mappings whose T_SC spans lines.  Returns the values written."""
+    prm = prm or ImuParams()
+    intr = synthetic.EUROC_INTR
+    lines = ["%YAML:1.0", "cameras:"]
+    for c in range(2):
+        T = synthetic.EUROC_T_SC[c]
+        rows = [", ".join(repr(float(x)) for x in T[r]) for r in range(4)]
+        lines += ["     - {T_SC:", "        [ " + ",\n          ".join(rows) + "],",
+                  f"        image_dimension: [{synthetic.IMAGE_W}, {synthetic.IMAGE_H}],",
+                  f"        distortion_coefficients: {_yaml_list(intr[c, 4:8])},",
+                  f"        distortion_type: {distortion_type},",
+                  f"        focal_length: {_yaml_list(intr[c, 0:2])},",
+                  f"        principal_point: {_yaml_list(intr[c, 2:4])}}}", ""]
+    lines += ["", "camera_params:",
+              f"    camera_rate: {int(frame_rate_hz)} # frames per second expected",
+              f"    sigma_absolute_translation: {_real(sigma_absolute_translation)} # [m]",
+              f"    sigma_absolute_orientation: {_real(sigma_absolute_orientation)} # [rad]",
+              "    sigma_c_relative_translation: 0.0 # [m]",
+              "    sigma_c_relative_orientation: 0.0 # [rad]",
+              "    timestamp_tolerance: 0.005 # [s]", "",
+              "imu_params:",
+              f"    a_max: {_real(prm.a_max)} # [m/s^2]", f"    g_max: {_real(prm.g_max)} # [rad/s]",
+              f"    sigma_g_c: {_real(prm.sigma_g_c)}", f"    sigma_a_c: {_real(prm.sigma_a_c)}",
+              f"    sigma_bg: {_real(prm.sigma_bg)}", f"    sigma_ba: {_real(prm.sigma_ba)}",
+              f"    sigma_gw_c: {_real(prm.sigma_gw_c)}", f"    sigma_aw_c: {_real(prm.sigma_aw_c)}",
+              f"    tau: {_real(getattr(prm, 'tau', 3600.0))}", f"    g: {_real(prm.g)}", "    a0: [ 0.0, 0.0, 0.0 ]",
+              f"    imu_rate: {int(imu_rate_hz)}", "    # transform Body-Sensor (IMU)", "    T_BS:",
+              "        [1.0000, 0.0000, 0.0000, 0.0000,", "         0.0000, 1.0000, 0.0000, 0.0000,",
+              "         0.0000, 0.0000, 1.0000, 0.0000,", "         0.0000, 0.0000, 0.0000, 1.0000]", "",
+              "# Estimator parameters", f"numKeyframes: {int(num_keyframes)} # keyframes in the window",
+              f"numImuFrames: {int(num_imu_frames)} # frames linked by the most recent IMU terms", "",
+              "ceres_options:", f"    minIterations: {int(min_iterations)}   # always performed",
+              f"    maxIterations: {int(max_iterations)}  # never more", f"    timeLimit: {_real(time_limit)}   # [s]", "",
+              "detection_options:", "    threshold: 40.0", "    octaves: 0", "    maxNoKeypoints: 400", "",
+              "imageDelay: 0.0  # [s]", "", "displayImages: false", "useDriver: false", "",
+              "publishing_options:", "    publish_rate: 200", "    publishLandmarks: true", "    trackedBodyFrame: B",
+              "    velocitiesFrame: Wc", ""]
+    with open(file, "w") as f:
+        f.write("\n".join(lines))
+    return dict(num_keyframes=num_keyframes, num_imu_frames=num_imu_frames, min_iterations=min_iterations, max_iterations=max_iterations,
+                time_limit=time_limit, camera_rate=int(frame_rate_hz), imu_rate=int(imu_rate_hz))
+
+
+def write_image_folders(path, t_frame_ns, extra_before=2, period_ns=50_000_000):
+    """<path>/cam<i>/data/<t_ns>.png (empty files: the backend replay only reads the names, as okvis_app_synchronous.cpp:264-318 does
+    before it decodes them) and <path>/cam<i>/data.csv: one image per recorded frame plus a few before the first frame."""
+    times = [int(t_frame_ns[0]) - (k + 1) * period_ns for k in range(extra_before)][::-1] + [int(t) for t in t_frame_ns]
+    for c in range(2):
+        d = os.path.join(path, f"cam{c}", "data")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(path, f"cam{c}", "data.csv"), "w") as f:
+            f.write("#timestamp [ns],filename\n")
+            for t in times:
+                open(os.path.join(d, f"{t}.png"), "w").close()
+                f.write(f"{t},{t}.png\n")
+    return np.array(times, np.int64)
+
+
 def _host_lib():
     from . import estimator
     return estimator.lib()._L
@@ -182,5 +252,93 @@ def run_replay(path, device=0, num_keyframes=5, num_imu_frames=3, num_iterations
                             os.fsencode(trajectory_csv) if trajectory_csv else None, stats.ctypes.data_as(_DP))
     if ok < 0:
         raise RuntimeError(L.okvis_est_last_error().decode())
+    return dict(frames=int(stats[0]), landmarks_removed=int(stats[1]), has_ground_truth=bool(stats[2]), rms_position=stats[3],
+                final_position=stats[4], final_rotation=stats[5], ms_optimize=stats[6], ms_marginalize=stats[7])
+
+
+def _check(L, ok):
+    if ok < 0:
+        L.okvis_est_last_error.restype = C.c_char_p
+        raise RuntimeError(L.okvis_est_last_error().decode())
+    return ok
+
+
+def yaml_to_json(text):
+    """The document as the C++ parser of okvis_config.hpp sees it: nested lists / dicts, scalars as ("i" | "r" | "s", text)."""
+    import json
+    L = _host_lib()
+    L.okvis_yaml_to_json.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    n = _check(L, L.okvis_yaml_to_json(text.encode(), None, 0))
+    buf = C.create_string_buffer(n + 1)
+    _check(L, L.okvis_yaml_to_json(text.encode(), buf, n + 1))
+
+    def conv(x):
+        if x is None:
+            return None
+        if isinstance(x, list):
+            return [conv(e) for e in x]
+        if "m" in x:
+            return {k: conv(v) for k, v in x["m"].items()}
+        (kind, val), = x.items()
+        return (kind, val)
+    return conv(json.loads(buf.value.decode()))
+
+
+def read_config(file, max_cameras=4):
+    """okvis_config_read: the values of a reference configuration file that reach the backend."""
+    L = _host_lib()
+    L.okvis_config_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), _DP]
+    ints = (C.c_int * (8 + 3 * max_cameras))()
+    reals = np.zeros(36 + 19 * max_cameras)
+    n = _check(L, L.okvis_config_read(os.fsencode(file), max_cameras, ints, reals.ctypes.data_as(_DP)))
+    cams = [dict(width=ints[8 + 3 * k], height=ints[9 + 3 * k], model=ints[10 + 3 * k], T_SC=reals[36 + 19 * k:43 + 19 * k].copy(),
+                 intr=reals[43 + 19 * k:55 + 19 * k].copy()) for k in range(min(n, max_cameras))]
+    return dict(num_keyframes=ints[0], num_imu_frames=ints[1], min_iterations=ints[2], max_iterations=ints[3], camera_rate=ints[4],
+                imu_rate=ints[5], n_cameras=n, time_limit=reals[0], image_delay=reals[1], timestamp_tolerance=reals[2],
+                extrinsics=reals[3:7].copy(), imu=reals[7:20].copy(), T_BS=reals[20:36].reshape(4, 4).copy(), cameras=cams)
+
+
+def list_images(path, cam):
+    L = _host_lib()
+    L.okvis_asl_list_images.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_longlong), C.c_int]
+    n = _check(L, L.okvis_asl_list_images(os.fsencode(path), cam, None, 0))
+    t = (C.c_longlong * max(n, 1))()
+    _check(L, L.okvis_asl_list_images(os.fsencode(path), cam, t, n))
+    return np.array(t[:n], np.int64)
+
+
+def read_image_csv(file):
+    L = _host_lib()
+    L.okvis_asl_read_image_csv.argtypes = [C.c_char_p, C.POINTER(C.c_longlong), C.c_int]
+    n = _check(L, L.okvis_asl_read_image_csv(os.fsencode(file), None, 0))
+    t = (C.c_longlong * max(n, 1))()
+    _check(L, L.okvis_asl_read_image_csv(os.fsencode(file), t, n))
+    return np.array(t[:n], np.int64)
+
+
+def probe_config(path, config, imu_as_float=True):
+    """The folder as readRecording(path, config) sees it: calibration and IMU parameters from the configuration file."""
+    L = _host_lib()
+    L.okvis_replay_probe_config.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_longlong), _DP, _DP, C.POINTER(C.c_int), _DP, _DP]
+    counts = (C.c_longlong * 6)()
+    T, intr, prm, ext = np.zeros(7), np.zeros(12), np.zeros(13), np.zeros(4)
+    model = C.c_int()
+    _check(L, L.okvis_replay_probe_config(os.fsencode(path), os.fsencode(config), int(imu_as_float), counts, T.ctypes.data_as(_DP),
+                                          intr.ctypes.data_as(_DP), C.byref(model), prm.ctypes.data_as(_DP), ext.ctypes.data_as(_DP)))
+    return dict(n_imu=counts[0], n_cameras=counts[1], n_ground_truth=counts[2], n_frames=counts[3], n_observations=counts[4],
+                n_landmarks=counts[5], cam0_T_SC=T, cam0_intr=intr, cam0_model=model.value, imu=prm, extrinsics=ext)
+
+
+def run_replay_config(path, config, device=0, num_keyframes=-1, num_imu_frames=-1, num_iterations=-1, num_threads=-1, max_frames=0,
+                      min_observations_per_landmark=0, imu_as_float=True, imu_overlap=0.02, use_time_limit=False, trajectory_csv=None):
+    """okvis_replay_run_config: `okvis_app_synchronous <config> <dataset folder>` on the backend (needs the GPU); values < 0 keep the
+    configuration file's."""
+    L = _host_lib()
+    L.okvis_replay_run_config.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_double, C.c_int, C.c_char_p, _DP]
+    opts = (C.c_int * 7)(num_keyframes, num_imu_frames, num_iterations, num_threads, max_frames, min_observations_per_landmark,
+                         int(imu_as_float))
+    stats = np.zeros(8)
+    _check(L, L.okvis_replay_run_config(os.fsencode(path), os.fsencode(config), device, opts, imu_overlap, int(use_time_limit),
+                                        os.fsencode(trajectory_csv) if trajectory_csv else None, stats.ctypes.data_as(_DP)))
     return dict(frames=int(stats[0]), landmarks_removed=int(stats[1]), has_ground_truth=bool(stats[2]), rms_position=stats[3],
                 final_position=stats[4], final_rotation=stats[5], ms_optimize=stats[6], ms_marginalize=stats[7])

@@ -67,6 +67,47 @@ def test_replay_executable(folder):
     assert subprocess.run([exe], capture_output=True, text=True).returncode != 0
 
 
+def test_replay_with_the_references_configuration_file(folder, tmp_path):
+    """`okvis_app_synchronous <config> <dataset folder>`: calibration, IMU parameters, window sizes and iteration counts from a file in
+    the format of the reference's config/config_fpga_p2_euroc.yaml, the EuRoC image folders present, no sensor.yaml read."""
+    import shutil
+    d0, info = folder
+    d = str(tmp_path / "euroc")
+    shutil.copytree(d0, d)
+    recording.write_image_folders(d, info["t_frame_ns"])
+    for s in ("cam0", "cam1", "imu0"):
+        os.remove(os.path.join(d, s, "sensor.yaml"))
+    cfg = str(tmp_path / "config.yaml")
+    recording.write_okvis_config(cfg, num_keyframes=5, num_imu_frames=3, min_iterations=3, max_iterations=10, time_limit=0.035)
+    a_csv, b_csv = str(tmp_path / "a.csv"), str(tmp_path / "b.csv")
+    a = recording.run_replay(d0, max_frames=30, trajectory_csv=a_csv)               # the ASL sensor.yaml files + the defaults (5 / 3 / 10)
+    b = recording.run_replay_config(d, cfg, max_frames=30, trajectory_csv=b_csv)    # the same numbers from the configuration file
+    timing = ("ms_optimize", "ms_marginalize")
+    assert {k: v for k, v in a.items() if k not in timing} == {k: v for k, v in b.items() if k not in timing}
+    ra, rb = (np.loadtxt(f, delimiter=",", comments="#") for f in (a_csv, b_csv))
+    assert np.array_equal(ra[:, :23], rb[:, :23])
+    # the file's window sizes and iteration counts are the ones used
+    recording.write_okvis_config(cfg, num_keyframes=3, num_imu_frames=2, min_iterations=1, max_iterations=4, time_limit=0.035)
+    c = recording.run_replay_config(d, cfg, max_frames=30, trajectory_csv=b_csv)
+    e = recording.run_replay(d0, max_frames=30, num_keyframes=3, num_imu_frames=2, num_iterations=4, trajectory_csv=a_csv)
+    assert {k: v for k, v in c.items() if k not in timing} == {k: v for k, v in e.items() if k not in timing}
+    rc = np.loadtxt(b_csv, delimiter=",", comments="#")
+    assert rc[:, 17].max() == 5 and rc[:, 20].max() <= 4
+    # ceres_options timeLimit / minIterations bound every optimize() when asked for (ThreadedKFVio's non-blocking mode): a limit of
+    # 0 s leaves minIterations
+    recording.write_okvis_config(cfg, num_keyframes=5, num_imu_frames=3, min_iterations=2, max_iterations=10, time_limit=0.0)
+    recording.run_replay_config(d, cfg, max_frames=20, use_time_limit=True, trajectory_csv=b_csv)
+    rt = np.loadtxt(b_csv, delimiter=",", comments="#")
+    assert rt[3:, 20].max() <= 4 and rt[3:, 20].min() >= 2 and ra[3:, 20].max() > 4    # minIterations (+ what was already under way)
+    # the executable in the argument order of okvis_app_synchronous
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "okvis_amd", "lib", "okvis_amd_replay")
+    p = subprocess.run([exe, cfg, d, b_csv, "--max-frames", "12", "--iterations", "5"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert "2 cameras, numKeyframes 5, numImuFrames 3, iterations 2..5" in p.stdout and "Finished: 12 frames" in p.stdout
+    p = subprocess.run([exe, d, "--config", str(tmp_path / "none.yaml")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "Could not open config file" in p.stderr
+
+
 # ---- the same recording through the reference's own okvis::Estimator ---------------------------------------------------
 def _ref_available():
     import ref_lib
