@@ -44,6 +44,9 @@ def parse():
                    help="the timed regions together cover at least this much wall time (more regions of EXACTLY --steps iterations each are "
                         "added: a 20-step region of the default batch is 3 ms, too short for a 1 Hz utilisation sampler to see)")
     p.add_argument("--streams", type=int, default=0, help="sub-batch streams (0 = auto)")
+    p.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
+                   help="okvis_ba_options::tuning field for the timed batch (launch-shape experiments: fused_max_windows=64, group_lm=16, ...); "
+                        "recorded under config.tuning")
     p.add_argument("--keyframes", type=int, default=10)
     p.add_argument("--landmarks", type=int, default=400)
     p.add_argument("--visibility", type=float, default=1.0)
@@ -129,6 +132,9 @@ def main():
     opt.parameter_tolerance = 0.0
     opt.use_graph = 0 if a.no_graph else 1
     opt.n_streams = a.streams
+    for kv in a.tune:
+        k, v = kv.split("=")
+        setattr(opt.tuning, k, int(v, 0))
     opt.fp32_linearize = 1 if a.fp32 else 0
     opt.gauss_newton = 1  # every timed iteration does identical full work (no trust-region collapse at the optimum)
     if a.pmc_separate:
@@ -448,6 +454,9 @@ def main():
         dopt = default_options()
         dopt.use_graph = 0 if a.no_graph else 1
         dopt.n_streams = a.streams
+        for kv in a.tune:
+            k, v = kv.split("=")
+            setattr(dopt.tuning, k, int(v, 0))
         n_batches, per_batch = 4, max(16, min(64, a.windows))
         it_total = slot_total = redo_total = 0
         t_total = 0.0
@@ -697,7 +706,8 @@ def main():
                                    f"({a.keyframes} KF / 2 cam / {a.landmarks} landmarks / {wins[0].n_obs} obs / "
                                    f"{wins[0].n_imu} IMU factors x ~100 samples, fp64), Gauss-Newton mode, tolerances off",
                        "windows_per_gpu": a.windows, "observations_per_window": wins[0].n_obs,
-                       "reduced_dim": wins[0].reduced_dim(), "graph": not a.no_graph, "parallelism": f"windows x{world}"},
+                       "reduced_dim": wins[0].reduced_dim(), "graph": not a.no_graph, "parallelism": f"windows x{world}",
+                       **({"tuning": a.tune} if a.tune else {})},
             "hip_event_ms_per_step": max(per_rank_ms) / a.steps,
             "timed_regions": {"n": len(walls), "steps_each": a.steps, "statistic": "median",
                               "ms_per_step": {"median": wall * 1e3 / a.steps, "p10": float(np.percentile(walls, 10)) * 1e3 / a.steps,

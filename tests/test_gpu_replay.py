@@ -98,7 +98,7 @@ def test_replay_with_the_references_configuration_file(folder, tmp_path):
     recording.write_okvis_config(cfg, num_keyframes=5, num_imu_frames=3, min_iterations=2, max_iterations=10, time_limit=0.0)
     recording.run_replay_config(d, cfg, max_frames=20, use_time_limit=True, trajectory_csv=b_csv)
     rt = np.loadtxt(b_csv, delimiter=",", comments="#")
-    assert rt[3:, 20].max() <= 4 and rt[3:, 20].min() >= 2 and ra[3:, 20].max() > 4    # minIterations (+ what was already under way)
+    assert rt[4:, 20].max() <= 4 and rt[4:, 20].min() >= 2 and ra[4:, 20].max() > 4    # minIterations (+ what was already under way)
     # the executable in the argument order of okvis_app_synchronous
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "okvis_amd", "lib", "okvis_amd_replay")
     p = subprocess.run([exe, cfg, d, b_csv, "--max-frames", "12", "--iterations", "5"], capture_output=True, text=True, timeout=120)

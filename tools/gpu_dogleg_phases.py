@@ -6,6 +6,8 @@ from okvis_amd import solver, synthetic
 from okvis_amd.window import default_options
 NW = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 opt = default_options()
+if len(sys.argv) > 2:
+    opt.tuning.flags = int(sys.argv[2], 0)      # okvis_ba_tuning::flags, e.g. 0x100 = OKVIS_BA_TUNE_FORK_SMALL
 res = []
 b = None
 for rep in range(6):
