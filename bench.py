@@ -219,7 +219,7 @@ def main():
 
         # (a) the shape the timed loop launches: n_streams sub-batches side by side, each a dependent chain schur -> solve ->
         #     linearise.  The roofline entry names the kernel that takes most of that chain.
-        nst = a.streams if a.streams > 0 else (3 if a.windows >= 56 else 2 if a.windows >= 8 else 1)   # the library's rule (okvis_ba_upload)
+        nst = a.streams if a.streams > 0 else (2 if a.windows >= 128 else 3 if a.windows >= 56 else 2 if a.windows >= 8 else 1)   # the library's rule (okvis_ba_upload)
         sub = (a.windows + nst - 1) // nst
         # a batch of `sub` windows on its own would run in fused mode (up to 48 windows); the sub-batches of a
         # larger upload do not: profile the kernels the timed loop launches

@@ -2028,7 +2028,9 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     // measured on MI355X / ROCm 7.2 (profiles/r01_notes.md): branches inside ONE captured graph are not
     // overlapped, but two independently replayed graphs on two streams are (+29 % at 64 windows); more
     // than two streams lose again
-    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 56 ? 3 : (n_windows >= 8 ? 2 : 1));   // (48 windows: 2 is better)
+    // (round 6, profiles/r06_notes.md: from 128 windows on two streams are ahead again — 128: 613 k against 601 k, 256: 692 k
+    //  against 659 k, 512: 727 k against 700 k window-iterations/s; 96 windows: three, 568 k against 549 k)
+    int nsub = s->opt.n_streams > 0 ? s->opt.n_streams : (n_windows >= 128 ? 2 : (n_windows >= 56 ? 3 : (n_windows >= 8 ? 2 : 1)));   // (48 windows: 2 is better)
     nsub = std::max(1, std::min(nsub, n_windows));
     s->sub_begin.assign(nsub + 1, 0);
     for (int k = 0; k <= nsub; ++k) s->sub_begin[k] = (int)((int64_t)n_windows * k / nsub);

@@ -412,7 +412,10 @@ __device__ __forceinline__ void chain_solve(double* S, const LChain& LY, int tid
 #pragma unroll
       for (int m = 0; m < 9; ++m) S[LY.oN + (k * 9 + m) * NP + cc] = ys[m];
       asm volatile("" ::: "memory");
-      if (lane == 0) atomicAdd(&cf_y[k], 1);   // (behind this wave's stores of y: the LDS performs a wave's requests in order)
+#ifdef LDL_SIGNAL_FENCE
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
+      if (lane == 0) atomicAdd(&cf_y[k], 1);   // (behind this wave's stores of y: the LDS performs a wave's requests in order; ldl_signal's invariant)
     };
     for (int t = 0; t < nst; ++t) {
       const int k = side == 0 ? t : Ks - 1 - t, n = side == 0 ? k + 1 : k - 1;

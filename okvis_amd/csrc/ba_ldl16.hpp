@@ -157,8 +157,17 @@ __device__ __forceinline__ unsigned long long ldl_ready_mask_bit(const int* flag
 // wave in the order they were issued (their answers return in that order), so a flag written behind the data is performed
 // behind the data; a workgroup-scope release fence would have the wave sit through the round trip of its own writes (~100
 // cycles in every hand-over).  The asm statement keeps the compiler from moving the flag's store in front of the data's.
+//
+// INVARIANT (everything published through ldl_signal / ch_signal must obey it): the payload is in LDS and every one of its
+// stores was issued by the wave that signals.  A payload in global memory, or one that a second wave helps to write, needs the
+// release fence: build with -DLDL_SIGNAL_FENCE (scripts/build_variant.sh fenced -DLDL_SIGNAL_FENCE) — the fenced library gives
+// the same bits (tests/test_gpu_variants.py runs the solver tests against it when the variant has been built).
 __device__ __forceinline__ void ldl_signal(int* flag, int v, int lane) {
+#ifdef LDL_SIGNAL_FENCE
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#else
   asm volatile("" ::: "memory");
+#endif
   if (lane == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");
 }

@@ -524,10 +524,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WinPtrs* __r
   // branch that is never taken: any inline assembly in this kernel makes the compiler read the whole record with vector loads.)
   int warm = 0;
   {
-    static_assert(sizeof(WinPtrs) <= 18 * 64, "lines touched below");
+    constexpr int lines = (int)((sizeof(WinPtrs) + 63) / 64);   // (never a line beyond the record: the next window's, or whatever follows the last)
+    static_assert(sizeof(WinPtrs) % 4 == 0 && (lines - 1) * 64 < (int)sizeof(WinPtrs), "lines touched below");
     const int* wi = reinterpret_cast<const int*>(&W);
 #pragma unroll
-    for (int k = 0; k < 18; ++k) warm |= wi[16 * k];
+    for (int k = 0; k < lines; ++k) warm |= wi[16 * k];
   }
   // the buffer that is accepted if the pending trial is (uniform: a scalar register, so are the addresses derived from it)
   const int spec0 = __builtin_amdgcn_readfirstlane(chead.y ? 1 - chead.x : chead.x);

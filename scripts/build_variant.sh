@@ -13,6 +13,6 @@ for u in ba_capi store_capi dist_capi fe_capi; do
   fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $V/obj/ba_capi.o $V/obj/store_capi.o $V/obj/dist_capi.o $V/obj/fe_capi.o -ldl -o $V/libokvis_amd_ba.so
-g++ -std=c++17 -O2 -fPIC -shared $C/host/estimator.cpp $C/host/estimator_capi.cpp $C/host/replay.cpp -o $V/libokvis_amd_estimator.so -L$V -lokvis_amd_ba '-Wl,-rpath,$ORIGIN'
+g++ -std=c++17 -O2 -fPIC -shared $C/host/estimator.cpp $C/host/estimator_capi.cpp $C/host/replay.cpp $C/host/okvis_config.cpp -o $V/libokvis_amd_estimator.so -L$V -lokvis_amd_ba '-Wl,-rpath,$ORIGIN'
 g++ -std=c++17 -O2 $C/host/replay_main.cpp -o $V/okvis_amd_replay -L$V -lokvis_amd_estimator -lokvis_amd_ba '-Wl,-rpath,$ORIGIN'
 echo built $V

@@ -235,13 +235,13 @@ class OracleWindow:
         self.n_pair = self._L.orc_window_pair_count(self._h)
 
     @classmethod
-    def from_c(cls, wc_ptr):
+    def from_c(cls, wc_ptr, extended=False):
         """from a POINTER(WindowC) somebody else owns (the library copies what it needs)"""
         import types
         self = cls.__new__(cls)
         wc = wc_ptr.contents
         self.window = types.SimpleNamespace(n_pose=wc.n_pose, n_sb=wc.n_sb, n_lm=wc.n_lm)
-        self._L = lib()
+        self._L = lib_ld() if extended else lib()
         self._h = self._L.orc_window_create(wc_ptr)
         self.D = self._L.orc_window_reduced_dim(self._h)
         self.n_pair = self._L.orc_window_pair_count(self._h)
