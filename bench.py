@@ -532,11 +532,23 @@ def main():
             bc.synchronize()
             msc.append(bc.last_iterate_ms() / 20)
         plc = {k: float(np.median(v)) * 1e3 for k, v in bc.profile_launches(12).items()}
+        bytes_c = bc.algorithmic_bytes()
         bc.finish()
         bc.close()
-        config_c = {"workload": f"1 window, 50 KF / 2 cam / 2000 landmarks / {wc.n_obs} observations, D = {wc.reduced_dim()}, Gauss-Newton mode",
+        # flops of one iteration by SURVEY.md section 8d (as in roofline.step): 1.5 kflop per observation, 3 E_l^2 per landmark with
+        # E_l = 6 x the poses that see it (all 50 here), D^3 / 3 + 2 D^2 for the reduced solve; against the fp64 peak (matrix = vector)
+        Dc = wc.reduced_dim()
+        fl_c = {"linearize": 1.5e3 * wc.n_obs, "schur": 3.0 * (6.0 * 50) ** 2 * wc.n_lm, "solve": Dc ** 3 / 3.0 + 2.0 * Dc ** 2}
+        t_c = float(np.median(msc)) * 1e-3
+        B_c = float(sum(bytes_c.values()))
+        config_c = {"workload": f"1 window, 50 KF / 2 cam / 2000 landmarks / {wc.n_obs} observations, D = {Dc}, Gauss-Newton mode",
                     "ms_per_iteration": float(np.median(msc)), "iterations_per_s": 1e3 / float(np.median(msc)),
-                    "launch_us": plc, "note": "launch_us.solve = assembly + tile export + tiled fp64-MFMA Cholesky + tail (four launches)"}
+                    "launch_us": plc, "note": "launch_us.solve = assembly + tile export + tiled fp64-MFMA Cholesky + tail (four launches)",
+                    "roofline": {"bound": "latency (one window: the tiled Cholesky is a chain of 16 tile columns, the Schur launch 2000 landmarks x 1275 block pairs on fp64 FMA)",
+                                 "flops_per_iteration": fl_c, "achieved_tflops": sum(fl_c.values()) / t_c / 1e12,
+                                 "fp64_peak_tflops": FP64_PEAK_TFLOPS, "fp64_frac": sum(fl_c.values()) / t_c / 1e12 / FP64_PEAK_TFLOPS,
+                                 "per_launch_tflops": {k: fl_c[k] / (plc[k] * 1e-6) / 1e12 for k in fl_c if plc.get(k)},
+                                 "algorithmic_bytes_per_iteration": B_c, "achieved_GBps": B_c / t_c / 1e9, "hbm_frac": B_c / t_c / 1e9 / HBM_PEAK_GBS}}
     fp32 = None
     if rank == 0 and not a.no_extras and not a.pmc_child and not a.fp32:
         # ---- BASELINE configs[4]: fp32 Jacobian / Hessian build, fp64 Schur complement and reduced solve (okvis_ba_options.
