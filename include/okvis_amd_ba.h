@@ -198,7 +198,7 @@ typedef struct okvis_ba_tuning {
   int32_t group_work;           /* > 0: close a linearise group at this many observations x blocks (work-balanced groups); 0 = off */
   int32_t split_small_min;      /* batches from this many windows on run the IMU / prior factors in a launch of their own; 0 = 40 */
   int32_t lin2_occupancy;       /* piece-path linearise kernel built for 4 (default, 0) or 3 workgroups per CU                   */
-  int32_t stagger_us;           /* start offset between the sub-batch streams; 0 = 20 us, < 0 = none                              */
+  int32_t stagger_us;           /* start offset between the sub-batch streams; 0 = 10 us, < 0 = none                              */
   int32_t solve_mode;           /* reduced solve: 0 = auto, see OKVIS_BA_SOLVE_*                                                  */
 } okvis_ba_tuning;
 typedef struct okvis_ba_options {

@@ -14,7 +14,9 @@ LIB = os.path.join(HERE, "lib", "libokvis_amd_ba.so")
 OBJ_DIR = os.path.join(HERE, "lib", "obj")
 # translation units of the HIP library and the headers each one is rebuilt for
 BA_HEADERS = ["ba_math.hpp", "ba_types.hpp", "ba_device.hpp", "ba_linearize.hpp", "ba_linearize2.hpp", "ba_schur.hpp", "ba_schur2.hpp", "ba_solve.hpp", "ba_chain.hpp", "ba_imu.hpp",
-              "ba_marg.hpp", "ba_marg_tiles.hpp", "ba_chol_tiles.hpp", "ba_ldl16.hpp", "ba_store.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")]
+              "ba_marg.hpp", "ba_marg_tiles.hpp", "ba_chol_tiles.hpp", "ba_ldl16.hpp", "ba_store.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h"),
+              # the parts of ba_capi.hip (one translation unit)
+              "capi_solver.inc", "capi_index_build.inc", "capi_launch.inc", "capi_standalone.inc", "capi_marginalize.inc"]
 UNITS = {
     "ba_capi.hip": BA_HEADERS,                                     # the bundle-adjustment path (include/okvis_amd_ba.h)
     "store_capi.hip": ["ba_store.hpp", os.path.join("..", "..", "include", "okvis_amd_ba.h")],   # host-side window container

@@ -174,7 +174,7 @@ def test_early_windows_gpu_oracle_and_dense_reference():
             assert costs[k][1] <= 1e-10 and costs[k][2] <= 1e-10, costs[k]
             for key in ("gpu_oracle", "gpu_dense", "oracle_dense", "gpu_referee"):
                 assert max(row[key]) <= 4e-8, (k, key, row[key])
-            assert abs(rec["summary"]["final_cost"] - row["cost_referee"]) <= 1e-10 * row["cost_referee"], k   # (measured <= 5e-12)
+            assert abs(tr[k]["summary"]["final_cost"] - row["cost_referee"]) <= 1e-10 * row["cost_referee"], k   # (measured <= 5e-12)
         else:
             assert costs[k][1] <= 1e-6 and costs[k][2] <= 1e-5, costs[k]
             assert max(row["gpu_oracle"][:2]) <= 1e-4 and row["gpu_oracle"][2] <= 1e-3, (k, row["gpu_oracle"])
@@ -184,7 +184,7 @@ def test_early_windows_gpu_oracle_and_dense_reference():
             # conditioning moves: the reference's DENSE solve is the one next to it (cost 3e-10, states 2e-7), the two Schur-complement
             # solvers — GPU and fp64 oracle alike — sit 1e-5 (poses) / 2e-4 (landmarks) / 1e-6 (cost) away in frame 0, 7e-8 / 1e-6 /
             # 2e-8 in frame 1, and from frame 2 on everything agrees to 1e-9.  Bounds: 10 x measured (profiles/r06_early_windows_referee.txt)
-            cgr = abs(rec["summary"]["final_cost"] - row["cost_referee"]) / row["cost_referee"]
+            cgr = abs(tr[k]["summary"]["final_cost"] - row["cost_referee"]) / row["cost_referee"]
             assert cgr <= (1e-5 if k == 0 else 2e-7), (k, cgr)
             lim = ([1.1e-4, 1e-6, 1.7e-3] if k == 0 else [7e-7, 3.3e-6, 1.1e-5])
             assert all(g <= l for g, l in zip(row["gpu_referee"], lim)), (k, row["gpu_referee"])
