@@ -186,7 +186,8 @@ int okvis_ba_destroy(okvis_ba_solver* s) {
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-  for (auto st : s->sub_streams) (void)hipStreamDestroy(st);
+  for (auto st : s->sub_streams)
+    if (st != s->stream) (void)hipStreamDestroy(st);
   for (auto ev : s->sub_events) (void)hipEventDestroy(ev);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -483,8 +484,9 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     }
   s->wins.swap(wins);
   // ---- sub-batches: opt.n_streams (0 = auto).  Measured at 64 windows (scripts/sweep_streams.sh, r02): 1 stream 272 k,
-  //      2: 300 k, 3: 325 k, 4: 198 k window-iterations/s — the main stream and the sub-streams together must not
-  //      exceed the 4 hardware queues of the default runtime configuration (GPU_MAX_HW_QUEUES) ----
+  //      2: 300 k, 3: 325 k, 4: 198 k window-iterations/s — the streams of the process that have work, or ever had, must not
+  //      exceed four (whatever GPU_MAX_HW_QUEUES and the stream priorities say: scripts/r06_streams.sh, r06_streams2.sh,
+  //      tools/micro/stream_concurrency.hip) ----
   {
     // measured on MI355X / ROCm 7.2 (profiles/r01_notes.md): branches inside ONE captured graph are not
     // overlapped, but two independently replayed graphs on two streams are (+29 % at 64 windows); more
@@ -497,7 +499,8 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
     for (int k = 0; k <= nsub; ++k) s->sub_begin[k] = (int)((int64_t)n_windows * k / nsub);
     const bool same = (nsub > 1 ? (int)s->sub_streams.size() == nsub : s->sub_streams.empty());
     if (!same) {
-      for (auto st : s->sub_streams) (void)hipStreamDestroy(st);
+      for (auto st : s->sub_streams)
+    if (st != s->stream) (void)hipStreamDestroy(st);
       for (auto ev : s->sub_events) (void)hipEventDestroy(ev);
       s->sub_streams.clear();
       s->sub_events.clear();
@@ -506,7 +509,11 @@ static int upload_impl(okvis_ba_solver* s, int n_windows, const okvis_ba_window*
       for (int k = 0; k < nsub; ++k) {
         hipStream_t st;
         hipEvent_t ev;
-        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        // the first sub-batch runs on the solver's own stream (round 6): an idle stream still holds one of the process's hardware
+        // queues, and the runtime runs four of them side by side, not more (profiles/r06_notes.md: 64 windows on 3 + 1 idle streams
+        // 479 k, on the solver's stream + 2: 486 k window-iterations/s; a fifth active stream halves the rate)
+        if (k == 0) st = s->stream;
+        else HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         s->sub_streams.push_back(st);
         s->sub_events.push_back(ev);
