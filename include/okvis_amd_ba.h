@@ -188,6 +188,8 @@ typedef struct okvis_ba_window {
 #define OKVIS_BA_TUNE_H0_ON_HOST 0x20u        /* H0 = J^T J of a large marginalisation prior on the host instead of marg_h0_kernel        */
 #define OKVIS_BA_TUNE_NO_EARLY_PREINTEGRATION 0x40u /* a new IMU term's first preintegration inside the first linearise launch, not at upload */
 #define OKVIS_BA_TUNE_NO_MARG_TILES 0x80u     /* okvis_ba_marginalize: kept blocks > 96 rows on the single workgroup, not on the tiled tail */
+#define OKVIS_BA_TUNE_NO_SMALL_RIDE 0x100u    /* IMU / prior factors evaluated in small_kernel behind the solve launch (rounds 4-5), not inside
+                                                 the decision-free Schur launch (schur_ride_kernel)                                          */
 #define OKVIS_BA_SOLVE_AUTO 0                  /* the library picks (OKVIS_BA_ROUTE_SOLVE_MODE reports what it picked)                     */
 #define OKVIS_BA_SOLVE_DENSE 1                /* blocked LDL^T of the whole D x D reduced system in LDS (rounds 3-5)                      */
 #define OKVIS_BA_SOLVE_CHAIN 2                /* speed/bias blocks eliminated along the IMU chain first, dense pose system behind it      */
@@ -499,6 +501,8 @@ int okvis_ba_helper_timeouts(okvis_ba_solver* s, int64_t* count);
 #define OKVIS_BA_ROUTE_MAX_CHUNKS 12            /* Schur chunks of the window that has most                                         */
 #define OKVIS_BA_ROUTE_SLOTS 13                 /* launch slots since okvis_ba_begin                                                */
 #define OKVIS_BA_ROUTE_SOLVE_MODE 14            /* OKVIS_BA_SOLVE_* the LDS-resident windows are solved with                         */
+#define OKVIS_BA_ROUTE_SMALL_RIDES 15           /* 1 = the IMU / prior factors are evaluated inside the Schur launch (schur_ride_kernel),
+                                                   small_prepare_kernel behind the solve launch only keeps the preintegrations up to date */
 #define OKVIS_BA_ROUTE_COUNT 16
 int okvis_ba_launch_route(okvis_ba_solver* s, int32_t* route);
 

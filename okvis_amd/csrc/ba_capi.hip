@@ -134,7 +134,9 @@ int okvis_ba_create(okvis_ba_solver** out, int device) {
     lds(reinterpret_cast<const void*>(&linearize2_kernel<float, true, false>), l2f);
     lds(reinterpret_cast<const void*>(&linearize2_kernel<float, true, true>), l2f);
     lds(reinterpret_cast<const void*>(&small_kernel), small_smem());
+    lds(reinterpret_cast<const void*>(&small_prepare_kernel), small_smem());
   }
+  lds(reinterpret_cast<const void*>(&schur_ride_kernel<3>), std::max((size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double), small_eval_smem()));
   lds(reinterpret_cast<const void*>(&schur_mfma_kernel<3>), (size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double));
   lds(reinterpret_cast<const void*>(&schur_mfma_kernel<9>), (size_t)sch2_tile_doubles(TILE_DIM, sch2_nlb(TILE_DIM, 9216)) * sizeof(double));
   if (e == hipSuccess)
@@ -1192,6 +1194,7 @@ int okvis_ba_launch_route(okvis_ba_solver* s, int32_t* route) {
   for (const HostWin& H : s->wins) ch = std::max(ch, H.n_chunk);
   route[OKVIS_BA_ROUTE_MAX_CHUNKS] = ch;
   route[OKVIS_BA_ROUTE_SLOTS] = (int32_t)std::min<long long>(s->slots, 0x7fffffff);
+  route[OKVIS_BA_ROUTE_SMALL_RIDES] = small_rides(s) ? 1 : 0;
   route[OKVIS_BA_ROUTE_SOLVE_MODE] = s->max_Dpad_small > 0 ? (s->chain ? OKVIS_BA_SOLVE_CHAIN : OKVIS_BA_SOLVE_DENSE) : 0;
   return OKVIS_BA_OK;
 }

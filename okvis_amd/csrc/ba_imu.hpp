@@ -656,6 +656,11 @@ __device__ void imu_redo(const WinPtrs& W, int f, const double* sb0, double* lds
 }
 #undef RSTAMP
 
+// MODE 0: the whole factor.  MODE 1 / 2 (round 6): its two halves in two launches of one slot — 1 = what may CHANGE the record (take
+// back a discarded evaluation's, the bias check, the re-preintegration; runs in small_kernel right behind the solve launch), 2 = the
+// evaluation at a record that is final for this slot (rides in the decision-free Schur launch in front of the next solve launch,
+// ba_schur2.hpp: the light half — 10 KB of LDS, no re-preintegration code — next to the Schur workgroups at their occupancy).
+template <int MODE = 0>
 __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int tid, int spec_discard = 0) {
   __shared__ double s_db[6];
   // the trial states p0[7] | p1[7] | b0[9] | b1[9] and the cache's reference bias [9]
@@ -675,19 +680,21 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
   // bias and the reference for the bias check, barrier, then the record came in, barrier, then work-item 0 fetched the poses
   // inside its serial part: three dependent round trips to memory in every IMU workgroup.)
   auto stage = [&]() {
-    if (tid < 4) ca[CA_DQ + tid] = cg->Delta_q[tid];
-    if (tid < 9) {
-      ca[CA_CI + tid] = cg->C_integral[tid];
-      ca[CA_CD + tid] = cg->C_doubleintegral[tid];
-      ca[CA_DA + tid] = cg->dalpha_db_g[tid];
-      ca[CA_DV + tid] = cg->dv_db_g[tid];
-      ca[CA_DP + tid] = cg->dp_db_g[tid];
+    if constexpr (MODE != 1) {   // (the first half only looks at the states and the record's reference bias)
+      if (tid < 4) ca[CA_DQ + tid] = cg->Delta_q[tid];
+      if (tid < 9) {
+        ca[CA_CI + tid] = cg->C_integral[tid];
+        ca[CA_CD + tid] = cg->C_doubleintegral[tid];
+        ca[CA_DA + tid] = cg->dalpha_db_g[tid];
+        ca[CA_DV + tid] = cg->dv_db_g[tid];
+        ca[CA_DP + tid] = cg->dp_db_g[tid];
+      }
+      if (tid < 3) {
+        ca[CA_AI + tid] = cg->acc_integral[tid];
+        ca[CA_AD + tid] = cg->acc_doubleintegral[tid];
+      }
+      if (tid < 225) ca[CA_SI + tid] = cg->sqrt_info[tid];
     }
-    if (tid < 3) {
-      ca[CA_AI + tid] = cg->acc_integral[tid];
-      ca[CA_AD + tid] = cg->acc_doubleintegral[tid];
-    }
-    if (tid < 225) ca[CA_SI + tid] = cg->sqrt_info[tid];
     const int u = tid - 192;   // (the last wave has the fewest of the loads above)
     if (u >= 0 && u < 7) s_st[u] = p0[u];
     else if (u >= 7 && u < 14) s_st[u] = p1[u - 7];
@@ -708,6 +715,7 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
   // saw a reference bias further away than the threshold and integrated once more, at ITS bias, where the reference still
   // has the preintegration of the last real evaluation — costs 1e-9 ... 1e-5 apart in the middle of radius-limited runs,
   // two re-preintegrations of 104 us for none.  Found with the long double referee, tools/gpu_cost_consistency.py.)
+  if constexpr (MODE != 2) {
   if (s_prev) {   // (uniform; rare: the previous evaluation of this term re-preintegrated)
     if (spec_discard) {
       const double* src = reinterpret_cast<const double*>(cp);
@@ -754,10 +762,13 @@ __device__ void imu_factor(const WinPtrs& W, int f, int trial, double* lds, int 
         for (int i = tid; i < (int)(sizeof(ImuCacheD) / 8); i += IMU_THREADS) dst[i] = src[i];
       }
       imu_redo(W, f, sbx, lds, tid);   // updates the HBM cache in place; ends with a barrier
+      if constexpr (MODE == 1) return;
       stage();
       __syncthreads();
     }
   }
+  }   // MODE != 2
+  if constexpr (MODE == 1) return;
   if (W.prof && f == 0 && tid == 0 && blockIdx.y == 0) W.prof[36] = (double)clock64();
   // the cache is valid now and, if it was just redone, its reference equals sb0 so that Delta_b is
   // exactly zero (ImuError.cpp:553)
@@ -1103,6 +1114,7 @@ __device__ void small_factors(const WinPtrs& W, int trial, double* lds, int tid)
 // prior.  Runs inside the linearise launch (ba_linearize.hpp): the IMU / prior factors and the reprojection
 // factors both depend only on the trial state of the solve kernel, so they share one launch and a slow
 // re-preintegration overlaps with the (wide) reprojection work instead of holding a kernel boundary.
+template <int MODE = 0>   // (imu_factor's; the priors are evaluated with the second half)
 __device__ __forceinline__ void small_body(const WinPtrs& W, int init, int bx, double* smem) {
   if (bx > W.n_imu) return;
   const Ctrl* ctrl = W.ctrl;
@@ -1110,8 +1122,8 @@ __device__ __forceinline__ void small_body(const WinPtrs& W, int init, int bx, d
   if (!init && !ctrl->pending) return;
   const int trial = 1 - ctrl->acc;
   if (bx < W.n_imu)
-    imu_factor(W, bx, trial, smem, threadIdx.x, init ? 0 : ctrl->spec_discard);
-  else
+    imu_factor<MODE>(W, bx, trial, smem, threadIdx.x, init ? 0 : ctrl->spec_discard);
+  else if (MODE != 1)
     small_factors(W, trial, smem, threadIdx.x);
 }
 

@@ -605,6 +605,12 @@ __global__ __launch_bounds__(LIN_THREADS, 2) void small_kernel(const WinPtrs* __
   extern __shared__ __attribute__((aligned(16))) double smem[];
   small_body(wins[blockIdx.y], init, blockIdx.x, smem);
 }
+// ... and its first half alone (imu_factor<1>: what may change an IMU term's preintegration record), where the evaluation rides in
+// the decision-free Schur launch of the same slot (schur_ride_kernel, ba_schur2.hpp); grid: the IMU terms only
+__global__ __launch_bounds__(LIN_THREADS, 2) void small_prepare_kernel(const WinPtrs* __restrict__ wins) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  small_body<1>(wins[blockIdx.y], 0, blockIdx.x, smem);
+}
 
 // First preintegration of IMU terms that arrive without one (okvis_ba_window::imu_sb_ref_valid = 0), started by okvis_ba_upload /
 // okvis_ba_patch_window BEFORE the host builds the window's index lists, so that the 0.1 ms recursion runs while the host works

@@ -16,6 +16,7 @@
 // 48 KB of LDS and 150 registers: three workgroups per CU (schur_kernel: two, at 222 registers), and the block products of
 // a 48-landmark chunk take 1.5 k matrix-core cycles per wave instead of 3 x 3 us of LDS-bound 6x6 block products.
 #pragma once
+#include "ba_imu.hpp"
 #include "ba_schur.hpp"
 
 namespace ba {
@@ -490,6 +491,24 @@ template <int SCH2_MAXT>
 __global__ __launch_bounds__(SCHUR_THREADS, SCH2_MAXT <= 3 ? 3 : 2) void schur_mfma_kernel(const WinPtrs* __restrict__ wins, const OptD* __restrict__ optp,
                                                                       int tile_rows, int final_call, int nlb, const CtrlSlot* __restrict__ ctrls, int nodec) {
   schur_mfma_body<SCH2_MAXT>(wins, optp, tile_rows, final_call, nlb, ctrls, nodec, (int)blockIdx.x);
+}
+
+// The decision-free Schur launch with the EVALUATION of the IMU / prior factors of the same trial riding along (round 6): workgroups
+// 0 .. n_small - 1 of a window are the second half of the factor workgroups (imu_factor<2>, small_factors: 14 KB of LDS, no
+// re-preintegration code — the records were brought up to date by small_prepare_kernel right behind the solve launch), the others the
+// Schur workgroups.  Neither kind waits for the other — the reduction does not need the factors' costs when it takes no decision —
+// and both only have to be through before the next solve launch.  (Round 5 let the WHOLE factor workgroups ride: 255 registers and
+// 62 KB of LDS of the re-preintegration path put the launch at two workgroups per CU and cost the line 6 %; this half keeps three.)
+template <int SCH2_MAXT>
+__global__ __launch_bounds__(SCHUR_THREADS, 3) void schur_ride_kernel(const WinPtrs* __restrict__ wins, const OptD* __restrict__ optp, int tile_rows,
+                                                                      int final_call, int nlb, const CtrlSlot* __restrict__ ctrls, int nodec, int n_small) {
+  static_assert(SCHUR_THREADS == IMU_THREADS && SCHUR_THREADS == LIN_THREADS, "one block size for both kinds of workgroup");
+  if ((int)blockIdx.x < n_small) {
+    extern __shared__ __attribute__((aligned(16))) double sch_smem[];
+    small_body<2>(wins[blockIdx.y], 0, (int)blockIdx.x, sch_smem);
+    return;
+  }
+  schur_mfma_body<SCH2_MAXT>(wins, optp, tile_rows, final_call, nlb, ctrls, nodec, (int)blockIdx.x - n_small);
 }
 
 }  // namespace ba

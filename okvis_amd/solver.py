@@ -281,7 +281,7 @@ class WindowBatch:
         return n.value
 
     ROUTE = ("windows", "fused", "decision_free_schur", "piece_path", "split_small", "sub_batches", "sub_batch_max_windows",
-             "schur_kernel", "solve_dbuf", "solve_tiled", "solve_helpers", "graph", "max_chunks", "slots", "solve_mode")
+             "schur_kernel", "solve_dbuf", "solve_tiled", "solve_helpers", "graph", "max_chunks", "slots", "solve_mode", "small_rides")
 
     def launch_route(self) -> dict:
         """okvis_ba_launch_route: which launches this batch takes under the current options (read-only)"""

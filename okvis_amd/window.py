@@ -52,7 +52,7 @@ class WindowC(C.Structure):
 
 # okvis_ba_tuning.flags (include/okvis_amd_ba.h, OKVIS_BA_TUNE_*) and okvis_ba_tuning.solve_mode (OKVIS_BA_SOLVE_*)
 TUNE_SCHUR_DECIDES, TUNE_SCHUR_VALU, TUNE_SCHUR_MFMA_LARGE, TUNE_NO_LDL_COMP, TUNE_LDL_COMP_ALL = 0x1, 0x2, 0x4, 0x8, 0x10
-TUNE_H0_ON_HOST, TUNE_NO_EARLY_PREINTEGRATION, TUNE_NO_MARG_TILES = 0x20, 0x40, 0x80
+TUNE_H0_ON_HOST, TUNE_NO_EARLY_PREINTEGRATION, TUNE_NO_MARG_TILES, TUNE_NO_SMALL_RIDE = 0x20, 0x40, 0x80, 0x100
 SOLVE_AUTO, SOLVE_DENSE, SOLVE_CHAIN = 0, 1, 2
 
 

@@ -50,7 +50,8 @@ def _assert_headline_route(b, n, opt, w0):
     assert r["fused"] == 0, r                       # (> 48 windows: no fused linearise + reduce launch)
     assert r["decision_free_schur"] == 1, r         # schur_mfma_kernel<3>, nodec
     assert r["schur_kernel"] == 2, r
-    assert r["piece_path"] == 1 and r["split_small"] == 1, r     # linearize2_kernel + small_kernel
+    assert r["piece_path"] == 1 and r["split_small"] == 1, r     # linearize2_kernel + a launch of their own for the IMU / prior factors ...
+    assert r["small_rides"] == 1, r                               # ... whose evaluation rides in the Schur launch (schur_ride_kernel, small_prepare_kernel)
     nsub = 3 if n < 128 else 2                      # (the library's rule: three streams from 56 windows, two again from 128)
     assert r["sub_batches"] == nsub and r["sub_batch_max_windows"] == (n + nsub - 1) // nsub, r
     assert r["solve_dbuf"] == 1 and r["solve_tiled"] == 0 and r["solve_helpers"] == 0, r

@@ -89,3 +89,51 @@ def test_decision_free_schur_launch_against_the_deciding_one():
     assert np.count_nonzero(a["dogleg_cost"] == b["dogleg_cost"]) >= len(a["dogleg_cost"]) // 2
     assert np.abs(a["dogleg_cost"] - b["dogleg_cost"]).max() <= 1e-10 * np.abs(b["dogleg_cost"]).max()
     assert np.abs(a["dogleg_pose"] - b["dogleg_pose"]).max() <= 1e-8
+
+
+def _ride_run(mode, flags, radius=None):
+    ws = _windows()
+    kw = dict(function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    if radius is not None:
+        kw["initial_radius"] = radius
+    o = _opts(mode, **kw)
+    o.tuning.split_small_min = 1          # the IMU / prior factors in a launch of their own, as from 40 windows on
+    o.tuning.flags = flags
+    b = solver.WindowBatch(ws, options=o)
+    route = b.launch_route()
+    out = dict(route=route, runs=[])
+    for n in (1, 3, 8):
+        sm = b.optimize(n)
+        out["runs"].append(dict(cost=[float(x["final_cost"]).hex() for x in sm], it=[(x["iterations"], x["successful_steps"]) for x in sm],
+                                pose=[b.get_state(i)[0].tobytes() for i in range(len(ws))],
+                                sb_ref=[b.array("IMU_SB_REF", i).tobytes() for i in range(len(ws))],
+                                redo=[b.array("IMU_REDO_COUNT", i).tobytes() for i in range(len(ws))], sm=sm))
+    b.close()
+    return ws, o, out
+
+
+@pytest.mark.parametrize("mode, radius", [("dogleg", None), ("dogleg", 30.0), ("gn", None)])
+def test_factor_evaluation_riding_in_the_schur_launch(oracle, mode, radius):
+    """Round 6: where the IMU / prior factors have a launch of their own and the Schur launch takes no decision, that launch carries
+    their EVALUATION (schur_ride_kernel) and small_prepare_kernel behind the solve launch only keeps the preintegration records up to date
+    (take-back of a discarded speculative evaluation's, bias check, re-preintegration).  Against OKVIS_BA_TUNE_NO_SMALL_RIDE (the whole
+    factors in small_kernel): the same bits everywhere — costs, book-keeping, poses, every term's reference bias and its count of
+    re-preintegrations, from near and far starts, with a radius that makes mis-speculated Gauss-Newton trials — and against the oracle."""
+    from okvis_amd.window import TUNE_NO_SMALL_RIDE
+    ws, o, ride = _ride_run(mode, 0, radius)
+    _, _, plain = _ride_run(mode, TUNE_NO_SMALL_RIDE, radius)
+    assert ride["route"]["small_rides"] == 1 and ride["route"]["split_small"] == 1 and ride["route"]["decision_free_schur"] == 1, ride["route"]
+    assert plain["route"]["small_rides"] == 0 and plain["route"]["split_small"] == 1, plain["route"]
+    for a, b in zip(ride["runs"], plain["runs"]):
+        for k in ("cost", "it", "pose", "sb_ref", "redo"):
+            assert a[k] == b[k], k
+    if mode == "dogleg":
+        assert any(np.frombuffer(r, np.float64).max() >= 2 for r in ride["runs"][-1]["redo"]), "no term re-preintegrated: the first half is not exercised"
+    # ... and the oracle (the batch keeps its states between the calls: the oracle repeats the calls)
+    for i, w in enumerate(ws):
+        ow = oracle.OracleWindow(w)
+        for run, n in zip(ride["runs"], (1, 3, 8)):
+            ref = ow.optimize(n, o)
+            g = run["sm"][i]
+            assert (g["iterations"], g["successful_steps"]) == (ref["iterations"], ref["successful_steps"]), (i, n)
+            assert abs(g["final_cost"] - ref["final_cost"]) <= (1e-8 if i >= 3 else 1e-9) * ref["final_cost"], (i, n, g["final_cost"], ref["final_cost"])
