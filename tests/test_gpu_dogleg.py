@@ -187,8 +187,11 @@ def test_dogleg_batch_with_different_slot_counts(oracle):
         sr = oracle.OracleWindow(w).optimize(7, _opts(initial_radius=30.0))
         assert sg[i]["iterations"] == 7 == sr["iterations"]
         assert sg[i]["successful_steps"] == sr["successful_steps"]
-        assert abs(sg[i]["final_cost"] - sr["final_cost"]) <= 1e-6 * sr["final_cost"], (i, sg[i], sr)
-        assert abs(sg[i]["final_radius"] - sr["final_radius"]) <= 1e-3 * sr["final_radius"]
+        # (round 6, tools/gpu_slot_counts_referee.py: measured 1.8e-10 on the cost and 5.3e-9 on the radius against the fp64 oracle; against
+        #  the long double referee the GPU sits at 4.1e-11 / 1.6e-8, the fp64 oracle at 1.6e-10 / 1.0e-8.  Bounds 10 x measured — these had
+        #  been the last 1e-6 / 1e-3 of the suite)
+        assert abs(sg[i]["final_cost"] - sr["final_cost"]) <= 2e-9 * sr["final_cost"], (i, sg[i], sr)
+        assert abs(sg[i]["final_radius"] - sr["final_radius"]) <= 1e-7 * sr["final_radius"]
     b.close()
 
 
